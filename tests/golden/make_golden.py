@@ -1,0 +1,224 @@
+"""Generate the golden fixtures in this directory by running the UNMODIFIED reference on CPU.
+
+    cd /root/repo && python tests/golden/make_golden.py          # build container only
+
+Every ``.npz`` written here holds inputs (including every random draw the reference would otherwise take from a
+global RNG) and the reference's outputs.  No reference source text is stored.  The fixtures pin ``oracle/``
+(``tests/test_oracle_golden.py``) and, through it or directly, the HIP kernels (``tests/test_*_gpu.py``).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness  # noqa: E402
+
+torch.set_num_threads(1)
+torch.manual_seed(2024)
+REF = ref_harness.load_reference()
+RNG = np.random.RandomState(20240917)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print("wrote %s (%d arrays, %.1f KB)" % (name, len(arrays), os.path.getsize(path) / 1024))
+
+
+def t32(x):
+    return torch.tensor(np.asarray(x), dtype=torch.float32)
+
+
+def make_cart_env(partial):
+    """CartSafeEnv whose global-RNG draw of ``partial_actions`` (cartpole.py:117) equals ``[partial]``."""
+    for seed in range(64):
+        np.random.seed(seed)
+        env = REF.CartSafeEnv()
+        if int(env.partial_actions[0]) == partial:
+            return env
+    raise RuntimeError("no seed gives partial_actions=[%d]" % partial)
+
+
+# ---------------------------------------------------------------------------------------------- CartSafe-v0
+
+def cart_states(n):
+    """Pre-step states: reset-like, mid-episode, near the termination edges, friction-sign flips."""
+    s = np.zeros((n, 6))
+    q = n // 4
+    s[:q] = RNG.uniform(-0.05, 0.05, size=(q, 6))
+    s[q:2 * q] = RNG.uniform(-1, 1, size=(q, 6)) * np.array([2.3, 3.0, 20.0, 0.2, 3.0, 60.0])
+    s[2 * q:3 * q] = RNG.uniform(-1, 1, size=(q, 6)) * np.array([0.1, 0.5, 5.0, 0.02, 0.5, 10.0])
+    s[2 * q:3 * q, 0] += RNG.choice([-2.4, 2.4], size=q)
+    s[3 * q:] = RNG.uniform(-1, 1, size=(n - 3 * q, 6)) * np.array([1.0, 1e-3, 5.0, 0.02, 1.0, 10.0])
+    s[3 * q:, 3] += RNG.choice([-1, 1], size=n - 3 * q) * 12 * 2 * np.pi / 360
+    return s
+
+
+def cart_actions(n):
+    a = RNG.uniform(-10, 10, size=(n, 2))
+    a[: n // 5] = RNG.uniform(-14, 14, size=(n // 5, 2))          # out of the box -> clipped by step()
+    a[n // 5: n // 5 + 8] = RNG.choice([-10.0, 10.0], size=(8, 2))
+    return a.astype(np.float32)
+
+
+def gen_cart():
+    for partial in (1, 0):
+        env = make_cart_env(partial)
+        n = 2048
+        states, actions = cart_states(n), cart_actions(n)
+        nxt = np.zeros((n, 6))
+        rew = np.zeros(n)
+        done = np.zeros(n, dtype=bool)
+        ineq = np.zeros((n, 6), dtype=np.float32)
+        eq = np.zeros((n, 1), dtype=np.float32)
+        for i in range(n):
+            env.state = tuple(states[i])
+            env.steps_beyond_done = None
+            o, r, d, info = env.step(actions[i])
+            nxt[i], rew[i], done[i] = o, r, d
+            ineq[i], eq[i] = info["ineq_viol"], info["eq_viol"].reshape(-1)
+        # constraint API, B = 1 and B > 1
+        ap = np.concatenate([RNG.uniform(-10, 10, size=(500, 1)), RNG.uniform(9.0, 10, size=(200, 1)),
+                             RNG.uniform(-10, -9.0, size=(200, 1))]).astype(np.float32)
+        st = t32(cart_states(ap.shape[0]))
+        full = env.complete_partial(st, t32(ap))
+        act_any = t32(cart_actions(ap.shape[0]))
+        out = dict(
+            partial=partial, states=states, actions=actions, next_states=nxt, reward=rew, done=done,
+            ineq_viol=ineq, eq_viol=eq,
+            C=env.diff_eq.numpy(), C_p=env.diff_eq_partial.numpy(), C_o_inv=env.diff_eq_other_inv.numpy(),
+            b=env.diff_eq_bias.numpy(), G=env.diff_ineq.numpy(), d=env.diff_ineq_bias.numpy(),
+            ap=ap, cp_states=st.numpy(), completed=full.numpy(),
+            eq_resid_completed=env.eq_resid(st, full).numpy(), ineq_resid_completed=env.ineq_resid(st, full).numpy(),
+            ineq_dist_completed=env.ineq_dist(st, full).numpy(), ipg_completed=env.ineq_partial_grad(st, full).numpy(),
+            any_actions=act_any.numpy(), eq_resid_any=env.eq_resid(st, act_any).numpy(),
+            ineq_resid_any=env.ineq_resid(st, act_any).numpy(), ipg_any=env.ineq_partial_grad(st, act_any).numpy(),
+            eq_grad_any=env.eq_grad(st, act_any).numpy(), ineq_grad_any=env.ineq_grad(st, act_any).numpy(),
+        )
+        # B = 1 calls of the same functions (rollout shape)
+        b1 = [env.ineq_partial_grad(st[i:i + 1], full[i:i + 1]).numpy()[0] for i in range(64)]
+        out["ipg_completed_b1"] = np.stack(b1)
+        save("cart_env_p%d" % partial, **out)
+
+
+def gen_cart_grad_steps():
+    """RPODDPG.grad_steps (rpo_ddpg.py:266-305) with the hyper-parameters of scripts/cart_exp.py:26-28."""
+    for partial in (1, 0):
+        env = make_cart_env(partial)
+        logger = REF.Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=10)
+        tr = REF.RPODDPG(env, "/tmp", name="g", logger=logger, batch_size=256, max_steps=10, warmup=0, lr_dual=0.2,
+                         corr_lr=2e-2, eps=1.0, eps_start=1.0, eps_epoch=20000, eval_lr=2e-2, eval_steps=50,
+                         grad_eps=0.1, corr_momentum=0.0, policy_fre=4, max_epochs=10, capacity=100,
+                         shared_param=True, value_type="add", clip_thres=0.2, embed_dim=128, hidden_dim=256,
+                         device=torch.device("cpu"))
+        ap = np.concatenate([RNG.uniform(-10, 10, size=(96, 1)), RNG.uniform(8.5, 10, size=(80, 1)),
+                             RNG.uniform(-10, -8.5, size=(80, 1))]).astype(np.float32)
+        st = t32(cart_states(ap.shape[0]))
+        a0 = env.complete_partial(st, t32(ap))
+        out = dict(partial=partial, ap=ap, states=st.numpy(), completed=a0.numpy())
+        tr_b1, ev_b1, ev_it = [], [], []
+        for i in range(ap.shape[0]):
+            tr_b1.append(tr.grad_steps(st[i:i + 1], a0[i:i + 1].clone(), train=True).numpy()[0])
+            a, it = tr.grad_steps(st[i:i + 1], a0[i:i + 1].clone(), train=False)
+            ev_b1.append(a.numpy()[0])
+            ev_it.append(it)
+        out.update(train_b1=np.stack(tr_b1), eval_b1=np.stack(ev_b1), eval_b1_iters=np.array(ev_it))
+        out["train_batched"] = tr.grad_steps(st, a0.clone(), train=True).numpy()
+        a, it = tr.grad_steps(st, a0.clone(), train=False)
+        out.update(eval_batched=a.numpy(), eval_batched_iters=it)
+        # momentum variant (default corr_momentum=0.5 of rpo_ddpg.py:19)
+        tr.corr_momentum = 0.5
+        out["train_b1_mom"] = np.stack([tr.grad_steps(st[i:i + 1], a0[i:i + 1].clone(), train=True).numpy()[0]
+                                        for i in range(ap.shape[0])])
+        out["train_batched_mom"] = tr.grad_steps(st, a0.clone(), train=True).numpy()
+        save("cart_grad_steps_p%d" % partial, **out)
+
+
+# ---------------------------------------------------------------------------------------------- SpringPendulum-v0
+
+def pend_internal(n):
+    s = np.zeros((n, 4))
+    h = n // 2
+    s[:h] = RNG.uniform([-np.pi / 12, -1, 0.95, -0.05], [np.pi / 12, 1, 1.05, 0.05], size=(h, 4))
+    s[h:] = RNG.uniform([-0.27, -8, 0.5, -1.0], [0.27, 8, 1.5, 1.0], size=(n - h, 4))
+    return s
+
+
+def pend_actions(n):
+    a = RNG.uniform(-6, 6, size=(n, 2))
+    a[: n // 5] = RNG.uniform(-9, 9, size=(n // 5, 2))
+    return a.astype(np.float32)
+
+
+def gen_pendulum():
+    env = REF.SpringPendulumEnv()
+    n = 2048
+    internal, actions = pend_internal(n), pend_actions(n)
+    nxt_int = np.zeros((n, 4))
+    nxt_obs = np.zeros((n, 5))
+    rew = np.zeros(n)
+    done = np.zeros(n, dtype=bool)
+    ineq = np.zeros((n, 1), dtype=np.float32)
+    eq = np.zeros((n, 1), dtype=np.float32)
+    for i in range(n):
+        env.state = internal[i].copy()
+        env.counter = 0
+        o, r, d, info = env.step(actions[i])
+        nxt_int[i], nxt_obs[i], rew[i], done[i] = env.state, o, r, d
+        ineq[i], eq[i] = info["ineq_viol"].reshape(-1), info["eq_viol"].reshape(-1)
+    m = 600
+    obs32 = t32(np.stack([np.cos(internal[:m, 0]), np.sin(internal[:m, 0]), internal[:m, 1], internal[:m, 2],
+                          internal[:m, 3]], axis=1))
+    ap = np.concatenate([RNG.uniform(-6, 6, size=(m - 200, 1)), RNG.uniform(5, 6, size=(100, 1)),
+                         RNG.uniform(-6, -5, size=(100, 1))]).astype(np.float32)
+    full = env.complete_partial(obs32, t32(ap))
+    act_any = t32(pend_actions(m))
+    out = dict(internal=internal, actions=actions, next_internal=nxt_int, next_obs=nxt_obs, reward=rew, done=done,
+               ineq_viol=ineq, eq_viol=eq, obs32=obs32.numpy(), ap=ap, completed=full.numpy(),
+               eq_resid_completed=env.eq_resid(obs32, full).numpy(),
+               ineq_resid_completed=env.ineq_resid(obs32, full).numpy(),
+               any_actions=act_any.numpy(), eq_resid_any=env.eq_resid(obs32, act_any).numpy(),
+               ineq_resid_any=env.ineq_resid(obs32, act_any).numpy(),
+               ipg_any_batched=env.ineq_partial_grad(obs32, act_any).numpy())
+    out["ipg_any_b1"] = np.stack([env.ineq_partial_grad(obs32[i:i + 1], act_any[i:i + 1]).numpy()[0]
+                                  for i in range(m)])
+    out["ipg_completed_b1"] = np.stack([env.ineq_partial_grad(obs32[i:i + 1], full[i:i + 1]).numpy()[0]
+                                        for i in range(m)])
+    out["ipg_batched_small"] = env.ineq_partial_grad(obs32[:8], act_any[:8]).numpy()
+    save("pendulum_env", **out)
+
+    logger = REF.Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=10)
+    tr = REF.RPODDPG(env, "/tmp", name="g", logger=logger, batch_size=256, max_steps=10, warmup=0, lr_dual=0.01,
+                     corr_lr=2e-3, eps=0.5, eps_start=0.5, eps_epoch=20000, eval_lr=2e-3, eval_steps=50,
+                     grad_eps=0.1, corr_momentum=0.0, policy_fre=4, max_epochs=10, capacity=100,
+                     shared_param=False, value_type="add", clip_thres=0.2, embed_dim=128, hidden_dim=256,
+                     device=torch.device("cpu"))
+    k = 256
+    tr_b1, ev_b1, ev_it = [], [], []
+    for i in range(k):
+        tr_b1.append(tr.grad_steps(obs32[i:i + 1], full[i:i + 1].clone(), train=True).numpy()[0])
+        a, it = tr.grad_steps(obs32[i:i + 1], full[i:i + 1].clone(), train=False)
+        ev_b1.append(a.numpy()[0])
+        ev_it.append(it)
+    gs = dict(obs32=obs32[:k].numpy(), ap=ap[:k], completed=full[:k].numpy(), train_b1=np.stack(tr_b1),
+              eval_b1=np.stack(ev_b1), eval_b1_iters=np.array(ev_it),
+              train_batched=tr.grad_steps(obs32[:k], full[:k].clone(), train=True).numpy())
+    # larger corr_lr so that several lanes actually reach feasibility inside 50 steps
+    tr.eval_lr = 2e-2
+    ev2, it2 = [], []
+    for i in range(k):
+        a, it = tr.grad_steps(obs32[i:i + 1], full[i:i + 1].clone(), train=False)
+        ev2.append(a.numpy()[0])
+        it2.append(it)
+    gs.update(eval_b1_lr2e2=np.stack(ev2), eval_b1_lr2e2_iters=np.array(it2))
+    save("pendulum_grad_steps", **gs)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["cart", "cart_gs", "pendulum"]
+    table = {"cart": gen_cart, "cart_gs": gen_cart_grad_steps, "pendulum": gen_pendulum}
+    for w in which:
+        table[w]()
