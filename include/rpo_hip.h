@@ -1,0 +1,249 @@
+/*
+ * rpo_hip.h -- C ABI of librpo_hip.so: the MI355X (gfx950) kernels behind the RPO rollout-collection +
+ * constrained-policy-update hot path.
+ *
+ * The reference (wadx2019/rpo) is pure Python and has NO native / FFI boundary: its seam is the
+ * duck-typed Python interface between `rpo/algo` trainers and `rpo/env` constraint oracles.  This header is the
+ * C boundary this build puts underneath that interface.  Every entry point names the reference code it replaces
+ * (paths relative to the reference root); INTEGRATION.md shows the ctypes binding a maintainer of the reference
+ * would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in `_host`;
+ *   - the caller owns all memory (PyTorch tensors in the shipped host code); nothing is allocated inside;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous and capturable in a hipGraph: all
+ *     per-iteration varying quantities (vector-step counter, ring position, Adam step) live in device memory;
+ *   - return value: 0 = ok, RPO_ERR_* (<0) = rejected arguments, >0 = hipError_t of the failed launch;
+ *   - re-entrant per stream; no hidden global state.
+ *
+ * Layouts (all float32 unless stated)
+ *   CartSafe-v0      state row  [6]  = (x, x_dot, xacc, theta, theta_dot, thetaacc)       cartpole.py:206
+ *                    action row [2]  ; basic ("partial") action index = consts.partial     cartpole.py:117
+ *                    transition row [24] = s[6] a[2] s'[6] r done eq_viol[1] ineq_viol[6] pad   (ReplayBuffer keys,
+ *                                                                       rpo/algo/agent/ddpg_pa.py:70-71)
+ *   SpringPendulum-v0 internal row [4] = (theta, theta_dot, l, l_dot)                      pendulum.py:126
+ *                    obs row [5] = (cos theta, sin theta, theta_dot, l, l_dot)             pendulum.py:138-140
+ *                    transition row [16] = obs[5] a[2] obs'[5] r done eq_viol[1] ineq_viol[1]
+ *   replay ring      rows [cap_steps * n_envs, W]; vector step t writes rows (t % cap_steps) * n_envs + lane.
+ *   ctrl             int64[RPO_CTRL_LEN]; ctrl[RPO_CTRL_T] = number of vector steps taken so far.  Written only by
+ *                    the *_step kernels (last finishing workgroup), read by every kernel that needs t.
+ *   stats            float[stats_cap, RPO_STATS_LEN] per-vector-step accumulators, row t % stats_cap.
+ */
+#ifndef RPO_HIP_H
+#define RPO_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPO_ABI_VERSION 1
+
+#define RPO_ERR_ARG (-1)
+#define RPO_ERR_NULL (-2)
+
+#define RPO_CART_STATE_DIM 6
+#define RPO_CART_ACTION_DIM 2
+#define RPO_CART_INEQ 6
+#define RPO_CART_ROW 24
+#define RPO_CART_CONSTS_LEN 35 /* C[2] C_p C_o_inv b G[12] d[6] G_r[6] d_r[6], cartpole.py:124-136,397-400 */
+
+#define RPO_PEND_INTERNAL_DIM 4
+#define RPO_PEND_OBS_DIM 5
+#define RPO_PEND_ACTION_DIM 2
+#define RPO_PEND_ROW 16
+
+#define RPO_CTRL_LEN 8
+#define RPO_CTRL_T 0        /* vector steps completed */
+#define RPO_CTRL_ARRIVE 1   /* workgroup arrival counter of the running *_step launch (always 0 between launches) */
+
+#define RPO_STATS_LEN 16
+#define RPO_STAT_REWARD_SUM 0    /* sum over envs of this step's reward                   rpo_ddpg.py:132 */
+#define RPO_STAT_EPISODES 1      /* episodes that ended at this step                       rpo_ddpg.py:134 */
+#define RPO_STAT_RETURN_SUM 2    /* sum of their returns                                   rpo_ddpg.py:134 */
+#define RPO_STAT_LENGTH_SUM 3    /* sum of their lengths                                                   */
+#define RPO_STAT_MAX_INEQ_SUM 4  /* sum over envs of max_i ineq_viol_i                     rpo_ddpg.py:121 */
+#define RPO_STAT_MAX_EQ_SUM 5    /* sum over envs of max_i |eq_viol_i|                     rpo_ddpg.py:120 */
+#define RPO_STAT_VIOL_COUNT 6    /* envs with max(max_ineq, max_eq) > viol_thresh          cartpole.py:326 */
+#define RPO_STAT_MAX_INEQ_MAX 7  /* max over envs                                                          */
+#define RPO_STAT_MAX_EQ_MAX 8
+#define RPO_STAT_PROJ_ITERS 9    /* sum over envs of GRG iterations taken by the rollout projection       */
+#define RPO_STAT_TERMINATED 10   /* episodes ended by the env's own termination test (not the TimeLimit)   */
+
+/* noise_mode of the *_act_project entry points (agent/ddpg_pa.py:101-112, rpo_ddpg.py:98-106) */
+#define RPO_NOISE_NONE 0      /* deterministic: ap used as is, not clipped          (take_action(deterministic=True)) */
+#define RPO_NOISE_EXPLICIT 1  /* ap += eps * noise[i], then clip to the box         (tests: noise injected)           */
+#define RPO_NOISE_PHILOX 2    /* ap += eps * N(0,1) from Philox(seed; env, t), clip (rollout)                         */
+#define RPO_NOISE_UNIFORM 3   /* ap  = U(box) from Philox, ignores ap_raw           (warm-up, BoxConstraint.sample)   */
+#define RPO_NOISE_CLIP_ONLY 4 /* ap clipped to the box, no noise                    (SAC: noise lives in rsample)     */
+
+/* Philox stream tags (counter word 2) */
+#define RPO_STREAM_RESET 1
+#define RPO_STREAM_ACT 2
+#define RPO_STREAM_SAMPLE 3
+#define RPO_STREAM_POLICY 4
+
+int rpo_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Philox4x32-10 (Salmon et al., SC'11), the build's counter-based RNG: key = seed, counter = (id, index, stream, 0).
+ * Fills out[n,4] (uint32) with the raw words for id = id_base + i.  Test hook for bit-exact comparison with
+ * oracle/philox.py.  The reference uses global numpy/torch generators instead (scripts/cart_exp.py:9-10), whose
+ * streams cannot be reproduced on a GPU; parity tests inject the draws explicitly (SURVEY.md §7 hard part iv).
+ * ------------------------------------------------------------------------------------------------------------- */
+int rpo_philox_fill(int n, unsigned* out, unsigned long long seed, unsigned id_base, unsigned index,
+                    unsigned stream_tag, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * CartSafe-v0
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* CartSafeEnv.reset() for every lane (cartpole.py:231-239): state = U(-0.05, 0.05)^6 from
+ * Philox(seed; env_id_base + lane, ep_count[lane], RPO_STREAM_RESET); zeroes ep_len / ep_ret. ep_count is kept. */
+int rpo_cartsafe_reset(int n_envs, float* state, int* ep_len, float* ep_ret, const unsigned* ep_count,
+                       unsigned long long seed, unsigned env_id_base, void* stream);
+
+/* One vectorised env step + TimeLimit + violation bookkeeping + replay scatter + auto-reset, fused.
+ * Replaces, per lane: CartSafeEnv.step (cartpole.py:166-229) incl. ineq_dist_np/eq_resid_np of the PRE-step state
+ * and UN-clipped action (:229, :410-422), gym TimeLimit(200) (classic_control/__init__.py:9),
+ * ReplayBuffer.add (rpo/utils/buffer.py:22-29), the per-step statistics of RPODDPG.run (rpo_ddpg.py:120-145) and
+ * the env.reset() that follows a done (:142).
+ *   state      [n,6]  in: pre-step state; out: post-step state, or a fresh reset state where done (auto_reset != 0)
+ *   action     [n,2]  un-clipped action (clipped to +-10 for the dynamics only)
+ *   ep_len/ep_ret/ep_count [n] per-lane episode bookkeeping (updated)
+ *   rows       replay ring (may be NULL: no scatter); ring row = (t % cap_steps) * n_envs + lane, t = ctrl[RPO_CTRL_T]
+ *   stats      [stats_cap, RPO_STATS_LEN] (may be NULL)
+ *   ctrl       int64[RPO_CTRL_LEN]; ctrl[RPO_CTRL_T] is incremented when the launch finishes
+ */
+int rpo_cartsafe_step(int n_envs, float* state, const float* action, int* ep_len, float* ep_ret, unsigned* ep_count,
+                      float* rows, long long cap_steps, float* stats, int stats_cap, long long* ctrl,
+                      const float* consts_host, int partial, int max_episode_steps, int auto_reset,
+                      float viol_thresh, unsigned long long seed, unsigned env_id_base, void* stream);
+
+/* Exploration noise + box clip + equation solver + GRG projection, fused; one lane per sample, per-lane stop test.
+ * Replaces PDDDPG_PA.take_action's noise/clip tail (agent/ddpg_pa.py:108-110) or BoxConstraint.sample (warm-up,
+ * model/utils.py:53-62), CartSafeEnv.complete_partial (cartpole.py:369-373) and RPODDPG.grad_steps
+ * (rpo_ddpg.py:266-305, corr_mode 0) with CartSafeEnv.eq_resid / ineq_dist / ineq_partial_grad (cartpole.py:375-408).
+ *   ap_raw   [n]     actor output (basic action) -- ignored for RPO_NOISE_UNIFORM
+ *   noise    [n]     only for RPO_NOISE_EXPLICIT
+ *   action   [n,2]   out: completed + projected action
+ *   iters    [n]     out (may be NULL): GRG iterations taken by the lane
+ *   eps_t = max(eps_end, eps_start - eps_decay * t) (PDDDPG_PA.eps_decay, ddpg_pa.py:118-119), t = ctrl[RPO_CTRL_T]
+ *   (ctrl may be NULL: t = 0).  stats may be NULL.
+ */
+int rpo_cartsafe_act_project(int n, const float* ap_raw, const float* noise, float* action, int* iters,
+                             int noise_mode, float eps_start, float eps_end, float eps_decay, float box_lo,
+                             float box_hi, int max_steps, float corr_lr, float corr_eps, float corr_momentum,
+                             const float* consts_host, int partial, unsigned long long seed, unsigned env_id_base,
+                             const long long* ctrl, float* stats, int stats_cap, void* stream);
+
+/* Backward of complete_partial for the actor loss (rpo_ddpg.py:310; autograd through cartpole.py:369-373):
+ * grad_ap[i] = grad_action[i,p] - grad_action[i,o] * C_p * C_o_inv. */
+int rpo_cartsafe_complete_bwd(int n, const float* grad_action, float* grad_ap, const float* consts_host,
+                              int partial, void* stream);
+
+/* Constraint residuals of a batch of full actions: eq_resid [n,1] (cartpole.py:375-376), ineq_resid [n,6] (:378-379).
+ * Either output may be NULL.  ineq_dist = max(ineq_resid, 0). */
+int rpo_cartsafe_resid(int n, const float* action, float* eq_resid, float* ineq_resid, const float* consts_host,
+                       int partial, void* stream);
+
+/* ineq_partial_grad (cartpole.py:396-408) -> step [n,2]. */
+int rpo_cartsafe_ineq_partial_grad(int n, const float* action, float* step, const float* consts_host, int partial,
+                                   void* stream);
+
+/* Lagrangian term of the actor loss, forward + backward fused (rpo_ddpg.py:312,319,322; Dual.forward dual.py:63-65):
+ *   loss_out[0] += scale * sum_b sum_i nu_i * max(0, g_i(a_b));   grad_action[b,:] = scale * sum_i nu_i 1[g_i>0] G_i;
+ *   grad_nu[i] += scale * sum_b max(0, g_i(a_b)).   loss_out / grad_nu must be zeroed by the caller. */
+int rpo_cartsafe_lagrangian(int n, const float* action, const float* nu, float scale, float* loss_out,
+                            float* grad_action, float* grad_nu, const float* consts_host, int partial, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * SpringPendulum-v0 (same roles; the equality is state dependent, pendulum.py:264-288)
+ * ------------------------------------------------------------------------------------------------------------- */
+int rpo_pendulum_reset(int n_envs, float* internal, float* obs, int* ep_len, float* ep_ret, const unsigned* ep_count,
+                       unsigned long long seed, unsigned env_id_base, void* stream);
+
+/* pendulum.py:80-128 + TimeLimit + scatter + auto-reset.  internal [n,4] in/out; obs [n,5] out (may be NULL): the
+ * next observation, or the reset observation where done.  The pre-step observation stored in the transition row is
+ * recomputed from `internal` (it is bit-identical to what a previous launch wrote to `obs`). */
+int rpo_pendulum_step(int n_envs, float* internal, float* obs, const float* action, int* ep_len, float* ep_ret,
+                      unsigned* ep_count, float* rows, long long cap_steps, float* stats, int stats_cap,
+                      long long* ctrl, int max_episode_steps, int auto_reset, float viol_thresh,
+                      unsigned long long seed, unsigned env_id_base, void* stream);
+
+/* noise/clip + complete_partial (pendulum.py:256-262) + grad_steps with the ROW-WISE ineq_partial_grad
+ * (pendulum.py:331-343 as evaluated for B = 1; the reference's batched call couples samples).
+ * obs rows are read with a row stride of obs_stride floats (>= 5): they may be columns of a gathered batch. */
+int rpo_pendulum_act_project(int n, const float* obs, int obs_stride, const float* ap_raw, const float* noise,
+                             float* action, int* iters, int noise_mode, float eps_start, float eps_end,
+                             float eps_decay, float box_lo, float box_hi, int max_steps, float corr_lr,
+                             float corr_eps, float corr_momentum, unsigned long long seed, unsigned env_id_base,
+                             const long long* ctrl, float* stats, int stats_cap, void* stream);
+
+/* grad_ap[i] = grad_action[i,0] - grad_action[i,1] * sin/cos (autograd through pendulum.py:256-262). */
+int rpo_pendulum_complete_bwd(int n, const float* obs, int obs_stride, const float* grad_action, float* grad_ap,
+                              void* stream);
+
+/* eq_resid [n] (pendulum.py:298-300), ineq_resid [n] (:302-303); either output may be NULL. */
+int rpo_pendulum_resid(int n, const float* obs, int obs_stride, const float* action, float* eq_resid,
+                       float* ineq_resid, void* stream);
+
+int rpo_pendulum_ineq_partial_grad(int n, const float* obs, int obs_stride, const float* action, float* step,
+                                   void* stream);
+
+/* g(a) = |a|^2 - 32: loss += scale * nu * sum_b max(0,g); grad_action = scale * nu * 1[g>0] * 2a; grad_nu likewise. */
+int rpo_pendulum_lagrangian(int n, const float* action, const float* nu, float scale, float* loss_out,
+                            float* grad_action, float* grad_nu, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Replay ring (rpo/utils/buffer.py:3-47)
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* ReplayBuffer.sample (buffer.py:31-34): uniform with replacement over the valid rows
+ * n_valid = min(t, cap_steps) * n_envs (t = ctrl[RPO_CTRL_T]); index b = mulhi64(Philox(seed; b, t + sample_salt,
+ * RPO_STREAM_SAMPLE).xy, n_valid); copies the row into batch[b, :].  idx_out (int64 [B], may be NULL) receives the
+ * drawn indices. */
+int rpo_replay_sample_gather(const float* rows, int row_floats, long long cap_steps, int n_envs, int batch,
+                             float* batch_out, long long* idx_out, unsigned long long seed, unsigned sample_salt,
+                             const long long* ctrl, void* stream);
+
+/* Same gather with caller-provided indices (int64 [B]) -- parity tests inject the reference's np.random.randint. */
+int rpo_replay_gather(const float* rows, int row_floats, int batch, const long long* idx, float* batch_out,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Fused TD target + Huber loss, forward + backward (RPODDPG.critic_loss rpo_ddpg.py:327-337,
+ * RPOSAC.critic_loss rpo_sac.py:342-353; F.smooth_l1_loss beta = 1, mean reduction)
+ *   y_b = r_b + gamma * (1 - done_b) * (min(qn1_b, qn2_b) - alpha * logp_b)        (qn2 / logp NULL: DDPG form)
+ *   loss_out[0] += (1/n) sum_b huber(q1_b - y_b) [+ huber(q2_b - y_b)];  grad_q*[b] = clamp(q*_b - y_b, -1, 1) / n
+ *   reward / done are read with an element stride (they are columns of the gathered batch).
+ * ------------------------------------------------------------------------------------------------------------- */
+int rpo_td_huber(int n, const float* q1, const float* q2, const float* qn1, const float* qn2, const float* logp,
+                 float alpha, const float* reward, int reward_stride, const float* done, int done_stride, float gamma,
+                 float* loss_out, float* grad_q1, float* grad_q2, float* target_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Optimiser plumbing of RPODDPG.train (rpo_ddpg.py:178-205) on flat float32 parameter buffers
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* max_out[0] = max(max_out[0], max_i |x_i|) -- the "inf" norm of clip_grad_norm_ (rpo_ddpg.py:180,193).
+ * max_out must hold a non-negative float (0 before the first call of an update). */
+int rpo_absmax(long long n, const float* x, float* max_out, void* stream);
+
+/* clip_grad_norm_(inf) + torch.optim.Adam step (+ optional DualAdam clamp, model/dual.py:37-45) (+ optional Polyak
+ * target update, agent/ddpg_pa.py:77-86), one pass over the flat buffer:
+ *   coef = min(1, clip_thres / (gradmax[0] + 1e-6)) when clip_thres > 0 (gradmax from rpo_absmax); g = coef * grad
+ *   (written back, as clip_grad_norm_ does); maximize: g = -g; weight decay; Adam with bias correction at step
+ *   step_dev[0] + 1 (the counter is advanced by the launch); clamp_min0: p = max(p, 0); target != NULL:
+ *   target = (1 - tau) * target + tau * p.   gradmax is reset to 0 by the launch when reset_gradmax != 0.
+ *   step_dev points at int32[4] (16-byte aligned): {step, pad, 8-byte arrival word (0 between launches)}. */
+int rpo_adam_step(long long n, float* param, float* grad, float* exp_avg, float* exp_avg_sq, int* step_dev,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int maximize, float clip_thres,
+                  float* gradmax, int reset_gradmax, int clamp_min0, float* target, float tau, void* stream);
+
+/* soft_update alone (agent/ddpg_pa.py:77-86, sac_pa.py:87-91): target = (1 - tau) * target + tau * param. */
+int rpo_polyak(long long n, const float* param, float* target, float tau, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPO_HIP_H */

@@ -1,0 +1,204 @@
+// Update-step kernels of RPODDPG.train / RPOSAC.train on MI355X: fused TD-target + Huber (forward + backward),
+// inf-norm of a flat gradient buffer, fused clip + Adam (+DualAdam clamp, + Polyak), Polyak alone, Philox test hook.
+// All are single-pass streaming kernels with wave64 shuffle reductions.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------- TD target + Huber
+__device__ __forceinline__ float huber(float d) {   // F.smooth_l1_loss, beta = 1
+    const float ad = fabsf(d);
+    return ad < 1.0f ? 0.5f * d * d : ad - 0.5f;
+}
+
+__global__ __launch_bounds__(RPO_BLOCK) void td_huber_kernel(
+    int n, const float* __restrict__ q1, const float* __restrict__ q2, const float* __restrict__ qn1,
+    const float* __restrict__ qn2, const float* __restrict__ logp, float alpha, const float* __restrict__ reward,
+    int reward_stride, const float* __restrict__ done, int done_stride, float gamma, float* __restrict__ loss_out,
+    float* __restrict__ grad_q1, float* __restrict__ grad_q2, float* __restrict__ target_out) {
+    __shared__ float red[RPO_BLOCK / RPO_WAVE];
+    const float inv_n = 1.0f / (float)n;
+    float acc = 0.0f;
+    for (int i = blockIdx.x * RPO_BLOCK + threadIdx.x; i < n; i += gridDim.x * RPO_BLOCK) {
+        float qn = qn1[i];
+        if (qn2) qn = fminf(qn, qn2[i]);                              // rpo_sac.py:346-347
+        if (logp) qn -= alpha * logp[i];
+        const float y = reward[(size_t)i * reward_stride] +
+                        gamma * (1.0f - done[(size_t)i * done_stride]) * qn;   // rpo_ddpg.py:332
+        if (target_out) target_out[i] = y;
+        const float d1 = q1[i] - y;
+        acc += huber(d1);
+        if (grad_q1) grad_q1[i] = fminf(fmaxf(d1, -1.0f), 1.0f) * inv_n;
+        if (q2) {
+            const float d2 = q2[i] - y;
+            acc += huber(d2);
+            if (grad_q2) grad_q2[i] = fminf(fmaxf(d2, -1.0f), 1.0f) * inv_n;
+        }
+    }
+    const float r = rpo_wave_sum(acc);
+    if ((threadIdx.x & (RPO_WAVE - 1)) == 0) red[threadIdx.x / RPO_WAVE] = r;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_out) {
+        float s = 0.0f;
+        for (int w = 0; w < RPO_BLOCK / RPO_WAVE; ++w) s += red[w];
+        atomicAdd(loss_out, s * inv_n);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- inf-norm
+__global__ __launch_bounds__(RPO_BLOCK) void absmax_kernel(long long n, const float* __restrict__ x,
+                                                           float* __restrict__ max_out) {
+    __shared__ float red[RPO_BLOCK / RPO_WAVE];
+    float m = 0.0f;
+    const long long n4 = n / 4;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (long long i = (long long)blockIdx.x * RPO_BLOCK + threadIdx.x; i < n4; i += (long long)gridDim.x * RPO_BLOCK) {
+        const float4 v = x4[i];
+        m = fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    for (long long i = n4 * 4 + (long long)blockIdx.x * RPO_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * RPO_BLOCK)
+        m = fmaxf(m, fabsf(x[i]));
+    m = rpo_wave_max(m);
+    if ((threadIdx.x & (RPO_WAVE - 1)) == 0) red[threadIdx.x / RPO_WAVE] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < RPO_BLOCK / RPO_WAVE; ++w) m = fmaxf(m, red[w]);
+        m = fmaxf(m, red[0]);
+        if (m > 0.0f) rpo_atomic_max_nonneg(max_out, m);
+    }
+}
+
+// -------------------------------------------------------------------------------------- clip + Adam + Polyak
+struct AdamArgs {
+    long long n;
+    float* param;
+    float* grad;
+    float* m;
+    float* v;
+    int* step_dev;
+    float lr, beta1, beta2, eps, weight_decay;
+    int maximize;
+    float clip_thres;
+    float* gradmax;
+    int reset_gradmax;
+    int clamp_min0;
+    float* target;
+    float tau;
+    long long* arrive;   // scratch word for the "last workgroup" epilogue (step counter / gradmax reset)
+};
+
+__global__ __launch_bounds__(RPO_BLOCK) void adam_kernel(AdamArgs p) {
+    // torch.optim.Adam (single-tensor path): bias corrections in double like torch's Python floats
+    const int step = p.step_dev[0] + 1;
+    const double bc1 = 1.0 - pow((double)p.beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)p.beta2, (double)step);
+    const float step_size = (float)((double)p.lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    float coef = 1.0f;
+    if (p.clip_thres > 0.0f) {   // clip_grad_norm_(..., norm_type=inf): clip_coef clamped to 1, always applied
+        coef = fminf(p.clip_thres / (p.gradmax[0] + 1e-6f), 1.0f);
+    }
+    const float omb1 = 1.0f - p.beta1, omb2 = 1.0f - p.beta2;
+    for (long long i = (long long)blockIdx.x * RPO_BLOCK + threadIdx.x; i < p.n; i += (long long)gridDim.x * RPO_BLOCK) {
+        float g = p.grad[i] * coef;
+        if (p.clip_thres > 0.0f) p.grad[i] = g;
+        if (p.maximize) g = -g;
+        float w = p.param[i];
+        if (p.weight_decay != 0.0f) g += p.weight_decay * w;
+        float m = p.m[i], v = p.v[i];
+        m = m + (g - m) * omb1;                       // exp_avg.lerp_(grad, 1 - beta1)
+        v = v * p.beta2 + omb2 * g * g;               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float denom = sqrtf(v) / bc2_sqrt + p.eps;
+        w = w - step_size * (m / denom);              // param.addcdiv_(exp_avg, denom, value=-step_size)
+        if (p.clamp_min0) w = fmaxf(w, 0.0f);         // DualAdam, model/dual.py:41-43
+        p.param[i] = w; p.m[i] = m; p.v[i] = v;
+        if (p.target) p.target[i] = p.target[i] * (1.0f - p.tau) + w * p.tau;   // soft_update, ddpg_pa.py:77-86
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long arrived = atomicAdd(reinterpret_cast<unsigned long long*>(p.arrive), 1ull);
+        if (arrived == (unsigned long long)gridDim.x - 1ull) {
+            *p.arrive = 0;
+            p.step_dev[0] = step;
+            if (p.reset_gradmax && p.gradmax) p.gradmax[0] = 0.0f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(RPO_BLOCK) void polyak_kernel(long long n, const float* __restrict__ param,
+                                                           float* __restrict__ target, float tau) {
+    for (long long i = (long long)blockIdx.x * RPO_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * RPO_BLOCK)
+        target[i] = target[i] * (1.0f - tau) + param[i] * tau;
+}
+
+__global__ __launch_bounds__(RPO_BLOCK) void philox_fill_kernel(int n, uint32_t* __restrict__ out, uint64_t seed,
+                                                                uint32_t id_base, uint32_t index, uint32_t tag) {
+    for (int i = blockIdx.x * RPO_BLOCK + threadIdx.x; i < n; i += gridDim.x * RPO_BLOCK) {
+        const rpo_u4 r = rpo_philox(seed, id_base + (uint32_t)i, index, tag);
+        reinterpret_cast<uint4*>(out)[i] = make_uint4(r.x, r.y, r.z, r.w);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rpo_abi_version(void) { return RPO_ABI_VERSION; }
+
+int rpo_philox_fill(int n, unsigned* out, unsigned long long seed, unsigned id_base, unsigned index,
+                    unsigned stream_tag, void* stream) {
+    if (n <= 0) return RPO_ERR_ARG;
+    if (!out) return RPO_ERR_NULL;
+    hipLaunchKernelGGL(philox_fill_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, out,
+                       (uint64_t)seed, (uint32_t)id_base, (uint32_t)index, (uint32_t)stream_tag);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_td_huber(int n, const float* q1, const float* q2, const float* qn1, const float* qn2, const float* logp,
+                 float alpha, const float* reward, int reward_stride, const float* done, int done_stride, float gamma,
+                 float* loss_out, float* grad_q1, float* grad_q2, float* target_out, void* stream) {
+    if (n <= 0 || reward_stride <= 0 || done_stride <= 0) return RPO_ERR_ARG;
+    if (!q1 || !qn1 || !reward || !done) return RPO_ERR_NULL;
+    hipLaunchKernelGGL(td_huber_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, q1, q2, qn1,
+                       qn2, logp, alpha, reward, reward_stride, done, done_stride, gamma, loss_out, grad_q1, grad_q2,
+                       target_out);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_absmax(long long n, const float* x, float* max_out, void* stream) {
+    if (n <= 0) return RPO_ERR_ARG;
+    if (!x || !max_out) return RPO_ERR_NULL;
+    if ((reinterpret_cast<uintptr_t>(x) & 15u) != 0) return RPO_ERR_ARG;
+    hipLaunchKernelGGL(absmax_kernel, dim3(rpo_grid_for(n / 4 + 1)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, x,
+                       max_out);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_adam_step(long long n, float* param, float* grad, float* exp_avg, float* exp_avg_sq, int* step_dev,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int maximize, float clip_thres,
+                  float* gradmax, int reset_gradmax, int clamp_min0, float* target, float tau, void* stream) {
+    if (n <= 0) return RPO_ERR_ARG;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return RPO_ERR_NULL;
+    if (clip_thres > 0.0f && !gradmax) return RPO_ERR_NULL;
+    // the arrival word lives right behind the step counter: step_dev must point at int32[4] = {step, pad, arrive(8 B)}
+    AdamArgs a{n, param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, weight_decay, maximize,
+               clip_thres, gradmax, reset_gradmax, clamp_min0, target, tau,
+               reinterpret_cast<long long*>(step_dev + 2)};
+    hipLaunchKernelGGL(adam_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, a);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_polyak(long long n, const float* param, float* target, float tau, void* stream) {
+    if (n <= 0) return RPO_ERR_ARG;
+    if (!param || !target) return RPO_ERR_NULL;
+    hipLaunchKernelGGL(polyak_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, param, target,
+                       tau);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,220 @@
+"""Tensor-level wrappers over the C ABI (include/rpo_hip.h).  PyTorch only provides device memory and the stream.
+
+Every wrapper launches on ``torch.cuda.current_stream()`` so that the calls are ordered with the surrounding torch ops
+and are captured when that stream is being captured into a hipGraph.  Tensors must already live on the GPU as
+contiguous float32 / int32 / int64: there is no CPU path here.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CONST, RpoHipError, check
+
+NOISE_NONE = CONST["RPO_NOISE_NONE"]
+NOISE_EXPLICIT = CONST["RPO_NOISE_EXPLICIT"]
+NOISE_PHILOX = CONST["RPO_NOISE_PHILOX"]
+NOISE_UNIFORM = CONST["RPO_NOISE_UNIFORM"]
+NOISE_CLIP_ONLY = CONST["RPO_NOISE_CLIP_ONLY"]
+STATS_LEN = CONST["RPO_STATS_LEN"]
+CTRL_LEN = CONST["RPO_CTRL_LEN"]
+STAT = {k[len("RPO_STAT_"):].lower(): v for k, v in CONST.items() if k.startswith("RPO_STAT_") and k != "RPO_STATS_LEN"}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, dtype=torch.float32, allow_none=False, contiguous=True):
+    if t is None:
+        if allow_none:
+            return None
+        raise RpoHipError("required tensor is None")
+    if not t.is_cuda:
+        raise RpoHipError("rpo_amd kernels need GPU tensors (got %s); there is no CPU fallback" % t.device)
+    if t.dtype != dtype:
+        raise RpoHipError("expected %s, got %s" % (dtype, t.dtype))
+    if contiguous and not t.is_contiguous():
+        raise RpoHipError("expected a contiguous tensor, got strides %s" % (t.stride(),))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _row_view(t, width):
+    """(pointer, row stride in floats) of a [n, width] float32 view whose rows are contiguous."""
+    if t.dim() != 2 or t.shape[1] != width or t.stride(1) != 1:
+        raise RpoHipError("expected a [n,%d] row view with unit column stride, got %s / %s" % (width, tuple(t.shape), t.stride()))
+    return _p(t, contiguous=False), int(t.stride(0))
+
+
+def _col_view(t):
+    """(pointer, element stride) of a 1-column view (a column of a gathered batch, or a contiguous vector)."""
+    if t.dim() == 2:
+        if t.shape[1] != 1:
+            raise RpoHipError("expected [n,1], got %s" % (tuple(t.shape),))
+        return _p(t, contiguous=False), int(t.stride(0))
+    return _p(t, contiguous=False), int(t.stride(0))
+
+
+def _host_consts(arr):
+    a = np.ascontiguousarray(arr, dtype=np.float32)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+# =================================================================================================== shared kernels
+
+def philox_fill(out, seed, id_base, index, stream_tag):
+    check(_lib.load().rpo_philox_fill(out.shape[0], _p(out, torch.int32), seed, id_base, index, stream_tag, _stream()),
+          "rpo_philox_fill")
+
+
+def replay_gather(rows, idx, out):
+    check(_lib.load().rpo_replay_gather(_p(rows), rows.shape[-1], idx.shape[0], _p(idx, torch.int64), _p(out),
+                                        _stream()), "rpo_replay_gather")
+
+
+def replay_sample_gather(rows, cap_steps, n_envs, out, idx_out, seed, salt, ctrl):
+    check(_lib.load().rpo_replay_sample_gather(_p(rows), rows.shape[-1], cap_steps, n_envs, out.shape[0], _p(out),
+                                               _p(idx_out, torch.int64, allow_none=True), seed, salt,
+                                               _p(ctrl, torch.int64), _stream()), "rpo_replay_sample_gather")
+
+
+def td_huber(q1, q2, qn1, qn2, logp, alpha, reward, done, gamma, loss_out, grad_q1, grad_q2, target_out=None):
+    n = q1.shape[0]
+    rp, rs = _col_view(reward)
+    dp, ds = _col_view(done)
+    check(_lib.load().rpo_td_huber(n, _p(q1), _p(q2, allow_none=True), _p(qn1), _p(qn2, allow_none=True),
+                                   _p(logp, allow_none=True), alpha, rp, rs, dp, ds, gamma, _p(loss_out),
+                                   _p(grad_q1, allow_none=True), _p(grad_q2, allow_none=True),
+                                   _p(target_out, allow_none=True), _stream()), "rpo_td_huber")
+
+
+def absmax(x, max_out):
+    check(_lib.load().rpo_absmax(x.numel(), _p(x), _p(max_out), _stream()), "rpo_absmax")
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
+              maximize=False, clip_thres=0.0, gradmax=None, reset_gradmax=True, clamp_min0=False, target=None,
+              tau=0.0):
+    check(_lib.load().rpo_adam_step(param.numel(), _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq),
+                                    _p(step_dev, torch.int32), lr, beta1, beta2, eps, weight_decay, int(maximize),
+                                    clip_thres, _p(gradmax, allow_none=True), int(reset_gradmax), int(clamp_min0),
+                                    _p(target, allow_none=True), tau, _stream()), "rpo_adam_step")
+
+
+def polyak(param, target, tau):
+    check(_lib.load().rpo_polyak(param.numel(), _p(param), _p(target), tau, _stream()), "rpo_polyak")
+
+
+# =================================================================================================== env kernel sets
+
+class CartSafeKernels(object):
+    """HIP kernels of CartSafe-v0.  ``consts`` is the float32[35] table of include/rpo_hip.h (RPO_CART_CONSTS_LEN)."""
+
+    name = "CartSafe-v0"
+    obs_dim, internal_dim, action_dim, eq_num, ineq_num = 6, 6, 2, 1, 6
+    row_floats = CONST["RPO_CART_ROW"]
+    # column ranges of a transition row
+    cols = dict(state=(0, 6), action=(6, 8), next_state=(8, 14), reward=(14, 15), done=(15, 16), eq_viol=(16, 17),
+                ineq_viol=(17, 23))
+
+    def __init__(self, consts, partial):
+        self.consts, self._cptr = _host_consts(consts)
+        if self.consts.shape != (CONST["RPO_CART_CONSTS_LEN"],):
+            raise RpoHipError("bad CartSafe constant table")
+        self.partial = int(partial)
+
+    def reset(self, internal, obs, ep_len, ep_ret, ep_count, seed, env_id_base):
+        # the observation IS the internal state for this env: `obs` aliases `internal`
+        check(_lib.load().rpo_cartsafe_reset(internal.shape[0], _p(internal), _p(ep_len, torch.int32), _p(ep_ret),
+                                             _p(ep_count, torch.int32), seed, env_id_base, _stream()),
+              "rpo_cartsafe_reset")
+
+    def step(self, internal, obs, action, ep_len, ep_ret, ep_count, rows, cap_steps, stats, ctrl, max_episode_steps,
+             auto_reset, viol_thresh, seed, env_id_base):
+        check(_lib.load().rpo_cartsafe_step(
+            internal.shape[0], _p(internal), _p(action), _p(ep_len, torch.int32), _p(ep_ret),
+            _p(ep_count, torch.int32), _p(rows, allow_none=True), cap_steps, _p(stats, allow_none=True),
+            0 if stats is None else stats.shape[0], _p(ctrl, torch.int64, allow_none=True), self._cptr, self.partial,
+            max_episode_steps, int(auto_reset), viol_thresh, seed, env_id_base, _stream()), "rpo_cartsafe_step")
+
+    def act_project(self, obs, ap_raw, noise, action, iters, noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi,
+                    max_steps, corr_lr, corr_eps, corr_momentum, seed=0, env_id_base=0, ctrl=None, stats=None):
+        check(_lib.load().rpo_cartsafe_act_project(
+            action.shape[0], _p(ap_raw, allow_none=True), _p(noise, allow_none=True), _p(action),
+            _p(iters, torch.int32, allow_none=True), noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi,
+            max_steps, corr_lr, corr_eps, corr_momentum, self._cptr, self.partial, seed, env_id_base,
+            _p(ctrl, torch.int64, allow_none=True), _p(stats, allow_none=True),
+            0 if stats is None else stats.shape[0], _stream()), "rpo_cartsafe_act_project")
+
+    def complete_bwd(self, obs, grad_action, grad_ap):
+        check(_lib.load().rpo_cartsafe_complete_bwd(grad_action.shape[0], _p(grad_action), _p(grad_ap), self._cptr,
+                                                    self.partial, _stream()), "rpo_cartsafe_complete_bwd")
+
+    def resid(self, obs, action, eq_out, ineq_out):
+        check(_lib.load().rpo_cartsafe_resid(action.shape[0], _p(action), _p(eq_out, allow_none=True),
+                                             _p(ineq_out, allow_none=True), self._cptr, self.partial, _stream()),
+              "rpo_cartsafe_resid")
+
+    def ineq_partial_grad(self, obs, action, step_out):
+        check(_lib.load().rpo_cartsafe_ineq_partial_grad(action.shape[0], _p(action), _p(step_out), self._cptr,
+                                                         self.partial, _stream()), "rpo_cartsafe_ineq_partial_grad")
+
+    def lagrangian(self, action, nu, scale, loss_out, grad_action, grad_nu):
+        check(_lib.load().rpo_cartsafe_lagrangian(action.shape[0], _p(action), _p(nu), scale, _p(loss_out),
+                                                  _p(grad_action, allow_none=True), _p(grad_nu, allow_none=True),
+                                                  self._cptr, self.partial, _stream()), "rpo_cartsafe_lagrangian")
+
+
+class PendulumKernels(object):
+    """HIP kernels of SpringPendulum-v0."""
+
+    name = "SpringPendulum-v0"
+    obs_dim, internal_dim, action_dim, eq_num, ineq_num = 5, 4, 2, 1, 1
+    row_floats = CONST["RPO_PEND_ROW"]
+    cols = dict(state=(0, 5), action=(5, 7), next_state=(7, 12), reward=(12, 13), done=(13, 14), eq_viol=(14, 15),
+                ineq_viol=(15, 16))
+    partial = 0
+
+    def reset(self, internal, obs, ep_len, ep_ret, ep_count, seed, env_id_base):
+        check(_lib.load().rpo_pendulum_reset(internal.shape[0], _p(internal), _p(obs, allow_none=True),
+                                             _p(ep_len, torch.int32), _p(ep_ret), _p(ep_count, torch.int32), seed,
+                                             env_id_base, _stream()), "rpo_pendulum_reset")
+
+    def step(self, internal, obs, action, ep_len, ep_ret, ep_count, rows, cap_steps, stats, ctrl, max_episode_steps,
+             auto_reset, viol_thresh, seed, env_id_base):
+        check(_lib.load().rpo_pendulum_step(
+            internal.shape[0], _p(internal), _p(obs, allow_none=True), _p(action), _p(ep_len, torch.int32), _p(ep_ret),
+            _p(ep_count, torch.int32), _p(rows, allow_none=True), cap_steps, _p(stats, allow_none=True),
+            0 if stats is None else stats.shape[0], _p(ctrl, torch.int64, allow_none=True), max_episode_steps,
+            int(auto_reset), viol_thresh, seed, env_id_base, _stream()), "rpo_pendulum_step")
+
+    def act_project(self, obs, ap_raw, noise, action, iters, noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi,
+                    max_steps, corr_lr, corr_eps, corr_momentum, seed=0, env_id_base=0, ctrl=None, stats=None):
+        op, ostride = _row_view(obs, 5)
+        check(_lib.load().rpo_pendulum_act_project(
+            action.shape[0], op, ostride, _p(ap_raw, allow_none=True), _p(noise, allow_none=True), _p(action),
+            _p(iters, torch.int32, allow_none=True), noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi,
+            max_steps, corr_lr, corr_eps, corr_momentum, seed, env_id_base, _p(ctrl, torch.int64, allow_none=True),
+            _p(stats, allow_none=True), 0 if stats is None else stats.shape[0], _stream()),
+            "rpo_pendulum_act_project")
+
+    def complete_bwd(self, obs, grad_action, grad_ap):
+        op, ostride = _row_view(obs, 5)
+        check(_lib.load().rpo_pendulum_complete_bwd(grad_action.shape[0], op, ostride, _p(grad_action), _p(grad_ap),
+                                                    _stream()), "rpo_pendulum_complete_bwd")
+
+    def resid(self, obs, action, eq_out, ineq_out):
+        op, ostride = _row_view(obs, 5)
+        check(_lib.load().rpo_pendulum_resid(action.shape[0], op, ostride, _p(action), _p(eq_out, allow_none=True),
+                                             _p(ineq_out, allow_none=True), _stream()), "rpo_pendulum_resid")
+
+    def ineq_partial_grad(self, obs, action, step_out):
+        op, ostride = _row_view(obs, 5)
+        check(_lib.load().rpo_pendulum_ineq_partial_grad(action.shape[0], op, ostride, _p(action), _p(step_out),
+                                                         _stream()), "rpo_pendulum_ineq_partial_grad")
+
+    def lagrangian(self, action, nu, scale, loss_out, grad_action, grad_nu):
+        check(_lib.load().rpo_pendulum_lagrangian(action.shape[0], _p(action), _p(nu), scale, _p(loss_out),
+                                                  _p(grad_action, allow_none=True), _p(grad_nu, allow_none=True),
+                                                  _stream()), "rpo_pendulum_lagrangian")

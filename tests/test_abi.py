@@ -1,0 +1,50 @@
+"""The C-ABI library loads and exports every symbol include/rpo_hip.h declares (no GPU needed, no compute calls)."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+from rpo_amd import _lib
+
+
+def test_header_parses():
+    protos, consts = _lib.parse_header()
+    assert len(protos) >= 20
+    for must in ("rpo_cartsafe_step", "rpo_cartsafe_act_project", "rpo_pendulum_step", "rpo_replay_sample_gather",
+                 "rpo_td_huber", "rpo_adam_step", "rpo_cartsafe_lagrangian", "rpo_abi_version"):
+        assert must in protos
+    assert consts["RPO_CART_ROW"] == 24 and consts["RPO_PEND_ROW"] == 16 and consts["RPO_ERR_ARG"] == -1
+    # spot-check the type mapping
+    assert protos["rpo_polyak"] == [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIBRARY):
+        from rpo_amd.csrc import build
+        build.build(verbose=False)
+    lib = _lib.load()
+    for name in _lib.PROTOTYPES:
+        assert hasattr(lib, name), name
+    assert lib.rpo_abi_version() == _lib.CONST["RPO_ABI_VERSION"]
+    # nothing torch-typed in the dynamic symbol table: the boundary is plain C
+    syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIBRARY], capture_output=True, text=True).stdout
+    exported = {line.split()[-1] for line in syms.splitlines() if " T " in line}
+    assert set(_lib.PROTOTYPES) <= exported
+
+
+def test_argument_validation_without_gpu():
+    """Argument checks run before any HIP call, so they can be exercised on a CPU-only box."""
+    lib = _lib.load()
+    assert lib.rpo_polyak(0, None, None, 0.5, None) == _lib.CONST["RPO_ERR_ARG"]
+    assert lib.rpo_polyak(4, None, None, 0.5, None) == _lib.CONST["RPO_ERR_NULL"]
+    assert lib.rpo_replay_gather(None, 23, 4, None, None, None) == _lib.CONST["RPO_ERR_ARG"]   # row not 16-B multiple
+    with pytest.raises(_lib.RpoHipError):
+        _lib.check(-1, "x")
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from rpo_amd import ops
+    with pytest.raises(_lib.RpoHipError):
+        ops.polyak(torch.zeros(4), torch.zeros(4), 0.5)
