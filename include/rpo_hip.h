@@ -93,6 +93,13 @@ int rpo_abi_version(void);
 int rpo_philox_fill(int n, unsigned* out, unsigned long long seed, unsigned id_base, unsigned index,
                     unsigned stream_tag, void* stream);
 
+/* out[i] = N(0,1) (Box-Muller, float32) from Philox(seed; id_base + i, t + salt, stream_tag), t = ctrl[RPO_CTRL_T]
+ * (ctrl may be NULL: t = 0).  Replaces the global-generator draws of the update step -- torch.randn_like in
+ * PDDDPG_PA.take_action (agent/ddpg_pa.py:109) and Normal.rsample in GaussianSharedPolicy (model/policy.py:59) --
+ * with a stream that is reproducible, capturable in a hipGraph and independent of the rank layout. */
+int rpo_philox_normal(int n, float* out, unsigned long long seed, unsigned id_base, unsigned salt,
+                      unsigned stream_tag, const long long* ctrl, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * CartSafe-v0
  * ------------------------------------------------------------------------------------------------------------- */
@@ -178,6 +185,14 @@ int rpo_pendulum_act_project(int n, const float* obs, int obs_stride, const floa
                              float eps_decay, float box_lo, float box_hi, int max_steps, float corr_lr,
                              float corr_eps, float corr_momentum, unsigned long long seed, unsigned env_id_base,
                              const long long* ctrl, float* stats, int stats_cap, void* stream);
+
+/* complete_partial + the reference's LITERAL batched grad_steps on a training batch (n <= 1024): batch-global stop
+ * test (rpo_ddpg.py:271-272) and the sample-coupled ineq_partial_grad of pendulum.py:337-339, grad_i = sum_j
+ * 1[a_x,i * dgp_j - bgp_i > 0] * dgp_j.  Used for the TD-target projection of critic_loss
+ * (rpo_ddpg.py:330) so that the update step matches the reference; iters_out (int32[1], may be NULL) = iterations. */
+int rpo_pendulum_project_batchref(int n, const float* obs, int obs_stride, const float* ap, float* action,
+                                  int* iters_out, int max_steps, float corr_lr, float corr_eps, float corr_momentum,
+                                  void* stream);
 
 /* grad_ap[i] = grad_action[i,0] - grad_action[i,1] * sin/cos (autograd through pendulum.py:256-262). */
 int rpo_pendulum_complete_bwd(int n, const float* obs, int obs_stride, const float* grad_action, float* grad_ap,

@@ -1,0 +1,104 @@
+"""Flat float32 parameter / gradient buffers and the fused optimiser launches built on them.
+
+The reference updates 6-12 small tensors with one ``torch.optim.Adam`` python loop per optimiser, a
+``clip_grad_norm_`` pass and a Polyak loop (rpo_ddpg.py:178-205, agent/ddpg_pa.py:77-86).  Here every optimiser owns a
+contiguous slice of ONE buffer, so clip + Adam (+ Polyak) is two kernel launches regardless of the number of tensors,
+and a data-parallel all-reduce is one collective on one bucket.
+
+Layout: ``[ critic-only | shared | actor-only ]`` (each segment padded to 4 floats for 16-byte alignment).  With
+``shared_param=True`` the state embedding belongs to both optimisers, exactly like the reference where both Adams hold
+the same Parameter objects (agent/ddpg_pa.py:34-36,52-53): critic Adam covers ``[0, c+s)``, actor Adam
+``[c, c+s+a)``, each with its own moments and step counter.
+"""
+import torch
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+def _unique(params):
+    seen, out = set(), []
+    for p in params:
+        if id(p) not in seen:
+            seen.add(id(p))
+            out.append(p)
+    return out
+
+
+class FlatParams(object):
+
+    def __init__(self, critic, actor, device):
+        cp, ap = _unique(critic.parameters()), _unique(actor.parameters())
+        a_ids, c_ids = set(id(p) for p in ap), set(id(p) for p in cp)
+        seg_c = [p for p in cp if id(p) not in a_ids]
+        seg_s = [p for p in cp if id(p) in a_ids]
+        seg_a = [p for p in ap if id(p) not in c_ids]
+        self.sizes = [sum(p.numel() for p in seg) for seg in (seg_c, seg_s, seg_a)]
+        c, s, a = [_pad4(n) for n in self.sizes]
+        self.critic_range = (0, c + s)
+        self.actor_range = (c, c + s + a)
+        self.total = c + s + a
+        self.data = torch.zeros(self.total, device=device)
+        self.grad = torch.zeros(self.total, device=device)
+        self.offset = {}
+        for start, seg in ((0, seg_c), (c, seg_s), (c + s, seg_a)):
+            off = start
+            for p in seg:
+                n = p.numel()
+                self.data[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.data[off:off + n].view(p.shape)
+                p.grad = self.grad[off:off + n].view(p.shape)
+                self.offset[id(p)] = off
+                off += n
+        self.unique_numel = sum(self.sizes)
+
+    def make_target(self, module, target_module, rng):
+        """Re-home ``target_module`` (a deepcopy of ``module``) into a flat buffer laid out like ``data[rng]``."""
+        lo, hi = rng
+        flat = torch.zeros(hi - lo, device=self.data.device)
+        for tp, p in zip(_unique(target_module.parameters()), _unique(module.parameters())):
+            off = self.offset[id(p)] - lo
+            n = p.numel()
+            flat[off:off + n].copy_(tp.data.reshape(-1))
+            tp.data = flat[off:off + n].view(tp.shape)
+            tp.requires_grad_(False)
+        return flat
+
+    def param(self, rng):
+        return self.data[rng[0]:rng[1]]
+
+    def gradient(self, rng):
+        return self.grad[rng[0]:rng[1]]
+
+
+class FusedAdam(object):
+    """clip_grad_norm_(inf) + Adam (+ clamp, + Polyak) on one flat slice: two launches (rpo_absmax, rpo_adam_step)."""
+
+    def __init__(self, backend, param, grad, lr, weight_decay=0.0, clip_thres=0.0, maximize=False, clamp_min0=False,
+                 betas=(0.9, 0.999), eps=1e-8):
+        self.backend, self.param, self.grad = backend, param, grad
+        self.lr, self.weight_decay, self.maximize, self.clamp_min0 = lr, weight_decay, maximize, clamp_min0
+        self.betas, self.eps = betas, eps
+        self.clip_thres = clip_thres
+        dev = param.device
+        self.exp_avg = torch.zeros_like(param)
+        self.exp_avg_sq = torch.zeros_like(param)
+        self.step_dev = torch.zeros(4, dtype=torch.int32, device=dev)       # {step, pad, arrival word}
+        self.gradmax = torch.zeros(1, device=dev)
+
+    def step(self, target=None, tau=0.0):
+        clip = self.clip_thres if self.clip_thres and self.clip_thres != float("inf") else 0.0
+        if clip > 0:
+            self.backend.absmax(self.grad, self.gradmax)
+        self.backend.adam_step(self.param, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr,
+                               self.betas[0], self.betas[1], self.eps, self.weight_decay, self.maximize, clip,
+                               self.gradmax, True, self.clamp_min0, target, tau)
+
+    def state_dict(self):
+        return dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, step=self.step_dev, lr=self.lr)
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_dev.copy_(sd["step"])

@@ -1,0 +1,78 @@
+"""RPO-DDPG on MI355X (reference: rpo/algo/rpo_ddpg.py).  Same constructor, attributes and methods as the reference's
+``RPODDPG``; the loop is vectorised over ``num_envs`` lanes (extra keyword / ``RPO_NUM_ENVS``, default 1)."""
+import torch
+
+from .. import ops as hip_ops
+from .agent import PDDDPG_PA
+from .model import BoxConstraint
+from .trainer import _SALT_ACTOR, RPOTrainerBase, _LagrangianFn, _TDHuberFn
+
+
+class RPODDPG(RPOTrainerBase):
+
+    def __init__(self, env, work_dir, name, logger, max_steps=10, embed_dim=256, hidden_dim=256, hidden_layer=1,
+                 shared_param=True, value_type="add", ex_action_dim=0, lr_actor=1e-4, lr_critic=3e-4, lr_dual=1e-4,
+                 reg=0, eps=0.1, eps_start=1.0, eps_epoch=10000, tau=0.005, gamma=0.95, capacity=10000, warmup=1000,
+                 corr_lr=1e-5, eval_lr=1e-5, corr_mode=0, corr_eps=1e-5, corr_momentum=0.5, batch_size=256,
+                 policy_fre=2, eval_fre=500, max_epochs=100000, grad_eps=1e-3, eval_steps=None, init_lamb=0.0,
+                 init_nju=0.0, fixed=False, clip_thres="inf", partial=False, partial_idx=None,
+                 device=torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu"),
+                 num_envs=None, seed=None, backend=None, use_graph=None):
+        base = getattr(env, "unwrapped", env)
+        agent = PDDDPG_PA(
+            base.state_dim, base.action_dim, base.eq_num, base.ineq_num, embed_dim=embed_dim, hidden_dim=hidden_dim,
+            hidden_layer=hidden_layer, shared_param=shared_param, value_type=value_type, ex_action_dim=ex_action_dim,
+            box_constraint=BoxConstraint(*base.box_constraint_partial, device=device, volatile=base.volatile,
+                                         update=base.update),
+            lr_actor=lr_actor, lr_critic=lr_critic, lr_dual=lr_dual, reg=reg, eps=eps_start, tau=tau, gamma=gamma,
+            capacity=capacity, init_lamb=init_lamb, init_nju=init_nju, partial=partial,
+            partial_idx=base.partial_actions if partial_idx is None else partial_idx, device=device, backend=backend,
+            clip_thres=clip_thres)
+        hp = dict(max_steps=max_steps, corr_lr=corr_lr, eval_lr=eval_lr, corr_eps=corr_eps, corr_momentum=corr_momentum,
+                  corr_mode=corr_mode, grad_eps=grad_eps, clip_thres=clip_thres, eval_steps=eval_steps,
+                  batch_size=batch_size, policy_fre=policy_fre, eval_fre=eval_fre, warmup=warmup, max_epochs=max_epochs,
+                  fixed=fixed, partial=partial, eps=eps, eps_start=eps_start, eps_epoch=eps_epoch)
+        self._setup(env, work_dir, name, logger, agent, hp, device, num_envs, seed, backend, use_graph)
+
+    # ---- rollout policy (rpo_ddpg.py:98-106, agent/ddpg_pa.py:101-112) ----------------------------------------
+    def _policy_partial(self, obs, warm):
+        if warm:
+            return None, hip_ops.NOISE_UNIFORM                      # BoxConstraint.sample, inside the kernel
+        return self.agent.actor(obs).reshape(-1), hip_ops.NOISE_PHILOX   # + eps_t * N(0,1), clip: inside the kernel
+
+    def _eval_partial(self, obs):
+        return self.agent.actor(obs).reshape(-1)
+
+    # ---- losses ---------------------------------------------------------------------------------------------
+    def critic_loss(self, state, action, next_state, done, reward, ineq_viol=None, eq_viol=None):
+        """Huber(Q(s,a), r + gamma (1-d) Q_targ(s', Proj(Complete(pi_targ(s'))))) (rpo_ddpg.py:327-337)."""
+        ag = self.agent
+        with torch.no_grad():
+            next_partial = ag.take_action(next_state, deterministic=True, target=True)
+            next_actions = self.process_action(next_state, next_partial)
+            next_q = ag.critic_target(next_state, next_actions)
+        q = ag.critic(state, action)
+        return _TDHuberFn.apply(self.backend, ag.gamma, 0.0, reward, done, next_q, None, None, q, None)
+
+    def actor_loss(self, state):
+        """mean(-Q(s, Complete(pi(s) + noise)) + nu . relu(g)) (rpo_ddpg.py:307-324); the exploration noise of
+        take_action comes from the Philox stream instead of torch's global generator."""
+        ag = self.agent
+        ap = ag.actor(state)
+        self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * self.batch_size, _SALT_ACTOR,
+                                   hip_ops.STREAM_POLICY, self.vec.ctrl)
+        ap = ag.actor.box_constraint.clip(ap + self._eps_now() * self._noise_b, state)
+        actions = self.base_env.complete_partial(state, ap)
+        loss = (-ag.critic(state, actions)).mean()
+        return loss + _LagrangianFn.apply(self.kernels, actions, ag.nju.weight)
+
+    # ---- optimiser steps (rpo_ddpg.py:178-205) --------------------------------------------------------------
+    def _critic_step(self, actor_step):
+        self.agent.critic_optim.step()
+
+    def _actor_step(self, actor_out):
+        ag = self.agent
+        ag.actor_optim.step()
+        if not self.fixed:
+            ag.nju_optim.step()                                    # lambda is never stepped (rpo_ddpg.py:202)
+        ag.soft_update()                                           # DDPG: only on policy steps (rpo_ddpg.py:205)

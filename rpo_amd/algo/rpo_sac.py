@@ -1,0 +1,98 @@
+"""RPO-SAC on MI355X (reference: rpo/algo/rpo_sac.py): twin critics, squashed-Gaussian actor, entropy term, critic
+Polyak update on every step."""
+import torch
+
+from .. import ops as hip_ops
+from .agent import PDSAC_PA
+from .model import BoxConstraint
+from .trainer import _SALT_ACTOR, _SALT_CRITIC, RPOTrainerBase, _LagrangianFn, _TDHuberFn
+
+
+class RPOSAC(RPOTrainerBase):
+    sac = True
+
+    def __init__(self, env, work_dir, name, logger, automatic_entropy_tuning=True, alpha=0.2, max_steps=10,
+                 embed_dim=256, hidden_dim=256, hidden_layer=1, shared_param=True, value_type="add", ex_action_dim=0,
+                 lr_alpha=1e-4, lr_actor=1e-4, lr_critic=3e-4, lr_dual=1e-4, reg=0, eps=0.1, eps_start=1.0,
+                 eps_epoch=10000, tau=0.005, gamma=0.95, capacity=10000, warmup=1000, corr_lr=1e-5, eval_lr=1e-5,
+                 corr_mode=0, corr_eps=1e-5, corr_momentum=0.5, batch_size=256, policy_fre=2, eval_fre=500,
+                 max_epochs=100000, grad_eps=1e-3, eval_steps=None, init_lamb=0.0, init_nju=0.0, fixed=False,
+                 clip_thres="inf", partial=False, partial_idx=None,
+                 device=torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu"),
+                 num_envs=None, seed=None, backend=None, use_graph=None):
+        base = getattr(env, "unwrapped", env)
+        agent = PDSAC_PA(
+            automatic_entropy_tuning, base.state_dim, base.action_dim, base.eq_num, base.ineq_num,
+            embed_dim=embed_dim, hidden_dim=hidden_dim, hidden_layer=hidden_layer, shared_param=shared_param,
+            value_type=value_type, ex_action_dim=ex_action_dim,
+            box_constraint=BoxConstraint(*base.box_constraint_partial, device=device, volatile=base.volatile,
+                                         update=base.update),
+            alpha=alpha, lr_alpha=lr_alpha, lr_actor=lr_actor, lr_critic=lr_critic, lr_dual=lr_dual, reg=reg,
+            eps=eps_start, tau=tau, gamma=gamma, capacity=capacity, init_lamb=init_lamb, init_nju=init_nju,
+            partial=partial, partial_idx=base.partial_actions if partial_idx is None else partial_idx, device=device,
+            backend=backend, clip_thres=clip_thres)
+        self.automatic_entropy_tuning = automatic_entropy_tuning
+        hp = dict(max_steps=max_steps, corr_lr=corr_lr, eval_lr=eval_lr, corr_eps=corr_eps, corr_momentum=corr_momentum,
+                  corr_mode=corr_mode, grad_eps=grad_eps, clip_thres=clip_thres, eval_steps=eval_steps,
+                  batch_size=batch_size, policy_fre=policy_fre, eval_fre=eval_fre, warmup=warmup, max_epochs=max_epochs,
+                  fixed=fixed, partial=partial, eps=eps, eps_start=eps_start, eps_epoch=eps_epoch)
+        self._setup(env, work_dir, name, logger, agent, hp, device, num_envs, seed, backend, use_graph)
+
+    def _draw(self, buf, id_base, salt):
+        self.backend.philox_normal(buf, self.seed, id_base, salt, hip_ops.STREAM_POLICY, self.vec.ctrl)
+        return buf
+
+    # ---- rollout policy (rpo_sac.py:102-110, agent/sac_pa.py:105-115) -------------------------------------------
+    def _policy_partial(self, obs, warm):
+        if warm:
+            return None, hip_ops.NOISE_UNIFORM
+        eps = self._draw(self._noise_n, self.vec.env_id_base, 0)
+        ap, _, _ = self.agent.actor(obs, eps=eps)                   # rsample of the squashed Gaussian
+        return ap.reshape(-1), hip_ops.NOISE_CLIP_ONLY              # the box clip happens inside the kernel
+
+    def _eval_partial(self, obs):
+        return self.agent.actor(obs)[2].reshape(-1)                 # the mean action (deterministic=True)
+
+    # ---- losses ---------------------------------------------------------------------------------------------
+    def critic_loss(self, state, action, next_state, done, reward, ineq_viol=None, eq_viol=None):
+        """y = r + gamma (1-d) (min Q_targ(s', a') - alpha log pi(a'|s')), a' ~ pi(s') projected; loss = sum of the
+        two Huber terms (rpo_sac.py:342-353)."""
+        ag = self.agent
+        with torch.no_grad():
+            eps = self._draw(self._noise_b, self.dist.rank * self.batch_size, _SALT_CRITIC)
+            next_partial, logp = ag.take_action(next_state, log_pi=True, eps=eps)
+            next_actions = self.process_action(next_state, next_partial)
+            nq1, nq2 = ag.critic_target(next_state, next_actions)
+        q1, q2 = ag.critic(state, action)
+        return _TDHuberFn.apply(self.backend, ag.gamma, float(ag.alpha), reward, done, nq1, nq2, logp, q1, q2)
+
+    def actor_loss(self, state):
+        """mean(alpha log pi - min Q(s, Complete(a)) + nu . relu(g)) (rpo_sac.py:321-339) -> (loss, log_pi)."""
+        ag = self.agent
+        eps = self._draw(self._noise_b, self.dist.rank * self.batch_size, _SALT_ACTOR)
+        ap, logp = ag.take_action(state, log_pi=True, eps=eps)
+        actions = self.base_env.complete_partial(state, ap)
+        q1, q2 = ag.critic(state, actions)
+        loss = (ag.alpha * logp - torch.min(q1, q2)).mean()
+        return loss + _LagrangianFn.apply(self.kernels, actions, ag.nju.weight), logp
+
+    # ---- optimiser steps (rpo_sac.py:181-219) ---------------------------------------------------------------
+    def _critic_step(self, actor_step):
+        ag = self.agent
+        ag.critic_optim.step()
+        if not actor_step:
+            ag.soft_update()                                        # every step (rpo_sac.py:219)
+
+    def _actor_step(self, actor_out):
+        ag = self.agent
+        ag.actor_optim.step()
+        if not self.fixed:
+            ag.nju_optim.step()
+        if self.automatic_entropy_tuning:
+            _, logp = actor_out
+            alpha_loss = -(ag.log_alpha * (logp + ag.target_entropy).detach()).mean()   # rpo_sac.py:210-216
+            ag.alpha_optim.zero_grad()
+            alpha_loss.backward()
+            ag.alpha_optim.step()
+            self.alpha = ag.log_alpha.exp()
+        ag.soft_update()

@@ -1,0 +1,433 @@
+"""Vectorised RPO trainer core shared by ``RPODDPG`` and ``RPOSAC`` (reference: rpo/algo/rpo_ddpg.py, rpo_sac.py).
+
+One loop iteration = one *vector* step: N env instances act, are projected onto their constraints, stepped and
+scattered into the replay ring by three launches (actor MLP -> ``*_act_project`` -> ``*_step``), followed -- at the
+reference's cadence -- by one constrained policy update on a batch of ``batch_size`` sampled transitions
+(rpo_ddpg.py:91-161).  Nothing in an iteration synchronises with the host: the step counter, ring position, RNG
+counters and Adam steps live in device memory, so a whole iteration is captured once into a hipGraph and replayed.
+With ``num_envs == 1`` the loop is the reference's algorithm step for step.
+
+Data parallelism (``torch.distributed`` initialised, backend nccl == RCCL): rank r owns env ids
+``[r * n_local, (r + 1) * n_local)`` and its own replay shard; the flat gradient slice of each optimiser is
+all-reduced (mean) once per update, so replicas stay bit-identical without parameter broadcasts.
+"""
+import copy
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import ops as hip_ops
+from .model import BoxConstraint
+
+_SALT_CRITIC = 1 << 20      # Philox index offsets that separate the update step's draws from the rollout's
+_SALT_ACTOR = 2 << 20
+
+
+# ------------------------------------------------------------------------------------------------ autograd bridges
+class _TDHuberFn(torch.autograd.Function):
+    """TD target + Huber loss, forward and backward in one HIP launch (rpo_td_huber)."""
+
+    @staticmethod
+    def forward(ctx, backend, gamma, alpha, reward, done, qn1, qn2, logp, q1, q2):
+        n = q1.shape[0]
+        loss = torch.zeros(1, device=q1.device)
+        g1 = torch.empty(n, device=q1.device)
+        g2 = torch.empty(n, device=q1.device) if q2 is not None else None
+        flat = lambda x: None if x is None else x.reshape(-1).contiguous()   # noqa: E731
+        backend.td_huber(flat(q1), flat(q2), flat(qn1), flat(qn2), flat(logp), alpha, reward, done, gamma, loss, g1, g2)
+        ctx.save_for_backward(g1, g2)
+        ctx.shape = q1.shape
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g1, g2 = ctx.saved_tensors
+        return (None,) * 8 + (grad_out * g1.view(ctx.shape), None if g2 is None else grad_out * g2.view(ctx.shape))
+
+
+class _LagrangianFn(torch.autograd.Function):
+    """mean_b nu . relu(g(a_b)): loss, d/da and d/dnu from one HIP launch (rpo_*_lagrangian)."""
+
+    @staticmethod
+    def forward(ctx, kernels, action, nu):
+        n = action.shape[0]
+        loss = torch.zeros(1, device=action.device)
+        g_a = torch.empty_like(action)
+        g_nu = torch.zeros(nu.numel(), device=action.device)
+        kernels.lagrangian(action.contiguous(), nu.reshape(-1).contiguous(), 1.0 / n, loss, g_a, g_nu)
+        ctx.save_for_backward(g_a, g_nu)
+        ctx.nu_shape = nu.shape
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g_a, g_nu = ctx.saved_tensors
+        return None, grad_out * g_a, grad_out * g_nu.view(ctx.nu_shape)
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+class _Dist(object):
+    def __init__(self):
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.rank = dist.get_rank() if self.on else 0
+        self.world = dist.get_world_size() if self.on else 1
+
+    def mean_(self, tensors):
+        """In-place all-reduce(mean) of a list of flat gradient buffers: ONE collective per tensor (1-2 per update)."""
+        if not self.on:
+            return
+        for t in tensors:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t.mul_(1.0 / self.world)
+
+    def sum_(self, t):
+        if self.on:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+
+class _GraphCache(object):
+    """Eager for the first ``warm`` calls of a key (on a side stream, as hipGraph capture of autograd wants), then
+    captured once and replayed.  Every call performs the work exactly once."""
+
+    def __init__(self, enabled, warm=3):
+        self.enabled, self.warm = enabled, warm
+        self.entries = {}
+        self.side = None
+
+    def run(self, key, fn):
+        if not self.enabled:
+            return fn()
+        e = self.entries.setdefault(key, {"count": 0, "graph": None})
+        if e["graph"] is not None:
+            e["graph"].replay()
+            return
+        if e["count"] < self.warm:
+            e["count"] += 1
+            if self.side is None:
+                self.side = torch.cuda.Stream()
+            cur = torch.cuda.current_stream()
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                fn()
+            cur.wait_stream(self.side)
+            return
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        e["graph"] = g
+        g.replay()
+
+
+def _env_int(name, default):
+    v = os.environ.get(name)
+    return default if v in (None, "") else int(v)
+
+
+# ------------------------------------------------------------------------------------------------ trainer core
+class RPOTrainerBase(object):
+    """Everything except agent construction and the two losses."""
+
+    sac = False
+
+    def _setup(self, env, work_dir, name, logger, agent, hp, device, num_envs=None, seed=None, backend=None,
+               use_graph=None):
+        self.env, self.agent, self.device = env, agent, device
+        self.work_dir, self.name, self.logger = work_dir, name, logger
+        for k, v in hp.items():
+            setattr(self, k, v)
+        if self.eval_steps is None:
+            self.eval_steps = self.max_steps
+        self.backend = backend if backend is not None else hip_ops
+        self.base_env = getattr(env, "unwrapped", env)
+        self.kernels = self.base_env.kernels
+        self.env_eval = copy.deepcopy(self.env)                          # rpo_ddpg.py:61
+        self.box_constraint = BoxConstraint(*self.base_env.box_constraint, device=device)
+        self.decay_value = (hp["eps_start"] - hp["eps"]) / hp["eps_epoch"]   # rpo_ddpg.py:70
+        self.dist = _Dist()
+        n_total = int(num_envs) if num_envs is not None else _env_int("RPO_NUM_ENVS", 1)
+        if n_total % self.dist.world:
+            raise ValueError("num_envs (%d) must be divisible by the world size (%d)" % (n_total, self.dist.world))
+        self.num_envs, self.n_local = n_total, n_total // self.dist.world
+        if seed is None:
+            seed = _env_int("RPO_SEED", None)
+        if seed is None:
+            # drawn from torch's global generator AFTER the networks were initialised, so that the initial weights
+            # match the reference for the same torch.manual_seed and the Philox streams still depend on that seed
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self.seed = int(seed)
+        self.max_episode_steps = getattr(env, "_max_episode_steps", None)
+        self.vec = self.base_env.make_vec(self.n_local, seed=self.seed, env_id_base=self.dist.rank * self.n_local,
+                                          max_episode_steps=self.max_episode_steps, device=device)
+        self.buffer = agent.attach_env(self.kernels, self.n_local, self.seed + 7919 * (self.dist.rank + 1), self.vec.ctrl)
+        self._batch = torch.zeros(self.batch_size, self.kernels.row_floats, device=device)
+        self._noise_b = torch.zeros(self.batch_size, 1, device=device)
+        self._noise_n = torch.zeros(self.n_local, 1, device=device)
+        self._box_lo, self._box_hi = self.base_env.partial_box
+        if use_graph is None:
+            use_graph = bool(_env_int("RPO_GRAPH", 1)) and device.type == "cuda"
+        self._graphs = _GraphCache(use_graph)
+        # projection of training batches: the reference's literal batched semantics (default) or row-wise
+        # (RPO_ROWWISE_PROJECTION=1); rollouts are always per lane == the reference's B = 1 calls
+        self.batch_reference = not bool(_env_int("RPO_ROWWISE_PROJECTION", 0))
+        self._t = 0                 # loop iterations (== vector steps) done
+        self._harvested = 0         # vector steps whose statistics were already pulled off the device
+        self._pending = []          # per-step rows waiting for the return of the episodes they belong to
+        self._vec_eval = None
+        self.last_losses = {}
+        self.viol_steps, self.env_steps, self.viol_rate, self.proj_iters_mean = 0.0, 0.0, 0.0, 0.0
+
+    # ------------------------------------------------------------------------------------------ projection API
+    def process_action(self, state, action_partial, train=True):
+        """Equation solver + GRG projection (rpo_ddpg.py:72-77), one fused launch."""
+        ref = self.batch_reference
+        if train:
+            return self.base_env.project(state, action_partial, self.max_steps, self.corr_lr, self.corr_eps,
+                                         self.corr_momentum, batch_reference=ref)
+        action, iters = self.base_env.project(state, action_partial, self.eval_steps, self.eval_lr, self.corr_eps,
+                                              self.corr_momentum, return_iters=True, batch_reference=ref)
+        return action, int(iters.max())
+
+    def grad_steps(self, state, action, train=True):
+        """GRG loop on an action that already satisfies the equalities (rpo_ddpg.py:266-305, corr_mode 0).  The fused
+        kernel restarts from the action's basic components, which reproduces the reference whenever the input lies on
+        the equality manifold -- the only way the reference ever calls it (rpo_ddpg.py:74-75)."""
+        if self.corr_mode != 0:
+            raise NotImplementedError("corr_mode=1 (Lagrangian direction, rpo_ddpg.py:276-278) is unused by every script")
+        idx = torch.as_tensor(np.asarray(self.base_env.partial_actions), device=self.device)
+        return self.process_action(state, torch.as_tensor(action, device=self.device)[:, idx], train=train)
+
+    # ------------------------------------------------------------------------------------------ rollout
+    def _policy_partial(self, obs, warm):
+        """Basic action proposed for every lane + the noise mode the projection kernel must apply."""
+        raise NotImplementedError
+
+    def _rollout(self, warm):
+        v = self.vec
+        with torch.no_grad():
+            ap, mode = self._policy_partial(v.obs, warm)
+            self.kernels.act_project(v.obs, ap, None, v.action, None, mode, self.eps_start, self.eps, self.decay_value,
+                                     self._box_lo, self._box_hi, self.max_steps, self.corr_lr, self.corr_eps,
+                                     self.corr_momentum, self.seed, v.env_id_base, v.ctrl, v.stats)
+            v.step(v.action, rows=self.buffer.rows, cap_steps=self.buffer.capacity, auto_reset=True)
+
+    # ------------------------------------------------------------------------------------------ update
+    def _sample(self):
+        self.buffer.sample_rows(self.batch_size, out=self._batch)
+        c = self.buffer.split(self._batch)
+        return c["state"], c["action"], c["next_state"], c["reward"], c["done"], c["ineq_viol"], c["eq_viol"]
+
+    def _eps_now(self):
+        """Exploration scale inside the update (take_action in actor_loss, rpo_ddpg.py:309).  Constant in every script
+        (eps == eps_start); computed from the device step counter when it decays so that graph replays stay exact."""
+        if self.decay_value == 0:
+            return self.eps_start
+        t = self.vec.ctrl[0].to(torch.float32)
+        return torch.clamp(self.eps_start - self.decay_value * t, min=self.eps)
+
+    def _critic_update(self, cols):
+        state, action, next_state, reward, done, ineq_viol, eq_viol = cols
+        loss = self.critic_loss(state, action, next_state, done, reward, ineq_viol, eq_viol)
+        self.agent.flat.grad.zero_()
+        loss.backward()
+        self.last_losses["critic"] = loss.detach()
+
+    def _actor_update(self, cols):
+        out = self.actor_loss(cols[0])
+        loss = out[0] if isinstance(out, tuple) else out
+        self.agent.flat.grad.zero_()
+        self.agent.nju.weight.grad.zero_()
+        self.agent.lamb.weight.grad.zero_()
+        loss.backward()
+        self.last_losses["actor"] = loss.detach()
+        return out
+
+    def _segments(self, warm, do_train, actor_step):
+        """The iteration as a list of (device work, gradient buffers to all-reduce afterwards)."""
+        ag, fl = self.agent, self.agent.flat
+        segs = []
+        if not do_train:
+            return [(lambda: self._rollout(warm), [])]
+        box = {}
+
+        def s1():
+            self._rollout(warm)
+            box["cols"] = self._sample()
+            self._critic_update(box["cols"])
+        segs.append((s1, [fl.gradient(fl.critic_range)]))
+        if actor_step:
+            def s2():
+                self._critic_step(actor_step)
+                box["actor_out"] = self._actor_update(box["cols"])
+            segs.append((s2, [fl.gradient(fl.actor_range), ag.nju.weight.grad]))
+
+            def s3():
+                self._actor_step(box["actor_out"])
+            segs.append((s3, []))
+        else:
+            segs.append((lambda: self._critic_step(actor_step), []))
+        return segs
+
+    def _critic_step(self, actor_step):
+        raise NotImplementedError
+
+    def _actor_step(self, actor_out):
+        raise NotImplementedError
+
+    def _iteration(self, warm, do_train, actor_step):
+        segs = self._segments(warm, do_train, actor_step)
+        if not self.dist.on:
+            self._graphs.run((warm, do_train, actor_step), lambda: [fn() for fn, _ in segs])
+            return
+        for i, (fn, reduce_after) in enumerate(segs):      # collectives stay eager between captured segments
+            self._graphs.run((warm, do_train, actor_step, i), fn)
+            self.dist.mean_(reduce_after)
+
+    def train(self, t):
+        """One constrained policy update at loop index ``t`` (rpo_ddpg.py:163-205), eagerly, without a rollout."""
+        cols = self._sample()
+        self._critic_update(cols)
+        fl = self.agent.flat
+        self.dist.mean_([fl.gradient(fl.critic_range)])
+        actor_step = t % self.policy_fre == 0
+        self._critic_step(actor_step)
+        if actor_step:
+            out = self._actor_update(cols)
+            self.dist.mean_([fl.gradient(fl.actor_range), self.agent.nju.weight.grad])
+            self._actor_step(out)
+
+    # ------------------------------------------------------------------------------------------ main loop
+    def run(self, logger=None, eval=True):
+        """rpo_ddpg.py:79-161 over vector steps.  ``max_epochs`` counts loop iterations exactly like the reference;
+        each one advances all ``num_envs`` lanes."""
+        if logger is not None:
+            self.logger = logger
+        if self._t == 0:
+            self.vec.reset()
+        self.run_steps(self.max_epochs - self._t, eval=eval)
+        self._harvest(final=True)
+
+    def run_steps(self, n, eval=False):
+        for _ in range(int(n)):
+            t = self._t
+            warm = t < self.warmup
+            do_train = (t + 1) >= self.warmup
+            actor_step = do_train and (t + 1) % self.policy_fre == 0
+            self._iteration(warm, do_train, actor_step)
+            self._t = t = t + 1
+            self.buffer.note_step()
+            self.vec.steps_host = t
+            self.agent.eps_decay(self.decay_value, self.eps)              # host mirror of the device-side schedule
+            if t - self._harvested >= self.vec.stats.shape[0] // 2:
+                self._harvest()
+            if eval and t % self.eval_fre == 0 and t > self.warmup:
+                self._harvest()
+                self._print_eval(t, self.eval())
+
+    # ------------------------------------------------------------------------------------------ statistics
+    def _harvest(self, final=False):
+        """Pull the per-vector-step statistics rows written by the step kernel and turn them into Logger rows:
+        ``epoch`` = vector step, ``max_ineq`` / ``max_eq`` = mean over lanes of the per-lane maxima
+        (rpo_ddpg.py:120-123), ``reward`` = mean return of the episodes the step belongs to, back-filled when they
+        finish (rpo_ddpg.py:135-137; identical to the reference for one lane)."""
+        lo, hi = self._harvested, self._t
+        if hi <= lo:
+            return
+        cap = self.vec.stats.shape[0]
+        idx = torch.arange(lo, hi, device=self.device) % cap
+        rows = self.vec.stats[idx].clone()
+        if self.dist.on:                                                # sums add up over ranks, maxima take the max
+            mx = rows.clone()
+            dist.all_reduce(rows, op=dist.ReduceOp.SUM)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            for k in ("max_ineq_max", "max_eq_max"):
+                rows[:, hip_ops.STAT[k]] = mx[:, hip_ops.STAT[k]]
+        rows = rows.cpu().numpy().astype(np.float64)
+        S = hip_ops.STAT
+        n = float(self.num_envs)
+        for i, r in enumerate(rows):
+            self._pending.append([lo + i, r[S["max_ineq_sum"]] / n, r[S["max_eq_sum"]] / n])
+            if r[S["episodes"]] > 0:
+                ret = r[S["return_sum"]] / r[S["episodes"]]
+                length = r[S["length_sum"]] / r[S["episodes"]]
+                if self.logger is not None:
+                    try:
+                        for ep, mi, me in self._pending:
+                            self.logger.add(epoch=ep, reward=ret, max_ineq=mi, max_eq=me)
+                    except StopIteration:
+                        pass
+                if self.dist.rank == 0 and _env_int("RPO_VERBOSE", 1):
+                    worst = max(p[1] for p in self._pending), max(p[2] for p in self._pending)
+                    print("episode %d ends. reward: %s, step: %s, ineq_viol: %s, eq_viol: %s"
+                          % (lo + i + 1, ret, length, worst[0], worst[1]))
+                self._pending = []
+        # constraint-violation rate: fraction of env steps with max(max_ineq, max_eq) > 1e-3
+        self.viol_steps += rows[:, S["viol_count"]].sum()
+        self.env_steps += n * (hi - lo)
+        self.viol_rate = self.viol_steps / self.env_steps
+        self.proj_iters_mean = rows[:, S["proj_iters"]].sum() / (n * (hi - lo))
+        self._harvested = hi
+
+    # ------------------------------------------------------------------------------------------ evaluation
+    def _eval_partial(self, obs):
+        raise NotImplementedError
+
+    def eval(self, rendering=False):
+        """10 evaluation episodes of at most 500 steps with the deterministic policy and ``eval_steps`` projection
+        iterations (rpo_ddpg.py:207-264), run as 10 parallel lanes.  Returns the reference's 10-tuple."""
+        lanes, horizon = 10, 500
+        if self._vec_eval is None:
+            self._vec_eval = self.base_env.make_vec(lanes, seed=self.seed ^ 0x5EED5EED, env_id_base=0,
+                                                    max_episode_steps=self.max_episode_steps, device=self.device,
+                                                    stats_cap=2)
+            self._eval_rows = torch.zeros(lanes, self.kernels.row_floats, device=self.device)
+        v, c = self._vec_eval, self.kernels.cols
+        v.ep_count += 1                                                 # fresh initial states at every evaluation
+        v.reset()
+        alive = torch.ones(lanes, device=self.device)
+        total = torch.zeros(lanes, device=self.device)
+        mean_ineq, mean_eq, max_ineq, max_eq = [torch.zeros(lanes, device=self.device) for _ in range(4)]
+        if self.max_episode_steps:
+            horizon = min(horizon, int(self.max_episode_steps))
+        with torch.no_grad():
+            for i in range(horizon):
+                ap = self._eval_partial(v.obs)
+                self.kernels.act_project(v.obs, ap, None, v.action, None, hip_ops.NOISE_NONE, 0.0, 0.0, 0.0, self._box_lo,
+                                         self._box_hi, self.eval_steps, self.eval_lr, self.corr_eps, self.corr_momentum)
+                v.ctrl.zero_()
+                v.step(v.action, rows=self._eval_rows, cap_steps=1, auto_reset=False)
+                row = self._eval_rows
+                ineq = row[:, c["ineq_viol"][0]:c["ineq_viol"][1]].max(dim=1).values
+                eq = row[:, c["eq_viol"][0]:c["eq_viol"][1]].abs().max(dim=1).values
+                total += alive * row[:, c["reward"][0]]
+                mean_ineq += alive * (ineq - mean_ineq) / (i + 1)
+                mean_eq += alive * (eq - mean_eq) / (i + 1)
+                max_ineq = torch.where(alive > 0, torch.maximum(max_ineq, ineq), max_ineq)
+                max_eq = torch.where(alive > 0, torch.maximum(max_eq, eq), max_eq)
+                alive = alive * (1 - row[:, c["done"][0]])
+        out = []
+        for x in (total, mean_ineq, mean_eq, max_ineq, max_eq):
+            x = x.cpu().numpy().astype(np.float64)
+            out += [x.mean(), x.std()]
+        return tuple(out)
+
+    def _print_eval(self, t, res):
+        if self.dist.rank != 0 or not _env_int("RPO_VERBOSE", 1):
+            return
+        rmean, rstd, ineqmean, ineqstd, eqmean, eqstd, maxineqmean, maxineqstd, maxeqmean, maxeqstd = res
+        print("\n============================")
+        print(f"Eval: epoch {t}, rewards: {rmean:.4f}({rstd:.4f}), mean_ineq_viol: {ineqmean:.4f}({ineqstd:.4f}),"
+              f" mean_eq_viol: {eqmean:.4f}({eqstd:.4f}), max_ineq_viol: {maxineqmean:.4f}({maxineqstd:.4f})"
+              f" max_eq_viol: {maxeqmean:.4f}({maxeqstd:.4f})")
+        print(f"lambda: {self.agent.lamb}, nju: {self.agent.nju}")
+        print("============================\n")
+
+    # ------------------------------------------------------------------------------------------ checkpoints
+    def load(self):
+        self.agent.load_model(self.work_dir)
+
+    def save(self):
+        os.makedirs(self.work_dir, exist_ok=True)
+        self.agent.save_model(self.work_dir)

@@ -139,9 +139,29 @@ __global__ __launch_bounds__(RPO_BLOCK) void philox_fill_kernel(int n, uint32_t*
     }
 }
 
+__global__ __launch_bounds__(RPO_BLOCK) void philox_normal_kernel(int n, float* __restrict__ out, uint64_t seed,
+                                                                  uint32_t id_base, uint32_t salt, uint32_t tag,
+                                                                  const long long* __restrict__ ctrl) {
+    const uint32_t t = ctrl ? (uint32_t)ctrl[RPO_CTRL_T] : 0u;
+    for (int i = blockIdx.x * RPO_BLOCK + threadIdx.x; i < n; i += gridDim.x * RPO_BLOCK) {
+        const rpo_u4 r = rpo_philox(seed, id_base + (uint32_t)i, t + salt, tag);
+        out[i] = rpo_normal(r.x, r.y);
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int rpo_philox_normal(int n, float* out, unsigned long long seed, unsigned id_base, unsigned salt,
+                      unsigned stream_tag, const long long* ctrl, void* stream) {
+    if (n <= 0) return RPO_ERR_ARG;
+    if (!out) return RPO_ERR_NULL;
+    hipLaunchKernelGGL(philox_normal_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, out,
+                       (uint64_t)seed, (uint32_t)id_base, (uint32_t)salt, (uint32_t)stream_tag, ctrl);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
 
 int rpo_abi_version(void) { return RPO_ABI_VERSION; }
 

@@ -1,0 +1,71 @@
+"""SpringPendulum-v0: a pendulum on a spring driven by a planar force (fx, fy); 1 state-dependent linear equality
+(the radial speed must be annihilated: l_dot' = 0) and 1 quadratic inequality |f|^2 <= 32 (reference:
+rpo/env/classic_control/pendulum.py).  All arithmetic runs in rpo_amd/csrc/pendulum.hip.
+
+Internal state (theta, theta_dot, l, l_dot); observation (cos theta, sin theta, theta_dot, l, l_dot).
+"""
+import numpy as np
+import torch
+
+from ..base import HardConstraintEnv, gym
+
+spaces = gym.spaces
+
+
+class SpringPendulumEnv(HardConstraintEnv):
+    metadata = {"render_modes": ["human", "rgb_array"], "render_fps": 30}
+
+    def __init__(self, g=10.0, backend=None):
+        super().__init__(backend)
+        if g != 10.0:
+            raise NotImplementedError("the HIP kernels are specialised for the registered g = 10 (pendulum.py:15)")
+        self.max_speed, self.max_torque, self.max_summation = 8.0, 6.0, 32.0
+        self.dt, self.g, self.m, self.k, self.l0 = 0.05, g, 0.5, 1.0, 1.0
+        self.m_dt = self.m / self.dt
+        high = np.array([1.0, 1.0, self.max_speed, 1.5, 0.05], dtype=np.float32)
+        low = np.array([-1.0, -1.0, -self.max_speed, 0.5, -0.05], dtype=np.float32)
+        action_high = self.max_torque * np.array([1.0, 1.0], dtype=np.float32)
+        self.action_space = spaces.Box(low=-action_high, high=action_high, shape=(2,), dtype=np.float32)
+        self.observation_space = spaces.Box(low=low, high=high, dtype=np.float32)
+        self.state_dim, self.action_dim, self.eq_num, self.ineq_num = 5, 2, 1, 1
+        self.fx_idx, self.fy_idx = 0, 1
+        self.idx_cos, self.idx_sin, self.idx_thdot, self.idx_l, self.idx_ldot = range(5)
+        self.seed()
+        self.partial_actions = np.array([0])                                  # pendulum.py:48
+        self.other_actions = np.array([1])
+        self.diff_ineq_bias = torch.tensor([self.max_summation], dtype=torch.float32, device=self.device)
+        self.state = None
+        self.counter = None
+
+    def _make_kernels(self):
+        return self._backend.PendulumKernels()
+
+    def _draw_initial(self):
+        high = np.array([np.pi / 12, 1.0, 1.05, 0.05], dtype=np.float32)      # pendulum.py:131-133
+        low = np.array([-np.pi / 12, -1.0, 0.95, -0.05], dtype=np.float32)
+        self.counter = 0
+        return self.np_random.uniform(low=low, high=high)
+
+    def _get_obs(self):
+        theta, thetadot, l, ldot = self.state
+        return np.array([np.cos(theta), np.sin(theta), thetadot, l, ldot])
+
+    def _resid_backward(self, obs, action, grad_eq, grad_ineq):
+        # eq = b(s) - (a_x sin + a_y cos) ; ineq = |a|^2 - 32
+        C = torch.stack([obs[:, self.idx_sin], obs[:, self.idx_cos]], dim=1)
+        return grad_ineq * 2 * action - grad_eq * C
+
+    def eq_grad(self, state, action):
+        state, action = self._t(state), self._t(action)
+        C = torch.stack([state[:, self.idx_sin], state[:, self.idx_cos]], dim=1)
+        return -2 * self.eq_resid(state, action) * C                          # row-wise form of pendulum.py:323-324
+
+    def ineq_grad(self, state, action):
+        action = self._t(action)
+        return 2 * (2 * action) * self.ineq_dist(state, action)               # row-wise form of pendulum.py:326-329
+
+    def ineq_dist_np(self, state, action):
+        return self.ineq_dist(self._t(state).view(1, -1), self._t(action).view(1, -1)).detach().cpu().numpy()
+
+    def eq_resid_np(self, state, action):
+        return self.eq_resid(self._t(state).view(1, -1), self._t(action).view(1, -1)).detach().cpu().numpy()

@@ -17,6 +17,7 @@ NOISE_EXPLICIT = CONST["RPO_NOISE_EXPLICIT"]
 NOISE_PHILOX = CONST["RPO_NOISE_PHILOX"]
 NOISE_UNIFORM = CONST["RPO_NOISE_UNIFORM"]
 NOISE_CLIP_ONLY = CONST["RPO_NOISE_CLIP_ONLY"]
+STREAM_POLICY = CONST["RPO_STREAM_POLICY"]
 STATS_LEN = CONST["RPO_STATS_LEN"]
 CTRL_LEN = CONST["RPO_CTRL_LEN"]
 STAT = {k[len("RPO_STAT_"):].lower(): v for k, v in CONST.items() if k.startswith("RPO_STAT_") and k != "RPO_STATS_LEN"}
@@ -56,9 +57,8 @@ def _col_view(t):
     return _p(t, contiguous=False), int(t.stride(0))
 
 
-def _host_consts(arr):
-    a = np.ascontiguousarray(arr, dtype=np.float32)
-    return a, a.ctypes.data_as(ctypes.c_void_p)
+def _host_ptr(arr):
+    return arr.ctypes.data_as(ctypes.c_void_p)
 
 
 # =================================================================================================== shared kernels
@@ -66,6 +66,11 @@ def _host_consts(arr):
 def philox_fill(out, seed, id_base, index, stream_tag):
     check(_lib.load().rpo_philox_fill(out.shape[0], _p(out, torch.int32), seed, id_base, index, stream_tag, _stream()),
           "rpo_philox_fill")
+
+
+def philox_normal(out, seed, id_base, salt, stream_tag, ctrl=None):
+    check(_lib.load().rpo_philox_normal(out.numel(), _p(out), seed, id_base, salt, stream_tag,
+                                        _p(ctrl, torch.int64, allow_none=True), _stream()), "rpo_philox_normal")
 
 
 def replay_gather(rows, idx, out):
@@ -119,10 +124,14 @@ class CartSafeKernels(object):
                 ineq_viol=(17, 23))
 
     def __init__(self, consts, partial):
-        self.consts, self._cptr = _host_consts(consts)
+        self.consts = np.ascontiguousarray(consts, dtype=np.float32)     # host table, copied into each launch
         if self.consts.shape != (CONST["RPO_CART_CONSTS_LEN"],):
             raise RpoHipError("bad CartSafe constant table")
         self.partial = int(partial)
+
+    @property
+    def _cptr(self):
+        return _host_ptr(self.consts)
 
     def reset(self, internal, obs, ep_len, ep_ret, ep_count, seed, env_id_base):
         # the observation IS the internal state for this env: `obs` aliases `internal`
@@ -198,6 +207,13 @@ class PendulumKernels(object):
             max_steps, corr_lr, corr_eps, corr_momentum, seed, env_id_base, _p(ctrl, torch.int64, allow_none=True),
             _p(stats, allow_none=True), 0 if stats is None else stats.shape[0], _stream()),
             "rpo_pendulum_act_project")
+
+    def project_batchref(self, obs, ap, action, iters_out, max_steps, corr_lr, corr_eps, corr_momentum):
+        op, ostride = _row_view(obs, 5)
+        check(_lib.load().rpo_pendulum_project_batchref(action.shape[0], op, ostride, _p(ap), _p(action),
+                                                        _p(iters_out, torch.int32, allow_none=True), max_steps, corr_lr,
+                                                        corr_eps, corr_momentum, _stream()),
+              "rpo_pendulum_project_batchref")
 
     def complete_bwd(self, obs, grad_action, grad_ap):
         op, ostride = _row_view(obs, 5)

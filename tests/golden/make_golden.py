@@ -217,8 +217,112 @@ def gen_pendulum():
     save("pendulum_grad_steps", **gs)
 
 
+# ---------------------------------------------------------------------------------------------- full update steps
+
+SCRIPT_HP = {   # scripts/cart_exp.py:26-28, cart_exp_sac.py:26-29, pen_exp.py:26-29, pen_exp_sac.py:26-29
+    ("ddpg", "cart"): dict(lr_dual=0.2, corr_lr=2e-2, eps=1.0, eps_start=1.0, eval_lr=2e-2, shared_param=True),
+    ("sac", "cart"): dict(lr_dual=0.2, corr_lr=2e-2, eps=5e-3, eps_start=5e-3, eval_lr=2e-2, shared_param=False,
+                          alpha=0.1, automatic_entropy_tuning=False),
+    ("ddpg", "pendulum"): dict(lr_dual=0.01, corr_lr=2e-3, eps=0.5, eps_start=0.5, eval_lr=2e-3, shared_param=False),
+    ("sac", "pendulum"): dict(lr_dual=0.01, corr_lr=2e-3, eps=1e-2, eps_start=1e-2, eval_lr=2e-3, shared_param=False,
+                              alpha=0.01, automatic_entropy_tuning=False),
+}
+
+
+def gen_train_steps():
+    """RPODDPG.train / RPOSAC.train (rpo_ddpg.py:163-205, rpo_sac.py:167-219) for t = 1..4 on a fixed buffer with every
+    random draw recorded: np.random.randint of ReplayBuffer.sample, torch.randn_like of take_action,
+    _standard_normal of Normal.rsample."""
+    import torch.distributions.normal as tdn
+    for (algo, envname), hp in SCRIPT_HP.items():
+        torch.manual_seed(123)
+        np.random.seed(123)
+        env = make_cart_env(1) if envname == "cart" else REF.SpringPendulumEnv()
+        cls = REF.RPODDPG if algo == "ddpg" else REF.RPOSAC
+        logger = REF.Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=10)
+        tr = cls(env, "/tmp", name="g", logger=logger, batch_size=256, max_steps=10, warmup=0, eps_epoch=20000,
+                 eval_steps=50, grad_eps=0.1, corr_momentum=0.0, policy_fre=4, max_epochs=10, capacity=512,
+                 value_type="add", clip_thres=0.2, embed_dim=128, hidden_dim=256, lr_actor=1e-4, lr_critic=3e-4,
+                 device=torch.device("cpu"), **hp)
+        out = {"actor0." + k: v.numpy().copy() for k, v in tr.agent.actor.state_dict().items()}
+        out.update({"critic0." + k: v.numpy().copy() for k, v in tr.agent.critic.state_dict().items()})
+        # a buffer of 400 plausible transitions: reference env stepped with projected random basic actions
+        n = 400
+        trans = {k: [] for k in ("state", "action", "next_state", "reward", "done", "eq_viol", "ineq_viol")}
+        genv = REF.gym.make("CartSafe-v0" if envname == "cart" else "SpringPendulum-v0")
+        if envname == "cart":
+            genv.env.partial_actions, genv.env.other_actions = env.partial_actions, env.other_actions
+            for name in ("diff_eq_partial", "diff_eq_other_inv", "diff_eq_partial_np", "diff_eq_other_inv_np"):
+                setattr(genv.env, name, getattr(env, name))
+        genv.seed(7)
+        s = genv.reset()
+        lo, hi = env.box_constraint_partial
+        for i in range(n):
+            ap = t32(RNG.uniform(lo[0] * 1.0, hi[0] * 1.0, size=(1, 1)))
+            st = t32(s[None, :])
+            a = tr.process_action(st, ap).numpy()[0]
+            s2, r, d, info = genv.step(a)
+            for k, v in zip(trans, (s, a, s2, r, d, info["eq_viol"].reshape(-1), info["ineq_viol"].reshape(-1))):
+                trans[k].append(np.asarray(v, dtype=np.float64 if k in ("state", "next_state") else np.float32))
+            tr.agent.add(s, a, s2, r, d, info["eq_viol"].reshape(-1), info["ineq_viol"].reshape(-1))
+            s = genv.reset() if d else s2
+        out.update({"buf." + k: np.stack(v) for k, v in trans.items()})
+        # record / replay the random draws
+        draws = {"idx": [], "noise": []}
+        orig_randint, orig_randn_like, orig_std_normal = np.random.randint, torch.randn_like, tdn._standard_normal
+
+        def rec_randint(*a, **k):
+            v = orig_randint(*a, **k)
+            draws["idx"].append(np.asarray(v).copy())
+            return v
+
+        def rec_randn_like(x, *a, **k):
+            v = orig_randn_like(x, *a, **k)
+            draws["noise"].append(v.numpy().copy())
+            return v
+
+        def rec_std_normal(shape, dtype, device):
+            v = orig_std_normal(shape, dtype, device)
+            draws["noise"].append(v.numpy().copy())
+            return v
+
+        losses = {"critic": [], "actor": []}
+        oc, oa = tr.critic_loss, tr.actor_loss
+
+        def rec_c(*a, **k):
+            v = oc(*a, **k)
+            losses["critic"].append(float(v))
+            return v
+
+        def rec_a(*a, **k):
+            v = oa(*a, **k)
+            losses["actor"].append(float(v[0] if isinstance(v, tuple) else v))
+            return v
+        tr.critic_loss, tr.actor_loss = rec_c, rec_a
+        np.random.randint, torch.randn_like, tdn._standard_normal = rec_randint, rec_randn_like, rec_std_normal
+        try:
+            for t in range(1, 5):
+                tr.train(t)
+                if t in (1, 4):
+                    out.update({"critic%d.%s" % (t, k): v.numpy().copy() for k, v in tr.agent.critic.state_dict().items()})
+        finally:
+            np.random.randint, torch.randn_like, tdn._standard_normal = orig_randint, orig_randn_like, orig_std_normal
+        out.update({"actor4." + k: v.numpy().copy() for k, v in tr.agent.actor.state_dict().items()})
+        out.update({"critic_target4." + k: v.numpy().copy() for k, v in tr.agent.critic_target.state_dict().items()})
+        if algo == "ddpg":
+            out.update({"actor_target4." + k: v.numpy().copy() for k, v in tr.agent.actor_target.state_dict().items()})
+        out["nju4"] = tr.agent.nju.weight.detach().numpy().copy()
+        out["idx"] = np.stack(draws["idx"])
+        for i, z in enumerate(draws["noise"]):
+            out["noise%d" % i] = z
+        out["n_noise"] = len(draws["noise"])
+        out["critic_losses"] = np.array(losses["critic"])
+        out["actor_losses"] = np.array(losses["actor"])
+        save("train_steps_%s_%s" % (algo, envname), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cart", "cart_gs", "pendulum"]
-    table = {"cart": gen_cart, "cart_gs": gen_cart_grad_steps, "pendulum": gen_pendulum}
+    which = sys.argv[1:] or ["cart", "cart_gs", "pendulum", "train"]
+    table = {"cart": gen_cart, "cart_gs": gen_cart_grad_steps, "pendulum": gen_pendulum, "train": gen_train_steps}
     for w in which:
         table[w]()

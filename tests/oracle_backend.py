@@ -1,0 +1,290 @@
+"""A stand-in for ``rpo_amd.ops`` built on ``oracle/`` -- TEST INFRASTRUCTURE, lives under tests/ on purpose.
+
+It implements the same kernel-set interface on CPU tensors with the oracle's numpy arithmetic, so that (a) the host
+logic of the trainers (loop cadence, flat parameter layout, optimiser order, logging, sharding, gradient buckets) is
+exercised by the CPU suite, and (b) a whole trainer driven by the oracle can be compared with the same trainer driven
+by the HIP kernels.  The product never imports this module; ``rpo_amd`` has no CPU fallback.
+"""
+import numpy as np
+import torch
+
+from oracle import cartsafe as cs
+from oracle import pendulum as pd
+from oracle import philox, train_ops
+from rpo_amd._lib import CONST
+
+NOISE_NONE, NOISE_EXPLICIT, NOISE_PHILOX, NOISE_UNIFORM, NOISE_CLIP_ONLY = 0, 1, 2, 3, 4
+STREAM_POLICY = CONST["RPO_STREAM_POLICY"]
+STATS_LEN = CONST["RPO_STATS_LEN"]
+CTRL_LEN = CONST["RPO_CTRL_LEN"]
+STAT = {k[len("RPO_STAT_"):].lower(): v for k, v in CONST.items() if k.startswith("RPO_STAT_") and k != "RPO_STATS_LEN"}
+
+
+def _np(t):
+    return t.detach().numpy()
+
+
+def _put(t, arr):
+    t.copy_(torch.as_tensor(np.asarray(arr), dtype=t.dtype).reshape(t.shape))
+
+
+class _EnvKernels(object):
+    """Vector-step bookkeeping shared by both envs (TimeLimit, auto-reset, ring scatter, statistics)."""
+
+    def _t(self, ctrl):
+        return 0 if ctrl is None else int(ctrl[0])
+
+    def _explore(self, ap_raw, noise, n, mode, eps_start, eps_end, eps_decay, lo, hi, seed, base, t):
+        eps_t = np.float32(max(eps_end, eps_start - eps_decay * t))
+        ids = np.arange(n) + base
+        if mode == NOISE_UNIFORM:
+            r = philox.draw(seed, ids, t, philox.STREAM_ACT)
+            scale = np.float32((hi - lo) * 0.5)
+            return (scale * (np.float32(2) * philox.u01(r[:, 0]) - np.float32(1)) + np.float32(lo + scale)).astype(np.float32)
+        ap = _np(ap_raw).reshape(-1).astype(np.float32)
+        if mode == NOISE_EXPLICIT:
+            ap = np.clip(ap + eps_t * _np(noise).reshape(-1), lo, hi)
+        elif mode == NOISE_PHILOX:
+            r = philox.draw(seed, ids, t, philox.STREAM_ACT)
+            ap = np.clip(ap + eps_t * philox.normal(r[:, 0], r[:, 1]), lo, hi)
+        elif mode == NOISE_CLIP_ONLY:
+            ap = np.clip(ap, lo, hi)
+        return ap.astype(np.float32)
+
+    def _finish_step(self, n, pre_obs, action, nxt_obs, reward, terminated, eq, ineq, ep_len, ep_ret, ep_count, rows,
+                     cap_steps, stats, ctrl, max_episode_steps, auto_reset, viol_thresh, t):
+        length = _np(ep_len) + 1
+        done = terminated | (length >= max_episode_steps)
+        ret = _np(ep_ret) + reward.astype(np.float32)
+        if rows is not None:
+            row = np.zeros((n, self.row_floats), dtype=np.float32)
+            c = self.cols
+            row[:, c["state"][0]:c["state"][1]] = pre_obs
+            row[:, c["action"][0]:c["action"][1]] = action
+            row[:, c["next_state"][0]:c["next_state"][1]] = nxt_obs
+            row[:, c["reward"][0]] = reward
+            row[:, c["done"][0]] = done
+            row[:, c["eq_viol"][0]:c["eq_viol"][1]] = eq
+            row[:, c["ineq_viol"][0]:c["ineq_viol"][1]] = ineq
+            base = (t % cap_steps) * n
+            rows[base:base + n] = torch.as_tensor(row)
+        if stats is not None:
+            cap = stats.shape[0]
+            r = stats[t % cap]
+            mi, me = ineq.max(axis=1), np.abs(eq).max(axis=1)
+            r[STAT["reward_sum"]] += float(reward.sum())
+            r[STAT["episodes"]] += float(done.sum())
+            r[STAT["return_sum"]] += float(ret[done].sum())
+            r[STAT["length_sum"]] += float(length[done].sum())
+            r[STAT["max_ineq_sum"]] += float(mi.sum())
+            r[STAT["max_eq_sum"]] += float(me.sum())
+            r[STAT["viol_count"]] += float((np.maximum(mi, me) > viol_thresh).sum())
+            r[STAT["terminated"]] += float((terminated & done).sum())
+            r[STAT["max_ineq_max"]] = max(float(r[STAT["max_ineq_max"]]), float(mi.max()))
+            r[STAT["max_eq_max"]] = max(float(r[STAT["max_eq_max"]]), float(me.max()))
+            if cap > 1 and ctrl is not None:
+                stats[(t + 1) % cap].zero_()
+        reset_mask = done & bool(auto_reset)
+        _put(ep_count, _np(ep_count) + reset_mask)
+        _put(ep_len, np.where(reset_mask, 0, length))
+        _put(ep_ret, np.where(reset_mask, 0, ret))
+        if ctrl is not None:
+            ctrl[0] = t + 1
+        return reset_mask
+
+    def _stat_iters(self, stats, ctrl, iters):
+        if stats is not None:
+            stats[self._t(ctrl) % stats.shape[0], STAT["proj_iters"]] += float(iters.sum())
+
+
+class CartSafeKernels(_EnvKernels):
+    name = "CartSafe-v0"
+    obs_dim, internal_dim, action_dim, eq_num, ineq_num = 6, 6, 2, 1, 6
+    row_floats = CONST["RPO_CART_ROW"]
+    cols = dict(state=(0, 6), action=(6, 8), next_state=(8, 14), reward=(14, 15), done=(15, 16), eq_viol=(16, 17),
+                ineq_viol=(17, 23))
+
+    def __init__(self, consts, partial):
+        self.c = cs.Constants(partial)
+        assert np.array_equal(np.asarray(consts, dtype=np.float32), self.c.as_array()), "constant table drifted"
+        self.partial = int(partial)
+
+    def reset(self, internal, obs, ep_len, ep_ret, ep_count, seed, env_id_base):
+        n = internal.shape[0]
+        _put(internal, philox.cart_reset(seed, np.arange(n) + env_id_base, _np(ep_count).astype(np.uint32)))
+        ep_len.zero_()
+        ep_ret.zero_()
+
+    def step(self, internal, obs, action, ep_len, ep_ret, ep_count, rows, cap_steps, stats, ctrl, max_episode_steps,
+             auto_reset, viol_thresh, seed, env_id_base):
+        n, t = internal.shape[0], self._t(ctrl)
+        s, a = _np(internal).astype(np.float64), _np(action)
+        nxt, rew, term, ineq, eq = cs.step(s, a, self.c)
+        nxt32 = nxt.astype(np.float32)
+        mask = self._finish_step(n, s.astype(np.float32), a, nxt32, rew, term, eq, ineq, ep_len, ep_ret, ep_count,
+                                 rows, cap_steps, stats, ctrl, max_episode_steps, auto_reset, viol_thresh, t)
+        fresh = philox.cart_reset(seed, np.arange(n) + env_id_base, _np(ep_count).astype(np.uint32))
+        _put(internal, np.where(mask[:, None], fresh, nxt32))
+
+    def act_project(self, obs, ap_raw, noise, action, iters, noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi,
+                    max_steps, corr_lr, corr_eps, corr_momentum, seed=0, env_id_base=0, ctrl=None, stats=None):
+        n = action.shape[0]
+        ap = self._explore(ap_raw, noise, n, noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi, seed,
+                           env_id_base, self._t(ctrl))
+        a, it = cs.grad_steps(cs.complete_partial(ap, self.c), self.c, corr_lr, max_steps, corr_eps, corr_momentum)
+        _put(action, a)
+        if iters is not None:
+            _put(iters, it)
+        self._stat_iters(stats, ctrl, it)
+
+    def complete_bwd(self, obs, grad_action, grad_ap):
+        k = -(self.c.C_p * self.c.C_o_inv)[0, 0]
+        g = _np(grad_action)
+        _put(grad_ap, g[:, self.c.partial] + k * g[:, self.c.other])
+
+    def resid(self, obs, action, eq_out, ineq_out):
+        if eq_out is not None:
+            _put(eq_out, cs.eq_resid(_np(action), self.c))
+        if ineq_out is not None:
+            _put(ineq_out, cs.ineq_resid(_np(action), self.c))
+
+    def ineq_partial_grad(self, obs, action, step_out):
+        _put(step_out, cs.ineq_partial_grad(_np(action), self.c))
+
+    def lagrangian(self, action, nu, scale, loss_out, grad_action, grad_nu):
+        loss, ga, gnu = train_ops.lagrangian_cart(_np(action), _np(nu), self.c, scale)
+        loss_out += float(loss)
+        if grad_action is not None:
+            _put(grad_action, ga)
+        if grad_nu is not None:
+            grad_nu += torch.as_tensor(gnu)
+
+
+class PendulumKernels(_EnvKernels):
+    name = "SpringPendulum-v0"
+    obs_dim, internal_dim, action_dim, eq_num, ineq_num = 5, 4, 2, 1, 1
+    row_floats = CONST["RPO_PEND_ROW"]
+    cols = dict(state=(0, 5), action=(5, 7), next_state=(7, 12), reward=(12, 13), done=(13, 14), eq_viol=(14, 15),
+                ineq_viol=(15, 16))
+    partial = 0
+
+    def reset(self, internal, obs, ep_len, ep_ret, ep_count, seed, env_id_base):
+        n = internal.shape[0]
+        s = philox.pendulum_reset(seed, np.arange(n) + env_id_base, _np(ep_count).astype(np.uint32))
+        _put(internal, s)
+        if obs is not None:
+            _put(obs, pd.get_obs(s.astype(np.float64)))
+        ep_len.zero_()
+        ep_ret.zero_()
+
+    def step(self, internal, obs, action, ep_len, ep_ret, ep_count, rows, cap_steps, stats, ctrl, max_episode_steps,
+             auto_reset, viol_thresh, seed, env_id_base):
+        n, t = internal.shape[0], self._t(ctrl)
+        s, a = _np(internal).astype(np.float64), _np(action)
+        nxt, nobs, rew, term, ineq, eq = pd.step(s, a)
+        mask = self._finish_step(n, pd.get_obs(s).astype(np.float32), a, nobs.astype(np.float32), rew, term, eq, ineq,
+                                 ep_len, ep_ret, ep_count, rows, cap_steps, stats, ctrl, max_episode_steps, auto_reset,
+                                 viol_thresh, t)
+        fresh = philox.pendulum_reset(seed, np.arange(n) + env_id_base, _np(ep_count).astype(np.uint32))
+        new = np.where(mask[:, None], fresh, nxt.astype(np.float32))
+        _put(internal, new)
+        if obs is not None:
+            _put(obs, pd.get_obs(new.astype(np.float64)))
+
+    def act_project(self, obs, ap_raw, noise, action, iters, noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi,
+                    max_steps, corr_lr, corr_eps, corr_momentum, seed=0, env_id_base=0, ctrl=None, stats=None):
+        n = action.shape[0]
+        ap = self._explore(ap_raw, noise, n, noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi, seed,
+                           env_id_base, self._t(ctrl))
+        o = _np(obs).astype(np.float32)
+        a, it = pd.grad_steps(o, pd.complete_partial(o, ap), corr_lr, max_steps, corr_eps, corr_momentum)
+        _put(action, a)
+        if iters is not None:
+            _put(iters, it)
+        self._stat_iters(stats, ctrl, it)
+
+    def project_batchref(self, obs, ap, action, iters_out, max_steps, corr_lr, corr_eps, corr_momentum):
+        o = _np(obs).astype(np.float32)
+        a, it = pd.grad_steps(o, pd.complete_partial(o, _np(ap).reshape(-1)), corr_lr, max_steps, corr_eps,
+                              corr_momentum, batch_global_stop=True, batched_reference=True)
+        _put(action, a)
+        if iters_out is not None:
+            iters_out[0] = int(it.max())
+
+    def complete_bwd(self, obs, grad_action, grad_ap):
+        o, g = _np(obs), _np(grad_action)
+        _put(grad_ap, g[:, 0] - g[:, 1] * (o[:, 1] * (np.float32(1) / o[:, 0])))
+
+    def resid(self, obs, action, eq_out, ineq_out):
+        if eq_out is not None:
+            _put(eq_out, pd.eq_resid(_np(obs).astype(np.float32), _np(action)))
+        if ineq_out is not None:
+            _put(ineq_out, pd.ineq_resid(_np(action)))
+
+    def ineq_partial_grad(self, obs, action, step_out):
+        _put(step_out, pd.ineq_partial_grad(_np(obs).astype(np.float32), _np(action)))
+
+    def lagrangian(self, action, nu, scale, loss_out, grad_action, grad_nu):
+        loss, ga, gnu = train_ops.lagrangian_pendulum(_np(action), _np(nu), scale)
+        loss_out += float(loss)
+        if grad_action is not None:
+            _put(grad_action, ga)
+        if grad_nu is not None:
+            grad_nu += torch.as_tensor(gnu)
+
+
+# ---------------------------------------------------------------------------------------------- shared kernels
+
+def philox_normal(out, seed, id_base, salt, stream_tag, ctrl=None):
+    t = 0 if ctrl is None else int(ctrl[0])
+    n = out.numel()
+    r = philox.draw(seed, np.arange(n) + id_base, (t + salt) & 0xFFFFFFFF, stream_tag)
+    _put(out, philox.normal(r[:, 0], r[:, 1]))
+
+
+def replay_sample_gather(rows, cap_steps, n_envs, out, idx_out, seed, salt, ctrl):
+    t = int(ctrl[0])
+    idx = philox.sample_indices(seed, out.shape[0], t, salt, min(t, cap_steps) * n_envs)
+    out.copy_(rows[torch.as_tensor(idx)])
+    if idx_out is not None:
+        _put(idx_out, idx)
+
+
+def replay_gather(rows, idx, out):
+    out.copy_(rows[idx])
+
+
+def td_huber(q1, q2, qn1, qn2, logp, alpha, reward, done, gamma, loss_out, grad_q1, grad_q2, target_out=None):
+    opt = lambda x: None if x is None else _np(x)   # noqa: E731
+    loss, y, g1, g2 = train_ops.td_huber(_np(q1), _np(qn1), _np(reward).reshape(-1), _np(done).reshape(-1), gamma,
+                                         q2=opt(q2), qn2=opt(qn2), logp=opt(logp), alpha=alpha)
+    loss_out += float(loss)
+    if grad_q1 is not None:
+        _put(grad_q1, g1)
+    if grad_q2 is not None and g2 is not None:
+        _put(grad_q2, g2)
+    if target_out is not None:
+        _put(target_out, y)
+
+
+def absmax(x, max_out):
+    max_out[0] = max(float(max_out[0]), float(x.abs().max()))
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
+              maximize=False, clip_thres=0.0, gradmax=None, reset_gradmax=True, clamp_min0=False, target=None, tau=0.0):
+    g = _np(grad)
+    if clip_thres > 0:
+        coef = min(np.float32(clip_thres) / (np.float32(float(gradmax[0])) + np.float32(1e-6)), np.float32(1.0))
+        g *= np.float32(coef)                         # in place, like clip_grad_norm_
+    step = train_ops.adam_step(_np(param), g, _np(exp_avg), _np(exp_avg_sq), int(step_dev[0]), lr, beta1, beta2, eps,
+                               weight_decay, maximize, clamp_min0)
+    step_dev[0] = step
+    if reset_gradmax and gradmax is not None:
+        gradmax.zero_()
+    if target is not None:
+        train_ops.polyak(_np(param), _np(target), tau)
+
+
+def polyak(param, target, tau):
+    train_ops.polyak(_np(param), _np(target), tau)

@@ -1,0 +1,167 @@
+"""One full constrained policy update (t = 1..4) against fixtures recorded from the unmodified reference:
+(a) the oracle loop (oracle/rpo_loop.py) and (b) the shipped trainer classes driven by the oracle backend on CPU --
+the same trainer code that runs on the HIP kernels on the GPU (tests/test_trainer_gpu.py repeats (b) there).
+
+Every random draw of the reference run (replay indices, exploration / rsample noise) is replayed from the fixture.
+Tolerance: float32 GEMMs + Adam over 4 steps; parameters agree to 2e-6 absolute (updates are O(1e-4)).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle_backend as ob
+from oracle import rpo_loop
+from rpo_amd import gym_shim
+from rpo_amd.algo import RPODDPG, RPOSAC
+from rpo_amd.env import CartSafeEnv, SpringPendulumEnv
+
+CASES = [("ddpg", "cart"), ("sac", "cart"), ("ddpg", "pendulum"), ("sac", "pendulum")]
+HP = {
+    ("ddpg", "cart"): dict(lr_dual=0.2, corr_lr=2e-2, eps=1.0, eps_start=1.0, eval_lr=2e-2, shared_param=True),
+    ("sac", "cart"): dict(lr_dual=0.2, corr_lr=2e-2, eps=5e-3, eps_start=5e-3, eval_lr=2e-2, shared_param=False,
+                          alpha=0.1),
+    ("ddpg", "pendulum"): dict(lr_dual=0.01, corr_lr=2e-3, eps=0.5, eps_start=0.5, eval_lr=2e-3, shared_param=False),
+    ("sac", "pendulum"): dict(lr_dual=0.01, corr_lr=2e-3, eps=1e-2, eps_start=1e-2, eval_lr=2e-3, shared_param=False,
+                              alpha=0.01),
+}
+COMMON = dict(batch_size=256, max_steps=10, warmup=0, eps_epoch=20000, eval_steps=50, corr_momentum=0.0, policy_fre=4,
+              capacity=512, clip_thres=0.2, embed_dim=128, hidden_dim=256, lr_actor=1e-4, lr_critic=3e-4)
+TOL = dict(rtol=0, atol=2e-6)
+
+
+def sd(g, prefix):
+    return {k[len(prefix) + 1:]: g[k] for k in g.files if k.startswith(prefix + ".")}
+
+
+def buffer_rows(g, cols, width):
+    n = g["buf.state"].shape[0]
+    rows = np.zeros((n, width), dtype=np.float32)
+    for key, (lo, hi) in cols.items():
+        rows[:, lo:hi] = np.asarray(g["buf." + key], dtype=np.float32).reshape(n, hi - lo)
+    return rows
+
+
+@pytest.mark.parametrize("algo,envname", CASES)
+def test_oracle_loop_matches_reference_update(golden, algo, envname):
+    torch.set_num_threads(1)
+    g = golden("train_steps_%s_%s" % (algo, envname))
+    torch.manual_seed(123)
+    env = rpo_loop.CartAdapter(1) if envname == "cart" else rpo_loop.PendulumAdapter(reference_batch_semantics=True)
+    noises = [torch.tensor(g["noise%d" % i]) for i in range(int(g["n_noise"]))]
+    idx = list(g["idx"])
+    hp = dict(HP[(algo, envname)])
+    hp.pop("eval_lr")
+    tr = rpo_loop.OracleRPO(env, sac=(algo == "sac"), noise_fn=lambda shape, tag: noises.pop(0),
+                            index_fn=lambda size, num: idx.pop(0), eval_lr=HP[(algo, envname)]["eval_lr"],
+                            **{k: v for k, v in COMMON.items() if k not in ("eval_steps",)}, eval_steps=50, **hp)
+    # same torch seed + same construction order => the reference's initial weights, bit for bit
+    for k, v in sd(g, "actor0").items():
+        np.testing.assert_array_equal(tr.nets.actor[k].detach().numpy(), v)
+    for k, v in sd(g, "critic0").items():
+        np.testing.assert_array_equal(tr.nets.critic[k].detach().numpy(), v)
+    for i in range(g["buf.state"].shape[0]):
+        tr.buffer.add(**{k: g["buf." + k][i] for k in ("state", "action", "next_state", "reward", "done", "eq_viol",
+                                                          "ineq_viol")})
+    closs, aloss = [], []
+    for t in range(1, 5):
+        out = tr.train(t)
+        closs.append(out["critic_loss"])
+        if "actor_loss" in out:
+            aloss.append(out["actor_loss"])
+        if t == 1:
+            for k, v in sd(g, "critic1").items():
+                np.testing.assert_allclose(tr.nets.critic[k].detach().numpy(), v, **TOL)
+    np.testing.assert_allclose(closs, g["critic_losses"], rtol=2e-5)
+    np.testing.assert_allclose(aloss, g["actor_losses"], rtol=2e-5, atol=1e-6)
+    for name, params in (("critic4", tr.nets.critic), ("actor4", tr.nets.actor), ("critic_target4", tr.nets.critic_target)):
+        for k, v in sd(g, name).items():
+            np.testing.assert_allclose(params[k].detach().numpy(), v, **TOL)
+    if algo == "ddpg":
+        for k, v in sd(g, "actor_target4").items():
+            np.testing.assert_allclose(tr.nets.actor_target[k].detach().numpy(), v, **TOL)
+    np.testing.assert_allclose(tr.nju.detach().numpy(), g["nju4"], rtol=1e-5, atol=1e-7)
+    assert not noises and not idx        # every recorded draw was consumed, in order
+
+
+def build_trainer(algo, envname, backend, device, **extra):
+    env_cls = CartSafeEnv if envname == "cart" else SpringPendulumEnv
+    kw = dict(partial_actions=[1]) if envname == "cart" else {}
+    env = gym_shim.TimeLimit(env_cls(backend=backend, **kw), 200)
+    cls = RPODDPG if algo == "ddpg" else RPOSAC
+    hp = dict(HP[(algo, envname)])
+    if algo == "sac":
+        hp["automatic_entropy_tuning"] = False
+    args = dict(COMMON)
+    args.update(hp)
+    args.update(extra)
+    return cls(env, "/tmp/rpo_test", name="t", logger=None, max_epochs=10, value_type="add", grad_eps=0.1,
+               device=device, backend=backend, seed=11, **args)
+
+
+class ReplayDraws(object):
+    """Backend proxy that replays the fixture's random draws instead of the Philox kernels."""
+
+    def __init__(self, inner, g, rows, device):
+        self._inner, self.dev = inner, device
+        self.noises = [torch.tensor(g["noise%d" % i]).to(device) for i in range(int(g["n_noise"]))]
+        self.idx = [torch.as_tensor(i, dtype=torch.int64).to(device) for i in g["idx"]]
+        self.rows = rows
+
+    def __getattr__(self, name):
+        return getattr(self._inner, name)
+
+    def philox_normal(self, out, *a, **k):
+        out.copy_(self.noises.pop(0).reshape(out.shape))
+
+    def replay_sample_gather(self, rows, cap_steps, n_envs, out, idx_out, seed, salt, ctrl):
+        self._inner.replay_gather(self.rows, self.idx.pop(0), out)
+
+
+def product_tol(envname):
+    return TOL
+
+
+def run_product_update(golden, algo, envname, backend, device):
+    g = golden("train_steps_%s_%s" % (algo, envname))
+    torch.manual_seed(123)
+    tr = build_trainer(algo, envname, backend, device, num_envs=1)
+    ag = tr.agent
+    for k, v in sd(g, "actor0").items():        # the shipped modules initialise exactly like the reference's
+        np.testing.assert_array_equal(ag.actor.state_dict()[k].cpu().numpy(), v)
+    for k, v in sd(g, "critic0").items():
+        np.testing.assert_array_equal(ag.critic.state_dict()[k].cpu().numpy(), v)
+    rows = torch.tensor(buffer_rows(g, tr.kernels.cols, tr.kernels.row_floats)).to(device)
+    proxy = ReplayDraws(backend, g, rows, device)
+    tr.backend = tr.buffer._ops = proxy
+    closs, aloss = [], []
+    for t in range(1, 5):
+        tr.train(t)
+        closs.append(float(tr.last_losses["critic"]))
+        if t % 4 == 0:
+            aloss.append(float(tr.last_losses["actor"]))
+        if t == 1:
+            for k, v in sd(g, "critic1").items():
+                np.testing.assert_allclose(ag.critic.state_dict()[k].cpu().numpy(), v, **product_tol(envname))
+    return g, tr, closs, aloss, proxy
+
+
+def check_product_update(g, tr, closs, aloss, proxy, algo, envname):
+    ag = tr.agent
+    tol = product_tol(envname)
+    np.testing.assert_allclose(closs, g["critic_losses"], rtol=2e-5)
+    np.testing.assert_allclose(aloss, g["actor_losses"], rtol=2e-5, atol=1e-6)
+    for name, net in (("critic4", ag.critic), ("actor4", ag.actor), ("critic_target4", ag.critic_target)):
+        for k, v in sd(g, name).items():
+            np.testing.assert_allclose(net.state_dict()[k].cpu().numpy(), v, **tol)
+    if algo == "ddpg":
+        for k, v in sd(g, "actor_target4").items():
+            np.testing.assert_allclose(ag.actor_target.state_dict()[k].cpu().numpy(), v, **tol)
+    np.testing.assert_allclose(ag.nju.weight.detach().cpu().numpy(), g["nju4"], rtol=1e-4, atol=1e-7)
+    assert not proxy.noises and not proxy.idx
+
+
+@pytest.mark.parametrize("algo,envname", CASES)
+def test_trainer_host_logic_matches_reference_update(golden, algo, envname):
+    torch.set_num_threads(1)
+    out = run_product_update(golden, algo, envname, ob, torch.device("cpu"))
+    check_product_update(*out, algo, envname)

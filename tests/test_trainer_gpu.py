@@ -1,0 +1,112 @@
+"""The shipped trainers on the HIP kernels (MI355X): (1) the reference's recorded update steps are reproduced through
+the C ABI, (2) a hipGraph-replayed run equals the eager run bit for bit, (3) several whole iterations (rollout +
+scatter + sample + update) agree with the same trainer driven by the oracle backend on the CPU.
+
+Tolerances: (1) 4 Adam steps of float32 MLPs on rocBLAS vs the reference's CPU GEMMs: parameters agree to 5e-6
+absolute, losses to 1e-4 relative.  (3) float32 env physics on the GPU vs float64 in the oracle, compounded over the
+iterations: parameters 2e-5 absolute, replay rows 2e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from test_train_step_golden import CASES, build_trainer, check_product_update, run_product_update, sd  # noqa: F401
+import test_train_step_golden as tsg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from rpo_amd import ops
+    assert torch.cuda.is_available()
+    return ops
+
+
+@pytest.mark.parametrize("algo,envname", CASES)
+def test_update_matches_reference_on_gpu(golden, hip, algo, envname, monkeypatch):
+    monkeypatch.setattr(tsg, "TOL", dict(rtol=0, atol=5e-6))
+    out = run_product_update(golden, algo, envname, hip, torch.device("cuda"))
+    g, tr, closs, aloss, proxy = out
+    np.testing.assert_allclose(closs, g["critic_losses"], rtol=1e-4)
+    np.testing.assert_allclose(aloss, g["actor_losses"], rtol=1e-4, atol=1e-6)
+    ag = tr.agent
+    for name, net in (("critic4", ag.critic), ("actor4", ag.actor), ("critic_target4", ag.critic_target)):
+        for k, v in sd(g, name).items():
+            np.testing.assert_allclose(net.state_dict()[k].cpu().numpy(), v, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(ag.nju.weight.detach().cpu().numpy(), g["nju4"], rtol=1e-4, atol=1e-7)
+
+
+def _run(algo, envname, backend, device, iters, n_envs, use_graph, seed_all=5):
+    torch.manual_seed(seed_all)
+    tr = build_trainer(algo, envname, backend, device, num_envs=n_envs, use_graph=use_graph)
+    tr.vec.reset()
+    tr.run_steps(iters)
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    return tr
+
+
+@pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "pendulum")])
+def test_graph_replay_equals_eager(hip, algo, envname):
+    dev = torch.device("cuda")
+    a = _run(algo, envname, hip, dev, 24, 512, use_graph=False)
+    b = _run(algo, envname, hip, dev, 24, 512, use_graph=True)
+    assert any(e["graph"] is not None for e in b._graphs.entries.values())
+    assert torch.equal(a.vec.internal, b.vec.internal)
+    assert torch.equal(a.buffer.rows, b.buffer.rows)
+    assert torch.equal(a.agent.flat.data, b.agent.flat.data)
+    assert torch.equal(a.agent.nju.weight, b.agent.nju.weight)
+    assert int(b.vec.ctrl[0]) == 24 == int(a.vec.ctrl[0])
+    assert torch.equal(a.vec.stats[:24], b.vec.stats[:24])
+
+
+@pytest.mark.parametrize("algo,envname", CASES)
+def test_iterations_match_oracle_backend(hip, algo, envname):
+    import oracle_backend as ob
+    iters, n = 8, 64
+    g = _run(algo, envname, hip, torch.device("cuda"), iters, n, use_graph=False)
+    c = _run(algo, envname, ob, torch.device("cpu"), iters, n, use_graph=False)
+    np.testing.assert_allclose(g.buffer.rows[: iters * n].cpu().numpy(), c.buffer.rows[: iters * n].numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(g.vec.internal.cpu().numpy(), c.vec.internal.numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(g.agent.flat.data.cpu().numpy(), c.agent.flat.data.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(g.agent.nju.weight.detach().cpu().numpy(), c.agent.nju.weight.detach().numpy(), rtol=1e-3, atol=1e-6)
+    np.testing.assert_array_equal(g.vec.ep_count.cpu().numpy(), c.vec.ep_count.numpy())
+    S = hip.STAT
+    gs, cs_ = g.vec.stats[:iters].cpu().numpy(), c.vec.stats[:iters].numpy()
+    for key in ("episodes", "reward_sum", "proj_iters"):
+        np.testing.assert_allclose(gs[:, S[key]], cs_[:, S[key]], rtol=1e-5)
+    np.testing.assert_allclose(gs[:, S["max_ineq_sum"]], cs_[:, S["max_ineq_sum"]], rtol=1e-3, atol=1e-3)
+
+
+def test_eval_and_logger_on_gpu(hip):
+    from rpo_amd.utils.logger import Logger
+    torch.manual_seed(3)
+    tr = build_trainer("ddpg", "cart", hip, torch.device("cuda"), num_envs=256, eval_fre=20)
+    tr.max_epochs = 40
+    tr.logger = Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=40)
+    tr.run(eval=True)
+    res = tr.eval()
+    assert len(res) == 10 and 1.0 <= res[0] <= 200.0 and res[5] < 1e-5       # equalities hold to round-off
+    assert tr.logger.pointer > 0 and tr.logger.tracker["reward"][0] > 0
+    assert 0.0 <= tr.viol_rate <= 1.0 and tr.env_steps == 40 * 256
+
+
+def test_gym_api_single_env_on_gpu(hip, golden):
+    """`gym.make("CartSafe-v0")` -> reset / step through the HIP kernel with n = 1, against the reference vectors."""
+    import gym
+    import rpo_amd.env  # noqa: F401  (registers the ids)
+    np.random.seed(123)
+    env = gym.make("CartSafe-v0")
+    assert list(env.partial_actions) == [1]
+    g = golden("cart_env_p1")
+    obs = env.reset()
+    assert obs.shape == (6,) and np.all(np.abs(obs) <= 0.05)
+    for i in range(5):
+        env.unwrapped._vec.set_internal(g["states"][i][None, :])
+        o, r, d, info = env.step(g["actions"][i])
+        np.testing.assert_allclose(o, g["next_states"][i], rtol=1e-4, atol=1e-4)
+        assert r == 1.0 and d == bool(g["done"][i])
+        np.testing.assert_allclose(info["ineq_viol"], g["ineq_viol"][i], atol=4e-6)
+        np.testing.assert_allclose(info["eq_viol"], g["eq_viol"][i], atol=2e-6)
+    env.close()
