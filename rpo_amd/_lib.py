@@ -54,6 +54,17 @@ PROTOTYPES, CONST = parse_header()
 _lib = None
 
 
+def _bind_to_torch_hip_runtime():
+    """PyTorch-ROCm wheels carry their own libamdhip64.so; the streams and device pointers handed to the kernels belong
+    to THAT runtime instance.  Put it into the global symbol scope before librpo_hip.so is loaded so that the library's
+    HIP calls bind to it instead of opening a second runtime from /opt/rocm (which fails with hipErrorNoDevice on the
+    first launch).  A non-Python host simply links the library against its own HIP runtime."""
+    import torch
+    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
+
+
 def load():
     """Load (once) and return the ctypes library with typed entry points.  Raises if it is not built."""
     global _lib
@@ -63,6 +74,7 @@ def load():
         raise RpoHipError(
             "%s is missing: build it with `python rpo_amd/csrc/build.py` (hipcc --offload-arch=gfx950). "
             "rpo_amd has no CPU fallback." % LIBRARY)
+    _bind_to_torch_hip_runtime()
     lib = ctypes.CDLL(LIBRARY)
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError = symbol missing: loud by construction

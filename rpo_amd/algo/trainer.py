@@ -309,11 +309,12 @@ class RPOTrainerBase(object):
         self.run_steps(self.max_epochs - self._t, eval=eval)
         self._harvest(final=True)
 
-    def run_steps(self, n, eval=False):
+    def run_steps(self, n, eval=False, train=True):
+        """``n`` loop iterations; ``train=False`` collects rollouts only (no sampling, no update)."""
         for _ in range(int(n)):
             t = self._t
             warm = t < self.warmup
-            do_train = (t + 1) >= self.warmup
+            do_train = train and (t + 1) >= self.warmup
             actor_step = do_train and (t + 1) % self.policy_fre == 0
             self._iteration(warm, do_train, actor_step)
             self._t = t = t + 1
@@ -358,10 +359,10 @@ class RPOTrainerBase(object):
                             self.logger.add(epoch=ep, reward=ret, max_ineq=mi, max_eq=me)
                     except StopIteration:
                         pass
-                if self.dist.rank == 0 and _env_int("RPO_VERBOSE", 1):
-                    worst = max(p[1] for p in self._pending), max(p[2] for p in self._pending)
-                    print("episode %d ends. reward: %s, step: %s, ineq_viol: %s, eq_viol: %s"
-                          % (lo + i + 1, ret, length, worst[0], worst[1]))
+                if self.num_envs == 1 and self.dist.rank == 0 and _env_int("RPO_VERBOSE", 1):
+                    worst = max(p[1] for p in self._pending), max(p[2] for p in self._pending)    # rpo_ddpg.py:134
+                    print("episode %d ends. reward: %s, step: %d, ineq_viol: %s, eq_viol: %s"
+                          % (lo + i + 1, ret, int(length), worst[0], worst[1]))
                 self._pending = []
         # constraint-violation rate: fraction of env steps with max(max_ineq, max_eq) > 1e-3
         self.viol_steps += rows[:, S["viol_count"]].sum()

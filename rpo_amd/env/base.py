@@ -64,8 +64,8 @@ class HardConstraintEnv(gym.Env):
     volatile = False      # state-independent action box (cartpole.py:147, pendulum.py:67)
     update = None
 
-    def __init__(self, backend=None):
-        self.device = default_device()
+    def __init__(self, backend=None, device=None):
+        self.device = torch.device(device) if device is not None else default_device()
         self._backend = backend if backend is not None else hip_ops
         self._kernels = None
         self._vec = None

@@ -19,8 +19,8 @@ spaces = gym.spaces
 class CartSafeEnv(HardConstraintEnv):
     metadata = {"render_modes": ["human", "rgb_array"], "render_fps": 50}
 
-    def __init__(self, partial_actions=None, backend=None):
-        super().__init__(backend)
+    def __init__(self, partial_actions=None, backend=None, device=None):
+        super().__init__(backend, device)
         self.delta = np.array([np.pi / 3, -np.pi / 6])                       # cartpole.py:85
         self.theta_threshold_radians = 12 * 2 * math.pi / 360
         self.x_threshold = 2.4

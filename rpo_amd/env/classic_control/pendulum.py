@@ -15,8 +15,8 @@ spaces = gym.spaces
 class SpringPendulumEnv(HardConstraintEnv):
     metadata = {"render_modes": ["human", "rgb_array"], "render_fps": 30}
 
-    def __init__(self, g=10.0, backend=None):
-        super().__init__(backend)
+    def __init__(self, g=10.0, backend=None, device=None):
+        super().__init__(backend, device)
         if g != 10.0:
             raise NotImplementedError("the HIP kernels are specialised for the registered g = 10 (pendulum.py:15)")
         self.max_speed, self.max_torque, self.max_summation = 8.0, 6.0, 32.0

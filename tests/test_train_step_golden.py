@@ -86,7 +86,7 @@ def test_oracle_loop_matches_reference_update(golden, algo, envname):
 def build_trainer(algo, envname, backend, device, **extra):
     env_cls = CartSafeEnv if envname == "cart" else SpringPendulumEnv
     kw = dict(partial_actions=[1]) if envname == "cart" else {}
-    env = gym_shim.TimeLimit(env_cls(backend=backend, **kw), 200)
+    env = gym_shim.TimeLimit(env_cls(backend=backend, device=device, **kw), 200)
     cls = RPODDPG if algo == "ddpg" else RPOSAC
     hp = dict(HP[(algo, envname)])
     if algo == "sac":
