@@ -1,0 +1,83 @@
+"""The N>1 path on CPU: world_size-2 `gloo`, trainer host logic driven by the oracle backend (tests/oracle_backend.py).
+
+Checks: env lanes shard by global env id (rank r owns ids [r*n, (r+1)*n)) and reproduce the single-process trajectories;
+the flat gradient slices are all-reduced to the mean of the per-rank gradients; replicas stay bit-identical through
+several updates without any parameter broadcast; statistics are reduced over ranks.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, algo, envname, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RPO_VERBOSE="0")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_backend as ob
+    from test_train_step_golden import build_trainer
+    torch.manual_seed(5)
+    tr = build_trainer(algo, envname, ob, torch.device("cpu"), num_envs=16)
+    assert tr.n_local == 8 and tr.vec.env_id_base == 8 * rank and tr.dist.world == 2
+    tr.vec.reset()
+    first_state = tr.vec.internal.clone()
+    tr.run_steps(1)
+    after_one = tr.vec.internal.clone()
+    # gradient bucket: per-rank critic gradient before the collective vs the reduced one
+    cols = tr._sample()
+    tr._critic_update(cols)
+    fl = tr.agent.flat
+    local = fl.gradient(fl.critic_range).clone()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    tr.dist.mean_([fl.gradient(fl.critic_range)])
+    np.testing.assert_allclose(fl.gradient(fl.critic_range).numpy(), (sum(gathered) / world).numpy(), rtol=1e-6, atol=1e-9)
+    assert not torch.equal(gathered[0], gathered[1])            # the shards really sampled different data
+    tr.run_steps(7)                                             # includes two policy steps (t = 4, 8)
+    tr._harvest(final=True)
+    torch.save(dict(first=first_state, after_one=after_one, flat=fl.data.clone(), nju=tr.agent.nju.weight.data.clone(),
+                    target=tr.agent.critic_target_flat.clone(), env_steps=float(tr.env_steps), viol=float(tr.viol_steps)),
+               os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "pendulum")])
+def test_two_rank_data_parallel(tmp_path, algo, envname):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, algo, envname, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"), weights_only=False)
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"), weights_only=False)
+    # replicas identical, bit for bit, after 8 iterations with all-reduced gradients
+    assert torch.equal(r0["flat"], r1["flat"]) and torch.equal(r0["nju"], r1["nju"]) and torch.equal(r0["target"], r1["target"])
+    assert r0["env_steps"] == r1["env_steps"] == 16 * 8          # statistics are summed over ranks
+    assert r0["viol"] == r1["viol"]
+    # single-process run with the same 16 global lanes: same initial states and same first vector step per env id
+    sys.path.insert(0, HERE)
+    import oracle_backend as ob
+    from test_train_step_golden import build_trainer
+    torch.set_num_threads(1)
+    torch.manual_seed(5)
+    tr = build_trainer(algo, envname, ob, torch.device("cpu"), num_envs=16)
+    tr.vec.reset()
+    both_first = torch.cat([r0["first"], r1["first"]])
+    assert torch.equal(tr.vec.internal, both_first)
+    tr.run_steps(1)
+    assert torch.equal(tr.vec.internal, torch.cat([r0["after_one"], r1["after_one"]]))
