@@ -258,6 +258,59 @@ int rpo_adam_step(long long n, float* param, float* grad, float* exp_avg, float*
 /* soft_update alone (agent/ddpg_pa.py:77-86, sac_pa.py:87-91): target = (1 - tau) * target + tau * param. */
 int rpo_polyak(long long n, const float* param, float* target, float tau, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Actor / critic MLPs, exact f32 on the matrix cores (v_mfma_f32_16x16x4_f32 == an fmaf chain).
+ * One descriptor covers every network of the reference's agents with hidden_layer = 1 (model/embedding.py:21-29,
+ * model/policy.py:24-33,48-57, model/value.py:51-59,125-140):
+ *     x0 = s Ws^T + bs (+ a Wa^T + ba; `cat`: [s-part | a-part] concatenated, model/value.py:22-31)
+ *     h1 = relu(x0) W0^T + b0 ;  out_k = relu(h1) W1_k^T + b1_k   (k < n_out; second head = SAC's log-std head)
+ * Weights are device pointers in torch's nn.Linear layout [out][in]; W0 must be 16-byte aligned.
+ * Supported sizes: H = 256 and Ein (= E, or 2E when cat) in {128, 256, 512}; S <= 64, A <= 48 (rpo_mlp_supported).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float *Ws, *bs, *Wa, *ba, *W0, *b0, *W1, *b1, *W1b, *b1b;
+    int S, A, E, H, n_out, cat;
+} rpo_mlp;
+typedef struct {
+    float *Ws, *bs, *Wa, *ba, *W0, *b0, *W1, *b1, *W1b, *b1b;
+} rpo_mlp_grad;
+
+int rpo_mlp_supported(int E, int H, int cat);
+
+/* Forward of n rows.  s [n, >=S] / a [n, >=A] are read with row strides (columns of a gathered batch are fine).
+ * out [n, n_out]; x0_save [n, Ein] / h1_save [n, H] (pre-activations, for rpo_mlp_backward) may be NULL.
+ * out_mode 1 applies BoxConstraint's tanh map to output 0: scale * tanh(o) + base (model/utils.py:40-51). */
+int rpo_mlp_forward(const rpo_mlp* net_host, int n, const float* s, int s_stride, const float* a, int a_stride,
+                    float* out, float* x0_save, float* h1_save, int out_mode, float scale, float base, void* stream);
+
+/* Backward of the same rows given dout [n, n_out] (two launches).  Parameter gradients are ACCUMULATED (+=) into
+ * grad_host's buffers (the shared state embedding of shared_param=True receives contributions from two networks,
+ * agent/ddpg_pa.py:34-36).  dh [n, H] and dx0 [n, Ein] are caller-provided scratch; da [n, A] (may be NULL) receives
+ * the gradient w.r.t. the action input (actor loss: -Q(s, a) back to the policy, rpo_ddpg.py:317).
+ * param_grads = 0: only dx0 / da; first_layer_state_only = 1: of the parameters only Ws / bs are accumulated. */
+int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int n, const float* s, int s_stride,
+                     const float* a, int a_stride, const float* x0, const float* h1, const float* dout, float* dh,
+                     float* dx0, float* da, int param_grads, int first_layer_state_only, void* stream);
+
+/* Policy heads around the MLP kernels.
+ * DDPG (model/policy.py:30-31, agent/ddpg_pa.py:108-110): ap = clip(ap_det + eps_t * noise), ap_det = scale*tanh(o)+base.
+ *   dout[i] = dap[i] * 1[lo <= ap_det + eps_t*noise <= hi] * scale * (1 - tanh(o)^2); noise NULL: no noise, no clip. */
+int rpo_tanh_box_bwd(int n, const float* dap, const float* ap_det, const float* noise, float eps_start, float eps_end,
+                     float eps_decay, const long long* ctrl, float lo, float hi, float scale, float base, float* dout,
+                     void* stream);
+
+/* SAC (GaussianSharedPolicy.forward, model/policy.py:53-66; PDSAC_PA.take_action, agent/sac_pa.py:105-115):
+ * raw [n,2] = (mean, log-std head) from rpo_mlp_forward, eps [n] the N(0,1) draw of rsample.
+ *   log_std = clamp(raw1 - 3, -23, -2); x = mean + eps * exp(log_std); y = tanh(x);
+ *   ap = clip(scale*y + base)  (deterministic: clip(scale*tanh(mean)+base));
+ *   log_prob = -eps^2/2 - log_std - log(sqrt(2 pi)) - log(scale*(1 - y^2) + 1e-6). */
+int rpo_gauss_head(int n, const float* raw, const float* eps, float scale, float base, float lo, float hi,
+                   int deterministic, float* ap_out, float* logp_out, void* stream);
+
+/* Backward of the above: draw [n,2] given dap [n] and a uniform d/d(log_prob) = dlogp (alpha / B in rpo_sac.py:331). */
+int rpo_gauss_head_bwd(int n, const float* raw, const float* eps, const float* dap, float dlogp, float scale,
+                       float base, float lo, float hi, float* draw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,7 +35,8 @@ class FlatParams(object):
         seg_s = [p for p in cp if id(p) in a_ids]
         seg_a = [p for p in ap if id(p) not in c_ids]
         self.sizes = [sum(p.numel() for p in seg) for seg in (seg_c, seg_s, seg_a)]
-        c, s, a = [_pad4(n) for n in self.sizes]
+        # every tensor starts on a 16-byte boundary (float4 loads in the MLP kernels); padding floats stay zero
+        c, s, a = [sum(_pad4(p.numel()) for p in seg) for seg in (seg_c, seg_s, seg_a)]
         self.critic_range = (0, c + s)
         self.actor_range = (c, c + s + a)
         self.total = c + s + a
@@ -50,7 +51,7 @@ class FlatParams(object):
                 p.data = self.data[off:off + n].view(p.shape)
                 p.grad = self.grad[off:off + n].view(p.shape)
                 self.offset[id(p)] = off
-                off += n
+                off += _pad4(n)
         self.unique_numel = sum(self.sizes)
 
     def make_target(self, module, target_module, rng):

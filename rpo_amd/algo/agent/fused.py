@@ -1,0 +1,127 @@
+"""Descriptors and scratch for running the agents' networks through the hand-written MLP kernels
+(rpo_mlp_forward / rpo_mlp_backward, exact f32 MFMA) instead of the rocBLAS + elementwise chain of the torch modules.
+
+The torch modules stay the owners of the parameters (state_dict, checkpoints, the `agent.actor(...)` API); the kernels
+read the same flat buffers through pointers.  Unsupported shapes (hidden_layer != 1, embed_layer != 1, partial critics,
+sizes other than those of ``rpo_mlp_supported``) return ``None`` from ``build`` and the trainers keep the torch path.
+"""
+import torch
+
+from ..model.nets import (DoubleValueAdd, DoubleValueCat, GaussianSharedPolicy, SharedPolicy, SharedValueAdd,
+                          SharedValueCat)
+
+
+def _lin(m):
+    return m.weight, m.bias
+
+
+class FusedNets(object):
+
+    def __init__(self, backend, descs, device):
+        self.backend, self.descs, self.device = backend, descs, device
+        self._scratch = {}
+
+    @classmethod
+    def build(cls, agent, backend, device):
+        if not hasattr(backend, "mlp_forward"):
+            return None
+        try:
+            descs = {}
+            for name in ("actor", "actor_target"):
+                net = getattr(agent, name, None)
+                if net is not None:
+                    descs[name] = cls._actor_desc(backend, net)
+            for name in ("critic", "critic_target"):
+                net = getattr(agent, name)
+                for suffix, d in cls._critic_descs(backend, net):
+                    descs[name + suffix] = d
+        except _Unsupported:
+            return None
+        return cls(backend, descs, device)
+
+    # ------------------------------------------------------------------------------------------ descriptors
+    @staticmethod
+    def _embed(e):
+        if len(e.embeds) != 1:
+            raise _Unsupported()
+        return _lin(e.embeds[0])
+
+    @classmethod
+    def _actor_desc(cls, backend, net):
+        Ws, bs = cls._embed(net.state_embed)
+        S, E = Ws.shape[1], Ws.shape[0]
+        if isinstance(net, SharedPolicy):
+            if len(net.affines) != 2 or net.affines[1].weight.shape[0] != 1:
+                raise _Unsupported()
+            W0, b0 = _lin(net.affines[0])
+            W1, b1 = _lin(net.affines[1])
+            t, n_out = dict(Ws=Ws, bs=bs, W0=W0, b0=b0, W1=W1, b1=b1), 1
+        elif isinstance(net, GaussianSharedPolicy):
+            if len(net.affines) != 1 or net.affine_mean.weight.shape[0] != 1:
+                raise _Unsupported()
+            W0, b0 = _lin(net.affines[0])
+            W1, b1 = _lin(net.affine_mean)
+            W1b, b1b = _lin(net.affine_log_std)
+            t, n_out = dict(Ws=Ws, bs=bs, W0=W0, b0=b0, W1=W1, b1=b1, W1b=W1b, b1b=b1b), 2
+        else:
+            raise _Unsupported()
+        H = W0.shape[0]
+        if net.box_constraint is None or net.box_constraint.volatile or not backend.mlp_supported(E, H, False):
+            raise _Unsupported()
+        return backend.MlpDesc(t, S, 0, E, H, n_out, False)
+
+    @classmethod
+    def _critic_descs(cls, backend, net):
+        if getattr(net, "partial", False):
+            raise _Unsupported()
+        if isinstance(net, (SharedValueAdd, SharedValueCat)):
+            parts = [("", net.state_embed, net.action_embed, net.affines)]
+        elif isinstance(net, (DoubleValueAdd, DoubleValueCat)):
+            parts = [("1", net.state_embed1, net.action_embed1, net.affines1),
+                     ("2", net.state_embed2, net.action_embed2, net.affines2)]
+        else:
+            raise _Unsupported()
+        cat = isinstance(net, (SharedValueCat, DoubleValueCat))
+        out = []
+        for suffix, se, ae, affines in parts:
+            if len(affines) != 2:
+                raise _Unsupported()
+            Ws, bs = cls._embed(se)
+            Wa, ba = cls._embed(ae)
+            W0, b0 = _lin(affines[0])
+            W1, b1 = _lin(affines[1])
+            S, A, E, H = Ws.shape[1], Wa.shape[1], Ws.shape[0], W0.shape[0]
+            if not backend.mlp_supported(E, H, cat) or S > 64 or A > 48:
+                raise _Unsupported()
+            out.append((suffix, backend.MlpDesc(dict(Ws=Ws, bs=bs, Wa=Wa, ba=ba, W0=W0, b0=b0, W1=W1, b1=b1), S, A, E, H,
+                                                1, cat)))
+        return out
+
+    # ------------------------------------------------------------------------------------------ execution
+    def buf(self, key, *shape):
+        k = (key,) + shape
+        t = self._scratch.get(k)
+        if t is None:
+            t = self._scratch[k] = torch.zeros(*shape, device=self.device)
+        return t
+
+    def forward(self, name, s, a, out, save=False, tanh_box=None):
+        """out [n, n_out]; ``save``: keep the pre-activations for ``backward``; ``tanh_box`` = (scale, base)."""
+        d = self.descs[name]
+        n = out.shape[0]
+        x0 = self.buf(name + ".x0", n, d.ein) if save else None
+        h1 = self.buf(name + ".h1", n, d.H) if save else None
+        mode, scale, base = (1, tanh_box[0], tanh_box[1]) if tanh_box is not None else (0, 1.0, 0.0)
+        self.backend.mlp_forward(d, s, a, out, x0, h1, mode, scale, base)
+        return out
+
+    def backward(self, name, s, a, dout, da=None, param_grads=True, first_layer_state_only=False):
+        d = self.descs[name]
+        n = dout.shape[0]
+        self.backend.mlp_backward(d, s, a, self.buf(name + ".x0", n, d.ein), self.buf(name + ".h1", n, d.H), dout,
+                                  self.buf(name + ".dh", n, d.H), self.buf(name + ".dx0", n, d.ein), da, param_grads,
+                                  first_layer_state_only)
+
+
+class _Unsupported(Exception):
+    pass

@@ -35,13 +35,73 @@ class RPODDPG(RPOTrainerBase):
         self._setup(env, work_dir, name, logger, agent, hp, device, num_envs, seed, backend, use_graph)
 
     # ---- rollout policy (rpo_ddpg.py:98-106, agent/ddpg_pa.py:101-112) ----------------------------------------
+    def _actor_out(self, name, obs, save=False):
+        """Deterministic basic action [n] of `actor` / `actor_target` through the fused MLP kernel."""
+        f = self.fused
+        return f.forward(name, obs, None, f.buf(name + ".out", obs.shape[0], 1), save=save,
+                         tanh_box=self._box_affine).view(-1)
+
     def _policy_partial(self, obs, warm):
         if warm:
             return None, hip_ops.NOISE_UNIFORM                      # BoxConstraint.sample, inside the kernel
+        if self.fused is not None:
+            return self._actor_out("actor", obs), hip_ops.NOISE_PHILOX
         return self.agent.actor(obs).reshape(-1), hip_ops.NOISE_PHILOX   # + eps_t * N(0,1), clip: inside the kernel
 
     def _eval_partial(self, obs):
+        if self.fused is not None:
+            return self._actor_out("actor", obs)
         return self.agent.actor(obs).reshape(-1)
+
+    # ---- the update through the hand-written MLP kernels (same arithmetic as critic_loss / actor_loss below) ------
+    def _critic_update(self, cols):
+        if self.fused is None:
+            return super()._critic_update(cols)
+        f, ag, B = self.fused, self.agent, self.batch_size
+        state, action, next_state, reward, done = cols[:5]
+        next_actions = self._project_batch(next_state, self._actor_out("actor_target", next_state))
+        qn = f.forward("critic_target", next_state, next_actions, f.buf("qn", B, 1))
+        q = f.forward("critic", state, action, f.buf("q", B, 1), save=True)
+        loss, dq = f.buf("loss_c", 1), f.buf("dq", B, 1)
+        loss.zero_()
+        self.backend.td_huber(q.view(-1), None, qn.view(-1), None, None, 0.0, reward, done, ag.gamma, loss, dq.view(-1),
+                              None)
+        ag.flat.grad.zero_()
+        f.backward("critic", state, action, dq)
+        self.last_losses["critic"] = loss[0]
+
+    def _actor_update(self, cols):
+        if self.fused is None:
+            return super()._actor_update(cols)
+        f, ag, B, k = self.fused, self.agent, self.batch_size, self.kernels
+        state = cols[0]
+        ap_det = self._actor_out("actor", state, save=True)
+        self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * B, _SALT_ACTOR, hip_ops.STREAM_POLICY,
+                                   self.vec.ctrl)
+        noise = self._noise_b.view(-1)
+        actions = self._complete_only(state, ap_det, noise)
+        q = f.forward("critic", state, actions, f.buf("q", B, 1), save=True)
+        lag, g_act = f.buf("loss_lag", 1), f.buf("g_act", B, k.action_dim)
+        lag.zero_()
+        ag.nju.weight.grad.zero_()
+        ag.lamb.weight.grad.zero_()
+        k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1))
+        ag.flat.grad.zero_()
+        dq = f.buf("dq", B, 1)
+        dq.fill_(-1.0 / B)
+        da = f.buf("da", B, k.action_dim)
+        shared = ag.flat.sizes[1] > 0      # shared embedding: the critic path contributes to its gradient (SURVEY H9)
+        f.backward("critic", state, actions, dq, da=da, param_grads=shared, first_layer_state_only=True)
+        da.add_(g_act)
+        dap, do = f.buf("dap", B), f.buf("do", B, 1)
+        k.complete_bwd(state, da, dap)
+        scale, base = self._box_affine
+        self.backend.tanh_box_bwd(dap, ap_det, noise, self.eps_start, self.eps, self.decay_value, self.vec.ctrl,
+                                  self._box_lo, self._box_hi, scale, base, do.view(-1))
+        f.backward("actor", state, None, do)
+        loss = lag[0] - q.mean()
+        self.last_losses["actor"] = loss
+        return loss
 
     # ---- losses ---------------------------------------------------------------------------------------------
     def critic_loss(self, state, action, next_state, done, reward, ineq_viol=None, eq_viol=None):

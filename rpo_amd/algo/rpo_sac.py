@@ -43,15 +43,90 @@ class RPOSAC(RPOTrainerBase):
         return buf
 
     # ---- rollout policy (rpo_sac.py:102-110, agent/sac_pa.py:105-115) -------------------------------------------
+    def _gauss(self, obs, eps, tag, save=False, deterministic=False, want_logp=True):
+        """Fused squashed-Gaussian policy: MLP kernel -> (mean, log-std head) -> rpo_gauss_head.  Returns the clipped
+        basic action [n] and log pi [n]."""
+        f = self.fused
+        n = obs.shape[0]
+        raw = f.forward("actor", obs, None, f.buf(tag + ".raw", n, 2), save=save)
+        ap = f.buf(tag + ".ap", n)
+        logp = f.buf(tag + ".logp", n) if want_logp else None
+        scale, base = self._box_affine
+        self.backend.gauss_head(raw, eps.view(-1), scale, base, self._box_lo, self._box_hi, deterministic, ap, logp)
+        return ap, logp, raw
+
     def _policy_partial(self, obs, warm):
         if warm:
             return None, hip_ops.NOISE_UNIFORM
         eps = self._draw(self._noise_n, self.vec.env_id_base, 0)
+        if self.fused is not None:
+            return self._gauss(obs, eps, "roll", want_logp=False)[0], hip_ops.NOISE_NONE     # already clipped
         ap, _, _ = self.agent.actor(obs, eps=eps)                   # rsample of the squashed Gaussian
         return ap.reshape(-1), hip_ops.NOISE_CLIP_ONLY              # the box clip happens inside the kernel
 
     def _eval_partial(self, obs):
+        if self.fused is not None:
+            zeros = self.fused.buf("eval.eps", obs.shape[0])
+            return self._gauss(obs, zeros, "eval", deterministic=True, want_logp=False)[0]
         return self.agent.actor(obs)[2].reshape(-1)                 # the mean action (deterministic=True)
+
+    # ---- the update through the hand-written MLP kernels (same arithmetic as critic_loss / actor_loss below) ------
+    def _critic_update(self, cols):
+        if self.fused is None:
+            return super()._critic_update(cols)
+        f, ag, B = self.fused, self.agent, self.batch_size
+        state, action, next_state, reward, done = cols[:5]
+        eps = self._draw(self._noise_b, self.dist.rank * B, _SALT_CRITIC)
+        ap_next, logp, _ = self._gauss(next_state, eps, "crit")
+        next_actions = self._project_batch(next_state, ap_next)
+        qn1 = f.forward("critic_target1", next_state, next_actions, f.buf("qn1", B, 1))
+        qn2 = f.forward("critic_target2", next_state, next_actions, f.buf("qn2", B, 1))
+        q1 = f.forward("critic1", state, action, f.buf("q1", B, 1), save=True)
+        q2 = f.forward("critic2", state, action, f.buf("q2", B, 1), save=True)
+        loss, dq1, dq2 = f.buf("loss_c", 1), f.buf("dq1", B, 1), f.buf("dq2", B, 1)
+        loss.zero_()
+        self.backend.td_huber(q1.view(-1), q2.view(-1), qn1.view(-1), qn2.view(-1), logp, float(ag.alpha), reward, done,
+                              ag.gamma, loss, dq1.view(-1), dq2.view(-1))
+        ag.flat.grad.zero_()
+        f.backward("critic1", state, action, dq1)
+        f.backward("critic2", state, action, dq2)
+        self.last_losses["critic"] = loss[0]
+
+    def _actor_update(self, cols):
+        if self.fused is None:
+            return super()._actor_update(cols)
+        f, ag, B, k = self.fused, self.agent, self.batch_size, self.kernels
+        state = cols[0]
+        eps = self._draw(self._noise_b, self.dist.rank * B, _SALT_ACTOR)
+        ap, logp, raw = self._gauss(state, eps, "pi", save=True)
+        actions = self._complete_only(state, ap)
+        q1 = f.forward("critic1", state, actions, f.buf("q1", B, 1), save=True)
+        q2 = f.forward("critic2", state, actions, f.buf("q2", B, 1), save=True)
+        lag, g_act = f.buf("loss_lag", 1), f.buf("g_act", B, k.action_dim)
+        lag.zero_()
+        ag.nju.weight.grad.zero_()
+        ag.lamb.weight.grad.zero_()
+        k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1))
+        ag.flat.grad.zero_()
+        # d(-min(q1, q2))/dq: the smaller one takes the gradient, ties are split (torch.min's backward)
+        w1 = (q1 < q2).to(torch.float32) + 0.5 * (q1 == q2).to(torch.float32)
+        dq1, dq2 = f.buf("dq1", B, 1), f.buf("dq2", B, 1)
+        torch.mul(w1, -1.0 / B, out=dq1)
+        torch.mul(1.0 - w1, -1.0 / B, out=dq2)
+        da1, da2 = f.buf("da1", B, k.action_dim), f.buf("da2", B, k.action_dim)
+        shared = ag.flat.sizes[1] > 0
+        f.backward("critic1", state, actions, dq1, da=da1, param_grads=shared, first_layer_state_only=True)
+        f.backward("critic2", state, actions, dq2, da=da2, param_grads=shared, first_layer_state_only=True)
+        da1.add_(da2).add_(g_act)
+        dap, draw = f.buf("dap", B), f.buf("draw", B, 2)
+        k.complete_bwd(state, da1, dap)
+        scale, base = self._box_affine
+        self.backend.gauss_head_bwd(raw, eps.view(-1), dap, float(ag.alpha) / B, scale, base, self._box_lo, self._box_hi,
+                                    draw)
+        f.backward("actor", state, None, draw)
+        loss = lag[0] + (float(ag.alpha) * logp.view(-1, 1) - torch.min(q1, q2)).mean()
+        self.last_losses["actor"] = loss
+        return loss, logp.view(-1, 1)
 
     # ---- losses ---------------------------------------------------------------------------------------------
     def critic_loss(self, state, action, next_state, done, reward, ineq_viol=None, eq_viol=None):

@@ -19,6 +19,7 @@ import torch
 import torch.distributed as dist
 
 from .. import ops as hip_ops
+from .agent.fused import FusedNets
 from .model import BoxConstraint
 
 _SALT_CRITIC = 1 << 20      # Philox index offsets that separate the update step's draws from the rollout's
@@ -172,6 +173,11 @@ class RPOTrainerBase(object):
         # projection of training batches: the reference's literal batched semantics (default) or row-wise
         # (RPO_ROWWISE_PROJECTION=1); rollouts are always per lane == the reference's B = 1 calls
         self.batch_reference = not bool(_env_int("RPO_ROWWISE_PROJECTION", 0))
+        # hand-written f32-MFMA MLP kernels for actor / critics (RPO_FUSED_MLP=0: the torch modules + autograd)
+        self.fused = FusedNets.build(agent, self.backend, device) if _env_int("RPO_FUSED_MLP", 1) else None
+        box = agent.actor.box_constraint
+        self._box_affine = (float(np.asarray(box.scale).reshape(-1)[0]), float(np.asarray(box.base).reshape(-1)[0])) \
+            if box is not None and not box.volatile else None
         self._t = 0                 # loop iterations (== vector steps) done
         self._harvested = 0         # vector steps whose statistics were already pulled off the device
         self._pending = []          # per-step rows waiting for the return of the episodes they belong to
@@ -297,6 +303,20 @@ class RPOTrainerBase(object):
             out = self._actor_update(cols)
             self.dist.mean_([fl.gradient(fl.actor_range), self.agent.nju.weight.grad])
             self._actor_step(out)
+
+    # ------------------------------------------------------------------------------------------ fused-MLP helpers
+    def _project_batch(self, state, ap_flat):
+        """Training-batch projection of `ap_flat` [B] -> actions [B, A] (same semantics as process_action)."""
+        return self.process_action(state, ap_flat)
+
+    def _complete_only(self, state, ap_flat, noise=None):
+        """clip(ap + eps_t * noise) -> equation solver, no GRG steps (actor loss, rpo_ddpg.py:309-310)."""
+        f = self.fused
+        act = f.buf("act_pi", ap_flat.shape[0], self.kernels.action_dim)
+        mode = hip_ops.NOISE_NONE if noise is None else hip_ops.NOISE_EXPLICIT
+        self.kernels.act_project(state, ap_flat, noise, act, None, mode, self.eps_start, self.eps, self.decay_value,
+                                 self._box_lo, self._box_hi, 0, 0.0, self.corr_eps, 0.0, self.seed, 0, self.vec.ctrl, None)
+        return act
 
     # ------------------------------------------------------------------------------------------ main loop
     def run(self, logger=None, eval=True):

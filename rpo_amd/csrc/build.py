@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["cartsafe.hip", "pendulum.hip", "replay.hip", "train_ops.hip"]
+SOURCES = ["cartsafe.hip", "pendulum.hip", "replay.hip", "train_ops.hip", "mlp.hip"]
 HEADERS = ["common.h", os.path.join("..", "..", "include", "rpo_hip.h")]
 TARGET = os.path.join(HERE, "librpo_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

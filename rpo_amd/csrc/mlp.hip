@@ -1,0 +1,668 @@
+// Small-MLP forward / backward for the RPO actor and critics on MI355X, exact f32 on the matrix cores.
+//
+// Every network of the reference's agents (rpo/algo/model/{embedding,policy,value}.py with hidden_layer = 1) is
+//     x0 = s Ws^T + bs (+ a Wa^T + ba | concatenated)      first layer, K = S (+A) <= ~100      -> VALU
+//     h1 = relu(x0) W0^T + b0                              Ein -> H (128 -> 256): all the flops  -> MFMA
+//     out = relu(h1) W1^T + b1                             H -> n_out (1 or 2)                   -> wave reductions
+// rocBLAS runs these M = 256 .. 4096 GEMMs in 8-36 us each (one or two macro-tiles busy); here one workgroup owns 16
+// rows through all three layers (activations stay in LDS / accumulators) and the backward pass is two launches.
+//
+// v_mfma_f32_16x16x4_f32 is an exact k-ordered fmaf chain.  Operand maps (wave64): A[i = l&15][k = l>>4],
+// B[k = l>>4][j = l&15], C/D col = l&15, row = 4*(l>>4) + reg.  Weights keep torch's nn.Linear layout [out][in]:
+//   forward   h1[r][j] = sum_k x1[r][k] W0[j][k]   K-contiguous: each lane loads a float4 along k (A from LDS the same
+//             way) and feeds 4 consecutive MFMAs -- an MFMA only needs A and B to agree on which k sits in slot l>>4;
+//   backward  dx0[r][e] = sum_j dh[r][j] W0[j][e]  N-contiguous: a float4 along e serves 4 interleaved output tiles
+//             (tile c, column n <-> e = 4n + c) that share the A operand;
+//   weights   dW0[j][e] = sum_b dh[b][j] x1[b][e]  both operands contiguous in their M / N index.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRows = 16;          // rows (samples) per workgroup
+constexpr int kThreads = 256;      // 4 waves
+
+struct Mlp {
+    const float *Ws, *bs, *Wa, *ba, *W0, *b0, *W1, *b1, *W1b, *b1b;   // W1b / b1b: second head (SAC log-std), n_out = 2
+    int S, A, E, H, n_out, cat;
+};
+struct MlpGrad {
+    float *Ws, *bs, *Wa, *ba, *W0, *b0, *W1, *b1, *W1b, *b1b;
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------- forward
+// out_mode: 0 identity, 1 tanh-box on output 0 (scale * tanh(o) + base; BoxConstraint, model/utils.py:40-51)
+struct FwdArgs {
+    Mlp net;
+    int n;
+    const float* s; int s_stride;
+    const float* a; int a_stride;
+    float* out;            // [n, n_out]
+    float* x0_save;        // [n, Ein] pre-activation of the first layer (NULL: not saved)
+    float* h1_save;        // [n, H]   pre-activation of the hidden layer (NULL: not saved)
+    int out_mode; float scale, base;
+};
+
+constexpr int kFwdWaves = 8;       // forward: 512 threads, every wave owns H / 8 hidden columns
+constexpr int kFwdThreads = kFwdWaves * 64;
+
+template <int EIN, int H>
+__global__ __launch_bounds__(kFwdThreads) void mlp_forward_kernel(FwdArgs p) {
+    constexpr int LDX = EIN + 4;                               // padded row stride of x1 (ds_read_b128, 16-B aligned)
+    __shared__ __attribute__((aligned(16))) float x1[kRows * LDX];
+    __shared__ float in_s[kRows * 64];                         // inputs of this row tile (S <= 64)
+    __shared__ float in_a[kRows * 48];                         // (A <= 48)
+    __shared__ float part[kFwdWaves * kRows * 2];
+    const Mlp& net = p.net;
+    const int row0 = blockIdx.x * kRows;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+
+    // ---- the wave's slice of W0 starts moving now; its latency hides behind the input staging and layer 1
+    constexpr int NT = H / (16 * kFwdWaves);                    // 16-column tiles per wave
+    constexpr int ITS = EIN / 16;                               // k-groups of 16
+    constexpr int PRE = ITS < 16 ? ITS : 16;                    // k-groups kept in registers up front
+    const int j0 = wave * (H / kFwdWaves);
+    float4 wpre[PRE][NT];
+#pragma unroll
+    for (int it = 0; it < PRE; ++it)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+            wpre[it][c] = *reinterpret_cast<const float4*>(&net.W0[(size_t)(j0 + c * 16 + li) * EIN + it * 16 + lg * 4]);
+
+    // the caches are cold at kernel entry and every dependent global read costs ~0.7 us of exposed latency with one
+    // or two waves per SIMD: everything the epilogue needs is requested now as well
+    float b0v[NT], w1av[NT], w1bv[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        b0v[c] = net.b0[j0 + c * 16 + li];
+        w1av[c] = net.W1[j0 + c * 16 + li];
+        w1bv[c] = net.n_out > 1 ? net.W1b[j0 + c * 16 + li] : 0.0f;
+    }
+    const float b1v = (tid < kRows * net.n_out) ? (((tid % net.n_out) == 0) ? net.b1[0] : net.b1b[0]) : 0.0f;
+
+    for (int idx = tid; idx < kRows * net.S; idx += kFwdThreads) {
+        const int r = idx / net.S, i = idx - r * net.S;
+        in_s[r * 64 + i] = (row0 + r < p.n) ? p.s[(size_t)(row0 + r) * p.s_stride + i] : 0.0f;
+    }
+    for (int idx = tid; idx < kRows * net.A; idx += kFwdThreads) {
+        const int r = idx / net.A, i = idx - r * net.A;
+        in_a[r * 48 + i] = (row0 + r < p.n) ? p.a[(size_t)(row0 + r) * p.a_stride + i] : 0.0f;
+    }
+    // first-layer weights of this thread's embedding column, fetched in chunks of 8 before they are needed
+    const int e_col = tid;                                      // EIN <= 512 == kFwdThreads: one column per thread
+    const bool has_col = e_col < EIN;
+    const bool act_part = has_col && net.cat && e_col >= net.E; // concatenating critic: columns [E, 2E) embed the action
+    const int er = act_part ? e_col - net.E : e_col;
+    float acc1[kRows];
+    float ws0[8], wa0[8];                                       // first chunk of this column's first-layer weights
+    {
+        const float bias = !has_col ? 0.0f
+                                    : (act_part ? net.ba[er] : (net.bs[er] + ((net.A > 0 && !net.cat) ? net.ba[er] : 0.0f)));
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) acc1[r] = bias;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            ws0[u] = (has_col && !act_part && u < net.S) ? net.Ws[er * net.S + u] : 0.0f;
+            wa0[u] = (has_col && net.A > 0 && (act_part || !net.cat) && u < net.A) ? net.Wa[er * net.A + u] : 0.0f;
+        }
+    }
+    __syncthreads();
+
+    // ---- layer 1 (VALU): x0[r][e]
+    if (has_col) {
+        if (!act_part) {
+            for (int i0 = 0; i0 < net.S; i0 += 8) {
+                float w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = (i0 == 0) ? ws0[u] : ((i0 + u < net.S) ? net.Ws[er * net.S + i0 + u] : 0.0f);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (i0 + u < net.S) {
+#pragma unroll
+                        for (int r = 0; r < kRows; ++r) acc1[r] = fmaf(in_s[r * 64 + i0 + u], w[u], acc1[r]);
+                    }
+                }
+            }
+        }
+        if (net.A > 0 && (act_part || !net.cat)) {
+            for (int i0 = 0; i0 < net.A; i0 += 8) {
+                float w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = (i0 == 0) ? wa0[u] : ((i0 + u < net.A) ? net.Wa[er * net.A + i0 + u] : 0.0f);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (i0 + u < net.A) {
+#pragma unroll
+                        for (int r = 0; r < kRows; ++r) acc1[r] = fmaf(in_a[r * 48 + i0 + u], w[u], acc1[r]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            if (p.x0_save && row0 + r < p.n) p.x0_save[(size_t)(row0 + r) * EIN + e_col] = acc1[r];
+            x1[r * LDX + e_col] = fmaxf(acc1[r], 0.0f);
+        }
+    }
+    __syncthreads();
+
+    // ---- layer 2 (MFMA): wave w owns hidden columns [w*H/8, (w+1)*H/8) = NT tiles of 16
+    f32x4 acc[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+        const float4 a4 = *reinterpret_cast<const float4*>(&x1[li * LDX + it * 16 + lg * 4]);
+        float4 b4[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+            b4[c] = (it < PRE) ? wpre[it < PRE ? it : 0][c]
+                               : *reinterpret_cast<const float4*>(&net.W0[(size_t)(j0 + c * 16 + li) * EIN + it * 16 + lg * 4]);
+        // consecutive MFMAs go to different accumulators (40-cycle dependent latency vs 32-cycle issue)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] = mfma4(a4.x, b4[c].x, acc[c]);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] = mfma4(a4.y, b4[c].y, acc[c]);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] = mfma4(a4.z, b4[c].z, acc[c]);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] = mfma4(a4.w, b4[c].w, acc[c]);
+    }
+    // acc[c][i] = h1[row = 4*lg + i][col = j0 + 16c + li] (before bias)
+    float po[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const int col = j0 + c * 16 + li;
+        const float b0 = b0v[c];
+        const float w1a = w1av[c], w1b = w1bv[c];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float h = acc[c][i] + b0;
+            const int row = row0 + lg * 4 + i;
+            if (p.h1_save && row < p.n) p.h1_save[(size_t)row * H + col] = h;
+            const float hr = fmaxf(h, 0.0f);
+            po[0][i] = fmaf(hr, w1a, po[0][i]);
+            po[1][i] = fmaf(hr, w1b, po[1][i]);
+        }
+    }
+    // ---- head: reduce over the 16 lanes that share lg, then over the waves (fixed order)
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = po[o][i];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            if (li == 0) part[(wave * kRows + lg * 4 + i) * 2 + o] = v;
+        }
+    __syncthreads();
+    if (tid < kRows * net.n_out) {
+        const int r = tid / net.n_out, o = tid - r * net.n_out;
+        if (row0 + r < p.n) {
+            float v = b1v;
+            for (int w = 0; w < kFwdWaves; ++w) v += part[(w * kRows + r) * 2 + o];
+            if (p.out_mode == 1 && o == 0) v = p.scale * tanhf(v) + p.base;
+            p.out[(size_t)(row0 + r) * net.n_out + o] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- backward, rows
+// Per row tile: dh = (dout W1) * 1[h1 > 0]  -> global (for the weights pass) and LDS; dW1 / db1 / db0 partial sums
+// (one atomic per value per workgroup); dx0 = (dh W0) * 1[x0 > 0] -> global; optionally da = dx0_a Wa.
+struct BwdArgs {
+    Mlp net;
+    MlpGrad g;
+    int n;
+    const float* s; int s_stride;
+    const float* a; int a_stride;
+    const float* x0;       // [n, Ein] saved by forward
+    const float* h1;       // [n, H]
+    const float* dout;     // [n, n_out]
+    float* dh;             // [n, H]   scratch
+    float* dx0;            // [n, Ein] scratch
+    float* da;             // [n, A] or NULL: gradient w.r.t. the action input
+    int param_grads;       // 0: only dx0 / da are needed (critic inside the actor loss, non-shared embedding)
+    int first_layer_state_only;   // 1: of the parameter gradients only dWs / dbs are accumulated (shared embedding)
+};
+
+template <int EIN, int H>
+__global__ __launch_bounds__(kThreads) void mlp_bwd_rows_kernel(BwdArgs p) {
+    constexpr int LDH = H + 4;
+    __shared__ __attribute__((aligned(16))) float dh_s[kRows * LDH];
+    __shared__ __attribute__((aligned(16))) float red[kRows * EIN];              // dx0 of the tile (waves add into it)
+    __shared__ float dout_s[kRows * 2];
+    const Mlp& net = p.net;
+    const int row0 = blockIdx.x * kRows;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < kRows * 2) {
+        const int r = tid >> 1, o = tid & 1;
+        dout_s[tid] = (o < net.n_out && row0 + r < p.n) ? p.dout[(size_t)(row0 + r) * net.n_out + o] : 0.0f;
+    }
+    __syncthreads();
+    // ---- dh (thread = hidden column j); the batch reductions dW1 / db0 / db1 happen in the weights pass, in a fixed
+    //      order, so that the whole backward is bitwise reproducible (no floating-point atomics anywhere)
+    for (int j = tid; j < H; j += kThreads) {
+        const float w1a = net.W1[j], w1b = net.n_out > 1 ? net.W1b[j] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            const bool live = row0 + r < p.n;
+            const float h = live ? p.h1[(size_t)(row0 + r) * H + j] : 0.0f;
+            const float d = (h > 0.0f) ? fmaf(dout_s[r * 2 + 1], w1b, dout_s[r * 2] * w1a) : 0.0f;
+            dh_s[r * LDH + j] = d;
+            if (live) p.dh[(size_t)(row0 + r) * H + j] = d;
+        }
+    }
+    __syncthreads();
+
+    // ---- dx0 partials (MFMA): wave w sums over hidden j in [w*H/4, (w+1)*H/4), all EIN columns
+    constexpr int NV = EIN / 64;                                   // float4 loads per k-step; 4 interleaved tiles each
+    f32x4 acc[NV][4];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[v][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int li = lane & 15, lg = lane >> 4;
+    const int jw = wave * (H / 4);
+#pragma unroll 8
+    for (int ks = 0; ks < H / 16; ++ks) {
+        const int j = jw + ks * 4 + lg;
+        const float av = dh_s[li * LDH + j];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float4 b4 = *reinterpret_cast<const float4*>(&net.W0[(size_t)j * EIN + v * 64 + li * 4]);
+            acc[v][0] = mfma4(av, b4.x, acc[v][0]);
+            acc[v][1] = mfma4(av, b4.y, acc[v][1]);
+            acc[v][2] = mfma4(av, b4.z, acc[v][2]);
+            acc[v][3] = mfma4(av, b4.w, acc[v][3]);
+        }
+    }
+    // acc[v][c][i] = partial dx0[row = 4*lg + i][e = 64v + 4*li + c]
+    for (int w = 0; w < 4; ++w) {                                  // waves add their partials in a fixed order
+        if (wave == w) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float4* dst = reinterpret_cast<float4*>(&red[(lg * 4 + i) * EIN + v * 64 + li * 4]);
+                    float4 o = make_float4(acc[v][0][i], acc[v][1][i], acc[v][2][i], acc[v][3][i]);
+                    if (w > 0) { const float4 c = *dst; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+                    *dst = o;
+                }
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < kRows * EIN; idx += kThreads) {
+        const int r = idx / EIN, e = idx - r * EIN;
+        float v = red[idx];
+        const bool live = row0 + r < p.n;
+        const float x = live ? p.x0[(size_t)(row0 + r) * EIN + e] : 0.0f;
+        v = (x > 0.0f) ? v : 0.0f;
+        red[idx] = v;                                              // masked dx0 of this tile (for da below)
+        if (live) p.dx0[(size_t)(row0 + r) * EIN + e] = v;
+    }
+    if (p.da) {
+        __syncthreads();
+        const int eoff = net.cat ? net.E : 0;                      // action embedding columns inside x0
+        for (int idx = tid; idx < kRows * net.A; idx += kThreads) {
+            const int r = idx / net.A, i = idx - r * net.A;
+            if (row0 + r < p.n) {
+                float s = 0.0f;
+                for (int e = 0; e < net.E; ++e) s = fmaf(red[r * EIN + eoff + e], net.Wa[e * net.A + i], s);
+                p.da[(size_t)(row0 + r) * net.A + i] = s;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward, weights
+// Workgroups [0, H/16 * EIN/256): dW0 tiles (wave = 16 hidden rows x 64 input columns, K = batch); one more
+// workgroup accumulates the first-layer gradients dWs / dbs / dWa / dba from dx0, and the last one db0 / dW1 / db1.
+// Every output element has exactly one owner and a fixed summation order: the backward pass is bitwise reproducible.
+template <int EIN, int H>
+__global__ __launch_bounds__(kThreads) void mlp_bwd_weights_kernel(BwdArgs p) {
+    const Mlp& net = p.net;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int GEMM_BLOCKS = (H / 16) * (EIN / 64);           // one 16 x 64 tile of dW0 per workgroup
+    if ((int)blockIdx.x < GEMM_BLOCKS) {
+        if (!p.param_grads || p.first_layer_state_only) return;
+        // the 4 waves split the batch (K) and combine through LDS in a fixed order
+        __shared__ __attribute__((aligned(16))) float tile[4][16 * 64];
+        const int jt = blockIdx.x / (EIN / 64), et = blockIdx.x - jt * (EIN / 64);
+        const int li = lane & 15, lg = lane >> 4;
+        const int j = jt * 16 + li, e0 = et * 64 + li * 4;
+        f32x4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const int nk = (p.n + 3) / 4;                              // k-steps of 4 samples
+        const int ks_lo = (nk * wave) / 4, ks_hi = (nk * (wave + 1)) / 4;
+        const int last = p.n - 1;
+        int ks = ks_lo;
+        for (; ks + 4 <= ks_hi; ks += 4) {                         // 4 k-steps of loads in flight before their MFMAs
+            float av[4];
+            float4 bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = (ks + u) * 4 + lg;
+                const int bc = b < last ? b : last;
+                av[u] = p.dh[(size_t)bc * H + j];
+                bv[u] = *reinterpret_cast<const float4*>(&p.x0[(size_t)bc * EIN + e0]);
+                if (b > last) av[u] = 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[0] = mfma4(av[u], fmaxf(bv[u].x, 0.0f), acc[0]);
+                acc[1] = mfma4(av[u], fmaxf(bv[u].y, 0.0f), acc[1]);
+                acc[2] = mfma4(av[u], fmaxf(bv[u].z, 0.0f), acc[2]);
+                acc[3] = mfma4(av[u], fmaxf(bv[u].w, 0.0f), acc[3]);
+            }
+        }
+        for (; ks < ks_hi; ++ks) {
+            const int b = ks * 4 + lg;
+            const int bc = b < last ? b : last;
+            float av = p.dh[(size_t)bc * H + j];
+            const float4 b4 = *reinterpret_cast<const float4*>(&p.x0[(size_t)bc * EIN + e0]);
+            if (b > last) av = 0.0f;
+            acc[0] = mfma4(av, fmaxf(b4.x, 0.0f), acc[0]);
+            acc[1] = mfma4(av, fmaxf(b4.y, 0.0f), acc[1]);
+            acc[2] = mfma4(av, fmaxf(b4.z, 0.0f), acc[2]);
+            acc[3] = mfma4(av, fmaxf(b4.w, 0.0f), acc[3]);
+        }
+        // acc[c][i] = partial dW0[j = 16 jt + 4 lg + i][e = 64 et + 4 li + c]
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(&tile[wave][(lg * 4 + i) * 64 + li * 4]) =
+                make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+        __syncthreads();
+        {
+            const int r = tid >> 4, c4 = (tid & 15) * 4;           // 256 threads x float4 = the 16 x 64 tile
+            const float4 t0 = *reinterpret_cast<const float4*>(&tile[0][r * 64 + c4]);
+            const float4 t1 = *reinterpret_cast<const float4*>(&tile[1][r * 64 + c4]);
+            const float4 t2 = *reinterpret_cast<const float4*>(&tile[2][r * 64 + c4]);
+            const float4 t3 = *reinterpret_cast<const float4*>(&tile[3][r * 64 + c4]);
+            float4* dst = reinterpret_cast<float4*>(&p.g.W0[(size_t)(jt * 16 + r) * EIN + et * 64 + c4]);
+            float4 cur = *dst;
+            cur.x += ((t0.x + t1.x) + t2.x) + t3.x;
+            cur.y += ((t0.y + t1.y) + t2.y) + t3.y;
+            cur.z += ((t0.z + t1.z) + t2.z) + t3.z;
+            cur.w += ((t0.w + t1.w) + t2.w) + t3.w;
+            *dst = cur;
+        }
+        return;
+    }
+    if (!p.param_grads) return;
+    // ---- batch reductions with one owner per output: 64 outputs per workgroup, the batch split over the 4 waves and
+    //      combined through LDS in a fixed order (bitwise reproducible)
+    __shared__ float partial[4][3][64];
+    const int o = tid & 63, part = tid >> 6;
+    const int b_lo = (int)(((long long)p.n * part) / 4), b_hi = (int)(((long long)p.n * (part + 1)) / 4);
+    const int rb = (int)blockIdx.x - GEMM_BLOCKS;
+    constexpr int HV_BLOCKS = H / 64;
+    if (rb < HV_BLOCKS) {
+        // hidden-layer vectors: db0[j] = sum_b dh[b][j]; dW1_k[j] = sum_b dout[b][k] relu(h1[b][j]); db1_k = sum_b dout[b][k]
+        if (p.first_layer_state_only) return;
+        const int j = rb * 64 + o;
+        float gb0 = 0.0f, gw1a = 0.0f, gw1b = 0.0f;
+        int bb = b_lo;
+        for (; bb + 8 <= b_hi; bb += 8) {
+            float d[8], h[8], oa[8], ob[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                d[u] = p.dh[(size_t)(bb + u) * H + j];
+                h[u] = p.h1[(size_t)(bb + u) * H + j];
+                oa[u] = p.dout[(size_t)(bb + u) * net.n_out];
+                ob[u] = net.n_out > 1 ? p.dout[(size_t)(bb + u) * net.n_out + 1] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                gb0 += d[u];
+                const float hr = fmaxf(h[u], 0.0f);
+                gw1a = fmaf(oa[u], hr, gw1a);
+                gw1b = fmaf(ob[u], hr, gw1b);
+            }
+        }
+        for (; bb < b_hi; ++bb) {
+            gb0 += p.dh[(size_t)bb * H + j];
+            const float hr = fmaxf(p.h1[(size_t)bb * H + j], 0.0f);
+            gw1a = fmaf(p.dout[(size_t)bb * net.n_out], hr, gw1a);
+            if (net.n_out > 1) gw1b = fmaf(p.dout[(size_t)bb * net.n_out + 1], hr, gw1b);
+        }
+        partial[part][0][o] = gb0; partial[part][1][o] = gw1a; partial[part][2][o] = gw1b;
+        __syncthreads();
+        if (part == 0) {
+            p.g.b0[j] += ((partial[0][0][o] + partial[1][0][o]) + partial[2][0][o]) + partial[3][0][o];
+            p.g.W1[j] += ((partial[0][1][o] + partial[1][1][o]) + partial[2][1][o]) + partial[3][1][o];
+            if (net.n_out > 1) p.g.W1b[j] += ((partial[0][2][o] + partial[1][2][o]) + partial[2][2][o]) + partial[3][2][o];
+        }
+        if (rb == 0 && tid < net.n_out) {
+            float sacc = 0.0f;
+            for (int b2 = 0; b2 < p.n; ++b2) sacc += p.dout[(size_t)b2 * net.n_out + tid];
+            if (tid == 0) p.g.b1[0] += sacc; else p.g.b1b[0] += sacc;
+        }
+        return;
+    }
+    // first layer: output list idx = q * E + e (e fastest: coalesced dx0 reads); q < wS: state weights / bias,
+    // q >= wS: action weights / bias.  Columns of x0: [0, E) <- state (+ action when added); [E, 2E) <- action (cat).
+    const int wS = net.S + 1, wA = (net.A > 0 && !p.first_layer_state_only) ? net.A + 1 : 0;   // +1: the bias
+    const int idx = (rb - HV_BLOCKS) * 64 + o;
+    const bool valid = idx < net.E * (wS + wA);
+    float acc = 0.0f;
+    int e = 0, i = 0, width = 0;
+    bool is_a = false;
+    if (valid) {
+        e = idx % net.E;
+        const int q = idx / net.E;
+        is_a = q >= wS;
+        i = is_a ? q - wS : q;
+        width = is_a ? net.A : net.S;
+        const int col = (is_a && net.cat) ? net.E + e : e;
+        const float* in = is_a ? p.a : p.s;
+        const int stride = is_a ? p.a_stride : p.s_stride;
+        const bool is_w = i < width;
+        int bb = b_lo;
+        for (; bb + 8 <= b_hi; bb += 8) {
+            float d[8], x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                d[u] = p.dx0[(size_t)(bb + u) * EIN + col];
+                x[u] = is_w ? in[(size_t)(bb + u) * stride + i] : 1.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(d[u], x[u], acc);
+        }
+        for (; bb < b_hi; ++bb) acc = fmaf(p.dx0[(size_t)bb * EIN + col], is_w ? in[(size_t)bb * stride + i] : 1.0f, acc);
+    }
+    partial[part][0][o] = acc;
+    __syncthreads();
+    if (part == 0 && valid) {
+        const float tot = ((partial[0][0][o] + partial[1][0][o]) + partial[2][0][o]) + partial[3][0][o];
+        float* dst = (i < width) ? (is_a ? &p.g.Wa[e * net.A + i] : &p.g.Ws[e * net.S + i]) : (is_a ? &p.g.ba[e] : &p.g.bs[e]);
+        *dst += tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- policy heads
+// DDPG head backward (model/policy.py:30-31 + agent/ddpg_pa.py:108-110): ap = clip(scale*tanh(o)+base + eps_t*noise);
+// dout = dap * 1[lo <= ap_noisy <= hi] * scale * (1 - tanh(o)^2), tanh(o) recovered from the stored deterministic ap.
+__global__ __launch_bounds__(RPO_BLOCK) void tanh_box_bwd_kernel(int n, const float* __restrict__ dap,
+                                                                 const float* __restrict__ ap_det,
+                                                                 const float* __restrict__ noise, float eps_start,
+                                                                 float eps_end, float eps_decay,
+                                                                 const long long* __restrict__ ctrl, float lo, float hi,
+                                                                 float scale, float base, float* __restrict__ dout) {
+    const float t = ctrl ? (float)ctrl[RPO_CTRL_T] : 0.0f;
+    const float eps_t = fmaxf(eps_end, eps_start - eps_decay * t);
+    for (int i = blockIdx.x * RPO_BLOCK + threadIdx.x; i < n; i += gridDim.x * RPO_BLOCK) {
+        const float a = ap_det[i];
+        const float x = noise ? a + eps_t * noise[i] : a;
+        const float y = (a - base) / scale;
+        const bool pass = !noise || (x >= lo && x <= hi);
+        dout[i] = pass ? dap[i] * scale * (1.0f - y * y) : 0.0f;
+    }
+}
+
+// Squashed-Gaussian head (GaussianSharedPolicy.forward, model/policy.py:53-66, + the clip of PDSAC_PA.take_action,
+// agent/sac_pa.py:111): raw = (mean, log-std head output); eps = the standard-normal draw of rsample.
+constexpr float kLogSigMin = -23.0f, kLogSigMax = -2.0f, kHalfLog2Pi = 0.9189385332046727f;
+
+__global__ __launch_bounds__(RPO_BLOCK) void gauss_head_kernel(int n, const float* __restrict__ raw,
+                                                               const float* __restrict__ eps, float scale, float base,
+                                                               float lo, float hi, int deterministic,
+                                                               float* __restrict__ ap_out, float* __restrict__ logp_out) {
+    for (int i = blockIdx.x * RPO_BLOCK + threadIdx.x; i < n; i += gridDim.x * RPO_BLOCK) {
+        const float2 r = reinterpret_cast<const float2*>(raw)[i];
+        const float ls = fminf(fmaxf(r.y - 3.0f, kLogSigMin), kLogSigMax);
+        const float e = eps[i];
+        const float x = r.x + e * expf(ls);
+        const float y = tanhf(x);
+        if (logp_out) logp_out[i] = -0.5f * e * e - ls - kHalfLog2Pi - logf(scale * (1.0f - y * y) + 1e-6f);
+        const float a = deterministic ? scale * tanhf(r.x) + base : scale * y + base;
+        ap_out[i] = fminf(fmaxf(a, lo), hi);
+    }
+}
+
+// d(loss)/d(raw) given d/d(ap) per row and a uniform d/d(log_prob) (SAC actor loss: alpha / B, rpo_sac.py:331).
+__global__ __launch_bounds__(RPO_BLOCK) void gauss_head_bwd_kernel(int n, const float* __restrict__ raw,
+                                                                   const float* __restrict__ eps,
+                                                                   const float* __restrict__ dap, float dlogp,
+                                                                   float scale, float base, float lo, float hi,
+                                                                   float* __restrict__ draw) {
+    for (int i = blockIdx.x * RPO_BLOCK + threadIdx.x; i < n; i += gridDim.x * RPO_BLOCK) {
+        const float2 r = reinterpret_cast<const float2*>(raw)[i];
+        const float lsr = r.y - 3.0f;
+        const float ls = fminf(fmaxf(lsr, kLogSigMin), kLogSigMax);
+        const float sd = expf(ls), e = eps[i];
+        const float y = tanhf(r.x + e * sd);
+        const float omy = 1.0f - y * y;
+        const float a = scale * y + base;
+        const float g_ap = (a >= lo && a <= hi) ? dap[i] * scale * omy : 0.0f;
+        const float g_lp = dlogp * (2.0f * scale * y * omy) / (scale * omy + 1e-6f);
+        const float gx = g_ap + g_lp;
+        const float dls = gx * e * sd - dlogp;
+        reinterpret_cast<float2*>(draw)[i] = make_float2(gx, (lsr >= kLogSigMin && lsr <= kLogSigMax) ? dls : 0.0f);
+    }
+}
+
+int check_net(const Mlp& m) {
+    if (m.S <= 0 || m.S > 64 || m.A < 0 || m.A > 48 || m.n_out < 1 || m.n_out > 2) return RPO_ERR_ARG;
+    if (!m.Ws || !m.bs || !m.W0 || !m.b0 || !m.W1 || !m.b1 || (m.A > 0 && (!m.Wa || !m.ba))) return RPO_ERR_NULL;
+    if (m.n_out > 1 && (!m.W1b || !m.b1b)) return RPO_ERR_NULL;
+    if (m.cat && m.A == 0) return RPO_ERR_ARG;
+    return 0;
+}
+
+// supported (Ein, H): (128,256) cart / pendulum scripts; (256,256); (512,256) concatenating critic with E = 256
+#define RPO_MLP_DISPATCH(EIN_, H_, KERNEL, GRID, ARGS)                                                    \
+    if (ein == EIN_ && net.H == H_) {                                                                       \
+        hipLaunchKernelGGL((KERNEL<EIN_, H_>), dim3(GRID), dim3(kFwdThreads), 0, (hipStream_t)stream, ARGS); \
+        RPO_LAUNCH_CHECK();                                                                                 \
+        return 0;                                                                                           \
+    }
+
+}  // namespace
+
+extern "C" {
+
+int rpo_mlp_supported(int E, int H, int cat) {
+    const int ein = cat ? 2 * E : E;
+    return (H == 256 && (ein == 128 || ein == 256 || ein == 512)) ? 1 : 0;   // instantiated (Ein, H) pairs
+}
+
+int rpo_mlp_forward(const rpo_mlp* net_host, int n, const float* s, int s_stride, const float* a, int a_stride,
+                    float* out, float* x0_save, float* h1_save, int out_mode, float scale, float base, void* stream) {
+    if (!net_host) return RPO_ERR_NULL;
+    Mlp net{net_host->Ws, net_host->bs, net_host->Wa, net_host->ba, net_host->W0, net_host->b0, net_host->W1,
+            net_host->b1, net_host->W1b, net_host->b1b, net_host->S, net_host->A, net_host->E, net_host->H,
+            net_host->n_out, net_host->cat};
+    if (int e = check_net(net)) return e;
+    if (n <= 0 || s_stride < net.S || (net.A > 0 && a_stride < net.A)) return RPO_ERR_ARG;
+    if (!s || !out || (net.A > 0 && !a)) return RPO_ERR_NULL;
+    const int ein = net.cat ? 2 * net.E : net.E;
+    FwdArgs args{net, n, s, s_stride, a, a_stride, out, x0_save, h1_save, out_mode, scale, base};
+    const int grid = (n + kRows - 1) / kRows;
+    RPO_MLP_DISPATCH(128, 256, mlp_forward_kernel, grid, args)
+    RPO_MLP_DISPATCH(256, 256, mlp_forward_kernel, grid, args)
+    RPO_MLP_DISPATCH(512, 256, mlp_forward_kernel, grid, args)
+    return RPO_ERR_ARG;
+}
+
+int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int n, const float* s, int s_stride,
+                     const float* a, int a_stride, const float* x0, const float* h1, const float* dout, float* dh,
+                     float* dx0, float* da, int param_grads, int first_layer_state_only, void* stream) {
+    if (!net_host) return RPO_ERR_NULL;
+    Mlp net{net_host->Ws, net_host->bs, net_host->Wa, net_host->ba, net_host->W0, net_host->b0, net_host->W1,
+            net_host->b1, net_host->W1b, net_host->b1b, net_host->S, net_host->A, net_host->E, net_host->H,
+            net_host->n_out, net_host->cat};
+    if (int e = check_net(net)) return e;
+    if (n <= 0 || s_stride < net.S || (net.A > 0 && a_stride < net.A)) return RPO_ERR_ARG;
+    if (!s || !x0 || !h1 || !dout || !dh || !dx0 || (net.A > 0 && !a)) return RPO_ERR_NULL;
+    MlpGrad g{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (param_grads) {
+        if (!grad_host) return RPO_ERR_NULL;
+        g = MlpGrad{grad_host->Ws, grad_host->bs, grad_host->Wa, grad_host->ba, grad_host->W0, grad_host->b0,
+                    grad_host->W1, grad_host->b1, grad_host->W1b, grad_host->b1b};
+        if (!g.Ws || !g.bs) return RPO_ERR_NULL;
+        if (!first_layer_state_only && (!g.W0 || !g.b0 || !g.W1 || !g.b1 || (net.A > 0 && (!g.Wa || !g.ba))))
+            return RPO_ERR_NULL;
+        if (!first_layer_state_only && net.n_out > 1 && (!g.W1b || !g.b1b)) return RPO_ERR_NULL;
+    }
+    const int ein = net.cat ? 2 * net.E : net.E;
+    BwdArgs args{net, g, n, s, s_stride, a, a_stride, x0, h1, dout, dh, dx0, da, param_grads, first_layer_state_only};
+    const int grid_rows = (n + kRows - 1) / kRows;
+    const int fl_outputs = net.E * (net.S + 1 + ((net.A > 0 && !first_layer_state_only) ? net.A + 1 : 0));
+    const int grid_w = (net.H / 16) * (ein / 64) + net.H / 64 + (fl_outputs + 63) / 64;
+#define RPO_MLP_BWD(EIN_, H_)                                                                                       \
+    if (ein == EIN_ && net.H == H_) {                                                                               \
+        hipLaunchKernelGGL((mlp_bwd_rows_kernel<EIN_, H_>), dim3(grid_rows), dim3(kThreads), 0, (hipStream_t)stream, \
+                           args);                                                                                   \
+        RPO_LAUNCH_CHECK();                                                                                         \
+        if (param_grads) {                                                                                          \
+            hipLaunchKernelGGL((mlp_bwd_weights_kernel<EIN_, H_>), dim3(grid_w), dim3(kThreads), 0,                 \
+                               (hipStream_t)stream, args);                                                          \
+            RPO_LAUNCH_CHECK();                                                                                     \
+        }                                                                                                           \
+        return 0;                                                                                                   \
+    }
+    RPO_MLP_BWD(128, 256)
+    RPO_MLP_BWD(256, 256)
+    RPO_MLP_BWD(512, 256)
+    return RPO_ERR_ARG;
+}
+
+int rpo_tanh_box_bwd(int n, const float* dap, const float* ap_det, const float* noise, float eps_start, float eps_end,
+                     float eps_decay, const long long* ctrl, float lo, float hi, float scale, float base, float* dout,
+                     void* stream) {
+    if (n <= 0 || scale == 0.0f) return RPO_ERR_ARG;
+    if (!dap || !ap_det || !dout) return RPO_ERR_NULL;
+    hipLaunchKernelGGL(tanh_box_bwd_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, dap,
+                       ap_det, noise, eps_start, eps_end, eps_decay, ctrl, lo, hi, scale, base, dout);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_gauss_head(int n, const float* raw, const float* eps, float scale, float base, float lo, float hi,
+                   int deterministic, float* ap_out, float* logp_out, void* stream) {
+    if (n <= 0) return RPO_ERR_ARG;
+    if (!raw || !eps || !ap_out) return RPO_ERR_NULL;
+    hipLaunchKernelGGL(gauss_head_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, raw, eps,
+                       scale, base, lo, hi, deterministic, ap_out, logp_out);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_gauss_head_bwd(int n, const float* raw, const float* eps, const float* dap, float dlogp, float scale,
+                       float base, float lo, float hi, float* draw, void* stream) {
+    if (n <= 0) return RPO_ERR_ARG;
+    if (!raw || !eps || !dap || !draw) return RPO_ERR_NULL;
+    hipLaunchKernelGGL(gauss_head_bwd_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, raw,
+                       eps, dap, dlogp, scale, base, lo, hi, draw);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -234,3 +234,80 @@ class PendulumKernels(object):
         check(_lib.load().rpo_pendulum_lagrangian(action.shape[0], _p(action), _p(nu), scale, _p(loss_out),
                                                   _p(grad_action, allow_none=True), _p(grad_nu, allow_none=True),
                                                   _stream()), "rpo_pendulum_lagrangian")
+
+
+# =================================================================================================== MLP kernels
+
+class _MlpStruct(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("Ws", "bs", "Wa", "ba", "W0", "b0", "W1", "b1", "W1b", "b1b")] + \
+               [(n, ctypes.c_int) for n in ("S", "A", "E", "H", "n_out", "cat")]
+
+
+class _MlpGradStruct(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("Ws", "bs", "Wa", "ba", "W0", "b0", "W1", "b1", "W1b", "b1b")]
+
+
+def mlp_supported(E, H, cat=False):
+    return bool(_lib.load().rpo_mlp_supported(int(E), int(H), int(bool(cat))))
+
+
+class MlpDesc(object):
+    """Pointers into the (flat) parameter / gradient buffers of one network, in the layout of ``rpo_mlp``.
+
+    ``tensors`` maps the field names Ws, bs, Wa, ba, W0, b0, W1, b1, W1b, b1b to parameter tensors (absent / None for
+    networks without an action input or a second head).  Gradient pointers come from ``tensor.grad``.
+    """
+    FIELDS = ("Ws", "bs", "Wa", "ba", "W0", "b0", "W1", "b1", "W1b", "b1b")
+
+    def __init__(self, tensors, S, A, E, H, n_out, cat):
+        self.tensors = {k: tensors.get(k) for k in self.FIELDS}
+        self.S, self.A, self.E, self.H, self.n_out, self.cat = int(S), int(A), int(E), int(H), int(n_out), int(bool(cat))
+        self.ein = self.E * (2 if self.cat else 1)
+        if self.tensors["W0"].data_ptr() % 16:
+            raise RpoHipError("W0 must be 16-byte aligned (FlatParams aligns every tensor)")
+
+    def _ptr(self, t):
+        return None if t is None else t.data_ptr()
+
+    def net_struct(self):
+        return _MlpStruct(*[self._ptr(self.tensors[k]) for k in self.FIELDS], self.S, self.A, self.E, self.H, self.n_out,
+                          self.cat)
+
+    def grad_struct(self):
+        return _MlpGradStruct(*[None if self.tensors[k] is None else self._ptr(self.tensors[k].grad) for k in self.FIELDS])
+
+
+def mlp_forward(desc, s, a, out, x0_save=None, h1_save=None, out_mode=0, scale=1.0, base=0.0):
+    sp, ss = _row_view(s, desc.S)
+    ap, as_ = (None, 0) if desc.A == 0 else _row_view(a, desc.A)
+    net = desc.net_struct()
+    check(_lib.load().rpo_mlp_forward(ctypes.byref(net), out.shape[0], sp, ss, ap, as_, _p(out),
+                                      _p(x0_save, allow_none=True), _p(h1_save, allow_none=True), out_mode, scale, base,
+                                      _stream()), "rpo_mlp_forward")
+
+
+def mlp_backward(desc, s, a, x0, h1, dout, dh, dx0, da=None, param_grads=True, first_layer_state_only=False):
+    sp, ss = _row_view(s, desc.S)
+    ap, as_ = (None, 0) if desc.A == 0 else _row_view(a, desc.A)
+    net = desc.net_struct()
+    grad = desc.grad_struct() if param_grads else None
+    check(_lib.load().rpo_mlp_backward(ctypes.byref(net), None if grad is None else ctypes.byref(grad), dout.shape[0],
+                                       sp, ss, ap, as_, _p(x0), _p(h1), _p(dout), _p(dh), _p(dx0),
+                                       _p(da, allow_none=True), int(param_grads), int(first_layer_state_only),
+                                       _stream()), "rpo_mlp_backward")
+
+
+def tanh_box_bwd(dap, ap_det, noise, eps_start, eps_end, eps_decay, ctrl, lo, hi, scale, base, dout):
+    check(_lib.load().rpo_tanh_box_bwd(dap.numel(), _p(dap), _p(ap_det), _p(noise, allow_none=True), eps_start, eps_end,
+                                       eps_decay, _p(ctrl, torch.int64, allow_none=True), lo, hi, scale, base, _p(dout),
+                                       _stream()), "rpo_tanh_box_bwd")
+
+
+def gauss_head(raw, eps, scale, base, lo, hi, deterministic, ap_out, logp_out=None):
+    check(_lib.load().rpo_gauss_head(raw.shape[0], _p(raw), _p(eps), scale, base, lo, hi, int(deterministic),
+                                     _p(ap_out), _p(logp_out, allow_none=True), _stream()), "rpo_gauss_head")
+
+
+def gauss_head_bwd(raw, eps, dap, dlogp, scale, base, lo, hi, draw):
+    check(_lib.load().rpo_gauss_head_bwd(raw.shape[0], _p(raw), _p(eps), _p(dap), dlogp, scale, base, lo, hi, _p(draw),
+                                         _stream()), "rpo_gauss_head_bwd")

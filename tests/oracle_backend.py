@@ -288,3 +288,110 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0
 
 def polyak(param, target, tau):
     train_ops.polyak(_np(param), _np(target), tau)
+
+
+# ---------------------------------------------------------------------------------------------- MLP kernels (torch-CPU)
+
+def mlp_supported(E, H, cat=False):
+    return H == 256 and (2 * E if cat else E) in (128, 256, 512)
+
+
+class MlpDesc(object):
+    FIELDS = ("Ws", "bs", "Wa", "ba", "W0", "b0", "W1", "b1", "W1b", "b1b")
+
+    def __init__(self, tensors, S, A, E, H, n_out, cat):
+        self.tensors = {k: tensors.get(k) for k in self.FIELDS}
+        self.S, self.A, self.E, self.H, self.n_out, self.cat = S, A, E, H, n_out, int(bool(cat))
+        self.ein = E * (2 if cat else 1)
+
+
+def _x0(d, s, a):
+    t = {k: (None if v is None else v.detach()) for k, v in d.tensors.items()}
+    xs = s @ t["Ws"].T + t["bs"]
+    if d.A == 0:
+        return xs
+    xa = a @ t["Wa"].T + t["ba"]
+    return torch.cat([xs, xa], dim=1) if d.cat else xs + xa
+
+
+def mlp_forward(d, s, a, out, x0_save=None, h1_save=None, out_mode=0, scale=1.0, base=0.0):
+    t = {k: (None if v is None else v.detach()) for k, v in d.tensors.items()}
+    with torch.no_grad():
+        x0 = _x0(d, s, a)
+        h1 = torch.relu(x0) @ t["W0"].T + t["b0"]
+        hr = torch.relu(h1)
+        o = hr @ t["W1"].T + t["b1"]
+        if d.n_out > 1:
+            o = torch.cat([o, hr @ t["W1b"].T + t["b1b"]], dim=1)
+        if out_mode == 1:
+            o = torch.cat([scale * torch.tanh(o[:, :1]) + base, o[:, 1:]], dim=1)
+        out.copy_(o)
+        if x0_save is not None:
+            x0_save.copy_(x0)
+        if h1_save is not None:
+            h1_save.copy_(h1)
+
+
+def mlp_backward(d, s, a, x0, h1, dout, dh, dx0, da=None, param_grads=True, first_layer_state_only=False):
+    t = {k: (None if v is None else v.detach()) for k, v in d.tensors.items()}
+    g = {k: (None if v is None else v.grad) for k, v in d.tensors.items()}
+    with torch.no_grad():
+        hr, xr = torch.relu(h1), torch.relu(x0)
+        w1 = t["W1"] if d.n_out == 1 else torch.cat([t["W1"], t["W1b"]], dim=0)
+        dh.copy_((dout @ w1) * (h1 > 0))
+        dx0.copy_((dh @ t["W0"]) * (x0 > 0))
+        E = d.E
+        dxs = dx0[:, :E]
+        dxa = dx0[:, E:] if d.cat else dx0
+        if da is not None:
+            da.copy_(dxa @ t["Wa"])
+        if not param_grads:
+            return
+        g["Ws"] += dxs.T @ s
+        g["bs"] += dxs.sum(0)
+        if first_layer_state_only:
+            return
+        if d.A > 0:
+            g["Wa"] += dxa.T @ a
+            g["ba"] += dxa.sum(0)
+        g["W0"] += dh.T @ xr
+        g["b0"] += dh.sum(0)
+        g["W1"] += dout[:, :1].T @ hr
+        g["b1"] += dout[:, 0].sum()
+        if d.n_out > 1:
+            g["W1b"] += dout[:, 1:2].T @ hr
+            g["b1b"] += dout[:, 1].sum()
+
+
+def tanh_box_bwd(dap, ap_det, noise, eps_start, eps_end, eps_decay, ctrl, lo, hi, scale, base, dout):
+    t = 0 if ctrl is None else int(ctrl[0])
+    eps_t = max(eps_end, eps_start - eps_decay * t)
+    y = (ap_det - base) / scale
+    g = dap * scale * (1 - y * y)
+    if noise is not None:
+        x = ap_det + eps_t * noise
+        g = g * ((x >= lo) & (x <= hi))
+    dout.copy_(g)
+
+
+def gauss_head(raw, eps, scale, base, lo, hi, deterministic, ap_out, logp_out=None):
+    mean, ls = raw[:, 0], torch.clamp(raw[:, 1] - 3, -23, -2)
+    e = eps.reshape(-1)
+    y = torch.tanh(mean + e * ls.exp())
+    if logp_out is not None:
+        logp_out.copy_((-0.5 * e * e - ls - 0.9189385332046727 - torch.log(scale * (1 - y * y) + 1e-6)).reshape(logp_out.shape))
+    a = scale * torch.tanh(mean) + base if deterministic else scale * y + base
+    ap_out.copy_(torch.clamp(a, lo, hi).reshape(ap_out.shape))
+
+
+def gauss_head_bwd(raw, eps, dap, dlogp, scale, base, lo, hi, draw):
+    mean, lsr = raw[:, 0], raw[:, 1] - 3
+    ls = torch.clamp(lsr, -23, -2)
+    e, sd = eps.reshape(-1), ls.exp()
+    y = torch.tanh(mean + e * sd)
+    omy = 1 - y * y
+    a = scale * y + base
+    g_ap = dap.reshape(-1) * scale * omy * ((a >= lo) & (a <= hi))
+    gx = g_ap + dlogp * (2 * scale * y * omy) / (scale * omy + 1e-6)
+    dls = (gx * e * sd - dlogp) * ((lsr >= -23) & (lsr <= -2))
+    draw.copy_(torch.stack([gx, dls], dim=1))

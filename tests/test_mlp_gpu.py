@@ -1,0 +1,138 @@
+"""Hand-written f32-MFMA MLP kernels (rpo_mlp_forward / rpo_mlp_backward) against the PyTorch modules they replace.
+
+Tolerance: both sides are float32; the MFMA is an exact fmaf chain, so only summation order differs from rocBLAS /
+torch reductions: forward 1e-5 relative, gradients 2e-5 relative to the largest entry of each gradient tensor.
+"""
+import numpy as np
+import pytest
+import torch
+
+from rpo_amd.algo.model import (ActionEmbedding, BoxConstraint, DoubleValueAdd, GaussianSharedPolicy, SharedPolicy,
+                                SharedValueAdd, SharedValueCat, StateEmbedding)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def aligned_params(module):
+    """Re-home the parameters 16-byte aligned on the GPU (what FlatParams does) and give every one a zero .grad."""
+    for p in module.parameters():
+        buf = torch.zeros(p.numel() + 8, device=DEV)
+        off = (-buf.data_ptr() // 4) % 4
+        v = buf[off:off + p.numel()].view(p.shape)
+        v.copy_(p.data)
+        p.data = v
+        g = torch.zeros(p.numel() + 8, device=DEV)
+        off = (-g.data_ptr() // 4) % 4
+        p.grad = g[off:off + p.numel()].view(p.shape)
+    return module
+
+
+def desc_for(ops, net, kind, S, A, E, H):
+    if kind == "actor":
+        t = dict(Ws=net.state_embed.embeds[0].weight, bs=net.state_embed.embeds[0].bias, W0=net.affines[0].weight,
+                 b0=net.affines[0].bias, W1=net.affines[1].weight, b1=net.affines[1].bias)
+        return ops.MlpDesc(t, S, 0, E, H, 1, False)
+    if kind == "gauss":
+        t = dict(Ws=net.state_embed.embeds[0].weight, bs=net.state_embed.embeds[0].bias, W0=net.affines[0].weight,
+                 b0=net.affines[0].bias, W1=net.affine_mean.weight, b1=net.affine_mean.bias,
+                 W1b=net.affine_log_std.weight, b1b=net.affine_log_std.bias)
+        return ops.MlpDesc(t, S, 0, E, H, 2, False)
+    t = dict(Ws=net.state_embed.embeds[0].weight, bs=net.state_embed.embeds[0].bias, Wa=net.action_embed.embeds[0].weight,
+             ba=net.action_embed.embeds[0].bias, W0=net.affines[0].weight, b0=net.affines[0].bias,
+             W1=net.affines[1].weight, b1=net.affines[1].bias)
+    return ops.MlpDesc(t, S, A, E, H, 1, kind == "cat")
+
+
+def gauss_raw(net, s):
+    x = net.state_embed(s)
+    for affine in net.affines:
+        x = affine(torch.relu(x))
+    x = torch.relu(x)
+    return torch.cat([net.affine_mean(x), net.affine_log_std(x)], dim=1)
+
+
+CASES = [("actor", 6, 0, 128, 256, 4096), ("actor", 5, 0, 128, 256, 250), ("add", 6, 2, 128, 256, 256),
+         ("add", 5, 2, 128, 256, 77), ("cat", 57, 43, 256, 256, 200), ("gauss", 5, 0, 128, 256, 256),
+         ("add", 6, 2, 256, 256, 512)]
+
+
+@pytest.mark.parametrize("kind,S,A,E,H,n", CASES)
+def test_mlp_forward_backward_match_torch(kind, S, A, E, H, n):
+    from rpo_amd import ops
+    torch.manual_seed(S * 100 + n)
+    se = StateEmbedding(S, E, H)
+    if kind == "actor":
+        net = SharedPolicy(S, 1, se, E, H, 1, None)
+    elif kind == "gauss":
+        net = GaussianSharedPolicy(S, 1, se, E, H, 1, None)
+    else:
+        cls = SharedValueCat if kind == "cat" else SharedValueAdd
+        net = cls(S, A, se, ActionEmbedding(A, E, H), E, H)
+    aligned_params(net)
+    assert ops.mlp_supported(E, H, kind == "cat")
+    d = desc_for(ops, net, kind, S, A, E, H)
+    # inputs as strided column views of a wider batch matrix, like the trainer's gathered rows
+    wide = torch.randn(n, S + A + 7, device=DEV)
+    s = wide[:, 3:3 + S]
+    a = wide[:, 3 + S:3 + S + A] if A else None
+    a_t = a.clone().requires_grad_() if A else None
+    if kind == "actor":
+        ref = net(s)
+    elif kind == "gauss":
+        ref = gauss_raw(net, s)
+    else:
+        ref = net(s, a_t)
+    n_out = ref.shape[1]
+    out = torch.empty(n, n_out, device=DEV)
+    x0 = torch.empty(n, d.ein, device=DEV)
+    h1 = torch.empty(n, H, device=DEV)
+    ops.mlp_forward(d, s, a, out, x0, h1)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, atol=2e-6)
+    out2 = torch.empty(n, n_out, device=DEV)
+    ops.mlp_forward(d, s, a, out2)                       # inference form (nothing saved) gives the same bits
+    assert torch.equal(out, out2)
+
+    dout = torch.randn(n, n_out, device=DEV) / n
+    ref.backward(dout)
+    want = {k: (None if t is None else t.grad.clone()) for k, t in d.tensors.items()}
+    for t in d.tensors.values():
+        if t is not None:
+            t.grad.zero_()
+    dh = torch.empty(n, H, device=DEV)
+    dx0 = torch.empty(n, d.ein, device=DEV)
+    da = torch.empty(n, A, device=DEV) if A else None
+    ops.mlp_backward(d, s, a, x0, h1, dout, dh, dx0, da)
+    for k, t in d.tensors.items():
+        if t is None:
+            continue
+        w = want[k].cpu().numpy()
+        np.testing.assert_allclose(t.grad.cpu().numpy(), w, rtol=2e-5, atol=2e-5 * np.abs(w).max() + 1e-12, err_msg=k)
+    if A:
+        w = a_t.grad.cpu().numpy()
+        np.testing.assert_allclose(da.cpu().numpy(), w, rtol=2e-5, atol=2e-5 * np.abs(w).max())
+    # accumulation semantics (+=) and the reduced modes
+    ops.mlp_backward(d, s, a, x0, h1, dout, dh, dx0, da)
+    np.testing.assert_allclose(d.tensors["W0"].grad.cpu().numpy(), 2 * want["W0"].cpu().numpy(), rtol=3e-5,
+                               atol=4e-5 * np.abs(want["W0"].cpu().numpy()).max())
+    for t in d.tensors.values():
+        if t is not None:
+            t.grad.zero_()
+    ops.mlp_backward(d, s, a, x0, h1, dout, dh, dx0, da, param_grads=True, first_layer_state_only=True)
+    np.testing.assert_allclose(d.tensors["Ws"].grad.cpu().numpy(), want["Ws"].cpu().numpy(), rtol=2e-5,
+                               atol=2e-5 * np.abs(want["Ws"].cpu().numpy()).max())
+    assert float(d.tensors["W0"].grad.abs().max()) == 0.0
+    ops.mlp_backward(d, s, a, x0, h1, dout, dh, dx0, da, param_grads=False)
+    assert float(d.tensors["W0"].grad.abs().max()) == 0.0
+
+
+def test_mlp_tanh_box_epilogue():
+    from rpo_amd import ops
+    torch.manual_seed(1)
+    box = BoxConstraint(np.array([-10.0], dtype=np.float32), np.array([10.0], dtype=np.float32), device=DEV)
+    net = aligned_params(SharedPolicy(6, 1, StateEmbedding(6, 128, 256), 128, 256, 1, box))
+    d = desc_for(ops, net, "actor", 6, 0, 128, 256)
+    s = torch.randn(1000, 6, device=DEV) * 3
+    out = torch.empty(1000, 1, device=DEV)
+    ops.mlp_forward(d, s, None, out, out_mode=1, scale=10.0, base=0.0)
+    np.testing.assert_allclose(out.cpu().numpy(), net(s).detach().cpu().numpy(), rtol=1e-5, atol=1e-5)

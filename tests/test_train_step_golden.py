@@ -83,7 +83,18 @@ def test_oracle_loop_matches_reference_update(golden, algo, envname):
     assert not noises and not idx        # every recorded draw was consumed, in order
 
 
-def build_trainer(algo, envname, backend, device, **extra):
+def build_trainer(algo, envname, backend, device, fused=True, **extra):
+    import os
+    os.environ["RPO_FUSED_MLP"] = "1" if fused else "0"
+    try:
+        tr = _build_trainer(algo, envname, backend, device, **extra)
+    finally:
+        os.environ.pop("RPO_FUSED_MLP", None)
+    assert (tr.fused is not None) == fused
+    return tr
+
+
+def _build_trainer(algo, envname, backend, device, **extra):
     env_cls = CartSafeEnv if envname == "cart" else SpringPendulumEnv
     kw = dict(partial_actions=[1]) if envname == "cart" else {}
     env = gym_shim.TimeLimit(env_cls(backend=backend, device=device, **kw), 200)
@@ -121,10 +132,10 @@ def product_tol(envname):
     return TOL
 
 
-def run_product_update(golden, algo, envname, backend, device):
+def run_product_update(golden, algo, envname, backend, device, fused=True):
     g = golden("train_steps_%s_%s" % (algo, envname))
     torch.manual_seed(123)
-    tr = build_trainer(algo, envname, backend, device, num_envs=1)
+    tr = build_trainer(algo, envname, backend, device, fused=fused, num_envs=1)
     ag = tr.agent
     for k, v in sd(g, "actor0").items():        # the shipped modules initialise exactly like the reference's
         np.testing.assert_array_equal(ag.actor.state_dict()[k].cpu().numpy(), v)
@@ -160,8 +171,11 @@ def check_product_update(g, tr, closs, aloss, proxy, algo, envname):
     assert not proxy.noises and not proxy.idx
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused_mlp", "torch_mlp"])
 @pytest.mark.parametrize("algo,envname", CASES)
-def test_trainer_host_logic_matches_reference_update(golden, algo, envname):
+def test_trainer_host_logic_matches_reference_update(golden, algo, envname, fused):
+    """fused_mlp: the hand-orchestrated forward / backward through the MLP kernels' interface (the path the GPU runs);
+    torch_mlp: the torch modules + autograd (`critic_loss` / `actor_loss`, the reference's formulation)."""
     torch.set_num_threads(1)
-    out = run_product_update(golden, algo, envname, ob, torch.device("cpu"))
+    out = run_product_update(golden, algo, envname, ob, torch.device("cpu"), fused=fused)
     check_product_update(*out, algo, envname)

@@ -23,10 +23,11 @@ def hip():
     return ops
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused_mlp", "torch_mlp"])
 @pytest.mark.parametrize("algo,envname", CASES)
-def test_update_matches_reference_on_gpu(golden, hip, algo, envname, monkeypatch):
+def test_update_matches_reference_on_gpu(golden, hip, algo, envname, fused, monkeypatch):
     monkeypatch.setattr(tsg, "TOL", dict(rtol=0, atol=5e-6))
-    out = run_product_update(golden, algo, envname, hip, torch.device("cuda"))
+    out = run_product_update(golden, algo, envname, hip, torch.device("cuda"), fused=fused)
     g, tr, closs, aloss, proxy = out
     np.testing.assert_allclose(closs, g["critic_losses"], rtol=1e-4)
     np.testing.assert_allclose(aloss, g["actor_losses"], rtol=1e-4, atol=1e-6)
@@ -37,9 +38,9 @@ def test_update_matches_reference_on_gpu(golden, hip, algo, envname, monkeypatch
     np.testing.assert_allclose(ag.nju.weight.detach().cpu().numpy(), g["nju4"], rtol=1e-4, atol=1e-7)
 
 
-def _run(algo, envname, backend, device, iters, n_envs, use_graph, seed_all=5):
+def _run(algo, envname, backend, device, iters, n_envs, use_graph, seed_all=5, fused=True):
     torch.manual_seed(seed_all)
-    tr = build_trainer(algo, envname, backend, device, num_envs=n_envs, use_graph=use_graph)
+    tr = build_trainer(algo, envname, backend, device, fused=fused, num_envs=n_envs, use_graph=use_graph)
     tr.vec.reset()
     tr.run_steps(iters)
     if device.type == "cuda":
@@ -47,11 +48,12 @@ def _run(algo, envname, backend, device, iters, n_envs, use_graph, seed_all=5):
     return tr
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused_mlp", "torch_mlp"])
 @pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "pendulum")])
-def test_graph_replay_equals_eager(hip, algo, envname):
+def test_graph_replay_equals_eager(hip, algo, envname, fused):
     dev = torch.device("cuda")
-    a = _run(algo, envname, hip, dev, 24, 512, use_graph=False)
-    b = _run(algo, envname, hip, dev, 24, 512, use_graph=True)
+    a = _run(algo, envname, hip, dev, 24, 512, use_graph=False, fused=fused)
+    b = _run(algo, envname, hip, dev, 24, 512, use_graph=True, fused=fused)
     assert any(e["graph"] is not None for e in b._graphs.entries.values())
     assert torch.equal(a.vec.internal, b.vec.internal)
     assert torch.equal(a.buffer.rows, b.buffer.rows)
