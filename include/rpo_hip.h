@@ -27,7 +27,8 @@
  *   replay ring      rows [cap_steps * n_envs, W]; vector step t writes rows (t % cap_steps) * n_envs + lane.
  *   ctrl             int64[RPO_CTRL_LEN]; ctrl[RPO_CTRL_T] = number of vector steps taken so far.  Written only by
  *                    the *_step kernels (last finishing workgroup), read by every kernel that needs t.
- *   stats            float[stats_cap, RPO_STATS_LEN] per-vector-step accumulators, row t % stats_cap.
+ *   stats            float[stats_cap, RPO_STATS_SUB, RPO_STATS_LEN] per-vector-step accumulators, row t % stats_cap;
+ *                    the value of a statistic is the sum (max for the *_MAX slots) over the RPO_STATS_SUB sub-rows.
  */
 #ifndef RPO_HIP_H
 #define RPO_HIP_H
@@ -52,10 +53,13 @@ extern "C" {
 #define RPO_PEND_ACTION_DIM 2
 #define RPO_PEND_ROW 16
 
-#define RPO_CTRL_LEN 8
+#define RPO_CTRL_LEN 288
 #define RPO_CTRL_T 0        /* vector steps completed */
-#define RPO_CTRL_ARRIVE 1   /* workgroup arrival counter of the running *_step launch (always 0 between launches) */
+#define RPO_CTRL_ARRIVE 1   /* top-level arrival counter of the running *_step launch (always 0 between launches) */
+#define RPO_CTRL_SUB0 16    /* 16 sub-counters, one per 128-byte line: ctrl[RPO_CTRL_SUB0 + RPO_CTRL_SUB_STRIDE * j] */
+#define RPO_CTRL_SUB_STRIDE 16
 
+#define RPO_STATS_SUB 16    /* sub-rows per statistics row: workgroup b adds into sub-row b % 16; the reader sums them */
 #define RPO_STATS_LEN 16
 #define RPO_STAT_REWARD_SUM 0    /* sum over envs of this step's reward                   rpo_ddpg.py:132 */
 #define RPO_STAT_EPISODES 1      /* episodes that ended at this step                       rpo_ddpg.py:134 */
@@ -118,7 +122,7 @@ int rpo_cartsafe_reset(int n_envs, float* state, int* ep_len, float* ep_ret, con
  *   action     [n,2]  un-clipped action (clipped to +-10 for the dynamics only)
  *   ep_len/ep_ret/ep_count [n] per-lane episode bookkeeping (updated)
  *   rows       replay ring (may be NULL: no scatter); ring row = (t % cap_steps) * n_envs + lane, t = ctrl[RPO_CTRL_T]
- *   stats      [stats_cap, RPO_STATS_LEN] (may be NULL)
+ *   stats      [stats_cap, RPO_STATS_SUB, RPO_STATS_LEN] (may be NULL)
  *   ctrl       int64[RPO_CTRL_LEN]; ctrl[RPO_CTRL_T] is incremented when the launch finishes
  */
 int rpo_cartsafe_step(int n_envs, float* state, const float* action, int* ep_len, float* ep_ret, unsigned* ep_count,

@@ -358,7 +358,7 @@ class RPOTrainerBase(object):
             return
         cap = self.vec.stats.shape[0]
         idx = torch.arange(lo, hi, device=self.device) % cap
-        rows = self.vec.stats[idx].clone()
+        rows = hip_ops.reduce_stats(self.vec.stats[idx])
         if self.dist.on:                                                # sums add up over ranks, maxima take the max
             mx = rows.clone()
             dist.all_reduce(rows, op=dist.ReduceOp.SUM)

@@ -94,121 +94,158 @@ struct StepArgs {
     float viol_thresh;
     uint64_t seed;
     uint32_t env_id_base;
+    int tiles_ok;        // state / rows pointers are 16-byte aligned: the coalesced tile path may be used
 };
 
 constexpr int kStepStats = 10;   // 0..7 sums (+terminated), 8..9 maxima -- see flush order below
 
+// One lane's step: dynamics, violations, TimeLimit, statistics, auto-reset.  `row` receives the 6 float4 chunks of the
+// transition row (ReplayBuffer.add, buffer.py:22-29), `ns` the state the lane continues from.
+__device__ __forceinline__ void cart_lane(const StepArgs& p, const CartConsts& c, int i, const float (&s)[6], float2 a,
+                                          float (&ns)[6], float4 (&row)[6], float (&st)[kStepStats]) {
+    // violations of the PRE-step state and UN-clipped action (cartpole.py:229)
+    float h, g[6];
+    eq_ineq(c, a.x, a.y, h, g);
+    float max_ineq = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { g[k] = fmaxf(g[k], 0.0f); max_ineq = fmaxf(max_ineq, g[k]); }
+    const float max_eq = fabsf(h);
+
+    // dynamics, cartpole.py:170-197
+    const float f0 = fminf(fmaxf(a.x, -kActMax), kActMax), f1 = fminf(fmaxf(a.y, -kActMax), kActMax);
+    const float force = f0 * kCosD0 + f1 * kCosD1;
+    const float force_y = f0 * kSinD0 + f1 * kSinD1;
+    const float x = s[0], x_dot = s[1], theta = s[3], theta_dot = s[4], thetaacc_prev = s[5];
+    float sn, cs;
+    sincosf(theta, &sn, &cs);
+    const float td2 = theta_dot * theta_dot;
+    const float n_c = force_y + kTotalMass * kGravity - kPoleMassLength * (thetaacc_prev * sn + td2 * cs);
+    const float prod = n_c * x_dot;
+    const float sign = (prod > 0.0f) ? 1.0f : ((prod < 0.0f) ? -1.0f : prod);   // np.sign (0 -> 0, nan -> nan)
+    const float temp = (force + kPoleMassLength * td2 * (sn + kMuC * sign * cs)) / kTotalMass + kMuC * kGravity * sign;
+    const float thetaacc = (kGravity * sn - cs * temp - kMuP * theta_dot / kPoleMassLength) /
+                           (kLength * (4.0f / 3.0f - kMassPole * cs * (cs - kMuC * kGravity * sign) / kTotalMass));
+    const float xacc = (force + kPoleMassLength * (td2 * sn - thetaacc * cs) - kMuC * n_c * sign) / kTotalMass;
+    ns[0] = x + kTau * x_dot;
+    ns[1] = x_dot + kTau * xacc;
+    ns[2] = xacc;
+    ns[3] = theta + kTau * theta_dot;
+    ns[4] = theta_dot + kTau * thetaacc;
+    ns[5] = thetaacc;
+    const bool terminated = ns[0] < -kXThreshold || ns[0] > kXThreshold || ns[3] < -kThetaThreshold ||
+                            ns[3] > kThetaThreshold;                                  // cartpole.py:208-213
+    const int len = p.ep_len[i] + 1;
+    const bool done = terminated || len >= p.max_episode_steps;                        // gym TimeLimit
+    const float reward = 1.0f;                                                         // cartpole.py:215-221
+    const float ret = p.ep_ret[i] + reward;
+
+    row[0] = make_float4(s[0], s[1], s[2], s[3]);
+    row[1] = make_float4(s[4], s[5], a.x, a.y);
+    row[2] = make_float4(ns[0], ns[1], ns[2], ns[3]);
+    row[3] = make_float4(ns[4], ns[5], reward, done ? 1.0f : 0.0f);
+    row[4] = make_float4(h, g[0], g[1], g[2]);
+    row[5] = make_float4(g[3], g[4], g[5], 0.0f);
+
+    st[0] += reward;
+    st[4] += max_ineq;
+    st[5] += max_eq;
+    st[6] += (fmaxf(max_ineq, max_eq) > p.viol_thresh) ? 1.0f : 0.0f;
+    st[8] = fmaxf(st[8], max_ineq);
+    st[9] = fmaxf(st[9], max_eq);
+    if (done) {
+        st[1] += 1.0f;
+        st[2] += ret;
+        st[3] += (float)len;
+        st[7] += terminated ? 1.0f : 0.0f;
+    }
+    if (done && p.auto_reset) {   // env.reset() after a done, rpo_ddpg.py:142
+        const unsigned ep = p.ep_count[i] + 1u;
+        p.ep_count[i] = ep;
+        reset_state(ns, p.seed, p.env_id_base + (uint32_t)i, ep);
+        p.ep_len[i] = 0;
+        p.ep_ret[i] = 0.0f;
+    } else {
+        p.ep_len[i] = len;
+        p.ep_ret[i] = ret;
+    }
+}
+
+// Tiles of 256 consecutive lanes: the 6 KB state tile and the 24 KB block of transition rows are contiguous in HBM, so
+// they move as fully coalesced float4 streams (1 KiB per wave instruction) and are transposed to / from the per-lane
+// view through LDS (row stride 7 float4 = 112 B: conflict-free ds_write_b128).  A partial last tile takes the direct
+// per-lane path.
 __global__ __launch_bounds__(RPO_BLOCK) void cartsafe_step_kernel(StepArgs p, CartConsts c) {
     __shared__ float red[(RPO_BLOCK / RPO_WAVE) * kStepStats];
+    __shared__ __attribute__((aligned(16))) float4 rows_s[RPO_BLOCK * 7];
+    __shared__ __attribute__((aligned(16))) float state_s[RPO_BLOCK * 6];
     const long long t = p.ctrl ? p.ctrl[RPO_CTRL_T] : 0;
     const long long ring_base = p.rows ? (t % p.cap_steps) * (long long)p.n : 0;
     // per-thread statistics: reward, episodes, return, length, max_ineq, max_eq, viol_count, terminated | maxima
     float st[kStepStats];
 #pragma unroll
     for (int k = 0; k < kStepStats; ++k) st[k] = 0.0f;
+    const int tid = threadIdx.x;
 
-    for (int i = blockIdx.x * RPO_BLOCK + threadIdx.x; i < p.n; i += gridDim.x * RPO_BLOCK) {
-        float s[6];
-        load_state(p.state + (size_t)i * 6, s);
-        const float2 a = reinterpret_cast<const float2*>(p.action)[i];
-
-        // violations of the PRE-step state and UN-clipped action (cartpole.py:229)
-        float h, g[6];
-        eq_ineq(c, a.x, a.y, h, g);
-        float max_ineq = 0.0f;
+    for (int base = blockIdx.x * RPO_BLOCK; base < p.n; base += gridDim.x * RPO_BLOCK) {
+        const int i = base + tid;
+        float s[6], ns[6];
+        float4 row[6];
+        if (p.tiles_ok && base + RPO_BLOCK <= p.n) {
+            // ---- full tile: coalesced state load -> LDS -> per-lane view
+            const float4* gs = reinterpret_cast<const float4*>(p.state + (size_t)base * 6);
+            float4* ls = reinterpret_cast<float4*>(state_s);
+            ls[tid] = gs[tid];
+            if (tid < RPO_BLOCK / 2) ls[RPO_BLOCK + tid] = gs[RPO_BLOCK + tid];
+            const float2 a = reinterpret_cast<const float2*>(p.action)[i];
+            __syncthreads();
+            {
+                const float2* q = reinterpret_cast<const float2*>(state_s + tid * 6);
+                const float2 u = q[0], v = q[1], w = q[2];
+                s[0] = u.x; s[1] = u.y; s[2] = v.x; s[3] = v.y; s[4] = w.x; s[5] = w.y;
+            }
+            cart_lane(p, c, i, s, a, ns, row, st);
+            __syncthreads();                                   // every lane has read its state: the tile can be reused
+            {
+                float2* q = reinterpret_cast<float2*>(state_s + tid * 6);
+                q[0] = make_float2(ns[0], ns[1]); q[1] = make_float2(ns[2], ns[3]); q[2] = make_float2(ns[4], ns[5]);
+            }
+            if (p.rows) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { g[k] = fmaxf(g[k], 0.0f); max_ineq = fmaxf(max_ineq, g[k]); }
-        const float max_eq = fabsf(h);
-
-        // dynamics, cartpole.py:170-197
-        const float f0 = fminf(fmaxf(a.x, -kActMax), kActMax), f1 = fminf(fmaxf(a.y, -kActMax), kActMax);
-        const float force = f0 * kCosD0 + f1 * kCosD1;
-        const float force_y = f0 * kSinD0 + f1 * kSinD1;
-        const float x = s[0], x_dot = s[1], theta = s[3], theta_dot = s[4], thetaacc_prev = s[5];
-        float sn, cs;
-        sincosf(theta, &sn, &cs);
-        const float td2 = theta_dot * theta_dot;
-        const float n_c = force_y + kTotalMass * kGravity - kPoleMassLength * (thetaacc_prev * sn + td2 * cs);
-        const float prod = n_c * x_dot;
-        const float sign = (prod > 0.0f) ? 1.0f : ((prod < 0.0f) ? -1.0f : prod);   // np.sign (0 -> 0, nan -> nan)
-        const float temp = (force + kPoleMassLength * td2 * (sn + kMuC * sign * cs)) / kTotalMass + kMuC * kGravity * sign;
-        const float thetaacc = (kGravity * sn - cs * temp - kMuP * theta_dot / kPoleMassLength) /
-                               (kLength * (4.0f / 3.0f - kMassPole * cs * (cs - kMuC * kGravity * sign) / kTotalMass));
-        const float xacc = (force + kPoleMassLength * (td2 * sn - thetaacc * cs) - kMuC * n_c * sign) / kTotalMass;
-        float ns[6];
-        ns[0] = x + kTau * x_dot;
-        ns[1] = x_dot + kTau * xacc;
-        ns[2] = xacc;
-        ns[3] = theta + kTau * theta_dot;
-        ns[4] = theta_dot + kTau * thetaacc;
-        ns[5] = thetaacc;
-        const bool terminated = ns[0] < -kXThreshold || ns[0] > kXThreshold || ns[3] < -kThetaThreshold ||
-                                ns[3] > kThetaThreshold;                                  // cartpole.py:208-213
-        const int len = p.ep_len[i] + 1;
-        const bool done = terminated || len >= p.max_episode_steps;                        // gym TimeLimit
-        const float reward = 1.0f;                                                         // cartpole.py:215-221
-        const float ret = p.ep_ret[i] + reward;
-
-        if (p.rows) {   // ReplayBuffer.add, buffer.py:22-29 -- one 96-byte row per lane
-            float4* row = reinterpret_cast<float4*>(p.rows + (size_t)(ring_base + i) * RPO_CART_ROW);
-            row[0] = make_float4(s[0], s[1], s[2], s[3]);
-            row[1] = make_float4(s[4], s[5], a.x, a.y);
-            row[2] = make_float4(ns[0], ns[1], ns[2], ns[3]);
-            row[3] = make_float4(ns[4], ns[5], reward, done ? 1.0f : 0.0f);
-            row[4] = make_float4(h, g[0], g[1], g[2]);
-            row[5] = make_float4(g[3], g[4], g[5], 0.0f);
+                for (int k = 0; k < 6; ++k) rows_s[tid * 7 + k] = row[k];
+            }
+            __syncthreads();
+            float4* gs_out = reinterpret_cast<float4*>(p.state + (size_t)base * 6);
+            gs_out[tid] = ls[tid];
+            if (tid < RPO_BLOCK / 2) gs_out[RPO_BLOCK + tid] = ls[RPO_BLOCK + tid];
+            if (p.rows) {
+                float4* gr = reinterpret_cast<float4*>(p.rows + (size_t)(ring_base + base) * RPO_CART_ROW);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int ch = k * RPO_BLOCK + tid;         // float4 chunk of the 24 KB row block
+                    const int r = ch / 6, part = ch - r * 6;
+                    gr[ch] = rows_s[r * 7 + part];
+                }
+            }
+            __syncthreads();                                   // LDS tiles are rewritten by the next iteration
+        } else if (i < p.n) {
+            // ---- partial last tile: direct per-lane accesses
+            load_state(p.state + (size_t)i * 6, s);
+            const float2 a = reinterpret_cast<const float2*>(p.action)[i];
+            cart_lane(p, c, i, s, a, ns, row, st);
+            if (p.rows) {
+                float4* gr = reinterpret_cast<float4*>(p.rows + (size_t)(ring_base + i) * RPO_CART_ROW);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) gr[k] = row[k];
+            }
+            store_state(p.state + (size_t)i * 6, ns);
         }
-
-        st[0] += reward;
-        st[4] += max_ineq;
-        st[5] += max_eq;
-        st[6] += (fmaxf(max_ineq, max_eq) > p.viol_thresh) ? 1.0f : 0.0f;
-        st[8] = fmaxf(st[8], max_ineq);
-        st[9] = fmaxf(st[9], max_eq);
-        if (done) {
-            st[1] += 1.0f;
-            st[2] += ret;
-            st[3] += (float)len;
-            st[7] += terminated ? 1.0f : 0.0f;
-        }
-        if (done && p.auto_reset) {   // env.reset() after a done, rpo_ddpg.py:142
-            const unsigned ep = p.ep_count[i] + 1u;
-            p.ep_count[i] = ep;
-            reset_state(ns, p.seed, p.env_id_base + (uint32_t)i, ep);
-            p.ep_len[i] = 0;
-            p.ep_ret[i] = 0.0f;
-        } else {
-            p.ep_len[i] = len;
-            p.ep_ret[i] = ret;
-        }
-        store_state(p.state + (size_t)i * 6, ns);
     }
 
     if (p.stats) {
-        float* row = p.stats + (t % p.stats_cap) * RPO_STATS_LEN;
-        // map the local order onto the RPO_STAT_* slots: sums 0..7 -> slots {0,1,2,3,4,5,6,10}; maxima -> {7,8}
-        float v[kStepStats];
-#pragma unroll
-        for (int k = 0; k < kStepStats; ++k) v[k] = st[k];
-        const int lane = threadIdx.x & (RPO_WAVE - 1), wave = threadIdx.x / RPO_WAVE;
-#pragma unroll
-        for (int k = 0; k < kStepStats; ++k) {
-            const float r = (k < 8) ? rpo_wave_sum(v[k]) : rpo_wave_max(v[k]);
-            if (lane == 0) red[wave * kStepStats + k] = r;
-        }
-        __syncthreads();
-        if (threadIdx.x < kStepStats) {
-            const int k = threadIdx.x;
-            float r = red[k];
-            for (int w = 1; w < RPO_BLOCK / RPO_WAVE; ++w)
-                r = (k < 8) ? r + red[w * kStepStats + k] : fmaxf(r, red[w * kStepStats + k]);
-            const int slot = (k < 7) ? k : (k == 7 ? RPO_STAT_TERMINATED : (k == 8 ? RPO_STAT_MAX_INEQ_MAX : RPO_STAT_MAX_EQ_MAX));
-            if (k < 8) {
-                if (r != 0.0f) atomicAdd(row + slot, r);
-            } else if (r > 0.0f) {
-                rpo_atomic_max_nonneg(row + slot, r);
-            }
-        }
+        const int slot[kStepStats] = {RPO_STAT_REWARD_SUM, RPO_STAT_EPISODES, RPO_STAT_RETURN_SUM, RPO_STAT_LENGTH_SUM,
+                                      RPO_STAT_MAX_INEQ_SUM, RPO_STAT_MAX_EQ_SUM, RPO_STAT_VIOL_COUNT, RPO_STAT_TERMINATED,
+                                      RPO_STAT_MAX_INEQ_MAX, RPO_STAT_MAX_EQ_MAX};
+        rpo_stats_flush<kStepStats>(st, 8, slot, rpo_stats_row(p.stats, p.stats_cap, t), red);
     }
     rpo_step_epilogue(p.ctrl, t, p.stats, p.stats_cap);
 }
@@ -289,7 +326,7 @@ __global__ __launch_bounds__(RPO_BLOCK) void cartsafe_act_project_kernel(ActArgs
         if (threadIdx.x == 0) {
             float s = 0.0f;
             for (int w = 0; w < RPO_BLOCK / RPO_WAVE; ++w) s += red[w];
-            if (s != 0.0f) atomicAdd(p.stats + (t % p.stats_cap) * RPO_STATS_LEN + RPO_STAT_PROJ_ITERS, s);
+            if (s != 0.0f) atomicAdd(rpo_stats_row(p.stats, p.stats_cap, t) + RPO_STAT_PROJ_ITERS, s);
         }
     }
 }
@@ -394,8 +431,9 @@ int rpo_cartsafe_step(int n_envs, float* state, const float* action, int* ep_len
     if (stats && stats_cap <= 0) return RPO_ERR_ARG;
     CartConsts c;
     if (int e = load_consts(c, consts_host, partial)) return e;
+    const int tiles_ok = ((reinterpret_cast<uintptr_t>(state) | reinterpret_cast<uintptr_t>(rows)) & 15u) == 0;
     StepArgs a{n_envs, state, action, ep_len, ep_ret, ep_count, rows, cap_steps, stats, stats_cap, ctrl,
-               max_episode_steps, auto_reset, viol_thresh, (uint64_t)seed, (uint32_t)env_id_base};
+               max_episode_steps, auto_reset, viol_thresh, (uint64_t)seed, (uint32_t)env_id_base, tiles_ok};
     hipLaunchKernelGGL(cartsafe_step_kernel, dim3(rpo_grid_for(n_envs)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, a, c);
     RPO_LAUNCH_CHECK();
     return 0;

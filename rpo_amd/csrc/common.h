@@ -74,19 +74,56 @@ __device__ __forceinline__ void rpo_atomic_max_nonneg(float* addr, float v) {
     atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 
-// The *_step kernels own ctrl[RPO_CTRL_T]: the last workgroup to finish advances it and clears the statistics row
-// of the next vector step.  Every workgroup read t at its start, before any workgroup can have arrived last.
+// Statistics rows are split into RPO_STATS_SUB sub-rows (one cache line each); a workgroup adds into sub-row
+// blockIdx % RPO_STATS_SUB.  Up to 16 workgroups therefore never share an address (bitwise reproducible sums, summed by
+// the host in a fixed order); large grids spread their same-address atomics (~8 ns each, serialised) 16 ways.
+__device__ __forceinline__ float* rpo_stats_row(float* stats, int stats_cap, long long t) {
+    return stats + ((t % stats_cap) * RPO_STATS_SUB + (blockIdx.x % RPO_STATS_SUB)) * RPO_STATS_LEN;
+}
+
+// Flush kStats per-thread partials (sums for k < n_sum, maxima after) of a 256-thread workgroup into `row` slots.
+template <int K>
+__device__ __forceinline__ void rpo_stats_flush(const float (&v)[K], int n_sum, const int (&slot)[K], float* row,
+                                                float* lds /* [4 * K] */) {
+    const int lane = threadIdx.x & (RPO_WAVE - 1), wave = threadIdx.x / RPO_WAVE;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float r = (k < n_sum) ? rpo_wave_sum(v[k]) : rpo_wave_max(v[k]);
+        if (lane == 0) lds[wave * K + k] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        const int k = threadIdx.x;
+        float r = lds[k];
+        for (int w = 1; w < RPO_BLOCK / RPO_WAVE; ++w) r = (k < n_sum) ? r + lds[w * K + k] : fmaxf(r, lds[w * K + k]);
+        if (k < n_sum) {
+            if (r != 0.0f) atomicAdd(row + slot[k], r);
+        } else if (r > 0.0f) {
+            rpo_atomic_max_nonneg(row + slot[k], r);
+        }
+    }
+}
+
+// The *_step kernels own ctrl[RPO_CTRL_T]: the last workgroup to finish advances it and clears the statistics rows of
+// the next vector step.  Every workgroup read t at its start, before any workgroup can have arrived last.  Arrival is
+// hierarchical -- 16 sub-counters on separate cache lines, then one top counter -- because 2048 returning atomics on
+// ONE address cost ~16 us (measured) while 128 per address cost ~1 us.
 __device__ __forceinline__ void rpo_step_epilogue(long long* ctrl, long long t, float* stats, int stats_cap) {
     __syncthreads();
     if (threadIdx.x == 0 && ctrl != nullptr) {
-        const unsigned long long arrived =
-            atomicAdd(reinterpret_cast<unsigned long long*>(ctrl + RPO_CTRL_ARRIVE), 1ull);
-        if (arrived == (unsigned long long)gridDim.x - 1ull) {
-            ctrl[RPO_CTRL_ARRIVE] = 0;
-            ctrl[RPO_CTRL_T] = t + 1;
-            if (stats != nullptr && stats_cap > 1) {
-                float* nxt = stats + ((t + 1) % stats_cap) * RPO_STATS_LEN;
-                for (int k = 0; k < RPO_STATS_LEN; ++k) nxt[k] = 0.0f;
+        const unsigned sub = blockIdx.x % RPO_STATS_SUB;
+        const unsigned subs = gridDim.x < RPO_STATS_SUB ? gridDim.x : RPO_STATS_SUB;
+        const unsigned long long in_sub = (gridDim.x - sub + RPO_STATS_SUB - 1) / RPO_STATS_SUB;
+        unsigned long long* sub_ctr = reinterpret_cast<unsigned long long*>(ctrl + RPO_CTRL_SUB0 + RPO_CTRL_SUB_STRIDE * sub);
+        if (atomicAdd(sub_ctr, 1ull) == in_sub - 1ull) {
+            *sub_ctr = 0;
+            if (atomicAdd(reinterpret_cast<unsigned long long*>(ctrl + RPO_CTRL_ARRIVE), 1ull) == subs - 1ull) {
+                ctrl[RPO_CTRL_ARRIVE] = 0;
+                ctrl[RPO_CTRL_T] = t + 1;
+                if (stats != nullptr && stats_cap > 1) {
+                    float* nxt = stats + ((t + 1) % stats_cap) * RPO_STATS_SUB * RPO_STATS_LEN;
+                    for (int k = 0; k < RPO_STATS_SUB * RPO_STATS_LEN; ++k) nxt[k] = 0.0f;
+                }
             }
         }
     }

@@ -158,26 +158,10 @@ __global__ __launch_bounds__(RPO_BLOCK) void pendulum_step_kernel(StepArgs p) {
     }
 
     if (p.stats) {
-        float* row = p.stats + (t % p.stats_cap) * RPO_STATS_LEN;
-        const int lane = threadIdx.x & (RPO_WAVE - 1), wave = threadIdx.x / RPO_WAVE;
-#pragma unroll
-        for (int k = 0; k < kStepStats; ++k) {
-            const float r = (k < 8) ? rpo_wave_sum(st[k]) : rpo_wave_max(st[k]);
-            if (lane == 0) red[wave * kStepStats + k] = r;
-        }
-        __syncthreads();
-        if (threadIdx.x < kStepStats) {
-            const int k = threadIdx.x;
-            float r = red[k];
-            for (int w = 1; w < RPO_BLOCK / RPO_WAVE; ++w)
-                r = (k < 8) ? r + red[w * kStepStats + k] : fmaxf(r, red[w * kStepStats + k]);
-            const int slot = (k < 7) ? k : (k == 7 ? RPO_STAT_TERMINATED : (k == 8 ? RPO_STAT_MAX_INEQ_MAX : RPO_STAT_MAX_EQ_MAX));
-            if (k < 8) {
-                if (r != 0.0f) atomicAdd(row + slot, r);
-            } else if (r > 0.0f) {
-                rpo_atomic_max_nonneg(row + slot, r);
-            }
-        }
+        const int slot[kStepStats] = {RPO_STAT_REWARD_SUM, RPO_STAT_EPISODES, RPO_STAT_RETURN_SUM, RPO_STAT_LENGTH_SUM,
+                                      RPO_STAT_MAX_INEQ_SUM, RPO_STAT_MAX_EQ_SUM, RPO_STAT_VIOL_COUNT, RPO_STAT_TERMINATED,
+                                      RPO_STAT_MAX_INEQ_MAX, RPO_STAT_MAX_EQ_MAX};
+        rpo_stats_flush<kStepStats>(st, 8, slot, rpo_stats_row(p.stats, p.stats_cap, t), red);
     }
     rpo_step_epilogue(p.ctrl, t, p.stats, p.stats_cap);
 }
@@ -258,7 +242,7 @@ __global__ __launch_bounds__(RPO_BLOCK) void pendulum_act_project_kernel(ActArgs
         if (threadIdx.x == 0) {
             float s = 0.0f;
             for (int w = 0; w < RPO_BLOCK / RPO_WAVE; ++w) s += red[w];
-            if (s != 0.0f) atomicAdd(p.stats + (t % p.stats_cap) * RPO_STATS_LEN + RPO_STAT_PROJ_ITERS, s);
+            if (s != 0.0f) atomicAdd(rpo_stats_row(p.stats, p.stats_cap, t) + RPO_STAT_PROJ_ITERS, s);
         }
     }
 }

@@ -28,7 +28,7 @@ class VecEnv(object):
         self.ep_len = torch.zeros(self.n, dtype=torch.int32, device=device)
         self.ep_ret = torch.zeros(self.n, device=device)
         self.ep_count = torch.zeros(self.n, dtype=torch.int32, device=device)
-        self.stats = torch.zeros(int(stats_cap), hip_ops.STATS_LEN, device=device)
+        self.stats = hip_ops.new_stats(stats_cap, device)
         self.ctrl = ctrl if ctrl is not None else torch.zeros(hip_ops.CTRL_LEN, dtype=torch.int64, device=device)
         self.steps_host = 0
 

@@ -19,8 +19,23 @@ NOISE_UNIFORM = CONST["RPO_NOISE_UNIFORM"]
 NOISE_CLIP_ONLY = CONST["RPO_NOISE_CLIP_ONLY"]
 STREAM_POLICY = CONST["RPO_STREAM_POLICY"]
 STATS_LEN = CONST["RPO_STATS_LEN"]
+STATS_SUB = CONST["RPO_STATS_SUB"]
 CTRL_LEN = CONST["RPO_CTRL_LEN"]
-STAT = {k[len("RPO_STAT_"):].lower(): v for k, v in CONST.items() if k.startswith("RPO_STAT_") and k != "RPO_STATS_LEN"}
+STAT = {k[len("RPO_STAT_"):].lower(): v for k, v in CONST.items()
+        if k.startswith("RPO_STAT_") and k not in ("RPO_STATS_LEN", "RPO_STATS_SUB")}
+
+
+def new_stats(stats_cap, device):
+    """Statistics buffer [stats_cap, RPO_STATS_SUB, RPO_STATS_LEN] (see include/rpo_hip.h)."""
+    return torch.zeros(int(stats_cap), STATS_SUB, STATS_LEN, device=device)
+
+
+def reduce_stats(rows):
+    """[..., RPO_STATS_SUB, RPO_STATS_LEN] -> [..., RPO_STATS_LEN]: sum over the sub-rows, max for the *_max slots."""
+    out = rows.sum(dim=-2)
+    for key in ("max_ineq_max", "max_eq_max"):
+        out[..., STAT[key]] = rows[..., STAT[key]].max(dim=-1).values
+    return out
 
 
 def _stream():

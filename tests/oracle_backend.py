@@ -17,7 +17,9 @@ NOISE_NONE, NOISE_EXPLICIT, NOISE_PHILOX, NOISE_UNIFORM, NOISE_CLIP_ONLY = 0, 1,
 STREAM_POLICY = CONST["RPO_STREAM_POLICY"]
 STATS_LEN = CONST["RPO_STATS_LEN"]
 CTRL_LEN = CONST["RPO_CTRL_LEN"]
-STAT = {k[len("RPO_STAT_"):].lower(): v for k, v in CONST.items() if k.startswith("RPO_STAT_") and k != "RPO_STATS_LEN"}
+STATS_SUB = CONST["RPO_STATS_SUB"]
+STAT = {k[len("RPO_STAT_"):].lower(): v for k, v in CONST.items()
+        if k.startswith("RPO_STAT_") and k not in ("RPO_STATS_LEN", "RPO_STATS_SUB")}
 
 
 def _np(t):
@@ -70,7 +72,7 @@ class _EnvKernels(object):
             rows[base:base + n] = torch.as_tensor(row)
         if stats is not None:
             cap = stats.shape[0]
-            r = stats[t % cap]
+            r = stats[t % cap, 0]                       # everything into sub-row 0 (the reader sums the sub-rows)
             mi, me = ineq.max(axis=1), np.abs(eq).max(axis=1)
             r[STAT["reward_sum"]] += float(reward.sum())
             r[STAT["episodes"]] += float(done.sum())
@@ -94,7 +96,7 @@ class _EnvKernels(object):
 
     def _stat_iters(self, stats, ctrl, iters):
         if stats is not None:
-            stats[self._t(ctrl) % stats.shape[0], STAT["proj_iters"]] += float(iters.sum())
+            stats[self._t(ctrl) % stats.shape[0], 0, STAT["proj_iters"]] += float(iters.sum())
 
 
 class CartSafeKernels(_EnvKernels):

@@ -61,7 +61,7 @@ def test_cart_step_matches_reference(ops, golden, partial):
     action = dev(g["actions"])
     ep_len, ep_ret, ep_count = env_buffers(n)
     rows = torch.zeros(n, 24, device=DEV)
-    stats = torch.zeros(4, ops.STATS_LEN, device=DEV)
+    stats = ops.new_stats(4, DEV)
     ctrl = torch.zeros(ops.CTRL_LEN, dtype=torch.int64, device=DEV)
     k.step(state, state, action, ep_len, ep_ret, ep_count, rows, 1, stats, ctrl, 200, False, 1e-3, 7, 0)
     torch.cuda.synchronize()
@@ -82,7 +82,7 @@ def test_cart_step_matches_reference(ops, golden, partial):
     np.testing.assert_array_equal(state.cpu().numpy(), r[:, 8:14])
     assert int(ctrl[0]) == 1 and int(ctrl[1]) == 0
     np.testing.assert_array_equal(ep_len.cpu().numpy(), 1)
-    s = stats[0].cpu().numpy()
+    s = ops.reduce_stats(stats[0]).cpu().numpy()
     assert s[ops.STAT["reward_sum"]] == n
     assert s[ops.STAT["episodes"]] == r[:, 15].sum() == s[ops.STAT["terminated"]]
     np.testing.assert_allclose(s[ops.STAT["max_ineq_sum"]], g["ineq_viol"].max(axis=1).sum(), rtol=1e-5)
@@ -102,7 +102,7 @@ def test_cart_rollout_bookkeeping(ops):
     state = torch.zeros(n, 6, device=DEV)
     ep_len, ep_ret, ep_count = env_buffers(n)
     rows = torch.zeros(cap * n, 24, device=DEV)
-    stats = torch.zeros(16, ops.STATS_LEN, device=DEV)
+    stats = ops.new_stats(16, DEV)
     ctrl = torch.zeros(ops.CTRL_LEN, dtype=torch.int64, device=DEV)
     k.reset(state, state, ep_len, ep_ret, ep_count, seed, base)
     ids = np.arange(n) + base
@@ -124,7 +124,7 @@ def test_cart_rollout_bookkeeping(ops):
         done = term | (o_len >= max_len)
         row = np.concatenate([o_state, act, nxt, rew[:, None], done[:, None], eq, ineq, np.zeros((n, 1))], axis=1)
         ring[(t % cap) * n:(t % cap + 1) * n] = row
-        srow = stats[t].cpu().numpy()
+        srow = ops.reduce_stats(stats[t]).cpu().numpy()
         assert srow[ops.STAT["episodes"]] == done.sum()
         assert srow[ops.STAT["terminated"]] == term.sum()
         np.testing.assert_allclose(srow[ops.STAT["return_sum"]], o_ret[done].sum(), rtol=1e-6)
@@ -180,7 +180,7 @@ def test_cart_exploration_modes(ops):
     action = torch.zeros(n, 2, device=DEV)
     ctrl = torch.zeros(ops.CTRL_LEN, dtype=torch.int64, device=DEV)
     ctrl[0] = 40
-    stats = torch.zeros(64, ops.STATS_LEN, device=DEV)
+    stats = ops.new_stats(64, DEV)
     iters = torch.zeros(n, dtype=torch.int32, device=DEV)
     # explicit noise, eps decays with t: eps_t = max(0.1, 1.0 - 0.01 * 40) = 0.6
     k.act_project(None, dev(ap), dev(noise), action, iters, ops.NOISE_EXPLICIT, 1.0, 0.1, 0.01, -10, 10, 10, 2e-2, 1e-5,
@@ -188,7 +188,7 @@ def test_cart_exploration_modes(ops):
     ap_n = np.clip(ap + np.float32(0.6) * noise, -10, 10).astype(np.float32)
     want, it = cs.grad_steps(cs.complete_partial(ap_n, c), c, 2e-2, 10)
     np.testing.assert_allclose(action.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
-    assert float(stats[40, ops.STAT["proj_iters"]]) == it.sum() == int(iters.sum())
+    assert float(ops.reduce_stats(stats[40])[ops.STAT["proj_iters"]]) == it.sum() == int(iters.sum())
     # Philox normal noise: reproducible from (seed, env id, t); statistics of a standard normal
     k.act_project(None, dev(ap), None, action, None, ops.NOISE_PHILOX, 1.0, 1.0, 0.0, -1e9, 1e9, 0, 0, 1e-5, 0.0, seed,
                   base, ctrl, None)
@@ -259,7 +259,7 @@ def test_pendulum_step_matches_reference(ops, golden):
     obs = torch.zeros(n, 5, device=DEV)
     ep_len, ep_ret, ep_count = env_buffers(n)
     rows = torch.zeros(n, 16, device=DEV)
-    stats = torch.zeros(4, ops.STATS_LEN, device=DEV)
+    stats = ops.new_stats(4, DEV)
     ctrl = torch.zeros(ops.CTRL_LEN, dtype=torch.int64, device=DEV)
     k.step(internal, obs, dev(g["actions"]), ep_len, ep_ret, ep_count, rows, 1, stats, ctrl, 200, False, 1e-3, 7, 0)
     r = rows.cpu().numpy()
@@ -276,7 +276,7 @@ def test_pendulum_step_matches_reference(ops, golden):
     np.testing.assert_allclose(internal.cpu().numpy(), nxt, rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(obs.cpu().numpy(), g["next_obs"], rtol=2e-5, atol=2e-5)
     assert int(ctrl[0]) == 1
-    s = stats[0].cpu().numpy()
+    s = ops.reduce_stats(stats[0]).cpu().numpy()
     np.testing.assert_allclose(s[ops.STAT["reward_sum"]], g["reward"].sum(), rtol=1e-5)
     assert s[ops.STAT["episodes"]] == r[:, 13].sum()
 

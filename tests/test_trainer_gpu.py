@@ -75,7 +75,8 @@ def test_iterations_match_oracle_backend(hip, algo, envname):
     np.testing.assert_allclose(g.agent.nju.weight.detach().cpu().numpy(), c.agent.nju.weight.detach().numpy(), rtol=1e-3, atol=1e-6)
     np.testing.assert_array_equal(g.vec.ep_count.cpu().numpy(), c.vec.ep_count.numpy())
     S = hip.STAT
-    gs, cs_ = g.vec.stats[:iters].cpu().numpy(), c.vec.stats[:iters].numpy()
+    gs = hip.reduce_stats(g.vec.stats[:iters]).cpu().numpy()
+    cs_ = hip.reduce_stats(c.vec.stats[:iters]).numpy()
     for key in ("episodes", "reward_sum", "proj_iters"):
         np.testing.assert_allclose(gs[:, S[key]], cs_[:, S[key]], rtol=1e-5)
     np.testing.assert_allclose(gs[:, S["max_ineq_sum"]], cs_[:, S["max_ineq_sum"]], rtol=1e-3, atol=1e-3)
