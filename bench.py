@@ -124,6 +124,16 @@ def kernel_clinic(tr):
     return out
 
 
+def pmc_traffic(kernel, lanes):
+    """HBM bytes per launch from the committed rocprofv3 PMC collection (profiles/r01_pmc_traffic.json; recipe and the
+    gfx950 FETCH_SIZE correction are described there).  None when that (kernel, size) was not collected."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)["kernels"][kernel][str(lanes)]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(seconds=15.0):
     """The oracle's single-env, per-step CPU loop (oracle/rpo_loop.py: the reference's cadence -- one env step + one
     batch-256 update per iteration) timed on one host core for a bounded sample."""
@@ -230,12 +240,13 @@ def main():
             d, big = clinic[dom], clinic[dom + "@1M"]
             result["roofline"] = {
                 "bound": "hbm", "kernel": dom, "achieved": d["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": d["GBs"] / HBM_PEAK_GBS, "traffic": None, "launch_us": d["us"], "units_per_launch": d["n"],
+                "frac": d["GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, d["n"]), "launch_us": d["us"],
+                "units_per_launch": d["n"],
                 "algorithmic_bytes_per_launch": d["bytes"],
                 "note": "latency-bound at 4096 lanes (%.2f MB per launch); same kernel at 1M lanes: %.1f GB/s = %.3f "
                         "of peak" % (d["bytes"] / 1e6, big["GBs"], big["GBs"] / HBM_PEAK_GBS),
                 "streaming_regime": {"units_per_launch": big["n"], "launch_us": big["us"], "achieved": big["GBs"],
-                                     "frac": big["GBs"] / HBM_PEAK_GBS},
+                                     "frac": big["GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, big["n"])},
                 "all_kernels": {k: {"us": v["us"], "GBs": v["GBs"]} for k, v in clinic.items()},
             }
         if not args.no_cpu_baseline and world == 1:

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Launch the hot kernels a few times at fixed sizes (for rocprofv3 --pmc / --kernel-trace collection).
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out -o fetch -- python3 tools/kernel_probe.py step
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("RPO_VERBOSE", "0")
+import torch  # noqa: E402
+
+
+def probe_step(reps=5):
+    from bench import make_trainer
+    from rpo_amd import ops
+    from rpo_amd.env.vec import VecEnv
+    tr = make_trainer(4096, torch.device("cuda"), 10, capacity=8)
+    k = tr.kernels
+    for n in (4096, 1 << 20):
+        v = VecEnv(k, n, torch.device("cuda"), seed=3, stats_cap=64)
+        v.reset()
+        rows = torch.zeros(8 * n, k.row_floats, device="cuda")
+        ap = torch.zeros(n, device="cuda")
+        batch = torch.zeros(n if n > 4096 else 256, k.row_floats, device="cuda")
+        for _ in range(reps):
+            k.act_project(v.obs, ap, None, v.action, None, ops.NOISE_PHILOX, 1.0, 1.0, 0.0, -10.0, 10.0, 10, 2e-2, 1e-5,
+                          0.0, v.seed, 0, v.ctrl, v.stats)
+            k.step(v.internal, v.obs, v.action, v.ep_len, v.ep_ret, v.ep_count, rows, 8, v.stats, v.ctrl, 200, True, 1e-3,
+                   v.seed, 0)
+            ops.replay_sample_gather(rows, 8, n, batch, None, 1, 0, v.ctrl)
+        torch.cuda.synchronize()
+
+
+def probe_mlp(reps=5):
+    from rpo_amd import ops
+    from rpo_amd.algo.model import ActionEmbedding, SharedPolicy, SharedValueAdd, StateEmbedding
+    from test_mlp_gpu import aligned_params, desc_for
+    S, A, E, H = 6, 2, 128, 256
+    actor = aligned_params(SharedPolicy(S, 1, StateEmbedding(S, E, H), E, H, 1, None))
+    critic = aligned_params(SharedValueAdd(S, A, StateEmbedding(S, E, H), ActionEmbedding(A, E, H), E, H))
+    da, dc = desc_for(ops, actor, "actor", S, 0, E, H), desc_for(ops, critic, "add", S, A, E, H)
+    for n in (256, 4096, 65536):
+        s, a = torch.randn(n, S, device="cuda"), torch.randn(n, A, device="cuda")
+        out = torch.empty(n, 1, device="cuda")
+        x0, h1 = torch.empty(n, E, device="cuda"), torch.empty(n, H, device="cuda")
+        dh, dx0, dA = torch.empty(n, H, device="cuda"), torch.empty(n, E, device="cuda"), torch.empty(n, A, device="cuda")
+        dout = torch.randn(n, 1, device="cuda")
+        for _ in range(reps):
+            ops.mlp_forward(da, s, None, out)
+            ops.mlp_forward(dc, s, a, out, x0, h1)
+            if n <= 4096:
+                ops.mlp_backward(dc, s, a, x0, h1, dout, dh, dx0, dA)
+        torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    {"step": probe_step, "mlp": probe_mlp}[sys.argv[1] if len(sys.argv) > 1 else "step"]()
