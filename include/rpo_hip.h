@@ -296,6 +296,37 @@ int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int
                      const float* a, int a_stride, const float* x0, const float* h1, const float* dout, float* dh,
                      float* dx0, float* da, int param_grads, int first_layer_state_only, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Fused pipelines of one RPODDPG iteration on CartSafe-v0 (rpo_amd/csrc/fused.hip): the row-local stages chained
+ * inside one workgroup of 16 rows, because at 4096 lanes / batch 256 every launch is dominated by dispatch + cold-start
+ * latency.  Bitwise identical to the sequences of single-stage launches they replace.
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* Rollout of one vector step (rpo_ddpg.py:93-145): actor MLP -> noise + clip -> complete_partial -> grad_steps ->
+ * env step + violations + TimeLimit -> replay scatter -> statistics -> auto-reset.
+ * == rpo_mlp_forward(actor, tanh box) + rpo_cartsafe_act_project + rpo_cartsafe_step (same arguments). */
+int rpo_cartsafe_ddpg_rollout(const rpo_mlp* actor_host, float scale, float base, int n_envs, float* state,
+                              float* action, int* ep_len, float* ep_ret, unsigned* ep_count, float* rows,
+                              long long cap_steps, float* stats, int stats_cap, long long* ctrl, int noise_mode,
+                              float eps_start, float eps_end, float eps_decay, float box_lo, float box_hi, int max_steps,
+                              float corr_lr, float corr_eps, float corr_momentum, const float* consts_host, int partial,
+                              int max_episode_steps, int auto_reset, float viol_thresh, unsigned long long seed,
+                              unsigned env_id_base, void* stream);
+
+/* Forward half of the critic update (rpo_ddpg.py:165-174, 327-337): ReplayBuffer.sample (Philox draw, or idx_in when
+ * given) -> batch_out [B,24]; pi_targ(s') -> Complete + Proj -> Q_targ(s', a') = qn_out; Q(s, a) = q_out with the
+ * critic's pre-activations saved (x0_save [B,E], h1_save [B,H]) for rpo_mlp_backward; y = r + gamma (1 - done) qn;
+ * dq_out = dHuber/dQ / B; loss_partial[g] = workgroup g's share of the mean Huber loss (g < ceil(B / 16)).
+ * == rpo_replay_sample_gather + 3 x rpo_mlp_forward + rpo_cartsafe_act_project + rpo_td_huber. */
+int rpo_cartsafe_ddpg_critic_forward(const rpo_mlp* actor_target_host, const rpo_mlp* critic_target_host,
+                                     const rpo_mlp* critic_host, float scale, float base, const float* rows,
+                                     long long cap_steps, int n_envs, int batch, float* batch_out, long long* idx_out,
+                                     const long long* idx_in, unsigned long long seed, unsigned sample_salt,
+                                     const long long* ctrl, int max_steps, float corr_lr, float corr_eps,
+                                     float corr_momentum, float box_lo, float box_hi, const float* consts_host,
+                                     int partial, float gamma, float* q_out, float* qn_out, float* dq_out,
+                                     float* loss_partial, float* x0_save, float* h1_save, void* stream);
+
 /* Policy heads around the MLP kernels.
  * DDPG (model/policy.py:30-31, agent/ddpg_pa.py:108-110): ap = clip(ap_det + eps_t * noise), ap_det = scale*tanh(o)+base.
  *   dout[i] = dap[i] * 1[lo <= ap_det + eps_t*noise <= hi] * scale * (1 - tanh(o)^2); noise NULL: no noise, no clip. */

@@ -8,6 +8,19 @@ from .model import BoxConstraint
 from .trainer import _SALT_ACTOR, RPOTrainerBase, _LagrangianFn, _TDHuberFn
 
 
+class _LazySum(object):
+    """Per-workgroup loss partials, summed only when somebody looks (keeps a reduction kernel out of the iteration)."""
+
+    def __init__(self, parts):
+        self.parts = parts
+
+    def __float__(self):
+        return float(self.parts.sum())
+
+    def detach(self):
+        return self.parts.sum()
+
+
 class RPODDPG(RPOTrainerBase):
 
     def __init__(self, env, work_dir, name, logger, max_steps=10, embed_dim=256, hidden_dim=256, hidden_layer=1,
@@ -53,10 +66,52 @@ class RPODDPG(RPOTrainerBase):
             return self._actor_out("actor", obs)
         return self.agent.actor(obs).reshape(-1)
 
+    # ---- fused pipelines (one launch per stage group; CartSafe kernels provide them) -----------------------------
+    @property
+    def _pipelines(self):
+        return (self.fused is not None and hasattr(self.kernels, "ddpg_critic_forward")
+                and "actor_target" in self.fused.descs and "critic" in self.fused.descs)
+
+    def _rollout(self, warm):
+        if warm or not self._pipelines:
+            return super()._rollout(warm)
+        v, buf = self.vec, self.buffer
+        scale, base = self._box_affine
+        self.kernels.ddpg_rollout(self.fused.descs["actor"], scale, base, v.internal, v.action, v.ep_len, v.ep_ret,
+                                  v.ep_count, buf.rows, buf.capacity, v.stats, v.ctrl, hip_ops.NOISE_PHILOX,
+                                  self.eps_start, self.eps, self.decay_value, self._box_lo, self._box_hi, self.max_steps,
+                                  self.corr_lr, self.corr_eps, self.corr_momentum, v.max_episode_steps, True,
+                                  v.viol_thresh, self.seed, v.env_id_base)
+
+    def _sample(self):
+        if self._pipelines:
+            # the critic-forward pipeline draws and gathers the batch itself (into self._batch)
+            c = self.buffer.split(self._batch)
+            return c["state"], c["action"], c["next_state"], c["reward"], c["done"], c["ineq_viol"], c["eq_viol"]
+        return super()._sample()
+
+    def _critic_update_pipeline(self, cols):
+        f, ag, B, buf = self.fused, self.agent, self.batch_size, self.buffer
+        state, action = cols[0], cols[1]
+        d = f.descs["critic"]
+        scale, base = self._box_affine
+        parts = f.buf("loss_parts", (B + 15) // 16)
+        idx_in = self._idx_inject() if self._idx_inject is not None else None
+        self.kernels.ddpg_critic_forward(
+            f.descs["actor_target"], f.descs["critic_target"], d, scale, base, buf.rows, buf.capacity, buf.n_envs,
+            self._batch, None, idx_in, buf.seed, 0, buf.ctrl, self.max_steps, self.corr_lr, self.corr_eps,
+            self.corr_momentum, self._box_lo, self._box_hi, ag.gamma, f.buf("q", B, 1), f.buf("qn", B, 1),
+            f.buf("dq", B, 1), parts, f.buf("critic.x0", B, d.ein), f.buf("critic.h1", B, d.H))
+        ag.flat.grad.zero_()
+        f.backward("critic", state, action, f.buf("dq", B, 1))
+        self.last_losses["critic"] = _LazySum(parts)
+
     # ---- the update through the hand-written MLP kernels (same arithmetic as critic_loss / actor_loss below) ------
     def _critic_update(self, cols):
         if self.fused is None:
             return super()._critic_update(cols)
+        if self._pipelines:
+            return self._critic_update_pipeline(cols)
         f, ag, B = self.fused, self.agent, self.batch_size
         state, action, next_state, reward, done = cols[:5]
         next_actions = self._project_batch(next_state, self._actor_out("actor_target", next_state))

@@ -183,6 +183,7 @@ class RPOTrainerBase(object):
         self._pending = []          # per-step rows waiting for the return of the episodes they belong to
         self._vec_eval = None
         self.last_losses = {}
+        self._idx_inject = None     # tests: callable returning the replay indices of the next sampled batch
         self.viol_steps, self.env_steps, self.viol_rate, self.proj_iters_mean = 0.0, 0.0, 0.0, 0.0
 
     # ------------------------------------------------------------------------------------------ projection API

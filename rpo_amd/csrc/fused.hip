@@ -1,0 +1,267 @@
+// Fused pipelines of the RPODDPG iteration on CartSafe-v0 (MI355X): at 4096 lanes / batch 256 every launch costs
+// ~2 us of dispatch plus a cold start of its caches, so the row-local stages are chained inside one workgroup instead:
+//
+//   rollout        obs tile -> actor MLP (f32 MFMA) -> exploration noise + box clip -> equation solver -> GRG projection
+//                  -> env step + violations + TimeLimit -> replay scatter -> statistics -> auto-reset
+//                  (rpo_ddpg.py:93-145; replaces rpo_mlp_forward + rpo_cartsafe_act_project + rpo_cartsafe_step)
+//   critic forward ReplayBuffer.sample -> pi_targ(s') -> Complete + Proj -> Q_targ(s', a') -> Q(s, a) -> TD target +
+//                  Huber loss and dLoss/dQ (rpo_ddpg.py:165-174, 327-337; replaces rpo_replay_sample_gather, three
+//                  rpo_mlp_forward launches, one projection launch and rpo_td_huber)
+//
+// One workgroup = 16 rows (lanes / batch samples) and 512 threads; the MLP tile forward is mlp_tile.h.
+#include "cartsafe_dev.h"
+#include "mlp_tile.h"
+
+namespace {
+
+using namespace rpo_mlp_dev;
+using namespace rpo_cart_dev;
+
+Mlp to_dev(const rpo_mlp* h) {
+    return Mlp{h->Ws, h->bs, h->Wa, h->ba, h->W0, h->b0, h->W1, h->b1, h->W1b, h->b1b, h->S, h->A, h->E, h->H, h->n_out, h->cat};
+}
+
+// ------------------------------------------------------------------------------------------------------ rollout
+struct RolloutArgs {
+    Mlp actor;
+    float scale, base;            // tanh box of the actor output (BoxConstraint)
+    ActArgs act;                  // exploration / projection parameters (ap_raw, noise, action unused / action out)
+    StepArgs step;                // env state, bookkeeping, ring, statistics, ctrl
+};
+
+template <int EIN, int H>
+__global__ __launch_bounds__(kFwdThreads) void cart_ddpg_rollout_kernel(RolloutArgs p, CartConsts c) {
+    __shared__ TileLds<EIN> lds;
+    const int row0 = blockIdx.x * kRows;
+    const int tid = threadIdx.x;
+    const int n = p.step.n;
+    const long long t = p.step.ctrl ? p.step.ctrl[RPO_CTRL_T] : 0;
+    if (tid < kRows * 6) {                                     // obs tile == state rows (CartSafe observes its state)
+        const int r = tid / 6, i = tid - r * 6;
+        lds.in_s[r * kInS + i] = (row0 + r < n) ? p.step.state[(size_t)(row0 + r) * 6 + i] : 0.0f;
+    }
+    mlp_tile_forward<EIN, H>(p.actor, lds, row0, n, nullptr, nullptr, 1, p.scale, p.base);
+
+    float st[kStepStats];
+#pragma unroll
+    for (int k = 0; k < kStepStats; ++k) st[k] = 0.0f;
+    float iters_f = 0.0f;
+    const int i = row0 + tid;
+    if (tid < kRows && i < n) {
+        const float eps_t = fmaxf(p.act.eps_end, p.act.eps_start - p.act.eps_decay * (float)t);
+        int k;
+        const float2 a = cart_explore_project(p.act, c, i, lds.out[tid * 2], eps_t, t, k);
+        iters_f = (float)k;
+        reinterpret_cast<float2*>(p.act.action)[i] = a;
+        float s[6], ns[6];
+        float4 row[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) s[q] = lds.in_s[tid * kInS + q];
+        cart_lane(p.step, c, i, s, a, ns, row, st);
+        if (p.step.rows) {
+            const long long ring_base = (t % p.step.cap_steps) * (long long)n;
+            float4* gr = reinterpret_cast<float4*>(p.step.rows + (size_t)(ring_base + i) * RPO_CART_ROW);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) gr[q] = row[q];
+        }
+        store_state(p.step.state + (size_t)i * 6, ns);
+    }
+    if (p.step.stats && tid < 64) {                            // only wave 0 holds data: wave reduction, lane 0 adds
+        float* srow = rpo_stats_row(p.step.stats, p.step.stats_cap, t);
+        const int slot[kStepStats] = {RPO_STAT_REWARD_SUM, RPO_STAT_EPISODES, RPO_STAT_RETURN_SUM, RPO_STAT_LENGTH_SUM,
+                                      RPO_STAT_MAX_INEQ_SUM, RPO_STAT_MAX_EQ_SUM, RPO_STAT_VIOL_COUNT, RPO_STAT_TERMINATED,
+                                      RPO_STAT_MAX_INEQ_MAX, RPO_STAT_MAX_EQ_MAX};
+#pragma unroll
+        for (int k = 0; k < kStepStats; ++k) {
+            const float r = (k < 8) ? rpo_wave_sum(st[k]) : rpo_wave_max(st[k]);
+            if (tid == 0) {
+                if (k < 8) { if (r != 0.0f) atomicAdd(srow + slot[k], r); }
+                else if (r > 0.0f) rpo_atomic_max_nonneg(srow + slot[k], r);
+            }
+        }
+        const float it = rpo_wave_sum(iters_f);
+        if (tid == 0 && it != 0.0f) atomicAdd(srow + RPO_STAT_PROJ_ITERS, it);
+    }
+    rpo_step_epilogue(p.step.ctrl, t, p.step.stats, p.step.stats_cap);
+}
+
+// ----------------------------------------------------------------------------------------------- critic forward
+struct CriticFwdArgs {
+    Mlp actor_target, critic_target, critic;
+    float scale, base;
+    const float* rows;            // replay ring
+    long long cap_steps;
+    int n_envs;
+    int batch;
+    float* batch_out;             // [B, 24] gathered rows (the backward pass reads s, a from it)
+    long long* idx_out;           // [B] or NULL
+    const long long* idx_in;      // [B] or NULL: caller-provided indices instead of the Philox draw (tests)
+    uint64_t seed;
+    uint32_t salt;
+    const long long* ctrl;
+    int max_steps; float corr_lr, corr_eps, corr_momentum, box_lo, box_hi;
+    float gamma;
+    float* q_out;                 // [B]
+    float* qn_out;                // [B]
+    float* dq_out;                // [B] dLoss/dQ
+    float* loss_partial;          // [gridDim.x] per-workgroup sums of huber / B
+    float* x0_save; float* h1_save;   // critic pre-activations for rpo_mlp_backward
+};
+
+template <int EIN, int H>
+__global__ __launch_bounds__(kFwdThreads) void cart_ddpg_critic_forward_kernel(CriticFwdArgs p, CartConsts c) {
+    __shared__ TileLds<EIN> lds;
+    __shared__ __attribute__((aligned(16))) float4 tile[kRows * 6];      // the 16 sampled transition rows
+    const int row0 = blockIdx.x * kRows;
+    const int tid = threadIdx.x;
+    const int B = p.batch;
+    const long long t = p.ctrl[RPO_CTRL_T];
+    // ---- ReplayBuffer.sample (buffer.py:31-34): counter-based draw + gather, 6 float4 chunks per row
+    if (tid < kRows * 6) {
+        const int r = tid / 6, ch = tid - r * 6;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (row0 + r < B) {
+            long long row;
+            if (p.idx_in) {
+                row = p.idx_in[row0 + r];
+            } else {
+                const unsigned long long n_valid = (unsigned long long)((t < p.cap_steps ? t : p.cap_steps) * (long long)p.n_envs);
+                const rpo_u4 u = rpo_philox(p.seed, (uint32_t)(row0 + r), (uint32_t)t + p.salt, RPO_STREAM_SAMPLE);
+                row = (long long)__umul64hi(((unsigned long long)u.x << 32) | u.y, n_valid);
+            }
+            v = reinterpret_cast<const float4*>(p.rows)[row * 6 + ch];
+            reinterpret_cast<float4*>(p.batch_out)[(size_t)(row0 + r) * 6 + ch] = v;
+            if (p.idx_out && ch == 0) p.idx_out[row0 + r] = row;
+        }
+        tile[tid] = v;
+    }
+    __syncthreads();
+    const float* tf = reinterpret_cast<const float*>(tile);    // row r: s[0:6] a[6:8] s'[8:14] r[14] done[15] ...
+    if (tid < kRows * 6) {
+        const int r = tid / 6, i = tid - r * 6;
+        lds.in_s[r * kInS + i] = tf[r * 24 + 8 + i];           // next_state
+    }
+    // ---- pi_targ(s') (deterministic, rpo_ddpg.py:329)
+    mlp_tile_forward<EIN, H>(p.actor_target, lds, row0, B, nullptr, nullptr, 1, p.scale, p.base);
+    // ---- Complete + Proj (rpo_ddpg.py:330): per-row stop test == the reference's batched call for this env
+    if (tid < kRows) {
+        ActArgs a{};
+        a.noise_mode = RPO_NOISE_NONE;
+        a.max_steps = p.max_steps; a.corr_lr = p.corr_lr; a.corr_eps = p.corr_eps; a.corr_momentum = p.corr_momentum;
+        a.box_lo = p.box_lo; a.box_hi = p.box_hi;
+        int k;
+        const float2 act = cart_explore_project(a, c, row0 + tid, lds.out[tid * 2], 0.0f, t, k);
+        lds.in_a[tid * kInA] = act.x;
+        lds.in_a[tid * kInA + 1] = act.y;
+    }
+    // ---- Q_targ(s', a')
+    mlp_tile_forward<EIN, H>(p.critic_target, lds, row0, B, nullptr, nullptr, 0, 1.0f, 0.0f);
+    float qn = 0.0f;
+    if (tid < kRows) qn = lds.out[tid * 2];
+    __syncthreads();                                           // everybody is done with in_s / in_a / out
+    if (tid < kRows * 6) {
+        const int r = tid / 6, i = tid - r * 6;
+        lds.in_s[r * kInS + i] = tf[r * 24 + i];               // state
+    }
+    if (tid < kRows * 2) {
+        const int r = tid >> 1, i = tid & 1;
+        lds.in_a[r * kInA + i] = tf[r * 24 + 6 + i];           // stored action
+    }
+    // ---- Q(s, a), pre-activations kept for the backward pass
+    mlp_tile_forward<EIN, H>(p.critic, lds, row0, B, p.x0_save, p.h1_save, 0, 1.0f, 0.0f);
+    // ---- TD target + Huber (rpo_ddpg.py:331-335), dLoss/dQ
+    float hub = 0.0f;
+    if (tid < kRows && row0 + tid < B) {
+        const float q = lds.out[tid * 2];
+        const float y = tf[tid * 24 + 14] + p.gamma * (1.0f - tf[tid * 24 + 15]) * qn;
+        const float d = q - y, ad = fabsf(d);
+        const float inv_n = 1.0f / (float)B;
+        hub = (ad < 1.0f ? 0.5f * d * d : ad - 0.5f) * inv_n;
+        p.q_out[row0 + tid] = q;
+        p.qn_out[row0 + tid] = qn;
+        p.dq_out[row0 + tid] = fminf(fmaxf(d, -1.0f), 1.0f) * inv_n;
+    }
+    if (tid < 64) {
+        const float s = rpo_wave_sum(hub);
+        if (tid == 0) p.loss_partial[blockIdx.x] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rpo_cartsafe_ddpg_rollout(const rpo_mlp* actor_host, float scale, float base, int n_envs, float* state,
+                              float* action, int* ep_len, float* ep_ret, unsigned* ep_count, float* rows,
+                              long long cap_steps, float* stats, int stats_cap, long long* ctrl, int noise_mode,
+                              float eps_start, float eps_end, float eps_decay, float box_lo, float box_hi, int max_steps,
+                              float corr_lr, float corr_eps, float corr_momentum, const float* consts_host, int partial,
+                              int max_episode_steps, int auto_reset, float viol_thresh, unsigned long long seed,
+                              unsigned env_id_base, void* stream) {
+    if (!actor_host) return RPO_ERR_NULL;
+    if (n_envs <= 0 || max_episode_steps <= 0 || max_steps < 0) return RPO_ERR_ARG;
+    if (noise_mode != RPO_NOISE_NONE && noise_mode != RPO_NOISE_PHILOX && noise_mode != RPO_NOISE_CLIP_ONLY) return RPO_ERR_ARG;
+    if (!state || !action || !ep_len || !ep_ret || !ep_count || !ctrl) return RPO_ERR_NULL;
+    if (rows && cap_steps <= 0) return RPO_ERR_ARG;
+    if (stats && stats_cap <= 0) return RPO_ERR_ARG;
+    const Mlp actor = to_dev(actor_host);
+    if (actor.S != 6 || actor.A != 0 || actor.n_out != 1 || actor.cat || actor.H != 256 || !actor.Ws || !actor.W0) return RPO_ERR_ARG;
+    CartConsts c;
+    if (int e = load_consts(c, consts_host, partial)) return e;
+    RolloutArgs args{};
+    args.actor = actor; args.scale = scale; args.base = base;
+    args.act = ActArgs{n_envs, nullptr, nullptr, action, nullptr, noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi,
+                       max_steps, corr_lr, corr_eps, corr_momentum, (uint64_t)seed, (uint32_t)env_id_base, ctrl, stats, stats_cap};
+    args.step = StepArgs{n_envs, state, action, ep_len, ep_ret, ep_count, rows, cap_steps, stats, stats_cap, ctrl,
+                         max_episode_steps, auto_reset, viol_thresh, (uint64_t)seed, (uint32_t)env_id_base, 0};
+    const int grid = (n_envs + kRows - 1) / kRows;
+    if (actor.E == 128) {
+        hipLaunchKernelGGL((cart_ddpg_rollout_kernel<128, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, args, c);
+    } else if (actor.E == 256) {
+        hipLaunchKernelGGL((cart_ddpg_rollout_kernel<256, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, args, c);
+    } else {
+        return RPO_ERR_ARG;
+    }
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_cartsafe_ddpg_critic_forward(const rpo_mlp* actor_target_host, const rpo_mlp* critic_target_host,
+                                     const rpo_mlp* critic_host, float scale, float base, const float* rows,
+                                     long long cap_steps, int n_envs, int batch, float* batch_out, long long* idx_out,
+                                     const long long* idx_in, unsigned long long seed, unsigned sample_salt,
+                                     const long long* ctrl, int max_steps, float corr_lr, float corr_eps,
+                                     float corr_momentum, float box_lo, float box_hi, const float* consts_host,
+                                     int partial, float gamma, float* q_out, float* qn_out, float* dq_out,
+                                     float* loss_partial, float* x0_save, float* h1_save, void* stream) {
+    if (!actor_target_host || !critic_target_host || !critic_host) return RPO_ERR_NULL;
+    if (batch <= 0 || cap_steps <= 0 || n_envs <= 0 || max_steps < 0) return RPO_ERR_ARG;
+    if (!rows || !batch_out || !ctrl || !q_out || !qn_out || !dq_out || !loss_partial || !x0_save || !h1_save) return RPO_ERR_NULL;
+    CriticFwdArgs a{};
+    a.actor_target = to_dev(actor_target_host); a.critic_target = to_dev(critic_target_host); a.critic = to_dev(critic_host);
+    const Mlp& at = a.actor_target;
+    const Mlp& ct = a.critic_target;
+    const Mlp& cr = a.critic;
+    if (at.S != 6 || at.A != 0 || at.n_out != 1 || at.cat || ct.S != 6 || ct.A != 2 || ct.cat || cr.S != 6 || cr.A != 2 || cr.cat ||
+        at.H != 256 || ct.H != 256 || cr.H != 256 || at.E != ct.E || at.E != cr.E || ct.n_out != 1 || cr.n_out != 1)
+        return RPO_ERR_ARG;
+    CartConsts c;
+    if (int e = load_consts(c, consts_host, partial)) return e;
+    a.scale = scale; a.base = base; a.rows = rows; a.cap_steps = cap_steps; a.n_envs = n_envs; a.batch = batch;
+    a.batch_out = batch_out; a.idx_out = idx_out; a.idx_in = idx_in; a.seed = (uint64_t)seed; a.salt = (uint32_t)sample_salt;
+    a.ctrl = ctrl; a.max_steps = max_steps; a.corr_lr = corr_lr; a.corr_eps = corr_eps; a.corr_momentum = corr_momentum;
+    a.box_lo = box_lo; a.box_hi = box_hi; a.gamma = gamma; a.q_out = q_out; a.qn_out = qn_out; a.dq_out = dq_out;
+    a.loss_partial = loss_partial; a.x0_save = x0_save; a.h1_save = h1_save;
+    const int grid = (batch + kRows - 1) / kRows;
+    if (at.E == 128) {
+        hipLaunchKernelGGL((cart_ddpg_critic_forward_kernel<128, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a, c);
+    } else if (at.E == 256) {
+        hipLaunchKernelGGL((cart_ddpg_critic_forward_kernel<256, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a, c);
+    } else {
+        return RPO_ERR_ARG;
+    }
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -14,26 +14,11 @@
 //   backward  dx0[r][e] = sum_j dh[r][j] W0[j][e]  N-contiguous: a float4 along e serves 4 interleaved output tiles
 //             (tile c, column n <-> e = 4n + c) that share the A operand;
 //   weights   dW0[j][e] = sum_b dh[b][j] x1[b][e]  both operands contiguous in their M / N index.
-#include "common.h"
+#include "mlp_tile.h"
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kRows = 16;          // rows (samples) per workgroup
-constexpr int kThreads = 256;      // 4 waves
-
-struct Mlp {
-    const float *Ws, *bs, *Wa, *ba, *W0, *b0, *W1, *b1, *W1b, *b1b;   // W1b / b1b: second head (SAC log-std), n_out = 2
-    int S, A, E, H, n_out, cat;
-};
-struct MlpGrad {
-    float *Ws, *bs, *Wa, *ba, *W0, *b0, *W1, *b1, *W1b, *b1b;
-};
-
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
+using namespace rpo_mlp_dev;
 
 // ------------------------------------------------------------------------------------------------- forward
 // out_mode: 0 identity, 1 tanh-box on output 0 (scale * tanh(o) + base; BoxConstraint, model/utils.py:40-51)
@@ -48,167 +33,24 @@ struct FwdArgs {
     int out_mode; float scale, base;
 };
 
-constexpr int kFwdWaves = 8;       // forward: 512 threads, every wave owns H / 8 hidden columns
-constexpr int kFwdThreads = kFwdWaves * 64;
-
 template <int EIN, int H>
 __global__ __launch_bounds__(kFwdThreads) void mlp_forward_kernel(FwdArgs p) {
-    constexpr int LDX = EIN + 4;                               // padded row stride of x1 (ds_read_b128, 16-B aligned)
-    __shared__ __attribute__((aligned(16))) float x1[kRows * LDX];
-    __shared__ float in_s[kRows * 64];                         // inputs of this row tile (S <= 64)
-    __shared__ float in_a[kRows * 48];                         // (A <= 48)
-    __shared__ float part[kFwdWaves * kRows * 2];
+    __shared__ TileLds<EIN> lds;
     const Mlp& net = p.net;
     const int row0 = blockIdx.x * kRows;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lg = lane >> 4;
-
-    // ---- the wave's slice of W0 starts moving now; its latency hides behind the input staging and layer 1
-    constexpr int NT = H / (16 * kFwdWaves);                    // 16-column tiles per wave
-    constexpr int ITS = EIN / 16;                               // k-groups of 16
-    constexpr int PRE = ITS < 16 ? ITS : 16;                    // k-groups kept in registers up front
-    const int j0 = wave * (H / kFwdWaves);
-    float4 wpre[PRE][NT];
-#pragma unroll
-    for (int it = 0; it < PRE; ++it)
-#pragma unroll
-        for (int c = 0; c < NT; ++c)
-            wpre[it][c] = *reinterpret_cast<const float4*>(&net.W0[(size_t)(j0 + c * 16 + li) * EIN + it * 16 + lg * 4]);
-
-    // the caches are cold at kernel entry and every dependent global read costs ~0.7 us of exposed latency with one
-    // or two waves per SIMD: everything the epilogue needs is requested now as well
-    float b0v[NT], w1av[NT], w1bv[NT];
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
-        b0v[c] = net.b0[j0 + c * 16 + li];
-        w1av[c] = net.W1[j0 + c * 16 + li];
-        w1bv[c] = net.n_out > 1 ? net.W1b[j0 + c * 16 + li] : 0.0f;
-    }
-    const float b1v = (tid < kRows * net.n_out) ? (((tid % net.n_out) == 0) ? net.b1[0] : net.b1b[0]) : 0.0f;
-
+    const int tid = threadIdx.x;
     for (int idx = tid; idx < kRows * net.S; idx += kFwdThreads) {
         const int r = idx / net.S, i = idx - r * net.S;
-        in_s[r * 64 + i] = (row0 + r < p.n) ? p.s[(size_t)(row0 + r) * p.s_stride + i] : 0.0f;
+        lds.in_s[r * kInS + i] = (row0 + r < p.n) ? p.s[(size_t)(row0 + r) * p.s_stride + i] : 0.0f;
     }
     for (int idx = tid; idx < kRows * net.A; idx += kFwdThreads) {
         const int r = idx / net.A, i = idx - r * net.A;
-        in_a[r * 48 + i] = (row0 + r < p.n) ? p.a[(size_t)(row0 + r) * p.a_stride + i] : 0.0f;
+        lds.in_a[r * kInA + i] = (row0 + r < p.n) ? p.a[(size_t)(row0 + r) * p.a_stride + i] : 0.0f;
     }
-    // first-layer weights of this thread's embedding column, fetched in chunks of 8 before they are needed
-    const int e_col = tid;                                      // EIN <= 512 == kFwdThreads: one column per thread
-    const bool has_col = e_col < EIN;
-    const bool act_part = has_col && net.cat && e_col >= net.E; // concatenating critic: columns [E, 2E) embed the action
-    const int er = act_part ? e_col - net.E : e_col;
-    float acc1[kRows];
-    float ws0[8], wa0[8];                                       // first chunk of this column's first-layer weights
-    {
-        const float bias = !has_col ? 0.0f
-                                    : (act_part ? net.ba[er] : (net.bs[er] + ((net.A > 0 && !net.cat) ? net.ba[er] : 0.0f)));
-#pragma unroll
-        for (int r = 0; r < kRows; ++r) acc1[r] = bias;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            ws0[u] = (has_col && !act_part && u < net.S) ? net.Ws[er * net.S + u] : 0.0f;
-            wa0[u] = (has_col && net.A > 0 && (act_part || !net.cat) && u < net.A) ? net.Wa[er * net.A + u] : 0.0f;
-        }
-    }
-    __syncthreads();
-
-    // ---- layer 1 (VALU): x0[r][e]
-    if (has_col) {
-        if (!act_part) {
-            for (int i0 = 0; i0 < net.S; i0 += 8) {
-                float w[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) w[u] = (i0 == 0) ? ws0[u] : ((i0 + u < net.S) ? net.Ws[er * net.S + i0 + u] : 0.0f);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (i0 + u < net.S) {
-#pragma unroll
-                        for (int r = 0; r < kRows; ++r) acc1[r] = fmaf(in_s[r * 64 + i0 + u], w[u], acc1[r]);
-                    }
-                }
-            }
-        }
-        if (net.A > 0 && (act_part || !net.cat)) {
-            for (int i0 = 0; i0 < net.A; i0 += 8) {
-                float w[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) w[u] = (i0 == 0) ? wa0[u] : ((i0 + u < net.A) ? net.Wa[er * net.A + i0 + u] : 0.0f);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (i0 + u < net.A) {
-#pragma unroll
-                        for (int r = 0; r < kRows; ++r) acc1[r] = fmaf(in_a[r * 48 + i0 + u], w[u], acc1[r]);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < kRows; ++r) {
-            if (p.x0_save && row0 + r < p.n) p.x0_save[(size_t)(row0 + r) * EIN + e_col] = acc1[r];
-            x1[r * LDX + e_col] = fmaxf(acc1[r], 0.0f);
-        }
-    }
-    __syncthreads();
-
-    // ---- layer 2 (MFMA): wave w owns hidden columns [w*H/8, (w+1)*H/8) = NT tiles of 16
-    f32x4 acc[NT];
-#pragma unroll
-    for (int c = 0; c < NT; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-        const float4 a4 = *reinterpret_cast<const float4*>(&x1[li * LDX + it * 16 + lg * 4]);
-        float4 b4[NT];
-#pragma unroll
-        for (int c = 0; c < NT; ++c)
-            b4[c] = (it < PRE) ? wpre[it < PRE ? it : 0][c]
-                               : *reinterpret_cast<const float4*>(&net.W0[(size_t)(j0 + c * 16 + li) * EIN + it * 16 + lg * 4]);
-        // consecutive MFMAs go to different accumulators (40-cycle dependent latency vs 32-cycle issue)
-#pragma unroll
-        for (int c = 0; c < NT; ++c) acc[c] = mfma4(a4.x, b4[c].x, acc[c]);
-#pragma unroll
-        for (int c = 0; c < NT; ++c) acc[c] = mfma4(a4.y, b4[c].y, acc[c]);
-#pragma unroll
-        for (int c = 0; c < NT; ++c) acc[c] = mfma4(a4.z, b4[c].z, acc[c]);
-#pragma unroll
-        for (int c = 0; c < NT; ++c) acc[c] = mfma4(a4.w, b4[c].w, acc[c]);
-    }
-    // acc[c][i] = h1[row = 4*lg + i][col = j0 + 16c + li] (before bias)
-    float po[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
-        const int col = j0 + c * 16 + li;
-        const float b0 = b0v[c];
-        const float w1a = w1av[c], w1b = w1bv[c];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float h = acc[c][i] + b0;
-            const int row = row0 + lg * 4 + i;
-            if (p.h1_save && row < p.n) p.h1_save[(size_t)row * H + col] = h;
-            const float hr = fmaxf(h, 0.0f);
-            po[0][i] = fmaf(hr, w1a, po[0][i]);
-            po[1][i] = fmaf(hr, w1b, po[1][i]);
-        }
-    }
-    // ---- head: reduce over the 16 lanes that share lg, then over the waves (fixed order)
-#pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float v = po[o][i];
-            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (li == 0) part[(wave * kRows + lg * 4 + i) * 2 + o] = v;
-        }
-    __syncthreads();
+    mlp_tile_forward<EIN, H>(net, lds, row0, p.n, p.x0_save, p.h1_save, p.out_mode, p.scale, p.base);
     if (tid < kRows * net.n_out) {
         const int r = tid / net.n_out, o = tid - r * net.n_out;
-        if (row0 + r < p.n) {
-            float v = b1v;
-            for (int w = 0; w < kFwdWaves; ++w) v += part[(w * kRows + r) * 2 + o];
-            if (p.out_mode == 1 && o == 0) v = p.scale * tanhf(v) + p.base;
-            p.out[(size_t)(row0 + r) * net.n_out + o] = v;
-        }
+        if (row0 + r < p.n) p.out[(size_t)(row0 + r) * net.n_out + o] = lds.out[r * 2 + o];
     }
 }
 

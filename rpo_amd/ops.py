@@ -171,6 +171,29 @@ class CartSafeKernels(object):
             _p(ctrl, torch.int64, allow_none=True), _p(stats, allow_none=True),
             0 if stats is None else stats.shape[0], _stream()), "rpo_cartsafe_act_project")
 
+    # ---- fused pipelines (rpo_amd/csrc/fused.hip) ----------------------------------------------------------------
+    def ddpg_rollout(self, actor_desc, scale, base, internal, action, ep_len, ep_ret, ep_count, rows, cap_steps, stats,
+                     ctrl, noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi, max_steps, corr_lr, corr_eps,
+                     corr_momentum, max_episode_steps, auto_reset, viol_thresh, seed, env_id_base):
+        net = actor_desc.net_struct()
+        check(_lib.load().rpo_cartsafe_ddpg_rollout(
+            ctypes.byref(net), scale, base, internal.shape[0], _p(internal), _p(action), _p(ep_len, torch.int32),
+            _p(ep_ret), _p(ep_count, torch.int32), _p(rows, allow_none=True), cap_steps, _p(stats, allow_none=True),
+            0 if stats is None else stats.shape[0], _p(ctrl, torch.int64), noise_mode, eps_start, eps_end, eps_decay,
+            box_lo, box_hi, max_steps, corr_lr, corr_eps, corr_momentum, self._cptr, self.partial, max_episode_steps,
+            int(auto_reset), viol_thresh, seed, env_id_base, _stream()), "rpo_cartsafe_ddpg_rollout")
+
+    def ddpg_critic_forward(self, actor_target, critic_target, critic, scale, base, rows, cap_steps, n_envs, batch_out,
+                            idx_out, idx_in, seed, salt, ctrl, max_steps, corr_lr, corr_eps, corr_momentum, box_lo, box_hi,
+                            gamma, q_out, qn_out, dq_out, loss_partial, x0_save, h1_save):
+        at, ct, cr = actor_target.net_struct(), critic_target.net_struct(), critic.net_struct()
+        check(_lib.load().rpo_cartsafe_ddpg_critic_forward(
+            ctypes.byref(at), ctypes.byref(ct), ctypes.byref(cr), scale, base, _p(rows), cap_steps, n_envs,
+            batch_out.shape[0], _p(batch_out), _p(idx_out, torch.int64, allow_none=True),
+            _p(idx_in, torch.int64, allow_none=True), seed, salt, _p(ctrl, torch.int64), max_steps, corr_lr, corr_eps,
+            corr_momentum, box_lo, box_hi, self._cptr, self.partial, gamma, _p(q_out), _p(qn_out), _p(dq_out),
+            _p(loss_partial), _p(x0_save), _p(h1_save), _stream()), "rpo_cartsafe_ddpg_critic_forward")
+
     def complete_bwd(self, obs, grad_action, grad_ap):
         check(_lib.load().rpo_cartsafe_complete_bwd(grad_action.shape[0], _p(grad_action), _p(grad_ap), self._cptr,
                                                     self.partial, _stream()), "rpo_cartsafe_complete_bwd")

@@ -127,6 +127,9 @@ class ReplayDraws(object):
     def replay_sample_gather(self, rows, cap_steps, n_envs, out, idx_out, seed, salt, ctrl):
         self._inner.replay_gather(self.rows, self.idx.pop(0), out)
 
+    def mlp_forward(self, *a, **k):          # FusedNets holds the backend it was built with: keep forwarding explicit
+        return self._inner.mlp_forward(*a, **k)
+
 
 def product_tol(envname):
     return TOL
@@ -144,6 +147,9 @@ def run_product_update(golden, algo, envname, backend, device, fused=True):
     rows = torch.tensor(buffer_rows(g, tr.kernels.cols, tr.kernels.row_floats)).to(device)
     proxy = ReplayDraws(backend, g, rows, device)
     tr.backend = tr.buffer._ops = proxy
+    tr.buffer.rows = rows                                      # fused pipelines sample from the ring directly ...
+    tr.buffer.ctrl[0] = 1
+    tr._idx_inject = lambda: proxy.idx.pop(0)                  # ... with the fixture's indices
     closs, aloss = [], []
     for t in range(1, 5):
         tr.train(t)
