@@ -281,10 +281,23 @@ __global__ __launch_bounds__(kThreads) void mlp_bwd_weights_kernel(BwdArgs p) {
             p.g.W1[j] += ((partial[0][1][o] + partial[1][1][o]) + partial[2][1][o]) + partial[3][1][o];
             if (net.n_out > 1) p.g.W1b[j] += ((partial[0][2][o] + partial[1][2][o]) + partial[2][2][o]) + partial[3][2][o];
         }
-        if (rb == 0 && tid < net.n_out) {
-            float sacc = 0.0f;
-            for (int b2 = 0; b2 < p.n; ++b2) sacc += p.dout[(size_t)b2 * net.n_out + tid];
-            if (tid == 0) p.g.b1[0] += sacc; else p.g.b1b[0] += sacc;
+        if (rb == 0) {
+            // db1_k = sum_b dout[b][k]: strided per-thread partials, fixed-pattern wave reduction, 4 wave partials added
+            // in order (a single-thread loop over the batch costs ~18 us of serialised load latency)
+            __syncthreads();                                   // `partial` is reused below
+            float s0 = 0.0f, s1 = 0.0f;
+            for (int b2 = tid; b2 < p.n; b2 += kThreads) {
+                s0 += p.dout[(size_t)b2 * net.n_out];
+                if (net.n_out > 1) s1 += p.dout[(size_t)b2 * net.n_out + 1];
+            }
+            s0 = rpo_wave_sum(s0);
+            s1 = rpo_wave_sum(s1);
+            if (o == 0) { partial[part][0][0] = s0; partial[part][1][0] = s1; }
+            __syncthreads();
+            if (tid == 0) {
+                p.g.b1[0] += ((partial[0][0][0] + partial[1][0][0]) + partial[2][0][0]) + partial[3][0][0];
+                if (net.n_out > 1) p.g.b1b[0] += ((partial[0][1][0] + partial[1][1][0]) + partial[2][1][0]) + partial[3][1][0];
+            }
         }
         return;
     }

@@ -50,29 +50,6 @@ __device__ __forceinline__ void mlp_tile_forward(const Mlp& net, TileLds<EIN>& l
     float* part = lds.part;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    // ---- the wave's slice of W0 starts moving now; its latency hides behind the input staging and layer 1
-    constexpr int NT = H / (16 * kFwdWaves);                    // 16-column tiles per wave
-    constexpr int ITS = EIN / 16;                               // k-groups of 16
-    constexpr int PRE = ITS < 16 ? ITS : 16;                    // k-groups kept in registers up front
-    const int j0 = wave * (H / kFwdWaves);
-    float4 wpre[PRE][NT];
-#pragma unroll
-    for (int it = 0; it < PRE; ++it)
-#pragma unroll
-        for (int c = 0; c < NT; ++c)
-            wpre[it][c] = *reinterpret_cast<const float4*>(&net.W0[(size_t)(j0 + c * 16 + li) * EIN + it * 16 + lg * 4]);
-
-    // the caches are cold at kernel entry and every dependent global read costs ~0.7 us of exposed latency with one
-    // or two waves per SIMD: everything the epilogue needs is requested now as well
-    float b0v[NT], w1av[NT], w1bv[NT];
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
-        b0v[c] = net.b0[j0 + c * 16 + li];
-        w1av[c] = net.W1[j0 + c * 16 + li];
-        w1bv[c] = net.n_out > 1 ? net.W1b[j0 + c * 16 + li] : 0.0f;
-    }
-    const float b1v = (tid < kRows * net.n_out) ? (((tid % net.n_out) == 0) ? net.b1[0] : net.b1b[0]) : 0.0f;
-
     // first-layer weights of this thread's embedding column, fetched in chunks of 8 before they are needed
     const int e_col = tid;                                      // EIN <= 512 == kFwdThreads: one column per thread
     const bool has_col = e_col < EIN;
@@ -91,6 +68,30 @@ __device__ __forceinline__ void mlp_tile_forward(const Mlp& net, TileLds<EIN>& l
             wa0[u] = (has_col && net.A > 0 && (act_part || !net.cat) && u < net.A) ? net.Wa[er * net.A + u] : 0.0f;
         }
     }
+    // ---- then the wave's slice of W0 (128 KB per workgroup, ~2.7 us at the ~47 GB/s one CU pulls from L2): requested
+    //      AFTER the few loads layer 1 waits for (returns are in order), it streams in underneath layer 1 and feeds
+    //      the MFMA loop k-group by k-group
+    constexpr int NT = H / (16 * kFwdWaves);                    // 16-column tiles per wave
+    constexpr int ITS = EIN / 16;                               // k-groups of 16
+    constexpr int PRE = ITS < 16 ? ITS : 16;                    // k-groups kept in registers up front
+    const int j0 = wave * (H / kFwdWaves);
+    float4 wpre[PRE][NT];
+#pragma unroll
+    for (int it = 0; it < PRE; ++it)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+            wpre[it][c] = *reinterpret_cast<const float4*>(&net.W0[(size_t)(j0 + c * 16 + li) * EIN + it * 16 + lg * 4]);
+
+    // what the epilogue needs is requested last
+    float b0v[NT], w1av[NT], w1bv[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        b0v[c] = net.b0[j0 + c * 16 + li];
+        w1av[c] = net.W1[j0 + c * 16 + li];
+        w1bv[c] = net.n_out > 1 ? net.W1b[j0 + c * 16 + li] : 0.0f;
+    }
+    const float b1v = (tid < kRows * net.n_out) ? (((tid % net.n_out) == 0) ? net.b1[0] : net.b1b[0]) : 0.0f;
+
     __syncthreads();
 
     // ---- layer 1 (VALU): x0[r][e]
