@@ -82,43 +82,75 @@ def time_kernel(fn, reps=100):
     return float(np.median(times)), float(np.mean(times))
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3              # v_mfma_f32_16x16x4_f32 == the f32 vector peak (MI355X_MICROARCH.md)
+ACTOR_FLOPS = 2 * (6 * 128 + 128 * 256 + 256)                  # per row, rpo/algo/model/policy.py:24-33 at 6-128-256-1
+CRITIC_FLOPS = 2 * (6 * 128 + 2 * 128 + 128 * 256 + 256)       # per row, model/value.py:51-59
+
+
 def kernel_clinic(tr):
-    """Per-kernel launch durations of the hand-written kernels at the bench size and in the streaming regime."""
+    """Per-launch durations of the kernels of one iteration (at the bench size) and of the streaming kernels at 1M
+    lanes.  HBM-bound kernels are priced in algorithmic bytes, the MLP pipelines in flops."""
     from rpo_amd import ops
     from rpo_amd.env.vec import VecEnv
     out = {}
-    k, v, buf = tr.kernels, tr.vec, tr.buffer
+    k, v, buf, f, B = tr.kernels, tr.vec, tr.buffer, tr.fused, tr.batch_size
+    scale, base = tr._box_affine
+    dev = v.device
 
     def step_at(vec, rows, cap):
         return lambda: k.step(vec.internal, vec.obs, vec.action, vec.ep_len, vec.ep_ret, vec.ep_count, rows, cap,
                               vec.stats, vec.ctrl, 200, True, 1e-3, vec.seed, vec.env_id_base)
-    ap = torch.zeros(v.n, device=v.device)
-    act = lambda vec, a: (lambda: k.act_project(vec.obs, a, None, vec.action, None, ops.NOISE_PHILOX, 1.0, 1.0, 0.0, -10.0,  # noqa: E731
-                                                 10.0, 10, 2e-2, 1e-5, 0.0, vec.seed, vec.env_id_base, vec.ctrl, vec.stats))
-    out["cartsafe_step_kernel"] = dict(n=v.n, us=time_kernel(step_at(v, buf.rows, buf.capacity))[0],
-                                       bytes=STEP_BYTES_PER_ENV * v.n)
-    out["cartsafe_act_project_kernel"] = dict(n=v.n, us=time_kernel(act(v, ap))[0], bytes=40 * v.n)
-    batch = torch.zeros(256, k.row_floats, device=v.device)
-    out["replay_sample_gather_kernel"] = dict(
-        n=256, us=time_kernel(lambda: ops.replay_sample_gather(buf.rows, buf.capacity, buf.n_envs, batch, None, 1, 0,
-                                                               v.ctrl))[0], bytes=(178 + 4) * 256)
-    # streaming regime: 1M lanes, ring of 8 vector steps
+
+    def act_at(vec, a):
+        return lambda: k.act_project(vec.obs, a, None, vec.action, None, ops.NOISE_PHILOX, 1.0, 1.0, 0.0, -10.0, 10.0, 10,
+                                     2e-2, 1e-5, 0.0, vec.seed, vec.env_id_base, vec.ctrl, vec.stats)
+
+    def rollout_at(vec, rows, cap):
+        return lambda: k.ddpg_rollout(f.descs["actor"], scale, base, vec.internal, vec.action, vec.ep_len, vec.ep_ret,
+                                      vec.ep_count, rows, cap, vec.stats, vec.ctrl, ops.NOISE_PHILOX, 1.0, 1.0, 0.0, -10.0,
+                                      10.0, 10, 2e-2, 1e-5, 0.0, 200, True, 1e-3, vec.seed, vec.env_id_base)
+
+    def hbm(name, n, us, bytes_per_unit):
+        out[name] = dict(n=n, us=us, bound="hbm", work=bytes_per_unit * n, rate=bytes_per_unit * n / us * 1e-3,
+                         unit="GB/s", peak=HBM_PEAK_GBS)
+
+    def mfma(name, n, us, flops_per_unit):
+        out[name] = dict(n=n, us=us, bound="mfma", work=flops_per_unit * n, rate=flops_per_unit * n / us * 1e-6,
+                         unit="TFLOP/s", peak=MFMA_F32_PEAK_TFLOPS)
+
+    # ---- the launches of one iteration at the bench size
+    mfma("cart_ddpg_rollout_kernel", v.n, time_kernel(rollout_at(v, buf.rows, buf.capacity))[0], ACTOR_FLOPS)
+    d = f.descs["critic"]
+    cf = lambda: k.ddpg_critic_forward(  # noqa: E731
+        f.descs["actor_target"], f.descs["critic_target"], d, scale, base, buf.rows, buf.capacity, buf.n_envs, tr._batch,
+        None, None, buf.seed, 0, buf.ctrl, 10, 2e-2, 1e-5, 0.0, -10.0, 10.0, 0.95, f.buf("q", B, 1), f.buf("qn", B, 1),
+        f.buf("dq", B, 1), f.buf("loss_parts", (B + 15) // 16), f.buf("critic.x0", B, d.ein), f.buf("critic.h1", B, d.H))
+    mfma("cart_ddpg_critic_forward_kernel", B, time_kernel(cf)[0], ACTOR_FLOPS + 2 * CRITIC_FLOPS)
+    cols = tr.buffer.split(tr._batch)
+    bw = lambda: f.backward("critic", cols["state"], cols["action"], f.buf("dq", B, 1))   # noqa: E731
+    mfma("mlp_bwd_rows+weights_kernels", B, time_kernel(bw)[0], 2 * CRITIC_FLOPS)
+    # ---- single-stage kernels (warm-up phase, SAC / pendulum path, API calls) and the streaming regime
+    ap = torch.zeros(v.n, device=dev)
+    hbm("cartsafe_step_kernel", v.n, time_kernel(step_at(v, buf.rows, buf.capacity))[0], STEP_BYTES_PER_ENV)
+    hbm("cartsafe_act_project_kernel", v.n, time_kernel(act_at(v, ap))[0], 40)
+    batch = torch.zeros(B, k.row_floats, device=dev)
+    hbm("replay_sample_gather_kernel", B, time_kernel(lambda: ops.replay_sample_gather(
+        buf.rows, buf.capacity, buf.n_envs, batch, None, 1, 0, v.ctrl))[0], 178 + 4)
     big_n = 1 << 20
-    big = VecEnv(k, big_n, v.device, seed=3, stats_cap=64)
+    big = VecEnv(k, big_n, dev, seed=3, stats_cap=64)
     big.reset()
-    rows = torch.zeros(8 * big_n, k.row_floats, device=v.device)
-    big_ap = torch.zeros(big_n, device=v.device)
-    out["cartsafe_step_kernel@1M"] = dict(n=big_n, us=time_kernel(step_at(big, rows, 8), reps=20)[0],
-                                          bytes=STEP_BYTES_PER_ENV * big_n)
-    out["cartsafe_act_project_kernel@1M"] = dict(n=big_n, us=time_kernel(act(big, big_ap), reps=20)[0], bytes=40 * big_n)
-    big_batch = torch.zeros(1 << 20, k.row_floats, device=v.device)
-    out["replay_sample_gather_kernel@1M"] = dict(
-        n=1 << 20, us=time_kernel(lambda: ops.replay_sample_gather(rows, 8, big_n, big_batch, None, 1, 0, big.ctrl),
-                                  reps=20)[0], bytes=(178 + 4) * (1 << 20))
-    for name, d in out.items():
-        d["GBs"] = d["bytes"] / d["us"] * 1e-3
-        log("  %-36s n=%-8d %9.2f us  %8.1f GB/s (%.1f%% of HBM peak)" % (name, d["n"], d["us"], d["GBs"],
-                                                                          100 * d["GBs"] / HBM_PEAK_GBS))
+    rows = torch.zeros(8 * big_n, k.row_floats, device=dev)
+    big_ap = torch.zeros(big_n, device=dev)
+    hbm("cartsafe_step_kernel@1M", big_n, time_kernel(step_at(big, rows, 8), reps=20)[0], STEP_BYTES_PER_ENV)
+    hbm("cartsafe_act_project_kernel@1M", big_n, time_kernel(act_at(big, big_ap), reps=20)[0], 40)
+    big_batch = torch.zeros(big_n, k.row_floats, device=dev)
+    hbm("replay_sample_gather_kernel@1M", big_n, time_kernel(lambda: ops.replay_sample_gather(
+        rows, 8, big_n, big_batch, None, 1, 0, big.ctrl), reps=20)[0], 178 + 4)
+    mfma("cart_ddpg_rollout_kernel@1M", big_n, time_kernel(rollout_at(big, rows, 8), reps=5)[0], ACTOR_FLOPS)
+    for name, e in out.items():
+        e["frac"] = e["rate"] / e["peak"]
+        log("  %-36s n=%-8d %9.2f us  %9.2f %-8s (%.1f%% of the %s peak)" % (name, e["n"], e["us"], e["rate"], e["unit"],
+                                                                           100 * e["frac"], e["bound"]))
     del big, rows, big_batch
     torch.cuda.empty_cache()
     return out
@@ -232,22 +264,27 @@ def main():
             torch.cuda.synchronize()
             result["rollout_only_env_steps_per_s"] = ENVS_PER_GPU * 1000 / (time.perf_counter() - t1)
             del ro
-        if not args.no_clinic and world == 1:
-            log("kernel clinic (HIP events on the launch stream):")
+        if not args.no_clinic and world == 1 and tr.fused is not None:
+            log("kernel clinic (hipGraph of back-to-back launches between two HIP events on the launch stream):")
             clinic = kernel_clinic(tr)
-            dom = max(("cartsafe_step_kernel", "cartsafe_act_project_kernel", "replay_sample_gather_kernel"),
-                      key=lambda n: clinic[n]["us"])
-            d, big = clinic[dom], clinic[dom + "@1M"]
+            in_iter = ("cart_ddpg_rollout_kernel", "cart_ddpg_critic_forward_kernel", "mlp_bwd_rows+weights_kernels")
+            dom = max(in_iter, key=lambda n: clinic[n]["us"])
+            d, st = clinic[dom], clinic["cartsafe_step_kernel@1M"]
             result["roofline"] = {
-                "bound": "hbm", "kernel": dom, "achieved": d["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": d["GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, d["n"]), "launch_us": d["us"],
-                "units_per_launch": d["n"],
-                "algorithmic_bytes_per_launch": d["bytes"],
-                "note": "latency-bound at 4096 lanes (%.2f MB per launch); same kernel at 1M lanes: %.1f GB/s = %.3f "
-                        "of peak" % (d["bytes"] / 1e6, big["GBs"], big["GBs"] / HBM_PEAK_GBS),
-                "streaming_regime": {"units_per_launch": big["n"], "launch_us": big["us"], "achieved": big["GBs"],
-                                     "frac": big["GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, big["n"])},
-                "all_kernels": {k: {"us": v["us"], "GBs": v["GBs"]} for k, v in clinic.items()},
+                "bound": d["bound"], "kernel": dom, "achieved": d["rate"], "peak": d["peak"], "unit": d["unit"],
+                "frac": d["frac"], "traffic": None, "launch_us": d["us"], "units_per_launch": d["n"],
+                "algorithmic_flops_per_launch": d["work"],
+                "note": "dominant launch of the iteration: ReplayBuffer.sample + pi_targ + projection + Q_targ + Q + TD/Huber "
+                        "for 256 samples in one workgroup-per-16-rows pipeline; latency-bound (16 workgroups, each "
+                        "streaming 3 x 128 KB of f32 weights at ~47 GB/s per CU). Streaming regime of the HBM-bound env-step "
+                        "kernel (1M lanes): %.0f GB/s = %.3f of the 8 TB/s peak, PMC traffic %s B vs %d algorithmic B."
+                        % (st["rate"], st["frac"], pmc_traffic("cartsafe_step_kernel", st["n"]), st["work"]),
+                "hbm_streaming": {"kernel": "cartsafe_step_kernel", "bound": "hbm", "units_per_launch": st["n"],
+                                  "launch_us": st["us"], "achieved": st["rate"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": st["frac"], "traffic": pmc_traffic("cartsafe_step_kernel", st["n"]),
+                                  "algorithmic_bytes_per_launch": st["work"]},
+                "all_kernels": {kk: {"us": vv["us"], "rate": vv["rate"], "unit": vv["unit"], "frac": vv["frac"]}
+                                for kk, vv in clinic.items()},
             }
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline()

@@ -9,6 +9,8 @@
 //                  rpo_mlp_forward launches, one projection launch and rpo_td_huber)
 //
 // One workgroup = 16 rows (lanes / batch samples) and 512 threads; the MLP tile forward is mlp_tile.h.
+#include <stdlib.h>
+
 #include "cartsafe_dev.h"
 #include "mlp_tile.h"
 
@@ -29,9 +31,12 @@ struct RolloutArgs {
     StepArgs step;                // env state, bookkeeping, ring, statistics, ctrl
 };
 
-template <int EIN, int H>
+template <int EIN, int H, int RT>
 __global__ __launch_bounds__(kFwdThreads) void cart_ddpg_rollout_kernel(RolloutArgs p, CartConsts c) {
-    __shared__ TileLds<EIN> lds;
+    typedef TileLds<EIN, RT, 8, 8> Lds;                          // 16 * RT lanes per workgroup; S = 6 fits stride 8
+    __shared__ Lds lds;
+    constexpr int kInS = Lds::kS;
+    constexpr int kRows = rpo_mlp_dev::kRows * RT;               // (shadows the 16-row constant below)
     const int row0 = blockIdx.x * kRows;
     const int tid = threadIdx.x;
     const int n = p.step.n;
@@ -40,7 +45,7 @@ __global__ __launch_bounds__(kFwdThreads) void cart_ddpg_rollout_kernel(RolloutA
         const int r = tid / 6, i = tid - r * 6;
         lds.in_s[r * kInS + i] = (row0 + r < n) ? p.step.state[(size_t)(row0 + r) * 6 + i] : 0.0f;
     }
-    mlp_tile_forward<EIN, H>(p.actor, lds, row0, n, nullptr, nullptr, 1, p.scale, p.base);
+    mlp_tile_forward<EIN, H, RT, Lds>(p.actor, lds, row0, n, nullptr, nullptr, 1, p.scale, p.base);
 
     float st[kStepStats];
 #pragma unroll
@@ -214,11 +219,19 @@ int rpo_cartsafe_ddpg_rollout(const rpo_mlp* actor_host, float scale, float base
                        max_steps, corr_lr, corr_eps, corr_momentum, (uint64_t)seed, (uint32_t)env_id_base, ctrl, stats, stats_cap};
     args.step = StepArgs{n_envs, state, action, ep_len, ep_ret, ep_count, rows, cap_steps, stats, stats_cap, ctrl,
                          max_episode_steps, auto_reset, viol_thresh, (uint64_t)seed, (uint32_t)env_id_base, 0};
-    const int grid = (n_envs + kRows - 1) / kRows;
-    if (actor.E == 128) {
-        hipLaunchKernelGGL((cart_ddpg_rollout_kernel<128, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, args, c);
+    // 64 lanes per workgroup once that still fills the chip: the 128 KB hidden-layer matrix is streamed once per
+    // workgroup, so wider tiles cut the L2 traffic 4x (RPO_ROLLOUT_WIDE=0/1 overrides the size rule)
+    const char* wide_env = getenv("RPO_ROLLOUT_WIDE");
+    const bool wide = actor.E == 128 && (wide_env ? atoi(wide_env) != 0 : n_envs >= 64 * 192);
+    if (actor.E == 128 && wide) {
+        hipLaunchKernelGGL((cart_ddpg_rollout_kernel<128, 256, 4>), dim3((n_envs + 63) / 64), dim3(kFwdThreads), 0,
+                           (hipStream_t)stream, args, c);
+    } else if (actor.E == 128) {
+        hipLaunchKernelGGL((cart_ddpg_rollout_kernel<128, 256, 1>), dim3((n_envs + 15) / 16), dim3(kFwdThreads), 0,
+                           (hipStream_t)stream, args, c);
     } else if (actor.E == 256) {
-        hipLaunchKernelGGL((cart_ddpg_rollout_kernel<256, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, args, c);
+        hipLaunchKernelGGL((cart_ddpg_rollout_kernel<256, 256, 1>), dim3((n_envs + 15) / 16), dim3(kFwdThreads), 0,
+                           (hipStream_t)stream, args, c);
     } else {
         return RPO_ERR_ARG;
     }

@@ -33,22 +33,24 @@ struct FwdArgs {
     int out_mode; float scale, base;
 };
 
-template <int EIN, int H>
+template <int EIN, int H, int RT, int INS, int INA>
 __global__ __launch_bounds__(kFwdThreads) void mlp_forward_kernel(FwdArgs p) {
-    __shared__ TileLds<EIN> lds;
+    typedef TileLds<EIN, RT, INS, INA> Lds;
+    __shared__ Lds lds;
+    constexpr int ROWS = kRows * RT;
     const Mlp& net = p.net;
-    const int row0 = blockIdx.x * kRows;
+    const int row0 = blockIdx.x * ROWS;
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < kRows * net.S; idx += kFwdThreads) {
+    for (int idx = tid; idx < ROWS * net.S; idx += kFwdThreads) {
         const int r = idx / net.S, i = idx - r * net.S;
-        lds.in_s[r * kInS + i] = (row0 + r < p.n) ? p.s[(size_t)(row0 + r) * p.s_stride + i] : 0.0f;
+        lds.in_s[r * INS + i] = (row0 + r < p.n) ? p.s[(size_t)(row0 + r) * p.s_stride + i] : 0.0f;
     }
-    for (int idx = tid; idx < kRows * net.A; idx += kFwdThreads) {
+    for (int idx = tid; idx < ROWS * net.A; idx += kFwdThreads) {
         const int r = idx / net.A, i = idx - r * net.A;
-        lds.in_a[r * kInA + i] = (row0 + r < p.n) ? p.a[(size_t)(row0 + r) * p.a_stride + i] : 0.0f;
+        lds.in_a[r * INA + i] = (row0 + r < p.n) ? p.a[(size_t)(row0 + r) * p.a_stride + i] : 0.0f;
     }
-    mlp_tile_forward<EIN, H>(net, lds, row0, p.n, p.x0_save, p.h1_save, p.out_mode, p.scale, p.base);
-    if (tid < kRows * net.n_out) {
+    mlp_tile_forward<EIN, H, RT, Lds>(net, lds, row0, p.n, p.x0_save, p.h1_save, p.out_mode, p.scale, p.base);
+    if (tid < ROWS * net.n_out) {
         const int r = tid / net.n_out, o = tid - r * net.n_out;
         if (row0 + r < p.n) p.out[(size_t)(row0 + r) * net.n_out + o] = lds.out[r * 2 + o];
     }
@@ -439,10 +441,23 @@ int rpo_mlp_forward(const rpo_mlp* net_host, int n, const float* s, int s_stride
     if (!s || !out || (net.A > 0 && !a)) return RPO_ERR_NULL;
     const int ein = net.cat ? 2 * net.E : net.E;
     FwdArgs args{net, n, s, s_stride, a, a_stride, out, x0_save, h1_save, out_mode, scale, base};
-    const int grid = (n + kRows - 1) / kRows;
-    RPO_MLP_DISPATCH(128, 256, mlp_forward_kernel, grid, args)
-    RPO_MLP_DISPATCH(256, 256, mlp_forward_kernel, grid, args)
-    RPO_MLP_DISPATCH(512, 256, mlp_forward_kernel, grid, args)
+    // 64 rows per workgroup once that still fills the chip (and the inputs fit the narrow LDS tiles); else 16
+    const bool wide = n >= 64 * 192 && net.S <= 8 && net.A <= 8 && ein == 128;   // (LDS: 64 x 132 floats of x1)
+#define RPO_MLP_FWD(EIN_, H_)                                                                                          \
+    if (ein == EIN_ && net.H == H_) {                                                                                  \
+        if (wide) {                                                                                                    \
+            hipLaunchKernelGGL((mlp_forward_kernel<128, H_, 4, 8, 8>), dim3((n + 63) / 64),                            \
+                               dim3(kFwdThreads), 0, (hipStream_t)stream, args);                                       \
+        } else {                                                                                                       \
+            hipLaunchKernelGGL((mlp_forward_kernel<EIN_, H_, 1, kInS, kInA>), dim3((n + kRows - 1) / kRows),           \
+                               dim3(kFwdThreads), 0, (hipStream_t)stream, args);                                       \
+        }                                                                                                              \
+        RPO_LAUNCH_CHECK();                                                                                            \
+        return 0;                                                                                                      \
+    }
+    RPO_MLP_FWD(128, 256)
+    RPO_MLP_FWD(256, 256)
+    RPO_MLP_FWD(512, 256)
     return RPO_ERR_ARG;
 }
 

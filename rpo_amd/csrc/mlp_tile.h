@@ -1,6 +1,11 @@
 // Device-side building block shared by the MLP kernels (mlp.hip) and the fused pipelines (fused.hip): one workgroup of
-// 512 threads pushes a tile of 16 rows through first layer -> hidden layer (f32 MFMA) -> head.  See mlp.hip for the
+// 512 threads pushes RT tiles of 16 rows through first layer -> hidden layer (f32 MFMA) -> head.  See mlp.hip for the
 // operand-layout notes.
+//
+// A workgroup has to pull the whole hidden-layer matrix W0 (128 KB at 128 -> 256) through its CU, which takes ~2.7 us
+// at the ~47 GB/s one CU draws from L2 (measured).  RT = 1 (16 rows) maximises the number of workgroups for the
+// batch-256 update kernels; RT = 4 (64 rows) amortises that stream over 4x the MFMA work and is used when there are
+// enough rows to fill the chip anyway (vectorised rollouts, large batches).
 #pragma once
 #include "common.h"
 
@@ -8,7 +13,7 @@ namespace rpo_mlp_dev {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kRows = 16;          // rows (samples) per workgroup
+constexpr int kRows = 16;          // rows per MFMA tile
 constexpr int kThreads = 256;      // backward kernels: 4 waves
 constexpr int kFwdWaves = 8;       // forward: 512 threads, every wave owns H / 8 hidden columns
 constexpr int kFwdThreads = kFwdWaves * 64;
@@ -26,54 +31,61 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// LDS working set of one tile forward
-template <int EIN>
+// LDS working set of one forward over RT * 16 rows
+template <int EIN, int RT = 1, int INS = kInS, int INA = kInA>
 struct TileLds {
-    __attribute__((aligned(16))) float x1[kRows * (EIN + 4)];   // relu(first layer), padded rows (ds_read_b128)
-    float in_s[kRows * kInS];                                    // state inputs of the tile
-    float in_a[kRows * kInA];                                    // action inputs of the tile
-    float part[kFwdWaves * kRows * 2];                           // per-wave head partials
-    float out[kRows * 2];                                        // outputs of the tile (after the epilogue)
+    static constexpr int ROWS = kRows * RT;
+    static constexpr int kS = INS, kA = INA;                     // row strides of in_s / in_a (>= S, >= A)
+    __attribute__((aligned(16))) float x1[ROWS * (EIN + 4)];    // relu(first layer), padded rows (ds_read_b128)
+    float in_s[ROWS * INS];                                      // state inputs of the rows
+    float in_a[ROWS * INA];                                      // action inputs of the rows
+    float part[kFwdWaves * ROWS * 2];                            // per-wave head partials
+    float out[ROWS * 2];                                         // outputs (after the epilogue)
 };
 
-// Forward of the 16 rows whose inputs sit in lds.in_s / lds.in_a (the caller wrote them; this function synchronises
-// before reading).  Outputs land in lds.out[r * 2 + o] and are visible to every thread on return.
+// Forward of the RT * 16 rows whose inputs sit in lds.in_s / lds.in_a (the caller wrote them; this function
+// synchronises before reading).  Outputs land in lds.out[r * 2 + o] and are visible to every thread on return.
 // out_mode 1: BoxConstraint's tanh map on output 0.  x0_save / h1_save (global, may be NULL) get the pre-activations
 // of rows row0 + r < n.
-template <int EIN, int H>
-__device__ __forceinline__ void mlp_tile_forward(const Mlp& net, TileLds<EIN>& lds, int row0, int n, float* x0_save,
+template <int EIN, int H, int RT = 1, class LDS = TileLds<EIN, RT>>
+__device__ __forceinline__ void mlp_tile_forward(const Mlp& net, LDS& lds, int row0, int n, float* x0_save,
                                                  float* h1_save, int out_mode, float scale, float base) {
+    constexpr int kInS = LDS::kS, kInA = LDS::kA;               // (shadow the default strides)
+    constexpr int ROWS = kRows * RT;
     constexpr int LDX = EIN + 4;
+    constexpr int GROUPS = kFwdThreads / EIN;                   // thread groups that split the rows in layer 1
+    constexpr int RPT = ROWS / GROUPS;                          // rows per thread in layer 1
+    static_assert(kFwdThreads % EIN == 0 && ROWS % GROUPS == 0, "layer-1 thread mapping");
     float* x1 = lds.x1;
     const float* in_s = lds.in_s;
     const float* in_a = lds.in_a;
     float* part = lds.part;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    // first-layer weights of this thread's embedding column, fetched in chunks of 8 before they are needed
-    const int e_col = tid;                                      // EIN <= 512 == kFwdThreads: one column per thread
-    const bool has_col = e_col < EIN;
-    const bool act_part = has_col && net.cat && e_col >= net.E; // concatenating critic: columns [E, 2E) embed the action
+
+    // ---- layer-1 operands of this thread: embedding column e_col, rows [r_lo, r_lo + RPT)
+    const int e_col = tid % EIN, r_lo = (tid / EIN) * RPT;
+    const bool act_part = net.cat && e_col >= net.E;            // concatenating critic: columns [E, 2E) embed the action
     const int er = act_part ? e_col - net.E : e_col;
-    float acc1[kRows];
-    float ws0[8], wa0[8];                                       // first chunk of this column's first-layer weights
+    const bool use_s = !act_part, use_a = net.A > 0 && (act_part || !net.cat);
+    float acc1[RPT];
+    float ws0[8], wa0[8];                                       // first chunk of the column's first-layer weights
     {
-        const float bias = !has_col ? 0.0f
-                                    : (act_part ? net.ba[er] : (net.bs[er] + ((net.A > 0 && !net.cat) ? net.ba[er] : 0.0f)));
+        const float bias = act_part ? net.ba[er] : (net.bs[er] + ((net.A > 0 && !net.cat) ? net.ba[er] : 0.0f));
 #pragma unroll
-        for (int r = 0; r < kRows; ++r) acc1[r] = bias;
+        for (int r = 0; r < RPT; ++r) acc1[r] = bias;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            ws0[u] = (has_col && !act_part && u < net.S) ? net.Ws[er * net.S + u] : 0.0f;
-            wa0[u] = (has_col && net.A > 0 && (act_part || !net.cat) && u < net.A) ? net.Wa[er * net.A + u] : 0.0f;
+            ws0[u] = (use_s && u < net.S) ? net.Ws[er * net.S + u] : 0.0f;
+            wa0[u] = (use_a && u < net.A) ? net.Wa[er * net.A + u] : 0.0f;
         }
     }
-    // ---- then the wave's slice of W0 (128 KB per workgroup, ~2.7 us at the ~47 GB/s one CU pulls from L2): requested
-    //      AFTER the few loads layer 1 waits for (returns are in order), it streams in underneath layer 1 and feeds
-    //      the MFMA loop k-group by k-group
+    // ---- then the wave's slice of W0: requested AFTER the few loads layer 1 waits for (returns are in order), it
+    //      streams in underneath layer 1 and feeds the MFMA loop k-group by k-group
     constexpr int NT = H / (16 * kFwdWaves);                    // 16-column tiles per wave
     constexpr int ITS = EIN / 16;                               // k-groups of 16
-    constexpr int PRE = ITS < 16 ? ITS : 16;                    // k-groups kept in registers up front
+    constexpr int PRE_MAX = RT > 1 ? 8 : 16;
+    constexpr int PRE = ITS < PRE_MAX ? ITS : PRE_MAX;          // k-groups kept in registers up front
     const int j0 = wave * (H / kFwdWaves);
     float4 wpre[PRE][NT];
 #pragma unroll
@@ -81,7 +93,6 @@ __device__ __forceinline__ void mlp_tile_forward(const Mlp& net, TileLds<EIN>& l
 #pragma unroll
         for (int c = 0; c < NT; ++c)
             wpre[it][c] = *reinterpret_cast<const float4*>(&net.W0[(size_t)(j0 + c * 16 + li) * EIN + it * 16 + lg * 4]);
-
     // what the epilogue needs is requested last
     float b0v[NT], w1av[NT], w1bv[NT];
 #pragma unroll
@@ -90,55 +101,57 @@ __device__ __forceinline__ void mlp_tile_forward(const Mlp& net, TileLds<EIN>& l
         w1av[c] = net.W1[j0 + c * 16 + li];
         w1bv[c] = net.n_out > 1 ? net.W1b[j0 + c * 16 + li] : 0.0f;
     }
-    const float b1v = (tid < kRows * net.n_out) ? (((tid % net.n_out) == 0) ? net.b1[0] : net.b1b[0]) : 0.0f;
-
+    const float b1v = (tid < ROWS * net.n_out) ? (((tid % net.n_out) == 0) ? net.b1[0] : net.b1b[0]) : 0.0f;
     __syncthreads();
 
     // ---- layer 1 (VALU): x0[r][e]
-    if (has_col) {
-        if (!act_part) {
-            for (int i0 = 0; i0 < net.S; i0 += 8) {
-                float w[8];
+    if (use_s) {
+        for (int i0 = 0; i0 < net.S; i0 += 8) {
+            float w[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) w[u] = (i0 == 0) ? ws0[u] : ((i0 + u < net.S) ? net.Ws[er * net.S + i0 + u] : 0.0f);
+            for (int u = 0; u < 8; ++u) w[u] = (i0 == 0) ? ws0[u] : ((i0 + u < net.S) ? net.Ws[er * net.S + i0 + u] : 0.0f);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (i0 + u < net.S) {
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u < net.S) {
 #pragma unroll
-                        for (int r = 0; r < kRows; ++r) acc1[r] = fmaf(in_s[r * kInS + i0 + u], w[u], acc1[r]);
-                    }
+                    for (int r = 0; r < RPT; ++r) acc1[r] = fmaf(in_s[(r_lo + r) * kInS + i0 + u], w[u], acc1[r]);
                 }
             }
         }
-        if (net.A > 0 && (act_part || !net.cat)) {
-            for (int i0 = 0; i0 < net.A; i0 += 8) {
-                float w[8];
+    }
+    if (use_a) {
+        for (int i0 = 0; i0 < net.A; i0 += 8) {
+            float w[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) w[u] = (i0 == 0) ? wa0[u] : ((i0 + u < net.A) ? net.Wa[er * net.A + i0 + u] : 0.0f);
+            for (int u = 0; u < 8; ++u) w[u] = (i0 == 0) ? wa0[u] : ((i0 + u < net.A) ? net.Wa[er * net.A + i0 + u] : 0.0f);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (i0 + u < net.A) {
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u < net.A) {
 #pragma unroll
-                        for (int r = 0; r < kRows; ++r) acc1[r] = fmaf(in_a[r * kInA + i0 + u], w[u], acc1[r]);
-                    }
+                    for (int r = 0; r < RPT; ++r) acc1[r] = fmaf(in_a[(r_lo + r) * kInA + i0 + u], w[u], acc1[r]);
                 }
             }
         }
+    }
 #pragma unroll
-        for (int r = 0; r < kRows; ++r) {
-            if (x0_save && row0 + r < n) x0_save[(size_t)(row0 + r) * EIN + e_col] = acc1[r];
-            x1[r * LDX + e_col] = fmaxf(acc1[r], 0.0f);
-        }
+    for (int r = 0; r < RPT; ++r) {
+        if (x0_save && row0 + r_lo + r < n) x0_save[(size_t)(row0 + r_lo + r) * EIN + e_col] = acc1[r];
+        x1[(r_lo + r) * LDX + e_col] = fmaxf(acc1[r], 0.0f);
     }
     __syncthreads();
 
-    // ---- layer 2 (MFMA): wave w owns hidden columns [w*H/8, (w+1)*H/8) = NT tiles of 16
-    f32x4 acc[NT];
+    // ---- layer 2 (MFMA): wave w owns hidden columns [w*H/8, (w+1)*H/8) = NT tiles of 16, for all RT row tiles
+    f32x4 acc[RT][NT];
 #pragma unroll
-    for (int c = 0; c < NT; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[rt][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
-        const float4 a4 = *reinterpret_cast<const float4*>(&x1[li * LDX + it * 16 + lg * 4]);
+        float4 a4[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+            a4[rt] = *reinterpret_cast<const float4*>(&x1[(rt * kRows + li) * LDX + it * 16 + lg * 4]);
         float4 b4[NT];
 #pragma unroll
         for (int c = 0; c < NT; ++c)
@@ -146,45 +159,54 @@ __device__ __forceinline__ void mlp_tile_forward(const Mlp& net, TileLds<EIN>& l
                                : *reinterpret_cast<const float4*>(&net.W0[(size_t)(j0 + c * 16 + li) * EIN + it * 16 + lg * 4]);
         // consecutive MFMAs go to different accumulators (40-cycle dependent latency vs 32-cycle issue)
 #pragma unroll
-        for (int c = 0; c < NT; ++c) acc[c] = mfma4(a4.x, b4[c].x, acc[c]);
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int c = 0; c < NT; ++c) acc[c] = mfma4(a4.y, b4[c].y, acc[c]);
+            for (int c = 0; c < NT; ++c) acc[rt][c] = mfma4(a4[rt].x, b4[c].x, acc[rt][c]);
 #pragma unroll
-        for (int c = 0; c < NT; ++c) acc[c] = mfma4(a4.z, b4[c].z, acc[c]);
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int c = 0; c < NT; ++c) acc[c] = mfma4(a4.w, b4[c].w, acc[c]);
+            for (int c = 0; c < NT; ++c) acc[rt][c] = mfma4(a4[rt].y, b4[c].y, acc[rt][c]);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[rt][c] = mfma4(a4[rt].z, b4[c].z, acc[rt][c]);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[rt][c] = mfma4(a4[rt].w, b4[c].w, acc[rt][c]);
     }
-    // acc[c][i] = h1[row = 4*lg + i][col = j0 + 16c + li] (before bias)
-    float po[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    // acc[rt][c][i] = h1[row = 16 rt + 4 lg + i][col = j0 + 16c + li] (before bias)
+    // ---- head: per-lane partial dot products, reduced over the 16 lanes that share lg, then over the waves
 #pragma unroll
-    for (int c = 0; c < NT; ++c) {
-        const int col = j0 + c * 16 + li;
-        const float b0 = b0v[c];
-        const float w1a = w1av[c], w1b = w1bv[c];
+    for (int rt = 0; rt < RT; ++rt) {
+        float po[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float h = acc[c][i] + b0;
-            const int row = row0 + lg * 4 + i;
-            if (h1_save && row < n) h1_save[(size_t)row * H + col] = h;
-            const float hr = fmaxf(h, 0.0f);
-            po[0][i] = fmaf(hr, w1a, po[0][i]);
-            po[1][i] = fmaf(hr, w1b, po[1][i]);
+        for (int c = 0; c < NT; ++c) {
+            const int col = j0 + c * 16 + li;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float h = acc[rt][c][i] + b0v[c];
+                const int row = row0 + rt * kRows + lg * 4 + i;
+                if (h1_save && row < n) h1_save[(size_t)row * H + col] = h;
+                const float hr = fmaxf(h, 0.0f);
+                po[0][i] = fmaf(hr, w1av[c], po[0][i]);
+                po[1][i] = fmaf(hr, w1bv[c], po[1][i]);
+            }
         }
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = po[o][i];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                if (li == 0) part[(wave * ROWS + rt * kRows + lg * 4 + i) * 2 + o] = v;
+            }
     }
-    // ---- head: reduce over the 16 lanes that share lg, then over the waves (fixed order)
-#pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float v = po[o][i];
-            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (li == 0) part[(wave * kRows + lg * 4 + i) * 2 + o] = v;
-        }
     __syncthreads();
-    if (tid < kRows * net.n_out) {
+    if (tid < ROWS * net.n_out) {
         const int r = tid / net.n_out, o = tid - r * net.n_out;
         float v = b1v;
-        for (int w = 0; w < kFwdWaves; ++w) v += part[(w * kRows + r) * 2 + o];
+        for (int w = 0; w < kFwdWaves; ++w) v += part[(w * ROWS + r) * 2 + o];       // fixed order
         if (out_mode == 1 && o == 0) v = scale * tanhf(v) + base;
         lds.out[r * 2 + o] = v;
     }

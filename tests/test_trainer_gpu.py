@@ -113,3 +113,69 @@ def test_gym_api_single_env_on_gpu(hip, golden):
         np.testing.assert_allclose(info["ineq_viol"], g["ineq_viol"][i], atol=4e-6)
         np.testing.assert_allclose(info["eq_viol"], g["eq_viol"][i], atol=2e-6)
     env.close()
+
+
+def _dp_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RPO_VERBOSE="0")
+    import torch.distributed as dist
+    from rpo_amd import ops
+    from test_train_step_golden import build_trainer
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share cuda:0; gloo moves GPU tensors
+    torch.manual_seed(5)
+    tr = build_trainer("ddpg", "cart", ops, torch.device("cuda"), num_envs=512, use_graph=True)
+    assert tr.n_local == 256 and tr.vec.env_id_base == 256 * rank
+    tr.vec.reset()
+    tr.run_steps(20)                        # eager passes, capture of the three graph segments, replays + collectives
+    tr._harvest(final=True)
+    torch.cuda.synchronize()
+    assert any(e["graph"] is not None for e in tr._graphs.entries.values())
+    torch.save(dict(flat=tr.agent.flat.data.cpu(), nju=tr.agent.nju.weight.data.cpu(), env_steps=float(tr.env_steps),
+                    state=tr.vec.internal.cpu()), os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_graph_segments_on_gpu(hip, tmp_path):
+    """Two ranks on the one GPU (gloo carries the collectives): the hipGraph-segmented iteration with eager gradient
+    all-reduces keeps the replicas bit-identical, and the lanes of rank 1 are env ids 256..511."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    import os
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"), weights_only=False)
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"), weights_only=False)
+    assert torch.equal(r0["flat"], r1["flat"]) and torch.equal(r0["nju"], r1["nju"])
+    assert r0["env_steps"] == r1["env_steps"] == 512 * 20
+    assert not torch.equal(r0["state"], r1["state"])
+
+
+def test_wide_rollout_tiles_are_bitwise_identical(hip, monkeypatch):
+    """The 64-lane-per-workgroup rollout pipeline (used from 12 288 lanes up) and the 16-lane one compute the same
+    bits: same per-row arithmetic, only the work distribution differs.  Same for the wide MLP forward."""
+    dev = torch.device("cuda")
+    monkeypatch.setenv("RPO_ROLLOUT_WIDE", "0")
+    a = _run("ddpg", "cart", hip, dev, 12, 1000, use_graph=False)
+    monkeypatch.setenv("RPO_ROLLOUT_WIDE", "1")
+    b = _run("ddpg", "cart", hip, dev, 12, 1000, use_graph=False)
+    assert torch.equal(a.vec.internal, b.vec.internal) and torch.equal(a.buffer.rows, b.buffer.rows)
+    assert torch.equal(a.agent.flat.data, b.agent.flat.data)
+    # statistics are float sums over differently shaped workgroups: equal up to summation order
+    np.testing.assert_allclose(hip.reduce_stats(a.vec.stats[:12]).cpu().numpy(),
+                               hip.reduce_stats(b.vec.stats[:12]).cpu().numpy(), rtol=1e-5, atol=1e-9)
+    # generic forward: n >= 12288 takes the wide path, a 4096-row slice of the same input the narrow one
+    f = a.fused
+    s = torch.randn(16384, 6, device=dev)
+    out_w = torch.empty(16384, 1, device=dev)
+    out_n = torch.empty(4096, 1, device=dev)
+    f.forward("actor", s, None, out_w)
+    f.forward("actor", s[:4096], None, out_n)
+    assert torch.equal(out_w[:4096], out_n)
