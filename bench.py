@@ -39,18 +39,31 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def make_trainer(n_envs, device, max_epochs, capacity=None):
+# the other scripts' hyper-parameters, for --workload
+WORKLOADS = {
+    "cart_ddpg": ("cart", "ddpg", {}),
+    "cart_sac": ("cart", "sac", dict(eps=5e-3, eps_start=5e-3, shared_param=False, alpha=0.1, automatic_entropy_tuning=False)),
+    "pen_ddpg": ("pen", "ddpg", dict(lr_dual=0.01, corr_lr=2e-3, eval_lr=2e-3, eps=0.5, eps_start=0.5, shared_param=False)),
+    "pen_sac": ("pen", "sac", dict(lr_dual=0.01, corr_lr=2e-3, eval_lr=2e-3, eps=1e-2, eps_start=1e-2, shared_param=False,
+                                   alpha=0.01, automatic_entropy_tuning=False)),
+}
+
+
+def make_trainer(n_envs, device, max_epochs, capacity=None, workload="cart_ddpg"):
     from rpo_amd import gym_shim
-    from rpo_amd.algo import RPODDPG
-    from rpo_amd.env import CartSafeEnv
+    from rpo_amd.algo import RPODDPG, RPOSAC
+    from rpo_amd.env import CartSafeEnv, SpringPendulumEnv
     np.random.seed(123)
     torch.manual_seed(123)                  # identical replicas on every rank
-    env = gym_shim.TimeLimit(CartSafeEnv(), 200)
+    envname, algo, over = WORKLOADS[workload]
+    env = gym_shim.TimeLimit(CartSafeEnv() if envname == "cart" else SpringPendulumEnv(), 200)
     hp = dict(HP)
+    hp.update(over)
     if capacity is not None:
         hp["capacity"] = capacity
-    return RPODDPG(env, "/tmp/rpo_bench", name="bench", logger=None, max_epochs=max_epochs, device=device,
-                   num_envs=n_envs, **hp)
+    cls = RPODDPG if algo == "ddpg" else RPOSAC
+    return cls(env, "/tmp/rpo_bench", name="bench", logger=None, max_epochs=max_epochs, device=device,
+               num_envs=n_envs, **hp)
 
 
 def time_kernel(fn, reps=100):
@@ -198,6 +211,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clinic", action="store_true")
+    ap.add_argument("--workload", default="cart_ddpg", choices=sorted(WORKLOADS),
+                    help="cart_ddpg is the headline (BASELINE.json configs[1]); the others are extra measurements")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -214,7 +229,8 @@ def main():
 
     n_total = ENVS_PER_GPU * world
     total_iters = args.warmup + args.steps
-    tr = make_trainer(n_total, device, total_iters)
+    tr = make_trainer(n_total, device, total_iters, workload=args.workload)
+    headline = args.workload == "cart_ddpg"
     tr.vec.reset()
 
     def fence():
@@ -242,9 +258,10 @@ def main():
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "CartSafe-v0 RPODDPG, %d vectorised envs per MI355X, scripts/cart_exp.py "
-                               "hyper-parameters, update batch 256 every vector step (reference cadence), replay "
-                               "capacity 20000 per env" % ENVS_PER_GPU,
+        "config": {"workload": ("CartSafe-v0 RPODDPG, %d vectorised envs per MI355X, scripts/cart_exp.py "
+                                "hyper-parameters, update batch 256 every vector step (reference cadence), replay "
+                                "capacity 20000 per env" % ENVS_PER_GPU) if headline else
+                               "%s, %d vectorised envs per MI355X (extra measurement, not the headline)" % (args.workload, ENVS_PER_GPU),
                    "envs_per_gpu": ENVS_PER_GPU, "global_envs": n_total, "update_batch": 256,
                    "parallelism": "dp%d (env shards, RCCL all-reduce of the flat gradient bucket)" % world,
                    "hip_graph": bool(tr._graphs.enabled)},
@@ -254,7 +271,7 @@ def main():
 
     if rank == 0:
         # (i) rollout-only throughput next to the headline, so that the cadence is visible
-        ro = make_trainer(ENVS_PER_GPU, device, 10 ** 9, capacity=64) if world == 1 else None
+        ro = make_trainer(ENVS_PER_GPU, device, 10 ** 9, capacity=64, workload=args.workload) if world == 1 else None
         if ro is not None:
             ro.vec.reset()
             ro.run_steps(50, train=False)
@@ -264,7 +281,7 @@ def main():
             torch.cuda.synchronize()
             result["rollout_only_env_steps_per_s"] = ENVS_PER_GPU * 1000 / (time.perf_counter() - t1)
             del ro
-        if not args.no_clinic and world == 1 and tr.fused is not None:
+        if not args.no_clinic and world == 1 and tr.fused is not None and headline:
             log("kernel clinic (hipGraph of back-to-back launches between two HIP events on the launch stream):")
             clinic = kernel_clinic(tr)
             in_iter = ("cart_ddpg_rollout_kernel", "cart_ddpg_critic_forward_kernel", "mlp_bwd_rows+weights_kernels")
@@ -286,7 +303,7 @@ def main():
                 "all_kernels": {kk: {"us": vv["us"], "rate": vv["rate"], "unit": vv["unit"], "frac": vv["frac"]}
                                 for kk, vv in clinic.items()},
             }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and headline:
             result["cpu_baseline"] = cpu_baseline()
             result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
         print(json.dumps(result), flush=True)
