@@ -49,7 +49,7 @@ WORKLOADS = {
 }
 
 
-def make_trainer(n_envs, device, max_epochs, capacity=None, workload="cart_ddpg"):
+def make_trainer(n_envs, device, max_epochs, capacity=None, workload="cart_ddpg", updates_per_step=None):
     from rpo_amd import gym_shim
     from rpo_amd.algo import RPODDPG, RPOSAC
     from rpo_amd.env import CartSafeEnv, SpringPendulumEnv
@@ -63,7 +63,7 @@ def make_trainer(n_envs, device, max_epochs, capacity=None, workload="cart_ddpg"
         hp["capacity"] = capacity
     cls = RPODDPG if algo == "ddpg" else RPOSAC
     return cls(env, "/tmp/rpo_bench", name="bench", logger=None, max_epochs=max_epochs, device=device,
-               num_envs=n_envs, **hp)
+               num_envs=n_envs, updates_per_step=updates_per_step, **hp)
 
 
 def time_kernel(fn, reps=100):
@@ -280,6 +280,20 @@ def main():
             ro.run_steps(1000, train=False)
             torch.cuda.synchronize()
             result["rollout_only_env_steps_per_s"] = ENVS_PER_GPU * 1000 / (time.perf_counter() - t1)
+            # (iii) UTD-matched: one batch-256 update per ENV step as in the reference, i.e. ENVS_PER_GPU updates per
+            # vector step -- a bounded sample of vector steps
+            utd = make_trainer(ENVS_PER_GPU, device, 10 ** 9, capacity=256, workload=args.workload,
+                               updates_per_step=ENVS_PER_GPU)
+            utd.vec.reset()
+            utd.run_steps(1)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            utd.run_steps(4)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t2
+            result["utd_matched_env_steps_per_s"] = ENVS_PER_GPU * 4 / dt
+            result["utd_matched_updates_per_s"] = ENVS_PER_GPU * 4 / dt
+            del utd
             del ro
         if not args.no_clinic and world == 1 and tr.fused is not None and headline:
             log("kernel clinic (hipGraph of back-to-back launches between two HIP events on the launch stream):")

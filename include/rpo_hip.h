@@ -56,6 +56,8 @@ extern "C" {
 #define RPO_CTRL_LEN 288
 #define RPO_CTRL_T 0        /* vector steps completed */
 #define RPO_CTRL_ARRIVE 1   /* top-level arrival counter of the running *_step launch (always 0 between launches) */
+#define RPO_CTRL_UPDATES 2  /* updates done within the current vector step (host-maintained, 0 unless several updates
+                               per step are requested): 4th Philox counter word of the sampling / update-noise draws */
 #define RPO_CTRL_SUB0 16    /* 16 sub-counters, one per 128-byte line: ctrl[RPO_CTRL_SUB0 + RPO_CTRL_SUB_STRIDE * j] */
 #define RPO_CTRL_SUB_STRIDE 16
 
@@ -89,7 +91,8 @@ extern "C" {
 int rpo_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * Philox4x32-10 (Salmon et al., SC'11), the build's counter-based RNG: key = seed, counter = (id, index, stream, 0).
+ * Philox4x32-10 (Salmon et al., SC'11), the build's counter-based RNG: key = seed, counter = (id, index, stream, sub);
+ * sub = 0 except for the replay-sampling and update-noise draws, where it is ctrl[RPO_CTRL_UPDATES].
  * Fills out[n,4] (uint32) with the raw words for id = id_base + i.  Test hook for bit-exact comparison with
  * oracle/philox.py.  The reference uses global numpy/torch generators instead (scripts/cart_exp.py:9-10), whose
  * streams cannot be reproduced on a GPU; parity tests inject the draws explicitly (SURVEY.md §7 hard part iv).

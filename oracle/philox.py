@@ -29,14 +29,15 @@ def philox4x32(counter, key, rounds=10):
     return c
 
 
-def draw(seed, ids, index, stream):
-    """Raw words for key = seed and counter = (id, index, stream, 0); ``ids`` is an array, index/stream scalars or arrays."""
+def draw(seed, ids, index, stream, sub=0):
+    """Raw words for key = seed and counter = (id, index, stream, sub); ``ids`` is an array, the rest scalars or arrays."""
     ids = np.asarray(ids, dtype=np.uint32).reshape(-1)
     n = ids.shape[0]
     ctr = np.zeros((n, 4), dtype=np.uint32)
     ctr[:, 0] = ids
     ctr[:, 1] = np.asarray(index, dtype=np.uint64).astype(np.uint32)
     ctr[:, 2] = np.asarray(stream, dtype=np.uint32)
+    ctr[:, 3] = np.asarray(sub, dtype=np.uint64).astype(np.uint32)
     key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
     return philox4x32(ctr, key)
 
@@ -68,8 +69,8 @@ def pendulum_reset(seed, env_ids, episode):
     return (lo + u01(draw(seed, env_ids, episode, STREAM_RESET)) * (hi - lo)).astype(np.float32)
 
 
-def sample_indices(seed, batch, t, salt, n_valid):
+def sample_indices(seed, batch, t, salt, n_valid, updates=0):
     """Row indices drawn by rpo_replay_sample_gather (uniform with replacement, buffer.py:32)."""
-    r = draw(seed, np.arange(batch), (int(t) + int(salt)) & 0xFFFFFFFF, STREAM_SAMPLE)
+    r = draw(seed, np.arange(batch), (int(t) + int(salt)) & 0xFFFFFFFF, STREAM_SAMPLE, updates)
     x = (r[:, 0].astype(np.uint64) << np.uint64(32)) | r[:, 1].astype(np.uint64)
     return np.array([(int(v) * int(n_valid)) >> 64 for v in x], dtype=np.int64)

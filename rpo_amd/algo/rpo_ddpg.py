@@ -30,7 +30,7 @@ class RPODDPG(RPOTrainerBase):
                  policy_fre=2, eval_fre=500, max_epochs=100000, grad_eps=1e-3, eval_steps=None, init_lamb=0.0,
                  init_nju=0.0, fixed=False, clip_thres="inf", partial=False, partial_idx=None,
                  device=torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu"),
-                 num_envs=None, seed=None, backend=None, use_graph=None):
+                 num_envs=None, seed=None, backend=None, use_graph=None, updates_per_step=None):
         base = getattr(env, "unwrapped", env)
         agent = PDDDPG_PA(
             base.state_dim, base.action_dim, base.eq_num, base.ineq_num, embed_dim=embed_dim, hidden_dim=hidden_dim,
@@ -45,7 +45,7 @@ class RPODDPG(RPOTrainerBase):
                   corr_mode=corr_mode, grad_eps=grad_eps, clip_thres=clip_thres, eval_steps=eval_steps,
                   batch_size=batch_size, policy_fre=policy_fre, eval_fre=eval_fre, warmup=warmup, max_epochs=max_epochs,
                   fixed=fixed, partial=partial, eps=eps, eps_start=eps_start, eps_epoch=eps_epoch)
-        self._setup(env, work_dir, name, logger, agent, hp, device, num_envs, seed, backend, use_graph)
+        self._setup(env, work_dir, name, logger, agent, hp, device, num_envs, seed, backend, use_graph, updates_per_step)
 
     # ---- rollout policy (rpo_ddpg.py:98-106, agent/ddpg_pa.py:101-112) ----------------------------------------
     def _actor_out(self, name, obs, save=False):

@@ -19,7 +19,7 @@ class RPOSAC(RPOTrainerBase):
                  max_epochs=100000, grad_eps=1e-3, eval_steps=None, init_lamb=0.0, init_nju=0.0, fixed=False,
                  clip_thres="inf", partial=False, partial_idx=None,
                  device=torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu"),
-                 num_envs=None, seed=None, backend=None, use_graph=None):
+                 num_envs=None, seed=None, backend=None, use_graph=None, updates_per_step=None):
         base = getattr(env, "unwrapped", env)
         agent = PDSAC_PA(
             automatic_entropy_tuning, base.state_dim, base.action_dim, base.eq_num, base.ineq_num,
@@ -36,7 +36,7 @@ class RPOSAC(RPOTrainerBase):
                   corr_mode=corr_mode, grad_eps=grad_eps, clip_thres=clip_thres, eval_steps=eval_steps,
                   batch_size=batch_size, policy_fre=policy_fre, eval_fre=eval_fre, warmup=warmup, max_epochs=max_epochs,
                   fixed=fixed, partial=partial, eps=eps, eps_start=eps_start, eps_epoch=eps_epoch)
-        self._setup(env, work_dir, name, logger, agent, hp, device, num_envs, seed, backend, use_graph)
+        self._setup(env, work_dir, name, logger, agent, hp, device, num_envs, seed, backend, use_graph, updates_per_step)
 
     def _draw(self, buf, id_base, salt):
         self.backend.philox_normal(buf, self.seed, id_base, salt, hip_ops.STREAM_POLICY, self.vec.ctrl)

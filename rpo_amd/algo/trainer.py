@@ -134,7 +134,7 @@ class RPOTrainerBase(object):
     sac = False
 
     def _setup(self, env, work_dir, name, logger, agent, hp, device, num_envs=None, seed=None, backend=None,
-               use_graph=None):
+               use_graph=None, updates_per_step=None):
         self.env, self.agent, self.device = env, agent, device
         self.work_dir, self.name, self.logger = work_dir, name, logger
         for k, v in hp.items():
@@ -175,6 +175,11 @@ class RPOTrainerBase(object):
         self.batch_reference = not bool(_env_int("RPO_ROWWISE_PROJECTION", 0))
         # hand-written f32-MFMA MLP kernels for actor / critics (RPO_FUSED_MLP=0: the torch modules + autograd)
         self.fused = FusedNets.build(agent, self.backend, device) if _env_int("RPO_FUSED_MLP", 1) else None
+        # updates per vector step: 1 = the reference's loop cadence (rpo_ddpg.py:160-161); num_envs = "UTD-matched":
+        # as many batch-`batch_size` updates per env step as the reference performs (metric iii)
+        self.updates_per_step = max(1, int(updates_per_step) if updates_per_step is not None
+                                    else _env_int("RPO_UPDATES_PER_STEP", 1))
+        self._updates = 0           # updates done so far (drives the policy_fre cadence of the extra updates)
         box = agent.actor.box_constraint
         self._box_affine = (float(np.asarray(box.scale).reshape(-1)[0]), float(np.asarray(box.base).reshape(-1)[0])) \
             if box is not None and not box.volatile else None
@@ -292,6 +297,25 @@ class RPOTrainerBase(object):
             self._graphs.run((warm, do_train, actor_step, i), fn)
             self.dist.mean_(reduce_after)
 
+    def _extra_update(self, k, actor_step):
+        """k-th additional update of the current vector step (updates_per_step > 1): same kernels as the first one,
+        with ctrl[RPO_CTRL_UPDATES] = k separating its Philox draws."""
+        def body():
+            self.vec.ctrl[hip_ops.CONST["RPO_CTRL_UPDATES"]] += 1
+            cols = self._sample()
+            self._critic_update(cols)
+            fl = self.agent.flat
+            self.dist.mean_([fl.gradient(fl.critic_range)])
+            self._critic_step(actor_step)
+            if actor_step:
+                out = self._actor_update(cols)
+                self.dist.mean_([fl.gradient(fl.actor_range), self.agent.nju.weight.grad])
+                self._actor_step(out)
+        if self.dist.on:
+            body()                      # collectives inside: eager
+        else:
+            self._graphs.run(("extra", actor_step), body)
+
     def train(self, t):
         """One constrained policy update at loop index ``t`` (rpo_ddpg.py:163-205), eagerly, without a rollout."""
         cols = self._sample()
@@ -338,6 +362,13 @@ class RPOTrainerBase(object):
             do_train = train and (t + 1) >= self.warmup
             actor_step = do_train and (t + 1) % self.policy_fre == 0
             self._iteration(warm, do_train, actor_step)
+            if do_train:
+                self._updates += 1
+                if self.updates_per_step > 1:
+                    for k in range(1, self.updates_per_step):
+                        self._updates += 1
+                        self._extra_update(k, self._updates % self.policy_fre == 0)
+                    self.vec.ctrl[hip_ops.CONST["RPO_CTRL_UPDATES"]] = 0
             self._t = t = t + 1
             self.buffer.note_step()
             self.vec.steps_host = t

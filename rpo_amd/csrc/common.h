@@ -29,8 +29,9 @@ struct rpo_u4 {
     uint32_t x, y, z, w;
 };
 
-__host__ __device__ __forceinline__ rpo_u4 rpo_philox(uint64_t seed, uint32_t id, uint32_t index, uint32_t stream) {
-    uint32_t c0 = id, c1 = index, c2 = stream, c3 = 0u;
+__host__ __device__ __forceinline__ rpo_u4 rpo_philox(uint64_t seed, uint32_t id, uint32_t index, uint32_t stream,
+                                                       uint32_t sub = 0u) {
+    uint32_t c0 = id, c1 = index, c2 = stream, c3 = sub;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {

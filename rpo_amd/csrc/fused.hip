@@ -131,7 +131,8 @@ __global__ __launch_bounds__(kFwdThreads) void cart_ddpg_critic_forward_kernel(C
                 row = p.idx_in[row0 + r];
             } else {
                 const unsigned long long n_valid = (unsigned long long)((t < p.cap_steps ? t : p.cap_steps) * (long long)p.n_envs);
-                const rpo_u4 u = rpo_philox(p.seed, (uint32_t)(row0 + r), (uint32_t)t + p.salt, RPO_STREAM_SAMPLE);
+                const rpo_u4 u = rpo_philox(p.seed, (uint32_t)(row0 + r), (uint32_t)t + p.salt, RPO_STREAM_SAMPLE,
+                                            (uint32_t)p.ctrl[RPO_CTRL_UPDATES]);
                 row = (long long)__umul64hi(((unsigned long long)u.x << 32) | u.y, n_valid);
             }
             v = reinterpret_cast<const float4*>(p.rows)[row * 6 + ch];

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(RPO_BLOCK) void replay_sample_gather_kernel(
         const long long b = j / chunks_per_row;
         const int c = (int)(j - b * chunks_per_row);
         // np.random.randint(0, size, B) of buffer.py:32 -> counter-based draw, unbiased multiply-shift reduction
-        const rpo_u4 r = rpo_philox(seed, (uint32_t)b, (uint32_t)t + salt, RPO_STREAM_SAMPLE);
+        const rpo_u4 r = rpo_philox(seed, (uint32_t)b, (uint32_t)t + salt, RPO_STREAM_SAMPLE, (uint32_t)ctrl[RPO_CTRL_UPDATES]);
         const unsigned long long x = ((unsigned long long)r.x << 32) | r.y;
         const long long row = (long long)__umul64hi(x, n_valid);
         out[j] = rows[row * chunks_per_row + c];

@@ -143,8 +143,9 @@ __global__ __launch_bounds__(RPO_BLOCK) void philox_normal_kernel(int n, float* 
                                                                   uint32_t id_base, uint32_t salt, uint32_t tag,
                                                                   const long long* __restrict__ ctrl) {
     const uint32_t t = ctrl ? (uint32_t)ctrl[RPO_CTRL_T] : 0u;
+    const uint32_t sub = ctrl ? (uint32_t)ctrl[RPO_CTRL_UPDATES] : 0u;
     for (int i = blockIdx.x * RPO_BLOCK + threadIdx.x; i < n; i += gridDim.x * RPO_BLOCK) {
-        const rpo_u4 r = rpo_philox(seed, id_base + (uint32_t)i, t + salt, tag);
+        const rpo_u4 r = rpo_philox(seed, id_base + (uint32_t)i, t + salt, tag, sub);
         out[i] = rpo_normal(r.x, r.y);
     }
 }

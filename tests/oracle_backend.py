@@ -240,13 +240,14 @@ class PendulumKernels(_EnvKernels):
 def philox_normal(out, seed, id_base, salt, stream_tag, ctrl=None):
     t = 0 if ctrl is None else int(ctrl[0])
     n = out.numel()
-    r = philox.draw(seed, np.arange(n) + id_base, (t + salt) & 0xFFFFFFFF, stream_tag)
+    sub = 0 if ctrl is None else int(ctrl[2])
+    r = philox.draw(seed, np.arange(n) + id_base, (t + salt) & 0xFFFFFFFF, stream_tag, sub)
     _put(out, philox.normal(r[:, 0], r[:, 1]))
 
 
 def replay_sample_gather(rows, cap_steps, n_envs, out, idx_out, seed, salt, ctrl):
     t = int(ctrl[0])
-    idx = philox.sample_indices(seed, out.shape[0], t, salt, min(t, cap_steps) * n_envs)
+    idx = philox.sample_indices(seed, out.shape[0], t, salt, min(t, cap_steps) * n_envs, int(ctrl[2]))
     out.copy_(rows[torch.as_tensor(idx)])
     if idx_out is not None:
         _put(idx_out, idx)

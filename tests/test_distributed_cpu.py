@@ -81,3 +81,26 @@ def test_two_rank_data_parallel(tmp_path, algo, envname):
     assert torch.equal(tr.vec.internal, both_first)
     tr.run_steps(1)
     assert torch.equal(tr.vec.internal, torch.cat([r0["after_one"], r1["after_one"]]))
+
+
+def test_updates_per_step_cadence():
+    """updates_per_step = G: G updates per vector step, the policy cadence follows the update counter, every extra
+    update draws its own replay batch (4th Philox counter word = update index within the step)."""
+    sys.path.insert(0, HERE)
+    import oracle_backend as ob
+    from test_train_step_golden import build_trainer
+    torch.set_num_threads(1)
+    torch.manual_seed(5)
+    tr = build_trainer("ddpg", "cart", ob, torch.device("cpu"), num_envs=8, updates_per_step=3)
+    seen = []
+    orig = ob.replay_sample_gather
+
+    def spy(rows, cap_steps, n_envs, out, idx_out, seed, salt, ctrl):
+        seen.append((int(ctrl[0]), int(ctrl[2])))
+        return orig(rows, cap_steps, n_envs, out, idx_out, seed, salt, ctrl)
+    tr.buffer._ops = type("P", (), {"replay_sample_gather": staticmethod(spy)})()
+    tr.vec.reset()
+    tr.run_steps(4)
+    assert int(tr.agent.critic_optim.step_dev[0]) == 12 and int(tr.agent.actor_optim.step_dev[0]) == 3
+    assert seen == [(t, k) for t in range(1, 5) for k in range(3)]
+    assert int(tr.vec.ctrl[2]) == 0 and int(tr.vec.ctrl[0]) == 4
