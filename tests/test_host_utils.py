@@ -1,0 +1,71 @@
+"""Host-side pieces of the reference's surface that are not kernels: Logger, gym stand-in, checkpoints (CPU)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_backend as ob
+from rpo_amd import gym_shim
+from rpo_amd.utils.logger import Logger
+from test_train_step_golden import build_trainer
+
+
+def test_logger_matches_reference_semantics(tmp_path):
+    """rpo/utils/logger.py:5-25: preallocated float64 tracks, StopIteration when full, pickles itself with a timestamp."""
+    lg = Logger(("epoch", "reward", "max_ineq", "max_eq"), epochs=3, times=2, name="cart_ddpg")
+    assert lg.tracker["reward"].shape == (6,) and lg.tracker["reward"].dtype == np.float64 and lg.pointer == 0
+    for i in range(6):
+        lg.add(epoch=i, reward=2.0 * i, max_ineq=0.1, max_eq=0.0)
+    with pytest.raises(StopIteration):
+        lg.add(epoch=6, reward=0, max_ineq=0, max_eq=0)
+    assert lg.pointer == 6 and lg.tracker["reward"][5] == 10.0
+    lg.save(os.path.join(tmp_path, "cart_ddpg"))
+    files = os.listdir(tmp_path)
+    assert len(files) == 1 and files[0].startswith("cart_ddpg_")
+    with open(os.path.join(tmp_path, files[0]), "rb") as f:
+        back = pickle.load(f)
+    np.testing.assert_array_equal(back.tracker["epoch"], np.arange(6))
+    lg2 = Logger(("a",), epochs=4, times=1)
+    lg2.add_rows(a=np.arange(3))
+    with pytest.raises(StopIteration):
+        lg2.add_rows(a=np.arange(2))
+
+
+def test_gym_stand_in_time_limit_and_spaces():
+    env = gym_shim.make("CartSafe-v0") if "CartSafe-v0" in gym_shim._REGISTRY else None
+    import rpo_amd.env  # noqa: F401  registers the ids
+    env = env or gym_shim.make("CartSafe-v0")
+    assert env._max_episode_steps == 200 and env.unwrapped is env.env
+    with pytest.raises(AttributeError):
+        env._no_such_private                                     # keeps copy.deepcopy from recursing
+    box = gym_shim.Box(np.array([-1, -2], dtype=np.float32), np.array([1, 2], dtype=np.float32))
+    assert box.contains(np.array([0.5, -2.0], dtype=np.float32))
+    assert not box.contains(np.array([0.5, -2.1], dtype=np.float32))
+    assert not box.contains(np.array([0.5, 0.0]))                # float64 is not castable to float32 (gym 0.19)
+    assert not box.contains(np.array([0.5], dtype=np.float32))
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    """save()/load() restore parameters, targets, multipliers and optimiser moments (the reference's save_model stores
+    parameter generators and cannot be loaded back, agent/ddpg_pa.py:92-99)."""
+    torch.set_num_threads(1)
+    torch.manual_seed(1)
+    a = build_trainer("ddpg", "cart", ob, torch.device("cpu"), num_envs=4)
+    a.work_dir = str(tmp_path)
+    a.vec.reset()
+    a.run_steps(6)
+    a.save()
+    torch.manual_seed(2)
+    b = build_trainer("ddpg", "cart", ob, torch.device("cpu"), num_envs=4)
+    b.work_dir = str(tmp_path)
+    assert not torch.equal(a.agent.flat.data, b.agent.flat.data)
+    b.load()
+    assert torch.equal(a.agent.flat.data, b.agent.flat.data)
+    assert torch.equal(a.agent.nju.weight, b.agent.nju.weight)
+    assert torch.equal(a.agent.critic_optim.exp_avg, b.agent.critic_optim.exp_avg)
+    assert int(b.agent.actor_optim.step_dev[0]) == int(a.agent.actor_optim.step_dev[0]) == 1
+    # load() ends with hard_update(): targets equal the online networks (agent/ddpg_pa.py:96-99)
+    fl = b.agent.flat
+    assert torch.equal(b.agent.critic_target_flat, fl.param(fl.critic_range))
