@@ -285,7 +285,7 @@ class OracleRPO(object):
         loss.backward()
         torch.nn.utils.clip_grad_norm_(Nets.unique(n.critic), self.clip_thres, float("inf"))
         self.critic_optim.step()
-        out["critic_loss"] = float(loss)
+        out["critic_loss"] = float(loss.detach())
         if t % self.policy_fre == 0:
             loss = self.actor_loss(b)
             self.actor_optim.zero_grad()
@@ -296,7 +296,7 @@ class OracleRPO(object):
             self.nju_optim.step()
             with torch.no_grad():
                 self.nju.clamp_(0)
-            out["actor_loss"] = float(loss)
+            out["actor_loss"] = float(loss.detach())
             if not self.sac:
                 self._polyak(n.actor_target, n.actor)
                 self._polyak(n.critic_target, n.critic)

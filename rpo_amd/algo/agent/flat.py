@@ -28,7 +28,7 @@ def _unique(params):
 
 class FlatParams(object):
 
-    def __init__(self, critic, actor, device):
+    def __init__(self, critic, actor, device, extras=()):
         cp, ap = _unique(critic.parameters()), _unique(actor.parameters())
         a_ids, c_ids = set(id(p) for p in ap), set(id(p) for p in cp)
         seg_c = [p for p in cp if id(p) not in a_ids]
@@ -37,13 +37,17 @@ class FlatParams(object):
         self.sizes = [sum(p.numel() for p in seg) for seg in (seg_c, seg_s, seg_a)]
         # every tensor starts on a 16-byte boundary (float4 loads in the MLP kernels); padding floats stay zero
         c, s, a = [sum(_pad4(p.numel()) for p in seg) for seg in (seg_c, seg_s, seg_a)]
+        x = sum(_pad4(p.numel()) for p in extras)
         self.critic_range = (0, c + s)
         self.actor_range = (c, c + s + a)
-        self.total = c + s + a
+        # the multipliers (`extras`) sit right behind the actor slice: on a policy step their gradient travels in the
+        # same all-reduce as the actor's (one bucket), while every optimiser still steps only its own slice
+        self.policy_bucket = (c, c + s + a + x)
+        self.total = c + s + a + x
         self.data = torch.zeros(self.total, device=device)
         self.grad = torch.zeros(self.total, device=device)
         self.offset = {}
-        for start, seg in ((0, seg_c), (c, seg_s), (c + s, seg_a)):
+        for start, seg in ((0, seg_c), (c, seg_s), (c + s, seg_a), (c + s + a, list(extras))):
             off = start
             for p in seg:
                 n = p.numel()

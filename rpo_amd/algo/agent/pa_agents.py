@@ -51,7 +51,12 @@ class _PartialActionAgent(Agent):
         dev = self.device
         self.actor_target = copy.deepcopy(self.actor) if has_actor_target else None
         self.critic_target = copy.deepcopy(self.critic)
-        self.flat = FlatParams(self.critic, self.actor, dev)
+        # multipliers: lambda (equalities, never stepped: rpo_ddpg.py:202) and nu (inequalities, DualAdam ascent)
+        self.lamb = Dual(self.eq_num)
+        self.nju = Dual(self.ineq_num)
+        self.lamb.reset_parameters(self._init_duals[0])
+        self.nju.reset_parameters(self._init_duals[1])
+        self.flat = FlatParams(self.critic, self.actor, dev, extras=[self.lamb.weight, self.nju.weight])
         self.critic_target_flat = self.flat.make_target(self.critic, self.critic_target, self.flat.critic_range)
         self.actor_target_flat = self.flat.make_target(self.actor, self.actor_target, self.flat.actor_range) \
             if has_actor_target else None
@@ -64,13 +69,6 @@ class _PartialActionAgent(Agent):
                                       self.flat.gradient(self.flat.critic_range), self.lr_critic, self.reg, clip)
         self.actor_optim = FusedAdam(self.backend, self.flat.param(self.flat.actor_range),
                                      self.flat.gradient(self.flat.actor_range), self.lr_actor, self.reg, clip)
-        # multipliers: lambda (equalities, never stepped: rpo_ddpg.py:202) and nu (inequalities, DualAdam ascent)
-        self.lamb = Dual(self.eq_num, device=dev)
-        self.nju = Dual(self.ineq_num, device=dev)
-        self.lamb.reset_parameters(self._init_duals[0])
-        self.nju.reset_parameters(self._init_duals[1])
-        for d in (self.lamb, self.nju):
-            d.weight.grad = torch.zeros_like(d.weight)
         self.lamb_optim = FusedAdam(self.backend, self.lamb.weight.data.view(-1), self.lamb.weight.grad.view(-1),
                                     self.lr_dual, maximize=True)
         self.nju_optim = FusedAdam(self.backend, self.nju.weight.data.view(-1), self.nju.weight.grad.view(-1),

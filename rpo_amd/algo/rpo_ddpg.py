@@ -138,10 +138,8 @@ class RPODDPG(RPOTrainerBase):
         q = f.forward("critic", state, actions, f.buf("q", B, 1), save=True)
         lag, g_act = f.buf("loss_lag", 1), f.buf("g_act", B, k.action_dim)
         lag.zero_()
-        ag.nju.weight.grad.zero_()
-        ag.lamb.weight.grad.zero_()
+        ag.flat.grad.zero_()               # parameters AND multipliers (they live in the same flat buffer)
         k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1))
-        ag.flat.grad.zero_()
         dq = f.buf("dq", B, 1)
         dq.fill_(-1.0 / B)
         da = f.buf("da", B, k.action_dim)

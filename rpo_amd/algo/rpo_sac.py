@@ -104,10 +104,8 @@ class RPOSAC(RPOTrainerBase):
         q2 = f.forward("critic2", state, actions, f.buf("q2", B, 1), save=True)
         lag, g_act = f.buf("loss_lag", 1), f.buf("g_act", B, k.action_dim)
         lag.zero_()
-        ag.nju.weight.grad.zero_()
-        ag.lamb.weight.grad.zero_()
+        ag.flat.grad.zero_()               # parameters AND multipliers (they live in the same flat buffer)
         k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1))
-        ag.flat.grad.zero_()
         # d(-min(q1, q2))/dq: the smaller one takes the gradient, ties are split (torch.min's backward)
         w1 = (q1 < q2).to(torch.float32) + 0.5 * (q1 == q2).to(torch.float32)
         dq1, dq2 = f.buf("dq1", B, 1), f.buf("dq2", B, 1)

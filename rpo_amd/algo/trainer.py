@@ -76,12 +76,17 @@ class _Dist(object):
         self.world = dist.get_world_size() if self.on else 1
 
     def mean_(self, tensors):
-        """In-place all-reduce(mean) of a list of flat gradient buffers: ONE collective per tensor (1-2 per update)."""
+        """In-place all-reduce(mean) of flat gradient buckets: ONE collective per bucket, one bucket per update (critic
+        slice; on policy steps also actor slice + multipliers)."""
         if not self.on:
             return
+        avg = dist.get_backend() == "nccl"          # RCCL averages in the collective; gloo needs the explicit scale
         for t in tensors:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            t.mul_(1.0 / self.world)
+            if avg:
+                dist.all_reduce(t, op=dist.ReduceOp.AVG)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                t.mul_(1.0 / self.world)
 
     def sum_(self, t):
         if self.on:
@@ -249,9 +254,7 @@ class RPOTrainerBase(object):
     def _actor_update(self, cols):
         out = self.actor_loss(cols[0])
         loss = out[0] if isinstance(out, tuple) else out
-        self.agent.flat.grad.zero_()
-        self.agent.nju.weight.grad.zero_()
-        self.agent.lamb.weight.grad.zero_()
+        self.agent.flat.grad.zero_()       # parameters and multipliers share the flat gradient buffer
         loss.backward()
         self.last_losses["actor"] = loss.detach()
         return out
@@ -273,7 +276,7 @@ class RPOTrainerBase(object):
             def s2():
                 self._critic_step(actor_step)
                 box["actor_out"] = self._actor_update(box["cols"])
-            segs.append((s2, [fl.gradient(fl.actor_range), ag.nju.weight.grad]))
+            segs.append((s2, [fl.gradient(fl.policy_bucket)]))
 
             def s3():
                 self._actor_step(box["actor_out"])
@@ -309,7 +312,7 @@ class RPOTrainerBase(object):
             self._critic_step(actor_step)
             if actor_step:
                 out = self._actor_update(cols)
-                self.dist.mean_([fl.gradient(fl.actor_range), self.agent.nju.weight.grad])
+                self.dist.mean_([fl.gradient(fl.policy_bucket)])
                 self._actor_step(out)
         if self.dist.on:
             body()                      # collectives inside: eager
@@ -326,7 +329,7 @@ class RPOTrainerBase(object):
         self._critic_step(actor_step)
         if actor_step:
             out = self._actor_update(cols)
-            self.dist.mean_([fl.gradient(fl.actor_range), self.agent.nju.weight.grad])
+            self.dist.mean_([fl.gradient(fl.policy_bucket)])
             self._actor_step(out)
 
     # ------------------------------------------------------------------------------------------ fused-MLP helpers

@@ -226,6 +226,12 @@ SCRIPT_HP = {   # scripts/cart_exp.py:26-28, cart_exp_sac.py:26-29, pen_exp.py:2
     ("ddpg", "pendulum"): dict(lr_dual=0.01, corr_lr=2e-3, eps=0.5, eps_start=0.5, eval_lr=2e-3, shared_param=False),
     ("sac", "pendulum"): dict(lr_dual=0.01, corr_lr=2e-3, eps=1e-2, eps_start=1e-2, eval_lr=2e-3, shared_param=False,
                               alpha=0.01, automatic_entropy_tuning=False),
+    # variants with large exploration noise and non-zero initial multipliers: the actor-loss batch violates the
+    # inequalities, so the Lagrangian term, its gradient and the DualAdam step are exercised (nu changes)
+    ("ddpg", "cart", "viol"): dict(lr_dual=0.2, corr_lr=2e-2, eps=8.0, eps_start=8.0, eval_lr=2e-2, shared_param=True,
+                                   init_nju=0.5),
+    ("ddpg", "pendulum", "viol"): dict(lr_dual=0.01, corr_lr=2e-3, eps=4.0, eps_start=4.0, eval_lr=2e-3,
+                                       shared_param=False, init_nju=0.3),
 }
 
 
@@ -234,7 +240,9 @@ def gen_train_steps():
     random draw recorded: np.random.randint of ReplayBuffer.sample, torch.randn_like of take_action,
     _standard_normal of Normal.rsample."""
     import torch.distributions.normal as tdn
-    for (algo, envname), hp in SCRIPT_HP.items():
+    for key, hp in SCRIPT_HP.items():
+        algo, envname = key[0], key[1]
+        tag = "" if len(key) == 2 else "_" + key[2]
         torch.manual_seed(123)
         np.random.seed(123)
         env = make_cart_env(1) if envname == "cart" else REF.SpringPendulumEnv()
@@ -318,7 +326,7 @@ def gen_train_steps():
         out["n_noise"] = len(draws["noise"])
         out["critic_losses"] = np.array(losses["critic"])
         out["actor_losses"] = np.array(losses["actor"])
-        save("train_steps_%s_%s" % (algo, envname), **out)
+        save("train_steps_%s_%s%s" % (algo, envname, tag), **out)
 
 
 # ---------------------------------------------------------------------------------------------- training statistics

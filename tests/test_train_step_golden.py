@@ -15,8 +15,15 @@ from rpo_amd import gym_shim
 from rpo_amd.algo import RPODDPG, RPOSAC
 from rpo_amd.env import CartSafeEnv, SpringPendulumEnv
 
-CASES = [("ddpg", "cart"), ("sac", "cart"), ("ddpg", "pendulum"), ("sac", "pendulum")]
+CASES = [("ddpg", "cart"), ("sac", "cart"), ("ddpg", "pendulum"), ("sac", "pendulum"), ("ddpg", "cart_viol"),
+         ("ddpg", "pendulum_viol")]
+# "*_viol": large exploration noise + non-zero initial multipliers, so that the batch of the actor loss violates the
+# inequalities and the Lagrangian gradient / DualAdam step are exercised (nu moves); see make_golden.py
 HP = {
+    ("ddpg", "cart_viol"): dict(lr_dual=0.2, corr_lr=2e-2, eps=8.0, eps_start=8.0, eval_lr=2e-2, shared_param=True,
+                                init_nju=0.5),
+    ("ddpg", "pendulum_viol"): dict(lr_dual=0.01, corr_lr=2e-3, eps=4.0, eps_start=4.0, eval_lr=2e-3, shared_param=False,
+                                    init_nju=0.3),
     ("ddpg", "cart"): dict(lr_dual=0.2, corr_lr=2e-2, eps=1.0, eps_start=1.0, eval_lr=2e-2, shared_param=True),
     ("sac", "cart"): dict(lr_dual=0.2, corr_lr=2e-2, eps=5e-3, eps_start=5e-3, eval_lr=2e-2, shared_param=False,
                           alpha=0.1),
@@ -46,7 +53,7 @@ def test_oracle_loop_matches_reference_update(golden, algo, envname):
     torch.set_num_threads(1)
     g = golden("train_steps_%s_%s" % (algo, envname))
     torch.manual_seed(123)
-    env = rpo_loop.CartAdapter(1) if envname == "cart" else rpo_loop.PendulumAdapter(reference_batch_semantics=True)
+    env = rpo_loop.CartAdapter(1) if envname.startswith("cart") else rpo_loop.PendulumAdapter(reference_batch_semantics=True)
     noises = [torch.tensor(g["noise%d" % i]) for i in range(int(g["n_noise"]))]
     idx = list(g["idx"])
     hp = dict(HP[(algo, envname)])
@@ -81,6 +88,8 @@ def test_oracle_loop_matches_reference_update(golden, algo, envname):
             np.testing.assert_allclose(tr.nets.actor_target[k].detach().numpy(), v, **TOL)
     np.testing.assert_allclose(tr.nju.detach().numpy(), g["nju4"], rtol=1e-5, atol=1e-7)
     assert not noises and not idx        # every recorded draw was consumed, in order
+    if envname.endswith("_viol"):
+        assert np.abs(g["nju4"] - hp["init_nju"]).max() > 5e-3          # the multipliers did move
 
 
 def build_trainer(algo, envname, backend, device, fused=True, **extra):
@@ -95,8 +104,8 @@ def build_trainer(algo, envname, backend, device, fused=True, **extra):
 
 
 def _build_trainer(algo, envname, backend, device, **extra):
-    env_cls = CartSafeEnv if envname == "cart" else SpringPendulumEnv
-    kw = dict(partial_actions=[1]) if envname == "cart" else {}
+    env_cls = CartSafeEnv if envname.startswith("cart") else SpringPendulumEnv
+    kw = dict(partial_actions=[1]) if envname.startswith("cart") else {}
     env = gym_shim.TimeLimit(env_cls(backend=backend, device=device, **kw), 200)
     cls = RPODDPG if algo == "ddpg" else RPOSAC
     hp = dict(HP[(algo, envname)])
