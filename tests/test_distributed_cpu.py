@@ -104,3 +104,27 @@ def test_updates_per_step_cadence():
     assert int(tr.agent.critic_optim.step_dev[0]) == 12 and int(tr.agent.actor_optim.step_dev[0]) == 3
     assert seen == [(t, k) for t in range(1, 5) for k in range(3)]
     assert int(tr.vec.ctrl[2]) == 0 and int(tr.vec.ctrl[0]) == 4
+
+
+def test_warmup_phase_uses_uniform_actions_and_delays_training():
+    """rpo_ddpg.py:97-101,160-161: for t < warmup the basic action is BoxConstraint.sample (uniform in the box), and
+    train(t) starts at loop index t == warmup."""
+    sys.path.insert(0, HERE)
+    import oracle_backend as ob
+    from oracle import philox
+    from test_train_step_golden import build_trainer
+    torch.set_num_threads(1)
+    torch.manual_seed(5)
+    tr = build_trainer("ddpg", "cart", ob, torch.device("cpu"), num_envs=8, warmup=3)
+    tr.vec.reset()
+    tr.run_steps(1)
+    r = philox.draw(tr.seed, np.arange(8), 0, philox.STREAM_ACT)
+    ap = 10.0 * (2.0 * philox.u01(r[:, 0]) - 1.0)
+    free = np.abs(ap) < 6.9                                     # larger draws are moved by the projection afterwards
+    np.testing.assert_allclose(tr.buffer.rows[:8, 7].numpy()[free], ap[free], rtol=1e-5, atol=1e-5)   # basic action = index 1
+    assert np.all(np.abs(tr.buffer.rows[:8, 7].numpy()[~free]) < np.abs(ap[~free]))
+    assert int(tr.agent.critic_optim.step_dev[0]) == 0
+    tr.run_steps(1)
+    assert int(tr.agent.critic_optim.step_dev[0]) == 0
+    tr.run_steps(3)                                              # loop indices 3, 4, 5 train
+    assert int(tr.agent.critic_optim.step_dev[0]) == 3 and int(tr.agent.actor_optim.step_dev[0]) == 1
