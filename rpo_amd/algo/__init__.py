@@ -1,4 +1,5 @@
+from .baselines import DDPG_LA, SAC_LA
 from .rpo_ddpg import RPODDPG
 from .rpo_sac import RPOSAC
 
-__all__ = ["RPODDPG", "RPOSAC"]
+__all__ = ["RPODDPG", "DDPG_LA", "RPOSAC", "SAC_LA"]
