@@ -43,92 +43,111 @@ struct TileLds {
     float out[ROWS * 2];                                         // outputs (after the epilogue)
 };
 
+// Everything a thread keeps in registers for one network: its first-layer column, its wave's slice of W0 and the head
+// vectors.  Loaded once (tile_load_weights) and reused for any number of row tiles (tile_compute): a persistent
+// workgroup streams the 128 KB hidden-layer matrix once instead of once per tile.
+template <int EIN, int H, int RT>
+struct TileWeights {
+    static constexpr int NT = H / (16 * kFwdWaves);              // 16-column tiles per wave
+    static constexpr int ITS = EIN / 16;                         // k-groups of 16
+    static constexpr int PRE_MAX = RT > 1 ? 8 : 16;
+    static constexpr int PRE = ITS < PRE_MAX ? ITS : PRE_MAX;    // k-groups kept in registers
+    float bias;
+    float ws0[8], wa0[8];                                        // first chunk of the column's first-layer weights
+    float4 wpre[PRE][NT];
+    float b0v[NT], w1av[NT], w1bv[NT];
+    float b1v;
+};
+
+template <int EIN, int H, int RT>
+__device__ __forceinline__ void tile_load_weights(const Mlp& net, TileWeights<EIN, H, RT>& w) {
+    constexpr int ROWS = kRows * RT;
+    constexpr int NT = TileWeights<EIN, H, RT>::NT, PRE = TileWeights<EIN, H, RT>::PRE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    // ---- layer-1 operands of this thread first: they are what layer 1 waits for (returns are in order)
+    const int e_col = tid % EIN;
+    const bool act_part = net.cat && e_col >= net.E;            // concatenating critic: columns [E, 2E) embed the action
+    const int er = act_part ? e_col - net.E : e_col;
+    const bool use_s = !act_part, use_a = net.A > 0 && (act_part || !net.cat);
+    w.bias = act_part ? net.ba[er] : (net.bs[er] + ((net.A > 0 && !net.cat) ? net.ba[er] : 0.0f));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        w.ws0[u] = (use_s && u < net.S) ? net.Ws[er * net.S + u] : 0.0f;
+        w.wa0[u] = (use_a && u < net.A) ? net.Wa[er * net.A + u] : 0.0f;
+    }
+    // ---- then the wave's slice of W0: it streams in underneath layer 1 and feeds the MFMA loop k-group by k-group
+    const int j0 = wave * (H / kFwdWaves);
+#pragma unroll
+    for (int it = 0; it < PRE; ++it)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+            w.wpre[it][c] = *reinterpret_cast<const float4*>(&net.W0[(size_t)(j0 + c * 16 + li) * EIN + it * 16 + lg * 4]);
+    // ---- what the epilogue needs is requested last
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        w.b0v[c] = net.b0[j0 + c * 16 + li];
+        w.w1av[c] = net.W1[j0 + c * 16 + li];
+        w.w1bv[c] = net.n_out > 1 ? net.W1b[j0 + c * 16 + li] : 0.0f;
+    }
+    w.b1v = (tid < ROWS * net.n_out) ? (((tid % net.n_out) == 0) ? net.b1[0] : net.b1b[0]) : 0.0f;
+}
+
 // Forward of the RT * 16 rows whose inputs sit in lds.in_s / lds.in_a (the caller wrote them; this function
 // synchronises before reading).  Outputs land in lds.out[r * 2 + o] and are visible to every thread on return.
 // out_mode 1: BoxConstraint's tanh map on output 0.  x0_save / h1_save (global, may be NULL) get the pre-activations
 // of rows row0 + r < n.
-template <int EIN, int H, int RT = 1, class LDS = TileLds<EIN, RT>>
-__device__ __forceinline__ void mlp_tile_forward(const Mlp& net, LDS& lds, int row0, int n, float* x0_save,
-                                                 float* h1_save, int out_mode, float scale, float base) {
+template <int EIN, int H, int RT, class LDS>
+__device__ __forceinline__ void tile_compute(const Mlp& net, const TileWeights<EIN, H, RT>& w, LDS& lds, int row0, int n,
+                                             float* x0_save, float* h1_save, int out_mode, float scale, float base) {
     constexpr int kInS = LDS::kS, kInA = LDS::kA;               // (shadow the default strides)
     constexpr int ROWS = kRows * RT;
     constexpr int LDX = EIN + 4;
     constexpr int GROUPS = kFwdThreads / EIN;                   // thread groups that split the rows in layer 1
     constexpr int RPT = ROWS / GROUPS;                          // rows per thread in layer 1
     static_assert(kFwdThreads % EIN == 0 && ROWS % GROUPS == 0, "layer-1 thread mapping");
+    constexpr int NT = TileWeights<EIN, H, RT>::NT, ITS = TileWeights<EIN, H, RT>::ITS, PRE = TileWeights<EIN, H, RT>::PRE;
     float* x1 = lds.x1;
     const float* in_s = lds.in_s;
     const float* in_a = lds.in_a;
     float* part = lds.part;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
-
-    // ---- layer-1 operands of this thread: embedding column e_col, rows [r_lo, r_lo + RPT)
     const int e_col = tid % EIN, r_lo = (tid / EIN) * RPT;
-    const bool act_part = net.cat && e_col >= net.E;            // concatenating critic: columns [E, 2E) embed the action
+    const bool act_part = net.cat && e_col >= net.E;
     const int er = act_part ? e_col - net.E : e_col;
     const bool use_s = !act_part, use_a = net.A > 0 && (act_part || !net.cat);
-    float acc1[RPT];
-    float ws0[8], wa0[8];                                       // first chunk of the column's first-layer weights
-    {
-        const float bias = act_part ? net.ba[er] : (net.bs[er] + ((net.A > 0 && !net.cat) ? net.ba[er] : 0.0f));
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) acc1[r] = bias;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            ws0[u] = (use_s && u < net.S) ? net.Ws[er * net.S + u] : 0.0f;
-            wa0[u] = (use_a && u < net.A) ? net.Wa[er * net.A + u] : 0.0f;
-        }
-    }
-    // ---- then the wave's slice of W0: requested AFTER the few loads layer 1 waits for (returns are in order), it
-    //      streams in underneath layer 1 and feeds the MFMA loop k-group by k-group
-    constexpr int NT = H / (16 * kFwdWaves);                    // 16-column tiles per wave
-    constexpr int ITS = EIN / 16;                               // k-groups of 16
-    constexpr int PRE_MAX = RT > 1 ? 8 : 16;
-    constexpr int PRE = ITS < PRE_MAX ? ITS : PRE_MAX;          // k-groups kept in registers up front
     const int j0 = wave * (H / kFwdWaves);
-    float4 wpre[PRE][NT];
+    float acc1[RPT];
 #pragma unroll
-    for (int it = 0; it < PRE; ++it)
-#pragma unroll
-        for (int c = 0; c < NT; ++c)
-            wpre[it][c] = *reinterpret_cast<const float4*>(&net.W0[(size_t)(j0 + c * 16 + li) * EIN + it * 16 + lg * 4]);
-    // what the epilogue needs is requested last
-    float b0v[NT], w1av[NT], w1bv[NT];
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
-        b0v[c] = net.b0[j0 + c * 16 + li];
-        w1av[c] = net.W1[j0 + c * 16 + li];
-        w1bv[c] = net.n_out > 1 ? net.W1b[j0 + c * 16 + li] : 0.0f;
-    }
-    const float b1v = (tid < ROWS * net.n_out) ? (((tid % net.n_out) == 0) ? net.b1[0] : net.b1b[0]) : 0.0f;
+    for (int r = 0; r < RPT; ++r) acc1[r] = w.bias;
     __syncthreads();
 
     // ---- layer 1 (VALU): x0[r][e]
     if (use_s) {
         for (int i0 = 0; i0 < net.S; i0 += 8) {
-            float w[8];
+            float wv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = (i0 == 0) ? ws0[u] : ((i0 + u < net.S) ? net.Ws[er * net.S + i0 + u] : 0.0f);
+            for (int u = 0; u < 8; ++u) wv[u] = (i0 == 0) ? w.ws0[u] : ((i0 + u < net.S) ? net.Ws[er * net.S + i0 + u] : 0.0f);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if (i0 + u < net.S) {
 #pragma unroll
-                    for (int r = 0; r < RPT; ++r) acc1[r] = fmaf(in_s[(r_lo + r) * kInS + i0 + u], w[u], acc1[r]);
+                    for (int r = 0; r < RPT; ++r) acc1[r] = fmaf(in_s[(r_lo + r) * kInS + i0 + u], wv[u], acc1[r]);
                 }
             }
         }
     }
     if (use_a) {
         for (int i0 = 0; i0 < net.A; i0 += 8) {
-            float w[8];
+            float wv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = (i0 == 0) ? wa0[u] : ((i0 + u < net.A) ? net.Wa[er * net.A + i0 + u] : 0.0f);
+            for (int u = 0; u < 8; ++u) wv[u] = (i0 == 0) ? w.wa0[u] : ((i0 + u < net.A) ? net.Wa[er * net.A + i0 + u] : 0.0f);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if (i0 + u < net.A) {
 #pragma unroll
-                    for (int r = 0; r < RPT; ++r) acc1[r] = fmaf(in_a[(r_lo + r) * kInA + i0 + u], w[u], acc1[r]);
+                    for (int r = 0; r < RPT; ++r) acc1[r] = fmaf(in_a[(r_lo + r) * kInA + i0 + u], wv[u], acc1[r]);
                 }
             }
         }
@@ -155,7 +174,7 @@ __device__ __forceinline__ void mlp_tile_forward(const Mlp& net, LDS& lds, int r
         float4 b4[NT];
 #pragma unroll
         for (int c = 0; c < NT; ++c)
-            b4[c] = (it < PRE) ? wpre[it < PRE ? it : 0][c]
+            b4[c] = (it < PRE) ? w.wpre[it < PRE ? it : 0][c]
                                : *reinterpret_cast<const float4*>(&net.W0[(size_t)(j0 + c * 16 + li) * EIN + it * 16 + lg * 4]);
         // consecutive MFMAs go to different accumulators (40-cycle dependent latency vs 32-cycle issue)
 #pragma unroll
@@ -185,12 +204,12 @@ __device__ __forceinline__ void mlp_tile_forward(const Mlp& net, LDS& lds, int r
             const int col = j0 + c * 16 + li;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float h = acc[rt][c][i] + b0v[c];
+                const float h = acc[rt][c][i] + w.b0v[c];
                 const int row = row0 + rt * kRows + lg * 4 + i;
                 if (h1_save && row < n) h1_save[(size_t)row * H + col] = h;
                 const float hr = fmaxf(h, 0.0f);
-                po[0][i] = fmaf(hr, w1av[c], po[0][i]);
-                po[1][i] = fmaf(hr, w1bv[c], po[1][i]);
+                po[0][i] = fmaf(hr, w.w1av[c], po[0][i]);
+                po[1][i] = fmaf(hr, w.w1bv[c], po[1][i]);
             }
         }
 #pragma unroll
@@ -205,12 +224,21 @@ __device__ __forceinline__ void mlp_tile_forward(const Mlp& net, LDS& lds, int r
     __syncthreads();
     if (tid < ROWS * net.n_out) {
         const int r = tid / net.n_out, o = tid - r * net.n_out;
-        float v = b1v;
-        for (int w = 0; w < kFwdWaves; ++w) v += part[(w * ROWS + r) * 2 + o];       // fixed order
+        float v = w.b1v;
+        for (int ww = 0; ww < kFwdWaves; ++ww) v += part[(ww * ROWS + r) * 2 + o];   // fixed order
         if (out_mode == 1 && o == 0) v = scale * tanhf(v) + base;
         lds.out[r * 2 + o] = v;
     }
     __syncthreads();
+}
+
+// load + compute for one tile
+template <int EIN, int H, int RT = 1, class LDS = TileLds<EIN, RT>>
+__device__ __forceinline__ void mlp_tile_forward(const Mlp& net, LDS& lds, int row0, int n, float* x0_save,
+                                                 float* h1_save, int out_mode, float scale, float base) {
+    TileWeights<EIN, H, RT> w;
+    tile_load_weights<EIN, H, RT>(net, w);
+    tile_compute<EIN, H, RT, LDS>(net, w, lds, row0, n, x0_save, h1_save, out_mode, scale, base);
 }
 
 }  // namespace rpo_mlp_dev
