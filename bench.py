@@ -119,9 +119,9 @@ def kernel_clinic(tr):
                                      2e-2, 1e-5, 0.0, vec.seed, vec.env_id_base, vec.ctrl, vec.stats)
 
     def rollout_at(vec, rows, cap):
-        return lambda: k.ddpg_rollout(f.descs["actor"], scale, base, vec.internal, vec.action, vec.ep_len, vec.ep_ret,
-                                      vec.ep_count, rows, cap, vec.stats, vec.ctrl, ops.NOISE_PHILOX, 1.0, 1.0, 0.0, -10.0,
-                                      10.0, 10, 2e-2, 1e-5, 0.0, 200, True, 1e-3, vec.seed, vec.env_id_base)
+        return lambda: k.rollout(f.descs["actor"], False, scale, base, vec.internal, None, vec.action, vec.ep_len,
+                                 vec.ep_ret, vec.ep_count, rows, cap, vec.stats, vec.ctrl, ops.NOISE_PHILOX, 1.0, 1.0, 0.0,
+                                 -10.0, 10.0, 10, 2e-2, 1e-5, 0.0, 200, True, 1e-3, vec.seed, vec.env_id_base)
 
     def hbm(name, n, us, bytes_per_unit):
         out[name] = dict(n=n, us=us, bound="hbm", work=bytes_per_unit * n, rate=bytes_per_unit * n / us * 1e-3,
@@ -132,7 +132,7 @@ def kernel_clinic(tr):
                          unit="TFLOP/s", peak=MFMA_F32_PEAK_TFLOPS)
 
     # ---- the launches of one iteration at the bench size
-    mfma("cart_ddpg_rollout_kernel", v.n, time_kernel(rollout_at(v, buf.rows, buf.capacity))[0], ACTOR_FLOPS)
+    mfma("rollout_kernel<CartEnv>", v.n, time_kernel(rollout_at(v, buf.rows, buf.capacity))[0], ACTOR_FLOPS)
     d = f.descs["critic"]
     cf = lambda: k.ddpg_critic_forward(  # noqa: E731
         f.descs["actor_target"], f.descs["critic_target"], d, scale, base, buf.rows, buf.capacity, buf.n_envs, tr._batch,
@@ -159,7 +159,7 @@ def kernel_clinic(tr):
     big_batch = torch.zeros(big_n, k.row_floats, device=dev)
     hbm("replay_sample_gather_kernel@1M", big_n, time_kernel(lambda: ops.replay_sample_gather(
         rows, 8, big_n, big_batch, None, 1, 0, big.ctrl), reps=20)[0], 178 + 4)
-    mfma("cart_ddpg_rollout_kernel@1M", big_n, time_kernel(rollout_at(big, rows, 8), reps=5)[0], ACTOR_FLOPS)
+    mfma("rollout_kernel<CartEnv>@1M", big_n, time_kernel(rollout_at(big, rows, 8), reps=5)[0], ACTOR_FLOPS)
     for name, e in out.items():
         e["frac"] = e["rate"] / e["peak"]
         log("  %-36s n=%-8d %9.2f us  %9.2f %-8s (%.1f%% of the %s peak)" % (name, e["n"], e["us"], e["rate"], e["unit"],
@@ -298,7 +298,7 @@ def main():
         if not args.no_clinic and world == 1 and tr.fused is not None and headline:
             log("kernel clinic (hipGraph of back-to-back launches between two HIP events on the launch stream):")
             clinic = kernel_clinic(tr)
-            in_iter = ("cart_ddpg_rollout_kernel", "cart_ddpg_critic_forward_kernel", "mlp_bwd_rows+weights_kernels")
+            in_iter = ("rollout_kernel<CartEnv>", "cart_ddpg_critic_forward_kernel", "mlp_bwd_rows+weights_kernels")
             dom = max(in_iter, key=lambda n: clinic[n]["us"])
             d, st = clinic[dom], clinic["cartsafe_step_kernel@1M"]
             result["roofline"] = {

@@ -300,21 +300,32 @@ int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int
                      float* dx0, float* da, int param_grads, int first_layer_state_only, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * Fused pipelines of one RPODDPG iteration on CartSafe-v0 (rpo_amd/csrc/fused.hip): the row-local stages chained
+ * Fused pipelines of one RPO iteration (rpo_amd/csrc/fused.hip): the row-local stages chained
  * inside one workgroup of 16 rows, because at 4096 lanes / batch 256 every launch is dominated by dispatch + cold-start
  * latency.  Bitwise identical to the sequences of single-stage launches they replace.
  * ------------------------------------------------------------------------------------------------------------- */
 
-/* Rollout of one vector step (rpo_ddpg.py:93-145): actor MLP -> noise + clip -> complete_partial -> grad_steps ->
- * env step + violations + TimeLimit -> replay scatter -> statistics -> auto-reset.
- * == rpo_mlp_forward(actor, tanh box) + rpo_cartsafe_act_project + rpo_cartsafe_step (same arguments). */
-int rpo_cartsafe_ddpg_rollout(const rpo_mlp* actor_host, float scale, float base, int n_envs, float* state,
-                              float* action, int* ep_len, float* ep_ret, unsigned* ep_count, float* rows,
-                              long long cap_steps, float* stats, int stats_cap, long long* ctrl, int noise_mode,
-                              float eps_start, float eps_end, float eps_decay, float box_lo, float box_hi, int max_steps,
-                              float corr_lr, float corr_eps, float corr_momentum, const float* consts_host, int partial,
-                              int max_episode_steps, int auto_reset, float viol_thresh, unsigned long long seed,
-                              unsigned env_id_base, void* stream);
+/* Rollout of one vector step (rpo_ddpg.py:93-145, rpo_sac.py:95-150): actor MLP -> policy head -> complete_partial ->
+ * grad_steps -> env step + violations + TimeLimit -> replay scatter -> statistics -> auto-reset.
+ * gauss = 0 (RPODDPG, agent/ddpg_pa.py:108-110): the actor's tanh-box output + noise_mode's exploration noise + clip;
+ *   == rpo_mlp_forward(actor, out_mode 1) + rpo_<env>_act_project(noise_mode) + rpo_<env>_step (same arguments).
+ * gauss = 1 (RPOSAC, agent/sac_pa.py:105-115): actor has the two heads (mean, log-std); the rsample draw of lane i is
+ *   normal(philox(seed, env_id_base + i, ctrl[T], RPO_STREAM_POLICY, ctrl[UPDATES])), i.e. rpo_philox_normal(salt 0);
+ *   == rpo_philox_normal + rpo_mlp_forward(actor) + rpo_gauss_head + rpo_<env>_act_project(RPO_NOISE_NONE) + step.
+ * CartSafe-v0: state [n,6] is the observation.  SpringPendulum-v0: internal [n,4], obs [n,5] (may be NULL: the
+ * pipeline itself derives observations from the internal state). */
+int rpo_cartsafe_rollout(const rpo_mlp* actor_host, int gauss, float scale, float base, int n_envs, float* state,
+                         float* action, int* ep_len, float* ep_ret, unsigned* ep_count, float* rows, long long cap_steps,
+                         float* stats, int stats_cap, long long* ctrl, int noise_mode, float eps_start, float eps_end,
+                         float eps_decay, float box_lo, float box_hi, int max_steps, float corr_lr, float corr_eps,
+                         float corr_momentum, const float* consts_host, int partial, int max_episode_steps,
+                         int auto_reset, float viol_thresh, unsigned long long seed, unsigned env_id_base, void* stream);
+int rpo_pendulum_rollout(const rpo_mlp* actor_host, int gauss, float scale, float base, int n_envs, float* internal,
+                         float* obs, float* action, int* ep_len, float* ep_ret, unsigned* ep_count, float* rows,
+                         long long cap_steps, float* stats, int stats_cap, long long* ctrl, int noise_mode,
+                         float eps_start, float eps_end, float eps_decay, float box_lo, float box_hi, int max_steps,
+                         float corr_lr, float corr_eps, float corr_momentum, int max_episode_steps, int auto_reset,
+                         float viol_thresh, unsigned long long seed, unsigned env_id_base, void* stream);
 
 /* Forward half of the critic update (rpo_ddpg.py:165-174, 327-337): ReplayBuffer.sample (Philox draw, or idx_in when
  * given) -> batch_out [B,24]; pi_targ(s') -> Complete + Proj -> Q_targ(s', a') = qn_out; Q(s, a) = q_out with the

@@ -72,17 +72,6 @@ class RPODDPG(RPOTrainerBase):
         return (self.fused is not None and hasattr(self.kernels, "ddpg_critic_forward")
                 and "actor_target" in self.fused.descs and "critic" in self.fused.descs)
 
-    def _rollout(self, warm):
-        if warm or not self._pipelines:
-            return super()._rollout(warm)
-        v, buf = self.vec, self.buffer
-        scale, base = self._box_affine
-        self.kernels.ddpg_rollout(self.fused.descs["actor"], scale, base, v.internal, v.action, v.ep_len, v.ep_ret,
-                                  v.ep_count, buf.rows, buf.capacity, v.stats, v.ctrl, hip_ops.NOISE_PHILOX,
-                                  self.eps_start, self.eps, self.decay_value, self._box_lo, self._box_hi, self.max_steps,
-                                  self.corr_lr, self.corr_eps, self.corr_momentum, v.max_episode_steps, True,
-                                  v.viol_thresh, self.seed, v.env_id_base)
-
     def _sample(self):
         if self._pipelines:
             # the critic-forward pipeline draws and gathers the batch itself (into self._batch)

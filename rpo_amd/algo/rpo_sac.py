@@ -38,6 +38,8 @@ class RPOSAC(RPOTrainerBase):
                   fixed=fixed, partial=partial, eps=eps, eps_start=eps_start, eps_epoch=eps_epoch)
         self._setup(env, work_dir, name, logger, agent, hp, device, num_envs, seed, backend, use_graph, updates_per_step)
 
+    _gauss_policy = True
+
     def _draw(self, buf, id_base, salt):
         self.backend.philox_normal(buf, self.seed, id_base, salt, hip_ops.STREAM_POLICY, self.vec.ctrl)
         return buf

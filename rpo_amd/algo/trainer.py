@@ -221,8 +221,28 @@ class RPOTrainerBase(object):
         """Basic action proposed for every lane + the noise mode the projection kernel must apply."""
         raise NotImplementedError
 
+    #: RPOSAC samples the squashed Gaussian inside the rollout pipeline; RPODDPG adds exploration noise to the actor
+    _gauss_policy = False
+
+    @property
+    def _rollout_pipeline(self):
+        return (self.fused is not None and hasattr(self.kernels, "rollout") and "actor" in self.fused.descs
+                and _env_int("RPO_FUSED_ROLLOUT", 1))
+
     def _rollout(self, warm):
         v = self.vec
+        if not warm and self._rollout_pipeline:
+            # actor -> head -> equation solver -> projection -> env step -> replay scatter in ONE launch (fused.hip)
+            scale, base = self._box_affine
+            self.kernels.rollout(self.fused.descs["actor"], self._gauss_policy, scale, base, v.internal,
+                                 None if v.obs is v.internal else v.obs, v.action, v.ep_len, v.ep_ret, v.ep_count,
+                                 self.buffer.rows, self.buffer.capacity, v.stats, v.ctrl,
+                                 hip_ops.NOISE_NONE if self._gauss_policy else hip_ops.NOISE_PHILOX, self.eps_start,
+                                 self.eps, self.decay_value, self._box_lo, self._box_hi, self.max_steps, self.corr_lr,
+                                 self.corr_eps, self.corr_momentum, v.max_episode_steps, True, v.viol_thresh, self.seed,
+                                 v.env_id_base)
+            v.steps_host += 1
+            return
         with torch.no_grad():
             ap, mode = self._policy_partial(v.obs, warm)
             self.kernels.act_project(v.obs, ap, None, v.action, None, mode, self.eps_start, self.eps, self.decay_value,

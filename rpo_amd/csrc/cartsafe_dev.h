@@ -33,12 +33,14 @@ constexpr float kThetaThreshold = 0.20943951023931953f, kXThreshold = 2.4f;   //
 constexpr float kActMax = 10.0f, kResetLo = -0.05f, kResetSpan = 0.1f;
 
 __device__ __forceinline__ void eq_ineq(const CartConsts& c, float a0, float a1, float& h, float (&g)[6]) {
+    RPO_FP_STRICT
     h = c.b - (a0 * c.C[0] + a1 * c.C[1]);                       // eq_resid, cartpole.py:375-376
 #pragma unroll
     for (int i = 0; i < 6; ++i) g[i] = (a0 * c.G[2 * i] + a1 * c.G[2 * i + 1]) - c.d[i];   // ineq_resid :378-379
 }
 
 __device__ __forceinline__ void reset_state(float (&s)[6], uint64_t seed, uint32_t env_id, uint32_t episode) {
+    RPO_FP_STRICT
     const rpo_u4 r0 = rpo_philox(seed, env_id, episode, RPO_STREAM_RESET);
     const rpo_u4 r1 = rpo_philox(seed, env_id, episode, RPO_STREAM_RESET + 0x100u);
     s[0] = kResetLo + rpo_u01(r0.x) * kResetSpan;
@@ -86,6 +88,7 @@ constexpr int kStepStats = 10;   // 0..7 sums (+terminated), 8..9 maxima -- see 
 // transition row (ReplayBuffer.add, buffer.py:22-29), `ns` the state the lane continues from.
 __device__ __forceinline__ void cart_lane(const StepArgs& p, const CartConsts& c, int i, const float (&s)[6], float2 a,
                                           float (&ns)[6], float4 (&row)[6], float (&st)[kStepStats]) {
+    RPO_FP_STRICT
     // violations of the PRE-step state and UN-clipped action (cartpole.py:229)
     float h, g[6];
     eq_ineq(c, a.x, a.y, h, g);
@@ -172,6 +175,7 @@ struct ActArgs {
 };
 
 __device__ __forceinline__ float reduced_grad(const CartConsts& c, float ap) {
+    RPO_FP_STRICT
     // ineq_partial_grad, cartpole.py:396-403: sign-based (sub)gradient of the reduced inequalities
     float grad = 0.0f;
 #pragma unroll
@@ -183,6 +187,7 @@ __device__ __forceinline__ float reduced_grad(const CartConsts& c, float ap) {
 // (rpo_ddpg.py:266-286, corr_mode 0, per-lane stop test) for one lane.  Returns the full action and the iteration count.
 __device__ __forceinline__ float2 cart_explore_project(const ActArgs& p, const CartConsts& c, int i, float ap_in, float eps_t,
                                                        long long t, int& iters) {
+    RPO_FP_STRICT
     float ap = (p.noise_mode == RPO_NOISE_UNIFORM) ? 0.0f : ap_in;
     if (p.noise_mode == RPO_NOISE_EXPLICIT) {
         ap = fminf(fmaxf(ap + eps_t * p.noise[i], p.box_lo), p.box_hi);                  // ddpg_pa.py:108-110

@@ -59,6 +59,13 @@ __device__ __forceinline__ float rpo_normal(uint32_t a, uint32_t b) {
 }
 
 // ------------------------------------------------------------------------------------------------ reductions
+// The env / head row functions live in headers and are inlined into several kernels (single-stage launches and the
+// fused pipelines).  With the default -ffp-contract=fast the compiler picks mul+add fusions per inlining context, so
+// the same source could round differently in two kernels; RPO_FP_STRICT at the top of a function body switches
+// contraction off for it, which makes "the pipeline equals the launches it replaces" hold bit for bit by construction
+// (and matches the unfused numpy / torch-CPU arithmetic of the reference).
+#define RPO_FP_STRICT _Pragma("clang fp contract(off)")
+
 __device__ __forceinline__ float rpo_wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, RPO_WAVE);

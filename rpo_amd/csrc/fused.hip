@@ -12,72 +12,145 @@
 #include <stdlib.h>
 
 #include "cartsafe_dev.h"
+#include "heads_dev.h"
 #include "mlp_tile.h"
+#include "pendulum_dev.h"
 
 namespace {
 
 using namespace rpo_mlp_dev;
-using namespace rpo_cart_dev;
+using rpo_cart_dev::ActArgs;
+using rpo_cart_dev::CartConsts;
+using rpo_cart_dev::cart_explore_project;
+using rpo_cart_dev::load_consts;
 
 Mlp to_dev(const rpo_mlp* h) {
     return Mlp{h->Ws, h->bs, h->Wa, h->ba, h->W0, h->b0, h->W1, h->b1, h->W1b, h->b1b, h->S, h->A, h->E, h->H, h->n_out, h->cat};
 }
 
 // ------------------------------------------------------------------------------------------------------ rollout
-struct RolloutArgs {
-    Mlp actor;
-    float scale, base;            // tanh box of the actor output (BoxConstraint)
-    ActArgs act;                  // exploration / projection parameters (ap_raw, noise, action unused / action out)
-    StepArgs step;                // env state, bookkeeping, ring, statistics, ctrl
-};
-
-template <int EIN, int H, int RT>
-__global__ __launch_bounds__(kFwdThreads) void cart_ddpg_rollout_kernel(RolloutArgs p, CartConsts c) {
-    typedef TileLds<EIN, RT, 8, 8> Lds;                          // 16 * RT lanes per workgroup; S = 6 fits stride 8
-    __shared__ Lds lds;
-    constexpr int kInS = Lds::kS;
-    constexpr int kRows = rpo_mlp_dev::kRows * RT;               // (shadows the 16-row constant below)
-    const int row0 = blockIdx.x * kRows;
-    const int tid = threadIdx.x;
-    const int n = p.step.n;
-    const long long t = p.step.ctrl ? p.step.ctrl[RPO_CTRL_T] : 0;
-    if (tid < kRows * 6) {                                     // obs tile == state rows (CartSafe observes its state)
-        const int r = tid / 6, i = tid - r * 6;
-        lds.in_s[r * kInS + i] = (row0 + r < n) ? p.step.state[(size_t)(row0 + r) * 6 + i] : 0.0f;
+// Env policies: how a lane's observation is staged for the actor, projected and stepped.
+struct CartEnv {
+    typedef rpo_cart_dev::StepArgs StepArgs;
+    typedef rpo_cart_dev::ActArgs ActArgs;
+    typedef rpo_cart_dev::CartConsts Consts;
+    static constexpr int OBS = 6;
+    __device__ static __forceinline__ void stage_obs(const StepArgs& p, int row0, int rows, float* in_s, int stride) {
+        const int tid = threadIdx.x;
+        if (tid < rows * 6) {                                  // CartSafe observes its state directly
+            const int r = tid / 6, i = tid - r * 6;
+            in_s[r * stride + i] = (row0 + r < p.n) ? p.state[(size_t)(row0 + r) * 6 + i] : 0.0f;
+        }
     }
-    mlp_tile_forward<EIN, H, RT, Lds>(p.actor, lds, row0, n, nullptr, nullptr, 1, p.scale, p.base);
-
-    float st[kStepStats];
-#pragma unroll
-    for (int k = 0; k < kStepStats; ++k) st[k] = 0.0f;
-    float iters_f = 0.0f;
-    const int i = row0 + tid;
-    if (tid < kRows && i < n) {
-        const float eps_t = fmaxf(p.act.eps_end, p.act.eps_start - p.act.eps_decay * (float)t);
-        int k;
-        const float2 a = cart_explore_project(p.act, c, i, lds.out[tid * 2], eps_t, t, k);
-        iters_f = (float)k;
-        reinterpret_cast<float2*>(p.act.action)[i] = a;
+    __device__ static __forceinline__ float2 project(const ActArgs& a, const Consts& c, const float* obs, int i, float ap,
+                                                     float eps_t, long long t, int& k) {
+        return rpo_cart_dev::cart_explore_project(a, c, i, ap, eps_t, t, k);
+    }
+    __device__ static __forceinline__ void lane(const StepArgs& p, const Consts& c, int i, const float* obs, float2 a,
+                                                long long ring_base, float (&st)[rpo_cart_dev::kStepStats]) {
         float s[6], ns[6];
         float4 row[6];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) s[q] = lds.in_s[tid * kInS + q];
-        cart_lane(p.step, c, i, s, a, ns, row, st);
-        if (p.step.rows) {
-            const long long ring_base = (t % p.step.cap_steps) * (long long)n;
-            float4* gr = reinterpret_cast<float4*>(p.step.rows + (size_t)(ring_base + i) * RPO_CART_ROW);
+        for (int q = 0; q < 6; ++q) s[q] = obs[q];
+        rpo_cart_dev::cart_lane(p, c, i, s, a, ns, row, st);
+        if (p.rows) {
+            float4* gr = reinterpret_cast<float4*>(p.rows + (size_t)(ring_base + i) * RPO_CART_ROW);
 #pragma unroll
             for (int q = 0; q < 6; ++q) gr[q] = row[q];
         }
-        store_state(p.step.state + (size_t)i * 6, ns);
+        rpo_cart_dev::store_state(p.state + (size_t)i * 6, ns);
+    }
+};
+
+struct PendEnv {
+    typedef rpo_pend_dev::StepArgs StepArgs;
+    typedef rpo_pend_dev::ActArgs ActArgs;
+    struct Consts { int unused; };
+    static constexpr int OBS = 5;
+    __device__ static __forceinline__ void stage_obs(const StepArgs& p, int row0, int rows, float* in_s, int stride) {
+        const int tid = threadIdx.x;
+        if (tid < rows) {                                      // obs = (cos, sin, theta_dot, l, l_dot) of the internal state
+            float4 s = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+            if (row0 + tid < p.n) s = reinterpret_cast<const float4*>(p.internal)[row0 + tid];
+            float sn, cs;
+            sincosf(s.x, &sn, &cs);
+            float* o = in_s + tid * stride;
+            o[0] = cs; o[1] = sn; o[2] = s.y; o[3] = s.z; o[4] = s.w;
+        }
+    }
+    __device__ static __forceinline__ float2 project(const ActArgs& a, const Consts&, const float* obs, int i, float ap,
+                                                     float eps_t, long long t, int& k) {
+        return rpo_pend_dev::pend_explore_project(a, obs, i, ap, eps_t, t, k);
+    }
+    __device__ static __forceinline__ void lane(const StepArgs& p, const Consts&, int i, const float* obs, float2 a,
+                                                long long ring_base, float (&st)[rpo_pend_dev::kStepStats]) {
+        const float4 s = reinterpret_cast<const float4*>(p.internal)[i];
+        float ns[4], ncs, nsn;
+        float4 row[4];
+        rpo_pend_dev::pend_lane(p, i, s, a, ns, ncs, nsn, row, st);
+        if (p.rows) {
+            float4* gr = reinterpret_cast<float4*>(p.rows + (size_t)(ring_base + i) * RPO_PEND_ROW);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gr[q] = row[q];
+        }
+        reinterpret_cast<float4*>(p.internal)[i] = make_float4(ns[0], ns[1], ns[2], ns[3]);
+        if (p.obs) rpo_pend_dev::store_obs(p.obs + (size_t)i * 5, ncs, nsn, ns[1], ns[2], ns[3]);
+    }
+};
+
+template <class ENV>
+struct RolloutArgs {
+    Mlp actor;
+    float scale, base;            // tanh box of the actor output (BoxConstraint)
+    int gauss;                    // 0: deterministic actor + exploration noise (DDPG); 1: squashed-Gaussian sample (SAC)
+    typename ENV::ActArgs act;    // exploration / projection parameters, action out
+    typename ENV::StepArgs step;  // env state, bookkeeping, ring, statistics, ctrl
+};
+
+template <class ENV, int EIN, int H, int RT>
+__global__ __launch_bounds__(kFwdThreads) void rollout_kernel(RolloutArgs<ENV> p, typename ENV::Consts c) {
+    typedef TileLds<EIN, RT, 8, 8> Lds;                          // 16 * RT lanes per workgroup; OBS <= 8
+    __shared__ Lds lds;
+    constexpr int kInS = Lds::kS;
+    constexpr int kLanes = rpo_mlp_dev::kRows * RT;
+    constexpr int kStats = 10;
+    const int row0 = blockIdx.x * kLanes;
+    const int tid = threadIdx.x;
+    const int n = p.step.n;
+    const long long t = p.step.ctrl ? p.step.ctrl[RPO_CTRL_T] : 0;
+    ENV::stage_obs(p.step, row0, kLanes, lds.in_s, kInS);
+    mlp_tile_forward<EIN, H, RT, Lds>(p.actor, lds, row0, n, nullptr, nullptr, p.gauss ? 0 : 1, p.scale, p.base);
+
+    float st[kStats];
+#pragma unroll
+    for (int k = 0; k < kStats; ++k) st[k] = 0.0f;
+    float iters_f = 0.0f;
+    const int i = row0 + tid;
+    if (tid < kLanes && i < n) {
+        const float eps_t = fmaxf(p.act.eps_end, p.act.eps_start - p.act.eps_decay * (float)t);
+        float ap = lds.out[tid * 2];
+        if (p.gauss) {
+            // rsample of the squashed Gaussian (model/policy.py:58-66) with the Philox stream of the policy draw,
+            // then the box clip of take_action (agent/sac_pa.py:111); p.act.noise_mode is RPO_NOISE_NONE
+            const rpo_u4 u = rpo_philox(p.act.seed, p.act.env_id_base + (uint32_t)i, (uint32_t)t, RPO_STREAM_POLICY,
+                                        (uint32_t)p.step.ctrl[RPO_CTRL_UPDATES]);
+            ap = rpo_head_dev::gauss_head_row(ap, lds.out[tid * 2 + 1], rpo_normal(u.x, u.y), p.scale, p.base,
+                                              p.act.box_lo, p.act.box_hi, 0, nullptr);
+        }
+        int k;
+        const float2 a = ENV::project(p.act, c, lds.in_s + tid * kInS, i, ap, eps_t, t, k);
+        iters_f = (float)k;
+        reinterpret_cast<float2*>(p.act.action)[i] = a;
+        const long long ring_base = p.step.rows ? (t % p.step.cap_steps) * (long long)n : 0;
+        ENV::lane(p.step, c, i, lds.in_s + tid * kInS, a, ring_base, st);
     }
     if (p.step.stats && tid < 64) {                            // only wave 0 holds data: wave reduction, lane 0 adds
         float* srow = rpo_stats_row(p.step.stats, p.step.stats_cap, t);
-        const int slot[kStepStats] = {RPO_STAT_REWARD_SUM, RPO_STAT_EPISODES, RPO_STAT_RETURN_SUM, RPO_STAT_LENGTH_SUM,
-                                      RPO_STAT_MAX_INEQ_SUM, RPO_STAT_MAX_EQ_SUM, RPO_STAT_VIOL_COUNT, RPO_STAT_TERMINATED,
-                                      RPO_STAT_MAX_INEQ_MAX, RPO_STAT_MAX_EQ_MAX};
+        const int slot[kStats] = {RPO_STAT_REWARD_SUM, RPO_STAT_EPISODES, RPO_STAT_RETURN_SUM, RPO_STAT_LENGTH_SUM,
+                                  RPO_STAT_MAX_INEQ_SUM, RPO_STAT_MAX_EQ_SUM, RPO_STAT_VIOL_COUNT, RPO_STAT_TERMINATED,
+                                  RPO_STAT_MAX_INEQ_MAX, RPO_STAT_MAX_EQ_MAX};
 #pragma unroll
-        for (int k = 0; k < kStepStats; ++k) {
+        for (int k = 0; k < kStats; ++k) {
             const float r = (k < 8) ? rpo_wave_sum(st[k]) : rpo_wave_max(st[k]);
             if (tid == 0) {
                 if (k < 8) { if (r != 0.0f) atomicAdd(srow + slot[k], r); }
@@ -88,6 +161,36 @@ __global__ __launch_bounds__(kFwdThreads) void cart_ddpg_rollout_kernel(RolloutA
         if (tid == 0 && it != 0.0f) atomicAdd(srow + RPO_STAT_PROJ_ITERS, it);
     }
     rpo_step_epilogue(p.step.ctrl, t, p.step.stats, p.step.stats_cap);
+}
+
+template <class ENV>
+int launch_rollout(const RolloutArgs<ENV>& args, const typename ENV::Consts& c, int n_envs, void* stream) {
+    // 64 lanes per workgroup once that still fills the chip: the 128 KB hidden-layer matrix is streamed once per
+    // workgroup, so wider tiles cut the L2 traffic 4x (RPO_ROLLOUT_WIDE=0/1 overrides the size rule)
+    const char* wide_env = getenv("RPO_ROLLOUT_WIDE");
+    const int E = args.actor.E;
+    const bool wide = E == 128 && (wide_env ? atoi(wide_env) != 0 : n_envs >= 64 * 192);
+    if (E == 128 && wide) {
+        hipLaunchKernelGGL((rollout_kernel<ENV, 128, 256, 4>), dim3((n_envs + 63) / 64), dim3(kFwdThreads), 0,
+                           (hipStream_t)stream, args, c);
+    } else if (E == 128) {
+        hipLaunchKernelGGL((rollout_kernel<ENV, 128, 256, 1>), dim3((n_envs + 15) / 16), dim3(kFwdThreads), 0,
+                           (hipStream_t)stream, args, c);
+    } else if (E == 256) {
+        hipLaunchKernelGGL((rollout_kernel<ENV, 256, 256, 1>), dim3((n_envs + 15) / 16), dim3(kFwdThreads), 0,
+                           (hipStream_t)stream, args, c);
+    } else {
+        return RPO_ERR_ARG;
+    }
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int check_actor(const Mlp& actor, int obs_dim, int gauss) {
+    if (actor.S != obs_dim || actor.A != 0 || actor.n_out != (gauss ? 2 : 1) || actor.cat || actor.H != 256 || !actor.Ws ||
+        !actor.W0 || !actor.W1 || (gauss && !actor.W1b))
+        return RPO_ERR_ARG;
+    return 0;
 }
 
 // ----------------------------------------------------------------------------------------------- critic forward
@@ -197,47 +300,54 @@ __global__ __launch_bounds__(kFwdThreads) void cart_ddpg_critic_forward_kernel(C
 
 extern "C" {
 
-int rpo_cartsafe_ddpg_rollout(const rpo_mlp* actor_host, float scale, float base, int n_envs, float* state,
-                              float* action, int* ep_len, float* ep_ret, unsigned* ep_count, float* rows,
-                              long long cap_steps, float* stats, int stats_cap, long long* ctrl, int noise_mode,
-                              float eps_start, float eps_end, float eps_decay, float box_lo, float box_hi, int max_steps,
-                              float corr_lr, float corr_eps, float corr_momentum, const float* consts_host, int partial,
-                              int max_episode_steps, int auto_reset, float viol_thresh, unsigned long long seed,
-                              unsigned env_id_base, void* stream) {
+int rpo_cartsafe_rollout(const rpo_mlp* actor_host, int gauss, float scale, float base, int n_envs, float* state,
+                         float* action, int* ep_len, float* ep_ret, unsigned* ep_count, float* rows, long long cap_steps,
+                         float* stats, int stats_cap, long long* ctrl, int noise_mode, float eps_start, float eps_end,
+                         float eps_decay, float box_lo, float box_hi, int max_steps, float corr_lr, float corr_eps,
+                         float corr_momentum, const float* consts_host, int partial, int max_episode_steps,
+                         int auto_reset, float viol_thresh, unsigned long long seed, unsigned env_id_base, void* stream) {
     if (!actor_host) return RPO_ERR_NULL;
     if (n_envs <= 0 || max_episode_steps <= 0 || max_steps < 0) return RPO_ERR_ARG;
     if (noise_mode != RPO_NOISE_NONE && noise_mode != RPO_NOISE_PHILOX && noise_mode != RPO_NOISE_CLIP_ONLY) return RPO_ERR_ARG;
     if (!state || !action || !ep_len || !ep_ret || !ep_count || !ctrl) return RPO_ERR_NULL;
-    if (rows && cap_steps <= 0) return RPO_ERR_ARG;
-    if (stats && stats_cap <= 0) return RPO_ERR_ARG;
-    const Mlp actor = to_dev(actor_host);
-    if (actor.S != 6 || actor.A != 0 || actor.n_out != 1 || actor.cat || actor.H != 256 || !actor.Ws || !actor.W0) return RPO_ERR_ARG;
+    if ((rows && cap_steps <= 0) || (stats && stats_cap <= 0)) return RPO_ERR_ARG;
+    RolloutArgs<CartEnv> args{};
+    args.actor = to_dev(actor_host);
+    if (int e = check_actor(args.actor, 6, gauss)) return e;
     CartConsts c;
     if (int e = load_consts(c, consts_host, partial)) return e;
-    RolloutArgs args{};
-    args.actor = actor; args.scale = scale; args.base = base;
-    args.act = ActArgs{n_envs, nullptr, nullptr, action, nullptr, noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi,
-                       max_steps, corr_lr, corr_eps, corr_momentum, (uint64_t)seed, (uint32_t)env_id_base, ctrl, stats, stats_cap};
-    args.step = StepArgs{n_envs, state, action, ep_len, ep_ret, ep_count, rows, cap_steps, stats, stats_cap, ctrl,
-                         max_episode_steps, auto_reset, viol_thresh, (uint64_t)seed, (uint32_t)env_id_base, 0};
-    // 64 lanes per workgroup once that still fills the chip: the 128 KB hidden-layer matrix is streamed once per
-    // workgroup, so wider tiles cut the L2 traffic 4x (RPO_ROLLOUT_WIDE=0/1 overrides the size rule)
-    const char* wide_env = getenv("RPO_ROLLOUT_WIDE");
-    const bool wide = actor.E == 128 && (wide_env ? atoi(wide_env) != 0 : n_envs >= 64 * 192);
-    if (actor.E == 128 && wide) {
-        hipLaunchKernelGGL((cart_ddpg_rollout_kernel<128, 256, 4>), dim3((n_envs + 63) / 64), dim3(kFwdThreads), 0,
-                           (hipStream_t)stream, args, c);
-    } else if (actor.E == 128) {
-        hipLaunchKernelGGL((cart_ddpg_rollout_kernel<128, 256, 1>), dim3((n_envs + 15) / 16), dim3(kFwdThreads), 0,
-                           (hipStream_t)stream, args, c);
-    } else if (actor.E == 256) {
-        hipLaunchKernelGGL((cart_ddpg_rollout_kernel<256, 256, 1>), dim3((n_envs + 15) / 16), dim3(kFwdThreads), 0,
-                           (hipStream_t)stream, args, c);
-    } else {
-        return RPO_ERR_ARG;
-    }
-    RPO_LAUNCH_CHECK();
-    return 0;
+    args.scale = scale; args.base = base; args.gauss = gauss;
+    args.act = rpo_cart_dev::ActArgs{n_envs, nullptr, nullptr, action, nullptr, noise_mode, eps_start, eps_end, eps_decay,
+                                     box_lo, box_hi, max_steps, corr_lr, corr_eps, corr_momentum, (uint64_t)seed,
+                                     (uint32_t)env_id_base, ctrl, stats, stats_cap};
+    args.step = rpo_cart_dev::StepArgs{n_envs, state, action, ep_len, ep_ret, ep_count, rows, cap_steps, stats, stats_cap,
+                                       ctrl, max_episode_steps, auto_reset, viol_thresh, (uint64_t)seed,
+                                       (uint32_t)env_id_base, 0};
+    return launch_rollout<CartEnv>(args, c, n_envs, stream);
+}
+
+int rpo_pendulum_rollout(const rpo_mlp* actor_host, int gauss, float scale, float base, int n_envs, float* internal,
+                         float* obs, float* action, int* ep_len, float* ep_ret, unsigned* ep_count, float* rows,
+                         long long cap_steps, float* stats, int stats_cap, long long* ctrl, int noise_mode,
+                         float eps_start, float eps_end, float eps_decay, float box_lo, float box_hi, int max_steps,
+                         float corr_lr, float corr_eps, float corr_momentum, int max_episode_steps, int auto_reset,
+                         float viol_thresh, unsigned long long seed, unsigned env_id_base, void* stream) {
+    if (!actor_host) return RPO_ERR_NULL;
+    if (n_envs <= 0 || max_episode_steps <= 0 || max_steps < 0) return RPO_ERR_ARG;
+    if (noise_mode != RPO_NOISE_NONE && noise_mode != RPO_NOISE_PHILOX && noise_mode != RPO_NOISE_CLIP_ONLY) return RPO_ERR_ARG;
+    if (!internal || !action || !ep_len || !ep_ret || !ep_count || !ctrl) return RPO_ERR_NULL;
+    if ((rows && cap_steps <= 0) || (stats && stats_cap <= 0)) return RPO_ERR_ARG;
+    RolloutArgs<PendEnv> args{};
+    args.actor = to_dev(actor_host);
+    if (int e = check_actor(args.actor, 5, gauss)) return e;
+    args.scale = scale; args.base = base; args.gauss = gauss;
+    args.act = rpo_pend_dev::ActArgs{n_envs, nullptr, 5, nullptr, nullptr, action, nullptr, noise_mode, eps_start, eps_end,
+                                     eps_decay, box_lo, box_hi, max_steps, corr_lr, corr_eps, corr_momentum, (uint64_t)seed,
+                                     (uint32_t)env_id_base, ctrl, stats, stats_cap};
+    args.step = rpo_pend_dev::StepArgs{n_envs, internal, obs, action, ep_len, ep_ret, ep_count, rows, cap_steps, stats,
+                                       stats_cap, ctrl, max_episode_steps, auto_reset, viol_thresh, (uint64_t)seed,
+                                       (uint32_t)env_id_base};
+    return launch_rollout<PendEnv>(args, PendEnv::Consts{0}, n_envs, stream);
 }
 
 int rpo_cartsafe_ddpg_critic_forward(const rpo_mlp* actor_target_host, const rpo_mlp* critic_target_host,

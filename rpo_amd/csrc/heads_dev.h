@@ -1,0 +1,22 @@
+// Policy-head arithmetic shared by the head kernels (mlp.hip) and the fused rollout pipelines (fused.hip).
+#pragma once
+#include "common.h"
+
+namespace rpo_head_dev {
+
+constexpr float kLogSigMin = -23.0f, kLogSigMax = -2.0f, kHalfLog2Pi = 0.9189385332046727f;   // model/policy.py:6-7
+
+// Squashed-Gaussian head (GaussianSharedPolicy.forward, model/policy.py:53-66, + the clip of PDSAC_PA.take_action,
+// agent/sac_pa.py:111) for one row: raw = (mean, log-std head output), e = the N(0,1) draw of rsample.
+__device__ __forceinline__ float gauss_head_row(float raw_mean, float raw_ls, float e, float scale, float base, float lo,
+                                                float hi, int deterministic, float* logp) {
+    RPO_FP_STRICT
+    const float ls = fminf(fmaxf(raw_ls - 3.0f, kLogSigMin), kLogSigMax);
+    const float x = raw_mean + e * expf(ls);
+    const float y = tanhf(x);
+    if (logp) *logp = -0.5f * e * e - ls - kHalfLog2Pi - logf(scale * (1.0f - y * y) + 1e-6f);
+    const float a = deterministic ? scale * tanhf(raw_mean) + base : scale * y + base;
+    return fminf(fmaxf(a, lo), hi);
+}
+
+}  // namespace rpo_head_dev

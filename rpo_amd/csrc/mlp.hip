@@ -14,6 +14,7 @@
 //   backward  dx0[r][e] = sum_j dh[r][j] W0[j][e]  N-contiguous: a float4 along e serves 4 interleaved output tiles
 //             (tile c, column n <-> e = 4n + c) that share the A operand;
 //   weights   dW0[j][e] = sum_b dh[b][j] x1[b][e]  both operands contiguous in their M / N index.
+#include "heads_dev.h"
 #include "mlp_tile.h"
 
 namespace {
@@ -365,7 +366,8 @@ __global__ __launch_bounds__(RPO_BLOCK) void tanh_box_bwd_kernel(int n, const fl
 
 // Squashed-Gaussian head (GaussianSharedPolicy.forward, model/policy.py:53-66, + the clip of PDSAC_PA.take_action,
 // agent/sac_pa.py:111): raw = (mean, log-std head output); eps = the standard-normal draw of rsample.
-constexpr float kLogSigMin = -23.0f, kLogSigMax = -2.0f, kHalfLog2Pi = 0.9189385332046727f;
+using rpo_head_dev::kLogSigMin;
+using rpo_head_dev::kLogSigMax;
 
 __global__ __launch_bounds__(RPO_BLOCK) void gauss_head_kernel(int n, const float* __restrict__ raw,
                                                                const float* __restrict__ eps, float scale, float base,
@@ -373,13 +375,9 @@ __global__ __launch_bounds__(RPO_BLOCK) void gauss_head_kernel(int n, const floa
                                                                float* __restrict__ ap_out, float* __restrict__ logp_out) {
     for (int i = blockIdx.x * RPO_BLOCK + threadIdx.x; i < n; i += gridDim.x * RPO_BLOCK) {
         const float2 r = reinterpret_cast<const float2*>(raw)[i];
-        const float ls = fminf(fmaxf(r.y - 3.0f, kLogSigMin), kLogSigMax);
-        const float e = eps[i];
-        const float x = r.x + e * expf(ls);
-        const float y = tanhf(x);
-        if (logp_out) logp_out[i] = -0.5f * e * e - ls - kHalfLog2Pi - logf(scale * (1.0f - y * y) + 1e-6f);
-        const float a = deterministic ? scale * tanhf(r.x) + base : scale * y + base;
-        ap_out[i] = fminf(fmaxf(a, lo), hi);
+        float lp;
+        ap_out[i] = rpo_head_dev::gauss_head_row(r.x, r.y, eps[i], scale, base, lo, hi, deterministic, &lp);
+        if (logp_out) logp_out[i] = lp;
     }
 }
 

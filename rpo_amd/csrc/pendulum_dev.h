@@ -1,0 +1,199 @@
+// Device-side pieces of SpringPendulum-v0 shared by pendulum.hip and the fused pipelines (fused.hip).
+#pragma once
+#include "common.h"
+
+namespace rpo_pend_dev {
+
+// pendulum.py:15-29
+constexpr float kMaxSpeed = 8.0f, kMaxTorque = 6.0f, kMaxSum = 32.0f, kDt = 0.05f, kG = 10.0f, kM = 0.5f;
+constexpr float kK = 1.0f, kL0 = 1.0f, kMDt = 10.0f;   // m / dt
+constexpr float kPi = 3.14159265358979323846f, kTwoPi = 6.28318530717958647692f;
+constexpr float kThetaLim = 0.26179938779914943654f;   // pi / 12
+// reset box, pendulum.py:131-132 (float32 arrays in the reference)
+__device__ constexpr float kResetLo[4] = {-0.26179938779914943654f, -1.0f, 0.95f, -0.05f};
+__device__ constexpr float kResetHi[4] = {0.26179938779914943654f, 1.0f, 1.05f, 0.05f};
+
+struct Eq {   // set_eq, pendulum.py:264-288
+    float C_p, C_o, C_o_inv, b;
+};
+
+__device__ __forceinline__ Eq set_eq(float cos_t, float sin_t, float thdot, float l, float ldot) {
+    RPO_FP_STRICT
+    Eq e;
+    e.C_p = sin_t;   // fx is the basic action (pendulum.py:48,275-278)
+    e.C_o = cos_t;
+    e.C_o_inv = 1.0f / cos_t;
+    e.b = -kMDt * ldot - (l * kM * thdot * thdot - kK * (l - kL0) - kM * kG * cos_t);   // :287
+    return e;
+}
+
+__device__ __forceinline__ void reset_internal(float (&s)[4], uint64_t seed, uint32_t env_id, uint32_t episode) {
+    RPO_FP_STRICT
+    const rpo_u4 r = rpo_philox(seed, env_id, episode, RPO_STREAM_RESET);
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = kResetLo[k] + rpo_u01(w[k]) * (kResetHi[k] - kResetLo[k]);
+}
+
+__device__ __forceinline__ void store_obs(float* __restrict__ o, float cs, float sn, float thdot, float l, float ldot) {
+    o[0] = cs; o[1] = sn; o[2] = thdot; o[3] = l; o[4] = ldot;
+}
+
+struct StepArgs {
+    int n;
+    float* internal;
+    float* obs;
+    const float* action;
+    int* ep_len;
+    float* ep_ret;
+    unsigned* ep_count;
+    float* rows;
+    long long cap_steps;
+    float* stats;
+    int stats_cap;
+    long long* ctrl;
+    int max_episode_steps;
+    int auto_reset;
+    float viol_thresh;
+    uint64_t seed;
+    uint32_t env_id_base;
+};
+
+constexpr int kStepStats = 10;
+
+// One lane's step: dynamics, violations, TimeLimit, statistics, auto-reset (pendulum.py:80-128 + the bookkeeping of
+// rpo_ddpg.py:120-145).  `row` gets the 4 float4 chunks of the transition row, `ns` / (ncs, nsn) the state and
+// observation the lane continues from.
+__device__ __forceinline__ void pend_lane(const StepArgs& p, int i, float4 s, float2 a, float (&ns)[4], float& ncs, float& nsn,
+                                          float4 (&row)[4], float (&st)[kStepStats]) {
+    RPO_FP_STRICT
+    const float th = s.x, thdot = s.y, l = s.z, ldot = s.w;
+    float sn, cs;
+    sincosf(th, &sn, &cs);
+
+    // violations of the PRE-step observation and UN-clipped action (pendulum.py:128,313-321)
+    const Eq e = set_eq(cs, sn, thdot, l, ldot);
+    const float h = e.b - (a.x * e.C_p + a.y * e.C_o);                       // eq_resid :298-300
+    const float gi = fmaxf(a.x * a.x + a.y * a.y - kMaxSum, 0.0f);           // ineq_dist :302-311
+    const float max_eq = fabsf(h);
+
+    // dynamics, pendulum.py:85-124
+    const float fx = fminf(fmaxf(a.x, -kMaxTorque), kMaxTorque), fy = fminf(fmaxf(a.y, -kMaxTorque), kMaxTorque);
+    const float fth = -fy * sn + fx * cs;
+    const float fl = fy * cs + fx * sn;
+    float an = fmodf(th + kPi, kTwoPi);                                      // angle_normalize :367-368
+    if (an < 0.0f) an += kTwoPi;
+    const float costs = fabsf(an - kPi);
+    const float thacc = (fth - kM * (kG * sn + 2.0f * ldot * thdot)) / (l * kM);
+    const float lacc = (fl - kM * kG * cs + kM * l * thdot * thdot - kK * (l - kL0)) / kM;
+    float nthdot = thdot + thacc * kDt;
+    const float nldot = ldot + lacc * kDt;
+    const float nth = th + nthdot * kDt;                                     // semi-implicit in theta :119
+    const float nl = l + ldot * kDt;                                         // explicit in l :120
+    nthdot = fminf(fmaxf(nthdot, -kMaxSpeed), kMaxSpeed);
+    const bool terminated = nl <= 0.5f || nl >= 1.5f || nth >= kThetaLim || nth <= -kThetaLim;   // :124
+    const float reward = 1.0f / (100.0f * costs + 1.0f);
+    const int len = p.ep_len[i] + 1;
+    const bool done = terminated || len >= p.max_episode_steps;
+    const float ret = p.ep_ret[i] + reward;
+    sincosf(nth, &nsn, &ncs);
+
+    row[0] = make_float4(cs, sn, thdot, l);
+    row[1] = make_float4(ldot, a.x, a.y, ncs);
+    row[2] = make_float4(nsn, nthdot, nl, nldot);
+    row[3] = make_float4(reward, done ? 1.0f : 0.0f, h, gi);
+    st[0] += reward;
+    st[4] += gi;
+    st[5] += max_eq;
+    st[6] += (fmaxf(gi, max_eq) > p.viol_thresh) ? 1.0f : 0.0f;
+    st[8] = fmaxf(st[8], gi);
+    st[9] = fmaxf(st[9], max_eq);
+    if (done) {
+        st[1] += 1.0f;
+        st[2] += ret;
+        st[3] += (float)len;
+        st[7] += terminated ? 1.0f : 0.0f;
+    }
+    ns[0] = nth; ns[1] = nthdot; ns[2] = nl; ns[3] = nldot;
+    if (done && p.auto_reset) {
+        const unsigned ep = p.ep_count[i] + 1u;
+        p.ep_count[i] = ep;
+        reset_internal(ns, p.seed, p.env_id_base + (uint32_t)i, ep);
+        sincosf(ns[0], &nsn, &ncs);
+        p.ep_len[i] = 0;
+        p.ep_ret[i] = 0.0f;
+    } else {
+        p.ep_len[i] = len;
+        p.ep_ret[i] = ret;
+    }
+}
+
+// ------------------------------------------------------------------------------- explore + complete + project
+struct ActArgs {
+    int n;
+    const float* obs;
+    int obs_stride;
+    const float* ap_raw;
+    const float* noise;
+    float* action;
+    int* iters;
+    int noise_mode;
+    float eps_start, eps_end, eps_decay, box_lo, box_hi;
+    int max_steps;
+    float corr_lr, corr_eps, corr_momentum;
+    uint64_t seed;
+    uint32_t env_id_base;
+    const long long* ctrl;
+    float* stats;
+    int stats_cap;
+};
+
+// ineq_partial_grad for one row, pendulum.py:331-343 (B = 1 semantics)
+__device__ __forceinline__ void ipg_row(const Eq& e, float ax, float ay, float& gx, float& gy) {
+    RPO_FP_STRICT
+    const float Gx = 2.0f * ax, Gy = 2.0f * ay;                                  // set_ineq :296
+    const float dgp = Gx - Gy * (e.C_o_inv * e.C_p);                             // :334-335
+    const float bgp = kMaxSum - (e.b * e.C_o_inv) * Gy;                          // :336
+    const float bm = ax * dgp - bgp;                                             // :337
+    gx = (bm > 0.0f) ? dgp : 0.0f;                                               // :339
+    gy = -(gx * e.C_p) * e.C_o_inv;                                              // :342
+}
+
+// Exploration + complete_partial (pendulum.py:256-262) + grad_steps with the row-wise ineq_partial_grad
+// (pendulum.py:331-343 as evaluated for B = 1) for one lane whose observation is o[0..4].
+__device__ __forceinline__ float2 pend_explore_project(const ActArgs& p, const float* o, int i, float ap_in, float eps_t,
+                                                       long long t, int& iters) {
+    RPO_FP_STRICT
+    const Eq e = set_eq(o[0], o[1], o[2], o[3], o[4]);
+    float ax = (p.noise_mode == RPO_NOISE_UNIFORM) ? 0.0f : ap_in;
+    if (p.noise_mode == RPO_NOISE_EXPLICIT) {
+        ax = fminf(fmaxf(ax + eps_t * p.noise[i], p.box_lo), p.box_hi);
+    } else if (p.noise_mode == RPO_NOISE_PHILOX) {
+        const rpo_u4 r = rpo_philox(p.seed, p.env_id_base + (uint32_t)i, (uint32_t)t, RPO_STREAM_ACT);
+        ax = fminf(fmaxf(ax + eps_t * rpo_normal(r.x, r.y), p.box_lo), p.box_hi);
+    } else if (p.noise_mode == RPO_NOISE_UNIFORM) {
+        const rpo_u4 r = rpo_philox(p.seed, p.env_id_base + (uint32_t)i, (uint32_t)t, RPO_STREAM_ACT);
+        const float scale = (p.box_hi - p.box_lo) * 0.5f;
+        ax = scale * (2.0f * rpo_u01(r.x) - 1.0f) + (p.box_lo + scale);
+    } else if (p.noise_mode == RPO_NOISE_CLIP_ONLY) {
+        ax = fminf(fmaxf(ax, p.box_lo), p.box_hi);
+    }
+    float ay = (e.b - ax * e.C_p) * e.C_o_inv;                               // complete_partial :256-262
+    float old_x = 0.0f, old_y = 0.0f;
+    int k = 0;
+    for (; k < p.max_steps; ++k) {                                           // grad_steps, rpo_ddpg.py:266-286
+        const float h = e.b - (ax * e.C_p + ay * e.C_o);
+        const float g = ax * ax + ay * ay - kMaxSum;
+        if (k > 0 && !(fabsf(h) > p.corr_eps || g > p.corr_eps)) break;
+        float gx, gy;
+        ipg_row(e, ax, ay, gx, gy);
+        const float sx = p.corr_lr * gx + p.corr_momentum * old_x;
+        const float sy = p.corr_lr * gy + p.corr_momentum * old_y;
+        ax -= sx; ay -= sy;
+        old_x = sx; old_y = sy;
+    }
+    iters = k;
+    return make_float2(ax, ay);
+}
+
+}  // namespace rpo_pend_dev

@@ -172,16 +172,17 @@ class CartSafeKernels(object):
             0 if stats is None else stats.shape[0], _stream()), "rpo_cartsafe_act_project")
 
     # ---- fused pipelines (rpo_amd/csrc/fused.hip) ----------------------------------------------------------------
-    def ddpg_rollout(self, actor_desc, scale, base, internal, action, ep_len, ep_ret, ep_count, rows, cap_steps, stats,
-                     ctrl, noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi, max_steps, corr_lr, corr_eps,
-                     corr_momentum, max_episode_steps, auto_reset, viol_thresh, seed, env_id_base):
+    def rollout(self, actor_desc, gauss, scale, base, internal, obs, action, ep_len, ep_ret, ep_count, rows, cap_steps,
+                stats, ctrl, noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi, max_steps, corr_lr, corr_eps,
+                corr_momentum, max_episode_steps, auto_reset, viol_thresh, seed, env_id_base):
         net = actor_desc.net_struct()
-        check(_lib.load().rpo_cartsafe_ddpg_rollout(
-            ctypes.byref(net), scale, base, internal.shape[0], _p(internal), _p(action), _p(ep_len, torch.int32),
-            _p(ep_ret), _p(ep_count, torch.int32), _p(rows, allow_none=True), cap_steps, _p(stats, allow_none=True),
-            0 if stats is None else stats.shape[0], _p(ctrl, torch.int64), noise_mode, eps_start, eps_end, eps_decay,
-            box_lo, box_hi, max_steps, corr_lr, corr_eps, corr_momentum, self._cptr, self.partial, max_episode_steps,
-            int(auto_reset), viol_thresh, seed, env_id_base, _stream()), "rpo_cartsafe_ddpg_rollout")
+        check(_lib.load().rpo_cartsafe_rollout(
+            ctypes.byref(net), int(gauss), scale, base, internal.shape[0], _p(internal), _p(action),
+            _p(ep_len, torch.int32), _p(ep_ret), _p(ep_count, torch.int32), _p(rows, allow_none=True), cap_steps,
+            _p(stats, allow_none=True), 0 if stats is None else stats.shape[0], _p(ctrl, torch.int64), noise_mode,
+            eps_start, eps_end, eps_decay, box_lo, box_hi, max_steps, corr_lr, corr_eps, corr_momentum, self._cptr,
+            self.partial, max_episode_steps, int(auto_reset), viol_thresh, seed, env_id_base, _stream()),
+            "rpo_cartsafe_rollout")
 
     def ddpg_critic_forward(self, actor_target, critic_target, critic, scale, base, rows, cap_steps, n_envs, batch_out,
                             idx_out, idx_in, seed, salt, ctrl, max_steps, corr_lr, corr_eps, corr_momentum, box_lo, box_hi,
@@ -245,6 +246,17 @@ class PendulumKernels(object):
             max_steps, corr_lr, corr_eps, corr_momentum, seed, env_id_base, _p(ctrl, torch.int64, allow_none=True),
             _p(stats, allow_none=True), 0 if stats is None else stats.shape[0], _stream()),
             "rpo_pendulum_act_project")
+
+    def rollout(self, actor_desc, gauss, scale, base, internal, obs, action, ep_len, ep_ret, ep_count, rows, cap_steps,
+                stats, ctrl, noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi, max_steps, corr_lr, corr_eps,
+                corr_momentum, max_episode_steps, auto_reset, viol_thresh, seed, env_id_base):
+        net = actor_desc.net_struct()
+        check(_lib.load().rpo_pendulum_rollout(
+            ctypes.byref(net), int(gauss), scale, base, internal.shape[0], _p(internal), _p(obs, allow_none=True),
+            _p(action), _p(ep_len, torch.int32), _p(ep_ret), _p(ep_count, torch.int32), _p(rows, allow_none=True),
+            cap_steps, _p(stats, allow_none=True), 0 if stats is None else stats.shape[0], _p(ctrl, torch.int64),
+            noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi, max_steps, corr_lr, corr_eps, corr_momentum,
+            max_episode_steps, int(auto_reset), viol_thresh, seed, env_id_base, _stream()), "rpo_pendulum_rollout")
 
     def project_batchref(self, obs, ap, action, iters_out, max_steps, corr_lr, corr_eps, corr_momentum):
         op, ostride = _row_view(obs, 5)

@@ -179,3 +179,26 @@ def test_wide_rollout_tiles_are_bitwise_identical(hip, monkeypatch):
     f.forward("actor", s, None, out_w)
     f.forward("actor", s[:4096], None, out_n)
     assert torch.equal(out_w[:4096], out_n)
+
+
+@pytest.mark.parametrize("n_envs", [100, 12500], ids=["16_lane_tiles", "64_lane_tiles"])
+@pytest.mark.parametrize("algo,envname", CASES)
+def test_rollout_pipeline_equals_single_stage_launches(hip, algo, envname, n_envs, monkeypatch):
+    """rpo_<env>_rollout (actor -> head -> complete -> project -> step -> scatter in one launch) reproduces the
+    sequence rpo_mlp_forward (+ rpo_philox_normal + rpo_gauss_head) + rpo_<env>_act_project + rpo_<env>_step bit for
+    bit, for both envs and both policy heads; n_envs is ragged against both tile heights."""
+    dev = torch.device("cuda")
+    iters = 10
+    monkeypatch.setenv("RPO_FUSED_ROLLOUT", "0")
+    a = _run(algo, envname, hip, dev, iters, n_envs, use_graph=False)
+    assert not a._rollout_pipeline
+    monkeypatch.setenv("RPO_FUSED_ROLLOUT", "1")
+    b = _run(algo, envname, hip, dev, iters, n_envs, use_graph=False)
+    assert b._rollout_pipeline
+    assert torch.equal(a.vec.internal, b.vec.internal) and torch.equal(a.vec.obs, b.vec.obs)
+    assert torch.equal(a.vec.action, b.vec.action)
+    assert torch.equal(a.buffer.rows, b.buffer.rows)
+    assert torch.equal(a.vec.ep_len, b.vec.ep_len) and torch.equal(a.vec.ep_count, b.vec.ep_count)
+    assert torch.equal(a.agent.flat.data, b.agent.flat.data)
+    np.testing.assert_allclose(hip.reduce_stats(a.vec.stats[:iters]).cpu().numpy(),
+                               hip.reduce_stats(b.vec.stats[:iters]).cpu().numpy(), rtol=1e-5, atol=1e-9)
