@@ -1,0 +1,154 @@
+"""EVOPF-v0 cross-check fixtures: the REFERENCE's rpo/env/electrical_grid/evopf.py run in this container on top of the
+data-only pypower stand-in of ref_harness (IEEE-14 tables and makeYbus restated in oracle/evopf.py).
+
+    python tests/golden/make_evopf_golden.py          # build container only
+
+What this pins: the restatement of evopf.py's own logic (index bookkeeping, eq_resid / eq_jac / ineq_resid,
+ineq_partial_grad, PFFunction forward + backward, Battery, step, update) and of rpo_ddpg.py's process_action on it.
+What it cannot pin: pypower's case data and Ybus -- EVOPF parity stays "unpinned" (oracle/evopf.py header).
+Every random draw the reference takes from a global RNG is replaced by explicit inputs stored in the fixture.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import ref_harness  # noqa: E402
+
+torch.set_num_threads(1)
+torch.manual_seed(77)
+torch.set_default_dtype(torch.float32)                       # scripts/evopf_exp.py:13
+REF = ref_harness.load_reference_evopf()
+from oracle import evopf as oe  # noqa: E402  (only its Philox episode data, injected into the reference's loaders)
+RNG = np.random.RandomState(14)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print("wrote %s (%d arrays, %.1f KB)" % (name, len(arrays), os.path.getsize(path) / 1024))
+
+
+def t32(x):
+    return torch.tensor(np.asarray(x), dtype=torch.float32)
+
+
+def states(n, seed=5):
+    """Observations [n, 57] of random hours of random episodes (build's Philox episode data), random state of charge."""
+    ids = np.arange(n)
+    hours = RNG.randint(0, 24, size=n)
+    s = np.concatenate([oe.episode_demand(seed, ids, 3, hours), RNG.uniform(0.1, 0.8, size=(n, 5)),
+                        oe.episode_price(seed, ids, 3, hours)], axis=1)
+    s[0, 28:33] = [0.1, 0.8, 0.2, 0.75, 0.15]              # bounds of the battery box active
+    return s.astype(np.float32)
+
+
+def partials(env, s):
+    low, high = env.update(t32(s))
+    u = RNG.uniform(0.05, 0.95, size=low.shape)
+    ap = low + u * (high - low)
+    ap[:, 4:9] = RNG.uniform(1.0, 1.06, size=(s.shape[0], 5))     # generator voltages near nominal
+    ap[:, :4] = RNG.uniform(0.0, 0.6, size=(s.shape[0], 4))
+    return ap.astype(np.float32)
+
+
+def gen_env():
+    np.random.seed(0)
+    env = REF.EVOPFEnv()
+    n = 12
+    S = states(n)
+    AP = partials(env, S)
+    low, high = env.update(t32(S))
+    # equation solver, one row at a time (== the reference's rollout calls), with its backward
+    A, DZ, DY = [], [], RNG.randn(n, 43).astype(np.float32)
+    for r in range(n):
+        ap = t32(AP[r:r + 1]).requires_grad_(True)
+        a = env.complete_partial(t32(S[r:r + 1]), ap)
+        a.backward(t32(DY[r:r + 1]))
+        A.append(a.detach().numpy()[0])
+        DZ.append(ap.grad.numpy()[0])
+    A = np.array(A)
+    a_batch = env.complete_partial(t32(S), t32(AP)).detach().numpy()     # batch call: batch-wide Newton stop test
+    # constraint functions on perturbed (infeasible) actions
+    AX = (A + 0.02 * RNG.randn(*A.shape)).astype(np.float32)
+    AX[:, 38:] = np.clip(AX[:, 38:] * 3, -0.3, 0.3)
+    eq = env.eq_resid(t32(S), t32(AX)).numpy()
+    ineq = env.ineq_resid(t32(S), t32(AX)).numpy()
+    jac = env.eq_jac(t32(AX)).numpy()
+    ipg = env.ineq_partial_grad(t32(S), t32(AX)).numpy()
+    ipg_a = env.ineq_partial_grad(t32(S), t32(A)).numpy()
+    save("evopf_env", Yr=env.Ybusr.numpy(), Yi=env.Ybusi.numpy(), action_low=env.action_space.low,
+         action_high=env.action_space.high, partial_actions=env.partial_actions, partial_vars=env.partial_vars,
+         other_vars=env.other_vars, S=S, AP=AP, box_low=low, box_high=high, A=A, A_batch=a_batch, DY=DY, DZ=np.array(DZ),
+         AX=AX, eq_resid=eq, ineq_resid=ineq, eq_jac=jac, ineq_partial_grad=ipg, ineq_partial_grad_feasible=ipg_a,
+         obj=env.obj_fn(AX).numpy())
+
+
+def gen_step():
+    """env.step with the loaders' caches injected (demand.py:35-44, price.py:29-38 draw them from np.random)."""
+    np.random.seed(1)
+    env = REF.EVOPFEnv()
+    seed, n = 9, 10
+    ids = np.arange(n)
+    out = dict(seed=seed, hour=[], soc=[], action=[], state=[], next_state=[], reward=[], done=[], eq_viol=[], ineq_viol=[])
+    for r in range(n):
+        hour = [0, 5, 22, 23, 11, 1, 17, 23, 8, 3][r]
+        env.reset()
+        env.data.cache = np.stack([oe.episode_demand(seed, ids[r:r + 1], 2, h)[0] for h in range(24)])
+        day = np.concatenate([oe.episode_price(seed, ids[r:r + 1], 2, 0)[0], np.zeros(24)]) * 100.0   # before /= genbase
+        env.p_data.cache = day
+        env.data.counter = env.p_data.counter = hour + 1
+        soc = RNG.uniform(0.1, 0.8, size=5)
+        if r == 3:
+            soc[:] = [0.1, 0.8, 0.79, 0.12, 0.45]
+        state = np.concatenate([env.data.cache[hour], soc, day[hour:hour + 24] / 100.0])
+        env.state = state.copy()
+        env.evs.state = state[28:].copy()
+        ap = partials(env, state[None].astype(np.float32))
+        a = env.complete_partial(t32(state[None]), t32(ap)).numpy()[0]
+        a[38:] += RNG.uniform(-0.15, 0.15, size=5).astype(np.float32)       # exercise the battery clip
+        nxt, reward, done, info = env.step(a.copy())
+        for k, v in dict(hour=hour, soc=soc, action=a, state=state, next_state=nxt, reward=float(np.asarray(reward).reshape(-1)[0]),
+                         done=done, eq_viol=info["eq_viol"][0], ineq_viol=info["ineq_viol"][0]).items():
+            out[k].append(v)
+    save("evopf_step", **out)
+
+
+def gen_project():
+    """process_action of RPODDPG (rpo_ddpg.py:72-77,266-305) with the hyper-parameters of scripts/evopf_exp.py:29-31,
+    one row at a time; corr_lr is also raised so that the projection visibly moves the action."""
+    np.random.seed(2)
+    env = REF.EVOPFEnv()
+    out = {}
+    S = states(8, seed=21)
+    AP = partials(env, S)
+    low, high = env.update(t32(S))
+    AP[:, 9:] = (high[:, 9:] + RNG.uniform(0.0, 0.1, size=(8, 5))).astype(np.float32)   # violates the charge bound
+    AP[:4, 4:9] = 1.07                                                                   # violates vmax
+    for tag, lr in (("script", 1e-4), ("large", 5e-4)):
+        logger = REF.Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=10, name="x")
+        tr = REF.RPODDPG(env, "/tmp/rpo_evopf_golden", name="x", logger=logger, batch_size=256, max_steps=10, warmup=0,
+                         lr_dual=2e-2, corr_lr=lr, eps=0.0001, eps_start=0.0001, eps_epoch=20000, eval_lr=lr,
+                         eval_steps=50, grad_eps=0.02, corr_momentum=0.0, policy_fre=4, ex_action_dim=1, gamma=0.95,
+                         max_epochs=10, capacity=100, clip_thres=0.2, shared_param=False, value_type="cat",
+                         device=torch.device("cpu"))
+        train, evala, iters = [], [], []
+        with torch.no_grad():
+            for r in range(S.shape[0]):
+                train.append(tr.process_action(t32(S[r:r + 1]), t32(AP[r:r + 1])).numpy()[0])
+                a, k = tr.process_action(t32(S[r:r + 1]), t32(AP[r:r + 1]), train=False)
+                evala.append(a.numpy()[0])
+                iters.append(k)
+        out.update({tag + "_lr": lr, tag + "_train": np.array(train), tag + "_eval": np.array(evala),
+                    tag + "_eval_iters": np.array(iters)})
+    save("evopf_project", S=S, AP=AP, **out)
+
+
+if __name__ == "__main__":
+    gen_env()
+    gen_step()
+    gen_project()

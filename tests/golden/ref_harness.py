@@ -147,3 +147,63 @@ def load_reference():
                                RPODDPG=algo.RPODDPG, RPOSAC=algo.RPOSAC, Logger=logger.Logger,
                                ReplayBuffer=buffer.ReplayBuffer)
     return ns
+
+
+def _build_pypower_standin():
+    """Data-only stand-in for the un-vendored ``pypower`` (and an empty ``igraph``, used by render() only) so that the
+    reference's ``rpo/env/electrical_grid/evopf.py`` can be imported here.  The numbers come from ``oracle/evopf.py``
+    (public IEEE-14 tables + the published makeYbus algorithm), therefore fixtures produced through this stand-in
+    cross-check the restatement of evopf.py's OWN logic and nothing about pypower: parity for EVOPF stays unpinned."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from oracle import evopf as oe
+    pp = types.ModuleType("pypower")
+    api = types.ModuleType("pypower.api")
+    idx_bus = types.ModuleType("pypower.idx_bus")
+    idx_gen = types.ModuleType("pypower.idx_gen")
+    ppoption = types.ModuleType("pypower.ppoption")
+    for k, v in dict(BUS_TYPE=1, PD=2, QD=3, GS=4, BS=5, VM=7, VA=8, VMAX=11, VMIN=12).items():
+        setattr(idx_bus, k, v)
+    for k, v in dict(PG=1, QG=2, QMAX=3, QMIN=4, MBASE=6, PMAX=8, PMIN=9).items():
+        setattr(idx_gen, k, v)
+
+    def case14():
+        gen = np.zeros((oe.GEN.shape[0], 21))
+        gen[:, :oe.GEN.shape[1]] = oe.GEN
+        return {"version": "2", "baseMVA": oe.BASE_MVA, "bus": oe.BUS.copy(), "gen": gen, "branch": oe.BRANCH.copy(),
+                "gencost": oe.GENCOST.copy()}
+
+    class _Dense(object):
+        def __init__(self, m):
+            self.m = m
+
+        def todense(self):
+            return np.asmatrix(self.m)
+
+    def makeYbus(base_mva, bus, branch):
+        b, br = bus.copy(), branch.copy()
+        b[:, 0] += 1                      # evopf.py:261-262 passes 0-based numbering
+        br[:, [0, 1]] += 1
+        return _Dense(oe.make_ybus(base_mva, b, br)), None, None
+
+    def _unavailable(*a, **k):
+        raise NotImplementedError("pypower stand-in: data only")
+
+    api.case14, api.makeYbus, api.opf = case14, makeYbus, _unavailable
+    ppoption.ppoption = _unavailable
+    pp.api, pp.idx_bus, pp.idx_gen, pp.ppoption = api, idx_bus, idx_gen, ppoption
+    sys.modules.update({"pypower": pp, "pypower.api": api, "pypower.idx_bus": idx_bus, "pypower.idx_gen": idx_gen,
+                        "pypower.ppoption": ppoption, "igraph": types.ModuleType("igraph")})
+
+
+def load_reference_evopf(ns=None):
+    """Reference EVOPFEnv on the pypower stand-in (see above); returns ``ns`` with ``EVOPFEnv`` added."""
+    ns = ns if ns is not None else load_reference()
+    _build_pypower_standin()
+    sys.path.insert(0, REFERENCE_ROOT)
+    try:
+        eg = importlib.import_module("rpo.env.electrical_grid")
+    finally:
+        sys.path.remove(REFERENCE_ROOT)
+    sys.modules["rpo.env"].EVOPFEnv = eg.EVOPFEnv
+    ns.EVOPFEnv = eg.EVOPFEnv
+    return ns
