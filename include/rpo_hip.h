@@ -53,6 +53,38 @@ extern "C" {
 #define RPO_PEND_ACTION_DIM 2
 #define RPO_PEND_ROW 16
 
+/* EVOPF-v0 (rpo/env/electrical_grid/evopf.py:333-337): observation = pd[14] qd[14] soc[5] price[24]; action = pg[5] qg[5]
+ * vm[14] va[14] pe[5]; 14 basic actions = pg at the 4 PV generators, vm at the 5 generator buses, pe[5] (:292-294). */
+#define RPO_EVOPF_STATE 57
+#define RPO_EVOPF_ACTION 43
+#define RPO_EVOPF_PARTIAL 14
+#define RPO_EVOPF_EQ 28
+#define RPO_EVOPF_INEQ 58
+#define RPO_EVOPF_ROW 248 /* state 57 | action 43 | next_state 57 | reward | done | eq_viol 28 | ineq_viol 58 | pad 3 */
+/* Constants buffer (device, float32) the host fills from its case tables (rpo_amd/env/electrical_grid/case14.py):
+ * Ybus real / imaginary parts row-major (evopf.py:263-266), generator and voltage limits per unit (:251-256), Newton
+ * start values (:299-300), cost coefficients already divided by mean(genbase)^2 and multiplied by genbase^(2|1)
+ * (obj_fn :509-518), the regularised load curve per hour in per unit of baseMVA (demand.py:48-49), (1 - rho) * nominal
+ * load shares and sign(Qd) per bus (demand.py:54-62), the regularised price curve / genbase (price.py:32, evopf.py:57). */
+#define RPO_EVOPF_C_YR 0
+#define RPO_EVOPF_C_YI 196
+#define RPO_EVOPF_C_PMAX 392
+#define RPO_EVOPF_C_PMIN 397
+#define RPO_EVOPF_C_QMAX 402
+#define RPO_EVOPF_C_QMIN 407
+#define RPO_EVOPF_C_VMAX 412
+#define RPO_EVOPF_C_VMIN 426
+#define RPO_EVOPF_C_VM_INIT 440
+#define RPO_EVOPF_C_VA_INIT 454
+#define RPO_EVOPF_C_QUAD 468
+#define RPO_EVOPF_C_LIN 473
+#define RPO_EVOPF_C_CONST 478
+#define RPO_EVOPF_C_PS 480
+#define RPO_EVOPF_C_SHARE 504
+#define RPO_EVOPF_C_QSIGN 518
+#define RPO_EVOPF_C_PRICE 532
+#define RPO_EVOPF_CONSTS_LEN 560
+
 #define RPO_CTRL_LEN 288
 #define RPO_CTRL_T 0        /* vector steps completed */
 #define RPO_CTRL_ARRIVE 1   /* top-level arrival counter of the running *_step launch (always 0 between launches) */
@@ -87,6 +119,8 @@ extern "C" {
 #define RPO_STREAM_ACT 2
 #define RPO_STREAM_SAMPLE 3
 #define RPO_STREAM_POLICY 4
+#define RPO_STREAM_EVOPF_DEMAND 5 /* episode load profile: Dirichlet + power factors (data/demand.py:53-62) */
+#define RPO_STREAM_EVOPF_PRICE 6  /* episode price profile: magnitude + hourly noise   (data/price.py:41-43)  */
 
 int rpo_abi_version(void);
 
@@ -298,6 +332,57 @@ int rpo_mlp_forward(const rpo_mlp* net_host, int n, const float* s, int s_stride
 int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int n, const float* s, int s_stride,
                      const float* a, int a_stride, const float* x0, const float* h1, const float* dout, float* dh,
                      float* dx0, float* da, int param_grads, int first_layer_state_only, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * EVOPF-v0 (rpo_amd/csrc/evopf.hip): one wavefront per env lane / batch row; the lane's 22x22 Newton system and the
+ * 28x28 block of the equality Jacobian are eliminated in LDS.  state [n,57], action [n,43], basic actions [n,14];
+ * consts_dev = the RPO_EVOPF_C_* buffer in device memory; state_stride = floats between consecutive state rows (57 for a
+ * dense matrix, RPO_EVOPF_ROW when the states are columns of gathered replay rows).  The IEEE-14 bus classification is compiled in, like the
+ * reference hard-wires case14 (evopf.py:211,336-337).
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* EVOPFEnv.reset (evopf.py:369-380): hour 0 of episode ep_count[i] (NULL: 0) of lane env_id_base + i; the loaders'
+ * random draws (demand.py:53-62, price.py:41-43) come from Philox(seed; env, episode, RPO_STREAM_EVOPF_*). */
+int rpo_evopf_reset(int n_envs, float* state, int* ep_len, float* ep_ret, const unsigned* ep_count,
+                    const float* consts_dev, unsigned long long seed, unsigned env_id_base, void* stream);
+
+/* EVOPFEnv.step (evopf.py:348-366) + Battery.step (:74-102) + run-loop bookkeeping (rpo_ddpg.py:120-145); same contract
+ * as rpo_cartsafe_step: transition rows [RPO_EVOPF_ROW] scattered into the ring, statistics, ctrl[T] advanced by the
+ * last workgroup, auto-reset.  An episode ends when the loaders run out of data after 24 hours (demand.py:71). */
+int rpo_evopf_step(int n_envs, float* state, const float* action, int* ep_len, float* ep_ret, unsigned* ep_count,
+                   float* rows, long long cap_steps, float* stats, int stats_cap, long long* ctrl, int max_episode_steps,
+                   int auto_reset, float viol_thresh, const float* consts_dev, unsigned long long seed,
+                   unsigned env_id_base, void* stream);
+
+/* take_action's noise + clip to the state-dependent box (agent/ddpg_pa.py:101-112; EVOPFEnv.update evopf.py:769-783)
+ * -> complete_partial = Newton power flow (PFFunction.forward, evopf.py:789-855; newton_tol 1e-5, newton_max_iters 50)
+ * -> grad_steps (rpo_ddpg.py:266-305, corr_mode 0).  Every row carries its own Newton and GRG stop tests (== the
+ * reference's B = 1 rollout calls; on a batch the reference tests the batch maximum, which adds iterations only to
+ * rows that had already met the test).  iters [n] (may be NULL) = GRG iterations.  Noise draw of basic action j:
+ * Philox(seed; env, ctrl[T], RPO_STREAM_ACT, j / 2) normals (x,y) | (z,w); RPO_NOISE_UNIFORM: word j % 4 of block j / 4. */
+int rpo_evopf_act_project(int n, const float* state, int state_stride, const float* ap_raw, const float* noise, float* action, int* iters,
+                          int noise_mode, float eps_start, float eps_end, float eps_decay, int max_steps, float corr_lr,
+                          float corr_eps, float corr_momentum, float newton_tol, int newton_max_iters,
+                          const float* consts_dev, unsigned long long seed, unsigned env_id_base, const long long* ctrl,
+                          float* stats, int stats_cap, void* stream);
+
+/* PFFunction.backward (evopf.py:857-910): grad_ap [n,14] = dL/dz given grad_action [n,43] = dL/dy and the completed
+ * action; the Jacobians are re-evaluated at that action (the reference keeps those of the last Newton point). */
+int rpo_evopf_complete_bwd(int n, const float* action, const float* grad_action, float* grad_ap, const float* consts_dev,
+                           void* stream);
+
+/* eq_resid [n,28] (evopf.py:520-546) and ineq_resid [n,58] (signed, :548-563); either output may be NULL. */
+int rpo_evopf_resid(int n, const float* state, int state_stride, const float* action, float* eq_out, float* ineq_out,
+                    const float* consts_dev, void* stream);
+
+/* ineq_partial_grad [n,43] (evopf.py:596-612): reduced gradient of the number of violated inequalities. */
+int rpo_evopf_ineq_partial_grad(int n, const float* state, int state_stride, const float* action, float* step_out, const float* consts_dev,
+                                void* stream);
+
+/* scale * sum_b sum_j nu_j relu(g_j(s_b, a_b)) accumulated into loss_out, d/d action into grad_action [n,43] (written),
+ * d/d nu accumulated into grad_nu [58] (rpo_ddpg.py:312-319, dual.py:63-65). */
+int rpo_evopf_lagrangian(int n, const float* state, int state_stride, const float* action, const float* nu, float scale, float* loss_out,
+                         float* grad_action, float* grad_nu, const float* consts_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused pipelines of one RPO iteration (rpo_amd/csrc/fused.hip): the row-local stages chained

@@ -166,7 +166,7 @@ class RPODDPG(RPOTrainerBase):
         ap = ag.actor.box_constraint.clip(ap + self._eps_now() * self._noise_b, state)
         actions = self.base_env.complete_partial(state, ap)
         loss = (-ag.critic(state, actions)).mean()
-        return loss + _LagrangianFn.apply(self.kernels, actions, ag.nju.weight)
+        return loss + _LagrangianFn.apply(self.kernels, actions, ag.nju.weight, state)
 
     # ---- optimiser steps (rpo_ddpg.py:178-205) --------------------------------------------------------------
     def _critic_step(self, actor_step):

@@ -149,7 +149,7 @@ class RPOSAC(RPOTrainerBase):
         actions = self.base_env.complete_partial(state, ap)
         q1, q2 = ag.critic(state, actions)
         loss = (ag.alpha * logp - torch.min(q1, q2)).mean()
-        return loss + _LagrangianFn.apply(self.kernels, actions, ag.nju.weight), logp
+        return loss + _LagrangianFn.apply(self.kernels, actions, ag.nju.weight, state), logp
 
     # ---- optimiser steps (rpo_sac.py:181-219) ---------------------------------------------------------------
     def _critic_step(self, actor_step):

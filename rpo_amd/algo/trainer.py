@@ -52,12 +52,12 @@ class _LagrangianFn(torch.autograd.Function):
     """mean_b nu . relu(g(a_b)): loss, d/da and d/dnu from one HIP launch (rpo_*_lagrangian)."""
 
     @staticmethod
-    def forward(ctx, kernels, action, nu):
+    def forward(ctx, kernels, action, nu, state=None):
         n = action.shape[0]
         loss = torch.zeros(1, device=action.device)
         g_a = torch.empty_like(action)
         g_nu = torch.zeros(nu.numel(), device=action.device)
-        kernels.lagrangian(action.contiguous(), nu.reshape(-1).contiguous(), 1.0 / n, loss, g_a, g_nu)
+        kernels.lagrangian(action.contiguous(), nu.reshape(-1).contiguous(), 1.0 / n, loss, g_a, g_nu, obs=state)
         ctx.save_for_backward(g_a, g_nu)
         ctx.nu_shape = nu.shape
         return loss[0]
@@ -65,7 +65,7 @@ class _LagrangianFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         g_a, g_nu = ctx.saved_tensors
-        return None, grad_out * g_a, grad_out * g_nu.view(ctx.nu_shape)
+        return None, grad_out * g_a, grad_out * g_nu.view(ctx.nu_shape), None
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -169,8 +169,9 @@ class RPOTrainerBase(object):
                                           max_episode_steps=self.max_episode_steps, device=device)
         self.buffer = agent.attach_env(self.kernels, self.n_local, self.seed + 7919 * (self.dist.rank + 1), self.vec.ctrl)
         self._batch = torch.zeros(self.batch_size, self.kernels.row_floats, device=device)
-        self._noise_b = torch.zeros(self.batch_size, 1, device=device)
-        self._noise_n = torch.zeros(self.n_local, 1, device=device)
+        P = self.kernels.partial_dim                                    # basic actions per env (1, 1, 14)
+        self._noise_b = torch.zeros(self.batch_size, P, device=device)
+        self._noise_n = torch.zeros(self.n_local, P, device=device)
         self._box_lo, self._box_hi = self.base_env.partial_box
         if use_graph is None:
             use_graph = bool(_env_int("RPO_GRAPH", 1)) and device.type == "cuda"

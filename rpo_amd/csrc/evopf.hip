@@ -1,0 +1,411 @@
+// EVOPF-v0 kernels (reference: rpo/env/electrical_grid/evopf.py, data/demand.py, data/price.py; projection loop of
+// rpo/algo/rpo_ddpg.py:72-77,266-305).  One wavefront per env lane / batch row -- see evopf_dev.h.
+#include "evopf_dev.h"
+
+using namespace rpo_evopf_dev;
+
+namespace {
+
+__device__ __forceinline__ void load_row(float* dst, const float* __restrict__ src, int n) {
+    for (int i = threadIdx.x; i < n; i += RPO_WAVE) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------------- reset
+__global__ __launch_bounds__(RPO_WAVE) void evopf_reset_kernel(int n, float* __restrict__ state, int* __restrict__ ep_len,
+                                                               float* __restrict__ ep_ret,
+                                                               const unsigned* __restrict__ ep_count,
+                                                               const float* __restrict__ consts, uint64_t seed,
+                                                               uint32_t env_id_base) {
+    __shared__ Ws w;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    load_consts(w, consts);
+    sync();
+    episode_obs(w, w.s, seed, env_id_base + (uint32_t)i, ep_count ? ep_count[i] : 0u, 0);
+    if (tid < NE) w.s[2 * NB + tid] = kBInit;
+    sync();
+    for (int k = tid; k < NS; k += RPO_WAVE) state[(size_t)i * NS + k] = w.s[k];
+    if (tid == 0) { ep_len[i] = 0; ep_ret[i] = 0.0f; }
+}
+
+// -------------------------------------------------------------------------------------------------------- step
+struct StepArgs {
+    int n;
+    float* state;
+    const float* action;
+    int* ep_len;
+    float* ep_ret;
+    unsigned* ep_count;
+    float* rows;
+    long long cap_steps;
+    float* stats;
+    int stats_cap;
+    long long* ctrl;
+    int max_episode_steps;
+    int auto_reset;
+    float viol_thresh;
+    const float* consts;
+    uint64_t seed;
+    uint32_t env_id_base;
+};
+
+// EVOPFEnv.step (evopf.py:348-366) + Battery.step (:74-102) + the bookkeeping of the run loop (rpo_ddpg.py:120-145):
+// violations of the pre-step observation, reward, next hour of the episode data, replay scatter, statistics, auto-reset.
+__global__ __launch_bounds__(RPO_WAVE) void evopf_step_kernel(StepArgs p) {
+    RPO_FP_STRICT
+    __shared__ Ws w;
+    __shared__ __align__(16) float row[RPO_EVOPF_ROW];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const long long t = p.ctrl ? p.ctrl[RPO_CTRL_T] : 0;
+    load_consts(w, p.consts);
+    load_row(w.s, p.state + (size_t)i * NS, NS);
+    load_row(w.a, p.action + (size_t)i * NY, NY);
+    sync();
+    flows(w);
+    eq_resid(w);
+    ineq_resid(w);
+    const uint32_t env_id = p.env_id_base + (uint32_t)i;
+    const int len = p.ep_len[i] + 1;                                   // == the loaders' counter (demand.py:69-73)
+    const unsigned ep = p.ep_count[i];
+    const bool data_done = len >= T;
+    const bool done = data_done || len >= p.max_episode_steps;
+
+    // reward = wg * (-obj_fn) + we * (-sum(pe * price)) (evopf.py:350-353,509-518; Battery.step :99-100)
+    float part = 0.0f;
+    if (tid < NG) {
+        const float pg = w.a[PG0 + tid];
+        part = -kWg * (w.c[RPO_EVOPF_C_QUAD + tid] * pg * pg + w.c[RPO_EVOPF_C_LIN + tid] * pg) -
+               kWe * (w.a[PE0 + tid] * w.s[2 * NB + NE]);
+    }
+    const float reward = rpo_wave_sum(part) - kWg * w.c[RPO_EVOPF_C_CONST];
+    const float max_eq = rpo_wave_max(tid < NEQ ? fabsf(w.eq[tid]) : 0.0f);
+    const float max_ineq = rpo_wave_max(tid < NINEQ ? fmaxf(w.ineq[tid], 0.0f) : 0.0f);
+
+    // transition row: state | action | next_state | reward | done | eq_viol | ineq_viol (ReplayBuffer.add, buffer.py:22-29)
+    for (int k = tid; k < NS; k += RPO_WAVE) row[k] = w.s[k];
+    if (tid < NY) row[NS + tid] = w.a[tid];
+    float* nxt = row + NS + NY;
+    episode_obs(w, nxt, p.seed, env_id, ep, len);
+    if (tid < NE) {                                                    // Battery.step :86-97
+        const float soc = w.s[2 * NB + tid];
+        float p_max, p_min;
+        battery_bounds(soc, p_max, p_min);
+        float x = fminf(fmaxf(w.a[PE0 + tid], p_min), p_max);
+        x = x >= 0.0f ? x * kEtaIn : x / kEtaOut;                       // process_action :145-149
+        nxt[2 * NB + tid] = soc + x;
+    }
+    if (tid == 0) { row[2 * NS + NY] = reward; row[2 * NS + NY + 1] = done ? 1.0f : 0.0f; }
+    if (tid < NEQ) row[2 * NS + NY + 2 + tid] = w.eq[tid];
+    if (tid < NINEQ) row[2 * NS + NY + 2 + NEQ + tid] = fmaxf(w.ineq[tid], 0.0f);
+    if (tid < RPO_EVOPF_ROW - (2 * NS + NY + 2 + NEQ + NINEQ)) row[2 * NS + NY + 2 + NEQ + NINEQ + tid] = 0.0f;
+    sync();
+    if (p.rows) {
+        const long long ring = (t % p.cap_steps) * (long long)p.n + i;
+        float4* dst = reinterpret_cast<float4*>(p.rows + (size_t)ring * RPO_EVOPF_ROW);
+        if (tid < RPO_EVOPF_ROW / 4) dst[tid] = reinterpret_cast<const float4*>(row)[tid];
+    }
+    // the lane continues from the next observation, or from a fresh episode (env.reset() after a done, rpo_ddpg.py:142)
+    const float ret = p.ep_ret[i] + reward;
+    if (done && p.auto_reset) {
+        episode_obs(w, w.s, p.seed, env_id, ep + 1u, 0);
+        if (tid < NE) w.s[2 * NB + tid] = kBInit;
+        sync();
+        for (int k = tid; k < NS; k += RPO_WAVE) p.state[(size_t)i * NS + k] = w.s[k];
+        if (tid == 0) { p.ep_count[i] = ep + 1u; p.ep_len[i] = 0; p.ep_ret[i] = 0.0f; }
+    } else {
+        for (int k = tid; k < NS; k += RPO_WAVE) p.state[(size_t)i * NS + k] = nxt[k];
+        if (tid == 0) { p.ep_len[i] = len; p.ep_ret[i] = ret; }
+    }
+    if (p.stats && tid == 0) {
+        float* srow = rpo_stats_row(p.stats, p.stats_cap, t);
+        atomicAdd(srow + RPO_STAT_REWARD_SUM, reward);
+        if (max_ineq != 0.0f) atomicAdd(srow + RPO_STAT_MAX_INEQ_SUM, max_ineq);
+        if (max_eq != 0.0f) atomicAdd(srow + RPO_STAT_MAX_EQ_SUM, max_eq);
+        if (fmaxf(max_ineq, max_eq) > p.viol_thresh) atomicAdd(srow + RPO_STAT_VIOL_COUNT, 1.0f);
+        if (max_ineq > 0.0f) rpo_atomic_max_nonneg(srow + RPO_STAT_MAX_INEQ_MAX, max_ineq);
+        if (max_eq > 0.0f) rpo_atomic_max_nonneg(srow + RPO_STAT_MAX_EQ_MAX, max_eq);
+        if (done) {
+            atomicAdd(srow + RPO_STAT_EPISODES, 1.0f);
+            atomicAdd(srow + RPO_STAT_RETURN_SUM, ret);
+            atomicAdd(srow + RPO_STAT_LENGTH_SUM, (float)len);
+            if (data_done) atomicAdd(srow + RPO_STAT_TERMINATED, 1.0f);
+        }
+    }
+    rpo_step_epilogue(p.ctrl, t, p.stats, p.stats_cap);
+}
+
+// ------------------------------------------------------------------------------- explore + complete + project
+struct ActArgs {
+    int n;
+    const float* state;
+    int state_stride;
+    const float* ap_raw;
+    const float* noise;
+    float* action;
+    int* iters;
+    int noise_mode;
+    float eps_start, eps_end, eps_decay;
+    int max_steps;
+    float corr_lr, corr_eps, corr_momentum;
+    float newton_tol;
+    int newton_iters;
+    const float* consts;
+    uint64_t seed;
+    uint32_t env_id_base;
+    const long long* ctrl;
+    float* stats;
+    int stats_cap;
+};
+
+// take_action's exploration + clip to the state-dependent box (agent/ddpg_pa.py:101-112, model/utils.py:53-62,90-101,
+// EVOPFEnv.update evopf.py:769-783) -> complete_partial -> grad_steps, one lane per wave.
+__global__ __launch_bounds__(RPO_WAVE) void evopf_act_project_kernel(ActArgs p) {
+    RPO_FP_STRICT
+    __shared__ Ws w;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const long long t = p.ctrl ? p.ctrl[RPO_CTRL_T] : 0;
+    load_consts(w, p.consts);
+    load_row(w.s, p.state + (size_t)i * p.state_stride, NS);
+    sync();
+    float z = 0.0f;
+    if (tid < NP) {
+        const float eps_t = fmaxf(p.eps_end, p.eps_start - p.eps_decay * (float)t);
+        const uint32_t env_id = p.env_id_base + (uint32_t)i;
+        float lo, hi;
+        partial_box(w, tid, lo, hi);
+        z = (p.noise_mode == RPO_NOISE_UNIFORM) ? 0.0f : p.ap_raw[(size_t)i * NP + tid];
+        if (p.noise_mode == RPO_NOISE_EXPLICIT) {
+            z = fminf(fmaxf(z + eps_t * p.noise[(size_t)i * NP + tid], lo), hi);
+        } else if (p.noise_mode == RPO_NOISE_PHILOX) {
+            const rpo_u4 r = rpo_philox(p.seed, env_id, (uint32_t)t, RPO_STREAM_ACT, (uint32_t)(tid >> 1));
+            const float nz = (tid & 1) ? rpo_normal(r.z, r.w) : rpo_normal(r.x, r.y);
+            z = fminf(fmaxf(z + eps_t * nz, lo), hi);
+        } else if (p.noise_mode == RPO_NOISE_UNIFORM) {
+            const rpo_u4 r = rpo_philox(p.seed, env_id, (uint32_t)t, RPO_STREAM_ACT, (uint32_t)(tid >> 2));
+            const uint32_t word = (tid & 3) == 0 ? r.x : ((tid & 3) == 1 ? r.y : ((tid & 3) == 2 ? r.z : r.w));
+            const float scale = (hi - lo) * 0.5f;
+            z = scale * (2.0f * rpo_u01(word) - 1.0f) + (lo + scale);
+        } else if (p.noise_mode == RPO_NOISE_CLIP_ONLY) {
+            z = fminf(fmaxf(z, lo), hi);
+        }
+    }
+    complete_partial(w, z, p.newton_tol, p.newton_iters);
+    const int k = grad_steps(w, p.max_steps, p.corr_lr, p.corr_eps, p.corr_momentum);
+    if (tid < NY) p.action[(size_t)i * NY + tid] = w.a[tid];
+    if (tid == 0) {
+        if (p.iters) p.iters[i] = k;
+        if (p.stats && k) atomicAdd(rpo_stats_row(p.stats, p.stats_cap, t) + RPO_STAT_PROJ_ITERS, (float)k);
+    }
+}
+
+// PFFunction.backward (evopf.py:857-910) with the Jacobians re-evaluated at the completed action (the reference keeps
+// those of the last Newton point, one update of size < tol earlier).  grad_ap [n,14] = dL/dz.
+__global__ __launch_bounds__(RPO_WAVE) void evopf_complete_bwd_kernel(int n, const float* __restrict__ action,
+                                                                      const float* __restrict__ grad_action,
+                                                                      float* __restrict__ grad_ap,
+                                                                      const float* __restrict__ consts) {
+    RPO_FP_STRICT
+    __shared__ Ws w;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    load_consts(w, consts);
+    load_row(w.a, action + (size_t)i * NY, NY);
+    load_row(w.dir, grad_action + (size_t)i * NY, NY);                   // dl_dy
+    sync();
+    flows(w);
+    // step 3 (:865-880): dl/d(vm, va) through pg_slack = -eq[0] and qg_j = -eq[14 + spv_j]
+    if (tid < 2 * NB) {
+        float acc = jac_entry(w, 0, VM0 + tid) * w.dir[PG0];
+        for (int j = 0; j < NG; ++j) acc += jac_entry(w, NB + kSpv[j], VM0 + tid) * w.dir[QG0 + j];
+        w.vec[tid] = w.dir[VM0 + tid] - acc;                            // dl_dy_total on the voltage block (:886)
+    }
+    sync();
+    // step 1 (:889-891): d_int = inv(J_newton)^T dl_dy_total[newton vars]
+    for (int e = tid; e < NN * NN; e += RPO_WAVE) {
+        const int r = e / NN, c = e - r * NN;
+        w.M[r][c] = jac_entry(w, kKeep[c], kNewtonVars[r]);             // transposed
+    }
+    if (tid < NN) w.M[tid][NN] = w.vec[kNewtonVars[tid] - VM0];
+    sync();
+    gauss_jordan(w, NN, NN + 1);
+    if (tid < NP) {
+        float g;
+        if (tid < 4) {                                                  // pg at pv gens (:894) + direct term (:907)
+            g = -w.M[tid][NN] + w.dir[PG0 + 1 + tid];
+        } else if (tid < 9) {                                           // vm at generator buses (:895-896)
+            const int var = VM0 + kSpv[tid - 4];
+            float acc = 0.0f;
+            for (int r = 0; r < NN; ++r) acc += jac_entry(w, kKeep[r], var) * w.M[r][NN];
+            g = -acc + w.vec[var - VM0];
+        } else if (tid == 9) {                                          // pe at the slack generator (:898)
+            g = w.dir[PG0] + w.dir[PE0];
+        } else {                                                        // pe at pv gens (:897)
+            g = w.M[tid - 10][NN] + w.dir[PE0 + tid - 9];
+        }
+        grad_ap[(size_t)i * NP + tid] = g;
+    }
+}
+
+__global__ __launch_bounds__(RPO_WAVE) void evopf_resid_kernel(int n, const float* __restrict__ state, int state_stride,
+                                                               const float* __restrict__ action, float* __restrict__ eq_out,
+                                                               float* __restrict__ ineq_out,
+                                                               const float* __restrict__ consts) {
+    __shared__ Ws w;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    load_consts(w, consts);
+    load_row(w.s, state + (size_t)i * state_stride, NS);
+    load_row(w.a, action + (size_t)i * NY, NY);
+    sync();
+    flows(w);
+    eq_resid(w);
+    ineq_resid(w);
+    if (eq_out && tid < NEQ) eq_out[(size_t)i * NEQ + tid] = w.eq[tid];
+    if (ineq_out && tid < NINEQ) ineq_out[(size_t)i * NINEQ + tid] = w.ineq[tid];
+}
+
+__global__ __launch_bounds__(RPO_WAVE) void evopf_ipg_kernel(int n, const float* __restrict__ state, int state_stride,
+                                                             const float* __restrict__ action, float* __restrict__ step_out,
+                                                             const float* __restrict__ consts) {
+    __shared__ Ws w;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    load_consts(w, consts);
+    load_row(w.s, state + (size_t)i * state_stride, NS);
+    load_row(w.a, action + (size_t)i * NY, NY);
+    sync();
+    flows(w);
+    ineq_partial_grad(w);
+    if (tid < NY) step_out[(size_t)i * NY + tid] = w.dir[tid];
+}
+
+// mean_b sum_j nu_j relu(g_j(s_b, a_b)) with its gradients (Dual.forward dual.py:63-65 on ineq_dist, rpo_ddpg.py:312-319)
+__global__ __launch_bounds__(RPO_WAVE) void evopf_lagrangian_kernel(int n, const float* __restrict__ state, int state_stride,
+                                                                    const float* __restrict__ action,
+                                                                    const float* __restrict__ nu, float scale,
+                                                                    float* __restrict__ loss_out,
+                                                                    float* __restrict__ grad_action,
+                                                                    float* __restrict__ grad_nu,
+                                                                    const float* __restrict__ consts) {
+    RPO_FP_STRICT
+    __shared__ Ws w;
+    const int tid = threadIdx.x;
+    load_consts(w, consts);
+    float loss = 0.0f, gnu = 0.0f;
+    const float nuj = tid < NINEQ ? nu[tid] : 0.0f;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        sync();
+        load_row(w.s, state + (size_t)i * state_stride, NS);
+        load_row(w.a, action + (size_t)i * NY, NY);
+        sync();
+        ineq_resid(w);
+        const float dist = tid < NINEQ ? fmaxf(w.ineq[tid], 0.0f) : 0.0f;
+        loss += nuj * dist;
+        gnu += dist;
+        w.vec[tid] = (tid < NINEQ && w.ineq[tid] > 0.0f) ? nuj : 0.0f;
+        sync();
+        if (grad_action && tid < NY) {                                   // ineq_jac^T (nu * 1[g > 0]), evopf.py:663-707
+            float g = 0.0f;
+            if (tid < QG0) g = w.vec[tid] - w.vec[5 + tid];
+            else if (tid < VM0) g = w.vec[10 + tid - QG0] - w.vec[15 + tid - QG0];
+            else if (tid < VA0) g = w.vec[20 + tid - VM0] - w.vec[34 + tid - VM0];
+            else if (tid >= PE0) g = w.vec[48 + tid - PE0] - w.vec[53 + tid - PE0];
+            grad_action[(size_t)i * NY + tid] = scale * g;
+        }
+    }
+    const float total = rpo_wave_sum(loss);
+    if (tid == 0 && loss_out && total != 0.0f) atomicAdd(loss_out, scale * total);
+    if (grad_nu && tid < NINEQ && gnu != 0.0f) atomicAdd(grad_nu + tid, scale * gnu);
+}
+
+int check_common(int n, const void* a, const void* b, const float* consts) {
+    if (n <= 0) return RPO_ERR_ARG;
+    if (!a || !b || !consts) return RPO_ERR_NULL;
+    return 0;
+}
+
+}  // namespace
+
+// ====================================================================================================== C ABI
+extern "C" {
+
+int rpo_evopf_reset(int n_envs, float* state, int* ep_len, float* ep_ret, const unsigned* ep_count,
+                    const float* consts_dev, unsigned long long seed, unsigned env_id_base, void* stream) {
+    if (int e = check_common(n_envs, state, ep_len, consts_dev)) return e;
+    if (!ep_ret) return RPO_ERR_NULL;
+    hipLaunchKernelGGL(evopf_reset_kernel, dim3(n_envs), dim3(RPO_WAVE), 0, (hipStream_t)stream, n_envs, state, ep_len,
+                       ep_ret, ep_count, consts_dev, (uint64_t)seed, (uint32_t)env_id_base);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_evopf_step(int n_envs, float* state, const float* action, int* ep_len, float* ep_ret, unsigned* ep_count,
+                   float* rows, long long cap_steps, float* stats, int stats_cap, long long* ctrl, int max_episode_steps,
+                   int auto_reset, float viol_thresh, const float* consts_dev, unsigned long long seed,
+                   unsigned env_id_base, void* stream) {
+    if (int e = check_common(n_envs, state, action, consts_dev)) return e;
+    if (!ep_len || !ep_ret || !ep_count) return RPO_ERR_NULL;
+    if (max_episode_steps <= 0 || (rows && cap_steps <= 0) || (stats && stats_cap <= 0)) return RPO_ERR_ARG;
+    StepArgs p{n_envs, state, action, ep_len, ep_ret, ep_count, rows, cap_steps, stats, stats_cap, ctrl, max_episode_steps,
+               auto_reset, viol_thresh, consts_dev, (uint64_t)seed, (uint32_t)env_id_base};
+    hipLaunchKernelGGL(evopf_step_kernel, dim3(n_envs), dim3(RPO_WAVE), 0, (hipStream_t)stream, p);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_evopf_act_project(int n, const float* state, int state_stride, const float* ap_raw, const float* noise, float* action, int* iters,
+                          int noise_mode, float eps_start, float eps_end, float eps_decay, int max_steps, float corr_lr,
+                          float corr_eps, float corr_momentum, float newton_tol, int newton_max_iters,
+                          const float* consts_dev, unsigned long long seed, unsigned env_id_base, const long long* ctrl,
+                          float* stats, int stats_cap, void* stream) {
+    if (int e = check_common(n, state, action, consts_dev)) return e;
+    if (max_steps < 0 || newton_max_iters <= 0 || (stats && stats_cap <= 0)) return RPO_ERR_ARG;
+    if (noise_mode < RPO_NOISE_NONE || noise_mode > RPO_NOISE_CLIP_ONLY) return RPO_ERR_ARG;
+    if (noise_mode != RPO_NOISE_UNIFORM && !ap_raw) return RPO_ERR_NULL;
+    if (noise_mode == RPO_NOISE_EXPLICIT && !noise) return RPO_ERR_NULL;
+    if (state_stride < RPO_EVOPF_STATE) return RPO_ERR_ARG;
+    ActArgs p{n, state, state_stride, ap_raw, noise, action, iters, noise_mode, eps_start, eps_end, eps_decay, max_steps, corr_lr,
+              corr_eps, corr_momentum, newton_tol, newton_max_iters, consts_dev, (uint64_t)seed, (uint32_t)env_id_base, ctrl,
+              stats, stats_cap};
+    hipLaunchKernelGGL(evopf_act_project_kernel, dim3(n), dim3(RPO_WAVE), 0, (hipStream_t)stream, p);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_evopf_complete_bwd(int n, const float* action, const float* grad_action, float* grad_ap, const float* consts_dev,
+                           void* stream) {
+    if (int e = check_common(n, action, grad_action, consts_dev)) return e;
+    if (!grad_ap) return RPO_ERR_NULL;
+    hipLaunchKernelGGL(evopf_complete_bwd_kernel, dim3(n), dim3(RPO_WAVE), 0, (hipStream_t)stream, n, action, grad_action,
+                       grad_ap, consts_dev);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_evopf_resid(int n, const float* state, int state_stride, const float* action, float* eq_out, float* ineq_out,
+                    const float* consts_dev, void* stream) {
+    if (int e = check_common(n, state, action, consts_dev)) return e;
+    hipLaunchKernelGGL(evopf_resid_kernel, dim3(n), dim3(RPO_WAVE), 0, (hipStream_t)stream, n, state, state_stride, action, eq_out,
+                       ineq_out, consts_dev);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_evopf_ineq_partial_grad(int n, const float* state, int state_stride, const float* action, float* step_out, const float* consts_dev,
+                                void* stream) {
+    if (int e = check_common(n, state, action, consts_dev)) return e;
+    if (!step_out) return RPO_ERR_NULL;
+    hipLaunchKernelGGL(evopf_ipg_kernel, dim3(n), dim3(RPO_WAVE), 0, (hipStream_t)stream, n, state, state_stride, action, step_out,
+                       consts_dev);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_evopf_lagrangian(int n, const float* state, int state_stride, const float* action, const float* nu, float scale, float* loss_out,
+                         float* grad_action, float* grad_nu, const float* consts_dev, void* stream) {
+    if (int e = check_common(n, state, action, consts_dev)) return e;
+    if (!nu) return RPO_ERR_NULL;
+    const int grid = n < 256 ? n : 256;
+    hipLaunchKernelGGL(evopf_lagrangian_kernel, dim3(grid), dim3(RPO_WAVE), 0, (hipStream_t)stream, n, state, state_stride, action, nu,
+                       scale, loss_out, grad_action, grad_nu, consts_dev);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,350 @@
+// EVOPF-v0 device code (reference: rpo/env/electrical_grid/evopf.py): ONE WAVEFRONT PER ENV LANE.
+//
+// Every lane needs dense linear algebra on its own small matrices -- the 22x22 Newton system of the power-flow
+// equation solver (PFFunction, evopf.py:786-855) and the 28x28 block of the equality Jacobian whose inverse defines the
+// GRG direction (ineq_partial_grad, evopf.py:596-612).  A thread per lane would keep ~1200 floats of matrix in scratch
+// memory; instead the 64 threads of a wave share one lane: the matrix lives in LDS (28 x 44 floats), a thread owns a
+// column during elimination, pivot search and the stop tests are wave reductions.  Workgroup = 1 wave, so the barriers
+// below only order LDS traffic of that wave.
+//
+// The network is the IEEE 14-bus case exactly like the reference (case14 hard-wired at evopf.py:211, eq_num = 28 and
+// ineq_num = 58 hard-coded at :336-337): the bus classification is compiled in, every number (admittances, limits, costs,
+// load / price curves) arrives through the constants buffer the host fills from its case tables (RPO_EVOPF_C_*).
+#pragma once
+#include "common.h"
+
+namespace rpo_evopf_dev {
+
+constexpr int NB = 14, NG = 5, NE = 5, NY = RPO_EVOPF_ACTION, NS = RPO_EVOPF_STATE, NEQ = 28, NINEQ = 58, NP = 14;
+constexpr int PG0 = 0, QG0 = 5, VM0 = 10, VA0 = 24, PE0 = 38;      // blocks of the action vector, evopf.py:278-282
+constexpr int NO = 28, NPV = 15, NN = 22;                          // other vars, partial vars (incl. slack angle), Newton
+constexpr int LD = 44;                                             // leading dimension of the LDS matrix
+constexpr int T = 24, NAHEAD = 24;
+// Battery(...) of evopf.py:243 (per unit)
+constexpr float kBLow = 0.1f, kBHigh = 0.8f, kBPmin = -0.2f, kBPmax = 0.2f, kEtaIn = 0.9f, kEtaOut = 0.9f;
+constexpr float kBInit = 0.2f;                                      // "empty": low + 0.1, evopf.py:62-63
+constexpr float kWe = 5.0f, kWg = 1.0f;                             // evopf.py:244-245
+constexpr float kRho = 0.5f, kMinPf = 0.9f, kMaxPf = 1.0f, kRegBias = 0.1f;   // loaders, evopf.py:212,216
+
+// bus classes of case14 (evopf.py:225-235): slack {0}, pv {1,2,5,7}, pq the rest; generator j sits at bus kSpv[j]
+__device__ constexpr int kSpv[NG] = {0, 1, 2, 5, 7};
+__device__ constexpr int kGenOfBus[NB] = {0, 1, 2, -1, -1, 3, -1, 4, -1, -1, -1, -1, -1, -1};
+__device__ constexpr int kLoadSlot[NB] = {-1, 0, 1, 2, 3, 4, -1, -1, 5, 6, 7, 8, 9, 10};   // buses with Pd != 0 (demand.py:46)
+// variables the actor sets (evopf.py:287-294; z order = pg at pv gens, vm at gens, [slack angle], pe) ...
+__device__ constexpr int kPartialVars[NPV] = {1, 2, 3, 4, 10, 11, 12, 15, 17, 24, 38, 39, 40, 41, 42};
+__device__ constexpr int kPartialActions[NP] = {1, 2, 3, 4, 10, 11, 12, 15, 17, 38, 39, 40, 41, 42};
+// ... and the ones the equations determine (evopf.py:290)
+__device__ constexpr int kOtherVars[NO] = {0, 5, 6, 7, 8, 9, 13, 14, 16, 18, 19, 20, 21, 22, 23,
+                                           25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37};
+// column of variable v in the elimination matrix [J_other | J_partial]
+__device__ constexpr int kColOf[NY] = {0, 28, 29, 30, 31, 1, 2, 3, 4, 5, 32, 33, 34, 6, 7, 35, 8, 36, 9, 10, 11, 12, 13, 14,
+                                       37, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 38, 39, 40, 41, 42};
+// Newton system (evopf.py:809-816): P at pv, P at pq, Q at pq  x  vm at pq, va at pv, va at pq
+__device__ constexpr int kKeep[NN] = {1, 2, 5, 7, 3, 4, 6, 8, 9, 10, 11, 12, 13, 17, 18, 20, 22, 23, 24, 25, 26, 27};
+__device__ constexpr int kNewtonVars[NN] = {13, 14, 16, 18, 19, 20, 21, 22, 23, 25, 26, 29, 31,
+                                            27, 28, 30, 32, 33, 34, 35, 36, 37};
+
+struct Ws {                       // per-wave workspace in LDS
+    float c[RPO_EVOPF_CONSTS_LEN];
+    float M[NEQ][LD];
+    float s[NS + 3];
+    float a[NY + 1];
+    float cs[NB], sn[NB], vr[NB], vi[NB], t1[NB], t2[NB];
+    float eq[NEQ];
+    float ineq[NINEQ + 2];
+    float dir[NY + 1];            // direct gradient / step
+    float fp[NPV + 1];            // full_partial_grad
+    float old[NY + 1];            // momentum term of grad_steps
+    float vec[64];                // scratch
+};
+
+__device__ __forceinline__ void sync() { __syncthreads(); }
+
+__device__ __forceinline__ void load_consts(Ws& w, const float* __restrict__ consts) {
+    for (int i = threadIdx.x; i < RPO_EVOPF_CONSTS_LEN; i += RPO_WAVE) w.c[i] = consts[i];
+}
+__device__ __forceinline__ float Yr(const Ws& w, int i, int k) { return w.c[RPO_EVOPF_C_YR + i * NB + k]; }
+__device__ __forceinline__ float Yi(const Ws& w, int i, int k) { return w.c[RPO_EVOPF_C_YI + i * NB + k]; }
+
+__device__ __forceinline__ float wave_max_all(float v) { return rpo_wave_max(v); }
+
+// Charge-rate box shrunk by the state of charge (Battery.update_bound / ineq_resid, evopf.py:110-116,135-141)
+__device__ __forceinline__ void battery_bounds(float soc, float& p_max, float& p_min) {
+    RPO_FP_STRICT
+    p_max = fminf(kBPmax, kBHigh - soc) / kEtaIn;
+    p_min = kEtaOut * fmaxf(kBPmin, kBLow - soc);
+}
+
+// Box of basic action j of the lane whose observation is in w.s (EVOPFEnv.update, evopf.py:769-783)
+__device__ __forceinline__ void partial_box(const Ws& w, int j, float& lo, float& hi) {
+    if (j < 4) { lo = w.c[RPO_EVOPF_C_PMIN + 1 + j]; hi = w.c[RPO_EVOPF_C_PMAX + 1 + j]; }
+    else if (j < 9) { lo = w.c[RPO_EVOPF_C_VMIN + kSpv[j - 4]]; hi = w.c[RPO_EVOPF_C_VMAX + kSpv[j - 4]]; }
+    else battery_bounds(w.s[2 * NB + j - 9], hi, lo);
+}
+
+// cos / sin / rectangular voltages and the two admittance products of eq_resid / eq_jac (evopf.py:523-528,623-630)
+__device__ __forceinline__ void flows(Ws& w) {
+    RPO_FP_STRICT
+    const int tid = threadIdx.x;
+    if (tid < NB) {
+        float sn, cs;
+        sincosf(w.a[VA0 + tid], &sn, &cs);
+        const float vm = w.a[VM0 + tid];
+        w.cs[tid] = cs; w.sn[tid] = sn; w.vr[tid] = vm * cs; w.vi[tid] = vm * sn;
+    }
+    sync();
+    if (tid < NB) {
+        float t1 = 0.0f, t2 = 0.0f;
+        for (int i = 0; i < NB; ++i) {                       // row vector @ matrix, as written at :527-528
+            t1 += w.vr[i] * Yr(w, i, tid) - w.vi[i] * Yi(w, i, tid);
+            t2 += w.vr[i] * Yi(w, i, tid) + w.vi[i] * Yr(w, i, tid);
+        }
+        w.t1[tid] = t1; w.t2[tid] = t2;
+    }
+    sync();
+}
+
+// eq_resid (evopf.py:520-546) of (w.s, w.a) into w.eq; flows() must be current
+__device__ __forceinline__ void eq_resid(Ws& w) {
+    RPO_FP_STRICT
+    const int tid = threadIdx.x;
+    if (tid < NEQ) {
+        const int i = tid < NB ? tid : tid - NB;
+        const int g = kGenOfBus[i];
+        if (tid < NB) {
+            const float inj = g >= 0 ? w.a[PG0 + g] + w.a[PE0 + g] : 0.0f;
+            w.eq[tid] = (inj - w.s[i]) - (w.vr[i] * w.t1[i] + w.vi[i] * w.t2[i]);
+        } else {
+            const float inj = g >= 0 ? w.a[QG0 + g] : 0.0f;
+            w.eq[tid] = (inj - w.s[NB + i]) - (-w.vr[i] * w.t2[i] + w.vi[i] * w.t1[i]);
+        }
+    }
+    sync();
+}
+
+// ineq_resid (evopf.py:548-563) into w.ineq (signed)
+__device__ __forceinline__ void ineq_resid(Ws& w) {
+    RPO_FP_STRICT
+    const int tid = threadIdx.x;
+    if (tid < NINEQ) {
+        float r;
+        if (tid < 5) r = w.a[PG0 + tid] - w.c[RPO_EVOPF_C_PMAX + tid];
+        else if (tid < 10) r = w.c[RPO_EVOPF_C_PMIN + tid - 5] - w.a[PG0 + tid - 5];
+        else if (tid < 15) r = w.a[QG0 + tid - 10] - w.c[RPO_EVOPF_C_QMAX + tid - 10];
+        else if (tid < 20) r = w.c[RPO_EVOPF_C_QMIN + tid - 15] - w.a[QG0 + tid - 15];
+        else if (tid < 34) r = w.a[VM0 + tid - 20] - w.c[RPO_EVOPF_C_VMAX + tid - 20];
+        else if (tid < 48) r = w.c[RPO_EVOPF_C_VMIN + tid - 34] - w.a[VM0 + tid - 34];
+        else {
+            const int j = (tid - 48) % NE;
+            float p_max, p_min;
+            battery_bounds(w.s[2 * NB + j], p_max, p_min);
+            r = tid < 53 ? w.a[PE0 + j] - p_max : p_min - w.a[PE0 + j];
+        }
+        w.ineq[tid] = r;
+    }
+    sync();
+}
+
+// One entry of eq_jac (evopf.py:614-661): d eq[row] / d action[var], in the reference's orientation and with its sign
+// for the battery columns (d real / d pe = -I at :639-640 although eq_resid adds +pe: reproduced, DESIGN.md hazard E1).
+__device__ __forceinline__ float jac_entry(const Ws& w, int row, int var) {
+    RPO_FP_STRICT
+    const bool real = row < NB;
+    const int i = real ? row : row - NB;
+    if (var < VM0) {                                           // pg / qg selectors
+        const bool mine = real ? var < QG0 : var >= QG0;
+        const int g = var < QG0 ? var : var - QG0;
+        return (mine && kSpv[g] == i) ? 1.0f : 0.0f;
+    }
+    if (var >= PE0) return (real && kSpv[var - PE0] == i) ? -1.0f : 0.0f;
+    const bool dvm = var < VA0;
+    const int k = dvm ? var - VM0 : var - VA0;
+    const float yr = Yr(w, i, k), yi = Yi(w, i, k);
+    const float p = dvm ? w.cs[k] : -w.vi[k];                  // d vr_k / d var
+    const float q = dvm ? w.sn[k] : w.vr[k];                   // d vi_k / d var
+    const float pi_ = dvm ? w.cs[i] : -w.vi[i], qi_ = dvm ? w.sn[i] : w.vr[i];
+    const float d = (i == k) ? 1.0f : 0.0f;
+    if (real)
+        return -(d * pi_ * w.t1[i]) - w.vr[i] * (yr * p - yi * q) - (d * qi_ * w.t2[i]) - w.vi[i] * (yi * p + yr * q);
+    return (d * pi_ * w.t2[i]) + w.vr[i] * (yi * p + yr * q) - (d * qi_ * w.t1[i]) - w.vi[i] * (yr * p - yi * q);
+}
+
+// Gauss-Jordan with partial pivoting on M[0..n) x [0..ncols): the leading n x n block becomes the identity, the trailing
+// columns hold inv(block) @ (their original content).  Thread c owns column c (ncols <= 64).
+__device__ __forceinline__ void gauss_jordan(Ws& w, int n, int ncols) {
+    const int tid = threadIdx.x;
+    for (int k = 0; k < n; ++k) {
+        float best = (tid >= k && tid < n) ? w.M[tid][k] : 0.0f;
+        float mag = (tid >= k && tid < n) ? fabsf(best) : -1.0f;
+        int idx = tid;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float om = __shfl_xor(mag, off, RPO_WAVE), ob = __shfl_xor(best, off, RPO_WAVE);
+            const int oi = __shfl_xor(idx, off, RPO_WAVE);
+            if (om > mag || (om == mag && oi < idx)) { mag = om; best = ob; idx = oi; }
+        }
+        const int p = idx;                                     // wave-uniform pivot row, `best` its (signed) value
+        float mkc = 0.0f;
+        if (tid >= k && tid < ncols) {                         // swap rows k <-> p, normalise the pivot row
+            const float xk = w.M[k][tid], xp = w.M[p][tid];
+            mkc = xp / best;
+            w.M[p][tid] = xk;
+            w.M[k][tid] = mkc;
+        }
+        sync();
+        if (tid > k && tid < ncols) {
+            for (int r = 0; r < n; ++r)
+                if (r != k) w.M[r][tid] -= w.M[r][k] * mkc;
+        }
+        sync();
+    }
+}
+
+// complete_partial (PFFunction.forward, evopf.py:789-855) for the lane in w.s with basic actions z[14] (registers of
+// threads 0..13 hold z[tid] in `zj`): Newton on (vm_pq, va_pv, va_pq) with the lane's own stop test, then qg and the
+// slack generation from the remaining equations.  Leaves flows()/eq of the completed action current.
+__device__ __forceinline__ int complete_partial(Ws& w, float zj, float tol, int max_iters) {
+    RPO_FP_STRICT
+    const int tid = threadIdx.x;
+    if (tid < NY) {
+        float v = 0.0f;                                        // qg and the slack pg start at zero (:806-807)
+        if (tid >= VM0 && tid < VA0) v = w.c[RPO_EVOPF_C_VM_INIT + tid - VM0];       // load-bus guesses (:802)
+        else if (tid >= VA0 && tid < PE0) v = w.c[RPO_EVOPF_C_VA_INIT + tid - VA0];  // (:798,803-805)
+        w.a[tid] = v;
+    }
+    sync();
+    if (tid < NP) w.a[kPartialActions[tid]] = zj;              // (:796-799)
+    sync();
+    int it = 0;
+    for (; it < max_iters;) {
+        flows(w);
+        eq_resid(w);
+        for (int e = tid; e < NN * NN; e += RPO_WAVE) {
+            const int r = e / NN, c = e - r * NN;
+            w.M[r][c] = jac_entry(w, kKeep[r], kNewtonVars[c]);
+        }
+        if (tid < NN) w.M[tid][NN] = w.eq[kKeep[tid]];
+        sync();
+        gauss_jordan(w, NN, NN + 1);
+        float d2 = 0.0f;
+        if (tid < NN) {
+            const float d = w.M[tid][NN];
+            w.a[kNewtonVars[tid]] -= d;
+            d2 = d * d;
+        }
+        sync();
+        ++it;
+        if (sqrtf(rpo_wave_sum(d2)) < tol) break;              // torch.norm(delta) < tol (:834), this lane only
+    }
+    flows(w);
+    eq_resid(w);                                               // with qg = 0 and slack pg = 0
+    if (tid < NG) w.a[QG0 + tid] = -w.eq[NB + kSpv[tid]];      // (:844-845)
+    if (tid == 0) w.a[PG0] = -w.eq[0];                         // (:847-848)
+    sync();
+    eq_resid(w);
+    return it;
+}
+
+// ineq_partial_grad (evopf.py:596-612) of (w.s, w.a) into w.dir[43]; flows() must be current.  Uses w.M.
+__device__ __forceinline__ void ineq_partial_grad(Ws& w) {
+    RPO_FP_STRICT
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NEQ * NY; e += RPO_WAVE) {
+        const int r = e / NY, v = e - r * NY;
+        w.M[r][kColOf[v]] = jac_entry(w, r, v);
+    }
+    ineq_resid(w);                                             // (syncs)
+    gauss_jordan(w, NO, NY);                                   // M[:, 28 + p] = inv(J_o) J_p = -dynz_dz
+    if (tid < NY) {                                            // ineq_grad_new (:590-594): +-1 per violated bound
+        float g = 0.0f;
+        if (tid < QG0) g = (w.ineq[tid] > 0.0f ? 1.0f : 0.0f) - (w.ineq[5 + tid] > 0.0f ? 1.0f : 0.0f);
+        else if (tid < VM0) g = (w.ineq[10 + tid - QG0] > 0.0f ? 1.0f : 0.0f) - (w.ineq[15 + tid - QG0] > 0.0f ? 1.0f : 0.0f);
+        else if (tid < VA0) g = (w.ineq[20 + tid - VM0] > 0.0f ? 1.0f : 0.0f) - (w.ineq[34 + tid - VM0] > 0.0f ? 1.0f : 0.0f);
+        else if (tid >= PE0) g = (w.ineq[48 + tid - PE0] > 0.0f ? 1.0f : 0.0f) - (w.ineq[53 + tid - PE0] > 0.0f ? 1.0f : 0.0f);
+        w.vec[tid] = g;
+    }
+    sync();
+    if (tid < NPV) {                                           // indirect + direct (:603-606)
+        float acc = 0.0f;
+        for (int o = 0; o < NO; ++o) acc += -w.M[o][NO + tid] * w.vec[kOtherVars[o]];
+        w.fp[tid] = acc + w.vec[kPartialVars[tid]];
+    }
+    sync();
+    if (tid < NPV) w.dir[kPartialVars[tid]] = w.fp[tid];
+    if (tid < NO) {                                            // (:610)
+        float acc = 0.0f;
+        for (int p = 0; p < NPV; ++p) acc += -w.M[tid][NO + p] * w.fp[p];
+        w.dir[kOtherVars[tid]] = acc;
+    }
+    sync();
+}
+
+// grad_steps (rpo_ddpg.py:266-305, corr_mode 0) on w.a with the lane's own stop test; returns the iteration count
+__device__ __forceinline__ int grad_steps(Ws& w, int max_steps, float lr, float corr_eps, float momentum) {
+    RPO_FP_STRICT
+    const int tid = threadIdx.x;
+    if (tid < NY) w.old[tid] = 0.0f;
+    int k = 0;
+    for (; k < max_steps; ++k) {
+        flows(w);
+        if (k > 0) {
+            eq_resid(w);
+            ineq_resid(w);
+            float m = tid < NEQ ? fabsf(w.eq[tid]) : 0.0f;
+            if (tid < NINEQ) m = fmaxf(m, w.ineq[tid]);
+            if (!(rpo_wave_max(m) > corr_eps)) break;
+        }
+        ineq_partial_grad(w);
+        if (tid < NY) {
+            const float st = lr * w.dir[tid] + momentum * w.old[tid];
+            w.a[tid] -= st;
+            w.old[tid] = st;
+        }
+        sync();
+    }
+    return k;
+}
+
+// Episode data of the loaders (data/demand.py:35-65, data/price.py:29-55) re-keyed on Philox(seed, env, episode):
+// hour-t observation (pd[14], qd[14]) into out[0..28) and the price window [t, t+24) into out[33..57) -- all zero when
+// t >= 24 (the loaders' `done`, demand.py:71 / price.py:51).
+__device__ __forceinline__ void episode_obs(Ws& w, float* out, uint64_t seed, uint32_t env_id, uint32_t episode, int t) {
+    RPO_FP_STRICT
+    const int tid = threadIdx.x;
+    const bool over = t >= T;
+    // demand: 11 Exp(1) draws (Dirichlet) + 14 power factors from 7 Philox blocks; word index = tid
+    if (tid < 28) {
+        const rpo_u4 r = rpo_philox(seed, env_id, episode, RPO_STREAM_EVOPF_DEMAND, (uint32_t)(t * 8 + (tid >> 2)));
+        const uint32_t word = (tid & 3) == 0 ? r.x : ((tid & 3) == 1 ? r.y : ((tid & 3) == 2 ? r.z : r.w));
+        w.vec[tid] = tid < 11 ? -logf((float)((word >> 8) + 1u) * 5.9604644775390625e-08f)
+                              : rpo_u01(word) * (kMaxPf - kMinPf) + kMinPf;
+    }
+    sync();
+    if (tid < NB) {
+        float esum = 0.0f;
+        for (int j = 0; j < 11; ++j) esum += w.vec[j];
+        const int slot = kLoadSlot[tid];
+        float ratio = w.c[RPO_EVOPF_C_SHARE + tid];
+        if (slot >= 0) ratio += kRho * (w.vec[slot] / esum);
+        const float pd = over ? 0.0f : ratio * w.c[RPO_EVOPF_C_PS + (t < T ? t : T - 1)];
+        const float pf = w.vec[11 + tid];
+        out[tid] = pd;
+        out[NB + tid] = over ? 0.0f : pd * tanf(acosf(pf)) * w.c[RPO_EVOPF_C_QSIGN + tid];
+    }
+    // price: hour h = t + tid of the day (zero past midnight), day = mag * curve * (1 + z)
+    if (tid < NAHEAD) {
+        const int h = t + tid;
+        float v = 0.0f;
+        if (!over && h < T) {
+            const rpo_u4 r = rpo_philox(seed, env_id, episode, RPO_STREAM_EVOPF_PRICE, (uint32_t)(h >> 1));
+            const float z = (h & 1) ? rpo_normal(r.z, r.w) : rpo_normal(r.x, r.y);
+            const rpo_u4 m = rpo_philox(seed, env_id, episode, RPO_STREAM_EVOPF_PRICE, (uint32_t)(T / 2));
+            const float mag = kRegBias * rpo_normal(m.x, m.y) + 1.0f;
+            v = mag * w.c[RPO_EVOPF_C_PRICE + h] * (1.0f + z);
+        }
+        out[2 * NB + NE + tid] = v;
+    }
+    sync();
+}
+
+}  // namespace rpo_evopf_dev

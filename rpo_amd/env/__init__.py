@@ -1,5 +1,5 @@
-"""`from rpo.env import *` surface of the reference (rpo/env/__init__.py:1-2).  EVOPF-v0 is not built yet: it needs
-pypower's case14 tables, which are absent from the reference tree and from this image."""
+"""`from rpo.env import *` surface of the reference (rpo/env/__init__.py:1-2); importing it registers the gym ids."""
 from .classic_control import CartSafeEnv, SpringPendulumEnv
+from .electrical_grid import EVOPFEnv
 
-__all__ = ["CartSafeEnv", "SpringPendulumEnv"]
+__all__ = ["CartSafeEnv", "SpringPendulumEnv", "EVOPFEnv"]

@@ -28,14 +28,16 @@ class _CompletePartialFn(torch.autograd.Function):
         lo, hi = env.partial_box
         k.act_project(obs, action_partial.reshape(-1).contiguous(), None, action, None, hip_ops.NOISE_NONE, 0.0, 0.0, 0.0,
                       lo, hi, 0, 0.0, 1e-5, 0.0)
-        ctx.env, ctx.obs = env, obs
+        ctx.env, ctx.obs, ctx.action = env, obs, action
         return action
 
     @staticmethod
     def backward(ctx, grad_action):
-        gap = torch.empty(grad_action.shape[0], device=grad_action.device)
-        ctx.env.kernels.complete_bwd(ctx.obs, grad_action.contiguous(), gap)
-        return None, None, gap.view(-1, 1)
+        k = ctx.env.kernels
+        n = grad_action.shape[0]
+        gap = torch.empty(n * k.partial_dim, device=grad_action.device)
+        k.complete_bwd(ctx.obs, grad_action.contiguous(), gap, action=ctx.action)
+        return None, None, gap.view(n, k.partial_dim)
 
 
 class _ResidFn(torch.autograd.Function):
@@ -177,7 +179,7 @@ class HardConstraintEnv(gym.Env):
         ``batch_reference=True`` asks for the reference's literal behaviour on a batch (one stop test for the whole
         batch, and for SpringPendulum the sample-coupled step of pendulum.py:337-339) where the env has
         such a kernel; otherwise every row is projected independently, as in the reference's B = 1 rollouts."""
-        ap = self._t(action_partial).reshape(-1).contiguous()
+        ap = self._t(action_partial).reshape(-1, self.kernels.partial_dim).contiguous()
         n = ap.shape[0]
         action = torch.empty(n, self.kernels.action_dim, device=self.device)
         iters = torch.empty(n, dtype=torch.int32, device=self.device) if return_iters else None

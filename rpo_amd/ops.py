@@ -132,7 +132,7 @@ class CartSafeKernels(object):
     """HIP kernels of CartSafe-v0.  ``consts`` is the float32[35] table of include/rpo_hip.h (RPO_CART_CONSTS_LEN)."""
 
     name = "CartSafe-v0"
-    obs_dim, internal_dim, action_dim, eq_num, ineq_num = 6, 6, 2, 1, 6
+    obs_dim, internal_dim, action_dim, eq_num, ineq_num, partial_dim = 6, 6, 2, 1, 6, 1
     row_floats = CONST["RPO_CART_ROW"]
     # column ranges of a transition row
     cols = dict(state=(0, 6), action=(6, 8), next_state=(8, 14), reward=(14, 15), done=(15, 16), eq_viol=(16, 17),
@@ -195,7 +195,7 @@ class CartSafeKernels(object):
             corr_momentum, box_lo, box_hi, self._cptr, self.partial, gamma, _p(q_out), _p(qn_out), _p(dq_out),
             _p(loss_partial), _p(x0_save), _p(h1_save), _stream()), "rpo_cartsafe_ddpg_critic_forward")
 
-    def complete_bwd(self, obs, grad_action, grad_ap):
+    def complete_bwd(self, obs, grad_action, grad_ap, action=None):
         check(_lib.load().rpo_cartsafe_complete_bwd(grad_action.shape[0], _p(grad_action), _p(grad_ap), self._cptr,
                                                     self.partial, _stream()), "rpo_cartsafe_complete_bwd")
 
@@ -208,17 +208,89 @@ class CartSafeKernels(object):
         check(_lib.load().rpo_cartsafe_ineq_partial_grad(action.shape[0], _p(action), _p(step_out), self._cptr,
                                                          self.partial, _stream()), "rpo_cartsafe_ineq_partial_grad")
 
-    def lagrangian(self, action, nu, scale, loss_out, grad_action, grad_nu):
+    def lagrangian(self, action, nu, scale, loss_out, grad_action, grad_nu, obs=None):
         check(_lib.load().rpo_cartsafe_lagrangian(action.shape[0], _p(action), _p(nu), scale, _p(loss_out),
                                                   _p(grad_action, allow_none=True), _p(grad_nu, allow_none=True),
                                                   self._cptr, self.partial, _stream()), "rpo_cartsafe_lagrangian")
+
+
+class EvopfKernels(object):
+    """HIP kernels of EVOPF-v0 (one wavefront per lane).  ``consts`` = float32[RPO_EVOPF_CONSTS_LEN] built by
+    rpo_amd/env/electrical_grid/case14.py; it is uploaded once per device."""
+
+    name = "EVOPF-v0"
+    obs_dim = internal_dim = CONST["RPO_EVOPF_STATE"]
+    action_dim, partial_dim = CONST["RPO_EVOPF_ACTION"], CONST["RPO_EVOPF_PARTIAL"]
+    eq_num, ineq_num = CONST["RPO_EVOPF_EQ"], CONST["RPO_EVOPF_INEQ"]
+    row_floats = CONST["RPO_EVOPF_ROW"]
+    cols = dict(state=(0, 57), action=(57, 100), next_state=(100, 157), reward=(157, 158), done=(158, 159),
+                eq_viol=(159, 187), ineq_viol=(187, 245))
+    newton_tol, newton_max_iters = 1e-5, 50          # PFFunction(env, tol=1e-5, bsz=256, max_iters=50), evopf.py:786
+    partial = 0
+
+    def __init__(self, consts):
+        self.consts = np.ascontiguousarray(consts, dtype=np.float32)
+        if self.consts.shape != (CONST["RPO_EVOPF_CONSTS_LEN"],):
+            raise RpoHipError("bad EVOPF constant table")
+        self._dev = {}
+
+    def _c(self, like):
+        key = like.device
+        if key not in self._dev:
+            self._dev[key] = torch.from_numpy(self.consts).to(like.device)
+        return _p(self._dev[key])
+
+    def reset(self, internal, obs, ep_len, ep_ret, ep_count, seed, env_id_base):
+        check(_lib.load().rpo_evopf_reset(internal.shape[0], _p(internal), _p(ep_len, torch.int32), _p(ep_ret),
+                                          _p(ep_count, torch.int32), self._c(internal), seed, env_id_base, _stream()),
+              "rpo_evopf_reset")
+
+    def step(self, internal, obs, action, ep_len, ep_ret, ep_count, rows, cap_steps, stats, ctrl, max_episode_steps,
+             auto_reset, viol_thresh, seed, env_id_base):
+        check(_lib.load().rpo_evopf_step(
+            internal.shape[0], _p(internal), _p(action), _p(ep_len, torch.int32), _p(ep_ret), _p(ep_count, torch.int32),
+            _p(rows, allow_none=True), cap_steps, _p(stats, allow_none=True), 0 if stats is None else stats.shape[0],
+            _p(ctrl, torch.int64, allow_none=True), max_episode_steps, int(auto_reset), viol_thresh, self._c(internal),
+            seed, env_id_base, _stream()), "rpo_evopf_step")
+
+    def act_project(self, obs, ap_raw, noise, action, iters, noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi,
+                    max_steps, corr_lr, corr_eps, corr_momentum, seed=0, env_id_base=0, ctrl=None, stats=None):
+        # box_lo / box_hi are ignored: the box is state dependent (EVOPFEnv.update) and evaluated inside the kernel
+        sp, ss = _row_view(obs, self.obs_dim)
+        check(_lib.load().rpo_evopf_act_project(
+            action.shape[0], sp, ss, _p(ap_raw, allow_none=True), _p(noise, allow_none=True), _p(action),
+            _p(iters, torch.int32, allow_none=True), noise_mode, eps_start, eps_end, eps_decay, max_steps, corr_lr,
+            corr_eps, corr_momentum, self.newton_tol, self.newton_max_iters, self._c(action), seed, env_id_base,
+            _p(ctrl, torch.int64, allow_none=True), _p(stats, allow_none=True), 0 if stats is None else stats.shape[0],
+            _stream()), "rpo_evopf_act_project")
+
+    def complete_bwd(self, obs, grad_action, grad_ap, action=None):
+        check(_lib.load().rpo_evopf_complete_bwd(grad_action.shape[0], _p(action), _p(grad_action), _p(grad_ap),
+                                                 self._c(action), _stream()), "rpo_evopf_complete_bwd")
+
+    def resid(self, obs, action, eq_out, ineq_out):
+        sp, ss = _row_view(obs, self.obs_dim)
+        check(_lib.load().rpo_evopf_resid(action.shape[0], sp, ss, _p(action), _p(eq_out, allow_none=True),
+                                          _p(ineq_out, allow_none=True), self._c(action), _stream()), "rpo_evopf_resid")
+
+    def ineq_partial_grad(self, obs, action, step_out):
+        sp, ss = _row_view(obs, self.obs_dim)
+        check(_lib.load().rpo_evopf_ineq_partial_grad(action.shape[0], sp, ss, _p(action), _p(step_out),
+                                                      self._c(action), _stream()), "rpo_evopf_ineq_partial_grad")
+
+    def lagrangian(self, action, nu, scale, loss_out, grad_action, grad_nu, obs=None):
+        sp, ss = _row_view(obs, self.obs_dim)
+        check(_lib.load().rpo_evopf_lagrangian(action.shape[0], sp, ss, _p(action), _p(nu), scale,
+                                               _p(loss_out, allow_none=True), _p(grad_action, allow_none=True),
+                                               _p(grad_nu, allow_none=True), self._c(action), _stream()),
+              "rpo_evopf_lagrangian")
 
 
 class PendulumKernels(object):
     """HIP kernels of SpringPendulum-v0."""
 
     name = "SpringPendulum-v0"
-    obs_dim, internal_dim, action_dim, eq_num, ineq_num = 5, 4, 2, 1, 1
+    obs_dim, internal_dim, action_dim, eq_num, ineq_num, partial_dim = 5, 4, 2, 1, 1, 1
     row_floats = CONST["RPO_PEND_ROW"]
     cols = dict(state=(0, 5), action=(5, 7), next_state=(7, 12), reward=(12, 13), done=(13, 14), eq_viol=(14, 15),
                 ineq_viol=(15, 16))
@@ -265,7 +337,7 @@ class PendulumKernels(object):
                                                         corr_eps, corr_momentum, _stream()),
               "rpo_pendulum_project_batchref")
 
-    def complete_bwd(self, obs, grad_action, grad_ap):
+    def complete_bwd(self, obs, grad_action, grad_ap, action=None):
         op, ostride = _row_view(obs, 5)
         check(_lib.load().rpo_pendulum_complete_bwd(grad_action.shape[0], op, ostride, _p(grad_action), _p(grad_ap),
                                                     _stream()), "rpo_pendulum_complete_bwd")
@@ -280,7 +352,7 @@ class PendulumKernels(object):
         check(_lib.load().rpo_pendulum_ineq_partial_grad(action.shape[0], op, ostride, _p(action), _p(step_out),
                                                          _stream()), "rpo_pendulum_ineq_partial_grad")
 
-    def lagrangian(self, action, nu, scale, loss_out, grad_action, grad_nu):
+    def lagrangian(self, action, nu, scale, loss_out, grad_action, grad_nu, obs=None):
         check(_lib.load().rpo_pendulum_lagrangian(action.shape[0], _p(action), _p(nu), scale, _p(loss_out),
                                                   _p(grad_action, allow_none=True), _p(grad_nu, allow_none=True),
                                                   _stream()), "rpo_pendulum_lagrangian")

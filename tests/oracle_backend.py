@@ -101,7 +101,7 @@ class _EnvKernels(object):
 
 class CartSafeKernels(_EnvKernels):
     name = "CartSafe-v0"
-    obs_dim, internal_dim, action_dim, eq_num, ineq_num = 6, 6, 2, 1, 6
+    obs_dim, internal_dim, action_dim, eq_num, ineq_num, partial_dim = 6, 6, 2, 1, 6, 1
     row_floats = CONST["RPO_CART_ROW"]
     cols = dict(state=(0, 6), action=(6, 8), next_state=(8, 14), reward=(14, 15), done=(15, 16), eq_viol=(16, 17),
                 ineq_viol=(17, 23))
@@ -139,7 +139,7 @@ class CartSafeKernels(_EnvKernels):
             _put(iters, it)
         self._stat_iters(stats, ctrl, it)
 
-    def complete_bwd(self, obs, grad_action, grad_ap):
+    def complete_bwd(self, obs, grad_action, grad_ap, action=None):
         k = -(self.c.C_p * self.c.C_o_inv)[0, 0]
         g = _np(grad_action)
         _put(grad_ap, g[:, self.c.partial] + k * g[:, self.c.other])
@@ -153,7 +153,7 @@ class CartSafeKernels(_EnvKernels):
     def ineq_partial_grad(self, obs, action, step_out):
         _put(step_out, cs.ineq_partial_grad(_np(action), self.c))
 
-    def lagrangian(self, action, nu, scale, loss_out, grad_action, grad_nu):
+    def lagrangian(self, action, nu, scale, loss_out, grad_action, grad_nu, obs=None):
         loss, ga, gnu = train_ops.lagrangian_cart(_np(action), _np(nu), self.c, scale)
         loss_out += float(loss)
         if grad_action is not None:
@@ -164,7 +164,7 @@ class CartSafeKernels(_EnvKernels):
 
 class PendulumKernels(_EnvKernels):
     name = "SpringPendulum-v0"
-    obs_dim, internal_dim, action_dim, eq_num, ineq_num = 5, 4, 2, 1, 1
+    obs_dim, internal_dim, action_dim, eq_num, ineq_num, partial_dim = 5, 4, 2, 1, 1, 1
     row_floats = CONST["RPO_PEND_ROW"]
     cols = dict(state=(0, 5), action=(5, 7), next_state=(7, 12), reward=(12, 13), done=(13, 14), eq_viol=(14, 15),
                 ineq_viol=(15, 16))
@@ -213,7 +213,7 @@ class PendulumKernels(_EnvKernels):
         if iters_out is not None:
             iters_out[0] = int(it.max())
 
-    def complete_bwd(self, obs, grad_action, grad_ap):
+    def complete_bwd(self, obs, grad_action, grad_ap, action=None):
         o, g = _np(obs), _np(grad_action)
         _put(grad_ap, g[:, 0] - g[:, 1] * (o[:, 1] * (np.float32(1) / o[:, 0])))
 
@@ -226,7 +226,7 @@ class PendulumKernels(_EnvKernels):
     def ineq_partial_grad(self, obs, action, step_out):
         _put(step_out, pd.ineq_partial_grad(_np(obs).astype(np.float32), _np(action)))
 
-    def lagrangian(self, action, nu, scale, loss_out, grad_action, grad_nu):
+    def lagrangian(self, action, nu, scale, loss_out, grad_action, grad_nu, obs=None):
         loss, ga, gnu = train_ops.lagrangian_pendulum(_np(action), _np(nu), scale)
         loss_out += float(loss)
         if grad_action is not None:
