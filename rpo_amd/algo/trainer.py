@@ -468,6 +468,7 @@ class RPOTrainerBase(object):
         mean_ineq, mean_eq, max_ineq, max_eq = [torch.zeros(lanes, device=self.device) for _ in range(4)]
         if self.max_episode_steps:
             horizon = min(horizon, int(self.max_episode_steps))
+        horizon = min(horizon, getattr(self.kernels, "episode_steps", horizon))     # EVOPF: one 24-hour day
         with torch.no_grad():
             for i in range(horizon):
                 ap = self._eval_partial(v.obs)

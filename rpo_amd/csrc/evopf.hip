@@ -275,43 +275,52 @@ __global__ __launch_bounds__(RPO_WAVE) void evopf_ipg_kernel(int n, const float*
     if (tid < NY) step_out[(size_t)i * NY + tid] = w.dir[tid];
 }
 
-// mean_b sum_j nu_j relu(g_j(s_b, a_b)) with its gradients (Dual.forward dual.py:63-65 on ineq_dist, rpo_ddpg.py:312-319)
-__global__ __launch_bounds__(RPO_WAVE) void evopf_lagrangian_kernel(int n, const float* __restrict__ state, int state_stride,
-                                                                    const float* __restrict__ action,
-                                                                    const float* __restrict__ nu, float scale,
-                                                                    float* __restrict__ loss_out,
-                                                                    float* __restrict__ grad_action,
-                                                                    float* __restrict__ grad_nu,
-                                                                    const float* __restrict__ consts) {
+// mean_b sum_j nu_j relu(g_j(s_b, a_b)) with its gradients (Dual.forward dual.py:63-65 on ineq_dist, rpo_ddpg.py:312-319).
+// The 58 inequalities are box bounds on single variables, so the work is elementwise: thread v of each of the 4 waves owns
+// action component v (its upper and its lower bound) for the rows b = wave (mod 4); the four partial sums are combined in
+// a fixed order by wave 0 -- one workgroup, no float atomics between workgroups, bitwise reproducible.
+__global__ __launch_bounds__(RPO_BLOCK) void evopf_lagrangian_kernel(int n, const float* __restrict__ state, int state_stride,
+                                                                     const float* __restrict__ action,
+                                                                     const float* __restrict__ nu, float scale,
+                                                                     float* __restrict__ loss_out,
+                                                                     float* __restrict__ grad_action,
+                                                                     float* __restrict__ grad_nu,
+                                                                     const float* __restrict__ consts) {
     RPO_FP_STRICT
-    __shared__ Ws w;
-    const int tid = threadIdx.x;
-    load_consts(w, consts);
-    float loss = 0.0f, gnu = 0.0f;
-    const float nuj = tid < NINEQ ? nu[tid] : 0.0f;
-    for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        sync();
-        load_row(w.s, state + (size_t)i * state_stride, NS);
-        load_row(w.a, action + (size_t)i * NY, NY);
-        sync();
-        ineq_resid(w);
-        const float dist = tid < NINEQ ? fmaxf(w.ineq[tid], 0.0f) : 0.0f;
-        loss += nuj * dist;
-        gnu += dist;
-        w.vec[tid] = (tid < NINEQ && w.ineq[tid] > 0.0f) ? nuj : 0.0f;
-        sync();
-        if (grad_action && tid < NY) {                                   // ineq_jac^T (nu * 1[g > 0]), evopf.py:663-707
+    __shared__ float red[RPO_BLOCK / RPO_WAVE][2 * RPO_WAVE];
+    const int v = threadIdx.x & (RPO_WAVE - 1), q = threadIdx.x / RPO_WAVE;
+    int up = -1, lo = -1;                                        // rows of ineq_resid (evopf.py:550-561) bounding component v
+    float hi_b = 0.0f, lo_b = 0.0f;
+    if (v < QG0) { up = v; lo = 5 + v; hi_b = consts[RPO_EVOPF_C_PMAX + v]; lo_b = consts[RPO_EVOPF_C_PMIN + v]; }
+    else if (v < VM0) { up = 10 + v - QG0; lo = 15 + v - QG0; hi_b = consts[RPO_EVOPF_C_QMAX + v - QG0]; lo_b = consts[RPO_EVOPF_C_QMIN + v - QG0]; }
+    else if (v < VA0) { up = 20 + v - VM0; lo = 34 + v - VM0; hi_b = consts[RPO_EVOPF_C_VMAX + v - VM0]; lo_b = consts[RPO_EVOPF_C_VMIN + v - VM0]; }
+    else if (v >= PE0 && v < NY) { up = 48 + v - PE0; lo = 53 + v - PE0; }
+    const float nu_up = up >= 0 ? nu[up] : 0.0f, nu_lo = lo >= 0 ? nu[lo] : 0.0f;
+    float acc_up = 0.0f, acc_lo = 0.0f;
+    if (v < NY) {
+        for (int b = q; b < n; b += RPO_BLOCK / RPO_WAVE) {
             float g = 0.0f;
-            if (tid < QG0) g = w.vec[tid] - w.vec[5 + tid];
-            else if (tid < VM0) g = w.vec[10 + tid - QG0] - w.vec[15 + tid - QG0];
-            else if (tid < VA0) g = w.vec[20 + tid - VM0] - w.vec[34 + tid - VM0];
-            else if (tid >= PE0) g = w.vec[48 + tid - PE0] - w.vec[53 + tid - PE0];
-            grad_action[(size_t)i * NY + tid] = scale * g;
+            if (up >= 0) {
+                const float a = action[(size_t)b * NY + v];
+                if (v >= PE0) battery_bounds(state[(size_t)b * state_stride + 2 * NB + v - PE0], hi_b, lo_b);
+                const float ru = a - hi_b, rl = lo_b - a;
+                acc_up += fmaxf(ru, 0.0f);
+                acc_lo += fmaxf(rl, 0.0f);
+                g = (ru > 0.0f ? nu_up : 0.0f) - (rl > 0.0f ? nu_lo : 0.0f);      // ineq_jac^T (nu * 1[g > 0]), :663-707
+            }
+            if (grad_action) grad_action[(size_t)b * NY + v] = scale * g;
         }
     }
-    const float total = rpo_wave_sum(loss);
-    if (tid == 0 && loss_out && total != 0.0f) atomicAdd(loss_out, scale * total);
-    if (grad_nu && tid < NINEQ && gnu != 0.0f) atomicAdd(grad_nu + tid, scale * gnu);
+    red[q][v] = acc_up;
+    red[q][RPO_WAVE + v] = acc_lo;
+    __syncthreads();
+    if (q == 0) {
+        float su = 0.0f, sl = 0.0f;
+        for (int w = 0; w < RPO_BLOCK / RPO_WAVE; ++w) { su += red[w][v]; sl += red[w][RPO_WAVE + v]; }
+        if (grad_nu && up >= 0) { grad_nu[up] += scale * su; grad_nu[lo] += scale * sl; }   // one writer per address
+        const float total = rpo_wave_sum(nu_up * su + nu_lo * sl);
+        if (v == 0 && loss_out) *loss_out += scale * total;
+    }
 }
 
 int check_common(int n, const void* a, const void* b, const float* consts) {
@@ -401,9 +410,8 @@ int rpo_evopf_lagrangian(int n, const float* state, int state_stride, const floa
                          float* grad_action, float* grad_nu, const float* consts_dev, void* stream) {
     if (int e = check_common(n, state, action, consts_dev)) return e;
     if (!nu) return RPO_ERR_NULL;
-    const int grid = n < 256 ? n : 256;
-    hipLaunchKernelGGL(evopf_lagrangian_kernel, dim3(grid), dim3(RPO_WAVE), 0, (hipStream_t)stream, n, state, state_stride, action, nu,
-                       scale, loss_out, grad_action, grad_nu, consts_dev);
+    hipLaunchKernelGGL(evopf_lagrangian_kernel, dim3(1), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, state, state_stride,
+                       action, nu, scale, loss_out, grad_action, grad_nu, consts_dev);
     RPO_LAUNCH_CHECK();
     return 0;
 }

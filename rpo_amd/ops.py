@@ -60,7 +60,8 @@ def _row_view(t, width):
     """(pointer, row stride in floats) of a [n, width] float32 view whose rows are contiguous."""
     if t.dim() != 2 or t.shape[1] != width or t.stride(1) != 1:
         raise RpoHipError("expected a [n,%d] row view with unit column stride, got %s / %s" % (width, tuple(t.shape), t.stride()))
-    return _p(t, contiguous=False), int(t.stride(0))
+    # the stride of a 1-row view is arbitrary (torch keeps whatever the producer left there)
+    return _p(t, contiguous=False), int(t.stride(0)) if t.shape[0] > 1 else width
 
 
 def _col_view(t):
@@ -226,6 +227,7 @@ class EvopfKernels(object):
     cols = dict(state=(0, 57), action=(57, 100), next_state=(100, 157), reward=(157, 158), done=(158, 159),
                 eq_viol=(159, 187), ineq_viol=(187, 245))
     newton_tol, newton_max_iters = 1e-5, 50          # PFFunction(env, tol=1e-5, bsz=256, max_iters=50), evopf.py:786
+    episode_steps = 24                               # the loaders run out of data after one day (demand.py:71)
     partial = 0
 
     def __init__(self, consts):

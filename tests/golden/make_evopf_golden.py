@@ -148,7 +148,84 @@ def gen_project():
     save("evopf_project", S=S, AP=AP, **out)
 
 
+EVOPF_HP = dict(batch_size=256, max_steps=10, warmup=0, lr_dual=2e-2, corr_lr=1e-4, eps=0.0001, eps_start=0.0001,
+                eps_epoch=20000, eval_lr=1e-4, eval_steps=50, grad_eps=0.02, corr_momentum=0.0, policy_fre=4,
+                ex_action_dim=1, gamma=0.95, clip_thres=0.2, shared_param=False, value_type="cat")   # scripts/evopf_exp.py:29-31
+
+
+def gen_train_steps():
+    """RPODDPG.train (rpo_ddpg.py:163-205) for t = 1..4 on EVOPF with the script's hyper-parameters (smaller networks
+    to keep the fixture small; init_nju > 0 so that the Lagrangian term has a gradient), every random draw recorded."""
+    torch.manual_seed(123)
+    np.random.seed(111)
+    env = REF.EVOPFEnv()
+    logger = REF.Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=10, name="x")
+    tr = REF.RPODDPG(env, "/tmp/rpo_evopf_golden", name="g", logger=logger, max_epochs=10, capacity=512, embed_dim=64,
+                     hidden_dim=64, init_nju=0.1, device=torch.device("cpu"), **EVOPF_HP)
+    out = {"actor0." + k: v.numpy().copy() for k, v in tr.agent.actor.state_dict().items()}
+    out.update({"critic0." + k: v.numpy().copy() for k, v in tr.agent.critic.state_dict().items()})
+    trans = {k: [] for k in ("state", "action", "next_state", "reward", "done", "eq_viol", "ineq_viol")}
+    s = env.reset()
+    with torch.no_grad():
+        for i in range(300):
+            ap = partials(env, s[None].astype(np.float32))
+            a = tr.process_action(t32(s[None]), t32(ap)).numpy()[0]
+            s2, r, d, info = env.step(a)
+            vals = (s, a, s2, float(np.asarray(r).reshape(-1)[0]), d, info["eq_viol"].reshape(-1), info["ineq_viol"].reshape(-1))
+            for k, v in zip(trans, vals):
+                trans[k].append(np.asarray(v, dtype=np.float32))
+            tr.agent.add(*vals)
+            s = env.reset() if d else s2
+    out.update({"buf." + k: np.stack(v) for k, v in trans.items()})
+    draws = {"idx": [], "noise": []}
+    orig_randint, orig_randn_like = np.random.randint, torch.randn_like
+
+    def rec_randint(*a, **k):
+        v = orig_randint(*a, **k)
+        draws["idx"].append(np.asarray(v).copy())
+        return v
+
+    def rec_randn_like(x, *a, **k):
+        v = orig_randn_like(x, *a, **k)
+        draws["noise"].append(v.numpy().copy())
+        return v
+
+    losses = {"critic": [], "actor": []}
+    oc, oa = tr.critic_loss, tr.actor_loss
+
+    def rec_c(*a, **k):
+        v = oc(*a, **k)
+        losses["critic"].append(float(v))
+        return v
+
+    def rec_a(*a, **k):
+        v = oa(*a, **k)
+        losses["actor"].append(float(v))
+        return v
+    tr.critic_loss, tr.actor_loss = rec_c, rec_a
+    np.random.randint, torch.randn_like = rec_randint, rec_randn_like
+    try:
+        for t in range(1, 5):
+            tr.train(t)
+            if t in (1, 4):
+                out.update({"critic%d.%s" % (t, k): v.numpy().copy() for k, v in tr.agent.critic.state_dict().items()})
+    finally:
+        np.random.randint, torch.randn_like = orig_randint, orig_randn_like
+    out.update({"actor4." + k: v.numpy().copy() for k, v in tr.agent.actor.state_dict().items()})
+    out.update({"critic_target4." + k: v.numpy().copy() for k, v in tr.agent.critic_target.state_dict().items()})
+    out.update({"actor_target4." + k: v.numpy().copy() for k, v in tr.agent.actor_target.state_dict().items()})
+    out["nju4"] = tr.agent.nju.weight.detach().numpy().copy()
+    out["idx"] = np.stack(draws["idx"])
+    for i, z in enumerate(draws["noise"]):
+        out["noise%d" % i] = z
+    out["n_noise"] = len(draws["noise"])
+    out["critic_losses"] = np.array(losses["critic"])
+    out["actor_losses"] = np.array(losses["actor"])
+    save("train_steps_ddpg_evopf", **out)
+
+
 if __name__ == "__main__":
     gen_env()
     gen_step()
     gen_project()
+    gen_train_steps()

@@ -242,3 +242,50 @@ def test_gym_api_runs_one_day(env):
     obs2 = e.reset()
     assert not np.allclose(obs2[:28], 0)
     e.close()
+
+
+# ------------------------------------------------------------------------------------------------ trainer
+def _golden(name):
+    return golden(name)
+
+
+def test_update_matches_reference_on_gpu():
+    """RPODDPG.train for t = 1..4 on EVOPF (critic steps, one policy + multiplier step, Polyak) against the fixture
+    recorded from the reference (make_evopf_golden.gen_train_steps), every random draw replayed.  Tolerance: float32
+    GEMMs + 4 Adam steps 5e-6 on parameters; the actor gradient passes through the 22x22 Newton inverse -> 2e-5."""
+    import test_train_step_golden as tsg
+    from rpo_amd import ops
+    g, tr, closs, aloss, proxy = tsg.run_product_update(_golden, "ddpg", "evopf", ops, torch.device("cuda"), fused=False)
+    ag = tr.agent
+    np.testing.assert_allclose(closs, g["critic_losses"], rtol=1e-4)
+    np.testing.assert_allclose(aloss, g["actor_losses"], rtol=1e-3, atol=1e-5)
+    for name, net, tol in (("critic4", ag.critic, 5e-6), ("critic_target4", ag.critic_target, 5e-6),
+                           ("actor4", ag.actor, 2e-5), ("actor_target4", ag.actor_target, 2e-5)):
+        for k, v in tsg.sd(g, name).items():
+            np.testing.assert_allclose(net.state_dict()[k].cpu().numpy(), v, rtol=0, atol=tol, err_msg=name + "." + k)
+    np.testing.assert_allclose(ag.nju.weight.detach().cpu().numpy(), g["nju4"], rtol=1e-4, atol=1e-6)
+    assert np.abs(g["nju4"] - 0.1).max() > 1e-2 and not proxy.noises and not proxy.idx
+
+
+def _run(n_envs, iters, use_graph, seed_all=5):
+    import test_train_step_golden as tsg
+    from rpo_amd import ops
+    torch.manual_seed(seed_all)
+    tr = tsg.build_trainer("ddpg", "evopf", ops, torch.device("cuda"), fused=False, num_envs=n_envs, use_graph=use_graph)
+    tr.vec.reset()
+    tr.run_steps(iters)
+    torch.cuda.synchronize()
+    return tr
+
+
+def test_training_iterations_graph_equals_eager_and_episodes_roll_over():
+    a = _run(64, 30, use_graph=False)
+    b = _run(64, 30, use_graph=True)
+    assert any(e["graph"] is not None for e in b._graphs.entries.values())
+    assert torch.equal(a.vec.internal, b.vec.internal) and torch.equal(a.buffer.rows, b.buffer.rows)
+    assert torch.equal(a.agent.flat.data, b.agent.flat.data)
+    assert int(a.vec.ctrl[0]) == 30 and (a.vec.ep_count == 1).all() and (a.vec.ep_len == 6).all()
+    a._harvest()
+    assert a.env_steps == 64 * 30 and 0.0 <= a.viol_rate <= 1.0
+    res = a.eval()
+    assert len(res) == 10 and np.isfinite(res).all()

@@ -103,11 +103,23 @@ def build_trainer(algo, envname, backend, device, fused=True, **extra):
     return tr
 
 
+EVOPF_HP = dict(batch_size=256, max_steps=10, warmup=0, lr_dual=2e-2, corr_lr=1e-4, eps=0.0001, eps_start=0.0001,
+                eps_epoch=20000, eval_lr=1e-4, eval_steps=50, grad_eps=0.02, corr_momentum=0.0, policy_fre=4,
+                ex_action_dim=1, gamma=0.95, clip_thres=0.2, shared_param=False, value_type="cat", capacity=512,
+                embed_dim=64, hidden_dim=64, init_nju=0.1)     # scripts/evopf_exp.py:29-31 + make_evopf_golden.py
+
+
 def _build_trainer(algo, envname, backend, device, **extra):
+    cls = RPODDPG if algo == "ddpg" else RPOSAC
+    if envname == "evopf":
+        from rpo_amd.env import EVOPFEnv
+        args = dict(EVOPF_HP)
+        args.update(extra)
+        return cls(EVOPFEnv(backend=backend, device=device), "/tmp/rpo_test", name="t", logger=None, max_epochs=10,
+                   device=device, backend=backend, seed=11, **args)
     env_cls = CartSafeEnv if envname.startswith("cart") else SpringPendulumEnv
     kw = dict(partial_actions=[1]) if envname.startswith("cart") else {}
     env = gym_shim.TimeLimit(env_cls(backend=backend, device=device, **kw), 200)
-    cls = RPODDPG if algo == "ddpg" else RPOSAC
     hp = dict(HP[(algo, envname)])
     if algo == "sac":
         hp["automatic_entropy_tuning"] = False
