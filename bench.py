@@ -46,19 +46,31 @@ WORKLOADS = {
     "pen_ddpg": ("pen", "ddpg", dict(lr_dual=0.01, corr_lr=2e-3, eval_lr=2e-3, eps=0.5, eps_start=0.5, shared_param=False)),
     "pen_sac": ("pen", "sac", dict(lr_dual=0.01, corr_lr=2e-3, eval_lr=2e-3, eps=1e-2, eps_start=1e-2, shared_param=False,
                                    alpha=0.01, automatic_entropy_tuning=False)),
+    # BASELINE.json configs[4]: EVOPF-v0, RPODDPG, 1024 envs on one MI355X (scripts/evopf_exp.py:29-31)
+    "evopf_ddpg": ("evopf", "ddpg", None),
 }
+EVOPF_HP = dict(batch_size=256, max_steps=10, warmup=0, lr_dual=2e-2, corr_lr=1e-4, eps=0.0001, eps_start=0.0001,
+                eps_epoch=20000, eval_lr=1e-4, eval_steps=50, grad_eps=0.02, corr_momentum=0.0, policy_fre=4,
+                ex_action_dim=1, gamma=0.95, capacity=20000, clip_thres=0.2, shared_param=False, value_type="cat")
+
+
+def envs_per_gpu(workload):
+    return 1024 if workload.startswith("evopf") else ENVS_PER_GPU
 
 
 def make_trainer(n_envs, device, max_epochs, capacity=None, workload="cart_ddpg", updates_per_step=None):
     from rpo_amd import gym_shim
     from rpo_amd.algo import RPODDPG, RPOSAC
-    from rpo_amd.env import CartSafeEnv, SpringPendulumEnv
+    from rpo_amd.env import CartSafeEnv, EVOPFEnv, SpringPendulumEnv
     np.random.seed(123)
     torch.manual_seed(123)                  # identical replicas on every rank
     envname, algo, over = WORKLOADS[workload]
-    env = gym_shim.TimeLimit(CartSafeEnv() if envname == "cart" else SpringPendulumEnv(), 200)
-    hp = dict(HP)
-    hp.update(over)
+    if envname == "evopf":
+        env, hp = EVOPFEnv(), dict(EVOPF_HP)
+    else:
+        env = gym_shim.TimeLimit(CartSafeEnv() if envname == "cart" else SpringPendulumEnv(), 200)
+        hp = dict(HP)
+        hp.update(over)
     if capacity is not None:
         hp["capacity"] = capacity
     cls = RPODDPG if algo == "ddpg" else RPOSAC
@@ -227,7 +239,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
 
-    n_total = ENVS_PER_GPU * world
+    EPG = envs_per_gpu(args.workload)
+    n_total = EPG * world
     total_iters = args.warmup + args.steps
     tr = make_trainer(n_total, device, total_iters, workload=args.workload)
     headline = args.workload == "cart_ddpg"
@@ -253,16 +266,16 @@ def main():
     value = n_total * args.steps / elapsed
 
     result = {
-        "metric": "env-steps/sec (whole node), SafeCartpole-v0 (CartSafe-v0) RPODDPG, rollout + one batch-256 "
-                  "constrained policy update per vector step",
+        "metric": "env-steps/sec (whole node), %s, rollout + one batch-256 constrained policy update per vector step"
+                  % ("SafeCartpole-v0 (CartSafe-v0) RPODDPG" if headline else args.workload),
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("CartSafe-v0 RPODDPG, %d vectorised envs per MI355X, scripts/cart_exp.py "
                                 "hyper-parameters, update batch 256 every vector step (reference cadence), replay "
-                                "capacity 20000 per env" % ENVS_PER_GPU) if headline else
-                               "%s, %d vectorised envs per MI355X (extra measurement, not the headline)" % (args.workload, ENVS_PER_GPU),
-                   "envs_per_gpu": ENVS_PER_GPU, "global_envs": n_total, "update_batch": 256,
+                                "capacity 20000 per env" % EPG) if headline else
+                               "%s, %d vectorised envs per MI355X (extra measurement, not the headline)" % (args.workload, EPG),
+                   "envs_per_gpu": EPG, "global_envs": n_total, "update_batch": 256,
                    "parallelism": "dp%d (env shards, RCCL all-reduce of the flat gradient bucket)" % world,
                    "hip_graph": bool(tr._graphs.enabled)},
         "constraint_violation_rate": tr.viol_rate,
@@ -271,7 +284,7 @@ def main():
 
     if rank == 0:
         # (i) rollout-only throughput next to the headline, so that the cadence is visible
-        ro = make_trainer(ENVS_PER_GPU, device, 10 ** 9, capacity=64, workload=args.workload) if world == 1 else None
+        ro = make_trainer(EPG, device, 10 ** 9, capacity=64, workload=args.workload) if world == 1 else None
         if ro is not None:
             ro.vec.reset()
             ro.run_steps(50, train=False)
@@ -279,11 +292,11 @@ def main():
             t1 = time.perf_counter()
             ro.run_steps(1000, train=False)
             torch.cuda.synchronize()
-            result["rollout_only_env_steps_per_s"] = ENVS_PER_GPU * 1000 / (time.perf_counter() - t1)
-            # (iii) UTD-matched: one batch-256 update per ENV step as in the reference, i.e. ENVS_PER_GPU updates per
+            result["rollout_only_env_steps_per_s"] = EPG * 1000 / (time.perf_counter() - t1)
+            # (iii) UTD-matched: one batch-256 update per ENV step as in the reference, i.e. EPG updates per
             # vector step -- a bounded sample of vector steps
-            utd = make_trainer(ENVS_PER_GPU, device, 10 ** 9, capacity=256, workload=args.workload,
-                               updates_per_step=ENVS_PER_GPU)
+            utd = make_trainer(EPG, device, 10 ** 9, capacity=256, workload=args.workload,
+                               updates_per_step=EPG)
             utd.vec.reset()
             utd.run_steps(1)
             torch.cuda.synchronize()
@@ -291,8 +304,8 @@ def main():
             utd.run_steps(4)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t2
-            result["utd_matched_env_steps_per_s"] = ENVS_PER_GPU * 4 / dt
-            result["utd_matched_updates_per_s"] = ENVS_PER_GPU * 4 / dt
+            result["utd_matched_env_steps_per_s"] = EPG * 4 / dt
+            result["utd_matched_updates_per_s"] = EPG * 4 / dt
             del utd
             del ro
         if not args.no_clinic and world == 1 and tr.fused is not None and headline:

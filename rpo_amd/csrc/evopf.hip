@@ -219,26 +219,30 @@ __global__ __launch_bounds__(RPO_WAVE) void evopf_complete_bwd_kernel(int n, con
     }
     sync();
     // step 1 (:889-891): d_int = inv(J_newton)^T dl_dy_total[newton vars]
-    for (int e = tid; e < NN * NN; e += RPO_WAVE) {
-        const int r = e / NN, c = e - r * NN;
-        w.M[r][c] = jac_entry(w, kKeep[c], kNewtonVars[r]);             // transposed
-    }
-    if (tid < NN) w.M[tid][NN] = w.vec[kNewtonVars[tid] - VM0];
+    float col[NN];                                                      // column tid of [J_newton^T | rhs]
+#pragma unroll
+    for (int r = 0; r < NN; ++r)
+        col[r] = tid < NN ? jac_entry(w, kKeep[tid], kNewtonVars[r]) : (tid == NN ? w.vec[kNewtonVars[r] - VM0] : 0.0f);
+    gauss_jordan<NN, 0>(col);
     sync();
-    gauss_jordan(w, NN, NN + 1);
+    if (tid == NN) {
+#pragma unroll
+        for (int r = 0; r < NN; ++r) w.old[r] = col[r];                 // d_int
+    }
+    sync();
     if (tid < NP) {
         float g;
         if (tid < 4) {                                                  // pg at pv gens (:894) + direct term (:907)
-            g = -w.M[tid][NN] + w.dir[PG0 + 1 + tid];
+            g = -w.old[tid] + w.dir[PG0 + 1 + tid];
         } else if (tid < 9) {                                           // vm at generator buses (:895-896)
             const int var = VM0 + kSpv[tid - 4];
             float acc = 0.0f;
-            for (int r = 0; r < NN; ++r) acc += jac_entry(w, kKeep[r], var) * w.M[r][NN];
+            for (int r = 0; r < NN; ++r) acc += jac_entry(w, kKeep[r], var) * w.old[r];
             g = -acc + w.vec[var - VM0];
         } else if (tid == 9) {                                          // pe at the slack generator (:898)
             g = w.dir[PG0] + w.dir[PE0];
         } else {                                                        // pe at pv gens (:897)
-            g = w.M[tid - 10][NN] + w.dir[PE0 + tid - 9];
+            g = w.old[tid - 10] + w.dir[PE0 + tid - 9];
         }
         grad_ap[(size_t)i * NP + tid] = g;
     }

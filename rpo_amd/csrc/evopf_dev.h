@@ -3,9 +3,12 @@
 // Every lane needs dense linear algebra on its own small matrices -- the 22x22 Newton system of the power-flow
 // equation solver (PFFunction, evopf.py:786-855) and the 28x28 block of the equality Jacobian whose inverse defines the
 // GRG direction (ineq_partial_grad, evopf.py:596-612).  A thread per lane would keep ~1200 floats of matrix in scratch
-// memory; instead the 64 threads of a wave share one lane: the matrix lives in LDS (28 x 44 floats), a thread owns a
-// column during elimination, pivot search and the stop tests are wave reductions.  Workgroup = 1 wave, so the barriers
-// below only order LDS traffic of that wave.
+// memory; instead the 64 threads of a wave share one lane and THREAD c KEEPS COLUMN c OF THE MATRIX IN ITS REGISTERS
+// (28 floats): it evaluates its own Jacobian column, Gauss-Jordan broadcasts the pivot column with v_readlane (the pivot
+// index is a compile-time constant once the pivot loop is unrolled), row swaps are predicated register moves, and only
+// the small result vectors go through LDS.  (A first version eliminated in LDS: every `M[r][c] -= M[r][k] * M[k][c]`
+// waited out the LDS round trip because loads and stores to the same array cannot be reordered -- 60 us per GRG
+// iteration, measured; see DESIGN.md.)  Workgroup = 1 wave, so the barriers below only order LDS traffic of that wave.
 //
 // The network is the IEEE 14-bus case exactly like the reference (case14 hard-wired at evopf.py:211, eq_num = 28 and
 // ineq_num = 58 hard-coded at :336-337): the bus classification is compiled in, every number (admittances, limits, costs,
@@ -18,7 +21,6 @@ namespace rpo_evopf_dev {
 constexpr int NB = 14, NG = 5, NE = 5, NY = RPO_EVOPF_ACTION, NS = RPO_EVOPF_STATE, NEQ = 28, NINEQ = 58, NP = 14;
 constexpr int PG0 = 0, QG0 = 5, VM0 = 10, VA0 = 24, PE0 = 38;      // blocks of the action vector, evopf.py:278-282
 constexpr int NO = 28, NPV = 15, NN = 22;                          // other vars, partial vars (incl. slack angle), Newton
-constexpr int LD = 44;                                             // leading dimension of the LDS matrix
 constexpr int T = 24, NAHEAD = 24;
 // Battery(...) of evopf.py:243 (per unit)
 constexpr float kBLow = 0.1f, kBHigh = 0.8f, kBPmin = -0.2f, kBPmax = 0.2f, kEtaIn = 0.9f, kEtaOut = 0.9f;
@@ -39,6 +41,11 @@ __device__ constexpr int kOtherVars[NO] = {0, 5, 6, 7, 8, 9, 13, 14, 16, 18, 19,
 // column of variable v in the elimination matrix [J_other | J_partial]
 __device__ constexpr int kColOf[NY] = {0, 28, 29, 30, 31, 1, 2, 3, 4, 5, 32, 33, 34, 6, 7, 35, 8, 36, 9, 10, 11, 12, 13, 14,
                                        37, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 38, 39, 40, 41, 42};
+// Equation order used for the 28 x 28 elimination: the first six "other" variables (slack pg, qg) appear in exactly
+// one equation each with coefficient 1 (P at the slack bus, Q at the generator buses), so with these rows first the
+// leading 6 x 6 block is the identity and the elimination starts at pivot 6; the rest are the Newton equations.
+__device__ constexpr int kRowOrder[NEQ] = {0, 14, 15, 16, 19, 21, 1, 2, 5, 7, 3, 4, 6, 8, 9, 10, 11, 12, 13,
+                                           17, 18, 20, 22, 23, 24, 25, 26, 27};
 // Newton system (evopf.py:809-816): P at pv, P at pq, Q at pq  x  vm at pq, va at pv, va at pq
 __device__ constexpr int kKeep[NN] = {1, 2, 5, 7, 3, 4, 6, 8, 9, 10, 11, 12, 13, 17, 18, 20, 22, 23, 24, 25, 26, 27};
 __device__ constexpr int kNewtonVars[NN] = {13, 14, 16, 18, 19, 20, 21, 22, 23, 25, 26, 29, 31,
@@ -46,7 +53,7 @@ __device__ constexpr int kNewtonVars[NN] = {13, 14, 16, 18, 19, 20, 21, 22, 23, 
 
 struct Ws {                       // per-wave workspace in LDS
     float c[RPO_EVOPF_CONSTS_LEN];
-    float M[NEQ][LD];
+    float D[NO][NPV + 1];         // inv(J_other) J_partial = -dynz_dz (evopf.py:598)
     float s[NS + 3];
     float a[NY + 1];
     float cs[NB], sn[NB], vr[NB], vi[NB], t1[NB], t2[NB];
@@ -169,34 +176,34 @@ __device__ __forceinline__ float jac_entry(const Ws& w, int row, int var) {
     return (d * pi_ * w.t2[i]) + w.vr[i] * (yi * p + yr * q) - (d * qi_ * w.t1[i]) - w.vi[i] * (yr * p - yi * q);
 }
 
-// Gauss-Jordan with partial pivoting on M[0..n) x [0..ncols): the leading n x n block becomes the identity, the trailing
-// columns hold inv(block) @ (their original content).  Thread c owns column c (ncols <= 64).
-__device__ __forceinline__ void gauss_jordan(Ws& w, int n, int ncols) {
-    const int tid = threadIdx.x;
-    for (int k = 0; k < n; ++k) {
-        float best = (tid >= k && tid < n) ? w.M[tid][k] : 0.0f;
-        float mag = (tid >= k && tid < n) ? fabsf(best) : -1.0f;
-        int idx = tid;
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// Gauss-Jordan with partial pivoting, matrix distributed one column per thread: col[r] = M[r][threadIdx.x].  On return
+// the leading N x N block is the identity and every further column holds inv(block) @ (its original content).  The
+// first K0 columns must already be unit vectors e_0 .. e_{K0-1}.  Threads whose column is not part of the system must
+// pass zeros.  Fully unrolled: all register indices and the broadcast lane are compile-time constants.
+template <int N, int K0>
+__device__ __forceinline__ void gauss_jordan(float (&col)[N]) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float om = __shfl_xor(mag, off, RPO_WAVE), ob = __shfl_xor(best, off, RPO_WAVE);
-            const int oi = __shfl_xor(idx, off, RPO_WAVE);
-            if (om > mag || (om == mag && oi < idx)) { mag = om; best = ob; idx = oi; }
-        }
-        const int p = idx;                                     // wave-uniform pivot row, `best` its (signed) value
-        float mkc = 0.0f;
-        if (tid >= k && tid < ncols) {                         // swap rows k <-> p, normalise the pivot row
-            const float xk = w.M[k][tid], xp = w.M[p][tid];
-            mkc = xp / best;
-            w.M[p][tid] = xk;
-            w.M[k][tid] = mkc;
-        }
-        sync();
-        if (tid > k && tid < ncols) {
-            for (int r = 0; r < n; ++r)
-                if (r != k) w.M[r][tid] -= w.M[r][k] * mkc;
-        }
-        sync();
+    for (int k = K0; k < N; ++k) {
+        float best = col[k];                                   // pivot search runs in every lane, lane k's result counts
+        int p = k;
+#pragma unroll
+        for (int r = k + 1; r < N; ++r)
+            if (fabsf(col[r]) > fabsf(best)) { best = col[r]; p = r; }
+        p = __builtin_amdgcn_readlane(p, k);
+        best = lane_bcast(best, k);
+        float xk = col[k];                                     // swap rows k <-> p of this thread's column
+#pragma unroll
+        for (int r = k + 1; r < N; ++r)
+            if (r == p) { const float t = col[r]; col[r] = xk; xk = t; }
+        const float mkc = xk / best;                           // normalised pivot row; 0 in finished columns, 1 in column k
+        col[k] = mkc;
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+            if (r != k) col[r] -= lane_bcast(col[r], k) * mkc;
     }
 }
 
@@ -219,16 +226,19 @@ __device__ __forceinline__ int complete_partial(Ws& w, float zj, float tol, int 
     for (; it < max_iters;) {
         flows(w);
         eq_resid(w);
-        for (int e = tid; e < NN * NN; e += RPO_WAVE) {
-            const int r = e / NN, c = e - r * NN;
-            w.M[r][c] = jac_entry(w, kKeep[r], kNewtonVars[c]);
+        float col[NN];                                         // column tid of [J_newton | g]
+#pragma unroll
+        for (int r = 0; r < NN; ++r)
+            col[r] = tid < NN ? jac_entry(w, kKeep[r], kNewtonVars[tid]) : (tid == NN ? w.eq[kKeep[r]] : 0.0f);
+        gauss_jordan<NN, 0>(col);
+        if (tid == NN) {
+#pragma unroll
+            for (int r = 0; r < NN; ++r) w.vec[r] = col[r];    // delta = inv(J) g (:832)
         }
-        if (tid < NN) w.M[tid][NN] = w.eq[kKeep[tid]];
         sync();
-        gauss_jordan(w, NN, NN + 1);
         float d2 = 0.0f;
         if (tid < NN) {
-            const float d = w.M[tid][NN];
+            const float d = w.vec[tid];
             w.a[kNewtonVars[tid]] -= d;
             d2 = d * d;
         }
@@ -245,16 +255,17 @@ __device__ __forceinline__ int complete_partial(Ws& w, float zj, float tol, int 
     return it;
 }
 
-// ineq_partial_grad (evopf.py:596-612) of (w.s, w.a) into w.dir[43]; flows() must be current.  Uses w.M.
+// ineq_partial_grad (evopf.py:596-612) of (w.s, w.a) into w.dir[43]; flows() must be current.
 __device__ __forceinline__ void ineq_partial_grad(Ws& w) {
     RPO_FP_STRICT
     const int tid = threadIdx.x;
-    for (int e = tid; e < NEQ * NY; e += RPO_WAVE) {
-        const int r = e / NY, v = e - r * NY;
-        w.M[r][kColOf[v]] = jac_entry(w, r, v);
-    }
+    // thread c owns column c of [J_other | J_partial] (variable kOtherVars[c] or kPartialVars[c - 28])
+    const int var = tid < NO ? kOtherVars[tid] : (tid < NY ? kPartialVars[tid - NO] : 0);
+    float col[NEQ];
+#pragma unroll
+    for (int r = 0; r < NEQ; ++r) col[r] = tid < NY ? jac_entry(w, kRowOrder[r], var) : 0.0f;
     ineq_resid(w);                                             // (syncs)
-    gauss_jordan(w, NO, NY);                                   // M[:, 28 + p] = inv(J_o) J_p = -dynz_dz
+    gauss_jordan<NEQ, 6>(col);                                 // columns 28.. now hold inv(J_o) J_p = -dynz_dz (:598)
     if (tid < NY) {                                            // ineq_grad_new (:590-594): +-1 per violated bound
         float g = 0.0f;
         if (tid < QG0) g = (w.ineq[tid] > 0.0f ? 1.0f : 0.0f) - (w.ineq[5 + tid] > 0.0f ? 1.0f : 0.0f);
@@ -264,16 +275,21 @@ __device__ __forceinline__ void ineq_partial_grad(Ws& w) {
         w.vec[tid] = g;
     }
     sync();
-    if (tid < NPV) {                                           // indirect + direct (:603-606)
+    if (tid >= NO && tid < NY) {                               // indirect + direct (:603-606), one partial var per thread
         float acc = 0.0f;
-        for (int o = 0; o < NO; ++o) acc += -w.M[o][NO + tid] * w.vec[kOtherVars[o]];
-        w.fp[tid] = acc + w.vec[kPartialVars[tid]];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            acc += -col[o] * w.vec[kOtherVars[o]];
+            w.D[o][tid - NO] = col[o];
+        }
+        w.fp[tid - NO] = acc + w.vec[var];
     }
     sync();
     if (tid < NPV) w.dir[kPartialVars[tid]] = w.fp[tid];
     if (tid < NO) {                                            // (:610)
         float acc = 0.0f;
-        for (int p = 0; p < NPV; ++p) acc += -w.M[tid][NO + p] * w.fp[p];
+#pragma unroll
+        for (int p = 0; p < NPV; ++p) acc += -w.D[tid][p] * w.fp[p];
         w.dir[kOtherVars[tid]] = acc;
     }
     sync();

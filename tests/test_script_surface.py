@@ -31,6 +31,14 @@ SNIPPET = textwrap.dedent('''
                  corr_lr=2e-3, eps=1e-2, eps_start=1e-2, eps_epoch=20000, eval_lr=2e-3, eval_steps=50, grad_eps=0.1,
                  corr_momentum=0.0, policy_fre=4, max_epochs=20000, alpha=0.01, automatic_entropy_tuning=False,
                  capacity=200, shared_param=False, value_type="add", clip_thres=0.2, embed_dim=128, hidden_dim=256)
+    env3 = gym.make("EVOPF-v0")                                      # scripts/evopf_exp.py:27-31
+    assert (env3.state_dim, env3.action_dim, env3.eq_num, env3.ineq_num, env3.volatile) == (57, 43, 28, 58, True)
+    assert list(env3.partial_actions) == [1, 2, 3, 4, 10, 11, 12, 15, 17, 38, 39, 40, 41, 42]
+    evopf = RPODDPG(env3, "./test", name="evopf_ddpg", logger=logger, batch_size=256, max_steps=10, warmup=0,
+                    lr_dual=2e-2, corr_lr=1e-4, eps=0.0001, eps_start=0.0001, eps_epoch=20000, eval_lr=1e-4,
+                    eval_steps=50, grad_eps=0.02, corr_momentum=0.0, policy_fre=4, ex_action_dim=1, gamma=0.95,
+                    max_epochs=40000, capacity=200, clip_thres=0.2, shared_param=False, value_type="cat")
+    assert evopf.agent.actor.affines[-1].weight.shape[0] == 14
     if not torch.cuda.is_available():
         try:
             agent.run()
