@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from oracle import cartsafe as cs
+from oracle import evopf as oe
 from oracle import pendulum as pd
 from oracle import philox, train_ops
 from rpo_amd._lib import CONST
@@ -160,6 +161,99 @@ class CartSafeKernels(_EnvKernels):
             _put(grad_action, ga)
         if grad_nu is not None:
             grad_nu += torch.as_tensor(gnu)
+
+
+class EvopfKernels(_EnvKernels):
+    """oracle/evopf.py behind the kernel-set interface of rpo_amd.ops.EvopfKernels (float64 arithmetic)."""
+    name = "EVOPF-v0"
+    obs_dim = internal_dim = 57
+    action_dim, partial_dim, eq_num, ineq_num = 43, 14, 28, 58
+    row_floats = CONST["RPO_EVOPF_ROW"]
+    cols = dict(state=(0, 57), action=(57, 100), next_state=(100, 157), reward=(157, 158), done=(158, 159),
+                eq_viol=(159, 187), ineq_viol=(187, 245))
+    episode_steps = 24
+    partial = 0
+
+    def __init__(self, consts):
+        self.consts = np.asarray(consts, dtype=np.float32)
+        C = CONST
+        np.testing.assert_allclose(self.consts[C["RPO_EVOPF_C_YR"]:C["RPO_EVOPF_C_YR"] + 196].reshape(14, 14), oe.GRID.Yr, atol=1e-6)
+
+    def reset(self, internal, obs, ep_len, ep_ret, ep_count, seed, env_id_base):
+        n = internal.shape[0]
+        _put(internal, oe.reset(seed, np.arange(n) + env_id_base, _np(ep_count).astype(np.int64)))
+        ep_len.zero_()
+        ep_ret.zero_()
+
+    def step(self, internal, obs, action, ep_len, ep_ret, ep_count, rows, cap_steps, stats, ctrl, max_episode_steps,
+             auto_reset, viol_thresh, seed, env_id_base):
+        n, t = internal.shape[0], self._t(ctrl)
+        s, a = _np(internal).astype(np.float64), _np(action).astype(np.float64)
+        ids = np.arange(n) + env_id_base
+        out = oe.step(s, a, _np(ep_len).astype(np.int64), _np(ep_count).astype(np.int64), seed, ids, auto_reset=False)
+        mask = self._finish_step(n, s.astype(np.float32), _np(action), out["next_state"].astype(np.float32),
+                                 out["reward"], out["done"], out["eq_viol"], out["ineq_viol"], ep_len, ep_ret, ep_count,
+                                 rows, cap_steps, stats, ctrl, max_episode_steps, auto_reset, viol_thresh, t)
+        fresh = oe.reset(seed, ids, _np(ep_count).astype(np.int64))
+        _put(internal, np.where(mask[:, None], fresh, out["next_state"]))
+
+    def _explore14(self, obs, ap_raw, noise, n, mode, eps_start, eps_end, eps_decay, seed, base, t):
+        lo, hi = oe.partial_box(_np(obs).astype(np.float64))
+        eps_t = max(eps_end, eps_start - eps_decay * t)
+        ids = np.arange(n) + base
+        if mode == NOISE_UNIFORM:
+            w = np.concatenate([philox.draw(seed, ids, t, philox.STREAM_ACT, c) for c in range(4)], axis=1)[:, :14]
+            scale = (hi - lo) * 0.5
+            return scale * (2.0 * philox.u01(w) - 1.0) + (lo + scale)
+        ap = _np(ap_raw).reshape(n, 14).astype(np.float64)
+        if mode == NOISE_EXPLICIT:
+            return np.clip(ap + eps_t * _np(noise).reshape(n, 14), lo, hi)
+        if mode == NOISE_PHILOX:
+            z = np.zeros((n, 14))
+            for c in range(7):
+                w = philox.draw(seed, ids, t, philox.STREAM_ACT, c)
+                z[:, 2 * c], z[:, 2 * c + 1] = philox.normal(w[:, 0], w[:, 1]), philox.normal(w[:, 2], w[:, 3])
+            return np.clip(ap + eps_t * z, lo, hi)
+        if mode == NOISE_CLIP_ONLY:
+            return np.clip(ap, lo, hi)
+        return ap
+
+    def act_project(self, obs, ap_raw, noise, action, iters, noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi,
+                    max_steps, corr_lr, corr_eps, corr_momentum, seed=0, env_id_base=0, ctrl=None, stats=None):
+        n = action.shape[0]
+        s = _np(obs).astype(np.float64)
+        ap = self._explore14(obs, ap_raw, noise, n, noise_mode, eps_start, eps_end, eps_decay, seed, env_id_base, self._t(ctrl))
+        a, it = oe.project(s, ap, max_steps, corr_lr, corr_eps, corr_momentum)
+        _put(action, a)
+        if iters is not None:
+            _put(iters, it)
+        self._stat_iters(stats, ctrl, it)
+
+    def complete_bwd(self, obs, grad_action, grad_ap, action=None):
+        a = _np(action).astype(np.float64)
+        jac = oe.eq_jac(a)
+        jn = jac[:, oe.GRID.keep_constr][:, :, oe.GRID.newton_vars]
+        _put(grad_ap, oe.complete_partial_bwd(_np(grad_action).astype(np.float64), jac, jn))
+
+    def resid(self, obs, action, eq_out, ineq_out):
+        s, a = _np(obs).astype(np.float64), _np(action).astype(np.float64)
+        if eq_out is not None:
+            _put(eq_out, oe.eq_resid(s, a))
+        if ineq_out is not None:
+            _put(ineq_out, oe.ineq_resid(s, a))
+
+    def ineq_partial_grad(self, obs, action, step_out):
+        _put(step_out, oe.ineq_partial_grad(_np(obs).astype(np.float64), _np(action).astype(np.float64)))
+
+    def lagrangian(self, action, nu, scale, loss_out, grad_action, grad_nu, obs=None):
+        s, a, v = _np(obs).astype(np.float64), _np(action).astype(np.float64), _np(nu).astype(np.float64)
+        g = oe.ineq_resid(s, a)
+        dist = np.maximum(g, 0.0)
+        loss_out += float(scale * (dist @ v).sum())
+        if grad_action is not None:
+            _put(grad_action, scale * (((g > 0) * v) @ oe.ineq_jac()))
+        if grad_nu is not None:
+            grad_nu += torch.as_tensor(scale * dist.sum(axis=0), dtype=grad_nu.dtype)
 
 
 class PendulumKernels(_EnvKernels):

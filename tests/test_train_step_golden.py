@@ -206,3 +206,37 @@ def test_trainer_host_logic_matches_reference_update(golden, algo, envname, fuse
     torch.set_num_threads(1)
     out = run_product_update(golden, algo, envname, ob, torch.device("cpu"), fused=fused)
     check_product_update(*out, algo, envname)
+
+
+def test_evopf_trainer_host_logic_matches_reference_update(golden):
+    """RPODDPG on EVOPF-v0 (torch modules + autograd, volatile box, 14 basic actions) driven by the oracle backend:
+    four updates against the fixture recorded from the reference's evopf.py on the pypower stand-in
+    (tests/golden/make_evopf_golden.py).  Parameters 5e-6 (critic) / 2e-5 (actor: gradient through the Newton inverse)."""
+    torch.set_num_threads(1)
+    g, tr, closs, aloss, proxy = run_product_update(golden, "ddpg", "evopf", ob, torch.device("cpu"), fused=False)
+    ag = tr.agent
+    np.testing.assert_allclose(closs, g["critic_losses"], rtol=1e-4)
+    np.testing.assert_allclose(aloss, g["actor_losses"], rtol=1e-3, atol=1e-5)
+    for name, net, tol in (("critic4", ag.critic, 5e-6), ("critic_target4", ag.critic_target, 5e-6),
+                           ("actor4", ag.actor, 2e-5), ("actor_target4", ag.actor_target, 2e-5)):
+        for k, v in sd(g, name).items():
+            np.testing.assert_allclose(net.state_dict()[k].cpu().numpy(), v, rtol=0, atol=tol, err_msg=name + "." + k)
+    np.testing.assert_allclose(ag.nju.weight.detach().cpu().numpy(), g["nju4"], rtol=1e-4, atol=1e-6)
+    assert not proxy.noises and not proxy.idx
+
+
+def test_evopf_iterations_on_oracle_backend():
+    """Whole iterations (rollout with Philox exploration, day roll-over after 24 steps, replay, updates) of the shipped
+    trainer on EVOPF-v0 through the oracle backend: bookkeeping and statistics."""
+    torch.set_num_threads(1)
+    torch.manual_seed(3)
+    tr = build_trainer("ddpg", "evopf", ob, torch.device("cpu"), fused=False, num_envs=4, use_graph=False, capacity=32)
+    tr.vec.reset()
+    tr.run_steps(26)
+    tr._harvest()
+    assert int(tr.vec.ctrl[0]) == 26 and (tr.vec.ep_count == 1).all() and (tr.vec.ep_len == 2).all()
+    assert tr.env_steps == 4 * 26 and 0.0 <= tr.viol_rate <= 1.0
+    c = tr.kernels.cols
+    rows = tr.buffer.rows.view(32, 4, -1)
+    assert (rows[23, :, c["done"][0]] == 1).all() and (rows[:23, :, c["done"][0]] == 0).all()
+    assert float(rows[24, :, c["state"][0] + 28:c["state"][0] + 33].sub(0.2).abs().max()) < 1e-6     # fresh batteries
