@@ -267,11 +267,12 @@ def test_update_matches_reference_on_gpu():
     assert np.abs(g["nju4"] - 0.1).max() > 1e-2 and not proxy.noises and not proxy.idx
 
 
-def _run(n_envs, iters, use_graph, seed_all=5):
+def _run(n_envs, iters, use_graph, seed_all=5, algo="ddpg", **extra):
     import test_train_step_golden as tsg
     from rpo_amd import ops
     torch.manual_seed(seed_all)
-    tr = tsg.build_trainer("ddpg", "evopf", ops, torch.device("cuda"), fused=False, num_envs=n_envs, use_graph=use_graph)
+    tr = tsg.build_trainer(algo, "evopf", ops, torch.device("cuda"), fused=False, num_envs=n_envs, use_graph=use_graph,
+                           **extra)
     tr.vec.reset()
     tr.run_steps(iters)
     torch.cuda.synchronize()
@@ -289,3 +290,20 @@ def test_training_iterations_graph_equals_eager_and_episodes_roll_over():
     assert a.env_steps == 64 * 30 and 0.0 <= a.viol_rate <= 1.0
     res = a.eval()
     assert len(res) == 10 and np.isfinite(res).all()
+
+
+def test_sac_on_evopf_runs_and_replays():
+    """scripts/evopf_exp_sac.py's configuration: RPOSAC with a 14-dimensional squashed-Gaussian policy and the
+    state-dependent box; hipGraph replay equals the eager run, stored transitions stay near the equality manifold."""
+    kw = dict(lr_actor=1e-4, lr_critic=3e-4, grad_eps=0.1, init_lamb=0.0, init_nju=0.0, alpha=0.001,
+              automatic_entropy_tuning=False, fixed=False)            # scripts/evopf_exp_sac.py:30-33
+    a = _run(32, 12, use_graph=False, algo="sac", **kw)
+    b = _run(32, 12, use_graph=True, algo="sac", **kw)
+    assert torch.equal(a.vec.internal, b.vec.internal) and torch.equal(a.agent.flat.data, b.agent.flat.data)
+    c = a.kernels.cols
+    rows = a.buffer.rows[:12 * 32]
+    # GRG steps leave the manifold at second order (and at first order along pe, hazard E1): small, not zero
+    assert float(rows[:, c["eq_viol"][0]:c["eq_viol"][1]].abs().max()) < 1e-2
+    lo, hi = a.base_env.update(rows[:, c["state"][0]:c["state"][1]].contiguous())
+    ap = rows[:, c["action"][0]:c["action"][1]][:, a.base_env.partial_actions]
+    assert bool((ap[:, :4] >= lo[:, :4] - 1e-3).all()) and bool((ap[:, :4] <= hi[:, :4] + 1e-3).all())
