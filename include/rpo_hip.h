@@ -311,6 +311,9 @@ int rpo_polyak(long long n, const float* param, float* target, float tau, void* 
 typedef struct {
     const float *Ws, *bs, *Wa, *ba, *W0, *b0, *W1, *b1, *W1b, *b1b;
     int S, A, E, H, n_out, cat;
+    int head_dim; /* outputs per head: 0 / 1 = scalar heads (out [n, n_out]); 2..16 = W1_k is [head_dim, H], b1_k
+                   * [head_dim], out [n, n_out * head_dim] head-major, raw (out_mode must be 0): the 14 basic actions of
+                   * EVOPF-v0, whose state-dependent tanh box is applied by rpo_evopf_act_project (ap_is_raw) */
 } rpo_mlp;
 typedef struct {
     float *Ws, *bs, *Wa, *ba, *W0, *b0, *W1, *b1, *W1b, *b1b;

@@ -25,7 +25,7 @@ using rpo_cart_dev::cart_explore_project;
 using rpo_cart_dev::load_consts;
 
 Mlp to_dev(const rpo_mlp* h) {
-    return Mlp{h->Ws, h->bs, h->Wa, h->ba, h->W0, h->b0, h->W1, h->b1, h->W1b, h->b1b, h->S, h->A, h->E, h->H, h->n_out, h->cat};
+    return Mlp{h->Ws, h->bs, h->Wa, h->ba, h->W0, h->b0, h->W1, h->b1, h->W1b, h->b1b, h->S, h->A, h->E, h->H, h->n_out, h->cat, h->head_dim};
 }
 
 // ------------------------------------------------------------------------------------------------------ rollout
@@ -187,7 +187,7 @@ int launch_rollout(const RolloutArgs<ENV>& args, const typename ENV::Consts& c, 
 }
 
 int check_actor(const Mlp& actor, int obs_dim, int gauss) {
-    if (actor.S != obs_dim || actor.A != 0 || actor.n_out != (gauss ? 2 : 1) || actor.cat || actor.H != 256 || !actor.Ws ||
+    if (actor.hd > 1 || actor.S != obs_dim || actor.A != 0 || actor.n_out != (gauss ? 2 : 1) || actor.cat || actor.H != 256 || !actor.Ws ||
         !actor.W0 || !actor.W1 || (gauss && !actor.W1b))
         return RPO_ERR_ARG;
     return 0;

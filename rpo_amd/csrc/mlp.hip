@@ -57,6 +57,33 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_forward_kernel(FwdArgs p) {
     }
 }
 
+// Multi-output networks (hd > 1, e.g. the 14 basic actions of EVOPF-v0): same tile, MFMA head, raw outputs
+// [n, n_out * hd] (head-major); the state-dependent tanh box of such actors is applied by the env's own kernels.
+template <int EIN, int H>
+__global__ __launch_bounds__(kFwdThreads) void mlp_forward_wide_kernel(FwdArgs p) {
+    typedef TileLdsWide<EIN, H> Lds;
+    __shared__ Lds lds;
+    const Mlp& net = p.net;
+    const int row0 = blockIdx.x * kRows;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < kRows * net.S; idx += kFwdThreads) {
+        const int r = idx / net.S, i = idx - r * net.S;
+        lds.in_s[r * kInS + i] = (row0 + r < p.n) ? p.s[(size_t)(row0 + r) * p.s_stride + i] : 0.0f;
+    }
+    for (int idx = tid; idx < kRows * net.A; idx += kFwdThreads) {
+        const int r = idx / net.A, i = idx - r * net.A;
+        lds.in_a[r * kInA + i] = (row0 + r < p.n) ? p.a[(size_t)(row0 + r) * p.a_stride + i] : 0.0f;
+    }
+    TileWeights<EIN, H, 1> w;
+    tile_load_weights<EIN, H, 1>(net, w);
+    tile_compute<EIN, H, 1, Lds, true>(net, w, lds, row0, p.n, p.x0_save, p.h1_save, 0, 1.0f, 0.0f);
+    const int outs = net.n_out * net.hd;
+    if (tid < kRows * outs) {
+        const int r = tid / outs, o = tid - r * outs;
+        if (row0 + r < p.n) p.out[(size_t)(row0 + r) * outs + o] = lds.outw[r * kWideOut + o];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------- backward, rows
 // Per row tile: dh = (dout W1) * 1[h1 > 0]  -> global (for the weights pass) and LDS; dW1 / db1 / db0 partial sums
 // (one atomic per value per workgroup); dx0 = (dh W0) * 1[x0 > 0] -> global; optionally da = dx0_a Wa.
@@ -81,26 +108,54 @@ __global__ __launch_bounds__(kThreads) void mlp_bwd_rows_kernel(BwdArgs p) {
     constexpr int LDH = H + 4;
     __shared__ __attribute__((aligned(16))) float dh_s[kRows * LDH];
     __shared__ __attribute__((aligned(16))) float red[kRows * EIN];              // dx0 of the tile (waves add into it)
-    __shared__ float dout_s[kRows * 2];
+    __shared__ float dout_s[kRows * kWideOut];
     const Mlp& net = p.net;
     const int row0 = blockIdx.x * kRows;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < kRows * 2) {
-        const int r = tid >> 1, o = tid & 1;
-        dout_s[tid] = (o < net.n_out && row0 + r < p.n) ? p.dout[(size_t)(row0 + r) * net.n_out + o] : 0.0f;
+    const bool wide_head = net.hd > 1;
+    const int outs = wide_head ? net.n_out * net.hd : net.n_out;
+    if (!wide_head) {
+        if (tid < kRows * 2) {
+            const int r = tid >> 1, o = tid & 1;
+            dout_s[tid] = (o < net.n_out && row0 + r < p.n) ? p.dout[(size_t)(row0 + r) * net.n_out + o] : 0.0f;
+        }
+    } else {
+        for (int idx = tid; idx < kRows * outs; idx += kThreads) {
+            const int r = idx / outs, o = idx - r * outs;
+            dout_s[r * kWideOut + o] = (row0 + r < p.n) ? p.dout[(size_t)(row0 + r) * outs + o] : 0.0f;
+        }
     }
     __syncthreads();
     // ---- dh (thread = hidden column j); the batch reductions dW1 / db0 / db1 happen in the weights pass, in a fixed
     //      order, so that the whole backward is bitwise reproducible (no floating-point atomics anywhere)
     for (int j = tid; j < H; j += kThreads) {
-        const float w1a = net.W1[j], w1b = net.n_out > 1 ? net.W1b[j] : 0.0f;
+        if (!wide_head) {
+            const float w1a = net.W1[j], w1b = net.n_out > 1 ? net.W1b[j] : 0.0f;
 #pragma unroll
-        for (int r = 0; r < kRows; ++r) {
-            const bool live = row0 + r < p.n;
-            const float h = live ? p.h1[(size_t)(row0 + r) * H + j] : 0.0f;
-            const float d = (h > 0.0f) ? fmaf(dout_s[r * 2 + 1], w1b, dout_s[r * 2] * w1a) : 0.0f;
-            dh_s[r * LDH + j] = d;
-            if (live) p.dh[(size_t)(row0 + r) * H + j] = d;
+            for (int r = 0; r < kRows; ++r) {
+                const bool live = row0 + r < p.n;
+                const float h = live ? p.h1[(size_t)(row0 + r) * H + j] : 0.0f;
+                const float d = (h > 0.0f) ? fmaf(dout_s[r * 2 + 1], w1b, dout_s[r * 2] * w1a) : 0.0f;
+                dh_s[r * LDH + j] = d;
+                if (live) p.dh[(size_t)(row0 + r) * H + j] = d;
+            }
+        } else {
+            float d[kRows];
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) d[r] = 0.0f;
+            for (int o = 0; o < outs; ++o) {                       // fixed order over the outputs
+                const float wv = (o < net.hd ? net.W1 : net.W1b)[(size_t)(o < net.hd ? o : o - net.hd) * H + j];
+#pragma unroll
+                for (int r = 0; r < kRows; ++r) d[r] = fmaf(dout_s[r * kWideOut + o], wv, d[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) {
+                const bool live = row0 + r < p.n;
+                const float h = live ? p.h1[(size_t)(row0 + r) * H + j] : 0.0f;
+                const float v = (h > 0.0f) ? d[r] : 0.0f;
+                dh_s[r * LDH + j] = v;
+                if (live) p.dh[(size_t)(row0 + r) * H + j] = v;
+            }
         }
     }
     __syncthreads();
@@ -248,6 +303,44 @@ __global__ __launch_bounds__(kThreads) void mlp_bwd_weights_kernel(BwdArgs p) {
     const int b_lo = (int)(((long long)p.n * part) / 4), b_hi = (int)(((long long)p.n * (part + 1)) / 4);
     const int rb = (int)blockIdx.x - GEMM_BLOCKS;
     constexpr int HV_BLOCKS = H / 64;
+    if (rb < HV_BLOCKS && net.hd > 1) {
+        // multi-output head: db0[j], dW1_k[o][j] = sum_b dout[b][k*hd + o] relu(h1[b][j]), db1_k[o] = sum_b dout[b][k*hd + o]
+        if (p.first_layer_state_only) return;
+        __shared__ float wide[4][kWideOut + 1][64];
+        const int outs = net.n_out * net.hd;
+        const int j = rb * 64 + o;
+        float gb0 = 0.0f, gw[kWideOut];
+#pragma unroll
+        for (int q = 0; q < kWideOut; ++q) gw[q] = 0.0f;
+        for (int bb = b_lo; bb < b_hi; ++bb) {
+            gb0 += p.dh[(size_t)bb * H + j];
+            const float hr = fmaxf(p.h1[(size_t)bb * H + j], 0.0f);
+#pragma unroll
+            for (int q = 0; q < kWideOut; ++q)
+                if (q < outs) gw[q] = fmaf(p.dout[(size_t)bb * outs + q], hr, gw[q]);
+        }
+        wide[part][kWideOut][o] = gb0;
+#pragma unroll
+        for (int q = 0; q < kWideOut; ++q) wide[part][q][o] = gw[q];
+        __syncthreads();
+        if (part == 0) {
+            p.g.b0[j] += ((wide[0][kWideOut][o] + wide[1][kWideOut][o]) + wide[2][kWideOut][o]) + wide[3][kWideOut][o];
+            for (int q = 0; q < outs; ++q) {
+                float* dst = q < net.hd ? &p.g.W1[(size_t)q * H + j] : &p.g.W1b[(size_t)(q - net.hd) * H + j];
+                *dst += ((wide[0][q][o] + wide[1][q][o]) + wide[2][q][o]) + wide[3][q][o];
+            }
+        }
+        if (rb == 0) {
+            __syncthreads();
+            if (tid < outs) {                                      // db1: one owner per output, batch order
+                float s0 = 0.0f;
+                for (int b2 = 0; b2 < p.n; ++b2) s0 += p.dout[(size_t)b2 * outs + tid];
+                float* dst = tid < net.hd ? &p.g.b1[tid] : &p.g.b1b[tid - net.hd];
+                *dst += s0;
+            }
+        }
+        return;
+    }
     if (rb < HV_BLOCKS) {
         // hidden-layer vectors: db0[j] = sum_b dh[b][j]; dW1_k[j] = sum_b dout[b][k] relu(h1[b][j]); db1_k = sum_b dout[b][k]
         if (p.first_layer_state_only) return;
@@ -405,6 +498,7 @@ __global__ __launch_bounds__(RPO_BLOCK) void gauss_head_bwd_kernel(int n, const 
 
 int check_net(const Mlp& m) {
     if (m.S <= 0 || m.S > 64 || m.A < 0 || m.A > 48 || m.n_out < 1 || m.n_out > 2) return RPO_ERR_ARG;
+    if (m.hd < 0 || m.hd > 16) return RPO_ERR_ARG;
     if (!m.Ws || !m.bs || !m.W0 || !m.b0 || !m.W1 || !m.b1 || (m.A > 0 && (!m.Wa || !m.ba))) return RPO_ERR_NULL;
     if (m.n_out > 1 && (!m.W1b || !m.b1b)) return RPO_ERR_NULL;
     if (m.cat && m.A == 0) return RPO_ERR_ARG;
@@ -433,12 +527,25 @@ int rpo_mlp_forward(const rpo_mlp* net_host, int n, const float* s, int s_stride
     if (!net_host) return RPO_ERR_NULL;
     Mlp net{net_host->Ws, net_host->bs, net_host->Wa, net_host->ba, net_host->W0, net_host->b0, net_host->W1,
             net_host->b1, net_host->W1b, net_host->b1b, net_host->S, net_host->A, net_host->E, net_host->H,
-            net_host->n_out, net_host->cat};
+            net_host->n_out, net_host->cat, net_host->head_dim};
     if (int e = check_net(net)) return e;
     if (n <= 0 || s_stride < net.S || (net.A > 0 && a_stride < net.A)) return RPO_ERR_ARG;
     if (!s || !out || (net.A > 0 && !a)) return RPO_ERR_NULL;
     const int ein = net.cat ? 2 * net.E : net.E;
     FwdArgs args{net, n, s, s_stride, a, a_stride, out, x0_save, h1_save, out_mode, scale, base};
+    if (net.hd > 1) {
+        if (out_mode != 0) return RPO_ERR_ARG;
+#define RPO_MLP_FWD_WIDE(EIN_, H_)                                                                                    \
+        if (ein == EIN_ && net.H == H_) {                                                                             \
+            hipLaunchKernelGGL((mlp_forward_wide_kernel<EIN_, H_>), dim3((n + kRows - 1) / kRows), dim3(kFwdThreads), \
+                               0, (hipStream_t)stream, args);                                                         \
+            RPO_LAUNCH_CHECK();                                                                                       \
+            return 0;                                                                                                 \
+        }
+        RPO_MLP_FWD_WIDE(128, 256)
+        RPO_MLP_FWD_WIDE(256, 256)
+        return RPO_ERR_ARG;
+    }
     // 64 rows per workgroup once that still fills the chip (and the inputs fit the narrow LDS tiles); else 16
     const bool wide = n >= 64 * 192 && net.S <= 8 && net.A <= 8 && ein == 128;   // (LDS: 64 x 132 floats of x1)
 #define RPO_MLP_FWD(EIN_, H_)                                                                                          \
@@ -465,7 +572,7 @@ int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int
     if (!net_host) return RPO_ERR_NULL;
     Mlp net{net_host->Ws, net_host->bs, net_host->Wa, net_host->ba, net_host->W0, net_host->b0, net_host->W1,
             net_host->b1, net_host->W1b, net_host->b1b, net_host->S, net_host->A, net_host->E, net_host->H,
-            net_host->n_out, net_host->cat};
+            net_host->n_out, net_host->cat, net_host->head_dim};
     if (int e = check_net(net)) return e;
     if (n <= 0 || s_stride < net.S || (net.A > 0 && a_stride < net.A)) return RPO_ERR_ARG;
     if (!s || !x0 || !h1 || !dout || !dh || !dx0 || (net.A > 0 && !a)) return RPO_ERR_NULL;

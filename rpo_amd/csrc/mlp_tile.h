@@ -22,6 +22,7 @@ constexpr int kInS = 64, kInA = 48;   // row strides of the LDS input tiles (S <
 struct Mlp {
     const float *Ws, *bs, *Wa, *ba, *W0, *b0, *W1, *b1, *W1b, *b1b;   // W1b / b1b: second head (SAC log-std), n_out = 2
     int S, A, E, H, n_out, cat;
+    int hd;   // outputs per head (0 / 1: scalar heads, reduced with wave shuffles; > 1: the head is a 16 x 16 MFMA tile)
 };
 struct MlpGrad {
     float *Ws, *bs, *Wa, *ba, *W0, *b0, *W1, *b1, *W1b, *b1b;
@@ -41,6 +42,15 @@ struct TileLds {
     float in_a[ROWS * INA];                                      // action inputs of the rows
     float part[kFwdWaves * ROWS * 2];                            // per-wave head partials
     float out[ROWS * 2];                                         // outputs (after the epilogue)
+};
+
+constexpr int kWideOut = 32;        // outputs per row of a multi-output network (2 heads x <= 16)
+
+// ... plus what a multi-output head (hd > 1: 14 basic actions of EVOPF-v0) needs: relu(h1) of the tile as an MFMA operand
+template <int EIN, int H>
+struct TileLdsWide : TileLds<EIN, 1, kInS, kInA> {
+    __attribute__((aligned(16))) float hr[kRows * (H + 4)];
+    float outw[kRows * kWideOut];
 };
 
 // Everything a thread keeps in registers for one network: its first-layer column, its wave's slice of W0 and the head
@@ -87,17 +97,17 @@ __device__ __forceinline__ void tile_load_weights(const Mlp& net, TileWeights<EI
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
         w.b0v[c] = net.b0[j0 + c * 16 + li];
-        w.w1av[c] = net.W1[j0 + c * 16 + li];
-        w.w1bv[c] = net.n_out > 1 ? net.W1b[j0 + c * 16 + li] : 0.0f;
+        w.w1av[c] = net.hd > 1 ? 0.0f : net.W1[j0 + c * 16 + li];
+        w.w1bv[c] = (net.n_out > 1 && net.hd <= 1) ? net.W1b[j0 + c * 16 + li] : 0.0f;
     }
-    w.b1v = (tid < ROWS * net.n_out) ? (((tid % net.n_out) == 0) ? net.b1[0] : net.b1b[0]) : 0.0f;
+    w.b1v = (net.hd <= 1 && tid < ROWS * net.n_out) ? (((tid % net.n_out) == 0) ? net.b1[0] : net.b1b[0]) : 0.0f;
 }
 
 // Forward of the RT * 16 rows whose inputs sit in lds.in_s / lds.in_a (the caller wrote them; this function
 // synchronises before reading).  Outputs land in lds.out[r * 2 + o] and are visible to every thread on return.
 // out_mode 1: BoxConstraint's tanh map on output 0.  x0_save / h1_save (global, may be NULL) get the pre-activations
 // of rows row0 + r < n.
-template <int EIN, int H, int RT, class LDS>
+template <int EIN, int H, int RT, class LDS, bool WIDE = false>
 __device__ __forceinline__ void tile_compute(const Mlp& net, const TileWeights<EIN, H, RT>& w, LDS& lds, int row0, int n,
                                              float* x0_save, float* h1_save, int out_mode, float scale, float base) {
     constexpr int kInS = LDS::kS, kInA = LDS::kA;               // (shadow the default strides)
@@ -195,6 +205,46 @@ __device__ __forceinline__ void tile_compute(const Mlp& net, const TileWeights<E
             for (int c = 0; c < NT; ++c) acc[rt][c] = mfma4(a4[rt].w, b4[c].w, acc[rt][c]);
     }
     // acc[rt][c][i] = h1[row = 16 rt + 4 lg + i][col = j0 + 16c + li] (before bias)
+    if constexpr (WIDE) {
+        // ---- multi-output head: relu(h1) of the tile becomes the A operand of one more MFMA tile per head
+        static_assert(RT == 1, "multi-output heads run on 16-row tiles");
+        constexpr int LDH = H + 4;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            const int col = j0 + c * 16 + li;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float h = acc[0][c][i] + w.b0v[c];
+                const int row = row0 + lg * 4 + i;
+                if (h1_save && row < n) h1_save[(size_t)row * H + col] = h;
+                lds.hr[(lg * 4 + i) * LDH + col] = fmaxf(h, 0.0f);
+            }
+        }
+        __syncthreads();
+        if (wave < net.n_out) {                                    // wave k computes head k: out[r][o] = hr[r][:] . W1_k[o][:]
+            const float* W = wave == 0 ? net.W1 : net.W1b;
+            const float* bvec = wave == 0 ? net.b1 : net.b1b;
+            const bool live = li < net.hd;
+            f32x4 o4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+            for (int it = 0; it < H / 16; ++it) {
+                const float4 a4 = *reinterpret_cast<const float4*>(&lds.hr[li * LDH + it * 16 + lg * 4]);
+                float4 b4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (live) b4 = *reinterpret_cast<const float4*>(&W[(size_t)li * H + it * 16 + lg * 4]);
+                o4 = mfma4(a4.x, b4.x, o4);
+                o4 = mfma4(a4.y, b4.y, o4);
+                o4 = mfma4(a4.z, b4.z, o4);
+                o4 = mfma4(a4.w, b4.w, o4);
+            }
+            if (live) {
+                const float bias = bvec[li];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lds.outw[(lg * 4 + i) * kWideOut + wave * net.hd + li] = o4[i] + bias;
+            }
+        }
+        __syncthreads();
+        return;
+    }
     // ---- head: per-lane partial dot products, reduced over the 16 lanes that share lg, then over the waves
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {

@@ -364,7 +364,7 @@ class PendulumKernels(object):
 
 class _MlpStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("Ws", "bs", "Wa", "ba", "W0", "b0", "W1", "b1", "W1b", "b1b")] + \
-               [(n, ctypes.c_int) for n in ("S", "A", "E", "H", "n_out", "cat")]
+               [(n, ctypes.c_int) for n in ("S", "A", "E", "H", "n_out", "cat", "head_dim")]
 
 
 class _MlpGradStruct(ctypes.Structure):
@@ -383,9 +383,11 @@ class MlpDesc(object):
     """
     FIELDS = ("Ws", "bs", "Wa", "ba", "W0", "b0", "W1", "b1", "W1b", "b1b")
 
-    def __init__(self, tensors, S, A, E, H, n_out, cat):
+    def __init__(self, tensors, S, A, E, H, n_out, cat, head_dim=1):
         self.tensors = {k: tensors.get(k) for k in self.FIELDS}
         self.S, self.A, self.E, self.H, self.n_out, self.cat = int(S), int(A), int(E), int(H), int(n_out), int(bool(cat))
+        self.head_dim = int(head_dim)
+        self.outs = self.n_out * max(1, self.head_dim)
         self.ein = self.E * (2 if self.cat else 1)
         if self.tensors["W0"].data_ptr() % 16:
             raise RpoHipError("W0 must be 16-byte aligned (FlatParams aligns every tensor)")
@@ -395,7 +397,7 @@ class MlpDesc(object):
 
     def net_struct(self):
         return _MlpStruct(*[self._ptr(self.tensors[k]) for k in self.FIELDS], self.S, self.A, self.E, self.H, self.n_out,
-                          self.cat)
+                          self.cat, self.head_dim)
 
     def grad_struct(self):
         return _MlpGradStruct(*[None if self.tensors[k] is None else self._ptr(self.tensors[k].grad) for k in self.FIELDS])

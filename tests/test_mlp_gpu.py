@@ -29,10 +29,15 @@ def aligned_params(module):
 
 
 def desc_for(ops, net, kind, S, A, E, H):
-    if kind == "actor":
+    if kind in ("actor", "actor14"):
         t = dict(Ws=net.state_embed.embeds[0].weight, bs=net.state_embed.embeds[0].bias, W0=net.affines[0].weight,
                  b0=net.affines[0].bias, W1=net.affines[1].weight, b1=net.affines[1].bias)
-        return ops.MlpDesc(t, S, 0, E, H, 1, False)
+        return ops.MlpDesc(t, S, 0, E, H, 1, False, head_dim=14 if kind == "actor14" else 1)
+    if kind == "gauss14":
+        t = dict(Ws=net.state_embed.embeds[0].weight, bs=net.state_embed.embeds[0].bias, W0=net.affines[0].weight,
+                 b0=net.affines[0].bias, W1=net.affine_mean.weight, b1=net.affine_mean.bias,
+                 W1b=net.affine_log_std.weight, b1b=net.affine_log_std.bias)
+        return ops.MlpDesc(t, S, 0, E, H, 2, False, head_dim=14)
     if kind == "gauss":
         t = dict(Ws=net.state_embed.embeds[0].weight, bs=net.state_embed.embeds[0].bias, W0=net.affines[0].weight,
                  b0=net.affines[0].bias, W1=net.affine_mean.weight, b1=net.affine_mean.bias,
@@ -54,7 +59,10 @@ def gauss_raw(net, s):
 
 CASES = [("actor", 6, 0, 128, 256, 4096), ("actor", 5, 0, 128, 256, 250), ("add", 6, 2, 128, 256, 256),
          ("add", 5, 2, 128, 256, 77), ("cat", 57, 43, 256, 256, 200), ("gauss", 5, 0, 128, 256, 256),
-         ("add", 6, 2, 256, 256, 512)]
+         ("add", 6, 2, 256, 256, 512),
+         # multi-output heads (MFMA head): EVOPF-v0 actor (57 -> 256 -> 256 -> 14) and its SAC form (2 x 14)
+         ("actor14", 57, 0, 256, 256, 1000), ("actor14", 57, 0, 256, 256, 256), ("gauss14", 57, 0, 256, 256, 77),
+         ("actor14", 6, 0, 128, 256, 300)]
 
 
 @pytest.mark.parametrize("kind,S,A,E,H,n", CASES)
@@ -64,6 +72,10 @@ def test_mlp_forward_backward_match_torch(kind, S, A, E, H, n):
     se = StateEmbedding(S, E, H)
     if kind == "actor":
         net = SharedPolicy(S, 1, se, E, H, 1, None)
+    elif kind == "actor14":
+        net = SharedPolicy(S, 14, se, E, H, 1, None)
+    elif kind == "gauss14":
+        net = GaussianSharedPolicy(S, 14, se, E, H, 1, None)
     elif kind == "gauss":
         net = GaussianSharedPolicy(S, 1, se, E, H, 1, None)
     else:
@@ -77,9 +89,9 @@ def test_mlp_forward_backward_match_torch(kind, S, A, E, H, n):
     s = wide[:, 3:3 + S]
     a = wide[:, 3 + S:3 + S + A] if A else None
     a_t = a.clone().requires_grad_() if A else None
-    if kind == "actor":
+    if kind in ("actor", "actor14"):
         ref = net(s)
-    elif kind == "gauss":
+    elif kind in ("gauss", "gauss14"):
         ref = gauss_raw(net, s)
     else:
         ref = net(s, a_t)
