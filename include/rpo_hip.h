@@ -362,12 +362,21 @@ int rpo_evopf_step(int n_envs, float* state, const float* action, int* ep_len, f
  * -> grad_steps (rpo_ddpg.py:266-305, corr_mode 0).  Every row carries its own Newton and GRG stop tests (== the
  * reference's B = 1 rollout calls; on a batch the reference tests the batch maximum, which adds iterations only to
  * rows that had already met the test).  iters [n] (may be NULL) = GRG iterations.  Noise draw of basic action j:
- * Philox(seed; env, ctrl[T], RPO_STREAM_ACT, j / 2) normals (x,y) | (z,w); RPO_NOISE_UNIFORM: word j % 4 of block j / 4. */
+ * Philox(seed; env, ctrl[T], RPO_STREAM_ACT, j / 2) normals (x,y) | (z,w); RPO_NOISE_UNIFORM: word j % 4 of block j / 4.
+ * ap_is_raw = 1: ap_raw holds the actor's pre-activation outputs and the kernel applies BoxConstraint's map
+ * scale(s) * tanh(.) + base(s) with the lane's own box first (model/utils.py:40-51,75-88). */
 int rpo_evopf_act_project(int n, const float* state, int state_stride, const float* ap_raw, const float* noise, float* action, int* iters,
-                          int noise_mode, float eps_start, float eps_end, float eps_decay, int max_steps, float corr_lr,
-                          float corr_eps, float corr_momentum, float newton_tol, int newton_max_iters,
+                          int noise_mode, int ap_is_raw, float eps_start, float eps_end, float eps_decay, int max_steps,
+                          float corr_lr, float corr_eps, float corr_momentum, float newton_tol, int newton_max_iters,
                           const float* consts_dev, unsigned long long seed, unsigned env_id_base, const long long* ctrl,
                           float* stats, int stats_cap, void* stream);
+
+/* Backward of the actor's output map for EVOPF: ap = clip(scale(s) * tanh(raw) + base(s) + eps_t * noise, lo(s), hi(s))
+ * (model/policy.py:24-33 with the state-dependent box, then ddpg_pa.py:108-110); dout [n,14] = dap * d ap / d raw.
+ * noise NULL: no noise and no clip. */
+int rpo_evopf_tanh_box_bwd(int n, const float* state, int state_stride, const float* raw, const float* noise,
+                           float eps_start, float eps_end, float eps_decay, const long long* ctrl, const float* dap,
+                           float* dout, const float* consts_dev, void* stream);
 
 /* PFFunction.backward (evopf.py:857-910): grad_ap [n,14] = dL/dz given grad_action [n,43] = dL/dy and the completed
  * action; the Jacobians are re-evaluated at that action (the reference keeps those of the last Newton point). */

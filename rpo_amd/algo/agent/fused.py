@@ -50,12 +50,13 @@ class FusedNets(object):
     def _actor_desc(cls, backend, net):
         Ws, bs = cls._embed(net.state_embed)
         S, E = Ws.shape[1], Ws.shape[0]
+        head_dim = 1
         if isinstance(net, SharedPolicy):
-            if len(net.affines) != 2 or net.affines[1].weight.shape[0] != 1:
+            if len(net.affines) != 2 or net.affines[1].weight.shape[0] > 16:
                 raise _Unsupported()
             W0, b0 = _lin(net.affines[0])
             W1, b1 = _lin(net.affines[1])
-            t, n_out = dict(Ws=Ws, bs=bs, W0=W0, b0=b0, W1=W1, b1=b1), 1
+            t, n_out, head_dim = dict(Ws=Ws, bs=bs, W0=W0, b0=b0, W1=W1, b1=b1), 1, W1.shape[0]
         elif isinstance(net, GaussianSharedPolicy):
             if len(net.affines) != 1 or net.affine_mean.weight.shape[0] != 1:
                 raise _Unsupported()
@@ -66,9 +67,13 @@ class FusedNets(object):
         else:
             raise _Unsupported()
         H = W0.shape[0]
-        if net.box_constraint is None or net.box_constraint.volatile or not backend.mlp_supported(E, H, False):
+        if net.box_constraint is None or not backend.mlp_supported(E, H, False):
             raise _Unsupported()
-        return backend.MlpDesc(t, S, 0, E, H, n_out, False)
+        # multi-output actors return raw outputs and leave the (state-dependent) box to the env kernels; a scalar actor
+        # with a state-dependent box has no such kernel
+        if (head_dim > 1) != bool(net.box_constraint.volatile) or (head_dim > 1 and E > 256):
+            raise _Unsupported()
+        return backend.MlpDesc(t, S, 0, E, H, n_out, False, head_dim=head_dim)
 
     @classmethod
     def _critic_descs(cls, backend, net):

@@ -51,7 +51,9 @@ class RPODDPG(RPOTrainerBase):
     def _actor_out(self, name, obs, save=False):
         """Deterministic basic action [n] of `actor` / `actor_target` through the fused MLP kernel."""
         f = self.fused
-        return f.forward(name, obs, None, f.buf(name + ".out", obs.shape[0], 1), save=save,
+        P = self.kernels.partial_dim
+        # P > 1 (EVOPF): raw outputs; the env kernels apply the state-dependent tanh box (ap_is_raw)
+        return f.forward(name, obs, None, f.buf(name + ".out", obs.shape[0], P), save=save,
                          tanh_box=self._box_affine).view(-1)
 
     def _policy_partial(self, obs, warm):
@@ -128,18 +130,22 @@ class RPODDPG(RPOTrainerBase):
         lag, g_act = f.buf("loss_lag", 1), f.buf("g_act", B, k.action_dim)
         lag.zero_()
         ag.flat.grad.zero_()               # parameters AND multipliers (they live in the same flat buffer)
-        k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1))
+        k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1), obs=state)
         dq = f.buf("dq", B, 1)
         dq.fill_(-1.0 / B)
         da = f.buf("da", B, k.action_dim)
         shared = ag.flat.sizes[1] > 0      # shared embedding: the critic path contributes to its gradient
         f.backward("critic", state, actions, dq, da=da, param_grads=shared, first_layer_state_only=True)
         da.add_(g_act)
-        dap, do = f.buf("dap", B), f.buf("do", B, 1)
-        k.complete_bwd(state, da, dap)
-        scale, base = self._box_affine
-        self.backend.tanh_box_bwd(dap, ap_det, noise, self.eps_start, self.eps, self.decay_value, self.vec.ctrl,
-                                  self._box_lo, self._box_hi, scale, base, do.view(-1))
+        P = k.partial_dim
+        dap, do = f.buf("dap", B * P), f.buf("do", B, P)
+        k.complete_bwd(state, da, dap, action=actions)
+        if self._box_affine is None:       # state-dependent box: the env's kernel knows it
+            k.tanh_box_bwd(state, ap_det, noise, self.eps_start, self.eps, self.decay_value, self.vec.ctrl, dap, do.view(-1))
+        else:
+            scale, base = self._box_affine
+            self.backend.tanh_box_bwd(dap, ap_det, noise, self.eps_start, self.eps, self.decay_value, self.vec.ctrl,
+                                      self._box_lo, self._box_hi, scale, base, do.view(-1))
         f.backward("actor", state, None, do)
         loss = lag[0] - q.mean()
         self.last_losses["actor"] = loss

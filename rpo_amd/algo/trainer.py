@@ -189,6 +189,8 @@ class RPOTrainerBase(object):
         box = agent.actor.box_constraint
         self._box_affine = (float(np.asarray(box.scale).reshape(-1)[0]), float(np.asarray(box.base).reshape(-1)[0])) \
             if box is not None and not box.volatile else None
+        # fused multi-output actor: raw outputs, the env's projection kernel applies the state-dependent tanh box
+        self._act_kw = dict(ap_is_raw=True) if (self.fused is not None and self._box_affine is None) else {}
         self._t = 0                 # loop iterations (== vector steps) done
         self._harvested = 0         # vector steps whose statistics were already pulled off the device
         self._pending = []          # per-step rows waiting for the return of the episodes they belong to
@@ -248,7 +250,8 @@ class RPOTrainerBase(object):
             ap, mode = self._policy_partial(v.obs, warm)
             self.kernels.act_project(v.obs, ap, None, v.action, None, mode, self.eps_start, self.eps, self.decay_value,
                                      self._box_lo, self._box_hi, self.max_steps, self.corr_lr, self.corr_eps,
-                                     self.corr_momentum, self.seed, v.env_id_base, v.ctrl, v.stats)
+                                     self.corr_momentum, self.seed, v.env_id_base, v.ctrl, v.stats,
+                                     **({} if warm else self._act_kw))
             v.step(v.action, rows=self.buffer.rows, cap_steps=self.buffer.capacity, auto_reset=True)
 
     # ------------------------------------------------------------------------------------------ update
@@ -356,15 +359,17 @@ class RPOTrainerBase(object):
     # ------------------------------------------------------------------------------------------ fused-MLP helpers
     def _project_batch(self, state, ap_flat):
         """Training-batch projection of `ap_flat` [B] -> actions [B, A] (same semantics as process_action)."""
-        return self.process_action(state, ap_flat)
+        return self.base_env.project(state, ap_flat, self.max_steps, self.corr_lr, self.corr_eps, self.corr_momentum,
+                                     batch_reference=self.batch_reference, **self._act_kw)
 
     def _complete_only(self, state, ap_flat, noise=None):
         """clip(ap + eps_t * noise) -> equation solver, no GRG steps (actor loss, rpo_ddpg.py:309-310)."""
         f = self.fused
-        act = f.buf("act_pi", ap_flat.shape[0], self.kernels.action_dim)
+        act = f.buf("act_pi", state.shape[0], self.kernels.action_dim)
         mode = hip_ops.NOISE_NONE if noise is None else hip_ops.NOISE_EXPLICIT
         self.kernels.act_project(state, ap_flat, noise, act, None, mode, self.eps_start, self.eps, self.decay_value,
-                                 self._box_lo, self._box_hi, 0, 0.0, self.corr_eps, 0.0, self.seed, 0, self.vec.ctrl, None)
+                                 self._box_lo, self._box_hi, 0, 0.0, self.corr_eps, 0.0, self.seed, 0, self.vec.ctrl, None,
+                                 **self._act_kw)
         return act
 
     # ------------------------------------------------------------------------------------------ main loop
@@ -473,7 +478,8 @@ class RPOTrainerBase(object):
             for i in range(horizon):
                 ap = self._eval_partial(v.obs)
                 self.kernels.act_project(v.obs, ap, None, v.action, None, hip_ops.NOISE_NONE, 0.0, 0.0, 0.0, self._box_lo,
-                                         self._box_hi, self.eval_steps, self.eval_lr, self.corr_eps, self.corr_momentum)
+                                         self._box_hi, self.eval_steps, self.eval_lr, self.corr_eps, self.corr_momentum,
+                                         **self._act_kw)
                 v.ctrl.zero_()
                 v.step(v.action, rows=self._eval_rows, cap_steps=1, auto_reset=False)
                 row = self._eval_rows

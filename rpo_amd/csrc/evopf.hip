@@ -143,6 +143,7 @@ struct ActArgs {
     float* action;
     int* iters;
     int noise_mode;
+    int ap_is_raw;
     float eps_start, eps_end, eps_decay;
     int max_steps;
     float corr_lr, corr_eps, corr_momentum;
@@ -173,6 +174,10 @@ __global__ __launch_bounds__(RPO_WAVE) void evopf_act_project_kernel(ActArgs p) 
         float lo, hi;
         partial_box(w, tid, lo, hi);
         z = (p.noise_mode == RPO_NOISE_UNIFORM) ? 0.0f : p.ap_raw[(size_t)i * NP + tid];
+        if (p.ap_is_raw && p.noise_mode != RPO_NOISE_UNIFORM) {         // BoxConstraint.__call__ (model/utils.py:40-51,75-88)
+            const float scale = (hi - lo) * 0.5f;
+            z = scale * tanhf(z) + (lo + scale);
+        }
         if (p.noise_mode == RPO_NOISE_EXPLICIT) {
             z = fminf(fmaxf(z + eps_t * p.noise[(size_t)i * NP + tid], lo), hi);
         } else if (p.noise_mode == RPO_NOISE_PHILOX) {
@@ -327,6 +332,36 @@ __global__ __launch_bounds__(RPO_BLOCK) void evopf_lagrangian_kernel(int n, cons
     }
 }
 
+// d/d(raw) of ap = clip(scale(s) * tanh(raw) + base(s) + eps_t * noise, lo(s), hi(s)) (SharedPolicy.forward
+// model/policy.py:24-33 with the volatile box of evopf.py:769-783, then take_action ddpg_pa.py:108-110); elementwise.
+__global__ __launch_bounds__(RPO_BLOCK) void evopf_tanh_box_bwd_kernel(int n, const float* __restrict__ state,
+                                                                       int state_stride, const float* __restrict__ raw,
+                                                                       const float* __restrict__ noise, float eps_start,
+                                                                       float eps_end, float eps_decay,
+                                                                       const long long* __restrict__ ctrl,
+                                                                       const float* __restrict__ dap,
+                                                                       float* __restrict__ dout,
+                                                                       const float* __restrict__ consts) {
+    RPO_FP_STRICT
+    const long long t = ctrl ? ctrl[RPO_CTRL_T] : 0;
+    const float eps_t = fmaxf(eps_end, eps_start - eps_decay * (float)t);
+    for (int idx = blockIdx.x * RPO_BLOCK + threadIdx.x; idx < n * NP; idx += gridDim.x * RPO_BLOCK) {
+        const int i = idx / NP, j = idx - i * NP;
+        float lo, hi;
+        if (j < 4) { lo = consts[RPO_EVOPF_C_PMIN + 1 + j]; hi = consts[RPO_EVOPF_C_PMAX + 1 + j]; }
+        else if (j < 9) { lo = consts[RPO_EVOPF_C_VMIN + kSpv[j - 4]]; hi = consts[RPO_EVOPF_C_VMAX + kSpv[j - 4]]; }
+        else battery_bounds(state[(size_t)i * state_stride + 2 * NB + j - 9], hi, lo);
+        const float scale = (hi - lo) * 0.5f;
+        const float th = tanhf(raw[idx]);
+        float g = dap[idx] * scale * (1.0f - th * th);
+        if (noise) {
+            const float pre = scale * th + (lo + scale) + eps_t * noise[idx];
+            if (pre < lo || pre > hi) g = 0.0f;                      // torch.clip's backward: zero outside [lo, hi]
+        }
+        dout[idx] = g;
+    }
+}
+
 int check_common(int n, const void* a, const void* b, const float* consts) {
     if (n <= 0) return RPO_ERR_ARG;
     if (!a || !b || !consts) return RPO_ERR_NULL;
@@ -363,8 +398,8 @@ int rpo_evopf_step(int n_envs, float* state, const float* action, int* ep_len, f
 }
 
 int rpo_evopf_act_project(int n, const float* state, int state_stride, const float* ap_raw, const float* noise, float* action, int* iters,
-                          int noise_mode, float eps_start, float eps_end, float eps_decay, int max_steps, float corr_lr,
-                          float corr_eps, float corr_momentum, float newton_tol, int newton_max_iters,
+                          int noise_mode, int ap_is_raw, float eps_start, float eps_end, float eps_decay, int max_steps,
+                          float corr_lr, float corr_eps, float corr_momentum, float newton_tol, int newton_max_iters,
                           const float* consts_dev, unsigned long long seed, unsigned env_id_base, const long long* ctrl,
                           float* stats, int stats_cap, void* stream) {
     if (int e = check_common(n, state, action, consts_dev)) return e;
@@ -373,10 +408,23 @@ int rpo_evopf_act_project(int n, const float* state, int state_stride, const flo
     if (noise_mode != RPO_NOISE_UNIFORM && !ap_raw) return RPO_ERR_NULL;
     if (noise_mode == RPO_NOISE_EXPLICIT && !noise) return RPO_ERR_NULL;
     if (state_stride < RPO_EVOPF_STATE) return RPO_ERR_ARG;
-    ActArgs p{n, state, state_stride, ap_raw, noise, action, iters, noise_mode, eps_start, eps_end, eps_decay, max_steps, corr_lr,
+    ActArgs p{n, state, state_stride, ap_raw, noise, action, iters, noise_mode, ap_is_raw, eps_start, eps_end, eps_decay, max_steps, corr_lr,
               corr_eps, corr_momentum, newton_tol, newton_max_iters, consts_dev, (uint64_t)seed, (uint32_t)env_id_base, ctrl,
               stats, stats_cap};
     hipLaunchKernelGGL(evopf_act_project_kernel, dim3(n), dim3(RPO_WAVE), 0, (hipStream_t)stream, p);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_evopf_tanh_box_bwd(int n, const float* state, int state_stride, const float* raw, const float* noise,
+                           float eps_start, float eps_end, float eps_decay, const long long* ctrl, const float* dap,
+                           float* dout, const float* consts_dev, void* stream) {
+    if (int e = check_common(n, state, raw, consts_dev)) return e;
+    if (!dap || !dout) return RPO_ERR_NULL;
+    if (state_stride < RPO_EVOPF_STATE) return RPO_ERR_ARG;
+    hipLaunchKernelGGL(evopf_tanh_box_bwd_kernel, dim3(rpo_grid_for((long long)n * NP)), dim3(RPO_BLOCK), 0,
+                       (hipStream_t)stream, n, state, state_stride, raw, noise, eps_start, eps_end, eps_decay, ctrl, dap,
+                       dout, consts_dev);
     RPO_LAUNCH_CHECK();
     return 0;
 }

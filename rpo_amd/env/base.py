@@ -173,7 +173,7 @@ class HardConstraintEnv(gym.Env):
         return out
 
     def project(self, state, action_partial, max_steps, lr, corr_eps=1e-5, momentum=0.0, return_iters=False,
-                batch_reference=False):
+                batch_reference=False, **act_kw):
         """complete_partial + grad_steps in one launch (the fused form the trainers use).
 
         ``batch_reference=True`` asks for the reference's literal behaviour on a batch (one stop test for the whole
@@ -192,7 +192,7 @@ class HardConstraintEnv(gym.Env):
         else:
             lo, hi = self.partial_box
             self.kernels.act_project(self._t(state), ap, None, action, iters, hip_ops.NOISE_NONE, 0.0, 0.0, 0.0, lo, hi,
-                                     int(max_steps), float(lr), float(corr_eps), float(momentum))
+                                     int(max_steps), float(lr), float(corr_eps), float(momentum), **act_kw)
         return (action, iters) if return_iters else action
 
     def hold_eq(self):

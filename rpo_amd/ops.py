@@ -256,15 +256,23 @@ class EvopfKernels(object):
             seed, env_id_base, _stream()), "rpo_evopf_step")
 
     def act_project(self, obs, ap_raw, noise, action, iters, noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi,
-                    max_steps, corr_lr, corr_eps, corr_momentum, seed=0, env_id_base=0, ctrl=None, stats=None):
+                    max_steps, corr_lr, corr_eps, corr_momentum, seed=0, env_id_base=0, ctrl=None, stats=None,
+                    ap_is_raw=False):
         # box_lo / box_hi are ignored: the box is state dependent (EVOPFEnv.update) and evaluated inside the kernel
         sp, ss = _row_view(obs, self.obs_dim)
         check(_lib.load().rpo_evopf_act_project(
             action.shape[0], sp, ss, _p(ap_raw, allow_none=True), _p(noise, allow_none=True), _p(action),
-            _p(iters, torch.int32, allow_none=True), noise_mode, eps_start, eps_end, eps_decay, max_steps, corr_lr,
+            _p(iters, torch.int32, allow_none=True), noise_mode, int(ap_is_raw), eps_start, eps_end, eps_decay, max_steps,
+            corr_lr,
             corr_eps, corr_momentum, self.newton_tol, self.newton_max_iters, self._c(action), seed, env_id_base,
             _p(ctrl, torch.int64, allow_none=True), _p(stats, allow_none=True), 0 if stats is None else stats.shape[0],
             _stream()), "rpo_evopf_act_project")
+
+    def tanh_box_bwd(self, obs, raw, noise, eps_start, eps_end, eps_decay, ctrl, dap, dout):
+        sp, ss = _row_view(obs, self.obs_dim)
+        check(_lib.load().rpo_evopf_tanh_box_bwd(dout.numel() // self.partial_dim, sp, ss, _p(raw), _p(noise, allow_none=True), eps_start,
+                                                 eps_end, eps_decay, _p(ctrl, torch.int64, allow_none=True), _p(dap),
+                                                 _p(dout), self._c(dout), _stream()), "rpo_evopf_tanh_box_bwd")
 
     def complete_bwd(self, obs, grad_action, grad_ap, action=None):
         check(_lib.load().rpo_evopf_complete_bwd(grad_action.shape[0], _p(action), _p(grad_action), _p(grad_ap),

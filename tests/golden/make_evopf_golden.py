@@ -153,17 +153,20 @@ EVOPF_HP = dict(batch_size=256, max_steps=10, warmup=0, lr_dual=2e-2, corr_lr=1e
                 ex_action_dim=1, gamma=0.95, clip_thres=0.2, shared_param=False, value_type="cat")   # scripts/evopf_exp.py:29-31
 
 
-def gen_train_steps():
-    """RPODDPG.train (rpo_ddpg.py:163-205) for t = 1..4 on EVOPF with the script's hyper-parameters (smaller networks
-    to keep the fixture small; init_nju > 0 so that the Lagrangian term has a gradient), every random draw recorded."""
+def gen_train_steps(width=64, sub=1):
+    """RPODDPG.train (rpo_ddpg.py:163-205) for t = 1..4 on EVOPF with the script's hyper-parameters, every random draw
+    recorded; init_nju > 0 so that the Lagrangian term has a gradient.  width = 64: small networks, stored in full;
+    width = 256 (the script's sizes, what the MLP kernels support): parameters stored as every `sub`-th element."""
     torch.manual_seed(123)
     np.random.seed(111)
     env = REF.EVOPFEnv()
     logger = REF.Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=10, name="x")
-    tr = REF.RPODDPG(env, "/tmp/rpo_evopf_golden", name="g", logger=logger, max_epochs=10, capacity=512, embed_dim=64,
-                     hidden_dim=64, init_nju=0.1, device=torch.device("cpu"), **EVOPF_HP)
-    out = {"actor0." + k: v.numpy().copy() for k, v in tr.agent.actor.state_dict().items()}
-    out.update({"critic0." + k: v.numpy().copy() for k, v in tr.agent.critic.state_dict().items()})
+    tr = REF.RPODDPG(env, "/tmp/rpo_evopf_golden", name="g", logger=logger, max_epochs=10, capacity=512, embed_dim=width,
+                     hidden_dim=width, init_nju=0.1, device=torch.device("cpu"), **EVOPF_HP)
+    pack = lambda v: v.numpy().reshape(-1)[::sub].copy() if sub > 1 else v.numpy().copy()   # noqa: E731
+    out = {"actor0." + k: pack(v) for k, v in tr.agent.actor.state_dict().items()}
+    out.update({"critic0." + k: pack(v) for k, v in tr.agent.critic.state_dict().items()})
+    out["sub"] = sub
     trans = {k: [] for k in ("state", "action", "next_state", "reward", "done", "eq_viol", "ineq_viol")}
     s = env.reset()
     with torch.no_grad():
@@ -208,12 +211,12 @@ def gen_train_steps():
         for t in range(1, 5):
             tr.train(t)
             if t in (1, 4):
-                out.update({"critic%d.%s" % (t, k): v.numpy().copy() for k, v in tr.agent.critic.state_dict().items()})
+                out.update({"critic%d.%s" % (t, k): pack(v) for k, v in tr.agent.critic.state_dict().items()})
     finally:
         np.random.randint, torch.randn_like = orig_randint, orig_randn_like
-    out.update({"actor4." + k: v.numpy().copy() for k, v in tr.agent.actor.state_dict().items()})
-    out.update({"critic_target4." + k: v.numpy().copy() for k, v in tr.agent.critic_target.state_dict().items()})
-    out.update({"actor_target4." + k: v.numpy().copy() for k, v in tr.agent.actor_target.state_dict().items()})
+    out.update({"actor4." + k: pack(v) for k, v in tr.agent.actor.state_dict().items()})
+    out.update({"critic_target4." + k: pack(v) for k, v in tr.agent.critic_target.state_dict().items()})
+    out.update({"actor_target4." + k: pack(v) for k, v in tr.agent.actor_target.state_dict().items()})
     out["nju4"] = tr.agent.nju.weight.detach().numpy().copy()
     out["idx"] = np.stack(draws["idx"])
     for i, z in enumerate(draws["noise"]):
@@ -221,7 +224,7 @@ def gen_train_steps():
     out["n_noise"] = len(draws["noise"])
     out["critic_losses"] = np.array(losses["critic"])
     out["actor_losses"] = np.array(losses["actor"])
-    save("train_steps_ddpg_evopf", **out)
+    save("train_steps_ddpg_evopf" + ("" if width == 64 else str(width)), **out)
 
 
 if __name__ == "__main__":
@@ -229,3 +232,4 @@ if __name__ == "__main__":
     gen_step()
     gen_project()
     gen_train_steps()
+    gen_train_steps(width=256, sub=8)

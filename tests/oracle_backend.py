@@ -219,15 +219,32 @@ class EvopfKernels(_EnvKernels):
         return ap
 
     def act_project(self, obs, ap_raw, noise, action, iters, noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi,
-                    max_steps, corr_lr, corr_eps, corr_momentum, seed=0, env_id_base=0, ctrl=None, stats=None):
+                    max_steps, corr_lr, corr_eps, corr_momentum, seed=0, env_id_base=0, ctrl=None, stats=None,
+                    ap_is_raw=False):
         n = action.shape[0]
         s = _np(obs).astype(np.float64)
+        if ap_is_raw and noise_mode != NOISE_UNIFORM:
+            lo, hi = oe.partial_box(s)
+            scale = (hi - lo) * 0.5
+            ap_raw = torch.as_tensor(scale * np.tanh(_np(ap_raw).reshape(n, 14).astype(np.float64)) + (lo + scale))
         ap = self._explore14(obs, ap_raw, noise, n, noise_mode, eps_start, eps_end, eps_decay, seed, env_id_base, self._t(ctrl))
         a, it = oe.project(s, ap, max_steps, corr_lr, corr_eps, corr_momentum)
         _put(action, a)
         if iters is not None:
             _put(iters, it)
         self._stat_iters(stats, ctrl, it)
+
+    def tanh_box_bwd(self, obs, raw, noise, eps_start, eps_end, eps_decay, ctrl, dap, dout):
+        n = dout.numel() // 14
+        lo, hi = oe.partial_box(_np(obs).astype(np.float64))
+        scale = (hi - lo) * 0.5
+        th = np.tanh(_np(raw).reshape(n, 14).astype(np.float64))
+        g = _np(dap).reshape(n, 14) * scale * (1 - th * th)
+        if noise is not None:
+            eps_t = max(eps_end, eps_start - eps_decay * self._t(ctrl))
+            pre = scale * th + (lo + scale) + eps_t * _np(noise).reshape(n, 14)
+            g = np.where((pre < lo) | (pre > hi), 0.0, g)
+        _put(dout, g)
 
     def complete_bwd(self, obs, grad_action, grad_ap, action=None):
         a = _np(action).astype(np.float64)
@@ -396,9 +413,10 @@ def mlp_supported(E, H, cat=False):
 class MlpDesc(object):
     FIELDS = ("Ws", "bs", "Wa", "ba", "W0", "b0", "W1", "b1", "W1b", "b1b")
 
-    def __init__(self, tensors, S, A, E, H, n_out, cat):
+    def __init__(self, tensors, S, A, E, H, n_out, cat, head_dim=1):
         self.tensors = {k: tensors.get(k) for k in self.FIELDS}
         self.S, self.A, self.E, self.H, self.n_out, self.cat = S, A, E, H, n_out, int(bool(cat))
+        self.head_dim = int(head_dim)
         self.ein = E * (2 if cat else 1)
 
 
@@ -453,8 +471,9 @@ def mlp_backward(d, s, a, x0, h1, dout, dh, dx0, da=None, param_grads=True, firs
             g["ba"] += dxa.sum(0)
         g["W0"] += dh.T @ xr
         g["b0"] += dh.sum(0)
-        g["W1"] += dout[:, :1].T @ hr
-        g["b1"] += dout[:, 0].sum()
+        hd = max(1, getattr(d, "head_dim", 1))
+        g["W1"] += dout[:, :hd].T @ hr
+        g["b1"] += dout[:, :hd].sum(0) if hd > 1 else dout[:, 0].sum()
         if d.n_out > 1:
             g["W1b"] += dout[:, 1:2].T @ hr
             g["b1b"] += dout[:, 1].sum()

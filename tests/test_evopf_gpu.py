@@ -249,39 +249,35 @@ def _golden(name):
     return golden(name)
 
 
-def test_update_matches_reference_on_gpu():
-    """RPODDPG.train for t = 1..4 on EVOPF (critic steps, one policy + multiplier step, Polyak) against the fixture
-    recorded from the reference (make_evopf_golden.gen_train_steps), every random draw replayed.  Tolerance: float32
-    GEMMs + 4 Adam steps 5e-6 on parameters; the actor gradient passes through the 22x22 Newton inverse -> 2e-5."""
+@pytest.mark.parametrize("envname,fused", [("evopf", False), ("evopf256", True), ("evopf256", False)],
+                         ids=["torch_mlp_64", "fused_mlp_256", "torch_mlp_256"])
+def test_update_matches_reference_on_gpu(envname, fused):
+    """RPODDPG.train for t = 1..4 on EVOPF (critic steps, one policy + multiplier step, Polyak) against the fixtures
+    recorded from the reference (make_evopf_golden.gen_train_steps), every random draw replayed; through the hand-written
+    MLP kernels (multi-output MFMA head) or the torch modules.  Tolerance: float32 GEMMs + 4 Adam steps 5e-6 on
+    parameters; the actor gradient passes through the 22x22 Newton inverse -> 2e-5."""
     import test_train_step_golden as tsg
     from rpo_amd import ops
-    g, tr, closs, aloss, proxy = tsg.run_product_update(_golden, "ddpg", "evopf", ops, torch.device("cuda"), fused=False)
-    ag = tr.agent
-    np.testing.assert_allclose(closs, g["critic_losses"], rtol=1e-4)
-    np.testing.assert_allclose(aloss, g["actor_losses"], rtol=1e-3, atol=1e-5)
-    for name, net, tol in (("critic4", ag.critic, 5e-6), ("critic_target4", ag.critic_target, 5e-6),
-                           ("actor4", ag.actor, 2e-5), ("actor_target4", ag.actor_target, 2e-5)):
-        for k, v in tsg.sd(g, name).items():
-            np.testing.assert_allclose(net.state_dict()[k].cpu().numpy(), v, rtol=0, atol=tol, err_msg=name + "." + k)
-    np.testing.assert_allclose(ag.nju.weight.detach().cpu().numpy(), g["nju4"], rtol=1e-4, atol=1e-6)
-    assert np.abs(g["nju4"] - 0.1).max() > 1e-2 and not proxy.noises and not proxy.idx
+    out = tsg.run_product_update(_golden, "ddpg", envname, ops, torch.device("cuda"), fused=fused)
+    tsg.check_evopf_update(*out)
 
 
-def _run(n_envs, iters, use_graph, seed_all=5, algo="ddpg", **extra):
+def _run(n_envs, iters, use_graph, seed_all=5, algo="ddpg", fused=False, **extra):
     import test_train_step_golden as tsg
     from rpo_amd import ops
     torch.manual_seed(seed_all)
-    tr = tsg.build_trainer(algo, "evopf", ops, torch.device("cuda"), fused=False, num_envs=n_envs, use_graph=use_graph,
-                           **extra)
+    tr = tsg.build_trainer(algo, "evopf256" if fused else "evopf", ops, torch.device("cuda"), fused=fused,
+                           num_envs=n_envs, use_graph=use_graph, **extra)
     tr.vec.reset()
     tr.run_steps(iters)
     torch.cuda.synchronize()
     return tr
 
 
-def test_training_iterations_graph_equals_eager_and_episodes_roll_over():
-    a = _run(64, 30, use_graph=False)
-    b = _run(64, 30, use_graph=True)
+@pytest.mark.parametrize("fused", [True, False], ids=["fused_mlp", "torch_mlp"])
+def test_training_iterations_graph_equals_eager_and_episodes_roll_over(fused):
+    a = _run(64, 30, use_graph=False, fused=fused)
+    b = _run(64, 30, use_graph=True, fused=fused)
     assert any(e["graph"] is not None for e in b._graphs.entries.values())
     assert torch.equal(a.vec.internal, b.vec.internal) and torch.equal(a.buffer.rows, b.buffer.rows)
     assert torch.equal(a.agent.flat.data, b.agent.flat.data)
@@ -307,3 +303,12 @@ def test_sac_on_evopf_runs_and_replays():
     lo, hi = a.base_env.update(rows[:, c["state"][0]:c["state"][1]].contiguous())
     ap = rows[:, c["action"][0]:c["action"][1]][:, a.base_env.partial_actions]
     assert bool((ap[:, :4] >= lo[:, :4] - 1e-3).all()) and bool((ap[:, :4] <= hi[:, :4] + 1e-3).all())
+
+
+def test_fused_and_torch_mlp_paths_agree_on_evopf():
+    """Same seeds, same Philox draws: the trainer on the hand-written MLP kernels and on the torch modules produce the
+    same transitions and (to float32 summation order) the same parameters after 12 iterations."""
+    a = _run(48, 12, use_graph=False, fused=True)
+    b = _run(48, 12, use_graph=False, fused=False, embed_dim=256, hidden_dim=256)
+    np.testing.assert_allclose(a.buffer.rows.cpu().numpy(), b.buffer.rows.cpu().numpy(), rtol=0, atol=2e-4)
+    np.testing.assert_allclose(a.agent.flat.data.cpu().numpy(), b.agent.flat.data.cpu().numpy(), rtol=0, atol=2e-5)

@@ -40,6 +40,13 @@ def sd(g, prefix):
     return {k[len(prefix) + 1:]: g[k] for k in g.files if k.startswith(prefix + ".")}
 
 
+def like(g, tensor):
+    """The view of a parameter tensor a fixture stores: everything, or every `sub`-th element (large networks)."""
+    sub = int(g["sub"]) if "sub" in g.files else 1
+    x = tensor.detach().cpu().numpy()
+    return x.reshape(-1)[::sub] if sub > 1 else x
+
+
 def buffer_rows(g, cols, width):
     n = g["buf.state"].shape[0]
     rows = np.zeros((n, width), dtype=np.float32)
@@ -111,9 +118,11 @@ EVOPF_HP = dict(batch_size=256, max_steps=10, warmup=0, lr_dual=2e-2, corr_lr=1e
 
 def _build_trainer(algo, envname, backend, device, **extra):
     cls = RPODDPG if algo == "ddpg" else RPOSAC
-    if envname == "evopf":
+    if envname.startswith("evopf"):
         from rpo_amd.env import EVOPFEnv
         args = dict(EVOPF_HP)
+        if envname != "evopf":                                  # "evopf256": the script's network sizes
+            args["embed_dim"] = args["hidden_dim"] = int(envname[5:])
         args.update(extra)
         return cls(EVOPFEnv(backend=backend, device=device), "/tmp/rpo_test", name="t", logger=None, max_epochs=10,
                    device=device, backend=backend, seed=11, **args)
@@ -153,7 +162,7 @@ class ReplayDraws(object):
 
 
 def product_tol(envname):
-    return TOL
+    return dict(rtol=0, atol=5e-6) if envname.startswith("evopf") else TOL
 
 
 def run_product_update(golden, algo, envname, backend, device, fused=True):
@@ -162,9 +171,9 @@ def run_product_update(golden, algo, envname, backend, device, fused=True):
     tr = build_trainer(algo, envname, backend, device, fused=fused, num_envs=1)
     ag = tr.agent
     for k, v in sd(g, "actor0").items():        # the shipped modules initialise exactly like the reference's
-        np.testing.assert_array_equal(ag.actor.state_dict()[k].cpu().numpy(), v)
+        np.testing.assert_array_equal(like(g, ag.actor.state_dict()[k]), v)
     for k, v in sd(g, "critic0").items():
-        np.testing.assert_array_equal(ag.critic.state_dict()[k].cpu().numpy(), v)
+        np.testing.assert_array_equal(like(g, ag.critic.state_dict()[k]), v)
     rows = torch.tensor(buffer_rows(g, tr.kernels.cols, tr.kernels.row_floats)).to(device)
     proxy = ReplayDraws(backend, g, rows, device)
     tr.backend = tr.buffer._ops = proxy
@@ -179,7 +188,7 @@ def run_product_update(golden, algo, envname, backend, device, fused=True):
             aloss.append(float(tr.last_losses["actor"]))
         if t == 1:
             for k, v in sd(g, "critic1").items():
-                np.testing.assert_allclose(ag.critic.state_dict()[k].cpu().numpy(), v, **product_tol(envname))
+                np.testing.assert_allclose(like(g, ag.critic.state_dict()[k]), v, **product_tol(envname))
     return g, tr, closs, aloss, proxy
 
 
@@ -208,21 +217,28 @@ def test_trainer_host_logic_matches_reference_update(golden, algo, envname, fuse
     check_product_update(*out, algo, envname)
 
 
-def test_evopf_trainer_host_logic_matches_reference_update(golden):
-    """RPODDPG on EVOPF-v0 (torch modules + autograd, volatile box, 14 basic actions) driven by the oracle backend:
-    four updates against the fixture recorded from the reference's evopf.py on the pypower stand-in
-    (tests/golden/make_evopf_golden.py).  Parameters 5e-6 (critic) / 2e-5 (actor: gradient through the Newton inverse)."""
+@pytest.mark.parametrize("envname,fused", [("evopf", False), ("evopf256", True), ("evopf256", False)],
+                         ids=["torch_mlp_64", "fused_mlp_256", "torch_mlp_256"])
+def test_evopf_trainer_host_logic_matches_reference_update(golden, envname, fused):
+    """RPODDPG on EVOPF-v0 (14 basic actions, state-dependent box; hand-orchestrated backward through the MLP kernels'
+    interface, or the torch modules + autograd) driven by the oracle backend: four updates against the fixtures
+    recorded from the reference's evopf.py on the pypower stand-in (tests/golden/make_evopf_golden.py).
+    Parameters 5e-6 (critic) / 2e-5 (actor: gradient through the Newton inverse)."""
     torch.set_num_threads(1)
-    g, tr, closs, aloss, proxy = run_product_update(golden, "ddpg", "evopf", ob, torch.device("cpu"), fused=False)
+    g, tr, closs, aloss, proxy = run_product_update(golden, "ddpg", envname, ob, torch.device("cpu"), fused=fused)
+    check_evopf_update(g, tr, closs, aloss, proxy)
+
+
+def check_evopf_update(g, tr, closs, aloss, proxy):
     ag = tr.agent
     np.testing.assert_allclose(closs, g["critic_losses"], rtol=1e-4)
     np.testing.assert_allclose(aloss, g["actor_losses"], rtol=1e-3, atol=1e-5)
     for name, net, tol in (("critic4", ag.critic, 5e-6), ("critic_target4", ag.critic_target, 5e-6),
                            ("actor4", ag.actor, 2e-5), ("actor_target4", ag.actor_target, 2e-5)):
         for k, v in sd(g, name).items():
-            np.testing.assert_allclose(net.state_dict()[k].cpu().numpy(), v, rtol=0, atol=tol, err_msg=name + "." + k)
+            np.testing.assert_allclose(like(g, net.state_dict()[k]), v, rtol=0, atol=tol, err_msg=name + "." + k)
     np.testing.assert_allclose(ag.nju.weight.detach().cpu().numpy(), g["nju4"], rtol=1e-4, atol=1e-6)
-    assert not proxy.noises and not proxy.idx
+    assert np.abs(g["nju4"] - 0.1).max() > 1e-2 and not proxy.noises and not proxy.idx
 
 
 def test_evopf_iterations_on_oracle_backend():
