@@ -160,7 +160,6 @@ struct ActArgs {
 // take_action's exploration + clip to the state-dependent box (agent/ddpg_pa.py:101-112, model/utils.py:53-62,90-101,
 // EVOPFEnv.update evopf.py:769-783) -> complete_partial -> grad_steps, one lane per wave.
 __global__ __launch_bounds__(RPO_WAVE) void evopf_act_project_kernel(ActArgs p) {
-    RPO_FP_STRICT
     __shared__ Ws w;
     const int i = blockIdx.x, tid = threadIdx.x;
     const long long t = p.ctrl ? p.ctrl[RPO_CTRL_T] : 0;

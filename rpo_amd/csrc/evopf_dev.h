@@ -91,7 +91,6 @@ __device__ __forceinline__ void partial_box(const Ws& w, int j, float& lo, float
 
 // cos / sin / rectangular voltages and the two admittance products of eq_resid / eq_jac (evopf.py:523-528,623-630)
 __device__ __forceinline__ void flows(Ws& w) {
-    RPO_FP_STRICT
     const int tid = threadIdx.x;
     if (tid < NB) {
         float sn, cs;
@@ -113,7 +112,6 @@ __device__ __forceinline__ void flows(Ws& w) {
 
 // eq_resid (evopf.py:520-546) of (w.s, w.a) into w.eq; flows() must be current
 __device__ __forceinline__ void eq_resid(Ws& w) {
-    RPO_FP_STRICT
     const int tid = threadIdx.x;
     if (tid < NEQ) {
         const int i = tid < NB ? tid : tid - NB;
@@ -155,7 +153,6 @@ __device__ __forceinline__ void ineq_resid(Ws& w) {
 // One entry of eq_jac (evopf.py:614-661): d eq[row] / d action[var], in the reference's orientation and with its sign
 // for the battery columns (d real / d pe = -I at :639-640 although eq_resid adds +pe: reproduced, DESIGN.md hazard E1).
 __device__ __forceinline__ float jac_entry(const Ws& w, int row, int var) {
-    RPO_FP_STRICT
     const bool real = row < NB;
     const int i = real ? row : row - NB;
     if (var < VM0) {                                           // pg / qg selectors
@@ -203,7 +200,7 @@ __device__ __forceinline__ void gauss_jordan(float (&col)[N]) {
         col[k] = mkc;
 #pragma unroll
         for (int r = 0; r < N; ++r)
-            if (r != k) col[r] -= lane_bcast(col[r], k) * mkc;
+            if (r != k) col[r] = fmaf(-lane_bcast(col[r], k), mkc, col[r]);
     }
 }
 
@@ -211,7 +208,6 @@ __device__ __forceinline__ void gauss_jordan(float (&col)[N]) {
 // threads 0..13 hold z[tid] in `zj`): Newton on (vm_pq, va_pv, va_pq) with the lane's own stop test, then qg and the
 // slack generation from the remaining equations.  Leaves flows()/eq of the completed action current.
 __device__ __forceinline__ int complete_partial(Ws& w, float zj, float tol, int max_iters) {
-    RPO_FP_STRICT
     const int tid = threadIdx.x;
     if (tid < NY) {
         float v = 0.0f;                                        // qg and the slack pg start at zero (:806-807)
@@ -257,7 +253,6 @@ __device__ __forceinline__ int complete_partial(Ws& w, float zj, float tol, int 
 
 // ineq_partial_grad (evopf.py:596-612) of (w.s, w.a) into w.dir[43]; flows() must be current.
 __device__ __forceinline__ void ineq_partial_grad(Ws& w) {
-    RPO_FP_STRICT
     const int tid = threadIdx.x;
     // thread c owns column c of [J_other | J_partial] (variable kOtherVars[c] or kPartialVars[c - 28])
     const int var = tid < NO ? kOtherVars[tid] : (tid < NY ? kPartialVars[tid - NO] : 0);
@@ -297,7 +292,6 @@ __device__ __forceinline__ void ineq_partial_grad(Ws& w) {
 
 // grad_steps (rpo_ddpg.py:266-305, corr_mode 0) on w.a with the lane's own stop test; returns the iteration count
 __device__ __forceinline__ int grad_steps(Ws& w, int max_steps, float lr, float corr_eps, float momentum) {
-    RPO_FP_STRICT
     const int tid = threadIdx.x;
     if (tid < NY) w.old[tid] = 0.0f;
     int k = 0;
