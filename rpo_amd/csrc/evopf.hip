@@ -223,16 +223,15 @@ __global__ __launch_bounds__(RPO_WAVE) void evopf_complete_bwd_kernel(int n, con
     }
     sync();
     // step 1 (:889-891): d_int = inv(J_newton)^T dl_dy_total[newton vars]
-    float col[NN];                                                      // column tid of [J_newton^T | rhs]
+    float row[NN + 1];                                                  // row tid of [J_newton^T | rhs]
 #pragma unroll
-    for (int r = 0; r < NN; ++r)
-        col[r] = tid < NN ? jac_entry(w, kKeep[tid], kNewtonVars[r]) : (tid == NN ? w.vec[kNewtonVars[r] - VM0] : 0.0f);
-    gauss_jordan<NN, 0>(col);
+    for (int c = 0; c < NN; ++c) row[c] = tid < NN ? jac_entry(w, kKeep[c], kNewtonVars[tid]) : 0.0f;
+    row[NN] = tid < NN ? w.vec[kNewtonVars[tid] - VM0] : 0.0f;
+    int mycol;
+    float mypiv;
+    gauss_jordan_rows<NN, NN + 1, 0>(row, mycol, mypiv);
     sync();
-    if (tid == NN) {
-#pragma unroll
-        for (int r = 0; r < NN; ++r) w.old[r] = col[r];                 // d_int
-    }
+    if (tid < NN) w.old[mycol] = row[NN] / mypiv;                       // d_int
     sync();
     if (tid < NP) {
         float g;

@@ -3,12 +3,14 @@
 // Every lane needs dense linear algebra on its own small matrices -- the 22x22 Newton system of the power-flow
 // equation solver (PFFunction, evopf.py:786-855) and the 28x28 block of the equality Jacobian whose inverse defines the
 // GRG direction (ineq_partial_grad, evopf.py:596-612).  A thread per lane would keep ~1200 floats of matrix in scratch
-// memory; instead the 64 threads of a wave share one lane and THREAD c KEEPS COLUMN c OF THE MATRIX IN ITS REGISTERS
-// (28 floats): it evaluates its own Jacobian column, Gauss-Jordan broadcasts the pivot column with v_readlane (the pivot
-// index is a compile-time constant once the pivot loop is unrolled), row swaps are predicated register moves, and only
-// the small result vectors go through LDS.  (A first version eliminated in LDS: every `M[r][c] -= M[r][k] * M[k][c]`
-// waited out the LDS round trip because loads and stores to the same array cannot be reordered -- 60 us per GRG
-// iteration, measured; see DESIGN.md.)  Workgroup = 1 wave, so the barriers below only order LDS traffic of that wave.
+// memory; instead the 64 threads of a wave share one lane and THREAD r KEEPS ROW r OF THE MATRIX IN ITS REGISTERS (up to
+// 43 floats): it evaluates its own Jacobian row (the column index is a compile-time constant in the unrolled loops, so
+// which block of the Jacobian an entry belongs to costs nothing), the pivot search is a 5-step DPP max over (|value|,
+// lane) keys, the pivot row is broadcast with v_readlane (lane index in an SGPR), rows are never swapped -- every
+// thread just remembers which unknown its row ended up solving -- and only the small result vectors go through LDS.
+// History: eliminating in LDS cost 60 us per GRG iteration (dependent LDS round trips); one COLUMN per
+// thread 16 us (the serial pivot search and the predicated row swaps ran in every thread); one ROW per thread: see
+// tools/evopf_probe.py.  Workgroup = 1 wave, so the barriers below only order LDS traffic of that wave.
 //
 // The network is the IEEE 14-bus case exactly like the reference (case14 hard-wired at evopf.py:211, eq_num = 28 and
 // ineq_num = 58 hard-coded at :336-337): the bus classification is compiled in, every number (admittances, limits, costs,
@@ -173,34 +175,79 @@ __device__ __forceinline__ float jac_entry(const Ws& w, int row, int var) {
     return (d * pi_ * w.t2[i]) + w.vr[i] * (yi * p + yr * q) - (d * qi_ * w.t1[i]) - w.vi[i] * (yr * p - yi * q);
 }
 
-__device__ __forceinline__ float lane_bcast(float v, int lane) {
+__device__ __forceinline__ float lane_bcast(float v, int lane) {          // lane: wave-uniform
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// Gauss-Jordan with partial pivoting, matrix distributed one column per thread: col[r] = M[r][threadIdx.x].  On return
-// the leading N x N block is the identity and every further column holds inv(block) @ (its original content).  The
-// first K0 columns must already be unit vectors e_0 .. e_{K0-1}.  Threads whose column is not part of the system must
-// pass zeros.  Fully unrolled: all register indices and the broadcast lane are compile-time constants.
-template <int N, int K0>
-__device__ __forceinline__ void gauss_jordan(float (&col)[N]) {
+// max over lanes 0..31 of a key, returned to every thread (DPP row shifts, then row 0's result is merged into row 1)
+__device__ __forceinline__ unsigned half_wave_umax(unsigned key) {
+    unsigned o;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x111, 0xf, 0xf, false); key = key > o ? key : o;   // row_shr:1
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x112, 0xf, 0xf, false); key = key > o ? key : o;   // row_shr:2
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x114, 0xf, 0xf, false); key = key > o ? key : o;   // row_shr:4
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x118, 0xf, 0xf, false); key = key > o ? key : o;   // row_shr:8
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, 0x142, 0xa, 0xf, false); key = key > o ? key : o;   // row_bcast:15
+    return (unsigned)__builtin_amdgcn_readlane((int)key, 31);
+}
+
+// Per-thread view of the equation (Jacobian row) a thread owns: everything of eq_jac (evopf.py:614-661) that does not
+// depend on the column.  With A = Yr[i][k] p_k - Yi[i][k] q_k and B = Yi[i][k] p_k + Yr[i][k] q_k, where (p, q) =
+// d(vr_k, vi_k)/d var = (cos, sin) for vm_k and (-vi, vr) for va_k:
+//   real row      d/dvar = -(vr_i A + vi_i B) - [i == k] (p_i t1_i + q_i t2_i)
+//   reactive row  d/dvar =  (vr_i B - vi_i A) + [i == k] (p_i t2_i - q_i t1_i)
+struct RowCoef {
+    int i;            // bus of the equation
+    bool real;        // active (true) or reactive power balance
+    float ca, cb;     // coefficients of A and B
+    float dg_vm, dg_va;   // diagonal terms for the vm / va column of the same bus
+};
+
+__device__ __forceinline__ RowCoef row_coef(const Ws& w, int eq) {
+    RowCoef c;
+    c.real = eq < NB;
+    c.i = c.real ? eq : eq - NB;
+    const float vr = w.vr[c.i], vi = w.vi[c.i], cs = w.cs[c.i], sn = w.sn[c.i], t1 = w.t1[c.i], t2 = w.t2[c.i];
+    c.ca = c.real ? -vr : -vi;
+    c.cb = c.real ? -vi : vr;
+    c.dg_vm = c.real ? -(cs * t1 + sn * t2) : (cs * t2 - sn * t1);
+    c.dg_va = c.real ? -(-vi * t1 + vr * t2) : (-vi * t2 - vr * t1);
+    return c;
+}
+
+// eq_jac entry (this thread's equation, variable `var`); `var` is a compile-time constant at every call site, so only
+// the block it names survives.  Battery columns carry the reference's sign (hazard E1).
+__device__ __forceinline__ float jac_row_entry(const Ws& w, const RowCoef& c, int var) {
+    if (var < QG0) return (c.real && kSpv[var] == c.i) ? 1.0f : 0.0f;
+    if (var < VM0) return (!c.real && kSpv[var - QG0] == c.i) ? 1.0f : 0.0f;
+    if (var >= PE0) return (c.real && kSpv[var - PE0] == c.i) ? -1.0f : 0.0f;
+    const bool dvm = var < VA0;
+    const int k = dvm ? var - VM0 : var - VA0;
+    const float yr = Yr(w, c.i, k), yi = Yi(w, c.i, k);
+    const float p = dvm ? w.cs[k] : -w.vi[k], q = dvm ? w.sn[k] : w.vr[k];
+    const float A = yr * p - yi * q, B = yi * p + yr * q;
+    return c.ca * A + c.cb * B + (c.i == k ? (dvm ? c.dg_vm : c.dg_va) : 0.0f);
+}
+
+// Gauss-Jordan with partial pivoting on an N x NC system distributed one ROW per thread (threads >= N pass zeros).
+// Rows are not swapped and pivot rows are not normalised: on return thread r's row solves unknown `mycol` and
+// row[c] / mypiv (c >= N) is entry [mycol][c] of inv(A) @ (the trailing columns).  The first K0 rows must be the unit
+// rows e_0 .. e_{K0-1} within the first K0 columns, and the other rows zero there.
+template <int N, int NC, int K0>
+__device__ __forceinline__ void gauss_jordan_rows(float (&row)[NC], int& mycol, float& mypiv) {
+    const int lane = threadIdx.x;
+    bool used = lane < K0 || lane >= N;
+    mycol = lane < K0 ? lane : 0;
+    mypiv = 1.0f;
 #pragma unroll
     for (int k = K0; k < N; ++k) {
-        float best = col[k];                                   // pivot search runs in every lane, lane k's result counts
-        int p = k;
+        const unsigned key = used ? 0u : ((__float_as_uint(fabsf(row[k])) & ~31u) | (unsigned)lane);
+        const int p = (int)(half_wave_umax(key) & 31u);
+        const float piv = lane_bcast(row[k], p);
+        const bool is_p = lane == p;
+        const float f = is_p ? 0.0f : -row[k] * (1.0f / piv);
+        if (is_p) { used = true; mycol = k; mypiv = piv; }
 #pragma unroll
-        for (int r = k + 1; r < N; ++r)
-            if (fabsf(col[r]) > fabsf(best)) { best = col[r]; p = r; }
-        p = __builtin_amdgcn_readlane(p, k);
-        best = lane_bcast(best, k);
-        float xk = col[k];                                     // swap rows k <-> p of this thread's column
-#pragma unroll
-        for (int r = k + 1; r < N; ++r)
-            if (r == p) { const float t = col[r]; col[r] = xk; xk = t; }
-        const float mkc = xk / best;                           // normalised pivot row; 0 in finished columns, 1 in column k
-        col[k] = mkc;
-#pragma unroll
-        for (int r = 0; r < N; ++r)
-            if (r != k) col[r] = fmaf(-lane_bcast(col[r], k), mkc, col[r]);
+        for (int c = k + 1; c < NC; ++c) row[c] = fmaf(f, lane_bcast(row[c], p), row[c]);
     }
 }
 
@@ -222,15 +269,17 @@ __device__ __forceinline__ int complete_partial(Ws& w, float zj, float tol, int 
     for (; it < max_iters;) {
         flows(w);
         eq_resid(w);
-        float col[NN];                                         // column tid of [J_newton | g]
+        float row[NN + 1];                                     // row tid of [J_newton | g]
+        {
+            const RowCoef rc = row_coef(w, kKeep[tid < NN ? tid : 0]);
 #pragma unroll
-        for (int r = 0; r < NN; ++r)
-            col[r] = tid < NN ? jac_entry(w, kKeep[r], kNewtonVars[tid]) : (tid == NN ? w.eq[kKeep[r]] : 0.0f);
-        gauss_jordan<NN, 0>(col);
-        if (tid == NN) {
-#pragma unroll
-            for (int r = 0; r < NN; ++r) w.vec[r] = col[r];    // delta = inv(J) g (:832)
+            for (int c = 0; c < NN; ++c) row[c] = tid < NN ? jac_row_entry(w, rc, kNewtonVars[c]) : 0.0f;
+            row[NN] = tid < NN ? w.eq[kKeep[tid]] : 0.0f;
         }
+        int mycol;
+        float mypiv;
+        gauss_jordan_rows<NN, NN + 1, 0>(row, mycol, mypiv);
+        if (tid < NN) w.vec[mycol] = row[NN] / mypiv;          // delta = inv(J) g (:832)
         sync();
         float d2 = 0.0f;
         if (tid < NN) {
@@ -254,13 +303,25 @@ __device__ __forceinline__ int complete_partial(Ws& w, float zj, float tol, int 
 // ineq_partial_grad (evopf.py:596-612) of (w.s, w.a) into w.dir[43]; flows() must be current.
 __device__ __forceinline__ void ineq_partial_grad(Ws& w) {
     const int tid = threadIdx.x;
-    // thread c owns column c of [J_other | J_partial] (variable kOtherVars[c] or kPartialVars[c - 28])
-    const int var = tid < NO ? kOtherVars[tid] : (tid < NY ? kPartialVars[tid - NO] : 0);
-    float col[NEQ];
+    // thread r owns equation kRowOrder[r] of [J_other | J_partial]
+    float row[NY];
+    {
+        const RowCoef rc = row_coef(w, kRowOrder[tid < NEQ ? tid : 0]);
 #pragma unroll
-    for (int r = 0; r < NEQ; ++r) col[r] = tid < NY ? jac_entry(w, kRowOrder[r], var) : 0.0f;
+        for (int c = 0; c < NY; ++c) {
+            const int var = c < NO ? kOtherVars[c] : kPartialVars[c - NO];
+            row[c] = tid < NEQ ? jac_row_entry(w, rc, var) : 0.0f;
+        }
+    }
     ineq_resid(w);                                             // (syncs)
-    gauss_jordan<NEQ, 6>(col);                                 // columns 28.. now hold inv(J_o) J_p = -dynz_dz (:598)
+    int mycol;
+    float mypiv;
+    gauss_jordan_rows<NEQ, NY, 6>(row, mycol, mypiv);
+    if (tid < NO) {                                            // inv(J_o) J_p = -dynz_dz (:598), row of unknown `mycol`
+        const float inv = 1.0f / mypiv;
+#pragma unroll
+        for (int p = 0; p < NPV; ++p) w.D[mycol][p] = row[NO + p] * inv;
+    }
     if (tid < NY) {                                            // ineq_grad_new (:590-594): +-1 per violated bound
         float g = 0.0f;
         if (tid < QG0) g = (w.ineq[tid] > 0.0f ? 1.0f : 0.0f) - (w.ineq[5 + tid] > 0.0f ? 1.0f : 0.0f);
@@ -270,21 +331,18 @@ __device__ __forceinline__ void ineq_partial_grad(Ws& w) {
         w.vec[tid] = g;
     }
     sync();
-    if (tid >= NO && tid < NY) {                               // indirect + direct (:603-606), one partial var per thread
+    if (tid < NPV) {                                           // indirect + direct (:603-606)
         float acc = 0.0f;
 #pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            acc += -col[o] * w.vec[kOtherVars[o]];
-            w.D[o][tid - NO] = col[o];
-        }
-        w.fp[tid - NO] = acc + w.vec[var];
+        for (int o = 0; o < NO; ++o) acc = fmaf(-w.D[o][tid], w.vec[kOtherVars[o]], acc);
+        w.fp[tid] = acc + w.vec[kPartialVars[tid]];
     }
     sync();
     if (tid < NPV) w.dir[kPartialVars[tid]] = w.fp[tid];
     if (tid < NO) {                                            // (:610)
         float acc = 0.0f;
 #pragma unroll
-        for (int p = 0; p < NPV; ++p) acc += -w.D[tid][p] * w.fp[p];
+        for (int p = 0; p < NPV; ++p) acc = fmaf(-w.D[tid][p], w.fp[p], acc);
         w.dir[kOtherVars[tid]] = acc;
     }
     sync();
