@@ -303,40 +303,73 @@ __global__ __launch_bounds__(kThreads) void mlp_bwd_weights_kernel(BwdArgs p) {
     const int b_lo = (int)(((long long)p.n * part) / 4), b_hi = (int)(((long long)p.n * (part + 1)) / 4);
     const int rb = (int)blockIdx.x - GEMM_BLOCKS;
     constexpr int HV_BLOCKS = H / 64;
-    if (rb < HV_BLOCKS && net.hd > 1) {
-        // multi-output head: db0[j], dW1_k[o][j] = sum_b dout[b][k*hd + o] relu(h1[b][j]), db1_k[o] = sum_b dout[b][k*hd + o]
+    const int hv_blocks = net.hd > 1 ? H / 16 : HV_BLOCKS;
+    if (rb < hv_blocks && net.hd > 1) {
+        // multi-output head: db0[j], dW1_k[o][j] = sum_b dout[b][k*hd + o] relu(h1[b][j]), db1_k[o] = sum_b dout[b][k*hd + o].
+        // 16 hidden columns per workgroup, the batch split 16 ways and combined through LDS in a fixed order (one owner per
+        // output): H/16 workgroups x 16 batch slices keep the exposed load latency to n/16 rows per thread.
         if (p.first_layer_state_only) return;
-        __shared__ float wide[4][kWideOut + 1][64];
+        __shared__ float wide[16][kWideOut + 1][16];
         const int outs = net.n_out * net.hd;
-        const int j = rb * 64 + o;
+        const int jj = tid & 15, slice = tid >> 4;
+        const int j = rb * 16 + jj;
+        const int lo = (int)(((long long)p.n * slice) / 16), hi = (int)(((long long)p.n * (slice + 1)) / 16);
         float gb0 = 0.0f, gw[kWideOut];
 #pragma unroll
         for (int q = 0; q < kWideOut; ++q) gw[q] = 0.0f;
-        for (int bb = b_lo; bb < b_hi; ++bb) {
+        int bb = lo;
+        for (; bb + 4 <= hi; bb += 4) {
+            float d[4], h[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                d[u] = p.dh[(size_t)(bb + u) * H + j];
+                h[u] = fmaxf(p.h1[(size_t)(bb + u) * H + j], 0.0f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                gb0 += d[u];
+                const float* drow = p.dout + (size_t)(bb + u) * outs;
+#pragma unroll
+                for (int q = 0; q < kWideOut; ++q)
+                    if (q < outs) gw[q] = fmaf(drow[q], h[u], gw[q]);
+            }
+        }
+        for (; bb < hi; ++bb) {
             gb0 += p.dh[(size_t)bb * H + j];
             const float hr = fmaxf(p.h1[(size_t)bb * H + j], 0.0f);
 #pragma unroll
             for (int q = 0; q < kWideOut; ++q)
                 if (q < outs) gw[q] = fmaf(p.dout[(size_t)bb * outs + q], hr, gw[q]);
         }
-        wide[part][kWideOut][o] = gb0;
+        wide[slice][kWideOut][jj] = gb0;
 #pragma unroll
-        for (int q = 0; q < kWideOut; ++q) wide[part][q][o] = gw[q];
+        for (int q = 0; q < kWideOut; ++q) wide[slice][q][jj] = gw[q];
         __syncthreads();
-        if (part == 0) {
-            p.g.b0[j] += ((wide[0][kWideOut][o] + wide[1][kWideOut][o]) + wide[2][kWideOut][o]) + wide[3][kWideOut][o];
-            for (int q = 0; q < outs; ++q) {
-                float* dst = q < net.hd ? &p.g.W1[(size_t)q * H + j] : &p.g.W1b[(size_t)(q - net.hd) * H + j];
-                *dst += ((wide[0][q][o] + wide[1][q][o]) + wide[2][q][o]) + wide[3][q][o];
-            }
+        for (int idx = tid; idx < (outs + 1) * 16; idx += kThreads) {
+            const int q = idx >> 4, c = idx & 15;                  // q == outs: the db0 column sums
+            const int src = q == outs ? kWideOut : q;
+            float tot = 0.0f;
+            for (int sl = 0; sl < 16; ++sl) tot += wide[sl][src][c];
+            float* dst = q == outs ? &p.g.b0[rb * 16 + c]
+                                   : (q < net.hd ? &p.g.W1[(size_t)q * H + rb * 16 + c] : &p.g.W1b[(size_t)(q - net.hd) * H + rb * 16 + c]);
+            *dst += tot;
         }
         if (rb == 0) {
+            // db1: 8 batch slices x 32 outputs, combined in a fixed order
             __syncthreads();
-            if (tid < outs) {                                      // db1: one owner per output, batch order
-                float s0 = 0.0f;
-                for (int b2 = 0; b2 < p.n; ++b2) s0 += p.dout[(size_t)b2 * outs + tid];
+            float* red = &wide[0][0][0];
+            const int q = tid & 31, sl8 = tid >> 5;
+            const int l8 = (int)(((long long)p.n * sl8) / 8), h8 = (int)(((long long)p.n * (sl8 + 1)) / 8);
+            float s0 = 0.0f;
+            if (q < outs)
+                for (int b2 = l8; b2 < h8; ++b2) s0 += p.dout[(size_t)b2 * outs + q];
+            red[sl8 * 32 + q] = s0;
+            __syncthreads();
+            if (tid < outs) {
+                float tot = 0.0f;
+                for (int sl = 0; sl < 8; ++sl) tot += red[sl * 32 + tid];
                 float* dst = tid < net.hd ? &p.g.b1[tid] : &p.g.b1b[tid - net.hd];
-                *dst += s0;
+                *dst += tot;
             }
         }
         return;
@@ -400,7 +433,7 @@ __global__ __launch_bounds__(kThreads) void mlp_bwd_weights_kernel(BwdArgs p) {
     // first layer: output list idx = q * E + e (e fastest: coalesced dx0 reads); q < wS: state weights / bias,
     // q >= wS: action weights / bias.  Columns of x0: [0, E) <- state (+ action when added); [E, 2E) <- action (cat).
     const int wS = net.S + 1, wA = (net.A > 0 && !p.first_layer_state_only) ? net.A + 1 : 0;   // +1: the bias
-    const int idx = (rb - HV_BLOCKS) * 64 + o;
+    const int idx = (rb - hv_blocks) * 64 + o;
     const bool valid = idx < net.E * (wS + wA);
     float acc = 0.0f;
     int e = 0, i = 0, width = 0;
@@ -590,7 +623,7 @@ int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int
     BwdArgs args{net, g, n, s, s_stride, a, a_stride, x0, h1, dout, dh, dx0, da, param_grads, first_layer_state_only};
     const int grid_rows = (n + kRows - 1) / kRows;
     const int fl_outputs = net.E * (net.S + 1 + ((net.A > 0 && !first_layer_state_only) ? net.A + 1 : 0));
-    const int grid_w = (net.H / 16) * (ein / 64) + net.H / 64 + (fl_outputs + 63) / 64;
+    const int grid_w = (net.H / 16) * (ein / 64) + (net.hd > 1 ? net.H / 16 : net.H / 64) + (fl_outputs + 63) / 64;
 #define RPO_MLP_BWD(EIN_, H_)                                                                                       \
     if (ein == EIN_ && net.H == H_) {                                                                               \
         hipLaunchKernelGGL((mlp_bwd_rows_kernel<EIN_, H_>), dim3(grid_rows), dim3(kThreads), 0, (hipStream_t)stream, \
