@@ -106,7 +106,8 @@ class _PartialActionAgent(Agent):
         torch.save(self.critic.state_dict(), os.path.join(save_dir, "critic.pth"))
         torch.save(dict(actor_optim=self.actor_optim.state_dict(), critic_optim=self.critic_optim.state_dict(),
                         nju=self.nju.state_dict(), lamb=self.lamb.state_dict(), nju_optim=self.nju_optim.state_dict(),
-                        eps=self.eps), os.path.join(save_dir, "agent_state.pth"))
+                        eps=self.eps, critic_target=self.critic_target_flat,
+                        actor_target=self.actor_target_flat), os.path.join(save_dir, "agent_state.pth"))
 
     def load_model(self, load_dir):
         dev = self.device
@@ -117,7 +118,7 @@ class _PartialActionAgent(Agent):
                     p.copy_(sd[k])          # in place: the tensors are views of the flat buffer
         extra = os.path.join(load_dir, "agent_state.pth")
         if os.path.exists(extra):
-            st = torch.load(extra, map_location=dev)
+            st = torch.load(extra, map_location=dev, weights_only=False)
             self.actor_optim.load_state_dict(st["actor_optim"])
             self.critic_optim.load_state_dict(st["critic_optim"])
             self.nju_optim.load_state_dict(st["nju_optim"])
@@ -126,6 +127,10 @@ class _PartialActionAgent(Agent):
                 self.lamb.weight.copy_(st["lamb"]["weight"])
             self.eps = st["eps"]
         self.hard_update()
+        if os.path.exists(extra) and st.get("critic_target") is not None:      # exact resume: the targets as they were
+            self.critic_target_flat.copy_(st["critic_target"])
+            if self.actor_target_flat is not None and st.get("actor_target") is not None:
+                self.actor_target_flat.copy_(st["actor_target"])
 
 
 class PDDDPG_PA(_PartialActionAgent):

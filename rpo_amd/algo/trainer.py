@@ -509,9 +509,50 @@ class RPOTrainerBase(object):
         print("============================\n")
 
     # ------------------------------------------------------------------------------------------ checkpoints
-    def load(self):
-        self.agent.load_model(self.work_dir)
+    def save(self, replay=True):
+        """Checkpoint for an exact resume (the reference's save/load, agent/ddpg_pa.py:92-99, stores
+        parameter generators and cannot be loaded): networks, targets, optimiser moments and step counters, multipliers,
+        the env lanes with their episode bookkeeping, the device step counter that keys every Philox stream, and
+        (``replay=True``) the filled part of this rank's replay shard.  One directory per rank when data-parallel."""
+        d = self._ckpt_dir()
+        os.makedirs(d, exist_ok=True)
+        self.agent.save_model(d)
+        self._harvest()
+        v, b = self.vec, self.buffer
+        filled = min(self._t, b.capacity) * b.n_envs
+        state = dict(t=self._t, updates=self._updates, seed=self.seed, num_envs=self.num_envs, world=self.dist.world,
+                     internal=v.internal, obs=None if v.obs is v.internal else v.obs, ep_len=v.ep_len, ep_ret=v.ep_ret,
+                     ep_count=v.ep_count, ctrl=v.ctrl, rows=b.rows[:filled].clone() if replay else None,
+                     pending=self._pending, viol_steps=self.viol_steps, env_steps=self.env_steps)
+        torch.save(state, os.path.join(d, "trainer_state.pth"))
 
-    def save(self):
-        os.makedirs(self.work_dir, exist_ok=True)
-        self.agent.save_model(self.work_dir)
+    def load(self):
+        d = self._ckpt_dir()
+        self.agent.load_model(d)
+        path = os.path.join(d, "trainer_state.pth")
+        if not os.path.exists(path):
+            return
+        st = torch.load(path, map_location=self.device, weights_only=False)
+        if st["seed"] != self.seed or st["num_envs"] != self.num_envs or st["world"] != self.dist.world:
+            raise ValueError("checkpoint was written with seed/num_envs/world = %s/%s/%s, this trainer has %s/%s/%s"
+                             % (st["seed"], st["num_envs"], st["world"], self.seed, self.num_envs, self.dist.world))
+        v, b = self.vec, self.buffer
+        v.internal.copy_(st["internal"])
+        if st["obs"] is not None:
+            v.obs.copy_(st["obs"])
+        v.ep_len.copy_(st["ep_len"])
+        v.ep_ret.copy_(st["ep_ret"])
+        v.ep_count.copy_(st["ep_count"])
+        v.ctrl.copy_(st["ctrl"])
+        v.stats.zero_()
+        if st["rows"] is not None:
+            b.rows[:st["rows"].shape[0]].copy_(st["rows"])
+        self._t = self._harvested = int(st["t"])
+        self._updates = int(st["updates"])
+        b._steps_host = v.steps_host = self._t
+        self._pending = list(st["pending"])
+        self.viol_steps, self.env_steps = st["viol_steps"], st["env_steps"]
+        self.agent.eps = max(self.eps, self.eps_start - self.decay_value * self._t)
+
+    def _ckpt_dir(self):
+        return self.work_dir if not self.dist.on else os.path.join(self.work_dir, "rank%d" % self.dist.rank)
