@@ -291,10 +291,13 @@ int rpo_absmax(long long n, const float* x, float* max_out, void* stream);
  *   (written back, as clip_grad_norm_ does); maximize: g = -g; weight decay; Adam with bias correction at step
  *   step_dev[0] + 1 (the counter is advanced by the launch); clamp_min0: p = max(p, 0); target != NULL:
  *   target = (1 - tau) * target + tau * p.   gradmax is reset to 0 by the launch when reset_gradmax != 0.
+ *   zero_grad != 0: instead of the clipped value, 0 is written back -- the gradient is consumed, so that the next
+ *   backward pass (which accumulates) needs no separate fill launch (optimizer.zero_grad() folded into the step).
  *   step_dev points at int32[4] (16-byte aligned): {step, pad, 8-byte arrival word (0 between launches)}. */
 int rpo_adam_step(long long n, float* param, float* grad, float* exp_avg, float* exp_avg_sq, int* step_dev,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int maximize, float clip_thres,
-                  float* gradmax, int reset_gradmax, int clamp_min0, float* target, float tau, void* stream);
+                  float* gradmax, int reset_gradmax, int zero_grad, int clamp_min0, float* target, float tau,
+                  void* stream);
 
 /* soft_update alone (agent/ddpg_pa.py:77-86, sac_pa.py:87-91): target = (1 - tau) * target + tau * param. */
 int rpo_polyak(long long n, const float* param, float* target, float tau, void* stream);

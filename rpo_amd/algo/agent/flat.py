@@ -91,6 +91,9 @@ class FusedAdam(object):
         self.exp_avg_sq = torch.zeros_like(param)
         self.step_dev = torch.zeros(4, dtype=torch.int32, device=dev)       # {step, pad, arrival word}
         self.gradmax = torch.zeros(1, device=dev)
+        # True: the step leaves a zeroed gradient slice behind (optimizer.zero_grad() folded into the Adam launch); the
+        # trainers switch it on when every backward of the iteration goes through the accumulating MLP kernels
+        self.zero_grad_after = False
 
     def step(self, target=None, tau=0.0):
         clip = self.clip_thres if self.clip_thres and self.clip_thres != float("inf") else 0.0
@@ -98,7 +101,7 @@ class FusedAdam(object):
             self.backend.absmax(self.grad, self.gradmax)
         self.backend.adam_step(self.param, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr,
                                self.betas[0], self.betas[1], self.eps, self.weight_decay, self.maximize, clip,
-                               self.gradmax, True, self.clamp_min0, target, tau)
+                               self.gradmax, True, self.clamp_min0, target, tau, zero_grad=self.zero_grad_after)
 
     def state_dict(self):
         return dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, step=self.step_dev, lr=self.lr)

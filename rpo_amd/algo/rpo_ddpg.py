@@ -93,7 +93,7 @@ class RPODDPG(RPOTrainerBase):
             self._batch, None, idx_in, buf.seed, 0, buf.ctrl, self.max_steps, self.corr_lr, self.corr_eps,
             self.corr_momentum, self._box_lo, self._box_hi, ag.gamma, f.buf("q", B, 1), f.buf("qn", B, 1),
             f.buf("dq", B, 1), parts, f.buf("critic.x0", B, d.ein), f.buf("critic.h1", B, d.H))
-        ag.flat.grad.zero_()
+        self._zero_grads()
         f.backward("critic", state, action, f.buf("dq", B, 1))
         self.last_losses["critic"] = _LazySum(parts)
 
@@ -112,7 +112,7 @@ class RPODDPG(RPOTrainerBase):
         loss.zero_()
         self.backend.td_huber(q.view(-1), None, qn.view(-1), None, None, 0.0, reward, done, ag.gamma, loss, dq.view(-1),
                               None)
-        ag.flat.grad.zero_()
+        self._zero_grads()
         f.backward("critic", state, action, dq)
         self.last_losses["critic"] = loss[0]
 
@@ -129,7 +129,7 @@ class RPODDPG(RPOTrainerBase):
         q = f.forward("critic", state, actions, f.buf("q", B, 1), save=True)
         lag, g_act = f.buf("loss_lag", 1), f.buf("g_act", B, k.action_dim)
         lag.zero_()
-        ag.flat.grad.zero_()               # parameters AND multipliers (they live in the same flat buffer)
+        self._zero_grads()                 # parameters AND multipliers (they live in the same flat buffer)
         k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1), obs=state)
         dq = f.buf("dq", B, 1)
         dq.fill_(-1.0 / B)

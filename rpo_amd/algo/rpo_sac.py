@@ -89,7 +89,7 @@ class RPOSAC(RPOTrainerBase):
         loss.zero_()
         self.backend.td_huber(q1.view(-1), q2.view(-1), qn1.view(-1), qn2.view(-1), logp, float(ag.alpha), reward, done,
                               ag.gamma, loss, dq1.view(-1), dq2.view(-1))
-        ag.flat.grad.zero_()
+        self._zero_grads()
         f.backward("critic1", state, action, dq1)
         f.backward("critic2", state, action, dq2)
         self.last_losses["critic"] = loss[0]
@@ -106,7 +106,7 @@ class RPOSAC(RPOTrainerBase):
         q2 = f.forward("critic2", state, actions, f.buf("q2", B, 1), save=True)
         lag, g_act = f.buf("loss_lag", 1), f.buf("g_act", B, k.action_dim)
         lag.zero_()
-        ag.flat.grad.zero_()               # parameters AND multipliers (they live in the same flat buffer)
+        self._zero_grads()                 # parameters AND multipliers (they live in the same flat buffer)
         k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1))
         # d(-min(q1, q2))/dq: the smaller one takes the gradient, ties are split (torch.min's backward)
         w1 = (q1 < q2).to(torch.float32) + 0.5 * (q1 == q2).to(torch.float32)

@@ -189,6 +189,13 @@ class RPOTrainerBase(object):
         box = agent.actor.box_constraint
         self._box_affine = (float(np.asarray(box.scale).reshape(-1)[0]), float(np.asarray(box.base).reshape(-1)[0])) \
             if box is not None and not box.volatile else None
+        # hand-written backward kernels accumulate into the flat gradient buffer; their optimiser steps then consume the
+        # gradients (zero them), which removes the fill launches from the iteration (data-parallel: the slices are
+        # averaged in place between backward and step, then consumed the same way).  The torch/autograd path keeps its
+        # explicit zeroing.
+        self._self_cleaning = self.fused is not None
+        for opt in (agent.critic_optim, agent.actor_optim, agent.nju_optim):
+            opt.zero_grad_after = self._self_cleaning
         # fused multi-output actor: raw outputs, the env's projection kernel applies the state-dependent tanh box
         self._act_kw = dict(ap_is_raw=True) if (self.fused is not None and self._box_affine is None) else {}
         self._t = 0                 # loop iterations (== vector steps) done
@@ -267,6 +274,14 @@ class RPOTrainerBase(object):
             return self.eps_start
         t = self.vec.ctrl[0].to(torch.float32)
         return torch.clamp(self.eps_start - self.decay_value * t, min=self.eps)
+
+    def _zero_grads(self):
+        """Before a backward of the fused path: nothing to do when the optimiser steps leave zeroed slices behind
+        (only the multipliers of a `fixed` run are never stepped)."""
+        if not self._self_cleaning:
+            self.agent.flat.grad.zero_()
+        elif self.fixed:
+            self.agent.nju.weight.grad.zero_()
 
     def _critic_update(self, cols):
         state, action, next_state, reward, done, ineq_viol, eq_viol = cols

@@ -81,6 +81,7 @@ struct AdamArgs {
     float clip_thres;
     float* gradmax;
     int reset_gradmax;
+    int zero_grad;
     int clamp_min0;
     float* target;
     float tau;
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(RPO_BLOCK) void adam_kernel(AdamArgs p) {
     const float omb1 = 1.0f - p.beta1, omb2 = 1.0f - p.beta2;
     for (long long i = (long long)blockIdx.x * RPO_BLOCK + threadIdx.x; i < p.n; i += (long long)gridDim.x * RPO_BLOCK) {
         float g = p.grad[i] * coef;
-        if (p.clip_thres > 0.0f) p.grad[i] = g;
+        if (p.zero_grad) p.grad[i] = 0.0f;            // the gradient is consumed: the next backward accumulates from zero
+        else if (p.clip_thres > 0.0f) p.grad[i] = g;  // clip_grad_norm_ scales the gradients in place
         if (p.maximize) g = -g;
         float w = p.param[i];
         if (p.weight_decay != 0.0f) g += p.weight_decay * w;
@@ -200,13 +202,14 @@ int rpo_absmax(long long n, const float* x, float* max_out, void* stream) {
 
 int rpo_adam_step(long long n, float* param, float* grad, float* exp_avg, float* exp_avg_sq, int* step_dev,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int maximize, float clip_thres,
-                  float* gradmax, int reset_gradmax, int clamp_min0, float* target, float tau, void* stream) {
+                  float* gradmax, int reset_gradmax, int zero_grad, int clamp_min0, float* target, float tau,
+                  void* stream) {
     if (n <= 0) return RPO_ERR_ARG;
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return RPO_ERR_NULL;
     if (clip_thres > 0.0f && !gradmax) return RPO_ERR_NULL;
     // the arrival word lives right behind the step counter: step_dev must point at int32[4] = {step, pad, arrive(8 B)}
     AdamArgs a{n, param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, weight_decay, maximize,
-               clip_thres, gradmax, reset_gradmax, clamp_min0, target, tau,
+               clip_thres, gradmax, reset_gradmax, zero_grad, clamp_min0, target, tau,
                reinterpret_cast<long long*>(step_dev + 2)};
     hipLaunchKernelGGL(adam_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, a);
     RPO_LAUNCH_CHECK();

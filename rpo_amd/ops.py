@@ -116,10 +116,10 @@ def absmax(x, max_out):
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
               maximize=False, clip_thres=0.0, gradmax=None, reset_gradmax=True, clamp_min0=False, target=None,
-              tau=0.0):
+              tau=0.0, zero_grad=False):
     check(_lib.load().rpo_adam_step(param.numel(), _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq),
                                     _p(step_dev, torch.int32), lr, beta1, beta2, eps, weight_decay, int(maximize),
-                                    clip_thres, _p(gradmax, allow_none=True), int(reset_gradmax), int(clamp_min0),
+                                    clip_thres, _p(gradmax, allow_none=True), int(reset_gradmax), int(zero_grad), int(clamp_min0),
                                     _p(target, allow_none=True), tau, _stream()), "rpo_adam_step")
 
 

@@ -386,7 +386,8 @@ def absmax(x, max_out):
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
-              maximize=False, clip_thres=0.0, gradmax=None, reset_gradmax=True, clamp_min0=False, target=None, tau=0.0):
+              maximize=False, clip_thres=0.0, gradmax=None, reset_gradmax=True, clamp_min0=False, target=None, tau=0.0,
+              zero_grad=False):
     g = _np(grad)
     if clip_thres > 0:
         coef = min(np.float32(clip_thres) / (np.float32(float(gradmax[0])) + np.float32(1e-6)), np.float32(1.0))
@@ -398,6 +399,8 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0
         gradmax.zero_()
     if target is not None:
         train_ops.polyak(_np(param), _np(target), tau)
+    if zero_grad:
+        grad.zero_()
 
 
 def polyak(param, target, tau):

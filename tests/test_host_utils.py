@@ -66,6 +66,6 @@ def test_checkpoint_roundtrip(tmp_path):
     assert torch.equal(a.agent.nju.weight, b.agent.nju.weight)
     assert torch.equal(a.agent.critic_optim.exp_avg, b.agent.critic_optim.exp_avg)
     assert int(b.agent.actor_optim.step_dev[0]) == int(a.agent.actor_optim.step_dev[0]) == 1
-    # load() ends with hard_update(): targets equal the online networks (agent/ddpg_pa.py:96-99)
-    fl = b.agent.flat
-    assert torch.equal(b.agent.critic_target_flat, fl.param(fl.critic_range))
+    # exact resume: the targets are restored as they were (not hard-updated like agent/ddpg_pa.py:96-99 does)
+    assert torch.equal(b.agent.critic_target_flat, a.agent.critic_target_flat)
+    assert torch.equal(b.agent.actor_target_flat, a.agent.actor_target_flat)
