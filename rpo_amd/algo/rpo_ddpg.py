@@ -175,12 +175,18 @@ class RPODDPG(RPOTrainerBase):
         return loss + _LagrangianFn.apply(self.kernels, actions, ag.nju.weight, state)
 
     # ---- optimiser steps (rpo_ddpg.py:178-205) --------------------------------------------------------------
+    # The Polyak updates of a policy step (rpo_ddpg.py:205) ride in the Adam launches that produce the parameters they
+    # average -- same arithmetic, two launches fewer.  With a shared state embedding the critic's target must see the
+    # embedding AFTER the actor's step, so its update stays a separate launch at the end.
     def _critic_step(self, actor_step):
-        self.agent.critic_optim.step()
+        ag = self.agent
+        fuse = actor_step and ag.flat.sizes[1] == 0
+        ag.critic_optim.step(target=ag.critic_target_flat if fuse else None, tau=ag.tau)
 
     def _actor_step(self, actor_out):
         ag = self.agent
-        ag.actor_optim.step()
+        ag.actor_optim.step(target=ag.actor_target_flat, tau=ag.tau)
         if not self.fixed:
             ag.nju_optim.step()                                    # lambda is never stepped (rpo_ddpg.py:202)
-        ag.soft_update()                                           # DDPG: only on policy steps (rpo_ddpg.py:205)
+        if ag.flat.sizes[1] > 0:
+            ag._polyak(ag.flat.param(ag.flat.critic_range), ag.critic_target_flat)

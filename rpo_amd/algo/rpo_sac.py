@@ -153,10 +153,16 @@ class RPOSAC(RPOTrainerBase):
 
     # ---- optimiser steps (rpo_sac.py:181-219) ---------------------------------------------------------------
     def _critic_step(self, actor_step):
+        # soft_update of the critics on every step (rpo_sac.py:219) inside the Adam launch that produces them; only a
+        # shared state embedding, which the actor's step also moves, forces the separate launch after that step
         ag = self.agent
+        self._fused_polyak = ag.flat.sizes[1] == 0
+        if self._fused_polyak:
+            ag.critic_optim.step(target=ag.critic_target_flat, tau=ag.tau)
+            return
         ag.critic_optim.step()
         if not actor_step:
-            ag.soft_update()                                        # every step (rpo_sac.py:219)
+            ag.soft_update()
 
     def _actor_step(self, actor_out):
         ag = self.agent
@@ -170,4 +176,5 @@ class RPOSAC(RPOTrainerBase):
             alpha_loss.backward()
             ag.alpha_optim.step()
             self.alpha = ag.log_alpha.exp()
-        ag.soft_update()
+        if not self._fused_polyak:
+            ag.soft_update()
