@@ -441,6 +441,25 @@ int rpo_cartsafe_ddpg_critic_forward(const rpo_mlp* actor_target_host, const rpo
                                      int partial, float gamma, float* q_out, float* qn_out, float* dq_out,
                                      float* loss_partial, float* x0_save, float* h1_save, void* stream);
 
+/* The same for RPOSAC.critic_loss (rpo_sac.py:342-353): sample -> a' ~ pi(s') with the ONLINE actor (mean / log-std
+ * heads, rsample, box clip; the N(0,1) draw of row b is normal(philox(noise_seed, noise_id_base + b, ctrl[T] +
+ * noise_salt, RPO_STREAM_POLICY, ctrl[UPDATES])), i.e. rpo_philox_normal, or eps_in[b] when given) -> Complete + Proj ->
+ * y = r + gamma (1 - done) (min(Q1_targ, Q2_targ)(s', a') - alpha log pi(a'|s')) -> Q1, Q2 (s, a) with their
+ * pre-activations saved -> dq_k = dHuber/dQ_k / B, loss_partial[g] = workgroup g's share of both mean Huber losses.
+ * == rpo_replay_sample_gather + rpo_philox_normal + 5 x rpo_mlp_forward + rpo_gauss_head + rpo_cartsafe_act_project +
+ *    rpo_td_huber. */
+int rpo_cartsafe_sac_critic_forward(const rpo_mlp* actor_host, const rpo_mlp* critic_target1_host,
+                                    const rpo_mlp* critic_target2_host, const rpo_mlp* critic1_host,
+                                    const rpo_mlp* critic2_host, float scale, float base, const float* rows,
+                                    long long cap_steps, int n_envs, int batch, float* batch_out, long long* idx_out,
+                                    const long long* idx_in, const float* eps_in, unsigned long long sample_seed,
+                                    unsigned sample_salt, unsigned long long noise_seed, unsigned noise_id_base,
+                                    unsigned noise_salt, const long long* ctrl, int max_steps, float corr_lr,
+                                    float corr_eps, float corr_momentum, float box_lo, float box_hi,
+                                    const float* consts_host, int partial, float gamma, float alpha, float* q1_out,
+                                    float* q2_out, float* dq1_out, float* dq2_out, float* loss_partial, float* x0_save1,
+                                    float* h1_save1, float* x0_save2, float* h1_save2, void* stream);
+
 /* Policy heads around the MLP kernels.
  * DDPG (model/policy.py:30-31, agent/ddpg_pa.py:108-110): ap = clip(ap_det + eps_t * noise), ap_det = scale*tanh(o)+base.
  *   dout[i] = dap[i] * 1[lo <= ap_det + eps_t*noise <= hi] * scale * (1 - tanh(o)^2); noise NULL: no noise, no clip. */

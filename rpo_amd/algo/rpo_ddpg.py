@@ -5,7 +5,7 @@ import torch
 from .. import ops as hip_ops
 from .agent import PDDDPG_PA
 from .model import BoxConstraint
-from .trainer import _SALT_ACTOR, RPOTrainerBase, _LagrangianFn, _TDHuberFn
+from .trainer import _SALT_ACTOR, RPOTrainerBase, _LagrangianFn, _TDHuberFn, _env_int
 
 
 class _LazySum(object):
@@ -72,7 +72,8 @@ class RPODDPG(RPOTrainerBase):
     @property
     def _pipelines(self):
         return (self.fused is not None and hasattr(self.kernels, "ddpg_critic_forward")
-                and "actor_target" in self.fused.descs and "critic" in self.fused.descs)
+                and "actor_target" in self.fused.descs and "critic" in self.fused.descs
+                and _env_int("RPO_FUSED_CRITIC", 1))
 
     def _sample(self):
         if self._pipelines:

@@ -5,7 +5,8 @@ import torch
 from .. import ops as hip_ops
 from .agent import PDSAC_PA
 from .model import BoxConstraint
-from .trainer import _SALT_ACTOR, _SALT_CRITIC, RPOTrainerBase, _LagrangianFn, _TDHuberFn
+from .rpo_ddpg import _LazySum
+from .trainer import _SALT_ACTOR, _SALT_CRITIC, RPOTrainerBase, _LagrangianFn, _TDHuberFn, _env_int
 
 
 class RPOSAC(RPOTrainerBase):
@@ -72,10 +73,48 @@ class RPOSAC(RPOTrainerBase):
             return self._gauss(obs, zeros, "eval", deterministic=True, want_logp=False)[0]
         return self.agent.actor(obs)[2].reshape(-1)                 # the mean action (deterministic=True)
 
+    # ---- fused critic-forward pipeline (CartSafe kernels provide it) ------------------------------------------------
+    @property
+    def _pipelines(self):
+        return (self.fused is not None and hasattr(self.kernels, "sac_critic_forward") and "critic1" in self.fused.descs
+                and "actor" in self.fused.descs and not self.automatic_entropy_tuning
+                and _env_int("RPO_FUSED_CRITIC", 1))
+
+    def _sample(self):
+        if self._pipelines:
+            # the critic-forward pipeline draws and gathers the batch itself (into self._batch)
+            c = self.buffer.split(self._batch)
+            return c["state"], c["action"], c["next_state"], c["reward"], c["done"], c["ineq_viol"], c["eq_viol"]
+        return super()._sample()
+
+    def _critic_update_pipeline(self, cols):
+        f, ag, B, buf = self.fused, self.agent, self.batch_size, self.buffer
+        state, action = cols[0], cols[1]
+        d = f.descs["critic1"]
+        scale, base = self._box_affine
+        parts = f.buf("loss_parts", (B + 15) // 16)
+        inject = self._idx_inject is not None                  # tests replay the reference's draws
+        idx_in = self._idx_inject() if inject else None
+        eps_in = self._draw(self._noise_b, self.dist.rank * B, _SALT_CRITIC).view(-1) if inject else None
+        dq1, dq2 = f.buf("dq1", B, 1), f.buf("dq2", B, 1)
+        self.kernels.sac_critic_forward(
+            f.descs["actor"], f.descs["critic_target1"], f.descs["critic_target2"], d, f.descs["critic2"], scale, base,
+            buf.rows, buf.capacity, buf.n_envs, self._batch, None, idx_in, eps_in, buf.seed, 0, self.seed,
+            self.dist.rank * B, _SALT_CRITIC, buf.ctrl, self.max_steps, self.corr_lr, self.corr_eps, self.corr_momentum,
+            self._box_lo, self._box_hi, ag.gamma, float(ag.alpha), f.buf("q1", B, 1), f.buf("q2", B, 1), dq1, dq2, parts,
+            f.buf("critic1.x0", B, d.ein), f.buf("critic1.h1", B, d.H), f.buf("critic2.x0", B, d.ein),
+            f.buf("critic2.h1", B, d.H))
+        self._zero_grads()
+        f.backward("critic1", state, action, dq1)
+        f.backward("critic2", state, action, dq2)
+        self.last_losses["critic"] = _LazySum(parts)
+
     # ---- the update through the hand-written MLP kernels (same arithmetic as critic_loss / actor_loss below) ------
     def _critic_update(self, cols):
         if self.fused is None:
             return super()._critic_update(cols)
+        if self._pipelines:
+            return self._critic_update_pipeline(cols)
         f, ag, B = self.fused, self.agent, self.batch_size
         state, action, next_state, reward, done = cols[:5]
         eps = self._draw(self._noise_b, self.dist.rank * B, _SALT_CRITIC)

@@ -296,6 +296,125 @@ __global__ __launch_bounds__(kFwdThreads) void cart_ddpg_critic_forward_kernel(C
     }
 }
 
+// ------------------------------------------------------------------------------------- critic forward, RPOSAC
+// ReplayBuffer.sample -> a' ~ pi(s') (squashed Gaussian, online actor; rpo_sac.py:344-345) -> Complete + Proj ->
+// min(Q1_targ, Q2_targ)(s', a') - alpha log pi -> Q1(s, a), Q2(s, a) -> TD target + both Huber losses and dLoss/dQ_k
+// (rpo_sac.py:342-353): five MLP tiles chained in one workgroup of 16 rows.
+struct SacCriticFwdArgs {
+    Mlp actor, critic_target1, critic_target2, critic1, critic2;
+    float scale, base;
+    const float* rows;
+    long long cap_steps;
+    int n_envs;
+    int batch;
+    float* batch_out;
+    long long* idx_out;
+    const long long* idx_in;      // [B] or NULL (tests)
+    const float* eps_in;          // [B] or NULL: caller-provided N(0,1) draws of rsample instead of Philox (tests)
+    uint64_t seed, sample_seed;
+    uint32_t salt, noise_salt, noise_id_base;
+    const long long* ctrl;
+    int max_steps; float corr_lr, corr_eps, corr_momentum, box_lo, box_hi;
+    float gamma, alpha;
+    float* q1_out; float* q2_out; float* dq1_out; float* dq2_out;     // [B]
+    float* loss_partial;          // [gridDim.x]
+    float* x0_save1; float* h1_save1; float* x0_save2; float* h1_save2;
+};
+
+template <int EIN, int H>
+__global__ __launch_bounds__(kFwdThreads) void cart_sac_critic_forward_kernel(SacCriticFwdArgs p, CartConsts c) {
+    __shared__ TileLds<EIN> lds;
+    __shared__ __attribute__((aligned(16))) float4 tile[kRows * 6];
+    const int row0 = blockIdx.x * kRows;
+    const int tid = threadIdx.x;
+    const int B = p.batch;
+    const long long t = p.ctrl[RPO_CTRL_T];
+    if (tid < kRows * 6) {                                     // ReplayBuffer.sample (buffer.py:31-34)
+        const int r = tid / 6, ch = tid - r * 6;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (row0 + r < B) {
+            long long row;
+            if (p.idx_in) {
+                row = p.idx_in[row0 + r];
+            } else {
+                const unsigned long long n_valid = (unsigned long long)((t < p.cap_steps ? t : p.cap_steps) * (long long)p.n_envs);
+                const rpo_u4 u = rpo_philox(p.sample_seed, (uint32_t)(row0 + r), (uint32_t)t + p.salt, RPO_STREAM_SAMPLE,
+                                            (uint32_t)p.ctrl[RPO_CTRL_UPDATES]);
+                row = (long long)__umul64hi(((unsigned long long)u.x << 32) | u.y, n_valid);
+            }
+            v = reinterpret_cast<const float4*>(p.rows)[row * 6 + ch];
+            reinterpret_cast<float4*>(p.batch_out)[(size_t)(row0 + r) * 6 + ch] = v;
+            if (p.idx_out && ch == 0) p.idx_out[row0 + r] = row;
+        }
+        tile[tid] = v;
+    }
+    __syncthreads();
+    const float* tf = reinterpret_cast<const float*>(tile);
+    if (tid < kRows * 6) {
+        const int r = tid / 6, i = tid - r * 6;
+        lds.in_s[r * kInS + i] = tf[r * 24 + 8 + i];           // next_state
+    }
+    // ---- a' ~ pi(s'): mean / log-std heads, rsample with the Philox draw of the update step, box clip
+    mlp_tile_forward<EIN, H>(p.actor, lds, row0, B, nullptr, nullptr, 0, 1.0f, 0.0f);
+    float logp = 0.0f;
+    if (tid < kRows) {
+        float e;
+        if (p.eps_in) {
+            e = row0 + tid < B ? p.eps_in[row0 + tid] : 0.0f;
+        } else {                                               // == rpo_philox_normal(id_base, salt, RPO_STREAM_POLICY)
+            const rpo_u4 u = rpo_philox(p.seed, p.noise_id_base + (uint32_t)(row0 + tid), (uint32_t)t + p.noise_salt,
+                                        RPO_STREAM_POLICY, (uint32_t)p.ctrl[RPO_CTRL_UPDATES]);
+            e = rpo_normal(u.x, u.y);
+        }
+        const float ap = rpo_head_dev::gauss_head_row(lds.out[tid * 2], lds.out[tid * 2 + 1], e, p.scale, p.base, p.box_lo,
+                                                      p.box_hi, 0, &logp);
+        ActArgs a{};
+        a.noise_mode = RPO_NOISE_NONE;
+        a.max_steps = p.max_steps; a.corr_lr = p.corr_lr; a.corr_eps = p.corr_eps; a.corr_momentum = p.corr_momentum;
+        a.box_lo = p.box_lo; a.box_hi = p.box_hi;
+        int k;
+        const float2 act = cart_explore_project(a, c, row0 + tid, ap, 0.0f, t, k);
+        lds.in_a[tid * kInA] = act.x;
+        lds.in_a[tid * kInA + 1] = act.y;
+    }
+    // ---- Q1_targ, Q2_targ (s', a')
+    mlp_tile_forward<EIN, H>(p.critic_target1, lds, row0, B, nullptr, nullptr, 0, 1.0f, 0.0f);
+    float qn = 0.0f;
+    if (tid < kRows) qn = lds.out[tid * 2];
+    mlp_tile_forward<EIN, H>(p.critic_target2, lds, row0, B, nullptr, nullptr, 0, 1.0f, 0.0f);
+    if (tid < kRows) qn = fminf(qn, lds.out[tid * 2]) - p.alpha * logp;        // rpo_sac.py:346-347
+    __syncthreads();
+    if (tid < kRows * 6) {
+        const int r = tid / 6, i = tid - r * 6;
+        lds.in_s[r * kInS + i] = tf[r * 24 + i];               // state
+    }
+    if (tid < kRows * 2) {
+        const int r = tid >> 1, i = tid & 1;
+        lds.in_a[r * kInA + i] = tf[r * 24 + 6 + i];           // stored action
+    }
+    // ---- Q1(s, a), Q2(s, a) with their pre-activations
+    mlp_tile_forward<EIN, H>(p.critic1, lds, row0, B, p.x0_save1, p.h1_save1, 0, 1.0f, 0.0f);
+    float q1 = 0.0f;
+    if (tid < kRows) q1 = lds.out[tid * 2];
+    mlp_tile_forward<EIN, H>(p.critic2, lds, row0, B, p.x0_save2, p.h1_save2, 0, 1.0f, 0.0f);
+    float hub = 0.0f;
+    if (tid < kRows && row0 + tid < B) {
+        const float q2 = lds.out[tid * 2];
+        const float y = tf[tid * 24 + 14] + p.gamma * (1.0f - tf[tid * 24 + 15]) * qn;
+        const float d1 = q1 - y, d2 = q2 - y, a1 = fabsf(d1), a2 = fabsf(d2);
+        const float inv_n = 1.0f / (float)B;
+        hub = ((a1 < 1.0f ? 0.5f * d1 * d1 : a1 - 0.5f) + (a2 < 1.0f ? 0.5f * d2 * d2 : a2 - 0.5f)) * inv_n;
+        p.q1_out[row0 + tid] = q1;
+        p.q2_out[row0 + tid] = q2;
+        p.dq1_out[row0 + tid] = fminf(fmaxf(d1, -1.0f), 1.0f) * inv_n;
+        p.dq2_out[row0 + tid] = fminf(fmaxf(d2, -1.0f), 1.0f) * inv_n;
+    }
+    if (tid < 64) {
+        const float s = rpo_wave_sum(hub);
+        if (tid == 0) p.loss_partial[blockIdx.x] = s;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -381,6 +500,51 @@ int rpo_cartsafe_ddpg_critic_forward(const rpo_mlp* actor_target_host, const rpo
         hipLaunchKernelGGL((cart_ddpg_critic_forward_kernel<128, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a, c);
     } else if (at.E == 256) {
         hipLaunchKernelGGL((cart_ddpg_critic_forward_kernel<256, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a, c);
+    } else {
+        return RPO_ERR_ARG;
+    }
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_cartsafe_sac_critic_forward(const rpo_mlp* actor_host, const rpo_mlp* critic_target1_host,
+                                    const rpo_mlp* critic_target2_host, const rpo_mlp* critic1_host,
+                                    const rpo_mlp* critic2_host, float scale, float base, const float* rows,
+                                    long long cap_steps, int n_envs, int batch, float* batch_out, long long* idx_out,
+                                    const long long* idx_in, const float* eps_in, unsigned long long sample_seed,
+                                    unsigned sample_salt, unsigned long long noise_seed, unsigned noise_id_base,
+                                    unsigned noise_salt, const long long* ctrl, int max_steps, float corr_lr,
+                                    float corr_eps, float corr_momentum, float box_lo, float box_hi,
+                                    const float* consts_host, int partial, float gamma, float alpha, float* q1_out,
+                                    float* q2_out, float* dq1_out, float* dq2_out, float* loss_partial, float* x0_save1,
+                                    float* h1_save1, float* x0_save2, float* h1_save2, void* stream) {
+    if (!actor_host || !critic_target1_host || !critic_target2_host || !critic1_host || !critic2_host) return RPO_ERR_NULL;
+    if (batch <= 0 || cap_steps <= 0 || n_envs <= 0 || max_steps < 0) return RPO_ERR_ARG;
+    if (!rows || !batch_out || !ctrl || !q1_out || !q2_out || !dq1_out || !dq2_out || !loss_partial || !x0_save1 || !h1_save1 ||
+        !x0_save2 || !h1_save2)
+        return RPO_ERR_NULL;
+    SacCriticFwdArgs a{};
+    a.actor = to_dev(actor_host);
+    a.critic_target1 = to_dev(critic_target1_host); a.critic_target2 = to_dev(critic_target2_host);
+    a.critic1 = to_dev(critic1_host); a.critic2 = to_dev(critic2_host);
+    if (int e = check_actor(a.actor, 6, 1)) return e;
+    const Mlp* qs[4] = {&a.critic_target1, &a.critic_target2, &a.critic1, &a.critic2};
+    for (const Mlp* q : qs)
+        if (q->S != 6 || q->A != 2 || q->cat || q->H != 256 || q->E != a.actor.E || q->n_out != 1 || q->hd > 1) return RPO_ERR_ARG;
+    CartConsts c;
+    if (int e = load_consts(c, consts_host, partial)) return e;
+    a.scale = scale; a.base = base; a.rows = rows; a.cap_steps = cap_steps; a.n_envs = n_envs; a.batch = batch;
+    a.batch_out = batch_out; a.idx_out = idx_out; a.idx_in = idx_in; a.eps_in = eps_in; a.seed = (uint64_t)noise_seed;
+    a.sample_seed = (uint64_t)sample_seed; a.salt = (uint32_t)sample_salt; a.noise_salt = (uint32_t)noise_salt;
+    a.noise_id_base = (uint32_t)noise_id_base; a.ctrl = ctrl; a.max_steps = max_steps; a.corr_lr = corr_lr;
+    a.corr_eps = corr_eps; a.corr_momentum = corr_momentum; a.box_lo = box_lo; a.box_hi = box_hi; a.gamma = gamma;
+    a.alpha = alpha; a.q1_out = q1_out; a.q2_out = q2_out; a.dq1_out = dq1_out; a.dq2_out = dq2_out;
+    a.loss_partial = loss_partial; a.x0_save1 = x0_save1; a.h1_save1 = h1_save1; a.x0_save2 = x0_save2; a.h1_save2 = h1_save2;
+    const int grid = (batch + kRows - 1) / kRows;
+    if (a.actor.E == 128) {
+        hipLaunchKernelGGL((cart_sac_critic_forward_kernel<128, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a, c);
+    } else if (a.actor.E == 256) {
+        hipLaunchKernelGGL((cart_sac_critic_forward_kernel<256, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a, c);
     } else {
         return RPO_ERR_ARG;
     }

@@ -196,6 +196,19 @@ class CartSafeKernels(object):
             corr_momentum, box_lo, box_hi, self._cptr, self.partial, gamma, _p(q_out), _p(qn_out), _p(dq_out),
             _p(loss_partial), _p(x0_save), _p(h1_save), _stream()), "rpo_cartsafe_ddpg_critic_forward")
 
+    def sac_critic_forward(self, actor, critic_target1, critic_target2, critic1, critic2, scale, base, rows, cap_steps,
+                           n_envs, batch_out, idx_out, idx_in, eps_in, sample_seed, sample_salt, noise_seed, noise_id_base,
+                           noise_salt, ctrl, max_steps, corr_lr, corr_eps, corr_momentum, box_lo, box_hi, gamma, alpha,
+                           q1_out, q2_out, dq1_out, dq2_out, loss_partial, x0_save1, h1_save1, x0_save2, h1_save2):
+        nets = [d.net_struct() for d in (actor, critic_target1, critic_target2, critic1, critic2)]
+        check(_lib.load().rpo_cartsafe_sac_critic_forward(
+            *[ctypes.byref(n) for n in nets], scale, base, _p(rows), cap_steps, n_envs, batch_out.shape[0], _p(batch_out),
+            _p(idx_out, torch.int64, allow_none=True), _p(idx_in, torch.int64, allow_none=True),
+            _p(eps_in, allow_none=True), sample_seed, sample_salt, noise_seed, noise_id_base, noise_salt,
+            _p(ctrl, torch.int64), max_steps, corr_lr, corr_eps, corr_momentum, box_lo, box_hi, self._cptr, self.partial,
+            gamma, alpha, _p(q1_out), _p(q2_out), _p(dq1_out), _p(dq2_out), _p(loss_partial), _p(x0_save1), _p(h1_save1),
+            _p(x0_save2), _p(h1_save2), _stream()), "rpo_cartsafe_sac_critic_forward")
+
     def complete_bwd(self, obs, grad_action, grad_ap, action=None):
         check(_lib.load().rpo_cartsafe_complete_bwd(grad_action.shape[0], _p(grad_action), _p(grad_ap), self._cptr,
                                                     self.partial, _stream()), "rpo_cartsafe_complete_bwd")
