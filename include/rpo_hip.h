@@ -339,6 +339,14 @@ int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int
                      const float* a, int a_stride, const float* x0, const float* h1, const float* dout, float* dh,
                      float* dx0, float* da, int param_grads, int first_layer_state_only, void* stream);
 
+/* rpo_mlp_backward of two networks of the same shape on the same inputs in one pair of launches (SAC's twin critics,
+ * model/value.py:125-140): gridDim.y = 2 selects the network.  Results are those of two rpo_mlp_backward calls. */
+int rpo_mlp_backward_pair(const rpo_mlp* net1_host, const rpo_mlp_grad* grad1_host, const rpo_mlp* net2_host,
+                          const rpo_mlp_grad* grad2_host, int n, const float* s, int s_stride, const float* a,
+                          int a_stride, const float* x0_1, const float* h1_1, const float* dout_1, float* dh_1,
+                          float* dx0_1, float* da_1, const float* x0_2, const float* h1_2, const float* dout_2, float* dh_2,
+                          float* dx0_2, float* da_2, int param_grads, int first_layer_state_only, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * EVOPF-v0 (rpo_amd/csrc/evopf.hip): one wavefront per env lane / batch row; the lane's 22x22 Newton system and the
  * 28x28 block of the equality Jacobian are eliminated in LDS.  state [n,57], action [n,43], basic actions [n,14];

@@ -128,5 +128,23 @@ class FusedNets(object):
                                   first_layer_state_only)
 
 
+    def backward_pair(self, name1, name2, s, a, dout1, dout2, da1=None, da2=None, param_grads=True,
+                      first_layer_state_only=False):
+        """Backward of two same-shaped networks (twin critics) in one pair of launches where the backend has it."""
+        d1, d2 = self.descs[name1], self.descs[name2]
+        shared = any(t is not None and d2.tensors[k] is not None and t.data_ptr() == d2.tensors[k].data_ptr()
+                     for k, t in d1.tensors.items())           # a shared embedding: both would accumulate into it at once
+        if shared or not hasattr(self.backend, "mlp_backward_pair"):
+            self.backward(name1, s, a, dout1, da1, param_grads, first_layer_state_only)
+            self.backward(name2, s, a, dout2, da2, param_grads, first_layer_state_only)
+            return
+        n = dout1.shape[0]
+        b = self.buf
+        self.backend.mlp_backward_pair(
+            d1, d2, s, a, b(name1 + ".x0", n, d1.ein), b(name1 + ".h1", n, d1.H), dout1, b(name1 + ".dh", n, d1.H),
+            b(name1 + ".dx0", n, d1.ein), da1, b(name2 + ".x0", n, d2.ein), b(name2 + ".h1", n, d2.H), dout2,
+            b(name2 + ".dh", n, d2.H), b(name2 + ".dx0", n, d2.ein), da2, param_grads, first_layer_state_only)
+
+
 class _Unsupported(Exception):
     pass

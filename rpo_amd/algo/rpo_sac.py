@@ -105,8 +105,7 @@ class RPOSAC(RPOTrainerBase):
             f.buf("critic1.x0", B, d.ein), f.buf("critic1.h1", B, d.H), f.buf("critic2.x0", B, d.ein),
             f.buf("critic2.h1", B, d.H))
         self._zero_grads()
-        f.backward("critic1", state, action, dq1)
-        f.backward("critic2", state, action, dq2)
+        f.backward_pair("critic1", "critic2", state, action, dq1, dq2)
         self.last_losses["critic"] = _LazySum(parts)
 
     # ---- the update through the hand-written MLP kernels (same arithmetic as critic_loss / actor_loss below) ------
@@ -129,8 +128,7 @@ class RPOSAC(RPOTrainerBase):
         self.backend.td_huber(q1.view(-1), q2.view(-1), qn1.view(-1), qn2.view(-1), logp, float(ag.alpha), reward, done,
                               ag.gamma, loss, dq1.view(-1), dq2.view(-1))
         self._zero_grads()
-        f.backward("critic1", state, action, dq1)
-        f.backward("critic2", state, action, dq2)
+        f.backward_pair("critic1", "critic2", state, action, dq1, dq2)
         self.last_losses["critic"] = loss[0]
 
     def _actor_update(self, cols):
@@ -154,8 +152,8 @@ class RPOSAC(RPOTrainerBase):
         torch.mul(1.0 - w1, -1.0 / B, out=dq2)
         da1, da2 = f.buf("da1", B, k.action_dim), f.buf("da2", B, k.action_dim)
         shared = ag.flat.sizes[1] > 0
-        f.backward("critic1", state, actions, dq1, da=da1, param_grads=shared, first_layer_state_only=True)
-        f.backward("critic2", state, actions, dq2, da=da2, param_grads=shared, first_layer_state_only=True)
+        f.backward_pair("critic1", "critic2", state, actions, dq1, dq2, da1, da2, param_grads=shared,
+                        first_layer_state_only=True)
         da1.add_(da2).add_(g_act)
         dap, draw = f.buf("dap", B), f.buf("draw", B, 2)
         k.complete_bwd(state, da1, dap)

@@ -104,7 +104,7 @@ struct BwdArgs {
 };
 
 template <int EIN, int H>
-__global__ __launch_bounds__(kThreads) void mlp_bwd_rows_kernel(BwdArgs p) {
+__device__ __forceinline__ void mlp_bwd_rows_body(const BwdArgs& p) {
     constexpr int LDH = H + 4;
     __shared__ __attribute__((aligned(16))) float dh_s[kRows * LDH];
     __shared__ __attribute__((aligned(16))) float red[kRows * EIN];              // dx0 of the tile (waves add into it)
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kThreads) void mlp_bwd_rows_kernel(BwdArgs p) {
 // workgroup accumulates the first-layer gradients dWs / dbs / dWa / dba from dx0, and the last one db0 / dW1 / db1.
 // Every output element has exactly one owner and a fixed summation order: the backward pass is bitwise reproducible.
 template <int EIN, int H>
-__global__ __launch_bounds__(kThreads) void mlp_bwd_weights_kernel(BwdArgs p) {
+__device__ __forceinline__ void mlp_bwd_weights_body(const BwdArgs& p) {
     const Mlp& net = p.net;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int GEMM_BLOCKS = (H / 16) * (EIN / 64);           // one 16 x 64 tile of dW0 per workgroup
@@ -470,6 +470,21 @@ __global__ __launch_bounds__(kThreads) void mlp_bwd_weights_kernel(BwdArgs p) {
     }
 }
 
+template <int EIN, int H>
+__global__ __launch_bounds__(kThreads) void mlp_bwd_rows_kernel(BwdArgs p) { mlp_bwd_rows_body<EIN, H>(p); }
+template <int EIN, int H>
+__global__ __launch_bounds__(kThreads) void mlp_bwd_weights_kernel(BwdArgs p) { mlp_bwd_weights_body<EIN, H>(p); }
+
+// Two networks of the same shape in one launch (blockIdx.y picks the network): SAC's twin critics.  Both backward
+// passes are latency-bound on a handful of workgroups, so the pair costs what one costs.
+struct BwdArgs2 {
+    BwdArgs net[2];
+};
+template <int EIN, int H>
+__global__ __launch_bounds__(kThreads) void mlp_bwd_rows_kernel2(BwdArgs2 p) { mlp_bwd_rows_body<EIN, H>(p.net[blockIdx.y]); }
+template <int EIN, int H>
+__global__ __launch_bounds__(kThreads) void mlp_bwd_weights_kernel2(BwdArgs2 p) { mlp_bwd_weights_body<EIN, H>(p.net[blockIdx.y]); }
+
 // ------------------------------------------------------------------------------------------------- policy heads
 // DDPG head backward (model/policy.py:30-31 + agent/ddpg_pa.py:108-110): ap = clip(scale*tanh(o)+base + eps_t*noise);
 // dout = dap * 1[lo <= ap_noisy <= hi] * scale * (1 - tanh(o)^2), tanh(o) recovered from the stored deterministic ap.
@@ -599,9 +614,9 @@ int rpo_mlp_forward(const rpo_mlp* net_host, int n, const float* s, int s_stride
     return RPO_ERR_ARG;
 }
 
-int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int n, const float* s, int s_stride,
-                     const float* a, int a_stride, const float* x0, const float* h1, const float* dout, float* dh,
-                     float* dx0, float* da, int param_grads, int first_layer_state_only, void* stream) {
+static int make_bwd_args(BwdArgs& args, const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int n, const float* s,
+                         int s_stride, const float* a, int a_stride, const float* x0, const float* h1, const float* dout,
+                         float* dh, float* dx0, float* da, int param_grads, int first_layer_state_only) {
     if (!net_host) return RPO_ERR_NULL;
     Mlp net{net_host->Ws, net_host->bs, net_host->Wa, net_host->ba, net_host->W0, net_host->b0, net_host->W1,
             net_host->b1, net_host->W1b, net_host->b1b, net_host->S, net_host->A, net_host->E, net_host->H,
@@ -619,11 +634,27 @@ int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int
             return RPO_ERR_NULL;
         if (!first_layer_state_only && net.n_out > 1 && (!g.W1b || !g.b1b)) return RPO_ERR_NULL;
     }
+    args = BwdArgs{net, g, n, s, s_stride, a, a_stride, x0, h1, dout, dh, dx0, da, param_grads, first_layer_state_only};
+    return 0;
+}
+
+static int bwd_weights_grid(const Mlp& net, int first_layer_state_only) {
     const int ein = net.cat ? 2 * net.E : net.E;
-    BwdArgs args{net, g, n, s, s_stride, a, a_stride, x0, h1, dout, dh, dx0, da, param_grads, first_layer_state_only};
-    const int grid_rows = (n + kRows - 1) / kRows;
     const int fl_outputs = net.E * (net.S + 1 + ((net.A > 0 && !first_layer_state_only) ? net.A + 1 : 0));
-    const int grid_w = (net.H / 16) * (ein / 64) + (net.hd > 1 ? net.H / 16 : net.H / 64) + (fl_outputs + 63) / 64;
+    return (net.H / 16) * (ein / 64) + (net.hd > 1 ? net.H / 16 : net.H / 64) + (fl_outputs + 63) / 64;
+}
+
+int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int n, const float* s, int s_stride,
+                     const float* a, int a_stride, const float* x0, const float* h1, const float* dout, float* dh,
+                     float* dx0, float* da, int param_grads, int first_layer_state_only, void* stream) {
+    BwdArgs args;
+    if (int e = make_bwd_args(args, net_host, grad_host, n, s, s_stride, a, a_stride, x0, h1, dout, dh, dx0, da,
+                              param_grads, first_layer_state_only))
+        return e;
+    const Mlp& net = args.net;
+    const int ein = net.cat ? 2 * net.E : net.E;
+    const int grid_rows = (n + kRows - 1) / kRows;
+    const int grid_w = bwd_weights_grid(net, first_layer_state_only);
 #define RPO_MLP_BWD(EIN_, H_)                                                                                       \
     if (ein == EIN_ && net.H == H_) {                                                                               \
         hipLaunchKernelGGL((mlp_bwd_rows_kernel<EIN_, H_>), dim3(grid_rows), dim3(kThreads), 0, (hipStream_t)stream, \
@@ -639,6 +670,43 @@ int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int
     RPO_MLP_BWD(128, 256)
     RPO_MLP_BWD(256, 256)
     RPO_MLP_BWD(512, 256)
+    return RPO_ERR_ARG;
+}
+
+int rpo_mlp_backward_pair(const rpo_mlp* net1_host, const rpo_mlp_grad* grad1_host, const rpo_mlp* net2_host,
+                          const rpo_mlp_grad* grad2_host, int n, const float* s, int s_stride, const float* a,
+                          int a_stride, const float* x0_1, const float* h1_1, const float* dout_1, float* dh_1,
+                          float* dx0_1, float* da_1, const float* x0_2, const float* h1_2, const float* dout_2, float* dh_2,
+                          float* dx0_2, float* da_2, int param_grads, int first_layer_state_only, void* stream) {
+    BwdArgs2 args;
+    if (int e = make_bwd_args(args.net[0], net1_host, grad1_host, n, s, s_stride, a, a_stride, x0_1, h1_1, dout_1, dh_1,
+                              dx0_1, da_1, param_grads, first_layer_state_only))
+        return e;
+    if (int e = make_bwd_args(args.net[1], net2_host, grad2_host, n, s, s_stride, a, a_stride, x0_2, h1_2, dout_2, dh_2,
+                              dx0_2, da_2, param_grads, first_layer_state_only))
+        return e;
+    const Mlp &n1 = args.net[0].net, &n2 = args.net[1].net;
+    if (n1.S != n2.S || n1.A != n2.A || n1.E != n2.E || n1.H != n2.H || n1.n_out != n2.n_out || n1.cat != n2.cat ||
+        n1.hd != n2.hd)
+        return RPO_ERR_ARG;
+    const int ein = n1.cat ? 2 * n1.E : n1.E;
+    const int grid_rows = (n + kRows - 1) / kRows;
+    const int grid_w = bwd_weights_grid(n1, first_layer_state_only);
+#define RPO_MLP_BWD2(EIN_, H_)                                                                                         \
+    if (ein == EIN_ && n1.H == H_) {                                                                                   \
+        hipLaunchKernelGGL((mlp_bwd_rows_kernel2<EIN_, H_>), dim3(grid_rows, 2), dim3(kThreads), 0, (hipStream_t)stream, \
+                           args);                                                                                      \
+        RPO_LAUNCH_CHECK();                                                                                            \
+        if (param_grads) {                                                                                             \
+            hipLaunchKernelGGL((mlp_bwd_weights_kernel2<EIN_, H_>), dim3(grid_w, 2), dim3(kThreads), 0,                \
+                               (hipStream_t)stream, args);                                                             \
+            RPO_LAUNCH_CHECK();                                                                                        \
+        }                                                                                                              \
+        return 0;                                                                                                      \
+    }
+    RPO_MLP_BWD2(128, 256)
+    RPO_MLP_BWD2(256, 256)
+    RPO_MLP_BWD2(512, 256)
     return RPO_ERR_ARG;
 }
 

@@ -458,3 +458,17 @@ def gauss_head(raw, eps, scale, base, lo, hi, deterministic, ap_out, logp_out=No
 def gauss_head_bwd(raw, eps, dap, dlogp, scale, base, lo, hi, draw):
     check(_lib.load().rpo_gauss_head_bwd(raw.shape[0], _p(raw), _p(eps), _p(dap), dlogp, scale, base, lo, hi, _p(draw),
                                          _stream()), "rpo_gauss_head_bwd")
+
+
+def mlp_backward_pair(desc1, desc2, s, a, x0_1, h1_1, dout_1, dh_1, dx0_1, da_1, x0_2, h1_2, dout_2, dh_2, dx0_2, da_2,
+                      param_grads=True, first_layer_state_only=False):
+    sp, ss = _row_view(s, desc1.S)
+    ap, as_ = (None, 0) if desc1.A == 0 else _row_view(a, desc1.A)
+    n1, n2 = desc1.net_struct(), desc2.net_struct()
+    g1 = desc1.grad_struct() if param_grads else None
+    g2 = desc2.grad_struct() if param_grads else None
+    check(_lib.load().rpo_mlp_backward_pair(
+        ctypes.byref(n1), None if g1 is None else ctypes.byref(g1), ctypes.byref(n2), None if g2 is None else ctypes.byref(g2),
+        dout_1.shape[0], sp, ss, ap, as_, _p(x0_1), _p(h1_1), _p(dout_1), _p(dh_1), _p(dx0_1), _p(da_1, allow_none=True),
+        _p(x0_2), _p(h1_2), _p(dout_2), _p(dh_2), _p(dx0_2), _p(da_2, allow_none=True), int(param_grads),
+        int(first_layer_state_only), _stream()), "rpo_mlp_backward_pair")
