@@ -468,6 +468,22 @@ int rpo_cartsafe_sac_critic_forward(const rpo_mlp* actor_host, const rpo_mlp* cr
                                     float* q2_out, float* dq1_out, float* dq2_out, float* loss_partial, float* x0_save1,
                                     float* h1_save1, float* x0_save2, float* h1_save2, void* stream);
 
+/* SpringPendulum-v0: the reference's batched projection couples the samples of a batch (pendulum.py:337-339), so the
+ * RPOSAC critic-forward chain is cut there into two launches around rpo_pendulum_project_batchref:
+ *   front: sample -> batch_out [B,16] -> a' ~ pi(s') -> ap_out [B] (clipped basic action), logp_out [B];
+ *   back:  Q1_targ, Q2_targ (s', next_actions [B,2]) -> y -> Q1, Q2 (s, a) of batch_rows -> dq_k, loss_partial. */
+int rpo_pendulum_sac_critic_front(const rpo_mlp* actor_host, float scale, float base, float box_lo, float box_hi,
+                                  const float* rows, long long cap_steps, int n_envs, int batch, float* batch_out,
+                                  long long* idx_out, const long long* idx_in, const float* eps_in,
+                                  unsigned long long sample_seed, unsigned sample_salt, unsigned long long noise_seed,
+                                  unsigned noise_id_base, unsigned noise_salt, const long long* ctrl, float* ap_out,
+                                  float* logp_out, void* stream);
+int rpo_pendulum_sac_critic_back(const rpo_mlp* critic_target1_host, const rpo_mlp* critic_target2_host,
+                                 const rpo_mlp* critic1_host, const rpo_mlp* critic2_host, int batch, float* batch_rows,
+                                 const float* next_actions, const float* logp, float gamma, float alpha, float* q1_out,
+                                 float* q2_out, float* dq1_out, float* dq2_out, float* loss_partial, float* x0_save1,
+                                 float* h1_save1, float* x0_save2, float* h1_save2, void* stream);
+
 /* Policy heads around the MLP kernels.
  * DDPG (model/policy.py:30-31, agent/ddpg_pa.py:108-110): ap = clip(ap_det + eps_t * noise), ap_det = scale*tanh(o)+base.
  *   dout[i] = dap[i] * 1[lo <= ap_det + eps_t*noise <= hi] * scale * (1 - tanh(o)^2); noise NULL: no noise, no clip. */

@@ -76,8 +76,9 @@ class RPOSAC(RPOTrainerBase):
     # ---- fused critic-forward pipeline (CartSafe kernels provide it) ------------------------------------------------
     @property
     def _pipelines(self):
-        return (self.fused is not None and hasattr(self.kernels, "sac_critic_forward") and "critic1" in self.fused.descs
-                and "actor" in self.fused.descs and not self.automatic_entropy_tuning
+        k = self.kernels
+        return (self.fused is not None and (hasattr(k, "sac_critic_forward") or hasattr(k, "sac_critic_front"))
+                and "critic1" in self.fused.descs and "actor" in self.fused.descs and not self.automatic_entropy_tuning
                 and _env_int("RPO_FUSED_CRITIC", 1))
 
     def _sample(self):
@@ -97,6 +98,22 @@ class RPOSAC(RPOTrainerBase):
         idx_in = self._idx_inject() if inject else None
         eps_in = self._draw(self._noise_b, self.dist.rank * B, _SALT_CRITIC).view(-1) if inject else None
         dq1, dq2 = f.buf("dq1", B, 1), f.buf("dq2", B, 1)
+        if not hasattr(self.kernels, "sac_critic_forward"):
+            # SpringPendulum: the chain is cut at the batch-coupled projection (front | project | back)
+            ap, logp = f.buf("crit.ap", B), f.buf("crit.logp", B)
+            self.kernels.sac_critic_front(f.descs["actor"], scale, base, self._box_lo, self._box_hi, buf.rows, buf.capacity,
+                                          buf.n_envs, self._batch, None, idx_in, eps_in, buf.seed, 0, self.seed,
+                                          self.dist.rank * B, _SALT_CRITIC, buf.ctrl, ap, logp)
+            next_actions = self._project_batch(cols[2], ap)
+            self.kernels.sac_critic_back(
+                f.descs["critic_target1"], f.descs["critic_target2"], d, f.descs["critic2"], self._batch, next_actions, logp,
+                ag.gamma, float(ag.alpha), f.buf("q1", B, 1), f.buf("q2", B, 1), dq1, dq2, parts,
+                f.buf("critic1.x0", B, d.ein), f.buf("critic1.h1", B, d.H), f.buf("critic2.x0", B, d.ein),
+                f.buf("critic2.h1", B, d.H))
+            self._zero_grads()
+            f.backward_pair("critic1", "critic2", state, action, dq1, dq2)
+            self.last_losses["critic"] = _LazySum(parts)
+            return
         self.kernels.sac_critic_forward(
             f.descs["actor"], f.descs["critic_target1"], f.descs["critic_target2"], d, f.descs["critic2"], scale, base,
             buf.rows, buf.capacity, buf.n_envs, self._batch, None, idx_in, eps_in, buf.seed, 0, self.seed,

@@ -299,7 +299,12 @@ __global__ __launch_bounds__(kFwdThreads) void cart_ddpg_critic_forward_kernel(C
 // ------------------------------------------------------------------------------------- critic forward, RPOSAC
 // ReplayBuffer.sample -> a' ~ pi(s') (squashed Gaussian, online actor; rpo_sac.py:344-345) -> Complete + Proj ->
 // min(Q1_targ, Q2_targ)(s', a') - alpha log pi -> Q1(s, a), Q2(s, a) -> TD target + both Huber losses and dLoss/dQ_k
-// (rpo_sac.py:342-353): five MLP tiles chained in one workgroup of 16 rows.
+// (rpo_sac.py:342-353).  CartSafe: all five MLP tiles chained in one workgroup of 16 rows.  SpringPendulum: the
+// reference's batched projection couples the samples of a batch (pendulum.py:337-339), so the chain is cut
+// there: front (sample -> policy) | rpo_pendulum_project_batchref | back (target critics -> critics -> TD).
+struct CartRow { static constexpr int ROW = 24, CH = 6, S = 6, A_OFF = 6, NS_OFF = 8, R_OFF = 14, D_OFF = 15; };
+struct PendRow { static constexpr int ROW = 16, CH = 4, S = 5, A_OFF = 5, NS_OFF = 7, R_OFF = 12, D_OFF = 13; };
+
 struct SacCriticFwdArgs {
     Mlp actor, critic_target1, critic_target2, critic1, critic2;
     float scale, base;
@@ -307,7 +312,7 @@ struct SacCriticFwdArgs {
     long long cap_steps;
     int n_envs;
     int batch;
-    float* batch_out;
+    float* batch_out;             // [B, ROW] gathered rows (front writes, back / backward pass read)
     long long* idx_out;
     const long long* idx_in;      // [B] or NULL (tests)
     const float* eps_in;          // [B] or NULL: caller-provided N(0,1) draws of rsample instead of Philox (tests)
@@ -319,18 +324,16 @@ struct SacCriticFwdArgs {
     float* q1_out; float* q2_out; float* dq1_out; float* dq2_out;     // [B]
     float* loss_partial;          // [gridDim.x]
     float* x0_save1; float* h1_save1; float* x0_save2; float* h1_save2;
+    float* ap_out; float* logp_out;                 // split form, front: clipped basic action and log pi of a'
+    const float* next_actions; const float* logp_in;   // split form, back: projected a' [B,2] and log pi
 };
 
-template <int EIN, int H>
-__global__ __launch_bounds__(kFwdThreads) void cart_sac_critic_forward_kernel(SacCriticFwdArgs p, CartConsts c) {
-    __shared__ TileLds<EIN> lds;
-    __shared__ __attribute__((aligned(16))) float4 tile[kRows * 6];
-    const int row0 = blockIdx.x * kRows;
-    const int tid = threadIdx.x;
-    const int B = p.batch;
-    const long long t = p.ctrl[RPO_CTRL_T];
-    if (tid < kRows * 6) {                                     // ReplayBuffer.sample (buffer.py:31-34)
-        const int r = tid / 6, ch = tid - r * 6;
+// ReplayBuffer.sample (buffer.py:31-34): counter-based draw + gather of the workgroup's 16 rows into `tile` / batch_out
+template <class L>
+__device__ __forceinline__ void sac_sample(const SacCriticFwdArgs& p, float4* tile, int row0, long long t) {
+    const int tid = threadIdx.x, B = p.batch;
+    if (tid < kRows * L::CH) {
+        const int r = tid / L::CH, ch = tid - r * L::CH;
         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (row0 + r < B) {
             long long row;
@@ -342,21 +345,28 @@ __global__ __launch_bounds__(kFwdThreads) void cart_sac_critic_forward_kernel(Sa
                                             (uint32_t)p.ctrl[RPO_CTRL_UPDATES]);
                 row = (long long)__umul64hi(((unsigned long long)u.x << 32) | u.y, n_valid);
             }
-            v = reinterpret_cast<const float4*>(p.rows)[row * 6 + ch];
-            reinterpret_cast<float4*>(p.batch_out)[(size_t)(row0 + r) * 6 + ch] = v;
+            v = reinterpret_cast<const float4*>(p.rows)[row * L::CH + ch];
+            reinterpret_cast<float4*>(p.batch_out)[(size_t)(row0 + r) * L::CH + ch] = v;
             if (p.idx_out && ch == 0) p.idx_out[row0 + r] = row;
         }
         tile[tid] = v;
     }
     __syncthreads();
-    const float* tf = reinterpret_cast<const float*>(tile);
-    if (tid < kRows * 6) {
-        const int r = tid / 6, i = tid - r * 6;
-        lds.in_s[r * kInS + i] = tf[r * 24 + 8 + i];           // next_state
+}
+
+// a' ~ pi(s'): mean / log-std heads, rsample with the Philox draw of the update step, box clip.  Threads < 16 return the
+// clipped basic action of their row and its log-probability.  Leaves s' staged in lds.in_s.
+template <class L, int EIN, int H>
+__device__ __forceinline__ float sac_policy(const SacCriticFwdArgs& p, TileLds<EIN>& lds, const float* tf, int row0,
+                                            long long t, float& logp) {
+    const int tid = threadIdx.x, B = p.batch;
+    if (tid < kRows * L::S) {
+        const int r = tid / L::S, i = tid - r * L::S;
+        lds.in_s[r * kInS + i] = tf[r * L::ROW + L::NS_OFF + i];
     }
-    // ---- a' ~ pi(s'): mean / log-std heads, rsample with the Philox draw of the update step, box clip
     mlp_tile_forward<EIN, H>(p.actor, lds, row0, B, nullptr, nullptr, 0, 1.0f, 0.0f);
-    float logp = 0.0f;
+    float ap = 0.0f;
+    logp = 0.0f;
     if (tid < kRows) {
         float e;
         if (p.eps_in) {
@@ -366,33 +376,30 @@ __global__ __launch_bounds__(kFwdThreads) void cart_sac_critic_forward_kernel(Sa
                                         RPO_STREAM_POLICY, (uint32_t)p.ctrl[RPO_CTRL_UPDATES]);
             e = rpo_normal(u.x, u.y);
         }
-        const float ap = rpo_head_dev::gauss_head_row(lds.out[tid * 2], lds.out[tid * 2 + 1], e, p.scale, p.base, p.box_lo,
-                                                      p.box_hi, 0, &logp);
-        ActArgs a{};
-        a.noise_mode = RPO_NOISE_NONE;
-        a.max_steps = p.max_steps; a.corr_lr = p.corr_lr; a.corr_eps = p.corr_eps; a.corr_momentum = p.corr_momentum;
-        a.box_lo = p.box_lo; a.box_hi = p.box_hi;
-        int k;
-        const float2 act = cart_explore_project(a, c, row0 + tid, ap, 0.0f, t, k);
-        lds.in_a[tid * kInA] = act.x;
-        lds.in_a[tid * kInA + 1] = act.y;
+        ap = rpo_head_dev::gauss_head_row(lds.out[tid * 2], lds.out[tid * 2 + 1], e, p.scale, p.base, p.box_lo, p.box_hi, 0,
+                                          &logp);
     }
-    // ---- Q1_targ, Q2_targ (s', a')
+    return ap;
+}
+
+// Q1_targ, Q2_targ on (s', a') staged in lds.in_s / lds.in_a, then Q1, Q2 on the stored (s, a), TD target and Huber
+template <class L, int EIN, int H>
+__device__ __forceinline__ void sac_td(const SacCriticFwdArgs& p, TileLds<EIN>& lds, const float* tf, int row0, float logp) {
+    const int tid = threadIdx.x, B = p.batch;
     mlp_tile_forward<EIN, H>(p.critic_target1, lds, row0, B, nullptr, nullptr, 0, 1.0f, 0.0f);
     float qn = 0.0f;
     if (tid < kRows) qn = lds.out[tid * 2];
     mlp_tile_forward<EIN, H>(p.critic_target2, lds, row0, B, nullptr, nullptr, 0, 1.0f, 0.0f);
     if (tid < kRows) qn = fminf(qn, lds.out[tid * 2]) - p.alpha * logp;        // rpo_sac.py:346-347
     __syncthreads();
-    if (tid < kRows * 6) {
-        const int r = tid / 6, i = tid - r * 6;
-        lds.in_s[r * kInS + i] = tf[r * 24 + i];               // state
+    if (tid < kRows * L::S) {
+        const int r = tid / L::S, i = tid - r * L::S;
+        lds.in_s[r * kInS + i] = tf[r * L::ROW + i];           // state
     }
     if (tid < kRows * 2) {
         const int r = tid >> 1, i = tid & 1;
-        lds.in_a[r * kInA + i] = tf[r * 24 + 6 + i];           // stored action
+        lds.in_a[r * kInA + i] = tf[r * L::ROW + L::A_OFF + i];   // stored action
     }
-    // ---- Q1(s, a), Q2(s, a) with their pre-activations
     mlp_tile_forward<EIN, H>(p.critic1, lds, row0, B, p.x0_save1, p.h1_save1, 0, 1.0f, 0.0f);
     float q1 = 0.0f;
     if (tid < kRows) q1 = lds.out[tid * 2];
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(kFwdThreads) void cart_sac_critic_forward_kernel(Sa
     float hub = 0.0f;
     if (tid < kRows && row0 + tid < B) {
         const float q2 = lds.out[tid * 2];
-        const float y = tf[tid * 24 + 14] + p.gamma * (1.0f - tf[tid * 24 + 15]) * qn;
+        const float y = tf[tid * L::ROW + L::R_OFF] + p.gamma * (1.0f - tf[tid * L::ROW + L::D_OFF]) * qn;
         const float d1 = q1 - y, d2 = q2 - y, a1 = fabsf(d1), a2 = fabsf(d2);
         const float inv_n = 1.0f / (float)B;
         hub = ((a1 < 1.0f ? 0.5f * d1 * d1 : a1 - 0.5f) + (a2 < 1.0f ? 0.5f * d2 * d2 : a2 - 0.5f)) * inv_n;
@@ -413,6 +420,72 @@ __global__ __launch_bounds__(kFwdThreads) void cart_sac_critic_forward_kernel(Sa
         const float s = rpo_wave_sum(hub);
         if (tid == 0) p.loss_partial[blockIdx.x] = s;
     }
+}
+
+template <int EIN, int H>
+__global__ __launch_bounds__(kFwdThreads) void cart_sac_critic_forward_kernel(SacCriticFwdArgs p, CartConsts c) {
+    __shared__ TileLds<EIN> lds;
+    __shared__ __attribute__((aligned(16))) float4 tile[kRows * CartRow::CH];
+    const int row0 = blockIdx.x * kRows, tid = threadIdx.x;
+    const long long t = p.ctrl[RPO_CTRL_T];
+    sac_sample<CartRow>(p, tile, row0, t);
+    const float* tf = reinterpret_cast<const float*>(tile);
+    float logp;
+    const float ap = sac_policy<CartRow, EIN, H>(p, lds, tf, row0, t, logp);
+    if (tid < kRows) {                                         // Complete + Proj: per-row stop test == the batched call
+        ActArgs a{};
+        a.noise_mode = RPO_NOISE_NONE;
+        a.max_steps = p.max_steps; a.corr_lr = p.corr_lr; a.corr_eps = p.corr_eps; a.corr_momentum = p.corr_momentum;
+        a.box_lo = p.box_lo; a.box_hi = p.box_hi;
+        int k;
+        const float2 act = cart_explore_project(a, c, row0 + tid, ap, 0.0f, t, k);
+        lds.in_a[tid * kInA] = act.x;
+        lds.in_a[tid * kInA + 1] = act.y;
+    }
+    sac_td<CartRow, EIN, H>(p, lds, tf, row0, logp);
+}
+
+template <int EIN, int H>
+__global__ __launch_bounds__(kFwdThreads) void pend_sac_critic_front_kernel(SacCriticFwdArgs p) {
+    __shared__ TileLds<EIN> lds;
+    __shared__ __attribute__((aligned(16))) float4 tile[kRows * PendRow::CH];
+    const int row0 = blockIdx.x * kRows, tid = threadIdx.x;
+    const long long t = p.ctrl[RPO_CTRL_T];
+    sac_sample<PendRow>(p, tile, row0, t);
+    float logp;
+    const float ap = sac_policy<PendRow, EIN, H>(p, lds, reinterpret_cast<const float*>(tile), row0, t, logp);
+    if (tid < kRows && row0 + tid < p.batch) {
+        p.ap_out[row0 + tid] = ap;
+        p.logp_out[row0 + tid] = logp;
+    }
+}
+
+template <int EIN, int H>
+__global__ __launch_bounds__(kFwdThreads) void pend_sac_critic_back_kernel(SacCriticFwdArgs p) {
+    __shared__ TileLds<EIN> lds;
+    __shared__ __attribute__((aligned(16))) float4 tile[kRows * PendRow::CH];
+    const int row0 = blockIdx.x * kRows, tid = threadIdx.x, B = p.batch;
+    if (tid < kRows * PendRow::CH) {
+        const int r = tid / PendRow::CH;
+        tile[tid] = row0 + r < B ? reinterpret_cast<const float4*>(p.batch_out)[(size_t)row0 * PendRow::CH + tid]
+                                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    __syncthreads();
+    const float* tf = reinterpret_cast<const float*>(tile);
+    if (tid < kRows * PendRow::S) {
+        const int r = tid / PendRow::S, i = tid - r * PendRow::S;
+        lds.in_s[r * kInS + i] = tf[r * PendRow::ROW + PendRow::NS_OFF + i];
+    }
+    float logp = 0.0f;
+    if (tid < kRows && row0 + tid < B) {
+        logp = p.logp_in[row0 + tid];
+        lds.in_a[tid * kInA] = p.next_actions[(size_t)(row0 + tid) * 2];
+        lds.in_a[tid * kInA + 1] = p.next_actions[(size_t)(row0 + tid) * 2 + 1];
+    } else if (tid < kRows) {
+        lds.in_a[tid * kInA] = 0.0f;
+        lds.in_a[tid * kInA + 1] = 0.0f;
+    }
+    sac_td<PendRow, EIN, H>(p, lds, tf, row0, logp);
 }
 
 }  // namespace
@@ -547,6 +620,77 @@ int rpo_cartsafe_sac_critic_forward(const rpo_mlp* actor_host, const rpo_mlp* cr
         hipLaunchKernelGGL((cart_sac_critic_forward_kernel<256, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a, c);
     } else {
         return RPO_ERR_ARG;
+    }
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+static int fill_sac_args(SacCriticFwdArgs& a, int obs_dim, const rpo_mlp* actor_host, const rpo_mlp* ct1, const rpo_mlp* ct2,
+                         const rpo_mlp* c1, const rpo_mlp* c2, bool need_actor, bool need_critics) {
+    if (need_actor) {
+        if (!actor_host) return RPO_ERR_NULL;
+        a.actor = to_dev(actor_host);
+        if (int e = check_actor(a.actor, obs_dim, 1)) return e;
+    }
+    if (need_critics) {
+        if (!ct1 || !ct2 || !c1 || !c2) return RPO_ERR_NULL;
+        a.critic_target1 = to_dev(ct1); a.critic_target2 = to_dev(ct2); a.critic1 = to_dev(c1); a.critic2 = to_dev(c2);
+        const Mlp* qs[4] = {&a.critic_target1, &a.critic_target2, &a.critic1, &a.critic2};
+        for (const Mlp* q : qs)
+            if (q->S != obs_dim || q->A != 2 || q->cat || q->H != 256 || (q->E != 128 && q->E != 256) || q->E != qs[0]->E ||
+                q->n_out != 1 || q->hd > 1)
+                return RPO_ERR_ARG;
+    }
+    return 0;
+}
+
+int rpo_pendulum_sac_critic_front(const rpo_mlp* actor_host, float scale, float base, float box_lo, float box_hi,
+                                  const float* rows, long long cap_steps, int n_envs, int batch, float* batch_out,
+                                  long long* idx_out, const long long* idx_in, const float* eps_in,
+                                  unsigned long long sample_seed, unsigned sample_salt, unsigned long long noise_seed,
+                                  unsigned noise_id_base, unsigned noise_salt, const long long* ctrl, float* ap_out,
+                                  float* logp_out, void* stream) {
+    if (batch <= 0 || cap_steps <= 0 || n_envs <= 0) return RPO_ERR_ARG;
+    if (!rows || !batch_out || !ctrl || !ap_out || !logp_out) return RPO_ERR_NULL;
+    SacCriticFwdArgs a{};
+    if (int e = fill_sac_args(a, 5, actor_host, nullptr, nullptr, nullptr, nullptr, true, false)) return e;
+    a.scale = scale; a.base = base; a.box_lo = box_lo; a.box_hi = box_hi; a.rows = rows; a.cap_steps = cap_steps;
+    a.n_envs = n_envs; a.batch = batch; a.batch_out = batch_out; a.idx_out = idx_out; a.idx_in = idx_in; a.eps_in = eps_in;
+    a.sample_seed = (uint64_t)sample_seed; a.salt = (uint32_t)sample_salt; a.seed = (uint64_t)noise_seed;
+    a.noise_id_base = (uint32_t)noise_id_base; a.noise_salt = (uint32_t)noise_salt; a.ctrl = ctrl; a.ap_out = ap_out;
+    a.logp_out = logp_out;
+    const int grid = (batch + kRows - 1) / kRows;
+    if (a.actor.E == 128) {
+        hipLaunchKernelGGL((pend_sac_critic_front_kernel<128, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
+    } else if (a.actor.E == 256) {
+        hipLaunchKernelGGL((pend_sac_critic_front_kernel<256, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
+    } else {
+        return RPO_ERR_ARG;
+    }
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_pendulum_sac_critic_back(const rpo_mlp* critic_target1_host, const rpo_mlp* critic_target2_host,
+                                 const rpo_mlp* critic1_host, const rpo_mlp* critic2_host, int batch, float* batch_rows,
+                                 const float* next_actions, const float* logp, float gamma, float alpha, float* q1_out,
+                                 float* q2_out, float* dq1_out, float* dq2_out, float* loss_partial, float* x0_save1,
+                                 float* h1_save1, float* x0_save2, float* h1_save2, void* stream) {
+    if (batch <= 0) return RPO_ERR_ARG;
+    if (!batch_rows || !next_actions || !logp || !q1_out || !q2_out || !dq1_out || !dq2_out || !loss_partial || !x0_save1 ||
+        !h1_save1 || !x0_save2 || !h1_save2)
+        return RPO_ERR_NULL;
+    SacCriticFwdArgs a{};
+    if (int e = fill_sac_args(a, 5, nullptr, critic_target1_host, critic_target2_host, critic1_host, critic2_host, false, true))
+        return e;
+    a.batch = batch; a.batch_out = batch_rows; a.next_actions = next_actions; a.logp_in = logp; a.gamma = gamma;
+    a.alpha = alpha; a.q1_out = q1_out; a.q2_out = q2_out; a.dq1_out = dq1_out; a.dq2_out = dq2_out;
+    a.loss_partial = loss_partial; a.x0_save1 = x0_save1; a.h1_save1 = h1_save1; a.x0_save2 = x0_save2; a.h1_save2 = h1_save2;
+    const int grid = (batch + kRows - 1) / kRows;
+    if (a.critic1.E == 128) {
+        hipLaunchKernelGGL((pend_sac_critic_back_kernel<128, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL((pend_sac_critic_back_kernel<256, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
     }
     RPO_LAUNCH_CHECK();
     return 0;

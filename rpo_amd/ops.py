@@ -353,6 +353,23 @@ class PendulumKernels(object):
             noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi, max_steps, corr_lr, corr_eps, corr_momentum,
             max_episode_steps, int(auto_reset), viol_thresh, seed, env_id_base, _stream()), "rpo_pendulum_rollout")
 
+    def sac_critic_front(self, actor, scale, base, box_lo, box_hi, rows, cap_steps, n_envs, batch_out, idx_out, idx_in,
+                         eps_in, sample_seed, sample_salt, noise_seed, noise_id_base, noise_salt, ctrl, ap_out, logp_out):
+        net = actor.net_struct()
+        check(_lib.load().rpo_pendulum_sac_critic_front(
+            ctypes.byref(net), scale, base, box_lo, box_hi, _p(rows), cap_steps, n_envs, batch_out.shape[0], _p(batch_out),
+            _p(idx_out, torch.int64, allow_none=True), _p(idx_in, torch.int64, allow_none=True),
+            _p(eps_in, allow_none=True), sample_seed, sample_salt, noise_seed, noise_id_base, noise_salt,
+            _p(ctrl, torch.int64), _p(ap_out), _p(logp_out), _stream()), "rpo_pendulum_sac_critic_front")
+
+    def sac_critic_back(self, critic_target1, critic_target2, critic1, critic2, batch_rows, next_actions, logp, gamma, alpha,
+                        q1_out, q2_out, dq1_out, dq2_out, loss_partial, x0_save1, h1_save1, x0_save2, h1_save2):
+        nets = [d.net_struct() for d in (critic_target1, critic_target2, critic1, critic2)]
+        check(_lib.load().rpo_pendulum_sac_critic_back(
+            *[ctypes.byref(n) for n in nets], batch_rows.shape[0], _p(batch_rows), _p(next_actions), _p(logp), gamma, alpha,
+            _p(q1_out), _p(q2_out), _p(dq1_out), _p(dq2_out), _p(loss_partial), _p(x0_save1), _p(h1_save1), _p(x0_save2),
+            _p(h1_save2), _stream()), "rpo_pendulum_sac_critic_back")
+
     def project_batchref(self, obs, ap, action, iters_out, max_steps, corr_lr, corr_eps, corr_momentum):
         op, ostride = _row_view(obs, 5)
         check(_lib.load().rpo_pendulum_project_batchref(action.shape[0], op, ostride, _p(ap), _p(action),

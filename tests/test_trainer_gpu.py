@@ -204,17 +204,17 @@ def test_rollout_pipeline_equals_single_stage_launches(hip, algo, envname, n_env
                                hip.reduce_stats(b.vec.stats[:iters]).cpu().numpy(), rtol=1e-5, atol=1e-9)
 
 
-@pytest.mark.parametrize("algo", ["ddpg", "sac"])
-def test_critic_forward_pipeline_equals_single_stage_launches(hip, algo, monkeypatch):
+@pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "cart"), ("sac", "pendulum")])
+def test_critic_forward_pipeline_equals_single_stage_launches(hip, algo, envname, monkeypatch):
     """rpo_cartsafe_{ddpg,sac}_critic_forward (sample -> policy -> projection -> target critics -> critics -> TD/Huber in
-    one launch) leaves the same bits behind as the launches it replaces: parameters, targets and replay after 16
+    one launch; SpringPendulum: front | batch-coupled projection | back) leaves the same bits behind as the launches it replaces: parameters, targets and replay after 16
     iterations with Philox-drawn batches and noise."""
     dev = torch.device("cuda")
     monkeypatch.setenv("RPO_FUSED_CRITIC", "0")
-    a = _run(algo, "cart", hip, dev, 16, 256, use_graph=False)
+    a = _run(algo, envname, hip, dev, 16, 256, use_graph=False)
     assert not a._pipelines
     monkeypatch.setenv("RPO_FUSED_CRITIC", "1")
-    b = _run(algo, "cart", hip, dev, 16, 256, use_graph=False)
+    b = _run(algo, envname, hip, dev, 16, 256, use_graph=False)
     assert b._pipelines
     assert torch.equal(a.agent.flat.data, b.agent.flat.data)
     assert torch.equal(a.agent.critic_target_flat, b.agent.critic_target_flat)
