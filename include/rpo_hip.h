@@ -402,6 +402,12 @@ int rpo_evopf_resid(int n, const float* state, int state_stride, const float* ac
 int rpo_evopf_ineq_partial_grad(int n, const float* state, int state_stride, const float* action, float* step_out, const float* consts_dev,
                                 void* stream);
 
+/* grad_action [n,43] = J_eq(action)^T grad_eq [n,28] with the entries of eq_jac (evopf.py:614-661): the backward of
+ * eq_resid in the Lagrangian baselines' actor loss (ddpg_lag.py:257-263).  autograd_sign != 0 gives the battery columns
+ * the sign torch autograd derives from the residual's +pe (evopf.py:532) instead of eq_jac's -I (:639-640). */
+int rpo_evopf_eq_vjp(int n, const float* action, const float* grad_eq, float* grad_action, int autograd_sign,
+                     const float* consts_dev, void* stream);
+
 /* scale * sum_b sum_j nu_j relu(g_j(s_b, a_b)) accumulated into loss_out, d/d action into grad_action [n,43] (written),
  * d/d nu accumulated into grad_nu [58] (rpo_ddpg.py:312-319, dual.py:63-65). */
 int rpo_evopf_lagrangian(int n, const float* state, int state_stride, const float* action, const float* nu, float scale, float* loss_out,

@@ -139,11 +139,12 @@ class PDDDPG_PA(_PartialActionAgent):
                  shared_param=True, value_type="add", box_constraint=None, lr_actor=1e-4, lr_critic=3e-4, lr_dual=1e-4,
                  reg=0, eps=0.1, tau=0.001, gamma=0.98, capacity=10000, ex_action_dim=0, partial=False,
                  partial_idx=None, init_lamb=0.0, init_nju=0.0, device=torch.device("cpu"), backend=None,
-                 clip_thres="inf"):
+                 clip_thres="inf", full_action=False):
         super().__init__(state_dim, action_dim, eq_num, ineq_num, box_constraint, lr_actor, lr_critic, lr_dual, reg,
                          eps, tau, gamma, capacity, partial, partial_idx, init_lamb, init_nju, device, backend,
                          clip_thres)
-        reduced = action_dim - eq_num - ex_action_dim
+        # full_action: the policy emits the whole action (agent/ddpg.py:34, the Lagrangian baselines' PDDDPG)
+        reduced = action_dim if full_action else action_dim - eq_num - ex_action_dim
         q_in = reduced if partial else action_dim
         # construction order == agent/ddpg_pa.py:32-49 (it fixes the RNG stream of the initial weights)
         state_embed = StateEmbedding(state_dim, embed_dim, hidden_dim)
@@ -181,12 +182,12 @@ class PDSAC_PA(_PartialActionAgent):
                  hidden_layer=1, shared_param=True, value_type="add", box_constraint=None, alpha=0.2, lr_alpha=1e-4,
                  lr_actor=1e-4, lr_critic=3e-4, lr_dual=1e-4, reg=0, eps=0.1, tau=0.005, gamma=0.98, capacity=10000,
                  ex_action_dim=0, partial=False, partial_idx=None, init_lamb=0.0, init_nju=0.0,
-                 device=torch.device("cpu"), backend=None, clip_thres="inf"):
+                 device=torch.device("cpu"), backend=None, clip_thres="inf", full_action=False):
         super().__init__(state_dim, action_dim, eq_num, ineq_num, box_constraint, lr_actor, lr_critic, lr_dual, reg,
                          eps, tau, gamma, capacity, partial, partial_idx, init_lamb, init_nju, device, backend,
                          clip_thres)
         self.automatic_entropy_tuning = automatic_entropy_tuning
-        reduced = action_dim - eq_num - ex_action_dim
+        reduced = action_dim if full_action else action_dim - eq_num - ex_action_dim  # agent/sac.py: PDSAC
         q_in = reduced if partial else action_dim
         # construction order == agent/sac_pa.py:32-52
         state_embed = StateEmbedding(state_dim, embed_dim, hidden_dim)

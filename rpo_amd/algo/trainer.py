@@ -471,6 +471,13 @@ class RPOTrainerBase(object):
     def _eval_partial(self, obs):
         raise NotImplementedError
 
+    def _eval_action(self, v):
+        """Deterministic policy + eval_steps projection iterations into v.action (rpo_ddpg.py:224-226)."""
+        ap = self._eval_partial(v.obs)
+        self.kernels.act_project(v.obs, ap, None, v.action, None, hip_ops.NOISE_NONE, 0.0, 0.0, 0.0, self._box_lo,
+                                 self._box_hi, self.eval_steps, self.eval_lr, self.corr_eps, self.corr_momentum,
+                                 **self._act_kw)
+
     def eval(self, rendering=False):
         """10 evaluation episodes of at most 500 steps with the deterministic policy and ``eval_steps`` projection
         iterations (rpo_ddpg.py:207-264), run as 10 parallel lanes.  Returns the reference's 10-tuple."""
@@ -491,10 +498,7 @@ class RPOTrainerBase(object):
         horizon = min(horizon, getattr(self.kernels, "episode_steps", horizon))     # EVOPF: one 24-hour day
         with torch.no_grad():
             for i in range(horizon):
-                ap = self._eval_partial(v.obs)
-                self.kernels.act_project(v.obs, ap, None, v.action, None, hip_ops.NOISE_NONE, 0.0, 0.0, 0.0, self._box_lo,
-                                         self._box_hi, self.eval_steps, self.eval_lr, self.corr_eps, self.corr_momentum,
-                                         **self._act_kw)
+                self._eval_action(v)
                 v.ctrl.zero_()
                 v.step(v.action, rows=self._eval_rows, cap_steps=1, auto_reset=False)
                 row = self._eval_rows

@@ -282,6 +282,28 @@ __global__ __launch_bounds__(RPO_WAVE) void evopf_ipg_kernel(int n, const float*
     if (tid < NY) step_out[(size_t)i * NY + tid] = w.dir[tid];
 }
 
+// Vector-Jacobian product of eq_resid: out[v] = sum_r grad_eq[r] * d eq_resid[r] / d action[v] with the entries of
+// eq_jac (evopf.py:614-661) -- what torch autograd computes through eq_resid (:520-546) in the Lagrangian baselines'
+// actor loss (ddpg_lag.py:257-263), except for the battery columns, where autograd differentiates the +pe of the
+// residual (:532) while eq_jac carries -I (hazard E1): `autograd_sign` != 0 flips them to the autograd value.
+__global__ __launch_bounds__(RPO_WAVE) void evopf_eq_vjp_kernel(int n, const float* __restrict__ action,
+                                                                const float* __restrict__ grad_eq, float* __restrict__ out,
+                                                                int autograd_sign, const float* __restrict__ consts) {
+    __shared__ Ws w;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    load_consts(w, consts);
+    load_row(w.a, action + (size_t)i * NY, NY);
+    load_row(w.eq, grad_eq + (size_t)i * NEQ, NEQ);
+    sync();
+    flows(w);
+    if (tid < NY) {
+        float acc = 0.0f;
+        for (int r = 0; r < NEQ; ++r) acc = fmaf(w.eq[r], jac_entry(w, r, tid), acc);
+        if (autograd_sign && tid >= PE0) acc = -acc;
+        out[(size_t)i * NY + tid] = acc;
+    }
+}
+
 // mean_b sum_j nu_j relu(g_j(s_b, a_b)) with its gradients (Dual.forward dual.py:63-65 on ineq_dist, rpo_ddpg.py:312-319).
 // The 58 inequalities are box bounds on single variables, so the work is elementwise: thread v of each of the 4 waves owns
 // action component v (its upper and its lower bound) for the rows b = wave (mod 4); the four partial sums are combined in
@@ -452,6 +474,16 @@ int rpo_evopf_ineq_partial_grad(int n, const float* state, int state_stride, con
     if (!step_out) return RPO_ERR_NULL;
     hipLaunchKernelGGL(evopf_ipg_kernel, dim3(n), dim3(RPO_WAVE), 0, (hipStream_t)stream, n, state, state_stride, action, step_out,
                        consts_dev);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_evopf_eq_vjp(int n, const float* action, const float* grad_eq, float* grad_action, int autograd_sign,
+                     const float* consts_dev, void* stream) {
+    if (int e = check_common(n, action, grad_eq, consts_dev)) return e;
+    if (!grad_action) return RPO_ERR_NULL;
+    hipLaunchKernelGGL(evopf_eq_vjp_kernel, dim3(n), dim3(RPO_WAVE), 0, (hipStream_t)stream, n, action, grad_eq, grad_action,
+                       autograd_sign, consts_dev);
     RPO_LAUNCH_CHECK();
     return 0;
 }

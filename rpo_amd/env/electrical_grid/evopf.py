@@ -183,16 +183,17 @@ class EVOPFEnv(HardConstraintEnv):
         return super().complete_partial(state if state.dim() == 2 else state.view(1, -1), ap)
 
     def _resid_backward(self, obs, action, grad_eq, grad_ineq):
-        """d/d action of the inequality residuals (constant +-identity blocks, evopf.py:663-707).  The equality
-        residuals are differentiated by the reference only inside PFFunction.backward, which complete_partial covers."""
-        if grad_eq is not None and bool((grad_eq != 0).any()):
-            raise NotImplementedError("autograd through eq_resid is not on the RPO path (only through complete_partial)")
+        """d/d action of the residuals: inequality rows are constant +-identity blocks (evopf.py:663-707); the equality
+        rows go through rpo_evopf_eq_vjp (torch autograd through eq_resid, used by the Lagrangian baselines)."""
         ng, nb = self.ng, self.nbus
         g = torch.zeros_like(action)
-        g[:, :ng] = grad_ineq[:, :ng] - grad_ineq[:, ng:2 * ng]
-        g[:, ng:2 * ng] = grad_ineq[:, 2 * ng:3 * ng] - grad_ineq[:, 3 * ng:4 * ng]
-        g[:, 2 * ng:2 * ng + nb] = grad_ineq[:, 4 * ng:4 * ng + nb] - grad_ineq[:, 4 * ng + nb:4 * ng + 2 * nb]
-        g[:, -self.ne:] = grad_ineq[:, -2 * self.ne:-self.ne] - grad_ineq[:, -self.ne:]
+        if grad_eq is not None:                                 # J_eq^T grad_eq, what autograd derives from eq_resid
+            self.kernels.eq_vjp(action.contiguous(), grad_eq.contiguous(), g, autograd_sign=True)
+        if grad_ineq is not None:
+            g[:, :ng] += grad_ineq[:, :ng] - grad_ineq[:, ng:2 * ng]
+            g[:, ng:2 * ng] += grad_ineq[:, 2 * ng:3 * ng] - grad_ineq[:, 3 * ng:4 * ng]
+            g[:, 2 * ng:2 * ng + nb] += grad_ineq[:, 4 * ng:4 * ng + nb] - grad_ineq[:, 4 * ng + nb:4 * ng + 2 * nb]
+            g[:, -self.ne:] += grad_ineq[:, -2 * self.ne:-self.ne] - grad_ineq[:, -self.ne:]
         return g
 
     def opt_solve(self, *a, **k):

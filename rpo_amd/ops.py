@@ -301,6 +301,10 @@ class EvopfKernels(object):
         check(_lib.load().rpo_evopf_ineq_partial_grad(action.shape[0], sp, ss, _p(action), _p(step_out),
                                                       self._c(action), _stream()), "rpo_evopf_ineq_partial_grad")
 
+    def eq_vjp(self, action, grad_eq, grad_action, autograd_sign=True):
+        check(_lib.load().rpo_evopf_eq_vjp(action.shape[0], _p(action), _p(grad_eq), _p(grad_action), int(autograd_sign),
+                                           self._c(action), _stream()), "rpo_evopf_eq_vjp")
+
     def lagrangian(self, action, nu, scale, loss_out, grad_action, grad_nu, obs=None):
         sp, ss = _row_view(obs, self.obs_dim)
         check(_lib.load().rpo_evopf_lagrangian(action.shape[0], sp, ss, _p(action), _p(nu), scale,

@@ -329,6 +329,96 @@ def gen_train_steps():
         save("train_steps_%s_%s%s" % (algo, envname, tag), **out)
 
 
+def gen_train_steps_la():
+    """DDPG_LA.train / SAC_LA.train (ddpg_lag.py:163-200, sac_lag.py:167-219) for t = 1..4 on a fixed buffer of
+    un-projected transitions, every random draw recorded; non-zero initial multipliers so that both dual steps move."""
+    import importlib
+    import torch.distributions.normal as tdn
+    sys.path.insert(0, ref_harness.REFERENCE_ROOT)
+    try:
+        la = {"ddpg": importlib.import_module("rpo.algo.ddpg_lag").DDPG_LA, "sac": importlib.import_module("rpo.algo.sac_lag").SAC_LA}
+    finally:
+        sys.path.remove(ref_harness.REFERENCE_ROOT)
+    for algo, envname in (("ddpg", "cart"), ("sac", "pendulum")):
+        torch.manual_seed(123)
+        np.random.seed(123)
+        env = make_cart_env(1) if envname == "cart" else REF.SpringPendulumEnv()
+        logger = REF.Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=10)
+        extra = dict(automatic_entropy_tuning=False, alpha=0.05) if algo == "sac" else {}
+        tr = la[algo](env, "/tmp", name="g", logger=logger, batch_size=256, warmup=0, policy_fre=4, max_epochs=10,
+                      capacity=512, value_type="add", clip_thres=0.2, embed_dim=128, hidden_dim=256, lr_actor=1e-4,
+                      lr_critic=3e-4, lr_dual=0.05, eps=0.3, init_lamb=0.2, init_nju=0.3, shared_param=(algo == "ddpg"),
+                      device=torch.device("cpu"), **extra)
+        out = {"actor0." + k: v.numpy().copy() for k, v in tr.agent.actor.state_dict().items()}
+        out.update({"critic0." + k: v.numpy().copy() for k, v in tr.agent.critic.state_dict().items()})
+        n = 400
+        trans = {k: [] for k in ("state", "action", "next_state", "reward", "done", "eq_viol", "ineq_viol")}
+        genv = REF.gym.make("CartSafe-v0" if envname == "cart" else "SpringPendulum-v0")
+        genv.seed(7)
+        s = genv.reset()
+        lo, hi = env.box_constraint
+        for i in range(n):
+            a = RNG.uniform(lo * 1.1, hi * 1.1).astype(np.float32)          # partly outside the box: violated bounds
+            s2, r, d, info = genv.step(a)
+            for k, v in zip(trans, (s, a, s2, r, d, info["eq_viol"].reshape(-1), info["ineq_viol"].reshape(-1))):
+                trans[k].append(np.asarray(v, dtype=np.float64 if k in ("state", "next_state") else np.float32))
+            tr.agent.add(s, a, s2, r, d, info["eq_viol"].reshape(-1), info["ineq_viol"].reshape(-1))
+            s = genv.reset() if d else s2
+        out.update({"buf." + k: np.stack(v) for k, v in trans.items()})
+        draws = {"idx": [], "noise": []}
+        orig_randint, orig_randn_like, orig_std_normal = np.random.randint, torch.randn_like, tdn._standard_normal
+
+        def rec_randint(*a, **k):
+            v = orig_randint(*a, **k)
+            draws["idx"].append(np.asarray(v).copy())
+            return v
+
+        def rec_randn_like(x, *a, **k):
+            v = orig_randn_like(x, *a, **k)
+            draws["noise"].append(v.numpy().copy())
+            return v
+
+        def rec_std_normal(shape, dtype, device):
+            v = orig_std_normal(shape, dtype, device)
+            draws["noise"].append(v.numpy().copy())
+            return v
+
+        losses = {"critic": [], "actor": []}
+        oc, oa = tr.critic_loss, tr.actor_loss
+
+        def rec_c(*a, **k):
+            v = oc(*a, **k)
+            losses["critic"].append(float(v))
+            return v
+
+        def rec_a(*a, **k):
+            v = oa(*a, **k)
+            losses["actor"].append(float(v[0] if isinstance(v, tuple) else v))
+            return v
+        tr.critic_loss, tr.actor_loss = rec_c, rec_a
+        np.random.randint, torch.randn_like, tdn._standard_normal = rec_randint, rec_randn_like, rec_std_normal
+        try:
+            for t in range(1, 5):
+                tr.train(t)
+                if t in (1, 4):
+                    out.update({"critic%d.%s" % (t, k): v.numpy().copy() for k, v in tr.agent.critic.state_dict().items()})
+        finally:
+            np.random.randint, torch.randn_like, tdn._standard_normal = orig_randint, orig_randn_like, orig_std_normal
+        out.update({"actor4." + k: v.numpy().copy() for k, v in tr.agent.actor.state_dict().items()})
+        out.update({"critic_target4." + k: v.numpy().copy() for k, v in tr.agent.critic_target.state_dict().items()})
+        if algo == "ddpg":
+            out.update({"actor_target4." + k: v.numpy().copy() for k, v in tr.agent.actor_target.state_dict().items()})
+        out["nju4"] = tr.agent.nju.weight.detach().numpy().copy()
+        out["lamb4"] = tr.agent.lamb.weight.detach().numpy().copy()
+        out["idx"] = np.stack(draws["idx"])
+        for i, z in enumerate(draws["noise"]):
+            out["noise%d" % i] = z
+        out["n_noise"] = len(draws["noise"])
+        out["critic_losses"] = np.array(losses["critic"])
+        out["actor_losses"] = np.array(losses["actor"])
+        save("train_steps_%sla_%s" % (algo, envname), **out)
+
+
 # ---------------------------------------------------------------------------------------------- training statistics
 
 def gen_training_stats(steps=3000, seeds=(0, 1, 2, 3, 4)):
@@ -375,8 +465,8 @@ def gen_training_stats(steps=3000, seeds=(0, 1, 2, 3, 4)):
 
 if __name__ == "__main__":
     # "stats" (reference training runs, ~4 min) is only generated on request
-    which = sys.argv[1:] or ["cart", "cart_gs", "pendulum", "train"]
+    which = sys.argv[1:] or ["cart", "cart_gs", "pendulum", "train", "train_la"]
     table = {"cart": gen_cart, "cart_gs": gen_cart_grad_steps, "pendulum": gen_pendulum, "train": gen_train_steps,
-             "stats": gen_training_stats}
+             "train_la": gen_train_steps_la, "stats": gen_training_stats}
     for w in which:
         table[w]()

@@ -234,6 +234,12 @@ class EvopfKernels(_EnvKernels):
             _put(iters, it)
         self._stat_iters(stats, ctrl, it)
 
+    def eq_vjp(self, action, grad_eq, grad_action, autograd_sign=True):
+        jac = oe.eq_jac(_np(action).astype(np.float64))
+        if autograd_sign:
+            jac[:, :, oe.GRID.pe0:] *= -1.0
+        _put(grad_action, np.einsum("nev,ne->nv", jac, _np(grad_eq).astype(np.float64)))
+
     def tanh_box_bwd(self, obs, raw, noise, eps_start, eps_end, eps_decay, ctrl, dap, dout):
         n = dout.numel() // 14
         lo, hi = oe.partial_box(_np(obs).astype(np.float64))

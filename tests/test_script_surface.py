@@ -7,7 +7,7 @@ import textwrap
 SNIPPET = textwrap.dedent('''
     import numpy as np
     import os
-    from rpo.algo import RPODDPG, RPOSAC
+    from rpo.algo import RPODDPG, RPOSAC, DDPG_LA, SAC_LA
     from rpo.env import *
     from rpo.utils.logger import Logger
     from rpo.utils.monitor import get_monitor
@@ -39,6 +39,9 @@ SNIPPET = textwrap.dedent('''
                     eval_steps=50, grad_eps=0.02, corr_momentum=0.0, policy_fre=4, ex_action_dim=1, gamma=0.95,
                     max_epochs=40000, capacity=200, clip_thres=0.2, shared_param=False, value_type="cat")
     assert evopf.agent.actor.affines[-1].weight.shape[0] == 14
+    la = DDPG_LA(env, "./test", name="cart_la", logger=logger, batch_size=256, warmup=0, lr_dual=0.2, capacity=200,
+                 embed_dim=128, hidden_dim=256, clip_thres=0.2)                      # rpo/algo/ddpg_lag.py:13-21
+    assert la.agent.actor.affines[-1].weight.shape[0] == 2 and la.process_action(None, 7) == 7
     if not torch.cuda.is_available():
         try:
             agent.run()
