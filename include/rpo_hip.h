@@ -349,7 +349,7 @@ int rpo_mlp_backward_pair(const rpo_mlp* net1_host, const rpo_mlp_grad* grad1_ho
 
 /* ---------------------------------------------------------------------------------------------------------------
  * EVOPF-v0 (rpo_amd/csrc/evopf.hip): one wavefront per env lane / batch row; the lane's 22x22 Newton system and the
- * 28x28 block of the equality Jacobian are eliminated in LDS.  state [n,57], action [n,43], basic actions [n,14];
+ * 28x28 block of the equality Jacobian are eliminated in registers, one matrix row per thread (evopf_dev.h).  state [n,57], action [n,43], basic actions [n,14];
  * consts_dev = the RPO_EVOPF_C_* buffer in device memory; state_stride = floats between consecutive state rows (57 for a
  * dense matrix, RPO_EVOPF_ROW when the states are columns of gathered replay rows).  The IEEE-14 bus classification is compiled in, like the
  * reference hard-wires case14 (evopf.py:211,336-337).

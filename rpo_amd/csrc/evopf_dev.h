@@ -40,9 +40,6 @@ __device__ constexpr int kPartialActions[NP] = {1, 2, 3, 4, 10, 11, 12, 15, 17, 
 // ... and the ones the equations determine (evopf.py:290)
 __device__ constexpr int kOtherVars[NO] = {0, 5, 6, 7, 8, 9, 13, 14, 16, 18, 19, 20, 21, 22, 23,
                                            25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37};
-// column of variable v in the elimination matrix [J_other | J_partial]
-__device__ constexpr int kColOf[NY] = {0, 28, 29, 30, 31, 1, 2, 3, 4, 5, 32, 33, 34, 6, 7, 35, 8, 36, 9, 10, 11, 12, 13, 14,
-                                       37, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 38, 39, 40, 41, 42};
 // Equation order used for the 28 x 28 elimination: the first six "other" variables (slack pg, qg) appear in exactly
 // one equation each with coefficient 1 (P at the slack bus, Q at the generator buses), so with these rows first the
 // leading 6 x 6 block is the identity and the elimination starts at pivot 6; the rest are the Newton equations.
@@ -74,8 +71,6 @@ __device__ __forceinline__ void load_consts(Ws& w, const float* __restrict__ con
 }
 __device__ __forceinline__ float Yr(const Ws& w, int i, int k) { return w.c[RPO_EVOPF_C_YR + i * NB + k]; }
 __device__ __forceinline__ float Yi(const Ws& w, int i, int k) { return w.c[RPO_EVOPF_C_YI + i * NB + k]; }
-
-__device__ __forceinline__ float wave_max_all(float v) { return rpo_wave_max(v); }
 
 // Charge-rate box shrunk by the state of charge (Battery.update_bound / ineq_resid, evopf.py:110-116,135-141)
 __device__ __forceinline__ void battery_bounds(float soc, float& p_max, float& p_min) {

@@ -227,7 +227,35 @@ def gen_train_steps(width=64, sub=1):
     save("train_steps_ddpg_evopf" + ("" if width == 64 else str(width)), **out)
 
 
+def gen_training_stats(steps=960, seeds=(0, 1, 2)):
+    """Statistics of short training runs of the reference on EVOPF (scripts/evopf_exp.py hyper-parameters; ~0.22 s per
+    step on one core here): per seed [logged steps, violation rate (max(max_ineq, max_eq) > 1e-3), mean max_ineq, mean
+    max_eq, max max_eq, mean episodic return, the same over the second half]."""
+    import contextlib
+    import io
+    rows = []
+    for seed in seeds:
+        np.random.seed(111 + seed)
+        torch.manual_seed(123 + seed)
+        env = REF.EVOPFEnv()
+        logger = REF.Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=steps, name="x")
+        tr = REF.RPODDPG(env, "/tmp/rpo_evopf_golden", name="x", logger=logger, max_epochs=steps, capacity=20000,
+                         device=torch.device("cpu"), **EVOPF_HP)
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr.run(eval=False)
+        n = logger.pointer
+        mi, me, rw = [logger.tracker[k][:n] for k in ("max_ineq", "max_eq", "reward")]
+        viol = np.maximum(mi, me) > 1e-3
+        rows.append([n, viol.mean(), mi.mean(), me.mean(), me.max(), rw.mean(), rw[n // 2:].mean()])
+        print("seed", seed, rows[-1], flush=True)
+    save("training_stats_ddpg_evopf", stats=np.array(rows), steps=steps,
+         columns=["logged", "viol_rate", "mean_max_ineq", "mean_max_eq", "max_max_eq", "mean_return", "mean_return_2nd_half"])
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["stats"]:                              # ~11 minutes, generated on request only
+        gen_training_stats()
+        sys.exit(0)
     gen_env()
     gen_step()
     gen_project()
