@@ -61,3 +61,48 @@ def test_training_statistics_match_reference(golden, algo, envname):
         d = abs(got[:, col].mean() - ref[:, col].mean())
         assert d <= 3 * se(col) + 0.35 * ref[:, col].mean(), (col, d, se(col))
     assert got[:, 0].min() > 0.9 * steps                         # the logger received (almost) every step
+
+
+def test_evopf_training_statistics_match_reference(golden):
+    """EVOPF-v0, RPODDPG with the hyper-parameters of scripts/evopf_exp.py: 3 seeds x 960 iterations (40 days) of the
+    reference (on the pypower stand-in, tests/golden/make_evopf_golden.py stats) vs the shipped trainer at num_envs = 1 on
+    the HIP kernels (MLP kernels, wave-per-lane power flow).  Different random days and exploration streams, so only
+    seed-averaged statistics are compared: violation rate within 3 SE + 0.05, mean max-inequality violation within
+    3 SE + 30 %, mean return within 3 SE + 15 %; the equalities hold to the level the reference reaches (GRG drift)."""
+    from rpo_amd import ops
+    from rpo_amd.algo import RPODDPG
+    from rpo_amd.env import EVOPFEnv
+    from rpo_amd.utils.logger import Logger
+    import test_train_step_golden as tsg
+    g = golden("training_stats_ddpg_evopf")
+    ref, steps = g["stats"], int(g["steps"])
+    hp = {k: v for k, v in tsg.EVOPF_HP.items() if k not in ("embed_dim", "hidden_dim", "init_nju", "capacity")}
+    rows = []
+    for seed in range(3):
+        torch.manual_seed(123 + seed)
+        tr = RPODDPG(EVOPFEnv(device="cuda"), "/tmp/rpo_test", name="t", logger=None, max_epochs=steps, capacity=20000,
+                     device=torch.device("cuda"), num_envs=1, seed=1000 + seed, **hp)
+        assert tr.fused is not None
+        tr.logger = Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=steps)
+        os.environ["RPO_VERBOSE"] = "0"
+        tr.run(eval=False)
+        n = tr.logger.pointer
+        mi, me, rw = [tr.logger.tracker[k][:n] for k in ("max_ineq", "max_eq", "reward")]
+        viol = np.maximum(mi, me) > 1e-3
+        rows.append([n, viol.mean(), mi.mean(), me.mean(), me.max(), rw.mean(), rw[n // 2:].mean()])
+    got = np.array(rows)
+    out = {"ref_mean": ref.mean(0).tolist(), "gpu_mean": got.mean(0).tolist(), "ref_std": ref.std(0).tolist(),
+           "gpu_std": got.std(0).tolist(), "columns": [str(c) for c in g["columns"]]}
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/statistical_parity_ddpg_evopf.json", "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out))
+
+    def se(col):
+        return np.sqrt(ref[:, col].var() / len(ref) + got[:, col].var() / len(got))
+    assert got[:, 0].min() == steps                              # 40 complete days, every step logged
+    assert abs(got[:, 1].mean() - ref[:, 1].mean()) <= 3 * se(1) + 0.05
+    assert abs(got[:, 2].mean() - ref[:, 2].mean()) <= 3 * se(2) + 0.3 * ref[:, 2].mean()
+    assert got[:, 4].max() <= max(2.0 * ref[:, 4].max(), 1e-2)   # equality drift no worse than the reference's
+    for col in (5, 6):
+        assert abs(got[:, col].mean() - ref[:, col].mean()) <= 3 * se(col) + 0.15 * abs(ref[:, col].mean())
