@@ -334,10 +334,12 @@ int rpo_mlp_forward(const rpo_mlp* net_host, int n, const float* s, int s_stride
  * grad_host's buffers (the shared state embedding of shared_param=True receives contributions from two networks,
  * agent/ddpg_pa.py:34-36).  dh [n, H] and dx0 [n, Ein] are caller-provided scratch; da [n, A] (may be NULL) receives
  * the gradient w.r.t. the action input (actor loss: -Q(s, a) back to the policy, rpo_ddpg.py:317).
- * param_grads = 0: only dx0 / da; first_layer_state_only = 1: of the parameters only Ws / bs are accumulated. */
+ * param_grads = 0: only dx0 / da; first_layer_state_only = 1: of the parameters only Ws / bs are accumulated.
+ * gradmax (may be NULL): receives max(gradmax[0], max |gradient element written by this call|) -- when the buffers were
+ * zero before the call this is clip_grad_norm_'s inf-norm of the network (rpo_ddpg.py:180), without the rpo_absmax pass. */
 int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int n, const float* s, int s_stride,
                      const float* a, int a_stride, const float* x0, const float* h1, const float* dout, float* dh,
-                     float* dx0, float* da, int param_grads, int first_layer_state_only, void* stream);
+                     float* dx0, float* da, int param_grads, int first_layer_state_only, float* gradmax, void* stream);
 
 /* rpo_mlp_backward of two networks of the same shape on the same inputs in one pair of launches (SAC's twin critics,
  * model/value.py:125-140): gridDim.y = 2 selects the network.  Results are those of two rpo_mlp_backward calls. */
@@ -345,7 +347,8 @@ int rpo_mlp_backward_pair(const rpo_mlp* net1_host, const rpo_mlp_grad* grad1_ho
                           const rpo_mlp_grad* grad2_host, int n, const float* s, int s_stride, const float* a,
                           int a_stride, const float* x0_1, const float* h1_1, const float* dout_1, float* dh_1,
                           float* dx0_1, float* da_1, const float* x0_2, const float* h1_2, const float* dout_2, float* dh_2,
-                          float* dx0_2, float* da_2, int param_grads, int first_layer_state_only, void* stream);
+                          float* dx0_2, float* da_2, int param_grads, int first_layer_state_only, float* gradmax,
+                          void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * EVOPF-v0 (rpo_amd/csrc/evopf.hip): one wavefront per env lane / batch row; the lane's 22x22 Newton system and the

@@ -95,9 +95,10 @@ class FusedAdam(object):
         # trainers switch it on when every backward of the iteration goes through the accumulating MLP kernels
         self.zero_grad_after = False
 
-    def step(self, target=None, tau=0.0):
+    def step(self, target=None, tau=0.0, gradmax_ready=False):
+        """``gradmax_ready``: the backward pass already left the inf-norm of this slice in ``self.gradmax``."""
         clip = self.clip_thres if self.clip_thres and self.clip_thres != float("inf") else 0.0
-        if clip > 0:
+        if clip > 0 and not gradmax_ready:
             self.backend.absmax(self.grad, self.gradmax)
         self.backend.adam_step(self.param, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr,
                                self.betas[0], self.betas[1], self.eps, self.weight_decay, self.maximize, clip,

@@ -120,30 +120,38 @@ class FusedNets(object):
         self.backend.mlp_forward(d, s, a, out, x0, h1, mode, scale, base)
         return out
 
-    def backward(self, name, s, a, dout, da=None, param_grads=True, first_layer_state_only=False):
+    def backward(self, name, s, a, dout, da=None, param_grads=True, first_layer_state_only=False, gradmax=None):
+        """``gradmax`` (1-element tensor or None): the weights pass leaves the inf-norm of the gradients it wrote there,
+        which saves the separate rpo_absmax launch of clip_grad_norm_ when the buffers were zero before."""
         d = self.descs[name]
         n = dout.shape[0]
+        kw = {} if gradmax is None else dict(gradmax=gradmax)
         self.backend.mlp_backward(d, s, a, self.buf(name + ".x0", n, d.ein), self.buf(name + ".h1", n, d.H), dout,
                                   self.buf(name + ".dh", n, d.H), self.buf(name + ".dx0", n, d.ein), da, param_grads,
-                                  first_layer_state_only)
+                                  first_layer_state_only, **kw)
 
 
     def backward_pair(self, name1, name2, s, a, dout1, dout2, da1=None, da2=None, param_grads=True,
-                      first_layer_state_only=False):
-        """Backward of two same-shaped networks (twin critics) in one pair of launches where the backend has it."""
+                      first_layer_state_only=False, gradmax=None):
+        """Backward of two same-shaped networks (twin critics) in one pair of launches where the backend has it.
+        Returns True when ``gradmax`` holds the inf-norm of the gradients afterwards (not with a shared embedding,
+        whose gradient is the sum of two passes)."""
         d1, d2 = self.descs[name1], self.descs[name2]
         shared = any(t is not None and d2.tensors[k] is not None and t.data_ptr() == d2.tensors[k].data_ptr()
                      for k, t in d1.tensors.items())           # a shared embedding: both would accumulate into it at once
         if shared or not hasattr(self.backend, "mlp_backward_pair"):
-            self.backward(name1, s, a, dout1, da1, param_grads, first_layer_state_only)
-            self.backward(name2, s, a, dout2, da2, param_grads, first_layer_state_only)
-            return
+            gm = None if shared else gradmax
+            self.backward(name1, s, a, dout1, da1, param_grads, first_layer_state_only, gradmax=gm)
+            self.backward(name2, s, a, dout2, da2, param_grads, first_layer_state_only, gradmax=gm)
+            return gm is not None
         n = dout1.shape[0]
         b = self.buf
         self.backend.mlp_backward_pair(
             d1, d2, s, a, b(name1 + ".x0", n, d1.ein), b(name1 + ".h1", n, d1.H), dout1, b(name1 + ".dh", n, d1.H),
             b(name1 + ".dx0", n, d1.ein), da1, b(name2 + ".x0", n, d2.ein), b(name2 + ".h1", n, d2.H), dout2,
-            b(name2 + ".dh", n, d2.H), b(name2 + ".dx0", n, d2.ein), da2, param_grads, first_layer_state_only)
+            b(name2 + ".dh", n, d2.H), b(name2 + ".dx0", n, d2.ein), da2, param_grads, first_layer_state_only,
+            **({} if gradmax is None else dict(gradmax=gradmax)))
+        return gradmax is not None
 
 
 class _Unsupported(Exception):

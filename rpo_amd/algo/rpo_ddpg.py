@@ -95,7 +95,9 @@ class RPODDPG(RPOTrainerBase):
             self.corr_momentum, self._box_lo, self._box_hi, ag.gamma, f.buf("q", B, 1), f.buf("qn", B, 1),
             f.buf("dq", B, 1), parts, f.buf("critic.x0", B, d.ein), f.buf("critic.h1", B, d.H))
         self._zero_grads()
-        f.backward("critic", state, action, f.buf("dq", B, 1))
+        gm = self._critic_gradmax()
+        f.backward("critic", state, action, f.buf("dq", B, 1), gradmax=gm)
+        self._gradmax_ready = gm is not None
         self.last_losses["critic"] = _LazySum(parts)
 
     # ---- the update through the hand-written MLP kernels (same arithmetic as critic_loss / actor_loss below) ------
@@ -114,7 +116,9 @@ class RPODDPG(RPOTrainerBase):
         self.backend.td_huber(q.view(-1), None, qn.view(-1), None, None, 0.0, reward, done, ag.gamma, loss, dq.view(-1),
                               None)
         self._zero_grads()
-        f.backward("critic", state, action, dq)
+        gm = self._critic_gradmax()
+        f.backward("critic", state, action, dq, gradmax=gm)
+        self._gradmax_ready = gm is not None
         self.last_losses["critic"] = loss[0]
 
     def _actor_update(self, cols):
@@ -182,7 +186,9 @@ class RPODDPG(RPOTrainerBase):
     def _critic_step(self, actor_step):
         ag = self.agent
         fuse = actor_step and ag.flat.sizes[1] == 0
-        ag.critic_optim.step(target=ag.critic_target_flat if fuse else None, tau=ag.tau)
+        ag.critic_optim.step(target=ag.critic_target_flat if fuse else None, tau=ag.tau,
+                             gradmax_ready=self._gradmax_ready)
+        self._gradmax_ready = False
 
     def _actor_step(self, actor_out):
         ag = self.agent

@@ -111,7 +111,8 @@ class RPOSAC(RPOTrainerBase):
                 f.buf("critic1.x0", B, d.ein), f.buf("critic1.h1", B, d.H), f.buf("critic2.x0", B, d.ein),
                 f.buf("critic2.h1", B, d.H))
             self._zero_grads()
-            f.backward_pair("critic1", "critic2", state, action, dq1, dq2)
+            self._gradmax_ready = f.backward_pair("critic1", "critic2", state, action, dq1, dq2,
+                                                  gradmax=self._critic_gradmax())
             self.last_losses["critic"] = _LazySum(parts)
             return
         self.kernels.sac_critic_forward(
@@ -122,7 +123,7 @@ class RPOSAC(RPOTrainerBase):
             f.buf("critic1.x0", B, d.ein), f.buf("critic1.h1", B, d.H), f.buf("critic2.x0", B, d.ein),
             f.buf("critic2.h1", B, d.H))
         self._zero_grads()
-        f.backward_pair("critic1", "critic2", state, action, dq1, dq2)
+        self._gradmax_ready = f.backward_pair("critic1", "critic2", state, action, dq1, dq2, gradmax=self._critic_gradmax())
         self.last_losses["critic"] = _LazySum(parts)
 
     # ---- the update through the hand-written MLP kernels (same arithmetic as critic_loss / actor_loss below) ------
@@ -145,7 +146,7 @@ class RPOSAC(RPOTrainerBase):
         self.backend.td_huber(q1.view(-1), q2.view(-1), qn1.view(-1), qn2.view(-1), logp, float(ag.alpha), reward, done,
                               ag.gamma, loss, dq1.view(-1), dq2.view(-1))
         self._zero_grads()
-        f.backward_pair("critic1", "critic2", state, action, dq1, dq2)
+        self._gradmax_ready = f.backward_pair("critic1", "critic2", state, action, dq1, dq2, gradmax=self._critic_gradmax())
         self.last_losses["critic"] = loss[0]
 
     def _actor_update(self, cols):
@@ -211,10 +212,11 @@ class RPOSAC(RPOTrainerBase):
         # shared state embedding, which the actor's step also moves, forces the separate launch after that step
         ag = self.agent
         self._fused_polyak = ag.flat.sizes[1] == 0
+        ready, self._gradmax_ready = self._gradmax_ready, False
         if self._fused_polyak:
-            ag.critic_optim.step(target=ag.critic_target_flat, tau=ag.tau)
+            ag.critic_optim.step(target=ag.critic_target_flat, tau=ag.tau, gradmax_ready=ready)
             return
-        ag.critic_optim.step()
+        ag.critic_optim.step(gradmax_ready=ready)
         if not actor_step:
             ag.soft_update()
 

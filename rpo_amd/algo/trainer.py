@@ -194,6 +194,7 @@ class RPOTrainerBase(object):
         # averaged in place between backward and step, then consumed the same way).  The torch/autograd path keeps its
         # explicit zeroing.
         self._self_cleaning = self.fused is not None
+        self._gradmax_ready = False
         for opt in (agent.critic_optim, agent.actor_optim, agent.nju_optim):
             opt.zero_grad_after = self._self_cleaning
         # fused multi-output actor: raw outputs, the env's projection kernel applies the state-dependent tanh box
@@ -274,6 +275,15 @@ class RPOTrainerBase(object):
             return self.eps_start
         t = self.vec.ctrl[0].to(torch.float32)
         return torch.clamp(self.eps_start - self.decay_value * t, min=self.eps)
+
+    def _critic_gradmax(self):
+        """Where the critic's backward kernels may leave the inf-norm of its gradient slice (clip_grad_norm_,
+        rpo_ddpg.py:180): only when that slice was zero before (self-cleaning steps) and is not averaged over ranks
+        afterwards.  `_critic_step` then skips the rpo_absmax launch."""
+        opt = self.agent.critic_optim
+        ok = self._self_cleaning and not self.dist.on and opt.clip_thres and opt.clip_thres != float("inf")
+        self._gradmax_ready = False
+        return opt.gradmax if ok else None
 
     def _zero_grads(self):
         """Before a backward of the fused path: nothing to do when the optimiser steps leave zeroed slices behind

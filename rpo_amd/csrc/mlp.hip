@@ -101,6 +101,7 @@ struct BwdArgs {
     float* da;             // [n, A] or NULL: gradient w.r.t. the action input
     int param_grads;       // 0: only dx0 / da are needed (critic inside the actor loss, non-shared embedding)
     int first_layer_state_only;   // 1: of the parameter gradients only dWs / dbs are accumulated (shared embedding)
+    float* gradmax;        // NULL, or where the weights pass leaves max |gradient element written| (clip_grad_norm_(inf))
 };
 
 template <int EIN, int H>
@@ -225,12 +226,13 @@ __device__ __forceinline__ void mlp_bwd_rows_body(const BwdArgs& p) {
 // workgroup accumulates the first-layer gradients dWs / dbs / dWa / dba from dx0, and the last one db0 / dW1 / db1.
 // Every output element has exactly one owner and a fixed summation order: the backward pass is bitwise reproducible.
 template <int EIN, int H>
-__device__ __forceinline__ void mlp_bwd_weights_body(const BwdArgs& p) {
+__device__ __forceinline__ float mlp_bwd_weights_body(const BwdArgs& p) {
+    float gmax = 0.0f;                                          // largest |gradient element| this thread wrote
     const Mlp& net = p.net;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int GEMM_BLOCKS = (H / 16) * (EIN / 64);           // one 16 x 64 tile of dW0 per workgroup
     if ((int)blockIdx.x < GEMM_BLOCKS) {
-        if (!p.param_grads || p.first_layer_state_only) return;
+        if (!p.param_grads || p.first_layer_state_only) return gmax;
         // the 4 waves split the batch (K) and combine through LDS in a fixed order
         __shared__ __attribute__((aligned(16))) float tile[4][16 * 64];
         const int jt = blockIdx.x / (EIN / 64), et = blockIdx.x - jt * (EIN / 64);
@@ -292,10 +294,11 @@ __device__ __forceinline__ void mlp_bwd_weights_body(const BwdArgs& p) {
             cur.z += ((t0.z + t1.z) + t2.z) + t3.z;
             cur.w += ((t0.w + t1.w) + t2.w) + t3.w;
             *dst = cur;
+            gmax = fmaxf(fmaxf(fabsf(cur.x), fabsf(cur.y)), fmaxf(fabsf(cur.z), fabsf(cur.w)));
         }
-        return;
+        return gmax;
     }
-    if (!p.param_grads) return;
+    if (!p.param_grads) return gmax;
     // ---- batch reductions with one owner per output: 64 outputs per workgroup, the batch split over the 4 waves and
     //      combined through LDS in a fixed order (bitwise reproducible)
     __shared__ float partial[4][3][64];
@@ -308,7 +311,7 @@ __device__ __forceinline__ void mlp_bwd_weights_body(const BwdArgs& p) {
         // multi-output head: db0[j], dW1_k[o][j] = sum_b dout[b][k*hd + o] relu(h1[b][j]), db1_k[o] = sum_b dout[b][k*hd + o].
         // 16 hidden columns per workgroup, the batch split 16 ways and combined through LDS in a fixed order (one owner per
         // output): H/16 workgroups x 16 batch slices keep the exposed load latency to n/16 rows per thread.
-        if (p.first_layer_state_only) return;
+        if (p.first_layer_state_only) return gmax;
         __shared__ float wide[16][kWideOut + 1][16];
         const int outs = net.n_out * net.hd;
         const int jj = tid & 15, slice = tid >> 4;
@@ -352,7 +355,9 @@ __device__ __forceinline__ void mlp_bwd_weights_body(const BwdArgs& p) {
             for (int sl = 0; sl < 16; ++sl) tot += wide[sl][src][c];
             float* dst = q == outs ? &p.g.b0[rb * 16 + c]
                                    : (q < net.hd ? &p.g.W1[(size_t)q * H + rb * 16 + c] : &p.g.W1b[(size_t)(q - net.hd) * H + rb * 16 + c]);
-            *dst += tot;
+            const float nv = *dst + tot;
+            *dst = nv;
+            gmax = fmaxf(gmax, fabsf(nv));
         }
         if (rb == 0) {
             // db1: 8 batch slices x 32 outputs, combined in a fixed order
@@ -369,14 +374,16 @@ __device__ __forceinline__ void mlp_bwd_weights_body(const BwdArgs& p) {
                 float tot = 0.0f;
                 for (int sl = 0; sl < 8; ++sl) tot += red[sl * 32 + tid];
                 float* dst = tid < net.hd ? &p.g.b1[tid] : &p.g.b1b[tid - net.hd];
-                *dst += tot;
+                const float nv = *dst + tot;
+                *dst = nv;
+                gmax = fmaxf(gmax, fabsf(nv));
             }
         }
-        return;
+        return gmax;
     }
     if (rb < HV_BLOCKS) {
         // hidden-layer vectors: db0[j] = sum_b dh[b][j]; dW1_k[j] = sum_b dout[b][k] relu(h1[b][j]); db1_k = sum_b dout[b][k]
-        if (p.first_layer_state_only) return;
+        if (p.first_layer_state_only) return gmax;
         const int j = rb * 64 + o;
         float gb0 = 0.0f, gw1a = 0.0f, gw1b = 0.0f;
         int bb = b_lo;
@@ -406,9 +413,16 @@ __device__ __forceinline__ void mlp_bwd_weights_body(const BwdArgs& p) {
         partial[part][0][o] = gb0; partial[part][1][o] = gw1a; partial[part][2][o] = gw1b;
         __syncthreads();
         if (part == 0) {
-            p.g.b0[j] += ((partial[0][0][o] + partial[1][0][o]) + partial[2][0][o]) + partial[3][0][o];
-            p.g.W1[j] += ((partial[0][1][o] + partial[1][1][o]) + partial[2][1][o]) + partial[3][1][o];
-            if (net.n_out > 1) p.g.W1b[j] += ((partial[0][2][o] + partial[1][2][o]) + partial[2][2][o]) + partial[3][2][o];
+            const float nb0 = p.g.b0[j] + (((partial[0][0][o] + partial[1][0][o]) + partial[2][0][o]) + partial[3][0][o]);
+            const float nw1 = p.g.W1[j] + (((partial[0][1][o] + partial[1][1][o]) + partial[2][1][o]) + partial[3][1][o]);
+            p.g.b0[j] = nb0;
+            p.g.W1[j] = nw1;
+            gmax = fmaxf(fabsf(nb0), fabsf(nw1));
+            if (net.n_out > 1) {
+                const float nw1b = p.g.W1b[j] + (((partial[0][2][o] + partial[1][2][o]) + partial[2][2][o]) + partial[3][2][o]);
+                p.g.W1b[j] = nw1b;
+                gmax = fmaxf(gmax, fabsf(nw1b));
+            }
         }
         if (rb == 0) {
             // db1_k = sum_b dout[b][k]: strided per-thread partials, fixed-pattern wave reduction, 4 wave partials added
@@ -424,11 +438,17 @@ __device__ __forceinline__ void mlp_bwd_weights_body(const BwdArgs& p) {
             if (o == 0) { partial[part][0][0] = s0; partial[part][1][0] = s1; }
             __syncthreads();
             if (tid == 0) {
-                p.g.b1[0] += ((partial[0][0][0] + partial[1][0][0]) + partial[2][0][0]) + partial[3][0][0];
-                if (net.n_out > 1) p.g.b1b[0] += ((partial[0][1][0] + partial[1][1][0]) + partial[2][1][0]) + partial[3][1][0];
+                const float nb1 = p.g.b1[0] + (((partial[0][0][0] + partial[1][0][0]) + partial[2][0][0]) + partial[3][0][0]);
+                p.g.b1[0] = nb1;
+                gmax = fmaxf(gmax, fabsf(nb1));
+                if (net.n_out > 1) {
+                    const float nb1b = p.g.b1b[0] + (((partial[0][1][0] + partial[1][1][0]) + partial[2][1][0]) + partial[3][1][0]);
+                    p.g.b1b[0] = nb1b;
+                    gmax = fmaxf(gmax, fabsf(nb1b));
+                }
             }
         }
-        return;
+        return gmax;
     }
     // first layer: output list idx = q * E + e (e fastest: coalesced dx0 reads); q < wS: state weights / bias,
     // q >= wS: action weights / bias.  Columns of x0: [0, E) <- state (+ action when added); [E, 2E) <- action (cat).
@@ -466,14 +486,32 @@ __device__ __forceinline__ void mlp_bwd_weights_body(const BwdArgs& p) {
     if (part == 0 && valid) {
         const float tot = ((partial[0][0][o] + partial[1][0][o]) + partial[2][0][o]) + partial[3][0][o];
         float* dst = (i < width) ? (is_a ? &p.g.Wa[e * net.A + i] : &p.g.Ws[e * net.S + i]) : (is_a ? &p.g.ba[e] : &p.g.bs[e]);
-        *dst += tot;
+        const float nv = *dst + tot;
+        *dst = nv;
+        gmax = fabsf(nv);
     }
+    return gmax;
 }
 
 template <int EIN, int H>
 __global__ __launch_bounds__(kThreads) void mlp_bwd_rows_kernel(BwdArgs p) { mlp_bwd_rows_body<EIN, H>(p); }
+// max over the workgroup of the gradient magnitudes its threads wrote -> one atomic max (order independent: exact)
+__device__ __forceinline__ void gradmax_flush(float* gradmax, float v) {
+    __shared__ float red[kThreads / 64];
+    if (gradmax == nullptr) return;
+    v = rpo_wave_max(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = red[0];
+        for (int w = 1; w < kThreads / 64; ++w) m = fmaxf(m, red[w]);
+        if (m > 0.0f) rpo_atomic_max_nonneg(gradmax, m);
+    }
+}
 template <int EIN, int H>
-__global__ __launch_bounds__(kThreads) void mlp_bwd_weights_kernel(BwdArgs p) { mlp_bwd_weights_body<EIN, H>(p); }
+__global__ __launch_bounds__(kThreads) void mlp_bwd_weights_kernel(BwdArgs p) {
+    gradmax_flush(p.gradmax, mlp_bwd_weights_body<EIN, H>(p));
+}
 
 // Two networks of the same shape in one launch (blockIdx.y picks the network): SAC's twin critics.  Both backward
 // passes are latency-bound on a handful of workgroups, so the pair costs what one costs.
@@ -483,7 +521,9 @@ struct BwdArgs2 {
 template <int EIN, int H>
 __global__ __launch_bounds__(kThreads) void mlp_bwd_rows_kernel2(BwdArgs2 p) { mlp_bwd_rows_body<EIN, H>(p.net[blockIdx.y]); }
 template <int EIN, int H>
-__global__ __launch_bounds__(kThreads) void mlp_bwd_weights_kernel2(BwdArgs2 p) { mlp_bwd_weights_body<EIN, H>(p.net[blockIdx.y]); }
+__global__ __launch_bounds__(kThreads) void mlp_bwd_weights_kernel2(BwdArgs2 p) {
+    gradmax_flush(p.net[blockIdx.y].gradmax, mlp_bwd_weights_body<EIN, H>(p.net[blockIdx.y]));
+}
 
 // ------------------------------------------------------------------------------------------------- policy heads
 // DDPG head backward (model/policy.py:30-31 + agent/ddpg_pa.py:108-110): ap = clip(scale*tanh(o)+base + eps_t*noise);
@@ -616,7 +656,7 @@ int rpo_mlp_forward(const rpo_mlp* net_host, int n, const float* s, int s_stride
 
 static int make_bwd_args(BwdArgs& args, const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int n, const float* s,
                          int s_stride, const float* a, int a_stride, const float* x0, const float* h1, const float* dout,
-                         float* dh, float* dx0, float* da, int param_grads, int first_layer_state_only) {
+                         float* dh, float* dx0, float* da, int param_grads, int first_layer_state_only, float* gradmax) {
     if (!net_host) return RPO_ERR_NULL;
     Mlp net{net_host->Ws, net_host->bs, net_host->Wa, net_host->ba, net_host->W0, net_host->b0, net_host->W1,
             net_host->b1, net_host->W1b, net_host->b1b, net_host->S, net_host->A, net_host->E, net_host->H,
@@ -634,7 +674,8 @@ static int make_bwd_args(BwdArgs& args, const rpo_mlp* net_host, const rpo_mlp_g
             return RPO_ERR_NULL;
         if (!first_layer_state_only && net.n_out > 1 && (!g.W1b || !g.b1b)) return RPO_ERR_NULL;
     }
-    args = BwdArgs{net, g, n, s, s_stride, a, a_stride, x0, h1, dout, dh, dx0, da, param_grads, first_layer_state_only};
+    args = BwdArgs{net, g, n, s, s_stride, a, a_stride, x0, h1, dout, dh, dx0, da, param_grads, first_layer_state_only,
+                   gradmax};
     return 0;
 }
 
@@ -646,10 +687,10 @@ static int bwd_weights_grid(const Mlp& net, int first_layer_state_only) {
 
 int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int n, const float* s, int s_stride,
                      const float* a, int a_stride, const float* x0, const float* h1, const float* dout, float* dh,
-                     float* dx0, float* da, int param_grads, int first_layer_state_only, void* stream) {
+                     float* dx0, float* da, int param_grads, int first_layer_state_only, float* gradmax, void* stream) {
     BwdArgs args;
     if (int e = make_bwd_args(args, net_host, grad_host, n, s, s_stride, a, a_stride, x0, h1, dout, dh, dx0, da,
-                              param_grads, first_layer_state_only))
+                              param_grads, first_layer_state_only, gradmax))
         return e;
     const Mlp& net = args.net;
     const int ein = net.cat ? 2 * net.E : net.E;
@@ -677,13 +718,14 @@ int rpo_mlp_backward_pair(const rpo_mlp* net1_host, const rpo_mlp_grad* grad1_ho
                           const rpo_mlp_grad* grad2_host, int n, const float* s, int s_stride, const float* a,
                           int a_stride, const float* x0_1, const float* h1_1, const float* dout_1, float* dh_1,
                           float* dx0_1, float* da_1, const float* x0_2, const float* h1_2, const float* dout_2, float* dh_2,
-                          float* dx0_2, float* da_2, int param_grads, int first_layer_state_only, void* stream) {
+                          float* dx0_2, float* da_2, int param_grads, int first_layer_state_only, float* gradmax,
+                          void* stream) {
     BwdArgs2 args;
     if (int e = make_bwd_args(args.net[0], net1_host, grad1_host, n, s, s_stride, a, a_stride, x0_1, h1_1, dout_1, dh_1,
-                              dx0_1, da_1, param_grads, first_layer_state_only))
+                              dx0_1, da_1, param_grads, first_layer_state_only, gradmax))
         return e;
     if (int e = make_bwd_args(args.net[1], net2_host, grad2_host, n, s, s_stride, a, a_stride, x0_2, h1_2, dout_2, dh_2,
-                              dx0_2, da_2, param_grads, first_layer_state_only))
+                              dx0_2, da_2, param_grads, first_layer_state_only, gradmax))
         return e;
     const Mlp &n1 = args.net[0].net, &n2 = args.net[1].net;
     if (n1.S != n2.S || n1.A != n2.A || n1.E != n2.E || n1.H != n2.H || n1.n_out != n2.n_out || n1.cat != n2.cat ||

@@ -454,7 +454,8 @@ def mlp_forward(desc, s, a, out, x0_save=None, h1_save=None, out_mode=0, scale=1
                                       _stream()), "rpo_mlp_forward")
 
 
-def mlp_backward(desc, s, a, x0, h1, dout, dh, dx0, da=None, param_grads=True, first_layer_state_only=False):
+def mlp_backward(desc, s, a, x0, h1, dout, dh, dx0, da=None, param_grads=True, first_layer_state_only=False,
+                 gradmax=None):
     sp, ss = _row_view(s, desc.S)
     ap, as_ = (None, 0) if desc.A == 0 else _row_view(a, desc.A)
     net = desc.net_struct()
@@ -462,7 +463,7 @@ def mlp_backward(desc, s, a, x0, h1, dout, dh, dx0, da=None, param_grads=True, f
     check(_lib.load().rpo_mlp_backward(ctypes.byref(net), None if grad is None else ctypes.byref(grad), dout.shape[0],
                                        sp, ss, ap, as_, _p(x0), _p(h1), _p(dout), _p(dh), _p(dx0),
                                        _p(da, allow_none=True), int(param_grads), int(first_layer_state_only),
-                                       _stream()), "rpo_mlp_backward")
+                                       _p(gradmax, allow_none=True), _stream()), "rpo_mlp_backward")
 
 
 def tanh_box_bwd(dap, ap_det, noise, eps_start, eps_end, eps_decay, ctrl, lo, hi, scale, base, dout):
@@ -482,7 +483,7 @@ def gauss_head_bwd(raw, eps, dap, dlogp, scale, base, lo, hi, draw):
 
 
 def mlp_backward_pair(desc1, desc2, s, a, x0_1, h1_1, dout_1, dh_1, dx0_1, da_1, x0_2, h1_2, dout_2, dh_2, dx0_2, da_2,
-                      param_grads=True, first_layer_state_only=False):
+                      param_grads=True, first_layer_state_only=False, gradmax=None):
     sp, ss = _row_view(s, desc1.S)
     ap, as_ = (None, 0) if desc1.A == 0 else _row_view(a, desc1.A)
     n1, n2 = desc1.net_struct(), desc2.net_struct()
@@ -492,4 +493,4 @@ def mlp_backward_pair(desc1, desc2, s, a, x0_1, h1_1, dout_1, dh_1, dx0_1, da_1,
         ctypes.byref(n1), None if g1 is None else ctypes.byref(g1), ctypes.byref(n2), None if g2 is None else ctypes.byref(g2),
         dout_1.shape[0], sp, ss, ap, as_, _p(x0_1), _p(h1_1), _p(dout_1), _p(dh_1), _p(dx0_1), _p(da_1, allow_none=True),
         _p(x0_2), _p(h1_2), _p(dout_2), _p(dh_2), _p(dx0_2), _p(da_2, allow_none=True), int(param_grads),
-        int(first_layer_state_only), _stream()), "rpo_mlp_backward_pair")
+        int(first_layer_state_only), _p(gradmax, allow_none=True), _stream()), "rpo_mlp_backward_pair")

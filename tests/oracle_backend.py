@@ -456,7 +456,16 @@ def mlp_forward(d, s, a, out, x0_save=None, h1_save=None, out_mode=0, scale=1.0,
             h1_save.copy_(h1)
 
 
-def mlp_backward(d, s, a, x0, h1, dout, dh, dx0, da=None, param_grads=True, first_layer_state_only=False):
+def mlp_backward(d, s, a, x0, h1, dout, dh, dx0, da=None, param_grads=True, first_layer_state_only=False, gradmax=None):
+    _mlp_backward(d, s, a, x0, h1, dout, dh, dx0, da, param_grads, first_layer_state_only)
+    if gradmax is not None and param_grads:
+        with torch.no_grad():
+            keys = ("Ws", "bs") if first_layer_state_only else tuple(d.tensors)
+            m = max(float(d.tensors[k].grad.abs().max()) for k in keys if d.tensors[k] is not None)
+            gradmax[0] = max(float(gradmax[0]), m)
+
+
+def _mlp_backward(d, s, a, x0, h1, dout, dh, dx0, da=None, param_grads=True, first_layer_state_only=False):
     t = {k: (None if v is None else v.detach()) for k, v in d.tensors.items()}
     g = {k: (None if v is None else v.grad) for k, v in d.tensors.items()}
     with torch.no_grad():
