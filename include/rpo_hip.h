@@ -458,6 +458,35 @@ int rpo_cartsafe_ddpg_critic_forward(const rpo_mlp* actor_target_host, const rpo
                                      int partial, float gamma, float* q_out, float* qn_out, float* dq_out,
                                      float* loss_partial, float* x0_save, float* h1_save, void* stream);
 
+/* The policy step of RPODDPG on CartSafe (rpo_ddpg.py:186-205, 307-324) as forward + backward pipelines (E = 128):
+ *   forward:  pi(s) with pre-activations saved -> ap = clip(ap_det + eps_t * N(0,1)) (noise_in[b], or the Philox draw of
+ *             rpo_philox_normal(noise_id_base, noise_salt, RPO_STREAM_POLICY)) -> Complete -> Q(s, a) saved ->
+ *             Lagrangian term: g_act [B,2] = d/d action / B, partial_out [ceil(B/16), 8] = per-workgroup sums of
+ *             (nu . relu(g), relu(g_0..5), Q); dq_out = -1/B.
+ *   backward: critic rows with da, da += g_act, autograd through Complete and the tanh box / clip, actor rows, the
+ *             actor's weights pass (with a shared state embedding the critic's dx0 is added to the actor's first, so one
+ *             first-layer reduction yields the embedding's gradient); lag_out = (mean Lagrangian term, mean Q),
+ *             nu_grad [6] += mean relu(g); gradmax as in rpo_mlp_backward (actor slice).
+ * == rpo_mlp_forward x 2, rpo_philox_normal, rpo_cartsafe_act_project, rpo_cartsafe_lagrangian, rpo_mlp_backward x 2,
+ *    rpo_cartsafe_complete_bwd, rpo_tanh_box_bwd and three elementwise launches. */
+int rpo_cartsafe_ddpg_actor_forward(const rpo_mlp* actor_host, const rpo_mlp* critic_host, float scale, float base,
+                                    float box_lo, float box_hi, float eps_start, float eps_end, float eps_decay,
+                                    const float* batch, int batch_size, const float* noise_in, unsigned long long seed,
+                                    unsigned noise_id_base, unsigned noise_salt, const long long* ctrl, const float* nu,
+                                    const float* consts_host, int partial, float* ap_det, float* noise_out,
+                                    float* actions, float* q_out, float* dq_out, float* g_act, float* partial_out,
+                                    float* actor_x0, float* actor_h1, float* critic_x0, float* critic_h1, void* stream);
+int rpo_cartsafe_ddpg_actor_backward(const rpo_mlp* actor_host, const rpo_mlp_grad* actor_grad_host,
+                                     const rpo_mlp* critic_host, int shared_embedding, const float* batch,
+                                     int batch_size, const float* actions, const float* g_act, const float* ap_det,
+                                     const float* noise, const float* dq, float eps_start, float eps_end,
+                                     float eps_decay, float box_lo, float box_hi, float scale, float base,
+                                     const long long* ctrl, const float* consts_host, int partial,
+                                     const float* actor_x0, const float* actor_h1, const float* critic_x0,
+                                     const float* critic_h1, float* actor_dh, float* actor_dx0, float* critic_dh,
+                                     float* critic_dx0, float* da, float* dout, const float* partial_in, float* lag_out,
+                                     float* nu_grad, float* gradmax, void* stream);
+
 /* The same for RPOSAC.critic_loss (rpo_sac.py:342-353): sample -> a' ~ pi(s') with the ONLINE actor (mean / log-std
  * heads, rsample, box clip; the N(0,1) draw of row b is normal(philox(noise_seed, noise_id_base + b, ctrl[T] +
  * noise_salt, RPO_STREAM_POLICY, ctrl[UPDATES])), i.e. rpo_philox_normal, or eps_in[b] when given) -> Complete + Proj ->

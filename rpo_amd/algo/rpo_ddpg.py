@@ -21,6 +21,19 @@ class _LazySum(object):
         return self.parts.sum()
 
 
+class _LazyDiff(object):
+    """mean Lagrangian term - mean Q from the two words the actor-backward pipeline leaves on the device."""
+
+    def __init__(self, pair):
+        self.pair = pair
+
+    def __float__(self):
+        return float(self.pair[0] - self.pair[1])
+
+    def detach(self):
+        return self.pair[0] - self.pair[1]
+
+
 class RPODDPG(RPOTrainerBase):
 
     def __init__(self, env, work_dir, name, logger, max_steps=10, embed_dim=256, hidden_dim=256, hidden_layer=1,
@@ -121,9 +134,52 @@ class RPODDPG(RPOTrainerBase):
         self._gradmax_ready = gm is not None
         self.last_losses["critic"] = loss[0]
 
+    @property
+    def _actor_pipeline(self):
+        d = self.fused.descs if self.fused is not None else {}
+        return (hasattr(self.kernels, "ddpg_actor_forward") and "actor" in d and "critic" in d and d["actor"].E == 128
+                and d["critic"].E == 128 and not d["critic"].cat and self._box_affine is not None
+                and self._batch.is_contiguous() and _env_int("RPO_FUSED_ACTOR", 1))
+
+    def _actor_update_pipeline(self, cols):
+        """The policy step in two launches + the actor's weights pass (fused.hip)."""
+        f, ag, B, k = self.fused, self.agent, self.batch_size, self.kernels
+        da_, dc = f.descs["actor"], f.descs["critic"]
+        scale, base = self._box_affine
+        b = f.buf
+        parts = b("actor.parts", (B + 15) // 16, 8)
+        ap_det, noise, actions = b("act.ap_det", B), b("act.noise", B), b("act_pi", B, k.action_dim)
+        q, dq, g_act = b("q_pi", B, 1), b("dq_pi", B, 1), b("g_act", B, k.action_dim)
+        noise_in = None
+        if self._idx_inject is not None:                       # tests replay the reference's draw
+            self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * B, _SALT_ACTOR, hip_ops.STREAM_POLICY,
+                                       self.vec.ctrl)
+            noise_in = self._noise_b.view(-1)
+        k.ddpg_actor_forward(da_, dc, scale, base, self._box_lo, self._box_hi, self.eps_start, self.eps, self.decay_value,
+                             self._batch, noise_in, self.seed, self.dist.rank * B, _SALT_ACTOR, self.vec.ctrl,
+                             ag.nju.weight.view(-1), ap_det, noise, actions, q, dq, g_act, parts, b("actor.x0", B, da_.ein),
+                             b("actor.h1", B, da_.H), b("critic.x0", B, dc.ein), b("critic.h1", B, dc.H))
+        self._zero_grads()
+        shared = ag.flat.sizes[1] > 0
+        opt = ag.actor_optim
+        fuse_max = self._self_cleaning and not self.dist.on and opt.clip_thres and opt.clip_thres != float("inf")
+        lag = b("actor.lag", 2)
+        k.ddpg_actor_backward(da_, dc, shared, self._batch, actions, g_act, ap_det, noise, dq, self.eps_start, self.eps,
+                              self.decay_value, self._box_lo, self._box_hi, scale, base, self.vec.ctrl,
+                              b("actor.x0", B, da_.ein), b("actor.h1", B, da_.H), b("critic.x0", B, dc.ein),
+                              b("critic.h1", B, dc.H), b("actor.dh", B, da_.H), b("actor.dx0", B, da_.ein),
+                              b("critic.dh", B, dc.H), b("critic.dx0", B, dc.ein), b("da", B, k.action_dim), b("do", B),
+                              parts, lag, ag.nju.weight.grad.view(-1), opt.gradmax if fuse_max else None)
+        self._actor_gradmax_ready = bool(fuse_max)
+        loss = _LazyDiff(lag)
+        self.last_losses["actor"] = loss
+        return loss
+
     def _actor_update(self, cols):
         if self.fused is None:
             return super()._actor_update(cols)
+        if self._actor_pipeline:
+            return self._actor_update_pipeline(cols)
         f, ag, B, k = self.fused, self.agent, self.batch_size, self.kernels
         state = cols[0]
         ap_det = self._actor_out("actor", state, save=True)
@@ -192,7 +248,9 @@ class RPODDPG(RPOTrainerBase):
 
     def _actor_step(self, actor_out):
         ag = self.agent
-        ag.actor_optim.step(target=ag.actor_target_flat, tau=ag.tau)
+        ag.actor_optim.step(target=ag.actor_target_flat, tau=ag.tau,
+                            gradmax_ready=getattr(self, "_actor_gradmax_ready", False))
+        self._actor_gradmax_ready = False
         if not self.fixed:
             ag.nju_optim.step()                                    # lambda is never stepped (rpo_ddpg.py:202)
         if ag.flat.sizes[1] > 0:

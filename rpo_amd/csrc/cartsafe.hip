@@ -130,10 +130,9 @@ __global__ __launch_bounds__(RPO_BLOCK) void cartsafe_act_project_kernel(ActArgs
 // ------------------------------------------------------------------------------------ small constraint kernels
 __global__ __launch_bounds__(RPO_BLOCK) void cartsafe_complete_bwd_kernel(int n, const float* __restrict__ ga,
                                                                           float* __restrict__ gap, CartConsts c) {
-    const float k = -(c.C_p * c.C_o_inv);
     for (int i = blockIdx.x * RPO_BLOCK + threadIdx.x; i < n; i += gridDim.x * RPO_BLOCK) {
         const float2 g = reinterpret_cast<const float2*>(ga)[i];
-        gap[i] = c.partial == 0 ? g.x + k * g.y : g.y + k * g.x;
+        gap[i] = complete_bwd_row(c, g.x, g.y);
     }
 }
 
@@ -174,16 +173,11 @@ __global__ __launch_bounds__(RPO_BLOCK) void cartsafe_lagrangian_kernel(int n, c
     float acc[7] = {0, 0, 0, 0, 0, 0, 0};   // loss, dist_0..5
     for (int i = blockIdx.x * RPO_BLOCK + threadIdx.x; i < n; i += gridDim.x * RPO_BLOCK) {
         const float2 a = reinterpret_cast<const float2*>(action)[i];
-        float h, g[6];
-        eq_ineq(c, a.x, a.y, h, g);
-        float g0 = 0.0f, g1 = 0.0f;
+        float row_loss, dist[6], g0, g1;
+        lagrangian_row(c, a.x, a.y, nuv, row_loss, dist, g0, g1);
+        acc[0] += row_loss;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const float dist = fmaxf(g[j], 0.0f);                   // ineq_dist, cartpole.py:385-387
-            acc[0] += nuv[j] * dist;                                // Dual.forward, dual.py:63-65
-            acc[1 + j] += dist;
-            if (g[j] > 0.0f) { g0 += nuv[j] * c.G[2 * j]; g1 += nuv[j] * c.G[2 * j + 1]; }
-        }
+        for (int j = 0; j < 6; ++j) acc[1 + j] += dist[j];
         if (grad_action) reinterpret_cast<float2*>(grad_action)[i] = make_float2(scale * g0, scale * g1);
     }
     const int lane = threadIdx.x & (RPO_WAVE - 1), wave = threadIdx.x / RPO_WAVE;

@@ -39,6 +39,29 @@ __device__ __forceinline__ void eq_ineq(const CartConsts& c, float a0, float a1,
     for (int i = 0; i < 6; ++i) g[i] = (a0 * c.G[2 * i] + a1 * c.G[2 * i + 1]) - c.d[i];   // ineq_resid :378-379
 }
 
+// One row of the Lagrangian term nu . relu(g(a)) (Dual.forward on ineq_dist, rpo_ddpg.py:312-319): its value, the
+// distances (d/d nu) and d/d action.  Shared by rpo_cartsafe_lagrangian and the fused actor-update pipeline.
+__device__ __forceinline__ void lagrangian_row(const CartConsts& c, float a0, float a1, const float (&nu)[6], float& loss,
+                                               float (&dist)[6], float& g0, float& g1) {
+    RPO_FP_STRICT
+    float h, g[6];
+    eq_ineq(c, a0, a1, h, g);
+    loss = 0.0f; g0 = 0.0f; g1 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        dist[j] = fmaxf(g[j], 0.0f);                              // ineq_dist, cartpole.py:385-387
+        loss += nu[j] * dist[j];                                  // Dual.forward, dual.py:63-65
+        if (g[j] > 0.0f) { g0 += nu[j] * c.G[2 * j]; g1 += nu[j] * c.G[2 * j + 1]; }
+    }
+}
+
+// autograd through complete_partial (cartpole.py:369-373): d/d ap of the loss given d/d action
+__device__ __forceinline__ float complete_bwd_row(const CartConsts& c, float g0, float g1) {
+    RPO_FP_STRICT
+    const float k = -(c.C_p * c.C_o_inv);
+    return c.partial == 0 ? g0 + k * g1 : g1 + k * g0;
+}
+
 __device__ __forceinline__ void reset_state(float (&s)[6], uint64_t seed, uint32_t env_id, uint32_t episode) {
     RPO_FP_STRICT
     const rpo_u4 r0 = rpo_philox(seed, env_id, episode, RPO_STREAM_RESET);

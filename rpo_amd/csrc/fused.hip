@@ -13,6 +13,7 @@
 
 #include "cartsafe_dev.h"
 #include "heads_dev.h"
+#include "mlp_bwd.h"
 #include "mlp_tile.h"
 #include "pendulum_dev.h"
 
@@ -488,6 +489,146 @@ __global__ __launch_bounds__(kFwdThreads) void pend_sac_critic_back_kernel(SacCr
     sac_td<PendRow, EIN, H>(p, lds, tf, row0, logp);
 }
 
+template <int EIN, int H>
+__global__ __launch_bounds__(kThreads) void actor_weights_kernel(BwdArgs p) {
+    gradmax_flush(p.gradmax, mlp_bwd_weights_body<EIN, H>(p));
+}
+
+// --------------------------------------------------------------------------------------- actor update, RPODDPG
+// The policy step of rpo_ddpg.py:186-205,307-324 on CartSafe in two launches + the weights pass:
+//   forward   pi(s) (pre-activations saved) -> exploration noise + clip (take_action) -> Complete -> Q(s, a) (saved) ->
+//             nu . relu(g(a)): value, d/d action, d/d nu partials; dq = -1/B
+//   backward  critic rows (d/d a of -Q) + d/d a of the Lagrangian -> autograd through Complete -> tanh box / clip ->
+//             actor rows; with a shared state embedding the critic's dx0 is added to the actor's, so that ONE
+//             first-layer reduction yields the embedding's gradient; workgroup 0 folds the Lagrangian partials.
+// == rpo_mlp_forward x 2, rpo_philox_normal, rpo_cartsafe_act_project, rpo_cartsafe_lagrangian, a fill, rpo_mlp_backward
+//    rows x 2 (+ the critic's first-layer weights pass), an add, rpo_cartsafe_complete_bwd, rpo_tanh_box_bwd.
+struct ActorFwdArgs {
+    Mlp actor, critic;
+    float scale, base, box_lo, box_hi, eps_start, eps_end, eps_decay;
+    const float* batch;           // [B, 24] gathered rows (state = columns 0..5)
+    int B;
+    const float* noise_in;        // [B] or NULL (tests): N(0,1) draws of take_action
+    uint64_t seed;
+    uint32_t noise_id_base, noise_salt;
+    const long long* ctrl;
+    const float* nu;              // [6]
+    float* ap_det; float* noise_out; float* actions; float* q_out; float* dq_out; float* g_act;
+    float* partial;               // [gridDim.x, 8]: sum nu.dist, sum dist_0..5, sum q
+    float* ax0; float* ah1; float* cx0; float* ch1;
+};
+
+template <int EIN, int H>
+__global__ __launch_bounds__(kFwdThreads) void cart_ddpg_actor_forward_kernel(ActorFwdArgs p, CartConsts c) {
+    __shared__ TileLds<EIN> lds;
+    const int row0 = blockIdx.x * kRows, tid = threadIdx.x, B = p.B;
+    const long long t = p.ctrl[RPO_CTRL_T];
+    if (tid < kRows * 6) {
+        const int r = tid / 6, i = tid - r * 6;
+        lds.in_s[r * kInS + i] = row0 + r < B ? p.batch[(size_t)(row0 + r) * RPO_CART_ROW + i] : 0.0f;
+    }
+    mlp_tile_forward<EIN, H>(p.actor, lds, row0, B, p.ax0, p.ah1, 1, p.scale, p.base);
+    float vals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float inv_b = 1.0f / (float)B;
+    const bool live = tid < kRows && row0 + tid < B;
+    if (tid < kRows) {
+        float a0 = 0.0f, a1 = 0.0f;
+        if (live) {
+            const int i = row0 + tid;
+            const float eps_t = fmaxf(p.eps_end, p.eps_start - p.eps_decay * (float)t);
+            const float ap_det = lds.out[tid * 2];
+            float e;
+            if (p.noise_in) {
+                e = p.noise_in[i];
+            } else {
+                const rpo_u4 u = rpo_philox(p.seed, p.noise_id_base + (uint32_t)i, (uint32_t)t + p.noise_salt, RPO_STREAM_POLICY,
+                                            (uint32_t)p.ctrl[RPO_CTRL_UPDATES]);
+                e = rpo_normal(u.x, u.y);
+            }
+            p.ap_det[i] = ap_det;
+            p.noise_out[i] = e;
+            ActArgs a{};
+            a.noise_mode = RPO_NOISE_EXPLICIT;                  // ap = clip(ap_det + eps_t * e): ddpg_pa.py:108-110
+            a.noise = p.noise_out;
+            a.box_lo = p.box_lo; a.box_hi = p.box_hi; a.max_steps = 0;
+            int k;
+            const float2 act = cart_explore_project(a, c, i, ap_det, eps_t, t, k);
+            a0 = act.x; a1 = act.y;
+            reinterpret_cast<float2*>(p.actions)[i] = act;
+            float nu[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) nu[j] = p.nu[j];
+            float dist[6], g0, g1;
+            rpo_cart_dev::lagrangian_row(c, a0, a1, nu, vals[0], dist, g0, g1);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) vals[1 + j] = dist[j];
+            reinterpret_cast<float2*>(p.g_act)[i] = make_float2(inv_b * g0, inv_b * g1);
+            p.dq_out[i] = -inv_b;                               // d mean(-Q) / dQ
+        }
+        lds.in_a[tid * kInA] = a0;
+        lds.in_a[tid * kInA + 1] = a1;
+    }
+    mlp_tile_forward<EIN, H>(p.critic, lds, row0, B, p.cx0, p.ch1, 0, 1.0f, 0.0f);
+    if (live) {
+        vals[7] = lds.out[tid * 2];
+        p.q_out[row0 + tid] = vals[7];
+    }
+    if (tid < 64) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float r = rpo_wave_sum(vals[k]);
+            if (tid == 0) p.partial[blockIdx.x * 8 + k] = r;
+        }
+    }
+}
+
+struct ActorBwdArgs {
+    BwdArgs critic, actor;
+    const float* g_act; const float* ap_det; const float* noise;
+    float eps_start, eps_end, eps_decay, box_lo, box_hi, scale, base;
+    const long long* ctrl;
+    float* dout;                  // [B] scratch: d loss / d (actor output)
+    const float* partial; int n_parts;
+    float* lag_out;               // [2]: mean Lagrangian term, mean Q
+    float* nu_grad;               // [6] accumulated
+    int shared_embedding;
+};
+
+template <int EIN, int H>
+__global__ __launch_bounds__(kThreads) void cart_ddpg_actor_backward_kernel(ActorBwdArgs p, CartConsts c) {
+    const int row0 = blockIdx.x * kRows, tid = threadIdx.x, B = p.critic.n;
+    mlp_bwd_rows_body<EIN, H>(p.critic);                        // dh, dx0 of the critic and da = d(-Q)/d action
+    __syncthreads();
+    if (tid < kRows && row0 + tid < B) {
+        const int i = row0 + tid;
+        const float t = (float)p.ctrl[RPO_CTRL_T];
+        const float eps_t = fmaxf(p.eps_end, p.eps_start - p.eps_decay * t);
+        const float2 d = reinterpret_cast<const float2*>(p.critic.da)[i];
+        const float2 g = reinterpret_cast<const float2*>(p.g_act)[i];
+        const float da0 = d.x + g.x, da1 = d.y + g.y;
+        reinterpret_cast<float2*>(p.critic.da)[i] = make_float2(da0, da1);
+        const float dap = rpo_cart_dev::complete_bwd_row(c, da0, da1);
+        p.dout[i] = rpo_head_dev::tanh_box_bwd_row(dap, p.ap_det[i], p.noise[i], 1, eps_t, p.box_lo, p.box_hi, p.scale, p.base);
+    }
+    __syncthreads();
+    mlp_bwd_rows_body<EIN, H>(p.actor);                         // reads p.actor.dout == p.dout
+    if (p.shared_embedding) {                                   // one first-layer reduction for the shared embedding
+        __syncthreads();
+        for (int idx = tid; idx < kRows * EIN; idx += kThreads) {
+            const int r = idx / EIN, e = idx - r * EIN;
+            if (row0 + r < B) p.actor.dx0[(size_t)(row0 + r) * EIN + e] += p.critic.dx0[(size_t)(row0 + r) * EIN + e];
+        }
+    }
+    if (blockIdx.x == 0 && tid < 8) {                           // Lagrangian value / multiplier gradient, fixed order
+        float sacc = 0.0f;
+        for (int g = 0; g < p.n_parts; ++g) sacc += p.partial[g * 8 + tid];
+        const float inv_b = 1.0f / (float)B;
+        if (tid == 0) p.lag_out[0] = inv_b * sacc;
+        else if (tid == 7) p.lag_out[1] = inv_b * sacc;
+        else p.nu_grad[tid - 1] += inv_b * sacc;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -692,6 +833,83 @@ int rpo_pendulum_sac_critic_back(const rpo_mlp* critic_target1_host, const rpo_m
     } else {
         hipLaunchKernelGGL((pend_sac_critic_back_kernel<256, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
     }
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_cartsafe_ddpg_actor_forward(const rpo_mlp* actor_host, const rpo_mlp* critic_host, float scale, float base,
+                                    float box_lo, float box_hi, float eps_start, float eps_end, float eps_decay,
+                                    const float* batch, int batch_size, const float* noise_in, unsigned long long seed,
+                                    unsigned noise_id_base, unsigned noise_salt, const long long* ctrl, const float* nu,
+                                    const float* consts_host, int partial, float* ap_det, float* noise_out,
+                                    float* actions, float* q_out, float* dq_out, float* g_act, float* partial_out,
+                                    float* actor_x0, float* actor_h1, float* critic_x0, float* critic_h1, void* stream) {
+    if (!actor_host || !critic_host) return RPO_ERR_NULL;
+    if (batch_size <= 0) return RPO_ERR_ARG;
+    if (!batch || !ctrl || !nu || !ap_det || !noise_out || !actions || !q_out || !dq_out || !g_act || !partial_out ||
+        !actor_x0 || !actor_h1 || !critic_x0 || !critic_h1)
+        return RPO_ERR_NULL;
+    ActorFwdArgs a{};
+    a.actor = to_dev(actor_host); a.critic = to_dev(critic_host);
+    if (int e = check_actor(a.actor, 6, 0)) return e;
+    if (a.actor.E != 128 || a.critic.S != 6 || a.critic.A != 2 || a.critic.cat || a.critic.H != 256 || a.critic.E != 128 ||
+        a.critic.n_out != 1 || a.critic.hd > 1)
+        return RPO_ERR_ARG;
+    CartConsts c;
+    if (int e = load_consts(c, consts_host, partial)) return e;
+    a.scale = scale; a.base = base; a.box_lo = box_lo; a.box_hi = box_hi; a.eps_start = eps_start; a.eps_end = eps_end;
+    a.eps_decay = eps_decay; a.batch = batch; a.B = batch_size; a.noise_in = noise_in; a.seed = (uint64_t)seed;
+    a.noise_id_base = (uint32_t)noise_id_base; a.noise_salt = (uint32_t)noise_salt; a.ctrl = ctrl; a.nu = nu;
+    a.ap_det = ap_det; a.noise_out = noise_out; a.actions = actions; a.q_out = q_out; a.dq_out = dq_out; a.g_act = g_act;
+    a.partial = partial_out; a.ax0 = actor_x0; a.ah1 = actor_h1; a.cx0 = critic_x0; a.ch1 = critic_h1;
+    hipLaunchKernelGGL((cart_ddpg_actor_forward_kernel<128, 256>), dim3((batch_size + kRows - 1) / kRows), dim3(kFwdThreads),
+                       0, (hipStream_t)stream, a, c);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_cartsafe_ddpg_actor_backward(const rpo_mlp* actor_host, const rpo_mlp_grad* actor_grad_host,
+                                     const rpo_mlp* critic_host, int shared_embedding, const float* batch,
+                                     int batch_size, const float* actions, const float* g_act, const float* ap_det,
+                                     const float* noise, const float* dq, float eps_start, float eps_end,
+                                     float eps_decay, float box_lo, float box_hi, float scale, float base,
+                                     const long long* ctrl, const float* consts_host, int partial,
+                                     const float* actor_x0, const float* actor_h1, const float* critic_x0,
+                                     const float* critic_h1, float* actor_dh, float* actor_dx0, float* critic_dh,
+                                     float* critic_dx0, float* da, float* dout, const float* partial_in, float* lag_out,
+                                     float* nu_grad, float* gradmax, void* stream) {
+    if (!actor_host || !actor_grad_host || !critic_host) return RPO_ERR_NULL;
+    if (batch_size <= 0) return RPO_ERR_ARG;
+    if (!batch || !actions || !g_act || !ap_det || !noise || !dq || !ctrl || !da || !dout || !partial_in || !lag_out || !nu_grad)
+        return RPO_ERR_NULL;
+    ActorBwdArgs p{};
+    Mlp actor = to_dev(actor_host), critic = to_dev(critic_host);
+    if (int e = check_actor(actor, 6, 0)) return e;
+    if (actor.E != 128 || critic.S != 6 || critic.A != 2 || critic.cat || critic.H != 256 || critic.E != 128 || critic.n_out != 1)
+        return RPO_ERR_ARG;
+    if (!actor_x0 || !actor_h1 || !critic_x0 || !critic_h1 || !actor_dh || !actor_dx0 || !critic_dh || !critic_dx0)
+        return RPO_ERR_NULL;
+    CartConsts c;
+    if (int e = load_consts(c, consts_host, partial)) return e;
+    MlpGrad none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    MlpGrad ag{actor_grad_host->Ws, actor_grad_host->bs, actor_grad_host->Wa, actor_grad_host->ba, actor_grad_host->W0,
+               actor_grad_host->b0, actor_grad_host->W1, actor_grad_host->b1, actor_grad_host->W1b, actor_grad_host->b1b};
+    if (!ag.Ws || !ag.bs || !ag.W0 || !ag.b0 || !ag.W1 || !ag.b1) return RPO_ERR_NULL;
+    // the critic only propagates (d/d action, and dx0 for a shared embedding): no parameter gradients of its own
+    p.critic = BwdArgs{critic, none, batch_size, batch, RPO_CART_ROW, actions, 2, critic_x0, critic_h1, dq, critic_dh,
+                       critic_dx0, da, 0, 0, nullptr};
+    p.actor = BwdArgs{actor, ag, batch_size, batch, RPO_CART_ROW, nullptr, 0, actor_x0, actor_h1, dout, actor_dh, actor_dx0,
+                      nullptr, 1, 0, gradmax};
+    p.g_act = g_act; p.ap_det = ap_det; p.noise = noise; p.eps_start = eps_start; p.eps_end = eps_end;
+    p.eps_decay = eps_decay; p.box_lo = box_lo; p.box_hi = box_hi; p.scale = scale; p.base = base; p.ctrl = ctrl;
+    p.dout = dout; p.partial = partial_in; p.n_parts = (batch_size + kRows - 1) / kRows; p.lag_out = lag_out;
+    p.nu_grad = nu_grad; p.shared_embedding = shared_embedding;
+    hipLaunchKernelGGL((cart_ddpg_actor_backward_kernel<128, 256>), dim3((batch_size + kRows - 1) / kRows), dim3(kThreads), 0,
+                       (hipStream_t)stream, p, c);
+    RPO_LAUNCH_CHECK();
+    const int fl_outputs = actor.E * (actor.S + 1);
+    const int grid_w = (actor.H / 16) * (128 / 64) + actor.H / 64 + (fl_outputs + 63) / 64;
+    hipLaunchKernelGGL((actor_weights_kernel<128, 256>), dim3(grid_w), dim3(kThreads), 0, (hipStream_t)stream, p.actor);
     RPO_LAUNCH_CHECK();
     return 0;
 }

@@ -19,4 +19,15 @@ __device__ __forceinline__ float gauss_head_row(float raw_mean, float raw_ls, fl
     return fminf(fmaxf(a, lo), hi);
 }
 
+// Backward of ap = clip(scale * tanh(o) + base + eps_t * noise, lo, hi) w.r.t. o (model/policy.py:30-31,
+// agent/ddpg_pa.py:108-110), expressed through ap_det = scale * tanh(o) + base; has_noise = 0: no noise, no clip.
+__device__ __forceinline__ float tanh_box_bwd_row(float dap, float ap_det, float noise, int has_noise, float eps_t, float lo,
+                                                  float hi, float scale, float base) {
+    RPO_FP_STRICT
+    const float x = has_noise ? ap_det + eps_t * noise : ap_det;
+    const float y = (ap_det - base) / scale;
+    const bool pass = !has_noise || (x >= lo && x <= hi);
+    return pass ? dap * scale * (1.0f - y * y) : 0.0f;
+}
+
 }  // namespace rpo_head_dev

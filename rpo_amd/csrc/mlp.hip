@@ -15,6 +15,7 @@
 //             (tile c, column n <-> e = 4n + c) that share the A operand;
 //   weights   dW0[j][e] = sum_b dh[b][j] x1[b][e]  both operands contiguous in their M / N index.
 #include "heads_dev.h"
+#include "mlp_bwd.h"
 #include "mlp_tile.h"
 
 namespace {
@@ -84,430 +85,8 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_forward_wide_kernel(FwdArgs p
     }
 }
 
-// ------------------------------------------------------------------------------------------------- backward, rows
-// Per row tile: dh = (dout W1) * 1[h1 > 0]  -> global (for the weights pass) and LDS; dW1 / db1 / db0 partial sums
-// (one atomic per value per workgroup); dx0 = (dh W0) * 1[x0 > 0] -> global; optionally da = dx0_a Wa.
-struct BwdArgs {
-    Mlp net;
-    MlpGrad g;
-    int n;
-    const float* s; int s_stride;
-    const float* a; int a_stride;
-    const float* x0;       // [n, Ein] saved by forward
-    const float* h1;       // [n, H]
-    const float* dout;     // [n, n_out]
-    float* dh;             // [n, H]   scratch
-    float* dx0;            // [n, Ein] scratch
-    float* da;             // [n, A] or NULL: gradient w.r.t. the action input
-    int param_grads;       // 0: only dx0 / da are needed (critic inside the actor loss, non-shared embedding)
-    int first_layer_state_only;   // 1: of the parameter gradients only dWs / dbs are accumulated (shared embedding)
-    float* gradmax;        // NULL, or where the weights pass leaves max |gradient element written| (clip_grad_norm_(inf))
-};
-
-template <int EIN, int H>
-__device__ __forceinline__ void mlp_bwd_rows_body(const BwdArgs& p) {
-    constexpr int LDH = H + 4;
-    __shared__ __attribute__((aligned(16))) float dh_s[kRows * LDH];
-    __shared__ __attribute__((aligned(16))) float red[kRows * EIN];              // dx0 of the tile (waves add into it)
-    __shared__ float dout_s[kRows * kWideOut];
-    const Mlp& net = p.net;
-    const int row0 = blockIdx.x * kRows;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool wide_head = net.hd > 1;
-    const int outs = wide_head ? net.n_out * net.hd : net.n_out;
-    if (!wide_head) {
-        if (tid < kRows * 2) {
-            const int r = tid >> 1, o = tid & 1;
-            dout_s[tid] = (o < net.n_out && row0 + r < p.n) ? p.dout[(size_t)(row0 + r) * net.n_out + o] : 0.0f;
-        }
-    } else {
-        for (int idx = tid; idx < kRows * outs; idx += kThreads) {
-            const int r = idx / outs, o = idx - r * outs;
-            dout_s[r * kWideOut + o] = (row0 + r < p.n) ? p.dout[(size_t)(row0 + r) * outs + o] : 0.0f;
-        }
-    }
-    __syncthreads();
-    // ---- dh (thread = hidden column j); the batch reductions dW1 / db0 / db1 happen in the weights pass, in a fixed
-    //      order, so that the whole backward is bitwise reproducible (no floating-point atomics anywhere)
-    for (int j = tid; j < H; j += kThreads) {
-        if (!wide_head) {
-            const float w1a = net.W1[j], w1b = net.n_out > 1 ? net.W1b[j] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < kRows; ++r) {
-                const bool live = row0 + r < p.n;
-                const float h = live ? p.h1[(size_t)(row0 + r) * H + j] : 0.0f;
-                const float d = (h > 0.0f) ? fmaf(dout_s[r * 2 + 1], w1b, dout_s[r * 2] * w1a) : 0.0f;
-                dh_s[r * LDH + j] = d;
-                if (live) p.dh[(size_t)(row0 + r) * H + j] = d;
-            }
-        } else {
-            float d[kRows];
-#pragma unroll
-            for (int r = 0; r < kRows; ++r) d[r] = 0.0f;
-            for (int o = 0; o < outs; ++o) {                       // fixed order over the outputs
-                const float wv = (o < net.hd ? net.W1 : net.W1b)[(size_t)(o < net.hd ? o : o - net.hd) * H + j];
-#pragma unroll
-                for (int r = 0; r < kRows; ++r) d[r] = fmaf(dout_s[r * kWideOut + o], wv, d[r]);
-            }
-#pragma unroll
-            for (int r = 0; r < kRows; ++r) {
-                const bool live = row0 + r < p.n;
-                const float h = live ? p.h1[(size_t)(row0 + r) * H + j] : 0.0f;
-                const float v = (h > 0.0f) ? d[r] : 0.0f;
-                dh_s[r * LDH + j] = v;
-                if (live) p.dh[(size_t)(row0 + r) * H + j] = v;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- dx0 partials (MFMA): wave w sums over hidden j in [w*H/4, (w+1)*H/4), all EIN columns
-    constexpr int NV = EIN / 64;                                   // float4 loads per k-step; 4 interleaved tiles each
-    f32x4 acc[NV][4];
-#pragma unroll
-    for (int v = 0; v < NV; ++v)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[v][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    const int li = lane & 15, lg = lane >> 4;
-    const int jw = wave * (H / 4);
-#pragma unroll 8
-    for (int ks = 0; ks < H / 16; ++ks) {
-        const int j = jw + ks * 4 + lg;
-        const float av = dh_s[li * LDH + j];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const float4 b4 = *reinterpret_cast<const float4*>(&net.W0[(size_t)j * EIN + v * 64 + li * 4]);
-            acc[v][0] = mfma4(av, b4.x, acc[v][0]);
-            acc[v][1] = mfma4(av, b4.y, acc[v][1]);
-            acc[v][2] = mfma4(av, b4.z, acc[v][2]);
-            acc[v][3] = mfma4(av, b4.w, acc[v][3]);
-        }
-    }
-    // acc[v][c][i] = partial dx0[row = 4*lg + i][e = 64v + 4*li + c]
-    for (int w = 0; w < 4; ++w) {                                  // waves add their partials in a fixed order
-        if (wave == w) {
-#pragma unroll
-            for (int v = 0; v < NV; ++v)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float4* dst = reinterpret_cast<float4*>(&red[(lg * 4 + i) * EIN + v * 64 + li * 4]);
-                    float4 o = make_float4(acc[v][0][i], acc[v][1][i], acc[v][2][i], acc[v][3][i]);
-                    if (w > 0) { const float4 c = *dst; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
-                    *dst = o;
-                }
-        }
-        __syncthreads();
-    }
-    for (int idx = tid; idx < kRows * EIN; idx += kThreads) {
-        const int r = idx / EIN, e = idx - r * EIN;
-        float v = red[idx];
-        const bool live = row0 + r < p.n;
-        const float x = live ? p.x0[(size_t)(row0 + r) * EIN + e] : 0.0f;
-        v = (x > 0.0f) ? v : 0.0f;
-        red[idx] = v;                                              // masked dx0 of this tile (for da below)
-        if (live) p.dx0[(size_t)(row0 + r) * EIN + e] = v;
-    }
-    if (p.da) {
-        __syncthreads();
-        const int eoff = net.cat ? net.E : 0;                      // action embedding columns inside x0
-        for (int idx = tid; idx < kRows * net.A; idx += kThreads) {
-            const int r = idx / net.A, i = idx - r * net.A;
-            if (row0 + r < p.n) {
-                float s = 0.0f;
-                for (int e = 0; e < net.E; ++e) s = fmaf(red[r * EIN + eoff + e], net.Wa[e * net.A + i], s);
-                p.da[(size_t)(row0 + r) * net.A + i] = s;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ backward, weights
-// Workgroups [0, H/16 * EIN/256): dW0 tiles (wave = 16 hidden rows x 64 input columns, K = batch); one more
-// workgroup accumulates the first-layer gradients dWs / dbs / dWa / dba from dx0, and the last one db0 / dW1 / db1.
-// Every output element has exactly one owner and a fixed summation order: the backward pass is bitwise reproducible.
-template <int EIN, int H>
-__device__ __forceinline__ float mlp_bwd_weights_body(const BwdArgs& p) {
-    float gmax = 0.0f;                                          // largest |gradient element| this thread wrote
-    const Mlp& net = p.net;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int GEMM_BLOCKS = (H / 16) * (EIN / 64);           // one 16 x 64 tile of dW0 per workgroup
-    if ((int)blockIdx.x < GEMM_BLOCKS) {
-        if (!p.param_grads || p.first_layer_state_only) return gmax;
-        // the 4 waves split the batch (K) and combine through LDS in a fixed order
-        __shared__ __attribute__((aligned(16))) float tile[4][16 * 64];
-        const int jt = blockIdx.x / (EIN / 64), et = blockIdx.x - jt * (EIN / 64);
-        const int li = lane & 15, lg = lane >> 4;
-        const int j = jt * 16 + li, e0 = et * 64 + li * 4;
-        f32x4 acc[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        const int nk = (p.n + 3) / 4;                              // k-steps of 4 samples
-        const int ks_lo = (nk * wave) / 4, ks_hi = (nk * (wave + 1)) / 4;
-        const int last = p.n - 1;
-        int ks = ks_lo;
-        for (; ks + 4 <= ks_hi; ks += 4) {                         // 4 k-steps of loads in flight before their MFMAs
-            float av[4];
-            float4 bv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int b = (ks + u) * 4 + lg;
-                const int bc = b < last ? b : last;
-                av[u] = p.dh[(size_t)bc * H + j];
-                bv[u] = *reinterpret_cast<const float4*>(&p.x0[(size_t)bc * EIN + e0]);
-                if (b > last) av[u] = 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc[0] = mfma4(av[u], fmaxf(bv[u].x, 0.0f), acc[0]);
-                acc[1] = mfma4(av[u], fmaxf(bv[u].y, 0.0f), acc[1]);
-                acc[2] = mfma4(av[u], fmaxf(bv[u].z, 0.0f), acc[2]);
-                acc[3] = mfma4(av[u], fmaxf(bv[u].w, 0.0f), acc[3]);
-            }
-        }
-        for (; ks < ks_hi; ++ks) {
-            const int b = ks * 4 + lg;
-            const int bc = b < last ? b : last;
-            float av = p.dh[(size_t)bc * H + j];
-            const float4 b4 = *reinterpret_cast<const float4*>(&p.x0[(size_t)bc * EIN + e0]);
-            if (b > last) av = 0.0f;
-            acc[0] = mfma4(av, fmaxf(b4.x, 0.0f), acc[0]);
-            acc[1] = mfma4(av, fmaxf(b4.y, 0.0f), acc[1]);
-            acc[2] = mfma4(av, fmaxf(b4.z, 0.0f), acc[2]);
-            acc[3] = mfma4(av, fmaxf(b4.w, 0.0f), acc[3]);
-        }
-        // acc[c][i] = partial dW0[j = 16 jt + 4 lg + i][e = 64 et + 4 li + c]
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(&tile[wave][(lg * 4 + i) * 64 + li * 4]) =
-                make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
-        __syncthreads();
-        {
-            const int r = tid >> 4, c4 = (tid & 15) * 4;           // 256 threads x float4 = the 16 x 64 tile
-            const float4 t0 = *reinterpret_cast<const float4*>(&tile[0][r * 64 + c4]);
-            const float4 t1 = *reinterpret_cast<const float4*>(&tile[1][r * 64 + c4]);
-            const float4 t2 = *reinterpret_cast<const float4*>(&tile[2][r * 64 + c4]);
-            const float4 t3 = *reinterpret_cast<const float4*>(&tile[3][r * 64 + c4]);
-            float4* dst = reinterpret_cast<float4*>(&p.g.W0[(size_t)(jt * 16 + r) * EIN + et * 64 + c4]);
-            float4 cur = *dst;
-            cur.x += ((t0.x + t1.x) + t2.x) + t3.x;
-            cur.y += ((t0.y + t1.y) + t2.y) + t3.y;
-            cur.z += ((t0.z + t1.z) + t2.z) + t3.z;
-            cur.w += ((t0.w + t1.w) + t2.w) + t3.w;
-            *dst = cur;
-            gmax = fmaxf(fmaxf(fabsf(cur.x), fabsf(cur.y)), fmaxf(fabsf(cur.z), fabsf(cur.w)));
-        }
-        return gmax;
-    }
-    if (!p.param_grads) return gmax;
-    // ---- batch reductions with one owner per output: 64 outputs per workgroup, the batch split over the 4 waves and
-    //      combined through LDS in a fixed order (bitwise reproducible)
-    __shared__ float partial[4][3][64];
-    const int o = tid & 63, part = tid >> 6;
-    const int b_lo = (int)(((long long)p.n * part) / 4), b_hi = (int)(((long long)p.n * (part + 1)) / 4);
-    const int rb = (int)blockIdx.x - GEMM_BLOCKS;
-    constexpr int HV_BLOCKS = H / 64;
-    const int hv_blocks = net.hd > 1 ? H / 16 : HV_BLOCKS;
-    if (rb < hv_blocks && net.hd > 1) {
-        // multi-output head: db0[j], dW1_k[o][j] = sum_b dout[b][k*hd + o] relu(h1[b][j]), db1_k[o] = sum_b dout[b][k*hd + o].
-        // 16 hidden columns per workgroup, the batch split 16 ways and combined through LDS in a fixed order (one owner per
-        // output): H/16 workgroups x 16 batch slices keep the exposed load latency to n/16 rows per thread.
-        if (p.first_layer_state_only) return gmax;
-        __shared__ float wide[16][kWideOut + 1][16];
-        const int outs = net.n_out * net.hd;
-        const int jj = tid & 15, slice = tid >> 4;
-        const int j = rb * 16 + jj;
-        const int lo = (int)(((long long)p.n * slice) / 16), hi = (int)(((long long)p.n * (slice + 1)) / 16);
-        float gb0 = 0.0f, gw[kWideOut];
-#pragma unroll
-        for (int q = 0; q < kWideOut; ++q) gw[q] = 0.0f;
-        int bb = lo;
-        for (; bb + 4 <= hi; bb += 4) {
-            float d[4], h[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                d[u] = p.dh[(size_t)(bb + u) * H + j];
-                h[u] = fmaxf(p.h1[(size_t)(bb + u) * H + j], 0.0f);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                gb0 += d[u];
-                const float* drow = p.dout + (size_t)(bb + u) * outs;
-#pragma unroll
-                for (int q = 0; q < kWideOut; ++q)
-                    if (q < outs) gw[q] = fmaf(drow[q], h[u], gw[q]);
-            }
-        }
-        for (; bb < hi; ++bb) {
-            gb0 += p.dh[(size_t)bb * H + j];
-            const float hr = fmaxf(p.h1[(size_t)bb * H + j], 0.0f);
-#pragma unroll
-            for (int q = 0; q < kWideOut; ++q)
-                if (q < outs) gw[q] = fmaf(p.dout[(size_t)bb * outs + q], hr, gw[q]);
-        }
-        wide[slice][kWideOut][jj] = gb0;
-#pragma unroll
-        for (int q = 0; q < kWideOut; ++q) wide[slice][q][jj] = gw[q];
-        __syncthreads();
-        for (int idx = tid; idx < (outs + 1) * 16; idx += kThreads) {
-            const int q = idx >> 4, c = idx & 15;                  // q == outs: the db0 column sums
-            const int src = q == outs ? kWideOut : q;
-            float tot = 0.0f;
-            for (int sl = 0; sl < 16; ++sl) tot += wide[sl][src][c];
-            float* dst = q == outs ? &p.g.b0[rb * 16 + c]
-                                   : (q < net.hd ? &p.g.W1[(size_t)q * H + rb * 16 + c] : &p.g.W1b[(size_t)(q - net.hd) * H + rb * 16 + c]);
-            const float nv = *dst + tot;
-            *dst = nv;
-            gmax = fmaxf(gmax, fabsf(nv));
-        }
-        if (rb == 0) {
-            // db1: 8 batch slices x 32 outputs, combined in a fixed order
-            __syncthreads();
-            float* red = &wide[0][0][0];
-            const int q = tid & 31, sl8 = tid >> 5;
-            const int l8 = (int)(((long long)p.n * sl8) / 8), h8 = (int)(((long long)p.n * (sl8 + 1)) / 8);
-            float s0 = 0.0f;
-            if (q < outs)
-                for (int b2 = l8; b2 < h8; ++b2) s0 += p.dout[(size_t)b2 * outs + q];
-            red[sl8 * 32 + q] = s0;
-            __syncthreads();
-            if (tid < outs) {
-                float tot = 0.0f;
-                for (int sl = 0; sl < 8; ++sl) tot += red[sl * 32 + tid];
-                float* dst = tid < net.hd ? &p.g.b1[tid] : &p.g.b1b[tid - net.hd];
-                const float nv = *dst + tot;
-                *dst = nv;
-                gmax = fmaxf(gmax, fabsf(nv));
-            }
-        }
-        return gmax;
-    }
-    if (rb < HV_BLOCKS) {
-        // hidden-layer vectors: db0[j] = sum_b dh[b][j]; dW1_k[j] = sum_b dout[b][k] relu(h1[b][j]); db1_k = sum_b dout[b][k]
-        if (p.first_layer_state_only) return gmax;
-        const int j = rb * 64 + o;
-        float gb0 = 0.0f, gw1a = 0.0f, gw1b = 0.0f;
-        int bb = b_lo;
-        for (; bb + 8 <= b_hi; bb += 8) {
-            float d[8], h[8], oa[8], ob[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                d[u] = p.dh[(size_t)(bb + u) * H + j];
-                h[u] = p.h1[(size_t)(bb + u) * H + j];
-                oa[u] = p.dout[(size_t)(bb + u) * net.n_out];
-                ob[u] = net.n_out > 1 ? p.dout[(size_t)(bb + u) * net.n_out + 1] : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                gb0 += d[u];
-                const float hr = fmaxf(h[u], 0.0f);
-                gw1a = fmaf(oa[u], hr, gw1a);
-                gw1b = fmaf(ob[u], hr, gw1b);
-            }
-        }
-        for (; bb < b_hi; ++bb) {
-            gb0 += p.dh[(size_t)bb * H + j];
-            const float hr = fmaxf(p.h1[(size_t)bb * H + j], 0.0f);
-            gw1a = fmaf(p.dout[(size_t)bb * net.n_out], hr, gw1a);
-            if (net.n_out > 1) gw1b = fmaf(p.dout[(size_t)bb * net.n_out + 1], hr, gw1b);
-        }
-        partial[part][0][o] = gb0; partial[part][1][o] = gw1a; partial[part][2][o] = gw1b;
-        __syncthreads();
-        if (part == 0) {
-            const float nb0 = p.g.b0[j] + (((partial[0][0][o] + partial[1][0][o]) + partial[2][0][o]) + partial[3][0][o]);
-            const float nw1 = p.g.W1[j] + (((partial[0][1][o] + partial[1][1][o]) + partial[2][1][o]) + partial[3][1][o]);
-            p.g.b0[j] = nb0;
-            p.g.W1[j] = nw1;
-            gmax = fmaxf(fabsf(nb0), fabsf(nw1));
-            if (net.n_out > 1) {
-                const float nw1b = p.g.W1b[j] + (((partial[0][2][o] + partial[1][2][o]) + partial[2][2][o]) + partial[3][2][o]);
-                p.g.W1b[j] = nw1b;
-                gmax = fmaxf(gmax, fabsf(nw1b));
-            }
-        }
-        if (rb == 0) {
-            // db1_k = sum_b dout[b][k]: strided per-thread partials, fixed-pattern wave reduction, 4 wave partials added
-            // in order (a single-thread loop over the batch costs ~18 us of serialised load latency)
-            __syncthreads();                                   // `partial` is reused below
-            float s0 = 0.0f, s1 = 0.0f;
-            for (int b2 = tid; b2 < p.n; b2 += kThreads) {
-                s0 += p.dout[(size_t)b2 * net.n_out];
-                if (net.n_out > 1) s1 += p.dout[(size_t)b2 * net.n_out + 1];
-            }
-            s0 = rpo_wave_sum(s0);
-            s1 = rpo_wave_sum(s1);
-            if (o == 0) { partial[part][0][0] = s0; partial[part][1][0] = s1; }
-            __syncthreads();
-            if (tid == 0) {
-                const float nb1 = p.g.b1[0] + (((partial[0][0][0] + partial[1][0][0]) + partial[2][0][0]) + partial[3][0][0]);
-                p.g.b1[0] = nb1;
-                gmax = fmaxf(gmax, fabsf(nb1));
-                if (net.n_out > 1) {
-                    const float nb1b = p.g.b1b[0] + (((partial[0][1][0] + partial[1][1][0]) + partial[2][1][0]) + partial[3][1][0]);
-                    p.g.b1b[0] = nb1b;
-                    gmax = fmaxf(gmax, fabsf(nb1b));
-                }
-            }
-        }
-        return gmax;
-    }
-    // first layer: output list idx = q * E + e (e fastest: coalesced dx0 reads); q < wS: state weights / bias,
-    // q >= wS: action weights / bias.  Columns of x0: [0, E) <- state (+ action when added); [E, 2E) <- action (cat).
-    const int wS = net.S + 1, wA = (net.A > 0 && !p.first_layer_state_only) ? net.A + 1 : 0;   // +1: the bias
-    const int idx = (rb - hv_blocks) * 64 + o;
-    const bool valid = idx < net.E * (wS + wA);
-    float acc = 0.0f;
-    int e = 0, i = 0, width = 0;
-    bool is_a = false;
-    if (valid) {
-        e = idx % net.E;
-        const int q = idx / net.E;
-        is_a = q >= wS;
-        i = is_a ? q - wS : q;
-        width = is_a ? net.A : net.S;
-        const int col = (is_a && net.cat) ? net.E + e : e;
-        const float* in = is_a ? p.a : p.s;
-        const int stride = is_a ? p.a_stride : p.s_stride;
-        const bool is_w = i < width;
-        int bb = b_lo;
-        for (; bb + 8 <= b_hi; bb += 8) {
-            float d[8], x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                d[u] = p.dx0[(size_t)(bb + u) * EIN + col];
-                x[u] = is_w ? in[(size_t)(bb + u) * stride + i] : 1.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc = fmaf(d[u], x[u], acc);
-        }
-        for (; bb < b_hi; ++bb) acc = fmaf(p.dx0[(size_t)bb * EIN + col], is_w ? in[(size_t)bb * stride + i] : 1.0f, acc);
-    }
-    partial[part][0][o] = acc;
-    __syncthreads();
-    if (part == 0 && valid) {
-        const float tot = ((partial[0][0][o] + partial[1][0][o]) + partial[2][0][o]) + partial[3][0][o];
-        float* dst = (i < width) ? (is_a ? &p.g.Wa[e * net.A + i] : &p.g.Ws[e * net.S + i]) : (is_a ? &p.g.ba[e] : &p.g.bs[e]);
-        const float nv = *dst + tot;
-        *dst = nv;
-        gmax = fabsf(nv);
-    }
-    return gmax;
-}
-
 template <int EIN, int H>
 __global__ __launch_bounds__(kThreads) void mlp_bwd_rows_kernel(BwdArgs p) { mlp_bwd_rows_body<EIN, H>(p); }
-// max over the workgroup of the gradient magnitudes its threads wrote -> one atomic max (order independent: exact)
-__device__ __forceinline__ void gradmax_flush(float* gradmax, float v) {
-    __shared__ float red[kThreads / 64];
-    if (gradmax == nullptr) return;
-    v = rpo_wave_max(v);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float m = red[0];
-        for (int w = 1; w < kThreads / 64; ++w) m = fmaxf(m, red[w]);
-        if (m > 0.0f) rpo_atomic_max_nonneg(gradmax, m);
-    }
-}
 template <int EIN, int H>
 __global__ __launch_bounds__(kThreads) void mlp_bwd_weights_kernel(BwdArgs p) {
     gradmax_flush(p.gradmax, mlp_bwd_weights_body<EIN, H>(p));
@@ -537,11 +116,8 @@ __global__ __launch_bounds__(RPO_BLOCK) void tanh_box_bwd_kernel(int n, const fl
     const float t = ctrl ? (float)ctrl[RPO_CTRL_T] : 0.0f;
     const float eps_t = fmaxf(eps_end, eps_start - eps_decay * t);
     for (int i = blockIdx.x * RPO_BLOCK + threadIdx.x; i < n; i += gridDim.x * RPO_BLOCK) {
-        const float a = ap_det[i];
-        const float x = noise ? a + eps_t * noise[i] : a;
-        const float y = (a - base) / scale;
-        const bool pass = !noise || (x >= lo && x <= hi);
-        dout[i] = pass ? dap[i] * scale * (1.0f - y * y) : 0.0f;
+        dout[i] = rpo_head_dev::tanh_box_bwd_row(dap[i], ap_det[i], noise ? noise[i] : 0.0f, noise != nullptr, eps_t, lo, hi,
+                                                 scale, base);
     }
 }
 
