@@ -9,6 +9,19 @@ from .rpo_ddpg import _LazySum
 from .trainer import _SALT_ACTOR, _SALT_CRITIC, RPOTrainerBase, _LagrangianFn, _TDHuberFn, _env_int
 
 
+class _LazySumPair(object):
+    """mean Lagrangian term + mean(alpha log pi - min Q) from the two words the actor-backward pipeline leaves behind."""
+
+    def __init__(self, pair):
+        self.pair = pair
+
+    def __float__(self):
+        return float(self.pair[0] + self.pair[1])
+
+    def detach(self):
+        return self.pair[0] + self.pair[1]
+
+
 class RPOSAC(RPOTrainerBase):
     sac = True
 
@@ -149,9 +162,51 @@ class RPOSAC(RPOTrainerBase):
         self._gradmax_ready = f.backward_pair("critic1", "critic2", state, action, dq1, dq2, gradmax=self._critic_gradmax())
         self.last_losses["critic"] = loss[0]
 
+    @property
+    def _actor_pipeline(self):
+        d = self.fused.descs if self.fused is not None else {}
+        return (hasattr(self.backend, "sac_actor_forward") and "actor" in d and "critic1" in d and d["actor"].E == 128
+                and d["critic1"].E == 128 and not d["critic1"].cat and self._box_affine is not None
+                and self.kernels.partial_dim == 1 and self.kernels.action_dim == 2
+                and not self.automatic_entropy_tuning and _env_int("RPO_FUSED_ACTOR", 1))
+
+    def _actor_update_pipeline(self, cols):
+        """The policy step in two launches + the actor's weights pass (fused.hip)."""
+        f, ag, B, k = self.fused, self.agent, self.batch_size, self.kernels
+        da_, d1, d2 = f.descs["actor"], f.descs["critic1"], f.descs["critic2"]
+        scale, base = self._box_affine
+        b = f.buf
+        parts = b("actor.parts", (B + 15) // 16, 8)
+        raw, noise, logp = b("pi.raw", B, 2), b("pi.noise", B), b("pi.logp", B)
+        actions, g_act = b("act_pi", B, 2), b("g_act", B, 2)
+        dq1, dq2 = b("dq1_pi", B, 1), b("dq2_pi", B, 1)
+        saved = (b("actor.x0", B, da_.ein), b("actor.h1", B, da_.H), b("critic1.x0", B, d1.ein), b("critic1.h1", B, d1.H),
+                 b("critic2.x0", B, d2.ein), b("critic2.h1", B, d2.H))
+        noise_in = self._draw(self._noise_b, self.dist.rank * B, _SALT_ACTOR).view(-1) if self._idx_inject is not None else None
+        alpha = float(ag.alpha)
+        self.backend.sac_actor_forward(k, da_, d1, d2, scale, base, self._box_lo, self._box_hi, alpha, self._batch, noise_in,
+                                       self.seed, self.dist.rank * B, _SALT_ACTOR, self.vec.ctrl, ag.nju.weight.view(-1),
+                                       raw, noise, logp, actions, dq1, dq2, g_act, parts, saved)
+        self._zero_grads()
+        opt = ag.actor_optim
+        fuse_max = self._self_cleaning and not self.dist.on and opt.clip_thres and opt.clip_thres != float("inf")
+        scratch = (b("actor.dh", B, da_.H), b("actor.dx0", B, da_.ein), b("critic1.dh", B, d1.H), b("critic1.dx0", B, d1.ein),
+                   b("critic2.dh", B, d2.H), b("critic2.dx0", B, d2.ein))
+        lag = b("actor.lag", 2)
+        self.backend.sac_actor_backward(k, da_, d1, d2, ag.flat.sizes[1] > 0, self._batch, actions, g_act, raw, noise, dq1,
+                                        dq2, alpha / B, self._box_lo, self._box_hi, scale, base, saved, scratch,
+                                        b("da1", B, 2), b("da2", B, 2), b("draw", B, 2), parts, lag,
+                                        ag.nju.weight.grad.view(-1), opt.gradmax if fuse_max else None)
+        self._actor_gradmax_ready = bool(fuse_max)
+        loss = _LazySumPair(lag)
+        self.last_losses["actor"] = loss
+        return loss, logp.view(-1, 1)
+
     def _actor_update(self, cols):
         if self.fused is None:
             return super()._actor_update(cols)
+        if self._actor_pipeline:
+            return self._actor_update_pipeline(cols)
         f, ag, B, k = self.fused, self.agent, self.batch_size, self.kernels
         state = cols[0]
         eps = self._draw(self._noise_b, self.dist.rank * B, _SALT_ACTOR)
@@ -222,7 +277,8 @@ class RPOSAC(RPOTrainerBase):
 
     def _actor_step(self, actor_out):
         ag = self.agent
-        ag.actor_optim.step()
+        ag.actor_optim.step(gradmax_ready=getattr(self, "_actor_gradmax_ready", False))
+        self._actor_gradmax_ready = False
         if not self.fixed:
             ag.nju_optim.step()
         if self.automatic_entropy_tuning:

@@ -629,6 +629,183 @@ __global__ __launch_bounds__(kThreads) void cart_ddpg_actor_backward_kernel(Acto
     }
 }
 
+// ---------------------------------------------------------------------------------------- actor update, RPOSAC
+// rpo_sac.py:191-219,321-339 on either env as forward + backward pipelines (the actor loss only completes the action, it
+// does not project it, so nothing couples the rows of a batch):
+//   forward   pi(s): mean / log-std heads (saved) -> rsample + box clip + log pi -> Complete -> Q1, Q2 (s, a) (saved) ->
+//             nu . relu(g(a)); d(-min(Q1, Q2))/dQ_k with ties split like torch.min's backward
+//   backward  both critics' rows -> d/d a -> Complete -> Gaussian head (incl. the alpha log pi term) -> actor rows
+struct CartActEnv {
+    typedef CartConsts Consts;
+    static constexpr int ROW = RPO_CART_ROW, S = 6, NI = 6;
+    __device__ static __forceinline__ float2 complete(const Consts& c, const float* obs, int i, float ap, long long t) {
+        ActArgs a{};
+        a.noise_mode = RPO_NOISE_NONE; a.max_steps = 0;
+        int k;
+        return cart_explore_project(a, c, i, ap, 0.0f, t, k);
+    }
+    __device__ static __forceinline__ float lagr(const Consts& c, float a0, float a1, const float* nu_p, float scale,
+                                                 float (&dist)[6], float2& g) {
+        float nu[6], loss, g0, g1;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) nu[j] = nu_p[j];
+        rpo_cart_dev::lagrangian_row(c, a0, a1, nu, loss, dist, g0, g1);
+        g = make_float2(scale * g0, scale * g1);
+        return loss;
+    }
+    __device__ static __forceinline__ float complete_bwd(const Consts& c, const float* obs, float g0, float g1) {
+        return rpo_cart_dev::complete_bwd_row(c, g0, g1);
+    }
+};
+
+struct PendActEnv {
+    struct Consts { int unused; };
+    static constexpr int ROW = RPO_PEND_ROW, S = 5, NI = 1;
+    __device__ static __forceinline__ float2 complete(const Consts&, const float* obs, int i, float ap, long long t) {
+        rpo_pend_dev::ActArgs a{};
+        a.noise_mode = RPO_NOISE_NONE; a.max_steps = 0;
+        int k;
+        return rpo_pend_dev::pend_explore_project(a, obs, i, ap, 0.0f, t, k);
+    }
+    __device__ static __forceinline__ float lagr(const Consts&, float a0, float a1, const float* nu_p, float scale,
+                                                 float (&dist)[6], float2& g) {
+#pragma unroll
+        for (int j = 1; j < 6; ++j) dist[j] = 0.0f;
+        return rpo_pend_dev::lagrangian_row(a0, a1, nu_p[0], scale, dist[0], g.x, g.y);
+    }
+    __device__ static __forceinline__ float complete_bwd(const Consts&, const float* obs, float g0, float g1) {
+        return rpo_pend_dev::complete_bwd_row(obs, g0, g1);
+    }
+};
+
+struct SacActorFwdArgs {
+    Mlp actor, critic1, critic2;
+    float scale, base, box_lo, box_hi, alpha;
+    const float* batch; int B;
+    const float* noise_in;
+    uint64_t seed;
+    uint32_t noise_id_base, noise_salt;
+    const long long* ctrl;
+    const float* nu;
+    float* raw; float* noise_out; float* logp; float* actions; float* dq1; float* dq2; float* g_act;
+    float* partial;               // [gridDim.x, 8]: sum nu.dist, sum dist_0..5, sum (alpha log pi - min Q)
+    float* ax0; float* ah1; float* c1x0; float* c1h1; float* c2x0; float* c2h1;
+};
+
+template <class ENV, int EIN, int H>
+__global__ __launch_bounds__(kFwdThreads) void sac_actor_forward_kernel(SacActorFwdArgs p, typename ENV::Consts c) {
+    __shared__ TileLds<EIN> lds;
+    const int row0 = blockIdx.x * kRows, tid = threadIdx.x, B = p.B;
+    const long long t = p.ctrl[RPO_CTRL_T];
+    if (tid < kRows * ENV::S) {
+        const int r = tid / ENV::S, i = tid - r * ENV::S;
+        lds.in_s[r * kInS + i] = row0 + r < B ? p.batch[(size_t)(row0 + r) * ENV::ROW + i] : 0.0f;
+    }
+    mlp_tile_forward<EIN, H>(p.actor, lds, row0, B, p.ax0, p.ah1, 0, 1.0f, 0.0f);
+    float vals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float inv_b = 1.0f / (float)B;
+    const bool live = tid < kRows && row0 + tid < B;
+    float logp = 0.0f;
+    if (tid < kRows) {
+        float2 act = make_float2(0.0f, 0.0f);
+        if (live) {
+            const int i = row0 + tid;
+            const float rm = lds.out[tid * 2], rl = lds.out[tid * 2 + 1];
+            float e;
+            if (p.noise_in) {
+                e = p.noise_in[i];
+            } else {
+                const rpo_u4 u = rpo_philox(p.seed, p.noise_id_base + (uint32_t)i, (uint32_t)t + p.noise_salt, RPO_STREAM_POLICY,
+                                            (uint32_t)p.ctrl[RPO_CTRL_UPDATES]);
+                e = rpo_normal(u.x, u.y);
+            }
+            reinterpret_cast<float2*>(p.raw)[i] = make_float2(rm, rl);
+            p.noise_out[i] = e;
+            const float ap = rpo_head_dev::gauss_head_row(rm, rl, e, p.scale, p.base, p.box_lo, p.box_hi, 0, &logp);
+            p.logp[i] = logp;
+            act = ENV::complete(c, lds.in_s + tid * kInS, i, ap, t);
+            reinterpret_cast<float2*>(p.actions)[i] = act;
+            float dist[6];
+            float2 g;
+            vals[0] = ENV::lagr(c, act.x, act.y, p.nu, inv_b, dist, g);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) vals[1 + j] = dist[j];
+            reinterpret_cast<float2*>(p.g_act)[i] = g;
+        }
+        lds.in_a[tid * kInA] = act.x;
+        lds.in_a[tid * kInA + 1] = act.y;
+    }
+    mlp_tile_forward<EIN, H>(p.critic1, lds, row0, B, p.c1x0, p.c1h1, 0, 1.0f, 0.0f);
+    float q1 = 0.0f;
+    if (tid < kRows) q1 = lds.out[tid * 2];
+    mlp_tile_forward<EIN, H>(p.critic2, lds, row0, B, p.c2x0, p.c2h1, 0, 1.0f, 0.0f);
+    if (live) {
+        const float q2 = lds.out[tid * 2];
+        // d(-min(q1, q2))/dq: the smaller one takes the gradient, ties are split (torch.min's backward)
+        const float w1 = (q1 < q2 ? 1.0f : 0.0f) + (q1 == q2 ? 0.5f : 0.0f);
+        p.dq1[row0 + tid] = w1 * -inv_b;
+        p.dq2[row0 + tid] = (1.0f - w1) * -inv_b;
+        vals[7] = p.alpha * logp - fminf(q1, q2);
+    }
+    if (tid < 64) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float r = rpo_wave_sum(vals[k]);
+            if (tid == 0) p.partial[blockIdx.x * 8 + k] = r;
+        }
+    }
+}
+
+struct SacActorBwdArgs {
+    BwdArgs critic1, critic2, actor;
+    const float* g_act; const float* raw; const float* noise;
+    float dlogp, box_lo, box_hi, scale, base;   // dlogp: coefficient of log pi in the loss / B (alpha / B)
+    float* dout;                  // [B, 2] scratch: d loss / d (mean head, log-std head)
+    const float* partial; int n_parts;
+    float* lag_out;               // [2]: mean Lagrangian term, mean (alpha log pi - min Q)
+    float* nu_grad; int n_ineq;
+    int shared_embedding;
+};
+
+template <class ENV, int EIN, int H>
+__global__ __launch_bounds__(kThreads) void sac_actor_backward_kernel(SacActorBwdArgs p, typename ENV::Consts c) {
+    const int row0 = blockIdx.x * kRows, tid = threadIdx.x, B = p.actor.n;
+    mlp_bwd_rows_body<EIN, H>(p.critic1);
+    __syncthreads();
+    mlp_bwd_rows_body<EIN, H>(p.critic2);
+    __syncthreads();
+    if (tid < kRows && row0 + tid < B) {
+        const int i = row0 + tid;
+        const float2 d1 = reinterpret_cast<const float2*>(p.critic1.da)[i], d2 = reinterpret_cast<const float2*>(p.critic2.da)[i];
+        const float2 g = reinterpret_cast<const float2*>(p.g_act)[i];
+        const float da0 = (d1.x + d2.x) + g.x, da1 = (d1.y + d2.y) + g.y;      // da1.add_(da2).add_(g_act)
+        const float dap = ENV::complete_bwd(c, p.actor.s + (size_t)i * p.actor.s_stride, da0, da1);
+        const float2 r = reinterpret_cast<const float2*>(p.raw)[i];
+        reinterpret_cast<float2*>(p.dout)[i] = rpo_head_dev::gauss_head_bwd_row(r.x, r.y, p.noise[i], dap, p.dlogp, p.scale,
+                                                                                p.base, p.box_lo, p.box_hi);
+    }
+    __syncthreads();
+    mlp_bwd_rows_body<EIN, H>(p.actor);
+    if (p.shared_embedding) {
+        __syncthreads();
+        for (int idx = tid; idx < kRows * EIN; idx += kThreads) {
+            const int r = idx / EIN, e = idx - r * EIN;
+            if (row0 + r < B) {
+                const size_t o = (size_t)(row0 + r) * EIN + e;
+                p.actor.dx0[o] += p.critic1.dx0[o] + p.critic2.dx0[o];
+            }
+        }
+    }
+    if (blockIdx.x == 0 && tid < 8) {
+        float sacc = 0.0f;
+        for (int g = 0; g < p.n_parts; ++g) sacc += p.partial[g * 8 + tid];
+        const float inv_b = 1.0f / (float)B;
+        if (tid == 0) p.lag_out[0] = inv_b * sacc;
+        else if (tid == 7) p.lag_out[1] = inv_b * sacc;
+        else if (tid - 1 < p.n_ineq) p.nu_grad[tid - 1] += inv_b * sacc;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -906,6 +1083,102 @@ int rpo_cartsafe_ddpg_actor_backward(const rpo_mlp* actor_host, const rpo_mlp_gr
     p.nu_grad = nu_grad; p.shared_embedding = shared_embedding;
     hipLaunchKernelGGL((cart_ddpg_actor_backward_kernel<128, 256>), dim3((batch_size + kRows - 1) / kRows), dim3(kThreads), 0,
                        (hipStream_t)stream, p, c);
+    RPO_LAUNCH_CHECK();
+    const int fl_outputs = actor.E * (actor.S + 1);
+    const int grid_w = (actor.H / 16) * (128 / 64) + actor.H / 64 + (fl_outputs + 63) / 64;
+    hipLaunchKernelGGL((actor_weights_kernel<128, 256>), dim3(grid_w), dim3(kThreads), 0, (hipStream_t)stream, p.actor);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+static int sac_actor_nets(int obs_dim, const rpo_mlp* actor_host, const rpo_mlp* c1, const rpo_mlp* c2, Mlp& actor, Mlp& q1,
+                          Mlp& q2) {
+    if (!actor_host || !c1 || !c2) return RPO_ERR_NULL;
+    actor = to_dev(actor_host); q1 = to_dev(c1); q2 = to_dev(c2);
+    if (int e = check_actor(actor, obs_dim, 1)) return e;
+    if (actor.E != 128) return RPO_ERR_ARG;
+    const Mlp* qs[2] = {&q1, &q2};
+    for (const Mlp* q : qs)
+        if (q->S != obs_dim || q->A != 2 || q->cat || q->H != 256 || q->E != 128 || q->n_out != 1 || q->hd > 1) return RPO_ERR_ARG;
+    return 0;
+}
+
+int rpo_sac_actor_forward(int env, const rpo_mlp* actor_host, const rpo_mlp* critic1_host, const rpo_mlp* critic2_host,
+                          float scale, float base, float box_lo, float box_hi, float alpha, const float* batch,
+                          int batch_size, const float* noise_in, unsigned long long seed, unsigned noise_id_base,
+                          unsigned noise_salt, const long long* ctrl, const float* nu, const float* consts_host,
+                          int partial, float* raw, float* noise_out, float* logp, float* actions, float* dq1, float* dq2,
+                          float* g_act, float* partial_out, float* actor_x0, float* actor_h1, float* critic1_x0,
+                          float* critic1_h1, float* critic2_x0, float* critic2_h1, void* stream) {
+    if (env != 0 && env != 1) return RPO_ERR_ARG;
+    if (batch_size <= 0) return RPO_ERR_ARG;
+    if (!batch || !ctrl || !nu || !raw || !noise_out || !logp || !actions || !dq1 || !dq2 || !g_act || !partial_out ||
+        !actor_x0 || !actor_h1 || !critic1_x0 || !critic1_h1 || !critic2_x0 || !critic2_h1)
+        return RPO_ERR_NULL;
+    SacActorFwdArgs a{};
+    if (int e = sac_actor_nets(env == 0 ? 6 : 5, actor_host, critic1_host, critic2_host, a.actor, a.critic1, a.critic2)) return e;
+    a.scale = scale; a.base = base; a.box_lo = box_lo; a.box_hi = box_hi; a.alpha = alpha; a.batch = batch; a.B = batch_size;
+    a.noise_in = noise_in; a.seed = (uint64_t)seed; a.noise_id_base = (uint32_t)noise_id_base;
+    a.noise_salt = (uint32_t)noise_salt; a.ctrl = ctrl; a.nu = nu; a.raw = raw; a.noise_out = noise_out; a.logp = logp;
+    a.actions = actions; a.dq1 = dq1; a.dq2 = dq2; a.g_act = g_act; a.partial = partial_out; a.ax0 = actor_x0;
+    a.ah1 = actor_h1; a.c1x0 = critic1_x0; a.c1h1 = critic1_h1; a.c2x0 = critic2_x0; a.c2h1 = critic2_h1;
+    const int grid = (batch_size + kRows - 1) / kRows;
+    if (env == 0) {
+        CartConsts c;
+        if (int e = load_consts(c, consts_host, partial)) return e;
+        hipLaunchKernelGGL((sac_actor_forward_kernel<CartActEnv, 128, 256>), dim3(grid), dim3(kFwdThreads), 0,
+                           (hipStream_t)stream, a, c);
+    } else {
+        hipLaunchKernelGGL((sac_actor_forward_kernel<PendActEnv, 128, 256>), dim3(grid), dim3(kFwdThreads), 0,
+                           (hipStream_t)stream, a, PendActEnv::Consts{0});
+    }
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_sac_actor_backward(int env, const rpo_mlp* actor_host, const rpo_mlp_grad* actor_grad_host,
+                           const rpo_mlp* critic1_host, const rpo_mlp* critic2_host, int shared_embedding,
+                           const float* batch, int batch_size, const float* actions, const float* g_act, const float* raw,
+                           const float* noise, const float* dq1, const float* dq2, float dlogp, float box_lo,
+                           float box_hi, float scale, float base, const float* consts_host, int partial,
+                           const float* actor_x0, const float* actor_h1, const float* critic1_x0, const float* critic1_h1,
+                           const float* critic2_x0, const float* critic2_h1, float* actor_dh, float* actor_dx0,
+                           float* critic1_dh, float* critic1_dx0, float* critic2_dh, float* critic2_dx0, float* da1,
+                           float* da2, float* dout, const float* partial_in, float* lag_out, float* nu_grad,
+                           float* gradmax, void* stream) {
+    if (env != 0 && env != 1) return RPO_ERR_ARG;
+    if (batch_size <= 0) return RPO_ERR_ARG;
+    if (!actor_grad_host || !batch || !actions || !g_act || !raw || !noise || !dq1 || !dq2 || !da1 || !da2 || !dout ||
+        !partial_in || !lag_out || !nu_grad || !actor_x0 || !actor_h1 || !critic1_x0 || !critic1_h1 || !critic2_x0 ||
+        !critic2_h1 || !actor_dh || !actor_dx0 || !critic1_dh || !critic1_dx0 || !critic2_dh || !critic2_dx0)
+        return RPO_ERR_NULL;
+    SacActorBwdArgs p{};
+    Mlp actor, q1, q2;
+    const int obs_dim = env == 0 ? 6 : 5, row = env == 0 ? RPO_CART_ROW : RPO_PEND_ROW;
+    if (int e = sac_actor_nets(obs_dim, actor_host, critic1_host, critic2_host, actor, q1, q2)) return e;
+    MlpGrad none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    MlpGrad ag{actor_grad_host->Ws, actor_grad_host->bs, actor_grad_host->Wa, actor_grad_host->ba, actor_grad_host->W0,
+               actor_grad_host->b0, actor_grad_host->W1, actor_grad_host->b1, actor_grad_host->W1b, actor_grad_host->b1b};
+    if (!ag.Ws || !ag.bs || !ag.W0 || !ag.b0 || !ag.W1 || !ag.b1 || !ag.W1b || !ag.b1b) return RPO_ERR_NULL;
+    p.critic1 = BwdArgs{q1, none, batch_size, batch, row, actions, 2, critic1_x0, critic1_h1, dq1, critic1_dh, critic1_dx0, da1,
+                        0, 0, nullptr};
+    p.critic2 = BwdArgs{q2, none, batch_size, batch, row, actions, 2, critic2_x0, critic2_h1, dq2, critic2_dh, critic2_dx0, da2,
+                        0, 0, nullptr};
+    p.actor = BwdArgs{actor, ag, batch_size, batch, row, nullptr, 0, actor_x0, actor_h1, dout, actor_dh, actor_dx0, nullptr, 1, 0,
+                      gradmax};
+    p.g_act = g_act; p.raw = raw; p.noise = noise; p.dlogp = dlogp; p.box_lo = box_lo; p.box_hi = box_hi; p.scale = scale;
+    p.base = base; p.dout = dout; p.partial = partial_in; p.n_parts = (batch_size + kRows - 1) / kRows; p.lag_out = lag_out;
+    p.nu_grad = nu_grad; p.n_ineq = env == 0 ? 6 : 1; p.shared_embedding = shared_embedding;
+    const int grid = (batch_size + kRows - 1) / kRows;
+    if (env == 0) {
+        CartConsts c;
+        if (int e = load_consts(c, consts_host, partial)) return e;
+        hipLaunchKernelGGL((sac_actor_backward_kernel<CartActEnv, 128, 256>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream,
+                           p, c);
+    } else {
+        hipLaunchKernelGGL((sac_actor_backward_kernel<PendActEnv, 128, 256>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream,
+                           p, PendActEnv::Consts{0});
+    }
     RPO_LAUNCH_CHECK();
     const int fl_outputs = actor.E * (actor.S + 1);
     const int grid_w = (actor.H / 16) * (128 / 64) + actor.H / 64 + (fl_outputs + 63) / 64;

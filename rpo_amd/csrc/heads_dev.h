@@ -19,6 +19,24 @@ __device__ __forceinline__ float gauss_head_row(float raw_mean, float raw_ls, fl
     return fminf(fmaxf(a, lo), hi);
 }
 
+// Backward of gauss_head_row w.r.t. (mean head, log-std head) given d loss / d ap and the coefficient of log pi in the
+// loss (SAC actor loss: alpha / B); autograd of model/policy.py:53-66 with the clip of agent/sac_pa.py:111.
+__device__ __forceinline__ float2 gauss_head_bwd_row(float raw_mean, float raw_ls, float e, float dap, float dlogp, float scale,
+                                                     float base, float lo, float hi) {
+    RPO_FP_STRICT
+    const float lsr = raw_ls - 3.0f;
+    const float ls = fminf(fmaxf(lsr, kLogSigMin), kLogSigMax);
+    const float sd = expf(ls);
+    const float y = tanhf(raw_mean + e * sd);
+    const float omy = 1.0f - y * y;
+    const float a = scale * y + base;
+    const float g_ap = (a >= lo && a <= hi) ? dap * scale * omy : 0.0f;
+    const float g_lp = dlogp * (2.0f * scale * y * omy) / (scale * omy + 1e-6f);
+    const float gx = g_ap + g_lp;
+    const float dls = gx * e * sd - dlogp;
+    return make_float2(gx, (lsr >= kLogSigMin && lsr <= kLogSigMax) ? dls : 0.0f);
+}
+
 // Backward of ap = clip(scale * tanh(o) + base + eps_t * noise, lo, hi) w.r.t. o (model/policy.py:30-31,
 // agent/ddpg_pa.py:108-110), expressed through ap_det = scale * tanh(o) + base; has_noise = 0: no noise, no clip.
 __device__ __forceinline__ float tanh_box_bwd_row(float dap, float ap_det, float noise, int has_noise, float eps_t, float lo,

@@ -146,17 +146,7 @@ __global__ __launch_bounds__(RPO_BLOCK) void gauss_head_bwd_kernel(int n, const 
                                                                    float* __restrict__ draw) {
     for (int i = blockIdx.x * RPO_BLOCK + threadIdx.x; i < n; i += gridDim.x * RPO_BLOCK) {
         const float2 r = reinterpret_cast<const float2*>(raw)[i];
-        const float lsr = r.y - 3.0f;
-        const float ls = fminf(fmaxf(lsr, kLogSigMin), kLogSigMax);
-        const float sd = expf(ls), e = eps[i];
-        const float y = tanhf(r.x + e * sd);
-        const float omy = 1.0f - y * y;
-        const float a = scale * y + base;
-        const float g_ap = (a >= lo && a <= hi) ? dap[i] * scale * omy : 0.0f;
-        const float g_lp = dlogp * (2.0f * scale * y * omy) / (scale * omy + 1e-6f);
-        const float gx = g_ap + g_lp;
-        const float dls = gx * e * sd - dlogp;
-        reinterpret_cast<float2*>(draw)[i] = make_float2(gx, (lsr >= kLogSigMin && lsr <= kLogSigMax) ? dls : 0.0f);
+        reinterpret_cast<float2*>(draw)[i] = rpo_head_dev::gauss_head_bwd_row(r.x, r.y, eps[i], dap[i], dlogp, scale, base, lo, hi);
     }
 }
 

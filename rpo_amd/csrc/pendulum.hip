@@ -144,7 +144,7 @@ __global__ __launch_bounds__(RPO_BLOCK) void pendulum_complete_bwd_kernel(int n,
     for (int i = blockIdx.x * RPO_BLOCK + threadIdx.x; i < n; i += gridDim.x * RPO_BLOCK) {
         const float* o = obs + (size_t)i * obs_stride;
         const float2 g = reinterpret_cast<const float2*>(ga)[i];
-        gap[i] = g.x - g.y * (o[1] * (1.0f / o[0]));     // d a_y / d a_x = -C_p * C_o_inv
+        gap[i] = complete_bwd_row(o, g.x, g.y);
     }
 }
 
@@ -185,12 +185,10 @@ __global__ __launch_bounds__(RPO_BLOCK) void pendulum_lagrangian_kernel(int n, c
     float acc = 0.0f;
     for (int i = blockIdx.x * RPO_BLOCK + threadIdx.x; i < n; i += gridDim.x * RPO_BLOCK) {
         const float2 a = reinterpret_cast<const float2*>(action)[i];
-        const float g = a.x * a.x + a.y * a.y - kMaxSum;
-        acc += fmaxf(g, 0.0f);
-        if (grad_action) {
-            const float k = (g > 0.0f) ? 2.0f * scale * nu0 : 0.0f;
-            reinterpret_cast<float2*>(grad_action)[i] = make_float2(k * a.x, k * a.y);
-        }
+        float dist, g0, g1;
+        lagrangian_row(a.x, a.y, nu0, scale, dist, g0, g1);
+        acc += dist;
+        if (grad_action) reinterpret_cast<float2*>(grad_action)[i] = make_float2(g0, g1);
     }
     const float r = rpo_wave_sum(acc);
     if ((threadIdx.x & (RPO_WAVE - 1)) == 0) red[threadIdx.x / RPO_WAVE] = r;

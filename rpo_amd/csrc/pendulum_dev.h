@@ -196,4 +196,21 @@ __device__ __forceinline__ float2 pend_explore_project(const ActArgs& p, const f
     return make_float2(ax, ay);
 }
 
+// One row of nu . relu(g(a)) with g = |a|^2 - 32 (pendulum.py:302-311; rpo_sac.py:326-335): returns nu0 * relu(g),
+// `dist` = relu(g) (d/d nu) and (g0, g1) = scale * d/d action.  Shared by rpo_pendulum_lagrangian and the fused pipelines.
+__device__ __forceinline__ float lagrangian_row(float ax, float ay, float nu0, float scale, float& dist, float& g0, float& g1) {
+    RPO_FP_STRICT
+    const float g = ax * ax + ay * ay - kMaxSum;
+    dist = fmaxf(g, 0.0f);
+    const float k = (g > 0.0f) ? 2.0f * scale * nu0 : 0.0f;
+    g0 = k * ax; g1 = k * ay;
+    return nu0 * dist;
+}
+
+// autograd through complete_partial (pendulum.py:256-262): d a_y / d a_x = -C_p * C_o_inv = -sin / cos
+__device__ __forceinline__ float complete_bwd_row(const float* o, float g0, float g1) {
+    RPO_FP_STRICT
+    return g0 - g1 * (o[1] * (1.0f / o[0]));
+}
+
 }  // namespace rpo_pend_dev

@@ -516,3 +516,30 @@ def mlp_backward_pair(desc1, desc2, s, a, x0_1, h1_1, dout_1, dh_1, dx0_1, da_1,
         dout_1.shape[0], sp, ss, ap, as_, _p(x0_1), _p(h1_1), _p(dout_1), _p(dh_1), _p(dx0_1), _p(da_1, allow_none=True),
         _p(x0_2), _p(h1_2), _p(dout_2), _p(dh_2), _p(dx0_2), _p(da_2, allow_none=True), int(param_grads),
         int(first_layer_state_only), _p(gradmax, allow_none=True), _stream()), "rpo_mlp_backward_pair")
+
+
+def sac_actor_forward(env_kernels, actor, critic1, critic2, scale, base, box_lo, box_hi, alpha, batch, noise_in, seed,
+                      noise_id_base, noise_salt, ctrl, nu, raw, noise_out, logp, actions, dq1, dq2, g_act, partial_out, bufs):
+    """bufs = (actor_x0, actor_h1, critic1_x0, critic1_h1, critic2_x0, critic2_h1)."""
+    is_cart = isinstance(env_kernels, CartSafeKernels)
+    nets = [d.net_struct() for d in (actor, critic1, critic2)]
+    check(_lib.load().rpo_sac_actor_forward(
+        0 if is_cart else 1, *[ctypes.byref(n) for n in nets], scale, base, box_lo, box_hi, alpha, _p(batch), batch.shape[0],
+        _p(noise_in, allow_none=True), seed, noise_id_base, noise_salt, _p(ctrl, torch.int64), _p(nu),
+        env_kernels._cptr if is_cart else None, env_kernels.partial if is_cart else 0, _p(raw), _p(noise_out), _p(logp),
+        _p(actions), _p(dq1), _p(dq2), _p(g_act), _p(partial_out), *[_p(b) for b in bufs], _stream()),
+        "rpo_sac_actor_forward")
+
+
+def sac_actor_backward(env_kernels, actor, critic1, critic2, shared_embedding, batch, actions, g_act, raw, noise, dq1, dq2,
+                       dlogp, box_lo, box_hi, scale, base, saved, scratch, da1, da2, dout, partial_in, lag_out, nu_grad,
+                       gradmax):
+    """saved = the six pre-activation buffers of the forward; scratch = (actor_dh, actor_dx0, c1_dh, c1_dx0, c2_dh, c2_dx0)."""
+    is_cart = isinstance(env_kernels, CartSafeKernels)
+    an, c1, c2, ag = actor.net_struct(), critic1.net_struct(), critic2.net_struct(), actor.grad_struct()
+    check(_lib.load().rpo_sac_actor_backward(
+        0 if is_cart else 1, ctypes.byref(an), ctypes.byref(ag), ctypes.byref(c1), ctypes.byref(c2), int(shared_embedding),
+        _p(batch), batch.shape[0], _p(actions), _p(g_act), _p(raw), _p(noise), _p(dq1), _p(dq2), dlogp, box_lo, box_hi, scale,
+        base, env_kernels._cptr if is_cart else None, env_kernels.partial if is_cart else 0, *[_p(b) for b in saved],
+        *[_p(b) for b in scratch], _p(da1), _p(da2), _p(dout), _p(partial_in), _p(lag_out), _p(nu_grad),
+        _p(gradmax, allow_none=True), _stream()), "rpo_sac_actor_backward")
