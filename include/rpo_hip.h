@@ -458,7 +458,8 @@ int rpo_cartsafe_ddpg_critic_forward(const rpo_mlp* actor_target_host, const rpo
                                      int partial, float gamma, float* q_out, float* qn_out, float* dq_out,
                                      float* loss_partial, float* x0_save, float* h1_save, void* stream);
 
-/* The policy step of RPODDPG on CartSafe (rpo_ddpg.py:186-205, 307-324) as forward + backward pipelines (E = 128):
+/* The policy step of RPODDPG (rpo_ddpg.py:186-205, 307-324) as forward + backward pipelines, env = 0 CartSafe-v0 /
+ * 1 SpringPendulum-v0 (E = 128; the actor loss completes the action but does not project it):
  *   forward:  pi(s) with pre-activations saved -> ap = clip(ap_det + eps_t * N(0,1)) (noise_in[b], or the Philox draw of
  *             rpo_philox_normal(noise_id_base, noise_salt, RPO_STREAM_POLICY)) -> Complete -> Q(s, a) saved ->
  *             Lagrangian term: g_act [B,2] = d/d action / B, partial_out [ceil(B/16), 8] = per-workgroup sums of
@@ -469,14 +470,14 @@ int rpo_cartsafe_ddpg_critic_forward(const rpo_mlp* actor_target_host, const rpo
  *             nu_grad [6] += mean relu(g); gradmax as in rpo_mlp_backward (actor slice).
  * == rpo_mlp_forward x 2, rpo_philox_normal, rpo_cartsafe_act_project, rpo_cartsafe_lagrangian, rpo_mlp_backward x 2,
  *    rpo_cartsafe_complete_bwd, rpo_tanh_box_bwd and three elementwise launches. */
-int rpo_cartsafe_ddpg_actor_forward(const rpo_mlp* actor_host, const rpo_mlp* critic_host, float scale, float base,
+int rpo_ddpg_actor_forward(int env, const rpo_mlp* actor_host, const rpo_mlp* critic_host, float scale, float base,
                                     float box_lo, float box_hi, float eps_start, float eps_end, float eps_decay,
                                     const float* batch, int batch_size, const float* noise_in, unsigned long long seed,
                                     unsigned noise_id_base, unsigned noise_salt, const long long* ctrl, const float* nu,
                                     const float* consts_host, int partial, float* ap_det, float* noise_out,
                                     float* actions, float* q_out, float* dq_out, float* g_act, float* partial_out,
                                     float* actor_x0, float* actor_h1, float* critic_x0, float* critic_h1, void* stream);
-int rpo_cartsafe_ddpg_actor_backward(const rpo_mlp* actor_host, const rpo_mlp_grad* actor_grad_host,
+int rpo_ddpg_actor_backward(int env, const rpo_mlp* actor_host, const rpo_mlp_grad* actor_grad_host,
                                      const rpo_mlp* critic_host, int shared_embedding, const float* batch,
                                      int batch_size, const float* actions, const float* g_act, const float* ap_det,
                                      const float* noise, const float* dq, float eps_start, float eps_end,

@@ -137,9 +137,10 @@ class RPODDPG(RPOTrainerBase):
     @property
     def _actor_pipeline(self):
         d = self.fused.descs if self.fused is not None else {}
-        return (hasattr(self.kernels, "ddpg_actor_forward") and "actor" in d and "critic" in d and d["actor"].E == 128
+        return (hasattr(self.backend, "ddpg_actor_forward") and "actor" in d and "critic" in d and d["actor"].E == 128
                 and d["critic"].E == 128 and not d["critic"].cat and self._box_affine is not None
-                and self._batch.is_contiguous() and _env_int("RPO_FUSED_ACTOR", 1))
+                and self.kernels.partial_dim == 1 and self.kernels.action_dim == 2
+                and _env_int("RPO_FUSED_ACTOR", 1))
 
     def _actor_update_pipeline(self, cols):
         """The policy step in two launches + the actor's weights pass (fused.hip)."""
@@ -155,7 +156,7 @@ class RPODDPG(RPOTrainerBase):
             self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * B, _SALT_ACTOR, hip_ops.STREAM_POLICY,
                                        self.vec.ctrl)
             noise_in = self._noise_b.view(-1)
-        k.ddpg_actor_forward(da_, dc, scale, base, self._box_lo, self._box_hi, self.eps_start, self.eps, self.decay_value,
+        self.backend.ddpg_actor_forward(k, da_, dc, scale, base, self._box_lo, self._box_hi, self.eps_start, self.eps, self.decay_value,
                              self._batch, noise_in, self.seed, self.dist.rank * B, _SALT_ACTOR, self.vec.ctrl,
                              ag.nju.weight.view(-1), ap_det, noise, actions, q, dq, g_act, parts, b("actor.x0", B, da_.ein),
                              b("actor.h1", B, da_.H), b("critic.x0", B, dc.ein), b("critic.h1", B, dc.H))
@@ -164,7 +165,7 @@ class RPODDPG(RPOTrainerBase):
         opt = ag.actor_optim
         fuse_max = self._self_cleaning and not self.dist.on and opt.clip_thres and opt.clip_thres != float("inf")
         lag = b("actor.lag", 2)
-        k.ddpg_actor_backward(da_, dc, shared, self._batch, actions, g_act, ap_det, noise, dq, self.eps_start, self.eps,
+        self.backend.ddpg_actor_backward(k, da_, dc, shared, self._batch, actions, g_act, ap_det, noise, dq, self.eps_start, self.eps,
                               self.decay_value, self._box_lo, self._box_hi, scale, base, self.vec.ctrl,
                               b("actor.x0", B, da_.ein), b("actor.h1", B, da_.H), b("critic.x0", B, dc.ein),
                               b("critic.h1", B, dc.H), b("actor.dh", B, da_.H), b("actor.dx0", B, da_.ein),

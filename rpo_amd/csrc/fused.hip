@@ -494,6 +494,65 @@ __global__ __launch_bounds__(kThreads) void actor_weights_kernel(BwdArgs p) {
     gradmax_flush(p.gradmax, mlp_bwd_weights_body<EIN, H>(p));
 }
 
+// Env policies of the actor-update pipelines: Complete, the Lagrangian row and the backward of Complete.
+struct CartActEnv {
+    typedef CartConsts Consts;
+    static constexpr int ROW = RPO_CART_ROW, S = 6, NI = 6;
+    __device__ static __forceinline__ float2 complete(const Consts& c, const float* obs, int i, float ap, long long t) {
+        ActArgs a{};
+        a.noise_mode = RPO_NOISE_NONE; a.max_steps = 0;
+        int k;
+        return cart_explore_project(a, c, i, ap, 0.0f, t, k);
+    }
+    // take_action's exploration: clip(ap_det + eps_t * noise[i]) (ddpg_pa.py:108-110), then Complete
+    __device__ static __forceinline__ float2 complete_noisy(const Consts& c, const float* obs, int i, float ap_det, float eps_t,
+                                                            const float* noise, float lo, float hi, long long t) {
+        ActArgs a{};
+        a.noise_mode = RPO_NOISE_EXPLICIT; a.noise = noise; a.box_lo = lo; a.box_hi = hi; a.max_steps = 0;
+        int k;
+        return cart_explore_project(a, c, i, ap_det, eps_t, t, k);
+    }
+    __device__ static __forceinline__ float lagr(const Consts& c, float a0, float a1, const float* nu_p, float scale,
+                                                 float (&dist)[6], float2& g) {
+        float nu[6], loss, g0, g1;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) nu[j] = nu_p[j];
+        rpo_cart_dev::lagrangian_row(c, a0, a1, nu, loss, dist, g0, g1);
+        g = make_float2(scale * g0, scale * g1);
+        return loss;
+    }
+    __device__ static __forceinline__ float complete_bwd(const Consts& c, const float* obs, float g0, float g1) {
+        return rpo_cart_dev::complete_bwd_row(c, g0, g1);
+    }
+};
+
+struct PendActEnv {
+    struct Consts { int unused; };
+    static constexpr int ROW = RPO_PEND_ROW, S = 5, NI = 1;
+    __device__ static __forceinline__ float2 complete(const Consts&, const float* obs, int i, float ap, long long t) {
+        rpo_pend_dev::ActArgs a{};
+        a.noise_mode = RPO_NOISE_NONE; a.max_steps = 0;
+        int k;
+        return rpo_pend_dev::pend_explore_project(a, obs, i, ap, 0.0f, t, k);
+    }
+    __device__ static __forceinline__ float2 complete_noisy(const Consts&, const float* obs, int i, float ap_det, float eps_t,
+                                                            const float* noise, float lo, float hi, long long t) {
+        rpo_pend_dev::ActArgs a{};
+        a.noise_mode = RPO_NOISE_EXPLICIT; a.noise = noise; a.box_lo = lo; a.box_hi = hi; a.max_steps = 0;
+        int k;
+        return rpo_pend_dev::pend_explore_project(a, obs, i, ap_det, eps_t, t, k);
+    }
+    __device__ static __forceinline__ float lagr(const Consts&, float a0, float a1, const float* nu_p, float scale,
+                                                 float (&dist)[6], float2& g) {
+#pragma unroll
+        for (int j = 1; j < 6; ++j) dist[j] = 0.0f;
+        return rpo_pend_dev::lagrangian_row(a0, a1, nu_p[0], scale, dist[0], g.x, g.y);
+    }
+    __device__ static __forceinline__ float complete_bwd(const Consts&, const float* obs, float g0, float g1) {
+        return rpo_pend_dev::complete_bwd_row(obs, g0, g1);
+    }
+};
+
 // --------------------------------------------------------------------------------------- actor update, RPODDPG
 // The policy step of rpo_ddpg.py:186-205,307-324 on CartSafe in two launches + the weights pass:
 //   forward   pi(s) (pre-activations saved) -> exploration noise + clip (take_action) -> Complete -> Q(s, a) (saved) ->
@@ -518,14 +577,14 @@ struct ActorFwdArgs {
     float* ax0; float* ah1; float* cx0; float* ch1;
 };
 
-template <int EIN, int H>
-__global__ __launch_bounds__(kFwdThreads) void cart_ddpg_actor_forward_kernel(ActorFwdArgs p, CartConsts c) {
+template <class ENV, int EIN, int H>
+__global__ __launch_bounds__(kFwdThreads) void ddpg_actor_forward_kernel(ActorFwdArgs p, typename ENV::Consts c) {
     __shared__ TileLds<EIN> lds;
     const int row0 = blockIdx.x * kRows, tid = threadIdx.x, B = p.B;
     const long long t = p.ctrl[RPO_CTRL_T];
-    if (tid < kRows * 6) {
-        const int r = tid / 6, i = tid - r * 6;
-        lds.in_s[r * kInS + i] = row0 + r < B ? p.batch[(size_t)(row0 + r) * RPO_CART_ROW + i] : 0.0f;
+    if (tid < kRows * ENV::S) {
+        const int r = tid / ENV::S, i = tid - r * ENV::S;
+        lds.in_s[r * kInS + i] = row0 + r < B ? p.batch[(size_t)(row0 + r) * ENV::ROW + i] : 0.0f;
     }
     mlp_tile_forward<EIN, H>(p.actor, lds, row0, B, p.ax0, p.ah1, 1, p.scale, p.base);
     float vals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -547,22 +606,15 @@ __global__ __launch_bounds__(kFwdThreads) void cart_ddpg_actor_forward_kernel(Ac
             }
             p.ap_det[i] = ap_det;
             p.noise_out[i] = e;
-            ActArgs a{};
-            a.noise_mode = RPO_NOISE_EXPLICIT;                  // ap = clip(ap_det + eps_t * e): ddpg_pa.py:108-110
-            a.noise = p.noise_out;
-            a.box_lo = p.box_lo; a.box_hi = p.box_hi; a.max_steps = 0;
-            int k;
-            const float2 act = cart_explore_project(a, c, i, ap_det, eps_t, t, k);
+            const float2 act = ENV::complete_noisy(c, lds.in_s + tid * kInS, i, ap_det, eps_t, p.noise_out, p.box_lo, p.box_hi, t);
             a0 = act.x; a1 = act.y;
             reinterpret_cast<float2*>(p.actions)[i] = act;
-            float nu[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) nu[j] = p.nu[j];
-            float dist[6], g0, g1;
-            rpo_cart_dev::lagrangian_row(c, a0, a1, nu, vals[0], dist, g0, g1);
+            float dist[6];
+            float2 g;
+            vals[0] = ENV::lagr(c, a0, a1, p.nu, inv_b, dist, g);
 #pragma unroll
             for (int j = 0; j < 6; ++j) vals[1 + j] = dist[j];
-            reinterpret_cast<float2*>(p.g_act)[i] = make_float2(inv_b * g0, inv_b * g1);
+            reinterpret_cast<float2*>(p.g_act)[i] = g;
             p.dq_out[i] = -inv_b;                               // d mean(-Q) / dQ
         }
         lds.in_a[tid * kInA] = a0;
@@ -594,8 +646,8 @@ struct ActorBwdArgs {
     int shared_embedding;
 };
 
-template <int EIN, int H>
-__global__ __launch_bounds__(kThreads) void cart_ddpg_actor_backward_kernel(ActorBwdArgs p, CartConsts c) {
+template <class ENV, int EIN, int H>
+__global__ __launch_bounds__(kThreads) void ddpg_actor_backward_kernel(ActorBwdArgs p, typename ENV::Consts c) {
     const int row0 = blockIdx.x * kRows, tid = threadIdx.x, B = p.critic.n;
     mlp_bwd_rows_body<EIN, H>(p.critic);                        // dh, dx0 of the critic and da = d(-Q)/d action
     __syncthreads();
@@ -607,7 +659,7 @@ __global__ __launch_bounds__(kThreads) void cart_ddpg_actor_backward_kernel(Acto
         const float2 g = reinterpret_cast<const float2*>(p.g_act)[i];
         const float da0 = d.x + g.x, da1 = d.y + g.y;
         reinterpret_cast<float2*>(p.critic.da)[i] = make_float2(da0, da1);
-        const float dap = rpo_cart_dev::complete_bwd_row(c, da0, da1);
+        const float dap = ENV::complete_bwd(c, p.actor.s + (size_t)i * p.actor.s_stride, da0, da1);
         p.dout[i] = rpo_head_dev::tanh_box_bwd_row(dap, p.ap_det[i], p.noise[i], 1, eps_t, p.box_lo, p.box_hi, p.scale, p.base);
     }
     __syncthreads();
@@ -625,7 +677,7 @@ __global__ __launch_bounds__(kThreads) void cart_ddpg_actor_backward_kernel(Acto
         const float inv_b = 1.0f / (float)B;
         if (tid == 0) p.lag_out[0] = inv_b * sacc;
         else if (tid == 7) p.lag_out[1] = inv_b * sacc;
-        else p.nu_grad[tid - 1] += inv_b * sacc;
+        else if (tid - 1 < ENV::NI) p.nu_grad[tid - 1] += inv_b * sacc;
     }
 }
 
@@ -635,49 +687,6 @@ __global__ __launch_bounds__(kThreads) void cart_ddpg_actor_backward_kernel(Acto
 //   forward   pi(s): mean / log-std heads (saved) -> rsample + box clip + log pi -> Complete -> Q1, Q2 (s, a) (saved) ->
 //             nu . relu(g(a)); d(-min(Q1, Q2))/dQ_k with ties split like torch.min's backward
 //   backward  both critics' rows -> d/d a -> Complete -> Gaussian head (incl. the alpha log pi term) -> actor rows
-struct CartActEnv {
-    typedef CartConsts Consts;
-    static constexpr int ROW = RPO_CART_ROW, S = 6, NI = 6;
-    __device__ static __forceinline__ float2 complete(const Consts& c, const float* obs, int i, float ap, long long t) {
-        ActArgs a{};
-        a.noise_mode = RPO_NOISE_NONE; a.max_steps = 0;
-        int k;
-        return cart_explore_project(a, c, i, ap, 0.0f, t, k);
-    }
-    __device__ static __forceinline__ float lagr(const Consts& c, float a0, float a1, const float* nu_p, float scale,
-                                                 float (&dist)[6], float2& g) {
-        float nu[6], loss, g0, g1;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) nu[j] = nu_p[j];
-        rpo_cart_dev::lagrangian_row(c, a0, a1, nu, loss, dist, g0, g1);
-        g = make_float2(scale * g0, scale * g1);
-        return loss;
-    }
-    __device__ static __forceinline__ float complete_bwd(const Consts& c, const float* obs, float g0, float g1) {
-        return rpo_cart_dev::complete_bwd_row(c, g0, g1);
-    }
-};
-
-struct PendActEnv {
-    struct Consts { int unused; };
-    static constexpr int ROW = RPO_PEND_ROW, S = 5, NI = 1;
-    __device__ static __forceinline__ float2 complete(const Consts&, const float* obs, int i, float ap, long long t) {
-        rpo_pend_dev::ActArgs a{};
-        a.noise_mode = RPO_NOISE_NONE; a.max_steps = 0;
-        int k;
-        return rpo_pend_dev::pend_explore_project(a, obs, i, ap, 0.0f, t, k);
-    }
-    __device__ static __forceinline__ float lagr(const Consts&, float a0, float a1, const float* nu_p, float scale,
-                                                 float (&dist)[6], float2& g) {
-#pragma unroll
-        for (int j = 1; j < 6; ++j) dist[j] = 0.0f;
-        return rpo_pend_dev::lagrangian_row(a0, a1, nu_p[0], scale, dist[0], g.x, g.y);
-    }
-    __device__ static __forceinline__ float complete_bwd(const Consts&, const float* obs, float g0, float g1) {
-        return rpo_pend_dev::complete_bwd_row(obs, g0, g1);
-    }
-};
-
 struct SacActorFwdArgs {
     Mlp actor, critic1, critic2;
     float scale, base, box_lo, box_hi, alpha;
@@ -1014,7 +1023,7 @@ int rpo_pendulum_sac_critic_back(const rpo_mlp* critic_target1_host, const rpo_m
     return 0;
 }
 
-int rpo_cartsafe_ddpg_actor_forward(const rpo_mlp* actor_host, const rpo_mlp* critic_host, float scale, float base,
+int rpo_ddpg_actor_forward(int env, const rpo_mlp* actor_host, const rpo_mlp* critic_host, float scale, float base,
                                     float box_lo, float box_hi, float eps_start, float eps_end, float eps_decay,
                                     const float* batch, int batch_size, const float* noise_in, unsigned long long seed,
                                     unsigned noise_id_base, unsigned noise_salt, const long long* ctrl, const float* nu,
@@ -1026,26 +1035,34 @@ int rpo_cartsafe_ddpg_actor_forward(const rpo_mlp* actor_host, const rpo_mlp* cr
     if (!batch || !ctrl || !nu || !ap_det || !noise_out || !actions || !q_out || !dq_out || !g_act || !partial_out ||
         !actor_x0 || !actor_h1 || !critic_x0 || !critic_h1)
         return RPO_ERR_NULL;
+    if (env != 0 && env != 1) return RPO_ERR_ARG;
+    const int obs_dim = env == 0 ? 6 : 5;
     ActorFwdArgs a{};
     a.actor = to_dev(actor_host); a.critic = to_dev(critic_host);
-    if (int e = check_actor(a.actor, 6, 0)) return e;
-    if (a.actor.E != 128 || a.critic.S != 6 || a.critic.A != 2 || a.critic.cat || a.critic.H != 256 || a.critic.E != 128 ||
+    if (int e = check_actor(a.actor, obs_dim, 0)) return e;
+    if (a.actor.E != 128 || a.critic.S != obs_dim || a.critic.A != 2 || a.critic.cat || a.critic.H != 256 || a.critic.E != 128 ||
         a.critic.n_out != 1 || a.critic.hd > 1)
         return RPO_ERR_ARG;
-    CartConsts c;
-    if (int e = load_consts(c, consts_host, partial)) return e;
     a.scale = scale; a.base = base; a.box_lo = box_lo; a.box_hi = box_hi; a.eps_start = eps_start; a.eps_end = eps_end;
     a.eps_decay = eps_decay; a.batch = batch; a.B = batch_size; a.noise_in = noise_in; a.seed = (uint64_t)seed;
     a.noise_id_base = (uint32_t)noise_id_base; a.noise_salt = (uint32_t)noise_salt; a.ctrl = ctrl; a.nu = nu;
     a.ap_det = ap_det; a.noise_out = noise_out; a.actions = actions; a.q_out = q_out; a.dq_out = dq_out; a.g_act = g_act;
     a.partial = partial_out; a.ax0 = actor_x0; a.ah1 = actor_h1; a.cx0 = critic_x0; a.ch1 = critic_h1;
-    hipLaunchKernelGGL((cart_ddpg_actor_forward_kernel<128, 256>), dim3((batch_size + kRows - 1) / kRows), dim3(kFwdThreads),
-                       0, (hipStream_t)stream, a, c);
+    const int grid = (batch_size + kRows - 1) / kRows;
+    if (env == 0) {
+        CartConsts c;
+        if (int e = load_consts(c, consts_host, partial)) return e;
+        hipLaunchKernelGGL((ddpg_actor_forward_kernel<CartActEnv, 128, 256>), dim3(grid), dim3(kFwdThreads), 0,
+                           (hipStream_t)stream, a, c);
+    } else {
+        hipLaunchKernelGGL((ddpg_actor_forward_kernel<PendActEnv, 128, 256>), dim3(grid), dim3(kFwdThreads), 0,
+                           (hipStream_t)stream, a, PendActEnv::Consts{0});
+    }
     RPO_LAUNCH_CHECK();
     return 0;
 }
 
-int rpo_cartsafe_ddpg_actor_backward(const rpo_mlp* actor_host, const rpo_mlp_grad* actor_grad_host,
+int rpo_ddpg_actor_backward(int env, const rpo_mlp* actor_host, const rpo_mlp_grad* actor_grad_host,
                                      const rpo_mlp* critic_host, int shared_embedding, const float* batch,
                                      int batch_size, const float* actions, const float* g_act, const float* ap_det,
                                      const float* noise, const float* dq, float eps_start, float eps_end,
@@ -1059,30 +1076,39 @@ int rpo_cartsafe_ddpg_actor_backward(const rpo_mlp* actor_host, const rpo_mlp_gr
     if (batch_size <= 0) return RPO_ERR_ARG;
     if (!batch || !actions || !g_act || !ap_det || !noise || !dq || !ctrl || !da || !dout || !partial_in || !lag_out || !nu_grad)
         return RPO_ERR_NULL;
+    if (env != 0 && env != 1) return RPO_ERR_ARG;
+    const int obs_dim = env == 0 ? 6 : 5, row = env == 0 ? RPO_CART_ROW : RPO_PEND_ROW;
     ActorBwdArgs p{};
     Mlp actor = to_dev(actor_host), critic = to_dev(critic_host);
-    if (int e = check_actor(actor, 6, 0)) return e;
-    if (actor.E != 128 || critic.S != 6 || critic.A != 2 || critic.cat || critic.H != 256 || critic.E != 128 || critic.n_out != 1)
+    if (int e = check_actor(actor, obs_dim, 0)) return e;
+    if (actor.E != 128 || critic.S != obs_dim || critic.A != 2 || critic.cat || critic.H != 256 || critic.E != 128 ||
+        critic.n_out != 1)
         return RPO_ERR_ARG;
     if (!actor_x0 || !actor_h1 || !critic_x0 || !critic_h1 || !actor_dh || !actor_dx0 || !critic_dh || !critic_dx0)
         return RPO_ERR_NULL;
-    CartConsts c;
-    if (int e = load_consts(c, consts_host, partial)) return e;
     MlpGrad none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     MlpGrad ag{actor_grad_host->Ws, actor_grad_host->bs, actor_grad_host->Wa, actor_grad_host->ba, actor_grad_host->W0,
                actor_grad_host->b0, actor_grad_host->W1, actor_grad_host->b1, actor_grad_host->W1b, actor_grad_host->b1b};
     if (!ag.Ws || !ag.bs || !ag.W0 || !ag.b0 || !ag.W1 || !ag.b1) return RPO_ERR_NULL;
     // the critic only propagates (d/d action, and dx0 for a shared embedding): no parameter gradients of its own
-    p.critic = BwdArgs{critic, none, batch_size, batch, RPO_CART_ROW, actions, 2, critic_x0, critic_h1, dq, critic_dh,
+    p.critic = BwdArgs{critic, none, batch_size, batch, row, actions, 2, critic_x0, critic_h1, dq, critic_dh,
                        critic_dx0, da, 0, 0, nullptr};
-    p.actor = BwdArgs{actor, ag, batch_size, batch, RPO_CART_ROW, nullptr, 0, actor_x0, actor_h1, dout, actor_dh, actor_dx0,
+    p.actor = BwdArgs{actor, ag, batch_size, batch, row, nullptr, 0, actor_x0, actor_h1, dout, actor_dh, actor_dx0,
                       nullptr, 1, 0, gradmax};
     p.g_act = g_act; p.ap_det = ap_det; p.noise = noise; p.eps_start = eps_start; p.eps_end = eps_end;
     p.eps_decay = eps_decay; p.box_lo = box_lo; p.box_hi = box_hi; p.scale = scale; p.base = base; p.ctrl = ctrl;
     p.dout = dout; p.partial = partial_in; p.n_parts = (batch_size + kRows - 1) / kRows; p.lag_out = lag_out;
     p.nu_grad = nu_grad; p.shared_embedding = shared_embedding;
-    hipLaunchKernelGGL((cart_ddpg_actor_backward_kernel<128, 256>), dim3((batch_size + kRows - 1) / kRows), dim3(kThreads), 0,
-                       (hipStream_t)stream, p, c);
+    const int grid = (batch_size + kRows - 1) / kRows;
+    if (env == 0) {
+        CartConsts c;
+        if (int e = load_consts(c, consts_host, partial)) return e;
+        hipLaunchKernelGGL((ddpg_actor_backward_kernel<CartActEnv, 128, 256>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream,
+                           p, c);
+    } else {
+        hipLaunchKernelGGL((ddpg_actor_backward_kernel<PendActEnv, 128, 256>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream,
+                           p, PendActEnv::Consts{0});
+    }
     RPO_LAUNCH_CHECK();
     const int fl_outputs = actor.E * (actor.S + 1);
     const int grid_w = (actor.H / 16) * (128 / 64) + actor.H / 64 + (fl_outputs + 63) / 64;

@@ -196,28 +196,6 @@ class CartSafeKernels(object):
             corr_momentum, box_lo, box_hi, self._cptr, self.partial, gamma, _p(q_out), _p(qn_out), _p(dq_out),
             _p(loss_partial), _p(x0_save), _p(h1_save), _stream()), "rpo_cartsafe_ddpg_critic_forward")
 
-    def ddpg_actor_forward(self, actor, critic, scale, base, box_lo, box_hi, eps_start, eps_end, eps_decay, batch, noise_in,
-                           seed, noise_id_base, noise_salt, ctrl, nu, ap_det, noise_out, actions, q_out, dq_out, g_act,
-                           partial_out, actor_x0, actor_h1, critic_x0, critic_h1):
-        an, cn = actor.net_struct(), critic.net_struct()
-        check(_lib.load().rpo_cartsafe_ddpg_actor_forward(
-            ctypes.byref(an), ctypes.byref(cn), scale, base, box_lo, box_hi, eps_start, eps_end, eps_decay, _p(batch),
-            batch.shape[0], _p(noise_in, allow_none=True), seed, noise_id_base, noise_salt, _p(ctrl, torch.int64), _p(nu),
-            self._cptr, self.partial, _p(ap_det), _p(noise_out), _p(actions), _p(q_out), _p(dq_out), _p(g_act),
-            _p(partial_out), _p(actor_x0), _p(actor_h1), _p(critic_x0), _p(critic_h1), _stream()),
-            "rpo_cartsafe_ddpg_actor_forward")
-
-    def ddpg_actor_backward(self, actor, critic, shared_embedding, batch, actions, g_act, ap_det, noise, dq, eps_start,
-                            eps_end, eps_decay, box_lo, box_hi, scale, base, ctrl, actor_x0, actor_h1, critic_x0, critic_h1,
-                            actor_dh, actor_dx0, critic_dh, critic_dx0, da, dout, partial_in, lag_out, nu_grad, gradmax):
-        an, cn, ag = actor.net_struct(), critic.net_struct(), actor.grad_struct()
-        check(_lib.load().rpo_cartsafe_ddpg_actor_backward(
-            ctypes.byref(an), ctypes.byref(ag), ctypes.byref(cn), int(shared_embedding), _p(batch), batch.shape[0],
-            _p(actions), _p(g_act), _p(ap_det), _p(noise), _p(dq), eps_start, eps_end, eps_decay, box_lo, box_hi, scale, base,
-            _p(ctrl, torch.int64), self._cptr, self.partial, _p(actor_x0), _p(actor_h1), _p(critic_x0), _p(critic_h1),
-            _p(actor_dh), _p(actor_dx0), _p(critic_dh), _p(critic_dx0), _p(da), _p(dout), _p(partial_in), _p(lag_out),
-            _p(nu_grad), _p(gradmax, allow_none=True), _stream()), "rpo_cartsafe_ddpg_actor_backward")
-
     def sac_critic_forward(self, actor, critic_target1, critic_target2, critic1, critic2, scale, base, rows, cap_steps,
                            n_envs, batch_out, idx_out, idx_in, eps_in, sample_seed, sample_salt, noise_seed, noise_id_base,
                            noise_salt, ctrl, max_steps, corr_lr, corr_eps, corr_momentum, box_lo, box_hi, gamma, alpha,
@@ -543,3 +521,30 @@ def sac_actor_backward(env_kernels, actor, critic1, critic2, shared_embedding, b
         base, env_kernels._cptr if is_cart else None, env_kernels.partial if is_cart else 0, *[_p(b) for b in saved],
         *[_p(b) for b in scratch], _p(da1), _p(da2), _p(dout), _p(partial_in), _p(lag_out), _p(nu_grad),
         _p(gradmax, allow_none=True), _stream()), "rpo_sac_actor_backward")
+
+
+def ddpg_actor_forward(env_kernels, actor, critic, scale, base, box_lo, box_hi, eps_start, eps_end, eps_decay, batch, noise_in,
+                       seed, noise_id_base, noise_salt, ctrl, nu, ap_det, noise_out, actions, q_out, dq_out, g_act,
+                       partial_out, actor_x0, actor_h1, critic_x0, critic_h1):
+    is_cart = isinstance(env_kernels, CartSafeKernels)
+    an, cn = actor.net_struct(), critic.net_struct()
+    check(_lib.load().rpo_ddpg_actor_forward(
+        0 if is_cart else 1, ctypes.byref(an), ctypes.byref(cn), scale, base, box_lo, box_hi, eps_start, eps_end, eps_decay,
+        _p(batch), batch.shape[0], _p(noise_in, allow_none=True), seed, noise_id_base, noise_salt, _p(ctrl, torch.int64), _p(nu),
+        env_kernels._cptr if is_cart else None, env_kernels.partial if is_cart else 0, _p(ap_det), _p(noise_out), _p(actions),
+        _p(q_out), _p(dq_out), _p(g_act), _p(partial_out), _p(actor_x0), _p(actor_h1), _p(critic_x0), _p(critic_h1), _stream()),
+        "rpo_ddpg_actor_forward")
+
+
+def ddpg_actor_backward(env_kernels, actor, critic, shared_embedding, batch, actions, g_act, ap_det, noise, dq, eps_start,
+                        eps_end, eps_decay, box_lo, box_hi, scale, base, ctrl, actor_x0, actor_h1, critic_x0, critic_h1,
+                        actor_dh, actor_dx0, critic_dh, critic_dx0, da, dout, partial_in, lag_out, nu_grad, gradmax):
+    is_cart = isinstance(env_kernels, CartSafeKernels)
+    an, cn, ag = actor.net_struct(), critic.net_struct(), actor.grad_struct()
+    check(_lib.load().rpo_ddpg_actor_backward(
+        0 if is_cart else 1, ctypes.byref(an), ctypes.byref(ag), ctypes.byref(cn), int(shared_embedding), _p(batch),
+        batch.shape[0], _p(actions), _p(g_act), _p(ap_det), _p(noise), _p(dq), eps_start, eps_end, eps_decay, box_lo, box_hi,
+        scale, base, _p(ctrl, torch.int64), env_kernels._cptr if is_cart else None, env_kernels.partial if is_cart else 0,
+        _p(actor_x0), _p(actor_h1), _p(critic_x0), _p(critic_h1), _p(actor_dh), _p(actor_dx0), _p(critic_dh), _p(critic_dx0),
+        _p(da), _p(dout), _p(partial_in), _p(lag_out), _p(nu_grad), _p(gradmax, allow_none=True), _stream()),
+        "rpo_ddpg_actor_backward")

@@ -256,3 +256,17 @@ def test_sac_actor_update_pipeline_matches_single_stage_launches(hip, envname, m
     np.testing.assert_allclose(a.agent.critic_target_flat.cpu().numpy(), b.agent.critic_target_flat.cpu().numpy(), rtol=0, atol=1e-7)
     assert torch.equal(a.buffer.rows[:256], b.buffer.rows[:256])
     np.testing.assert_allclose(float(a.last_losses["actor"]), float(b.last_losses["actor"]), rtol=1e-5, atol=1e-6)
+
+
+def test_ddpg_actor_update_pipeline_on_pendulum(hip, monkeypatch):
+    """The env-generic RPODDPG actor pipelines on SpringPendulum-v0 against the single-stage launches (1e-7)."""
+    dev = torch.device("cuda")
+    monkeypatch.setenv("RPO_FUSED_ACTOR", "0")
+    a = _run("ddpg", "pendulum_viol", hip, dev, 24, 256, use_graph=False)
+    assert not a._actor_pipeline
+    monkeypatch.setenv("RPO_FUSED_ACTOR", "1")
+    b = _run("ddpg", "pendulum_viol", hip, dev, 24, 256, use_graph=False)
+    assert b._actor_pipeline
+    np.testing.assert_allclose(a.agent.flat.data.cpu().numpy(), b.agent.flat.data.cpu().numpy(), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(a.agent.nju.weight.detach().cpu().numpy(), b.agent.nju.weight.detach().cpu().numpy(), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(float(a.last_losses["actor"]), float(b.last_losses["actor"]), rtol=1e-5, atol=1e-6)
