@@ -548,6 +548,17 @@ int rpo_pendulum_sac_critic_back(const rpo_mlp* critic_target1_host, const rpo_m
                                  float* q2_out, float* dq1_out, float* dq2_out, float* loss_partial, float* x0_save1,
                                  float* h1_save1, float* x0_save2, float* h1_save2, void* stream);
 
+/* The RPODDPG form of the cut pipeline for SpringPendulum-v0 (rpo_ddpg.py:327-337):
+ *   front: sample -> batch_out [B,16] -> ap_out [B] = pi_targ(s') (tanh box);
+ *   back:  Q_targ(s', next_actions) -> y -> Q(s, a) of batch_rows (pre-activations saved) -> dq, loss_partial. */
+int rpo_pendulum_ddpg_critic_front(const rpo_mlp* actor_target_host, float scale, float base, const float* rows,
+                                   long long cap_steps, int n_envs, int batch, float* batch_out, long long* idx_out,
+                                   const long long* idx_in, unsigned long long sample_seed, unsigned sample_salt,
+                                   const long long* ctrl, float* ap_out, void* stream);
+int rpo_pendulum_ddpg_critic_back(const rpo_mlp* critic_target_host, const rpo_mlp* critic_host, int batch,
+                                  float* batch_rows, const float* next_actions, float gamma, float* q_out, float* qn_out,
+                                  float* dq_out, float* loss_partial, float* x0_save, float* h1_save, void* stream);
+
 /* Policy heads around the MLP kernels.
  * DDPG (model/policy.py:30-31, agent/ddpg_pa.py:108-110): ap = clip(ap_det + eps_t * noise), ap_det = scale*tanh(o)+base.
  *   dout[i] = dap[i] * 1[lo <= ap_det + eps_t*noise <= hi] * scale * (1 - tanh(o)^2); noise NULL: no noise, no clip. */

@@ -84,7 +84,8 @@ class RPODDPG(RPOTrainerBase):
     # ---- fused pipelines (one launch per stage group; CartSafe kernels provide them) -----------------------------
     @property
     def _pipelines(self):
-        return (self.fused is not None and hasattr(self.kernels, "ddpg_critic_forward")
+        k = self.kernels
+        return (self.fused is not None and (hasattr(k, "ddpg_critic_forward") or hasattr(k, "ddpg_critic_front"))
                 and "actor_target" in self.fused.descs and "critic" in self.fused.descs
                 and _env_int("RPO_FUSED_CRITIC", 1))
 
@@ -102,6 +103,21 @@ class RPODDPG(RPOTrainerBase):
         scale, base = self._box_affine
         parts = f.buf("loss_parts", (B + 15) // 16)
         idx_in = self._idx_inject() if self._idx_inject is not None else None
+        if not hasattr(self.kernels, "ddpg_critic_forward"):
+            # SpringPendulum: the chain is cut at the batch-coupled projection (front | project | back)
+            ap = f.buf("crit.ap", B)
+            self.kernels.ddpg_critic_front(f.descs["actor_target"], scale, base, buf.rows, buf.capacity, buf.n_envs,
+                                           self._batch, None, idx_in, buf.seed, 0, buf.ctrl, ap)
+            next_actions = self._project_batch(cols[2], ap)
+            self.kernels.ddpg_critic_back(f.descs["critic_target"], d, self._batch, next_actions, ag.gamma, f.buf("q", B, 1),
+                                          f.buf("qn", B, 1), f.buf("dq", B, 1), parts, f.buf("critic.x0", B, d.ein),
+                                          f.buf("critic.h1", B, d.H))
+            self._zero_grads()
+            gm = self._critic_gradmax()
+            f.backward("critic", state, action, f.buf("dq", B, 1), gradmax=gm)
+            self._gradmax_ready = gm is not None
+            self.last_losses["critic"] = _LazySum(parts)
+            return
         self.kernels.ddpg_critic_forward(
             f.descs["actor_target"], f.descs["critic_target"], d, scale, base, buf.rows, buf.capacity, buf.n_envs,
             self._batch, None, idx_in, buf.seed, 0, buf.ctrl, self.max_steps, self.corr_lr, self.corr_eps,

@@ -494,6 +494,76 @@ __global__ __launch_bounds__(kThreads) void actor_weights_kernel(BwdArgs p) {
     gradmax_flush(p.gradmax, mlp_bwd_weights_body<EIN, H>(p));
 }
 
+// RPODDPG critic forward on SpringPendulum, cut at the batch-coupled projection like the SAC form:
+//   front: sample -> pi_targ(s') (tanh box)                       -> ap_out
+//   back:  Q_targ(s', next_actions) -> y -> Q(s, a) saved -> dq, loss partials   (rpo_ddpg.py:327-337)
+template <int EIN, int H>
+__global__ __launch_bounds__(kFwdThreads) void pend_ddpg_critic_front_kernel(SacCriticFwdArgs p) {
+    __shared__ TileLds<EIN> lds;
+    __shared__ __attribute__((aligned(16))) float4 tile[kRows * PendRow::CH];
+    const int row0 = blockIdx.x * kRows, tid = threadIdx.x;
+    const long long t = p.ctrl[RPO_CTRL_T];
+    sac_sample<PendRow>(p, tile, row0, t);
+    const float* tf = reinterpret_cast<const float*>(tile);
+    if (tid < kRows * PendRow::S) {
+        const int r = tid / PendRow::S, i = tid - r * PendRow::S;
+        lds.in_s[r * kInS + i] = tf[r * PendRow::ROW + PendRow::NS_OFF + i];
+    }
+    mlp_tile_forward<EIN, H>(p.actor, lds, row0, p.batch, nullptr, nullptr, 1, p.scale, p.base);
+    if (tid < kRows && row0 + tid < p.batch) p.ap_out[row0 + tid] = lds.out[tid * 2];
+}
+
+template <int EIN, int H>
+__global__ __launch_bounds__(kFwdThreads) void pend_ddpg_critic_back_kernel(SacCriticFwdArgs p) {
+    __shared__ TileLds<EIN> lds;
+    __shared__ __attribute__((aligned(16))) float4 tile[kRows * PendRow::CH];
+    const int row0 = blockIdx.x * kRows, tid = threadIdx.x, B = p.batch;
+    if (tid < kRows * PendRow::CH) {
+        const int r = tid / PendRow::CH;
+        tile[tid] = row0 + r < B ? reinterpret_cast<const float4*>(p.batch_out)[(size_t)row0 * PendRow::CH + tid]
+                                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    __syncthreads();
+    const float* tf = reinterpret_cast<const float*>(tile);
+    if (tid < kRows * PendRow::S) {
+        const int r = tid / PendRow::S, i = tid - r * PendRow::S;
+        lds.in_s[r * kInS + i] = tf[r * PendRow::ROW + PendRow::NS_OFF + i];
+    }
+    if (tid < kRows) {
+        const bool live = row0 + tid < B;
+        lds.in_a[tid * kInA] = live ? p.next_actions[(size_t)(row0 + tid) * 2] : 0.0f;
+        lds.in_a[tid * kInA + 1] = live ? p.next_actions[(size_t)(row0 + tid) * 2 + 1] : 0.0f;
+    }
+    mlp_tile_forward<EIN, H>(p.critic_target1, lds, row0, B, nullptr, nullptr, 0, 1.0f, 0.0f);
+    float qn = 0.0f;
+    if (tid < kRows) qn = lds.out[tid * 2];
+    __syncthreads();
+    if (tid < kRows * PendRow::S) {
+        const int r = tid / PendRow::S, i = tid - r * PendRow::S;
+        lds.in_s[r * kInS + i] = tf[r * PendRow::ROW + i];
+    }
+    if (tid < kRows * 2) {
+        const int r = tid >> 1, i = tid & 1;
+        lds.in_a[r * kInA + i] = tf[r * PendRow::ROW + PendRow::A_OFF + i];
+    }
+    mlp_tile_forward<EIN, H>(p.critic1, lds, row0, B, p.x0_save1, p.h1_save1, 0, 1.0f, 0.0f);
+    float hub = 0.0f;
+    if (tid < kRows && row0 + tid < B) {
+        const float q = lds.out[tid * 2];
+        const float y = tf[tid * PendRow::ROW + PendRow::R_OFF] + p.gamma * (1.0f - tf[tid * PendRow::ROW + PendRow::D_OFF]) * qn;
+        const float d = q - y, ad = fabsf(d);
+        const float inv_n = 1.0f / (float)B;
+        hub = (ad < 1.0f ? 0.5f * d * d : ad - 0.5f) * inv_n;
+        p.q1_out[row0 + tid] = q;
+        p.q2_out[row0 + tid] = qn;
+        p.dq1_out[row0 + tid] = fminf(fmaxf(d, -1.0f), 1.0f) * inv_n;
+    }
+    if (tid < 64) {
+        const float s = rpo_wave_sum(hub);
+        if (tid == 0) p.loss_partial[blockIdx.x] = s;
+    }
+}
+
 // Env policies of the actor-update pipelines: Complete, the Lagrangian row and the backward of Complete.
 struct CartActEnv {
     typedef CartConsts Consts;
@@ -1209,6 +1279,56 @@ int rpo_sac_actor_backward(int env, const rpo_mlp* actor_host, const rpo_mlp_gra
     const int fl_outputs = actor.E * (actor.S + 1);
     const int grid_w = (actor.H / 16) * (128 / 64) + actor.H / 64 + (fl_outputs + 63) / 64;
     hipLaunchKernelGGL((actor_weights_kernel<128, 256>), dim3(grid_w), dim3(kThreads), 0, (hipStream_t)stream, p.actor);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_pendulum_ddpg_critic_front(const rpo_mlp* actor_target_host, float scale, float base, const float* rows,
+                                   long long cap_steps, int n_envs, int batch, float* batch_out, long long* idx_out,
+                                   const long long* idx_in, unsigned long long sample_seed, unsigned sample_salt,
+                                   const long long* ctrl, float* ap_out, void* stream) {
+    if (!actor_target_host) return RPO_ERR_NULL;
+    if (batch <= 0 || cap_steps <= 0 || n_envs <= 0) return RPO_ERR_ARG;
+    if (!rows || !batch_out || !ctrl || !ap_out) return RPO_ERR_NULL;
+    SacCriticFwdArgs a{};
+    a.actor = to_dev(actor_target_host);
+    if (int e = check_actor(a.actor, 5, 0)) return e;
+    a.scale = scale; a.base = base; a.rows = rows; a.cap_steps = cap_steps; a.n_envs = n_envs; a.batch = batch;
+    a.batch_out = batch_out; a.idx_out = idx_out; a.idx_in = idx_in; a.sample_seed = (uint64_t)sample_seed;
+    a.salt = (uint32_t)sample_salt; a.ctrl = ctrl; a.ap_out = ap_out;
+    const int grid = (batch + kRows - 1) / kRows;
+    if (a.actor.E == 128) {
+        hipLaunchKernelGGL((pend_ddpg_critic_front_kernel<128, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
+    } else if (a.actor.E == 256) {
+        hipLaunchKernelGGL((pend_ddpg_critic_front_kernel<256, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
+    } else {
+        return RPO_ERR_ARG;
+    }
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_pendulum_ddpg_critic_back(const rpo_mlp* critic_target_host, const rpo_mlp* critic_host, int batch,
+                                  float* batch_rows, const float* next_actions, float gamma, float* q_out, float* qn_out,
+                                  float* dq_out, float* loss_partial, float* x0_save, float* h1_save, void* stream) {
+    if (!critic_target_host || !critic_host) return RPO_ERR_NULL;
+    if (batch <= 0) return RPO_ERR_ARG;
+    if (!batch_rows || !next_actions || !q_out || !qn_out || !dq_out || !loss_partial || !x0_save || !h1_save) return RPO_ERR_NULL;
+    SacCriticFwdArgs a{};
+    a.critic_target1 = to_dev(critic_target_host); a.critic1 = to_dev(critic_host);
+    const Mlp* qs[2] = {&a.critic_target1, &a.critic1};
+    for (const Mlp* q : qs)
+        if (q->S != 5 || q->A != 2 || q->cat || q->H != 256 || (q->E != 128 && q->E != 256) || q->E != qs[0]->E || q->n_out != 1 ||
+            q->hd > 1)
+            return RPO_ERR_ARG;
+    a.batch = batch; a.batch_out = batch_rows; a.next_actions = next_actions; a.gamma = gamma; a.q1_out = q_out;
+    a.q2_out = qn_out; a.dq1_out = dq_out; a.loss_partial = loss_partial; a.x0_save1 = x0_save; a.h1_save1 = h1_save;
+    const int grid = (batch + kRows - 1) / kRows;
+    if (a.critic1.E == 128) {
+        hipLaunchKernelGGL((pend_ddpg_critic_back_kernel<128, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL((pend_ddpg_critic_back_kernel<256, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
+    }
     RPO_LAUNCH_CHECK();
     return 0;
 }

@@ -357,6 +357,21 @@ class PendulumKernels(object):
             noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi, max_steps, corr_lr, corr_eps, corr_momentum,
             max_episode_steps, int(auto_reset), viol_thresh, seed, env_id_base, _stream()), "rpo_pendulum_rollout")
 
+    def ddpg_critic_front(self, actor_target, scale, base, rows, cap_steps, n_envs, batch_out, idx_out, idx_in, sample_seed,
+                          sample_salt, ctrl, ap_out):
+        net = actor_target.net_struct()
+        check(_lib.load().rpo_pendulum_ddpg_critic_front(
+            ctypes.byref(net), scale, base, _p(rows), cap_steps, n_envs, batch_out.shape[0], _p(batch_out),
+            _p(idx_out, torch.int64, allow_none=True), _p(idx_in, torch.int64, allow_none=True), sample_seed, sample_salt,
+            _p(ctrl, torch.int64), _p(ap_out), _stream()), "rpo_pendulum_ddpg_critic_front")
+
+    def ddpg_critic_back(self, critic_target, critic, batch_rows, next_actions, gamma, q_out, qn_out, dq_out, loss_partial,
+                         x0_save, h1_save):
+        ct, cr = critic_target.net_struct(), critic.net_struct()
+        check(_lib.load().rpo_pendulum_ddpg_critic_back(
+            ctypes.byref(ct), ctypes.byref(cr), batch_rows.shape[0], _p(batch_rows), _p(next_actions), gamma, _p(q_out),
+            _p(qn_out), _p(dq_out), _p(loss_partial), _p(x0_save), _p(h1_save), _stream()), "rpo_pendulum_ddpg_critic_back")
+
     def sac_critic_front(self, actor, scale, base, box_lo, box_hi, rows, cap_steps, n_envs, batch_out, idx_out, idx_in,
                          eps_in, sample_seed, sample_salt, noise_seed, noise_id_base, noise_salt, ctrl, ap_out, logp_out):
         net = actor.net_struct()

@@ -204,7 +204,7 @@ def test_rollout_pipeline_equals_single_stage_launches(hip, algo, envname, n_env
                                hip.reduce_stats(b.vec.stats[:iters]).cpu().numpy(), rtol=1e-5, atol=1e-9)
 
 
-@pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "cart"), ("sac", "pendulum")])
+@pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "cart"), ("sac", "pendulum"), ("ddpg", "pendulum")])
 def test_critic_forward_pipeline_equals_single_stage_launches(hip, algo, envname, monkeypatch):
     """rpo_cartsafe_{ddpg,sac}_critic_forward (sample -> policy -> projection -> target critics -> critics -> TD/Huber in
     one launch; SpringPendulum: front | batch-coupled projection | back) leaves the same bits behind as the launches it replaces: parameters, targets and replay after 16
