@@ -20,16 +20,8 @@ class _LagrangianBase(RPOTrainerBase):
     """process_action is the identity (ddpg_lag.py:72-75); both multipliers are stepped (ddpg_lag.py:196-198)."""
 
     def _setup_la(self, env, work_dir, name, logger, agent, hp, device, num_envs, seed, backend, shape):
-        import os
-        prev = os.environ.get("RPO_FUSED_MLP")
-        os.environ["RPO_FUSED_MLP"] = "0"                       # torch modules + autograd
-        try:
-            self._setup(env, work_dir, name, logger, agent, hp, device, num_envs, seed, backend, use_graph=False)
-        finally:
-            if prev is None:
-                os.environ.pop("RPO_FUSED_MLP", None)
-            else:
-                os.environ["RPO_FUSED_MLP"] = prev
+        # torch modules + autograd, eager loop: the baselines are comparison points, not part of the tuned hot path
+        self._setup(env, work_dir, name, logger, agent, hp, device, num_envs, seed, backend, use_graph=False, fused=False)
         self.shape = shape
         A = self.kernels.action_dim
         self._noise_b = torch.zeros(self.batch_size, A, device=device)

@@ -139,7 +139,7 @@ class RPOTrainerBase(object):
     sac = False
 
     def _setup(self, env, work_dir, name, logger, agent, hp, device, num_envs=None, seed=None, backend=None,
-               use_graph=None, updates_per_step=None):
+               use_graph=None, updates_per_step=None, fused=None):
         self.env, self.agent, self.device = env, agent, device
         self.work_dir, self.name, self.logger = work_dir, name, logger
         for k, v in hp.items():
@@ -180,7 +180,8 @@ class RPOTrainerBase(object):
         # (RPO_ROWWISE_PROJECTION=1); rollouts are always per lane == the reference's B = 1 calls
         self.batch_reference = not bool(_env_int("RPO_ROWWISE_PROJECTION", 0))
         # hand-written f32-MFMA MLP kernels for actor / critics (RPO_FUSED_MLP=0: the torch modules + autograd)
-        self.fused = FusedNets.build(agent, self.backend, device) if _env_int("RPO_FUSED_MLP", 1) else None
+        want_fused = bool(_env_int("RPO_FUSED_MLP", 1)) if fused is None else bool(fused)
+        self.fused = FusedNets.build(agent, self.backend, device) if want_fused else None
         # updates per vector step: 1 = the reference's loop cadence (rpo_ddpg.py:160-161); num_envs = "UTD-matched":
         # as many batch-`batch_size` updates per env step as the reference performs (metric iii)
         self.updates_per_step = max(1, int(updates_per_step) if updates_per_step is not None
