@@ -336,7 +336,7 @@ def main():
             d, st = clinic[dom], clinic["cartsafe_step_kernel@1M"]
             result["roofline"] = {
                 "bound": d["bound"], "kernel": dom, "achieved": d["rate"], "peak": d["peak"], "unit": d["unit"],
-                "frac": d["frac"], "traffic": None, "launch_us": d["us"], "units_per_launch": d["n"],
+                "frac": d["frac"], "traffic": pmc_traffic(dom, d["n"]), "launch_us": d["us"], "units_per_launch": d["n"],
                 "algorithmic_flops_per_launch": d["work"],
                 "note": "dominant launch of the iteration: ReplayBuffer.sample + pi_targ + projection + Q_targ + Q + TD/Huber "
                         "for 256 samples in one workgroup-per-16-rows pipeline; latency-bound (16 workgroups, each "

@@ -56,5 +56,15 @@ def probe_mlp(reps=5):
         torch.cuda.synchronize()
 
 
+def probe_iter(iters=24):
+    """Whole iterations of the bench trainer, eagerly (every kernel is a separate dispatch the profiler can attribute)."""
+    from bench import make_trainer
+    tr = make_trainer(4096, torch.device("cuda"), 10 ** 9, capacity=64)
+    tr._graphs.enabled = False
+    tr.vec.reset()
+    tr.run_steps(iters)
+    torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
-    {"step": probe_step, "mlp": probe_mlp}[sys.argv[1] if len(sys.argv) > 1 else "step"]()
+    {"step": probe_step, "mlp": probe_mlp, "iter": probe_iter}[sys.argv[1] if len(sys.argv) > 1 else "step"]()
