@@ -48,6 +48,9 @@ WORKLOADS = {
                                    alpha=0.01, automatic_entropy_tuning=False)),
     # BASELINE.json configs[4]: EVOPF-v0, RPODDPG, 1024 envs on one MI355X (scripts/evopf_exp.py:29-31)
     "evopf_ddpg": ("evopf", "ddpg", None),
+    # scripts/evopf_exp_sac.py:30-33
+    "evopf_sac": ("evopf", "sac", dict(lr_actor=1e-4, lr_critic=3e-4, grad_eps=0.1, fixed=False, init_lamb=0.0, init_nju=0.0,
+                                       alpha=0.001, automatic_entropy_tuning=False)),
 }
 EVOPF_HP = dict(batch_size=256, max_steps=10, warmup=0, lr_dual=2e-2, corr_lr=1e-4, eps=0.0001, eps_start=0.0001,
                 eps_epoch=20000, eval_lr=1e-4, eval_steps=50, grad_eps=0.02, corr_momentum=0.0, policy_fre=4,
@@ -67,6 +70,9 @@ def make_trainer(n_envs, device, max_epochs, capacity=None, workload="cart_ddpg"
     envname, algo, over = WORKLOADS[workload]
     if envname == "evopf":
         env, hp = EVOPFEnv(), dict(EVOPF_HP)
+        if over:
+            hp.update(over)
+            hp.pop("gamma", None)                     # evopf_exp_sac.py keeps RPOSAC's default discount
     else:
         env = gym_shim.TimeLimit(CartSafeEnv() if envname == "cart" else SpringPendulumEnv(), 200)
         hp = dict(HP)

@@ -392,6 +392,15 @@ int rpo_evopf_tanh_box_bwd(int n, const float* state, int state_stride, const fl
                            float eps_start, float eps_end, float eps_decay, const long long* ctrl, const float* dap,
                            float* dout, const float* consts_dev, void* stream);
 
+/* RPOSAC's policy head on EVOPF: squashed Gaussian with the state-dependent box (model/policy.py:53-66 with
+ * BoxConstraint.update_box; the clip of agent/sac_pa.py:111).  raw [n,28] = (mean heads [14] | log-std heads [14]) from
+ * rpo_mlp_forward (head_dim 14, n_out 2), eps [n,14]; ap_out [n,14], logp_out [n] (sum over the 14 dimensions, may be
+ * NULL); the backward writes draw [n,28] given dap [n,14] and dlogp = coefficient of log pi in the loss. */
+int rpo_evopf_gauss_head(int n, const float* state, int state_stride, const float* raw, const float* eps, int deterministic,
+                         float* ap_out, float* logp_out, const float* consts_dev, void* stream);
+int rpo_evopf_gauss_head_bwd(int n, const float* state, int state_stride, const float* raw, const float* eps,
+                             const float* dap, float dlogp, float* draw, const float* consts_dev, void* stream);
+
 /* PFFunction.backward (evopf.py:857-910): grad_ap [n,14] = dL/dz given grad_action [n,43] = dL/dy and the completed
  * action; the Jacobians are re-evaluated at that action (the reference keeps those of the last Newton point). */
 int rpo_evopf_complete_bwd(int n, const float* action, const float* grad_action, float* grad_ap, const float* consts_dev,

@@ -58,12 +58,12 @@ class FusedNets(object):
             W1, b1 = _lin(net.affines[1])
             t, n_out, head_dim = dict(Ws=Ws, bs=bs, W0=W0, b0=b0, W1=W1, b1=b1), 1, W1.shape[0]
         elif isinstance(net, GaussianSharedPolicy):
-            if len(net.affines) != 1 or net.affine_mean.weight.shape[0] != 1:
+            if len(net.affines) != 1 or net.affine_mean.weight.shape[0] > 16:
                 raise _Unsupported()
             W0, b0 = _lin(net.affines[0])
             W1, b1 = _lin(net.affine_mean)
             W1b, b1b = _lin(net.affine_log_std)
-            t, n_out = dict(Ws=Ws, bs=bs, W0=W0, b0=b0, W1=W1, b1=b1, W1b=W1b, b1b=b1b), 2
+            t, n_out, head_dim = dict(Ws=Ws, bs=bs, W0=W0, b0=b0, W1=W1, b1=b1, W1b=W1b, b1b=b1b), 2, W1.shape[0]
         else:
             raise _Unsupported()
         H = W0.shape[0]

@@ -169,7 +169,7 @@ class RPODDPG(RPOTrainerBase):
         q, dq, g_act = b("q_pi", B, 1), b("dq_pi", B, 1), b("g_act", B, k.action_dim)
         noise_in = None
         if self._idx_inject is not None:                       # tests replay the reference's draw
-            self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * B, _SALT_ACTOR, hip_ops.STREAM_POLICY,
+            self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * B * k.partial_dim, _SALT_ACTOR, hip_ops.STREAM_POLICY,
                                        self.vec.ctrl)
             noise_in = self._noise_b.view(-1)
         self.backend.ddpg_actor_forward(k, da_, dc, scale, base, self._box_lo, self._box_hi, self.eps_start, self.eps, self.decay_value,
@@ -200,7 +200,7 @@ class RPODDPG(RPOTrainerBase):
         f, ag, B, k = self.fused, self.agent, self.batch_size, self.kernels
         state = cols[0]
         ap_det = self._actor_out("actor", state, save=True)
-        self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * B, _SALT_ACTOR, hip_ops.STREAM_POLICY,
+        self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * B * k.partial_dim, _SALT_ACTOR, hip_ops.STREAM_POLICY,
                                    self.vec.ctrl)
         noise = self._noise_b.view(-1)
         actions = self._complete_only(state, ap_det, noise)
@@ -245,7 +245,7 @@ class RPODDPG(RPOTrainerBase):
         take_action comes from the Philox stream instead of torch's global generator."""
         ag = self.agent
         ap = ag.actor(state)
-        self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * self.batch_size, _SALT_ACTOR,
+        self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * self.batch_size * self.kernels.partial_dim, _SALT_ACTOR,
                                    hip_ops.STREAM_POLICY, self.vec.ctrl)
         ap = ag.actor.box_constraint.clip(ap + self._eps_now() * self._noise_b, state)
         actions = self.base_env.complete_partial(state, ap)

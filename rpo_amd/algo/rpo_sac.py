@@ -51,6 +51,7 @@ class RPOSAC(RPOTrainerBase):
                   batch_size=batch_size, policy_fre=policy_fre, eval_fre=eval_fre, warmup=warmup, max_epochs=max_epochs,
                   fixed=fixed, partial=partial, eps=eps, eps_start=eps_start, eps_epoch=eps_epoch)
         self._setup(env, work_dir, name, logger, agent, hp, device, num_envs, seed, backend, use_graph, updates_per_step)
+        self._act_kw = {}        # the Gaussian head kernels emit finished (boxed, clipped) basic actions, never raw ones
 
     _gauss_policy = True
 
@@ -60,21 +61,24 @@ class RPOSAC(RPOTrainerBase):
 
     # ---- rollout policy (rpo_sac.py:102-110, agent/sac_pa.py:105-115) -------------------------------------------
     def _gauss(self, obs, eps, tag, save=False, deterministic=False, want_logp=True):
-        """Fused squashed-Gaussian policy: MLP kernel -> (mean, log-std head) -> rpo_gauss_head.  Returns the clipped
-        basic action [n] and log pi [n]."""
-        f = self.fused
+        """Fused squashed-Gaussian policy: MLP kernel -> (mean, log-std heads) -> Gaussian head kernel (the env's own one
+        when the box depends on the state).  Returns the clipped basic actions [n * P], log pi [n] and the raw heads."""
+        f, P = self.fused, self.kernels.partial_dim
         n = obs.shape[0]
-        raw = f.forward("actor", obs, None, f.buf(tag + ".raw", n, 2), save=save)
-        ap = f.buf(tag + ".ap", n)
+        raw = f.forward("actor", obs, None, f.buf(tag + ".raw", n, 2 * P), save=save)
+        ap = f.buf(tag + ".ap", n * P)
         logp = f.buf(tag + ".logp", n) if want_logp else None
-        scale, base = self._box_affine
-        self.backend.gauss_head(raw, eps.view(-1), scale, base, self._box_lo, self._box_hi, deterministic, ap, logp)
+        if self._box_affine is None:
+            self.kernels.gauss_head(obs, raw, eps.view(-1), deterministic, ap, logp)
+        else:
+            scale, base = self._box_affine
+            self.backend.gauss_head(raw, eps.view(-1), scale, base, self._box_lo, self._box_hi, deterministic, ap, logp)
         return ap, logp, raw
 
     def _policy_partial(self, obs, warm):
         if warm:
             return None, hip_ops.NOISE_UNIFORM
-        eps = self._draw(self._noise_n, self.vec.env_id_base, 0)
+        eps = self._draw(self._noise_n, self.vec.env_id_base * self.kernels.partial_dim, 0)
         if self.fused is not None:
             return self._gauss(obs, eps, "roll", want_logp=False)[0], hip_ops.NOISE_NONE     # already clipped
         ap, _, _ = self.agent.actor(obs, eps=eps)                   # rsample of the squashed Gaussian
@@ -82,7 +86,7 @@ class RPOSAC(RPOTrainerBase):
 
     def _eval_partial(self, obs):
         if self.fused is not None:
-            zeros = self.fused.buf("eval.eps", obs.shape[0])
+            zeros = self.fused.buf("eval.eps", obs.shape[0] * self.kernels.partial_dim)
             return self._gauss(obs, zeros, "eval", deterministic=True, want_logp=False)[0]
         return self.agent.actor(obs)[2].reshape(-1)                 # the mean action (deterministic=True)
 
@@ -109,7 +113,7 @@ class RPOSAC(RPOTrainerBase):
         parts = f.buf("loss_parts", (B + 15) // 16)
         inject = self._idx_inject is not None                  # tests replay the reference's draws
         idx_in = self._idx_inject() if inject else None
-        eps_in = self._draw(self._noise_b, self.dist.rank * B, _SALT_CRITIC).view(-1) if inject else None
+        eps_in = self._draw(self._noise_b, self.dist.rank * B * self.kernels.partial_dim, _SALT_CRITIC).view(-1) if inject else None
         dq1, dq2 = f.buf("dq1", B, 1), f.buf("dq2", B, 1)
         if not hasattr(self.kernels, "sac_critic_forward"):
             # SpringPendulum: the chain is cut at the batch-coupled projection (front | project | back)
@@ -147,7 +151,7 @@ class RPOSAC(RPOTrainerBase):
             return self._critic_update_pipeline(cols)
         f, ag, B = self.fused, self.agent, self.batch_size
         state, action, next_state, reward, done = cols[:5]
-        eps = self._draw(self._noise_b, self.dist.rank * B, _SALT_CRITIC)
+        eps = self._draw(self._noise_b, self.dist.rank * B * self.kernels.partial_dim, _SALT_CRITIC)
         ap_next, logp, _ = self._gauss(next_state, eps, "crit")
         next_actions = self._project_batch(next_state, ap_next)
         qn1 = f.forward("critic_target1", next_state, next_actions, f.buf("qn1", B, 1))
@@ -182,7 +186,7 @@ class RPOSAC(RPOTrainerBase):
         dq1, dq2 = b("dq1_pi", B, 1), b("dq2_pi", B, 1)
         saved = (b("actor.x0", B, da_.ein), b("actor.h1", B, da_.H), b("critic1.x0", B, d1.ein), b("critic1.h1", B, d1.H),
                  b("critic2.x0", B, d2.ein), b("critic2.h1", B, d2.H))
-        noise_in = self._draw(self._noise_b, self.dist.rank * B, _SALT_ACTOR).view(-1) if self._idx_inject is not None else None
+        noise_in = self._draw(self._noise_b, self.dist.rank * B * self.kernels.partial_dim, _SALT_ACTOR).view(-1) if self._idx_inject is not None else None
         alpha = float(ag.alpha)
         self.backend.sac_actor_forward(k, da_, d1, d2, scale, base, self._box_lo, self._box_hi, alpha, self._batch, noise_in,
                                        self.seed, self.dist.rank * B, _SALT_ACTOR, self.vec.ctrl, ag.nju.weight.view(-1),
@@ -209,7 +213,7 @@ class RPOSAC(RPOTrainerBase):
             return self._actor_update_pipeline(cols)
         f, ag, B, k = self.fused, self.agent, self.batch_size, self.kernels
         state = cols[0]
-        eps = self._draw(self._noise_b, self.dist.rank * B, _SALT_ACTOR)
+        eps = self._draw(self._noise_b, self.dist.rank * B * self.kernels.partial_dim, _SALT_ACTOR)
         ap, logp, raw = self._gauss(state, eps, "pi", save=True)
         actions = self._complete_only(state, ap)
         q1 = f.forward("critic1", state, actions, f.buf("q1", B, 1), save=True)
@@ -217,7 +221,7 @@ class RPOSAC(RPOTrainerBase):
         lag, g_act = f.buf("loss_lag", 1), f.buf("g_act", B, k.action_dim)
         lag.zero_()
         self._zero_grads()                 # parameters AND multipliers (they live in the same flat buffer)
-        k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1))
+        k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1), obs=state)
         # d(-min(q1, q2))/dq: the smaller one takes the gradient, ties are split (torch.min's backward)
         w1 = (q1 < q2).to(torch.float32) + 0.5 * (q1 == q2).to(torch.float32)
         dq1, dq2 = f.buf("dq1", B, 1), f.buf("dq2", B, 1)
@@ -228,11 +232,15 @@ class RPOSAC(RPOTrainerBase):
         f.backward_pair("critic1", "critic2", state, actions, dq1, dq2, da1, da2, param_grads=shared,
                         first_layer_state_only=True)
         da1.add_(da2).add_(g_act)
-        dap, draw = f.buf("dap", B), f.buf("draw", B, 2)
-        k.complete_bwd(state, da1, dap)
-        scale, base = self._box_affine
-        self.backend.gauss_head_bwd(raw, eps.view(-1), dap, float(ag.alpha) / B, scale, base, self._box_lo, self._box_hi,
-                                    draw)
+        P = k.partial_dim
+        dap, draw = f.buf("dap", B * P), f.buf("draw", B, 2 * P)
+        k.complete_bwd(state, da1, dap, action=actions)
+        if self._box_affine is None:
+            k.gauss_head_bwd(state, raw, eps.view(-1), dap, float(ag.alpha) / B, draw)
+        else:
+            scale, base = self._box_affine
+            self.backend.gauss_head_bwd(raw, eps.view(-1), dap, float(ag.alpha) / B, scale, base, self._box_lo,
+                                        self._box_hi, draw)
         f.backward("actor", state, None, draw)
         loss = lag[0] + (float(ag.alpha) * logp.view(-1, 1) - torch.min(q1, q2)).mean()
         self.last_losses["actor"] = loss
@@ -254,7 +262,7 @@ class RPOSAC(RPOTrainerBase):
     def actor_loss(self, state):
         """mean(alpha log pi - min Q(s, Complete(a)) + nu . relu(g)) (rpo_sac.py:321-339) -> (loss, log_pi)."""
         ag = self.agent
-        eps = self._draw(self._noise_b, self.dist.rank * self.batch_size, _SALT_ACTOR)
+        eps = self._draw(self._noise_b, self.dist.rank * self.batch_size * self.kernels.partial_dim, _SALT_ACTOR)
         ap, logp = ag.take_action(state, log_pi=True, eps=eps)
         actions = self.base_env.complete_partial(state, ap)
         q1, q2 = ag.critic(state, actions)

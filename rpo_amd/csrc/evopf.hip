@@ -1,6 +1,7 @@
 // EVOPF-v0 kernels (reference: rpo/env/electrical_grid/evopf.py, data/demand.py, data/price.py; projection loop of
 // rpo/algo/rpo_ddpg.py:72-77,266-305).  One wavefront per env lane / batch row -- see evopf_dev.h.
 #include "evopf_dev.h"
+#include "heads_dev.h"
 
 using namespace rpo_evopf_dev;
 
@@ -352,6 +353,57 @@ __global__ __launch_bounds__(RPO_BLOCK) void evopf_lagrangian_kernel(int n, cons
     }
 }
 
+// Box of basic action j of row i straight from global memory (EVOPFEnv.update, evopf.py:769-783)
+__device__ __forceinline__ void row_box(const float* __restrict__ state, int state_stride, const float* __restrict__ consts,
+                                        int i, int j, float& lo, float& hi) {
+    if (j < 4) { lo = consts[RPO_EVOPF_C_PMIN + 1 + j]; hi = consts[RPO_EVOPF_C_PMAX + 1 + j]; }
+    else if (j < 9) { lo = consts[RPO_EVOPF_C_VMIN + kSpv[j - 4]]; hi = consts[RPO_EVOPF_C_VMAX + kSpv[j - 4]]; }
+    else battery_bounds(state[(size_t)i * state_stride + 2 * NB + j - 9], hi, lo);
+}
+
+// Squashed-Gaussian policy head with the state-dependent box (GaussianSharedPolicy.forward, model/policy.py:53-66, with
+// BoxConstraint.update_box; PDSAC_PA.take_action's clip, agent/sac_pa.py:111): raw [n,28] = (mean[14] | log-std[14]),
+// eps [n,14] -> ap [n,14], logp [n] = sum over the 14 dimensions.  One 16-lane group per row.
+__global__ __launch_bounds__(RPO_BLOCK) void evopf_gauss_head_kernel(int n, const float* __restrict__ state, int state_stride,
+                                                                     const float* __restrict__ raw,
+                                                                     const float* __restrict__ eps, int deterministic,
+                                                                     float* __restrict__ ap, float* __restrict__ logp,
+                                                                     const float* __restrict__ consts) {
+    const int j = threadIdx.x & 15;
+    for (int i = blockIdx.x * (RPO_BLOCK / 16) + (threadIdx.x >> 4); i < n; i += gridDim.x * (RPO_BLOCK / 16)) {
+        float lp = 0.0f;
+        if (j < NP) {
+            float lo, hi;
+            row_box(state, state_stride, consts, i, j, lo, hi);
+            const float scale = (hi - lo) * 0.5f;
+            ap[(size_t)i * NP + j] = rpo_head_dev::gauss_head_row(raw[(size_t)i * 2 * NP + j], raw[(size_t)i * 2 * NP + NP + j],
+                                                                  eps[(size_t)i * NP + j], scale, lo + scale, lo, hi,
+                                                                  deterministic, &lp);
+        }
+        lp += __shfl_xor(lp, 1, 16); lp += __shfl_xor(lp, 2, 16); lp += __shfl_xor(lp, 4, 16); lp += __shfl_xor(lp, 8, 16);
+        if (j == 0 && logp) logp[i] = lp;
+    }
+}
+
+// its backward: draw [n,28] = d loss / d (mean | log-std heads) given dap [n,14] and the coefficient of log pi
+__global__ __launch_bounds__(RPO_BLOCK) void evopf_gauss_head_bwd_kernel(int n, const float* __restrict__ state,
+                                                                         int state_stride, const float* __restrict__ raw,
+                                                                         const float* __restrict__ eps,
+                                                                         const float* __restrict__ dap, float dlogp,
+                                                                         float* __restrict__ draw,
+                                                                         const float* __restrict__ consts) {
+    for (int idx = blockIdx.x * RPO_BLOCK + threadIdx.x; idx < n * NP; idx += gridDim.x * RPO_BLOCK) {
+        const int i = idx / NP, j = idx - i * NP;
+        float lo, hi;
+        row_box(state, state_stride, consts, i, j, lo, hi);
+        const float scale = (hi - lo) * 0.5f;
+        const float2 g = rpo_head_dev::gauss_head_bwd_row(raw[(size_t)i * 2 * NP + j], raw[(size_t)i * 2 * NP + NP + j], eps[idx],
+                                                          dap[idx], dlogp, scale, lo + scale, lo, hi);
+        draw[(size_t)i * 2 * NP + j] = g.x;
+        draw[(size_t)i * 2 * NP + NP + j] = g.y;
+    }
+}
+
 // d/d(raw) of ap = clip(scale(s) * tanh(raw) + base(s) + eps_t * noise, lo(s), hi(s)) (SharedPolicy.forward
 // model/policy.py:24-33 with the volatile box of evopf.py:769-783, then take_action ddpg_pa.py:108-110); elementwise.
 __global__ __launch_bounds__(RPO_BLOCK) void evopf_tanh_box_bwd_kernel(int n, const float* __restrict__ state,
@@ -445,6 +497,28 @@ int rpo_evopf_tanh_box_bwd(int n, const float* state, int state_stride, const fl
     hipLaunchKernelGGL(evopf_tanh_box_bwd_kernel, dim3(rpo_grid_for((long long)n * NP)), dim3(RPO_BLOCK), 0,
                        (hipStream_t)stream, n, state, state_stride, raw, noise, eps_start, eps_end, eps_decay, ctrl, dap,
                        dout, consts_dev);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_evopf_gauss_head(int n, const float* state, int state_stride, const float* raw, const float* eps, int deterministic,
+                         float* ap_out, float* logp_out, const float* consts_dev, void* stream) {
+    if (int e = check_common(n, state, raw, consts_dev)) return e;
+    if (!eps || !ap_out) return RPO_ERR_NULL;
+    if (state_stride < RPO_EVOPF_STATE) return RPO_ERR_ARG;
+    hipLaunchKernelGGL(evopf_gauss_head_kernel, dim3(rpo_grid_for((long long)n * 16)), dim3(RPO_BLOCK), 0, (hipStream_t)stream,
+                       n, state, state_stride, raw, eps, deterministic, ap_out, logp_out, consts_dev);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_evopf_gauss_head_bwd(int n, const float* state, int state_stride, const float* raw, const float* eps,
+                             const float* dap, float dlogp, float* draw, const float* consts_dev, void* stream) {
+    if (int e = check_common(n, state, raw, consts_dev)) return e;
+    if (!eps || !dap || !draw) return RPO_ERR_NULL;
+    if (state_stride < RPO_EVOPF_STATE) return RPO_ERR_ARG;
+    hipLaunchKernelGGL(evopf_gauss_head_bwd_kernel, dim3(rpo_grid_for((long long)n * NP)), dim3(RPO_BLOCK), 0,
+                       (hipStream_t)stream, n, state, state_stride, raw, eps, dap, dlogp, draw, consts_dev);
     RPO_LAUNCH_CHECK();
     return 0;
 }

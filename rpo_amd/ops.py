@@ -287,6 +287,17 @@ class EvopfKernels(object):
                                                  eps_end, eps_decay, _p(ctrl, torch.int64, allow_none=True), _p(dap),
                                                  _p(dout), self._c(dout), _stream()), "rpo_evopf_tanh_box_bwd")
 
+    def gauss_head(self, obs, raw, eps, deterministic, ap_out, logp_out):
+        sp, ss = _row_view(obs, self.obs_dim)
+        check(_lib.load().rpo_evopf_gauss_head(ap_out.numel() // self.partial_dim, sp, ss, _p(raw), _p(eps), int(deterministic), _p(ap_out),
+                                               _p(logp_out, allow_none=True), self._c(raw), _stream()),
+              "rpo_evopf_gauss_head")
+
+    def gauss_head_bwd(self, obs, raw, eps, dap, dlogp, draw):
+        sp, ss = _row_view(obs, self.obs_dim)
+        check(_lib.load().rpo_evopf_gauss_head_bwd(draw.numel() // (2 * self.partial_dim), sp, ss, _p(raw), _p(eps), _p(dap), dlogp, _p(draw),
+                                                   self._c(raw), _stream()), "rpo_evopf_gauss_head_bwd")
+
     def complete_bwd(self, obs, grad_action, grad_ap, action=None):
         check(_lib.load().rpo_evopf_complete_bwd(grad_action.shape[0], _p(action), _p(grad_action), _p(grad_ap),
                                                  self._c(action), _stream()), "rpo_evopf_complete_bwd")

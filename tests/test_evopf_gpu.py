@@ -312,3 +312,19 @@ def test_fused_and_torch_mlp_paths_agree_on_evopf():
     b = _run(48, 12, use_graph=False, fused=False, embed_dim=256, hidden_dim=256)
     np.testing.assert_allclose(a.buffer.rows.cpu().numpy(), b.buffer.rows.cpu().numpy(), rtol=0, atol=2e-4)
     np.testing.assert_allclose(a.agent.flat.data.cpu().numpy(), b.agent.flat.data.cpu().numpy(), rtol=0, atol=2e-5)
+
+
+def test_sac_fused_and_torch_paths_agree_on_evopf():
+    """RPOSAC on EVOPF through the MLP kernels (2 x 14 MFMA heads) + rpo_evopf_gauss_head(_bwd) vs the torch modules:
+    same Philox draws, same transitions, parameters equal to float32 summation order after 12 iterations; hipGraph
+    replay of the fused path equals its eager run."""
+    kw = dict(lr_actor=1e-4, lr_critic=3e-4, grad_eps=0.1, init_lamb=0.0, init_nju=0.1, alpha=0.001,
+              automatic_entropy_tuning=False, fixed=False)
+    a = _run(48, 12, use_graph=False, algo="sac", fused=True, **kw)
+    b = _run(48, 12, use_graph=False, algo="sac", fused=False, embed_dim=256, hidden_dim=256, **kw)
+    assert a.fused is not None and a.fused.descs["actor"].head_dim == 14
+    np.testing.assert_allclose(a.buffer.rows.cpu().numpy(), b.buffer.rows.cpu().numpy(), rtol=0, atol=2e-4)
+    np.testing.assert_allclose(a.agent.flat.data.cpu().numpy(), b.agent.flat.data.cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(a.agent.nju.weight.detach().cpu().numpy(), b.agent.nju.weight.detach().cpu().numpy(), rtol=1e-3, atol=1e-6)
+    c = _run(48, 12, use_graph=True, algo="sac", fused=True, **kw)
+    assert torch.equal(a.agent.flat.data, c.agent.flat.data) and torch.equal(a.buffer.rows, c.buffer.rows)
