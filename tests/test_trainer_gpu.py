@@ -270,3 +270,22 @@ def test_ddpg_actor_update_pipeline_on_pendulum(hip, monkeypatch):
     np.testing.assert_allclose(a.agent.flat.data.cpu().numpy(), b.agent.flat.data.cpu().numpy(), rtol=0, atol=1e-7)
     np.testing.assert_allclose(a.agent.nju.weight.detach().cpu().numpy(), b.agent.nju.weight.detach().cpu().numpy(), rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(float(a.last_losses["actor"]), float(b.last_losses["actor"]), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("algo,envname", [("ddpg", "cart_viol"), ("sac", "cart"), ("sac", "pendulum"), ("ddpg", "pendulum_viol")])
+def test_pipelines_with_a_ragged_batch(hip, algo, envname, monkeypatch):
+    """batch_size = 100 (not a multiple of the 16-row tile): critic-forward and actor-update pipelines against the
+    single-stage launches."""
+    dev = torch.device("cuda")
+    monkeypatch.setenv("RPO_FUSED_CRITIC", "0")
+    monkeypatch.setenv("RPO_FUSED_ACTOR", "0")
+    a = _run(algo, envname, hip, dev, 16, 64, use_graph=False, batch_size=100)
+    assert not a._pipelines and not a._actor_pipeline
+    monkeypatch.setenv("RPO_FUSED_CRITIC", "1")
+    monkeypatch.setenv("RPO_FUSED_ACTOR", "1")
+    b = _run(algo, envname, hip, dev, 16, 64, use_graph=False, batch_size=100)
+    assert b._pipelines and b._actor_pipeline
+    np.testing.assert_allclose(a.agent.flat.data.cpu().numpy(), b.agent.flat.data.cpu().numpy(), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(a.agent.critic_target_flat.cpu().numpy(), b.agent.critic_target_flat.cpu().numpy(), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(float(a.last_losses["critic"]), float(b.last_losses["critic"]), rtol=1e-5)
+    assert torch.equal(a.buffer.rows, b.buffer.rows)
