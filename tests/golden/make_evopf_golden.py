@@ -153,16 +153,23 @@ EVOPF_HP = dict(batch_size=256, max_steps=10, warmup=0, lr_dual=2e-2, corr_lr=1e
                 ex_action_dim=1, gamma=0.95, clip_thres=0.2, shared_param=False, value_type="cat")   # scripts/evopf_exp.py:29-31
 
 
-def gen_train_steps(width=64, sub=1):
-    """RPODDPG.train (rpo_ddpg.py:163-205) for t = 1..4 on EVOPF with the script's hyper-parameters, every random draw
-    recorded; init_nju > 0 so that the Lagrangian term has a gradient.  width = 64: small networks, stored in full;
-    width = 256 (the script's sizes, what the MLP kernels support): parameters stored as every `sub`-th element."""
+EVOPF_SAC_HP = dict({k: v for k, v in EVOPF_HP.items() if k != "gamma"}, grad_eps=0.1, alpha=0.001,
+                    automatic_entropy_tuning=False, fixed=False)                                # scripts/evopf_exp_sac.py:29-32
+
+
+def gen_train_steps(width=64, sub=1, algo="ddpg"):
+    """RPODDPG.train / RPOSAC.train (rpo_ddpg.py:163-205, rpo_sac.py:167-219) for t = 1..4 on EVOPF with the scripts'
+    hyper-parameters, every random draw recorded; init_nju > 0 so that the Lagrangian term has a gradient.  width = 64:
+    small networks, stored in full; width = 256 (the scripts' sizes, what the MLP kernels support): parameters stored as
+    every `sub`-th element."""
+    import torch.distributions.normal as tdn
     torch.manual_seed(123)
     np.random.seed(111)
     env = REF.EVOPFEnv()
     logger = REF.Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=10, name="x")
-    tr = REF.RPODDPG(env, "/tmp/rpo_evopf_golden", name="g", logger=logger, max_epochs=10, capacity=512, embed_dim=width,
-                     hidden_dim=width, init_nju=0.1, device=torch.device("cpu"), **EVOPF_HP)
+    cls, hp = (REF.RPODDPG, EVOPF_HP) if algo == "ddpg" else (REF.RPOSAC, EVOPF_SAC_HP)
+    tr = cls(env, "/tmp/rpo_evopf_golden", name="g", logger=logger, max_epochs=10, capacity=512, embed_dim=width,
+             hidden_dim=width, init_nju=0.1, device=torch.device("cpu"), **hp)
     pack = lambda v: v.numpy().reshape(-1)[::sub].copy() if sub > 1 else v.numpy().copy()   # noqa: E731
     out = {"actor0." + k: pack(v) for k, v in tr.agent.actor.state_dict().items()}
     out.update({"critic0." + k: pack(v) for k, v in tr.agent.critic.state_dict().items()})
@@ -181,7 +188,12 @@ def gen_train_steps(width=64, sub=1):
             s = env.reset() if d else s2
     out.update({"buf." + k: np.stack(v) for k, v in trans.items()})
     draws = {"idx": [], "noise": []}
-    orig_randint, orig_randn_like = np.random.randint, torch.randn_like
+    orig_randint, orig_randn_like, orig_std_normal = np.random.randint, torch.randn_like, tdn._standard_normal
+
+    def rec_std_normal(shape, dtype, device):
+        v = orig_std_normal(shape, dtype, device)
+        draws["noise"].append(v.numpy().copy())
+        return v
 
     def rec_randint(*a, **k):
         v = orig_randint(*a, **k)
@@ -203,20 +215,21 @@ def gen_train_steps(width=64, sub=1):
 
     def rec_a(*a, **k):
         v = oa(*a, **k)
-        losses["actor"].append(float(v))
+        losses["actor"].append(float(v[0] if isinstance(v, tuple) else v))
         return v
     tr.critic_loss, tr.actor_loss = rec_c, rec_a
-    np.random.randint, torch.randn_like = rec_randint, rec_randn_like
+    np.random.randint, torch.randn_like, tdn._standard_normal = rec_randint, rec_randn_like, rec_std_normal
     try:
         for t in range(1, 5):
             tr.train(t)
             if t in (1, 4):
                 out.update({"critic%d.%s" % (t, k): pack(v) for k, v in tr.agent.critic.state_dict().items()})
     finally:
-        np.random.randint, torch.randn_like = orig_randint, orig_randn_like
+        np.random.randint, torch.randn_like, tdn._standard_normal = orig_randint, orig_randn_like, orig_std_normal
     out.update({"actor4." + k: pack(v) for k, v in tr.agent.actor.state_dict().items()})
     out.update({"critic_target4." + k: pack(v) for k, v in tr.agent.critic_target.state_dict().items()})
-    out.update({"actor_target4." + k: pack(v) for k, v in tr.agent.actor_target.state_dict().items()})
+    if algo == "ddpg":
+        out.update({"actor_target4." + k: pack(v) for k, v in tr.agent.actor_target.state_dict().items()})
     out["nju4"] = tr.agent.nju.weight.detach().numpy().copy()
     out["idx"] = np.stack(draws["idx"])
     for i, z in enumerate(draws["noise"]):
@@ -224,7 +237,7 @@ def gen_train_steps(width=64, sub=1):
     out["n_noise"] = len(draws["noise"])
     out["critic_losses"] = np.array(losses["critic"])
     out["actor_losses"] = np.array(losses["actor"])
-    save("train_steps_ddpg_evopf" + ("" if width == 64 else str(width)), **out)
+    save("train_steps_%s_evopf" % algo + ("" if width == 64 else str(width)), **out)
 
 
 def gen_training_stats(steps=960, seeds=(0, 1, 2)):
@@ -256,8 +269,12 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["stats"]:                              # ~11 minutes, generated on request only
         gen_training_stats()
         sys.exit(0)
+    if sys.argv[1:] == ["sac"]:
+        gen_train_steps(width=256, sub=8, algo="sac")
+        sys.exit(0)
     gen_env()
     gen_step()
     gen_project()
     gen_train_steps()
     gen_train_steps(width=256, sub=8)
+    gen_train_steps(width=256, sub=8, algo="sac")

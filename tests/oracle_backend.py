@@ -252,6 +252,32 @@ class EvopfKernels(_EnvKernels):
             g = np.where((pre < lo) | (pre > hi), 0.0, g)
         _put(dout, g)
 
+    def gauss_head(self, obs, raw, eps, deterministic, ap_out, logp_out):
+        """GaussianSharedPolicy.forward (model/policy.py:53-66) with the volatile box (evopf.py:769-783) + the clip of
+        PDSAC_PA.take_action (agent/sac_pa.py:111); raw [n,28] = (mean | log-std heads)."""
+        n = ap_out.numel() // 14
+        lo, hi = oe.partial_box(_np(obs).astype(np.float64))
+        scale, r, e = (hi - lo) * 0.5, _np(raw).reshape(n, 28).astype(np.float64), _np(eps).reshape(n, 14).astype(np.float64)
+        ls = np.clip(r[:, 14:] - 3.0, -23.0, -2.0)
+        y = np.tanh(r[:, :14] + e * np.exp(ls))
+        if logp_out is not None:
+            _put(logp_out, (-0.5 * e * e - ls - 0.9189385332046727 - np.log(scale * (1 - y * y) + 1e-6)).sum(axis=1))
+        a = scale * (np.tanh(r[:, :14]) if deterministic else y) + lo + scale
+        _put(ap_out, np.clip(a, lo, hi))
+
+    def gauss_head_bwd(self, obs, raw, eps, dap, dlogp, draw):
+        n = draw.numel() // 28
+        lo, hi = oe.partial_box(_np(obs).astype(np.float64))
+        scale, r, e = (hi - lo) * 0.5, _np(raw).reshape(n, 28).astype(np.float64), _np(eps).reshape(n, 14).astype(np.float64)
+        lsr = r[:, 14:] - 3.0
+        sd = np.exp(np.clip(lsr, -23.0, -2.0))
+        y = np.tanh(r[:, :14] + e * sd)
+        omy = 1 - y * y
+        a = scale * y + lo + scale
+        gx = _np(dap).reshape(n, 14) * scale * omy * ((a >= lo) & (a <= hi)) + dlogp * (2 * scale * y * omy) / (scale * omy + 1e-6)
+        dls = (gx * e * sd - dlogp) * ((lsr >= -23.0) & (lsr <= -2.0))
+        _put(draw, np.concatenate([gx, dls], axis=1))
+
     def complete_bwd(self, obs, grad_action, grad_ap, action=None):
         a = _np(action).astype(np.float64)
         jac = oe.eq_jac(a)
@@ -493,8 +519,8 @@ def _mlp_backward(d, s, a, x0, h1, dout, dh, dx0, da=None, param_grads=True, fir
         g["W1"] += dout[:, :hd].T @ hr
         g["b1"] += dout[:, :hd].sum(0) if hd > 1 else dout[:, 0].sum()
         if d.n_out > 1:
-            g["W1b"] += dout[:, 1:2].T @ hr
-            g["b1b"] += dout[:, 1].sum()
+            g["W1b"] += dout[:, hd:2 * hd].T @ hr
+            g["b1b"] += dout[:, hd:2 * hd].sum(0) if hd > 1 else dout[:, 1].sum()
 
 
 def tanh_box_bwd(dap, ap_det, noise, eps_start, eps_end, eps_decay, ctrl, lo, hi, scale, base, dout):

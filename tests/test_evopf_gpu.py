@@ -262,6 +262,16 @@ def test_update_matches_reference_on_gpu(envname, fused):
     tsg.check_evopf_update(*out)
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused_mlp_256", "torch_mlp_256"])
+def test_sac_update_matches_reference_on_gpu(fused):
+    """RPOSAC.train for t = 1..4 on EVOPF (scripts/evopf_exp_sac.py hyper-parameters; 14-dimensional squashed-Gaussian head
+    in the state-dependent box) against the reference fixture, every random draw replayed."""
+    import test_train_step_golden as tsg
+    from rpo_amd import ops
+    out = tsg.run_product_update(_golden, "sac", "evopf256", ops, torch.device("cuda"), fused=fused)
+    tsg.check_evopf_update(*out, algo="sac")
+
+
 def _run(n_envs, iters, use_graph, seed_all=5, algo="ddpg", fused=False, **extra):
     import test_train_step_golden as tsg
     from rpo_amd import ops

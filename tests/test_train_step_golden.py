@@ -135,6 +135,9 @@ def _build_trainer(algo, envname, backend, device, **extra):
     if envname.startswith("evopf"):
         from rpo_amd.env import EVOPFEnv
         args = dict(EVOPF_HP)
+        if algo == "sac":                                       # scripts/evopf_exp_sac.py:29-32
+            del args["gamma"]
+            args.update(grad_eps=0.1, alpha=0.001, automatic_entropy_tuning=False, fixed=False)
         if envname != "evopf":                                  # "evopf256": the script's network sizes
             args["embed_dim"] = args["hidden_dim"] = int(envname[5:])
         args.update(extra)
@@ -243,12 +246,23 @@ def test_evopf_trainer_host_logic_matches_reference_update(golden, envname, fuse
     check_evopf_update(g, tr, closs, aloss, proxy)
 
 
-def check_evopf_update(g, tr, closs, aloss, proxy):
+@pytest.mark.parametrize("fused", [True, False], ids=["fused_mlp_256", "torch_mlp_256"])
+def test_evopf_sac_trainer_host_logic_matches_reference_update(golden, fused):
+    """RPOSAC on EVOPF-v0 (scripts/evopf_exp_sac.py; 14-dimensional Gaussian head squashed into the state-dependent
+    box): four updates against the reference fixture, oracle backend."""
+    torch.set_num_threads(1)
+    g, tr, closs, aloss, proxy = run_product_update(golden, "sac", "evopf256", ob, torch.device("cpu"), fused=fused)
+    check_evopf_update(g, tr, closs, aloss, proxy, algo="sac")
+
+
+def check_evopf_update(g, tr, closs, aloss, proxy, algo="ddpg"):
     ag = tr.agent
     np.testing.assert_allclose(closs, g["critic_losses"], rtol=1e-4)
     np.testing.assert_allclose(aloss, g["actor_losses"], rtol=1e-3, atol=1e-5)
-    for name, net, tol in (("critic4", ag.critic, 5e-6), ("critic_target4", ag.critic_target, 5e-6),
-                           ("actor4", ag.actor, 2e-5), ("actor_target4", ag.actor_target, 2e-5)):
+    nets = [("critic4", ag.critic, 5e-6), ("critic_target4", ag.critic_target, 5e-6), ("actor4", ag.actor, 2e-5)]
+    if algo == "ddpg":
+        nets.append(("actor_target4", ag.actor_target, 2e-5))
+    for name, net, tol in nets:
         for k, v in sd(g, name).items():
             np.testing.assert_allclose(like(g, net.state_dict()[k]), v, rtol=0, atol=tol, err_msg=name + "." + k)
     np.testing.assert_allclose(ag.nju.weight.detach().cpu().numpy(), g["nju4"], rtol=1e-4, atol=1e-6)
