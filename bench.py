@@ -265,12 +265,15 @@ def main():
     pre = make_trainer(n_total, device, 10 ** 9, capacity=64, workload=args.workload)
     pre.vec.reset()
     pre.run_steps(1500)
+    pre._harvest(final=True)                # first use of the statistics path (gather / reduce / copy-out kernels)
     torch.cuda.synchronize()
     del pre
-    total_iters = args.warmup + args.steps
-    tr = make_trainer(n_total, device, total_iters, workload=args.workload)
+    tr = make_trainer(n_total, device, 10 ** 9, workload=args.workload)
     headline = args.workload == "cart_ddpg"
     tr.vec.reset()
+    # untimed setup, independent of --warmup: three eager passes + capture of every hipGraph the steady state replays
+    # (single iterations with / without the policy step, and the multi-iteration window), like a compile step
+    tr.run_steps(5 * max(tr._cycle, 4))
 
     def fence():
         torch.cuda.synchronize()
@@ -278,7 +281,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    tr.run_steps(args.warmup)               # includes the three eager passes + hipGraph capture of every phase
+    tr.run_steps(args.warmup)
+    if os.environ.get("RPO_BENCH_DEBUG"):    # extra untimed windows, to see drift / host stalls (stderr)
+        for w in range(6):
+            fence()
+            tw = time.perf_counter()
+            tr.run_steps(500)
+            fence()
+            log("debug window %d: %.4f ms/iter" % (w, (time.perf_counter() - tw) / 500 * 1e3))
     fence()
     t0 = time.perf_counter()
     tr.run_steps(args.steps)

@@ -240,8 +240,8 @@ def gen_train_steps(width=64, sub=1, algo="ddpg"):
     save("train_steps_%s_evopf" % algo + ("" if width == 64 else str(width)), **out)
 
 
-def gen_training_stats(steps=960, seeds=(0, 1, 2)):
-    """Statistics of short training runs of the reference on EVOPF (scripts/evopf_exp.py hyper-parameters; ~0.22 s per
+def gen_training_stats(steps=960, seeds=(0, 1, 2), algo="ddpg"):
+    """Statistics of short training runs of the reference on EVOPF (scripts/evopf_exp{,_sac}.py hyper-parameters; ~0.22 s per
     step on one core here): per seed [logged steps, violation rate (max(max_ineq, max_eq) > 1e-3), mean max_ineq, mean
     max_eq, max max_eq, mean episodic return, the same over the second half]."""
     import contextlib
@@ -252,8 +252,9 @@ def gen_training_stats(steps=960, seeds=(0, 1, 2)):
         torch.manual_seed(123 + seed)
         env = REF.EVOPFEnv()
         logger = REF.Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=steps, name="x")
-        tr = REF.RPODDPG(env, "/tmp/rpo_evopf_golden", name="x", logger=logger, max_epochs=steps, capacity=20000,
-                         device=torch.device("cpu"), **EVOPF_HP)
+        cls, hp = (REF.RPODDPG, EVOPF_HP) if algo == "ddpg" else (REF.RPOSAC, EVOPF_SAC_HP)
+        tr = cls(env, "/tmp/rpo_evopf_golden", name="x", logger=logger, max_epochs=steps, capacity=20000,
+                 device=torch.device("cpu"), **hp)
         with contextlib.redirect_stdout(io.StringIO()):
             tr.run(eval=False)
         n = logger.pointer
@@ -261,13 +262,13 @@ def gen_training_stats(steps=960, seeds=(0, 1, 2)):
         viol = np.maximum(mi, me) > 1e-3
         rows.append([n, viol.mean(), mi.mean(), me.mean(), me.max(), rw.mean(), rw[n // 2:].mean()])
         print("seed", seed, rows[-1], flush=True)
-    save("training_stats_ddpg_evopf", stats=np.array(rows), steps=steps,
+    save("training_stats_%s_evopf" % algo, stats=np.array(rows), steps=steps,
          columns=["logged", "viol_rate", "mean_max_ineq", "mean_max_eq", "max_max_eq", "mean_return", "mean_return_2nd_half"])
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] == ["stats"]:                              # ~11 minutes, generated on request only
-        gen_training_stats()
+    if sys.argv[1:2] == ["stats"]:                             # ~11 minutes each, generated on request only
+        gen_training_stats(algo=(sys.argv[2:] or ["ddpg"])[0])
         sys.exit(0)
     if sys.argv[1:] == ["sac"]:
         gen_train_steps(width=256, sub=8, algo="sac")

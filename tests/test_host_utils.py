@@ -69,3 +69,42 @@ def test_checkpoint_roundtrip(tmp_path):
     # exact resume: the targets are restored as they were (not hard-updated like agent/ddpg_pa.py:96-99 does)
     assert torch.equal(b.agent.critic_target_flat, a.agent.critic_target_flat)
     assert torch.equal(b.agent.actor_target_flat, a.agent.actor_target_flat)
+
+
+def test_harvest_bookkeeping_matches_per_row_loop(capsys):
+    """Trainer._harvest turns statistics rows into Logger rows with whole-array operations; compare with the per-row
+    bookkeeping of the reference loop (rpo_ddpg.py:120-137: every step's max violations are logged with the return of
+    the episode that step belongs to, once it has finished) over several harvests, a logger that fills up, and rows
+    left pending across harvests."""
+    from rpo_amd import ops as hip_ops
+    S = hip_ops.STAT
+    torch.manual_seed(0)
+    tr = build_trainer("ddpg", "cart", ob, torch.device("cpu"), num_envs=1)
+    rng = np.random.default_rng(3)
+    cap = tr.vec.stats.shape[0]
+    total = 700
+    stats = np.zeros((total, hip_ops.STATS_SUB, hip_ops.STATS_LEN), dtype=np.float32)
+    stats[:, 0, S["max_ineq_sum"]] = rng.random(total)
+    stats[:, 0, S["max_eq_sum"]] = rng.random(total) * 0.1
+    ends = np.sort(rng.choice(np.arange(5, total - 40), size=9, replace=False))
+    stats[ends, 0, S["episodes"]] = 1
+    stats[ends, 0, S["return_sum"]] = rng.random(9) * 100
+    stats[ends, 0, S["length_sum"]] = rng.integers(1, 200, 9)
+    tr.logger = Logger(("epoch", "reward", "max_ineq", "max_eq"), epochs=int(ends[-2]) + 5, times=1)   # fills up early
+    want, pending = [], []
+    for i in range(total):                                     # the per-row form
+        pending.append((i, stats[i, 0, S["max_ineq_sum"]], stats[i, 0, S["max_eq_sum"]]))
+        if stats[i, 0, S["episodes"]] > 0:
+            want.extend((ep, stats[i, 0, S["return_sum"]], mi, me) for ep, mi, me in pending)
+            pending = []
+    want = np.array(want[:tr.logger.capacity], dtype=np.float64)
+    for lo, hi in ((0, 3), (3, 250), (250, 251), (251, 640), (640, 700)):
+        tr.vec.stats[torch.arange(lo, hi) % cap] = torch.tensor(stats[lo:hi])
+        tr._t = hi
+        tr._harvest()
+    assert tr.logger.pointer == len(want) == tr.logger.capacity
+    for col, key in enumerate(("epoch", "reward", "max_ineq", "max_eq")):
+        np.testing.assert_allclose(tr.logger.tracker[key][:len(want)], want[:, col], rtol=1e-6)
+    assert [int(p[0]) for p in tr._pending] == list(range(int(ends[-1]) + 1, total))
+    out = capsys.readouterr().out
+    assert out.count("episode") == 9 and ("episode %d ends." % (ends[0] + 1)) in out

@@ -63,6 +63,28 @@ def test_graph_replay_equals_eager(hip, algo, envname, fused):
     assert torch.equal(a.vec.stats[:24], b.vec.stats[:24])
 
 
+@pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "cart"), ("ddpg", "pendulum")])
+def test_multi_iteration_graph_equals_single_iteration_graphs(hip, algo, envname, monkeypatch):
+    """RPO_GRAPH_CYCLE: one hipGraph per 8 iterations (two policy_fre periods) against one graph per iteration and
+    against eager launches; 70 iterations = 3 eager passes of the window, its capture, 4 replays and a ragged tail."""
+    dev = torch.device("cuda")
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
+    a = _run(algo, envname, hip, dev, 70, 256, use_graph=True)
+    assert a._cycle == 8 and a._graphs.entries[("cycle", 8)]["graph"] is not None
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "1")
+    b = _run(algo, envname, hip, dev, 70, 256, use_graph=True)
+    assert ("cycle", 8) not in b._graphs.entries
+    c = _run(algo, envname, hip, dev, 70, 256, use_graph=False)
+    for other in (b, c):
+        assert torch.equal(a.vec.internal, other.vec.internal)
+        assert torch.equal(a.buffer.rows, other.buffer.rows)
+        assert torch.equal(a.agent.flat.data, other.agent.flat.data)
+        assert torch.equal(a.agent.critic_target_flat, other.agent.critic_target_flat)
+        assert torch.equal(a.agent.nju.weight, other.agent.nju.weight)
+        assert torch.equal(a.vec.stats[:70], other.vec.stats[:70])
+    assert int(a.vec.ctrl[0]) == 70 and a._t == 70 and a._updates == b._updates == 70
+
+
 @pytest.mark.parametrize("algo,envname", CASES)
 def test_iterations_match_oracle_backend(hip, algo, envname):
     import oracle_backend as ob
