@@ -323,7 +323,7 @@ def main():
         ro = make_trainer(EPG, device, 10 ** 9, capacity=64, workload=args.workload) if world == 1 else None
         if ro is not None:
             ro.vec.reset()
-            ro.run_steps(50, train=False)
+            ro.run_steps(5 * max(ro._cycle, 4), train=False)      # eager passes + graph capture
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             ro.run_steps(1000, train=False)

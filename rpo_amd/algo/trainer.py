@@ -351,24 +351,36 @@ class RPOTrainerBase(object):
             self._graphs.run((warm, do_train, actor_step, i), fn)
             self.dist.mean_(reduce_after)
 
-    def _extra_update(self, k, actor_step):
-        """k-th additional update of the current vector step (updates_per_step > 1): same kernels as the first one,
-        with ctrl[RPO_CTRL_UPDATES] = k separating its Philox draws."""
-        def body():
-            self.vec.ctrl[hip_ops.CONST["RPO_CTRL_UPDATES"]] += 1
-            cols = self._sample()
-            self._critic_update(cols)
-            fl = self.agent.flat
-            self.dist.mean_([fl.gradient(fl.critic_range)])
-            self._critic_step(actor_step)
-            if actor_step:
-                out = self._actor_update(cols)
-                self.dist.mean_([fl.gradient(fl.policy_bucket)])
-                self._actor_step(out)
-        if self.dist.on:
-            body()                      # collectives inside: eager
-        else:
-            self._graphs.run(("extra", actor_step), body)
+    def _extra_body(self, actor_step):
+        self.vec.ctrl[hip_ops.CONST["RPO_CTRL_UPDATES"]] += 1
+        cols = self._sample()
+        self._critic_update(cols)
+        fl = self.agent.flat
+        self.dist.mean_([fl.gradient(fl.critic_range)])
+        self._critic_step(actor_step)
+        if actor_step:
+            out = self._actor_update(cols)
+            self.dist.mean_([fl.gradient(fl.policy_bucket)])
+            self._actor_step(out)
+
+    def _extra_updates(self):
+        """The 2nd .. updates_per_step-th update of the current vector step: same kernels as the first one, with
+        ctrl[RPO_CTRL_UPDATES] = k separating their Philox draws; windows of RPO_GRAPH_CYCLE updates share a hipGraph."""
+        F, k, U = self.policy_fre, 1, self.updates_per_step
+        while k < U:
+            L = self._cycle
+            if L > 1 and U - k >= L and self._updates % F == 0 and self._graphs.enabled and not self.dist.on:
+                base = self._updates
+                self._graphs.run(("extra", L), lambda: [self._extra_body((base + j + 1) % F == 0) for j in range(L)])
+            else:
+                L = 1
+                actor_step = (self._updates + 1) % F == 0
+                if self.dist.on:
+                    self._extra_body(actor_step)                # collectives inside: eager
+                else:
+                    self._graphs.run(("extra", actor_step), lambda: self._extra_body(actor_step))
+            self._updates += L
+            k += L
 
     def train(self, t):
         """One constrained policy update at loop index ``t`` (rpo_ddpg.py:163-205), eagerly, without a rollout."""
@@ -422,17 +434,15 @@ class RPOTrainerBase(object):
             if L > 1:
                 # one hipGraph for L consecutive iterations (policy_fre-periodic launch pattern): the same launches
                 # in the same order as L single-iteration replays, minus L - 1 graph-to-graph gaps (8.5 us each)
-                self._graphs.run(("cycle", L), lambda: [fn() for i in range(L) for fn, _ in
-                                                        self._segments(False, True, (t + i + 1) % self.policy_fre == 0)])
-                self._updates += L
+                self._graphs.run(("cycle", L, do_train), lambda: [fn() for i in range(L) for fn, _ in self._segments(
+                    False, do_train, do_train and (t + i + 1) % self.policy_fre == 0)])
+                self._updates += L if do_train else 0
             else:
                 self._iteration(warm, do_train, actor_step)
                 if do_train:
                     self._updates += 1
                     if self.updates_per_step > 1:
-                        for k in range(1, self.updates_per_step):
-                            self._updates += 1
-                            self._extra_update(k, self._updates % self.policy_fre == 0)
+                        self._extra_updates()
                         self.vec.ctrl[hip_ops.CONST["RPO_CTRL_UPDATES"]] = 0
             for _ in range(L):
                 self._t = t = t + 1
@@ -448,11 +458,12 @@ class RPOTrainerBase(object):
 
     def _cycle_len(self, t, left, warm, do_train, eval):
         """Iterations the next launch may cover: RPO_GRAPH_CYCLE (default 16, rounded to a multiple of policy_fre) in the
-        steady state of a single-rank graph run, when the window starts on a policy_fre boundary and neither an
-        evaluation nor the statistics harvest falls inside it; otherwise 1."""
+        steady state of a single-rank graph run (training: the window starts on a policy_fre boundary; or rollouts only),
+        when neither an evaluation nor the statistics harvest falls inside it; otherwise 1."""
         L = self._cycle
-        if (L <= 1 or left < L or warm or not do_train or t < self.warmup or t % self.policy_fre or self.dist.on
-                or self.updates_per_step > 1 or not self._graphs.enabled):
+        if L <= 1 or left < L or warm or self.dist.on or not self._graphs.enabled:
+            return 1
+        if do_train and (t < self.warmup or t % self.policy_fre or self.updates_per_step > 1):
             return 1
         if eval and (t // self.eval_fre + 1) * self.eval_fre < t + L:
             return 1

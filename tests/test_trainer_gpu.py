@@ -70,10 +70,10 @@ def test_multi_iteration_graph_equals_single_iteration_graphs(hip, algo, envname
     dev = torch.device("cuda")
     monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
     a = _run(algo, envname, hip, dev, 70, 256, use_graph=True)
-    assert a._cycle == 8 and a._graphs.entries[("cycle", 8)]["graph"] is not None
+    assert a._cycle == 8 and a._graphs.entries[("cycle", 8, True)]["graph"] is not None
     monkeypatch.setenv("RPO_GRAPH_CYCLE", "1")
     b = _run(algo, envname, hip, dev, 70, 256, use_graph=True)
-    assert ("cycle", 8) not in b._graphs.entries
+    assert ("cycle", 8, True) not in b._graphs.entries
     c = _run(algo, envname, hip, dev, 70, 256, use_graph=False)
     for other in (b, c):
         assert torch.equal(a.vec.internal, other.vec.internal)
@@ -83,6 +83,40 @@ def test_multi_iteration_graph_equals_single_iteration_graphs(hip, algo, envname
         assert torch.equal(a.agent.nju.weight, other.agent.nju.weight)
         assert torch.equal(a.vec.stats[:70], other.vec.stats[:70])
     assert int(a.vec.ctrl[0]) == 70 and a._t == 70 and a._updates == b._updates == 70
+
+
+def test_multi_iteration_graph_of_rollouts_only(hip, monkeypatch):
+    dev = torch.device("cuda")
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
+    out = []
+    for use_graph in (True, False):
+        torch.manual_seed(5)
+        tr = build_trainer("ddpg", "cart", hip, dev, num_envs=256, use_graph=use_graph)
+        tr.vec.reset()
+        tr.run_steps(70, train=False)
+        torch.cuda.synchronize()
+        out.append(tr)
+    a, c = out
+    assert a._graphs.entries[("cycle", 8, False)]["graph"] is not None and a._updates == 0
+    assert torch.equal(a.vec.internal, c.vec.internal) and torch.equal(a.buffer.rows, c.buffer.rows)
+    assert torch.equal(a.vec.stats[:70], c.vec.stats[:70]) and int(a.vec.ctrl[0]) == 70
+
+
+@pytest.mark.parametrize("algo", ["ddpg", "sac"])
+def test_multi_update_graph_in_utd_mode(hip, algo, monkeypatch):
+    """updates_per_step = 23: the 22 extra updates of a vector step run as two 8-update hipGraph windows + single-update
+    graphs (alignment to policy_fre, ragged tail); same bits as eager launches."""
+    dev = torch.device("cuda")
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
+    out = []
+    for use_graph in (True, False):
+        out.append(_run(algo, "cart", hip, dev, 6, 64, use_graph=use_graph, updates_per_step=23))
+    a, c = out
+    assert a._graphs.entries[("extra", 8)]["graph"] is not None and a._updates == c._updates == 6 * 23
+    assert torch.equal(a.agent.flat.data, c.agent.flat.data) and torch.equal(a.buffer.rows, c.buffer.rows)
+    assert torch.equal(a.agent.critic_target_flat, c.agent.critic_target_flat)
+    assert int(a.agent.critic_optim.step_dev[0]) == 6 * 23
+    assert int(a.agent.actor_optim.step_dev[0]) == int(c.agent.actor_optim.step_dev[0]) >= 6 * 23 // 4 - 1
 
 
 @pytest.mark.parametrize("algo,envname", CASES)
