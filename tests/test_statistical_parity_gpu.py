@@ -63,25 +63,31 @@ def test_training_statistics_match_reference(golden, algo, envname):
     assert got[:, 0].min() > 0.9 * steps                         # the logger received (almost) every step
 
 
-def test_evopf_training_statistics_match_reference(golden):
-    """EVOPF-v0, RPODDPG with the hyper-parameters of scripts/evopf_exp.py: 3 seeds x 960 iterations (40 days) of the
-    reference (on the pypower stand-in, tests/golden/make_evopf_golden.py stats) vs the shipped trainer at num_envs = 1 on
-    the HIP kernels (MLP kernels, wave-per-lane power flow).  Different random days and exploration streams, so only
-    seed-averaged statistics are compared: violation rate within 3 SE + 0.05, mean max-inequality violation within
-    3 SE + 30 %, mean return within 3 SE + 15 %; the equalities hold to the level the reference reaches (GRG drift)."""
+@pytest.mark.parametrize("algo", ["ddpg", "sac"])
+def test_evopf_training_statistics_match_reference(golden, algo):
+    """EVOPF-v0, RPODDPG / RPOSAC with the hyper-parameters of scripts/evopf_exp.py / evopf_exp_sac.py: 3 seeds x 960
+    iterations (40 days) of the reference (on the pypower stand-in, tests/golden/make_evopf_golden.py stats [sac]) vs the
+    shipped trainer at num_envs = 1 on the HIP kernels (MLP kernels, wave-per-lane power flow).  Different random days and
+    exploration streams, so only seed-averaged statistics are compared: violation rate within 3 SE + 0.05, mean
+    max-inequality violation within 3 SE + 30 %, mean return within 3 SE + 15 %; the equalities hold to the level the
+    reference reaches (GRG drift)."""
     from rpo_amd import ops
-    from rpo_amd.algo import RPODDPG
+    from rpo_amd.algo import RPODDPG, RPOSAC
     from rpo_amd.env import EVOPFEnv
     from rpo_amd.utils.logger import Logger
     import test_train_step_golden as tsg
-    g = golden("training_stats_ddpg_evopf")
+    g = golden("training_stats_%s_evopf" % algo)
     ref, steps = g["stats"], int(g["steps"])
     hp = {k: v for k, v in tsg.EVOPF_HP.items() if k not in ("embed_dim", "hidden_dim", "init_nju", "capacity")}
+    if algo == "sac":                                            # scripts/evopf_exp_sac.py:29-32
+        del hp["gamma"]
+        hp.update(grad_eps=0.1, alpha=0.001, automatic_entropy_tuning=False, fixed=False)
+    cls = RPODDPG if algo == "ddpg" else RPOSAC
     rows = []
     for seed in range(3):
         torch.manual_seed(123 + seed)
-        tr = RPODDPG(EVOPFEnv(device="cuda"), "/tmp/rpo_test", name="t", logger=None, max_epochs=steps, capacity=20000,
-                     device=torch.device("cuda"), num_envs=1, seed=1000 + seed, **hp)
+        tr = cls(EVOPFEnv(device="cuda"), "/tmp/rpo_test", name="t", logger=None, max_epochs=steps, capacity=20000,
+                 device=torch.device("cuda"), num_envs=1, seed=1000 + seed, **hp)
         assert tr.fused is not None
         tr.logger = Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=steps)
         os.environ["RPO_VERBOSE"] = "0"
@@ -94,7 +100,7 @@ def test_evopf_training_statistics_match_reference(golden):
     out = {"ref_mean": ref.mean(0).tolist(), "gpu_mean": got.mean(0).tolist(), "ref_std": ref.std(0).tolist(),
            "gpu_std": got.std(0).tolist(), "columns": [str(c) for c in g["columns"]]}
     os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/statistical_parity_ddpg_evopf.json", "w") as f:
+    with open("gpurun_out/statistical_parity_%s_evopf.json" % algo, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out))
 
