@@ -165,11 +165,13 @@ def kernel_clinic(tr):
     d = f.descs["critic"]
     cf = lambda: k.ddpg_critic_forward(  # noqa: E731
         f.descs["actor_target"], f.descs["critic_target"], d, scale, base, buf.rows, buf.capacity, buf.n_envs, tr._batch,
-        None, None, buf.seed, 0, buf.ctrl, 10, 2e-2, 1e-5, 0.0, -10.0, 10.0, 0.95, f.buf("q", B, 1), f.buf("qn", B, 1),
-        f.buf("dq", B, 1), f.buf("loss_parts", (B + 15) // 16), f.buf("critic.x0", B, d.ein), f.buf("critic.h1", B, d.H))
+        None, None, buf.seed, 0, buf.ctrl, 10, 2e-2, 1e-5, 0.0, -10.0, 10.0, f.buf("q", B, 1), f.buf("qn", B, 1),
+        f.buf("critic.x0", B, d.ein), f.buf("critic.h1", B, d.H))
     mfma("cart_ddpg_critic_forward_kernel", B, time_kernel(cf)[0], ACTOR_FLOPS + 2 * CRITIC_FLOPS)
     cols = tr.buffer.split(tr._batch)
-    bw = lambda: f.backward("critic", cols["state"], cols["action"], f.buf("dq", B, 1))   # noqa: E731
+    td = ops.Td(f.buf("q", B, 1).view(-1), f.buf("qn", B, 1).view(-1), None, None, cols["reward"], cols["done"], 0.0, 0.95,
+                f.buf("dq", B, 1).view(-1), f.buf("loss_parts", (B + 15) // 16))
+    bw = lambda: f.backward("critic", cols["state"], cols["action"], None, td=td)   # noqa: E731  (TD prologue included)
     mfma("mlp_bwd_rows+weights_kernels", B, time_kernel(bw)[0], 2 * CRITIC_FLOPS)
     # ---- single-stage kernels (warm-up phase, SAC / pendulum path, API calls) and the streaming regime
     ap = torch.zeros(v.n, device=dev)

@@ -322,6 +322,21 @@ typedef struct {
     float *Ws, *bs, *Wa, *ba, *W0, *b0, *W1, *b1, *W1b, *b1b;
 } rpo_mlp_grad;
 
+/* TD target + Huber loss as a prologue of the critic's backward pass (rpo_ddpg.py:331-335, rpo_sac.py:346-353): with
+ * td != NULL rpo_mlp_backward ignores `dout` and computes, per row i,
+ *   y = reward + gamma (1 - done) (min(qn1, qn2) - alpha logp),  dq_out[i] = clamp(q[i] - y, -1, 1) / n  (its dout),
+ * and loss_partial[i / 16] = that row tile's share of the mean smooth-L1 loss (n_out must be 1).  qn2 / logp may be
+ * NULL (RPODDPG).  This is what lets the critic-forward pipelines run Q, Q_targ (and the twin critics) in separate
+ * workgroups: the values meet at the kernel boundary instead of inside one workgroup. */
+typedef struct {
+    const float *q, *qn1, *qn2, *logp;
+    const float* reward; int reward_stride;
+    const float* done; int done_stride;
+    float alpha, gamma;
+    float* dq_out;
+    float* loss_partial;
+} rpo_td;
+
 int rpo_mlp_supported(int E, int H, int cat);
 
 /* Forward of n rows.  s [n, >=S] / a [n, >=A] are read with row strides (columns of a gathered batch are fine).
@@ -339,7 +354,8 @@ int rpo_mlp_forward(const rpo_mlp* net_host, int n, const float* s, int s_stride
  * zero before the call this is clip_grad_norm_'s inf-norm of the network (rpo_ddpg.py:180), without the rpo_absmax pass. */
 int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int n, const float* s, int s_stride,
                      const float* a, int a_stride, const float* x0, const float* h1, const float* dout, float* dh,
-                     float* dx0, float* da, int param_grads, int first_layer_state_only, float* gradmax, void* stream);
+                     float* dx0, float* da, int param_grads, int first_layer_state_only, float* gradmax,
+                     const rpo_td* td, void* stream);
 
 /* rpo_mlp_backward of two networks of the same shape on the same inputs in one pair of launches (SAC's twin critics,
  * model/value.py:125-140): gridDim.y = 2 selects the network.  Results are those of two rpo_mlp_backward calls. */
@@ -348,7 +364,7 @@ int rpo_mlp_backward_pair(const rpo_mlp* net1_host, const rpo_mlp_grad* grad1_ho
                           int a_stride, const float* x0_1, const float* h1_1, const float* dout_1, float* dh_1,
                           float* dx0_1, float* da_1, const float* x0_2, const float* h1_2, const float* dout_2, float* dh_2,
                           float* dx0_2, float* da_2, int param_grads, int first_layer_state_only, float* gradmax,
-                          void* stream);
+                          const rpo_td* td1, const rpo_td* td2, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * EVOPF-v0 (rpo_amd/csrc/evopf.hip): one wavefront per env lane / batch row; the lane's 22x22 Newton system and the
@@ -455,17 +471,18 @@ int rpo_pendulum_rollout(const rpo_mlp* actor_host, int gauss, float scale, floa
 
 /* Forward half of the critic update (rpo_ddpg.py:165-174, 327-337): ReplayBuffer.sample (Philox draw, or idx_in when
  * given) -> batch_out [B,24]; pi_targ(s') -> Complete + Proj -> Q_targ(s', a') = qn_out; Q(s, a) = q_out with the
- * critic's pre-activations saved (x0_save [B,E], h1_save [B,H]) for rpo_mlp_backward; y = r + gamma (1 - done) qn;
- * dq_out = dHuber/dQ / B; loss_partial[g] = workgroup g's share of the mean Huber loss (g < ceil(B / 16)).
- * == rpo_replay_sample_gather + 3 x rpo_mlp_forward + rpo_cartsafe_act_project + rpo_td_huber. */
+ * critic's pre-activations saved (x0_save [B,E], h1_save [B,H]) for rpo_mlp_backward.  Two workgroups per 16-row tile
+ * (gridDim.y: target chain | critic) that never talk to each other; the TD target / Huber loss is the prologue of
+ * rpo_mlp_backward (rpo_td), where their results meet.
+ * == rpo_replay_sample_gather + 3 x rpo_mlp_forward + rpo_cartsafe_act_project. */
 int rpo_cartsafe_ddpg_critic_forward(const rpo_mlp* actor_target_host, const rpo_mlp* critic_target_host,
                                      const rpo_mlp* critic_host, float scale, float base, const float* rows,
                                      long long cap_steps, int n_envs, int batch, float* batch_out, long long* idx_out,
                                      const long long* idx_in, unsigned long long seed, unsigned sample_salt,
                                      const long long* ctrl, int max_steps, float corr_lr, float corr_eps,
                                      float corr_momentum, float box_lo, float box_hi, const float* consts_host,
-                                     int partial, float gamma, float* q_out, float* qn_out, float* dq_out,
-                                     float* loss_partial, float* x0_save, float* h1_save, void* stream);
+                                     int partial, float* q_out, float* qn_out, float* x0_save, float* h1_save,
+                                     void* stream);
 
 /* The policy step of RPODDPG (rpo_ddpg.py:186-205, 307-324) as forward + backward pipelines, env = 0 CartSafe-v0 /
  * 1 SpringPendulum-v0 (E = 128; the actor loss completes the action but does not project it):
@@ -525,10 +542,11 @@ int rpo_sac_actor_backward(int env, const rpo_mlp* actor_host, const rpo_mlp_gra
 /* The same for RPOSAC.critic_loss (rpo_sac.py:342-353): sample -> a' ~ pi(s') with the ONLINE actor (mean / log-std
  * heads, rsample, box clip; the N(0,1) draw of row b is normal(philox(noise_seed, noise_id_base + b, ctrl[T] +
  * noise_salt, RPO_STREAM_POLICY, ctrl[UPDATES])), i.e. rpo_philox_normal, or eps_in[b] when given) -> Complete + Proj ->
- * y = r + gamma (1 - done) (min(Q1_targ, Q2_targ)(s', a') - alpha log pi(a'|s')) -> Q1, Q2 (s, a) with their
- * pre-activations saved -> dq_k = dHuber/dQ_k / B, loss_partial[g] = workgroup g's share of both mean Huber losses.
- * == rpo_replay_sample_gather + rpo_philox_normal + 5 x rpo_mlp_forward + rpo_gauss_head + rpo_cartsafe_act_project +
- *    rpo_td_huber. */
+ * qn_k = Qk_targ(s', a'), logp_out = log pi(a'|s'); q_k = Qk(s, a) with the pre-activations saved.  Four independent
+ * workgroups per 16-row tile (gridDim.y: Q1_targ chain | Q2_targ chain | Q1 | Q2); the TD target
+ * y = r + gamma (1 - done) (min(qn1, qn2) - alpha logp) and both Huber terms are the prologue of rpo_mlp_backward_pair
+ * (rpo_td).
+ * == rpo_replay_sample_gather + rpo_philox_normal + 5 x rpo_mlp_forward + rpo_gauss_head + rpo_cartsafe_act_project. */
 int rpo_cartsafe_sac_critic_forward(const rpo_mlp* actor_host, const rpo_mlp* critic_target1_host,
                                     const rpo_mlp* critic_target2_host, const rpo_mlp* critic1_host,
                                     const rpo_mlp* critic2_host, float scale, float base, const float* rows,
@@ -537,14 +555,15 @@ int rpo_cartsafe_sac_critic_forward(const rpo_mlp* actor_host, const rpo_mlp* cr
                                     unsigned sample_salt, unsigned long long noise_seed, unsigned noise_id_base,
                                     unsigned noise_salt, const long long* ctrl, int max_steps, float corr_lr,
                                     float corr_eps, float corr_momentum, float box_lo, float box_hi,
-                                    const float* consts_host, int partial, float gamma, float alpha, float* q1_out,
-                                    float* q2_out, float* dq1_out, float* dq2_out, float* loss_partial, float* x0_save1,
-                                    float* h1_save1, float* x0_save2, float* h1_save2, void* stream);
+                                    const float* consts_host, int partial, float* q1_out, float* q2_out,
+                                    float* qn1_out, float* qn2_out, float* logp_out, float* x0_save1, float* h1_save1,
+                                    float* x0_save2, float* h1_save2, void* stream);
 
 /* SpringPendulum-v0: the reference's batched projection couples the samples of a batch (pendulum.py:337-339), so the
  * RPOSAC critic-forward chain is cut there into two launches around rpo_pendulum_project_batchref:
  *   front: sample -> batch_out [B,16] -> a' ~ pi(s') -> ap_out [B] (clipped basic action), logp_out [B];
- *   back:  Q1_targ, Q2_targ (s', next_actions [B,2]) -> y -> Q1, Q2 (s, a) of batch_rows -> dq_k, loss_partial. */
+ *   back:  four independent workgroups per tile: qn_k = Qk_targ(s', next_actions [B,2]) | q_k = Qk(s, a) of batch_rows
+ *          (pre-activations saved); TD / Huber: rpo_td prologue of rpo_mlp_backward_pair. */
 int rpo_pendulum_sac_critic_front(const rpo_mlp* actor_host, float scale, float base, float box_lo, float box_hi,
                                   const float* rows, long long cap_steps, int n_envs, int batch, float* batch_out,
                                   long long* idx_out, const long long* idx_in, const float* eps_in,
@@ -553,20 +572,20 @@ int rpo_pendulum_sac_critic_front(const rpo_mlp* actor_host, float scale, float 
                                   float* logp_out, void* stream);
 int rpo_pendulum_sac_critic_back(const rpo_mlp* critic_target1_host, const rpo_mlp* critic_target2_host,
                                  const rpo_mlp* critic1_host, const rpo_mlp* critic2_host, int batch, float* batch_rows,
-                                 const float* next_actions, const float* logp, float gamma, float alpha, float* q1_out,
-                                 float* q2_out, float* dq1_out, float* dq2_out, float* loss_partial, float* x0_save1,
-                                 float* h1_save1, float* x0_save2, float* h1_save2, void* stream);
+                                 const float* next_actions, float* q1_out, float* q2_out, float* qn1_out, float* qn2_out,
+                                 float* x0_save1, float* h1_save1, float* x0_save2, float* h1_save2, void* stream);
 
 /* The RPODDPG form of the cut pipeline for SpringPendulum-v0 (rpo_ddpg.py:327-337):
  *   front: sample -> batch_out [B,16] -> ap_out [B] = pi_targ(s') (tanh box);
- *   back:  Q_targ(s', next_actions) -> y -> Q(s, a) of batch_rows (pre-activations saved) -> dq, loss_partial. */
+ *   back:  two independent workgroups per tile: qn = Q_targ(s', next_actions) | q = Q(s, a) of batch_rows
+ *          (pre-activations saved); TD / Huber: rpo_td prologue of rpo_mlp_backward. */
 int rpo_pendulum_ddpg_critic_front(const rpo_mlp* actor_target_host, float scale, float base, const float* rows,
                                    long long cap_steps, int n_envs, int batch, float* batch_out, long long* idx_out,
                                    const long long* idx_in, unsigned long long sample_seed, unsigned sample_salt,
                                    const long long* ctrl, float* ap_out, void* stream);
 int rpo_pendulum_ddpg_critic_back(const rpo_mlp* critic_target_host, const rpo_mlp* critic_host, int batch,
-                                  float* batch_rows, const float* next_actions, float gamma, float* q_out, float* qn_out,
-                                  float* dq_out, float* loss_partial, float* x0_save, float* h1_save, void* stream);
+                                  float* batch_rows, const float* next_actions, float* q_out, float* qn_out,
+                                  float* x0_save, float* h1_save, void* stream);
 
 /* Policy heads around the MLP kernels.
  * DDPG (model/policy.py:30-31, agent/ddpg_pa.py:108-110): ap = clip(ap_det + eps_t * noise), ap_det = scale*tanh(o)+base.

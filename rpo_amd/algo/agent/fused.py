@@ -120,19 +120,22 @@ class FusedNets(object):
         self.backend.mlp_forward(d, s, a, out, x0, h1, mode, scale, base)
         return out
 
-    def backward(self, name, s, a, dout, da=None, param_grads=True, first_layer_state_only=False, gradmax=None):
+    def backward(self, name, s, a, dout, da=None, param_grads=True, first_layer_state_only=False, gradmax=None, td=None):
         """``gradmax`` (1-element tensor or None): the weights pass leaves the inf-norm of the gradients it wrote there,
-        which saves the separate rpo_absmax launch of clip_grad_norm_ when the buffers were zero before."""
+        which saves the separate rpo_absmax launch of clip_grad_norm_ when the buffers were zero before.
+        ``td`` (backend.Td): dout is produced by the TD / Huber prologue of the rows pass instead of being read."""
         d = self.descs[name]
-        n = dout.shape[0]
+        n = dout.shape[0] if td is None else td.dq_out.shape[0]
         kw = {} if gradmax is None else dict(gradmax=gradmax)
+        if td is not None:
+            kw["td"] = td
         self.backend.mlp_backward(d, s, a, self.buf(name + ".x0", n, d.ein), self.buf(name + ".h1", n, d.H), dout,
                                   self.buf(name + ".dh", n, d.H), self.buf(name + ".dx0", n, d.ein), da, param_grads,
                                   first_layer_state_only, **kw)
 
 
     def backward_pair(self, name1, name2, s, a, dout1, dout2, da1=None, da2=None, param_grads=True,
-                      first_layer_state_only=False, gradmax=None):
+                      first_layer_state_only=False, gradmax=None, td1=None, td2=None):
         """Backward of two same-shaped networks (twin critics) in one pair of launches where the backend has it.
         Returns True when ``gradmax`` holds the inf-norm of the gradients afterwards (not with a shared embedding,
         whose gradient is the sum of two passes)."""
@@ -141,16 +144,16 @@ class FusedNets(object):
                      for k, t in d1.tensors.items())           # a shared embedding: both would accumulate into it at once
         if shared or not hasattr(self.backend, "mlp_backward_pair"):
             gm = None if shared else gradmax
-            self.backward(name1, s, a, dout1, da1, param_grads, first_layer_state_only, gradmax=gm)
-            self.backward(name2, s, a, dout2, da2, param_grads, first_layer_state_only, gradmax=gm)
+            self.backward(name1, s, a, dout1, da1, param_grads, first_layer_state_only, gradmax=gm, td=td1)
+            self.backward(name2, s, a, dout2, da2, param_grads, first_layer_state_only, gradmax=gm, td=td2)
             return gm is not None
-        n = dout1.shape[0]
+        n = dout1.shape[0] if td1 is None else td1.dq_out.shape[0]
         b = self.buf
         self.backend.mlp_backward_pair(
             d1, d2, s, a, b(name1 + ".x0", n, d1.ein), b(name1 + ".h1", n, d1.H), dout1, b(name1 + ".dh", n, d1.H),
             b(name1 + ".dx0", n, d1.ein), da1, b(name2 + ".x0", n, d2.ein), b(name2 + ".h1", n, d2.H), dout2,
             b(name2 + ".dh", n, d2.H), b(name2 + ".dx0", n, d2.ein), da2, param_grads, first_layer_state_only,
-            **({} if gradmax is None else dict(gradmax=gradmax)))
+            **dict(({} if gradmax is None else dict(gradmax=gradmax)), **({} if td1 is None else dict(td1=td1, td2=td2))))
         return gradmax is not None
 
 

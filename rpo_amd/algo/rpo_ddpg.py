@@ -109,23 +109,26 @@ class RPODDPG(RPOTrainerBase):
             self.kernels.ddpg_critic_front(f.descs["actor_target"], scale, base, buf.rows, buf.capacity, buf.n_envs,
                                            self._batch, None, idx_in, buf.seed, 0, buf.ctrl, ap)
             next_actions = self._project_batch(cols[2], ap)
-            self.kernels.ddpg_critic_back(f.descs["critic_target"], d, self._batch, next_actions, ag.gamma, f.buf("q", B, 1),
-                                          f.buf("qn", B, 1), f.buf("dq", B, 1), parts, f.buf("critic.x0", B, d.ein),
-                                          f.buf("critic.h1", B, d.H))
-            self._zero_grads()
-            gm = self._critic_gradmax()
-            f.backward("critic", state, action, f.buf("dq", B, 1), gradmax=gm)
-            self._gradmax_ready = gm is not None
-            self.last_losses["critic"] = _LazySum(parts)
-            return
+            q, qn = f.buf("q", B, 1), f.buf("qn", B, 1)
+            self.kernels.ddpg_critic_back(f.descs["critic_target"], d, self._batch, next_actions, q, qn,
+                                          f.buf("critic.x0", B, d.ein), f.buf("critic.h1", B, d.H))
+            return self._critic_backward_td(cols, q, qn, parts)
+        q, qn = f.buf("q", B, 1), f.buf("qn", B, 1)
         self.kernels.ddpg_critic_forward(
             f.descs["actor_target"], f.descs["critic_target"], d, scale, base, buf.rows, buf.capacity, buf.n_envs,
             self._batch, None, idx_in, buf.seed, 0, buf.ctrl, self.max_steps, self.corr_lr, self.corr_eps,
-            self.corr_momentum, self._box_lo, self._box_hi, ag.gamma, f.buf("q", B, 1), f.buf("qn", B, 1),
-            f.buf("dq", B, 1), parts, f.buf("critic.x0", B, d.ein), f.buf("critic.h1", B, d.H))
+            self.corr_momentum, self._box_lo, self._box_hi, q, qn, f.buf("critic.x0", B, d.ein), f.buf("critic.h1", B, d.H))
+        self._critic_backward_td(cols, q, qn, parts)
+
+    def _critic_backward_td(self, cols, q, qn, parts):
+        """Backward of the critic with the TD target / Huber loss as its prologue (rpo_td): the forward pipeline's target
+        chain and critic ran in separate workgroups and meet here."""
+        f, B = self.fused, self.batch_size
+        td = self.backend.Td(q.view(-1), qn.view(-1), None, None, cols[3], cols[4], 0.0, self.agent.gamma,
+                             f.buf("dq", B, 1).view(-1), parts)
         self._zero_grads()
         gm = self._critic_gradmax()
-        f.backward("critic", state, action, f.buf("dq", B, 1), gradmax=gm)
+        f.backward("critic", cols[0], cols[1], None, gradmax=gm, td=td)
         self._gradmax_ready = gm is not None
         self.last_losses["critic"] = _LazySum(parts)
 

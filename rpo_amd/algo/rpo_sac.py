@@ -110,37 +110,36 @@ class RPOSAC(RPOTrainerBase):
         state, action = cols[0], cols[1]
         d = f.descs["critic1"]
         scale, base = self._box_affine
-        parts = f.buf("loss_parts", (B + 15) // 16)
         inject = self._idx_inject is not None                  # tests replay the reference's draws
         idx_in = self._idx_inject() if inject else None
         eps_in = self._draw(self._noise_b, self.dist.rank * B * self.kernels.partial_dim, _SALT_CRITIC).view(-1) if inject else None
-        dq1, dq2 = f.buf("dq1", B, 1), f.buf("dq2", B, 1)
+        q1, q2, qn1, qn2 = f.buf("q1", B, 1), f.buf("q2", B, 1), f.buf("qn1", B, 1), f.buf("qn2", B, 1)
+        saves = (f.buf("critic1.x0", B, d.ein), f.buf("critic1.h1", B, d.H), f.buf("critic2.x0", B, d.ein),
+                 f.buf("critic2.h1", B, d.H))
+        logp = f.buf("crit.logp", B)
         if not hasattr(self.kernels, "sac_critic_forward"):
             # SpringPendulum: the chain is cut at the batch-coupled projection (front | project | back)
-            ap, logp = f.buf("crit.ap", B), f.buf("crit.logp", B)
+            ap = f.buf("crit.ap", B)
             self.kernels.sac_critic_front(f.descs["actor"], scale, base, self._box_lo, self._box_hi, buf.rows, buf.capacity,
                                           buf.n_envs, self._batch, None, idx_in, eps_in, buf.seed, 0, self.seed,
                                           self.dist.rank * B, _SALT_CRITIC, buf.ctrl, ap, logp)
             next_actions = self._project_batch(cols[2], ap)
-            self.kernels.sac_critic_back(
-                f.descs["critic_target1"], f.descs["critic_target2"], d, f.descs["critic2"], self._batch, next_actions, logp,
-                ag.gamma, float(ag.alpha), f.buf("q1", B, 1), f.buf("q2", B, 1), dq1, dq2, parts,
-                f.buf("critic1.x0", B, d.ein), f.buf("critic1.h1", B, d.H), f.buf("critic2.x0", B, d.ein),
-                f.buf("critic2.h1", B, d.H))
-            self._zero_grads()
-            self._gradmax_ready = f.backward_pair("critic1", "critic2", state, action, dq1, dq2,
-                                                  gradmax=self._critic_gradmax())
-            self.last_losses["critic"] = _LazySum(parts)
-            return
-        self.kernels.sac_critic_forward(
-            f.descs["actor"], f.descs["critic_target1"], f.descs["critic_target2"], d, f.descs["critic2"], scale, base,
-            buf.rows, buf.capacity, buf.n_envs, self._batch, None, idx_in, eps_in, buf.seed, 0, self.seed,
-            self.dist.rank * B, _SALT_CRITIC, buf.ctrl, self.max_steps, self.corr_lr, self.corr_eps, self.corr_momentum,
-            self._box_lo, self._box_hi, ag.gamma, float(ag.alpha), f.buf("q1", B, 1), f.buf("q2", B, 1), dq1, dq2, parts,
-            f.buf("critic1.x0", B, d.ein), f.buf("critic1.h1", B, d.H), f.buf("critic2.x0", B, d.ein),
-            f.buf("critic2.h1", B, d.H))
+            self.kernels.sac_critic_back(f.descs["critic_target1"], f.descs["critic_target2"], d, f.descs["critic2"],
+                                         self._batch, next_actions, q1, q2, qn1, qn2, *saves)
+        else:
+            self.kernels.sac_critic_forward(
+                f.descs["actor"], f.descs["critic_target1"], f.descs["critic_target2"], d, f.descs["critic2"], scale, base,
+                buf.rows, buf.capacity, buf.n_envs, self._batch, None, idx_in, eps_in, buf.seed, 0, self.seed,
+                self.dist.rank * B, _SALT_CRITIC, buf.ctrl, self.max_steps, self.corr_lr, self.corr_eps, self.corr_momentum,
+                self._box_lo, self._box_hi, q1, q2, qn1, qn2, logp, *saves)
+        # the four (two) chains of a tile ran in separate workgroups; the TD target / Huber terms are the prologue of the
+        # twin critics' backward pass (rpo_td): one loss-partial row per critic
+        parts = f.buf("loss_parts2", 2, (B + 15) // 16)
+        tds = [self.backend.Td(q.view(-1), qn1.view(-1), qn2.view(-1), logp, cols[3], cols[4], float(ag.alpha), ag.gamma,
+                               f.buf(name, B, 1).view(-1), parts[i]) for i, (q, name) in enumerate(((q1, "dq1"), (q2, "dq2")))]
         self._zero_grads()
-        self._gradmax_ready = f.backward_pair("critic1", "critic2", state, action, dq1, dq2, gradmax=self._critic_gradmax())
+        self._gradmax_ready = f.backward_pair("critic1", "critic2", state, action, None, None,
+                                              gradmax=self._critic_gradmax(), td1=tds[0], td2=tds[1])
         self.last_losses["critic"] = _LazySum(parts)
 
     # ---- the update through the hand-written MLP kernels (same arithmetic as critic_loss / actor_loss below) ------

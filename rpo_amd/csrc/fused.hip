@@ -209,11 +209,8 @@ struct CriticFwdArgs {
     uint32_t salt;
     const long long* ctrl;
     int max_steps; float corr_lr, corr_eps, corr_momentum, box_lo, box_hi;
-    float gamma;
-    float* q_out;                 // [B]
-    float* qn_out;                // [B]
-    float* dq_out;                // [B] dLoss/dQ
-    float* loss_partial;          // [gridDim.x] per-workgroup sums of huber / B
+    float* q_out;                 // [B] Q(s, a)
+    float* qn_out;                // [B] Q_targ(s', a')
     float* x0_save; float* h1_save;   // critic pre-activations for rpo_mlp_backward
 };
 
@@ -240,60 +237,48 @@ __global__ __launch_bounds__(kFwdThreads) void cart_ddpg_critic_forward_kernel(C
                 row = (long long)__umul64hi(((unsigned long long)u.x << 32) | u.y, n_valid);
             }
             v = reinterpret_cast<const float4*>(p.rows)[row * 6 + ch];
-            reinterpret_cast<float4*>(p.batch_out)[(size_t)(row0 + r) * 6 + ch] = v;
-            if (p.idx_out && ch == 0) p.idx_out[row0 + r] = row;
+            if (blockIdx.y == 0) {                             // both roles draw the same rows; one publishes them
+                reinterpret_cast<float4*>(p.batch_out)[(size_t)(row0 + r) * 6 + ch] = v;
+                if (p.idx_out && ch == 0) p.idx_out[row0 + r] = row;
+            }
         }
         tile[tid] = v;
     }
     __syncthreads();
     const float* tf = reinterpret_cast<const float*>(tile);    // row r: s[0:6] a[6:8] s'[8:14] r[14] done[15] ...
-    if (tid < kRows * 6) {
-        const int r = tid / 6, i = tid - r * 6;
-        lds.in_s[r * kInS + i] = tf[r * 24 + 8 + i];           // next_state
-    }
-    // ---- pi_targ(s') (deterministic, rpo_ddpg.py:329)
-    mlp_tile_forward<EIN, H>(p.actor_target, lds, row0, B, nullptr, nullptr, 1, p.scale, p.base);
-    // ---- Complete + Proj (rpo_ddpg.py:330): per-row stop test == the reference's batched call for this env
-    if (tid < kRows) {
-        ActArgs a{};
-        a.noise_mode = RPO_NOISE_NONE;
-        a.max_steps = p.max_steps; a.corr_lr = p.corr_lr; a.corr_eps = p.corr_eps; a.corr_momentum = p.corr_momentum;
-        a.box_lo = p.box_lo; a.box_hi = p.box_hi;
-        int k;
-        const float2 act = cart_explore_project(a, c, row0 + tid, lds.out[tid * 2], 0.0f, t, k);
-        lds.in_a[tid * kInA] = act.x;
-        lds.in_a[tid * kInA + 1] = act.y;
-    }
-    // ---- Q_targ(s', a')
-    mlp_tile_forward<EIN, H>(p.critic_target, lds, row0, B, nullptr, nullptr, 0, 1.0f, 0.0f);
-    float qn = 0.0f;
-    if (tid < kRows) qn = lds.out[tid * 2];
-    __syncthreads();                                           // everybody is done with in_s / in_a / out
-    if (tid < kRows * 6) {
-        const int r = tid / 6, i = tid - r * 6;
-        lds.in_s[r * kInS + i] = tf[r * 24 + i];               // state
-    }
-    if (tid < kRows * 2) {
-        const int r = tid >> 1, i = tid & 1;
-        lds.in_a[r * kInA + i] = tf[r * 24 + 6 + i];           // stored action
-    }
-    // ---- Q(s, a), pre-activations kept for the backward pass
-    mlp_tile_forward<EIN, H>(p.critic, lds, row0, B, p.x0_save, p.h1_save, 0, 1.0f, 0.0f);
-    // ---- TD target + Huber (rpo_ddpg.py:331-335), dLoss/dQ
-    float hub = 0.0f;
-    if (tid < kRows && row0 + tid < B) {
-        const float q = lds.out[tid * 2];
-        const float y = tf[tid * 24 + 14] + p.gamma * (1.0f - tf[tid * 24 + 15]) * qn;
-        const float d = q - y, ad = fabsf(d);
-        const float inv_n = 1.0f / (float)B;
-        hub = (ad < 1.0f ? 0.5f * d * d : ad - 0.5f) * inv_n;
-        p.q_out[row0 + tid] = q;
-        p.qn_out[row0 + tid] = qn;
-        p.dq_out[row0 + tid] = fminf(fmaxf(d, -1.0f), 1.0f) * inv_n;
-    }
-    if (tid < 64) {
-        const float s = rpo_wave_sum(hub);
-        if (tid == 0) p.loss_partial[blockIdx.x] = s;
+    if (blockIdx.y == 0) {
+        // ---- target role: pi_targ(s') (deterministic, rpo_ddpg.py:329)
+        if (tid < kRows * 6) {
+            const int r = tid / 6, i = tid - r * 6;
+            lds.in_s[r * kInS + i] = tf[r * 24 + 8 + i];       // next_state
+        }
+        mlp_tile_forward<EIN, H>(p.actor_target, lds, row0, B, nullptr, nullptr, 1, p.scale, p.base);
+        // ---- Complete + Proj (rpo_ddpg.py:330): per-row stop test == the reference's batched call for this env
+        if (tid < kRows) {
+            ActArgs a{};
+            a.noise_mode = RPO_NOISE_NONE;
+            a.max_steps = p.max_steps; a.corr_lr = p.corr_lr; a.corr_eps = p.corr_eps; a.corr_momentum = p.corr_momentum;
+            a.box_lo = p.box_lo; a.box_hi = p.box_hi;
+            int k;
+            const float2 act = cart_explore_project(a, c, row0 + tid, lds.out[tid * 2], 0.0f, t, k);
+            lds.in_a[tid * kInA] = act.x;
+            lds.in_a[tid * kInA + 1] = act.y;
+        }
+        // ---- Q_targ(s', a')
+        mlp_tile_forward<EIN, H>(p.critic_target, lds, row0, B, nullptr, nullptr, 0, 1.0f, 0.0f);
+        if (tid < kRows && row0 + tid < B) p.qn_out[row0 + tid] = lds.out[tid * 2];
+    } else {
+        // ---- critic role: Q(s, a), pre-activations kept for the backward pass
+        if (tid < kRows * 6) {
+            const int r = tid / 6, i = tid - r * 6;
+            lds.in_s[r * kInS + i] = tf[r * 24 + i];           // state
+        }
+        if (tid < kRows * 2) {
+            const int r = tid >> 1, i = tid & 1;
+            lds.in_a[r * kInA + i] = tf[r * 24 + 6 + i];       // stored action
+        }
+        mlp_tile_forward<EIN, H>(p.critic, lds, row0, B, p.x0_save, p.h1_save, 0, 1.0f, 0.0f);
+        if (tid < kRows && row0 + tid < B) p.q_out[row0 + tid] = lds.out[tid * 2];
     }
 }
 
@@ -303,8 +288,8 @@ __global__ __launch_bounds__(kFwdThreads) void cart_ddpg_critic_forward_kernel(C
 // (rpo_sac.py:342-353).  CartSafe: all five MLP tiles chained in one workgroup of 16 rows.  SpringPendulum: the
 // reference's batched projection couples the samples of a batch (pendulum.py:337-339), so the chain is cut
 // there: front (sample -> policy) | rpo_pendulum_project_batchref | back (target critics -> critics -> TD).
-struct CartRow { static constexpr int ROW = 24, CH = 6, S = 6, A_OFF = 6, NS_OFF = 8, R_OFF = 14, D_OFF = 15; };
-struct PendRow { static constexpr int ROW = 16, CH = 4, S = 5, A_OFF = 5, NS_OFF = 7, R_OFF = 12, D_OFF = 13; };
+struct CartRow { static constexpr int ROW = 24, CH = 6, S = 6, A_OFF = 6, NS_OFF = 8; };
+struct PendRow { static constexpr int ROW = 16, CH = 4, S = 5, A_OFF = 5, NS_OFF = 7; };
 
 struct SacCriticFwdArgs {
     Mlp actor, critic_target1, critic_target2, critic1, critic2;
@@ -321,9 +306,8 @@ struct SacCriticFwdArgs {
     uint32_t salt, noise_salt, noise_id_base;
     const long long* ctrl;
     int max_steps; float corr_lr, corr_eps, corr_momentum, box_lo, box_hi;
-    float gamma, alpha;
-    float* q1_out; float* q2_out; float* dq1_out; float* dq2_out;     // [B]
-    float* loss_partial;          // [gridDim.x]
+    float* q1_out; float* q2_out;       // [B] Q1(s, a), Q2(s, a)   (RPODDPG back: q1_out only)
+    float* qn1_out; float* qn2_out;     // [B] target critics at (s', a')
     float* x0_save1; float* h1_save1; float* x0_save2; float* h1_save2;
     float* ap_out; float* logp_out;                 // split form, front: clipped basic action and log pi of a'
     const float* next_actions; const float* logp_in;   // split form, back: projected a' [B,2] and log pi
@@ -347,8 +331,10 @@ __device__ __forceinline__ void sac_sample(const SacCriticFwdArgs& p, float4* ti
                 row = (long long)__umul64hi(((unsigned long long)u.x << 32) | u.y, n_valid);
             }
             v = reinterpret_cast<const float4*>(p.rows)[row * L::CH + ch];
-            reinterpret_cast<float4*>(p.batch_out)[(size_t)(row0 + r) * L::CH + ch] = v;
-            if (p.idx_out && ch == 0) p.idx_out[row0 + r] = row;
+            if (blockIdx.y == 0) {                             // every role draws the same rows; one publishes them
+                reinterpret_cast<float4*>(p.batch_out)[(size_t)(row0 + r) * L::CH + ch] = v;
+                if (p.idx_out && ch == 0) p.idx_out[row0 + r] = row;
+            }
         }
         tile[tid] = v;
     }
@@ -383,16 +369,18 @@ __device__ __forceinline__ float sac_policy(const SacCriticFwdArgs& p, TileLds<E
     return ap;
 }
 
-// Q1_targ, Q2_targ on (s', a') staged in lds.in_s / lds.in_a, then Q1, Q2 on the stored (s, a), TD target and Huber
+// One target critic on (s', a') staged in lds.in_s / lds.in_a  -> qn_out
+template <int EIN, int H>
+__device__ __forceinline__ void target_role(const Mlp& net, TileLds<EIN>& lds, int row0, int B, float* qn_out) {
+    mlp_tile_forward<EIN, H>(net, lds, row0, B, nullptr, nullptr, 0, 1.0f, 0.0f);
+    if (threadIdx.x < kRows && row0 + threadIdx.x < B) qn_out[row0 + threadIdx.x] = lds.out[threadIdx.x * 2];
+}
+
+// One critic on the stored (s, a) of the tile, pre-activations kept for the backward pass  -> q_out
 template <class L, int EIN, int H>
-__device__ __forceinline__ void sac_td(const SacCriticFwdArgs& p, TileLds<EIN>& lds, const float* tf, int row0, float logp) {
-    const int tid = threadIdx.x, B = p.batch;
-    mlp_tile_forward<EIN, H>(p.critic_target1, lds, row0, B, nullptr, nullptr, 0, 1.0f, 0.0f);
-    float qn = 0.0f;
-    if (tid < kRows) qn = lds.out[tid * 2];
-    mlp_tile_forward<EIN, H>(p.critic_target2, lds, row0, B, nullptr, nullptr, 0, 1.0f, 0.0f);
-    if (tid < kRows) qn = fminf(qn, lds.out[tid * 2]) - p.alpha * logp;        // rpo_sac.py:346-347
-    __syncthreads();
+__device__ __forceinline__ void critic_role(const Mlp& net, TileLds<EIN>& lds, const float* tf, int row0, int B, float* q_out,
+                                            float* x0_save, float* h1_save) {
+    const int tid = threadIdx.x;
     if (tid < kRows * L::S) {
         const int r = tid / L::S, i = tid - r * L::S;
         lds.in_s[r * kInS + i] = tf[r * L::ROW + i];           // state
@@ -401,36 +389,26 @@ __device__ __forceinline__ void sac_td(const SacCriticFwdArgs& p, TileLds<EIN>& 
         const int r = tid >> 1, i = tid & 1;
         lds.in_a[r * kInA + i] = tf[r * L::ROW + L::A_OFF + i];   // stored action
     }
-    mlp_tile_forward<EIN, H>(p.critic1, lds, row0, B, p.x0_save1, p.h1_save1, 0, 1.0f, 0.0f);
-    float q1 = 0.0f;
-    if (tid < kRows) q1 = lds.out[tid * 2];
-    mlp_tile_forward<EIN, H>(p.critic2, lds, row0, B, p.x0_save2, p.h1_save2, 0, 1.0f, 0.0f);
-    float hub = 0.0f;
-    if (tid < kRows && row0 + tid < B) {
-        const float q2 = lds.out[tid * 2];
-        const float y = tf[tid * L::ROW + L::R_OFF] + p.gamma * (1.0f - tf[tid * L::ROW + L::D_OFF]) * qn;
-        const float d1 = q1 - y, d2 = q2 - y, a1 = fabsf(d1), a2 = fabsf(d2);
-        const float inv_n = 1.0f / (float)B;
-        hub = ((a1 < 1.0f ? 0.5f * d1 * d1 : a1 - 0.5f) + (a2 < 1.0f ? 0.5f * d2 * d2 : a2 - 0.5f)) * inv_n;
-        p.q1_out[row0 + tid] = q1;
-        p.q2_out[row0 + tid] = q2;
-        p.dq1_out[row0 + tid] = fminf(fmaxf(d1, -1.0f), 1.0f) * inv_n;
-        p.dq2_out[row0 + tid] = fminf(fmaxf(d2, -1.0f), 1.0f) * inv_n;
-    }
-    if (tid < 64) {
-        const float s = rpo_wave_sum(hub);
-        if (tid == 0) p.loss_partial[blockIdx.x] = s;
-    }
+    mlp_tile_forward<EIN, H>(net, lds, row0, B, x0_save, h1_save, 0, 1.0f, 0.0f);
+    if (tid < kRows && row0 + tid < B) q_out[row0 + tid] = lds.out[tid * 2];
 }
 
+// gridDim.y = 4 roles per 16-row tile, independent of each other (their results meet in the TD prologue of the backward
+// pass, rpo_td): 0 / 1 = a' ~ pi(s') -> Complete + Proj -> Q1_targ / Q2_targ (role 0 also publishes the batch and log pi),
+// 2 / 3 = Q1 / Q2 on the stored (s, a).
 template <int EIN, int H>
 __global__ __launch_bounds__(kFwdThreads) void cart_sac_critic_forward_kernel(SacCriticFwdArgs p, CartConsts c) {
     __shared__ TileLds<EIN> lds;
     __shared__ __attribute__((aligned(16))) float4 tile[kRows * CartRow::CH];
-    const int row0 = blockIdx.x * kRows, tid = threadIdx.x;
+    const int row0 = blockIdx.x * kRows, tid = threadIdx.x, role = blockIdx.y;
     const long long t = p.ctrl[RPO_CTRL_T];
     sac_sample<CartRow>(p, tile, row0, t);
     const float* tf = reinterpret_cast<const float*>(tile);
+    if (role >= 2) {
+        if (role == 2) critic_role<CartRow, EIN, H>(p.critic1, lds, tf, row0, p.batch, p.q1_out, p.x0_save1, p.h1_save1);
+        else critic_role<CartRow, EIN, H>(p.critic2, lds, tf, row0, p.batch, p.q2_out, p.x0_save2, p.h1_save2);
+        return;
+    }
     float logp;
     const float ap = sac_policy<CartRow, EIN, H>(p, lds, tf, row0, t, logp);
     if (tid < kRows) {                                         // Complete + Proj: per-row stop test == the batched call
@@ -442,8 +420,10 @@ __global__ __launch_bounds__(kFwdThreads) void cart_sac_critic_forward_kernel(Sa
         const float2 act = cart_explore_project(a, c, row0 + tid, ap, 0.0f, t, k);
         lds.in_a[tid * kInA] = act.x;
         lds.in_a[tid * kInA + 1] = act.y;
+        if (role == 0 && row0 + tid < p.batch) p.logp_out[row0 + tid] = logp;
     }
-    sac_td<CartRow, EIN, H>(p, lds, tf, row0, logp);
+    if (role == 0) target_role<EIN, H>(p.critic_target1, lds, row0, p.batch, p.qn1_out);
+    else target_role<EIN, H>(p.critic_target2, lds, row0, p.batch, p.qn2_out);
 }
 
 template <int EIN, int H>
@@ -461,11 +441,29 @@ __global__ __launch_bounds__(kFwdThreads) void pend_sac_critic_front_kernel(SacC
     }
 }
 
-template <int EIN, int H>
-__global__ __launch_bounds__(kFwdThreads) void pend_sac_critic_back_kernel(SacCriticFwdArgs p) {
+// Stage the projected a' and s' of the tile for a target critic
+template <int EIN>
+__device__ __forceinline__ void stage_next(const SacCriticFwdArgs& p, TileLds<EIN>& lds, const float* tf, int row0) {
+    const int tid = threadIdx.x, B = p.batch;
+    if (tid < kRows * PendRow::S) {
+        const int r = tid / PendRow::S, i = tid - r * PendRow::S;
+        lds.in_s[r * kInS + i] = tf[r * PendRow::ROW + PendRow::NS_OFF + i];
+    }
+    if (tid < kRows) {
+        const bool live = row0 + tid < B;
+        lds.in_a[tid * kInA] = live ? p.next_actions[(size_t)(row0 + tid) * 2] : 0.0f;
+        lds.in_a[tid * kInA + 1] = live ? p.next_actions[(size_t)(row0 + tid) * 2 + 1] : 0.0f;
+    }
+}
+
+// back: gridDim.y = 4 independent roles per tile (Q1_targ | Q2_targ on (s', a'); Q1 | Q2 on (s, a)); RPODDPG: 2 roles
+// (Q_targ | Q).  The TD target / Huber loss is the prologue of the backward pass (rpo_td).
+template <int EIN, int H, int TWIN>
+__global__ __launch_bounds__(kFwdThreads) void pend_critic_back_kernel(SacCriticFwdArgs p) {
     __shared__ TileLds<EIN> lds;
     __shared__ __attribute__((aligned(16))) float4 tile[kRows * PendRow::CH];
     const int row0 = blockIdx.x * kRows, tid = threadIdx.x, B = p.batch;
+    const int role = TWIN ? blockIdx.y : (blockIdx.y == 0 ? 0 : 2);
     if (tid < kRows * PendRow::CH) {
         const int r = tid / PendRow::CH;
         tile[tid] = row0 + r < B ? reinterpret_cast<const float4*>(p.batch_out)[(size_t)row0 * PendRow::CH + tid]
@@ -473,20 +471,15 @@ __global__ __launch_bounds__(kFwdThreads) void pend_sac_critic_back_kernel(SacCr
     }
     __syncthreads();
     const float* tf = reinterpret_cast<const float*>(tile);
-    if (tid < kRows * PendRow::S) {
-        const int r = tid / PendRow::S, i = tid - r * PendRow::S;
-        lds.in_s[r * kInS + i] = tf[r * PendRow::ROW + PendRow::NS_OFF + i];
+    if (role < 2) {
+        stage_next<EIN>(p, lds, tf, row0);
+        if (role == 0) target_role<EIN, H>(p.critic_target1, lds, row0, B, p.qn1_out);
+        else target_role<EIN, H>(p.critic_target2, lds, row0, B, p.qn2_out);
+    } else if (role == 2) {
+        critic_role<PendRow, EIN, H>(p.critic1, lds, tf, row0, B, p.q1_out, p.x0_save1, p.h1_save1);
+    } else {
+        critic_role<PendRow, EIN, H>(p.critic2, lds, tf, row0, B, p.q2_out, p.x0_save2, p.h1_save2);
     }
-    float logp = 0.0f;
-    if (tid < kRows && row0 + tid < B) {
-        logp = p.logp_in[row0 + tid];
-        lds.in_a[tid * kInA] = p.next_actions[(size_t)(row0 + tid) * 2];
-        lds.in_a[tid * kInA + 1] = p.next_actions[(size_t)(row0 + tid) * 2 + 1];
-    } else if (tid < kRows) {
-        lds.in_a[tid * kInA] = 0.0f;
-        lds.in_a[tid * kInA + 1] = 0.0f;
-    }
-    sac_td<PendRow, EIN, H>(p, lds, tf, row0, logp);
 }
 
 template <int EIN, int H>
@@ -496,7 +489,7 @@ __global__ __launch_bounds__(kThreads) void actor_weights_kernel(BwdArgs p) {
 
 // RPODDPG critic forward on SpringPendulum, cut at the batch-coupled projection like the SAC form:
 //   front: sample -> pi_targ(s') (tanh box)                       -> ap_out
-//   back:  Q_targ(s', next_actions) -> y -> Q(s, a) saved -> dq, loss partials   (rpo_ddpg.py:327-337)
+//   back:  Q_targ(s', next_actions) | Q(s, a) saved  (pend_critic_back_kernel<.., 0>; rpo_ddpg.py:327-337)
 template <int EIN, int H>
 __global__ __launch_bounds__(kFwdThreads) void pend_ddpg_critic_front_kernel(SacCriticFwdArgs p) {
     __shared__ TileLds<EIN> lds;
@@ -511,57 +504,6 @@ __global__ __launch_bounds__(kFwdThreads) void pend_ddpg_critic_front_kernel(Sac
     }
     mlp_tile_forward<EIN, H>(p.actor, lds, row0, p.batch, nullptr, nullptr, 1, p.scale, p.base);
     if (tid < kRows && row0 + tid < p.batch) p.ap_out[row0 + tid] = lds.out[tid * 2];
-}
-
-template <int EIN, int H>
-__global__ __launch_bounds__(kFwdThreads) void pend_ddpg_critic_back_kernel(SacCriticFwdArgs p) {
-    __shared__ TileLds<EIN> lds;
-    __shared__ __attribute__((aligned(16))) float4 tile[kRows * PendRow::CH];
-    const int row0 = blockIdx.x * kRows, tid = threadIdx.x, B = p.batch;
-    if (tid < kRows * PendRow::CH) {
-        const int r = tid / PendRow::CH;
-        tile[tid] = row0 + r < B ? reinterpret_cast<const float4*>(p.batch_out)[(size_t)row0 * PendRow::CH + tid]
-                                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    __syncthreads();
-    const float* tf = reinterpret_cast<const float*>(tile);
-    if (tid < kRows * PendRow::S) {
-        const int r = tid / PendRow::S, i = tid - r * PendRow::S;
-        lds.in_s[r * kInS + i] = tf[r * PendRow::ROW + PendRow::NS_OFF + i];
-    }
-    if (tid < kRows) {
-        const bool live = row0 + tid < B;
-        lds.in_a[tid * kInA] = live ? p.next_actions[(size_t)(row0 + tid) * 2] : 0.0f;
-        lds.in_a[tid * kInA + 1] = live ? p.next_actions[(size_t)(row0 + tid) * 2 + 1] : 0.0f;
-    }
-    mlp_tile_forward<EIN, H>(p.critic_target1, lds, row0, B, nullptr, nullptr, 0, 1.0f, 0.0f);
-    float qn = 0.0f;
-    if (tid < kRows) qn = lds.out[tid * 2];
-    __syncthreads();
-    if (tid < kRows * PendRow::S) {
-        const int r = tid / PendRow::S, i = tid - r * PendRow::S;
-        lds.in_s[r * kInS + i] = tf[r * PendRow::ROW + i];
-    }
-    if (tid < kRows * 2) {
-        const int r = tid >> 1, i = tid & 1;
-        lds.in_a[r * kInA + i] = tf[r * PendRow::ROW + PendRow::A_OFF + i];
-    }
-    mlp_tile_forward<EIN, H>(p.critic1, lds, row0, B, p.x0_save1, p.h1_save1, 0, 1.0f, 0.0f);
-    float hub = 0.0f;
-    if (tid < kRows && row0 + tid < B) {
-        const float q = lds.out[tid * 2];
-        const float y = tf[tid * PendRow::ROW + PendRow::R_OFF] + p.gamma * (1.0f - tf[tid * PendRow::ROW + PendRow::D_OFF]) * qn;
-        const float d = q - y, ad = fabsf(d);
-        const float inv_n = 1.0f / (float)B;
-        hub = (ad < 1.0f ? 0.5f * d * d : ad - 0.5f) * inv_n;
-        p.q1_out[row0 + tid] = q;
-        p.q2_out[row0 + tid] = qn;
-        p.dq1_out[row0 + tid] = fminf(fmaxf(d, -1.0f), 1.0f) * inv_n;
-    }
-    if (tid < 64) {
-        const float s = rpo_wave_sum(hub);
-        if (tid == 0) p.loss_partial[blockIdx.x] = s;
-    }
 }
 
 // Env policies of the actor-update pipelines: Complete, the Lagrangian row and the backward of Complete.
@@ -945,11 +887,11 @@ int rpo_cartsafe_ddpg_critic_forward(const rpo_mlp* actor_target_host, const rpo
                                      const long long* idx_in, unsigned long long seed, unsigned sample_salt,
                                      const long long* ctrl, int max_steps, float corr_lr, float corr_eps,
                                      float corr_momentum, float box_lo, float box_hi, const float* consts_host,
-                                     int partial, float gamma, float* q_out, float* qn_out, float* dq_out,
-                                     float* loss_partial, float* x0_save, float* h1_save, void* stream) {
+                                     int partial, float* q_out, float* qn_out, float* x0_save, float* h1_save,
+                                     void* stream) {
     if (!actor_target_host || !critic_target_host || !critic_host) return RPO_ERR_NULL;
     if (batch <= 0 || cap_steps <= 0 || n_envs <= 0 || max_steps < 0) return RPO_ERR_ARG;
-    if (!rows || !batch_out || !ctrl || !q_out || !qn_out || !dq_out || !loss_partial || !x0_save || !h1_save) return RPO_ERR_NULL;
+    if (!rows || !batch_out || !ctrl || !q_out || !qn_out || !x0_save || !h1_save) return RPO_ERR_NULL;
     CriticFwdArgs a{};
     a.actor_target = to_dev(actor_target_host); a.critic_target = to_dev(critic_target_host); a.critic = to_dev(critic_host);
     const Mlp& at = a.actor_target;
@@ -963,13 +905,12 @@ int rpo_cartsafe_ddpg_critic_forward(const rpo_mlp* actor_target_host, const rpo
     a.scale = scale; a.base = base; a.rows = rows; a.cap_steps = cap_steps; a.n_envs = n_envs; a.batch = batch;
     a.batch_out = batch_out; a.idx_out = idx_out; a.idx_in = idx_in; a.seed = (uint64_t)seed; a.salt = (uint32_t)sample_salt;
     a.ctrl = ctrl; a.max_steps = max_steps; a.corr_lr = corr_lr; a.corr_eps = corr_eps; a.corr_momentum = corr_momentum;
-    a.box_lo = box_lo; a.box_hi = box_hi; a.gamma = gamma; a.q_out = q_out; a.qn_out = qn_out; a.dq_out = dq_out;
-    a.loss_partial = loss_partial; a.x0_save = x0_save; a.h1_save = h1_save;
-    const int grid = (batch + kRows - 1) / kRows;
+    a.box_lo = box_lo; a.box_hi = box_hi; a.q_out = q_out; a.qn_out = qn_out; a.x0_save = x0_save; a.h1_save = h1_save;
+    const int grid = (batch + kRows - 1) / kRows;                   // x: row tile, y: role (target chain | critic)
     if (at.E == 128) {
-        hipLaunchKernelGGL((cart_ddpg_critic_forward_kernel<128, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a, c);
+        hipLaunchKernelGGL((cart_ddpg_critic_forward_kernel<128, 256>), dim3(grid, 2), dim3(kFwdThreads), 0, (hipStream_t)stream, a, c);
     } else if (at.E == 256) {
-        hipLaunchKernelGGL((cart_ddpg_critic_forward_kernel<256, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a, c);
+        hipLaunchKernelGGL((cart_ddpg_critic_forward_kernel<256, 256>), dim3(grid, 2), dim3(kFwdThreads), 0, (hipStream_t)stream, a, c);
     } else {
         return RPO_ERR_ARG;
     }
@@ -985,12 +926,12 @@ int rpo_cartsafe_sac_critic_forward(const rpo_mlp* actor_host, const rpo_mlp* cr
                                     unsigned sample_salt, unsigned long long noise_seed, unsigned noise_id_base,
                                     unsigned noise_salt, const long long* ctrl, int max_steps, float corr_lr,
                                     float corr_eps, float corr_momentum, float box_lo, float box_hi,
-                                    const float* consts_host, int partial, float gamma, float alpha, float* q1_out,
-                                    float* q2_out, float* dq1_out, float* dq2_out, float* loss_partial, float* x0_save1,
-                                    float* h1_save1, float* x0_save2, float* h1_save2, void* stream) {
+                                    const float* consts_host, int partial, float* q1_out, float* q2_out,
+                                    float* qn1_out, float* qn2_out, float* logp_out, float* x0_save1, float* h1_save1,
+                                    float* x0_save2, float* h1_save2, void* stream) {
     if (!actor_host || !critic_target1_host || !critic_target2_host || !critic1_host || !critic2_host) return RPO_ERR_NULL;
     if (batch <= 0 || cap_steps <= 0 || n_envs <= 0 || max_steps < 0) return RPO_ERR_ARG;
-    if (!rows || !batch_out || !ctrl || !q1_out || !q2_out || !dq1_out || !dq2_out || !loss_partial || !x0_save1 || !h1_save1 ||
+    if (!rows || !batch_out || !ctrl || !q1_out || !q2_out || !qn1_out || !qn2_out || !logp_out || !x0_save1 || !h1_save1 ||
         !x0_save2 || !h1_save2)
         return RPO_ERR_NULL;
     SacCriticFwdArgs a{};
@@ -1007,14 +948,14 @@ int rpo_cartsafe_sac_critic_forward(const rpo_mlp* actor_host, const rpo_mlp* cr
     a.batch_out = batch_out; a.idx_out = idx_out; a.idx_in = idx_in; a.eps_in = eps_in; a.seed = (uint64_t)noise_seed;
     a.sample_seed = (uint64_t)sample_seed; a.salt = (uint32_t)sample_salt; a.noise_salt = (uint32_t)noise_salt;
     a.noise_id_base = (uint32_t)noise_id_base; a.ctrl = ctrl; a.max_steps = max_steps; a.corr_lr = corr_lr;
-    a.corr_eps = corr_eps; a.corr_momentum = corr_momentum; a.box_lo = box_lo; a.box_hi = box_hi; a.gamma = gamma;
-    a.alpha = alpha; a.q1_out = q1_out; a.q2_out = q2_out; a.dq1_out = dq1_out; a.dq2_out = dq2_out;
-    a.loss_partial = loss_partial; a.x0_save1 = x0_save1; a.h1_save1 = h1_save1; a.x0_save2 = x0_save2; a.h1_save2 = h1_save2;
-    const int grid = (batch + kRows - 1) / kRows;
+    a.corr_eps = corr_eps; a.corr_momentum = corr_momentum; a.box_lo = box_lo; a.box_hi = box_hi;
+    a.q1_out = q1_out; a.q2_out = q2_out; a.qn1_out = qn1_out; a.qn2_out = qn2_out; a.logp_out = logp_out;
+    a.x0_save1 = x0_save1; a.h1_save1 = h1_save1; a.x0_save2 = x0_save2; a.h1_save2 = h1_save2;
+    const int grid = (batch + kRows - 1) / kRows;                   // x: row tile, y: role
     if (a.actor.E == 128) {
-        hipLaunchKernelGGL((cart_sac_critic_forward_kernel<128, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a, c);
+        hipLaunchKernelGGL((cart_sac_critic_forward_kernel<128, 256>), dim3(grid, 4), dim3(kFwdThreads), 0, (hipStream_t)stream, a, c);
     } else if (a.actor.E == 256) {
-        hipLaunchKernelGGL((cart_sac_critic_forward_kernel<256, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a, c);
+        hipLaunchKernelGGL((cart_sac_critic_forward_kernel<256, 256>), dim3(grid, 4), dim3(kFwdThreads), 0, (hipStream_t)stream, a, c);
     } else {
         return RPO_ERR_ARG;
     }
@@ -1070,24 +1011,23 @@ int rpo_pendulum_sac_critic_front(const rpo_mlp* actor_host, float scale, float 
 
 int rpo_pendulum_sac_critic_back(const rpo_mlp* critic_target1_host, const rpo_mlp* critic_target2_host,
                                  const rpo_mlp* critic1_host, const rpo_mlp* critic2_host, int batch, float* batch_rows,
-                                 const float* next_actions, const float* logp, float gamma, float alpha, float* q1_out,
-                                 float* q2_out, float* dq1_out, float* dq2_out, float* loss_partial, float* x0_save1,
-                                 float* h1_save1, float* x0_save2, float* h1_save2, void* stream) {
+                                 const float* next_actions, float* q1_out, float* q2_out, float* qn1_out, float* qn2_out,
+                                 float* x0_save1, float* h1_save1, float* x0_save2, float* h1_save2, void* stream) {
     if (batch <= 0) return RPO_ERR_ARG;
-    if (!batch_rows || !next_actions || !logp || !q1_out || !q2_out || !dq1_out || !dq2_out || !loss_partial || !x0_save1 ||
-        !h1_save1 || !x0_save2 || !h1_save2)
+    if (!batch_rows || !next_actions || !q1_out || !q2_out || !qn1_out || !qn2_out || !x0_save1 || !h1_save1 || !x0_save2 ||
+        !h1_save2)
         return RPO_ERR_NULL;
     SacCriticFwdArgs a{};
     if (int e = fill_sac_args(a, 5, nullptr, critic_target1_host, critic_target2_host, critic1_host, critic2_host, false, true))
         return e;
-    a.batch = batch; a.batch_out = batch_rows; a.next_actions = next_actions; a.logp_in = logp; a.gamma = gamma;
-    a.alpha = alpha; a.q1_out = q1_out; a.q2_out = q2_out; a.dq1_out = dq1_out; a.dq2_out = dq2_out;
-    a.loss_partial = loss_partial; a.x0_save1 = x0_save1; a.h1_save1 = h1_save1; a.x0_save2 = x0_save2; a.h1_save2 = h1_save2;
-    const int grid = (batch + kRows - 1) / kRows;
+    a.batch = batch; a.batch_out = batch_rows; a.next_actions = next_actions;
+    a.q1_out = q1_out; a.q2_out = q2_out; a.qn1_out = qn1_out; a.qn2_out = qn2_out;
+    a.x0_save1 = x0_save1; a.h1_save1 = h1_save1; a.x0_save2 = x0_save2; a.h1_save2 = h1_save2;
+    const int grid = (batch + kRows - 1) / kRows;                   // x: row tile, y: role
     if (a.critic1.E == 128) {
-        hipLaunchKernelGGL((pend_sac_critic_back_kernel<128, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((pend_critic_back_kernel<128, 256, 1>), dim3(grid, 4), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
     } else {
-        hipLaunchKernelGGL((pend_sac_critic_back_kernel<256, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((pend_critic_back_kernel<256, 256, 1>), dim3(grid, 4), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
     }
     RPO_LAUNCH_CHECK();
     return 0;
@@ -1309,11 +1249,11 @@ int rpo_pendulum_ddpg_critic_front(const rpo_mlp* actor_target_host, float scale
 }
 
 int rpo_pendulum_ddpg_critic_back(const rpo_mlp* critic_target_host, const rpo_mlp* critic_host, int batch,
-                                  float* batch_rows, const float* next_actions, float gamma, float* q_out, float* qn_out,
-                                  float* dq_out, float* loss_partial, float* x0_save, float* h1_save, void* stream) {
+                                  float* batch_rows, const float* next_actions, float* q_out, float* qn_out,
+                                  float* x0_save, float* h1_save, void* stream) {
     if (!critic_target_host || !critic_host) return RPO_ERR_NULL;
     if (batch <= 0) return RPO_ERR_ARG;
-    if (!batch_rows || !next_actions || !q_out || !qn_out || !dq_out || !loss_partial || !x0_save || !h1_save) return RPO_ERR_NULL;
+    if (!batch_rows || !next_actions || !q_out || !qn_out || !x0_save || !h1_save) return RPO_ERR_NULL;
     SacCriticFwdArgs a{};
     a.critic_target1 = to_dev(critic_target_host); a.critic1 = to_dev(critic_host);
     const Mlp* qs[2] = {&a.critic_target1, &a.critic1};
@@ -1321,13 +1261,13 @@ int rpo_pendulum_ddpg_critic_back(const rpo_mlp* critic_target_host, const rpo_m
         if (q->S != 5 || q->A != 2 || q->cat || q->H != 256 || (q->E != 128 && q->E != 256) || q->E != qs[0]->E || q->n_out != 1 ||
             q->hd > 1)
             return RPO_ERR_ARG;
-    a.batch = batch; a.batch_out = batch_rows; a.next_actions = next_actions; a.gamma = gamma; a.q1_out = q_out;
-    a.q2_out = qn_out; a.dq1_out = dq_out; a.loss_partial = loss_partial; a.x0_save1 = x0_save; a.h1_save1 = h1_save;
-    const int grid = (batch + kRows - 1) / kRows;
+    a.batch = batch; a.batch_out = batch_rows; a.next_actions = next_actions; a.q1_out = q_out; a.qn1_out = qn_out;
+    a.x0_save1 = x0_save; a.h1_save1 = h1_save;
+    const int grid = (batch + kRows - 1) / kRows;                   // x: row tile, y: role (Q_targ | Q)
     if (a.critic1.E == 128) {
-        hipLaunchKernelGGL((pend_ddpg_critic_back_kernel<128, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((pend_critic_back_kernel<128, 256, 0>), dim3(grid, 2), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
     } else {
-        hipLaunchKernelGGL((pend_ddpg_critic_back_kernel<256, 256>), dim3(grid), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((pend_critic_back_kernel<256, 256, 0>), dim3(grid, 2), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
     }
     RPO_LAUNCH_CHECK();
     return 0;

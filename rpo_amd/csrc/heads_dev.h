@@ -48,4 +48,24 @@ __device__ __forceinline__ float tanh_box_bwd_row(float dap, float ap_det, float
     return pass ? dap * scale * (1.0f - y * y) : 0.0f;
 }
 
+// TD target and Huber loss of one sample (rpo_ddpg.py:331-335, rpo_sac.py:346-353): qn = Q_targ(s', a') for RPODDPG,
+// min(Q1_targ, Q2_targ) - alpha log pi(a'|s') for RPOSAC (has_q2 / has_logp); returns dLoss/dQ = clamp(q - y, -1, 1) / n
+// and the sample's share of the mean smooth-L1 loss.  Shared by rpo_td_huber and the prologue of the backward kernels.
+__device__ __forceinline__ float td_next_value(float qn1, float qn2, int has_q2, float logp, int has_logp, float alpha) {
+    RPO_FP_STRICT
+    float qn = has_q2 ? fminf(qn1, qn2) : qn1;
+    if (has_logp) qn = qn - alpha * logp;
+    return qn;
+}
+__device__ __forceinline__ float td_target(float reward, float done, float gamma, float qn) {
+    RPO_FP_STRICT
+    return reward + gamma * (1.0f - done) * qn;
+}
+__device__ __forceinline__ float td_huber_row(float q, float y, float inv_n, float* hub) {
+    RPO_FP_STRICT
+    const float d = q - y, ad = fabsf(d);
+    *hub = (ad < 1.0f ? 0.5f * d * d : ad - 0.5f) * inv_n;
+    return fminf(fmaxf(d, -1.0f), 1.0f) * inv_n;
+}
+
 }  // namespace rpo_head_dev

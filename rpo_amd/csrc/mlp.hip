@@ -222,13 +222,23 @@ int rpo_mlp_forward(const rpo_mlp* net_host, int n, const float* s, int s_stride
 
 static int make_bwd_args(BwdArgs& args, const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int n, const float* s,
                          int s_stride, const float* a, int a_stride, const float* x0, const float* h1, const float* dout,
-                         float* dh, float* dx0, float* da, int param_grads, int first_layer_state_only, float* gradmax) {
+                         float* dh, float* dx0, float* da, int param_grads, int first_layer_state_only, float* gradmax,
+                         const rpo_td* td) {
     if (!net_host) return RPO_ERR_NULL;
     Mlp net{net_host->Ws, net_host->bs, net_host->Wa, net_host->ba, net_host->W0, net_host->b0, net_host->W1,
             net_host->b1, net_host->W1b, net_host->b1b, net_host->S, net_host->A, net_host->E, net_host->H,
             net_host->n_out, net_host->cat, net_host->head_dim};
     if (int e = check_net(net)) return e;
     if (n <= 0 || s_stride < net.S || (net.A > 0 && a_stride < net.A)) return RPO_ERR_ARG;
+    TdArgs t{};
+    if (td) {                                                   // TD / Huber prologue: dout is produced, not read
+        if (net.n_out != 1 || net.hd > 1) return RPO_ERR_ARG;
+        if (!td->q || !td->qn1 || !td->reward || !td->done || !td->dq_out || !td->loss_partial) return RPO_ERR_NULL;
+        if (td->reward_stride <= 0 || td->done_stride <= 0) return RPO_ERR_ARG;
+        t = TdArgs{td->q, td->qn1, td->qn2, td->logp, td->reward, td->reward_stride, td->done, td->done_stride, td->alpha,
+                   td->gamma, td->dq_out, td->loss_partial};
+        dout = td->dq_out;
+    }
     if (!s || !x0 || !h1 || !dout || !dh || !dx0 || (net.A > 0 && !a)) return RPO_ERR_NULL;
     MlpGrad g{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (param_grads) {
@@ -241,7 +251,7 @@ static int make_bwd_args(BwdArgs& args, const rpo_mlp* net_host, const rpo_mlp_g
         if (!first_layer_state_only && net.n_out > 1 && (!g.W1b || !g.b1b)) return RPO_ERR_NULL;
     }
     args = BwdArgs{net, g, n, s, s_stride, a, a_stride, x0, h1, dout, dh, dx0, da, param_grads, first_layer_state_only,
-                   gradmax};
+                   gradmax, t};
     return 0;
 }
 
@@ -253,10 +263,11 @@ static int bwd_weights_grid(const Mlp& net, int first_layer_state_only) {
 
 int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int n, const float* s, int s_stride,
                      const float* a, int a_stride, const float* x0, const float* h1, const float* dout, float* dh,
-                     float* dx0, float* da, int param_grads, int first_layer_state_only, float* gradmax, void* stream) {
+                     float* dx0, float* da, int param_grads, int first_layer_state_only, float* gradmax,
+                     const rpo_td* td, void* stream) {
     BwdArgs args;
     if (int e = make_bwd_args(args, net_host, grad_host, n, s, s_stride, a, a_stride, x0, h1, dout, dh, dx0, da,
-                              param_grads, first_layer_state_only, gradmax))
+                              param_grads, first_layer_state_only, gradmax, td))
         return e;
     const Mlp& net = args.net;
     const int ein = net.cat ? 2 * net.E : net.E;
@@ -285,13 +296,13 @@ int rpo_mlp_backward_pair(const rpo_mlp* net1_host, const rpo_mlp_grad* grad1_ho
                           int a_stride, const float* x0_1, const float* h1_1, const float* dout_1, float* dh_1,
                           float* dx0_1, float* da_1, const float* x0_2, const float* h1_2, const float* dout_2, float* dh_2,
                           float* dx0_2, float* da_2, int param_grads, int first_layer_state_only, float* gradmax,
-                          void* stream) {
+                          const rpo_td* td1, const rpo_td* td2, void* stream) {
     BwdArgs2 args;
     if (int e = make_bwd_args(args.net[0], net1_host, grad1_host, n, s, s_stride, a, a_stride, x0_1, h1_1, dout_1, dh_1,
-                              dx0_1, da_1, param_grads, first_layer_state_only, gradmax))
+                              dx0_1, da_1, param_grads, first_layer_state_only, gradmax, td1))
         return e;
     if (int e = make_bwd_args(args.net[1], net2_host, grad2_host, n, s, s_stride, a, a_stride, x0_2, h1_2, dout_2, dh_2,
-                              dx0_2, da_2, param_grads, first_layer_state_only, gradmax))
+                              dx0_2, da_2, param_grads, first_layer_state_only, gradmax, td2))
         return e;
     const Mlp &n1 = args.net[0].net, &n2 = args.net[1].net;
     if (n1.S != n2.S || n1.A != n2.A || n1.E != n2.E || n1.H != n2.H || n1.n_out != n2.n_out || n1.cat != n2.cat ||

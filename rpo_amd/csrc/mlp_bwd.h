@@ -2,12 +2,28 @@
 // kernels (mlp.hip) and the fused actor-update pipeline (fused.hip).
 #pragma once
 #include "mlp_tile.h"
+#include "heads_dev.h"
 
 namespace rpo_mlp_dev {
 
 // ------------------------------------------------------------------------------------------------- backward, rows
 // Per row tile: dh = (dout W1) * 1[h1 > 0]  -> global (for the weights pass) and LDS; dW1 / db1 / db0 partial sums
 // (one atomic per value per workgroup); dx0 = (dh W0) * 1[x0 > 0] -> global; optionally da = dx0_a Wa.
+// Optional TD / Huber prologue of the rows pass (critic update): dout = dLoss/dQ is computed here from the critic's and
+// the target critics' outputs instead of being read, written to dq_out for the weights pass, and the row tile's share of
+// the loss goes to loss_partial[blockIdx.x].  q == NULL: no prologue.
+struct TdArgs {
+    const float* q;            // [n] Q(s, a) of this network
+    const float* qn1;          // [n] Q_targ(s', a')
+    const float* qn2;          // [n] second target critic or NULL
+    const float* logp;         // [n] log pi(a'|s') or NULL
+    const float* reward; int reward_stride;
+    const float* done; int done_stride;
+    float alpha, gamma;
+    float* dq_out;             // [n]
+    float* loss_partial;       // [ceil(n / 16)]
+};
+
 struct BwdArgs {
     Mlp net;
     MlpGrad g;
@@ -23,6 +39,7 @@ struct BwdArgs {
     int param_grads;       // 0: only dx0 / da are needed (critic inside the actor loss, non-shared embedding)
     int first_layer_state_only;   // 1: of the parameter gradients only dWs / dbs are accumulated (shared embedding)
     float* gradmax;        // NULL, or where the weights pass leaves max |gradient element written| (clip_grad_norm_(inf))
+    TdArgs td;
 };
 
 template <int EIN, int H>
@@ -36,7 +53,24 @@ __device__ __forceinline__ void mlp_bwd_rows_body(const BwdArgs& p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool wide_head = net.hd > 1;
     const int outs = wide_head ? net.n_out * net.hd : net.n_out;
-    if (!wide_head) {
+    if (p.td.q) {                                                  // TD target + Huber of the tile's rows (n_out == 1)
+        if (tid < 64) {
+            float dq = 0.0f, hub = 0.0f;
+            const int i = row0 + tid;
+            if (tid < kRows && i < p.n) {
+                const TdArgs& t = p.td;
+                const float qn = rpo_head_dev::td_next_value(t.qn1[i], t.qn2 ? t.qn2[i] : 0.0f, t.qn2 != nullptr,
+                                                             t.logp ? t.logp[i] : 0.0f, t.logp != nullptr, t.alpha);
+                const float y = rpo_head_dev::td_target(t.reward[(size_t)i * t.reward_stride],
+                                                        t.done[(size_t)i * t.done_stride], t.gamma, qn);
+                dq = rpo_head_dev::td_huber_row(t.q[i], y, 1.0f / (float)p.n, &hub);
+                t.dq_out[i] = dq;
+            }
+            if (tid < kRows) { dout_s[tid * 2] = dq; dout_s[tid * 2 + 1] = 0.0f; }
+            const float sum = rpo_wave_sum(hub);
+            if (tid == 0) p.td.loss_partial[blockIdx.x] = sum;
+        }
+    } else if (!wide_head) {
         if (tid < kRows * 2) {
             const int r = tid >> 1, o = tid & 1;
             dout_s[tid] = (o < net.n_out && row0 + r < p.n) ? p.dout[(size_t)(row0 + r) * net.n_out + o] : 0.0f;

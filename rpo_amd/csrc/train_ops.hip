@@ -2,15 +2,11 @@
 // inf-norm of a flat gradient buffer, fused clip + Adam (+DualAdam clamp, + Polyak), Polyak alone, Philox test hook.
 // All are single-pass streaming kernels with wave64 shuffle reductions.
 #include "common.h"
+#include "heads_dev.h"
 
 namespace {
 
 // ------------------------------------------------------------------------------------------- TD target + Huber
-__device__ __forceinline__ float huber(float d) {   // F.smooth_l1_loss, beta = 1
-    const float ad = fabsf(d);
-    return ad < 1.0f ? 0.5f * d * d : ad - 0.5f;
-}
-
 __global__ __launch_bounds__(RPO_BLOCK) void td_huber_kernel(
     int n, const float* __restrict__ q1, const float* __restrict__ q2, const float* __restrict__ qn1,
     const float* __restrict__ qn2, const float* __restrict__ logp, float alpha, const float* __restrict__ reward,
@@ -20,20 +16,19 @@ __global__ __launch_bounds__(RPO_BLOCK) void td_huber_kernel(
     const float inv_n = 1.0f / (float)n;
     float acc = 0.0f;
     for (int i = blockIdx.x * RPO_BLOCK + threadIdx.x; i < n; i += gridDim.x * RPO_BLOCK) {
-        float qn = qn1[i];
-        if (qn2) qn = fminf(qn, qn2[i]);                              // rpo_sac.py:346-347
-        if (logp) qn -= alpha * logp[i];
-        const float y = reward[(size_t)i * reward_stride] +
-                        gamma * (1.0f - done[(size_t)i * done_stride]) * qn;   // rpo_ddpg.py:332
+        const float qn = rpo_head_dev::td_next_value(qn1[i], qn2 ? qn2[i] : 0.0f, qn2 != nullptr,           // rpo_sac.py:346-347
+                                                     logp ? logp[i] : 0.0f, logp != nullptr, alpha);
+        const float y = rpo_head_dev::td_target(reward[(size_t)i * reward_stride], done[(size_t)i * done_stride], gamma,
+                                                qn);                                                            // rpo_ddpg.py:332
         if (target_out) target_out[i] = y;
-        const float d1 = q1[i] - y;
-        acc += huber(d1);
-        if (grad_q1) grad_q1[i] = fminf(fmaxf(d1, -1.0f), 1.0f) * inv_n;
+        float h1 = 0.0f, h2 = 0.0f;
+        const float g1 = rpo_head_dev::td_huber_row(q1[i], y, inv_n, &h1);
+        if (grad_q1) grad_q1[i] = g1;
         if (q2) {
-            const float d2 = q2[i] - y;
-            acc += huber(d2);
-            if (grad_q2) grad_q2[i] = fminf(fmaxf(d2, -1.0f), 1.0f) * inv_n;
+            const float g2 = rpo_head_dev::td_huber_row(q2[i], y, inv_n, &h2);
+            if (grad_q2) grad_q2[i] = g2;
         }
+        acc += h1 + h2;
     }
     const float r = rpo_wave_sum(acc);
     if ((threadIdx.x & (RPO_WAVE - 1)) == 0) red[threadIdx.x / RPO_WAVE] = r;
@@ -41,7 +36,7 @@ __global__ __launch_bounds__(RPO_BLOCK) void td_huber_kernel(
     if (threadIdx.x == 0 && loss_out) {
         float s = 0.0f;
         for (int w = 0; w < RPO_BLOCK / RPO_WAVE; ++w) s += red[w];
-        atomicAdd(loss_out, s * inv_n);
+        atomicAdd(loss_out, s);
     }
 }
 

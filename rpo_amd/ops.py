@@ -187,26 +187,26 @@ class CartSafeKernels(object):
 
     def ddpg_critic_forward(self, actor_target, critic_target, critic, scale, base, rows, cap_steps, n_envs, batch_out,
                             idx_out, idx_in, seed, salt, ctrl, max_steps, corr_lr, corr_eps, corr_momentum, box_lo, box_hi,
-                            gamma, q_out, qn_out, dq_out, loss_partial, x0_save, h1_save):
+                            q_out, qn_out, x0_save, h1_save):
         at, ct, cr = actor_target.net_struct(), critic_target.net_struct(), critic.net_struct()
         check(_lib.load().rpo_cartsafe_ddpg_critic_forward(
             ctypes.byref(at), ctypes.byref(ct), ctypes.byref(cr), scale, base, _p(rows), cap_steps, n_envs,
             batch_out.shape[0], _p(batch_out), _p(idx_out, torch.int64, allow_none=True),
             _p(idx_in, torch.int64, allow_none=True), seed, salt, _p(ctrl, torch.int64), max_steps, corr_lr, corr_eps,
-            corr_momentum, box_lo, box_hi, self._cptr, self.partial, gamma, _p(q_out), _p(qn_out), _p(dq_out),
-            _p(loss_partial), _p(x0_save), _p(h1_save), _stream()), "rpo_cartsafe_ddpg_critic_forward")
+            corr_momentum, box_lo, box_hi, self._cptr, self.partial, _p(q_out), _p(qn_out), _p(x0_save), _p(h1_save),
+            _stream()), "rpo_cartsafe_ddpg_critic_forward")
 
     def sac_critic_forward(self, actor, critic_target1, critic_target2, critic1, critic2, scale, base, rows, cap_steps,
                            n_envs, batch_out, idx_out, idx_in, eps_in, sample_seed, sample_salt, noise_seed, noise_id_base,
-                           noise_salt, ctrl, max_steps, corr_lr, corr_eps, corr_momentum, box_lo, box_hi, gamma, alpha,
-                           q1_out, q2_out, dq1_out, dq2_out, loss_partial, x0_save1, h1_save1, x0_save2, h1_save2):
+                           noise_salt, ctrl, max_steps, corr_lr, corr_eps, corr_momentum, box_lo, box_hi,
+                           q1_out, q2_out, qn1_out, qn2_out, logp_out, x0_save1, h1_save1, x0_save2, h1_save2):
         nets = [d.net_struct() for d in (actor, critic_target1, critic_target2, critic1, critic2)]
         check(_lib.load().rpo_cartsafe_sac_critic_forward(
             *[ctypes.byref(n) for n in nets], scale, base, _p(rows), cap_steps, n_envs, batch_out.shape[0], _p(batch_out),
             _p(idx_out, torch.int64, allow_none=True), _p(idx_in, torch.int64, allow_none=True),
             _p(eps_in, allow_none=True), sample_seed, sample_salt, noise_seed, noise_id_base, noise_salt,
             _p(ctrl, torch.int64), max_steps, corr_lr, corr_eps, corr_momentum, box_lo, box_hi, self._cptr, self.partial,
-            gamma, alpha, _p(q1_out), _p(q2_out), _p(dq1_out), _p(dq2_out), _p(loss_partial), _p(x0_save1), _p(h1_save1),
+            _p(q1_out), _p(q2_out), _p(qn1_out), _p(qn2_out), _p(logp_out), _p(x0_save1), _p(h1_save1),
             _p(x0_save2), _p(h1_save2), _stream()), "rpo_cartsafe_sac_critic_forward")
 
     def complete_bwd(self, obs, grad_action, grad_ap, action=None):
@@ -376,12 +376,11 @@ class PendulumKernels(object):
             _p(idx_out, torch.int64, allow_none=True), _p(idx_in, torch.int64, allow_none=True), sample_seed, sample_salt,
             _p(ctrl, torch.int64), _p(ap_out), _stream()), "rpo_pendulum_ddpg_critic_front")
 
-    def ddpg_critic_back(self, critic_target, critic, batch_rows, next_actions, gamma, q_out, qn_out, dq_out, loss_partial,
-                         x0_save, h1_save):
+    def ddpg_critic_back(self, critic_target, critic, batch_rows, next_actions, q_out, qn_out, x0_save, h1_save):
         ct, cr = critic_target.net_struct(), critic.net_struct()
         check(_lib.load().rpo_pendulum_ddpg_critic_back(
-            ctypes.byref(ct), ctypes.byref(cr), batch_rows.shape[0], _p(batch_rows), _p(next_actions), gamma, _p(q_out),
-            _p(qn_out), _p(dq_out), _p(loss_partial), _p(x0_save), _p(h1_save), _stream()), "rpo_pendulum_ddpg_critic_back")
+            ctypes.byref(ct), ctypes.byref(cr), batch_rows.shape[0], _p(batch_rows), _p(next_actions), _p(q_out),
+            _p(qn_out), _p(x0_save), _p(h1_save), _stream()), "rpo_pendulum_ddpg_critic_back")
 
     def sac_critic_front(self, actor, scale, base, box_lo, box_hi, rows, cap_steps, n_envs, batch_out, idx_out, idx_in,
                          eps_in, sample_seed, sample_salt, noise_seed, noise_id_base, noise_salt, ctrl, ap_out, logp_out):
@@ -392,12 +391,12 @@ class PendulumKernels(object):
             _p(eps_in, allow_none=True), sample_seed, sample_salt, noise_seed, noise_id_base, noise_salt,
             _p(ctrl, torch.int64), _p(ap_out), _p(logp_out), _stream()), "rpo_pendulum_sac_critic_front")
 
-    def sac_critic_back(self, critic_target1, critic_target2, critic1, critic2, batch_rows, next_actions, logp, gamma, alpha,
-                        q1_out, q2_out, dq1_out, dq2_out, loss_partial, x0_save1, h1_save1, x0_save2, h1_save2):
+    def sac_critic_back(self, critic_target1, critic_target2, critic1, critic2, batch_rows, next_actions,
+                        q1_out, q2_out, qn1_out, qn2_out, x0_save1, h1_save1, x0_save2, h1_save2):
         nets = [d.net_struct() for d in (critic_target1, critic_target2, critic1, critic2)]
         check(_lib.load().rpo_pendulum_sac_critic_back(
-            *[ctypes.byref(n) for n in nets], batch_rows.shape[0], _p(batch_rows), _p(next_actions), _p(logp), gamma, alpha,
-            _p(q1_out), _p(q2_out), _p(dq1_out), _p(dq2_out), _p(loss_partial), _p(x0_save1), _p(h1_save1), _p(x0_save2),
+            *[ctypes.byref(n) for n in nets], batch_rows.shape[0], _p(batch_rows), _p(next_actions),
+            _p(q1_out), _p(q2_out), _p(qn1_out), _p(qn2_out), _p(x0_save1), _p(h1_save1), _p(x0_save2),
             _p(h1_save2), _stream()), "rpo_pendulum_sac_critic_back")
 
     def project_batchref(self, obs, ap, action, iters_out, max_steps, corr_lr, corr_eps, corr_momentum):
@@ -437,6 +436,33 @@ class _MlpStruct(ctypes.Structure):
 
 class _MlpGradStruct(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("Ws", "bs", "Wa", "ba", "W0", "b0", "W1", "b1", "W1b", "b1b")]
+
+
+class _TdStruct(ctypes.Structure):
+    _fields_ = [("q", ctypes.c_void_p), ("qn1", ctypes.c_void_p), ("qn2", ctypes.c_void_p), ("logp", ctypes.c_void_p),
+                ("reward", ctypes.c_void_p), ("reward_stride", ctypes.c_int), ("done", ctypes.c_void_p),
+                ("done_stride", ctypes.c_int), ("alpha", ctypes.c_float), ("gamma", ctypes.c_float),
+                ("dq_out", ctypes.c_void_p), ("loss_partial", ctypes.c_void_p)]
+
+
+class Td(object):
+    """``rpo_td``: the TD target / Huber loss as the prologue of the critic's backward pass.  q / qn1 / qn2 / logp /
+    dq_out are [n] tensors (qn2, logp may be None), reward / done column views of the gathered batch, loss_partial
+    [ceil(n / 16)]."""
+
+    def __init__(self, q, qn1, qn2, logp, reward, done, alpha, gamma, dq_out, loss_partial):
+        self.q, self.qn1, self.qn2, self.logp, self.reward, self.done = q, qn1, qn2, logp, reward, done
+        self.alpha, self.gamma, self.dq_out, self.loss_partial = float(alpha), float(gamma), dq_out, loss_partial
+
+    def struct(self):
+        col = lambda t: (_p(t, contiguous=False), int(t.stride(0)) if t.dim() else 1)      # noqa: E731
+        (rp, rs), (dp, ds) = col(self.reward), col(self.done)
+        return _TdStruct(_p(self.q), _p(self.qn1), _p(self.qn2, allow_none=True), _p(self.logp, allow_none=True), rp, rs,
+                         dp, ds, self.alpha, self.gamma, _p(self.dq_out), _p(self.loss_partial))
+
+
+def _td_ref(td):
+    return None if td is None else ctypes.byref(td.struct())
 
 
 def mlp_supported(E, H, cat=False):
@@ -481,15 +507,19 @@ def mlp_forward(desc, s, a, out, x0_save=None, h1_save=None, out_mode=0, scale=1
 
 
 def mlp_backward(desc, s, a, x0, h1, dout, dh, dx0, da=None, param_grads=True, first_layer_state_only=False,
-                 gradmax=None):
+                 gradmax=None, td=None):
+    """td (a ``Td``): dout is not read; the rows pass computes it (TD target + Huber) into td.dq_out."""
     sp, ss = _row_view(s, desc.S)
     ap, as_ = (None, 0) if desc.A == 0 else _row_view(a, desc.A)
     net = desc.net_struct()
     grad = desc.grad_struct() if param_grads else None
-    check(_lib.load().rpo_mlp_backward(ctypes.byref(net), None if grad is None else ctypes.byref(grad), dout.shape[0],
-                                       sp, ss, ap, as_, _p(x0), _p(h1), _p(dout), _p(dh), _p(dx0),
+    n = dout.shape[0] if td is None else td.dq_out.shape[0]
+    tds = None if td is None else td.struct()
+    check(_lib.load().rpo_mlp_backward(ctypes.byref(net), None if grad is None else ctypes.byref(grad), n,
+                                       sp, ss, ap, as_, _p(x0), _p(h1), _p(dout, allow_none=td is not None), _p(dh), _p(dx0),
                                        _p(da, allow_none=True), int(param_grads), int(first_layer_state_only),
-                                       _p(gradmax, allow_none=True), _stream()), "rpo_mlp_backward")
+                                       _p(gradmax, allow_none=True), None if tds is None else ctypes.byref(tds), _stream()),
+          "rpo_mlp_backward")
 
 
 def tanh_box_bwd(dap, ap_det, noise, eps_start, eps_end, eps_decay, ctrl, lo, hi, scale, base, dout):
@@ -509,17 +539,22 @@ def gauss_head_bwd(raw, eps, dap, dlogp, scale, base, lo, hi, draw):
 
 
 def mlp_backward_pair(desc1, desc2, s, a, x0_1, h1_1, dout_1, dh_1, dx0_1, da_1, x0_2, h1_2, dout_2, dh_2, dx0_2, da_2,
-                      param_grads=True, first_layer_state_only=False, gradmax=None):
+                      param_grads=True, first_layer_state_only=False, gradmax=None, td1=None, td2=None):
     sp, ss = _row_view(s, desc1.S)
     ap, as_ = (None, 0) if desc1.A == 0 else _row_view(a, desc1.A)
     n1, n2 = desc1.net_struct(), desc2.net_struct()
     g1 = desc1.grad_struct() if param_grads else None
     g2 = desc2.grad_struct() if param_grads else None
+    n = dout_1.shape[0] if td1 is None else td1.dq_out.shape[0]
+    t1 = None if td1 is None else td1.struct()
+    t2 = None if td2 is None else td2.struct()
     check(_lib.load().rpo_mlp_backward_pair(
         ctypes.byref(n1), None if g1 is None else ctypes.byref(g1), ctypes.byref(n2), None if g2 is None else ctypes.byref(g2),
-        dout_1.shape[0], sp, ss, ap, as_, _p(x0_1), _p(h1_1), _p(dout_1), _p(dh_1), _p(dx0_1), _p(da_1, allow_none=True),
-        _p(x0_2), _p(h1_2), _p(dout_2), _p(dh_2), _p(dx0_2), _p(da_2, allow_none=True), int(param_grads),
-        int(first_layer_state_only), _p(gradmax, allow_none=True), _stream()), "rpo_mlp_backward_pair")
+        n, sp, ss, ap, as_, _p(x0_1), _p(h1_1), _p(dout_1, allow_none=td1 is not None), _p(dh_1), _p(dx0_1),
+        _p(da_1, allow_none=True), _p(x0_2), _p(h1_2), _p(dout_2, allow_none=td2 is not None), _p(dh_2), _p(dx0_2),
+        _p(da_2, allow_none=True), int(param_grads), int(first_layer_state_only), _p(gradmax, allow_none=True),
+        None if t1 is None else ctypes.byref(t1), None if t2 is None else ctypes.byref(t2), _stream()),
+        "rpo_mlp_backward_pair")
 
 
 def sac_actor_forward(env_kernels, actor, critic1, critic2, scale, base, box_lo, box_hi, alpha, batch, noise_in, seed,
