@@ -143,15 +143,8 @@ class RPODDPG(RPOTrainerBase):
         next_actions = self._project_batch(next_state, self._actor_out("actor_target", next_state))
         qn = f.forward("critic_target", next_state, next_actions, f.buf("qn", B, 1))
         q = f.forward("critic", state, action, f.buf("q", B, 1), save=True)
-        loss, dq = f.buf("loss_c", 1), f.buf("dq", B, 1)
-        loss.zero_()
-        self.backend.td_huber(q.view(-1), None, qn.view(-1), None, None, 0.0, reward, done, ag.gamma, loss, dq.view(-1),
-                              None)
-        self._zero_grads()
-        gm = self._critic_gradmax()
-        f.backward("critic", state, action, dq, gradmax=gm)
-        self._gradmax_ready = gm is not None
-        self.last_losses["critic"] = loss[0]
+        # TD target / Huber loss: the prologue of the backward pass (rpo_td)
+        self._critic_backward_td(cols, q, qn, f.buf("loss_parts", (B + 15) // 16))
 
     @property
     def _actor_pipeline(self):

@@ -132,13 +132,17 @@ class RPOSAC(RPOTrainerBase):
                 buf.rows, buf.capacity, buf.n_envs, self._batch, None, idx_in, eps_in, buf.seed, 0, self.seed,
                 self.dist.rank * B, _SALT_CRITIC, buf.ctrl, self.max_steps, self.corr_lr, self.corr_eps, self.corr_momentum,
                 self._box_lo, self._box_hi, q1, q2, qn1, qn2, logp, *saves)
-        # the four (two) chains of a tile ran in separate workgroups; the TD target / Huber terms are the prologue of the
-        # twin critics' backward pass (rpo_td): one loss-partial row per critic
+        self._critic_backward_td(cols, q1, q2, qn1, qn2, logp)
+
+    def _critic_backward_td(self, cols, q1, q2, qn1, qn2, logp):
+        """Backward of the twin critics with the TD target / Huber terms as its prologue (rpo_td; one loss-partial row
+        per critic): with the pipelines, the four chains of a tile ran in separate workgroups and meet here."""
+        f, ag, B = self.fused, self.agent, self.batch_size
         parts = f.buf("loss_parts2", 2, (B + 15) // 16)
         tds = [self.backend.Td(q.view(-1), qn1.view(-1), qn2.view(-1), logp, cols[3], cols[4], float(ag.alpha), ag.gamma,
                                f.buf(name, B, 1).view(-1), parts[i]) for i, (q, name) in enumerate(((q1, "dq1"), (q2, "dq2")))]
         self._zero_grads()
-        self._gradmax_ready = f.backward_pair("critic1", "critic2", state, action, None, None,
+        self._gradmax_ready = f.backward_pair("critic1", "critic2", cols[0], cols[1], None, None,
                                               gradmax=self._critic_gradmax(), td1=tds[0], td2=tds[1])
         self.last_losses["critic"] = _LazySum(parts)
 
@@ -157,13 +161,7 @@ class RPOSAC(RPOTrainerBase):
         qn2 = f.forward("critic_target2", next_state, next_actions, f.buf("qn2", B, 1))
         q1 = f.forward("critic1", state, action, f.buf("q1", B, 1), save=True)
         q2 = f.forward("critic2", state, action, f.buf("q2", B, 1), save=True)
-        loss, dq1, dq2 = f.buf("loss_c", 1), f.buf("dq1", B, 1), f.buf("dq2", B, 1)
-        loss.zero_()
-        self.backend.td_huber(q1.view(-1), q2.view(-1), qn1.view(-1), qn2.view(-1), logp, float(ag.alpha), reward, done,
-                              ag.gamma, loss, dq1.view(-1), dq2.view(-1))
-        self._zero_grads()
-        self._gradmax_ready = f.backward_pair("critic1", "critic2", state, action, dq1, dq2, gradmax=self._critic_gradmax())
-        self.last_losses["critic"] = loss[0]
+        self._critic_backward_td(cols, q1, q2, qn1, qn2, logp)
 
     @property
     def _actor_pipeline(self):

@@ -482,7 +482,35 @@ def mlp_forward(d, s, a, out, x0_save=None, h1_save=None, out_mode=0, scale=1.0,
             h1_save.copy_(h1)
 
 
-def mlp_backward(d, s, a, x0, h1, dout, dh, dx0, da=None, param_grads=True, first_layer_state_only=False, gradmax=None):
+class Td(object):
+    """Mirror of rpo_amd.ops.Td (rpo_td): TD target + Huber as the prologue of the critic's backward pass."""
+
+    def __init__(self, q, qn1, qn2, logp, reward, done, alpha, gamma, dq_out, loss_partial):
+        self.q, self.qn1, self.qn2, self.logp, self.reward, self.done = q, qn1, qn2, logp, reward, done
+        self.alpha, self.gamma, self.dq_out, self.loss_partial = float(alpha), float(gamma), dq_out, loss_partial
+
+    def apply(self):
+        """rpo_ddpg.py:331-335 / rpo_sac.py:346-353 in float32, loss partials per 16-row tile; returns dout [n, 1]."""
+        n = self.dq_out.shape[0]
+        qn = self.qn1 if self.qn2 is None else torch.minimum(self.qn1, self.qn2)
+        if self.logp is not None:
+            qn = qn - self.alpha * self.logp.reshape(-1)
+        y = self.reward.reshape(-1) + self.gamma * (1.0 - self.done.reshape(-1)) * qn
+        d = self.q - y
+        ad = d.abs()
+        hub = torch.where(ad < 1.0, 0.5 * d * d, ad - 0.5) / n
+        self.dq_out.copy_(torch.clamp(d, -1.0, 1.0) / n)
+        tiles = self.loss_partial.shape[0]
+        pad = torch.zeros(tiles * 16)
+        pad[:n] = hub
+        self.loss_partial.copy_(pad.view(tiles, 16).sum(1))
+        return self.dq_out.view(n, 1)
+
+
+def mlp_backward(d, s, a, x0, h1, dout, dh, dx0, da=None, param_grads=True, first_layer_state_only=False, gradmax=None,
+                 td=None):
+    if td is not None:
+        dout = td.apply()
     _mlp_backward(d, s, a, x0, h1, dout, dh, dx0, da, param_grads, first_layer_state_only)
     if gradmax is not None and param_grads:
         with torch.no_grad():
