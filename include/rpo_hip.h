@@ -345,6 +345,13 @@ int rpo_mlp_supported(int E, int H, int cat);
 int rpo_mlp_forward(const rpo_mlp* net_host, int n, const float* s, int s_stride, const float* a, int a_stride,
                     float* out, float* x0_save, float* h1_save, int out_mode, float scale, float base, void* stream);
 
+/* rpo_mlp_forward (out_mode 0) of 1..4 same-shaped scalar-head networks, each on its own inputs, in ONE launch
+ * (gridDim.y = network): Q_targ(s', a') and Q(s, a) of a critic update, and RPOSAC's twins (model/value.py:125-140), do
+ * not depend on each other.  All arguments are arrays of `count` entries; x0_save[k] / h1_save[k] may be NULL. */
+int rpo_mlp_forward_multi(int count, const rpo_mlp* const* nets, int n, const float* const* s, const int* s_stride,
+                          const float* const* a, const int* a_stride, float* const* out, float* const* x0_save,
+                          float* const* h1_save, void* stream);
+
 /* Backward of the same rows given dout [n, n_out] (two launches).  Parameter gradients are ACCUMULATED (+=) into
  * grad_host's buffers (the shared state embedding of shared_param=True receives contributions from two networks,
  * agent/ddpg_pa.py:34-36).  dh [n, H] and dx0 [n, Ein] are caller-provided scratch; da [n, A] (may be NULL) receives

@@ -120,6 +120,22 @@ class FusedNets(object):
         self.backend.mlp_forward(d, s, a, out, x0, h1, mode, scale, base)
         return out
 
+    def forward_multi(self, calls):
+        """calls = [(name, s, a, out, save), ...] for same-shaped scalar-head networks: one launch where the backend has
+        rpo_mlp_forward_multi, else one launch each.  Returns the ``out`` tensors."""
+        descs = [self.descs[c[0]] for c in calls]
+        same = all((d.S, d.A, d.E, d.H, d.n_out, d.cat) == (descs[0].S, descs[0].A, descs[0].E, descs[0].H, descs[0].n_out,
+                                                               descs[0].cat) and d.head_dim <= 1 for d in descs)
+        if not same or len(calls) > 4 or not hasattr(self.backend, "mlp_forward_multi"):
+            return [self.forward(name, s, a, out, save=save) for name, s, a, out, save in calls]
+        packed = []
+        for (name, s, a, out, save), d in zip(calls, descs):
+            n = out.shape[0]
+            packed.append((d, s, a, out, self.buf(name + ".x0", n, d.ein) if save else None,
+                           self.buf(name + ".h1", n, d.H) if save else None))
+        self.backend.mlp_forward_multi(packed)
+        return [c[3] for c in calls]
+
     def backward(self, name, s, a, dout, da=None, param_grads=True, first_layer_state_only=False, gradmax=None, td=None):
         """``gradmax`` (1-element tensor or None): the weights pass leaves the inf-norm of the gradients it wrote there,
         which saves the separate rpo_absmax launch of clip_grad_norm_ when the buffers were zero before.

@@ -141,8 +141,8 @@ class RPODDPG(RPOTrainerBase):
         f, ag, B = self.fused, self.agent, self.batch_size
         state, action, next_state, reward, done = cols[:5]
         next_actions = self._project_batch(next_state, self._actor_out("actor_target", next_state))
-        qn = f.forward("critic_target", next_state, next_actions, f.buf("qn", B, 1))
-        q = f.forward("critic", state, action, f.buf("q", B, 1), save=True)
+        qn, q = f.forward_multi([("critic_target", next_state, next_actions, f.buf("qn", B, 1), False),
+                                 ("critic", state, action, f.buf("q", B, 1), True)])
         # TD target / Huber loss: the prologue of the backward pass (rpo_td)
         self._critic_backward_td(cols, q, qn, f.buf("loss_parts", (B + 15) // 16))
 

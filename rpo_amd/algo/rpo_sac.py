@@ -157,10 +157,10 @@ class RPOSAC(RPOTrainerBase):
         eps = self._draw(self._noise_b, self.dist.rank * B * self.kernels.partial_dim, _SALT_CRITIC)
         ap_next, logp, _ = self._gauss(next_state, eps, "crit")
         next_actions = self._project_batch(next_state, ap_next)
-        qn1 = f.forward("critic_target1", next_state, next_actions, f.buf("qn1", B, 1))
-        qn2 = f.forward("critic_target2", next_state, next_actions, f.buf("qn2", B, 1))
-        q1 = f.forward("critic1", state, action, f.buf("q1", B, 1), save=True)
-        q2 = f.forward("critic2", state, action, f.buf("q2", B, 1), save=True)
+        qn1, qn2, q1, q2 = f.forward_multi([("critic_target1", next_state, next_actions, f.buf("qn1", B, 1), False),
+                                            ("critic_target2", next_state, next_actions, f.buf("qn2", B, 1), False),
+                                            ("critic1", state, action, f.buf("q1", B, 1), True),
+                                            ("critic2", state, action, f.buf("q2", B, 1), True)])
         self._critic_backward_td(cols, q1, q2, qn1, qn2, logp)
 
     @property

@@ -36,7 +36,7 @@ struct FwdArgs {
 };
 
 template <int EIN, int H, int RT, int INS, int INA>
-__global__ __launch_bounds__(kFwdThreads) void mlp_forward_kernel(FwdArgs p) {
+__device__ __forceinline__ void mlp_forward_body(const FwdArgs& p) {
     typedef TileLds<EIN, RT, INS, INA> Lds;
     __shared__ Lds lds;
     constexpr int ROWS = kRows * RT;
@@ -56,6 +56,19 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_forward_kernel(FwdArgs p) {
         const int r = tid / net.n_out, o = tid - r * net.n_out;
         if (row0 + r < p.n) p.out[(size_t)(row0 + r) * net.n_out + o] = lds.out[r * 2 + o];
     }
+}
+
+template <int EIN, int H, int RT, int INS, int INA>
+__global__ __launch_bounds__(kFwdThreads) void mlp_forward_kernel(FwdArgs p) { mlp_forward_body<EIN, H, RT, INS, INA>(p); }
+
+// Up to four same-shaped networks on their own inputs in one launch (gridDim.y = network): Q_targ(s', a') and Q(s, a) of a
+// critic update (and SAC's twins) are independent of each other.
+struct FwdArgs4 {
+    FwdArgs net[4];
+};
+template <int EIN, int H>
+__global__ __launch_bounds__(kFwdThreads) void mlp_forward_multi_kernel(FwdArgs4 p) {
+    mlp_forward_body<EIN, H, 1, kInS, kInA>(p.net[blockIdx.y]);
 }
 
 // Multi-output networks (hd > 1, e.g. the 14 basic actions of EVOPF-v0): same tile, MFMA head, raw outputs
@@ -259,6 +272,42 @@ static int bwd_weights_grid(const Mlp& net, int first_layer_state_only) {
     const int ein = net.cat ? 2 * net.E : net.E;
     const int fl_outputs = net.E * (net.S + 1 + ((net.A > 0 && !first_layer_state_only) ? net.A + 1 : 0));
     return (net.H / 16) * (ein / 64) + (net.hd > 1 ? net.H / 16 : net.H / 64) + (fl_outputs + 63) / 64;
+}
+
+int rpo_mlp_forward_multi(int count, const rpo_mlp* const* nets, int n, const float* const* s, const int* s_stride,
+                          const float* const* a, const int* a_stride, float* const* out, float* const* x0_save,
+                          float* const* h1_save, void* stream) {
+    if (count < 1 || count > 4 || n <= 0) return RPO_ERR_ARG;
+    if (!nets || !s || !s_stride || !a || !a_stride || !out || !x0_save || !h1_save) return RPO_ERR_NULL;
+    FwdArgs4 args;
+    for (int k = 0; k < count; ++k) {
+        const rpo_mlp* h = nets[k];
+        if (!h) return RPO_ERR_NULL;
+        Mlp net{h->Ws, h->bs, h->Wa, h->ba, h->W0, h->b0, h->W1, h->b1, h->W1b, h->b1b, h->S, h->A, h->E, h->H,
+                h->n_out, h->cat, h->head_dim};
+        if (int e = check_net(net)) return e;
+        if (net.hd > 1 || s_stride[k] < net.S || (net.A > 0 && a_stride[k] < net.A)) return RPO_ERR_ARG;
+        if (!s[k] || !out[k] || (net.A > 0 && !a[k])) return RPO_ERR_NULL;
+        if (k > 0) {
+            const Mlp& f = args.net[0].net;
+            if (net.S != f.S || net.A != f.A || net.E != f.E || net.H != f.H || net.n_out != f.n_out || net.cat != f.cat)
+                return RPO_ERR_ARG;
+        }
+        args.net[k] = FwdArgs{net, n, s[k], s_stride[k], a[k], a_stride[k], out[k], x0_save[k], h1_save[k], 0, 1.0f, 0.0f};
+    }
+    const Mlp& net = args.net[0].net;
+    const int ein = net.cat ? 2 * net.E : net.E;
+#define RPO_MLP_FWD_MULTI(EIN_, H_)                                                                                  \
+    if (ein == EIN_ && net.H == H_) {                                                                                \
+        hipLaunchKernelGGL((mlp_forward_multi_kernel<EIN_, H_>), dim3((n + kRows - 1) / kRows, count),               \
+                           dim3(kFwdThreads), 0, (hipStream_t)stream, args);                                         \
+        RPO_LAUNCH_CHECK();                                                                                          \
+        return 0;                                                                                                    \
+    }
+    RPO_MLP_FWD_MULTI(128, 256)
+    RPO_MLP_FWD_MULTI(256, 256)
+    RPO_MLP_FWD_MULTI(512, 256)
+    return RPO_ERR_ARG;
 }
 
 int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int n, const float* s, int s_stride,

@@ -455,8 +455,7 @@ class Td(object):
         self.alpha, self.gamma, self.dq_out, self.loss_partial = float(alpha), float(gamma), dq_out, loss_partial
 
     def struct(self):
-        col = lambda t: (_p(t, contiguous=False), int(t.stride(0)) if t.dim() else 1)      # noqa: E731
-        (rp, rs), (dp, ds) = col(self.reward), col(self.done)
+        (rp, rs), (dp, ds) = _col_view(self.reward), _col_view(self.done)
         return _TdStruct(_p(self.q), _p(self.qn1), _p(self.qn2, allow_none=True), _p(self.logp, allow_none=True), rp, rs,
                          dp, ds, self.alpha, self.gamma, _p(self.dq_out), _p(self.loss_partial))
 
@@ -504,6 +503,22 @@ def mlp_forward(desc, s, a, out, x0_save=None, h1_save=None, out_mode=0, scale=1
     check(_lib.load().rpo_mlp_forward(ctypes.byref(net), out.shape[0], sp, ss, ap, as_, _p(out),
                                       _p(x0_save, allow_none=True), _p(h1_save, allow_none=True), out_mode, scale, base,
                                       _stream()), "rpo_mlp_forward")
+
+
+def mlp_forward_multi(calls):
+    """One launch for up to four same-shaped networks: calls = [(desc, s, a, out, x0_save, h1_save), ...]."""
+    k = len(calls)
+    nets = [c[0].net_struct() for c in calls]
+    svs = [_row_view(c[1], c[0].S) for c in calls]
+    avs = [(None, 0) if c[0].A == 0 else _row_view(c[2], c[0].A) for c in calls]
+    ptrs = lambda vals: (ctypes.c_void_p * k)(*vals)                                   # noqa: E731
+    as_int = lambda v: None if v is None else (v.value if isinstance(v, ctypes.c_void_p) else v)   # noqa: E731
+    check(_lib.load().rpo_mlp_forward_multi(
+        k, ptrs([ctypes.addressof(n) for n in nets]), calls[0][3].shape[0],
+        ptrs([as_int(v[0]) for v in svs]), (ctypes.c_int * k)(*[v[1] for v in svs]),
+        ptrs([as_int(v[0]) for v in avs]), (ctypes.c_int * k)(*[v[1] for v in avs]),
+        ptrs([as_int(_p(c[3])) for c in calls]), ptrs([as_int(_p(c[4], allow_none=True)) for c in calls]),
+        ptrs([as_int(_p(c[5], allow_none=True)) for c in calls]), _stream()), "rpo_mlp_forward_multi")
 
 
 def mlp_backward(desc, s, a, x0, h1, dout, dh, dx0, da=None, param_grads=True, first_layer_state_only=False,

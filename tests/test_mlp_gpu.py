@@ -151,3 +151,57 @@ def test_mlp_tanh_box_epilogue():
     out = torch.empty(1000, 1, device=DEV)
     ops.mlp_forward(d, s, None, out, out_mode=1, scale=10.0, base=0.0)
     np.testing.assert_allclose(out.cpu().numpy(), net(s).detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_forward_multi_equals_single_launches():
+    """rpo_mlp_forward_multi (gridDim.y = network): four same-shaped critics on two different input pairs, bitwise equal to
+    four rpo_mlp_forward launches, pre-activations included; and the TD prologue of rpo_mlp_backward (rpo_td) against
+    rpo_td_huber + rpo_mlp_backward."""
+    from rpo_amd import ops
+    torch.manual_seed(3)
+    S, A, E, H, n = 6, 2, 128, 256, 200
+    nets = [aligned_params(SharedValueAdd(S, A, StateEmbedding(S, E, H), ActionEmbedding(A, E, H), E, H)) for _ in range(4)]
+    descs = [desc_for(ops, m, "add", S, A, E, H) for m in nets]
+    wide = torch.randn(n, 24, device=DEV)
+    s1, a1, s2, a2 = wide[:, 0:6], wide[:, 6:8], wide[:, 8:14], wide[:, 14:16]
+    ins = [(s2, a2), (s2, a2), (s1, a1), (s1, a1)]
+    single = []
+    for d, (s, a) in zip(descs, ins):
+        out, x0, h1 = torch.empty(n, 1, device=DEV), torch.empty(n, E, device=DEV), torch.empty(n, H, device=DEV)
+        ops.mlp_forward(d, s, a, out, x0, h1)
+        single.append((out, x0, h1))
+    multi = [(torch.empty(n, 1, device=DEV), torch.empty(n, E, device=DEV) if k >= 2 else None,
+              torch.empty(n, H, device=DEV) if k >= 2 else None) for k in range(4)]
+    ops.mlp_forward_multi([(d, s, a) + m for d, (s, a), m in zip(descs, ins, multi)])
+    for k in range(4):
+        assert torch.equal(single[k][0], multi[k][0])
+        if k >= 2:
+            assert torch.equal(single[k][1], multi[k][1]) and torch.equal(single[k][2], multi[k][2])
+    # TD prologue (SAC form: min of the targets, entropy term) for critic 2 (index 2)
+    qn1, qn2, q = single[0][0].view(-1), single[1][0].view(-1), single[2][0].view(-1)
+    logp = torch.randn(n, device=DEV)
+    reward, done = wide[:, 16:17], (wide[:, 17:18] > 0.5).float()
+    loss, dq = torch.zeros(1, device=DEV), torch.empty(n, device=DEV)
+    ops.td_huber(q, None, qn1, qn2, logp, 0.2, reward, done, 0.95, loss, dq, None, None)
+    d = descs[2]
+    grads_a = {}
+    for mode in ("dout", "td"):
+        for t in d.tensors.values():
+            if t is not None:
+                t.grad.zero_()
+        dh, dx0, da = torch.empty(n, H, device=DEV), torch.empty(n, E, device=DEV), torch.empty(n, A, device=DEV)
+        if mode == "dout":
+            ops.mlp_backward(d, s1, a1, single[2][1], single[2][2], dq.view(n, 1), dh, dx0, da)
+        else:
+            dq2, parts = torch.empty(n, device=DEV), torch.zeros((n + 15) // 16, device=DEV)
+            td = ops.Td(q, qn1, qn2, logp, reward, done, 0.2, 0.95, dq2, parts)
+            ops.mlp_backward(d, s1, a1, single[2][1], single[2][2], None, dh, dx0, da, td=td)
+            assert torch.equal(dq2, dq)
+            np.testing.assert_allclose(float(parts.sum()), float(loss), rtol=1e-5)
+        got = {k: t.grad.clone() for k, t in d.tensors.items() if t is not None}
+        got["da"] = da.clone()
+        if mode == "dout":
+            grads_a = got
+        else:
+            for k in got:
+                assert torch.equal(got[k], grads_a[k]), k
