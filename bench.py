@@ -349,16 +349,18 @@ def main():
         if not args.no_clinic and world == 1 and tr.fused is not None and headline:
             log("kernel clinic (hipGraph of back-to-back launches between two HIP events on the launch stream):")
             clinic = kernel_clinic(tr)
-            in_iter = ("rollout_kernel<CartEnv>", "cart_ddpg_critic_forward_kernel", "mlp_bwd_rows+weights_kernels")
+            # single launches of the iteration (the backward entry is a PAIR of launches, ~half each)
+            in_iter = ("rollout_kernel<CartEnv>", "cart_ddpg_critic_forward_kernel")
             dom = max(in_iter, key=lambda n: clinic[n]["us"])
             d, st = clinic[dom], clinic["cartsafe_step_kernel@1M"]
             result["roofline"] = {
                 "bound": d["bound"], "kernel": dom, "achieved": d["rate"], "peak": d["peak"], "unit": d["unit"],
                 "frac": d["frac"], "traffic": pmc_traffic(dom, d["n"]), "launch_us": d["us"], "units_per_launch": d["n"],
                 "algorithmic_flops_per_launch": d["work"],
-                "note": "dominant launch of the iteration: ReplayBuffer.sample + pi_targ + projection + Q_targ + Q + TD/Huber "
-                        "for 256 samples in one workgroup-per-16-rows pipeline; latency-bound (16 workgroups, each "
-                        "streaming 3 x 128 KB of f32 weights at ~47 GB/s per CU). Streaming regime of the HBM-bound env-step "
+                "note": "dominant launch of the iteration: ReplayBuffer.sample + pi_targ + projection + Q_targ | Q for 256 "
+                        "samples, two independent workgroups per 16-row tile (TD/Huber is the prologue of the backward "
+                        "pass); latency-bound (32 workgroups, the longer chain streams 2 x 128 KB of f32 weights at "
+                        "~47 GB/s per CU). Streaming regime of the HBM-bound env-step "
                         "kernel (1M lanes): %.0f GB/s = %.3f of the 8 TB/s peak, PMC traffic %s B vs %d algorithmic B."
                         % (st["rate"], st["frac"], pmc_traffic("cartsafe_step_kernel", st["n"]), st["work"]),
                 "hbm_streaming": {"kernel": "cartsafe_step_kernel", "bound": "hbm", "units_per_launch": st["n"],
