@@ -121,8 +121,17 @@ class _GraphCache(object):
             cur.wait_stream(self.side)
             return
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            fn()
+        try:
+            # thread-local capture mode: the collective backend's watchdog thread may touch the HIP runtime meanwhile
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                fn()
+        except Exception as exc:                                # noqa: BLE001  (capture is an optimisation, not a need)
+            import warnings
+            warnings.warn("hipGraph capture failed (%s: %s); continuing with eager launches" % (type(exc).__name__, exc))
+            self.enabled = False
+            torch.cuda.synchronize()
+            fn()                                                # nothing ran during the aborted capture
+            return
         e["graph"] = g
         g.replay()
 
