@@ -64,7 +64,14 @@ struct Ws {                       // per-wave workspace in LDS
     float vec[64];                // scratch
 };
 
-__device__ __forceinline__ void sync() { __syncthreads(); }
+// Workgroup == one wavefront (every kernel that uses Ws is launched with 64 threads): the LDS instructions of a wave
+// execute in issue order, so a cross-lane hand-over through LDS needs neither s_barrier nor the s_waitcnt 0 that
+// __syncthreads() implies -- only that the compiler keeps stores and loads in program order (act_project 133.8 -> 131.5 us).
+__device__ __forceinline__ void sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __device__ __forceinline__ void load_consts(Ws& w, const float* __restrict__ consts) {
     for (int i = threadIdx.x; i < RPO_EVOPF_CONSTS_LEN; i += RPO_WAVE) w.c[i] = consts[i];
