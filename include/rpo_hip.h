@@ -299,6 +299,30 @@ int rpo_adam_step(long long n, float* param, float* grad, float* exp_avg, float*
                   float* gradmax, int reset_gradmax, int zero_grad, int clamp_min0, float* target, float tau,
                   void* stream);
 
+/* Up to four independent optimiser slices in ONE launch (gridDim.y = slice): the tail of a policy step is
+ * actor Adam + multiplier DualAdam + the Polyak update of the critic target (rpo_ddpg.py:197-205), three launches of a
+ * few microseconds each otherwise.  Every field as in rpo_adam_step; additionally
+ *   target2 / n2: a second Polyak target for the first n2 elements of the slice (with a shared state embedding the
+ *                 actor's step also moves the critic's copy of it: critic_target[shared] follows in the same pass);
+ *   polyak_only:  no optimiser step for this slice, only target = (1 - tau) target + tau param (grad etc. unused).
+ * The slices must not overlap. */
+typedef struct {
+    long long n;
+    float *param, *grad, *exp_avg, *exp_avg_sq;
+    int* step_dev;
+    float lr, beta1, beta2, eps, weight_decay;
+    int maximize;
+    float clip_thres;
+    float* gradmax;
+    int reset_gradmax, zero_grad, clamp_min0;
+    float* target;
+    float tau;
+    float* target2;
+    long long n2;
+    int polyak_only;
+} rpo_adam_seg;
+int rpo_adam_step_multi(int count, const rpo_adam_seg* segs, void* stream);
+
 /* soft_update alone (agent/ddpg_pa.py:77-86, sac_pa.py:87-91): target = (1 - tau) * target + tau * param. */
 int rpo_polyak(long long n, const float* param, float* target, float tau, void* stream);
 

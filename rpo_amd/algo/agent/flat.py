@@ -104,6 +104,34 @@ class FusedAdam(object):
                                self.betas[0], self.betas[1], self.eps, self.weight_decay, self.maximize, clip,
                                self.gradmax, True, self.clamp_min0, target, tau, zero_grad=self.zero_grad_after)
 
+    def segment(self, target=None, tau=0.0, gradmax_ready=False, target2=None, n2=0):
+        """This optimiser's step as one slice of ``step_many`` (the inf-norm launch, when needed, happens here)."""
+        clip = self.clip_thres if self.clip_thres and self.clip_thres != float("inf") else 0.0
+        if clip > 0 and not gradmax_ready:
+            self.backend.absmax(self.grad, self.gradmax)
+        return dict(param=self.param, grad=self.grad, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq,
+                    step_dev=self.step_dev, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
+                    weight_decay=self.weight_decay, maximize=self.maximize, clip_thres=clip, gradmax=self.gradmax,
+                    reset_gradmax=True, clamp_min0=self.clamp_min0, target=target, tau=tau, zero_grad=self.zero_grad_after,
+                    target2=target2, n2=n2)
+
+    @staticmethod
+    def step_many(backend, segs):
+        """Several non-overlapping slices (``segment()`` dicts or ``dict(polyak_only=True, param=, target=, tau=)``) in
+        one launch where the backend has rpo_adam_step_multi; one launch each otherwise."""
+        if hasattr(backend, "adam_step_multi") and 1 < len(segs) <= 4:
+            return backend.adam_step_multi(segs)
+        for g in segs:
+            if g.get("polyak_only"):
+                backend.polyak(g["param"], g["target"], g["tau"])
+                continue
+            g = dict(g)
+            param, t2, n2 = g.pop("param"), g.pop("target2", None), g.pop("n2", 0)
+            backend.adam_step(param, g.pop("grad"), g.pop("exp_avg"), g.pop("exp_avg_sq"), g.pop("step_dev"), g.pop("lr"),
+                              **g)
+            if t2 is not None and n2 > 0:
+                backend.polyak(param[:n2], t2, g["tau"])
+
     def state_dict(self):
         return dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, step=self.step_dev, lr=self.lr)
 

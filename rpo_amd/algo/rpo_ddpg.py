@@ -5,6 +5,7 @@ import torch
 from .. import ops as hip_ops
 from .agent import PDDDPG_PA
 from .model import BoxConstraint
+from .agent.flat import FusedAdam
 from .trainer import _SALT_ACTOR, RPOTrainerBase, _LagrangianFn, _TDHuberFn, _env_int
 
 
@@ -260,11 +261,18 @@ class RPODDPG(RPOTrainerBase):
         self._gradmax_ready = False
 
     def _actor_step(self, actor_out):
-        ag = self.agent
-        ag.actor_optim.step(target=ag.actor_target_flat, tau=ag.tau,
-                            gradmax_ready=getattr(self, "_actor_gradmax_ready", False))
+        # actor Adam (+ Polyak of the actor target) | multiplier DualAdam | Polyak of the critic target: one launch.
+        # With a shared state embedding the actor's step moves the critic's copy of it too, so the shared part of the
+        # critic target follows inside the actor's slice (target2) and only the critic-only part is a slice of its own.
+        ag, fl = self.agent, self.agent.flat
+        c = fl.actor_range[0]                                  # [critic-only | shared | actor-only], padded offsets
+        sh = fl.critic_range[1] - c if fl.sizes[1] > 0 else 0
+        segs = [ag.actor_optim.segment(target=ag.actor_target_flat, tau=ag.tau,
+                                       gradmax_ready=getattr(self, "_actor_gradmax_ready", False),
+                                       target2=ag.critic_target_flat[c:c + sh] if sh > 0 else None, n2=sh)]
         self._actor_gradmax_ready = False
         if not self.fixed:
-            ag.nju_optim.step()                                    # lambda is never stepped (rpo_ddpg.py:202)
-        if ag.flat.sizes[1] > 0:
-            ag._polyak(ag.flat.param(ag.flat.critic_range), ag.critic_target_flat)
+            segs.append(ag.nju_optim.segment())                    # lambda is never stepped (rpo_ddpg.py:202)
+        if sh > 0 and c > 0:
+            segs.append(dict(polyak_only=True, param=fl.param((0, c)), target=ag.critic_target_flat[:c], tau=ag.tau))
+        FusedAdam.step_many(self.backend, segs)

@@ -5,6 +5,7 @@ import torch
 from .. import ops as hip_ops
 from .agent import PDSAC_PA
 from .model import BoxConstraint
+from .agent.flat import FusedAdam
 from .rpo_ddpg import _LazySum
 from .trainer import _SALT_ACTOR, _SALT_CRITIC, RPOTrainerBase, _LagrangianFn, _TDHuberFn, _env_int
 
@@ -282,10 +283,11 @@ class RPOSAC(RPOTrainerBase):
 
     def _actor_step(self, actor_out):
         ag = self.agent
-        ag.actor_optim.step(gradmax_ready=getattr(self, "_actor_gradmax_ready", False))
+        segs = [ag.actor_optim.segment(gradmax_ready=getattr(self, "_actor_gradmax_ready", False))]
         self._actor_gradmax_ready = False
         if not self.fixed:
-            ag.nju_optim.step()
+            segs.append(ag.nju_optim.segment())
+        FusedAdam.step_many(self.backend, segs)                 # actor Adam | multiplier DualAdam: one launch
         if self.automatic_entropy_tuning:
             _, logp = actor_out
             alpha_loss = -(ag.log_alpha * (logp + ag.target_entropy).detach()).mean()   # rpo_sac.py:210-216

@@ -81,9 +81,17 @@ struct AdamArgs {
     float* target;
     float tau;
     long long* arrive;   // scratch word for the "last workgroup" epilogue (step counter / gradmax reset)
+    float* target2;      // second Polyak target for elements [0, n2)
+    long long n2;
+    int polyak_only;
 };
 
-__global__ __launch_bounds__(RPO_BLOCK) void adam_kernel(AdamArgs p) {
+__device__ __forceinline__ void adam_body(const AdamArgs& p) {
+    if (p.polyak_only) {
+        for (long long i = (long long)blockIdx.x * RPO_BLOCK + threadIdx.x; i < p.n; i += (long long)gridDim.x * RPO_BLOCK)
+            p.target[i] = p.target[i] * (1.0f - p.tau) + p.param[i] * p.tau;
+        return;
+    }
     // torch.optim.Adam (single-tensor path): bias corrections in double like torch's Python floats
     const int step = p.step_dev[0] + 1;
     const double bc1 = 1.0 - pow((double)p.beta1, (double)step);
@@ -110,6 +118,7 @@ __global__ __launch_bounds__(RPO_BLOCK) void adam_kernel(AdamArgs p) {
         if (p.clamp_min0) w = fmaxf(w, 0.0f);         // DualAdam, model/dual.py:41-43
         p.param[i] = w; p.m[i] = m; p.v[i] = v;
         if (p.target) p.target[i] = p.target[i] * (1.0f - p.tau) + w * p.tau;   // soft_update, ddpg_pa.py:77-86
+        if (p.target2 && i < p.n2) p.target2[i] = p.target2[i] * (1.0f - p.tau) + w * p.tau;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -121,6 +130,13 @@ __global__ __launch_bounds__(RPO_BLOCK) void adam_kernel(AdamArgs p) {
         }
     }
 }
+
+__global__ __launch_bounds__(RPO_BLOCK) void adam_kernel(AdamArgs p) { adam_body(p); }
+
+struct AdamArgs4 {
+    AdamArgs seg[4];
+};
+__global__ __launch_bounds__(RPO_BLOCK) void adam_multi_kernel(AdamArgs4 p) { adam_body(p.seg[blockIdx.y]); }
 
 __global__ __launch_bounds__(RPO_BLOCK) void polyak_kernel(long long n, const float* __restrict__ param,
                                                            float* __restrict__ target, float tau) {
@@ -205,8 +221,34 @@ int rpo_adam_step(long long n, float* param, float* grad, float* exp_avg, float*
     // the arrival word lives right behind the step counter: step_dev must point at int32[4] = {step, pad, arrive(8 B)}
     AdamArgs a{n, param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, weight_decay, maximize,
                clip_thres, gradmax, reset_gradmax, zero_grad, clamp_min0, target, tau,
-               reinterpret_cast<long long*>(step_dev + 2)};
+               reinterpret_cast<long long*>(step_dev + 2), nullptr, 0, 0};
     hipLaunchKernelGGL(adam_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, a);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_adam_step_multi(int count, const rpo_adam_seg* segs, void* stream) {
+    if (count < 1 || count > 4) return RPO_ERR_ARG;
+    if (!segs) return RPO_ERR_NULL;
+    AdamArgs4 a;
+    long long n_max = 0;
+    for (int k = 0; k < count; ++k) {
+        const rpo_adam_seg& g = segs[k];
+        if (g.n <= 0 || g.n2 < 0 || g.n2 > g.n) return RPO_ERR_ARG;
+        if (!g.param) return RPO_ERR_NULL;
+        if (g.polyak_only) {
+            if (!g.target) return RPO_ERR_NULL;
+        } else {
+            if (!g.grad || !g.exp_avg || !g.exp_avg_sq || !g.step_dev) return RPO_ERR_NULL;
+            if (g.clip_thres > 0.0f && !g.gradmax) return RPO_ERR_NULL;
+        }
+        a.seg[k] = AdamArgs{g.n, g.param, g.grad, g.exp_avg, g.exp_avg_sq, g.step_dev, g.lr, g.beta1, g.beta2, g.eps,
+                            g.weight_decay, g.maximize, g.clip_thres, g.gradmax, g.reset_gradmax, g.zero_grad, g.clamp_min0,
+                            g.target, g.tau, g.polyak_only ? nullptr : reinterpret_cast<long long*>(g.step_dev + 2),
+                            g.target2, g.n2, g.polyak_only};
+        n_max = g.n > n_max ? g.n : n_max;
+    }
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(rpo_grid_for(n_max), count), dim3(RPO_BLOCK), 0, (hipStream_t)stream, a);
     RPO_LAUNCH_CHECK();
     return 0;
 }

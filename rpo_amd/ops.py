@@ -123,6 +123,36 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0
                                     _p(target, allow_none=True), tau, _stream()), "rpo_adam_step")
 
 
+class _AdamSegStruct(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_longlong), ("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
+                ("exp_avg_sq", ctypes.c_void_p), ("step_dev", ctypes.c_void_p), ("lr", ctypes.c_float),
+                ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
+                ("weight_decay", ctypes.c_float), ("maximize", ctypes.c_int), ("clip_thres", ctypes.c_float),
+                ("gradmax", ctypes.c_void_p), ("reset_gradmax", ctypes.c_int), ("zero_grad", ctypes.c_int),
+                ("clamp_min0", ctypes.c_int), ("target", ctypes.c_void_p), ("tau", ctypes.c_float),
+                ("target2", ctypes.c_void_p), ("n2", ctypes.c_longlong), ("polyak_only", ctypes.c_int)]
+
+
+def adam_step_multi(segs):
+    """One launch for up to four non-overlapping optimiser slices (rpo_adam_step_multi).  Each entry is a dict with the
+    keyword arguments of ``adam_step`` (+ ``target2`` / ``n2``), or ``dict(polyak_only=True, param=, target=, tau=)``."""
+    arr = (_AdamSegStruct * len(segs))()
+    vp = lambda t, dt=torch.float32: None if t is None else _p(t, dt).value                      # noqa: E731
+    for a, g in zip(arr, segs):
+        a.n, a.param, a.tau = g["param"].numel(), vp(g["param"]), g.get("tau", 0.0)
+        a.target, a.target2, a.n2 = vp(g.get("target")), vp(g.get("target2")), int(g.get("n2", 0))
+        a.polyak_only = int(bool(g.get("polyak_only", False)))
+        if a.polyak_only:
+            continue
+        a.grad, a.exp_avg, a.exp_avg_sq = vp(g["grad"]), vp(g["exp_avg"]), vp(g["exp_avg_sq"])
+        a.step_dev = vp(g["step_dev"], torch.int32)
+        a.lr, a.beta1, a.beta2, a.eps = g["lr"], g.get("beta1", 0.9), g.get("beta2", 0.999), g.get("eps", 1e-8)
+        a.weight_decay, a.maximize, a.clip_thres = g.get("weight_decay", 0.0), int(g.get("maximize", False)), g.get("clip_thres", 0.0)
+        a.gradmax, a.reset_gradmax = vp(g.get("gradmax")), int(g.get("reset_gradmax", True))
+        a.zero_grad, a.clamp_min0 = int(g.get("zero_grad", False)), int(g.get("clamp_min0", False))
+    check(_lib.load().rpo_adam_step_multi(len(segs), arr, _stream()), "rpo_adam_step_multi")
+
+
 def polyak(param, target, tau):
     check(_lib.load().rpo_polyak(param.numel(), _p(param), _p(target), tau, _stream()), "rpo_polyak")
 

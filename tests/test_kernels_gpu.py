@@ -533,3 +533,48 @@ def test_cart_full_size_properties(ops):
     s1, c1 = rollout([(0, n)])
     s2, c2 = rollout([(0, n // 2), (n // 2, n)])
     assert torch.equal(s1, s2) and torch.equal(c1, c2) and int(c1.sum()) >= 2 * n
+
+
+def test_adam_step_multi_equals_single_launches(ops):
+    """rpo_adam_step_multi (gridDim.y = slice): actor Adam with two Polyak targets (the second over a prefix: the shared
+    embedding's copy in the critic target) | DualAdam | Polyak-only slice, bitwise equal to rpo_adam_step / rpo_polyak."""
+    rng = np.random.RandomState(5)
+
+    def fresh():
+        st = {}
+        rs = np.random.RandomState(6)
+        for name, n in (("p", 34180), ("d", 6), ("c", 33796)):
+            st[name] = dict(param=dev(rs.randn(n).astype(np.float32) * 0.1), m=torch.zeros(n, device=DEV),
+                            v=torch.zeros(n, device=DEV), step=torch.zeros(4, dtype=torch.int32, device=DEV),
+                            gmax=torch.zeros(1, device=DEV))
+        st["p"]["target"] = dev(rs.randn(34180).astype(np.float32))
+        st["p"]["target2"] = dev(rs.randn(768).astype(np.float32))
+        st["c"]["target"] = dev(rs.randn(33796).astype(np.float32))
+        return st
+    a, b = fresh(), fresh()
+    for it in range(3):
+        gp, gd = rng.randn(34180).astype(np.float32), rng.randn(6).astype(np.float32)
+        for st, multi in ((a, False), (b, True)):
+            grad_p, grad_d = dev(gp), dev(gd)
+            ops.absmax(grad_p, st["p"]["gmax"])
+            if not multi:
+                ops.adam_step(st["p"]["param"], grad_p, st["p"]["m"], st["p"]["v"], st["p"]["step"], 1e-4, clip_thres=0.2,
+                              gradmax=st["p"]["gmax"], target=st["p"]["target"], tau=0.005, zero_grad=True)
+                ops.polyak(st["p"]["param"][:768], st["p"]["target2"], 0.005)
+                ops.adam_step(st["d"]["param"], grad_d, st["d"]["m"], st["d"]["v"], st["d"]["step"], 0.2, maximize=True,
+                              clamp_min0=True, zero_grad=True)
+                ops.polyak(st["c"]["param"], st["c"]["target"], 0.005)
+            else:
+                ops.adam_step_multi([
+                    dict(param=st["p"]["param"], grad=grad_p, exp_avg=st["p"]["m"], exp_avg_sq=st["p"]["v"],
+                         step_dev=st["p"]["step"], lr=1e-4, clip_thres=0.2, gradmax=st["p"]["gmax"], target=st["p"]["target"],
+                         tau=0.005, zero_grad=True, target2=st["p"]["target2"], n2=768),
+                    dict(param=st["d"]["param"], grad=grad_d, exp_avg=st["d"]["m"], exp_avg_sq=st["d"]["v"],
+                         step_dev=st["d"]["step"], lr=0.2, maximize=True, clamp_min0=True, zero_grad=True,
+                         gradmax=st["d"]["gmax"]),
+                    dict(polyak_only=True, param=st["c"]["param"], target=st["c"]["target"], tau=0.005)])
+            assert float(grad_p.abs().max()) == 0.0 and float(grad_d.abs().max()) == 0.0      # consumed
+    for name in a:
+        for key in a[name]:
+            assert torch.equal(a[name][key], b[name][key]), (name, key)
+    assert int(b["p"]["step"][0]) == 3 and int(b["d"]["step"][0]) == 3 and int(b["p"]["step"][2]) == 0
