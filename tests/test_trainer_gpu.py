@@ -85,6 +85,31 @@ def test_multi_iteration_graph_equals_single_iteration_graphs(hip, algo, envname
     assert int(a.vec.ctrl[0]) == 70 and a._t == 70 and a._updates == b._updates == 70
 
 
+def test_multi_iteration_graph_with_evaluation_and_logger(hip, monkeypatch, capsys):
+    """run(eval=True) over 1100 iterations (evaluations at 500 and 1000, Logger attached): graph windows of 16 iterations
+    must stop at the evaluation boundaries and give the same parameters, Logger rows and evaluation lines as one graph
+    per iteration."""
+    from rpo_amd.utils.logger import Logger
+    dev = torch.device("cuda")
+    out = []
+    for cyc in ("16", "1"):
+        monkeypatch.setenv("RPO_GRAPH_CYCLE", cyc)
+        torch.manual_seed(5)
+        tr = build_trainer("ddpg", "cart", hip, dev, num_envs=256, use_graph=True)
+        tr.max_epochs = 1100
+        tr.logger = Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=1100)
+        tr.run(eval=True)
+        torch.cuda.synchronize()
+        out.append((tr, capsys.readouterr().out))
+    (a, ta), (b, tb) = out
+    assert ("cycle", 16, True) in a._graphs.entries and not any(k[0] == "cycle" for k in b._graphs.entries)
+    assert a._t == b._t == 1100 and a.logger.pointer == b.logger.pointer > 1000
+    assert torch.equal(a.agent.flat.data, b.agent.flat.data) and torch.equal(a.buffer.rows, b.buffer.rows)
+    for key in ("epoch", "reward", "max_ineq", "max_eq"):
+        np.testing.assert_array_equal(a.logger.tracker[key], b.logger.tracker[key])
+    assert ta == tb and ta.count("\n") >= 2
+
+
 def test_multi_iteration_graph_of_rollouts_only(hip, monkeypatch):
     dev = torch.device("cuda")
     monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
