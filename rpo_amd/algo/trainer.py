@@ -185,6 +185,8 @@ class RPOTrainerBase(object):
         if use_graph is None:
             use_graph = bool(_env_int("RPO_GRAPH", 1)) and device.type == "cuda"
         self._graphs = _GraphCache(use_graph)
+        self._tail = None           # data-parallel runs: deferred last segment of the previous iteration
+        self._last_cols = self._last_actor_out = None
         self._cycle = _env_int("RPO_GRAPH_CYCLE", 16) // max(1, self.policy_fre) * max(1, self.policy_fre)
         # projection of training batches: the reference's literal batched semantics (default) or row-wise
         # (RPO_ROWWISE_PROJECTION=1); rollouts are always per lane == the reference's B = 1 calls
@@ -325,21 +327,22 @@ class RPOTrainerBase(object):
         segs = []
         if not do_train:
             return [(lambda: self._rollout(warm), [])]
-        box = {}
+        # the sampled columns / the actor's outputs are views of static buffers: they are kept on the trainer (not in a
+        # per-iteration closure) because a segment may be replayed from its graph while a later one still runs eagerly
 
         def s1():
             self._rollout(warm)
-            box["cols"] = self._sample()
-            self._critic_update(box["cols"])
+            self._last_cols = self._sample()
+            self._critic_update(self._last_cols)
         segs.append((s1, [fl.gradient(fl.critic_range)]))
         if actor_step:
             def s2():
                 self._critic_step(actor_step)
-                box["actor_out"] = self._actor_update(box["cols"])
+                self._last_actor_out = self._actor_update(self._last_cols)
             segs.append((s2, [fl.gradient(fl.policy_bucket)]))
 
             def s3():
-                self._actor_step(box["actor_out"])
+                self._actor_step(self._last_actor_out)
             segs.append((s3, []))
         else:
             segs.append((lambda: self._critic_step(actor_step), []))
@@ -356,9 +359,26 @@ class RPOTrainerBase(object):
         if not self.dist.on:
             self._graphs.run((warm, do_train, actor_step), lambda: [fn() for fn, _ in segs])
             return
-        for i, (fn, reduce_after) in enumerate(segs):      # collectives stay eager between captured segments
-            self._graphs.run((warm, do_train, actor_step, i), fn)
+        # Collectives stay eager between captured segments.  The last segment of an iteration (the optimiser step that
+        # follows the last all-reduce) has no collective behind it: it is deferred and captured together with the first
+        # segment of the NEXT iteration, so that an iteration costs as many graph launches as it has all-reduces.
+        tail, self._tail = self._tail, None
+        for i, (fn, reduce_after) in enumerate(segs):
+            key = (warm, do_train, actor_step, i)
+            if i == 0 and tail is not None:
+                prev_fn, first = tail[1], fn
+                key, fn = ("after",) + tail[0] + key, (lambda: (prev_fn(), first()))
+            if i == len(segs) - 1 and not reduce_after and i > 0 and not getattr(self, "automatic_entropy_tuning", False):
+                self._tail = (key, fn)                             # flushed by the next iteration or _flush_tail()
+                return
+            self._graphs.run(key, fn)
             self.dist.mean_(reduce_after)
+
+    def _flush_tail(self):
+        """Run the deferred last segment of the previous iteration now (before anything reads the parameters)."""
+        tail, self._tail = self._tail, None
+        if tail is not None:
+            self._graphs.run(tail[0], tail[1])
 
     def _extra_body(self, actor_step):
         self.vec.ctrl[hip_ops.CONST["RPO_CTRL_UPDATES"]] += 1
@@ -451,6 +471,7 @@ class RPOTrainerBase(object):
                 if do_train:
                     self._updates += 1
                     if self.updates_per_step > 1:
+                        self._flush_tail()
                         self._extra_updates()
                         self.vec.ctrl[hip_ops.CONST["RPO_CTRL_UPDATES"]] = 0
             for _ in range(L):
@@ -462,8 +483,10 @@ class RPOTrainerBase(object):
             if t - self._harvested >= self.vec.stats.shape[0] // 2:
                 self._harvest()
             if eval and t % self.eval_fre == 0 and t > self.warmup:
+                self._flush_tail()
                 self._harvest()
                 self._print_eval(t, self.eval())
+        self._flush_tail()
 
     def _cycle_len(self, t, left, warm, do_train, eval):
         """Iterations the next launch may cover: RPO_GRAPH_CYCLE (default 16, rounded to a multiple of policy_fre) in the

@@ -196,7 +196,7 @@ def test_gym_api_single_env_on_gpu(hip, golden):
     env.close()
 
 
-def _dp_worker(rank, world, port, out_dir):
+def _dp_worker(rank, world, port, out_dir, use_graph=True):
     import os
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -208,13 +208,16 @@ def _dp_worker(rank, world, port, out_dir):
     from test_train_step_golden import build_trainer
     dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share cuda:0; gloo moves GPU tensors
     torch.manual_seed(5)
-    tr = build_trainer("ddpg", "cart", ops, torch.device("cuda"), num_envs=512, use_graph=True)
+    tr = build_trainer("ddpg", "cart", ops, torch.device("cuda"), num_envs=512, use_graph=use_graph)
     assert tr.n_local == 256 and tr.vec.env_id_base == 256 * rank
     tr.vec.reset()
-    tr.run_steps(20)                        # eager passes, capture of the three graph segments, replays + collectives
+    tr.run_steps(13)                        # eager passes, capture of the graph segments, replays + collectives;
+    tr.run_steps(27)                        # the deferred optimiser tail is flushed at the end of each call
     tr._harvest(final=True)
     torch.cuda.synchronize()
-    assert any(e["graph"] is not None for e in tr._graphs.entries.values())
+    if use_graph:
+        captured = [k for k, e in tr._graphs.entries.items() if e["graph"] is not None]
+        assert any(k[0] == "after" for k in captured), captured      # tail of iteration i + head of iteration i + 1
     torch.save(dict(flat=tr.agent.flat.data.cpu(), nju=tr.agent.nju.weight.data.cpu(), env_steps=float(tr.env_steps),
                     state=tr.vec.internal.cpu()), os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
@@ -226,27 +229,39 @@ def test_data_parallel_graph_segments_on_gpu(hip, tmp_path):
     all-reduces keeps the replicas bit-identical, and the lanes of rank 1 are env ids 256..511."""
     import socket
     import torch.multiprocessing as mp
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=False)
+    ports = []
+    for _ in range(2):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        ports.append(s.getsockname()[1])
+        s.close()
     import os
     import time
-    deadline = time.time() + 240
-    while not ctx.join(timeout=5):                             # raises if a rank failed
-        if time.time() > deadline:
-            # two processes time-slicing one GPU through gloo is a stand-in for one process per GPU over RCCL; it hung
-            # once in ~20 runs on this pool.  Never leave a hung box behind: end exactly the ranks we started.
-            for proc in ctx.processes:
-                if proc.is_alive():
-                    proc.kill()
-            pytest.skip("two ranks sharing one GPU did not finish within 240 s; the N > 1 path is covered by the "
-                        "world_size-2 gloo tests on CPU (tests/test_distributed_cpu.py)")
+    results = {}
+    for use_graph in (True, False):
+        out_dir = os.path.join(str(tmp_path), "graph" if use_graph else "eager")
+        os.makedirs(out_dir)
+        ctx = mp.spawn(_dp_worker, args=(2, ports[0 if use_graph else 1], out_dir, use_graph), nprocs=2, join=False)
+        deadline = time.time() + 200
+        while not ctx.join(timeout=5):                         # raises if a rank failed
+            if time.time() > deadline:
+                # two processes time-slicing one GPU through gloo is a stand-in for one process per GPU over RCCL; it
+                # hung once in ~20 runs on this pool.  Never leave a hung box behind: end exactly the ranks we started.
+                for proc in ctx.processes:
+                    if proc.is_alive():
+                        proc.kill()
+                pytest.skip("two ranks sharing one GPU did not finish within 200 s; the N > 1 path is covered by the "
+                            "world_size-2 gloo tests on CPU (tests/test_distributed_cpu.py)")
+        results[use_graph] = [torch.load(os.path.join(out_dir, "rank%d.pt" % r), weights_only=False) for r in (0, 1)]
+    tmp_path = os.path.join(str(tmp_path), "graph")
+    # graph segments (with the deferred optimiser tail) == eager launches, bit for bit
+    for r in (0, 1):
+        assert torch.equal(results[True][r]["flat"], results[False][r]["flat"])
+        assert torch.equal(results[True][r]["state"], results[False][r]["state"])
     r0 = torch.load(os.path.join(tmp_path, "rank0.pt"), weights_only=False)
     r1 = torch.load(os.path.join(tmp_path, "rank1.pt"), weights_only=False)
     assert torch.equal(r0["flat"], r1["flat"]) and torch.equal(r0["nju"], r1["nju"])
-    assert r0["env_steps"] == r1["env_steps"] == 512 * 20
+    assert r0["env_steps"] == r1["env_steps"] == 512 * 40
     assert not torch.equal(r0["state"], r1["state"])
 
 
