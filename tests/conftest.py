@@ -20,7 +20,7 @@ def pytest_collection_modifyitems(config, items):
         return
     for item in items:
         if item.get_closest_marker("timeout") is None:
-            item.add_marker(pytest.mark.timeout(600))
+            item.add_marker(pytest.mark.timeout(600, method="thread"))   # a hang inside a HIP call ignores signals
 
 
 @pytest.fixture(scope="session")
