@@ -91,6 +91,7 @@ def test_multi_iteration_graph_with_evaluation_and_logger(hip, monkeypatch, caps
     per iteration."""
     from rpo_amd.utils.logger import Logger
     dev = torch.device("cuda")
+    monkeypatch.setenv("RPO_VERBOSE", "1")                     # (other tests of the session switch the printing off)
     out = []
     for cyc in ("16", "1"):
         monkeypatch.setenv("RPO_GRAPH_CYCLE", cyc)
