@@ -547,11 +547,14 @@ int rpo_ddpg_actor_backward(int env, const rpo_mlp* actor_host, const rpo_mlp_gr
 
 /* The policy step of RPOSAC (rpo_sac.py:191-219, 321-339) as forward + backward pipelines, env = 0 CartSafe-v0 /
  * 1 SpringPendulum-v0 (E = 128; the actor loss completes the action but does not project it, so nothing couples rows):
- *   forward:  pi(s) heads saved in raw [B,2] -> rsample (noise_in[b] or the Philox draw) + box clip, logp [B] -> Complete
- *             -> Q1, Q2 (s, a) saved -> dq_k = d(-min(Q1, Q2))/dQ_k / B (ties split) -> Lagrangian term: g_act, partial_out
- *             [ceil(B/16), 8] = sums of (nu . relu(g), relu(g_0..5), alpha log pi - min Q);
- *   backward: both critics' rows (da_k), da = da1 + da2 + g_act, Complete, Gaussian head with dlogp = alpha / B, actor
- *             rows, the actor's weights pass; lag_out = (mean Lagrangian term, mean(alpha log pi - min Q)), nu_grad +=. */
+ *   forward:  two independent workgroups per 16-row tile (gridDim.y = critic): pi(s) heads -> rsample (noise_in[b] or the
+ *             Philox draw) + box clip, logp [B] -> Complete -> Q_k(s, a) saved, left in dq_k [B] (a Q value at this point);
+ *             role 0 also writes raw [B,2], noise_out, logp, actions, the Lagrangian term's g_act and partial_out
+ *             [ceil(B/16), 8] columns 0..6 = sums of (nu . relu(g), relu(g_0..5));
+ *   backward: prologue per tile: dq_k <- d(-min(Q1, Q2))/dQ_k / B in place (ties split like torch.min's backward) and
+ *             partial[tile][7] = sum(alpha log pi - min Q); then both critics' rows (da_k), da = da1 + da2 + g_act, Complete,
+ *             Gaussian head with dlogp = alpha / B, actor rows, the actor's weights pass; lag_out[0] = mean Lagrangian
+ *             term, nu_grad +=.  (mean(alpha log pi - min Q) = sum of partial[:, 7] / B, summed by whoever reads the loss.) */
 int rpo_sac_actor_forward(int env, const rpo_mlp* actor_host, const rpo_mlp* critic1_host, const rpo_mlp* critic2_host,
                           float scale, float base, float box_lo, float box_hi, float alpha, const float* batch,
                           int batch_size, const float* noise_in, unsigned long long seed, unsigned noise_id_base,
@@ -562,12 +565,12 @@ int rpo_sac_actor_forward(int env, const rpo_mlp* actor_host, const rpo_mlp* cri
 int rpo_sac_actor_backward(int env, const rpo_mlp* actor_host, const rpo_mlp_grad* actor_grad_host,
                            const rpo_mlp* critic1_host, const rpo_mlp* critic2_host, int shared_embedding,
                            const float* batch, int batch_size, const float* actions, const float* g_act, const float* raw,
-                           const float* noise, const float* dq1, const float* dq2, float dlogp, float box_lo,
+                           const float* noise, const float* logp, float* dq1, float* dq2, float dlogp, float box_lo,
                            float box_hi, float scale, float base, const float* consts_host, int partial,
                            const float* actor_x0, const float* actor_h1, const float* critic1_x0, const float* critic1_h1,
                            const float* critic2_x0, const float* critic2_h1, float* actor_dh, float* actor_dx0,
                            float* critic1_dh, float* critic1_dx0, float* critic2_dh, float* critic2_dx0, float* da1,
-                           float* da2, float* dout, const float* partial_in, float* lag_out, float* nu_grad,
+                           float* da2, float* dout, float* partial_in, float* lag_out, float* nu_grad,
                            float* gradmax, void* stream);
 
 /* The same for RPOSAC.critic_loss (rpo_sac.py:342-353): sample -> a' ~ pi(s') with the ONLINE actor (mean / log-std

@@ -11,16 +11,17 @@ from .trainer import _SALT_ACTOR, _SALT_CRITIC, RPOTrainerBase, _LagrangianFn, _
 
 
 class _LazySumPair(object):
-    """mean Lagrangian term + mean(alpha log pi - min Q) from the two words the actor-backward pipeline leaves behind."""
+    """mean Lagrangian term (one word left by the actor-backward pipeline) + mean(alpha log pi - min Q) (per-tile sums in
+    column 7 of the pipeline's partials), added up only when somebody looks."""
 
-    def __init__(self, pair):
-        self.pair = pair
-
-    def __float__(self):
-        return float(self.pair[0] + self.pair[1])
+    def __init__(self, lag, parts, batch):
+        self.lag, self.parts, self.batch = lag, parts, batch
 
     def detach(self):
-        return self.pair[0] + self.pair[1]
+        return self.lag[0] + self.parts[:, 7].sum() / self.batch
+
+    def __float__(self):
+        return float(self.detach())
 
 
 class RPOSAC(RPOTrainerBase):
@@ -195,12 +196,12 @@ class RPOSAC(RPOTrainerBase):
         scratch = (b("actor.dh", B, da_.H), b("actor.dx0", B, da_.ein), b("critic1.dh", B, d1.H), b("critic1.dx0", B, d1.ein),
                    b("critic2.dh", B, d2.H), b("critic2.dx0", B, d2.ein))
         lag = b("actor.lag", 2)
-        self.backend.sac_actor_backward(k, da_, d1, d2, ag.flat.sizes[1] > 0, self._batch, actions, g_act, raw, noise, dq1,
-                                        dq2, alpha / B, self._box_lo, self._box_hi, scale, base, saved, scratch,
+        self.backend.sac_actor_backward(k, da_, d1, d2, ag.flat.sizes[1] > 0, self._batch, actions, g_act, raw, noise, logp,
+                                        dq1, dq2, alpha / B, self._box_lo, self._box_hi, scale, base, saved, scratch,
                                         b("da1", B, 2), b("da2", B, 2), b("draw", B, 2), parts, lag,
                                         ag.nju.weight.grad.view(-1), opt.gradmax if fuse_max else None)
         self._actor_gradmax_ready = bool(fuse_max)
-        loss = _LazySumPair(lag)
+        loss = _LazySumPair(lag, parts, B)
         self.last_losses["actor"] = loss
         return loss, logp.view(-1, 1)
 

@@ -708,25 +708,27 @@ struct SacActorFwdArgs {
     uint32_t noise_id_base, noise_salt;
     const long long* ctrl;
     const float* nu;
-    float* raw; float* noise_out; float* logp; float* actions; float* dq1; float* dq2; float* g_act;
-    float* partial;               // [gridDim.x, 8]: sum nu.dist, sum dist_0..5, sum (alpha log pi - min Q)
+    float* raw; float* noise_out; float* logp; float* actions; float* dq1; float* dq2; float* g_act;   // dq_k: Q_k here
+    float* partial;               // [gridDim.x, 8]: sum nu.dist, sum dist_0..5 (column 7: the backward kernel's)
     float* ax0; float* ah1; float* c1x0; float* c1h1; float* c2x0; float* c2h1;
 };
 
+// gridDim.y = 2 roles per tile: both evaluate pi(s) -> head -> Complete (deterministic given the Philox counters); role k
+// continues with critic k on the completed action and leaves Q_k in q_out_k.  Role 0 publishes the policy's outputs and
+// the Lagrangian partials.  min(Q1, Q2), its gradient split and the loss term meet in the backward kernel's prologue.
 template <class ENV, int EIN, int H>
 __global__ __launch_bounds__(kFwdThreads) void sac_actor_forward_kernel(SacActorFwdArgs p, typename ENV::Consts c) {
     __shared__ TileLds<EIN> lds;
-    const int row0 = blockIdx.x * kRows, tid = threadIdx.x, B = p.B;
+    const int row0 = blockIdx.x * kRows, tid = threadIdx.x, B = p.B, role = blockIdx.y;
     const long long t = p.ctrl[RPO_CTRL_T];
     if (tid < kRows * ENV::S) {
         const int r = tid / ENV::S, i = tid - r * ENV::S;
         lds.in_s[r * kInS + i] = row0 + r < B ? p.batch[(size_t)(row0 + r) * ENV::ROW + i] : 0.0f;
     }
-    mlp_tile_forward<EIN, H>(p.actor, lds, row0, B, p.ax0, p.ah1, 0, 1.0f, 0.0f);
-    float vals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    mlp_tile_forward<EIN, H>(p.actor, lds, row0, B, role == 0 ? p.ax0 : nullptr, role == 0 ? p.ah1 : nullptr, 0, 1.0f, 0.0f);
+    float vals[7] = {0, 0, 0, 0, 0, 0, 0};
     const float inv_b = 1.0f / (float)B;
     const bool live = tid < kRows && row0 + tid < B;
-    float logp = 0.0f;
     if (tid < kRows) {
         float2 act = make_float2(0.0f, 0.0f);
         if (live) {
@@ -740,37 +742,31 @@ __global__ __launch_bounds__(kFwdThreads) void sac_actor_forward_kernel(SacActor
                                             (uint32_t)p.ctrl[RPO_CTRL_UPDATES]);
                 e = rpo_normal(u.x, u.y);
             }
-            reinterpret_cast<float2*>(p.raw)[i] = make_float2(rm, rl);
-            p.noise_out[i] = e;
+            float logp = 0.0f;
             const float ap = rpo_head_dev::gauss_head_row(rm, rl, e, p.scale, p.base, p.box_lo, p.box_hi, 0, &logp);
-            p.logp[i] = logp;
             act = ENV::complete(c, lds.in_s + tid * kInS, i, ap, t);
-            reinterpret_cast<float2*>(p.actions)[i] = act;
-            float dist[6];
-            float2 g;
-            vals[0] = ENV::lagr(c, act.x, act.y, p.nu, inv_b, dist, g);
+            if (role == 0) {
+                reinterpret_cast<float2*>(p.raw)[i] = make_float2(rm, rl);
+                p.noise_out[i] = e;
+                p.logp[i] = logp;
+                reinterpret_cast<float2*>(p.actions)[i] = act;
+                float dist[6];
+                float2 g;
+                vals[0] = ENV::lagr(c, act.x, act.y, p.nu, inv_b, dist, g);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) vals[1 + j] = dist[j];
-            reinterpret_cast<float2*>(p.g_act)[i] = g;
+                for (int j = 0; j < 6; ++j) vals[1 + j] = dist[j];
+                reinterpret_cast<float2*>(p.g_act)[i] = g;
+            }
         }
         lds.in_a[tid * kInA] = act.x;
         lds.in_a[tid * kInA + 1] = act.y;
     }
-    mlp_tile_forward<EIN, H>(p.critic1, lds, row0, B, p.c1x0, p.c1h1, 0, 1.0f, 0.0f);
-    float q1 = 0.0f;
-    if (tid < kRows) q1 = lds.out[tid * 2];
-    mlp_tile_forward<EIN, H>(p.critic2, lds, row0, B, p.c2x0, p.c2h1, 0, 1.0f, 0.0f);
-    if (live) {
-        const float q2 = lds.out[tid * 2];
-        // d(-min(q1, q2))/dq: the smaller one takes the gradient, ties are split (torch.min's backward)
-        const float w1 = (q1 < q2 ? 1.0f : 0.0f) + (q1 == q2 ? 0.5f : 0.0f);
-        p.dq1[row0 + tid] = w1 * -inv_b;
-        p.dq2[row0 + tid] = (1.0f - w1) * -inv_b;
-        vals[7] = p.alpha * logp - fminf(q1, q2);
-    }
-    if (tid < 64) {
+    if (role == 0) mlp_tile_forward<EIN, H>(p.critic1, lds, row0, B, p.c1x0, p.c1h1, 0, 1.0f, 0.0f);
+    else mlp_tile_forward<EIN, H>(p.critic2, lds, row0, B, p.c2x0, p.c2h1, 0, 1.0f, 0.0f);
+    if (live) (role == 0 ? p.dq1 : p.dq2)[row0 + tid] = lds.out[tid * 2];        // Q_k(s, a): turned into dLoss/dQ_k later
+    if (role == 0 && tid < 64) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 7; ++k) {
             const float r = rpo_wave_sum(vals[k]);
             if (tid == 0) p.partial[blockIdx.x * 8 + k] = r;
         }
@@ -782,8 +778,10 @@ struct SacActorBwdArgs {
     const float* g_act; const float* raw; const float* noise;
     float dlogp, box_lo, box_hi, scale, base;   // dlogp: coefficient of log pi in the loss / B (alpha / B)
     float* dout;                  // [B, 2] scratch: d loss / d (mean head, log-std head)
-    const float* partial; int n_parts;
-    float* lag_out;               // [2]: mean Lagrangian term, mean (alpha log pi - min Q)
+    float* partial; int n_parts;  // [n_parts, 8]: columns 0..6 from the forward kernel; column 7 written here
+    const float* logp;            // [B] log pi of the sampled actions
+    float* q_dq1; float* q_dq2;   // [B] in: Q_k(s, a) from the forward kernel; out: dLoss/dQ_k (the critics' dout)
+    float* lag_out;               // [1]: mean Lagrangian term
     float* nu_grad; int n_ineq;
     int shared_embedding;
 };
@@ -791,6 +789,23 @@ struct SacActorBwdArgs {
 template <class ENV, int EIN, int H>
 __global__ __launch_bounds__(kThreads) void sac_actor_backward_kernel(SacActorBwdArgs p, typename ENV::Consts c) {
     const int row0 = blockIdx.x * kRows, tid = threadIdx.x, B = p.actor.n;
+    // ---- where the two critic roles of the forward kernel meet: d(-min(q1, q2))/dq -- the smaller one takes the gradient,
+    //      ties are split (torch.min's backward) -- and this tile's share of sum(alpha log pi - min Q)
+    if (tid < 64) {
+        float v = 0.0f;
+        if (tid < kRows && row0 + tid < B) {
+            const int i = row0 + tid;
+            const float q1 = p.q_dq1[i], q2 = p.q_dq2[i];
+            const float w1 = (q1 < q2 ? 1.0f : 0.0f) + (q1 == q2 ? 0.5f : 0.0f);
+            const float inv_b = 1.0f / (float)B;
+            p.q_dq1[i] = w1 * -inv_b;
+            p.q_dq2[i] = (1.0f - w1) * -inv_b;
+            v = p.dlogp * (float)B * p.logp[i] - fminf(q1, q2);
+        }
+        const float sum = rpo_wave_sum(v);
+        if (tid == 0) p.partial[blockIdx.x * 8 + 7] = sum;
+    }
+    __syncthreads();
     mlp_bwd_rows_body<EIN, H>(p.critic1);
     __syncthreads();
     mlp_bwd_rows_body<EIN, H>(p.critic2);
@@ -817,12 +832,11 @@ __global__ __launch_bounds__(kThreads) void sac_actor_backward_kernel(SacActorBw
             }
         }
     }
-    if (blockIdx.x == 0 && tid < 8) {
+    if (blockIdx.x == 0 && tid < 7) {                             // (column 7 is being written by the other tiles right now)
         float sacc = 0.0f;
         for (int g = 0; g < p.n_parts; ++g) sacc += p.partial[g * 8 + tid];
         const float inv_b = 1.0f / (float)B;
         if (tid == 0) p.lag_out[0] = inv_b * sacc;
-        else if (tid == 7) p.lag_out[1] = inv_b * sacc;
         else if (tid - 1 < p.n_ineq) p.nu_grad[tid - 1] += inv_b * sacc;
     }
 }
@@ -1162,10 +1176,10 @@ int rpo_sac_actor_forward(int env, const rpo_mlp* actor_host, const rpo_mlp* cri
     if (env == 0) {
         CartConsts c;
         if (int e = load_consts(c, consts_host, partial)) return e;
-        hipLaunchKernelGGL((sac_actor_forward_kernel<CartActEnv, 128, 256>), dim3(grid), dim3(kFwdThreads), 0,
+        hipLaunchKernelGGL((sac_actor_forward_kernel<CartActEnv, 128, 256>), dim3(grid, 2), dim3(kFwdThreads), 0,
                            (hipStream_t)stream, a, c);
     } else {
-        hipLaunchKernelGGL((sac_actor_forward_kernel<PendActEnv, 128, 256>), dim3(grid), dim3(kFwdThreads), 0,
+        hipLaunchKernelGGL((sac_actor_forward_kernel<PendActEnv, 128, 256>), dim3(grid, 2), dim3(kFwdThreads), 0,
                            (hipStream_t)stream, a, PendActEnv::Consts{0});
     }
     RPO_LAUNCH_CHECK();
@@ -1175,16 +1189,16 @@ int rpo_sac_actor_forward(int env, const rpo_mlp* actor_host, const rpo_mlp* cri
 int rpo_sac_actor_backward(int env, const rpo_mlp* actor_host, const rpo_mlp_grad* actor_grad_host,
                            const rpo_mlp* critic1_host, const rpo_mlp* critic2_host, int shared_embedding,
                            const float* batch, int batch_size, const float* actions, const float* g_act, const float* raw,
-                           const float* noise, const float* dq1, const float* dq2, float dlogp, float box_lo,
+                           const float* noise, const float* logp, float* dq1, float* dq2, float dlogp, float box_lo,
                            float box_hi, float scale, float base, const float* consts_host, int partial,
                            const float* actor_x0, const float* actor_h1, const float* critic1_x0, const float* critic1_h1,
                            const float* critic2_x0, const float* critic2_h1, float* actor_dh, float* actor_dx0,
                            float* critic1_dh, float* critic1_dx0, float* critic2_dh, float* critic2_dx0, float* da1,
-                           float* da2, float* dout, const float* partial_in, float* lag_out, float* nu_grad,
+                           float* da2, float* dout, float* partial_in, float* lag_out, float* nu_grad,
                            float* gradmax, void* stream) {
     if (env != 0 && env != 1) return RPO_ERR_ARG;
     if (batch_size <= 0) return RPO_ERR_ARG;
-    if (!actor_grad_host || !batch || !actions || !g_act || !raw || !noise || !dq1 || !dq2 || !da1 || !da2 || !dout ||
+    if (!actor_grad_host || !batch || !actions || !g_act || !raw || !noise || !logp || !dq1 || !dq2 || !da1 || !da2 || !dout ||
         !partial_in || !lag_out || !nu_grad || !actor_x0 || !actor_h1 || !critic1_x0 || !critic1_h1 || !critic2_x0 ||
         !critic2_h1 || !actor_dh || !actor_dx0 || !critic1_dh || !critic1_dx0 || !critic2_dh || !critic2_dx0)
         return RPO_ERR_NULL;
@@ -1202,6 +1216,7 @@ int rpo_sac_actor_backward(int env, const rpo_mlp* actor_host, const rpo_mlp_gra
                         0, 0, nullptr};
     p.actor = BwdArgs{actor, ag, batch_size, batch, row, nullptr, 0, actor_x0, actor_h1, dout, actor_dh, actor_dx0, nullptr, 1, 0,
                       gradmax};
+    p.logp = logp; p.q_dq1 = dq1; p.q_dq2 = dq2;
     p.g_act = g_act; p.raw = raw; p.noise = noise; p.dlogp = dlogp; p.box_lo = box_lo; p.box_hi = box_hi; p.scale = scale;
     p.base = base; p.dout = dout; p.partial = partial_in; p.n_parts = (batch_size + kRows - 1) / kRows; p.lag_out = lag_out;
     p.nu_grad = nu_grad; p.n_ineq = env == 0 ? 6 : 1; p.shared_embedding = shared_embedding;

@@ -615,15 +615,15 @@ def sac_actor_forward(env_kernels, actor, critic1, critic2, scale, base, box_lo,
         "rpo_sac_actor_forward")
 
 
-def sac_actor_backward(env_kernels, actor, critic1, critic2, shared_embedding, batch, actions, g_act, raw, noise, dq1, dq2,
-                       dlogp, box_lo, box_hi, scale, base, saved, scratch, da1, da2, dout, partial_in, lag_out, nu_grad,
+def sac_actor_backward(env_kernels, actor, critic1, critic2, shared_embedding, batch, actions, g_act, raw, noise, logp, dq1,
+                       dq2, dlogp, box_lo, box_hi, scale, base, saved, scratch, da1, da2, dout, partial_in, lag_out, nu_grad,
                        gradmax):
     """saved = the six pre-activation buffers of the forward; scratch = (actor_dh, actor_dx0, c1_dh, c1_dx0, c2_dh, c2_dx0)."""
     is_cart = isinstance(env_kernels, CartSafeKernels)
     an, c1, c2, ag = actor.net_struct(), critic1.net_struct(), critic2.net_struct(), actor.grad_struct()
     check(_lib.load().rpo_sac_actor_backward(
         0 if is_cart else 1, ctypes.byref(an), ctypes.byref(ag), ctypes.byref(c1), ctypes.byref(c2), int(shared_embedding),
-        _p(batch), batch.shape[0], _p(actions), _p(g_act), _p(raw), _p(noise), _p(dq1), _p(dq2), dlogp, box_lo, box_hi, scale,
+        _p(batch), batch.shape[0], _p(actions), _p(g_act), _p(raw), _p(noise), _p(logp), _p(dq1), _p(dq2), dlogp, box_lo, box_hi, scale,
         base, env_kernels._cptr if is_cart else None, env_kernels.partial if is_cart else 0, *[_p(b) for b in saved],
         *[_p(b) for b in scratch], _p(da1), _p(da2), _p(dout), _p(partial_in), _p(lag_out), _p(nu_grad),
         _p(gradmax, allow_none=True), _stream()), "rpo_sac_actor_backward")
