@@ -45,7 +45,7 @@ class _PartialActionAgent(Agent):
         self.replay_buffer = None
 
     # ---- construction helpers ---------------------------------------------------------------------------------
-    def _finish(self, has_actor_target):
+    def _finish(self, has_actor_target, extra_params=()):
         """Called by subclasses after ``self.actor`` / ``self.critic`` exist (built on the CPU in the reference's
         order so that the same torch seed gives the same initial weights)."""
         dev = self.device
@@ -56,7 +56,8 @@ class _PartialActionAgent(Agent):
         self.nju = Dual(self.ineq_num)
         self.lamb.reset_parameters(self._init_duals[0])
         self.nju.reset_parameters(self._init_duals[1])
-        self.flat = FlatParams(self.critic, self.actor, dev, extras=[self.lamb.weight, self.nju.weight])
+        # `extra_params` (RPOSAC's log_alpha) ride behind the multipliers: same flat buffer, same policy-step bucket
+        self.flat = FlatParams(self.critic, self.actor, dev, extras=[self.lamb.weight, self.nju.weight] + list(extra_params))
         self.critic_target_flat = self.flat.make_target(self.critic, self.critic_target, self.flat.critic_range)
         self.actor_target_flat = self.flat.make_target(self.actor, self.actor_target, self.flat.actor_range) \
             if has_actor_target else None
@@ -106,8 +107,10 @@ class _PartialActionAgent(Agent):
         torch.save(self.critic.state_dict(), os.path.join(save_dir, "critic.pth"))
         torch.save(dict(actor_optim=self.actor_optim.state_dict(), critic_optim=self.critic_optim.state_dict(),
                         nju=self.nju.state_dict(), lamb=self.lamb.state_dict(), nju_optim=self.nju_optim.state_dict(),
-                        eps=self.eps, critic_target=self.critic_target_flat,
-                        actor_target=self.actor_target_flat), os.path.join(save_dir, "agent_state.pth"))
+                        eps=self.eps, critic_target=self.critic_target_flat, actor_target=self.actor_target_flat,
+                        log_alpha=None if getattr(self, "log_alpha", None) is None else self.log_alpha.data.clone(),
+                        alpha_optim=None if getattr(self, "log_alpha", None) is None else self.alpha_optim.state_dict()),
+                   os.path.join(save_dir, "agent_state.pth"))
 
     def load_model(self, load_dir):
         dev = self.device
@@ -125,6 +128,9 @@ class _PartialActionAgent(Agent):
             with torch.no_grad():
                 self.nju.weight.copy_(st["nju"]["weight"])
                 self.lamb.weight.copy_(st["lamb"]["weight"])
+                if getattr(self, "log_alpha", None) is not None and st.get("log_alpha") is not None:
+                    self.log_alpha.copy_(st["log_alpha"])
+                    self.alpha_optim.load_state_dict(st["alpha_optim"])
             self.eps = st["eps"]
         self.hard_update()
         if os.path.exists(extra) and st.get("critic_target") is not None:      # exact resume: the targets as they were
@@ -208,14 +214,18 @@ class PDSAC_PA(_PartialActionAgent):
             raise Exception("Unknown Value Net!")
         self.critic = value_cls(state_dim, q_in, sv1, sv2, action_embed1, action_embed2, embed_dim, hidden_dim,
                                 partial=partial, partial_idx=partial_idx)
-        self._finish(has_actor_target=False)
         self.alpha = alpha
+        self.log_alpha = None
         if automatic_entropy_tuning:
             # the reference's target entropy is read from an uninitialised tensor (agent/sac_pa.py:60);
-            # the conventional -|A_partial| is used instead.  No script enables this path.
+            # the conventional -|A_partial| is used instead.  No script enables this path.  log_alpha is one more word
+            # of the flat buffer, stepped by the fused Adam kernel: capturable in the iteration's hipGraph, and its
+            # gradient travels in the policy-step all-reduce of a data-parallel run.
             self.target_entropy = -float(reduced)
-            self.log_alpha = torch.zeros(1, requires_grad=True, device=device)
-            self.alpha_optim = torch.optim.Adam([self.log_alpha], lr=lr_alpha)
+            self.log_alpha = torch.nn.Parameter(torch.zeros(1))
+        self._finish(has_actor_target=False, extra_params=[] if self.log_alpha is None else [self.log_alpha])
+        if automatic_entropy_tuning:
+            self.alpha_optim = FusedAdam(self.backend, self.log_alpha.data.view(-1), self.log_alpha.grad.view(-1), lr_alpha)
 
     def soft_update(self):
         """Critic-only Polyak update (agent/sac_pa.py:87-91)."""

@@ -206,9 +206,8 @@ class SAC_LA(_LagrangianBase):
         ag = self.agent
         if self.automatic_entropy_tuning:
             _, logp = actor_out
-            alpha_loss = -(ag.log_alpha * (logp + ag.target_entropy).detach()).mean()          # sac_lag.py:208-215
-            ag.alpha_optim.zero_grad()
-            alpha_loss.backward()
+            # d/d log_alpha of -(log_alpha (log pi + H_target)).mean() (sac_lag.py:208-215), stepped by the fused Adam
+            torch.neg(logp.detach().mean() + ag.target_entropy, out=ag.log_alpha.grad.view(()))
             ag.alpha_optim.step()
-            ag.alpha = ag.log_alpha.exp().detach()
+            ag.alpha = ag.log_alpha.detach().exp()
         ag.soft_update()

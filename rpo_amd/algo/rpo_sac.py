@@ -97,8 +97,7 @@ class RPOSAC(RPOTrainerBase):
     def _pipelines(self):
         k = self.kernels
         return (self.fused is not None and (hasattr(k, "sac_critic_forward") or hasattr(k, "sac_critic_front"))
-                and "critic1" in self.fused.descs and "actor" in self.fused.descs and not self.automatic_entropy_tuning
-                and _env_int("RPO_FUSED_CRITIC", 1))
+                and "critic1" in self.fused.descs and "actor" in self.fused.descs and _env_int("RPO_FUSED_CRITIC", 1))
 
     def _sample(self):
         if self._pipelines:
@@ -170,8 +169,7 @@ class RPOSAC(RPOTrainerBase):
         d = self.fused.descs if self.fused is not None else {}
         return (hasattr(self.backend, "sac_actor_forward") and "actor" in d and "critic1" in d and d["actor"].E == 128
                 and d["critic1"].E == 128 and not d["critic1"].cat and self._box_affine is not None
-                and self.kernels.partial_dim == 1 and self.kernels.action_dim == 2
-                and not self.automatic_entropy_tuning and _env_int("RPO_FUSED_ACTOR", 1))
+                and self.kernels.partial_dim == 1 and self.kernels.action_dim == 2 and _env_int("RPO_FUSED_ACTOR", 1))
 
     def _actor_update_pipeline(self, cols):
         """The policy step in two launches + the actor's weights pass (fused.hip)."""
@@ -205,7 +203,23 @@ class RPOSAC(RPOTrainerBase):
         self.last_losses["actor"] = loss
         return loss, logp.view(-1, 1)
 
+    @property
+    def alpha(self):
+        """The tuned temperature exp(log_alpha) (rpo_sac.py:216) -- reported only: like the reference, the losses read
+        the agent's fixed `alpha` (rpo_sac.py:331,347)."""
+        ag = self.agent
+        return ag.log_alpha.detach().exp() if ag.log_alpha is not None else ag.alpha
+
     def _actor_update(self, cols):
+        out = self._actor_update_impl(cols)
+        if self.automatic_entropy_tuning:
+            # d/d log_alpha of -(log_alpha (log pi + H_target)).mean() (rpo_sac.py:210); written AFTER the backward (which
+            # may have zeroed the flat gradient) and before the policy-step all-reduce
+            ag = self.agent
+            torch.neg(out[1].detach().mean() + ag.target_entropy, out=ag.log_alpha.grad.view(()))
+        return out
+
+    def _actor_update_impl(self, cols):
         if self.fused is None:
             return super()._actor_update(cols)
         if self._actor_pipeline:
@@ -251,7 +265,7 @@ class RPOSAC(RPOTrainerBase):
         two Huber terms (rpo_sac.py:342-353)."""
         ag = self.agent
         with torch.no_grad():
-            eps = self._draw(self._noise_b, self.dist.rank * self.batch_size, _SALT_CRITIC)
+            eps = self._draw(self._noise_b, self.dist.rank * self.batch_size * self.kernels.partial_dim, _SALT_CRITIC)
             next_partial, logp = ag.take_action(next_state, log_pi=True, eps=eps)
             next_actions = self.process_action(next_state, next_partial)
             nq1, nq2 = ag.critic_target(next_state, next_actions)
@@ -288,13 +302,8 @@ class RPOSAC(RPOTrainerBase):
         self._actor_gradmax_ready = False
         if not self.fixed:
             segs.append(ag.nju_optim.segment())
-        FusedAdam.step_many(self.backend, segs)                 # actor Adam | multiplier DualAdam: one launch
         if self.automatic_entropy_tuning:
-            _, logp = actor_out
-            alpha_loss = -(ag.log_alpha * (logp + ag.target_entropy).detach()).mean()   # rpo_sac.py:210-216
-            ag.alpha_optim.zero_grad()
-            alpha_loss.backward()
-            ag.alpha_optim.step()
-            self.alpha = ag.log_alpha.exp()
+            segs.append(ag.alpha_optim.segment())               # rpo_sac.py:210-216, gradient left by _actor_update
+        FusedAdam.step_many(self.backend, segs)                 # actor Adam | multiplier DualAdam (| log_alpha): one launch
         if not self._fused_polyak:
             ag.soft_update()

@@ -71,9 +71,16 @@ class _LagrangianFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------ helpers
 class _Dist(object):
     def __init__(self):
-        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        init = dist.is_available() and dist.is_initialized()
+        # RPO_DIST_FORCE=1: take the data-parallel code path with a single rank too (tests: the RCCL collective inside
+        # the iteration's hipGraph can be exercised on a one-GPU box)
+        self.on = init and (dist.get_world_size() > 1 or bool(_env_int("RPO_DIST_FORCE", 0)))
         self.rank = dist.get_rank() if self.on else 0
         self.world = dist.get_world_size() if self.on else 1
+        # RCCL collectives are stream-ordered device work: they are captured INSIDE the iteration's hipGraph (and inside
+        # the multi-iteration windows) like any kernel.  Host-driven backends (gloo: CPU tests, two ranks sharing one
+        # GPU) cannot be captured: there the iteration is cut into graph segments with eager collectives in between.
+        self.in_graph = self.on and dist.get_backend() == "nccl" and bool(_env_int("RPO_DP_GRAPH", 1))
 
     def mean_(self, tensors):
         """In-place all-reduce(mean) of flat gradient buckets: ONE collective per bucket, one bucket per update (critic
@@ -87,6 +94,17 @@ class _Dist(object):
             else:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
                 t.mul_(1.0 / self.world)
+
+    def sync_initial_state(self, seed, agent, device):
+        """Broadcast rank 0's parameters (flat buffer incl. the multipliers), target networks and Philox seed."""
+        bufs = [agent.flat.data, agent.critic_target_flat]
+        if agent.actor_target_flat is not None:
+            bufs.append(agent.actor_target_flat)
+        for b in bufs:
+            dist.broadcast(b, src=0)
+        s = torch.tensor([int(seed)], dtype=torch.int64, device=device)
+        dist.broadcast(s, src=0)
+        return int(s.item())
 
     def sum_(self, t):
         if self.on:
@@ -172,6 +190,12 @@ class RPOTrainerBase(object):
             # drawn from torch's global generator AFTER the networks were initialised, so that the initial weights
             # match the reference for the same torch.manual_seed and the Philox streams still depend on that seed
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        if self.dist.on:
+            # data-parallel replicas must start identical and draw from ONE Philox seed; only gradients travel
+            # afterwards.  Rank 0's initial state is made everybody's, once, here (a rank that skipped
+            # torch.manual_seed, or built its networks in another order, would otherwise average the gradients of a
+            # different model without any error).
+            seed = self.dist.sync_initial_state(seed, agent, device)
         self.seed = int(seed)
         self.max_episode_steps = getattr(env, "_max_episode_steps", None)
         self.vec = self.base_env.make_vec(self.n_local, seed=self.seed, env_id_base=self.dist.rank * self.n_local,
@@ -218,6 +242,7 @@ class RPOTrainerBase(object):
         self._vec_eval = None
         self.last_losses = {}
         self._idx_inject = None     # tests: callable returning the replay indices of the next sampled batch
+        self._eval_init_inject = None   # tests: [10, internal_dim] initial states of the evaluation episodes
         self.viol_steps, self.env_steps, self.viol_rate, self.proj_iters_mean = 0.0, 0.0, 0.0, 0.0
 
     # ------------------------------------------------------------------------------------------ projection API
@@ -319,10 +344,13 @@ class RPOTrainerBase(object):
         self.agent.flat.grad.zero_()       # parameters and multipliers share the flat gradient buffer
         loss.backward()
         self.last_losses["actor"] = loss.detach()
-        return out
+        # detached: the result outlives the iteration on the trainer (segments / graph replays), and must not keep the
+        # autograd graph alive across iterations
+        return tuple(x.detach() for x in out) if isinstance(out, tuple) else loss.detach()
 
-    def _segments(self, warm, do_train, actor_step):
-        """The iteration as a list of (device work, gradient buffers to all-reduce afterwards)."""
+    def _segments(self, warm, do_train, actor_step, rollout=True):
+        """The iteration as a list of (device work, gradient buffers to all-reduce afterwards).  ``rollout=False``: the
+        update alone (the iteration of an evaluation is split: rollout | eval() | update, rpo_ddpg.py:140-161)."""
         ag, fl = self.agent, self.agent.flat
         segs = []
         if not do_train:
@@ -331,7 +359,8 @@ class RPOTrainerBase(object):
         # per-iteration closure) because a segment may be replayed from its graph while a later one still runs eagerly
 
         def s1():
-            self._rollout(warm)
+            if rollout:
+                self._rollout(warm)
             self._last_cols = self._sample()
             self._critic_update(self._last_cols)
         segs.append((s1, [fl.gradient(fl.critic_range)]))
@@ -354,24 +383,31 @@ class RPOTrainerBase(object):
     def _actor_step(self, actor_out):
         raise NotImplementedError
 
-    def _iteration(self, warm, do_train, actor_step):
-        segs = self._segments(warm, do_train, actor_step)
-        if not self.dist.on:
-            self._graphs.run((warm, do_train, actor_step), lambda: [fn() for fn, _ in segs])
+    def _iteration(self, warm, do_train, actor_step, rollout=True):
+        segs = self._segments(warm, do_train, actor_step, rollout)
+        if not self.dist.on or self.dist.in_graph:
+            self._graphs.run((warm, do_train, actor_step, rollout), lambda: self._run_segments(segs))
             return
         # Collectives stay eager between captured segments.  The last segment of an iteration (the optimiser step that
         # follows the last all-reduce) has no collective behind it: it is deferred and captured together with the first
         # segment of the NEXT iteration, so that an iteration costs as many graph launches as it has all-reduces.
         tail, self._tail = self._tail, None
         for i, (fn, reduce_after) in enumerate(segs):
-            key = (warm, do_train, actor_step, i)
+            key = (warm, do_train, actor_step, rollout, i)
             if i == 0 and tail is not None:
                 prev_fn, first = tail[1], fn
                 key, fn = ("after",) + tail[0] + key, (lambda: (prev_fn(), first()))
-            if i == len(segs) - 1 and not reduce_after and i > 0 and not getattr(self, "automatic_entropy_tuning", False):
+            if i == len(segs) - 1 and not reduce_after and i > 0:
                 self._tail = (key, fn)                             # flushed by the next iteration or _flush_tail()
                 return
             self._graphs.run(key, fn)
+            self.dist.mean_(reduce_after)
+
+    def _run_segments(self, segs):
+        """Segments back to back on the current stream, each followed by the all-reduce of its gradient bucket
+        (data-parallel runs over RCCL: the collective is captured with the kernels around it)."""
+        for fn, reduce_after in segs:
+            fn()
             self.dist.mean_(reduce_after)
 
     def _flush_tail(self):
@@ -398,14 +434,15 @@ class RPOTrainerBase(object):
         F, k, U = self.policy_fre, 1, self.updates_per_step
         while k < U:
             L = self._cycle
-            if L > 1 and U - k >= L and self._updates % F == 0 and self._graphs.enabled and not self.dist.on:
+            if L > 1 and U - k >= L and self._updates % F == 0 and self._graphs.enabled and \
+                    (not self.dist.on or self.dist.in_graph):
                 base = self._updates
                 self._graphs.run(("extra", L), lambda: [self._extra_body((base + j + 1) % F == 0) for j in range(L)])
             else:
                 L = 1
                 actor_step = (self._updates + 1) % F == 0
-                if self.dist.on:
-                    self._extra_body(actor_step)                # collectives inside: eager
+                if self.dist.on and not self.dist.in_graph:
+                    self._extra_body(actor_step)                # host-driven collectives inside: eager
                 else:
                     self._graphs.run(("extra", actor_step), lambda: self._extra_body(actor_step))
             self._updates += L
@@ -460,11 +497,28 @@ class RPOTrainerBase(object):
             do_train = train and (t + 1) >= self.warmup
             actor_step = do_train and (t + 1) % self.policy_fre == 0
             L = self._cycle_len(t, left, warm, do_train, eval)
+            eval_now = eval and (t + 1) % self.eval_fre == 0 and (t + 1) > self.warmup
+            if eval_now and do_train:
+                # the reference evaluates between the env step and train(t) of this iteration (rpo_ddpg.py:140-161):
+                # rollout | eval() | update, so that eval() and the printed multipliers see the same parameters
+                self._iteration(warm, False, False)
+                self._advance_host(t + 1)
+                self._flush_tail()
+                self._harvest()
+                self._print_eval(t + 1, self.eval())
+                self._iteration(warm, True, actor_step, rollout=False)
+                self._updates += 1
+                if self.updates_per_step > 1:
+                    self._flush_tail()
+                    self._extra_updates()
+                    self.vec.ctrl[hip_ops.CONST["RPO_CTRL_UPDATES"]] = 0
+                left -= 1
+                continue
             if L > 1:
                 # one hipGraph for L consecutive iterations (policy_fre-periodic launch pattern): the same launches
                 # in the same order as L single-iteration replays, minus L - 1 graph-to-graph gaps (8.5 us each)
-                self._graphs.run(("cycle", L, do_train), lambda: [fn() for i in range(L) for fn, _ in self._segments(
-                    False, do_train, do_train and (t + i + 1) % self.policy_fre == 0)])
+                self._graphs.run(("cycle", L, do_train), lambda: [self._run_segments(self._segments(
+                    False, do_train, do_train and (t + i + 1) % self.policy_fre == 0)) for i in range(L)])
                 self._updates += L if do_train else 0
             else:
                 self._iteration(warm, do_train, actor_step)
@@ -475,29 +529,34 @@ class RPOTrainerBase(object):
                         self._extra_updates()
                         self.vec.ctrl[hip_ops.CONST["RPO_CTRL_UPDATES"]] = 0
             for _ in range(L):
-                self._t = t = t + 1
-                self.buffer.note_step()
-                self.agent.eps_decay(self.decay_value, self.eps)          # host mirror of the device-side schedule
+                t = t + 1
+                self._advance_host(t)
             left -= L
-            self.vec.steps_host = t
             if t - self._harvested >= self.vec.stats.shape[0] // 2:
                 self._harvest()
-            if eval and t % self.eval_fre == 0 and t > self.warmup:
+            if eval_now:                                                   # (rollout-only runs: nothing to order against)
                 self._flush_tail()
                 self._harvest()
                 self._print_eval(t, self.eval())
         self._flush_tail()
 
+    def _advance_host(self, t):
+        """Host mirrors of the device-side counters after vector step ``t``."""
+        self._t = t
+        self.buffer.note_step()
+        self.agent.eps_decay(self.decay_value, self.eps)
+        self.vec.steps_host = t
+
     def _cycle_len(self, t, left, warm, do_train, eval):
         """Iterations the next launch may cover: RPO_GRAPH_CYCLE (default 16, rounded to a multiple of policy_fre) in the
-        steady state of a single-rank graph run (training: the window starts on a policy_fre boundary; or rollouts only),
-        when neither an evaluation nor the statistics harvest falls inside it; otherwise 1."""
+        steady state of a graph run (single rank, or data-parallel over RCCL whose collectives are captured too; training:
+        the window starts on a policy_fre boundary; or rollouts only), when neither an evaluation nor the statistics harvest falls inside it; otherwise 1."""
         L = self._cycle
-        if L <= 1 or left < L or warm or self.dist.on or not self._graphs.enabled:
+        if L <= 1 or left < L or warm or (self.dist.on and not self.dist.in_graph) or not self._graphs.enabled:
             return 1
         if do_train and (t < self.warmup or t % self.policy_fre or self.updates_per_step > 1):
             return 1
-        if eval and (t // self.eval_fre + 1) * self.eval_fre < t + L:
+        if eval and (t // self.eval_fre + 1) * self.eval_fre <= t + L:      # the evaluation splits its own iteration
             return 1
         if t + L - self._harvested >= self.vec.stats.shape[0]:
             return 1
@@ -578,6 +637,8 @@ class RPOTrainerBase(object):
         v, c = self._vec_eval, self.kernels.cols
         v.ep_count += 1                                                 # fresh initial states at every evaluation
         v.reset()
+        if self._eval_init_inject is not None:
+            v.set_internal(self._eval_init_inject)
         alive = torch.ones(lanes, device=self.device)
         total = torch.zeros(lanes, device=self.device)
         mean_ineq, mean_eq, max_ineq, max_eq = [torch.zeros(lanes, device=self.device) for _ in range(4)]
@@ -592,12 +653,14 @@ class RPOTrainerBase(object):
                 row = self._eval_rows
                 ineq = row[:, c["ineq_viol"][0]:c["ineq_viol"][1]].max(dim=1).values
                 eq = row[:, c["eq_viol"][0]:c["eq_viol"][1]].abs().max(dim=1).values
-                total += alive * row[:, c["reward"][0]]
-                mean_ineq += alive * (ineq - mean_ineq) / (i + 1)
-                mean_eq += alive * (eq - mean_eq) / (i + 1)
-                max_ineq = torch.where(alive > 0, torch.maximum(max_ineq, ineq), max_ineq)
-                max_eq = torch.where(alive > 0, torch.maximum(max_eq, eq), max_eq)
-                alive = alive * (1 - row[:, c["done"][0]])
+                # finished lanes keep stepping (no reset) and may run off to inf / nan: select, never multiply
+                live = alive > 0
+                total = torch.where(live, total + row[:, c["reward"][0]], total)
+                mean_ineq = torch.where(live, mean_ineq + (ineq - mean_ineq) / (i + 1), mean_ineq)
+                mean_eq = torch.where(live, mean_eq + (eq - mean_eq) / (i + 1), mean_eq)
+                max_ineq = torch.where(live, torch.maximum(max_ineq, ineq), max_ineq)
+                max_eq = torch.where(live, torch.maximum(max_eq, eq), max_eq)
+                alive = torch.where(live & (row[:, c["done"][0]] == 0), alive, torch.zeros_like(alive))
         out = []
         for x in (total, mean_ineq, mean_eq, max_ineq, max_eq):
             x = x.cpu().numpy().astype(np.float64)
@@ -630,19 +693,33 @@ class RPOTrainerBase(object):
         state = dict(t=self._t, updates=self._updates, seed=self.seed, num_envs=self.num_envs, world=self.dist.world,
                      internal=v.internal, obs=None if v.obs is v.internal else v.obs, ep_len=v.ep_len, ep_ret=v.ep_ret,
                      ep_count=v.ep_count, ctrl=v.ctrl, rows=b.rows[:filled].clone() if replay else None,
-                     pending=self._pending, viol_steps=self.viol_steps, env_steps=self.env_steps)
+                     pending=self._pending, viol_steps=self.viol_steps, env_steps=self.env_steps,
+                     capacity=b.capacity, row_floats=self.kernels.row_floats, algo=type(self).__name__,
+                     env=self.kernels.name)
         torch.save(state, os.path.join(d, "trainer_state.pth"))
 
-    def load(self):
+    def load(self, weights_only=False):
+        """Restore a checkpoint.  ``weights_only=True``: networks, targets, optimiser state and multipliers only (to
+        evaluate, or to start a fresh run from trained weights); otherwise the exact resume of ``save()``, which needs
+        the replay shard: a checkpoint written with ``replay=False`` cannot resume training (the sampler would draw
+        from a ring of zeros) and is refused."""
         d = self._ckpt_dir()
-        self.agent.load_model(d)
         path = os.path.join(d, "trainer_state.pth")
-        if not os.path.exists(path):
+        st = torch.load(path, map_location=self.device, weights_only=False) if os.path.exists(path) else None
+        if st is not None and not weights_only:
+            # validate BEFORE anything is modified
+            b = self.buffer
+            mine = dict(seed=self.seed, num_envs=self.num_envs, world=self.dist.world, capacity=b.capacity,
+                        row_floats=self.kernels.row_floats, algo=type(self).__name__, env=self.kernels.name)
+            diff = {k: (st[k], v) for k, v in mine.items() if k in st and st[k] != v}
+            if diff:
+                raise ValueError("checkpoint does not match this trainer (checkpoint, trainer): %s" % diff)
+            if st["rows"] is None and st["t"] > 0:
+                raise ValueError("checkpoint was saved with replay=False: training cannot resume from an empty replay "
+                                 "ring; use load(weights_only=True) to restore the networks only")
+        self.agent.load_model(d)
+        if st is None or weights_only:
             return
-        st = torch.load(path, map_location=self.device, weights_only=False)
-        if st["seed"] != self.seed or st["num_envs"] != self.num_envs or st["world"] != self.dist.world:
-            raise ValueError("checkpoint was written with seed/num_envs/world = %s/%s/%s, this trainer has %s/%s/%s"
-                             % (st["seed"], st["num_envs"], st["world"], self.seed, self.num_envs, self.dist.world))
         v, b = self.vec, self.buffer
         v.internal.copy_(st["internal"])
         if st["obs"] is not None:

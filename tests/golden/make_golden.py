@@ -463,10 +463,91 @@ def gen_training_stats(steps=3000, seeds=(0, 1, 2, 3, 4)):
                                "mean_return_second_half", "max_nu"]))
 
 
+# ---------------------------------------------------------------------------------------------- eval() protocol
+
+class _InjectedStates(object):
+    """Stands in for ``env.np_random`` during ``eval()``: ``reset()`` (cartpole.py:233, pendulum.py:133) receives the
+    next injected initial state instead of a draw."""
+
+    def __init__(self, states):
+        self.states = [np.asarray(s, dtype=np.float64) for s in states]
+
+    def uniform(self, low=None, high=None, size=None):
+        return self.states.pop(0).copy()
+
+
+def gen_eval(train_iters=400):
+    """RPODDPG.eval / RPOSAC.eval (rpo_ddpg.py:207-264, rpo_sac.py:221-278): the 10-tuple of a policy trained for
+    `train_iters` loop iterations with the scripts' hyper-parameters, from 10 injected initial states.  The fixture
+    holds the trained actor's state_dict, the initial states, the reference's 10-tuple and, for diagnosis, the per-episode
+    return / length / violation summaries the tuple is built from."""
+    import io
+    import contextlib
+    # "sat": the trained actor's output bias is shifted by +3 before eval(), so that the basic action sits at the edge of
+    # its box and the 50 evaluation-time projection steps leave a non-zero inequality violation (the plain cases
+    # evaluate to zero violations)
+    for algo, envname, shift in (("ddpg", "cart", 0.0), ("sac", "pendulum", 0.0), ("sac", "cart", 0.0),
+                                 ("ddpg", "pendulum", 0.0), ("ddpg", "cart", 3.0), ("ddpg", "pendulum", 3.0)):
+        np.random.seed(123)
+        torch.manual_seed(123)
+        env = None
+        for s in range(64):                       # CartSafeEnv draws partial_actions from the global RNG (cartpole.py:117)
+            np.random.seed(s)
+            e = REF.gym.make("CartSafe-v0" if envname == "cart" else "SpringPendulum-v0")
+            if envname != "cart" or int(e.partial_actions[0]) == 1:
+                env = e
+                break
+        np.random.seed(123)
+        env.seed(77)
+        logger = REF.Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=train_iters)
+        cls = REF.RPODDPG if algo == "ddpg" else REF.RPOSAC
+        tr = cls(env, "/tmp", name="g", logger=logger, batch_size=256, max_steps=10, warmup=0, eps_epoch=20000,
+                 eval_steps=50, grad_eps=0.1, corr_momentum=0.0, policy_fre=4, max_epochs=train_iters, capacity=20000,
+                 value_type="add", clip_thres=0.2, embed_dim=128, hidden_dim=256, lr_actor=1e-4, lr_critic=3e-4,
+                 device=torch.device("cpu"), **SCRIPT_HP[(algo, envname)])
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr.run(eval=False)
+        if shift:
+            with torch.no_grad():
+                tr.agent.actor.affines[-1].bias += shift
+        base = tr.env_eval.env
+        if envname == "cart":
+            init = RNG.uniform(-0.05, 0.05, size=(10, 6))
+        else:
+            init = RNG.uniform([-np.pi / 12, -1, 0.95, -0.05], [np.pi / 12, 1, 1.05, 0.05], size=(10, 4))
+        base.np_random = _InjectedStates(init)
+        episodes = []
+        orig_step, orig_reset = tr.env_eval.step, tr.env_eval.reset
+
+        def rec_reset():
+            episodes.append(dict(ret=0.0, length=0, max_ineq=0.0, max_eq=0.0))
+            return orig_reset()
+
+        def rec_step(a):
+            o, r, d, info = orig_step(a)
+            ep = episodes[-1]
+            ep["ret"] += r
+            ep["length"] += 1
+            ep["max_ineq"] = max(ep["max_ineq"], float(info["ineq_viol"].max()))
+            ep["max_eq"] = max(ep["max_eq"], float(np.abs(info["eq_viol"]).max()))
+            return o, r, d, info
+        tr.env_eval.step, tr.env_eval.reset = rec_step, rec_reset
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = tr.eval()
+        out = {"actor." + k: v.numpy().copy() for k, v in tr.agent.actor.state_dict().items()}
+        out.update(init=init, result=np.array(res, dtype=np.float64),
+                   ep_return=np.array([e["ret"] for e in episodes]), ep_length=np.array([e["length"] for e in episodes]),
+                   ep_max_ineq=np.array([e["max_ineq"] for e in episodes]),
+                   ep_max_eq=np.array([e["max_eq"] for e in episodes]))
+        print(algo, envname, "eval:", np.round(res, 5), "lengths", out["ep_length"])
+        print("   max_ineq per episode", np.round(out["ep_max_ineq"], 4))
+        save("eval_%s_%s%s" % (algo, envname, "_sat" if shift else ""), **out)
+
+
 if __name__ == "__main__":
     # "stats" (reference training runs, ~4 min) is only generated on request
-    which = sys.argv[1:] or ["cart", "cart_gs", "pendulum", "train", "train_la"]
+    which = sys.argv[1:] or ["cart", "cart_gs", "pendulum", "train", "train_la", "eval"]
     table = {"cart": gen_cart, "cart_gs": gen_cart_grad_steps, "pendulum": gen_pendulum, "train": gen_train_steps,
-             "train_la": gen_train_steps_la, "stats": gen_training_stats}
+             "train_la": gen_train_steps_la, "stats": gen_training_stats, "eval": gen_eval}
     for w in which:
         table[w]()

@@ -55,8 +55,31 @@ def test_load_rejects_a_checkpoint_of_another_configuration(tmp_path):
     a.save(replay=False)
     b = build_trainer("ddpg", "cart", ob, torch.device("cpu"), num_envs=8, use_graph=False, capacity=8)
     b.work_dir = a.work_dir
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError, match="num_envs"):
         b.load()
+    # a larger ring would silently remap the stored rows (position = t mod capacity): refused, nothing modified
+    torch.manual_seed(5)
+    c = build_trainer("ddpg", "cart", ob, torch.device("cpu"), num_envs=4, use_graph=False, capacity=16)
+    c.work_dir = a.work_dir
+    before = c.agent.flat.data.clone()
+    with pytest.raises(ValueError, match="capacity"):
+        c.load()
+    assert torch.equal(before, c.agent.flat.data) and c._t == 0
+    # same configuration, but the checkpoint holds no replay rows: training cannot resume (the sampler would draw
+    # zeros); the networks alone can be restored
+    torch.manual_seed(6)
+    d = build_trainer("ddpg", "cart", ob, torch.device("cpu"), num_envs=4, use_graph=False, capacity=8)
+    d.work_dir = a.work_dir
+    with pytest.raises(ValueError, match="replay=False"):
+        d.load()
+    assert not torch.equal(d.agent.flat.data, a.agent.flat.data)
+    d.load(weights_only=True)
+    assert torch.equal(d.agent.flat.data, a.agent.flat.data) and d._t == 0 and int(d.vec.ctrl[0]) == 0
+    # another algorithm on the same env
+    e = build_trainer("sac", "cart", ob, torch.device("cpu"), num_envs=4, use_graph=False, capacity=8)
+    e.work_dir = a.work_dir
+    with pytest.raises(ValueError, match="algo"):
+        e.load()
 
 
 @pytest.mark.gpu

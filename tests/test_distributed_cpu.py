@@ -2,7 +2,8 @@
 
 Checks: env lanes shard by global env id (rank r owns ids [r*n, (r+1)*n)) and reproduce the single-process trajectories;
 the flat gradient slices are all-reduced to the mean of the per-rank gradients; replicas stay bit-identical through
-several updates without any parameter broadcast; statistics are reduced over ranks.
+several updates with no parameter traffic after the one-off broadcast of rank 0's initial state; statistics are reduced
+over ranks.
 """
 import os
 import socket
@@ -33,8 +34,13 @@ def _worker(rank, world, port, algo, envname, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import oracle_backend as ob
     from test_train_step_golden import build_trainer
-    torch.manual_seed(5)
+    # rank 1 deliberately seeds differently: the trainer makes rank 0's initial weights, targets, multipliers and Philox
+    # seed everybody's at construction (one broadcast each), so the replicas still start identical
+    torch.manual_seed(5 + 17 * rank)
     tr = build_trainer(algo, envname, ob, torch.device("cpu"), num_envs=16)
+    seeds = [None, None]
+    dist.all_gather_object(seeds, (tr.seed, float(tr.agent.flat.data.double().sum())))
+    assert seeds[0] == seeds[1]
     assert tr.n_local == 8 and tr.vec.env_id_base == 8 * rank and tr.dist.world == 2
     tr.vec.reset()
     first_state = tr.vec.internal.clone()

@@ -33,6 +33,45 @@ def test_logger_matches_reference_semantics(tmp_path):
         lg2.add_rows(a=np.arange(2))
 
 
+def test_logger_pickle_loads_without_rpo_amd(tmp_path):
+    """On-disk compatibility (rpo/utils/logger.py:23-25): the file names ``rpo.utils.logger.Logger`` and carries only
+    the reference's attributes, so a process that can import a package called ``rpo`` with a plain ``Logger`` class --
+    the reference's layout -- and NOT ``rpo_amd`` reads it back.  The stand-in package below is written for this
+    test (a bare class with the same name); the interpreter runs isolated from this repository."""
+    import pickletools
+    import subprocess
+    import sys
+    lg = Logger(("epoch", "reward", "max_ineq", "max_eq"), epochs=4, times=1, name="cart_ddpg")
+    for i in range(3):
+        lg.add(epoch=i, reward=1.5 * i, max_ineq=0.25, max_eq=1e-7)
+    out = tmp_path / "logs"
+    out.mkdir()
+    lg.save(str(out / "cart_ddpg"))
+    path = str(out / os.listdir(out)[0])
+    with open(path, "rb") as f:
+        raw = f.read()
+    names = [arg for op, arg, _ in pickletools.genops(raw) if op.name in ("GLOBAL", "STACK_GLOBAL", "SHORT_BINUNICODE",
+                                                                          "BINUNICODE", "UNICODE")]
+    assert "rpo.utils.logger" in names and not any("rpo_amd" in str(n) for n in names if n)
+    pkg = tmp_path / "site" / "rpo" / "utils"
+    pkg.mkdir(parents=True)
+    (tmp_path / "site" / "rpo" / "__init__.py").write_text("")
+    (pkg / "__init__.py").write_text("")
+    (pkg / "logger.py").write_text("class Logger(object):\n    pass\n")
+    code = ("import sys, pickle\n"
+            "sys.path[:] = [p for p in sys.path if 'repo' not in p]\n"
+            "sys.path.insert(0, %r)\n"
+            "lg = pickle.load(open(%r, 'rb'))\n"
+            "assert 'rpo_amd' not in sys.modules and type(lg).__module__ == 'rpo.utils.logger'\n"
+            "assert lg.pointer == 3 and lg.epochs == 4 and lg.times == 1 and lg.name == 'cart_ddpg'\n"
+            "assert sorted(lg.__dict__) == ['epochs', 'name', 'pointer', 'times', 'tracker']\n"
+            "assert lg.tracker['reward'][2] == 3.0 and lg.tracker['reward'].dtype.name == 'float64'\n"
+            "print('ok')\n") % (str(tmp_path / "site"), path)
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), env=env)
+    assert res.returncode == 0 and res.stdout.strip() == "ok", res.stderr
+
+
 def test_gym_stand_in_time_limit_and_spaces():
     env = gym_shim.make("CartSafe-v0") if "CartSafe-v0" in gym_shim._REGISTRY else None
     import rpo_amd.env  # noqa: F401  registers the ids
@@ -108,3 +147,26 @@ def test_harvest_bookkeeping_matches_per_row_loop(capsys):
     assert [int(p[0]) for p in tr._pending] == list(range(int(ends[-1]) + 1, total))
     out = capsys.readouterr().out
     assert out.count("episode") == 9 and ("episode %d ends." % (ends[0] + 1)) in out
+
+
+def test_entropy_tuning_steps_log_alpha_in_the_flat_buffer():
+    """rpo_sac.py:210-216 with `automatic_entropy_tuning=True` (no script enables it; the reference's target entropy is
+    read from uninitialised memory, sac_pa.py:60): log_alpha is a word of the flat parameter buffer behind the
+    multipliers, its gradient -(mean log pi + H_target) travels in the policy-step bucket and the fused Adam steps it;
+    the first steps of Adam move it by lr each, against the sign of the gradient.  The losses keep the agent's fixed
+    alpha, like the reference (rpo_sac.py:331,347)."""
+    torch.set_num_threads(1)
+    for fused in (True, False):
+        torch.manual_seed(5)
+        tr = build_trainer("sac", "cart", ob, torch.device("cpu"), fused=fused, num_envs=8, use_graph=False,
+                           automatic_entropy_tuning=True, lr_alpha=1e-3)
+        ag, fl = tr.agent, tr.agent.flat
+        lo, hi = fl.policy_bucket
+        assert fl.offset[id(ag.log_alpha)] == hi - 4 and ag.log_alpha.data_ptr() == fl.data[hi - 4:].data_ptr()
+        tr.vec.reset()
+        tr.run_steps(12)                                           # policy steps at t = 4, 8, 12
+        assert int(ag.alpha_optim.step_dev[0]) == 3
+        sign = -float(torch.sign(ag.log_alpha.grad)[0])
+        np.testing.assert_allclose(float(ag.log_alpha), 3e-3 * sign, rtol=5e-3)
+        np.testing.assert_allclose(float(tr.alpha), np.exp(3e-3 * sign), rtol=1e-4)
+        assert ag.alpha == 0.1                                     # what the losses use
