@@ -3,7 +3,7 @@
 (BASELINE.json configs[1]), one constrained policy update of batch 256 per vector step (the reference's cadence,
 rpo/algo/rpo_ddpg.py:160-161).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]          # N > 1: starts N ranks itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one vector step: actor forward on N lanes -> noise + equation solver + GRG projection -> fused env step +
@@ -13,6 +13,8 @@ update.  Rank 0 prints ONE JSON line; everything else goes to stderr.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,9 +28,7 @@ if ROOT not in sys.path:
 
 ENVS_PER_GPU = 4096
 HBM_PEAK_GBS = 8000.0                      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-# algorithmic bytes per env-step of the fused step + violation + replay-scatter kernel (CartSafe):
-# read s 24 + a 8, write s' 24 (in place) + transition row 89
-STEP_BYTES_PER_ENV = 145
+MFMA_F32_PEAK_TFLOPS = 157.3               # v_mfma_f32_16x16x4_f32 == the f32 vector peak (MI355X_MICROARCH.md)
 HP = dict(batch_size=256, max_steps=10, warmup=0, lr_dual=0.2, corr_lr=2e-2, eps=1.0, eps_start=1.0, lr_actor=1e-4,
           lr_critic=3e-4, eps_epoch=20000, eval_lr=2e-2, eval_steps=50, grad_eps=0.1, corr_momentum=0.0, policy_fre=4,
           capacity=20000, shared_param=True, value_type="add", clip_thres=0.2, embed_dim=128,
@@ -55,33 +55,48 @@ WORKLOADS = {
 EVOPF_HP = dict(batch_size=256, max_steps=10, warmup=0, lr_dual=2e-2, corr_lr=1e-4, eps=0.0001, eps_start=0.0001,
                 eps_epoch=20000, eval_lr=1e-4, eval_steps=50, grad_eps=0.02, corr_momentum=0.0, policy_fre=4,
                 ex_action_dim=1, gamma=0.95, capacity=20000, clip_thres=0.2, shared_param=False, value_type="cat")
+DESCRIBE = {
+    "cart_ddpg": "CartSafe-v0 RPODDPG (scripts/cart_exp.py)", "cart_sac": "CartSafe-v0 RPOSAC (scripts/cart_exp_sac.py)",
+    "pen_ddpg": "SpringPendulum-v0 RPODDPG (scripts/pen_exp.py)", "pen_sac": "SpringPendulum-v0 RPOSAC (scripts/pen_exp_sac.py)",
+    "evopf_ddpg": "EVOPF-v0 RPODDPG (scripts/evopf_exp.py)", "evopf_sac": "EVOPF-v0 RPOSAC (scripts/evopf_exp_sac.py)"}
 
 
 def envs_per_gpu(workload):
     return 1024 if workload.startswith("evopf") else ENVS_PER_GPU
 
 
-def make_trainer(n_envs, device, max_epochs, capacity=None, workload="cart_ddpg", updates_per_step=None):
-    from rpo_amd import gym_shim
-    from rpo_amd.algo import RPODDPG, RPOSAC
-    from rpo_amd.env import CartSafeEnv, EVOPFEnv, SpringPendulumEnv
-    np.random.seed(123)
-    torch.manual_seed(123)                  # identical replicas on every rank
+def workload_hp(workload):
     envname, algo, over = WORKLOADS[workload]
     if envname == "evopf":
-        env, hp = EVOPFEnv(), dict(EVOPF_HP)
+        hp = dict(EVOPF_HP)
         if over:
             hp.update(over)
             hp.pop("gamma", None)                     # evopf_exp_sac.py keeps RPOSAC's default discount
     else:
-        env = gym_shim.TimeLimit(CartSafeEnv() if envname == "cart" else SpringPendulumEnv(), 200)
         hp = dict(HP)
         hp.update(over)
+    return envname, algo, hp
+
+
+def make_trainer(n_envs, device, max_epochs, capacity=None, workload="cart_ddpg", updates_per_step=None, backend=None,
+                 **extra):
+    from rpo_amd import gym_shim
+    from rpo_amd.algo import RPODDPG, RPOSAC
+    from rpo_amd.env import CartSafeEnv, EVOPFEnv, SpringPendulumEnv
+    np.random.seed(123)
+    torch.manual_seed(123)                  # identical replicas on every rank (the trainer broadcasts rank 0's anyway)
+    envname, algo, hp = workload_hp(workload)
+    kw = {} if backend is None else dict(backend=backend, device=device)
+    if envname == "evopf":
+        env = EVOPFEnv(**kw)
+    else:
+        env = gym_shim.TimeLimit(CartSafeEnv(**kw) if envname == "cart" else SpringPendulumEnv(**kw), 200)
     if capacity is not None:
         hp["capacity"] = capacity
+    hp.update(extra)
     cls = RPODDPG if algo == "ddpg" else RPOSAC
     return cls(env, "/tmp/rpo_bench", name="bench", logger=None, max_epochs=max_epochs, device=device,
-               num_envs=n_envs, updates_per_step=updates_per_step, **hp)
+               num_envs=n_envs, updates_per_step=updates_per_step, backend=backend, **hp)
 
 
 def spin_up(device, seconds=1.5):
@@ -124,114 +139,389 @@ def time_kernel(fn, reps=100):
     return float(np.median(times)), float(np.mean(times))
 
 
-MFMA_F32_PEAK_TFLOPS = 157.3              # v_mfma_f32_16x16x4_f32 == the f32 vector peak (MI355X_MICROARCH.md)
-ACTOR_FLOPS = 2 * (6 * 128 + 128 * 256 + 256)                  # per row, rpo/algo/model/policy.py:24-33 at 6-128-256-1
-CRITIC_FLOPS = 2 * (6 * 128 + 2 * 128 + 128 * 256 + 256)       # per row, model/value.py:51-59
+# ------------------------------------------------------------------------------------------------ kernel clinic
+
+class LaunchRecorder(object):
+    """Records every call that goes through the C ABI wrappers (rpo_amd.ops functions and the env's kernel set) during
+    a few eager iterations, so that each launch of the iteration can afterwards be replayed and timed on its own with
+    the very arguments the trainer uses (static device buffers)."""
+
+    def __init__(self, tr):
+        from rpo_amd import ops
+        self.tr, self.ops, self.calls, self._undo = tr, ops, [], []
+        skip = ("new_stats", "reduce_stats", "mlp_supported", "check")
+        for name, fn in list(vars(ops).items()):
+            if callable(fn) and not name.startswith("_") and not isinstance(fn, type) and name not in skip \
+                    and getattr(fn, "__module__", None) == ops.__name__:
+                self._wrap(ops, name, fn)
+        k = tr.kernels
+        for name in dir(k):
+            fn = getattr(k, name)
+            if callable(fn) and not name.startswith("_") and hasattr(fn, "__self__"):
+                self._wrap(k, name, fn, prefix=type(k).__name__ + ".")
+
+    def _wrap(self, owner, name, fn, prefix=""):
+        rec = self
+
+        def wrapped(*a, **kw):
+            rec.calls.append((prefix + name, fn, a, kw))
+            return fn(*a, **kw)
+        had = name in vars(owner)
+        self._undo.append((owner, name, vars(owner).get(name), had))
+        setattr(owner, name, wrapped)
+
+    def close(self):
+        for owner, name, old, had in reversed(self._undo):
+            if had:
+                setattr(owner, name, old)
+            else:
+                delattr(owner, name)
 
 
-def kernel_clinic(tr):
-    """Per-launch durations of the kernels of one iteration (at the bench size) and of the streaming kernels at 1M
-    lanes.  HBM-bound kernels are priced in algorithmic bytes, the MLP pipelines in flops."""
+def mlp_flops(d):
+    """Forward flops per row of one rpo_mlp network (2 x multiply-adds of its three layers)."""
+    return 2 * (d.S * d.E + d.A * d.E + d.ein * d.H + d.H * d.outs)
+
+
+def launch_models(tr, workload):
+    """Algorithmic work per launch for the launches of one iteration: name -> (bound, units, per unit).
+    HBM-bound kernels are priced in bytes, the MLP pipelines in flops (forward x1, backward x2)."""
+    k, f, B, n = tr.kernels, tr.fused, tr.batch_size, tr.n_local
+    S, A, P, E_, I_ = k.obs_dim, k.action_dim, k.partial_dim, k.eq_num, k.ineq_num
+    row = 4 * (2 * S + A + 1 + E_ + I_) + 1                     # the reference's transition (rpo/utils/buffer.py:3-20)
+    step_bytes = 4 * S + 4 * A + 4 * S + row                     # cart: 145 B, pendulum: 109 B, EVOPF: 1605 B
+    d = f.descs if f is not None else {}
+    fa = mlp_flops(d["actor"]) if "actor" in d else 0
+    crit = d.get("critic", d.get("critic1"))
+    fc = mlp_flops(crit) if crit is not None else 0
+    twin = 2 if "critic1" in d else 1
+    kn = type(k).__name__ + "."
+    m = {
+        kn + "rollout": ("mfma", n, fa), kn + "step": ("hbm", n, step_bytes),
+        kn + "act_project": ("hbm", None, 4 * S + 4 * P + 4 * A + 4),        # units = rows of the call
+        "replay_sample_gather": ("hbm", B, 2 * row + 4),
+        kn + "ddpg_critic_forward": ("mfma", B, fa + 2 * fc), kn + "sac_critic_forward": ("mfma", B, 2 * fa + 4 * fc),
+        kn + "ddpg_critic_front": ("mfma", B, fa), kn + "sac_critic_front": ("mfma", B, fa),
+        kn + "ddpg_critic_back": ("mfma", B, 2 * fc), kn + "sac_critic_back": ("mfma", B, 4 * fc),
+        kn + "project_batchref": ("hbm", B, 4 * S + 4 * P + 4 * A + 4),
+        "mlp_backward": ("mfma", B, 2 * fc), "mlp_backward_pair": ("mfma", B, 4 * fc),
+        "mlp_forward_multi": ("mfma", B, 2 * twin * fc), "mlp_forward": ("mfma", None, None),
+        "ddpg_actor_forward": ("mfma", B, fa + fc), "ddpg_actor_backward": ("mfma", B, 2 * (fa + fc)),
+        "sac_actor_forward": ("mfma", B, 2 * fa + 2 * fc), "sac_actor_backward": ("mfma", B, 2 * (fa + 2 * fc)),
+        "adam_step": ("hbm", None, 36), "adam_step_multi": ("hbm", None, 36), "absmax": ("hbm", None, 4),
+    }
+    return m
+
+
+def kernel_clinic(tr, workload):
+    """Per-launch durations of every launch of one policy_fre period of the iteration (at the bench size), each priced
+    against its roofline; for the headline also the streaming kernels at 1M lanes."""
+    from rpo_amd import ops
+    out = {}
+    models = launch_models(tr, workload)
+    graphs_on = tr._graphs.enabled
+    tr._graphs.enabled = False
+    tr._flush_tail()
+    rec = LaunchRecorder(tr)
+    try:
+        t0 = tr._t
+        for i in range(tr.policy_fre):
+            tr._iteration(False, True, (t0 + i + 1) % tr.policy_fre == 0)
+            tr._advance_host(t0 + i + 1)
+            tr._updates += 1
+    finally:
+        rec.close()
+        tr._graphs.enabled = graphs_on
+    torch.cuda.synchronize()
+    seen = {}
+    for name, fn, a, kw in rec.calls:
+        # one entry per distinct (entry point, row count): the first occurrence is timed
+        rows = None
+        if name.endswith("act_project"):
+            rows = a[3].shape[0]
+        elif name == "mlp_forward":
+            rows = a[3].shape[0]
+        elif name in ("adam_step", "absmax"):
+            rows = a[0].numel()
+        elif name == "adam_step_multi":
+            rows = sum(g["param"].numel() for g in a[0])
+        key = name if rows is None else "%s[%d]" % (name, rows)
+        if key in seen:
+            seen[key]["count"] += 1
+            continue
+        seen[key] = dict(name=name, fn=fn, a=a, kw=kw, rows=rows, count=1)
+    for key, c in seen.items():
+        us = time_kernel(lambda c=c: c["fn"](*c["a"], **c["kw"]))[0]
+        bound, units, per = models.get(c["name"], (None, None, None))
+        if c["name"] == "mlp_forward":
+            per, units = mlp_flops(c["a"][0]), c["rows"]
+        elif units is None:
+            units = c["rows"]
+        e = dict(us=us, launches_per_period=c["count"])
+        if bound is not None and per:
+            work = per * units
+            rate, peak, unit = (work / us * 1e-3, HBM_PEAK_GBS, "GB/s") if bound == "hbm" else \
+                (work / us * 1e-6, MFMA_F32_PEAK_TFLOPS, "TFLOP/s")
+            e.update(bound=bound, n=units, work=work, rate=rate, unit=unit, peak=peak, frac=rate / peak)
+        out[key] = e
+    if workload == "cart_ddpg":
+        out.update(streaming_clinic(tr))
+    for name, e in sorted(out.items(), key=lambda kv: -kv[1]["us"]):
+        if "rate" in e:
+            log("  %-46s n=%-8d %9.2f us x%d  %9.2f %-8s (%.2f%% of the %s peak)" % (
+                name, e["n"], e["us"], e.get("launches_per_period", 0), e["rate"], e["unit"], 100 * e["frac"], e["bound"]))
+        else:
+            log("  %-46s %20.2f us x%d" % (name, e["us"], e.get("launches_per_period", 0)))
+    return out
+
+
+def streaming_clinic(tr):
+    """The HBM-bound CartSafe kernels at 1M lanes, where the streaming regime is actually reached."""
     from rpo_amd import ops
     from rpo_amd.env.vec import VecEnv
     out = {}
-    k, v, buf, f, B = tr.kernels, tr.vec, tr.buffer, tr.fused, tr.batch_size
+    k, f = tr.kernels, tr.fused
     scale, base = tr._box_affine
-    dev = v.device
-
-    def step_at(vec, rows, cap):
-        return lambda: k.step(vec.internal, vec.obs, vec.action, vec.ep_len, vec.ep_ret, vec.ep_count, rows, cap,
-                              vec.stats, vec.ctrl, 200, True, 1e-3, vec.seed, vec.env_id_base)
-
-    def act_at(vec, a):
-        return lambda: k.act_project(vec.obs, a, None, vec.action, None, ops.NOISE_PHILOX, 1.0, 1.0, 0.0, -10.0, 10.0, 10,
-                                     2e-2, 1e-5, 0.0, vec.seed, vec.env_id_base, vec.ctrl, vec.stats)
-
-    def rollout_at(vec, rows, cap):
-        return lambda: k.rollout(f.descs["actor"], False, scale, base, vec.internal, None, vec.action, vec.ep_len,
-                                 vec.ep_ret, vec.ep_count, rows, cap, vec.stats, vec.ctrl, ops.NOISE_PHILOX, 1.0, 1.0, 0.0,
-                                 -10.0, 10.0, 10, 2e-2, 1e-5, 0.0, 200, True, 1e-3, vec.seed, vec.env_id_base)
-
-    def hbm(name, n, us, bytes_per_unit):
-        out[name] = dict(n=n, us=us, bound="hbm", work=bytes_per_unit * n, rate=bytes_per_unit * n / us * 1e-3,
-                         unit="GB/s", peak=HBM_PEAK_GBS)
-
-    def mfma(name, n, us, flops_per_unit):
-        out[name] = dict(n=n, us=us, bound="mfma", work=flops_per_unit * n, rate=flops_per_unit * n / us * 1e-6,
-                         unit="TFLOP/s", peak=MFMA_F32_PEAK_TFLOPS)
-
-    # ---- the launches of one iteration at the bench size
-    mfma("rollout_kernel<CartEnv>", v.n, time_kernel(rollout_at(v, buf.rows, buf.capacity))[0], ACTOR_FLOPS)
-    d = f.descs["critic"]
-    cf = lambda: k.ddpg_critic_forward(  # noqa: E731
-        f.descs["actor_target"], f.descs["critic_target"], d, scale, base, buf.rows, buf.capacity, buf.n_envs, tr._batch,
-        None, None, buf.seed, 0, buf.ctrl, 10, 2e-2, 1e-5, 0.0, -10.0, 10.0, f.buf("q", B, 1), f.buf("qn", B, 1),
-        f.buf("critic.x0", B, d.ein), f.buf("critic.h1", B, d.H))
-    mfma("cart_ddpg_critic_forward_kernel", B, time_kernel(cf)[0], ACTOR_FLOPS + 2 * CRITIC_FLOPS)
-    cols = tr.buffer.split(tr._batch)
-    td = ops.Td(f.buf("q", B, 1).view(-1), f.buf("qn", B, 1).view(-1), None, None, cols["reward"], cols["done"], 0.0, 0.95,
-                f.buf("dq", B, 1).view(-1), f.buf("loss_parts", (B + 15) // 16))
-    bw = lambda: f.backward("critic", cols["state"], cols["action"], None, td=td)   # noqa: E731  (TD prologue included)
-    mfma("mlp_bwd_rows+weights_kernels", B, time_kernel(bw)[0], 2 * CRITIC_FLOPS)
-    # ---- single-stage kernels (warm-up phase, SAC / pendulum path, API calls) and the streaming regime
-    ap = torch.zeros(v.n, device=dev)
-    hbm("cartsafe_step_kernel", v.n, time_kernel(step_at(v, buf.rows, buf.capacity))[0], STEP_BYTES_PER_ENV)
-    hbm("cartsafe_act_project_kernel", v.n, time_kernel(act_at(v, ap))[0], 40)
-    batch = torch.zeros(B, k.row_floats, device=dev)
-    hbm("replay_sample_gather_kernel", B, time_kernel(lambda: ops.replay_sample_gather(
-        buf.rows, buf.capacity, buf.n_envs, batch, None, 1, 0, v.ctrl))[0], 178 + 4)
+    dev = tr.vec.device
     big_n = 1 << 20
     big = VecEnv(k, big_n, dev, seed=3, stats_cap=64)
     big.reset()
     rows = torch.zeros(8 * big_n, k.row_floats, device=dev)
     big_ap = torch.zeros(big_n, device=dev)
-    hbm("cartsafe_step_kernel@1M", big_n, time_kernel(step_at(big, rows, 8), reps=20)[0], STEP_BYTES_PER_ENV)
-    hbm("cartsafe_act_project_kernel@1M", big_n, time_kernel(act_at(big, big_ap), reps=20)[0], 40)
     big_batch = torch.zeros(big_n, k.row_floats, device=dev)
-    hbm("replay_sample_gather_kernel@1M", big_n, time_kernel(lambda: ops.replay_sample_gather(
+
+    def hbm(name, us, per):
+        r = per * big_n / us * 1e-3
+        out[name] = dict(n=big_n, us=us, bound="hbm", work=per * big_n, rate=r, unit="GB/s", peak=HBM_PEAK_GBS,
+                         frac=r / HBM_PEAK_GBS)
+    hbm("cartsafe_step_kernel@1M", time_kernel(lambda: k.step(
+        big.internal, big.obs, big.action, big.ep_len, big.ep_ret, big.ep_count, rows, 8, big.stats, big.ctrl, 200, True,
+        1e-3, big.seed, big.env_id_base), reps=20)[0], 145)
+    hbm("cartsafe_act_project_kernel@1M", time_kernel(lambda: k.act_project(
+        big.obs, big_ap, None, big.action, None, ops.NOISE_PHILOX, 1.0, 1.0, 0.0, -10.0, 10.0, 10, 2e-2, 1e-5, 0.0,
+        big.seed, big.env_id_base, big.ctrl, big.stats), reps=20)[0], 40)
+    hbm("replay_sample_gather_kernel@1M", time_kernel(lambda: ops.replay_sample_gather(
         rows, 8, big_n, big_batch, None, 1, 0, big.ctrl), reps=20)[0], 178 + 4)
-    mfma("rollout_kernel<CartEnv>@1M", big_n, time_kernel(rollout_at(big, rows, 8), reps=5)[0], ACTOR_FLOPS)
-    for name, e in out.items():
-        e["frac"] = e["rate"] / e["peak"]
-        log("  %-36s n=%-8d %9.2f us  %9.2f %-8s (%.1f%% of the %s peak)" % (name, e["n"], e["us"], e["rate"], e["unit"],
-                                                                           100 * e["frac"], e["bound"]))
+    us = time_kernel(lambda: k.rollout(
+        f.descs["actor"], False, scale, base, big.internal, None, big.action, big.ep_len, big.ep_ret, big.ep_count, rows,
+        8, big.stats, big.ctrl, ops.NOISE_PHILOX, 1.0, 1.0, 0.0, -10.0, 10.0, 10, 2e-2, 1e-5, 0.0, 200, True, 1e-3,
+        big.seed, big.env_id_base), reps=5)[0]
+    fl = mlp_flops(f.descs["actor"])
+    out["rollout_kernel<CartEnv>@1M"] = dict(n=big_n, us=us, bound="mfma", work=fl * big_n, rate=fl * big_n / us * 1e-6,
+                                             unit="TFLOP/s", peak=MFMA_F32_PEAK_TFLOPS,
+                                             frac=fl * big_n / us * 1e-6 / MFMA_F32_PEAK_TFLOPS)
     del big, rows, big_batch
     torch.cuda.empty_cache()
     return out
 
 
+# the device-side kernel each recorded entry point launches (for matching with the rocprofv3 summaries in profiles/)
+KERNEL_OF = {
+    "CartSafeKernels.rollout": "rollout_kernel<CartEnv>", "PendulumKernels.rollout": "rollout_kernel<PendEnv>",
+    "CartSafeKernels.ddpg_critic_forward": "cart_ddpg_critic_forward_kernel",
+    "CartSafeKernels.sac_critic_forward": "cart_sac_critic_forward_kernel",
+    "PendulumKernels.ddpg_critic_front": "pend_ddpg_critic_front_kernel",
+    "PendulumKernels.sac_critic_front": "pend_sac_critic_front_kernel",
+    "PendulumKernels.ddpg_critic_back": "pend_critic_back_kernel", "PendulumKernels.sac_critic_back": "pend_critic_back_kernel",
+    "EvopfKernels.act_project": "evopf_act_project_kernel", "mlp_backward": "mlp_bwd_rows_kernel + mlp_bwd_weights_kernel",
+    "mlp_backward_pair": "mlp_bwd_rows_kernel + mlp_bwd_weights_kernel (twin)",
+}
+
+
 def pmc_traffic(kernel, lanes):
-    """HBM bytes per launch from the committed rocprofv3 PMC collection (profiles/r01_pmc_traffic.json; recipe and the
+    """HBM bytes per launch from the committed rocprofv3 PMC collections (profiles/r0*_pmc_traffic.json; recipe and the
     gfx950 FETCH_SIZE correction are described there).  None when that (kernel, size) was not collected."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["kernels"][kernel][str(lanes)]["traffic_bytes"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+
+def _oracle_loop(workload):
+    """The oracle's single-env, per-step CPU loop for `workload` (reference cadence: one env step + one batch-256
+    update per iteration): returns run(n_steps)."""
+    envname, algo, hp = workload_hp(workload)
+    if envname == "evopf":
+        # no OracleRPO adapter for EVOPF: the shipped trainer's host loop driven by the oracle's kernels
+        # (tests/oracle_backend.py -> oracle/evopf.py), 1 env, torch-CPU MLPs
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_backend as ob
+        tr = make_trainer(1, torch.device("cpu"), 10 ** 9, workload=workload, backend=ob, capacity=2000, use_graph=False)
+        tr.vec.reset()
+        return lambda n: tr.run_steps(n)
+    from oracle import rpo_loop
+    np.random.seed(123)
+    torch.manual_seed(123)
+    drop = ("grad_eps", "value_type", "automatic_entropy_tuning")
+    hp = {k: v for k, v in hp.items() if k not in drop}
+    env = rpo_loop.CartAdapter(1, seed=0) if envname == "cart" else rpo_loop.PendulumAdapter(seed=0)
+    tr = rpo_loop.OracleRPO(env, sac=(algo == "sac"), **hp)
+    return lambda n: tr.run(n)
+
+
+def _cpu_worker(workload, seconds, chunk, barrier, q):
+    torch.set_num_threads(1)
+    run = _oracle_loop(workload)
+    run(max(2, chunk // 2))                  # page in
+    if barrier is not None:
+        barrier.wait()
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        run(chunk)
+        done += chunk
+    q.put((done, time.perf_counter() - t0))
+
+
+def physical_cores():
+    """Physical cores this process may run on ((physical id, core id) pairs of /proc/cpuinfo within the affinity mask)."""
+    allowed = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else set(range(os.cpu_count() or 1))
+    cores, cur = set(), {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return json.load(f)["kernels"][kernel][str(lanes)]["traffic_bytes"]
-    except (OSError, KeyError, ValueError):
+        with open("/proc/cpuinfo") as f:
+            for line in f.read().split("\n") + [""]:
+                if not line.strip():
+                    if "processor" in cur and int(cur["processor"]) in allowed:
+                        cores.add((cur.get("physical id", "0"), cur.get("core id", cur["processor"])))
+                    cur = {}
+                elif ":" in line:
+                    a, b = line.split(":", 1)
+                    cur[a.strip()] = b.strip()
+    except OSError:
+        pass
+    return max(1, len(cores)) if cores else max(1, len(allowed))
+
+
+def cpu_quota():
+    """CPUs the container may actually use at once (cgroup v2 cpu.max / v1 cfs quota); None when unlimited."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+            return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = float(f.read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
         return None
 
 
-def cpu_baseline(seconds=15.0):
-    """The oracle's single-env, per-step CPU loop (oracle/rpo_loop.py: the reference's cadence -- one env step + one
-    batch-256 update per iteration) timed on one host core for a bounded sample."""
-    from oracle import rpo_loop
-    threads = torch.get_num_threads()
-    torch.set_num_threads(1)                # the reference is 22x slower with 8 intra-op threads (BASELINE.md)
+def cpu_baseline(workload, seconds=12.0):
+    """Reference-cadence CPU port timed on the host cores BEFORE this process touches the GPU (fork is safe then):
+    (1) one single-thread process alone, (2) P single-thread processes at once, P = physical cores (bounded by memory:
+    each worker holds its own torch state) -- the whole-node CPU number of SURVEY.md 8d.  `value` is the whole-node figure."""
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")
+    chunk = 4 if workload.startswith("evopf") else 100
+    q = ctx.Queue()
+    p = ctx.Process(target=_cpu_worker, args=(workload, seconds, chunk, None, q))
+    p.start()
+    done1, dt1 = q.get()
+    p.join()
+    solo = done1 / dt1
+    P = phys = physical_cores()
+    quota = cpu_quota()
+    cap_note = ""
+    if quota is not None and quota < P:
+        P = max(1, int(quota))
+        cap_note = " (%d physical cores visible, cgroup CPU quota %.1f)" % (phys, quota)
     try:
-        np.random.seed(123)
-        torch.manual_seed(123)
-        hp = {k: v for k, v in HP.items() if k not in ("grad_eps", "value_type")}
-        tr = rpo_loop.OracleRPO(rpo_loop.CartAdapter(1, seed=0), sac=False, **hp)
-        tr.run(50)                          # page in
-        done, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < seconds:
-            tr.run(100)
-            done += 100
-        dt = time.perf_counter() - t0
-    finally:
-        torch.set_num_threads(threads)
-    return dict(value=done / dt, unit="env-steps/s", cores=1, kind="port",
-                sample="%d env steps (rollout + one batch-256 update each) of oracle/rpo_loop.py OracleRPO on "
-                       "CartSafe-v0, 1 env, 1 thread, %.1f s" % (done, dt))
+        with open("/proc/meminfo") as f:
+            avail = [int(l.split()[1]) for l in f if l.startswith("MemAvailable")][0] / 1e6      # GB
+        P_mem = max(1, int(avail / 0.75))
+    except (OSError, IndexError):
+        P_mem = P
+    if P_mem < P:
+        cap_note = " (%d physical cores visible, capped by available memory)" % phys
+        P = P_mem
+    barrier = ctx.Barrier(P)
+    procs = [ctx.Process(target=_cpu_worker, args=(workload, seconds, chunk, barrier, q)) for _ in range(P)]
+    for pr in procs:
+        pr.start()
+    res = [q.get() for _ in procs]
+    for pr in procs:
+        pr.join()
+    node = sum(d / t for d, t in res)
+    kind = "shipped trainer host loop on tests/oracle_backend.py (oracle/evopf.py kernels), torch-CPU MLPs" \
+        if workload.startswith("evopf") else "oracle/rpo_loop.py OracleRPO"
+    return dict(value=node, unit="env-steps/s", cores=P, kind="port", single_core_value=solo,
+                per_process_under_load=node / P,
+                sample="%s, %s, 1 env per process, rollout + one batch-256 update per env step, 1 thread per process: "
+                       "1 process alone %.1f s (%d steps) and %d processes at once%s %.1f s each (%d steps in total)"
+                       % (kind, DESCRIBE[workload], dt1, done1, P, cap_note, seconds, sum(d for d, _ in res)))
+
+
+# ------------------------------------------------------------------------------------------------ launch of N ranks
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks as children of a process that has NOT touched the GPU
+    (torch.cuda.device_count() does not initialise HIP on this image) and pass their output / exit code through."""
+    have = torch.cuda.device_count()
+    if have < n:
+        log("bench.py: --gpus %d requested but only %d GPU(s) are visible; refusing to print a %d-GPU line" % (n, have, have))
+        sys.exit(2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL peer buffers across processes
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    log("bench.py: starting %d ranks: %s" % (n, " ".join(cmd)))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def timed_run(tr, steps, warmup, world, device):
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+    tr.run_steps(warmup)
+    if os.environ.get("RPO_BENCH_DEBUG"):    # extra untimed windows, to see drift / host stalls (stderr)
+        for w in range(6):
+            fence()
+            tw = time.perf_counter()
+            tr.run_steps(500)
+            fence()
+            log("debug window %d: %.4f ms/iter" % (w, (time.perf_counter() - tw) / 500 * 1e3))
+    fence()
+    t0 = time.perf_counter()
+    tr.run_steps(steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    return elapsed
+
+
+def prepared_trainer(n_total, device, workload):
+    """Untimed pre-conditioning on a throw-away trainer (tiny replay ring) -- the first process on a fresh box otherwise
+    pays for paging in the libraries and code paths of the iteration inside the timed window (measured: 0.14 instead of
+    0.10 ms per iteration in 4 of 4 first-process runs) -- then the measured trainer with every hipGraph of the steady
+    state captured (three eager passes + capture: single iterations with / without the policy step, and the
+    multi-iteration window), like a compile step."""
+    pre = make_trainer(n_total, device, 10 ** 9, capacity=64, workload=workload)
+    pre.vec.reset()
+    pre.run_steps(1500)
+    pre._harvest(final=True)                # first use of the statistics path (gather / reduce / copy-out kernels)
+    torch.cuda.synchronize()
+    del pre
+    tr = make_trainer(n_total, device, 10 ** 9, workload=workload)
+    tr.vec.reset()
+    tr.run_steps(5 * max(tr._cycle, 4))
+    return tr
 
 
 def main():
@@ -242,66 +532,47 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clinic", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the rollout-only / UTD-matched / cart_sac legs")
     ap.add_argument("--workload", default="cart_ddpg", choices=sorted(WORKLOADS),
                     help="cart_ddpg is the headline (BASELINE.json configs[1]); the others are extra measurements")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus, sys.argv[1:])                     # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
+    headline = args.workload == "cart_ddpg"
+
+    # CPU leg first: forked single-thread workers, before this process initialises the GPU
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        cpu = cpu_baseline(args.workload)
+        log("cpu baseline: %.1f env-steps/s on %d cores (1 core alone: %.1f)" % (cpu["value"], cpu["cores"],
+                                                                                cpu["single_core_value"]))
+
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
+        log("rank %d/%d on cuda:%d: process group up, backend %s (RCCL), %d ranks" % (
+            rank, world, local_rank, dist.get_backend(), dist.get_world_size()))
 
     EPG = envs_per_gpu(args.workload)
     n_total = EPG * world
     spin_up(device)
-    # untimed pre-conditioning on a throw-away trainer (tiny replay ring): the first process on a fresh box otherwise pays
-    # for paging in the libraries and code paths of the iteration inside the timed window (measured: 0.14 instead of
-    # 0.10 ms per iteration in 4 of 4 first-process runs)
-    pre = make_trainer(n_total, device, 10 ** 9, capacity=64, workload=args.workload)
-    pre.vec.reset()
-    pre.run_steps(1500)
-    pre._harvest(final=True)                # first use of the statistics path (gather / reduce / copy-out kernels)
-    torch.cuda.synchronize()
-    del pre
-    tr = make_trainer(n_total, device, 10 ** 9, workload=args.workload)
-    headline = args.workload == "cart_ddpg"
-    tr.vec.reset()
-    # untimed setup, independent of --warmup: three eager passes + capture of every hipGraph the steady state replays
-    # (single iterations with / without the policy step, and the multi-iteration window), like a compile step
-    tr.run_steps(5 * max(tr._cycle, 4))
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    tr.run_steps(args.warmup)
-    if os.environ.get("RPO_BENCH_DEBUG"):    # extra untimed windows, to see drift / host stalls (stderr)
-        for w in range(6):
-            fence()
-            tw = time.perf_counter()
-            tr.run_steps(500)
-            fence()
-            log("debug window %d: %.4f ms/iter" % (w, (time.perf_counter() - tw) / 500 * 1e3))
-    fence()
-    t0 = time.perf_counter()
-    tr.run_steps(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    tr._harvest(final=True)
+    tr = prepared_trainer(n_total, device, args.workload)
+    elapsed = timed_run(tr, args.steps, args.warmup, world, device)
     value = n_total * args.steps / elapsed
+    # the violation rate needs a window of its own: over a few dozen vector steps it is noise (measured 0.325 over
+    # 20 steps vs 0.023 over 2000).  Continue the same run, untimed, to at least 1000 vector steps.
+    if tr._t < 1000:
+        tr.run_steps(1000 - tr._t)
+    tr._harvest(final=True)
 
     result = {
         "metric": "env-steps/sec (whole node), %s, rollout + one batch-256 constrained policy update per vector step"
@@ -312,18 +583,34 @@ def main():
         "config": {"workload": ("CartSafe-v0 RPODDPG, %d vectorised envs per MI355X, scripts/cart_exp.py "
                                 "hyper-parameters, update batch 256 every vector step (reference cadence), replay "
                                 "capacity 20000 per env" % EPG) if headline else
-                               "%s, %d vectorised envs per MI355X (extra measurement, not the headline)" % (args.workload, EPG),
+                               "%s, %d vectorised envs per MI355X (extra measurement, not the headline)" % (DESCRIBE[args.workload], EPG),
                    "envs_per_gpu": EPG, "global_envs": n_total, "update_batch": 256,
-                   "parallelism": "dp%d (env shards, RCCL all-reduce of the flat gradient bucket)" % world,
-                   "hip_graph": bool(tr._graphs.enabled)},
+                   "parallelism": "dp%d (env shards, one RCCL all-reduce of the flat gradient bucket per update, "
+                                  "captured inside the iteration's hipGraph)" % world,
+                   "hip_graph": bool(tr._graphs.enabled), "graph_window_iterations": tr._cycle,
+                   "collectives_in_graph": bool(tr.dist.in_graph)},
         "constraint_violation_rate": tr.viol_rate,
+        "constraint_violation_window": "%d vector steps x %d envs" % (tr._t, n_total),
         "mean_projection_iters": tr.proj_iters_mean,
     }
 
-    if rank == 0:
-        # (i) rollout-only throughput next to the headline, so that the cadence is visible
-        ro = make_trainer(EPG, device, 10 ** 9, capacity=64, workload=args.workload) if world == 1 else None
-        if ro is not None:
+    extras = not args.no_extras
+    if extras and headline:
+        # config 4's algorithm (RPOSAC on CartSafe-v0, scripts/cart_exp_sac.py) on the same ranks, same protocol
+        del tr
+        torch.cuda.empty_cache()
+        sac = prepared_trainer(n_total, device, "cart_sac")
+        e2 = timed_run(sac, args.steps, args.warmup, world, device)
+        result["cart_sac_env_steps_per_s"] = n_total * args.steps / e2
+        result["cart_sac_ms_per_step"] = e2 / args.steps * 1e3
+        del sac
+        torch.cuda.empty_cache()
+        tr = None
+
+    if rank == 0 and world == 1:
+        if extras:
+            # (i) rollout-only throughput next to the headline, so that the cadence is visible
+            ro = make_trainer(EPG, device, 10 ** 9, capacity=64, workload=args.workload)
             ro.vec.reset()
             ro.run_steps(5 * max(ro._cycle, 4), train=False)      # eager passes + graph capture
             torch.cuda.synchronize()
@@ -331,10 +618,10 @@ def main():
             ro.run_steps(1000, train=False)
             torch.cuda.synchronize()
             result["rollout_only_env_steps_per_s"] = EPG * 1000 / (time.perf_counter() - t1)
+            del ro
             # (iii) UTD-matched: one batch-256 update per ENV step as in the reference, i.e. EPG updates per
             # vector step -- a bounded sample of vector steps
-            utd = make_trainer(EPG, device, 10 ** 9, capacity=256, workload=args.workload,
-                               updates_per_step=EPG)
+            utd = make_trainer(EPG, device, 10 ** 9, capacity=256, workload=args.workload, updates_per_step=EPG)
             utd.vec.reset()
             utd.run_steps(1)
             torch.cuda.synchronize()
@@ -344,39 +631,52 @@ def main():
             dt = time.perf_counter() - t2
             result["utd_matched_env_steps_per_s"] = EPG * 4 / dt
             result["utd_matched_updates_per_s"] = EPG * 4 / dt
+            result["utd_matched_us_per_update"] = dt / (EPG * 4) * 1e6
             del utd
-            del ro
-        if not args.no_clinic and world == 1 and tr.fused is not None and headline:
-            log("kernel clinic (hipGraph of back-to-back launches between two HIP events on the launch stream):")
-            clinic = kernel_clinic(tr)
-            # single launches of the iteration (the backward entry is a PAIR of launches, ~half each)
-            in_iter = ("rollout_kernel<CartEnv>", "cart_ddpg_critic_forward_kernel")
-            dom = max(in_iter, key=lambda n: clinic[n]["us"])
-            d, st = clinic[dom], clinic["cartsafe_step_kernel@1M"]
-            result["roofline"] = {
-                "bound": d["bound"], "kernel": dom, "achieved": d["rate"], "peak": d["peak"], "unit": d["unit"],
-                "frac": d["frac"], "traffic": pmc_traffic(dom, d["n"]), "launch_us": d["us"], "units_per_launch": d["n"],
-                "algorithmic_flops_per_launch": d["work"],
-                "note": "dominant launch of the iteration: ReplayBuffer.sample + pi_targ + projection + Q_targ | Q for 256 "
-                        "samples, two independent workgroups per 16-row tile (TD/Huber is the prologue of the backward "
-                        "pass); latency-bound (32 workgroups, the longer chain streams 2 x 128 KB of f32 weights at "
-                        "~47 GB/s per CU). Streaming regime of the HBM-bound env-step "
-                        "kernel (1M lanes): %.0f GB/s = %.3f of the 8 TB/s peak, PMC traffic %s B vs %d algorithmic B."
-                        % (st["rate"], st["frac"], pmc_traffic("cartsafe_step_kernel", st["n"]), st["work"]),
-                "hbm_streaming": {"kernel": "cartsafe_step_kernel", "bound": "hbm", "units_per_launch": st["n"],
-                                  "launch_us": st["us"], "achieved": st["rate"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": st["frac"], "traffic": pmc_traffic("cartsafe_step_kernel", st["n"]),
-                                  "algorithmic_bytes_per_launch": st["work"]},
-                "all_kernels": {kk: {"us": vv["us"], "rate": vv["rate"], "unit": vv["unit"], "frac": vv["frac"]}
-                                for kk, vv in clinic.items()},
-            }
-        if not args.no_cpu_baseline and world == 1 and headline:
-            result["cpu_baseline"] = cpu_baseline()
-            result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+        if not args.no_clinic:
+            if tr is None:
+                tr = prepared_trainer(n_total, device, args.workload)
+            if tr.fused is not None:
+                log("kernel clinic (hipGraph of back-to-back launches between two HIP events on the launch stream):")
+                result["roofline"] = roofline(kernel_clinic(tr, args.workload), args.workload)
+        if cpu is not None:
+            result["cpu_baseline"] = cpu
+            result["gpu_over_cpu"] = value / cpu["value"]
+            result["gpu_over_cpu_single_core"] = value / cpu["single_core_value"]
+            if "utd_matched_env_steps_per_s" in result:
+                result["utd_matched_over_cpu"] = result["utd_matched_env_steps_per_s"] / cpu["value"]
+                result["utd_matched_over_cpu_single_core"] = result["utd_matched_env_steps_per_s"] / cpu["single_core_value"]
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def roofline(clinic, workload):
+    """The dominant kernel of the iteration: the single launch with the largest share of one policy_fre period
+    (duration x launches per period) among the priced launches at the bench size; the backward entries are PAIRS of
+    launches (rows pass + weights pass) and are listed in all_kernels only."""
+    in_iter = {k: v for k, v in clinic.items() if "rate" in v and "@1M" not in k and not k.startswith("mlp_backward")}
+    dom = max(in_iter, key=lambda n: in_iter[n]["us"] * in_iter[n].get("launches_per_period", 1))
+    d = in_iter[dom]
+    kernel = KERNEL_OF.get(dom.split("[")[0], dom)
+    r = {"bound": d["bound"], "kernel": kernel, "entry_point": dom, "achieved": d["rate"], "peak": d["peak"],
+         "unit": d["unit"], "frac": d["frac"], "traffic": pmc_traffic(kernel, d["n"]), "launch_us": d["us"],
+         "units_per_launch": d["n"],
+         "algorithmic_%s_per_launch" % ("bytes" if d["bound"] == "hbm" else "flops"): d["work"],
+         "note": "dominant launch of the iteration at the bench size (latency-bound: %d units per launch); "
+                 "all_kernels lists every launch of one policy_fre period with its own roofline" % d["n"],
+         "all_kernels": {k: {kk: vv for kk, vv in v.items() if kk in ("us", "rate", "unit", "frac", "bound", "n",
+                                                                     "launches_per_period")}
+                         for k, v in clinic.items()}}
+    st = clinic.get("cartsafe_step_kernel@1M")
+    if st is not None:
+        r["hbm_streaming"] = {"kernel": "cartsafe_step_kernel", "bound": "hbm", "units_per_launch": st["n"],
+                              "launch_us": st["us"], "achieved": st["rate"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": st["frac"], "traffic": pmc_traffic("cartsafe_step_kernel", st["n"]),
+                              "algorithmic_bytes_per_launch": st["work"]}
+    return r
 
 
 if __name__ == "__main__":

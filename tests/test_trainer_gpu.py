@@ -251,8 +251,8 @@ def test_data_parallel_graph_segments_on_gpu(hip, tmp_path):
                 for proc in ctx.processes:
                     if proc.is_alive():
                         proc.kill()
-                pytest.skip("two ranks sharing one GPU did not finish within 200 s; the N > 1 path is covered by the "
-                            "world_size-2 gloo tests on CPU (tests/test_distributed_cpu.py)")
+                pytest.fail("two ranks sharing one GPU did not finish within 200 s: a hung collective path must not "
+                            "pass as a skip")
         results[use_graph] = [torch.load(os.path.join(out_dir, "rank%d.pt" % r), weights_only=False) for r in (0, 1)]
     tmp_path = os.path.join(str(tmp_path), "graph")
     # graph segments (with the deferred optimiser tail) == eager launches, bit for bit
@@ -263,6 +263,89 @@ def test_data_parallel_graph_segments_on_gpu(hip, tmp_path):
     r1 = torch.load(os.path.join(tmp_path, "rank1.pt"), weights_only=False)
     assert torch.equal(r0["flat"], r1["flat"]) and torch.equal(r0["nju"], r1["nju"])
     assert r0["env_steps"] == r1["env_steps"] == 512 * 40
+    assert not torch.equal(r0["state"], r1["state"])
+
+
+def _rccl_worker(rank, world, port, out_dir, algo, n_total, iters):
+    """One rank per GPU over RCCL (backend "nccl"); world == 1 exercises the same code path on a one-GPU box through
+    RPO_DIST_FORCE (the collective is then a self-reduce, but it is issued, captured and replayed like any other)."""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RPO_VERBOSE="0", RPO_DIST_FORCE="1",
+                      RPO_GRAPH_CYCLE="8")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from rpo_amd import ops
+    from test_train_step_golden import build_trainer
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    torch.manual_seed(5 + rank)             # rank 0's initial state is broadcast at construction
+    tr = build_trainer(algo, "cart", ops, dev, num_envs=n_total, use_graph=True)
+    assert tr.dist.on and tr.dist.in_graph and tr.dist.world == world and tr.n_local == n_total // world
+    tr.vec.reset()
+    tr.run_steps(iters)
+    tr._harvest(final=True)
+    torch.cuda.synchronize()
+    captured = [k for k, e in tr._graphs.entries.items() if e["graph"] is not None]
+    assert ("cycle", 8, True) in captured, captured          # multi-iteration windows WITH the collectives inside
+    assert tr._graphs.enabled                                 # no capture failure fell back to eager launches
+    torch.save(dict(flat=tr.agent.flat.data.cpu(), nju=tr.agent.nju.weight.data.cpu(), env_steps=float(tr.env_steps),
+                    state=tr.vec.internal.cpu(), rows=tr.buffer.rows[:64 * tr.n_local].cpu(), seed=tr.seed),
+               os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _spawn_rccl(world, out_dir, algo, n_total, iters, budget=240):
+    import os
+    import socket
+    import time
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.spawn(_rccl_worker, args=(world, port, out_dir, algo, n_total, iters), nprocs=world, join=False)
+    deadline = time.time() + budget
+    while not ctx.join(timeout=5):
+        if time.time() > deadline:
+            for proc in ctx.processes:
+                if proc.is_alive():
+                    proc.kill()
+            pytest.fail("RCCL ranks did not finish within %d s" % budget)
+    return [torch.load(os.path.join(out_dir, "rank%d.pt" % r), weights_only=False) for r in range(world)]
+
+
+@pytest.mark.parametrize("algo", ["ddpg", "sac"])
+def test_rccl_collectives_inside_the_graph_single_rank(hip, tmp_path, algo, monkeypatch):
+    """The data-parallel iteration over RCCL on the one GPU of this box (world size 1, RPO_DIST_FORCE): every gradient
+    all-reduce is issued inside the hipGraph of the iteration / of the 8-iteration window.  With one rank the mean over
+    ranks is the identity, so the run must equal the plain single-process run bit for bit -- which also pins that the
+    data-parallel path (no in-backward inf-norm, explicit rpo_absmax) computes the same update."""
+    (r0,) = _spawn_rccl(1, str(tmp_path), algo, 256, 70)
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
+    torch.manual_seed(5)
+    tr = build_trainer(algo, "cart", hip, torch.device("cuda"), num_envs=256, use_graph=True)
+    assert not tr.dist.on and tr.seed == r0["seed"]
+    tr.vec.reset()
+    tr.run_steps(70)
+    torch.cuda.synchronize()
+    assert torch.equal(tr.vec.internal.cpu(), r0["state"])
+    assert torch.equal(tr.buffer.rows[:64 * 256].cpu(), r0["rows"])
+    assert torch.equal(tr.agent.flat.data.cpu(), r0["flat"]) and torch.equal(tr.agent.nju.weight.data.cpu(), r0["nju"])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (one rank per GPU over RCCL / xGMI)")
+def test_rccl_two_ranks_one_per_gpu(hip, tmp_path):
+    """Two ranks, one per GPU, RCCL all-reduce inside the graph windows: replicas stay bit-identical, lanes are sharded
+    by global env id, statistics are summed over ranks."""
+    r0, r1 = _spawn_rccl(2, str(tmp_path), "sac", 512, 70)
+    assert torch.equal(r0["flat"], r1["flat"]) and torch.equal(r0["nju"], r1["nju"])
+    assert r0["env_steps"] == r1["env_steps"] == 512 * 70 and r0["seed"] == r1["seed"]
     assert not torch.equal(r0["state"], r1["state"])
 
 
