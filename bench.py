@@ -154,6 +154,15 @@ class LaunchRecorder(object):
             if callable(fn) and not name.startswith("_") and not isinstance(fn, type) and name not in skip \
                     and getattr(fn, "__module__", None) == ops.__name__:
                 self._wrap(ops, name, fn)
+        if hasattr(ops, "SplitUpdate"):                           # stages of the column-split update: one launch each
+            orig_run = ops.SplitUpdate.run
+            rec = self
+
+            def run(su, stage):
+                rec.calls.append(("split_" + stage, orig_run, (su, stage), {}))
+                return orig_run(su, stage)
+            self._undo.append((ops.SplitUpdate, "run", orig_run, True))
+            ops.SplitUpdate.run = run
         k = tr.kernels
         for name in dir(k):
             fn = getattr(k, name)
@@ -209,6 +218,10 @@ def launch_models(tr, workload):
         "ddpg_actor_forward": ("mfma", B, fa + fc), "ddpg_actor_backward": ("mfma", B, 2 * (fa + fc)),
         "sac_actor_forward": ("mfma", B, 2 * fa + 2 * fc), "sac_actor_backward": ("mfma", B, 2 * (fa + 2 * fc)),
         "adam_step": ("hbm", None, 36), "adam_step_multi": ("hbm", None, 36), "absmax": ("hbm", None, 4),
+        # column-split update stages (rpo_amd/csrc/nsplit.hip)
+        "split_critic_fwd_a": ("mfma", B, fa + twin * fc), "split_critic_fwd_b": ("mfma", B, twin * fc),
+        "split_pend_head_project": ("hbm", B, 4 * S + 4 * P + 4 * A + 4),
+        "split_critic_bwd_a": ("mfma", B, 2 * twin * fc), "split_critic_bwd_b": ("mfma", B, twin * 2 * 128 * (S + A + 2)),
     }
     return m
 
@@ -325,6 +338,9 @@ KERNEL_OF = {
     "PendulumKernels.ddpg_critic_back": "pend_critic_back_kernel", "PendulumKernels.sac_critic_back": "pend_critic_back_kernel",
     "EvopfKernels.act_project": "evopf_act_project_kernel", "mlp_backward": "mlp_bwd_rows_kernel + mlp_bwd_weights_kernel",
     "mlp_backward_pair": "mlp_bwd_rows_kernel + mlp_bwd_weights_kernel (twin)",
+    "split_critic_fwd_a": "split_critic_fwd_a_kernel", "split_critic_fwd_b": "split_critic_fwd_b_kernel",
+    "split_critic_bwd_a": "split_critic_bwd_a_kernel", "split_critic_bwd_b": "split_critic_bwd_b_kernel",
+    "split_pend_head_project": "split_pend_head_project_kernel",
 }
 
 

@@ -376,6 +376,86 @@ int rpo_mlp_forward_multi(int count, const rpo_mlp* const* nets, int n, const fl
                           const float* const* a, const int* a_stride, float* const* out, float* const* x0_save,
                           float* const* h1_save, void* stream);
 
+/* Column-split forward (rpo_amd/csrc/nsplit_dev.h): the hidden layer of 1..4 same-shaped scalar-head networks (E = 128,
+ * H = 256, "add" critics / actors, S, A <= 8) on 16 row tiles x 8 column groups of workgroups each.  Leaves the head
+ * partials of the column groups in part_k [8, n, 2]; rpo_mlp_split_head (or the prologue of any consumer kernel) adds
+ * them in the order of rpo_mlp_forward's wave loop, so the outputs are bitwise those of rpo_mlp_forward.  This is how
+ * the batch-256 update kernels use the width of the chip: one network evaluation is 128 workgroups with a 16 KB weight
+ * slice and a 32-instruction MFMA chain each, instead of 16 workgroups with 128 KB and 128 instructions per SIMD. */
+int rpo_mlp_split_supported(const rpo_mlp* net_host);
+int rpo_mlp_forward_split(int count, const rpo_mlp* const* nets, int n, const float* const* s, const int* s_stride,
+                          const float* const* a, const int* a_stride, float* const* part, float* const* x0_save,
+                          float* const* h1_save, void* stream);
+int rpo_mlp_split_head(const rpo_mlp* net_host, int n, const float* part, float* out, int out_mode, float scale,
+                       float base, void* stream);
+
+/* ---- Column-split update of RPODDPG / RPOSAC on CartSafe-v0 / SpringPendulum-v0 (rpo_amd/csrc/nsplit.hip) -------------
+ * The batch-256 constrained policy update (rpo_ddpg.py:163-205, rpo_sac.py:167-219) as a chain of SHORT launches that
+ * each use the width of the chip (>= 128 workgroups), cut where a value needs every hidden column or every sample:
+ *
+ *   critic update   fwd_a   ReplayBuffer.sample -> {pi_targ / pi hidden slabs on s' | Q1 (, Q2) hidden slabs on (s, a)}
+ *                   fwd_b   head of pi -> (rsample, log pi) -> Complete + Proj -> Q_targ (x2) hidden slabs on (s', a')
+ *                           (SpringPendulum: head + the batch-coupled projection are one single-workgroup launch,
+ *                           rpo_split_pend_head_project, followed by fwd_b on the projected actions)
+ *                   bwd_a   TD target + Huber (from the slab partials) -> {dx0 column groups | dW0 tiles | hidden vectors}
+ *                   bwd_b   first-layer gradients (batch reduction of dx0), inf-norm of everything written
+ *                   then rpo_adam_step.
+ *   policy step     pol_a   pi hidden slabs on s (saved)
+ *                   pol_b   head -> noise / rsample + clip -> Complete -> Lagrangian row terms -> Q (x2) slabs on (s, a_pi)
+ *                   pol_c   d(-Q or -min Q)/dQ -> critic dx0 column groups -> per-group partials of d/d action
+ *                   pol_d   d/d action -> Complete -> head backward -> {actor dx0 column groups | dW0 tiles | vectors}
+ *                   pol_e   actor first-layer gradients (+ the critics' dx0 under a shared embedding), multiplier terms
+ *                   then rpo_adam_step_multi.
+ * Every network is E = 128, H = 256, "add" critic / scalar-head actor (rpo_mlp_split_supported).  All values are
+ * bitwise those of the row-tile pipelines (rpo_cartsafe_*_critic_forward + rpo_mlp_backward) for the critic update;
+ * the policy step sums d/d action over column groups (agrees to 1e-7 relative).  One struct carries the arguments
+ * of all stages; a stage reads only the fields it needs.  part_* are [8, batch, 2] float buffers. */
+typedef struct {
+    const rpo_mlp *actor, *actor_target, *critic1, *critic2, *critic_target1, *critic_target2;
+    const rpo_mlp_grad *critic1_grad, *critic2_grad, *actor_grad;
+    int env;                     /* 0 CartSafe-v0 (consts_host / partial), 1 SpringPendulum-v0 */
+    int twin;                    /* 0 RPODDPG (actor_target, critic1, critic_target1), 1 RPOSAC (actor, twins) */
+    int batch;
+    /* ReplayBuffer.sample */
+    const float* rows; long long cap_steps; int n_envs;
+    float* batch_out; long long* idx_out; const long long* idx_in;
+    unsigned long long sample_seed; unsigned sample_salt;
+    /* policy draws: rsample of a' (critic update) / take_action noise (policy step); eps_in / noise_in replace Philox */
+    const float* eps_in; unsigned long long noise_seed; unsigned noise_id_base, noise_salt;
+    const long long* ctrl;
+    float scale, base, box_lo, box_hi;
+    int max_steps; float corr_lr, corr_eps, corr_momentum;
+    const float* consts_host; int partial;
+    float alpha, gamma;
+    float eps_start, eps_end, eps_decay;          /* exploration schedule of take_action in the actor loss (RPODDPG) */
+    /* slab partials and saved pre-activations */
+    float *part_pi, *part_q1, *part_q2, *part_qn1, *part_qn2;
+    float *x0_1, *h1_1, *x0_2, *h1_2, *x0_a, *h1_a;
+    float *logp;                 /* [batch] log pi(a'|s') (critic update) / log pi(a|s) (policy step) */
+    float *next_actions;         /* [batch, 2] SpringPendulum: projected a' */
+    int *proj_iters;             /* NULL or [1] */
+    /* backward */
+    float *dq1, *dq2;            /* [batch] dLoss/dQ_k */
+    float *loss_partial;         /* [2, ceil(batch / 16)] */
+    float *dx0_1, *dx0_2, *dx0_a;
+    float *gradmax;              /* NULL or [1] */
+    /* policy step */
+    const float* nu; float* nu_grad;
+    float *ap_det, *noise_out, *raw, *actions, *g_act, *lag_partial, *lag_out, *da_part, *dout;
+    int shared_embedding;
+} rpo_split_update;
+
+int rpo_split_critic_fwd_a(const rpo_split_update* u, void* stream);
+int rpo_split_critic_fwd_b(const rpo_split_update* u, void* stream);
+int rpo_split_pend_head_project(const rpo_split_update* u, void* stream);
+int rpo_split_critic_bwd_a(const rpo_split_update* u, void* stream);
+int rpo_split_critic_bwd_b(const rpo_split_update* u, void* stream);
+int rpo_split_policy_a(const rpo_split_update* u, void* stream);
+int rpo_split_policy_b(const rpo_split_update* u, void* stream);
+int rpo_split_policy_c(const rpo_split_update* u, void* stream);
+int rpo_split_policy_d(const rpo_split_update* u, void* stream);
+int rpo_split_policy_e(const rpo_split_update* u, void* stream);
+
 /* Backward of the same rows given dout [n, n_out] (two launches).  Parameter gradients are ACCUMULATED (+=) into
  * grad_host's buffers (the shared state embedding of shared_param=True receives contributions from two networks,
  * agent/ddpg_pa.py:34-36).  dh [n, H] and dx0 [n, Ein] are caller-provided scratch; da [n, A] (may be NULL) receives

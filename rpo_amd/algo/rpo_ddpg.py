@@ -138,6 +138,9 @@ class RPODDPG(RPOTrainerBase):
         if self.fused is None:
             return super()._critic_update(cols)
         if self._pipelines:
+            su = self._split_state()
+            if su is not None:
+                return self._critic_update_split(su)
             return self._critic_update_pipeline(cols)
         f, ag, B = self.fused, self.agent, self.batch_size
         state, action, next_state, reward, done = cols[:5]
@@ -193,6 +196,12 @@ class RPODDPG(RPOTrainerBase):
         if self.fused is None:
             return super()._actor_update(cols)
         if self._actor_pipeline:
+            su = self._split_state()
+            if su is not None:
+                lag, _, _ = self._actor_update_split(su)
+                loss = _LazyDiff(lag)
+                self.last_losses["actor"] = loss
+                return loss
             return self._actor_update_pipeline(cols)
         f, ag, B, k = self.fused, self.agent, self.batch_size, self.kernels
         state = cols[0]

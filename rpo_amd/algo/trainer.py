@@ -461,6 +461,116 @@ class RPOTrainerBase(object):
             self.dist.mean_([fl.gradient(fl.policy_bucket)])
             self._actor_step(out)
 
+    # ------------------------------------------------------------------------------------------ column-split update
+    def _split_state(self):
+        """The column-split update stages (rpo_split_*, rpo_amd/csrc/nsplit.hip) when this configuration supports them:
+        CartSafe / SpringPendulum kernels, every network 128 -> 256 with scalar heads, the reference's batched projection
+        semantics on SpringPendulum, batch <= 1024.  ``RPO_SPLIT=0`` keeps the row-tile pipelines."""
+        if getattr(self, "_split_cache", False) is not False:
+            return self._split_cache
+        self._split_cache = None
+        f, k, be = self.fused, self.kernels, self.backend
+        if f is None or not hasattr(be, "SplitUpdate") or not _env_int("RPO_SPLIT", 1) or self._box_affine is None:
+            return None
+        if not isinstance(k, (be.CartSafeKernels, be.PendulumKernels)) or self.batch_size > 1024:
+            return None
+        if isinstance(k, be.PendulumKernels) and not self.batch_reference:
+            return None
+        d = f.descs
+        names = ("actor", "critic1", "critic2", "critic_target1", "critic_target2") if self.sac else \
+            ("actor", "actor_target", "critic", "critic_target")
+        if any(n not in d or not be.mlp_split_supported(d[n]) for n in names):
+            return None
+        B, ag, buf = self.batch_size, self.agent, self.buffer
+        T = (B + 15) // 16
+        b = f.buf
+        descs = dict(actor=d["actor"])
+        if self.sac:
+            descs.update(critic1=d["critic1"], critic2=d["critic2"], critic_target1=d["critic_target1"],
+                         critic_target2=d["critic_target2"])
+        else:
+            descs.update(actor_target=d["actor_target"], critic1=d["critic"], critic_target1=d["critic_target"])
+        scale, base = self._box_affine
+        c1 = "critic1" if self.sac else "critic"
+        fields = dict(
+            rows=buf.rows, cap_steps=buf.capacity, n_envs=buf.n_envs, batch_out=self._batch, sample_seed=buf.seed,
+            sample_salt=0, noise_seed=self.seed, noise_id_base=self.dist.rank * B, noise_salt=_SALT_CRITIC, ctrl=buf.ctrl,
+            scale=scale, base=base, box_lo=self._box_lo, box_hi=self._box_hi, max_steps=self.max_steps,
+            corr_lr=self.corr_lr, corr_eps=self.corr_eps, corr_momentum=self.corr_momentum,
+            alpha=float(getattr(ag, "alpha", 0.0)), gamma=ag.gamma, eps_start=self.eps_start, eps_end=self.eps,
+            eps_decay=self.decay_value,
+            part_pi=b("split.part_pi", 8, B, 2), part_q1=b("split.part_q1", 8, B, 2), part_qn1=b("split.part_qn1", 8, B, 2),
+            x0_1=b(c1 + ".x0", B, d[c1].ein), h1_1=b(c1 + ".h1", B, d[c1].H), dq1=b("dq1" if self.sac else "dq", B, 1),
+            dx0_1=b(c1 + ".dx0", B, d[c1].ein), loss_partial=b("split.loss_parts", 2, T),
+            next_actions=b("split.next_actions", B, 2), logp=b("crit.logp", B))
+        if self.sac:
+            fields.update(part_q2=b("split.part_q2", 8, B, 2), part_qn2=b("split.part_qn2", 8, B, 2),
+                          x0_2=b("critic2.x0", B, d["critic2"].ein), h1_2=b("critic2.h1", B, d["critic2"].H),
+                          dq2=b("dq2", B, 1), dx0_2=b("critic2.dx0", B, d["critic2"].ein))
+        # policy step
+        da_ = d["actor"]
+        fields.update(nu=ag.nju.weight.view(-1), nu_grad=ag.nju.weight.grad.view(-1), noise_out=b("act.noise", B),
+                      actions=b("act_pi", B, 2), g_act=b("g_act", B, 2), lag_partial=b("actor.parts", T, 8),
+                      lag_out=b("actor.lag", 2), da_part=b("split.da_part", 2, 8, B, 2), dout=b("split.dout", B, 2),
+                      x0_a=b("actor.x0", B, da_.ein), h1_a=b("actor.h1", B, da_.H), dx0_a=b("actor.dx0", B, da_.ein),
+                      shared_embedding=int(ag.flat.sizes[1] > 0))
+        if self.sac:
+            fields.update(raw=b("pi.raw", B, 2))
+        else:
+            fields.update(ap_det=b("act.ap_det", B))
+        self._split_cache = be.SplitUpdate(k, descs, self.sac, B, fields)
+        self._split_loss = fields["loss_partial"]
+        self._split_logp = (fields["logp"], b("pi.logp", B))          # log pi(a'|s') of the critic update | log pi(a|s)
+        return self._split_cache
+
+    def _actor_update_split(self, su):
+        """Policy step through the column-split stages: pol_a .. pol_e (rpo_amd/csrc/nsplit.hip)."""
+        B, ag, k = self.batch_size, self.agent, self.kernels
+        noise_in = None
+        if self._idx_inject is not None:                          # tests replay the reference's draw
+            self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * B * k.partial_dim, _SALT_ACTOR,
+                                       hip_ops.STREAM_POLICY, self.vec.ctrl)
+            noise_in = self._noise_b.view(-1)
+        crit_logp, pi_logp = self._split_logp
+        su.set(noise_salt=_SALT_ACTOR, eps_in=noise_in, logp=pi_logp)
+        su.run("policy_a")
+        su.run("policy_b")
+        su.run("policy_c")
+        self._zero_grads()
+        opt = ag.actor_optim
+        fuse_max = self._self_cleaning and not self.dist.on and opt.clip_thres and opt.clip_thres != float("inf")
+        su.set(gradmax=opt.gradmax if fuse_max else None)
+        su.run("policy_d")
+        su.run("policy_e")
+        su.set(noise_salt=_SALT_CRITIC, eps_in=None, logp=crit_logp)
+        self._actor_gradmax_ready = bool(fuse_max)
+        f = self.fused
+        return f.buf("actor.lag", 2), f.buf("actor.parts", (B + 15) // 16, 8), pi_logp
+
+    def _critic_update_split(self, su):
+        """Critic update through the column-split stages: fwd_a | (pend: head + batch projection) | fwd_b | bwd_a | bwd_b."""
+        inject = self._idx_inject is not None                   # tests replay the reference's draws
+        idx_in = self._idx_inject() if inject else None
+        eps_in = None
+        if inject and self.sac:
+            B = self.batch_size
+            self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * B * self.kernels.partial_dim, _SALT_CRITIC,
+                                       hip_ops.STREAM_POLICY, self.vec.ctrl)
+            eps_in = self._noise_b.view(-1)
+        su.set(idx_in=idx_in, eps_in=eps_in)
+        su.run("critic_fwd_a")
+        if su.st.env == 1:
+            su.run("pend_head_project")
+        su.run("critic_fwd_b")
+        self._zero_grads()
+        gm = self._critic_gradmax()
+        su.set(gradmax=gm)
+        su.run("critic_bwd_a")
+        su.run("critic_bwd_b")
+        self._gradmax_ready = gm is not None
+        from .rpo_ddpg import _LazySum
+        self.last_losses["critic"] = _LazySum(self._split_loss if self.sac else self._split_loss[0])
+
     # ------------------------------------------------------------------------------------------ fused-MLP helpers
     def _project_batch(self, state, ap_flat):
         """Training-batch projection of `ap_flat` [B] -> actions [B, A] (same semantics as process_action)."""

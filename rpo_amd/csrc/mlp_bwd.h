@@ -176,6 +176,59 @@ __device__ __forceinline__ void mlp_bwd_rows_body(const BwdArgs& p) {
     }
 }
 
+// First-layer gradients from dx0 (batch reduction, one owner per output, 64 outputs per workgroup, the batch split over
+// the 4 waves and combined through LDS in a fixed order).  Output list idx = q * E + e (e fastest: coalesced dx0 reads);
+// q < wS: state weights / bias, q >= wS: action weights / bias.  Columns of x0: [0, E) <- state (+ action when added);
+// [E, 2E) <- action (cat).  `fl_block` = index of the workgroup among the first-layer workgroups.
+template <int EIN>
+__device__ __forceinline__ float mlp_bwd_first_layer(const BwdArgs& p, int fl_block) {
+    __shared__ float fl_partial[4][64];
+    const Mlp& net = p.net;
+    const int tid = threadIdx.x;
+    const int o = tid & 63, part = tid >> 6;
+    const int b_lo = (int)(((long long)p.n * part) / 4), b_hi = (int)(((long long)p.n * (part + 1)) / 4);
+    float gmax = 0.0f;
+    const int wS = net.S + 1, wA = (net.A > 0 && !p.first_layer_state_only) ? net.A + 1 : 0;   // +1: the bias
+    const int idx = fl_block * 64 + o;
+    const bool valid = idx < net.E * (wS + wA);
+    float acc = 0.0f;
+    int e = 0, i = 0, width = 0;
+    bool is_a = false;
+    if (valid) {
+        e = idx % net.E;
+        const int q = idx / net.E;
+        is_a = q >= wS;
+        i = is_a ? q - wS : q;
+        width = is_a ? net.A : net.S;
+        const int col = (is_a && net.cat) ? net.E + e : e;
+        const float* in = is_a ? p.a : p.s;
+        const int stride = is_a ? p.a_stride : p.s_stride;
+        const bool is_w = i < width;
+        int bb = b_lo;
+        for (; bb + 8 <= b_hi; bb += 8) {
+            float d[8], x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                d[u] = p.dx0[(size_t)(bb + u) * EIN + col];
+                x[u] = is_w ? in[(size_t)(bb + u) * stride + i] : 1.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(d[u], x[u], acc);
+        }
+        for (; bb < b_hi; ++bb) acc = fmaf(p.dx0[(size_t)bb * EIN + col], is_w ? in[(size_t)bb * stride + i] : 1.0f, acc);
+    }
+    fl_partial[part][o] = acc;
+    __syncthreads();
+    if (part == 0 && valid) {
+        const float tot = ((fl_partial[0][o] + fl_partial[1][o]) + fl_partial[2][o]) + fl_partial[3][o];
+        float* dst = (i < width) ? (is_a ? &p.g.Wa[e * net.A + i] : &p.g.Ws[e * net.S + i]) : (is_a ? &p.g.ba[e] : &p.g.bs[e]);
+        const float nv = *dst + tot;
+        *dst = nv;
+        gmax = fabsf(nv);
+    }
+    return gmax;
+}
+
 // ------------------------------------------------------------------------------------------------ backward, weights
 // Workgroups [0, H/16 * EIN/256): dW0 tiles (wave = 16 hidden rows x 64 input columns, K = batch); one more
 // workgroup accumulates the first-layer gradients dWs / dbs / dWa / dba from dx0, and the last one db0 / dW1 / db1.
@@ -405,47 +458,7 @@ __device__ __forceinline__ float mlp_bwd_weights_body(const BwdArgs& p) {
         }
         return gmax;
     }
-    // first layer: output list idx = q * E + e (e fastest: coalesced dx0 reads); q < wS: state weights / bias,
-    // q >= wS: action weights / bias.  Columns of x0: [0, E) <- state (+ action when added); [E, 2E) <- action (cat).
-    const int wS = net.S + 1, wA = (net.A > 0 && !p.first_layer_state_only) ? net.A + 1 : 0;   // +1: the bias
-    const int idx = (rb - hv_blocks) * 64 + o;
-    const bool valid = idx < net.E * (wS + wA);
-    float acc = 0.0f;
-    int e = 0, i = 0, width = 0;
-    bool is_a = false;
-    if (valid) {
-        e = idx % net.E;
-        const int q = idx / net.E;
-        is_a = q >= wS;
-        i = is_a ? q - wS : q;
-        width = is_a ? net.A : net.S;
-        const int col = (is_a && net.cat) ? net.E + e : e;
-        const float* in = is_a ? p.a : p.s;
-        const int stride = is_a ? p.a_stride : p.s_stride;
-        const bool is_w = i < width;
-        int bb = b_lo;
-        for (; bb + 8 <= b_hi; bb += 8) {
-            float d[8], x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                d[u] = p.dx0[(size_t)(bb + u) * EIN + col];
-                x[u] = is_w ? in[(size_t)(bb + u) * stride + i] : 1.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc = fmaf(d[u], x[u], acc);
-        }
-        for (; bb < b_hi; ++bb) acc = fmaf(p.dx0[(size_t)bb * EIN + col], is_w ? in[(size_t)bb * stride + i] : 1.0f, acc);
-    }
-    partial[part][0][o] = acc;
-    __syncthreads();
-    if (part == 0 && valid) {
-        const float tot = ((partial[0][0][o] + partial[1][0][o]) + partial[2][0][o]) + partial[3][0][o];
-        float* dst = (i < width) ? (is_a ? &p.g.Wa[e * net.A + i] : &p.g.Ws[e * net.S + i]) : (is_a ? &p.g.ba[e] : &p.g.bs[e]);
-        const float nv = *dst + tot;
-        *dst = nv;
-        gmax = fabsf(nv);
-    }
-    return gmax;
+    return mlp_bwd_first_layer<EIN>(p, rb - hv_blocks);
 }
 
 // max over the workgroup of the gradient magnitudes its threads wrote -> one atomic max (order independent: exact)

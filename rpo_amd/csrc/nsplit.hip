@@ -1,0 +1,1186 @@
+// Column-split update kernels (MI355X): the batch-256 update of RPODDPG / RPOSAC as short launches that use the width
+// of the chip -- 128 workgroups per network evaluation instead of 16 -- cut at the seams where a value needs every
+// hidden column (the heads).  nsplit_dev.h has the slab function and the argument for why the results are bitwise
+// those of the row-tile kernels.
+#include "cartsafe_dev.h"
+#include "heads_dev.h"
+#include "mlp_bwd.h"
+#include "nsplit_dev.h"
+#include "pendulum_dev.h"
+
+namespace {
+
+using namespace rpo_mlp_dev;
+
+Mlp to_dev(const rpo_mlp* h) {
+    return Mlp{h->Ws, h->bs, h->Wa, h->ba, h->W0, h->b0, h->W1, h->b1, h->W1b, h->b1b, h->S, h->A, h->E, h->H, h->n_out, h->cat, h->head_dim};
+}
+
+bool split_ok(const Mlp& m) {
+    return m.E == 128 && m.H == 256 && !m.cat && m.hd <= 1 && m.S <= 8 && m.A <= 8 && m.n_out >= 1 && m.n_out <= 2 && m.Ws && m.W0 &&
+           m.W1 && (m.A == 0 || m.Wa) && (m.n_out == 1 || m.W1b);
+}
+
+// ------------------------------------------------------------------------------------------- stand-alone split forward
+struct SplitFwdArgs {
+    Mlp net;
+    int n;
+    const float* s; int s_stride;
+    const float* a; int a_stride;
+    float* part;           // [8, n, 2] head partials of the column groups
+    float* x0_save; float* h1_save;
+};
+
+// grid (row tiles, 8 column groups, networks)
+struct SplitFwdArgs4 { SplitFwdArgs net[4]; };
+
+__global__ __launch_bounds__(kNsThreads) void mlp_forward_split_kernel(SplitFwdArgs4 all) {
+    __shared__ NsLds<128> lds;
+    const SplitFwdArgs& p = all.net[blockIdx.z];
+    const int row0 = blockIdx.x * kRows, g = blockIdx.y, tid = threadIdx.x;
+    NsWeights<128> w;
+    ns_load_weights<128, 256>(p.net, g, w);
+    if (tid < kRows * 8) {
+        const int r = tid >> 3, i = tid & 7;
+        const bool live = row0 + r < p.n;
+        lds.in_s[tid] = (live && i < p.net.S) ? p.s[(size_t)(row0 + r) * p.s_stride + i] : 0.0f;
+        lds.in_a[tid] = (live && i < p.net.A) ? p.a[(size_t)(row0 + r) * p.a_stride + i] : 0.0f;
+    }
+    ns_hidden<128, 256>(p.net, w, lds, g, row0, p.n, p.part, p.x0_save, p.h1_save);
+}
+
+__global__ __launch_bounds__(RPO_BLOCK) void mlp_split_head_kernel(Mlp net, int n, const float* __restrict__ part,
+                                                                   float* __restrict__ out, int out_mode, float scale,
+                                                                   float base) {
+    const int idx = blockIdx.x * RPO_BLOCK + threadIdx.x;
+    if (idx >= n * net.n_out) return;
+    const int r = idx / net.n_out, o = idx - r * net.n_out;
+    float v = ns_head(part, n, r, o, o == 0 ? net.b1[0] : net.b1b[0]);
+    if (out_mode == 1 && o == 0) v = scale * tanhf(v) + base;
+    out[idx] = v;
+}
+
+
+// ====================================================================================== column-split critic update
+using rpo_cart_dev::CartConsts;
+
+struct CartRow { static constexpr int ROW = RPO_CART_ROW, CH = 6, S = 6, A_OFF = 6, NS_OFF = 8, R_OFF = 14; };
+struct PendRow { static constexpr int ROW = RPO_PEND_ROW, CH = 4, S = 5, A_OFF = 5, NS_OFF = 7, R_OFF = 12; };
+
+// Device view of rpo_split_update (host network descriptors resolved to device pointer sets).
+struct SplitArgs {
+    Mlp actor, actor_target, critic[2], critic_target[2];
+    MlpGrad critic_grad[2], actor_grad;
+    int twin, B;
+    const float* rows; long long cap_steps; int n_envs;
+    float* batch_out; long long* idx_out; const long long* idx_in;
+    uint64_t sample_seed; uint32_t sample_salt;
+    const float* eps_in; uint64_t noise_seed; uint32_t noise_id_base, noise_salt;
+    const long long* ctrl;
+    float scale, base, box_lo, box_hi;
+    int max_steps; float corr_lr, corr_eps, corr_momentum;
+    float alpha, gamma, eps_start, eps_end, eps_decay;
+    float *part_pi, *part_q[2], *part_qn[2];
+    float *x0[2], *h1[2], *x0_a, *h1_a;
+    float *logp, *next_actions; int* proj_iters;
+    float *dq[2], *loss_partial, *dx0[2], *dx0_a, *gradmax;
+    const float* nu; float* nu_grad;
+    float *ap_det, *noise_out, *raw, *actions, *g_act, *lag_partial, *lag_out, *da_part, *dout;
+    int shared_embedding;
+};
+
+// ReplayBuffer.sample (buffer.py:31-34): counter-based draw + gather of the tile's 16 rows (same draw in every workgroup
+// of the tile; `publish` stores the gathered rows / indices once).
+template <class L>
+__device__ __forceinline__ void ns_sample(const SplitArgs& p, float4* tile, int row0, long long t, bool publish) {
+    const int tid = threadIdx.x, B = p.B;
+    if (tid < kRows * L::CH) {
+        const int r = tid / L::CH, ch = tid - r * L::CH;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (row0 + r < B) {
+            long long row;
+            if (p.idx_in) {
+                row = p.idx_in[row0 + r];
+            } else {
+                const unsigned long long n_valid = (unsigned long long)((t < p.cap_steps ? t : p.cap_steps) * (long long)p.n_envs);
+                const rpo_u4 u = rpo_philox(p.sample_seed, (uint32_t)(row0 + r), (uint32_t)t + p.sample_salt, RPO_STREAM_SAMPLE,
+                                            (uint32_t)p.ctrl[RPO_CTRL_UPDATES]);
+                row = (long long)__umul64hi(((unsigned long long)u.x << 32) | u.y, n_valid);
+            }
+            v = reinterpret_cast<const float4*>(p.rows)[row * L::CH + ch];
+            if (publish) {
+                reinterpret_cast<float4*>(p.batch_out)[(size_t)(row0 + r) * L::CH + ch] = v;
+                if (p.idx_out && ch == 0) p.idx_out[row0 + r] = row;
+            }
+        }
+        tile[tid] = v;
+    }
+}
+
+// The tile's 16 gathered rows from batch_out (written by an earlier launch)
+template <class L>
+__device__ __forceinline__ void ns_load_tile(const SplitArgs& p, float4* tile, int row0) {
+    const int tid = threadIdx.x;
+    if (tid < kRows * L::CH) {
+        const int r = tid / L::CH;
+        tile[tid] = row0 + r < p.B ? reinterpret_cast<const float4*>(p.batch_out)[(size_t)row0 * L::CH + tid]
+                                   : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+
+template <class L>
+__device__ __forceinline__ void ns_stage(NsLds<128>& lds, const float* tf, bool next, bool with_action) {
+    const int tid = threadIdx.x;
+    if (tid < kRows * 8) {
+        const int r = tid >> 3, i = tid & 7;
+        lds.in_s[tid] = i < L::S ? tf[r * L::ROW + (next ? L::NS_OFF : 0) + i] : 0.0f;
+        lds.in_a[tid] = (with_action && i < 2) ? tf[r * L::ROW + L::A_OFF + i] : 0.0f;
+    }
+}
+
+// ---- fwd_a: grid (row tiles, 8 column groups, roles).  Role 0 = the policy on s' (pi_targ for RPODDPG, pi for RPOSAC),
+//      roles 1.. = the critics on the stored (s, a), pre-activations saved for the backward pass.
+template <class L>
+__global__ __launch_bounds__(kNsThreads) void split_critic_fwd_a_kernel(SplitArgs p) {
+    __shared__ NsLds<128> lds;
+    __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
+    const int row0 = blockIdx.x * kRows, g = blockIdx.y, role = blockIdx.z;
+    const Mlp& net = role == 0 ? (p.twin ? p.actor : p.actor_target) : p.critic[role - 1];
+    NsWeights<128> w;
+    ns_load_weights<128, 256>(net, g, w);
+    const long long t = p.ctrl[RPO_CTRL_T];
+    ns_sample<L>(p, tile, row0, t, role == 0 && g == 0);
+    __syncthreads();
+    ns_stage<L>(lds, reinterpret_cast<const float*>(tile), role == 0, role != 0);
+    if (role == 0) ns_hidden<128, 256>(net, w, lds, g, row0, p.B, p.part_pi, nullptr, nullptr);
+    else ns_hidden<128, 256>(net, w, lds, g, row0, p.B, p.part_q[role - 1], p.x0[role - 1], p.h1[role - 1]);
+}
+
+// The policy head of row i from the slab partials: tanh box (RPODDPG, model/policy.py:30-31) or rsample of the squashed
+// Gaussian + clip (RPOSAC, model/policy.py:53-66, agent/sac_pa.py:111; the draw of the update step)
+__device__ __forceinline__ float ns_policy_head(const SplitArgs& p, int i, long long t, float* logp) {
+    if (!p.twin) {
+        const float v = ns_head(p.part_pi, p.B, i, 0, p.actor_target.b1[0]);
+        return p.scale * tanhf(v) + p.base;
+    }
+    const float rm = ns_head(p.part_pi, p.B, i, 0, p.actor.b1[0]);
+    const float rl = ns_head(p.part_pi, p.B, i, 1, p.actor.b1b[0]);
+    float e;
+    if (p.eps_in) {
+        e = p.eps_in[i];
+    } else {                                                   // == rpo_philox_normal(id_base, salt, RPO_STREAM_POLICY)
+        const rpo_u4 u = rpo_philox(p.noise_seed, p.noise_id_base + (uint32_t)i, (uint32_t)t + p.noise_salt, RPO_STREAM_POLICY,
+                                    (uint32_t)p.ctrl[RPO_CTRL_UPDATES]);
+        e = rpo_normal(u.x, u.y);
+    }
+    return rpo_head_dev::gauss_head_row(rm, rl, e, p.scale, p.base, p.box_lo, p.box_hi, 0, logp);
+}
+
+// ---- fwd_b: grid (row tiles, 8 column groups, target critics).  PROJ = 1 (CartSafe): head -> Complete + Proj per row
+//      (== the reference's batched call for this env) in the prologue; PROJ = 0 (SpringPendulum): the projected actions
+//      come from rpo_split_pend_head_project.
+template <class L, int PROJ>
+__global__ __launch_bounds__(kNsThreads) void split_critic_fwd_b_kernel(SplitArgs p, CartConsts c) {
+    __shared__ NsLds<128> lds;
+    __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
+    const int row0 = blockIdx.x * kRows, g = blockIdx.y, k = blockIdx.z, tid = threadIdx.x;
+    const Mlp& net = p.critic_target[k];
+    NsWeights<128> w;
+    ns_load_weights<128, 256>(net, g, w);
+    ns_load_tile<L>(p, tile, row0);
+    __syncthreads();
+    ns_stage<L>(lds, reinterpret_cast<const float*>(tile), true, false);
+    __syncthreads();                                             // (ns_stage zeroed in_a: order it before the writes below)
+    if (tid < kRows) {
+        const int i = row0 + tid;
+        float2 act = make_float2(0.0f, 0.0f);
+        if (i < p.B) {
+            if (PROJ) {
+                const long long t = p.ctrl[RPO_CTRL_T];
+                float logp = 0.0f;
+                const float ap = ns_policy_head(p, i, t, &logp);
+                rpo_cart_dev::ActArgs a{};
+                a.noise_mode = RPO_NOISE_NONE;
+                a.max_steps = p.max_steps; a.corr_lr = p.corr_lr; a.corr_eps = p.corr_eps; a.corr_momentum = p.corr_momentum;
+                a.box_lo = p.box_lo; a.box_hi = p.box_hi;
+                int it;
+                act = rpo_cart_dev::cart_explore_project(a, c, i, ap, 0.0f, t, it);
+                if (p.twin && g == 0 && k == 0) p.logp[i] = logp;
+            } else {
+                act = reinterpret_cast<const float2*>(p.next_actions)[i];
+            }
+        }
+        lds.in_a[tid * 8] = act.x;
+        lds.in_a[tid * 8 + 1] = act.y;
+    }
+    ns_hidden<128, 256>(net, w, lds, g, row0, p.B, p.part_qn[k], nullptr, nullptr);
+}
+
+// ---- SpringPendulum: head of the policy + the reference's batch-coupled projection (pendulum.py:337-339), one workgroup
+__global__ __launch_bounds__(1024) void split_pend_head_project_kernel(SplitArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int i = threadIdx.x;
+    float ap = 0.0f;
+    if (i < p.B) {
+        float logp = 0.0f;
+        ap = ns_policy_head(p, i, p.ctrl[RPO_CTRL_T], &logp);
+        if (p.twin) p.logp[i] = logp;
+    }
+    rpo_pend_dev::project_batchref_body(p.B, i < p.B ? p.batch_out + (size_t)i * RPO_PEND_ROW + PendRow::NS_OFF : nullptr, ap,
+                                        p.next_actions, p.proj_iters, p.max_steps, p.corr_lr, p.corr_eps, p.corr_momentum, lds);
+}
+
+// ---- TD target + Huber for row i of critic k from the slab partials (rpo_ddpg.py:331-335, rpo_sac.py:346-353)
+template <class L>
+__device__ __forceinline__ float ns_td_row(const SplitArgs& p, int k, int i, float* hub) {
+    const float q = ns_head(p.part_q[k], p.B, i, 0, p.critic[k].b1[0]);
+    const float qn1 = ns_head(p.part_qn[0], p.B, i, 0, p.critic_target[0].b1[0]);
+    const float qn2 = p.twin ? ns_head(p.part_qn[1], p.B, i, 0, p.critic_target[1].b1[0]) : 0.0f;
+    const float qn = rpo_head_dev::td_next_value(qn1, qn2, p.twin, p.twin ? p.logp[i] : 0.0f, p.twin, p.alpha);
+    const float* row = p.batch_out + (size_t)i * L::ROW;
+    const float y = rpo_head_dev::td_target(row[L::R_OFF], row[L::R_OFF + 1], p.gamma, qn);
+    return rpo_head_dev::td_huber_row(q, y, 1.0f / (float)p.B, hub);
+}
+
+constexpr int kBwdMaxB = 1024;
+
+// ---- bwd_a: blocks [0, K*T*8): dx0 column groups (critic k, row tile, 16 first-layer columns);
+//             then K*32: dW0 tiles (16 hidden rows x 64 input columns, K = batch over the 4 waves);
+//             then K*4: hidden-layer vectors db0 / dW1 / db1.
+//      dh = dLoss/dQ * W1 * 1[h1 > 0] is formed on the fly from the TD prologue, never stored: nothing in this launch
+//      waits for another workgroup.
+template <class L>
+__global__ __launch_bounds__(kThreads) void split_critic_bwd_a_kernel(SplitArgs p) {
+    constexpr int EIN = 128, H = 256, LDH = H + 4;
+    __shared__ __attribute__((aligned(16))) float smem[4 * 16 * 64 + kBwdMaxB + 256];   // 21 KB: the largest of the three roles
+    const int K = p.twin ? 2 : 1, T = (p.B + kRows - 1) / kRows, B = p.B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    int b = blockIdx.x;
+    float gmax = 0.0f;
+    if (b < K * T * kNsGroups) {
+        // ------------------------------------------------------------------------------------------- dx0 column group
+        const int k = b / (T * kNsGroups), rem = b - k * T * kNsGroups, tile = rem / kNsGroups, g = rem - tile * kNsGroups;
+        const int row0 = tile * kRows;
+        const Mlp& net = p.critic[k];
+        float* dh_s = smem;                                       // [16][LDH]
+        float* dq_s = smem + kRows * LDH;                         // [16]
+        float* wpart = dq_s + 16;                                 // [4][16][16]
+        // operands that depend on nothing are requested first: this wave's W0 column slice and the tile's h1 column
+        const int jw = wave * (H / 4), e = g * 16 + li;
+        float wv[H / 16], hv[kRows];
+#pragma unroll
+        for (int ks = 0; ks < H / 16; ++ks) wv[ks] = net.W0[(size_t)(jw + ks * 4 + lg) * EIN + e];
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) hv[r] = row0 + r < B ? p.h1[k][(size_t)(row0 + r) * H + tid] : 0.0f;
+        const float w1a = net.W1[tid];                            // 256 threads = 256 hidden columns
+        if (tid < 64) {
+            float dq = 0.0f, hub = 0.0f;
+            if (tid < kRows && row0 + tid < B) {
+                dq = ns_td_row<L>(p, k, row0 + tid, &hub);
+                if (g == 0) p.dq[k][row0 + tid] = dq;
+            }
+            if (tid < kRows) dq_s[tid] = dq;
+            const float sum = rpo_wave_sum(hub);
+            if (tid == 0 && g == 0) p.loss_partial[k * T + tile] = sum;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) dh_s[r * LDH + tid] = (hv[r] > 0.0f) ? dq_s[r] * w1a : 0.0f;
+        __syncthreads();
+        f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int ks = 0; ks < H / 16; ++ks) acc = mfma4(dh_s[li * LDH + jw + ks * 4 + lg], wv[ks], acc);
+        // acc[i] = partial dx0[row = 4 lg + i][e = 16 g + li] of this wave's quarter of the hidden columns
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wpart[(wave * 16 + lg * 4 + i) * 16 + li] = acc[i];
+        __syncthreads();
+        {
+            const int r = tid >> 4, ee = tid & 15;
+            float v = wpart[(0 * 16 + r) * 16 + ee];               // waves added in the order of mlp_bwd_rows_body
+            v = wpart[(1 * 16 + r) * 16 + ee] + v;
+            v = wpart[(2 * 16 + r) * 16 + ee] + v;
+            v = wpart[(3 * 16 + r) * 16 + ee] + v;
+            if (row0 + r < B) {
+                const size_t o = (size_t)(row0 + r) * EIN + g * 16 + ee;
+                p.dx0[k][o] = p.x0[k][o] > 0.0f ? v : 0.0f;
+            }
+        }
+        return;
+    }
+    b -= K * T * kNsGroups;
+    // every remaining workgroup needs dLoss/dQ of the whole batch
+    const bool is_w0 = b < K * 32;
+    const int k = is_w0 ? b / 32 : (b - K * 32) / 4;
+    const Mlp& net = p.critic[k];
+    const MlpGrad& gr = p.critic_grad[k];
+    float* dq_s = smem + 4 * 16 * 64;
+    for (int i = tid; i < B; i += kThreads) {
+        float hub;
+        dq_s[i] = ns_td_row<L>(p, k, i, &hub);
+    }
+    __syncthreads();
+    if (is_w0) {
+        // ------------------------------------------------------------------------------------------------ dW0 tile
+        const int blk = b - k * 32;
+        float (*tile)[16 * 64] = reinterpret_cast<float (*)[16 * 64]>(smem);
+        const int jt = blk / (EIN / 64), et = blk - jt * (EIN / 64);
+        const int j = jt * 16 + li, e0 = et * 64 + li * 4;
+        const float w1j = net.W1[j];
+        f32x4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const int nk = (B + 3) / 4;
+        const int ks_lo = (nk * wave) / 4, ks_hi = (nk * (wave + 1)) / 4;
+        const int last = B - 1;
+        int ks = ks_lo;
+        for (; ks + 4 <= ks_hi; ks += 4) {
+            float av[4];
+            float4 bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int bb = (ks + u) * 4 + lg;
+                const int bc = bb < last ? bb : last;
+                const float h = p.h1[k][(size_t)bc * H + j];
+                av[u] = (h > 0.0f) ? dq_s[bc] * w1j : 0.0f;
+                bv[u] = *reinterpret_cast<const float4*>(&p.x0[k][(size_t)bc * EIN + e0]);
+                if (bb > last) av[u] = 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[0] = mfma4(av[u], fmaxf(bv[u].x, 0.0f), acc[0]);
+                acc[1] = mfma4(av[u], fmaxf(bv[u].y, 0.0f), acc[1]);
+                acc[2] = mfma4(av[u], fmaxf(bv[u].z, 0.0f), acc[2]);
+                acc[3] = mfma4(av[u], fmaxf(bv[u].w, 0.0f), acc[3]);
+            }
+        }
+        for (; ks < ks_hi; ++ks) {
+            const int bb = ks * 4 + lg;
+            const int bc = bb < last ? bb : last;
+            const float h = p.h1[k][(size_t)bc * H + j];
+            float av = (h > 0.0f) ? dq_s[bc] * w1j : 0.0f;
+            const float4 b4 = *reinterpret_cast<const float4*>(&p.x0[k][(size_t)bc * EIN + e0]);
+            if (bb > last) av = 0.0f;
+            acc[0] = mfma4(av, fmaxf(b4.x, 0.0f), acc[0]);
+            acc[1] = mfma4(av, fmaxf(b4.y, 0.0f), acc[1]);
+            acc[2] = mfma4(av, fmaxf(b4.z, 0.0f), acc[2]);
+            acc[3] = mfma4(av, fmaxf(b4.w, 0.0f), acc[3]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(&tile[wave][(lg * 4 + i) * 64 + li * 4]) =
+                make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+        __syncthreads();
+        {
+            const int r = tid >> 4, c4 = (tid & 15) * 4;
+            const float4 t0 = *reinterpret_cast<const float4*>(&tile[0][r * 64 + c4]);
+            const float4 t1 = *reinterpret_cast<const float4*>(&tile[1][r * 64 + c4]);
+            const float4 t2 = *reinterpret_cast<const float4*>(&tile[2][r * 64 + c4]);
+            const float4 t3 = *reinterpret_cast<const float4*>(&tile[3][r * 64 + c4]);
+            float4* dst = reinterpret_cast<float4*>(&gr.W0[(size_t)(jt * 16 + r) * EIN + et * 64 + c4]);
+            float4 cur = *dst;
+            cur.x += ((t0.x + t1.x) + t2.x) + t3.x;
+            cur.y += ((t0.y + t1.y) + t2.y) + t3.y;
+            cur.z += ((t0.z + t1.z) + t2.z) + t3.z;
+            cur.w += ((t0.w + t1.w) + t2.w) + t3.w;
+            *dst = cur;
+            gmax = fmaxf(fmaxf(fabsf(cur.x), fabsf(cur.y)), fmaxf(fabsf(cur.z), fabsf(cur.w)));
+        }
+    } else {
+        // ---------------------------------------------------------- hidden-layer vectors: db0[j], dW1[j], db1 (block 0)
+        const int rb = (b - K * 32) - k * 4;
+        float (*partial)[3][64] = reinterpret_cast<float (*)[3][64]>(smem);
+        const int o = tid & 63, part = tid >> 6;
+        const int b_lo = (int)(((long long)B * part) / 4), b_hi = (int)(((long long)B * (part + 1)) / 4);
+        const int j = rb * 64 + o;
+        const float w1j = net.W1[j];
+        float gb0 = 0.0f, gw1a = 0.0f;
+        int bb = b_lo;
+        for (; bb + 8 <= b_hi; bb += 8) {
+            float h[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) h[u] = p.h1[k][(size_t)(bb + u) * H + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                gb0 += (h[u] > 0.0f) ? dq_s[bb + u] * w1j : 0.0f;
+                gw1a = fmaf(dq_s[bb + u], fmaxf(h[u], 0.0f), gw1a);
+            }
+        }
+        for (; bb < b_hi; ++bb) {
+            const float h = p.h1[k][(size_t)bb * H + j];
+            gb0 += (h > 0.0f) ? dq_s[bb] * w1j : 0.0f;
+            gw1a = fmaf(dq_s[bb], fmaxf(h, 0.0f), gw1a);
+        }
+        partial[part][0][o] = gb0; partial[part][1][o] = gw1a;
+        __syncthreads();
+        if (part == 0) {
+            const float nb0 = gr.b0[j] + (((partial[0][0][o] + partial[1][0][o]) + partial[2][0][o]) + partial[3][0][o]);
+            const float nw1 = gr.W1[j] + (((partial[0][1][o] + partial[1][1][o]) + partial[2][1][o]) + partial[3][1][o]);
+            gr.b0[j] = nb0;
+            gr.W1[j] = nw1;
+            gmax = fmaxf(fabsf(nb0), fabsf(nw1));
+        }
+        if (rb == 0) {
+            __syncthreads();
+            float s0 = 0.0f;
+            for (int b2 = tid; b2 < B; b2 += kThreads) s0 += dq_s[b2];
+            s0 = rpo_wave_sum(s0);
+            if (o == 0) partial[part][0][0] = s0;
+            __syncthreads();
+            if (tid == 0) {
+                const float nb1 = gr.b1[0] + (((partial[0][0][0] + partial[1][0][0]) + partial[2][0][0]) + partial[3][0][0]);
+                gr.b1[0] = nb1;
+                gmax = fmaxf(gmax, fabsf(nb1));
+            }
+        }
+    }
+    gradmax_flush(p.gradmax, gmax);
+}
+
+// ---- bwd_b: first-layer gradients dWs / dbs / dWa / dba of critic k = blockIdx.y from dx0 (batch reduction, one owner per
+//      output, fixed order): the first-layer branch of mlp_bwd_weights_body.
+template <class L>
+__global__ __launch_bounds__(kThreads) void split_critic_bwd_b_kernel(SplitArgs p) {
+    const int k = blockIdx.y;
+    BwdArgs a{};
+    a.net = p.critic[k];
+    a.g = p.critic_grad[k];
+    a.n = p.B;
+    a.s = p.batch_out; a.s_stride = L::ROW;
+    a.a = p.batch_out + L::A_OFF; a.a_stride = L::ROW;
+    a.dx0 = p.dx0[k];
+    a.param_grads = 1;
+    a.first_layer_state_only = 0;
+    gradmax_flush(p.gradmax, mlp_bwd_first_layer<128>(a, blockIdx.x));
+}
+
+}  // namespace
+
+extern "C" {
+
+int rpo_mlp_split_supported(const rpo_mlp* net) { return net && split_ok(to_dev(net)) ? 1 : 0; }
+
+int rpo_mlp_forward_split(int k, const rpo_mlp* const* nets, int n, const float* const* s, const int* s_stride,
+                          const float* const* a, const int* a_stride, float* const* part, float* const* x0_save,
+                          float* const* h1_save, void* stream) {
+    if (k < 1 || k > 4 || n <= 0 || !nets || !s || !part) return RPO_ERR_ARG;
+    SplitFwdArgs4 all{};
+    for (int i = 0; i < k; ++i) {
+        if (!nets[i] || !s[i] || !part[i]) return RPO_ERR_NULL;
+        const Mlp m = to_dev(nets[i]);
+        if (!split_ok(m) || (m.A > 0 && (!a || !a[i]))) return RPO_ERR_ARG;
+        all.net[i] = SplitFwdArgs{m, n, s[i], s_stride[i], m.A > 0 ? a[i] : nullptr, m.A > 0 ? a_stride[i] : 0, part[i],
+                                  x0_save ? x0_save[i] : nullptr, h1_save ? h1_save[i] : nullptr};
+    }
+    hipLaunchKernelGGL(mlp_forward_split_kernel, dim3((n + kRows - 1) / kRows, kNsGroups, k), dim3(kNsThreads), 0,
+                       (hipStream_t)stream, all);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_mlp_split_head(const rpo_mlp* net, int n, const float* part, float* out, int out_mode, float scale, float base,
+                       void* stream) {
+    if (!net || !part || !out || n <= 0) return RPO_ERR_NULL;
+    const Mlp m = to_dev(net);
+    if (!split_ok(m)) return RPO_ERR_ARG;
+    hipLaunchKernelGGL(mlp_split_head_kernel, dim3((n * m.n_out + RPO_BLOCK - 1) / RPO_BLOCK), dim3(RPO_BLOCK), 0,
+                       (hipStream_t)stream, m, n, part, out, out_mode, scale, base);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+// ======================================================================================== column-split policy step
+// Env policies of the actor loss: Complete, the Lagrangian row and the backward of Complete (rpo_ddpg.py:307-324).
+struct CartPol {
+    typedef CartRow L;
+    static constexpr int NI = 6;
+    __device__ static __forceinline__ float2 complete(const CartConsts& c, const float* obs, int i, float ap, long long t) {
+        rpo_cart_dev::ActArgs a{};
+        a.noise_mode = RPO_NOISE_NONE; a.max_steps = 0;
+        int k;
+        return rpo_cart_dev::cart_explore_project(a, c, i, ap, 0.0f, t, k);
+    }
+    __device__ static __forceinline__ float lagr(const CartConsts& c, float a0, float a1, const float* nu_p, float scale,
+                                                 float (&dist)[6], float2& g) {
+        float nu[6], loss, g0, g1;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) nu[j] = nu_p[j];
+        rpo_cart_dev::lagrangian_row(c, a0, a1, nu, loss, dist, g0, g1);
+        g = make_float2(scale * g0, scale * g1);
+        return loss;
+    }
+    __device__ static __forceinline__ float complete_bwd(const CartConsts& c, const float* obs, float g0, float g1) {
+        return rpo_cart_dev::complete_bwd_row(c, g0, g1);
+    }
+};
+struct PendPol {
+    typedef PendRow L;
+    static constexpr int NI = 1;
+    __device__ static __forceinline__ float2 complete(const CartConsts&, const float* obs, int i, float ap, long long t) {
+        rpo_pend_dev::ActArgs a{};
+        a.noise_mode = RPO_NOISE_NONE; a.max_steps = 0;
+        int k;
+        return rpo_pend_dev::pend_explore_project(a, obs, i, ap, 0.0f, t, k);
+    }
+    __device__ static __forceinline__ float lagr(const CartConsts&, float a0, float a1, const float* nu_p, float scale,
+                                                 float (&dist)[6], float2& g) {
+#pragma unroll
+        for (int j = 1; j < 6; ++j) dist[j] = 0.0f;
+        return rpo_pend_dev::lagrangian_row(a0, a1, nu_p[0], scale, dist[0], g.x, g.y);
+    }
+    __device__ static __forceinline__ float complete_bwd(const CartConsts&, const float* obs, float g0, float g1) {
+        return rpo_pend_dev::complete_bwd_row(obs, g0, g1);
+    }
+};
+
+// take_action's exploration (agent/ddpg_pa.py:108-110): the arithmetic of cart/pend_explore_project's RPO_NOISE_EXPLICIT
+__device__ __forceinline__ float explore_clip(float ap_det, float eps_t, float e, float lo, float hi) {
+    RPO_FP_STRICT
+    return fminf(fmaxf(ap_det + eps_t * e, lo), hi);
+}
+
+// ---- pol_a: pi hidden slabs on the batch states, pre-activations saved.  grid (row tiles, 8)
+template <class L>
+__global__ __launch_bounds__(kNsThreads) void split_policy_a_kernel(SplitArgs p) {
+    __shared__ NsLds<128> lds;
+    __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
+    const int row0 = blockIdx.x * kRows, g = blockIdx.y;
+    NsWeights<128> w;
+    ns_load_weights<128, 256>(p.actor, g, w);
+    ns_load_tile<L>(p, tile, row0);
+    __syncthreads();
+    ns_stage<L>(lds, reinterpret_cast<const float*>(tile), false, false);
+    ns_hidden<128, 256>(p.actor, w, lds, g, row0, p.B, p.part_pi, p.x0_a, p.h1_a);
+}
+
+// ---- pol_b: head -> exploration noise + clip (RPODDPG) / rsample + clip + log pi (RPOSAC) -> Complete -> Lagrangian row
+//      terms -> Q_k hidden slabs on (s, a_pi), pre-activations saved.  grid (row tiles, 8, critics); workgroup
+//      (tile, 0, 0) publishes the per-row outputs and the tile's Lagrangian partial sums.
+template <class ENV>
+__global__ __launch_bounds__(kNsThreads) void split_policy_b_kernel(SplitArgs p, CartConsts c) {
+    typedef typename ENV::L L;
+    __shared__ NsLds<128> lds;
+    __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
+    const int row0 = blockIdx.x * kRows, g = blockIdx.y, k = blockIdx.z, tid = threadIdx.x, B = p.B;
+    const Mlp& net = p.critic[k];
+    NsWeights<128> w;
+    ns_load_weights<128, 256>(net, g, w);
+    ns_load_tile<L>(p, tile, row0);
+    __syncthreads();
+    ns_stage<L>(lds, reinterpret_cast<const float*>(tile), false, false);
+    __syncthreads();
+    const bool writer = g == 0 && k == 0;
+    float vals[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (tid < kRows) {
+        const int i = row0 + tid;
+        float2 act = make_float2(0.0f, 0.0f);
+        if (i < B) {
+            const long long t = p.ctrl[RPO_CTRL_T];
+            const float inv_b = 1.0f / (float)B;
+            float e;
+            if (p.eps_in) {
+                e = p.eps_in[i];
+            } else {
+                const rpo_u4 u = rpo_philox(p.noise_seed, p.noise_id_base + (uint32_t)i, (uint32_t)t + p.noise_salt,
+                                            RPO_STREAM_POLICY, (uint32_t)p.ctrl[RPO_CTRL_UPDATES]);
+                e = rpo_normal(u.x, u.y);
+            }
+            float ap, logp = 0.0f, rm = 0.0f, rl = 0.0f, ap_det = 0.0f;
+            if (p.twin) {
+                rm = ns_head(p.part_pi, B, i, 0, p.actor.b1[0]);
+                rl = ns_head(p.part_pi, B, i, 1, p.actor.b1b[0]);
+                ap = rpo_head_dev::gauss_head_row(rm, rl, e, p.scale, p.base, p.box_lo, p.box_hi, 0, &logp);
+            } else {
+                const float v = ns_head(p.part_pi, B, i, 0, p.actor.b1[0]);
+                ap_det = p.scale * tanhf(v) + p.base;
+                const float eps_t = fmaxf(p.eps_end, p.eps_start - p.eps_decay * (float)t);
+                ap = explore_clip(ap_det, eps_t, e, p.box_lo, p.box_hi);
+            }
+            act = ENV::complete(c, lds.in_s + tid * 8, i, ap, t);
+            if (writer) {
+                if (p.twin) {
+                    reinterpret_cast<float2*>(p.raw)[i] = make_float2(rm, rl);
+                    p.logp[i] = logp;
+                } else {
+                    p.ap_det[i] = ap_det;
+                }
+                p.noise_out[i] = e;
+                reinterpret_cast<float2*>(p.actions)[i] = act;
+                float dist[6];
+                float2 gg;
+                vals[0] = ENV::lagr(c, act.x, act.y, p.nu, inv_b, dist, gg);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) vals[1 + j] = dist[j];
+                reinterpret_cast<float2*>(p.g_act)[i] = gg;
+            }
+        }
+        lds.in_a[tid * 8] = act.x;
+        lds.in_a[tid * 8 + 1] = act.y;
+    }
+    if (writer && tid < 64) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const float r = rpo_wave_sum(vals[q]);
+            if (tid == 0) p.lag_partial[blockIdx.x * 8 + q] = r;
+        }
+    }
+    ns_hidden<128, 256>(net, w, lds, g, row0, B, p.part_q[k], p.x0[k], p.h1[k]);
+}
+
+// dLoss/dQ_k of row i in the actor loss: -1/B (RPODDPG, rpo_ddpg.py:317) or the split of d(-min(Q1, Q2)) with ties
+// shared (torch.min's backward, rpo_sac.py:331); *term = the row's share of column 7 of the loss partials
+// (Q for RPODDPG, alpha log pi - min Q for RPOSAC).
+__device__ __forceinline__ float ns_policy_dq(const SplitArgs& p, int k, int i, float* term) {
+    const float inv_b = 1.0f / (float)p.B;
+    const float q1 = ns_head(p.part_q[0], p.B, i, 0, p.critic[0].b1[0]);
+    if (!p.twin) {
+        *term = q1;
+        return -inv_b;
+    }
+    const float q2 = ns_head(p.part_q[1], p.B, i, 0, p.critic[1].b1[0]);
+    const float w1 = (q1 < q2 ? 1.0f : 0.0f) + (q1 == q2 ? 0.5f : 0.0f);
+    *term = p.alpha * p.logp[i] - fminf(q1, q2);
+    return k == 0 ? w1 * -inv_b : (1.0f - w1) * -inv_b;
+}
+
+// ---- pol_c: the critics' rows pass inside the actor loss: dx0 column groups (no parameter gradients of their own) and,
+//      per group, its share of d(-Q)/d action = dx0 Wa.  blocks (critic, row tile, column group), 256 threads.
+__global__ __launch_bounds__(kThreads) void split_policy_c_kernel(SplitArgs p) {
+    constexpr int EIN = 128, H = 256, LDH = H + 4;
+    __shared__ __attribute__((aligned(16))) float dh_s[kRows * LDH];
+    __shared__ float dq_s[kRows];
+    __shared__ float wpart[4 * 16 * 16];
+    const int T = (p.B + kRows - 1) / kRows, B = p.B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int b = blockIdx.x;
+    const int k = b / (T * kNsGroups), rem = b - k * T * kNsGroups, tile = rem / kNsGroups, g = rem - tile * kNsGroups;
+    const int row0 = tile * kRows;
+    const Mlp& net = p.critic[k];
+    const int jw = wave * (H / 4), e = g * 16 + li;
+    float wv[H / 16], hv[kRows];
+#pragma unroll
+    for (int ks = 0; ks < H / 16; ++ks) wv[ks] = net.W0[(size_t)(jw + ks * 4 + lg) * EIN + e];
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) hv[r] = row0 + r < B ? p.h1[k][(size_t)(row0 + r) * H + tid] : 0.0f;
+    const float w1a = net.W1[tid];
+    if (tid < 64) {
+        float dq = 0.0f, term = 0.0f;
+        if (tid < kRows && row0 + tid < B) dq = ns_policy_dq(p, k, row0 + tid, &term);
+        if (tid < kRows) dq_s[tid] = dq;
+        const float sum = rpo_wave_sum(term);
+        if (tid == 0 && g == 0 && k == 0) p.lag_partial[tile * 8 + 7] = sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) dh_s[r * LDH + tid] = (hv[r] > 0.0f) ? dq_s[r] * w1a : 0.0f;
+    __syncthreads();
+    f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int ks = 0; ks < H / 16; ++ks) acc = mfma4(dh_s[li * LDH + jw + ks * 4 + lg], wv[ks], acc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wpart[(wave * 16 + lg * 4 + i) * 16 + li] = acc[i];
+    __syncthreads();
+    {
+        const int r = tid >> 4, ee = tid & 15;
+        float v = wpart[(0 * 16 + r) * 16 + ee];
+        v = wpart[(1 * 16 + r) * 16 + ee] + v;
+        v = wpart[(2 * 16 + r) * 16 + ee] + v;
+        v = wpart[(3 * 16 + r) * 16 + ee] + v;
+        const bool live = row0 + r < B;
+        const size_t o = (size_t)(row0 + r) * EIN + g * 16 + ee;
+        v = (live && p.x0[k][o] > 0.0f) ? v : 0.0f;
+        if (live) p.dx0[k][o] = v;
+        // this group's share of d/d action: sum over its 16 columns (fixed butterfly), 2 action components
+        const int col = g * 16 + ee;
+        float d0 = v * net.Wa[col * 2], d1 = v * net.Wa[col * 2 + 1];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { d0 += __shfl_xor(d0, off, 64); d1 += __shfl_xor(d1, off, 64); }
+        if (ee == 0 && live)
+            reinterpret_cast<float2*>(p.da_part)[((size_t)k * kNsGroups + g) * B + row0 + r] = make_float2(d0, d1);
+    }
+}
+
+// d loss / d (actor head outputs) of row i: sum of the critics' d/d action shares + the Lagrangian's -> autograd through
+// Complete -> head backward (rpo_ddpg.py:307-324, rpo_sac.py:321-339)
+template <class ENV>
+__device__ __forceinline__ float2 ns_policy_dout(const SplitArgs& p, const CartConsts& c, int i) {
+    typedef typename ENV::L L;
+    const int K = p.twin ? 2 : 1;
+    float da0 = 0.0f, da1 = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int g = 0; g < kNsGroups; ++g) {
+            const float2 d = reinterpret_cast<const float2*>(p.da_part)[((size_t)k * kNsGroups + g) * p.B + i];
+            s0 += d.x; s1 += d.y;
+        }
+        da0 = k == 0 ? s0 : da0 + s0;
+        da1 = k == 0 ? s1 : da1 + s1;
+    }
+    const float2 gg = reinterpret_cast<const float2*>(p.g_act)[i];
+    da0 += gg.x; da1 += gg.y;
+    const float dap = ENV::complete_bwd(c, p.batch_out + (size_t)i * L::ROW, da0, da1);
+    if (p.twin) {
+        const float2 r = reinterpret_cast<const float2*>(p.raw)[i];
+        return rpo_head_dev::gauss_head_bwd_row(r.x, r.y, p.noise_out[i], dap, p.alpha / (float)p.B, p.scale, p.base, p.box_lo,
+                                                p.box_hi);
+    }
+    const float t = (float)p.ctrl[RPO_CTRL_T];
+    const float eps_t = fmaxf(p.eps_end, p.eps_start - p.eps_decay * t);
+    return make_float2(rpo_head_dev::tanh_box_bwd_row(dap, p.ap_det[i], p.noise_out[i], 1, eps_t, p.box_lo, p.box_hi, p.scale,
+                                                      p.base), 0.0f);
+}
+
+// ---- pol_d: actor backward.  blocks [0, T*8): dx0 column groups; then 32 dW0 tiles; then 4 hidden-vector blocks.
+template <class ENV>
+__global__ __launch_bounds__(kThreads) void split_policy_d_kernel(SplitArgs p, CartConsts c) {
+    constexpr int EIN = 128, H = 256, LDH = H + 4;
+    __shared__ __attribute__((aligned(16))) float smem[4 * 16 * 64 + 2 * kBwdMaxB + 256];
+    const int T = (p.B + kRows - 1) / kRows, B = p.B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const Mlp& net = p.actor;
+    const MlpGrad& gr = p.actor_grad;
+    int b = blockIdx.x;
+    float gmax = 0.0f;
+    if (b < T * kNsGroups) {
+        const int tile = b / kNsGroups, g = b - tile * kNsGroups, row0 = tile * kRows;
+        float* dh_s = smem;
+        float* do_s = smem + kRows * LDH;                          // [16][2]
+        float* wpart = do_s + 32;
+        const int jw = wave * (H / 4), e = g * 16 + li;
+        float wv[H / 16], hv[kRows];
+#pragma unroll
+        for (int ks = 0; ks < H / 16; ++ks) wv[ks] = net.W0[(size_t)(jw + ks * 4 + lg) * EIN + e];
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) hv[r] = row0 + r < B ? p.h1_a[(size_t)(row0 + r) * H + tid] : 0.0f;
+        const float w1a = net.W1[tid], w1b = net.n_out > 1 ? net.W1b[tid] : 0.0f;
+        if (tid < kRows) {
+            float2 d = make_float2(0.0f, 0.0f);
+            if (row0 + tid < B) {
+                d = ns_policy_dout<ENV>(p, c, row0 + tid);
+                if (g == 0) {
+                    if (p.twin) reinterpret_cast<float2*>(p.dout)[row0 + tid] = d;
+                    else p.dout[row0 + tid] = d.x;
+                }
+            }
+            do_s[tid * 2] = d.x; do_s[tid * 2 + 1] = d.y;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kRows; ++r)
+            dh_s[r * LDH + tid] = (hv[r] > 0.0f) ? fmaf(do_s[r * 2 + 1], w1b, do_s[r * 2] * w1a) : 0.0f;
+        __syncthreads();
+        f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int ks = 0; ks < H / 16; ++ks) acc = mfma4(dh_s[li * LDH + jw + ks * 4 + lg], wv[ks], acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wpart[(wave * 16 + lg * 4 + i) * 16 + li] = acc[i];
+        __syncthreads();
+        {
+            const int r = tid >> 4, ee = tid & 15;
+            float v = wpart[(0 * 16 + r) * 16 + ee];
+            v = wpart[(1 * 16 + r) * 16 + ee] + v;
+            v = wpart[(2 * 16 + r) * 16 + ee] + v;
+            v = wpart[(3 * 16 + r) * 16 + ee] + v;
+            if (row0 + r < B) {
+                const size_t o = (size_t)(row0 + r) * EIN + g * 16 + ee;
+                v = p.x0_a[o] > 0.0f ? v : 0.0f;
+                // shared state embedding: ONE first-layer reduction yields its gradient from both losses' dx0
+                if (p.shared_embedding) v += p.twin ? p.dx0[0][o] + p.dx0[1][o] : p.dx0[0][o];
+                p.dx0_a[o] = v;
+            }
+        }
+        return;
+    }
+    b -= T * kNsGroups;
+    float* do0_s = smem + 4 * 16 * 64;
+    float* do1_s = do0_s + kBwdMaxB;
+    for (int i = tid; i < B; i += kThreads) {
+        const float2 d = ns_policy_dout<ENV>(p, c, i);
+        do0_s[i] = d.x; do1_s[i] = d.y;
+    }
+    __syncthreads();
+    if (b < 32) {
+        float (*tile)[16 * 64] = reinterpret_cast<float (*)[16 * 64]>(smem);
+        const int jt = b / (EIN / 64), et = b - jt * (EIN / 64);
+        const int j = jt * 16 + li, e0 = et * 64 + li * 4;
+        const float w1a = net.W1[j], w1b = net.n_out > 1 ? net.W1b[j] : 0.0f;
+        f32x4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const int nk = (B + 3) / 4;
+        const int ks_lo = (nk * wave) / 4, ks_hi = (nk * (wave + 1)) / 4;
+        const int last = B - 1;
+        int ks = ks_lo;
+        for (; ks + 4 <= ks_hi; ks += 4) {
+            float av[4];
+            float4 bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int bb = (ks + u) * 4 + lg;
+                const int bc = bb < last ? bb : last;
+                const float h = p.h1_a[(size_t)bc * H + j];
+                av[u] = (h > 0.0f) ? fmaf(do1_s[bc], w1b, do0_s[bc] * w1a) : 0.0f;
+                bv[u] = *reinterpret_cast<const float4*>(&p.x0_a[(size_t)bc * EIN + e0]);
+                if (bb > last) av[u] = 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[0] = mfma4(av[u], fmaxf(bv[u].x, 0.0f), acc[0]);
+                acc[1] = mfma4(av[u], fmaxf(bv[u].y, 0.0f), acc[1]);
+                acc[2] = mfma4(av[u], fmaxf(bv[u].z, 0.0f), acc[2]);
+                acc[3] = mfma4(av[u], fmaxf(bv[u].w, 0.0f), acc[3]);
+            }
+        }
+        for (; ks < ks_hi; ++ks) {
+            const int bb = ks * 4 + lg;
+            const int bc = bb < last ? bb : last;
+            const float h = p.h1_a[(size_t)bc * H + j];
+            float av = (h > 0.0f) ? fmaf(do1_s[bc], w1b, do0_s[bc] * w1a) : 0.0f;
+            const float4 b4 = *reinterpret_cast<const float4*>(&p.x0_a[(size_t)bc * EIN + e0]);
+            if (bb > last) av = 0.0f;
+            acc[0] = mfma4(av, fmaxf(b4.x, 0.0f), acc[0]);
+            acc[1] = mfma4(av, fmaxf(b4.y, 0.0f), acc[1]);
+            acc[2] = mfma4(av, fmaxf(b4.z, 0.0f), acc[2]);
+            acc[3] = mfma4(av, fmaxf(b4.w, 0.0f), acc[3]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(&tile[wave][(lg * 4 + i) * 64 + li * 4]) =
+                make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+        __syncthreads();
+        {
+            const int r = tid >> 4, c4 = (tid & 15) * 4;
+            const float4 t0 = *reinterpret_cast<const float4*>(&tile[0][r * 64 + c4]);
+            const float4 t1 = *reinterpret_cast<const float4*>(&tile[1][r * 64 + c4]);
+            const float4 t2 = *reinterpret_cast<const float4*>(&tile[2][r * 64 + c4]);
+            const float4 t3 = *reinterpret_cast<const float4*>(&tile[3][r * 64 + c4]);
+            float4* dst = reinterpret_cast<float4*>(&gr.W0[(size_t)(jt * 16 + r) * EIN + et * 64 + c4]);
+            float4 cur = *dst;
+            cur.x += ((t0.x + t1.x) + t2.x) + t3.x;
+            cur.y += ((t0.y + t1.y) + t2.y) + t3.y;
+            cur.z += ((t0.z + t1.z) + t2.z) + t3.z;
+            cur.w += ((t0.w + t1.w) + t2.w) + t3.w;
+            *dst = cur;
+            gmax = fmaxf(fmaxf(fabsf(cur.x), fabsf(cur.y)), fmaxf(fabsf(cur.z), fabsf(cur.w)));
+        }
+    } else {
+        const int rb = b - 32;
+        float (*partial)[3][64] = reinterpret_cast<float (*)[3][64]>(smem);
+        const int o = tid & 63, part = tid >> 6;
+        const int b_lo = (int)(((long long)B * part) / 4), b_hi = (int)(((long long)B * (part + 1)) / 4);
+        const int j = rb * 64 + o;
+        const float w1a = net.W1[j], w1b = net.n_out > 1 ? net.W1b[j] : 0.0f;
+        float gb0 = 0.0f, gw1a = 0.0f, gw1b = 0.0f;
+        int bb = b_lo;
+        for (; bb + 8 <= b_hi; bb += 8) {                          // 8 rows of loads in flight (a plain loop exposes each)
+            float h[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) h[u] = p.h1_a[(size_t)(bb + u) * H + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                gb0 += (h[u] > 0.0f) ? fmaf(do1_s[bb + u], w1b, do0_s[bb + u] * w1a) : 0.0f;
+                const float hr = fmaxf(h[u], 0.0f);
+                gw1a = fmaf(do0_s[bb + u], hr, gw1a);
+                gw1b = fmaf(do1_s[bb + u], hr, gw1b);
+            }
+        }
+        for (; bb < b_hi; ++bb) {
+            const float h = p.h1_a[(size_t)bb * H + j];
+            gb0 += (h > 0.0f) ? fmaf(do1_s[bb], w1b, do0_s[bb] * w1a) : 0.0f;
+            const float hr = fmaxf(h, 0.0f);
+            gw1a = fmaf(do0_s[bb], hr, gw1a);
+            gw1b = fmaf(do1_s[bb], hr, gw1b);
+        }
+        partial[part][0][o] = gb0; partial[part][1][o] = gw1a; partial[part][2][o] = gw1b;
+        __syncthreads();
+        if (part == 0) {
+            const float nb0 = gr.b0[j] + (((partial[0][0][o] + partial[1][0][o]) + partial[2][0][o]) + partial[3][0][o]);
+            const float nw1 = gr.W1[j] + (((partial[0][1][o] + partial[1][1][o]) + partial[2][1][o]) + partial[3][1][o]);
+            gr.b0[j] = nb0;
+            gr.W1[j] = nw1;
+            gmax = fmaxf(fabsf(nb0), fabsf(nw1));
+            if (net.n_out > 1) {
+                const float nw1b = gr.W1b[j] + (((partial[0][2][o] + partial[1][2][o]) + partial[2][2][o]) + partial[3][2][o]);
+                gr.W1b[j] = nw1b;
+                gmax = fmaxf(gmax, fabsf(nw1b));
+            }
+        }
+        if (rb == 0) {
+            __syncthreads();
+            float s0 = 0.0f, s1 = 0.0f;
+            for (int b2 = tid; b2 < B; b2 += kThreads) { s0 += do0_s[b2]; s1 += do1_s[b2]; }
+            s0 = rpo_wave_sum(s0);
+            s1 = rpo_wave_sum(s1);
+            if (o == 0) { partial[part][0][0] = s0; partial[part][1][0] = s1; }
+            __syncthreads();
+            if (tid == 0) {
+                const float nb1 = gr.b1[0] + (((partial[0][0][0] + partial[1][0][0]) + partial[2][0][0]) + partial[3][0][0]);
+                gr.b1[0] = nb1;
+                gmax = fmaxf(gmax, fabsf(nb1));
+                if (net.n_out > 1) {
+                    const float nb1b = gr.b1b[0] + (((partial[0][1][0] + partial[1][1][0]) + partial[2][1][0]) + partial[3][1][0]);
+                    gr.b1b[0] = nb1b;
+                    gmax = fmaxf(gmax, fabsf(nb1b));
+                }
+            }
+        }
+    }
+    gradmax_flush(p.gradmax, gmax);
+}
+
+// ---- pol_e: actor first-layer gradients from dx0_a; one more workgroup folds the Lagrangian partials (value, d/d nu)
+template <class ENV>
+__global__ __launch_bounds__(kThreads) void split_policy_e_kernel(SplitArgs p, int fl_blocks) {
+    typedef typename ENV::L L;
+    if ((int)blockIdx.x == fl_blocks) {
+        const int tid = threadIdx.x, T = (p.B + kRows - 1) / kRows;
+        if (tid < 8) {
+            float sacc = 0.0f;
+            for (int g = 0; g < T; ++g) sacc += p.lag_partial[g * 8 + tid];
+            const float inv_b = 1.0f / (float)p.B;
+            if (tid == 0) p.lag_out[0] = inv_b * sacc;
+            else if (tid == 7) { if (!p.twin) p.lag_out[1] = inv_b * sacc; }
+            else if (tid - 1 < ENV::NI) p.nu_grad[tid - 1] += inv_b * sacc;
+        }
+        return;
+    }
+    BwdArgs a{};
+    a.net = p.actor;
+    a.g = p.actor_grad;
+    a.n = p.B;
+    a.s = p.batch_out; a.s_stride = L::ROW;
+    a.dx0 = p.dx0_a;
+    a.param_grads = 1;
+    gradmax_flush(p.gradmax, mlp_bwd_first_layer<128>(a, blockIdx.x));
+}
+
+}  // namespace
+
+namespace {
+
+MlpGrad grad_dev(const rpo_mlp_grad* g) {
+    if (!g) return MlpGrad{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return MlpGrad{g->Ws, g->bs, g->Wa, g->ba, g->W0, g->b0, g->W1, g->b1, g->W1b, g->b1b};
+}
+
+// Resolve and validate the parts of rpo_split_update a stage needs.  need: bit 0 policy net, 1 critics, 2 target
+// critics, 3 critic gradients, 4 actor gradients, 5 online actor (policy step).
+int to_args(const rpo_split_update* u, unsigned need, SplitArgs& a, CartConsts& c) {
+    if (!u) return RPO_ERR_NULL;
+    if (u->batch <= 0 || u->batch > kBwdMaxB || (u->env != 0 && u->env != 1)) return RPO_ERR_ARG;
+    const int S = u->env == 0 ? 6 : 5, K = u->twin ? 2 : 1;
+    a = SplitArgs{};
+    a.twin = u->twin ? 1 : 0; a.B = u->batch;
+    auto ok_actor = [&](const rpo_mlp* h, Mlp& m) {
+        if (!h) return (int)RPO_ERR_NULL;
+        m = to_dev(h);
+        return (split_ok(m) && m.S == S && m.A == 0 && m.n_out == (u->twin ? 2 : 1)) ? 0 : (int)RPO_ERR_ARG;
+    };
+    auto ok_critic = [&](const rpo_mlp* h, Mlp& m) {
+        if (!h) return (int)RPO_ERR_NULL;
+        m = to_dev(h);
+        return (split_ok(m) && m.S == S && m.A == 2 && m.n_out == 1) ? 0 : (int)RPO_ERR_ARG;
+    };
+    if (need & 1u) {
+        if (int e = u->twin ? ok_actor(u->actor, a.actor) : ok_actor(u->actor_target, a.actor_target)) return e;
+    }
+    if (need & 32u) {
+        if (int e = ok_actor(u->actor, a.actor)) return e;
+    }
+    if (need & 2u) {
+        if (int e = ok_critic(u->critic1, a.critic[0])) return e;
+        if (K == 2) if (int e = ok_critic(u->critic2, a.critic[1])) return e;
+    }
+    if (need & 4u) {
+        if (int e = ok_critic(u->critic_target1, a.critic_target[0])) return e;
+        if (K == 2) if (int e = ok_critic(u->critic_target2, a.critic_target[1])) return e;
+    }
+    if (need & 8u) {
+        if (!u->critic1_grad || (K == 2 && !u->critic2_grad)) return RPO_ERR_NULL;
+        a.critic_grad[0] = grad_dev(u->critic1_grad);
+        a.critic_grad[1] = grad_dev(u->critic2_grad);
+        for (int k = 0; k < K; ++k) {
+            const MlpGrad& g = a.critic_grad[k];
+            if (!g.Ws || !g.bs || !g.Wa || !g.ba || !g.W0 || !g.b0 || !g.W1 || !g.b1) return RPO_ERR_NULL;
+        }
+    }
+    if (need & 16u) {
+        if (!u->actor_grad) return RPO_ERR_NULL;
+        a.actor_grad = grad_dev(u->actor_grad);
+        const MlpGrad& g = a.actor_grad;
+        if (!g.Ws || !g.bs || !g.W0 || !g.b0 || !g.W1 || !g.b1 || (u->twin && (!g.W1b || !g.b1b))) return RPO_ERR_NULL;
+    }
+    c = CartConsts{};
+    if (u->env == 0) {
+        if (int e = rpo_cart_dev::load_consts(c, u->consts_host, u->partial)) return e;
+    }
+    a.rows = u->rows; a.cap_steps = u->cap_steps; a.n_envs = u->n_envs; a.batch_out = u->batch_out; a.idx_out = u->idx_out;
+    a.idx_in = u->idx_in; a.sample_seed = (uint64_t)u->sample_seed; a.sample_salt = (uint32_t)u->sample_salt;
+    a.eps_in = u->eps_in; a.noise_seed = (uint64_t)u->noise_seed; a.noise_id_base = (uint32_t)u->noise_id_base;
+    a.noise_salt = (uint32_t)u->noise_salt; a.ctrl = u->ctrl;
+    a.scale = u->scale; a.base = u->base; a.box_lo = u->box_lo; a.box_hi = u->box_hi;
+    a.max_steps = u->max_steps; a.corr_lr = u->corr_lr; a.corr_eps = u->corr_eps; a.corr_momentum = u->corr_momentum;
+    a.alpha = u->alpha; a.gamma = u->gamma; a.eps_start = u->eps_start; a.eps_end = u->eps_end; a.eps_decay = u->eps_decay;
+    a.part_pi = u->part_pi; a.part_q[0] = u->part_q1; a.part_q[1] = u->part_q2; a.part_qn[0] = u->part_qn1; a.part_qn[1] = u->part_qn2;
+    a.x0[0] = u->x0_1; a.h1[0] = u->h1_1; a.x0[1] = u->x0_2; a.h1[1] = u->h1_2; a.x0_a = u->x0_a; a.h1_a = u->h1_a;
+    a.logp = u->logp; a.next_actions = u->next_actions; a.proj_iters = u->proj_iters;
+    a.dq[0] = u->dq1; a.dq[1] = u->dq2; a.loss_partial = u->loss_partial; a.dx0[0] = u->dx0_1; a.dx0[1] = u->dx0_2;
+    a.dx0_a = u->dx0_a; a.gradmax = u->gradmax; a.nu = u->nu; a.nu_grad = u->nu_grad;
+    a.ap_det = u->ap_det; a.noise_out = u->noise_out; a.raw = u->raw; a.actions = u->actions; a.g_act = u->g_act;
+    a.lag_partial = u->lag_partial; a.lag_out = u->lag_out; a.da_part = u->da_part; a.dout = u->dout;
+    a.shared_embedding = u->shared_embedding;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rpo_split_critic_fwd_a(const rpo_split_update* u, void* stream) {
+    SplitArgs a; CartConsts c;
+    if (int e = to_args(u, 1u | 2u, a, c)) return e;
+    const int K = a.twin ? 2 : 1;
+    if (!a.rows || !a.batch_out || !a.ctrl || !a.part_pi || a.cap_steps <= 0 || a.n_envs <= 0) return RPO_ERR_NULL;
+    for (int k = 0; k < K; ++k)
+        if (!a.part_q[k] || !a.x0[k] || !a.h1[k]) return RPO_ERR_NULL;
+    const dim3 grid((a.B + kRows - 1) / kRows, kNsGroups, 1 + K);
+    if (u->env == 0) hipLaunchKernelGGL(split_critic_fwd_a_kernel<CartRow>, grid, dim3(kNsThreads), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(split_critic_fwd_a_kernel<PendRow>, grid, dim3(kNsThreads), 0, (hipStream_t)stream, a);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_split_critic_fwd_b(const rpo_split_update* u, void* stream) {
+    SplitArgs a; CartConsts c;
+    if (int e = to_args(u, (u && u->env == 0 ? 1u : 0u) | 4u, a, c)) return e;
+    const int K = a.twin ? 2 : 1;
+    if (!a.batch_out || !a.ctrl) return RPO_ERR_NULL;
+    for (int k = 0; k < K; ++k)
+        if (!a.part_qn[k]) return RPO_ERR_NULL;
+    const dim3 grid((a.B + kRows - 1) / kRows, kNsGroups, K);
+    if (u->env == 0) {
+        if (!a.part_pi || (a.twin && !a.logp) || a.max_steps < 0) return RPO_ERR_NULL;
+        hipLaunchKernelGGL((split_critic_fwd_b_kernel<CartRow, 1>), grid, dim3(kNsThreads), 0, (hipStream_t)stream, a, c);
+    } else {
+        if (!a.next_actions) return RPO_ERR_NULL;
+        hipLaunchKernelGGL((split_critic_fwd_b_kernel<PendRow, 0>), grid, dim3(kNsThreads), 0, (hipStream_t)stream, a, c);
+    }
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_split_pend_head_project(const rpo_split_update* u, void* stream) {
+    SplitArgs a; CartConsts c;
+    if (int e = to_args(u, 1u, a, c)) return e;
+    if (u->env != 1 || a.max_steps < 0) return RPO_ERR_ARG;
+    if (!a.batch_out || !a.ctrl || !a.part_pi || !a.next_actions || (a.twin && !a.logp)) return RPO_ERR_NULL;
+    const size_t lds = ((size_t)a.B + 4) * sizeof(float);
+    const int threads = (a.B + RPO_WAVE - 1) / RPO_WAVE * RPO_WAVE;
+    hipLaunchKernelGGL(split_pend_head_project_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, a);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_split_critic_bwd_a(const rpo_split_update* u, void* stream) {
+    SplitArgs a; CartConsts c;
+    if (int e = to_args(u, 2u | 4u | 8u, a, c)) return e;
+    const int K = a.twin ? 2 : 1, T = (a.B + kRows - 1) / kRows;
+    if (!a.batch_out || !a.loss_partial || (a.twin && !a.logp)) return RPO_ERR_NULL;
+    for (int k = 0; k < K; ++k)
+        if (!a.part_q[k] || !a.part_qn[k] || !a.x0[k] || !a.h1[k] || !a.dq[k] || !a.dx0[k]) return RPO_ERR_NULL;
+    const int grid = K * T * kNsGroups + K * 32 + K * 4;
+    if (u->env == 0) hipLaunchKernelGGL(split_critic_bwd_a_kernel<CartRow>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(split_critic_bwd_a_kernel<PendRow>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_split_critic_bwd_b(const rpo_split_update* u, void* stream) {
+    SplitArgs a; CartConsts c;
+    if (int e = to_args(u, 2u | 8u, a, c)) return e;
+    const int K = a.twin ? 2 : 1;
+    if (!a.batch_out) return RPO_ERR_NULL;
+    for (int k = 0; k < K; ++k)
+        if (!a.dx0[k]) return RPO_ERR_NULL;
+    const Mlp& m = a.critic[0];
+    const int blocks = (m.E * (m.S + 1 + m.A + 1) + 63) / 64;
+    if (u->env == 0) hipLaunchKernelGGL(split_critic_bwd_b_kernel<CartRow>, dim3(blocks, K), dim3(kThreads), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(split_critic_bwd_b_kernel<PendRow>, dim3(blocks, K), dim3(kThreads), 0, (hipStream_t)stream, a);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+int rpo_split_policy_a(const rpo_split_update* u, void* stream) {
+    SplitArgs a; CartConsts c;
+    if (int e = to_args(u, 32u, a, c)) return e;
+    if (!a.batch_out || !a.part_pi || !a.x0_a || !a.h1_a) return RPO_ERR_NULL;
+    const dim3 grid((a.B + kRows - 1) / kRows, kNsGroups);
+    if (u->env == 0) hipLaunchKernelGGL(split_policy_a_kernel<CartRow>, grid, dim3(kNsThreads), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(split_policy_a_kernel<PendRow>, grid, dim3(kNsThreads), 0, (hipStream_t)stream, a);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_split_policy_b(const rpo_split_update* u, void* stream) {
+    SplitArgs a; CartConsts c;
+    if (int e = to_args(u, 32u | 2u, a, c)) return e;
+    const int K = a.twin ? 2 : 1;
+    if (!a.batch_out || !a.ctrl || !a.part_pi || !a.nu || !a.noise_out || !a.actions || !a.g_act || !a.lag_partial) return RPO_ERR_NULL;
+    if (a.twin ? (!a.raw || !a.logp) : !a.ap_det) return RPO_ERR_NULL;
+    for (int k = 0; k < K; ++k)
+        if (!a.part_q[k] || !a.x0[k] || !a.h1[k]) return RPO_ERR_NULL;
+    const dim3 grid((a.B + kRows - 1) / kRows, kNsGroups, K);
+    if (u->env == 0) hipLaunchKernelGGL(split_policy_b_kernel<CartPol>, grid, dim3(kNsThreads), 0, (hipStream_t)stream, a, c);
+    else hipLaunchKernelGGL(split_policy_b_kernel<PendPol>, grid, dim3(kNsThreads), 0, (hipStream_t)stream, a, c);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_split_policy_c(const rpo_split_update* u, void* stream) {
+    SplitArgs a; CartConsts c;
+    if (int e = to_args(u, 2u, a, c)) return e;
+    const int K = a.twin ? 2 : 1, T = (a.B + kRows - 1) / kRows;
+    if (!a.da_part || !a.lag_partial || (a.twin && !a.logp)) return RPO_ERR_NULL;
+    for (int k = 0; k < K; ++k)
+        if (!a.part_q[k] || !a.x0[k] || !a.h1[k] || !a.dx0[k]) return RPO_ERR_NULL;
+    hipLaunchKernelGGL(split_policy_c_kernel, dim3(K * T * kNsGroups), dim3(kThreads), 0, (hipStream_t)stream, a);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_split_policy_d(const rpo_split_update* u, void* stream) {
+    SplitArgs a; CartConsts c;
+    if (int e = to_args(u, 32u | 16u, a, c)) return e;
+    const int K = a.twin ? 2 : 1, T = (a.B + kRows - 1) / kRows;
+    if (!a.batch_out || !a.ctrl || !a.da_part || !a.g_act || !a.noise_out || !a.x0_a || !a.h1_a || !a.dx0_a || !a.dout) return RPO_ERR_NULL;
+    if (a.twin ? !a.raw : !a.ap_det) return RPO_ERR_NULL;
+    if (a.shared_embedding)
+        for (int k = 0; k < K; ++k)
+            if (!a.dx0[k]) return RPO_ERR_NULL;
+    const int grid = T * kNsGroups + 32 + 4;
+    if (u->env == 0) hipLaunchKernelGGL(split_policy_d_kernel<CartPol>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a, c);
+    else hipLaunchKernelGGL(split_policy_d_kernel<PendPol>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a, c);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_split_policy_e(const rpo_split_update* u, void* stream) {
+    SplitArgs a; CartConsts c;
+    if (int e = to_args(u, 32u | 16u, a, c)) return e;
+    if (!a.batch_out || !a.dx0_a || !a.lag_partial || !a.lag_out || !a.nu_grad) return RPO_ERR_NULL;
+    const int fl_blocks = (a.actor.E * (a.actor.S + 1) + 63) / 64;
+    if (u->env == 0) hipLaunchKernelGGL(split_policy_e_kernel<CartPol>, dim3(fl_blocks + 1), dim3(kThreads), 0, (hipStream_t)stream, a, fl_blocks);
+    else hipLaunchKernelGGL(split_policy_e_kernel<PendPol>, dim3(fl_blocks + 1), dim3(kThreads), 0, (hipStream_t)stream, a, fl_blocks);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,143 @@
+// Column-split ("N-split") form of the MLP tile for the batch-256 update kernels (see nsplit.hip).
+//
+// mlp_tile.h gives one workgroup 16 rows through the WHOLE hidden layer: 128 f32 MFMAs per SIMD (~1.7 us of matrix
+// pipe on one CU) behind a 128 KB weight stream, on 16 of the 256 CUs.  Here a workgroup of 2 waves owns 16 rows x 32
+// hidden columns -- exactly the slab ONE wave of the row-tile kernel owns -- so a batch of 256 rows becomes
+// 16 row tiles x 8 column groups = 128 workgroups per network, each with a 16 KB weight slice and a 32-MFMA chain.
+// The price is that the head (a dot product over all hidden columns) cannot finish inside the launch: every workgroup
+// leaves the per-row partial its slab contributes, and the CONSUMER adds the 8 partials in the fixed order of the
+// row-tile kernel's wave loop.  Same arithmetic, same order -> bitwise the same outputs as mlp_tile.h
+// (tests/test_mlp_gpu.py::test_split_forward_is_bitwise_the_tile_forward).
+#pragma once
+#include "mlp_tile.h"
+
+namespace rpo_mlp_dev {
+
+constexpr int kNsThreads = 128;            // 2 waves: wave w owns column tile c = w of the group's 32 columns
+constexpr int kNsGroups = 8;               // column groups == waves of the row-tile forward (H / 32)
+
+template <int EIN>
+struct NsLds {
+    __attribute__((aligned(16))) float x1[kRows * (EIN + 4)];   // relu(first layer) of the 16 rows
+    float in_s[kRows * 8];                                        // state inputs (S <= 8)
+    float in_a[kRows * 8];                                        // action inputs (A <= 8)
+    float xch[2 * 4 * 64];                                        // wave 0 -> wave 1: head partials after column tile 0
+};
+
+// What a thread keeps in registers: its first-layer column and its wave's 16 x EIN slice of W0.
+template <int EIN>
+struct NsWeights {
+    float bias, ws0[8], wa0[8];
+    float4 w0[EIN / 16];
+    float b0v, w1av, w1bv;
+};
+
+// Issue every weight load of the slab (they return underneath the input staging / gather of the caller).
+template <int EIN, int H>
+__device__ __forceinline__ void ns_load_weights(const Mlp& net, int g, NsWeights<EIN>& w) {
+    static_assert(EIN == kNsThreads, "one first-layer column per thread");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int e = tid;
+    w.bias = net.bs[e] + (net.A > 0 ? net.ba[e] : 0.0f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        w.ws0[u] = u < net.S ? net.Ws[e * net.S + u] : 0.0f;
+        w.wa0[u] = (net.A > 0 && u < net.A) ? net.Wa[e * net.A + u] : 0.0f;
+    }
+    const int j = g * 32 + wave * 16 + li;                       // hidden column of this lane's B operand / outputs
+#pragma unroll
+    for (int it = 0; it < EIN / 16; ++it)
+        w.w0[it] = *reinterpret_cast<const float4*>(&net.W0[(size_t)j * EIN + it * 16 + lg * 4]);
+    w.b0v = net.b0[j];
+    w.w1av = net.W1[j];
+    w.w1bv = net.n_out > 1 ? net.W1b[j] : 0.0f;
+}
+
+// Hidden slab of column group g for the 16 rows staged in lds.in_s / lds.in_a (the caller wrote them; this function
+// synchronises before reading).  Writes part[(g * n + row) * 2 + o] for rows < n (o < n_out), h1_save columns of the
+// group, x0_save (group 0 only).  S, A <= 8, "add" critics / actors with EIN = E = 128.
+template <int EIN, int H>
+__device__ __forceinline__ void ns_hidden(const Mlp& net, const NsWeights<EIN>& w, NsLds<EIN>& lds, int g, int row0, int n,
+                                          float* part, float* x0_save, float* h1_save) {
+    constexpr int LDX = EIN + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    __syncthreads();
+    // ---- layer 1 (VALU): thread = column e, all 16 rows; same fmaf order as tile_compute (state inputs, then action)
+    float acc1[kRows];
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) acc1[r] = w.bias;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        if (u < net.S) {
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) acc1[r] = fmaf(lds.in_s[r * 8 + u], w.ws0[u], acc1[r]);
+        }
+    }
+    if (net.A > 0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (u < net.A) {
+#pragma unroll
+                for (int r = 0; r < kRows; ++r) acc1[r] = fmaf(lds.in_a[r * 8 + u], w.wa0[u], acc1[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+        if (x0_save && g == 0 && row0 + r < n) x0_save[(size_t)(row0 + r) * EIN + tid] = acc1[r];
+        lds.x1[r * LDX + tid] = fmaxf(acc1[r], 0.0f);
+    }
+    __syncthreads();
+    // ---- layer 2 (MFMA): one 16 x 16 output tile per wave, k-ordered chain of EIN / 4 instructions
+    f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int it = 0; it < EIN / 16; ++it) {
+        const float4 a4 = *reinterpret_cast<const float4*>(&lds.x1[li * LDX + it * 16 + lg * 4]);
+        acc = mfma4(a4.x, w.w0[it].x, acc);
+        acc = mfma4(a4.y, w.w0[it].y, acc);
+        acc = mfma4(a4.z, w.w0[it].z, acc);
+        acc = mfma4(a4.w, w.w0[it].w, acc);
+    }
+    // acc[i] = h1[row = 4 lg + i][col = 32 g + 16 wave + li] (before bias)
+    const int col = g * 32 + wave * 16 + li;
+    float hr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float h = acc[i] + w.b0v;
+        const int row = row0 + lg * 4 + i;
+        if (h1_save && row < n) h1_save[(size_t)row * H + col] = h;
+        hr[i] = fmaxf(h, 0.0f);
+    }
+    // ---- head partial of the slab: the row-tile kernel's wave runs fmaf over its two column tiles in order, so wave 0
+    //      hands its term to wave 1, which adds its own and reduces over the 16 lanes of a row
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lds.xch[(0 * 4 + i) * 64 + lane] = fmaf(hr[i], w.w1av, 0.0f);
+            lds.xch[(1 * 4 + i) * 64 + lane] = fmaf(hr[i], w.w1bv, 0.0f);
+        }
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = fmaf(hr[i], o == 0 ? w.w1av : w.w1bv, lds.xch[(o * 4 + i) * 64 + lane]);
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                const int row = row0 + lg * 4 + i;
+                if (li == 0 && row < n && o < net.n_out) part[((size_t)g * n + row) * 2 + o] = v;
+            }
+    }
+}
+
+// The consumer's side of the seam: head output o of `row` from the 8 slab partials (fixed order == the wave loop of
+// tile_compute), bias first.
+__device__ __forceinline__ float ns_head(const float* part, int n, int row, int o, float bias) {
+    float v = bias;
+#pragma unroll
+    for (int g = 0; g < kNsGroups; ++g) v += part[((size_t)g * n + row) * 2 + o];
+    return v;
+}
+
+}  // namespace rpo_mlp_dev

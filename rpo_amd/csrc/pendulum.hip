@@ -94,47 +94,9 @@ __global__ __launch_bounds__(1024) void pendulum_project_batchref_kernel(
     int n, const float* __restrict__ obs, int obs_stride, const float* __restrict__ ap, float* __restrict__ action,
     int* __restrict__ iters_out, int max_steps, float corr_lr, float corr_eps, float corr_momentum) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // dgp[n] | stop flag
-    float* dgp_s = lds;
-    int* flag = reinterpret_cast<int*>(lds + n);
     const int i = threadIdx.x;                                     // one sample per thread, n <= blockDim.x <= 1024
-    const bool live = i < n;
-    Eq e = {0.0f, 1.0f, 1.0f, 0.0f};
-    float ax = 0.0f, ay = 0.0f, ox = 0.0f, oy = 0.0f;
-    if (live) {
-        const float* o = obs + (size_t)i * obs_stride;
-        e = set_eq(o[0], o[1], o[2], o[3], o[4]);
-        ax = ap[i];
-        ay = (e.b - ax * e.C_p) * e.C_o_inv;                       // complete_partial :256-262
-    }
-    int k = 0;
-    for (; k < max_steps; ++k) {
-        if (threadIdx.x == 0) *flag = 0;
-        __syncthreads();
-        if (live) {
-            const float h = e.b - (ax * e.C_p + ay * e.C_o);
-            const float g = ax * ax + ay * ay - kMaxSum;
-            if (fabsf(h) > corr_eps || g > corr_eps) atomicOr(flag, 1);
-            dgp_s[i] = 2.0f * ax - 2.0f * ay * (e.C_o_inv * e.C_p);                  // :334-335
-        }
-        __syncthreads();
-        if (k > 0 && *flag == 0) break;                            // batch-global stop test, rpo_ddpg.py:271-272
-        if (live) {
-            const float bgp = kMaxSum - (e.b * e.C_o_inv) * (2.0f * ay);             // :336
-            float grad = 0.0f;
-            for (int j = 0; j < n; ++j) {                          // [B,1] @ [1,B] coupling, :337-339
-                const float d = dgp_s[j];
-                grad += (ax * d - bgp > 0.0f) ? d : 0.0f;
-            }
-            const float gy = -(grad * e.C_p) * e.C_o_inv;                            // :342
-            const float sx = corr_lr * grad + corr_momentum * ox;
-            const float sy = corr_lr * gy + corr_momentum * oy;
-            ax -= sx; ay -= sy;
-            ox = sx; oy = sy;
-        }
-        __syncthreads();
-    }
-    if (live) reinterpret_cast<float2*>(action)[i] = make_float2(ax, ay);
-    if (threadIdx.x == 0 && iters_out) *iters_out = k;
+    project_batchref_body(n, i < n ? obs + (size_t)i * obs_stride : nullptr, i < n ? ap[i] : 0.0f, action, iters_out,
+                          max_steps, corr_lr, corr_eps, corr_momentum, lds);
 }
 
 __global__ __launch_bounds__(RPO_BLOCK) void pendulum_complete_bwd_kernel(int n, const float* __restrict__ obs,

@@ -196,6 +196,56 @@ __device__ __forceinline__ float2 pend_explore_project(const ActArgs& p, const f
     return make_float2(ax, ay);
 }
 
+// RPODDPG.grad_steps on a BATCH, literally (rpo_ddpg.py:266-286 with pendulum.py:331-343 for B > 1): one workgroup owns
+// the batch (thread i = sample i; `o` = its observation or NULL beyond n, `ap_i` its basic action), `lds` holds n + 4
+// floats.  Body of rpo_pendulum_project_batchref and of the column-split update's head + projection kernel
+// (nsplit.hip): contraction off, so that both round identically.
+__device__ __forceinline__ void project_batchref_body(int n, const float* o, float ap_i, float* __restrict__ action,
+                                                      int* __restrict__ iters_out, int max_steps, float corr_lr,
+                                                      float corr_eps, float corr_momentum, float* lds) {
+    RPO_FP_STRICT
+    float* dgp_s = lds;
+    int* flag = reinterpret_cast<int*>(lds + n);
+    const int i = threadIdx.x;
+    const bool live = i < n;
+    Eq e = {0.0f, 1.0f, 1.0f, 0.0f};
+    float ax = 0.0f, ay = 0.0f, ox = 0.0f, oy = 0.0f;
+    if (live) {
+        e = set_eq(o[0], o[1], o[2], o[3], o[4]);
+        ax = ap_i;
+        ay = (e.b - ax * e.C_p) * e.C_o_inv;                       // complete_partial :256-262
+    }
+    int k = 0;
+    for (; k < max_steps; ++k) {
+        if (threadIdx.x == 0) *flag = 0;
+        __syncthreads();
+        if (live) {
+            const float h = e.b - (ax * e.C_p + ay * e.C_o);
+            const float g = ax * ax + ay * ay - kMaxSum;
+            if (fabsf(h) > corr_eps || g > corr_eps) atomicOr(flag, 1);
+            dgp_s[i] = 2.0f * ax - 2.0f * ay * (e.C_o_inv * e.C_p);                  // :334-335
+        }
+        __syncthreads();
+        if (k > 0 && *flag == 0) break;                            // batch-global stop test, rpo_ddpg.py:271-272
+        if (live) {
+            const float bgp = kMaxSum - (e.b * e.C_o_inv) * (2.0f * ay);             // :336
+            float grad = 0.0f;
+            for (int j = 0; j < n; ++j) {                          // [B,1] @ [1,B] coupling, :337-339
+                const float d = dgp_s[j];
+                grad += (ax * d - bgp > 0.0f) ? d : 0.0f;
+            }
+            const float gy = -(grad * e.C_p) * e.C_o_inv;                            // :342
+            const float sx = corr_lr * grad + corr_momentum * ox;
+            const float sy = corr_lr * gy + corr_momentum * oy;
+            ax -= sx; ay -= sy;
+            ox = sx; oy = sy;
+        }
+        __syncthreads();
+    }
+    if (live) reinterpret_cast<float2*>(action)[i] = make_float2(ax, ay);
+    if (threadIdx.x == 0 && iters_out) *iters_out = k;
+}
+
 // One row of nu . relu(g(a)) with g = |a|^2 - 32 (pendulum.py:302-311; rpo_sac.py:326-335): returns nu0 * relu(g),
 // `dist` = relu(g) (d/d nu) and (g0, g1) = scale * d/d action.  Shared by rpo_pendulum_lagrangian and the fused pipelines.
 __device__ __forceinline__ float lagrangian_row(float ax, float ay, float nu0, float scale, float& dist, float& g0, float& g1) {

@@ -551,6 +551,35 @@ def mlp_forward_multi(calls):
         ptrs([as_int(_p(c[5], allow_none=True)) for c in calls]), _stream()), "rpo_mlp_forward_multi")
 
 
+def mlp_split_supported(desc):
+    net = desc.net_struct()
+    return bool(_lib.load().rpo_mlp_split_supported(ctypes.byref(net)))
+
+
+def mlp_forward_split(calls):
+    """Column-split hidden layers of 1..4 networks in one launch: calls = [(desc, s, a, part [8, n, 2], x0_save,
+    h1_save), ...]; the head outputs are completed by ``mlp_split_head`` or by the consumer kernel's prologue."""
+    k = len(calls)
+    nets = [c[0].net_struct() for c in calls]
+    svs = [_row_view(c[1], c[0].S) for c in calls]
+    avs = [(None, 0) if c[0].A == 0 else _row_view(c[2], c[0].A) for c in calls]
+    ptrs = lambda vals: (ctypes.c_void_p * k)(*vals)                                   # noqa: E731
+    as_int = lambda v: None if v is None else (v.value if isinstance(v, ctypes.c_void_p) else v)   # noqa: E731
+    n = calls[0][3].shape[1]
+    check(_lib.load().rpo_mlp_forward_split(
+        k, ptrs([ctypes.addressof(x) for x in nets]), n,
+        ptrs([as_int(v[0]) for v in svs]), (ctypes.c_int * k)(*[v[1] for v in svs]),
+        ptrs([as_int(v[0]) for v in avs]), (ctypes.c_int * k)(*[v[1] for v in avs]),
+        ptrs([as_int(_p(c[3])) for c in calls]), ptrs([as_int(_p(c[4], allow_none=True)) for c in calls]),
+        ptrs([as_int(_p(c[5], allow_none=True)) for c in calls]), _stream()), "rpo_mlp_forward_split")
+
+
+def mlp_split_head(desc, part, out, out_mode=0, scale=1.0, base=0.0):
+    net = desc.net_struct()
+    check(_lib.load().rpo_mlp_split_head(ctypes.byref(net), part.shape[1], _p(part), _p(out), out_mode, scale, base,
+                                         _stream()), "rpo_mlp_split_head")
+
+
 def mlp_backward(desc, s, a, x0, h1, dout, dh, dx0, da=None, param_grads=True, first_layer_state_only=False,
                  gradmax=None, td=None):
     """td (a ``Td``): dout is not read; the rows pass computes it (TD target + Huber) into td.dq_out."""
@@ -654,3 +683,75 @@ def ddpg_actor_backward(env_kernels, actor, critic, shared_embedding, batch, act
         _p(actor_x0), _p(actor_h1), _p(critic_x0), _p(critic_h1), _p(actor_dh), _p(actor_dx0), _p(critic_dh), _p(critic_dx0),
         _p(da), _p(dout), _p(partial_in), _p(lag_out), _p(nu_grad), _p(gradmax, allow_none=True), _stream()),
         "rpo_ddpg_actor_backward")
+
+
+# =================================================================================================== column-split update
+
+class _SplitUpdateStruct(ctypes.Structure):
+    """rpo_split_update of include/rpo_hip.h (same field order)."""
+    _P, _I, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    _fields_ = (
+        [(n, ctypes.c_void_p) for n in ("actor", "actor_target", "critic1", "critic2", "critic_target1", "critic_target2",
+                                        "critic1_grad", "critic2_grad", "actor_grad")] +
+        [("env", ctypes.c_int), ("twin", ctypes.c_int), ("batch", ctypes.c_int),
+         ("rows", ctypes.c_void_p), ("cap_steps", ctypes.c_longlong), ("n_envs", ctypes.c_int),
+         ("batch_out", ctypes.c_void_p), ("idx_out", ctypes.c_void_p), ("idx_in", ctypes.c_void_p),
+         ("sample_seed", ctypes.c_ulonglong), ("sample_salt", ctypes.c_uint),
+         ("eps_in", ctypes.c_void_p), ("noise_seed", ctypes.c_ulonglong), ("noise_id_base", ctypes.c_uint),
+         ("noise_salt", ctypes.c_uint), ("ctrl", ctypes.c_void_p),
+         ("scale", ctypes.c_float), ("base", ctypes.c_float), ("box_lo", ctypes.c_float), ("box_hi", ctypes.c_float),
+         ("max_steps", ctypes.c_int), ("corr_lr", ctypes.c_float), ("corr_eps", ctypes.c_float),
+         ("corr_momentum", ctypes.c_float), ("consts_host", ctypes.c_void_p), ("partial", ctypes.c_int),
+         ("alpha", ctypes.c_float), ("gamma", ctypes.c_float),
+         ("eps_start", ctypes.c_float), ("eps_end", ctypes.c_float), ("eps_decay", ctypes.c_float)] +
+        [(n, ctypes.c_void_p) for n in ("part_pi", "part_q1", "part_q2", "part_qn1", "part_qn2", "x0_1", "h1_1", "x0_2",
+                                        "h1_2", "x0_a", "h1_a", "logp", "next_actions", "proj_iters", "dq1", "dq2",
+                                        "loss_partial", "dx0_1", "dx0_2", "dx0_a", "gradmax", "nu", "nu_grad", "ap_det",
+                                        "noise_out", "raw", "actions", "g_act", "lag_partial", "lag_out", "da_part",
+                                        "dout")] +
+        [("shared_embedding", ctypes.c_int)])
+
+
+class SplitUpdate(object):
+    """Arguments of the column-split update stages (rpo_split_*), built once per trainer: every pointer refers to a static
+    device buffer, so the struct is reused for every launch (and every hipGraph capture)."""
+
+    STAGES = ("critic_fwd_a", "critic_fwd_b", "pend_head_project", "critic_bwd_a", "critic_bwd_b", "policy_a", "policy_b",
+              "policy_c", "policy_d", "policy_e")
+
+    def __init__(self, env_kernels, descs, twin, batch, fields):
+        """descs: name -> MlpDesc for actor, actor_target (RPODDPG), critic1, critic2, critic_target1, critic_target2;
+        fields: remaining struct fields (tensors become device pointers, Python scalars are copied)."""
+        self._keep, self._held = [], {}
+        st = self.st = _SplitUpdateStruct()
+        for name in ("actor", "actor_target", "critic1", "critic2", "critic_target1", "critic_target2"):
+            d = descs.get(name)
+            if d is not None:
+                net = d.net_struct()
+                self._keep.append(net)
+                setattr(st, name, ctypes.addressof(net))
+        for name, key in (("critic1_grad", "critic1"), ("critic2_grad", "critic2"), ("actor_grad", "actor")):
+            d = descs.get(key)
+            if d is not None and d.tensors["W0"].grad is not None:
+                g = d.grad_struct()
+                self._keep.append(g)
+                setattr(st, name, ctypes.addressof(g))
+        is_cart = isinstance(env_kernels, CartSafeKernels)
+        st.env, st.twin, st.batch = (0 if is_cart else 1), int(bool(twin)), int(batch)
+        if is_cart:
+            self._keep.append(env_kernels.consts)
+            st.consts_host, st.partial = env_kernels.consts.ctypes.data, env_kernels.partial
+        self.set(**fields)
+
+    def set(self, **fields):
+        for k, v in fields.items():
+            if isinstance(v, torch.Tensor):
+                dt = torch.int64 if k in ("idx_out", "idx_in", "ctrl") else (torch.int32 if k == "proj_iters" else torch.float32)
+                self._held[k] = v                                   # keeps the buffer alive while the struct points at it
+                setattr(self.st, k, _p(v, dt).value)
+            else:
+                self._held.pop(k, None)
+                setattr(self.st, k, v)
+
+    def run(self, stage):
+        check(getattr(_lib.load(), "rpo_split_" + stage)(ctypes.byref(self.st), _stream()), "rpo_split_" + stage)

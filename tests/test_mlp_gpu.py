@@ -205,3 +205,37 @@ def test_forward_multi_equals_single_launches():
         else:
             for k in got:
                 assert torch.equal(got[k], grads_a[k]), k
+
+
+@pytest.mark.parametrize("kind,S,A,n", [("actor", 6, 0, 256), ("add", 6, 2, 256), ("add", 5, 2, 77), ("gauss", 5, 0, 256),
+                                         ("gauss", 6, 0, 250)])
+def test_split_forward_is_bitwise_the_tile_forward(kind, S, A, n):
+    """rpo_mlp_forward_split + rpo_mlp_split_head (16 row tiles x 8 column groups of workgroups, head partials added by
+    the consumer in the tile kernel's wave order) == rpo_mlp_forward, bit for bit: outputs and both saved
+    pre-activations; two networks in one launch as well."""
+    from rpo_amd import ops
+    E, H = 128, 256
+    torch.manual_seed(S * 10 + n)
+    se = StateEmbedding(S, E, H)
+    if kind == "actor":
+        net = SharedPolicy(S, 1, se, E, H, 1, None)
+    elif kind == "gauss":
+        net = GaussianSharedPolicy(S, 1, se, E, H, 1, None)
+    else:
+        net = SharedValueAdd(S, A, se, ActionEmbedding(A, E, H), E, H)
+    aligned_params(net)
+    d = desc_for(ops, net, kind, S, A, E, H)
+    assert ops.mlp_split_supported(d)
+    wide = torch.randn(n, S + A + 7, device=DEV)
+    s = wide[:, 3:3 + S]
+    a = wide[:, 3 + S:3 + S + A] if A else None
+    n_out = d.n_out
+    out, x0, h1 = torch.empty(n, n_out, device=DEV), torch.empty(n, E, device=DEV), torch.empty(n, H, device=DEV)
+    mode = (1, 2.5, 0.25) if kind == "actor" else (0, 1.0, 0.0)
+    ops.mlp_forward(d, s, a, out, x0, h1, *mode)
+    part, part2 = torch.zeros(8, n, 2, device=DEV), torch.zeros(8, n, 2, device=DEV)
+    out_s, x0_s, h1_s = torch.empty(n, n_out, device=DEV), torch.zeros(n, E, device=DEV), torch.zeros(n, H, device=DEV)
+    ops.mlp_forward_split([(d, s, a, part, x0_s, h1_s), (d, s, a, part2, None, None)])
+    ops.mlp_split_head(d, part, out_s, *mode)
+    assert torch.equal(out, out_s) and torch.equal(x0, x0_s) and torch.equal(h1, h1_s)
+    assert torch.equal(part, part2)

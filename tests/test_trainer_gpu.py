@@ -482,3 +482,34 @@ def test_pipelines_with_a_ragged_batch(hip, algo, envname, monkeypatch):
     np.testing.assert_allclose(float(a.last_losses["critic"]), float(b.last_losses["critic"]), rtol=1e-5)
     # the actor pipelines agree with the single-stage launches to 1e-7 (not bitwise), so do the rollouts that follow
     np.testing.assert_allclose(a.buffer.rows.cpu().numpy(), b.buffer.rows.cpu().numpy(), rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("algo,envname", CASES[:4])
+def test_split_update_equals_row_tile_pipelines(hip, algo, envname, monkeypatch):
+    """The column-split update (rpo_split_*: 128 workgroups per network evaluation, head partials summed by the
+    consumer, TD prologue + on-the-fly dh in the backward) against the row-tile pipelines it replaces."""
+    dev = torch.device("cuda")
+    monkeypatch.setenv("RPO_SPLIT", "0")
+    a = _run(algo, envname, hip, dev, 26, 300, use_graph=False)
+    assert a._split_state() is None
+    monkeypatch.setenv("RPO_SPLIT", "1")
+    b = _run(algo, envname, hip, dev, 26, 300, use_graph=False)
+    assert b._split_state() is not None
+    c = _run(algo, envname, hip, dev, 26, 300, use_graph=True)
+    assert torch.equal(b.agent.flat.data, c.agent.flat.data) and torch.equal(b.buffer.rows, c.buffer.rows)   # graph == eager
+    # critic update: bit for bit (3 iterations: before the first policy step)
+    monkeypatch.setenv("RPO_SPLIT", "0")
+    a3 = _run(algo, envname, hip, dev, 3, 300, use_graph=False)
+    monkeypatch.setenv("RPO_SPLIT", "1")
+    b3 = _run(algo, envname, hip, dev, 3, 300, use_graph=False)
+    assert torch.equal(a3.agent.flat.data, b3.agent.flat.data)
+    assert torch.equal(a3.agent.critic_target_flat, b3.agent.critic_target_flat)
+    assert torch.equal(a3.agent.critic_optim.exp_avg_sq, b3.agent.critic_optim.exp_avg_sq)
+    assert float(a3.last_losses["critic"]) == float(b3.last_losses["critic"])
+    # with policy steps: d(-Q)/d action is summed over column groups instead of one 128-term chain, so the actor's
+    # gradient agrees to ~1e-7 relative and the runs drift apart at that level (Adam normalises the step: 26 iterations
+    # of lr 1e-4 / 3e-4 steps keep the parameters within 2e-6)
+    np.testing.assert_allclose(a.agent.flat.data.cpu().numpy(), b.agent.flat.data.cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(a.agent.nju.weight.detach().cpu().numpy(), b.agent.nju.weight.detach().cpu().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(float(a.last_losses["critic"]), float(b.last_losses["critic"]), rtol=1e-4)
+    np.testing.assert_allclose(float(a.last_losses["actor"]), float(b.last_losses["actor"]), rtol=1e-4, atol=1e-6)
