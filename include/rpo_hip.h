@@ -293,7 +293,9 @@ int rpo_absmax(long long n, const float* x, float* max_out, void* stream);
  *   target = (1 - tau) * target + tau * p.   gradmax is reset to 0 by the launch when reset_gradmax != 0.
  *   zero_grad != 0: instead of the clipped value, 0 is written back -- the gradient is consumed, so that the next
  *   backward pass (which accumulates) needs no separate fill launch (optimizer.zero_grad() folded into the step).
- *   step_dev points at int32[4] (16-byte aligned): {step, pad, 8-byte arrival word (0 between launches)}. */
+ *   step_dev points at int32[8] (16-byte aligned): {step, pad, 8-byte arrival word (0 between launches), two doubles:
+ *   the bias corrections 1 - beta1^(step+1), sqrt(1 - beta2^(step+1)) cached by the previous launch (0.0 = not cached:
+ *   they are then computed by every thread; zero-initialise the buffer, and zero the cache when betas change)}. */
 int rpo_adam_step(long long n, float* param, float* grad, float* exp_avg, float* exp_avg_sq, int* step_dev,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int maximize, float clip_thres,
                   float* gradmax, int reset_gradmax, int zero_grad, int clamp_min0, float* target, float tau,

@@ -89,7 +89,8 @@ class FusedAdam(object):
         dev = param.device
         self.exp_avg = torch.zeros_like(param)
         self.exp_avg_sq = torch.zeros_like(param)
-        self.step_dev = torch.zeros(4, dtype=torch.int32, device=dev)       # {step, pad, arrival word}
+        # {step, pad, arrival word (8 B), cached bias corrections of the next step (2 doubles)}
+        self.step_dev = torch.zeros(8, dtype=torch.int32, device=dev)
         self.gradmax = torch.zeros(1, device=dev)
         # True: the step leaves a zeroed gradient slice behind (optimizer.zero_grad() folded into the Adam launch); the
         # trainers switch it on when every backward of the iteration goes through the accumulating MLP kernels
@@ -138,4 +139,6 @@ class FusedAdam(object):
     def load_state_dict(self, sd):
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.step_dev.copy_(sd["step"])
+        step = sd["step"]
+        self.step_dev.zero_()                                   # (older checkpoints hold 4 words: the cache starts empty)
+        self.step_dev[:step.numel()].copy_(step)

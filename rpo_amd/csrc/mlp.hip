@@ -271,7 +271,7 @@ static int make_bwd_args(BwdArgs& args, const rpo_mlp* net_host, const rpo_mlp_g
 static int bwd_weights_grid(const Mlp& net, int first_layer_state_only) {
     const int ein = net.cat ? 2 * net.E : net.E;
     const int fl_outputs = net.E * (net.S + 1 + ((net.A > 0 && !first_layer_state_only) ? net.A + 1 : 0));
-    return (net.H / 16) * (ein / 64) + (net.hd > 1 ? net.H / 16 : net.H / 64) + (fl_outputs + 63) / 64;
+    return (net.H / 16) * (ein / 64) + (net.hd > 1 ? net.H / 16 : net.H / 64) + mlp_fl_blocks(fl_outputs);
 }
 
 int rpo_mlp_forward_multi(int count, const rpo_mlp* const* nets, int n, const float* const* s, const int* s_stride,

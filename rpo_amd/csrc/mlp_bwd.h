@@ -176,20 +176,25 @@ __device__ __forceinline__ void mlp_bwd_rows_body(const BwdArgs& p) {
     }
 }
 
-// First-layer gradients from dx0 (batch reduction, one owner per output, 64 outputs per workgroup, the batch split over
-// the 4 waves and combined through LDS in a fixed order).  Output list idx = q * E + e (e fastest: coalesced dx0 reads);
-// q < wS: state weights / bias, q >= wS: action weights / bias.  Columns of x0: [0, E) <- state (+ action when added);
-// [E, 2E) <- action (cat).  `fl_block` = index of the workgroup among the first-layer workgroups.
+// First-layer gradients from dx0: batch reductions with one owner per output and a fixed summation order.  A workgroup
+// owns kFlOut = 16 consecutive outputs and splits the batch 16 ways (256 threads = 16 outputs x 16 slices), so a thread's
+// serial chain of dependent loads is n / 16 rows (two groups of 8 at batch 256) -- with 64 outputs x 4 slices it was eight
+// groups, ~3 us of exposed latency on a launch that is otherwise the boundary floor.  The 16 slice sums are added in
+// order.  Output list idx = q * E + e (e fastest: contiguous dx0 reads); q < wS: state weights / bias, q >= wS: action
+// weights / bias.  Columns of x0: [0, E) <- state (+ action when added); [E, 2E) <- action (cat).
+constexpr int kFlOut = 16;
+__host__ __device__ constexpr int mlp_fl_blocks(int outputs) { return (outputs + kFlOut - 1) / kFlOut; }
+
 template <int EIN>
 __device__ __forceinline__ float mlp_bwd_first_layer(const BwdArgs& p, int fl_block) {
-    __shared__ float fl_partial[4][64];
+    __shared__ float fl_partial[16][kFlOut];
     const Mlp& net = p.net;
     const int tid = threadIdx.x;
-    const int o = tid & 63, part = tid >> 6;
-    const int b_lo = (int)(((long long)p.n * part) / 4), b_hi = (int)(((long long)p.n * (part + 1)) / 4);
+    const int o = tid & (kFlOut - 1), part = tid >> 4;
+    const int b_lo = (int)(((long long)p.n * part) / 16), b_hi = (int)(((long long)p.n * (part + 1)) / 16);
     float gmax = 0.0f;
     const int wS = net.S + 1, wA = (net.A > 0 && !p.first_layer_state_only) ? net.A + 1 : 0;   // +1: the bias
-    const int idx = fl_block * 64 + o;
+    const int idx = fl_block * kFlOut + o;
     const bool valid = idx < net.E * (wS + wA);
     float acc = 0.0f;
     int e = 0, i = 0, width = 0;
@@ -205,22 +210,24 @@ __device__ __forceinline__ float mlp_bwd_first_layer(const BwdArgs& p, int fl_bl
         const int stride = is_a ? p.a_stride : p.s_stride;
         const bool is_w = i < width;
         int bb = b_lo;
-        for (; bb + 8 <= b_hi; bb += 8) {
-            float d[8], x[8];
+        for (; bb + 16 <= b_hi; bb += 16) {
+            float d[16], x[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 d[u] = p.dx0[(size_t)(bb + u) * EIN + col];
                 x[u] = is_w ? in[(size_t)(bb + u) * stride + i] : 1.0f;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = fmaf(d[u], x[u], acc);
+            for (int u = 0; u < 16; ++u) acc = fmaf(d[u], x[u], acc);
         }
         for (; bb < b_hi; ++bb) acc = fmaf(p.dx0[(size_t)bb * EIN + col], is_w ? in[(size_t)bb * stride + i] : 1.0f, acc);
     }
     fl_partial[part][o] = acc;
     __syncthreads();
     if (part == 0 && valid) {
-        const float tot = ((fl_partial[0][o] + fl_partial[1][o]) + fl_partial[2][o]) + fl_partial[3][o];
+        float tot = fl_partial[0][o];
+#pragma unroll
+        for (int sl = 1; sl < 16; ++sl) tot += fl_partial[sl][o];
         float* dst = (i < width) ? (is_a ? &p.g.Wa[e * net.A + i] : &p.g.Ws[e * net.S + i]) : (is_a ? &p.g.ba[e] : &p.g.bs[e]);
         const float nv = *dst + tot;
         *dst = nv;

@@ -2,6 +2,8 @@
 // of the chip -- 128 workgroups per network evaluation instead of 16 -- cut at the seams where a value needs every
 // hidden column (the heads).  nsplit_dev.h has the slab function and the argument for why the results are bitwise
 // those of the row-tile kernels.
+#include <stdlib.h>
+
 #include "cartsafe_dev.h"
 #include "heads_dev.h"
 #include "mlp_bwd.h"
@@ -87,6 +89,7 @@ struct SplitArgs {
     const float* nu; float* nu_grad;
     float *ap_det, *noise_out, *raw, *actions, *g_act, *lag_partial, *lag_out, *da_part, *dout;
     int shared_embedding;
+    int dbg;                      // RPO_SPLIT_DBG (timing experiments only): 1 = skip the weight roles, 2 = skip the dx0 role
 };
 
 // ReplayBuffer.sample (buffer.py:31-34): counter-based draw + gather of the tile's 16 rows (same draw in every workgroup
@@ -244,21 +247,161 @@ __device__ __forceinline__ float ns_td_row(const SplitArgs& p, int k, int i, flo
 
 constexpr int kBwdMaxB = 1024;
 
-// ---- bwd_a: blocks [0, K*T*8): dx0 column groups (critic k, row tile, 16 first-layer columns);
-//             then K*32: dW0 tiles (16 hidden rows x 64 input columns, K = batch over the 4 waves);
-//             then K*4: hidden-layer vectors db0 / dW1 / db1.
-//      dh = dLoss/dQ * W1 * 1[h1 > 0] is formed on the fly from the TD prologue, never stored: nothing in this launch
-//      waits for another workgroup.
+// dh[b][j] = d loss / d h1 of row b, hidden column j, from the rows' head gradients (d0 [, d1]): formed where it is needed
+__device__ __forceinline__ float ns_dh(float h, float d0, float d1, float w1a, float w1b) {
+    return (h > 0.0f) ? fmaf(d1, w1b, d0 * w1a) : 0.0f;
+}
+
+// ---- Weight roles of a backward pass.  A workgroup's operand stream comes from L2 at ~50-100 GB/s, so the tiles are
+//      kept small: the 16 x 64 dW0 tiles of the row-tile kernels need 80 KB each (~6 us measured for the role), 16 x 16
+//      tiles 32 KB.  Summation orders are those of mlp_bwd_weights_body (batch split in 4 ranges, each a sequential chain,
+//      the 4 sums added in order), so the gradients are bitwise the same.
+constexpr int kW0Tiles = (256 / 16) * (128 / 16);   // 128 dW0 tiles of 16 hidden rows x 16 input columns
+constexpr int kHvBlocks = 256 / 16;                 // 16 blocks of 16 hidden columns: db0, dW1 (, dW1b), block 0 also db1
+constexpr int kWeightBlocks = kW0Tiles + kHvBlocks;
+
+// dW0 tile: wave w sums the batch range [w, w + 1) * B / 4 (k-steps of 4 rows), dh formed on the fly.
+__device__ __forceinline__ float ns_dw0_tile(const Mlp& net, float* gW0, const float* __restrict__ h1,
+                                             const float* __restrict__ x0, const float* dglob, int dstride, bool two, int B,
+                                             int blk, float* smem) {
+    constexpr int EIN = 128, H = 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int jt = blk / (EIN / 16), et = blk - jt * (EIN / 16);
+    const int j = jt * 16 + li, e = et * 16 + li;
+    const int nk = (B + 3) / 4, ks_lo = (nk * wave) / 4, ks_hi = (nk * (wave + 1)) / 4, last = B - 1;
+    // everything is requested up front, straight-line (rows past the wave's range are clamped and zeroed below)
+    float hv[16], xv[16], d0[16], d1[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int bb = (ks_lo + u) * 4 + lg, bc = bb < last ? bb : last;
+        hv[u] = h1[(size_t)bc * H + j];
+        xv[u] = x0[(size_t)bc * EIN + e];
+        d0[u] = dglob[(size_t)bc * dstride];
+        d1[u] = two ? dglob[(size_t)bc * dstride + 1] : 0.0f;
+    }
+    const float w1a = net.W1[j], w1b = two ? net.W1b[j] : 0.0f;
+    float* dst = &gW0[(size_t)(jt * 16 + (tid >> 4)) * EIN + et * 16 + (tid & 15)];
+    const float cur = *dst;
+    f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int bb = (ks_lo + u) * 4 + lg;
+        float av = ns_dh(hv[u], d0[u], d1[u], w1a, w1b);
+        if (bb > last || ks_lo + u >= ks_hi) av = 0.0f;
+        if (ks_lo + u < ks_hi || u == 0) acc = mfma4(av, fmaxf(xv[u], 0.0f), acc);
+    }
+    for (int ks = ks_lo + 16; ks < ks_hi; ++ks) {                  // batches beyond 256 rows
+        const int bb = ks * 4 + lg, bc = bb < last ? bb : last;
+        float av = ns_dh(h1[(size_t)bc * H + j], dglob[(size_t)bc * dstride], two ? dglob[(size_t)bc * dstride + 1] : 0.0f, w1a, w1b);
+        if (bb > last) av = 0.0f;
+        acc = mfma4(av, fmaxf(x0[(size_t)bc * EIN + e], 0.0f), acc);
+    }
+    // acc[i] = this wave's share of dW0[j = 16 jt + 4 lg + i][e = 16 et + li]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) smem[(wave * 16 + lg * 4 + i) * 16 + li] = acc[i];
+    __syncthreads();
+    const int r = tid >> 4, c = tid & 15;
+    const float nv = cur + (((smem[(0 * 16 + r) * 16 + c] + smem[(1 * 16 + r) * 16 + c]) + smem[(2 * 16 + r) * 16 + c]) +
+                            smem[(3 * 16 + r) * 16 + c]);
+    *dst = nv;
+    return fabsf(nv);
+}
+
+// Hidden-layer vectors of 16 columns: thread = (column, batch range); 64 threads of the workgroup work, each a sequential
+// chain over its B / 4 rows (the order of mlp_bwd_weights_body); block 0 also sums d_k over the batch for db1_k.
+__device__ __forceinline__ float ns_hv_block(const Mlp& net, const MlpGrad& gr, const float* __restrict__ h1, const float* dglob,
+                                             int dstride, bool two, int B, int rb, float* smem) {
+    constexpr int H = 256;
+    const int tid = threadIdx.x;
+    float gmax = 0.0f;
+    float (*partial)[3][16] = reinterpret_cast<float (*)[3][16]>(smem);       // [4][3][16]
+    if (tid < 64) {
+        const int o = tid & 15, part = tid >> 4;
+        const int b_lo = (int)(((long long)B * part) / 4), b_hi = (int)(((long long)B * (part + 1)) / 4);
+        const int j = rb * 16 + o;
+        const float w1a = net.W1[j], w1b = two ? net.W1b[j] : 0.0f;
+        float gb0 = 0.0f, gw1a = 0.0f, gw1b = 0.0f;
+        for (int c0 = b_lo; c0 < b_hi; c0 += 32) {                 // 32 rows of loads in flight, straight-line inside
+            float hv[32], d0[32], d1[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int bb = c0 + u < b_hi ? c0 + u : b_hi - 1;
+                hv[u] = h1[(size_t)bb * H + j];
+                d0[u] = dglob[(size_t)bb * dstride];
+                d1[u] = two ? dglob[(size_t)bb * dstride + 1] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const bool ok = c0 + u < b_hi;
+                const float h = ok ? hv[u] : 0.0f, a0 = ok ? d0[u] : 0.0f, a1 = ok ? d1[u] : 0.0f;
+                gb0 += ns_dh(h, a0, a1, w1a, w1b);
+                const float hr = fmaxf(h, 0.0f);
+                gw1a = fmaf(a0, hr, gw1a);
+                gw1b = fmaf(a1, hr, gw1b);
+            }
+        }
+        partial[part][0][o] = gb0; partial[part][1][o] = gw1a; partial[part][2][o] = gw1b;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const int o = tid, j = rb * 16 + o;
+        const float nb0 = gr.b0[j] + (((partial[0][0][o] + partial[1][0][o]) + partial[2][0][o]) + partial[3][0][o]);
+        const float nw1 = gr.W1[j] + (((partial[0][1][o] + partial[1][1][o]) + partial[2][1][o]) + partial[3][1][o]);
+        gr.b0[j] = nb0;
+        gr.W1[j] = nw1;
+        gmax = fmaxf(fabsf(nb0), fabsf(nw1));
+        if (two) {
+            const float nw1b = gr.W1b[j] + (((partial[0][2][o] + partial[1][2][o]) + partial[2][2][o]) + partial[3][2][o]);
+            gr.W1b[j] = nw1b;
+            gmax = fmaxf(gmax, fabsf(nw1b));
+        }
+    }
+    if (rb == 0) {
+        // db1_k = sum_b d_k[b]: strided per-thread partials, wave reduction, 4 wave partials added in order
+        __syncthreads();
+        float s0 = 0.0f, s1 = 0.0f;
+        for (int b2 = tid; b2 < B; b2 += kThreads) {
+            s0 += dglob[(size_t)b2 * dstride];
+            if (two) s1 += dglob[(size_t)b2 * dstride + 1];
+        }
+        s0 = rpo_wave_sum(s0);
+        s1 = rpo_wave_sum(s1);
+        float* red = smem + 256;
+        if ((tid & 63) == 0) { red[(tid >> 6) * 2] = s0; red[(tid >> 6) * 2 + 1] = s1; }
+        __syncthreads();
+        if (tid == 0) {
+            const float nb1 = gr.b1[0] + (((red[0] + red[2]) + red[4]) + red[6]);
+            gr.b1[0] = nb1;
+            gmax = fmaxf(gmax, fabsf(nb1));
+            if (two) {
+                const float nb1b = gr.b1b[0] + (((red[1] + red[3]) + red[5]) + red[7]);
+                gr.b1b[0] = nb1b;
+                gmax = fmaxf(gmax, fabsf(nb1b));
+            }
+        }
+    }
+    return gmax;
+}
+
+// block w < kW0Tiles: dW0 tile, else hidden-vector block.  The rows' head gradients d0 [, d1] were left in global memory by
+// the dx0 launch before this one (row stride `dstride` floats).
+__device__ __forceinline__ float ns_weight_role(const Mlp& net, const MlpGrad& gr, const float* h1, const float* x0,
+                                                const float* dglob, int dstride, bool two, int B, int w, float* smem) {
+    if (w < kW0Tiles) return ns_dw0_tile(net, gr.W0, h1, x0, dglob, dstride, two, B, w, smem);
+    return ns_hv_block(net, gr, h1, dglob, dstride, two, B, w - kW0Tiles, smem);
+}
+
+// ---- bwd_a: TD target + Huber (from the slab partials) -> dh = dLoss/dQ * W1 * 1[h1 > 0] (on the fly) -> dx0 of one
+//      (critic k, row tile, 16 first-layer columns); the column-group-0 workgroup of a tile leaves dLoss/dQ and the loss share.
+//      blocks (critic, row tile, column group), 256 threads.
 template <class L>
 __global__ __launch_bounds__(kThreads) void split_critic_bwd_a_kernel(SplitArgs p) {
     constexpr int EIN = 128, H = 256, LDH = H + 4;
-    __shared__ __attribute__((aligned(16))) float smem[4 * 16 * 64 + kBwdMaxB + 256];   // 21 KB: the largest of the three roles
-    const int K = p.twin ? 2 : 1, T = (p.B + kRows - 1) / kRows, B = p.B;
+    __shared__ __attribute__((aligned(16))) float smem[kRows * LDH + 16 + 4 * 16 * 16];
+    const int T = (p.B + kRows - 1) / kRows, B = p.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    int b = blockIdx.x;
-    float gmax = 0.0f;
-    if (b < K * T * kNsGroups) {
-        // ------------------------------------------------------------------------------------------- dx0 column group
+    const int b = blockIdx.x;
+    {
         const int k = b / (T * kNsGroups), rem = b - k * T * kNsGroups, tile = rem / kNsGroups, g = rem - tile * kNsGroups;
         const int row0 = tile * kRows;
         const Mlp& net = p.critic[k];
@@ -273,6 +416,8 @@ __global__ __launch_bounds__(kThreads) void split_critic_bwd_a_kernel(SplitArgs 
 #pragma unroll
         for (int r = 0; r < kRows; ++r) hv[r] = row0 + r < B ? p.h1[k][(size_t)(row0 + r) * H + tid] : 0.0f;
         const float w1a = net.W1[tid];                            // 256 threads = 256 hidden columns
+        const size_t xo = (size_t)(row0 + (tid >> 4)) * EIN + g * 16 + (tid & 15);
+        const float x0v = row0 + (tid >> 4) < B ? p.x0[k][xo] : 0.0f;   // mask of this thread's output, requested early
         if (tid < 64) {
             float dq = 0.0f, hub = 0.0f;
             if (tid < kRows && row0 + tid < B) {
@@ -300,147 +445,25 @@ __global__ __launch_bounds__(kThreads) void split_critic_bwd_a_kernel(SplitArgs 
             v = wpart[(1 * 16 + r) * 16 + ee] + v;
             v = wpart[(2 * 16 + r) * 16 + ee] + v;
             v = wpart[(3 * 16 + r) * 16 + ee] + v;
-            if (row0 + r < B) {
-                const size_t o = (size_t)(row0 + r) * EIN + g * 16 + ee;
-                p.dx0[k][o] = p.x0[k][o] > 0.0f ? v : 0.0f;
-            }
-        }
-        return;
-    }
-    b -= K * T * kNsGroups;
-    // every remaining workgroup needs dLoss/dQ of the whole batch
-    const bool is_w0 = b < K * 32;
-    const int k = is_w0 ? b / 32 : (b - K * 32) / 4;
-    const Mlp& net = p.critic[k];
-    const MlpGrad& gr = p.critic_grad[k];
-    float* dq_s = smem + 4 * 16 * 64;
-    for (int i = tid; i < B; i += kThreads) {
-        float hub;
-        dq_s[i] = ns_td_row<L>(p, k, i, &hub);
-    }
-    __syncthreads();
-    if (is_w0) {
-        // ------------------------------------------------------------------------------------------------ dW0 tile
-        const int blk = b - k * 32;
-        float (*tile)[16 * 64] = reinterpret_cast<float (*)[16 * 64]>(smem);
-        const int jt = blk / (EIN / 64), et = blk - jt * (EIN / 64);
-        const int j = jt * 16 + li, e0 = et * 64 + li * 4;
-        const float w1j = net.W1[j];
-        f32x4 acc[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        const int nk = (B + 3) / 4;
-        const int ks_lo = (nk * wave) / 4, ks_hi = (nk * (wave + 1)) / 4;
-        const int last = B - 1;
-        int ks = ks_lo;
-        for (; ks + 4 <= ks_hi; ks += 4) {
-            float av[4];
-            float4 bv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int bb = (ks + u) * 4 + lg;
-                const int bc = bb < last ? bb : last;
-                const float h = p.h1[k][(size_t)bc * H + j];
-                av[u] = (h > 0.0f) ? dq_s[bc] * w1j : 0.0f;
-                bv[u] = *reinterpret_cast<const float4*>(&p.x0[k][(size_t)bc * EIN + e0]);
-                if (bb > last) av[u] = 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc[0] = mfma4(av[u], fmaxf(bv[u].x, 0.0f), acc[0]);
-                acc[1] = mfma4(av[u], fmaxf(bv[u].y, 0.0f), acc[1]);
-                acc[2] = mfma4(av[u], fmaxf(bv[u].z, 0.0f), acc[2]);
-                acc[3] = mfma4(av[u], fmaxf(bv[u].w, 0.0f), acc[3]);
-            }
-        }
-        for (; ks < ks_hi; ++ks) {
-            const int bb = ks * 4 + lg;
-            const int bc = bb < last ? bb : last;
-            const float h = p.h1[k][(size_t)bc * H + j];
-            float av = (h > 0.0f) ? dq_s[bc] * w1j : 0.0f;
-            const float4 b4 = *reinterpret_cast<const float4*>(&p.x0[k][(size_t)bc * EIN + e0]);
-            if (bb > last) av = 0.0f;
-            acc[0] = mfma4(av, fmaxf(b4.x, 0.0f), acc[0]);
-            acc[1] = mfma4(av, fmaxf(b4.y, 0.0f), acc[1]);
-            acc[2] = mfma4(av, fmaxf(b4.z, 0.0f), acc[2]);
-            acc[3] = mfma4(av, fmaxf(b4.w, 0.0f), acc[3]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(&tile[wave][(lg * 4 + i) * 64 + li * 4]) =
-                make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
-        __syncthreads();
-        {
-            const int r = tid >> 4, c4 = (tid & 15) * 4;
-            const float4 t0 = *reinterpret_cast<const float4*>(&tile[0][r * 64 + c4]);
-            const float4 t1 = *reinterpret_cast<const float4*>(&tile[1][r * 64 + c4]);
-            const float4 t2 = *reinterpret_cast<const float4*>(&tile[2][r * 64 + c4]);
-            const float4 t3 = *reinterpret_cast<const float4*>(&tile[3][r * 64 + c4]);
-            float4* dst = reinterpret_cast<float4*>(&gr.W0[(size_t)(jt * 16 + r) * EIN + et * 64 + c4]);
-            float4 cur = *dst;
-            cur.x += ((t0.x + t1.x) + t2.x) + t3.x;
-            cur.y += ((t0.y + t1.y) + t2.y) + t3.y;
-            cur.z += ((t0.z + t1.z) + t2.z) + t3.z;
-            cur.w += ((t0.w + t1.w) + t2.w) + t3.w;
-            *dst = cur;
-            gmax = fmaxf(fmaxf(fabsf(cur.x), fabsf(cur.y)), fmaxf(fabsf(cur.z), fabsf(cur.w)));
-        }
-    } else {
-        // ---------------------------------------------------------- hidden-layer vectors: db0[j], dW1[j], db1 (block 0)
-        const int rb = (b - K * 32) - k * 4;
-        float (*partial)[3][64] = reinterpret_cast<float (*)[3][64]>(smem);
-        const int o = tid & 63, part = tid >> 6;
-        const int b_lo = (int)(((long long)B * part) / 4), b_hi = (int)(((long long)B * (part + 1)) / 4);
-        const int j = rb * 64 + o;
-        const float w1j = net.W1[j];
-        float gb0 = 0.0f, gw1a = 0.0f;
-        int bb = b_lo;
-        for (; bb + 8 <= b_hi; bb += 8) {
-            float h[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) h[u] = p.h1[k][(size_t)(bb + u) * H + j];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                gb0 += (h[u] > 0.0f) ? dq_s[bb + u] * w1j : 0.0f;
-                gw1a = fmaf(dq_s[bb + u], fmaxf(h[u], 0.0f), gw1a);
-            }
-        }
-        for (; bb < b_hi; ++bb) {
-            const float h = p.h1[k][(size_t)bb * H + j];
-            gb0 += (h > 0.0f) ? dq_s[bb] * w1j : 0.0f;
-            gw1a = fmaf(dq_s[bb], fmaxf(h, 0.0f), gw1a);
-        }
-        partial[part][0][o] = gb0; partial[part][1][o] = gw1a;
-        __syncthreads();
-        if (part == 0) {
-            const float nb0 = gr.b0[j] + (((partial[0][0][o] + partial[1][0][o]) + partial[2][0][o]) + partial[3][0][o]);
-            const float nw1 = gr.W1[j] + (((partial[0][1][o] + partial[1][1][o]) + partial[2][1][o]) + partial[3][1][o]);
-            gr.b0[j] = nb0;
-            gr.W1[j] = nw1;
-            gmax = fmaxf(fabsf(nb0), fabsf(nw1));
-        }
-        if (rb == 0) {
-            __syncthreads();
-            float s0 = 0.0f;
-            for (int b2 = tid; b2 < B; b2 += kThreads) s0 += dq_s[b2];
-            s0 = rpo_wave_sum(s0);
-            if (o == 0) partial[part][0][0] = s0;
-            __syncthreads();
-            if (tid == 0) {
-                const float nb1 = gr.b1[0] + (((partial[0][0][0] + partial[1][0][0]) + partial[2][0][0]) + partial[3][0][0]);
-                gr.b1[0] = nb1;
-                gmax = fmaxf(gmax, fabsf(nb1));
-            }
+            if (row0 + r < B) p.dx0[k][xo] = x0v > 0.0f ? v : 0.0f;
         }
     }
-    gradmax_flush(p.gradmax, gmax);
 }
 
-// ---- bwd_b: first-layer gradients dWs / dbs / dWa / dba of critic k = blockIdx.y from dx0 (batch reduction, one owner per
-//      output, fixed order): the first-layer branch of mlp_bwd_weights_body.
+// ---- bwd_b: every parameter gradient of critic k = blockIdx.y.  blocks [0, 36): dW0 tiles and hidden-layer vectors from
+//      dLoss/dQ (left by bwd_a) and the saved activations, dh formed on the fly; then the first-layer gradients dWs / dbs /
+//      dWa / dba from dx0 (batch reduction, one owner per output, fixed order).  Leaves the inf-norm of what it wrote.
 template <class L>
 __global__ __launch_bounds__(kThreads) void split_critic_bwd_b_kernel(SplitArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * 16 * 16];
     const int k = blockIdx.y;
+    if (blockIdx.x < kWeightBlocks) {
+        if ((p.dbg == 6 && blockIdx.x >= kW0Tiles) || (p.dbg == 7 && blockIdx.x < kW0Tiles) || p.dbg == 8) return;
+        gradmax_flush(p.gradmax, ns_weight_role(p.critic[k], p.critic_grad[k], p.h1[k], p.x0[k], p.dq[k], 1, false, p.B,
+                                                blockIdx.x, smem));
+        return;
+    }
+    if (p.dbg == 9) return;
     BwdArgs a{};
     a.net = p.critic[k];
     a.g = p.critic_grad[k];
@@ -450,7 +473,7 @@ __global__ __launch_bounds__(kThreads) void split_critic_bwd_b_kernel(SplitArgs 
     a.dx0 = p.dx0[k];
     a.param_grads = 1;
     a.first_layer_state_only = 0;
-    gradmax_flush(p.gradmax, mlp_bwd_first_layer<128>(a, blockIdx.x));
+    gradmax_flush(p.gradmax, mlp_bwd_first_layer<128>(a, blockIdx.x - kWeightBlocks));
 }
 
 }  // namespace
@@ -666,6 +689,9 @@ __global__ __launch_bounds__(kThreads) void split_policy_c_kernel(SplitArgs p) {
 #pragma unroll
     for (int r = 0; r < kRows; ++r) hv[r] = row0 + r < B ? p.h1[k][(size_t)(row0 + r) * H + tid] : 0.0f;
     const float w1a = net.W1[tid];
+    const size_t xo = (size_t)(row0 + (tid >> 4)) * EIN + g * 16 + (tid & 15);
+    const float x0v = row0 + (tid >> 4) < B ? p.x0[k][xo] : 0.0f;
+    const float2 wa2 = *reinterpret_cast<const float2*>(&net.Wa[(g * 16 + (tid & 15)) * 2]);
     if (tid < 64) {
         float dq = 0.0f, term = 0.0f;
         if (tid < kRows && row0 + tid < B) dq = ns_policy_dq(p, k, row0 + tid, &term);
@@ -690,12 +716,10 @@ __global__ __launch_bounds__(kThreads) void split_policy_c_kernel(SplitArgs p) {
         v = wpart[(2 * 16 + r) * 16 + ee] + v;
         v = wpart[(3 * 16 + r) * 16 + ee] + v;
         const bool live = row0 + r < B;
-        const size_t o = (size_t)(row0 + r) * EIN + g * 16 + ee;
-        v = (live && p.x0[k][o] > 0.0f) ? v : 0.0f;
-        if (live) p.dx0[k][o] = v;
+        v = (live && x0v > 0.0f) ? v : 0.0f;
+        if (live) p.dx0[k][xo] = v;
         // this group's share of d/d action: sum over its 16 columns (fixed butterfly), 2 action components
-        const int col = g * 16 + ee;
-        float d0 = v * net.Wa[col * 2], d1 = v * net.Wa[col * 2 + 1];
+        float d0 = v * wa2.x, d1 = v * wa2.y;
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) { d0 += __shfl_xor(d0, off, 64); d1 += __shfl_xor(d1, off, 64); }
         if (ee == 0 && live)
@@ -734,18 +758,17 @@ __device__ __forceinline__ float2 ns_policy_dout(const SplitArgs& p, const CartC
                                                       p.base), 0.0f);
 }
 
-// ---- pol_d: actor backward.  blocks [0, T*8): dx0 column groups; then 32 dW0 tiles; then 4 hidden-vector blocks.
+// ---- pol_d: d loss / d (actor head outputs) of the tile's rows -> actor dx0 of one (row tile, 16 first-layer columns);
+//      the column-group-0 workgroup of a tile leaves the rows' head gradients for pol_e.  blocks (row tile, group).
 template <class ENV>
 __global__ __launch_bounds__(kThreads) void split_policy_d_kernel(SplitArgs p, CartConsts c) {
     constexpr int EIN = 128, H = 256, LDH = H + 4;
-    __shared__ __attribute__((aligned(16))) float smem[4 * 16 * 64 + 2 * kBwdMaxB + 256];
-    const int T = (p.B + kRows - 1) / kRows, B = p.B;
+    __shared__ __attribute__((aligned(16))) float smem[kRows * LDH + 32 + 4 * 16 * 16];
+    const int B = p.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     const Mlp& net = p.actor;
-    const MlpGrad& gr = p.actor_grad;
-    int b = blockIdx.x;
-    float gmax = 0.0f;
-    if (b < T * kNsGroups) {
+    const int b = blockIdx.x;
+    {
         const int tile = b / kNsGroups, g = b - tile * kNsGroups, row0 = tile * kRows;
         float* dh_s = smem;
         float* do_s = smem + kRows * LDH;                          // [16][2]
@@ -757,14 +780,16 @@ __global__ __launch_bounds__(kThreads) void split_policy_d_kernel(SplitArgs p, C
 #pragma unroll
         for (int r = 0; r < kRows; ++r) hv[r] = row0 + r < B ? p.h1_a[(size_t)(row0 + r) * H + tid] : 0.0f;
         const float w1a = net.W1[tid], w1b = net.n_out > 1 ? net.W1b[tid] : 0.0f;
+        const size_t xo = (size_t)(row0 + (tid >> 4)) * EIN + g * 16 + (tid & 15);
+        const bool xlive = row0 + (tid >> 4) < B;
+        const float x0v = xlive ? p.x0_a[xo] : 0.0f;
+        float cdx = 0.0f;                                          // the critics' dx0 under a shared state embedding
+        if (xlive && p.shared_embedding) cdx = p.twin ? p.dx0[0][xo] + p.dx0[1][xo] : p.dx0[0][xo];
         if (tid < kRows) {
             float2 d = make_float2(0.0f, 0.0f);
             if (row0 + tid < B) {
                 d = ns_policy_dout<ENV>(p, c, row0 + tid);
-                if (g == 0) {
-                    if (p.twin) reinterpret_cast<float2*>(p.dout)[row0 + tid] = d;
-                    else p.dout[row0 + tid] = d.x;
-                }
+                if (g == 0) reinterpret_cast<float2*>(p.dout)[row0 + tid] = d;      // [B, 2] for both head types
             }
             do_s[tid * 2] = d.x; do_s[tid * 2 + 1] = d.y;
         }
@@ -785,158 +810,30 @@ __global__ __launch_bounds__(kThreads) void split_policy_d_kernel(SplitArgs p, C
             v = wpart[(1 * 16 + r) * 16 + ee] + v;
             v = wpart[(2 * 16 + r) * 16 + ee] + v;
             v = wpart[(3 * 16 + r) * 16 + ee] + v;
-            if (row0 + r < B) {
-                const size_t o = (size_t)(row0 + r) * EIN + g * 16 + ee;
-                v = p.x0_a[o] > 0.0f ? v : 0.0f;
+            if (xlive) {
+                v = x0v > 0.0f ? v : 0.0f;
                 // shared state embedding: ONE first-layer reduction yields its gradient from both losses' dx0
-                if (p.shared_embedding) v += p.twin ? p.dx0[0][o] + p.dx0[1][o] : p.dx0[0][o];
-                p.dx0_a[o] = v;
-            }
-        }
-        return;
-    }
-    b -= T * kNsGroups;
-    float* do0_s = smem + 4 * 16 * 64;
-    float* do1_s = do0_s + kBwdMaxB;
-    for (int i = tid; i < B; i += kThreads) {
-        const float2 d = ns_policy_dout<ENV>(p, c, i);
-        do0_s[i] = d.x; do1_s[i] = d.y;
-    }
-    __syncthreads();
-    if (b < 32) {
-        float (*tile)[16 * 64] = reinterpret_cast<float (*)[16 * 64]>(smem);
-        const int jt = b / (EIN / 64), et = b - jt * (EIN / 64);
-        const int j = jt * 16 + li, e0 = et * 64 + li * 4;
-        const float w1a = net.W1[j], w1b = net.n_out > 1 ? net.W1b[j] : 0.0f;
-        f32x4 acc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        const int nk = (B + 3) / 4;
-        const int ks_lo = (nk * wave) / 4, ks_hi = (nk * (wave + 1)) / 4;
-        const int last = B - 1;
-        int ks = ks_lo;
-        for (; ks + 4 <= ks_hi; ks += 4) {
-            float av[4];
-            float4 bv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int bb = (ks + u) * 4 + lg;
-                const int bc = bb < last ? bb : last;
-                const float h = p.h1_a[(size_t)bc * H + j];
-                av[u] = (h > 0.0f) ? fmaf(do1_s[bc], w1b, do0_s[bc] * w1a) : 0.0f;
-                bv[u] = *reinterpret_cast<const float4*>(&p.x0_a[(size_t)bc * EIN + e0]);
-                if (bb > last) av[u] = 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc[0] = mfma4(av[u], fmaxf(bv[u].x, 0.0f), acc[0]);
-                acc[1] = mfma4(av[u], fmaxf(bv[u].y, 0.0f), acc[1]);
-                acc[2] = mfma4(av[u], fmaxf(bv[u].z, 0.0f), acc[2]);
-                acc[3] = mfma4(av[u], fmaxf(bv[u].w, 0.0f), acc[3]);
-            }
-        }
-        for (; ks < ks_hi; ++ks) {
-            const int bb = ks * 4 + lg;
-            const int bc = bb < last ? bb : last;
-            const float h = p.h1_a[(size_t)bc * H + j];
-            float av = (h > 0.0f) ? fmaf(do1_s[bc], w1b, do0_s[bc] * w1a) : 0.0f;
-            const float4 b4 = *reinterpret_cast<const float4*>(&p.x0_a[(size_t)bc * EIN + e0]);
-            if (bb > last) av = 0.0f;
-            acc[0] = mfma4(av, fmaxf(b4.x, 0.0f), acc[0]);
-            acc[1] = mfma4(av, fmaxf(b4.y, 0.0f), acc[1]);
-            acc[2] = mfma4(av, fmaxf(b4.z, 0.0f), acc[2]);
-            acc[3] = mfma4(av, fmaxf(b4.w, 0.0f), acc[3]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(&tile[wave][(lg * 4 + i) * 64 + li * 4]) =
-                make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
-        __syncthreads();
-        {
-            const int r = tid >> 4, c4 = (tid & 15) * 4;
-            const float4 t0 = *reinterpret_cast<const float4*>(&tile[0][r * 64 + c4]);
-            const float4 t1 = *reinterpret_cast<const float4*>(&tile[1][r * 64 + c4]);
-            const float4 t2 = *reinterpret_cast<const float4*>(&tile[2][r * 64 + c4]);
-            const float4 t3 = *reinterpret_cast<const float4*>(&tile[3][r * 64 + c4]);
-            float4* dst = reinterpret_cast<float4*>(&gr.W0[(size_t)(jt * 16 + r) * EIN + et * 64 + c4]);
-            float4 cur = *dst;
-            cur.x += ((t0.x + t1.x) + t2.x) + t3.x;
-            cur.y += ((t0.y + t1.y) + t2.y) + t3.y;
-            cur.z += ((t0.z + t1.z) + t2.z) + t3.z;
-            cur.w += ((t0.w + t1.w) + t2.w) + t3.w;
-            *dst = cur;
-            gmax = fmaxf(fmaxf(fabsf(cur.x), fabsf(cur.y)), fmaxf(fabsf(cur.z), fabsf(cur.w)));
-        }
-    } else {
-        const int rb = b - 32;
-        float (*partial)[3][64] = reinterpret_cast<float (*)[3][64]>(smem);
-        const int o = tid & 63, part = tid >> 6;
-        const int b_lo = (int)(((long long)B * part) / 4), b_hi = (int)(((long long)B * (part + 1)) / 4);
-        const int j = rb * 64 + o;
-        const float w1a = net.W1[j], w1b = net.n_out > 1 ? net.W1b[j] : 0.0f;
-        float gb0 = 0.0f, gw1a = 0.0f, gw1b = 0.0f;
-        int bb = b_lo;
-        for (; bb + 8 <= b_hi; bb += 8) {                          // 8 rows of loads in flight (a plain loop exposes each)
-            float h[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) h[u] = p.h1_a[(size_t)(bb + u) * H + j];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                gb0 += (h[u] > 0.0f) ? fmaf(do1_s[bb + u], w1b, do0_s[bb + u] * w1a) : 0.0f;
-                const float hr = fmaxf(h[u], 0.0f);
-                gw1a = fmaf(do0_s[bb + u], hr, gw1a);
-                gw1b = fmaf(do1_s[bb + u], hr, gw1b);
-            }
-        }
-        for (; bb < b_hi; ++bb) {
-            const float h = p.h1_a[(size_t)bb * H + j];
-            gb0 += (h > 0.0f) ? fmaf(do1_s[bb], w1b, do0_s[bb] * w1a) : 0.0f;
-            const float hr = fmaxf(h, 0.0f);
-            gw1a = fmaf(do0_s[bb], hr, gw1a);
-            gw1b = fmaf(do1_s[bb], hr, gw1b);
-        }
-        partial[part][0][o] = gb0; partial[part][1][o] = gw1a; partial[part][2][o] = gw1b;
-        __syncthreads();
-        if (part == 0) {
-            const float nb0 = gr.b0[j] + (((partial[0][0][o] + partial[1][0][o]) + partial[2][0][o]) + partial[3][0][o]);
-            const float nw1 = gr.W1[j] + (((partial[0][1][o] + partial[1][1][o]) + partial[2][1][o]) + partial[3][1][o]);
-            gr.b0[j] = nb0;
-            gr.W1[j] = nw1;
-            gmax = fmaxf(fabsf(nb0), fabsf(nw1));
-            if (net.n_out > 1) {
-                const float nw1b = gr.W1b[j] + (((partial[0][2][o] + partial[1][2][o]) + partial[2][2][o]) + partial[3][2][o]);
-                gr.W1b[j] = nw1b;
-                gmax = fmaxf(gmax, fabsf(nw1b));
-            }
-        }
-        if (rb == 0) {
-            __syncthreads();
-            float s0 = 0.0f, s1 = 0.0f;
-            for (int b2 = tid; b2 < B; b2 += kThreads) { s0 += do0_s[b2]; s1 += do1_s[b2]; }
-            s0 = rpo_wave_sum(s0);
-            s1 = rpo_wave_sum(s1);
-            if (o == 0) { partial[part][0][0] = s0; partial[part][1][0] = s1; }
-            __syncthreads();
-            if (tid == 0) {
-                const float nb1 = gr.b1[0] + (((partial[0][0][0] + partial[1][0][0]) + partial[2][0][0]) + partial[3][0][0]);
-                gr.b1[0] = nb1;
-                gmax = fmaxf(gmax, fabsf(nb1));
-                if (net.n_out > 1) {
-                    const float nb1b = gr.b1b[0] + (((partial[0][1][0] + partial[1][1][0]) + partial[2][1][0]) + partial[3][1][0]);
-                    gr.b1b[0] = nb1b;
-                    gmax = fmaxf(gmax, fabsf(nb1b));
-                }
+                if (p.shared_embedding) v += cdx;
+                p.dx0_a[xo] = v;
             }
         }
     }
-    gradmax_flush(p.gradmax, gmax);
 }
 
-// ---- pol_e: actor first-layer gradients from dx0_a; one more workgroup folds the Lagrangian partials (value, d/d nu)
+// ---- pol_e: every parameter gradient of the actor.  blocks [0, 36): dW0 tiles and hidden-layer vectors from the rows' head
+//      gradients (left by pol_d) and the saved activations; then the first-layer gradients from dx0_a; one more workgroup
+//      folds the Lagrangian partials (value, d/d nu).
 template <class ENV>
 __global__ __launch_bounds__(kThreads) void split_policy_e_kernel(SplitArgs p, int fl_blocks) {
     typedef typename ENV::L L;
-    if ((int)blockIdx.x == fl_blocks) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * 16 * 16];
+    if (blockIdx.x < kWeightBlocks) {
+        gradmax_flush(p.gradmax, ns_weight_role(p.actor, p.actor_grad, p.h1_a, p.x0_a, p.dout, 2, p.actor.n_out > 1, p.B,
+                                                blockIdx.x, smem));
+        return;
+    }
+    const int fb = blockIdx.x - kWeightBlocks;
+    if (fb == fl_blocks) {
         const int tid = threadIdx.x, T = (p.B + kRows - 1) / kRows;
         if (tid < 8) {
             float sacc = 0.0f;
@@ -955,7 +852,7 @@ __global__ __launch_bounds__(kThreads) void split_policy_e_kernel(SplitArgs p, i
     a.s = p.batch_out; a.s_stride = L::ROW;
     a.dx0 = p.dx0_a;
     a.param_grads = 1;
-    gradmax_flush(p.gradmax, mlp_bwd_first_layer<128>(a, blockIdx.x));
+    gradmax_flush(p.gradmax, mlp_bwd_first_layer<128>(a, fb));
 }
 
 }  // namespace
@@ -1033,6 +930,8 @@ int to_args(const rpo_split_update* u, unsigned need, SplitArgs& a, CartConsts& 
     a.ap_det = u->ap_det; a.noise_out = u->noise_out; a.raw = u->raw; a.actions = u->actions; a.g_act = u->g_act;
     a.lag_partial = u->lag_partial; a.lag_out = u->lag_out; a.da_part = u->da_part; a.dout = u->dout;
     a.shared_embedding = u->shared_embedding;
+    const char* dbg = getenv("RPO_SPLIT_DBG");
+    a.dbg = dbg ? atoi(dbg) : 0;
     return 0;
 }
 
@@ -1087,12 +986,12 @@ int rpo_split_pend_head_project(const rpo_split_update* u, void* stream) {
 
 int rpo_split_critic_bwd_a(const rpo_split_update* u, void* stream) {
     SplitArgs a; CartConsts c;
-    if (int e = to_args(u, 2u | 4u | 8u, a, c)) return e;
+    if (int e = to_args(u, 2u | 4u, a, c)) return e;
     const int K = a.twin ? 2 : 1, T = (a.B + kRows - 1) / kRows;
     if (!a.batch_out || !a.loss_partial || (a.twin && !a.logp)) return RPO_ERR_NULL;
     for (int k = 0; k < K; ++k)
         if (!a.part_q[k] || !a.part_qn[k] || !a.x0[k] || !a.h1[k] || !a.dq[k] || !a.dx0[k]) return RPO_ERR_NULL;
-    const int grid = K * T * kNsGroups + K * 32 + K * 4;
+    const int grid = K * T * kNsGroups;
     if (u->env == 0) hipLaunchKernelGGL(split_critic_bwd_a_kernel<CartRow>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(split_critic_bwd_a_kernel<PendRow>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a);
     RPO_LAUNCH_CHECK();
@@ -1105,9 +1004,9 @@ int rpo_split_critic_bwd_b(const rpo_split_update* u, void* stream) {
     const int K = a.twin ? 2 : 1;
     if (!a.batch_out) return RPO_ERR_NULL;
     for (int k = 0; k < K; ++k)
-        if (!a.dx0[k]) return RPO_ERR_NULL;
+        if (!a.dx0[k] || !a.dq[k] || !a.x0[k] || !a.h1[k]) return RPO_ERR_NULL;
     const Mlp& m = a.critic[0];
-    const int blocks = (m.E * (m.S + 1 + m.A + 1) + 63) / 64;
+    const int blocks = kWeightBlocks + mlp_fl_blocks(m.E * (m.S + 1 + m.A + 1));
     if (u->env == 0) hipLaunchKernelGGL(split_critic_bwd_b_kernel<CartRow>, dim3(blocks, K), dim3(kThreads), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(split_critic_bwd_b_kernel<PendRow>, dim3(blocks, K), dim3(kThreads), 0, (hipStream_t)stream, a);
     RPO_LAUNCH_CHECK();
@@ -1165,7 +1064,7 @@ int rpo_split_policy_d(const rpo_split_update* u, void* stream) {
     if (a.shared_embedding)
         for (int k = 0; k < K; ++k)
             if (!a.dx0[k]) return RPO_ERR_NULL;
-    const int grid = T * kNsGroups + 32 + 4;
+    const int grid = T * kNsGroups;
     if (u->env == 0) hipLaunchKernelGGL(split_policy_d_kernel<CartPol>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a, c);
     else hipLaunchKernelGGL(split_policy_d_kernel<PendPol>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a, c);
     RPO_LAUNCH_CHECK();
@@ -1175,10 +1074,10 @@ int rpo_split_policy_d(const rpo_split_update* u, void* stream) {
 int rpo_split_policy_e(const rpo_split_update* u, void* stream) {
     SplitArgs a; CartConsts c;
     if (int e = to_args(u, 32u | 16u, a, c)) return e;
-    if (!a.batch_out || !a.dx0_a || !a.lag_partial || !a.lag_out || !a.nu_grad) return RPO_ERR_NULL;
-    const int fl_blocks = (a.actor.E * (a.actor.S + 1) + 63) / 64;
-    if (u->env == 0) hipLaunchKernelGGL(split_policy_e_kernel<CartPol>, dim3(fl_blocks + 1), dim3(kThreads), 0, (hipStream_t)stream, a, fl_blocks);
-    else hipLaunchKernelGGL(split_policy_e_kernel<PendPol>, dim3(fl_blocks + 1), dim3(kThreads), 0, (hipStream_t)stream, a, fl_blocks);
+    if (!a.batch_out || !a.dx0_a || !a.lag_partial || !a.lag_out || !a.nu_grad || !a.dout || !a.x0_a || !a.h1_a) return RPO_ERR_NULL;
+    const int fl_blocks = mlp_fl_blocks(a.actor.E * (a.actor.S + 1));
+    if (u->env == 0) hipLaunchKernelGGL(split_policy_e_kernel<CartPol>, dim3(kWeightBlocks + fl_blocks + 1), dim3(kThreads), 0, (hipStream_t)stream, a, fl_blocks);
+    else hipLaunchKernelGGL(split_policy_e_kernel<PendPol>, dim3(kWeightBlocks + fl_blocks + 1), dim3(kThreads), 0, (hipStream_t)stream, a, fl_blocks);
     RPO_LAUNCH_CHECK();
     return 0;
 }

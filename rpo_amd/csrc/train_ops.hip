@@ -92,12 +92,19 @@ __device__ __forceinline__ void adam_body(const AdamArgs& p) {
             p.target[i] = p.target[i] * (1.0f - p.tau) + p.param[i] * p.tau;
         return;
     }
-    // torch.optim.Adam (single-tensor path): bias corrections in double like torch's Python floats
+    // torch.optim.Adam (single-tensor path): bias corrections in double like torch's Python floats.  The two double-
+    // precision pow() calls are ~1 us of every thread's critical path, so the workgroup that finishes a step last leaves
+    // the corrections of the NEXT step behind the arrival word (step_dev + 4: {1 - beta1^t, sqrt(1 - beta2^t)} as doubles,
+    // 0.0 = not cached yet): same functions, same arguments, same bits -- computed once instead of 34 000 times.
     const int step = p.step_dev[0] + 1;
-    const double bc1 = 1.0 - pow((double)p.beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)p.beta2, (double)step);
+    double* cache = reinterpret_cast<double*>(p.step_dev + 4);
+    double bc1 = cache[0], bc2s = cache[1];
+    if (bc1 == 0.0) {
+        bc1 = 1.0 - pow((double)p.beta1, (double)step);
+        bc2s = sqrt(1.0 - pow((double)p.beta2, (double)step));
+    }
     const float step_size = (float)((double)p.lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
+    const float bc2_sqrt = (float)bc2s;
     float coef = 1.0f;
     if (p.clip_thres > 0.0f) {   // clip_grad_norm_(..., norm_type=inf): clip_coef clamped to 1, always applied
         coef = fminf(p.clip_thres / (p.gradmax[0] + 1e-6f), 1.0f);
@@ -126,6 +133,8 @@ __device__ __forceinline__ void adam_body(const AdamArgs& p) {
         if (arrived == (unsigned long long)gridDim.x - 1ull) {
             *p.arrive = 0;
             p.step_dev[0] = step;
+            cache[0] = 1.0 - pow((double)p.beta1, (double)(step + 1));
+            cache[1] = sqrt(1.0 - pow((double)p.beta2, (double)(step + 1)));
             if (p.reset_gradmax && p.gradmax) p.gradmax[0] = 0.0f;
         }
     }
@@ -218,7 +227,8 @@ int rpo_adam_step(long long n, float* param, float* grad, float* exp_avg, float*
     if (n <= 0) return RPO_ERR_ARG;
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return RPO_ERR_NULL;
     if (clip_thres > 0.0f && !gradmax) return RPO_ERR_NULL;
-    // the arrival word lives right behind the step counter: step_dev must point at int32[4] = {step, pad, arrive(8 B)}
+    // the arrival word lives right behind the step counter: step_dev must point at int32[8] = {step, pad, arrive (8 B),
+    // cached bias corrections of the next step (2 doubles)}
     AdamArgs a{n, param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, weight_decay, maximize,
                clip_thres, gradmax, reset_gradmax, zero_grad, clamp_min0, target, tau,
                reinterpret_cast<long long*>(step_dev + 2), nullptr, 0, 0};
