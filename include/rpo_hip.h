@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RPO_ABI_VERSION 1
+#define RPO_ABI_VERSION 2
 
 #define RPO_ERR_ARG (-1)
 #define RPO_ERR_NULL (-2)
@@ -299,7 +299,11 @@ int rpo_absmax(long long n, const float* x, float* max_out, void* stream);
 int rpo_adam_step(long long n, float* param, float* grad, float* exp_avg, float* exp_avg_sq, int* step_dev,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int maximize, float clip_thres,
                   float* gradmax, int reset_gradmax, int zero_grad, int clamp_min0, float* target, float tau,
-                  void* stream);
+                  long long* clock, void* stream);
+/*   clock (may be NULL): a device counter advanced by one when the launch has finished.  The trainers use it as the
+ *   UPDATE clock: the update kernels read their step index from it instead of ctrl[RPO_CTRL_T], so that the next
+ *   rollout -- which advances ctrl[RPO_CTRL_T] -- may run concurrently with the update (another stream of the same
+ *   hipGraph) without the update seeing the counter move. */
 
 /* Up to four independent optimiser slices in ONE launch (gridDim.y = slice): the tail of a policy step is
  * actor Adam + multiplier DualAdam + the Polyak update of the critic target (rpo_ddpg.py:197-205), three launches of a
@@ -323,7 +327,7 @@ typedef struct {
     long long n2;
     int polyak_only;
 } rpo_adam_seg;
-int rpo_adam_step_multi(int count, const rpo_adam_seg* segs, void* stream);
+int rpo_adam_step_multi(int count, const rpo_adam_seg* segs, long long* clock, void* stream);
 
 /* soft_update alone (agent/ddpg_pa.py:77-86, sac_pa.py:87-91): target = (1 - tau) * target + tau * param. */
 int rpo_polyak(long long n, const float* param, float* target, float tau, void* stream);

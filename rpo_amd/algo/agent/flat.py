@@ -96,14 +96,16 @@ class FusedAdam(object):
         # trainers switch it on when every backward of the iteration goes through the accumulating MLP kernels
         self.zero_grad_after = False
 
-    def step(self, target=None, tau=0.0, gradmax_ready=False):
-        """``gradmax_ready``: the backward pass already left the inf-norm of this slice in ``self.gradmax``."""
+    def step(self, target=None, tau=0.0, gradmax_ready=False, clock=None):
+        """``gradmax_ready``: the backward pass already left the inf-norm of this slice in ``self.gradmax``.
+        ``clock``: device counter the launch advances when it has finished (the trainers' update clock)."""
         clip = self.clip_thres if self.clip_thres and self.clip_thres != float("inf") else 0.0
         if clip > 0 and not gradmax_ready:
             self.backend.absmax(self.grad, self.gradmax)
+        kw = {} if clock is None else dict(clock=clock)
         self.backend.adam_step(self.param, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr,
                                self.betas[0], self.betas[1], self.eps, self.weight_decay, self.maximize, clip,
-                               self.gradmax, True, self.clamp_min0, target, tau, zero_grad=self.zero_grad_after)
+                               self.gradmax, True, self.clamp_min0, target, tau, zero_grad=self.zero_grad_after, **kw)
 
     def segment(self, target=None, tau=0.0, gradmax_ready=False, target2=None, n2=0):
         """This optimiser's step as one slice of ``step_many`` (the inf-norm launch, when needed, happens here)."""
@@ -117,17 +119,19 @@ class FusedAdam(object):
                     target2=target2, n2=n2)
 
     @staticmethod
-    def step_many(backend, segs):
+    def step_many(backend, segs, clock=None):
         """Several non-overlapping slices (``segment()`` dicts or ``dict(polyak_only=True, param=, target=, tau=)``) in
-        one launch where the backend has rpo_adam_step_multi; one launch each otherwise."""
+        one launch where the backend has rpo_adam_step_multi; one launch each otherwise.  ``clock`` rides on slice 0."""
         if hasattr(backend, "adam_step_multi") and 1 < len(segs) <= 4:
-            return backend.adam_step_multi(segs)
-        for g in segs:
+            return backend.adam_step_multi(segs, **({} if clock is None else dict(clock=clock)))
+        for i, g in enumerate(segs):
             if g.get("polyak_only"):
                 backend.polyak(g["param"], g["target"], g["tau"])
                 continue
             g = dict(g)
             param, t2, n2 = g.pop("param"), g.pop("target2", None), g.pop("n2", 0)
+            if clock is not None and i == 0:
+                g["clock"] = clock
             backend.adam_step(param, g.pop("grad"), g.pop("exp_avg"), g.pop("exp_avg_sq"), g.pop("step_dev"), g.pop("lr"),
                               **g)
             if t2 is not None and n2 > 0:

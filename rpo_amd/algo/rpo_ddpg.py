@@ -266,7 +266,7 @@ class RPODDPG(RPOTrainerBase):
         ag = self.agent
         fuse = actor_step and ag.flat.sizes[1] == 0
         ag.critic_optim.step(target=ag.critic_target_flat if fuse else None, tau=ag.tau,
-                             gradmax_ready=self._gradmax_ready)
+                             gradmax_ready=self._gradmax_ready, clock=self._clock(not actor_step))
         self._gradmax_ready = False
 
     def _actor_step(self, actor_out):
@@ -284,4 +284,4 @@ class RPODDPG(RPOTrainerBase):
             segs.append(ag.nju_optim.segment())                    # lambda is never stepped (rpo_ddpg.py:202)
         if sh > 0 and c > 0:
             segs.append(dict(polyak_only=True, param=fl.param((0, c)), target=ag.critic_target_flat[:c], tau=ag.tau))
-        FusedAdam.step_many(self.backend, segs)
+        FusedAdam.step_many(self.backend, segs, clock=self._clock(True))

@@ -299,9 +299,9 @@ class RPOSAC(RPOTrainerBase):
         self._fused_polyak = ag.flat.sizes[1] == 0
         ready, self._gradmax_ready = self._gradmax_ready, False
         if self._fused_polyak:
-            ag.critic_optim.step(target=ag.critic_target_flat, tau=ag.tau, gradmax_ready=ready)
+            ag.critic_optim.step(target=ag.critic_target_flat, tau=ag.tau, gradmax_ready=ready, clock=self._clock(not actor_step))
             return
-        ag.critic_optim.step(gradmax_ready=ready)
+        ag.critic_optim.step(gradmax_ready=ready, clock=self._clock(not actor_step))
         if not actor_step:
             ag.soft_update()
 
@@ -313,6 +313,6 @@ class RPOSAC(RPOTrainerBase):
             segs.append(ag.nju_optim.segment())
         if self.automatic_entropy_tuning:
             segs.append(ag.alpha_optim.segment())               # rpo_sac.py:210-216, gradient left by _actor_update
-        FusedAdam.step_many(self.backend, segs)                 # actor Adam | multiplier DualAdam (| log_alpha): one launch
+        FusedAdam.step_many(self.backend, segs, clock=self._clock(True))   # actor Adam | DualAdam (| log_alpha): one launch
         if not self._fused_polyak:
             ag.soft_update()

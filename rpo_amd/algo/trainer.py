@@ -236,6 +236,13 @@ class RPOTrainerBase(object):
             opt.zero_grad_after = self._self_cleaning
         # fused multi-output actor: raw outputs, the env's projection kernel applies the state-dependent tanh box
         self._act_kw = dict(ap_is_raw=True) if (self.fused is not None and self._box_affine is None) else {}
+        # Update clock: the update kernels of the column-split path read their step index from `_uctrl[0]` instead of
+        # ctrl[RPO_CTRL_T], and the iteration's last optimiser launch advances it -- so the NEXT rollout (which advances
+        # ctrl[RPO_CTRL_T]) may run on another stream of the same hipGraph while the update is still going.  Without the
+        # split path it is an alias of the rollout's ctrl and nothing changes.
+        self._uctrl, self._uclock_ok, self._after_front, self._ovl_stream = self.vec.ctrl, True, None, None
+        self._bump = self.updates_per_step == 1
+        self._split_state()
         self._t = 0                 # loop iterations (== vector steps) done
         self._harvested = 0         # vector steps whose statistics were already pulled off the device
         self._pending = []          # per-step rows waiting for the return of the episodes they belong to
@@ -380,11 +387,28 @@ class RPOTrainerBase(object):
     def _critic_step(self, actor_step):
         raise NotImplementedError
 
+    def _clock(self, last):
+        """`clock=` argument of the optimiser launch that ends the iteration's update (``last``), see `_uctrl`."""
+        return self._uctrl if (last and self._bump and self._uctrl is not self.vec.ctrl) else None
+
+    def _sync_uclock(self, rollout_pending):
+        """Set the update clock to the number of vector steps the next update must see (eagerly, outside any capture):
+        needed whenever the previous iteration did not end with a clock-advancing optimiser launch."""
+        if self._uctrl is self.vec.ctrl or self._uclock_ok:
+            return
+        if rollout_pending:
+            torch.add(self.vec.ctrl[0:1], 1, out=self._uctrl[0:1])
+        else:
+            self._uctrl[0:1].copy_(self.vec.ctrl[0:1])
+
     def _actor_step(self, actor_out):
         raise NotImplementedError
 
     def _iteration(self, warm, do_train, actor_step, rollout=True):
         segs = self._segments(warm, do_train, actor_step, rollout)
+        if do_train:
+            self._sync_uclock(rollout_pending=rollout)
+        self._uclock_ok = do_train and self._bump
         if not self.dist.on or self.dist.in_graph:
             self._graphs.run((warm, do_train, actor_step, rollout), lambda: self._run_segments(segs))
             return
@@ -417,7 +441,7 @@ class RPOTrainerBase(object):
             self._graphs.run(tail[0], tail[1])
 
     def _extra_body(self, actor_step):
-        self.vec.ctrl[hip_ops.CONST["RPO_CTRL_UPDATES"]] += 1
+        self._uctrl[hip_ops.CONST["RPO_CTRL_UPDATES"]] += 1
         cols = self._sample()
         self._critic_update(cols)
         fl = self.agent.flat
@@ -450,6 +474,16 @@ class RPOTrainerBase(object):
 
     def train(self, t):
         """One constrained policy update at loop index ``t`` (rpo_ddpg.py:163-205), eagerly, without a rollout."""
+        self._uclock_ok = False
+        self._sync_uclock(rollout_pending=False)                # the update sees the vector steps taken so far
+        bump, self._bump = self._bump, False                    # ... and leaves the clock alone
+        try:
+            self._train_body(t)
+        finally:
+            self._bump = bump
+            self._uclock_ok = False
+
+    def _train_body(self, t):
         cols = self._sample()
         self._critic_update(cols)
         fl = self.agent.flat
@@ -470,7 +504,8 @@ class RPOTrainerBase(object):
             return self._split_cache
         self._split_cache = None
         f, k, be = self.fused, self.kernels, self.backend
-        if f is None or not hasattr(be, "SplitUpdate") or not _env_int("RPO_SPLIT", 1) or self._box_affine is None:
+        if f is None or not hasattr(be, "SplitUpdate") or not _env_int("RPO_SPLIT", 1) or self._box_affine is None \
+                or self.device.type != "cuda":
             return None
         if not isinstance(k, (be.CartSafeKernels, be.PendulumKernels)) or self.batch_size > 1024:
             return None
@@ -484,6 +519,7 @@ class RPOTrainerBase(object):
         B, ag, buf = self.batch_size, self.agent, self.buffer
         T = (B + 15) // 16
         b = f.buf
+        self._uctrl, self._uclock_ok = torch.zeros_like(self.vec.ctrl), False
         descs = dict(actor=d["actor"])
         if self.sac:
             descs.update(critic1=d["critic1"], critic2=d["critic2"], critic_target1=d["critic_target1"],
@@ -494,7 +530,7 @@ class RPOTrainerBase(object):
         c1 = "critic1" if self.sac else "critic"
         fields = dict(
             rows=buf.rows, cap_steps=buf.capacity, n_envs=buf.n_envs, batch_out=self._batch, sample_seed=buf.seed,
-            sample_salt=0, noise_seed=self.seed, noise_id_base=self.dist.rank * B, noise_salt=_SALT_CRITIC, ctrl=buf.ctrl,
+            sample_salt=0, noise_seed=self.seed, noise_id_base=self.dist.rank * B, noise_salt=_SALT_CRITIC, ctrl=self._uctrl,
             scale=scale, base=base, box_lo=self._box_lo, box_hi=self._box_hi, max_steps=self.max_steps,
             corr_lr=self.corr_lr, corr_eps=self.corr_eps, corr_momentum=self.corr_momentum,
             alpha=float(getattr(ag, "alpha", 0.0)), gamma=ag.gamma, eps_start=self.eps_start, eps_end=self.eps,
@@ -529,7 +565,7 @@ class RPOTrainerBase(object):
         noise_in = None
         if self._idx_inject is not None:                          # tests replay the reference's draw
             self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * B * k.partial_dim, _SALT_ACTOR,
-                                       hip_ops.STREAM_POLICY, self.vec.ctrl)
+                                       hip_ops.STREAM_POLICY, self._uctrl)
             noise_in = self._noise_b.view(-1)
         crit_logp, pi_logp = self._split_logp
         su.set(noise_salt=_SALT_ACTOR, eps_in=noise_in, logp=pi_logp)
@@ -555,10 +591,13 @@ class RPOTrainerBase(object):
         if inject and self.sac:
             B = self.batch_size
             self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * B * self.kernels.partial_dim, _SALT_CRITIC,
-                                       hip_ops.STREAM_POLICY, self.vec.ctrl)
+                                       hip_ops.STREAM_POLICY, self._uctrl)
             eps_in = self._noise_b.view(-1)
-        su.set(idx_in=idx_in, eps_in=eps_in)
+        buf = self.buffer
+        su.set(idx_in=idx_in, eps_in=eps_in, rows=buf.rows, cap_steps=buf.capacity, n_envs=buf.n_envs)   # (tests swap the ring)
         su.run("critic_fwd_a")
+        if self._after_front is not None:                       # overlapped windows: the next rollout forks off here
+            self._after_front()
         if su.st.env == 1:
             su.run("pend_head_project")
         su.run("critic_fwd_b")
@@ -621,14 +660,20 @@ class RPOTrainerBase(object):
                 if self.updates_per_step > 1:
                     self._flush_tail()
                     self._extra_updates()
-                    self.vec.ctrl[hip_ops.CONST["RPO_CTRL_UPDATES"]] = 0
+                    self._uctrl[hip_ops.CONST["RPO_CTRL_UPDATES"]] = 0
                 left -= 1
                 continue
             if L > 1:
                 # one hipGraph for L consecutive iterations (policy_fre-periodic launch pattern): the same launches
                 # in the same order as L single-iteration replays, minus L - 1 graph-to-graph gaps (8.5 us each)
-                self._graphs.run(("cycle", L, do_train), lambda: [self._run_segments(self._segments(
-                    False, do_train, do_train and (t + i + 1) % self.policy_fre == 0)) for i in range(L)])
+                if do_train:
+                    self._sync_uclock(rollout_pending=True)
+                self._uclock_ok = do_train and self._bump
+                if self._overlap_ok(do_train):
+                    self._graphs.run(("cycle", L, True, "overlap"), lambda: self._overlapped_window(t, L))
+                else:
+                    self._graphs.run(("cycle", L, do_train), lambda: [self._run_segments(self._segments(
+                        False, do_train, do_train and (t + i + 1) % self.policy_fre == 0)) for i in range(L)])
                 self._updates += L if do_train else 0
             else:
                 self._iteration(warm, do_train, actor_step)
@@ -637,7 +682,7 @@ class RPOTrainerBase(object):
                     if self.updates_per_step > 1:
                         self._flush_tail()
                         self._extra_updates()
-                        self.vec.ctrl[hip_ops.CONST["RPO_CTRL_UPDATES"]] = 0
+                        self._uctrl[hip_ops.CONST["RPO_CTRL_UPDATES"]] = 0
             for _ in range(L):
                 t = t + 1
                 self._advance_host(t)
@@ -656,6 +701,51 @@ class RPOTrainerBase(object):
         self.buffer.note_step()
         self.agent.eps_decay(self.decay_value, self.eps)
         self.vec.steps_host = t
+
+    def _overlap_ok(self, do_train):
+        """Rollout t+1 may run beside the update of t (on a second stream of the window's hipGraph) when the update does
+        not touch what the rollout reads -- no shared state embedding, and not on policy steps -- and the update reads
+        its own clock (`_uctrl`).  Results are identical either way.  OFF unless ``RPO_OVERLAP=1``: on one MI355X the
+        fork / join of the second graph branch costs more than the 16 us rollout it hides (cart-SAC 75.7 vs 71.0 us per
+        iteration, measured); it is kept for data-parallel runs, where the branch would hide the all-reduce as well."""
+        return (do_train and self._uctrl is not self.vec.ctrl and self.agent.flat.sizes[1] == 0 and self._bump
+                and self._rollout_pipeline and bool(_env_int("RPO_OVERLAP", 0)) and self.device.type == "cuda")
+
+    def _overlapped_window(self, t, L):
+        """L iterations (t is a policy_fre boundary) with rollout i+1 forked off right after the sampling launch of update i
+        -- the gather must see the ring before the next rollout overwrites its oldest slot -- and joined before update
+        i+1 samples.  After a policy step the next rollout waits for the new actor (serial)."""
+        F, fl = self.policy_fre, self.agent.flat
+        main = torch.cuda.current_stream()
+        if self._ovl_stream is None:
+            self._ovl_stream = torch.cuda.Stream()
+        side = self._ovl_stream
+        self._rollout(False)
+        for i in range(L):
+            actor_step = (t + i + 1) % F == 0
+            more = i + 1 < L
+            overlap = more and not actor_step
+
+            def fork():
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._rollout(False)
+            self._after_front = fork if overlap else None
+            try:
+                cols = self._last_cols = self._sample()
+                self._critic_update(cols)
+            finally:
+                self._after_front = None
+            self.dist.mean_([fl.gradient(fl.critic_range)])
+            self._critic_step(actor_step)
+            if actor_step:
+                self._last_actor_out = self._actor_update(cols)
+                self.dist.mean_([fl.gradient(fl.policy_bucket)])
+                self._actor_step(self._last_actor_out)
+            if overlap:
+                main.wait_stream(side)
+            elif more:
+                self._rollout(False)
 
     def _cycle_len(self, t, left, warm, do_train, eval):
         """Iterations the next launch may cover: RPO_GRAPH_CYCLE (default 16, rounded to a multiple of policy_fre) in the
@@ -842,6 +932,7 @@ class RPOTrainerBase(object):
         if st["rows"] is not None:
             b.rows[:st["rows"].shape[0]].copy_(st["rows"])
         self._t = self._harvested = int(st["t"])
+        self._uclock_ok = False
         self._updates = int(st["updates"])
         b._steps_host = v.steps_host = self._t
         self._pending = list(st["pending"])

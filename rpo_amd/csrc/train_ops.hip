@@ -84,6 +84,7 @@ struct AdamArgs {
     float* target2;      // second Polyak target for elements [0, n2)
     long long n2;
     int polyak_only;
+    long long* clock;    // NULL, or a device counter advanced by one when the launch has finished (update clock)
 };
 
 __device__ __forceinline__ void adam_body(const AdamArgs& p) {
@@ -136,6 +137,7 @@ __device__ __forceinline__ void adam_body(const AdamArgs& p) {
             cache[0] = 1.0 - pow((double)p.beta1, (double)(step + 1));
             cache[1] = sqrt(1.0 - pow((double)p.beta2, (double)(step + 1)));
             if (p.reset_gradmax && p.gradmax) p.gradmax[0] = 0.0f;
+            if (p.clock) p.clock[0] += 1;
         }
     }
 }
@@ -223,7 +225,7 @@ int rpo_absmax(long long n, const float* x, float* max_out, void* stream) {
 int rpo_adam_step(long long n, float* param, float* grad, float* exp_avg, float* exp_avg_sq, int* step_dev,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int maximize, float clip_thres,
                   float* gradmax, int reset_gradmax, int zero_grad, int clamp_min0, float* target, float tau,
-                  void* stream) {
+                  long long* clock, void* stream) {
     if (n <= 0) return RPO_ERR_ARG;
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return RPO_ERR_NULL;
     if (clip_thres > 0.0f && !gradmax) return RPO_ERR_NULL;
@@ -231,13 +233,13 @@ int rpo_adam_step(long long n, float* param, float* grad, float* exp_avg, float*
     // cached bias corrections of the next step (2 doubles)}
     AdamArgs a{n, param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, weight_decay, maximize,
                clip_thres, gradmax, reset_gradmax, zero_grad, clamp_min0, target, tau,
-               reinterpret_cast<long long*>(step_dev + 2), nullptr, 0, 0};
+               reinterpret_cast<long long*>(step_dev + 2), nullptr, 0, 0, clock};
     hipLaunchKernelGGL(adam_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, a);
     RPO_LAUNCH_CHECK();
     return 0;
 }
 
-int rpo_adam_step_multi(int count, const rpo_adam_seg* segs, void* stream) {
+int rpo_adam_step_multi(int count, const rpo_adam_seg* segs, long long* clock, void* stream) {
     if (count < 1 || count > 4) return RPO_ERR_ARG;
     if (!segs) return RPO_ERR_NULL;
     AdamArgs4 a;
@@ -247,7 +249,7 @@ int rpo_adam_step_multi(int count, const rpo_adam_seg* segs, void* stream) {
         if (g.n <= 0 || g.n2 < 0 || g.n2 > g.n) return RPO_ERR_ARG;
         if (!g.param) return RPO_ERR_NULL;
         if (g.polyak_only) {
-            if (!g.target) return RPO_ERR_NULL;
+            if (!g.target || (k == 0 && clock)) return RPO_ERR_NULL;     // the clock rides on slice 0's arrival counter
         } else {
             if (!g.grad || !g.exp_avg || !g.exp_avg_sq || !g.step_dev) return RPO_ERR_NULL;
             if (g.clip_thres > 0.0f && !g.gradmax) return RPO_ERR_NULL;
@@ -255,7 +257,7 @@ int rpo_adam_step_multi(int count, const rpo_adam_seg* segs, void* stream) {
         a.seg[k] = AdamArgs{g.n, g.param, g.grad, g.exp_avg, g.exp_avg_sq, g.step_dev, g.lr, g.beta1, g.beta2, g.eps,
                             g.weight_decay, g.maximize, g.clip_thres, g.gradmax, g.reset_gradmax, g.zero_grad, g.clamp_min0,
                             g.target, g.tau, g.polyak_only ? nullptr : reinterpret_cast<long long*>(g.step_dev + 2),
-                            g.target2, g.n2, g.polyak_only};
+                            g.target2, g.n2, g.polyak_only, (k == 0 && !g.polyak_only) ? clock : nullptr};
         n_max = g.n > n_max ? g.n : n_max;
     }
     hipLaunchKernelGGL(adam_multi_kernel, dim3(rpo_grid_for(n_max), count), dim3(RPO_BLOCK), 0, (hipStream_t)stream, a);

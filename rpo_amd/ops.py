@@ -116,13 +116,14 @@ def absmax(x, max_out):
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
               maximize=False, clip_thres=0.0, gradmax=None, reset_gradmax=True, clamp_min0=False, target=None,
-              tau=0.0, zero_grad=False):
+              tau=0.0, zero_grad=False, clock=None):
     if step_dev.numel() < 8:
         raise RpoHipError("step_dev must be int32[8]: {step, pad, arrival word, cached bias corrections} (include/rpo_hip.h)")
     check(_lib.load().rpo_adam_step(param.numel(), _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq),
                                     _p(step_dev, torch.int32), lr, beta1, beta2, eps, weight_decay, int(maximize),
                                     clip_thres, _p(gradmax, allow_none=True), int(reset_gradmax), int(zero_grad), int(clamp_min0),
-                                    _p(target, allow_none=True), tau, _stream()), "rpo_adam_step")
+                                    _p(target, allow_none=True), tau, _p(clock, torch.int64, allow_none=True), _stream()),
+          "rpo_adam_step")
 
 
 class _AdamSegStruct(ctypes.Structure):
@@ -135,7 +136,7 @@ class _AdamSegStruct(ctypes.Structure):
                 ("target2", ctypes.c_void_p), ("n2", ctypes.c_longlong), ("polyak_only", ctypes.c_int)]
 
 
-def adam_step_multi(segs):
+def adam_step_multi(segs, clock=None):
     """One launch for up to four non-overlapping optimiser slices (rpo_adam_step_multi).  Each entry is a dict with the
     keyword arguments of ``adam_step`` (+ ``target2`` / ``n2``), or ``dict(polyak_only=True, param=, target=, tau=)``."""
     arr = (_AdamSegStruct * len(segs))()
@@ -154,7 +155,8 @@ def adam_step_multi(segs):
         a.weight_decay, a.maximize, a.clip_thres = g.get("weight_decay", 0.0), int(g.get("maximize", False)), g.get("clip_thres", 0.0)
         a.gradmax, a.reset_gradmax = vp(g.get("gradmax")), int(g.get("reset_gradmax", True))
         a.zero_grad, a.clamp_min0 = int(g.get("zero_grad", False)), int(g.get("clamp_min0", False))
-    check(_lib.load().rpo_adam_step_multi(len(segs), arr, _stream()), "rpo_adam_step_multi")
+    check(_lib.load().rpo_adam_step_multi(len(segs), arr, _p(clock, torch.int64, allow_none=True), _stream()),
+          "rpo_adam_step_multi")
 
 
 def polyak(param, target, tau):

@@ -513,3 +513,32 @@ def test_split_update_equals_row_tile_pipelines(hip, algo, envname, monkeypatch)
     np.testing.assert_allclose(a.agent.nju.weight.detach().cpu().numpy(), b.agent.nju.weight.detach().cpu().numpy(), rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(float(a.last_losses["critic"]), float(b.last_losses["critic"]), rtol=1e-4)
     np.testing.assert_allclose(float(a.last_losses["actor"]), float(b.last_losses["actor"]), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("algo,envname", [("sac", "cart"), ("ddpg", "pendulum"), ("sac", "pendulum")])
+def test_overlapped_rollout_equals_serial(hip, algo, envname, monkeypatch):
+    """Inside a multi-iteration hipGraph the rollout of step t+1 runs on a second stream beside the update of step t (no
+    shared embedding; forked after the sampling launch, joined before the next one; serial after policy steps).  The
+    update reads its own clock, so nothing it sees moves: 70 iterations equal the serial order bit for bit."""
+    dev = torch.device("cuda")
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
+    monkeypatch.setenv("RPO_OVERLAP", "1")
+    a = _run(algo, envname, hip, dev, 70, 300, use_graph=True)
+    assert a._overlap_ok(True) and a._graphs.entries[("cycle", 8, True, "overlap")]["graph"] is not None
+    monkeypatch.setenv("RPO_OVERLAP", "0")
+    b = _run(algo, envname, hip, dev, 70, 300, use_graph=True)
+    assert ("cycle", 8, True, "overlap") not in b._graphs.entries
+    c = _run(algo, envname, hip, dev, 70, 300, use_graph=False)
+    for other in (b, c):
+        assert torch.equal(a.vec.internal, other.vec.internal)
+        assert torch.equal(a.buffer.rows, other.buffer.rows)
+        assert torch.equal(a.agent.flat.data, other.agent.flat.data)
+        assert torch.equal(a.agent.critic_target_flat, other.agent.critic_target_flat)
+        assert torch.equal(a.agent.nju.weight, other.agent.nju.weight)
+        assert torch.equal(a.vec.stats[:70], other.vec.stats[:70])
+    assert int(a._uctrl[0]) == 71 and int(a.vec.ctrl[0]) == 70       # the update clock runs one ahead between iterations
+    # a full ring: the fork sits behind the gather, so the rollout never overwrites a slot the sampler still reads
+    d = _run(algo, envname, hip, dev, 70, 64, use_graph=True, capacity=5)
+    monkeypatch.setenv("RPO_OVERLAP", "1")
+    e = _run(algo, envname, hip, dev, 70, 64, use_graph=True, capacity=5)
+    assert torch.equal(d.agent.flat.data, e.agent.flat.data) and torch.equal(d.buffer.rows, e.buffer.rows)
