@@ -220,17 +220,19 @@ __global__ __launch_bounds__(kNsThreads) void split_critic_fwd_b_kernel(SplitArg
 }
 
 // ---- SpringPendulum: head of the policy + the reference's batch-coupled projection (pendulum.py:337-339), one workgroup
+template <int LPS>
 __global__ __launch_bounds__(1024) void split_pend_head_project_kernel(SplitArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int i = threadIdx.x;
+    const int i = threadIdx.x / LPS;
     float ap = 0.0f;
     if (i < p.B) {
         float logp = 0.0f;
         ap = ns_policy_head(p, i, p.ctrl[RPO_CTRL_T], &logp);
-        if (p.twin) p.logp[i] = logp;
+        if (p.twin && threadIdx.x % LPS == 0) p.logp[i] = logp;
     }
-    rpo_pend_dev::project_batchref_body(p.B, i < p.B ? p.batch_out + (size_t)i * RPO_PEND_ROW + PendRow::NS_OFF : nullptr, ap,
-                                        p.next_actions, p.proj_iters, p.max_steps, p.corr_lr, p.corr_eps, p.corr_momentum, lds);
+    rpo_pend_dev::project_batchref_body<LPS>(p.B, i < p.B ? p.batch_out + (size_t)i * RPO_PEND_ROW + PendRow::NS_OFF : nullptr,
+                                             ap, p.next_actions, p.proj_iters, p.max_steps, p.corr_lr, p.corr_eps,
+                                             p.corr_momentum, lds);
 }
 
 // ---- TD target + Huber for row i of critic k from the slab partials (rpo_ddpg.py:331-335, rpo_sac.py:346-353)
@@ -978,8 +980,13 @@ int rpo_split_pend_head_project(const rpo_split_update* u, void* stream) {
     if (u->env != 1 || a.max_steps < 0) return RPO_ERR_ARG;
     if (!a.batch_out || !a.ctrl || !a.part_pi || !a.next_actions || (a.twin && !a.logp)) return RPO_ERR_NULL;
     const size_t lds = ((size_t)a.B + 4) * sizeof(float);
-    const int threads = (a.B + RPO_WAVE - 1) / RPO_WAVE * RPO_WAVE;
-    hipLaunchKernelGGL(split_pend_head_project_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, a);
+    if (a.B <= 256) {
+        const int threads = (a.B * 4 + RPO_WAVE - 1) / RPO_WAVE * RPO_WAVE;
+        hipLaunchKernelGGL(split_pend_head_project_kernel<4>, dim3(1), dim3(threads), lds, (hipStream_t)stream, a);
+    } else {
+        const int threads = (a.B + RPO_WAVE - 1) / RPO_WAVE * RPO_WAVE;
+        hipLaunchKernelGGL(split_pend_head_project_kernel<1>, dim3(1), dim3(threads), lds, (hipStream_t)stream, a);
+    }
     RPO_LAUNCH_CHECK();
     return 0;
 }

@@ -90,13 +90,14 @@ __global__ __launch_bounds__(RPO_BLOCK) void pendulum_act_project_kernel(ActArgs
 //   grad_i = sum_j 1[a_x,i * dgp_j - bgp_i > 0] * dgp_j      (:337-339),
 // and the loop's stop test is one max over the whole batch (rpo_ddpg.py:271-272).  This kernel reproduces exactly that
 //  for the update step's target projection; one workgroup owns the batch, dgp lives in LDS.
+template <int LPS>
 __global__ __launch_bounds__(1024) void pendulum_project_batchref_kernel(
     int n, const float* __restrict__ obs, int obs_stride, const float* __restrict__ ap, float* __restrict__ action,
     int* __restrict__ iters_out, int max_steps, float corr_lr, float corr_eps, float corr_momentum) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // dgp[n] | stop flag
-    const int i = threadIdx.x;                                     // one sample per thread, n <= blockDim.x <= 1024
-    project_batchref_body(n, i < n ? obs + (size_t)i * obs_stride : nullptr, i < n ? ap[i] : 0.0f, action, iters_out,
-                          max_steps, corr_lr, corr_eps, corr_momentum, lds);
+    const int i = threadIdx.x / LPS;                               // LPS lanes per sample, n * LPS <= blockDim.x <= 1024
+    project_batchref_body<LPS>(n, i < n ? obs + (size_t)i * obs_stride : nullptr, i < n ? ap[i] : 0.0f, action, iters_out,
+                               max_steps, corr_lr, corr_eps, corr_momentum, lds);
 }
 
 __global__ __launch_bounds__(RPO_BLOCK) void pendulum_complete_bwd_kernel(int n, const float* __restrict__ obs,
@@ -218,9 +219,15 @@ int rpo_pendulum_project_batchref(int n, const float* obs, int obs_stride, const
     if (n <= 0 || n > 1024 || max_steps < 0 || obs_stride < RPO_PEND_OBS_DIM) return RPO_ERR_ARG;
     if (!obs || !ap || !action) return RPO_ERR_NULL;
     const size_t lds = ((size_t)n + 4) * sizeof(float);
-    const int threads = (n + RPO_WAVE - 1) / RPO_WAVE * RPO_WAVE;
-    hipLaunchKernelGGL(pendulum_project_batchref_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, n, obs,
-                       obs_stride, ap, action, iters_out, max_steps, corr_lr, corr_eps, corr_momentum);
+    if (n <= 256) {                                                // 4 lanes per sample (see project_batchref_body)
+        const int threads = (n * 4 + RPO_WAVE - 1) / RPO_WAVE * RPO_WAVE;
+        hipLaunchKernelGGL(pendulum_project_batchref_kernel<4>, dim3(1), dim3(threads), lds, (hipStream_t)stream, n, obs,
+                           obs_stride, ap, action, iters_out, max_steps, corr_lr, corr_eps, corr_momentum);
+    } else {
+        const int threads = (n + RPO_WAVE - 1) / RPO_WAVE * RPO_WAVE;
+        hipLaunchKernelGGL(pendulum_project_batchref_kernel<1>, dim3(1), dim3(threads), lds, (hipStream_t)stream, n, obs,
+                           obs_stride, ap, action, iters_out, max_steps, corr_lr, corr_eps, corr_momentum);
+    }
     RPO_LAUNCH_CHECK();
     return 0;
 }

@@ -421,44 +421,56 @@ def gen_train_steps_la():
 
 # ---------------------------------------------------------------------------------------------- training statistics
 
-def gen_training_stats(steps=3000, seeds=(0, 1, 2, 3, 4)):
-    """Returns / constraint-violation statistics of short reference training runs (scripts/cart_exp.py and
-    scripts/pen_exp_sac.py hyper-parameters, `steps` loop iterations, eval off) -- the statistical side of parity:
-    violation rate = fraction of env steps with max(max_ineq, max_eq) > 1e-3."""
+def _stats_run(job):
+    """One reference training run (worker of gen_training_stats): returns the row of seed statistics."""
     import io
     import contextlib
-    for algo, envname in (("ddpg", "cart"), ("sac", "pendulum")):
-        rows = []
-        for seed in seeds:
-            np.random.seed(123 + seed)
-            torch.manual_seed(123 + seed)
-            env = REF.gym.make("CartSafe-v0" if envname == "cart" else "SpringPendulum-v0")
-            env.seed(1000 + seed)
-            if envname == "cart" and int(env.partial_actions[0]) != 1:
-                env = None
-                for s in range(64):
-                    np.random.seed(s)
-                    e = REF.gym.make("CartSafe-v0")
-                    if int(e.partial_actions[0]) == 1:
-                        env = e
-                        env.seed(1000 + seed)
-                        break
-                np.random.seed(123 + seed)
-            logger = REF.Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=steps)
-            cls = REF.RPODDPG if algo == "ddpg" else REF.RPOSAC
-            tr = cls(env, "/tmp", name="g", logger=logger, batch_size=256, max_steps=10, warmup=0, eps_epoch=20000,
-                     eval_steps=50, grad_eps=0.1, corr_momentum=0.0, policy_fre=4, max_epochs=steps, capacity=20000,
-                     value_type="add", clip_thres=0.2, embed_dim=128, hidden_dim=256, lr_actor=1e-4, lr_critic=3e-4,
-                     device=torch.device("cpu"), **SCRIPT_HP[(algo, envname)])
-            with contextlib.redirect_stdout(io.StringIO()):
-                tr.run(eval=False)
-            n = logger.pointer
-            mi, me, rw = logger.tracker["max_ineq"][:n], logger.tracker["max_eq"][:n], logger.tracker["reward"][:n]
-            viol = np.maximum(mi, me) > 1e-3
-            rows.append([n, viol.mean(), mi.mean(), me.mean(), rw.mean(), rw[n // 2:].mean(),
-                         float(tr.agent.nju.weight.detach().abs().max())])
-            print(algo, envname, "seed", seed, rows[-1])
-        save("training_stats_%s_%s" % (algo, envname), stats=np.array(rows), steps=steps,
+    algo, envname, seed, steps = job
+    torch.set_num_threads(1)
+    np.random.seed(123 + seed)
+    torch.manual_seed(123 + seed)
+    env = REF.gym.make("CartSafe-v0" if envname == "cart" else "SpringPendulum-v0")
+    env.seed(1000 + seed)
+    if envname == "cart" and int(env.partial_actions[0]) != 1:
+        env = None
+        for s in range(64):
+            np.random.seed(s)
+            e = REF.gym.make("CartSafe-v0")
+            if int(e.partial_actions[0]) == 1:
+                env = e
+                env.seed(1000 + seed)
+                break
+        np.random.seed(123 + seed)
+    logger = REF.Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=steps)
+    cls = REF.RPODDPG if algo == "ddpg" else REF.RPOSAC
+    tr = cls(env, "/tmp", name="g", logger=logger, batch_size=256, max_steps=10, warmup=0, eps_epoch=20000,
+             eval_steps=50, grad_eps=0.1, corr_momentum=0.0, policy_fre=4, max_epochs=steps, capacity=20000,
+             value_type="add", clip_thres=0.2, embed_dim=128, hidden_dim=256, lr_actor=1e-4, lr_critic=3e-4,
+             device=torch.device("cpu"), **SCRIPT_HP[(algo, envname)])
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.run(eval=False)
+    n = logger.pointer
+    mi, me, rw = logger.tracker["max_ineq"][:n], logger.tracker["max_eq"][:n], logger.tracker["reward"][:n]
+    viol = np.maximum(mi, me) > 1e-3
+    return [n, viol.mean(), mi.mean(), me.mean(), rw.mean(), rw[n // 2:].mean(), float(tr.agent.nju.weight.detach().abs().max())]
+
+
+def gen_training_stats(steps=3000, n_seeds=None, workers=8):
+    """Returns / constraint-violation statistics of short reference training runs (scripts/cart_exp.py and
+    scripts/pen_exp_sac.py hyper-parameters, `steps` loop iterations, eval off) -- the statistical side of parity:
+    violation rate = fraction of env steps with max(max_ineq, max_eq) > 1e-3.  The seed-to-seed spread of
+    the rate is ~3.3e-3 for cart-RPODDPG at this budget, so 96 seeds put the standard error of the reference mean at
+    ~3.4e-4: together with a larger number of GPU runs the comparison resolves the north_star's 1e-3 at two sigma.
+    SpringPendulum-RPOSAC violates ~5e-4 of the steps with a spread of ~5e-4: 24 seeds are ample."""
+    import multiprocessing as mp
+    plan = n_seeds or {("ddpg", "cart"): 96, ("sac", "pendulum"): 24}
+    for (algo, envname), count in plan.items():
+        jobs = [(algo, envname, seed, steps) for seed in range(count)]
+        with mp.get_context("fork").Pool(workers) as pool:
+            rows = pool.map(_stats_run, jobs, chunksize=1)
+        rows = np.array(rows)
+        print(algo, envname, "mean", rows.mean(0), "se", rows.std(0) / np.sqrt(len(rows)))
+        save("training_stats_%s_%s" % (algo, envname), stats=rows, steps=steps,
              columns=np.array(["logged_steps", "viol_rate", "mean_max_ineq", "mean_max_eq", "mean_return_per_step",
                                "mean_return_second_half", "max_nu"]))
 

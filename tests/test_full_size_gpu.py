@@ -1,0 +1,176 @@
+"""Size-independent properties at BASELINE.json's full sizes for the configs that have no oracle run at that size:
+config 3 (SpringPendulum-v0, RPOSAC, 4096 lanes) and config 5 (EVOPF-v0, RPODDPG, 1024 lanes) -- the analogues of
+tests/test_kernels_gpu.py::test_cart_full_size_properties, through the shipped trainers with bench.py's exact
+hyper-parameters (scripts/pen_exp_sac.py, scripts/evopf_exp.py) and the hipGraph windows of the bench.
+
+Checked over 80 whole iterations (rollout -> projection -> step -> scatter -> sample -> update):
+  * the replay ring holds exactly the transitions that were stepped: row (t, lane) continues row (t - 1, lane) -- its
+    state equals the previous next_state -- unless the lane's episode ended there, in which case it restarts inside the
+    env's reset box; rows are finite and the ring is full up to the step counter and untouched beyond it;
+  * every stored action satisfies the equality constraints to the solver's tolerance (the stored eq_viol column is what
+    env.step recomputes from (state, action): rpo/env/.../pendulum.py:128, evopf.py:366), and the stored inequality
+    violations are the distances of the stored action recomputed by the constraint kernel;
+  * the device-side statistics (violation counter, reward sums, episode counts) equal what the ring rows give;
+  * lanes are a pure function of (seed, env id): one rollout of all lanes == two half-size rollouts with env_id_base
+    offsets (the rank layout of the data-parallel run), bit for bit;
+  * replayed hipGraph windows == eager launches, bit for bit, at this size.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+DEV = torch.device("cuda")
+T = 80            # 5 windows of 16 iterations: three eager passes, the capture, one replay
+
+
+def run(workload, n, use_graph, iters=T, capacity=96):
+    import bench
+    os.environ["RPO_VERBOSE"] = "0"
+    tr = bench.make_trainer(n, DEV, 10 ** 9, capacity=capacity, workload=workload, use_graph=use_graph)
+    tr.vec.reset()
+    first = tr.vec.internal.clone()
+    tr.run_steps(iters)
+    tr._harvest(final=True)
+    torch.cuda.synchronize()
+    return tr, first
+
+
+def ring(tr, iters=T):
+    n = tr.n_local
+    rows = tr.buffer.rows[: iters * n].view(iters, n, -1)
+    c = tr.kernels.cols
+    return rows, {k: rows[:, :, lo:hi] for k, (lo, hi) in c.items()}
+
+
+def check_chain(cols, reset_ok):
+    """state[t] == next_state[t - 1] for lanes that did not finish at t - 1; restarted lanes are inside the reset box."""
+    s, ns, done = cols["state"], cols["next_state"], cols["done"][:, :, 0]
+    cont = done[:-1] == 0
+    same = (s[1:] == ns[:-1]).all(dim=2)
+    assert bool(same[cont].all()), "a continuing lane's state is not the previous next_state"
+    restarted = s[1:][~cont]
+    if restarted.numel():
+        assert bool(reset_ok(restarted).all()), "a restarted lane is outside the reset box"
+    return int((~cont).sum())
+
+
+def test_pendulum_sac_4096_lanes_properties():
+    from rpo_amd import ops
+    n = 4096
+    g, first = run("pen_sac", n, use_graph=True)
+    assert g.fused is not None and g._split_state() is not None and any(
+        k[0] == "cycle" and e["graph"] is not None for k, e in g._graphs.entries.items() if isinstance(k, tuple))
+    rows, cols = ring(g)
+    assert bool(torch.isfinite(rows).all()) and float(g.buffer.rows[T * n:].abs().max()) == 0.0
+    assert int(g.vec.ctrl[0]) == T
+    # trajectory continuity; pendulum obs = (cos, sin, theta_dot, l, l_dot): reset box of pendulum.py:131-133
+    def reset_ok(s):
+        th = torch.atan2(s[:, 1], s[:, 0])
+        return (th.abs() <= np.pi / 12 + 1e-6) & (s[:, 2].abs() <= 1 + 1e-6) & (s[:, 3] >= 0.95 - 1e-6) & \
+               (s[:, 3] <= 1.05 + 1e-6) & (s[:, 4].abs() <= 0.05 + 1e-6)
+    ended = check_chain(cols, reset_ok)
+    assert ended > 0                                             # some lanes did finish within 80 steps
+    # equalities hold for every stored action; stored violations == the constraint kernel on (state, action)
+    assert float(cols["eq_viol"].abs().max()) < 2e-5
+    flat_s = cols["state"].reshape(-1, 5).contiguous()
+    flat_a = cols["action"].reshape(-1, 2).contiguous()
+    eq = torch.zeros(flat_a.shape[0], device=DEV)
+    ineq = torch.zeros(flat_a.shape[0], device=DEV)
+    g.kernels.resid(flat_s, flat_a, eq, ineq)
+    np.testing.assert_allclose(eq.cpu().numpy(), cols["eq_viol"].reshape(-1).cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(ineq.clamp(min=0).cpu().numpy(), cols["ineq_viol"].reshape(-1).cpu().numpy(), atol=2e-5)
+    # projection: |a|^2 <= 32 up to what 10 GRG steps of lr 2e-3 leave; never a NaN, and mostly feasible
+    assert float((cols["ineq_viol"] <= 1e-3).float().mean()) > 0.95
+    # statistics == ring
+    S = ops.STAT
+    st = ops.reduce_stats(g.vec.stats[:T]).cpu().numpy()
+    viol = (torch.maximum(cols["ineq_viol"].max(dim=2).values, cols["eq_viol"].abs().max(dim=2).values) > 1e-3)
+    np.testing.assert_array_equal(st[:, S["viol_count"]], viol.sum(dim=1).cpu().numpy().astype(np.float32))
+    np.testing.assert_allclose(st[:, S["reward_sum"]], cols["reward"][:, :, 0].sum(dim=1).cpu().numpy(), rtol=1e-5)
+    np.testing.assert_array_equal(st[:, S["episodes"]], cols["done"][:, :, 0].sum(dim=1).cpu().numpy())
+    assert abs(g.viol_rate - float(viol.float().mean())) < 1e-9 and g.env_steps == T * n
+    # hipGraph windows == eager launches, at this size
+    e, _ = run("pen_sac", n, use_graph=False)
+    assert torch.equal(g.buffer.rows, e.buffer.rows) and torch.equal(g.agent.flat.data, e.agent.flat.data)
+    assert torch.equal(g.vec.internal, e.vec.internal) and torch.equal(g.agent.nju.weight, e.agent.nju.weight)
+    # rank layout: the first vector step of lanes [0, n) == two launches of n / 2 lanes with env_id_base offsets
+    from rpo_amd.env.vec import VecEnv
+    k = g.kernels
+    whole = VecEnv(k, n, DEV, seed=g.seed, env_id_base=0, max_episode_steps=200)
+    whole.reset()
+    assert torch.equal(whole.internal, first)
+    halves = [VecEnv(k, n // 2, DEV, seed=g.seed, env_id_base=b, max_episode_steps=200) for b in (0, n // 2)]
+    for h in halves:
+        h.reset()
+    assert torch.equal(torch.cat([h.internal for h in halves]), first)
+    ap = torch.linspace(-7, 7, n, device=DEV)
+    for v, lo in ((whole, 0), (halves[0], 0), (halves[1], n // 2)):
+        k.act_project(v.obs, ap[lo:lo + v.n].contiguous(), None, v.action, None, ops.NOISE_PHILOX, 0.5, 0.5, 0.0, -6.0, 6.0,
+                      10, 2e-3, 1e-5, 0.0, v.seed, v.env_id_base, v.ctrl, None)
+        v.step(v.action)
+    assert torch.equal(whole.internal, torch.cat([h.internal for h in halves]))
+    assert torch.equal(whole.action, torch.cat([h.action for h in halves]))
+
+
+def test_evopf_ddpg_1024_lanes_properties():
+    from rpo_amd import ops
+    n = 1024
+    g, first = run("evopf_ddpg", n, use_graph=True)
+    rows, cols = ring(g)
+    assert bool(torch.isfinite(rows).all()) and float(g.buffer.rows[T * n:].abs().max()) == 0.0
+    assert int(g.vec.ctrl[0]) == T
+    # 24-hour episodes: every lane finishes exactly at step 23 (0-based) and restarts with fresh batteries (soc 0.2)
+    done = cols["done"][:, :, 0]
+    ends = [23, 47, 71]
+    assert all(bool((done[t] == 1).all()) for t in ends) and float(done.sum()) == 3.0 * n
+    s, ns = cols["state"], cols["next_state"]
+    cont = torch.ones(T - 1, dtype=torch.bool, device=DEV)
+    cont[ends] = False
+    assert bool((s[1:][cont] == ns[:-1][cont]).all())
+    assert float((s[24, :, 28:33] - 0.2).abs().max()) < 1e-6
+    # Newton power flow: the 28 equalities of every stored action hold to the solver's tolerance (GRG drift included:
+    # DESIGN 4b E1 reports <= 3e-3 after 10 projection steps)
+    assert float(cols["eq_viol"].abs().max()) < 5e-3
+    assert float(cols["eq_viol"].abs().mean()) < 2e-4
+    # stored violations == the constraint kernel on (state, action)
+    flat_s = s.reshape(-1, s.shape[2]).contiguous()
+    flat_a = cols["action"].reshape(-1, cols["action"].shape[2]).contiguous()
+    m = flat_a.shape[0]
+    eq = torch.zeros(m, 28, device=DEV)
+    ineq = torch.zeros(m, 58, device=DEV)
+    g.kernels.resid(flat_s, flat_a, eq, ineq)
+    np.testing.assert_allclose(eq.cpu().numpy(), cols["eq_viol"].reshape(m, 28).cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(ineq.clamp(min=0).cpu().numpy(), cols["ineq_viol"].reshape(m, 58).cpu().numpy(), atol=2e-5)
+    # statistics == ring
+    S = ops.STAT
+    st = ops.reduce_stats(g.vec.stats[:T]).cpu().numpy()
+    viol = (torch.maximum(cols["ineq_viol"].max(dim=2).values, cols["eq_viol"].abs().max(dim=2).values) > 1e-3)
+    np.testing.assert_array_equal(st[:, S["viol_count"]], viol.sum(dim=1).cpu().numpy().astype(np.float32))
+    np.testing.assert_allclose(st[:, S["reward_sum"]], cols["reward"][:, :, 0].sum(dim=1).cpu().numpy(), rtol=2e-5)
+    np.testing.assert_array_equal(st[:, S["episodes"]], done.sum(dim=1).cpu().numpy())
+    # hipGraph replay == eager at this size
+    e, _ = run("evopf_ddpg", n, use_graph=False)
+    assert torch.equal(g.buffer.rows, e.buffer.rows) and torch.equal(g.agent.flat.data, e.agent.flat.data)
+    # rank layout: lanes are a pure function of (seed, env id)
+    from rpo_amd.env.vec import VecEnv
+    k = g.kernels
+    whole = VecEnv(k, n, DEV, seed=g.seed, env_id_base=0)
+    whole.reset()
+    assert torch.equal(whole.internal, first)
+    halves = [VecEnv(k, n // 2, DEV, seed=g.seed, env_id_base=b) for b in (0, n // 2)]
+    for h in halves:
+        h.reset()
+    assert torch.equal(torch.cat([h.internal for h in halves]), first)
+    for v in (whole, halves[0], halves[1]):
+        k.act_project(v.obs, None, None, v.action, None, ops.NOISE_UNIFORM, 0.0, 0.0, 0.0, 0.0, 0.0, 10, 1e-4, 1e-5, 0.0,
+                      v.seed, v.env_id_base, v.ctrl, None)
+        v.step(v.action)
+    assert torch.equal(whole.internal, torch.cat([h.internal for h in halves]))
+    assert torch.equal(whole.action, torch.cat([h.action for h in halves]))

@@ -1,14 +1,18 @@
 """Statistical parity with the reference's CPU runs (north_star: returns and constraint-violation rate).
 
-tests/golden/training_stats_*.npz hold, for 5 seeds each, the statistics of 3000-iteration training runs of the
-unmodified reference (scripts/cart_exp.py and scripts/pen_exp_sac.py hyper-parameters).  The same runs are repeated here
-with the shipped trainers at num_envs = 1 -- the reference's cadence, step for step -- on the HIP kernels.  Random
-streams differ (Philox vs numpy/torch global generators) and trajectories are chaotic, so the comparison is between
-seed-averaged statistics: violation rate = fraction of env steps with max(max_ineq, max_eq) > 1e-3.
+tests/golden/training_stats_*.npz hold the statistics of 3000-iteration training runs of the unmodified reference
+(scripts/cart_exp.py: 96 seeds; scripts/pen_exp_sac.py: 24 seeds; tests/golden/make_golden.py stats).  The same runs are
+repeated here with the shipped trainers at num_envs = 1 -- the reference's cadence, step for step -- on the HIP kernels,
+on TWICE as many seeds (GPU runs are cheap).  Random streams differ (Philox vs numpy/torch global generators) and
+trajectories are chaotic, so the comparison is between seed-averaged statistics: violation rate = fraction of env steps
+with max(max_ineq, max_eq) > 1e-3.
 
-Tolerance: |mean_gpu - mean_ref| <= 3 standard errors of the difference (seed-to-seed spread of both sides) + 1e-3 for
-the violation rate (the north_star's 1e-3 target is reported; 15 000 env steps per side resolve ~2e-3), and the mean
-episodic return within 35 % (+ 3 SE).  The equality constraint must hold to float32 round-off on every step.
+Resolution.  The seed-to-seed spread of the cart-RPODDPG violation rate is ~3.3e-3, so the standard error of the
+difference of the two means is ~4e-4 with 96 + 192 seeds: the north_star's 1e-3 is a 2.4-sigma effect.  The test asserts
+(a) that resolution (SE of the difference <= 5e-4) and (b) |rate_gpu - rate_ref| <= 1e-3 + 1 SE.  The mean of the
+per-step maximum inequality violation must agree within 15 % + 2 SE (a 70 % gap, as an earlier 5-seed version of this
+test could not tell apart, is ~10 SE here), the mean episodic return within 10 % + 2 SE.  The equality constraint must
+hold to float32 round-off on every step of every run.
 """
 import json
 import os
@@ -22,19 +26,21 @@ from test_train_step_golden import build_trainer
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.timeout(1500, method="thread")
 @pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "pendulum")])
 def test_training_statistics_match_reference(golden, algo, envname):
     from rpo_amd import ops
     from rpo_amd.utils.logger import Logger
     g = golden("training_stats_%s_%s" % (algo, envname))
     ref, steps = g["stats"], int(g["steps"])
+    n_gpu = 2 * len(ref)
+    os.environ["RPO_VERBOSE"] = "0"
     rows = []
-    for seed in range(5):
+    for seed in range(n_gpu):
         torch.manual_seed(123 + seed)
-        tr = build_trainer(algo, envname, ops, torch.device("cuda"), num_envs=1, capacity=20000)
+        tr = build_trainer(algo, envname, ops, torch.device("cuda"), num_envs=1, capacity=steps)
         tr.max_epochs = steps
         tr.logger = Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=steps)
-        os.environ["RPO_VERBOSE"] = "0"
         tr.run(eval=False)
         n = tr.logger.pointer
         mi, me, rw = [tr.logger.tracker[k][:n] for k in ("max_ineq", "max_eq", "reward")]
@@ -43,23 +49,26 @@ def test_training_statistics_match_reference(golden, algo, envname):
                      float(tr.agent.nju.weight.detach().abs().max())])
         assert me.max() < 1e-4                                  # the equality holds on every step (equation solver)
         assert abs(tr.viol_rate - viol.mean()) < 5e-3           # device-side counter agrees with the logged rows
+        del tr
     got = np.array(rows)
-    out = {"ref_mean": ref.mean(0).tolist(), "gpu_mean": got.mean(0).tolist(), "ref_std": ref.std(0).tolist(),
-           "gpu_std": got.std(0).tolist(), "columns": [str(c) for c in g["columns"]]}
+
+    def se(col):
+        return float(np.sqrt(ref[:, col].var(ddof=1) / len(ref) + got[:, col].var(ddof=1) / len(got)))
+    out = {"ref_seeds": len(ref), "gpu_seeds": len(got), "steps": steps, "ref_mean": ref.mean(0).tolist(),
+           "gpu_mean": got.mean(0).tolist(), "ref_std": ref.std(0, ddof=1).tolist(), "gpu_std": got.std(0, ddof=1).tolist(),
+           "se_of_difference": [se(c) for c in range(ref.shape[1])], "columns": [str(c) for c in g["columns"]]}
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/statistical_parity_%s_%s.json" % (algo, envname), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out))
-
-    def se(col):
-        return np.sqrt(ref[:, col].var() / len(ref) + got[:, col].var() / len(got))
     d_viol = abs(got[:, 1].mean() - ref[:, 1].mean())
-    assert d_viol <= 3 * se(1) + 1e-3, (d_viol, se(1))
+    assert se(1) <= 5e-4, se(1)                                   # the comparison resolves 1e-3 at two sigma
+    assert d_viol <= 1e-3 + se(1), (d_viol, se(1))
     d_ineq = abs(got[:, 2].mean() - ref[:, 2].mean())
-    assert d_ineq <= 3 * se(2) + 2e-3, (d_ineq, se(2))
+    assert d_ineq <= 0.15 * ref[:, 2].mean() + 2 * se(2) + 1e-5, (d_ineq, se(2))
     for col in (4, 5):                                           # episodic return, whole run and second half
         d = abs(got[:, col].mean() - ref[:, col].mean())
-        assert d <= 3 * se(col) + 0.35 * ref[:, col].mean(), (col, d, se(col))
+        assert d <= 0.10 * ref[:, col].mean() + 2 * se(col), (col, d, se(col))
     assert got[:, 0].min() > 0.9 * steps                         # the logger received (almost) every step
 
 
