@@ -35,6 +35,19 @@ class _LazyDiff(object):
         return self.pair[0] - self.pair[1]
 
 
+class _LazyMeanDiff(object):
+    """mean Lagrangian term (one device word) - mean Q (a [B, 1] buffer): no reduction launch inside the iteration."""
+
+    def __init__(self, lag, q):
+        self.lag, self.q = lag, q
+
+    def __float__(self):
+        return float(self.detach())
+
+    def detach(self):
+        return self.lag[0] - self.q.mean()
+
+
 class RPODDPG(RPOTrainerBase):
 
     def __init__(self, env, work_dir, name, logger, max_steps=10, embed_dim=256, hidden_dim=256, hidden_layer=1,
@@ -108,7 +121,7 @@ class RPODDPG(RPOTrainerBase):
             # SpringPendulum: the chain is cut at the batch-coupled projection (front | project | back)
             ap = f.buf("crit.ap", B)
             self.kernels.ddpg_critic_front(f.descs["actor_target"], scale, base, buf.rows, buf.capacity, buf.n_envs,
-                                           self._batch, None, idx_in, buf.seed, 0, buf.ctrl, ap)
+                                           self._batch, None, idx_in, buf.seed, 0, self._uctrl, ap)
             next_actions = self._project_batch(cols[2], ap)
             q, qn = f.buf("q", B, 1), f.buf("qn", B, 1)
             self.kernels.ddpg_critic_back(f.descs["critic_target"], d, self._batch, next_actions, q, qn,
@@ -117,7 +130,7 @@ class RPODDPG(RPOTrainerBase):
         q, qn = f.buf("q", B, 1), f.buf("qn", B, 1)
         self.kernels.ddpg_critic_forward(
             f.descs["actor_target"], f.descs["critic_target"], d, scale, base, buf.rows, buf.capacity, buf.n_envs,
-            self._batch, None, idx_in, buf.seed, 0, buf.ctrl, self.max_steps, self.corr_lr, self.corr_eps,
+            self._batch, None, idx_in, buf.seed, 0, self._uctrl, self.max_steps, self.corr_lr, self.corr_eps,
             self.corr_momentum, self._box_lo, self._box_hi, q, qn, f.buf("critic.x0", B, d.ein), f.buf("critic.h1", B, d.H))
         self._critic_backward_td(cols, q, qn, parts)
 
@@ -170,10 +183,10 @@ class RPODDPG(RPOTrainerBase):
         noise_in = None
         if self._idx_inject is not None:                       # tests replay the reference's draw
             self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * B * k.partial_dim, _SALT_ACTOR, hip_ops.STREAM_POLICY,
-                                       self.vec.ctrl)
+                                       self._uctrl)
             noise_in = self._noise_b.view(-1)
         self.backend.ddpg_actor_forward(k, da_, dc, scale, base, self._box_lo, self._box_hi, self.eps_start, self.eps, self.decay_value,
-                             self._batch, noise_in, self.seed, self.dist.rank * B, _SALT_ACTOR, self.vec.ctrl,
+                             self._batch, noise_in, self.seed, self.dist.rank * B, _SALT_ACTOR, self._uctrl,
                              ag.nju.weight.view(-1), ap_det, noise, actions, q, dq, g_act, parts, b("actor.x0", B, da_.ein),
                              b("actor.h1", B, da_.H), b("critic.x0", B, dc.ein), b("critic.h1", B, dc.H))
         self._zero_grads()
@@ -182,7 +195,7 @@ class RPODDPG(RPOTrainerBase):
         fuse_max = self._self_cleaning and not self.dist.on and opt.clip_thres and opt.clip_thres != float("inf")
         lag = b("actor.lag", 2)
         self.backend.ddpg_actor_backward(k, da_, dc, shared, self._batch, actions, g_act, ap_det, noise, dq, self.eps_start, self.eps,
-                              self.decay_value, self._box_lo, self._box_hi, scale, base, self.vec.ctrl,
+                              self.decay_value, self._box_lo, self._box_hi, scale, base, self._uctrl,
                               b("actor.x0", B, da_.ein), b("actor.h1", B, da_.H), b("critic.x0", B, dc.ein),
                               b("critic.h1", B, dc.H), b("actor.dh", B, da_.H), b("actor.dx0", B, da_.ein),
                               b("critic.dh", B, dc.H), b("critic.dx0", B, dc.ein), b("da", B, k.action_dim), b("do", B),
@@ -207,7 +220,7 @@ class RPODDPG(RPOTrainerBase):
         state = cols[0]
         ap_det = self._actor_out("actor", state, save=True)
         self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * B * k.partial_dim, _SALT_ACTOR, hip_ops.STREAM_POLICY,
-                                   self.vec.ctrl)
+                                   self._uctrl)
         noise = self._noise_b.view(-1)
         actions = self._complete_only(state, ap_det, noise)
         q = f.forward("critic", state, actions, f.buf("q", B, 1), save=True)
@@ -215,8 +228,7 @@ class RPODDPG(RPOTrainerBase):
         lag.zero_()
         self._zero_grads()                 # parameters AND multipliers (they live in the same flat buffer)
         k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1), obs=state)
-        dq = f.buf("dq", B, 1)
-        dq.fill_(-1.0 / B)
+        dq = self._const_dq(B)                                 # d mean(-Q) / dQ: a constant, filled once
         da = f.buf("da", B, k.action_dim)
         shared = ag.flat.sizes[1] > 0      # shared embedding: the critic path contributes to its gradient
         f.backward("critic", state, actions, dq, da=da, param_grads=shared, first_layer_state_only=True)
@@ -225,15 +237,21 @@ class RPODDPG(RPOTrainerBase):
         dap, do = f.buf("dap", B * P), f.buf("do", B, P)
         k.complete_bwd(state, da, dap, action=actions)
         if self._box_affine is None:       # state-dependent box: the env's kernel knows it
-            k.tanh_box_bwd(state, ap_det, noise, self.eps_start, self.eps, self.decay_value, self.vec.ctrl, dap, do.view(-1))
+            k.tanh_box_bwd(state, ap_det, noise, self.eps_start, self.eps, self.decay_value, self._uctrl, dap, do.view(-1))
         else:
             scale, base = self._box_affine
-            self.backend.tanh_box_bwd(dap, ap_det, noise, self.eps_start, self.eps, self.decay_value, self.vec.ctrl,
+            self.backend.tanh_box_bwd(dap, ap_det, noise, self.eps_start, self.eps, self.decay_value, self._uctrl,
                                       self._box_lo, self._box_hi, scale, base, do.view(-1))
         f.backward("actor", state, None, do)
-        loss = lag[0] - q.mean()
+        loss = _LazyMeanDiff(lag, q)                          # lag[0] - mean(Q), reduced only when somebody looks
         self.last_losses["actor"] = loss
         return loss
+
+    def _const_dq(self, B):
+        key = ("dq_pi_const", B)
+        if key not in self.fused._scratch:
+            self.fused._scratch[key] = torch.full((B, 1), -1.0 / B, device=self.device)
+        return self.fused._scratch[key]
 
     # ---- losses ---------------------------------------------------------------------------------------------
     def critic_loss(self, state, action, next_state, done, reward, ineq_viol=None, eq_viol=None):
@@ -252,7 +270,7 @@ class RPODDPG(RPOTrainerBase):
         ag = self.agent
         ap = ag.actor(state)
         self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * self.batch_size * self.kernels.partial_dim, _SALT_ACTOR,
-                                   hip_ops.STREAM_POLICY, self.vec.ctrl)
+                                   hip_ops.STREAM_POLICY, self._uctrl)
         ap = ag.actor.box_constraint.clip(ap + self._eps_now() * self._noise_b, state)
         actions = self.base_env.complete_partial(state, ap)
         loss = (-ag.critic(state, actions)).mean()

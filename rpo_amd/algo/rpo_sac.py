@@ -57,8 +57,10 @@ class RPOSAC(RPOTrainerBase):
 
     _gauss_policy = True
 
-    def _draw(self, buf, id_base, salt):
-        self.backend.philox_normal(buf, self.seed, id_base, salt, hip_ops.STREAM_POLICY, self.vec.ctrl)
+    def _draw(self, buf, id_base, salt, rollout=False):
+        """N(0,1) draws keyed by the step counter: the rollout's (ctrl[T]) or the update's clock (`_uctrl`)."""
+        self.backend.philox_normal(buf, self.seed, id_base, salt, hip_ops.STREAM_POLICY,
+                                   self.vec.ctrl if rollout else self._uctrl)
         return buf
 
     # ---- rollout policy (rpo_sac.py:102-110, agent/sac_pa.py:105-115) -------------------------------------------
@@ -80,7 +82,7 @@ class RPOSAC(RPOTrainerBase):
     def _policy_partial(self, obs, warm):
         if warm:
             return None, hip_ops.NOISE_UNIFORM
-        eps = self._draw(self._noise_n, self.vec.env_id_base * self.kernels.partial_dim, 0)
+        eps = self._draw(self._noise_n, self.vec.env_id_base * self.kernels.partial_dim, 0, rollout=True)
         if self.fused is not None:
             return self._gauss(obs, eps, "roll", want_logp=False)[0], hip_ops.NOISE_NONE     # already clipped
         ap, _, _ = self.agent.actor(obs, eps=eps)                   # rsample of the squashed Gaussian
@@ -123,7 +125,7 @@ class RPOSAC(RPOTrainerBase):
             ap = f.buf("crit.ap", B)
             self.kernels.sac_critic_front(f.descs["actor"], scale, base, self._box_lo, self._box_hi, buf.rows, buf.capacity,
                                           buf.n_envs, self._batch, None, idx_in, eps_in, buf.seed, 0, self.seed,
-                                          self.dist.rank * B, _SALT_CRITIC, buf.ctrl, ap, logp)
+                                          self.dist.rank * B, _SALT_CRITIC, self._uctrl, ap, logp)
             next_actions = self._project_batch(cols[2], ap)
             self.kernels.sac_critic_back(f.descs["critic_target1"], f.descs["critic_target2"], d, f.descs["critic2"],
                                          self._batch, next_actions, q1, q2, qn1, qn2, *saves)
@@ -131,7 +133,7 @@ class RPOSAC(RPOTrainerBase):
             self.kernels.sac_critic_forward(
                 f.descs["actor"], f.descs["critic_target1"], f.descs["critic_target2"], d, f.descs["critic2"], scale, base,
                 buf.rows, buf.capacity, buf.n_envs, self._batch, None, idx_in, eps_in, buf.seed, 0, self.seed,
-                self.dist.rank * B, _SALT_CRITIC, buf.ctrl, self.max_steps, self.corr_lr, self.corr_eps, self.corr_momentum,
+                self.dist.rank * B, _SALT_CRITIC, self._uctrl, self.max_steps, self.corr_lr, self.corr_eps, self.corr_momentum,
                 self._box_lo, self._box_hi, q1, q2, qn1, qn2, logp, *saves)
         self._critic_backward_td(cols, q1, q2, qn1, qn2, logp)
 
@@ -189,7 +191,7 @@ class RPOSAC(RPOTrainerBase):
         noise_in = self._draw(self._noise_b, self.dist.rank * B * self.kernels.partial_dim, _SALT_ACTOR).view(-1) if self._idx_inject is not None else None
         alpha = float(ag.alpha)
         self.backend.sac_actor_forward(k, da_, d1, d2, scale, base, self._box_lo, self._box_hi, alpha, self._batch, noise_in,
-                                       self.seed, self.dist.rank * B, _SALT_ACTOR, self.vec.ctrl, ag.nju.weight.view(-1),
+                                       self.seed, self.dist.rank * B, _SALT_ACTOR, self._uctrl, ag.nju.weight.view(-1),
                                        raw, noise, logp, actions, dq1, dq2, g_act, parts, saved)
         self._zero_grads()
         opt = ag.actor_optim

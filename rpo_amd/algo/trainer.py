@@ -242,6 +242,9 @@ class RPOTrainerBase(object):
         # split path it is an alias of the rollout's ctrl and nothing changes.
         self._uctrl, self._uclock_ok, self._after_front, self._ovl_stream = self.vec.ctrl, True, None, None
         self._bump = self.updates_per_step == 1
+        if self.fused is not None and device.type == "cuda" and getattr(self.backend, "ADAM_CLOCK", False):
+            self._uctrl, self._uclock_ok = torch.zeros_like(self.vec.ctrl), False
+        self.buffer.sample_ctrl = self._uctrl
         self._split_state()
         self._t = 0                 # loop iterations (== vector steps) done
         self._harvested = 0         # vector steps whose statistics were already pulled off the device
@@ -318,7 +321,7 @@ class RPOTrainerBase(object):
         (eps == eps_start); computed from the device step counter when it decays so that graph replays stay exact."""
         if self.decay_value == 0:
             return self.eps_start
-        t = self.vec.ctrl[0].to(torch.float32)
+        t = self._uctrl[0].to(torch.float32)
         return torch.clamp(self.eps_start - self.decay_value * t, min=self.eps)
 
     def _critic_gradmax(self):
@@ -519,7 +522,6 @@ class RPOTrainerBase(object):
         B, ag, buf = self.batch_size, self.agent, self.buffer
         T = (B + 15) // 16
         b = f.buf
-        self._uctrl, self._uclock_ok = torch.zeros_like(self.vec.ctrl), False
         descs = dict(actor=d["actor"])
         if self.sac:
             descs.update(critic1=d["critic1"], critic2=d["critic2"], critic_target1=d["critic_target1"],
@@ -622,7 +624,7 @@ class RPOTrainerBase(object):
         act = f.buf("act_pi", state.shape[0], self.kernels.action_dim)
         mode = hip_ops.NOISE_NONE if noise is None else hip_ops.NOISE_EXPLICIT
         self.kernels.act_project(state, ap_flat, noise, act, None, mode, self.eps_start, self.eps, self.decay_value,
-                                 self._box_lo, self._box_hi, 0, 0.0, self.corr_eps, 0.0, self.seed, 0, self.vec.ctrl, None,
+                                 self._box_lo, self._box_hi, 0, 0.0, self.corr_eps, 0.0, self.seed, 0, self._uctrl, None,
                                  **self._act_kw)
         return act
 
@@ -705,11 +707,17 @@ class RPOTrainerBase(object):
     def _overlap_ok(self, do_train):
         """Rollout t+1 may run beside the update of t (on a second stream of the window's hipGraph) when the update does
         not touch what the rollout reads -- no shared state embedding, and not on policy steps -- and the update reads
-        its own clock (`_uctrl`).  Results are identical either way.  OFF unless ``RPO_OVERLAP=1``: on one MI355X the
-        fork / join of the second graph branch costs more than the 16 us rollout it hides (cart-SAC 75.7 vs 71.0 us per
-        iteration, measured); it is kept for data-parallel runs, where the branch would hide the all-reduce as well."""
-        return (do_train and self._uctrl is not self.vec.ctrl and self.agent.flat.sizes[1] == 0 and self._bump
-                and self._rollout_pipeline and bool(_env_int("RPO_OVERLAP", 0)) and self.device.type == "cuda")
+        its own clock (`_uctrl`).  Results are identical either way.  ``RPO_OVERLAP`` = 0 / 1 overrides the default: OFF for
+        the classic-control envs -- on one MI355X the fork / join of the second graph branch costs more than the 16 us
+        rollout it hides (cart-SAC 75.7 vs 71.0 us per iteration, measured) -- and ON for EVOPF-v0, whose rollout is a
+        ~160 us chain of latency-bound launches (one wavefront per lane) that runs well beside the update's."""
+        if not (do_train and self._uctrl is not self.vec.ctrl and self.agent.flat.sizes[1] == 0 and self._bump):
+            return False
+        # the fork point needs the sampling launch on its own or first in the split path (not inside a row-tile pipeline)
+        if getattr(self, "_pipelines", False) and self._split_state() is None:
+            return False
+        default = 0 if getattr(self, "_pipelines", False) else 1          # long kernels (EVOPF): the branch pays
+        return bool(_env_int("RPO_OVERLAP", default))
 
     def _overlapped_window(self, t, L):
         """L iterations (t is a policy_fre boundary) with rollout i+1 forked off right after the sampling launch of update i
@@ -730,9 +738,12 @@ class RPOTrainerBase(object):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     self._rollout(False)
-            self._after_front = fork if overlap else None
+            split = self._split_state() is not None and getattr(self, "_pipelines", False)
+            self._after_front = fork if (overlap and split) else None       # split path: fork behind its sampling launch
             try:
                 cols = self._last_cols = self._sample()
+                if overlap and not split:
+                    fork()                                                  # generic path: _sample() launched the gather
                 self._critic_update(cols)
             finally:
                 self._after_front = None

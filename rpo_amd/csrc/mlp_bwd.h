@@ -177,24 +177,28 @@ __device__ __forceinline__ void mlp_bwd_rows_body(const BwdArgs& p) {
 }
 
 // First-layer gradients from dx0: batch reductions with one owner per output and a fixed summation order.  A workgroup
-// owns kFlOut = 16 consecutive outputs and splits the batch 16 ways (256 threads = 16 outputs x 16 slices), so a thread's
+// owns 16 consecutive outputs and splits the batch 16 ways (256 threads = 16 outputs x 16 slices), so a thread's
 // serial chain of dependent loads is n / 16 rows (two groups of 8 at batch 256) -- with 64 outputs x 4 slices it was eight
 // groups, ~3 us of exposed latency on a launch that is otherwise the boundary floor.  The 16 slice sums are added in
 // order.  Output list idx = q * E + e (e fastest: contiguous dx0 reads); q < wS: state weights / bias, q >= wS: action
 // weights / bias.  Columns of x0: [0, E) <- state (+ action when added); [E, 2E) <- action (cat).
-constexpr int kFlOut = 16;
-__host__ __device__ constexpr int mlp_fl_blocks(int outputs) { return (outputs + kFlOut - 1) / kFlOut; }
+// Large first layers (EVOPF: 256 x 101 = 25 856 outputs) keep 64 outputs x 4 slices: there the launch is bound by the
+// number of workgroups, not by one workgroup's load chain (928 instead of 232 workgroups cost +10 us, measured).
+constexpr int kFlWideFrom = 4096;
+__host__ __device__ constexpr int mlp_fl_out(int outputs) { return outputs > kFlWideFrom ? 64 : 16; }
+__host__ __device__ constexpr int mlp_fl_blocks(int outputs) { return (outputs + mlp_fl_out(outputs) - 1) / mlp_fl_out(outputs); }
 
-template <int EIN>
-__device__ __forceinline__ float mlp_bwd_first_layer(const BwdArgs& p, int fl_block) {
-    __shared__ float fl_partial[16][kFlOut];
+template <int EIN, int OUT>
+__device__ __forceinline__ float mlp_bwd_first_layer_impl(const BwdArgs& p, int fl_block) {
+    constexpr int SL = kThreads / OUT, CH = OUT == 16 ? 16 : 8;    // batch slices; rows of loads in flight per slice
+    __shared__ float fl_partial[SL][OUT];
     const Mlp& net = p.net;
     const int tid = threadIdx.x;
-    const int o = tid & (kFlOut - 1), part = tid >> 4;
-    const int b_lo = (int)(((long long)p.n * part) / 16), b_hi = (int)(((long long)p.n * (part + 1)) / 16);
+    const int o = tid % OUT, part = tid / OUT;
+    const int b_lo = (int)(((long long)p.n * part) / SL), b_hi = (int)(((long long)p.n * (part + 1)) / SL);
     float gmax = 0.0f;
     const int wS = net.S + 1, wA = (net.A > 0 && !p.first_layer_state_only) ? net.A + 1 : 0;   // +1: the bias
-    const int idx = fl_block * kFlOut + o;
+    const int idx = fl_block * OUT + o;
     const bool valid = idx < net.E * (wS + wA);
     float acc = 0.0f;
     int e = 0, i = 0, width = 0;
@@ -210,15 +214,15 @@ __device__ __forceinline__ float mlp_bwd_first_layer(const BwdArgs& p, int fl_bl
         const int stride = is_a ? p.a_stride : p.s_stride;
         const bool is_w = i < width;
         int bb = b_lo;
-        for (; bb + 16 <= b_hi; bb += 16) {
-            float d[16], x[16];
+        for (; bb + CH <= b_hi; bb += CH) {
+            float d[CH], x[CH];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < CH; ++u) {
                 d[u] = p.dx0[(size_t)(bb + u) * EIN + col];
                 x[u] = is_w ? in[(size_t)(bb + u) * stride + i] : 1.0f;
             }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) acc = fmaf(d[u], x[u], acc);
+            for (int u = 0; u < CH; ++u) acc = fmaf(d[u], x[u], acc);
         }
         for (; bb < b_hi; ++bb) acc = fmaf(p.dx0[(size_t)bb * EIN + col], is_w ? in[(size_t)bb * stride + i] : 1.0f, acc);
     }
@@ -227,13 +231,21 @@ __device__ __forceinline__ float mlp_bwd_first_layer(const BwdArgs& p, int fl_bl
     if (part == 0 && valid) {
         float tot = fl_partial[0][o];
 #pragma unroll
-        for (int sl = 1; sl < 16; ++sl) tot += fl_partial[sl][o];
+        for (int sl = 1; sl < SL; ++sl) tot += fl_partial[sl][o];
         float* dst = (i < width) ? (is_a ? &p.g.Wa[e * net.A + i] : &p.g.Ws[e * net.S + i]) : (is_a ? &p.g.ba[e] : &p.g.bs[e]);
         const float nv = *dst + tot;
         *dst = nv;
         gmax = fabsf(nv);
     }
     return gmax;
+}
+
+template <int EIN>
+__device__ __forceinline__ float mlp_bwd_first_layer(const BwdArgs& p, int fl_block) {
+    const Mlp& net = p.net;
+    const int outputs = net.E * (net.S + 1 + ((net.A > 0 && !p.first_layer_state_only) ? net.A + 1 : 0));
+    if (outputs > kFlWideFrom) return mlp_bwd_first_layer_impl<EIN, 64>(p, fl_block);
+    return mlp_bwd_first_layer_impl<EIN, 16>(p, fl_block);
 }
 
 // ------------------------------------------------------------------------------------------------ backward, weights

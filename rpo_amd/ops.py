@@ -18,6 +18,7 @@ NOISE_PHILOX = CONST["RPO_NOISE_PHILOX"]
 NOISE_UNIFORM = CONST["RPO_NOISE_UNIFORM"]
 NOISE_CLIP_ONLY = CONST["RPO_NOISE_CLIP_ONLY"]
 STREAM_POLICY = CONST["RPO_STREAM_POLICY"]
+ADAM_CLOCK = True           # rpo_adam_step / _multi take the update-clock argument (trainer._uctrl)
 STATS_LEN = CONST["RPO_STATS_LEN"]
 STATS_SUB = CONST["RPO_STATS_SUB"]
 CTRL_LEN = CONST["RPO_CTRL_LEN"]

@@ -26,6 +26,8 @@ class ReplayBuffer(object):
         # ctrl[0] = vector steps taken so far; owned by the step kernel, shared with the env state
         self.ctrl = ctrl if ctrl is not None else torch.zeros(hip_ops.CTRL_LEN, dtype=torch.int64, device=device)
         self._steps_host = 0                          # host mirror of ctrl[0] (no device sync needed)
+        # the counter words the SAMPLER reads (valid range, Philox index): the trainers point it at their update clock
+        self.sample_ctrl = self.ctrl
 
     # -- reference surface -------------------------------------------------------------------------------------
     def __len__(self):
@@ -53,12 +55,14 @@ class ReplayBuffer(object):
             self.rows[base:base + self.n_envs, lo:hi] = v
         self._steps_host += 1
         self.ctrl[0] = self._steps_host
+        if self.sample_ctrl is not self.ctrl:
+            self.sample_ctrl[0] = self._steps_host
 
     def sample_rows(self, num, out=None, idx_out=None, salt=0):
         """Uniform-with-replacement draw + gather of ``num`` rows (buffer.py:31-34) -> [num, W] device tensor."""
         if out is None:
             out = torch.empty(num, self.rows.shape[1], device=self.device)
-        self._ops.replay_sample_gather(self.rows, self.capacity, self.n_envs, out, idx_out, self.seed, salt, self.ctrl)
+        self._ops.replay_sample_gather(self.rows, self.capacity, self.n_envs, out, idx_out, self.seed, salt, self.sample_ctrl)
         return out
 
     def split(self, batch):

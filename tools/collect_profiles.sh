@@ -1,0 +1,35 @@
+#!/bin/bash
+# Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repository root):
+#   kernel-trace + stats of the bench command (default workload and two others), the launch timeline of the graph
+#   windows, and HBM traffic counters (FETCH_SIZE / WRITE_SIZE in separate passes) of eager iterations.
+# Everything lands in gpurun_out/prof_rNN/ as text; copy what is to be judged into profiles/.
+set -u
+R=${1:-r02}
+OUT=$PWD/gpurun_out/prof_$R
+mkdir -p $OUT
+export TMPDIR=/tmp RPO_VERBOSE=0
+ROOT=$PWD
+cd /tmp
+for W in cart_ddpg cart_sac pen_sac evopf_ddpg; do
+  rm -rf /tmp/p_$W
+  rocprofv3 --kernel-trace --stats -d /tmp/p_$W -o t -- python3 $ROOT/bench.py --no-cpu-baseline --no-clinic --no-extras \
+      --workload $W --steps 2000 --warmup 200 > $OUT/bench_$W.json 2> $OUT/bench_$W.err
+  DB=$(ls /tmp/p_$W/*results.db 2>/dev/null | head -1)
+  if [ -n "$DB" ]; then
+    python3 $ROOT/tools/rocpd_summary.py $DB 40 > $OUT/${W}_kernel_stats.txt
+    A=rollout_kernel; [ $W = evopf_ddpg ] && A=evopf_step_kernel
+    python3 $ROOT/tools/rocpd_timeline.py $DB $A 200 > $OUT/${W}_timeline.txt
+  fi
+done
+for C in FETCH_SIZE WRITE_SIZE; do
+  for P in step iter; do
+    rm -rf /tmp/q_${C}_$P
+    rocprofv3 --pmc $C --kernel-trace -d /tmp/q_${C}_$P -o t -- python3 $ROOT/tools/kernel_probe.py $P > /dev/null 2> $OUT/pmc_${C}_$P.err
+    DB=$(ls /tmp/q_${C}_$P/*results.db 2>/dev/null | head -1)
+    [ -n "$DB" ] && python3 $ROOT/tools/rocpd_pmc.py $DB > $OUT/pmc_${C}_$P.txt
+  done
+done
+cd $ROOT
+python3 tools/pmc_to_json.py $OUT/pmc_traffic.json $OUT/pmc_FETCH_SIZE_step.txt $OUT/pmc_WRITE_SIZE_step.txt \
+    $OUT/pmc_FETCH_SIZE_iter.txt $OUT/pmc_WRITE_SIZE_iter.txt
+ls -la $OUT
