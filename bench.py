@@ -207,7 +207,10 @@ def launch_models(tr, workload):
     kn = type(k).__name__ + "."
     m = {
         kn + "rollout": ("mfma", n, fa), kn + "step": ("hbm", n, step_bytes),
-        kn + "act_project": ("hbm", None, 4 * S + 4 * P + 4 * A + 4),        # units = rows of the call
+        # units = rows of the call.  EVOPF: one wavefront per lane solves a 22 x 22 Newton system (~5 iterations) and
+        # eliminates a 28 x 43 Jacobian per GRG iteration (10): ~5.2e5 flops per lane, priced against the f32
+        # peak (VALU == MFMA rate for f32); the classic-control projections are a few dozen flops on 40 bytes: HBM-priced
+        kn + "act_project": ("mfma", None, 520000) if workload.startswith("evopf") else ("hbm", None, 4 * S + 4 * P + 4 * A + 4),
         "replay_sample_gather": ("hbm", B, 2 * row + 4),
         kn + "ddpg_critic_forward": ("mfma", B, fa + 2 * fc), kn + "sac_critic_forward": ("mfma", B, 2 * fa + 4 * fc),
         kn + "ddpg_critic_front": ("mfma", B, fa), kn + "sac_critic_front": ("mfma", B, fa),

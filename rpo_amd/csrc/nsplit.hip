@@ -39,7 +39,7 @@ struct SplitFwdArgs4 { SplitFwdArgs net[4]; };
 __global__ __launch_bounds__(kNsThreads) void mlp_forward_split_kernel(SplitFwdArgs4 all) {
     __shared__ NsLds<128> lds;
     const SplitFwdArgs& p = all.net[blockIdx.z];
-    const int row0 = blockIdx.x * kRows, g = blockIdx.y, tid = threadIdx.x;
+    const int row0 = blockIdx.y * kRows, g = blockIdx.x, tid = threadIdx.x;      // g fastest: block -> XCD g (see fwd_a)
     NsWeights<128> w;
     ns_load_weights<128, 256>(p.net, g, w);
     if (tid < kRows * 8) {
@@ -147,7 +147,10 @@ template <class L>
 __global__ __launch_bounds__(kNsThreads) void split_critic_fwd_a_kernel(SplitArgs p) {
     __shared__ NsLds<128> lds;
     __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
-    const int row0 = blockIdx.x * kRows, g = blockIdx.y, role = blockIdx.z;
+    // the column group is the FASTEST grid dimension: workgroup b lands on XCD b % 8 == g, so each XCD's L2 fetches only the
+    // 1/8 slice of W0 its groups read (with the row tile fastest every XCD pulled every network's whole W0 per launch:
+    // 3.0 MB of traffic for ~0.35 MB of unique bytes, profiles/r02_pmc_traffic.json)
+    const int row0 = blockIdx.y * kRows, g = blockIdx.x, role = blockIdx.z;
     const Mlp& net = role == 0 ? (p.twin ? p.actor : p.actor_target) : p.critic[role - 1];
     NsWeights<128> w;
     ns_load_weights<128, 256>(net, g, w);
@@ -186,7 +189,7 @@ template <class L, int PROJ>
 __global__ __launch_bounds__(kNsThreads) void split_critic_fwd_b_kernel(SplitArgs p, CartConsts c) {
     __shared__ NsLds<128> lds;
     __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
-    const int row0 = blockIdx.x * kRows, g = blockIdx.y, k = blockIdx.z, tid = threadIdx.x;
+    const int row0 = blockIdx.y * kRows, g = blockIdx.x, k = blockIdx.z, tid = threadIdx.x;
     const Mlp& net = p.critic_target[k];
     NsWeights<128> w;
     ns_load_weights<128, 256>(net, g, w);
@@ -496,7 +499,7 @@ int rpo_mlp_forward_split(int k, const rpo_mlp* const* nets, int n, const float*
         all.net[i] = SplitFwdArgs{m, n, s[i], s_stride[i], m.A > 0 ? a[i] : nullptr, m.A > 0 ? a_stride[i] : 0, part[i],
                                   x0_save ? x0_save[i] : nullptr, h1_save ? h1_save[i] : nullptr};
     }
-    hipLaunchKernelGGL(mlp_forward_split_kernel, dim3((n + kRows - 1) / kRows, kNsGroups, k), dim3(kNsThreads), 0,
+    hipLaunchKernelGGL(mlp_forward_split_kernel, dim3(kNsGroups, (n + kRows - 1) / kRows, k), dim3(kNsThreads), 0,
                        (hipStream_t)stream, all);
     RPO_LAUNCH_CHECK();
     return 0;
@@ -572,7 +575,7 @@ template <class L>
 __global__ __launch_bounds__(kNsThreads) void split_policy_a_kernel(SplitArgs p) {
     __shared__ NsLds<128> lds;
     __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
-    const int row0 = blockIdx.x * kRows, g = blockIdx.y;
+    const int row0 = blockIdx.y * kRows, g = blockIdx.x;
     NsWeights<128> w;
     ns_load_weights<128, 256>(p.actor, g, w);
     ns_load_tile<L>(p, tile, row0);
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(kNsThreads) void split_policy_b_kernel(SplitArgs p,
     typedef typename ENV::L L;
     __shared__ NsLds<128> lds;
     __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
-    const int row0 = blockIdx.x * kRows, g = blockIdx.y, k = blockIdx.z, tid = threadIdx.x, B = p.B;
+    const int row0 = blockIdx.y * kRows, g = blockIdx.x, k = blockIdx.z, tid = threadIdx.x, B = p.B;
     const Mlp& net = p.critic[k];
     NsWeights<128> w;
     ns_load_weights<128, 256>(net, g, w);
@@ -649,7 +652,7 @@ __global__ __launch_bounds__(kNsThreads) void split_policy_b_kernel(SplitArgs p,
 #pragma unroll
         for (int q = 0; q < 7; ++q) {
             const float r = rpo_wave_sum(vals[q]);
-            if (tid == 0) p.lag_partial[blockIdx.x * 8 + q] = r;
+            if (tid == 0) p.lag_partial[blockIdx.y * 8 + q] = r;
         }
     }
     ns_hidden<128, 256>(net, w, lds, g, row0, B, p.part_q[k], p.x0[k], p.h1[k]);
@@ -948,7 +951,7 @@ int rpo_split_critic_fwd_a(const rpo_split_update* u, void* stream) {
     if (!a.rows || !a.batch_out || !a.ctrl || !a.part_pi || a.cap_steps <= 0 || a.n_envs <= 0) return RPO_ERR_NULL;
     for (int k = 0; k < K; ++k)
         if (!a.part_q[k] || !a.x0[k] || !a.h1[k]) return RPO_ERR_NULL;
-    const dim3 grid((a.B + kRows - 1) / kRows, kNsGroups, 1 + K);
+    const dim3 grid(kNsGroups, (a.B + kRows - 1) / kRows, 1 + K);
     if (u->env == 0) hipLaunchKernelGGL(split_critic_fwd_a_kernel<CartRow>, grid, dim3(kNsThreads), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(split_critic_fwd_a_kernel<PendRow>, grid, dim3(kNsThreads), 0, (hipStream_t)stream, a);
     RPO_LAUNCH_CHECK();
@@ -962,7 +965,7 @@ int rpo_split_critic_fwd_b(const rpo_split_update* u, void* stream) {
     if (!a.batch_out || !a.ctrl) return RPO_ERR_NULL;
     for (int k = 0; k < K; ++k)
         if (!a.part_qn[k]) return RPO_ERR_NULL;
-    const dim3 grid((a.B + kRows - 1) / kRows, kNsGroups, K);
+    const dim3 grid(kNsGroups, (a.B + kRows - 1) / kRows, K);
     if (u->env == 0) {
         if (!a.part_pi || (a.twin && !a.logp) || a.max_steps < 0) return RPO_ERR_NULL;
         hipLaunchKernelGGL((split_critic_fwd_b_kernel<CartRow, 1>), grid, dim3(kNsThreads), 0, (hipStream_t)stream, a, c);
@@ -1028,7 +1031,7 @@ int rpo_split_policy_a(const rpo_split_update* u, void* stream) {
     SplitArgs a; CartConsts c;
     if (int e = to_args(u, 32u, a, c)) return e;
     if (!a.batch_out || !a.part_pi || !a.x0_a || !a.h1_a) return RPO_ERR_NULL;
-    const dim3 grid((a.B + kRows - 1) / kRows, kNsGroups);
+    const dim3 grid(kNsGroups, (a.B + kRows - 1) / kRows);
     if (u->env == 0) hipLaunchKernelGGL(split_policy_a_kernel<CartRow>, grid, dim3(kNsThreads), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(split_policy_a_kernel<PendRow>, grid, dim3(kNsThreads), 0, (hipStream_t)stream, a);
     RPO_LAUNCH_CHECK();
@@ -1043,7 +1046,7 @@ int rpo_split_policy_b(const rpo_split_update* u, void* stream) {
     if (a.twin ? (!a.raw || !a.logp) : !a.ap_det) return RPO_ERR_NULL;
     for (int k = 0; k < K; ++k)
         if (!a.part_q[k] || !a.x0[k] || !a.h1[k]) return RPO_ERR_NULL;
-    const dim3 grid((a.B + kRows - 1) / kRows, kNsGroups, K);
+    const dim3 grid(kNsGroups, (a.B + kRows - 1) / kRows, K);
     if (u->env == 0) hipLaunchKernelGGL(split_policy_b_kernel<CartPol>, grid, dim3(kNsThreads), 0, (hipStream_t)stream, a, c);
     else hipLaunchKernelGGL(split_policy_b_kernel<PendPol>, grid, dim3(kNsThreads), 0, (hipStream_t)stream, a, c);
     RPO_LAUNCH_CHECK();

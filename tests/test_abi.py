@@ -48,3 +48,41 @@ def test_ops_refuse_cpu_tensors():
     from rpo_amd import ops
     with pytest.raises(_lib.RpoHipError):
         ops.polyak(torch.zeros(4), torch.zeros(4), 0.5)
+
+
+def test_struct_layouts_match_the_compiler(tmp_path):
+    """The ctypes mirrors of the header's structs (rpo_split_update, rpo_adam_seg, rpo_mlp, rpo_td) have the compiler's
+    size and field offsets: a C program that includes include/rpo_hip.h prints them, gcc only."""
+    import torch  # noqa: F401  (rpo_amd.ops imports it)
+    from rpo_amd import ops
+    structs = {"rpo_split_update": ops._SplitUpdateStruct, "rpo_adam_seg": ops._AdamSegStruct, "rpo_mlp": ops._MlpStruct,
+               "rpo_mlp_grad": ops._MlpGradStruct, "rpo_td": ops._TdStruct}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % _lib.HEADER, "int main(void) {"]
+    for cname, st in structs.items():
+        lines.append('printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in st._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ["return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    seen = 0
+    for line in out.splitlines():
+        cname, field, value = line.split()
+        st = structs[cname]
+        if field == "size":
+            assert ctypes.sizeof(st) == int(value), (cname, ctypes.sizeof(st), value)
+        else:
+            assert getattr(st, field).offset == int(value), (cname, field)
+        seen += 1
+    assert seen > 120
+
+
+def test_split_update_stages_validate_arguments():
+    lib = _lib.load()
+    for stage in ("critic_fwd_a", "critic_fwd_b", "pend_head_project", "critic_bwd_a", "critic_bwd_b", "policy_a",
+                  "policy_b", "policy_c", "policy_d", "policy_e"):
+        assert getattr(lib, "rpo_split_" + stage)(None, None) == _lib.CONST["RPO_ERR_NULL"]
+    assert _lib.CONST["RPO_ABI_VERSION"] == 2
