@@ -2,8 +2,6 @@
 // of the chip -- 128 workgroups per network evaluation instead of 16 -- cut at the seams where a value needs every
 // hidden column (the heads).  nsplit_dev.h has the slab function and the argument for why the results are bitwise
 // those of the row-tile kernels.
-#include <stdlib.h>
-
 #include "cartsafe_dev.h"
 #include "heads_dev.h"
 #include "mlp_bwd.h"
@@ -89,7 +87,6 @@ struct SplitArgs {
     const float* nu; float* nu_grad;
     float *ap_det, *noise_out, *raw, *actions, *g_act, *lag_partial, *lag_out, *da_part, *dout;
     int shared_embedding;
-    int dbg;                      // RPO_SPLIT_DBG (timing experiments only): 1 = skip the weight roles, 2 = skip the dx0 role
 };
 
 // ReplayBuffer.sample (buffer.py:31-34): counter-based draw + gather of the tile's 16 rows (same draw in every workgroup
@@ -463,12 +460,10 @@ __global__ __launch_bounds__(kThreads) void split_critic_bwd_b_kernel(SplitArgs 
     __shared__ __attribute__((aligned(16))) float smem[4 * 16 * 16];
     const int k = blockIdx.y;
     if (blockIdx.x < kWeightBlocks) {
-        if ((p.dbg == 6 && blockIdx.x >= kW0Tiles) || (p.dbg == 7 && blockIdx.x < kW0Tiles) || p.dbg == 8) return;
         gradmax_flush(p.gradmax, ns_weight_role(p.critic[k], p.critic_grad[k], p.h1[k], p.x0[k], p.dq[k], 1, false, p.B,
                                                 blockIdx.x, smem));
         return;
     }
-    if (p.dbg == 9) return;
     BwdArgs a{};
     a.net = p.critic[k];
     a.g = p.critic_grad[k];
@@ -935,8 +930,6 @@ int to_args(const rpo_split_update* u, unsigned need, SplitArgs& a, CartConsts& 
     a.ap_det = u->ap_det; a.noise_out = u->noise_out; a.raw = u->raw; a.actions = u->actions; a.g_act = u->g_act;
     a.lag_partial = u->lag_partial; a.lag_out = u->lag_out; a.da_part = u->da_part; a.dout = u->dout;
     a.shared_embedding = u->shared_embedding;
-    const char* dbg = getenv("RPO_SPLIT_DBG");
-    a.dbg = dbg ? atoi(dbg) : 0;
     return 0;
 }
 

@@ -170,3 +170,16 @@ def test_entropy_tuning_steps_log_alpha_in_the_flat_buffer():
         np.testing.assert_allclose(float(ag.log_alpha), 3e-3 * sign, rtol=5e-3)
         np.testing.assert_allclose(float(tr.alpha), np.exp(3e-3 * sign), rtol=1e-4)
         assert ag.alpha == 0.1                                     # what the losses use
+
+
+def test_bench_refuses_to_print_a_line_for_fewer_gpus_than_asked():
+    """`python bench.py --gpus N` without a launcher starts its N ranks itself -- and when fewer than N GPUs are visible it
+    exits non-zero with a message instead of printing a 1-GPU line (this container has none)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    if torch.cuda.device_count() < 2:
+        assert r.returncode == 2 and "refusing" in r.stderr and r.stdout.strip() == ""
