@@ -121,6 +121,7 @@ LA_HP = dict(batch_size=256, warmup=0, policy_fre=4, capacity=512, value_type="a
 
 
 def _build_trainer(algo, envname, backend, device, **extra):
+    seed = extra.pop("seed", 11)                                # Philox seed of the trainer's random streams
     if algo.endswith("la"):                                     # the Lagrangian baselines (make_golden.gen_train_steps_la)
         env_cls = CartSafeEnv if envname.startswith("cart") else SpringPendulumEnv
         kw = dict(partial_actions=[1]) if envname.startswith("cart") else {}
@@ -130,7 +131,7 @@ def _build_trainer(algo, envname, backend, device, **extra):
             args.update(automatic_entropy_tuning=False, alpha=0.05)
         args.update({k: v for k, v in extra.items() if k != "use_graph"})
         return (DDPG_LA if algo == "ddpgla" else SAC_LA)(env, "/tmp/rpo_test", name="t", logger=None, max_epochs=10,
-                                                         device=device, backend=backend, seed=11, **args)
+                                                         device=device, backend=backend, seed=seed, **args)
     cls = RPODDPG if algo == "ddpg" else RPOSAC
     if envname.startswith("evopf"):
         from rpo_amd.env import EVOPFEnv
@@ -142,7 +143,7 @@ def _build_trainer(algo, envname, backend, device, **extra):
             args["embed_dim"] = args["hidden_dim"] = int(envname[5:])
         args.update(extra)
         return cls(EVOPFEnv(backend=backend, device=device), "/tmp/rpo_test", name="t", logger=None, max_epochs=10,
-                   device=device, backend=backend, seed=11, **args)
+                   device=device, backend=backend, seed=seed, **args)
     env_cls = CartSafeEnv if envname.startswith("cart") else SpringPendulumEnv
     kw = dict(partial_actions=[1]) if envname.startswith("cart") else {}
     env = gym_shim.TimeLimit(env_cls(backend=backend, device=device, **kw), 200)
@@ -153,7 +154,7 @@ def _build_trainer(algo, envname, backend, device, **extra):
     args.update(hp)
     args.update(extra)
     return cls(env, "/tmp/rpo_test", name="t", logger=None, max_epochs=10, value_type="add", grad_eps=0.1,
-               device=device, backend=backend, seed=11, **args)
+               device=device, backend=backend, seed=seed, **args)
 
 
 class ReplayDraws(object):
