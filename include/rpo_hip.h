@@ -462,6 +462,50 @@ int rpo_split_policy_c(const rpo_split_update* u, void* stream);
 int rpo_split_policy_d(const rpo_split_update* u, void* stream);
 int rpo_split_policy_e(const rpo_split_update* u, void* stream);
 
+/* ---- Rollout stages riding on the critic update's launches ---------------------------------------------------------------
+ * Vector step t+1 of the loop (rpo_ddpg.py:93-145) reads nothing the critic update of step t writes when the policy and
+ * the critics share no parameters and no policy step lies in between; the update stages above read their own clock
+ * (`ctrl` of rpo_split_update), so the two can run side by side.  Instead of a second stream (on one MI355X the fork /
+ * join of a hipGraph branch costs more than the 16 us rollout it hides) the rollout's work is handed to workgroups the
+ * update launches leave idle:
+ *   rpo_split_critic_fwd_a_ride, rpo_split_critic_fwd_b_ride
+ *       = the stage + the actor's hidden slabs on the observations of lanes [lane_begin, lane_end) (8 column groups x
+ *         lanes / 16 workgroups of 128 threads; partials to `part`).  The forward touches neither the ring nor anything
+ *         the update writes, so it may ride anywhere; split over two launches it stays in their shadow.
+ *   rpo_split_critic_bwd_b_ride
+ *       = the stage + head -> exploration noise / rsample -> box clip -> equation solver -> GRG projection -> env step ->
+ *         replay scatter -> statistics -> auto-reset of ALL lanes (one thread per lane, 256 lanes per workgroup);
+ *         advances r->ctrl[RPO_CTRL_T].  Must follow rpo_split_critic_fwd_a(_ride) of the same update, which gathers
+ *         the batch out of the ring this stage writes into, and forward stages covering every lane.
+ * Together they compute exactly what rpo_cartsafe_rollout / rpo_pendulum_rollout compute (same bits: the slab forward is
+ * bitwise the row-tile forward and the lane functions are the same code).  u->actor is the rollout policy; u must not
+ * have a shared state embedding.  Fields as in rpo_*_rollout. */
+typedef struct {
+    int n_envs;
+    int gauss;                   /* 0: tanh box + exploration noise (RPODDPG), 1: squashed-Gaussian sample (RPOSAC) */
+    float scale, base;
+    float* state;                /* CartSafe-v0: state [n_envs, 6]; SpringPendulum-v0: internal state [n_envs, 4] */
+    float* obs;                  /* SpringPendulum-v0: observation out [n_envs, 5] or NULL; CartSafe-v0: NULL */
+    float* action;               /* [n_envs, 2] */
+    int* ep_len; float* ep_ret; unsigned* ep_count;
+    float* rows; long long cap_steps;             /* replay ring (may be NULL) */
+    float* stats; int stats_cap;
+    int noise_mode;
+    long long* ctrl;             /* the ROLLOUT clock (ctrl[RPO_CTRL_T] = vector steps taken) */
+    float eps_start, eps_end, eps_decay, box_lo, box_hi;
+    int max_steps; float corr_lr, corr_eps, corr_momentum;
+    int max_episode_steps, auto_reset;
+    float viol_thresh;
+    unsigned env_id_base;
+    unsigned long long seed;
+    float* part;                 /* [8, n_envs, 2] head partials of the actor between the forward stages and the step */
+    int lane_begin, lane_end;    /* forward stages: the lanes of this launch (multiples of 16; lane_end may be n_envs) */
+} rpo_rollout_rider;
+
+int rpo_split_critic_fwd_a_ride(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream);
+int rpo_split_critic_fwd_b_ride(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream);
+int rpo_split_critic_bwd_b_ride(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream);
+
 /* Backward of the same rows given dout [n, n_out] (two launches).  Parameter gradients are ACCUMULATED (+=) into
  * grad_host's buffers (the shared state embedding of shared_param=True receives contributions from two networks,
  * agent/ddpg_pa.py:34-36).  dh [n, H] and dx0 [n, Ein] are caller-provided scratch; da [n, A] (may be NULL) receives

@@ -241,6 +241,7 @@ class RPOTrainerBase(object):
         # ctrl[RPO_CTRL_T]) may run on another stream of the same hipGraph while the update is still going.  Without the
         # split path it is an alias of the rollout's ctrl and nothing changes.
         self._uctrl, self._uclock_ok, self._after_front, self._ovl_stream = self.vec.ctrl, True, None, None
+        self._ride, self._rider_cache, self._ride_cut = None, None, 0
         self._bump = self.updates_per_step == 1
         if self.fused is not None and device.type == "cuda" and getattr(self.backend, "ADAM_CLOCK", False):
             self._uctrl, self._uclock_ok = torch.zeros_like(self.vec.ctrl), False
@@ -597,17 +598,25 @@ class RPOTrainerBase(object):
             eps_in = self._noise_b.view(-1)
         buf = self.buffer
         su.set(idx_in=idx_in, eps_in=eps_in, rows=buf.rows, cap_steps=buf.capacity, n_envs=buf.n_envs)   # (tests swap the ring)
-        su.run("critic_fwd_a")
+        ride = self._ride                                       # ridden windows: the next vector step rides along
+        if ride is not None:
+            n, cut = self.vec.internal.shape[0], self._ride_cut
+            ride.set(lane_begin=0, lane_end=cut)
+        su.run("critic_fwd_a", rider=ride)                      # + actor forward of lanes [0, cut)
         if self._after_front is not None:                       # overlapped windows: the next rollout forks off here
             self._after_front()
         if su.st.env == 1:
             su.run("pend_head_project")
-        su.run("critic_fwd_b")
+        if ride is not None:
+            ride.set(lane_begin=cut, lane_end=n)
+        su.run("critic_fwd_b", rider=ride)                      # + actor forward of lanes [cut, n)
         self._zero_grads()
         gm = self._critic_gradmax()
         su.set(gradmax=gm)
         su.run("critic_bwd_a")
-        su.run("critic_bwd_b")
+        su.run("critic_bwd_b", rider=ride)                      # + explore / project / step / scatter of every lane
+        if ride is not None:
+            self.vec.steps_host += 1
         self._gradmax_ready = gm is not None
         from .rpo_ddpg import _LazySum
         self.last_losses["critic"] = _LazySum(self._split_loss if self.sac else self._split_loss[0])
@@ -671,7 +680,9 @@ class RPOTrainerBase(object):
                 if do_train:
                     self._sync_uclock(rollout_pending=True)
                 self._uclock_ok = do_train and self._bump
-                if self._overlap_ok(do_train):
+                if self._ride_ok(do_train):
+                    self._graphs.run(("cycle", L, True, "ride"), lambda: self._ridden_window(t, L))
+                elif self._overlap_ok(do_train):
                     self._graphs.run(("cycle", L, True, "overlap"), lambda: self._overlapped_window(t, L))
                 else:
                     self._graphs.run(("cycle", L, do_train), lambda: [self._run_segments(self._segments(
@@ -703,6 +714,62 @@ class RPOTrainerBase(object):
         self.buffer.note_step()
         self.agent.eps_decay(self.decay_value, self.eps)
         self.vec.steps_host = t
+
+    def _ride_ok(self, do_train):
+        """The next vector step may ride on the critic update's launches (rpo_split_critic_fwd_a_ride / _fwd_b_ride /
+        _bwd_b_ride, rpo_amd/csrc/nsplit.hip): column-split update, one-launch rollout available, no shared state embedding, the update
+        on its own clock.  Results are identical to the serial order.  ``RPO_RIDE=0`` keeps the serial windows."""
+        if not (do_train and self._uctrl is not self.vec.ctrl and self.agent.flat.sizes[1] == 0 and self._bump):
+            return False
+        if not (getattr(self, "_pipelines", False) and self._split_state() is not None and self._rollout_pipeline):
+            return False
+        return bool(_env_int("RPO_RIDE", 1)) and not _env_int("RPO_OVERLAP", 0)
+
+    def _rider(self):
+        """Arguments of the riding rollout halves: what `_rollout` hands to the one-launch rollout."""
+        v, buf = self.vec, self.buffer
+        if self._rider_cache is None:
+            scale, base = self._box_affine
+            self._rider_cache = self.backend.RolloutRider(
+                n_envs=v.internal.shape[0], gauss=int(self._gauss_policy), scale=scale, base=base, state=v.internal,
+                obs=None if v.obs is v.internal else v.obs, action=v.action, ep_len=v.ep_len, ep_ret=v.ep_ret,
+                ep_count=v.ep_count, stats=v.stats, stats_cap=v.stats.shape[0], ctrl=v.ctrl,
+                noise_mode=hip_ops.NOISE_NONE if self._gauss_policy else hip_ops.NOISE_PHILOX, eps_start=self.eps_start,
+                eps_end=self.eps, eps_decay=self.decay_value, box_lo=self._box_lo, box_hi=self._box_hi,
+                max_steps=self.max_steps, corr_lr=self.corr_lr, corr_eps=self.corr_eps, corr_momentum=self.corr_momentum,
+                max_episode_steps=v.max_episode_steps, auto_reset=1, viol_thresh=v.viol_thresh, seed=self.seed,
+                env_id_base=v.env_id_base, part=self.fused.buf("ride.part", 8, v.internal.shape[0], 2))
+        self._rider_cache.set(rows=buf.rows, cap_steps=buf.capacity)
+        # lanes whose actor forward rides on fwd_a; the rest ride on fwd_b (RPO_RIDE_SPLIT = share of fwd_a in percent)
+        n = v.internal.shape[0]
+        self._ride_cut = min(n, (n * _env_int("RPO_RIDE_SPLIT", 50) // 100 + 15) // 16 * 16)
+        return self._rider_cache
+
+    def _ridden_window(self, t, L):
+        """L iterations (t is a policy_fre boundary): the rollout of iteration i+1 rides on the critic update of iteration
+        i -- its actor forward in the launches of fwd_a and fwd_b (a lane range each), its explore / project / step / scatter
+        in bwd_b's, behind fwd_a, which gathers the batch out of the ring first -- unless iteration i ends with a policy step,
+        whose new actor the next rollout has to wait for."""
+        F, fl = self.policy_fre, self.agent.flat
+        self._rollout(False)
+        for i in range(L):
+            actor_step = (t + i + 1) % F == 0
+            more = i + 1 < L
+            ride = more and not actor_step
+            self._ride = self._rider() if ride else None
+            try:
+                cols = self._last_cols = self._sample()
+                self._critic_update(cols)
+            finally:
+                self._ride = None
+            self.dist.mean_([fl.gradient(fl.critic_range)])
+            self._critic_step(actor_step)
+            if actor_step:
+                self._last_actor_out = self._actor_update(cols)
+                self.dist.mean_([fl.gradient(fl.policy_bucket)])
+                self._actor_step(self._last_actor_out)
+            if more and not ride:
+                self._rollout(False)
 
     def _overlap_ok(self, do_train):
         """Rollout t+1 may run beside the update of t (on a second stream of the window's hipGraph) when the update does

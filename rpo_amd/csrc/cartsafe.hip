@@ -56,7 +56,7 @@ __global__ __launch_bounds__(RPO_BLOCK) void cartsafe_step_kernel(StepArgs p, Ca
                 const float2 u = q[0], v = q[1], w = q[2];
                 s[0] = u.x; s[1] = u.y; s[2] = v.x; s[3] = v.y; s[4] = w.x; s[5] = w.y;
             }
-            cart_lane(p, c, i, s, a, ns, row, st);
+            cart_lane(p, c, i, s, a, rpo_load_episode(p.ep_len, p.ep_ret, p.ep_count, i), ns, row, st);
             __syncthreads();                                   // every lane has read its state: the tile can be reused
             {
                 float2* q = reinterpret_cast<float2*>(state_s + tid * 6);
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(RPO_BLOCK) void cartsafe_step_kernel(StepArgs p, Ca
             // ---- partial last tile: direct per-lane accesses
             load_state(p.state + (size_t)i * 6, s);
             const float2 a = reinterpret_cast<const float2*>(p.action)[i];
-            cart_lane(p, c, i, s, a, ns, row, st);
+            cart_lane(p, c, i, s, a, rpo_load_episode(p.ep_len, p.ep_ret, p.ep_count, i), ns, row, st);
             if (p.rows) {
                 float4* gr = reinterpret_cast<float4*>(p.rows + (size_t)(ring_base + i) * RPO_CART_ROW);
 #pragma unroll

@@ -110,7 +110,7 @@ constexpr int kStepStats = 10;   // 0..7 sums (+terminated), 8..9 maxima -- see 
 // One lane's step: dynamics, violations, TimeLimit, statistics, auto-reset.  `row` receives the 6 float4 chunks of the
 // transition row (ReplayBuffer.add, buffer.py:22-29), `ns` the state the lane continues from.
 __device__ __forceinline__ void cart_lane(const StepArgs& p, const CartConsts& c, int i, const float (&s)[6], float2 a,
-                                          float (&ns)[6], float4 (&row)[6], float (&st)[kStepStats]) {
+                                          const RpoEpisode& ep, float (&ns)[6], float4 (&row)[6], float (&st)[kStepStats]) {
     RPO_FP_STRICT
     // violations of the PRE-step state and UN-clipped action (cartpole.py:229)
     float h, g[6];
@@ -143,10 +143,10 @@ __device__ __forceinline__ void cart_lane(const StepArgs& p, const CartConsts& c
     ns[5] = thetaacc;
     const bool terminated = ns[0] < -kXThreshold || ns[0] > kXThreshold || ns[3] < -kThetaThreshold ||
                             ns[3] > kThetaThreshold;                                  // cartpole.py:208-213
-    const int len = p.ep_len[i] + 1;
+    const int len = ep.len + 1;
     const bool done = terminated || len >= p.max_episode_steps;                        // gym TimeLimit
     const float reward = 1.0f;                                                         // cartpole.py:215-221
-    const float ret = p.ep_ret[i] + reward;
+    const float ret = ep.ret + reward;
 
     row[0] = make_float4(s[0], s[1], s[2], s[3]);
     row[1] = make_float4(s[4], s[5], a.x, a.y);
@@ -168,9 +168,9 @@ __device__ __forceinline__ void cart_lane(const StepArgs& p, const CartConsts& c
         st[7] += terminated ? 1.0f : 0.0f;
     }
     if (done && p.auto_reset) {   // env.reset() after a done, rpo_ddpg.py:142
-        const unsigned ep = p.ep_count[i] + 1u;
-        p.ep_count[i] = ep;
-        reset_state(ns, p.seed, p.env_id_base + (uint32_t)i, ep);
+        const unsigned episode = ep.count + 1u;
+        p.ep_count[i] = episode;
+        reset_state(ns, p.seed, p.env_id_base + (uint32_t)i, episode);
         p.ep_len[i] = 0;
         p.ep_ret[i] = 0.0f;
     } else {

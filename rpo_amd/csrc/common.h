@@ -82,11 +82,21 @@ __device__ __forceinline__ void rpo_atomic_max_nonneg(float* addr, float v) {
     atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 
+// Episode bookkeeping of a lane (gym TimeLimit counter, running return, episode index of the reset stream): loaded as
+// early as the kernel allows -- the step itself is a dependent chain, and these three loads would otherwise sit at its end.
+struct RpoEpisode { int len; float ret; unsigned count; };
+__device__ __forceinline__ RpoEpisode rpo_load_episode(const int* ep_len, const float* ep_ret, const unsigned* ep_count, int i) {
+    return RpoEpisode{ep_len[i], ep_ret[i], ep_count[i]};
+}
+
 // Statistics rows are split into RPO_STATS_SUB sub-rows (one cache line each); a workgroup adds into sub-row
 // blockIdx % RPO_STATS_SUB.  Up to 16 workgroups therefore never share an address (bitwise reproducible sums, summed by
 // the host in a fixed order); large grids spread their same-address atomics (~8 ns each, serialised) 16 ways.
+__device__ __forceinline__ float* rpo_stats_row_at(float* stats, int stats_cap, long long t, unsigned blk) {
+    return stats + ((t % stats_cap) * RPO_STATS_SUB + (blk % RPO_STATS_SUB)) * RPO_STATS_LEN;
+}
 __device__ __forceinline__ float* rpo_stats_row(float* stats, int stats_cap, long long t) {
-    return stats + ((t % stats_cap) * RPO_STATS_SUB + (blockIdx.x % RPO_STATS_SUB)) * RPO_STATS_LEN;
+    return rpo_stats_row_at(stats, stats_cap, t, blockIdx.x);
 }
 
 // Flush kStats per-thread partials (sums for k < n_sum, maxima after) of a 256-thread workgroup into `row` slots.
@@ -116,15 +126,18 @@ __device__ __forceinline__ void rpo_stats_flush(const float (&v)[K], int n_sum, 
 // the next vector step.  Every workgroup read t at its start, before any workgroup can have arrived last.  Arrival is
 // hierarchical -- 16 sub-counters on separate cache lines, then one top counter -- because 2048 returning atomics on
 // ONE address cost ~16 us (measured) while 128 per address cost ~1 us.
-__device__ __forceinline__ void rpo_step_epilogue(long long* ctrl, long long t, float* stats, int stats_cap) {
+// (`blk` of `nblk`: the stepping workgroups may be a subset of a larger launch -- the riding stages of nsplit.hip)
+__device__ __forceinline__ void rpo_step_epilogue_at(long long* ctrl, long long t, float* stats, int stats_cap, unsigned blk,
+                                                     unsigned nblk) {
     __syncthreads();
     if (threadIdx.x == 0 && ctrl != nullptr) {
-        const unsigned sub = blockIdx.x % RPO_STATS_SUB;
-        const unsigned subs = gridDim.x < RPO_STATS_SUB ? gridDim.x : RPO_STATS_SUB;
-        const unsigned long long in_sub = (gridDim.x - sub + RPO_STATS_SUB - 1) / RPO_STATS_SUB;
+        const unsigned sub = blk % RPO_STATS_SUB;
+        const unsigned subs = nblk < RPO_STATS_SUB ? nblk : RPO_STATS_SUB;
+        const unsigned long long in_sub = (nblk - sub + RPO_STATS_SUB - 1) / RPO_STATS_SUB;
         unsigned long long* sub_ctr = reinterpret_cast<unsigned long long*>(ctrl + RPO_CTRL_SUB0 + RPO_CTRL_SUB_STRIDE * sub);
-        if (atomicAdd(sub_ctr, 1ull) == in_sub - 1ull) {
-            *sub_ctr = 0;
+        // (up to 16 workgroups: every sub-counter would see one arrival -- they go to the top counter directly)
+        if (nblk <= RPO_STATS_SUB || atomicAdd(sub_ctr, 1ull) == in_sub - 1ull) {
+            if (nblk > RPO_STATS_SUB) *sub_ctr = 0;
             if (atomicAdd(reinterpret_cast<unsigned long long*>(ctrl + RPO_CTRL_ARRIVE), 1ull) == subs - 1ull) {
                 ctrl[RPO_CTRL_ARRIVE] = 0;
                 ctrl[RPO_CTRL_T] = t + 1;
@@ -135,4 +148,7 @@ __device__ __forceinline__ void rpo_step_epilogue(long long* ctrl, long long t, 
             }
         }
     }
+}
+__device__ __forceinline__ void rpo_step_epilogue(long long* ctrl, long long t, float* stats, int stats_cap) {
+    rpo_step_epilogue_at(ctrl, t, stats, stats_cap, blockIdx.x, gridDim.x);
 }

@@ -2,11 +2,14 @@
 // of the chip -- 128 workgroups per network evaluation instead of 16 -- cut at the seams where a value needs every
 // hidden column (the heads).  nsplit_dev.h has the slab function and the argument for why the results are bitwise
 // those of the row-tile kernels.
+#include <stdlib.h>
+
 #include "cartsafe_dev.h"
 #include "heads_dev.h"
 #include "mlp_bwd.h"
 #include "nsplit_dev.h"
 #include "pendulum_dev.h"
+#include "rollout_env.h"
 
 namespace {
 
@@ -64,8 +67,8 @@ __global__ __launch_bounds__(RPO_BLOCK) void mlp_split_head_kernel(Mlp net, int 
 // ====================================================================================== column-split critic update
 using rpo_cart_dev::CartConsts;
 
-struct CartRow { static constexpr int ROW = RPO_CART_ROW, CH = 6, S = 6, A_OFF = 6, NS_OFF = 8, R_OFF = 14; };
-struct PendRow { static constexpr int ROW = RPO_PEND_ROW, CH = 4, S = 5, A_OFF = 5, NS_OFF = 7, R_OFF = 12; };
+struct CartRow { typedef CartEnv Env; static constexpr int ROW = RPO_CART_ROW, CH = 6, S = 6, A_OFF = 6, NS_OFF = 8, R_OFF = 14; };
+struct PendRow { typedef PendEnv Env; static constexpr int ROW = RPO_PEND_ROW, CH = 4, S = 5, A_OFF = 5, NS_OFF = 7, R_OFF = 12; };
 
 // Device view of rpo_split_update (host network descriptors resolved to device pointer sets).
 struct SplitArgs {
@@ -141,13 +144,7 @@ __device__ __forceinline__ void ns_stage(NsLds<128>& lds, const float* tf, bool 
 // ---- fwd_a: grid (row tiles, 8 column groups, roles).  Role 0 = the policy on s' (pi_targ for RPODDPG, pi for RPOSAC),
 //      roles 1.. = the critics on the stored (s, a), pre-activations saved for the backward pass.
 template <class L>
-__global__ __launch_bounds__(kNsThreads) void split_critic_fwd_a_kernel(SplitArgs p) {
-    __shared__ NsLds<128> lds;
-    __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
-    // the column group is the FASTEST grid dimension: workgroup b lands on XCD b % 8 == g, so each XCD's L2 fetches only the
-    // 1/8 slice of W0 its groups read (with the row tile fastest every XCD pulled every network's whole W0 per launch:
-    // 3.0 MB of traffic for ~0.35 MB of unique bytes, profiles/r02_pmc_traffic.json)
-    const int row0 = blockIdx.y * kRows, g = blockIdx.x, role = blockIdx.z;
+__device__ __forceinline__ void fwd_a_role(const SplitArgs& p, NsLds<128>& lds, float4* tile, int row0, int g, int role) {
     const Mlp& net = role == 0 ? (p.twin ? p.actor : p.actor_target) : p.critic[role - 1];
     NsWeights<128> w;
     ns_load_weights<128, 256>(net, g, w);
@@ -157,6 +154,16 @@ __global__ __launch_bounds__(kNsThreads) void split_critic_fwd_a_kernel(SplitArg
     ns_stage<L>(lds, reinterpret_cast<const float*>(tile), role == 0, role != 0);
     if (role == 0) ns_hidden<128, 256>(net, w, lds, g, row0, p.B, p.part_pi, nullptr, nullptr);
     else ns_hidden<128, 256>(net, w, lds, g, row0, p.B, p.part_q[role - 1], p.x0[role - 1], p.h1[role - 1]);
+}
+
+template <class L>
+__global__ __launch_bounds__(kNsThreads) void split_critic_fwd_a_kernel(SplitArgs p) {
+    __shared__ NsLds<128> lds;
+    __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
+    // the column group is the FASTEST grid dimension: workgroup b lands on XCD b % 8 == g, so each XCD's L2 fetches only the
+    // 1/8 slice of W0 its groups read (with the row tile fastest every XCD pulled every network's whole W0 per launch:
+    // 3.0 MB of traffic for ~0.35 MB of unique bytes, profiles/r02_pmc_traffic.json)
+    fwd_a_role<L>(p, lds, tile, blockIdx.y * kRows, blockIdx.x, blockIdx.z);
 }
 
 // The policy head of row i from the slab partials: tanh box (RPODDPG, model/policy.py:30-31) or rsample of the squashed
@@ -183,10 +190,9 @@ __device__ __forceinline__ float ns_policy_head(const SplitArgs& p, int i, long 
 //      (== the reference's batched call for this env) in the prologue; PROJ = 0 (SpringPendulum): the projected actions
 //      come from rpo_split_pend_head_project.
 template <class L, int PROJ>
-__global__ __launch_bounds__(kNsThreads) void split_critic_fwd_b_kernel(SplitArgs p, CartConsts c) {
-    __shared__ NsLds<128> lds;
-    __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
-    const int row0 = blockIdx.y * kRows, g = blockIdx.x, k = blockIdx.z, tid = threadIdx.x;
+__device__ __forceinline__ void fwd_b_role(const SplitArgs& p, const CartConsts& c, NsLds<128>& lds, float4* tile, int row0, int g,
+                                           int k) {
+    const int tid = threadIdx.x;
     const Mlp& net = p.critic_target[k];
     NsWeights<128> w;
     ns_load_weights<128, 256>(net, g, w);
@@ -217,6 +223,131 @@ __global__ __launch_bounds__(kNsThreads) void split_critic_fwd_b_kernel(SplitArg
         lds.in_a[tid * 8 + 1] = act.y;
     }
     ns_hidden<128, 256>(net, w, lds, g, row0, p.B, p.part_qn[k], nullptr, nullptr);
+}
+
+template <class L, int PROJ>
+__global__ __launch_bounds__(kNsThreads) void split_critic_fwd_b_kernel(SplitArgs p, CartConsts c) {
+    __shared__ NsLds<128> lds;
+    __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
+    fwd_b_role<L, PROJ>(p, c, lds, tile, blockIdx.y * kRows, blockIdx.x, blockIdx.z);
+}
+
+// ============================================================================== rollout stages riding on update launches
+// Vector step t+1 needs nothing the critic update of step t produces (no shared state embedding, no policy step in
+// between) and the update reads its own clock, so the step is given to workgroups the update launches leave idle:
+//   * the actor forward of the lanes (column-split: 16 lanes x 32 hidden columns per workgroup, head partials to `part`)
+//     touches neither the ring nor anything the update writes: it rides on fwd_a AND fwd_b, a lane range each -- 2048
+//     extra workgroups behind one launch cost more than the launch (13.3 vs 8.8 us), ~1000 ride almost free;
+//   * explore + project + env step + replay scatter + statistics (one thread per lane) write the ring, so they run behind
+//     fwd_a's gather: they ride on bwd_b, the longest of the remaining launches.
+// Same arithmetic as rollout_kernel (fused.hip): the slab forward is bitwise the row-tile forward (nsplit_dev.h), the lane
+// functions are the same inlined code.
+template <class ENV>
+struct RideArgs {
+    Mlp actor;
+    float scale, base;
+    int gauss, n;
+    int lane0, lane1;             // forward stages: the lanes of this launch (multiples of 16, or n)
+    typename ENV::ActArgs act;
+    typename ENV::StepArgs step;
+    float* part;                  // [8, n, 2]
+};
+
+__device__ __forceinline__ const CartConsts& env_consts(const CartConsts& c, CartEnv*) { return c; }
+__device__ __forceinline__ PendEnv::Consts env_consts(const CartConsts&, PendEnv*) { return PendEnv::Consts{0}; }
+
+// forward workgroup `wg` of the launch: column group g of lanes [lane0 + 16 wg, +16)
+template <class ENV>
+__device__ __forceinline__ void ride_forward(const RideArgs<ENV>& r, NsLds<128>& lds, int wg, int g) {
+    const int row0 = r.lane0 + wg * kRows;
+    if (row0 >= r.lane1) return;
+    NsWeights<128> w;
+    ns_load_weights<128, 256>(r.actor, g, w);
+    ENV::stage_obs(r.step, row0, kRows, lds.in_s, 8);           // (S <= 6 entries per lane; the slab reads only those)
+    ns_hidden<128, 256>(r.actor, w, lds, g, row0, r.n, r.part, nullptr, nullptr);
+}
+
+// blocks `blk` of `nblk` (kThreads lanes each); smem: 4 * 11 floats
+template <class ENV>
+__device__ __forceinline__ void ride_tail(const RideArgs<ENV>& r, const CartConsts& cc, float* smem, unsigned blk, unsigned nblk) {
+    constexpr int kStats = 10;
+    const int tid = threadIdx.x, i = (int)blk * kThreads + tid;
+    const long long t = r.step.ctrl[RPO_CTRL_T];
+    float st[kStats + 1];
+#pragma unroll
+    for (int k = 0; k <= kStats; ++k) st[k] = 0.0f;
+    if (i < r.n) {
+        // everything the lane reads is requested up front: the step below is one dependent chain
+        const RpoEpisode ep = ENV::episode(r.step, i);
+        float obs[8];
+        ENV::lane_obs(r.step, i, obs);
+        float ap = ns_head(r.part, r.n, i, 0, r.actor.b1[0]);
+        const float eps_t = fmaxf(r.act.eps_end, r.act.eps_start - r.act.eps_decay * (float)t);
+        if (r.gauss) {
+            const float rl = ns_head(r.part, r.n, i, 1, r.actor.b1b[0]);
+            const rpo_u4 u = rpo_philox(r.act.seed, r.act.env_id_base + (uint32_t)i, (uint32_t)t, RPO_STREAM_POLICY,
+                                        (uint32_t)r.step.ctrl[RPO_CTRL_UPDATES]);
+            ap = rpo_head_dev::gauss_head_row(ap, rl, rpo_normal(u.x, u.y), r.scale, r.base, r.act.box_lo, r.act.box_hi, 0, nullptr);
+        } else {
+            ap = r.scale * tanhf(ap) + r.base;
+        }
+        int k;
+        const auto c = env_consts(cc, (ENV*)nullptr);
+        const float2 a = ENV::project(r.act, c, obs, i, ap, eps_t, t, k);
+        reinterpret_cast<float2*>(r.act.action)[i] = a;
+        const long long ring_base = r.step.rows ? (t % r.step.cap_steps) * (long long)r.n : 0;
+        float lane_st[kStats];
+#pragma unroll
+        for (int q = 0; q < kStats; ++q) lane_st[q] = 0.0f;
+        ENV::lane(r.step, c, i, obs, a, ep, ring_base, lane_st);
+#pragma unroll
+        for (int q = 0; q < kStats; ++q) st[q] = lane_st[q];
+        st[kStats] = (float)k;
+    }
+    if (r.step.stats) {
+        // sums 0..7, maxima 8..9 (rollout_kernel's slots), then the projection-iteration sum; every block owns a sub-row
+        float* srow = rpo_stats_row_at(r.step.stats, r.step.stats_cap, t, blk);
+        const int lane = tid & (RPO_WAVE - 1), wave = tid / RPO_WAVE;
+#pragma unroll
+        for (int k = 0; k <= kStats; ++k) {
+            const bool mx = k == 8 || k == 9;
+            const float v = mx ? rpo_wave_max(st[k]) : rpo_wave_sum(st[k]);
+            if (lane == 0) smem[wave * (kStats + 1) + k] = v;
+        }
+        __syncthreads();
+        if (tid <= kStats) {
+            const int slot[kStats + 1] = {RPO_STAT_REWARD_SUM, RPO_STAT_EPISODES, RPO_STAT_RETURN_SUM, RPO_STAT_LENGTH_SUM,
+                                          RPO_STAT_MAX_INEQ_SUM, RPO_STAT_MAX_EQ_SUM, RPO_STAT_VIOL_COUNT, RPO_STAT_TERMINATED,
+                                          RPO_STAT_MAX_INEQ_MAX, RPO_STAT_MAX_EQ_MAX, RPO_STAT_PROJ_ITERS};
+            const bool mx = tid == 8 || tid == 9;
+            float v = smem[tid];
+            for (int w = 1; w < kThreads / RPO_WAVE; ++w)
+                v = mx ? fmaxf(v, smem[w * (kStats + 1) + tid]) : v + smem[w * (kStats + 1) + tid];
+            if (mx) { if (v > 0.0f) rpo_atomic_max_nonneg(srow + slot[tid], v); }
+            else if (v != 0.0f) atomicAdd(srow + slot[tid], v);
+        }
+    }
+    rpo_step_epilogue_at(r.step.ctrl, t, r.step.stats, r.step.stats_cap, blk, nblk);
+}
+
+// fwd_a / fwd_b + the actor forward of a lane range: grid (8 column groups, row tiles of the batch, roles + planes of lane
+// tiles); the update's own workgroups come first in dispatch order
+template <class L>
+__global__ __launch_bounds__(kNsThreads) void split_critic_fwd_a_ride_kernel(SplitArgs p, RideArgs<typename L::Env> r) {
+    __shared__ NsLds<128> lds;
+    __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
+    const int roles = (p.twin ? 2 : 1) + 1;
+    if ((int)blockIdx.z < roles) fwd_a_role<L>(p, lds, tile, blockIdx.y * kRows, blockIdx.x, blockIdx.z);
+    else ride_forward<typename L::Env>(r, lds, ((int)blockIdx.z - roles) * (int)gridDim.y + (int)blockIdx.y, blockIdx.x);
+}
+
+template <class L, int PROJ>
+__global__ __launch_bounds__(kNsThreads) void split_critic_fwd_b_ride_kernel(SplitArgs p, CartConsts c, RideArgs<typename L::Env> r) {
+    __shared__ NsLds<128> lds;
+    __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
+    const int K = p.twin ? 2 : 1;
+    if ((int)blockIdx.z < K) fwd_b_role<L, PROJ>(p, c, lds, tile, blockIdx.y * kRows, blockIdx.x, blockIdx.z);
+    else ride_forward<typename L::Env>(r, lds, ((int)blockIdx.z - K) * (int)gridDim.y + (int)blockIdx.y, blockIdx.x);
 }
 
 // ---- SpringPendulum: head of the policy + the reference's batch-coupled projection (pendulum.py:337-339), one workgroup
@@ -396,13 +527,13 @@ __device__ __forceinline__ float ns_weight_role(const Mlp& net, const MlpGrad& g
 // ---- bwd_a: TD target + Huber (from the slab partials) -> dh = dLoss/dQ * W1 * 1[h1 > 0] (on the fly) -> dx0 of one
 //      (critic k, row tile, 16 first-layer columns); the column-group-0 workgroup of a tile leaves dLoss/dQ and the loss share.
 //      blocks (critic, row tile, column group), 256 threads.
+constexpr int kBwdASmem = kRows * (256 + 4) + 16 + 4 * 16 * 16;
+
 template <class L>
-__global__ __launch_bounds__(kThreads) void split_critic_bwd_a_kernel(SplitArgs p) {
+__device__ __forceinline__ void bwd_a_role(const SplitArgs& p, float* smem, int b) {
     constexpr int EIN = 128, H = 256, LDH = H + 4;
-    __shared__ __attribute__((aligned(16))) float smem[kRows * LDH + 16 + 4 * 16 * 16];
     const int T = (p.B + kRows - 1) / kRows, B = p.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    const int b = blockIdx.x;
     {
         const int k = b / (T * kNsGroups), rem = b - k * T * kNsGroups, tile = rem / kNsGroups, g = rem - tile * kNsGroups;
         const int row0 = tile * kRows;
@@ -452,16 +583,19 @@ __global__ __launch_bounds__(kThreads) void split_critic_bwd_a_kernel(SplitArgs 
     }
 }
 
+template <class L>
+__global__ __launch_bounds__(kThreads) void split_critic_bwd_a_kernel(SplitArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[kBwdASmem];
+    bwd_a_role<L>(p, smem, blockIdx.x);
+}
+
 // ---- bwd_b: every parameter gradient of critic k = blockIdx.y.  blocks [0, 36): dW0 tiles and hidden-layer vectors from
 //      dLoss/dQ (left by bwd_a) and the saved activations, dh formed on the fly; then the first-layer gradients dWs / dbs /
 //      dWa / dba from dx0 (batch reduction, one owner per output, fixed order).  Leaves the inf-norm of what it wrote.
 template <class L>
-__global__ __launch_bounds__(kThreads) void split_critic_bwd_b_kernel(SplitArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * 16 * 16];
-    const int k = blockIdx.y;
-    if (blockIdx.x < kWeightBlocks) {
-        gradmax_flush(p.gradmax, ns_weight_role(p.critic[k], p.critic_grad[k], p.h1[k], p.x0[k], p.dq[k], 1, false, p.B,
-                                                blockIdx.x, smem));
+__device__ __forceinline__ void bwd_b_role(const SplitArgs& p, float* smem, int bx, int k) {
+    if (bx < kWeightBlocks) {
+        gradmax_flush(p.gradmax, ns_weight_role(p.critic[k], p.critic_grad[k], p.h1[k], p.x0[k], p.dq[k], 1, false, p.B, bx, smem));
         return;
     }
     BwdArgs a{};
@@ -473,7 +607,23 @@ __global__ __launch_bounds__(kThreads) void split_critic_bwd_b_kernel(SplitArgs 
     a.dx0 = p.dx0[k];
     a.param_grads = 1;
     a.first_layer_state_only = 0;
-    gradmax_flush(p.gradmax, mlp_bwd_first_layer<128>(a, blockIdx.x - kWeightBlocks));
+    gradmax_flush(p.gradmax, mlp_bwd_first_layer<128>(a, bx - kWeightBlocks));
+}
+
+template <class L>
+__global__ __launch_bounds__(kThreads) void split_critic_bwd_b_kernel(SplitArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * 16 * 16];
+    bwd_b_role<L>(p, smem, blockIdx.x, blockIdx.y);
+}
+
+// bwd_b + explore / project / step / scatter of the lanes: grid (own_blocks + lane blocks, K); the extra x-blocks of plane 0
+// step 256 lanes each (those of plane 1 leave at once)
+template <class L>
+__global__ __launch_bounds__(kThreads) void split_critic_bwd_b_ride_kernel(SplitArgs p, CartConsts c, RideArgs<typename L::Env> r,
+                                                                           int own_blocks) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * 16 * 16];
+    if ((int)blockIdx.x < own_blocks) bwd_b_role<L>(p, smem, blockIdx.x, blockIdx.y);
+    else if (blockIdx.y == 0) ride_tail<typename L::Env>(r, c, smem, blockIdx.x - own_blocks, gridDim.x - own_blocks);
 }
 
 }  // namespace
@@ -1012,6 +1162,125 @@ int rpo_split_critic_bwd_b(const rpo_split_update* u, void* stream) {
     const int blocks = kWeightBlocks + mlp_fl_blocks(m.E * (m.S + 1 + m.A + 1));
     if (u->env == 0) hipLaunchKernelGGL(split_critic_bwd_b_kernel<CartRow>, dim3(blocks, K), dim3(kThreads), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(split_critic_bwd_b_kernel<PendRow>, dim3(blocks, K), dim3(kThreads), 0, (hipStream_t)stream, a);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- riding rollout stages
+namespace {
+
+int ride_check(const rpo_split_update* u, const rpo_rollout_rider* r) {
+    if (!u || !r) return RPO_ERR_NULL;
+    if (r->n_envs <= 0 || r->max_episode_steps <= 0 || r->max_steps < 0) return RPO_ERR_ARG;
+    if (r->noise_mode != RPO_NOISE_NONE && r->noise_mode != RPO_NOISE_PHILOX && r->noise_mode != RPO_NOISE_CLIP_ONLY) return RPO_ERR_ARG;
+    if (!r->state || !r->action || !r->ep_len || !r->ep_ret || !r->ep_count || !r->ctrl || !r->part) return RPO_ERR_NULL;
+    if ((r->rows && r->cap_steps <= 0) || (r->stats && r->stats_cap <= 0)) return RPO_ERR_ARG;
+    if ((r->gauss != 0) != (u->twin != 0)) return RPO_ERR_ARG;          // u->actor is the rollout policy
+    if (u->shared_embedding) return RPO_ERR_ARG;                         // the critic step would change the policy under the rollout
+    return 0;
+}
+
+void ride_env(const rpo_rollout_rider* r, RideArgs<CartEnv>& o) {
+    o.act = rpo_cart_dev::ActArgs{r->n_envs, nullptr, nullptr, r->action, nullptr, r->noise_mode, r->eps_start, r->eps_end,
+                                  r->eps_decay, r->box_lo, r->box_hi, r->max_steps, r->corr_lr, r->corr_eps, r->corr_momentum,
+                                  (uint64_t)r->seed, (uint32_t)r->env_id_base, r->ctrl, r->stats, r->stats_cap};
+    o.step = rpo_cart_dev::StepArgs{r->n_envs, r->state, r->action, r->ep_len, r->ep_ret, r->ep_count, r->rows, r->cap_steps,
+                                    r->stats, r->stats_cap, r->ctrl, r->max_episode_steps, r->auto_reset, r->viol_thresh,
+                                    (uint64_t)r->seed, (uint32_t)r->env_id_base, 0};
+}
+
+void ride_env(const rpo_rollout_rider* r, RideArgs<PendEnv>& o) {
+    o.act = rpo_pend_dev::ActArgs{r->n_envs, nullptr, 5, nullptr, nullptr, r->action, nullptr, r->noise_mode, r->eps_start,
+                                  r->eps_end, r->eps_decay, r->box_lo, r->box_hi, r->max_steps, r->corr_lr, r->corr_eps,
+                                  r->corr_momentum, (uint64_t)r->seed, (uint32_t)r->env_id_base, r->ctrl, r->stats, r->stats_cap};
+    o.step = rpo_pend_dev::StepArgs{r->n_envs, r->state, r->obs, r->action, r->ep_len, r->ep_ret, r->ep_count, r->rows,
+                                    r->cap_steps, r->stats, r->stats_cap, r->ctrl, r->max_episode_steps, r->auto_reset,
+                                    r->viol_thresh, (uint64_t)r->seed, (uint32_t)r->env_id_base};
+}
+
+template <class ENV>
+RideArgs<ENV> ride_args(const SplitArgs& a, const rpo_rollout_rider* r) {
+    RideArgs<ENV> o{};
+    o.actor = a.actor; o.scale = r->scale; o.base = r->base; o.gauss = r->gauss ? 1 : 0; o.n = r->n_envs; o.part = r->part;
+    o.lane0 = r->lane_begin; o.lane1 = r->lane_end;
+    ride_env(r, o);
+    return o;
+}
+
+}  // namespace
+
+extern "C" {
+
+// forward stages: lanes [lane_begin, lane_end) of this launch
+static int ride_range(const rpo_rollout_rider* r) {
+    if (r->lane_begin < 0 || r->lane_begin % kRows || r->lane_end < r->lane_begin || r->lane_end > r->n_envs ||
+        (r->lane_end % kRows && r->lane_end != r->n_envs))
+        return RPO_ERR_ARG;
+    return 0;
+}
+
+int rpo_split_critic_fwd_a_ride(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream) {
+    if (int e = ride_check(u, r)) return e;
+    if (int e = ride_range(r)) return e;
+    SplitArgs a; CartConsts c;
+    if (int e = to_args(u, 1u | 2u | 32u, a, c)) return e;
+    const int K = a.twin ? 2 : 1, T = (a.B + kRows - 1) / kRows;
+    if (!a.rows || !a.batch_out || !a.ctrl || !a.part_pi || a.cap_steps <= 0 || a.n_envs <= 0) return RPO_ERR_NULL;
+    for (int k = 0; k < K; ++k)
+        if (!a.part_q[k] || !a.x0[k] || !a.h1[k]) return RPO_ERR_NULL;
+    const int lane_wgs = (r->lane_end - r->lane_begin + kRows - 1) / kRows;
+    const dim3 grid(kNsGroups, T, 1 + K + (lane_wgs + T - 1) / T);
+    if (u->env == 0)
+        hipLaunchKernelGGL(split_critic_fwd_a_ride_kernel<CartRow>, grid, dim3(kNsThreads), 0, (hipStream_t)stream, a, ride_args<CartEnv>(a, r));
+    else
+        hipLaunchKernelGGL(split_critic_fwd_a_ride_kernel<PendRow>, grid, dim3(kNsThreads), 0, (hipStream_t)stream, a, ride_args<PendEnv>(a, r));
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_split_critic_fwd_b_ride(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream) {
+    if (int e = ride_check(u, r)) return e;
+    if (int e = ride_range(r)) return e;
+    SplitArgs a; CartConsts c;
+    if (int e = to_args(u, (u->env == 0 ? 1u : 0u) | 4u | 32u, a, c)) return e;
+    const int K = a.twin ? 2 : 1, T = (a.B + kRows - 1) / kRows;
+    if (!a.batch_out || !a.ctrl) return RPO_ERR_NULL;
+    for (int k = 0; k < K; ++k)
+        if (!a.part_qn[k]) return RPO_ERR_NULL;
+    const int lane_wgs = (r->lane_end - r->lane_begin + kRows - 1) / kRows;
+    const dim3 grid(kNsGroups, T, K + (lane_wgs + T - 1) / T);
+    if (u->env == 0) {
+        if (!a.part_pi || (a.twin && !a.logp) || a.max_steps < 0) return RPO_ERR_NULL;
+        hipLaunchKernelGGL((split_critic_fwd_b_ride_kernel<CartRow, 1>), grid, dim3(kNsThreads), 0, (hipStream_t)stream, a, c,
+                           ride_args<CartEnv>(a, r));
+    } else {
+        if (!a.next_actions) return RPO_ERR_NULL;
+        hipLaunchKernelGGL((split_critic_fwd_b_ride_kernel<PendRow, 0>), grid, dim3(kNsThreads), 0, (hipStream_t)stream, a, c,
+                           ride_args<PendEnv>(a, r));
+    }
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_split_critic_bwd_b_ride(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream) {
+    if (int e = ride_check(u, r)) return e;
+    SplitArgs a; CartConsts c;
+    if (int e = to_args(u, 2u | 8u | 32u, a, c)) return e;
+    const int K = a.twin ? 2 : 1;
+    if (!a.batch_out) return RPO_ERR_NULL;
+    for (int k = 0; k < K; ++k)
+        if (!a.dx0[k] || !a.dq[k] || !a.x0[k] || !a.h1[k]) return RPO_ERR_NULL;
+    const Mlp& m = a.critic[0];
+    const int own = kWeightBlocks + mlp_fl_blocks(m.E * (m.S + 1 + m.A + 1));
+    const dim3 grid(own + (r->n_envs + kThreads - 1) / kThreads, K);
+    if (u->env == 0)
+        hipLaunchKernelGGL(split_critic_bwd_b_ride_kernel<CartRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c,
+                           ride_args<CartEnv>(a, r), own);
+    else
+        hipLaunchKernelGGL(split_critic_bwd_b_ride_kernel<PendRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c,
+                           ride_args<PendEnv>(a, r), own);
     RPO_LAUNCH_CHECK();
     return 0;
 }

@@ -64,8 +64,8 @@ constexpr int kStepStats = 10;
 // One lane's step: dynamics, violations, TimeLimit, statistics, auto-reset (pendulum.py:80-128 + the bookkeeping of
 // rpo_ddpg.py:120-145).  `row` gets the 4 float4 chunks of the transition row, `ns` / (ncs, nsn) the state and
 // observation the lane continues from.
-__device__ __forceinline__ void pend_lane(const StepArgs& p, int i, float4 s, float2 a, float (&ns)[4], float& ncs, float& nsn,
-                                          float4 (&row)[4], float (&st)[kStepStats]) {
+__device__ __forceinline__ void pend_lane(const StepArgs& p, int i, float4 s, float2 a, const RpoEpisode& ep, float (&ns)[4],
+                                          float& ncs, float& nsn, float4 (&row)[4], float (&st)[kStepStats]) {
     RPO_FP_STRICT
     const float th = s.x, thdot = s.y, l = s.z, ldot = s.w;
     float sn, cs;
@@ -93,9 +93,9 @@ __device__ __forceinline__ void pend_lane(const StepArgs& p, int i, float4 s, fl
     nthdot = fminf(fmaxf(nthdot, -kMaxSpeed), kMaxSpeed);
     const bool terminated = nl <= 0.5f || nl >= 1.5f || nth >= kThetaLim || nth <= -kThetaLim;   // :124
     const float reward = 1.0f / (100.0f * costs + 1.0f);
-    const int len = p.ep_len[i] + 1;
+    const int len = ep.len + 1;
     const bool done = terminated || len >= p.max_episode_steps;
-    const float ret = p.ep_ret[i] + reward;
+    const float ret = ep.ret + reward;
     sincosf(nth, &nsn, &ncs);
 
     row[0] = make_float4(cs, sn, thdot, l);
@@ -116,9 +116,9 @@ __device__ __forceinline__ void pend_lane(const StepArgs& p, int i, float4 s, fl
     }
     ns[0] = nth; ns[1] = nthdot; ns[2] = nl; ns[3] = nldot;
     if (done && p.auto_reset) {
-        const unsigned ep = p.ep_count[i] + 1u;
-        p.ep_count[i] = ep;
-        reset_internal(ns, p.seed, p.env_id_base + (uint32_t)i, ep);
+        const unsigned episode = ep.count + 1u;
+        p.ep_count[i] = episode;
+        reset_internal(ns, p.seed, p.env_id_base + (uint32_t)i, episode);
         sincosf(ns[0], &nsn, &ncs);
         p.ep_len[i] = 0;
         p.ep_ret[i] = 0.0f;

@@ -719,6 +719,42 @@ class _SplitUpdateStruct(ctypes.Structure):
         [("shared_embedding", ctypes.c_int)])
 
 
+class _RolloutRiderStruct(ctypes.Structure):
+    """rpo_rollout_rider of include/rpo_hip.h (same field order)."""
+    _fields_ = [("n_envs", ctypes.c_int), ("gauss", ctypes.c_int), ("scale", ctypes.c_float), ("base", ctypes.c_float),
+                ("state", ctypes.c_void_p), ("obs", ctypes.c_void_p), ("action", ctypes.c_void_p),
+                ("ep_len", ctypes.c_void_p), ("ep_ret", ctypes.c_void_p), ("ep_count", ctypes.c_void_p),
+                ("rows", ctypes.c_void_p), ("cap_steps", ctypes.c_longlong), ("stats", ctypes.c_void_p),
+                ("stats_cap", ctypes.c_int), ("noise_mode", ctypes.c_int), ("ctrl", ctypes.c_void_p),
+                ("eps_start", ctypes.c_float), ("eps_end", ctypes.c_float), ("eps_decay", ctypes.c_float),
+                ("box_lo", ctypes.c_float), ("box_hi", ctypes.c_float), ("max_steps", ctypes.c_int),
+                ("corr_lr", ctypes.c_float), ("corr_eps", ctypes.c_float), ("corr_momentum", ctypes.c_float),
+                ("max_episode_steps", ctypes.c_int), ("auto_reset", ctypes.c_int), ("viol_thresh", ctypes.c_float),
+                ("env_id_base", ctypes.c_uint), ("seed", ctypes.c_ulonglong), ("part", ctypes.c_void_p),
+                ("lane_begin", ctypes.c_int), ("lane_end", ctypes.c_int)]
+
+
+class RolloutRider(object):
+    """Arguments of the rollout stages that ride on the critic update's launches (rpo_split_critic_fwd_a_ride /
+    _fwd_b_ride: the actor forward of a lane range; _bwd_b_ride: the step): the same values `rollout()` of the env kernels
+    takes, plus the partials workspace and the lane range."""
+
+    _DTYPES = dict(ep_len=torch.int32, ep_count=torch.int32, ctrl=torch.int64)
+
+    def __init__(self, **fields):
+        self.st, self._held = _RolloutRiderStruct(), {}
+        self.set(**fields)
+
+    def set(self, **fields):
+        for k, v in fields.items():
+            if isinstance(v, torch.Tensor):
+                self._held[k] = v
+                setattr(self.st, k, _p(v, self._DTYPES.get(k, torch.float32)).value)
+            else:
+                self._held.pop(k, None)
+                setattr(self.st, k, v)
+
+
 class SplitUpdate(object):
     """Arguments of the column-split update stages (rpo_split_*), built once per trainer: every pointer refers to a static
     device buffer, so the struct is reused for every launch (and every hipGraph capture)."""
@@ -760,5 +796,11 @@ class SplitUpdate(object):
                 self._held.pop(k, None)
                 setattr(self.st, k, v)
 
-    def run(self, stage):
-        check(getattr(_lib.load(), "rpo_split_" + stage)(ctypes.byref(self.st), _stream()), "rpo_split_" + stage)
+    def run(self, stage, rider=None):
+        """``rider``: a RolloutRider whose share of the next vector step rides on this launch (critic_fwd_a / critic_fwd_b:
+        the actor forward of lanes [lane_begin, lane_end), critic_bwd_b: explore / project / step / scatter)."""
+        if rider is None:
+            check(getattr(_lib.load(), "rpo_split_" + stage)(ctypes.byref(self.st), _stream()), "rpo_split_" + stage)
+        else:
+            name = "rpo_split_" + stage + "_ride"
+            check(getattr(_lib.load(), name)(ctypes.byref(self.st), ctypes.byref(rider.st), _stream()), name)

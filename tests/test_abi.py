@@ -56,7 +56,7 @@ def test_struct_layouts_match_the_compiler(tmp_path):
     import torch  # noqa: F401  (rpo_amd.ops imports it)
     from rpo_amd import ops
     structs = {"rpo_split_update": ops._SplitUpdateStruct, "rpo_adam_seg": ops._AdamSegStruct, "rpo_mlp": ops._MlpStruct,
-               "rpo_mlp_grad": ops._MlpGradStruct, "rpo_td": ops._TdStruct}
+               "rpo_mlp_grad": ops._MlpGradStruct, "rpo_td": ops._TdStruct, "rpo_rollout_rider": ops._RolloutRiderStruct}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % _lib.HEADER, "int main(void) {"]
     for cname, st in structs.items():
         lines.append('printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
@@ -85,4 +85,6 @@ def test_split_update_stages_validate_arguments():
     for stage in ("critic_fwd_a", "critic_fwd_b", "pend_head_project", "critic_bwd_a", "critic_bwd_b", "policy_a",
                   "policy_b", "policy_c", "policy_d", "policy_e"):
         assert getattr(lib, "rpo_split_" + stage)(None, None) == _lib.CONST["RPO_ERR_NULL"]
+    for stage in ("critic_fwd_a_ride", "critic_fwd_b_ride", "critic_bwd_b_ride"):            # the riding rollout halves: both structs are required
+        assert getattr(lib, "rpo_split_" + stage)(None, None, None) == _lib.CONST["RPO_ERR_NULL"]
     assert _lib.CONST["RPO_ABI_VERSION"] == 2

@@ -48,6 +48,17 @@ def _run(algo, envname, backend, device, iters, n_envs, use_graph, seed_all=5, f
     return tr
 
 
+def _stats_equal(a, b, n):
+    """Per-step statistics of two runs: counters exactly, float sums over lanes to rounding (the riding rollout adds the
+    lanes of a step in another association than the one-launch rollout; both are sums of the same per-lane values)."""
+    from rpo_amd import ops
+    S = ops.STAT
+    exact = [S[k] for k in ("episodes", "length_sum", "viol_count", "terminated", "proj_iters")]
+    sa, sb = ops.reduce_stats(a.vec.stats[:n]).cpu().numpy(), ops.reduce_stats(b.vec.stats[:n]).cpu().numpy()
+    np.testing.assert_array_equal(sa[:, exact], sb[:, exact])
+    np.testing.assert_allclose(sa, sb, rtol=2e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize("fused", [True, False], ids=["fused_mlp", "torch_mlp"])
 @pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "pendulum")])
 def test_graph_replay_equals_eager(hip, algo, envname, fused):
@@ -60,7 +71,7 @@ def test_graph_replay_equals_eager(hip, algo, envname, fused):
     assert torch.equal(a.agent.flat.data, b.agent.flat.data)
     assert torch.equal(a.agent.nju.weight, b.agent.nju.weight)
     assert int(b.vec.ctrl[0]) == 24 == int(a.vec.ctrl[0])
-    assert torch.equal(a.vec.stats[:24], b.vec.stats[:24])
+    _stats_equal(a, b, 24)
 
 
 @pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "cart"), ("ddpg", "pendulum")])
@@ -69,6 +80,7 @@ def test_multi_iteration_graph_equals_single_iteration_graphs(hip, algo, envname
     against eager launches; 70 iterations = 3 eager passes of the window, its capture, 4 replays and a ragged tail."""
     dev = torch.device("cuda")
     monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
+    monkeypatch.setenv("RPO_RIDE", "0")                        # (the riding rollout has its own test below)
     a = _run(algo, envname, hip, dev, 70, 256, use_graph=True)
     assert a._cycle == 8 and a._graphs.entries[("cycle", 8, True)]["graph"] is not None
     monkeypatch.setenv("RPO_GRAPH_CYCLE", "1")
@@ -305,7 +317,8 @@ def _rccl_worker(rank, world, port, out_dir, algo, n_total, iters):
     tr._harvest(final=True)
     torch.cuda.synchronize()
     captured = [k for k, e in tr._graphs.entries.items() if e["graph"] is not None]
-    assert ("cycle", 8, True) in captured, captured          # multi-iteration windows WITH the collectives inside
+    # multi-iteration windows WITH the collectives inside
+    assert ("cycle", 8, True) in captured or ("cycle", 8, True, "ride") in captured, captured
     assert tr._graphs.enabled                                 # no capture failure fell back to eager launches
     torch.save(dict(flat=tr.agent.flat.data.cpu(), nju=tr.agent.nju.weight.data.cpu(), env_steps=float(tr.env_steps),
                     state=tr.vec.internal.cpu(), rows=tr.buffer.rows[:64 * tr.n_local].cpu(), seed=tr.seed),
@@ -536,6 +549,7 @@ def test_overlapped_rollout_equals_serial(hip, algo, envname, monkeypatch):
     update reads its own clock, so nothing it sees moves: 70 iterations equal the serial order bit for bit."""
     dev = torch.device("cuda")
     monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
+    monkeypatch.setenv("RPO_RIDE", "0")
     monkeypatch.setenv("RPO_OVERLAP", "1")
     a = _run(algo, envname, hip, dev, 70, 300, use_graph=True)
     assert a._overlap_ok(True) and a._graphs.entries[("cycle", 8, True, "overlap")]["graph"] is not None
@@ -556,3 +570,40 @@ def test_overlapped_rollout_equals_serial(hip, algo, envname, monkeypatch):
     monkeypatch.setenv("RPO_OVERLAP", "1")
     e = _run(algo, envname, hip, dev, 70, 64, use_graph=True, capacity=5)
     assert torch.equal(d.agent.flat.data, e.agent.flat.data) and torch.equal(d.buffer.rows, e.buffer.rows)
+
+
+@pytest.mark.parametrize("algo,envname", [("sac", "cart"), ("ddpg", "pendulum"), ("sac", "pendulum")])
+def test_ridden_rollout_equals_serial(hip, algo, envname, monkeypatch):
+    """Inside a multi-iteration window the rollout of step t+1 rides on the launches of the critic update of step t
+    (rpo_split_critic_fwd_a_ride / _fwd_b_ride: the actor forward of a lane range each; rpo_split_critic_bwd_b_ride:
+    explore / project / step / scatter, behind fwd_a's gather); serial after policy steps.  Same arithmetic, and the update reads its own clock: 70
+    iterations equal the serial order bit for bit (the per-step statistics are float sums over lanes in a different
+    association: equal to rounding, the counters exactly)."""
+    dev = torch.device("cuda")
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
+    a = _run(algo, envname, hip, dev, 70, 300, use_graph=True)
+    assert a._ride_ok(True) and a._graphs.entries[("cycle", 8, True, "ride")]["graph"] is not None
+    monkeypatch.setenv("RPO_RIDE", "0")
+    b = _run(algo, envname, hip, dev, 70, 300, use_graph=True)
+    assert not b._ride_ok(True) and ("cycle", 8, True, "ride") not in b._graphs.entries
+    c = _run(algo, envname, hip, dev, 70, 300, use_graph=False)
+    for other in (b, c):
+        assert torch.equal(a.vec.internal, other.vec.internal)
+        assert torch.equal(a.vec.action, other.vec.action)
+        assert torch.equal(a.vec.ep_len, other.vec.ep_len) and torch.equal(a.vec.ep_count, other.vec.ep_count)
+        assert torch.equal(a.buffer.rows, other.buffer.rows)
+        assert torch.equal(a.agent.flat.data, other.agent.flat.data)
+        assert torch.equal(a.agent.critic_target_flat, other.agent.critic_target_flat)
+        assert torch.equal(a.agent.nju.weight, other.agent.nju.weight)
+        _stats_equal(a, other, 70)
+    assert int(a._uctrl[0]) == 71 and int(a.vec.ctrl[0]) == 70 and a.vec.steps_host == 70
+    # a full ring: both halves sit behind the gather, so the step never overwrites a slot the sampler still reads
+    d = _run(algo, envname, hip, dev, 70, 64, use_graph=True, capacity=5)
+    monkeypatch.setenv("RPO_RIDE", "1")
+    e = _run(algo, envname, hip, dev, 70, 64, use_graph=True, capacity=5)
+    assert ("cycle", 8, True, "ride") in e._graphs.entries
+    assert torch.equal(d.agent.flat.data, e.agent.flat.data) and torch.equal(d.buffer.rows, e.buffer.rows)
+    assert torch.equal(d.vec.internal, e.vec.internal)
+    # a shared state embedding (scripts/cart_exp.py): the critic step changes the policy, nothing rides
+    f = build_trainer("ddpg", "cart", hip, dev, num_envs=64, use_graph=True)
+    assert f.agent.flat.sizes[1] > 0 and not f._ride_ok(True)
