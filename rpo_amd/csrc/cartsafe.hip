@@ -181,11 +181,10 @@ __global__ __launch_bounds__(RPO_BLOCK) void cartsafe_lagrangian_kernel(int n, c
         if (grad_action) reinterpret_cast<float2*>(grad_action)[i] = make_float2(scale * g0, scale * g1);
     }
     const int lane = threadIdx.x & (RPO_WAVE - 1), wave = threadIdx.x / RPO_WAVE;
+    rpo_wave_reduce_many(acc, 0u);
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        const float r = rpo_wave_sum(acc[k]);
-        if (lane == 0) red[wave * 7 + k] = r;
-    }
+    for (int k = 0; k < 7; ++k)
+        if (lane == 0) red[wave * 7 + k] = acc[k];
     __syncthreads();
     if (threadIdx.x < 7) {
         float r = 0.0f;

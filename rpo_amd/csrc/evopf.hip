@@ -116,20 +116,14 @@ __global__ __launch_bounds__(RPO_WAVE) void evopf_step_kernel(StepArgs p) {
         for (int k = tid; k < NS; k += RPO_WAVE) p.state[(size_t)i * NS + k] = nxt[k];
         if (tid == 0) { p.ep_len[i] = len; p.ep_ret[i] = ret; }
     }
-    if (p.stats && tid == 0) {
-        float* srow = rpo_stats_row(p.stats, p.stats_cap, t);
-        atomicAdd(srow + RPO_STAT_REWARD_SUM, reward);
-        if (max_ineq != 0.0f) atomicAdd(srow + RPO_STAT_MAX_INEQ_SUM, max_ineq);
-        if (max_eq != 0.0f) atomicAdd(srow + RPO_STAT_MAX_EQ_SUM, max_eq);
-        if (fmaxf(max_ineq, max_eq) > p.viol_thresh) atomicAdd(srow + RPO_STAT_VIOL_COUNT, 1.0f);
-        if (max_ineq > 0.0f) rpo_atomic_max_nonneg(srow + RPO_STAT_MAX_INEQ_MAX, max_ineq);
-        if (max_eq > 0.0f) rpo_atomic_max_nonneg(srow + RPO_STAT_MAX_EQ_MAX, max_eq);
-        if (done) {
-            atomicAdd(srow + RPO_STAT_EPISODES, 1.0f);
-            atomicAdd(srow + RPO_STAT_RETURN_SUM, ret);
-            atomicAdd(srow + RPO_STAT_LENGTH_SUM, (float)len);
-            if (data_done) atomicAdd(srow + RPO_STAT_TERMINATED, 1.0f);
-        }
+    if (p.stats) {                                             // (uniform values: one request per lane, rpo_stats_commit)
+        const float dn = done ? 1.0f : 0.0f;
+        const float vals[10] = {reward, max_ineq, max_eq, fmaxf(max_ineq, max_eq) > p.viol_thresh ? 1.0f : 0.0f, max_ineq, max_eq,
+                                dn, dn * ret, dn * (float)len, (done && data_done) ? 1.0f : 0.0f};
+        const int slot[10] = {RPO_STAT_REWARD_SUM, RPO_STAT_MAX_INEQ_SUM, RPO_STAT_MAX_EQ_SUM, RPO_STAT_VIOL_COUNT,
+                              RPO_STAT_MAX_INEQ_MAX, RPO_STAT_MAX_EQ_MAX, RPO_STAT_EPISODES, RPO_STAT_RETURN_SUM,
+                              RPO_STAT_LENGTH_SUM, RPO_STAT_TERMINATED};
+        rpo_stats_commit(vals, 3u << 4, slot, rpo_stats_row(p.stats, p.stats_cap, t));
     }
     rpo_step_epilogue(p.ctrl, t, p.stats, p.stats_cap);
 }

@@ -81,19 +81,15 @@ __global__ __launch_bounds__(kFwdThreads) void rollout_kernel(RolloutArgs<ENV> p
     }
     if (p.step.stats && tid < 64) {                            // only wave 0 holds data: wave reduction, lane 0 adds
         float* srow = rpo_stats_row(p.step.stats, p.step.stats_cap, t);
-        const int slot[kStats] = {RPO_STAT_REWARD_SUM, RPO_STAT_EPISODES, RPO_STAT_RETURN_SUM, RPO_STAT_LENGTH_SUM,
-                                  RPO_STAT_MAX_INEQ_SUM, RPO_STAT_MAX_EQ_SUM, RPO_STAT_VIOL_COUNT, RPO_STAT_TERMINATED,
-                                  RPO_STAT_MAX_INEQ_MAX, RPO_STAT_MAX_EQ_MAX};
+        const int slot[kStats + 1] = {RPO_STAT_REWARD_SUM, RPO_STAT_EPISODES, RPO_STAT_RETURN_SUM, RPO_STAT_LENGTH_SUM,
+                                      RPO_STAT_MAX_INEQ_SUM, RPO_STAT_MAX_EQ_SUM, RPO_STAT_VIOL_COUNT, RPO_STAT_TERMINATED,
+                                      RPO_STAT_MAX_INEQ_MAX, RPO_STAT_MAX_EQ_MAX, RPO_STAT_PROJ_ITERS};
+        float red[kStats + 1];
 #pragma unroll
-        for (int k = 0; k < kStats; ++k) {
-            const float r = (k < 8) ? rpo_wave_sum(st[k]) : rpo_wave_max(st[k]);
-            if (tid == 0) {
-                if (k < 8) { if (r != 0.0f) atomicAdd(srow + slot[k], r); }
-                else if (r > 0.0f) rpo_atomic_max_nonneg(srow + slot[k], r);
-            }
-        }
-        const float it = rpo_wave_sum(iters_f);
-        if (tid == 0 && it != 0.0f) atomicAdd(srow + RPO_STAT_PROJ_ITERS, it);
+        for (int k = 0; k < kStats; ++k) red[k] = st[k];
+        red[kStats] = iters_f;
+        rpo_wave_reduce_many<kStats + 1, (kLanes <= 16 ? 8 : 32)>(red, 3u << 8);   // (lanes 0..15 end with the results)
+        rpo_stats_commit(red, 3u << 8, slot, srow);
     }
     rpo_step_epilogue(p.step.ctrl, t, p.step.stats, p.step.stats_cap);
 }
@@ -572,11 +568,10 @@ __global__ __launch_bounds__(kFwdThreads) void ddpg_actor_forward_kernel(ActorFw
         p.q_out[row0 + tid] = vals[7];
     }
     if (tid < 64) {
+        rpo_wave_reduce_many<8>(vals, 0u);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float r = rpo_wave_sum(vals[k]);
-            if (tid == 0) p.partial[blockIdx.x * 8 + k] = r;
-        }
+        for (int k = 0; k < 8; ++k)
+            if (tid == 0) p.partial[blockIdx.x * 8 + k] = vals[k];
     }
 }
 
@@ -699,11 +694,10 @@ __global__ __launch_bounds__(kFwdThreads) void sac_actor_forward_kernel(SacActor
     else mlp_tile_forward<EIN, H>(p.critic2, lds, row0, B, p.c2x0, p.c2h1, 0, 1.0f, 0.0f);
     if (live) (role == 0 ? p.dq1 : p.dq2)[row0 + tid] = lds.out[tid * 2];        // Q_k(s, a): turned into dLoss/dQ_k later
     if (role == 0 && tid < 64) {
+        rpo_wave_reduce_many(vals, 0u);
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const float r = rpo_wave_sum(vals[k]);
-            if (tid == 0) p.partial[blockIdx.x * 8 + k] = r;
-        }
+        for (int k = 0; k < 7; ++k)
+            if (tid == 0) p.partial[blockIdx.x * 8 + k] = vals[k];
     }
 }
 

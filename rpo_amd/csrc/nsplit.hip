@@ -308,12 +308,10 @@ __device__ __forceinline__ void ride_tail(const RideArgs<ENV>& r, const CartCons
         // sums 0..7, maxima 8..9 (rollout_kernel's slots), then the projection-iteration sum; every block owns a sub-row
         float* srow = rpo_stats_row_at(r.step.stats, r.step.stats_cap, t, blk);
         const int lane = tid & (RPO_WAVE - 1), wave = tid / RPO_WAVE;
+        rpo_wave_reduce_many(st, 3u << 8);
 #pragma unroll
-        for (int k = 0; k <= kStats; ++k) {
-            const bool mx = k == 8 || k == 9;
-            const float v = mx ? rpo_wave_max(st[k]) : rpo_wave_sum(st[k]);
-            if (lane == 0) smem[wave * (kStats + 1) + k] = v;
-        }
+        for (int k = 0; k <= kStats; ++k)
+            if (lane == 0) smem[wave * (kStats + 1) + k] = st[k];
         __syncthreads();
         if (tid <= kStats) {
             const int slot[kStats + 1] = {RPO_STAT_REWARD_SUM, RPO_STAT_EPISODES, RPO_STAT_RETURN_SUM, RPO_STAT_LENGTH_SUM,
@@ -794,11 +792,10 @@ __global__ __launch_bounds__(kNsThreads) void split_policy_b_kernel(SplitArgs p,
         lds.in_a[tid * 8 + 1] = act.y;
     }
     if (writer && tid < 64) {
+        rpo_wave_reduce_many(vals, 0u);
 #pragma unroll
-        for (int q = 0; q < 7; ++q) {
-            const float r = rpo_wave_sum(vals[q]);
-            if (tid == 0) p.lag_partial[blockIdx.y * 8 + q] = r;
-        }
+        for (int q = 0; q < 7; ++q)
+            if (tid == 0) p.lag_partial[blockIdx.y * 8 + q] = vals[q];
     }
     ns_hidden<128, 256>(net, w, lds, g, row0, B, p.part_q[k], p.x0[k], p.h1[k]);
 }
