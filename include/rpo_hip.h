@@ -449,6 +449,9 @@ typedef struct {
     const float* nu; float* nu_grad;
     float *ap_det, *noise_out, *raw, *actions, *g_act, *lag_partial, *lag_out, *da_part, *dout;
     int shared_embedding;
+    /* fwd_a: NULL, or the clock / statistics of a rollout launched with defer_clock = 1 right before this update:
+     * fwd_a advances rollout_ctrl[RPO_CTRL_T] and clears the next statistics row on its behalf */
+    long long* rollout_ctrl; float* rollout_stats; int rollout_stats_cap;
 } rpo_split_update;
 
 int rpo_split_critic_fwd_a(const rpo_split_update* u, void* stream);
@@ -616,19 +619,24 @@ int rpo_evopf_lagrangian(int n, const float* state, int state_stride, const floa
  *   normal(philox(seed, env_id_base + i, ctrl[T], RPO_STREAM_POLICY, ctrl[UPDATES])), i.e. rpo_philox_normal(salt 0);
  *   == rpo_philox_normal + rpo_mlp_forward(actor) + rpo_gauss_head + rpo_<env>_act_project(RPO_NOISE_NONE) + step.
  * CartSafe-v0: state [n,6] is the observation.  SpringPendulum-v0: internal [n,4], obs [n,5] (may be NULL: the
- * pipeline itself derives observations from the internal state). */
+ * pipeline itself derives observations from the internal state).
+ * defer_clock = 1: the launch does NOT advance ctrl[RPO_CTRL_T] / clear the next statistics row (two dependent atomic
+ *   round trips behind its last workgroup, ~1.5 us); the caller's NEXT launch on the stream does it instead --
+ *   rpo_split_critic_fwd_a with `rollout_ctrl` set (one plain store, no arrival counting: a later launch starts after
+ *   every workgroup of this one has finished). */
 int rpo_cartsafe_rollout(const rpo_mlp* actor_host, int gauss, float scale, float base, int n_envs, float* state,
                          float* action, int* ep_len, float* ep_ret, unsigned* ep_count, float* rows, long long cap_steps,
                          float* stats, int stats_cap, long long* ctrl, int noise_mode, float eps_start, float eps_end,
                          float eps_decay, float box_lo, float box_hi, int max_steps, float corr_lr, float corr_eps,
                          float corr_momentum, const float* consts_host, int partial, int max_episode_steps,
-                         int auto_reset, float viol_thresh, unsigned long long seed, unsigned env_id_base, void* stream);
+                         int auto_reset, float viol_thresh, unsigned long long seed, unsigned env_id_base, int defer_clock,
+                         void* stream);
 int rpo_pendulum_rollout(const rpo_mlp* actor_host, int gauss, float scale, float base, int n_envs, float* internal,
                          float* obs, float* action, int* ep_len, float* ep_ret, unsigned* ep_count, float* rows,
                          long long cap_steps, float* stats, int stats_cap, long long* ctrl, int noise_mode,
                          float eps_start, float eps_end, float eps_decay, float box_lo, float box_hi, int max_steps,
                          float corr_lr, float corr_eps, float corr_momentum, int max_episode_steps, int auto_reset,
-                         float viol_thresh, unsigned long long seed, unsigned env_id_base, void* stream);
+                         float viol_thresh, unsigned long long seed, unsigned env_id_base, int defer_clock, void* stream);
 
 /* Forward half of the critic update (rpo_ddpg.py:165-174, 327-337): ReplayBuffer.sample (Philox draw, or idx_in when
  * given) -> batch_out [B,24]; pi_targ(s') -> Complete + Proj -> Q_targ(s', a') = qn_out; Q(s, a) = q_out with the

@@ -40,7 +40,7 @@ class _LagrangianBase(RPOTrainerBase):
     def _explore(self, obs, warm):
         raise NotImplementedError
 
-    def _rollout(self, warm):
+    def _rollout(self, warm, defer_clock=False):          # (no column-split update here: the step kernel keeps its clock)
         v, buf = self.vec, self.buffer
         with torch.no_grad():
             if warm:                                             # agent.random_action: uniform in the (full) box

@@ -242,6 +242,7 @@ class RPOTrainerBase(object):
         # split path it is an alias of the rollout's ctrl and nothing changes.
         self._uctrl, self._uclock_ok, self._after_front, self._ovl_stream = self.vec.ctrl, True, None, None
         self._ride, self._rider_cache, self._ride_cut = None, None, 0
+        self._clock_pending = False
         self._bump = self.updates_per_step == 1
         if self.fused is not None and device.type == "cuda" and getattr(self.backend, "ADAM_CLOCK", False):
             self._uctrl, self._uclock_ok = torch.zeros_like(self.vec.ctrl), False
@@ -289,8 +290,18 @@ class RPOTrainerBase(object):
         return (self.fused is not None and hasattr(self.kernels, "rollout") and "actor" in self.fused.descs
                 and _env_int("RPO_FUSED_ROLLOUT", 1))
 
-    def _rollout(self, warm):
+    @property
+    def _defer_ok(self):
+        """A rollout that is followed by the column-split critic update may leave its step counter to that update's first
+        launch (rpo_*_rollout(defer_clock=1), rpo_split_update.rollout_ctrl): saves the arrival counting behind the
+        rollout's last workgroup.  ``RPO_DEFER_CLOCK=0`` keeps the counter in the rollout."""
+        return bool(getattr(self, "_pipelines", False) and self._split_state() is not None and _env_int("RPO_DEFER_CLOCK", 1))
+
+    def _rollout(self, warm, defer_clock=False):
+        """``defer_clock``: the caller runs the column-split critic update next, whose first launch advances the step
+        counter for this one (`_critic_update_split`)."""
         v = self.vec
+        defer_clock = bool(defer_clock and not warm and self._rollout_pipeline and self._defer_ok)
         if not warm and self._rollout_pipeline:
             # actor -> head -> equation solver -> projection -> env step -> replay scatter in ONE launch (fused.hip)
             scale, base = self._box_affine
@@ -300,7 +311,8 @@ class RPOTrainerBase(object):
                                  hip_ops.NOISE_NONE if self._gauss_policy else hip_ops.NOISE_PHILOX, self.eps_start,
                                  self.eps, self.decay_value, self._box_lo, self._box_hi, self.max_steps, self.corr_lr,
                                  self.corr_eps, self.corr_momentum, v.max_episode_steps, True, v.viol_thresh, self.seed,
-                                 v.env_id_base)
+                                 v.env_id_base, **(dict(defer_clock=True) if defer_clock else {}))
+            self._clock_pending = defer_clock
             v.steps_host += 1
             return
         with torch.no_grad():
@@ -371,7 +383,7 @@ class RPOTrainerBase(object):
 
         def s1():
             if rollout:
-                self._rollout(warm)
+                self._rollout(warm, defer_clock=True)
             self._last_cols = self._sample()
             self._critic_update(self._last_cols)
         segs.append((s1, [fl.gradient(fl.critic_range)]))
@@ -598,6 +610,9 @@ class RPOTrainerBase(object):
             eps_in = self._noise_b.view(-1)
         buf = self.buffer
         su.set(idx_in=idx_in, eps_in=eps_in, rows=buf.rows, cap_steps=buf.capacity, n_envs=buf.n_envs)   # (tests swap the ring)
+        pending, self._clock_pending = self._clock_pending, False   # a rollout left its clock to this update's first launch
+        su.set(rollout_ctrl=self.vec.ctrl if pending else None, rollout_stats=self.vec.stats if pending else None,
+               rollout_stats_cap=self.vec.stats.shape[0] if pending else 0)
         ride = self._ride                                       # ridden windows: the next vector step rides along
         if ride is not None:
             n, cut = self.vec.internal.shape[0], self._ride_cut
@@ -751,7 +766,7 @@ class RPOTrainerBase(object):
         in bwd_b's, behind fwd_a, which gathers the batch out of the ring first -- unless iteration i ends with a policy step,
         whose new actor the next rollout has to wait for."""
         F, fl = self.policy_fre, self.agent.flat
-        self._rollout(False)
+        self._rollout(False, defer_clock=True)
         for i in range(L):
             actor_step = (t + i + 1) % F == 0
             more = i + 1 < L
@@ -769,7 +784,7 @@ class RPOTrainerBase(object):
                 self.dist.mean_([fl.gradient(fl.policy_bucket)])
                 self._actor_step(self._last_actor_out)
             if more and not ride:
-                self._rollout(False)
+                self._rollout(False, defer_clock=True)
 
     def _overlap_ok(self, do_train):
         """Rollout t+1 may run beside the update of t (on a second stream of the window's hipGraph) when the update does

@@ -36,6 +36,7 @@ struct RolloutArgs {
     Mlp actor;
     float scale, base;            // tanh box of the actor output (BoxConstraint)
     int gauss;                    // 0: deterministic actor + exploration noise (DDPG); 1: squashed-Gaussian sample (SAC)
+    int defer_clock;              // 1: the caller's next launch advances ctrl[T] and clears the next statistics row
     typename ENV::ActArgs act;    // exploration / projection parameters, action out
     typename ENV::StepArgs step;  // env state, bookkeeping, ring, statistics, ctrl
 };
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(kFwdThreads) void rollout_kernel(RolloutArgs<ENV> p
         rpo_wave_reduce_many<kStats + 1, (kLanes <= 16 ? 8 : 32)>(red, 3u << 8);   // (lanes 0..15 end with the results)
         rpo_stats_commit(red, 3u << 8, slot, srow);
     }
-    rpo_step_epilogue(p.step.ctrl, t, p.step.stats, p.step.stats_cap);
+    if (!p.defer_clock) rpo_step_epilogue(p.step.ctrl, t, p.step.stats, p.step.stats_cap);
 }
 
 template <class ENV>
@@ -778,7 +779,8 @@ int rpo_cartsafe_rollout(const rpo_mlp* actor_host, int gauss, float scale, floa
                          float* stats, int stats_cap, long long* ctrl, int noise_mode, float eps_start, float eps_end,
                          float eps_decay, float box_lo, float box_hi, int max_steps, float corr_lr, float corr_eps,
                          float corr_momentum, const float* consts_host, int partial, int max_episode_steps,
-                         int auto_reset, float viol_thresh, unsigned long long seed, unsigned env_id_base, void* stream) {
+                         int auto_reset, float viol_thresh, unsigned long long seed, unsigned env_id_base, int defer_clock,
+                         void* stream) {
     if (!actor_host) return RPO_ERR_NULL;
     if (n_envs <= 0 || max_episode_steps <= 0 || max_steps < 0) return RPO_ERR_ARG;
     if (noise_mode != RPO_NOISE_NONE && noise_mode != RPO_NOISE_PHILOX && noise_mode != RPO_NOISE_CLIP_ONLY) return RPO_ERR_ARG;
@@ -789,7 +791,7 @@ int rpo_cartsafe_rollout(const rpo_mlp* actor_host, int gauss, float scale, floa
     if (int e = check_actor(args.actor, 6, gauss)) return e;
     CartConsts c;
     if (int e = load_consts(c, consts_host, partial)) return e;
-    args.scale = scale; args.base = base; args.gauss = gauss;
+    args.scale = scale; args.base = base; args.gauss = gauss; args.defer_clock = defer_clock ? 1 : 0;
     args.act = rpo_cart_dev::ActArgs{n_envs, nullptr, nullptr, action, nullptr, noise_mode, eps_start, eps_end, eps_decay,
                                      box_lo, box_hi, max_steps, corr_lr, corr_eps, corr_momentum, (uint64_t)seed,
                                      (uint32_t)env_id_base, ctrl, stats, stats_cap};
@@ -804,7 +806,7 @@ int rpo_pendulum_rollout(const rpo_mlp* actor_host, int gauss, float scale, floa
                          long long cap_steps, float* stats, int stats_cap, long long* ctrl, int noise_mode,
                          float eps_start, float eps_end, float eps_decay, float box_lo, float box_hi, int max_steps,
                          float corr_lr, float corr_eps, float corr_momentum, int max_episode_steps, int auto_reset,
-                         float viol_thresh, unsigned long long seed, unsigned env_id_base, void* stream) {
+                         float viol_thresh, unsigned long long seed, unsigned env_id_base, int defer_clock, void* stream) {
     if (!actor_host) return RPO_ERR_NULL;
     if (n_envs <= 0 || max_episode_steps <= 0 || max_steps < 0) return RPO_ERR_ARG;
     if (noise_mode != RPO_NOISE_NONE && noise_mode != RPO_NOISE_PHILOX && noise_mode != RPO_NOISE_CLIP_ONLY) return RPO_ERR_ARG;
@@ -813,7 +815,7 @@ int rpo_pendulum_rollout(const rpo_mlp* actor_host, int gauss, float scale, floa
     RolloutArgs<PendEnv> args{};
     args.actor = to_dev(actor_host);
     if (int e = check_actor(args.actor, 5, gauss)) return e;
-    args.scale = scale; args.base = base; args.gauss = gauss;
+    args.scale = scale; args.base = base; args.gauss = gauss; args.defer_clock = defer_clock ? 1 : 0;
     args.act = rpo_pend_dev::ActArgs{n_envs, nullptr, 5, nullptr, nullptr, action, nullptr, noise_mode, eps_start, eps_end,
                                      eps_decay, box_lo, box_hi, max_steps, corr_lr, corr_eps, corr_momentum, (uint64_t)seed,
                                      (uint32_t)env_id_base, ctrl, stats, stats_cap};

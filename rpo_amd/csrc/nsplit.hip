@@ -90,6 +90,7 @@ struct SplitArgs {
     const float* nu; float* nu_grad;
     float *ap_det, *noise_out, *raw, *actions, *g_act, *lag_partial, *lag_out, *da_part, *dout;
     int shared_embedding;
+    long long* rollout_ctrl; float* rollout_stats; int rollout_stats_cap;
 };
 
 // ReplayBuffer.sample (buffer.py:31-34): counter-based draw + gather of the tile's 16 rows (same draw in every workgroup
@@ -145,6 +146,16 @@ __device__ __forceinline__ void ns_stage(NsLds<128>& lds, const float* tf, bool 
 //      roles 1.. = the critics on the stored (s, a), pre-activations saved for the backward pass.
 template <class L>
 __device__ __forceinline__ void fwd_a_role(const SplitArgs& p, NsLds<128>& lds, float4* tile, int row0, int g, int role) {
+    if (p.rollout_ctrl && role == 0 && g == 0 && row0 == 0 && threadIdx.x < RPO_WAVE) {
+        // the rollout before this update left its clock to us (defer_clock): every workgroup of it has finished, so one
+        // wave advances the step counter and clears the statistics row of the next step -- no arrival counting
+        const long long tr = p.rollout_ctrl[RPO_CTRL_T];
+        if (p.rollout_stats && p.rollout_stats_cap > 1) {
+            float* nxt = p.rollout_stats + ((tr + 1) % p.rollout_stats_cap) * RPO_STATS_SUB * RPO_STATS_LEN;
+            for (int k = threadIdx.x; k < RPO_STATS_SUB * RPO_STATS_LEN; k += RPO_WAVE) nxt[k] = 0.0f;
+        }
+        if (threadIdx.x == 0) p.rollout_ctrl[RPO_CTRL_T] = tr + 1;
+    }
     const Mlp& net = role == 0 ? (p.twin ? p.actor : p.actor_target) : p.critic[role - 1];
     NsWeights<128> w;
     ns_load_weights<128, 256>(net, g, w);
@@ -1077,6 +1088,7 @@ int to_args(const rpo_split_update* u, unsigned need, SplitArgs& a, CartConsts& 
     a.ap_det = u->ap_det; a.noise_out = u->noise_out; a.raw = u->raw; a.actions = u->actions; a.g_act = u->g_act;
     a.lag_partial = u->lag_partial; a.lag_out = u->lag_out; a.da_part = u->da_part; a.dout = u->dout;
     a.shared_embedding = u->shared_embedding;
+    a.rollout_ctrl = u->rollout_ctrl; a.rollout_stats = u->rollout_stats; a.rollout_stats_cap = u->rollout_stats_cap;
     return 0;
 }
 
@@ -1089,6 +1101,7 @@ int rpo_split_critic_fwd_a(const rpo_split_update* u, void* stream) {
     if (int e = to_args(u, 1u | 2u, a, c)) return e;
     const int K = a.twin ? 2 : 1;
     if (!a.rows || !a.batch_out || !a.ctrl || !a.part_pi || a.cap_steps <= 0 || a.n_envs <= 0) return RPO_ERR_NULL;
+    if (a.rollout_ctrl && a.rollout_stats && a.rollout_stats_cap <= 0) return RPO_ERR_ARG;
     for (int k = 0; k < K; ++k)
         if (!a.part_q[k] || !a.x0[k] || !a.h1[k]) return RPO_ERR_NULL;
     const dim3 grid(kNsGroups, (a.B + kRows - 1) / kRows, 1 + K);
@@ -1225,6 +1238,7 @@ int rpo_split_critic_fwd_a_ride(const rpo_split_update* u, const rpo_rollout_rid
     if (int e = to_args(u, 1u | 2u | 32u, a, c)) return e;
     const int K = a.twin ? 2 : 1, T = (a.B + kRows - 1) / kRows;
     if (!a.rows || !a.batch_out || !a.ctrl || !a.part_pi || a.cap_steps <= 0 || a.n_envs <= 0) return RPO_ERR_NULL;
+    if (a.rollout_ctrl && a.rollout_stats && a.rollout_stats_cap <= 0) return RPO_ERR_ARG;
     for (int k = 0; k < K; ++k)
         if (!a.part_q[k] || !a.x0[k] || !a.h1[k]) return RPO_ERR_NULL;
     const int lane_wgs = (r->lane_end - r->lane_begin + kRows - 1) / kRows;

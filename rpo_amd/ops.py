@@ -212,14 +212,14 @@ class CartSafeKernels(object):
     # ---- fused pipelines (rpo_amd/csrc/fused.hip) ----------------------------------------------------------------
     def rollout(self, actor_desc, gauss, scale, base, internal, obs, action, ep_len, ep_ret, ep_count, rows, cap_steps,
                 stats, ctrl, noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi, max_steps, corr_lr, corr_eps,
-                corr_momentum, max_episode_steps, auto_reset, viol_thresh, seed, env_id_base):
+                corr_momentum, max_episode_steps, auto_reset, viol_thresh, seed, env_id_base, defer_clock=False):
         net = actor_desc.net_struct()
         check(_lib.load().rpo_cartsafe_rollout(
             ctypes.byref(net), int(gauss), scale, base, internal.shape[0], _p(internal), _p(action),
             _p(ep_len, torch.int32), _p(ep_ret), _p(ep_count, torch.int32), _p(rows, allow_none=True), cap_steps,
             _p(stats, allow_none=True), 0 if stats is None else stats.shape[0], _p(ctrl, torch.int64), noise_mode,
             eps_start, eps_end, eps_decay, box_lo, box_hi, max_steps, corr_lr, corr_eps, corr_momentum, self._cptr,
-            self.partial, max_episode_steps, int(auto_reset), viol_thresh, seed, env_id_base, _stream()),
+            self.partial, max_episode_steps, int(auto_reset), viol_thresh, seed, env_id_base, int(defer_clock), _stream()),
             "rpo_cartsafe_rollout")
 
     def ddpg_critic_forward(self, actor_target, critic_target, critic, scale, base, rows, cap_steps, n_envs, batch_out,
@@ -396,14 +396,15 @@ class PendulumKernels(object):
 
     def rollout(self, actor_desc, gauss, scale, base, internal, obs, action, ep_len, ep_ret, ep_count, rows, cap_steps,
                 stats, ctrl, noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi, max_steps, corr_lr, corr_eps,
-                corr_momentum, max_episode_steps, auto_reset, viol_thresh, seed, env_id_base):
+                corr_momentum, max_episode_steps, auto_reset, viol_thresh, seed, env_id_base, defer_clock=False):
         net = actor_desc.net_struct()
         check(_lib.load().rpo_pendulum_rollout(
             ctypes.byref(net), int(gauss), scale, base, internal.shape[0], _p(internal), _p(obs, allow_none=True),
             _p(action), _p(ep_len, torch.int32), _p(ep_ret), _p(ep_count, torch.int32), _p(rows, allow_none=True),
             cap_steps, _p(stats, allow_none=True), 0 if stats is None else stats.shape[0], _p(ctrl, torch.int64),
             noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi, max_steps, corr_lr, corr_eps, corr_momentum,
-            max_episode_steps, int(auto_reset), viol_thresh, seed, env_id_base, _stream()), "rpo_pendulum_rollout")
+            max_episode_steps, int(auto_reset), viol_thresh, seed, env_id_base, int(defer_clock), _stream()),
+            "rpo_pendulum_rollout")
 
     def ddpg_critic_front(self, actor_target, scale, base, rows, cap_steps, n_envs, batch_out, idx_out, idx_in, sample_seed,
                           sample_salt, ctrl, ap_out):
@@ -716,7 +717,8 @@ class _SplitUpdateStruct(ctypes.Structure):
                                         "loss_partial", "dx0_1", "dx0_2", "dx0_a", "gradmax", "nu", "nu_grad", "ap_det",
                                         "noise_out", "raw", "actions", "g_act", "lag_partial", "lag_out", "da_part",
                                         "dout")] +
-        [("shared_embedding", ctypes.c_int)])
+        [("shared_embedding", ctypes.c_int), ("rollout_ctrl", ctypes.c_void_p), ("rollout_stats", ctypes.c_void_p),
+         ("rollout_stats_cap", ctypes.c_int)])
 
 
 class _RolloutRiderStruct(ctypes.Structure):
@@ -789,7 +791,8 @@ class SplitUpdate(object):
     def set(self, **fields):
         for k, v in fields.items():
             if isinstance(v, torch.Tensor):
-                dt = torch.int64 if k in ("idx_out", "idx_in", "ctrl") else (torch.int32 if k == "proj_iters" else torch.float32)
+                dt = torch.int64 if k in ("idx_out", "idx_in", "ctrl", "rollout_ctrl") else \
+                    (torch.int32 if k == "proj_iters" else torch.float32)
                 self._held[k] = v                                   # keeps the buffer alive while the struct points at it
                 setattr(self.st, k, _p(v, dt).value)
             else:

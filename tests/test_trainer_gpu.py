@@ -607,3 +607,22 @@ def test_ridden_rollout_equals_serial(hip, algo, envname, monkeypatch):
     # a shared state embedding (scripts/cart_exp.py): the critic step changes the policy, nothing rides
     f = build_trainer("ddpg", "cart", hip, dev, num_envs=64, use_graph=True)
     assert f.agent.flat.sizes[1] > 0 and not f._ride_ok(True)
+
+
+@pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "pendulum")])
+def test_deferred_rollout_clock_equals_own_clock(hip, algo, envname, monkeypatch):
+    """rpo_*_rollout(defer_clock=1) leaves ctrl[RPO_CTRL_T] and the clearing of the next statistics row to the first launch
+    of the column-split update that follows (rpo_split_update.rollout_ctrl): same steps, same statistics, same parameters
+    as the rollout counting its own workgroups in."""
+    dev = torch.device("cuda")
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
+    a = _run(algo, envname, hip, dev, 45, 300, use_graph=True)
+    assert a._defer_ok
+    monkeypatch.setenv("RPO_DEFER_CLOCK", "0")
+    b = _run(algo, envname, hip, dev, 45, 300, use_graph=True)
+    assert not b._defer_ok
+    assert int(a.vec.ctrl[0]) == int(b.vec.ctrl[0]) == 45 and not a._clock_pending
+    assert torch.equal(a.vec.ctrl, b.vec.ctrl)                    # arrival counters back at zero either way
+    assert torch.equal(a.vec.internal, b.vec.internal) and torch.equal(a.buffer.rows, b.buffer.rows)
+    assert torch.equal(a.agent.flat.data, b.agent.flat.data)
+    assert torch.equal(a.vec.stats, b.vec.stats)                  # incl. the cleared rows ahead of the step counter
