@@ -93,6 +93,11 @@ extern "C" {
 #define RPO_CTRL_SUB0 16    /* 16 sub-counters, one per 128-byte line: ctrl[RPO_CTRL_SUB0 + RPO_CTRL_SUB_STRIDE * j] */
 #define RPO_CTRL_SUB_STRIDE 16
 
+#define RPO_GRADMAX_SLOTS 16   /* `gradmax` buffers (inf-norm of a gradient slice, clip_grad_norm_) are float[RPO_GRADMAX_LEN]: */
+#define RPO_GRADMAX_LEN 256    /* 16 slots 64 bytes apart (slot j at [16 j]), a producing workgroup maxes into slot
+                                  (block index) % 16 and the norm is the maximum over the slots -- several hundred atomics on
+                                  ONE cache line are served one after the other (2.9 us behind a 448-workgroup backward);
+                                  rpo_absmax writes slot 0; rpo_adam_step* read all slots and zero them (reset_gradmax) */
 #define RPO_STATS_SUB 16    /* sub-rows per statistics row: workgroup b adds into sub-row b % 16; the reader sums them */
 #define RPO_STATS_LEN 16
 #define RPO_STAT_REWARD_SUM 0    /* sum over envs of this step's reward                   rpo_ddpg.py:132 */
@@ -287,7 +292,8 @@ int rpo_absmax(long long n, const float* x, float* max_out, void* stream);
 
 /* clip_grad_norm_(inf) + torch.optim.Adam step (+ optional DualAdam clamp, model/dual.py:37-45) (+ optional Polyak
  * target update, agent/ddpg_pa.py:77-86), one pass over the flat buffer:
- *   coef = min(1, clip_thres / (gradmax[0] + 1e-6)) when clip_thres > 0 (gradmax from rpo_absmax); g = coef * grad
+ *   coef = min(1, clip_thres / (max over the slots of gradmax [RPO_GRADMAX_LEN] + 1e-6)) when clip_thres > 0 (gradmax from
+ *   rpo_absmax or left by a backward launch); g = coef * grad
  *   (written back, as clip_grad_norm_ does); maximize: g = -g; weight decay; Adam with bias correction at step
  *   step_dev[0] + 1 (the counter is advanced by the launch); clamp_min0: p = max(p, 0); target != NULL:
  *   target = (1 - tau) * target + tau * p.   gradmax is reset to 0 by the launch when reset_gradmax != 0.
@@ -444,7 +450,7 @@ typedef struct {
     float *dq1, *dq2;            /* [batch] dLoss/dQ_k */
     float *loss_partial;         /* [2, ceil(batch / 16)] */
     float *dx0_1, *dx0_2, *dx0_a;
-    float *gradmax;              /* NULL or [1] */
+    float *gradmax;              /* NULL or [RPO_GRADMAX_LEN] */
     /* policy step */
     const float* nu; float* nu_grad;
     float *ap_det, *noise_out, *raw, *actions, *g_act, *lag_partial, *lag_out, *da_part, *dout;
@@ -514,7 +520,7 @@ int rpo_split_critic_bwd_b_ride(const rpo_split_update* u, const rpo_rollout_rid
  * agent/ddpg_pa.py:34-36).  dh [n, H] and dx0 [n, Ein] are caller-provided scratch; da [n, A] (may be NULL) receives
  * the gradient w.r.t. the action input (actor loss: -Q(s, a) back to the policy, rpo_ddpg.py:317).
  * param_grads = 0: only dx0 / da; first_layer_state_only = 1: of the parameters only Ws / bs are accumulated.
- * gradmax (may be NULL): receives max(gradmax[0], max |gradient element written by this call|) -- when the buffers were
+ * gradmax (may be NULL; [RPO_GRADMAX_LEN]): its slots receive max(slot, max |gradient element written by this call|) -- when the buffers were
  * zero before the call this is clip_grad_norm_'s inf-norm of the network (rpo_ddpg.py:180), without the rpo_absmax pass. */
 int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int n, const float* s, int s_stride,
                      const float* a, int a_stride, const float* x0, const float* h1, const float* dout, float* dh,

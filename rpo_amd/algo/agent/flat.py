@@ -91,7 +91,8 @@ class FusedAdam(object):
         self.exp_avg_sq = torch.zeros_like(param)
         # {step, pad, arrival word (8 B), cached bias corrections of the next step (2 doubles)}
         self.step_dev = torch.zeros(8, dtype=torch.int32, device=dev)
-        self.gradmax = torch.zeros(1, device=dev)
+        # inf-norm of the gradient slice, in RPO_GRADMAX_SLOTS slots on separate cache lines (include/rpo_hip.h)
+        self.gradmax = torch.zeros(getattr(backend, "CONST", {}).get("RPO_GRADMAX_LEN", 256), device=dev)
         # True: the step leaves a zeroed gradient slice behind (optimizer.zero_grad() folded into the Adam launch); the
         # trainers switch it on when every backward of the iteration goes through the accumulating MLP kernels
         self.zero_grad_after = False

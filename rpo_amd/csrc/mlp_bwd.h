@@ -480,7 +480,8 @@ __device__ __forceinline__ float mlp_bwd_weights_body(const BwdArgs& p) {
     return mlp_bwd_first_layer<EIN>(p, rb - hv_blocks);
 }
 
-// max over the workgroup of the gradient magnitudes its threads wrote -> one atomic max (order independent: exact)
+// max over the workgroup of the gradient magnitudes its threads wrote -> one atomic max into one of the gradmax slots
+// (order independent: exact)
 __device__ __forceinline__ void gradmax_flush(float* gradmax, float v) {
     __shared__ float red[kThreads / 64];
     if (gradmax == nullptr) return;
@@ -490,7 +491,9 @@ __device__ __forceinline__ void gradmax_flush(float* gradmax, float v) {
     if (threadIdx.x == 0) {
         float m = red[0];
         for (int w = 1; w < kThreads / 64; ++w) m = fmaxf(m, red[w]);
-        if (m > 0.0f) rpo_atomic_max_nonneg(gradmax, m);
+        // slot (workgroup index) % 16, 64 bytes apart: same-line atomics of a wide launch queue up behind each other
+        const unsigned b = blockIdx.x + blockIdx.y * gridDim.x;
+        if (m > 0.0f) rpo_atomic_max_nonneg(gradmax + (b % RPO_GRADMAX_SLOTS) * (RPO_GRADMAX_LEN / RPO_GRADMAX_SLOTS), m);
     }
 }
 }  // namespace rpo_mlp_dev

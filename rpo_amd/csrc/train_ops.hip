@@ -108,7 +108,10 @@ __device__ __forceinline__ void adam_body(const AdamArgs& p) {
     const float bc2_sqrt = (float)bc2s;
     float coef = 1.0f;
     if (p.clip_thres > 0.0f) {   // clip_grad_norm_(..., norm_type=inf): clip_coef clamped to 1, always applied
-        coef = fminf(p.clip_thres / (p.gradmax[0] + 1e-6f), 1.0f);
+        float gm = 0.0f;                                    // the norm is the maximum over the slots (RPO_GRADMAX_SLOTS)
+#pragma unroll
+        for (int j = 0; j < RPO_GRADMAX_SLOTS; ++j) gm = fmaxf(gm, p.gradmax[j * (RPO_GRADMAX_LEN / RPO_GRADMAX_SLOTS)]);
+        coef = fminf(p.clip_thres / (gm + 1e-6f), 1.0f);
     }
     const float omb1 = 1.0f - p.beta1, omb2 = 1.0f - p.beta2;
     for (long long i = (long long)blockIdx.x * RPO_BLOCK + threadIdx.x; i < p.n; i += (long long)gridDim.x * RPO_BLOCK) {
@@ -136,7 +139,8 @@ __device__ __forceinline__ void adam_body(const AdamArgs& p) {
             p.step_dev[0] = step;
             cache[0] = 1.0 - pow((double)p.beta1, (double)(step + 1));
             cache[1] = sqrt(1.0 - pow((double)p.beta2, (double)(step + 1)));
-            if (p.reset_gradmax && p.gradmax) p.gradmax[0] = 0.0f;
+            if (p.reset_gradmax && p.gradmax)
+                for (int j = 0; j < RPO_GRADMAX_SLOTS; ++j) p.gradmax[j * (RPO_GRADMAX_LEN / RPO_GRADMAX_SLOTS)] = 0.0f;
             if (p.clock) p.clock[0] += 1;
         }
     }

@@ -422,7 +422,7 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0
               zero_grad=False):
     g = _np(grad)
     if clip_thres > 0:
-        coef = min(np.float32(clip_thres) / (np.float32(float(gradmax[0])) + np.float32(1e-6)), np.float32(1.0))
+        coef = min(np.float32(clip_thres) / (np.float32(float(gradmax.max())) + np.float32(1e-6)), np.float32(1.0))
         g *= np.float32(coef)                         # in place, like clip_grad_norm_
     step = train_ops.adam_step(_np(param), g, _np(exp_avg), _np(exp_avg_sq), int(step_dev[0]), lr, beta1, beta2, eps,
                                weight_decay, maximize, clamp_min0)

@@ -448,7 +448,7 @@ def test_adam_step_matches_torch(ops, mode):
     m = torch.zeros(n, device=DEV)
     v = torch.zeros(n, device=DEV)
     step = torch.zeros(8, dtype=torch.int32, device=DEV)
-    gmax = torch.zeros(1, device=DEV)
+    gmax = torch.zeros(ops.CONST["RPO_GRADMAX_LEN"], device=DEV)      # 16 slots, 64 bytes apart; rpo_absmax fills slot 0
     # torch reference on the CPU (the reference trainer's own optimiser classes, rebuilt from torch.optim.Adam)
     tp = torch.nn.Parameter(torch.tensor(p0))
     topt = torch.optim.Adam([tp], lr=0.2 if dual else 3e-4, maximize=dual)
@@ -464,14 +464,14 @@ def test_adam_step_matches_torch(ops, mode):
                 tp.clamp_(0)                                           # DualAdam, model/dual.py:41-43
         else:
             ops.absmax(grad, gmax)
-            np.testing.assert_allclose(float(gmax), np.abs(gnp).max(), rtol=0)
+            np.testing.assert_allclose(float(gmax.max()), np.abs(gnp).max(), rtol=0)
             ops.adam_step(param, grad, m, v, step, 3e-4, clip_thres=0.2, gradmax=gmax, target=target, tau=0.005)
             torch.nn.utils.clip_grad_norm_([tp], 0.2, "inf")
             np.testing.assert_allclose(grad.cpu().numpy(), tp.grad.numpy(), rtol=1e-6, atol=1e-9)   # clipped in place
             topt.step()
             with torch.no_grad():
                 tt.copy_(tt * (1.0 - 0.005) + tp.data * 0.005)
-            assert float(gmax) == 0.0
+            assert float(gmax.abs().max()) == 0.0
         assert int(step[0]) == it + 1 and int(step[2]) == 0
         np.testing.assert_allclose(param.cpu().numpy(), tp.detach().numpy(), rtol=2e-6, atol=2e-7)
         if not dual:
@@ -546,7 +546,7 @@ def test_adam_step_multi_equals_single_launches(ops):
         for name, n in (("p", 34180), ("d", 6), ("c", 33796)):
             st[name] = dict(param=dev(rs.randn(n).astype(np.float32) * 0.1), m=torch.zeros(n, device=DEV),
                             v=torch.zeros(n, device=DEV), step=torch.zeros(8, dtype=torch.int32, device=DEV),
-                            gmax=torch.zeros(1, device=DEV))
+                            gmax=torch.zeros(ops.CONST["RPO_GRADMAX_LEN"], device=DEV))
         st["p"]["target"] = dev(rs.randn(34180).astype(np.float32))
         st["p"]["target2"] = dev(rs.randn(768).astype(np.float32))
         st["c"]["target"] = dev(rs.randn(33796).astype(np.float32))

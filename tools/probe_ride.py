@@ -33,4 +33,13 @@ print("fwd_a_ride[0,2048) %.2f us" % bench.time_kernel(lambda: su.run("critic_fw
 rd.set(lane_begin=2048, lane_end=4096)
 print("fwd_b_ride[2048,4096) %.2f us" % bench.time_kernel(lambda: su.run("critic_fwd_b", rider=rd)))
 print("bwd_b_ride %.2f us" % bench.time_kernel(lambda: su.run("critic_bwd_b", rider=rd)))
+gm = tr.agent.critic_optim.gradmax
+for label, val in (("gradmax", gm), ("no gradmax", None)):
+    su.set(gradmax=val)
+    print("critic_bwd_b (%s) %.2f us" % (label, bench.time_kernel(lambda: su.run("critic_bwd_b"))))
+su.set(gradmax=gm)
+opt = tr.agent.critic_optim
+print("adam (critic slice) %.2f us" % bench.time_kernel(lambda: opt.step(target=None, tau=0.0, gradmax_ready=True)))
+tgt = torch.zeros_like(opt.param)
+print("polyak on the same slice (no arrival counting) %.2f us, n = %d" % (bench.time_kernel(lambda: ops.polyak(opt.param, tgt, 0.005)), opt.param.numel()))
 print("rollout %.2f us" % bench.time_kernel(lambda: tr._rollout(False)))
