@@ -89,10 +89,11 @@ class FusedAdam(object):
         dev = param.device
         self.exp_avg = torch.zeros_like(param)
         self.exp_avg_sq = torch.zeros_like(param)
-        # {step, pad, arrival word (8 B), cached bias corrections of the next step (2 doubles)}
-        self.step_dev = torch.zeros(8, dtype=torch.int32, device=dev)
+        # {step, pad, arrival word (8 B), cached bias corrections of the next step (2 doubles), ..., 16 sub-counters}
+        const = getattr(backend, "CONST", {})
+        self.step_dev = torch.zeros(const.get("RPO_ADAM_STATE_LEN", 544), dtype=torch.int32, device=dev)
         # inf-norm of the gradient slice, in RPO_GRADMAX_SLOTS slots on separate cache lines (include/rpo_hip.h)
-        self.gradmax = torch.zeros(getattr(backend, "CONST", {}).get("RPO_GRADMAX_LEN", 256), device=dev)
+        self.gradmax = torch.zeros(const.get("RPO_GRADMAX_LEN", 512), device=dev)
         # True: the step leaves a zeroed gradient slice behind (optimizer.zero_grad() folded into the Adam launch); the
         # trainers switch it on when every backward of the iteration goes through the accumulating MLP kernels
         self.zero_grad_after = False
@@ -145,5 +146,6 @@ class FusedAdam(object):
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         step = sd["step"]
-        self.step_dev.zero_()                                   # (older checkpoints hold 4 words: the cache starts empty)
-        self.step_dev[:step.numel()].copy_(step)
+        self.step_dev.zero_()                                   # (older checkpoints hold 4 / 8 words: the cache starts empty)
+        k = min(8, step.numel())
+        self.step_dev[:k].copy_(step[:k])

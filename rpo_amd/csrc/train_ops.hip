@@ -1,3 +1,4 @@
+#include <stdlib.h>
 // Update-step kernels of RPODDPG.train / RPOSAC.train on MI355X: fused TD-target + Huber (forward + backward),
 // inf-norm of a flat gradient buffer, fused clip + Adam (+DualAdam clamp, + Polyak), Polyak alone, Philox test hook.
 // All are single-pass streaming kernels with wave64 shuffle reductions.
@@ -133,9 +134,24 @@ __device__ __forceinline__ void adam_body(const AdamArgs& p) {
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long arrived = atomicAdd(reinterpret_cast<unsigned long long*>(p.arrive), 1ull);
-        if (arrived == (unsigned long long)gridDim.x - 1ull) {
-            *p.arrive = 0;
+        // last workgroup of the launch: two-level arrival (sub-counter b % 16, then the top word) once the grid is wide
+        // enough for same-word atomics to queue up; every counter is back at 0 when the launch ends
+        const unsigned n = gridDim.x, sub = blockIdx.x % 16u;
+        unsigned long long* top = reinterpret_cast<unsigned long long*>(p.arrive);
+        bool last;
+        if (n <= 16u) {
+            last = atomicAdd(top, 1ull) == (unsigned long long)n - 1ull;
+        } else {
+            unsigned long long* sc = reinterpret_cast<unsigned long long*>(p.step_dev + 32 + 32 * sub);
+            const unsigned long long in_sub = (n - sub + 15u) / 16u;
+            last = false;
+            if (atomicAdd(sc, 1ull) == in_sub - 1ull) {
+                *sc = 0;
+                last = atomicAdd(top, 1ull) == 15ull;
+            }
+        }
+        if (last) {
+            *top = 0;
             p.step_dev[0] = step;
             cache[0] = 1.0 - pow((double)p.beta1, (double)(step + 1));
             cache[1] = sqrt(1.0 - pow((double)p.beta2, (double)(step + 1)));
@@ -216,6 +232,13 @@ int rpo_td_huber(int n, const float* q1, const float* q2, const float* qn1, cons
     return 0;
 }
 
+static int adam_grid(long long n) {
+    const char* e = getenv("RPO_ADAM_GRID");
+    const int cap = e ? atoi(e) : 0;
+    const int g = rpo_grid_for(n);
+    return (cap > 0 && g > cap) ? cap : g;
+}
+
 int rpo_absmax(long long n, const float* x, float* max_out, void* stream) {
     if (n <= 0) return RPO_ERR_ARG;
     if (!x || !max_out) return RPO_ERR_NULL;
@@ -233,12 +256,12 @@ int rpo_adam_step(long long n, float* param, float* grad, float* exp_avg, float*
     if (n <= 0) return RPO_ERR_ARG;
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return RPO_ERR_NULL;
     if (clip_thres > 0.0f && !gradmax) return RPO_ERR_NULL;
-    // the arrival word lives right behind the step counter: step_dev must point at int32[8] = {step, pad, arrive (8 B),
-    // cached bias corrections of the next step (2 doubles)}
+    // the arrival word lives right behind the step counter: step_dev must point at int32[RPO_ADAM_STATE_LEN] = {step, pad,
+    // arrive (8 B), cached bias corrections of the next step (2 doubles), ..., 16 sub-counters from word 32 on}
     AdamArgs a{n, param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, weight_decay, maximize,
                clip_thres, gradmax, reset_gradmax, zero_grad, clamp_min0, target, tau,
                reinterpret_cast<long long*>(step_dev + 2), nullptr, 0, 0, clock};
-    hipLaunchKernelGGL(adam_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(adam_kernel, dim3(adam_grid(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, a);
     RPO_LAUNCH_CHECK();
     return 0;
 }
@@ -264,7 +287,7 @@ int rpo_adam_step_multi(int count, const rpo_adam_seg* segs, long long* clock, v
                             g.target2, g.n2, g.polyak_only, (k == 0 && !g.polyak_only) ? clock : nullptr};
         n_max = g.n > n_max ? g.n : n_max;
     }
-    hipLaunchKernelGGL(adam_multi_kernel, dim3(rpo_grid_for(n_max), count), dim3(RPO_BLOCK), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(adam_grid(n_max), count), dim3(RPO_BLOCK), 0, (hipStream_t)stream, a);
     RPO_LAUNCH_CHECK();
     return 0;
 }

@@ -118,8 +118,9 @@ def absmax(x, max_out):
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
               maximize=False, clip_thres=0.0, gradmax=None, reset_gradmax=True, clamp_min0=False, target=None,
               tau=0.0, zero_grad=False, clock=None):
-    if step_dev.numel() < 8:
-        raise RpoHipError("step_dev must be int32[8]: {step, pad, arrival word, cached bias corrections} (include/rpo_hip.h)")
+    if step_dev.numel() < CONST["RPO_ADAM_STATE_LEN"]:
+        raise RpoHipError("step_dev must be int32[RPO_ADAM_STATE_LEN]: {step, pad, arrival word, cached bias corrections, "
+                          "sub-counters} (include/rpo_hip.h)")
     check(_lib.load().rpo_adam_step(param.numel(), _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq),
                                     _p(step_dev, torch.int32), lr, beta1, beta2, eps, weight_decay, int(maximize),
                                     clip_thres, _p(gradmax, allow_none=True), int(reset_gradmax), int(zero_grad), int(clamp_min0),
@@ -149,8 +150,8 @@ def adam_step_multi(segs, clock=None):
         if a.polyak_only:
             continue
         a.grad, a.exp_avg, a.exp_avg_sq = vp(g["grad"]), vp(g["exp_avg"]), vp(g["exp_avg_sq"])
-        if g["step_dev"].numel() < 8:
-            raise RpoHipError("step_dev must be int32[8] (include/rpo_hip.h)")
+        if g["step_dev"].numel() < CONST["RPO_ADAM_STATE_LEN"]:
+            raise RpoHipError("step_dev must be int32[RPO_ADAM_STATE_LEN] (include/rpo_hip.h)")
         a.step_dev = vp(g["step_dev"], torch.int32)
         a.lr, a.beta1, a.beta2, a.eps = g["lr"], g.get("beta1", 0.9), g.get("beta2", 0.999), g.get("eps", 1e-8)
         a.weight_decay, a.maximize, a.clip_thres = g.get("weight_decay", 0.0), int(g.get("maximize", False)), g.get("clip_thres", 0.0)

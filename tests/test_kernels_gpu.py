@@ -447,7 +447,7 @@ def test_adam_step_matches_torch(ops, mode):
     target = dev(p0 * 0.5)
     m = torch.zeros(n, device=DEV)
     v = torch.zeros(n, device=DEV)
-    step = torch.zeros(8, dtype=torch.int32, device=DEV)
+    step = torch.zeros(ops.CONST["RPO_ADAM_STATE_LEN"], dtype=torch.int32, device=DEV)
     gmax = torch.zeros(ops.CONST["RPO_GRADMAX_LEN"], device=DEV)      # 16 slots, 64 bytes apart; rpo_absmax fills slot 0
     # torch reference on the CPU (the reference trainer's own optimiser classes, rebuilt from torch.optim.Adam)
     tp = torch.nn.Parameter(torch.tensor(p0))
@@ -545,7 +545,7 @@ def test_adam_step_multi_equals_single_launches(ops):
         rs = np.random.RandomState(6)
         for name, n in (("p", 34180), ("d", 6), ("c", 33796)):
             st[name] = dict(param=dev(rs.randn(n).astype(np.float32) * 0.1), m=torch.zeros(n, device=DEV),
-                            v=torch.zeros(n, device=DEV), step=torch.zeros(8, dtype=torch.int32, device=DEV),
+                            v=torch.zeros(n, device=DEV), step=torch.zeros(ops.CONST["RPO_ADAM_STATE_LEN"], dtype=torch.int32, device=DEV),
                             gmax=torch.zeros(ops.CONST["RPO_GRADMAX_LEN"], device=DEV))
         st["p"]["target"] = dev(rs.randn(34180).astype(np.float32))
         st["p"]["target2"] = dev(rs.randn(768).astype(np.float32))
