@@ -158,9 +158,10 @@ class LaunchRecorder(object):
             orig_run = ops.SplitUpdate.run
             rec = self
 
-            def run(su, stage):
-                rec.calls.append(("split_" + stage, orig_run, (su, stage), {}))
-                return orig_run(su, stage)
+            def run(su, stage, rider=None):
+                kw = {} if rider is None else dict(rider=rider)
+                rec.calls.append(("split_" + stage + ("" if rider is None else "_ride"), orig_run, (su, stage), kw))
+                return orig_run(su, stage, **kw)
             self._undo.append((ops.SplitUpdate, "run", orig_run, True))
             ops.SplitUpdate.run = run
         k = tr.kernels
@@ -225,6 +226,11 @@ def launch_models(tr, workload):
         "split_critic_fwd_a": ("mfma", B, fa + twin * fc), "split_critic_fwd_b": ("mfma", B, twin * fc),
         "split_pend_head_project": ("hbm", B, 4 * S + 4 * P + 4 * A + 4),
         "split_critic_bwd_a": ("mfma", B, 2 * twin * fc), "split_critic_bwd_b": ("mfma", B, twin * 2 * 128 * (S + A + 2)),
+        # ... with the next vector step riding along: the stage's own flops + the actor forward of half the lanes
+        # each (fwd_a / fwd_b); bwd_b + the step of every lane is priced by the step's bytes
+        "split_critic_fwd_a_ride": ("mfma", n, (B * (fa + twin * fc) + (n // 2) * fa) / float(n)),
+        "split_critic_fwd_b_ride": ("mfma", n, (B * twin * fc + (n - n // 2) * fa) / float(n)),
+        "split_critic_bwd_b_ride": ("hbm", n, step_bytes),
     }
     return m
 
@@ -241,10 +247,20 @@ def kernel_clinic(tr, workload):
     rec = LaunchRecorder(tr)
     try:
         t0 = tr._t
-        for i in range(tr.policy_fre):
-            tr._iteration(False, True, (t0 + i + 1) % tr.policy_fre == 0)
-            tr._advance_host(t0 + i + 1)
-            tr._updates += 1
+        if getattr(tr, "_ride_ok", lambda d: False)(True):
+            # the launches of one policy_fre period as the graph windows issue them: the rollout rides on the critic update's
+            # launches except behind the policy step
+            tr._sync_uclock(rollout_pending=True)
+            tr._uclock_ok = True
+            tr._ridden_window(t0, tr.policy_fre)
+            for i in range(tr.policy_fre):
+                tr._advance_host(t0 + i + 1)
+            tr._updates += tr.policy_fre
+        else:
+            for i in range(tr.policy_fre):
+                tr._iteration(False, True, (t0 + i + 1) % tr.policy_fre == 0)
+                tr._advance_host(t0 + i + 1)
+                tr._updates += 1
     finally:
         rec.close()
         tr._graphs.enabled = graphs_on
@@ -344,6 +360,8 @@ KERNEL_OF = {
     "split_critic_fwd_a": "split_critic_fwd_a_kernel", "split_critic_fwd_b": "split_critic_fwd_b_kernel",
     "split_critic_bwd_a": "split_critic_bwd_a_kernel", "split_critic_bwd_b": "split_critic_bwd_b_kernel",
     "split_pend_head_project": "split_pend_head_project_kernel",
+    "split_critic_fwd_a_ride": "split_critic_fwd_a_ride_kernel", "split_critic_fwd_b_ride": "split_critic_fwd_b_ride_kernel",
+    "split_critic_bwd_b_ride": "split_critic_bwd_b_ride_kernel",
 }
 
 
