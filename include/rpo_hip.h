@@ -300,16 +300,20 @@ int rpo_absmax(long long n, const float* x, float* max_out, void* stream);
  *   target = (1 - tau) * target + tau * p.   gradmax is reset to 0 by the launch when reset_gradmax != 0.
  *   zero_grad != 0: instead of the clipped value, 0 is written back -- the gradient is consumed, so that the next
  *   backward pass (which accumulates) needs no separate fill launch (optimizer.zero_grad() folded into the step).
- *   step_dev points at int32[RPO_ADAM_STATE_LEN] (128-byte aligned): {step, pad, 8-byte arrival word (0 between launches),
+ *   step_dev points at int32[RPO_ADAM_STATE_LEN] (128-byte aligned): {step, the step the cached corrections belong to,
+ *   8-byte arrival word (0 between launches),
  *   two doubles: the bias corrections 1 - beta1^(step+1), sqrt(1 - beta2^(step+1)) cached by the previous launch (0.0 = not
  *   cached: they are then computed by every thread; zero-initialise the buffer, and zero the cache when betas change)},
  *   then from word 32 on 16 sub-counters 128 bytes apart (0 between launches): the launch finds its last workgroup
  *   through a two-level arrival tree -- 135 returning atomics on ONE word are served one after the other (3.3 us of a
- *   5.8 us launch, 4.7 us with 270 workgroups); 9 per sub-counter + 16 on the top word are not. */
+ *   5.8 us launch, 4.7 us with 270 workgroups); 9 per sub-counter + 16 on the top word are not.
+ *   prepared = 1: the caller's previous launch did the bookkeeping (rpo_split_update.prep_step: step_dev[0] already holds
+ *   THIS step, the cache its corrections) -- the launch is then purely elementwise: it neither counts its workgroups in
+ *   nor touches step_dev, gradmax (reset by the next rpo_split_critic_fwd_a, gradmax_reset) or `clock`. */
 int rpo_adam_step(long long n, float* param, float* grad, float* exp_avg, float* exp_avg_sq, int* step_dev,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int maximize, float clip_thres,
                   float* gradmax, int reset_gradmax, int zero_grad, int clamp_min0, float* target, float tau,
-                  long long* clock, void* stream);
+                  long long* clock, int prepared, void* stream);
 /*   clock (may be NULL): a device counter advanced by one when the launch has finished.  The trainers use it as the
  *   UPDATE clock: the update kernels read their step index from it instead of ctrl[RPO_CTRL_T], so that the next
  *   rollout -- which advances ctrl[RPO_CTRL_T] -- may run concurrently with the update (another stream of the same
@@ -462,6 +466,12 @@ typedef struct {
     /* fwd_a: NULL, or the clock / statistics of a rollout launched with defer_clock = 1 right before this update:
      * fwd_a advances rollout_ctrl[RPO_CTRL_T] and clears the next statistics row on its behalf */
     long long* rollout_ctrl; float* rollout_stats; int rollout_stats_cap;
+    /* bwd_b: bookkeeping for the rpo_adam_step(prepared = 1) launch of the critic that follows it.  prep_step: NULL, or that
+     * optimiser's state buffer -- one thread of bwd_b advances step_dev[0] and leaves the bias corrections of the new step
+     * (prep_beta1 / prep_beta2 = the optimiser's betas).  clock_out: NULL, or the update clock, advanced by one (set it
+     * when the critic step is the iteration's last optimiser launch).  gradmax_reset (fwd_a): NULL, or the gradmax buffer a
+     * prepared Adam launch of the PREVIOUS update consumed: fwd_a zeroes its slots before this update's backward fills them. */
+    int* prep_step; float prep_beta1, prep_beta2; long long* clock_out; float* gradmax_reset;
 } rpo_split_update;
 
 int rpo_split_critic_fwd_a(const rpo_split_update* u, void* stream);

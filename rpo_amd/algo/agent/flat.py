@@ -98,13 +98,17 @@ class FusedAdam(object):
         # trainers switch it on when every backward of the iteration goes through the accumulating MLP kernels
         self.zero_grad_after = False
 
-    def step(self, target=None, tau=0.0, gradmax_ready=False, clock=None):
+    def step(self, target=None, tau=0.0, gradmax_ready=False, clock=None, prepared=False):
         """``gradmax_ready``: the backward pass already left the inf-norm of this slice in ``self.gradmax``.
-        ``clock``: device counter the launch advances when it has finished (the trainers' update clock)."""
+        ``clock``: device counter the launch advances when it has finished (the trainers' update clock).
+        ``prepared``: the launch before this one advanced the step counter, left the bias corrections and (if due) advanced
+        the clock (rpo_split_update.prep_step / clock_out); the next update's first launch zeroes ``gradmax``."""
         clip = self.clip_thres if self.clip_thres and self.clip_thres != float("inf") else 0.0
         if clip > 0 and not gradmax_ready:
             self.backend.absmax(self.grad, self.gradmax)
         kw = {} if clock is None else dict(clock=clock)
+        if prepared:
+            kw = dict(prepared=True)
         self.backend.adam_step(self.param, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr,
                                self.betas[0], self.betas[1], self.eps, self.weight_decay, self.maximize, clip,
                                self.gradmax, True, self.clamp_min0, target, tau, zero_grad=self.zero_grad_after, **kw)

@@ -283,8 +283,9 @@ class RPODDPG(RPOTrainerBase):
     def _critic_step(self, actor_step):
         ag = self.agent
         fuse = actor_step and ag.flat.sizes[1] == 0
+        prepared, self._critic_prepared = getattr(self, "_critic_prepared", False), False
         ag.critic_optim.step(target=ag.critic_target_flat if fuse else None, tau=ag.tau,
-                             gradmax_ready=self._gradmax_ready, clock=self._clock(not actor_step))
+                             gradmax_ready=self._gradmax_ready, clock=self._clock(not actor_step), prepared=prepared)
         self._gradmax_ready = False
 
     def _actor_step(self, actor_out):

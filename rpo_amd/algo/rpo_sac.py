@@ -300,10 +300,12 @@ class RPOSAC(RPOTrainerBase):
         ag = self.agent
         self._fused_polyak = ag.flat.sizes[1] == 0
         ready, self._gradmax_ready = self._gradmax_ready, False
+        prepared, self._critic_prepared = getattr(self, "_critic_prepared", False), False
         if self._fused_polyak:
-            ag.critic_optim.step(target=ag.critic_target_flat, tau=ag.tau, gradmax_ready=ready, clock=self._clock(not actor_step))
+            ag.critic_optim.step(target=ag.critic_target_flat, tau=ag.tau, gradmax_ready=ready, clock=self._clock(not actor_step),
+                                 prepared=prepared)
             return
-        ag.critic_optim.step(gradmax_ready=ready, clock=self._clock(not actor_step))
+        ag.critic_optim.step(gradmax_ready=ready, clock=self._clock(not actor_step), prepared=prepared)
         if not actor_step:
             ag.soft_update()
 

@@ -242,7 +242,7 @@ class RPOTrainerBase(object):
         # split path it is an alias of the rollout's ctrl and nothing changes.
         self._uctrl, self._uclock_ok, self._after_front, self._ovl_stream = self.vec.ctrl, True, None, None
         self._ride, self._rider_cache, self._ride_cut = None, None, 0
-        self._clock_pending = False
+        self._clock_pending, self._iter_actor_step, self._critic_prepared, self._gradmax_stale = False, None, False, False
         self._bump = self.updates_per_step == 1
         if self.fused is not None and device.type == "cuda" and getattr(self.backend, "ADAM_CLOCK", False):
             self._uctrl, self._uclock_ok = torch.zeros_like(self.vec.ctrl), False
@@ -385,6 +385,7 @@ class RPOTrainerBase(object):
             if rollout:
                 self._rollout(warm, defer_clock=True)
             self._last_cols = self._sample()
+            self._iter_actor_step = actor_step
             self._critic_update(self._last_cols)
         segs.append((s1, [fl.gradient(fl.critic_range)]))
         if actor_step:
@@ -459,6 +460,7 @@ class RPOTrainerBase(object):
     def _extra_body(self, actor_step):
         self._uctrl[hip_ops.CONST["RPO_CTRL_UPDATES"]] += 1
         cols = self._sample()
+        self._iter_actor_step = actor_step
         self._critic_update(cols)
         fl = self.agent.flat
         self.dist.mean_([fl.gradient(fl.critic_range)])
@@ -501,10 +503,10 @@ class RPOTrainerBase(object):
 
     def _train_body(self, t):
         cols = self._sample()
+        actor_step = self._iter_actor_step = t % self.policy_fre == 0
         self._critic_update(cols)
         fl = self.agent.flat
         self.dist.mean_([fl.gradient(fl.critic_range)])
-        actor_step = t % self.policy_fre == 0
         self._critic_step(actor_step)
         if actor_step:
             out = self._actor_update(cols)
@@ -610,6 +612,17 @@ class RPOTrainerBase(object):
             eps_in = self._noise_b.view(-1)
         buf = self.buffer
         su.set(idx_in=idx_in, eps_in=eps_in, rows=buf.rows, cap_steps=buf.capacity, n_envs=buf.n_envs)   # (tests swap the ring)
+        # "prepared" critic step (single GPU, in-backward inf-norm, the caller said whether a policy step follows): bwd_b
+        # advances the optimiser's step counter (and the update clock when the critic step ends the iteration), the NEXT
+        # fwd_a zeroes gradmax -- the Adam launch in between does no bookkeeping and counts no workgroups in
+        opt = self.agent.critic_optim
+        actor_step, self._iter_actor_step = self._iter_actor_step, None
+        prep = actor_step is not None and not self.dist.on and _env_int("RPO_PREPARED_ADAM", 1) and self._critic_gradmax() is not None
+        self._critic_prepared = bool(prep)
+        clock_out = self._clock(not actor_step) if prep else None
+        su.set(prep_step=opt.step_dev if prep else None, prep_beta1=opt.betas[0], prep_beta2=opt.betas[1],
+               clock_out=clock_out, gradmax_reset=opt.gradmax if self._gradmax_stale else None)
+        self._gradmax_stale = bool(prep)
         pending, self._clock_pending = self._clock_pending, False   # a rollout left its clock to this update's first launch
         su.set(rollout_ctrl=self.vec.ctrl if pending else None, rollout_stats=self.vec.stats if pending else None,
                rollout_stats_cap=self.vec.stats.shape[0] if pending else 0)
@@ -772,6 +785,7 @@ class RPOTrainerBase(object):
             more = i + 1 < L
             ride = more and not actor_step
             self._ride = self._rider() if ride else None
+            self._iter_actor_step = actor_step
             try:
                 cols = self._last_cols = self._sample()
                 self._critic_update(cols)
@@ -822,6 +836,7 @@ class RPOTrainerBase(object):
                     self._rollout(False)
             split = self._split_state() is not None and getattr(self, "_pipelines", False)
             self._after_front = fork if (overlap and split) else None       # split path: fork behind its sampling launch
+            self._iter_actor_step = actor_step
             try:
                 cols = self._last_cols = self._sample()
                 if overlap and not split:

@@ -91,6 +91,7 @@ struct SplitArgs {
     float *ap_det, *noise_out, *raw, *actions, *g_act, *lag_partial, *lag_out, *da_part, *dout;
     int shared_embedding;
     long long* rollout_ctrl; float* rollout_stats; int rollout_stats_cap;
+    int* prep_step; float prep_beta1, prep_beta2; long long* clock_out; float* gradmax_reset;
 };
 
 // ReplayBuffer.sample (buffer.py:31-34): counter-based draw + gather of the tile's 16 rows (same draw in every workgroup
@@ -156,6 +157,8 @@ __device__ __forceinline__ void fwd_a_role(const SplitArgs& p, NsLds<128>& lds, 
         }
         if (threadIdx.x == 0) p.rollout_ctrl[RPO_CTRL_T] = tr + 1;
     }
+    if (p.gradmax_reset && role == 0 && g == 0 && row0 == 0 && threadIdx.x < RPO_GRADMAX_SLOTS)
+        p.gradmax_reset[threadIdx.x * (RPO_GRADMAX_LEN / RPO_GRADMAX_SLOTS)] = 0.0f;   // on behalf of the previous (prepared) Adam launch
     const Mlp& net = role == 0 ? (p.twin ? p.actor : p.actor_target) : p.critic[role - 1];
     NsWeights<128> w;
     ns_load_weights<128, 256>(net, g, w);
@@ -601,8 +604,30 @@ __global__ __launch_bounds__(kThreads) void split_critic_bwd_a_kernel(SplitArgs 
 // ---- bwd_b: every parameter gradient of critic k = blockIdx.y.  blocks [0, 36): dW0 tiles and hidden-layer vectors from
 //      dLoss/dQ (left by bwd_a) and the saved activations, dh formed on the fly; then the first-layer gradients dWs / dbs /
 //      dWa / dba from dx0 (batch reduction, one owner per output, fixed order).  Leaves the inf-norm of what it wrote.
+// Bookkeeping for the optimiser launch that follows bwd_b ("prepared" rpo_adam_step): one thread advances the step counter
+// and leaves the bias corrections of that step -- nothing in this launch reads them -- and, when the critic step is the
+// last optimiser launch of the iteration, the update clock (bwd_a / bwd_b do not read it).  The Adam launch then has no
+// bookkeeping left and needs no last-workgroup detection (two atomic round trips, 2.3 us).
+__device__ __forceinline__ void bwd_b_bookkeeping(const SplitArgs& p) {
+    if (threadIdx.x != 0) return;
+    if (p.prep_step) {
+        const int s = p.prep_step[0] + 1;
+        double* cache = reinterpret_cast<double*>(p.prep_step + 4);
+        cache[0] = 1.0 - pow((double)p.prep_beta1, (double)s);
+        cache[1] = sqrt(1.0 - pow((double)p.prep_beta2, (double)s));
+        p.prep_step[1] = s;
+        p.prep_step[0] = s;
+    }
+    if (p.clock_out) p.clock_out[0] += 1;
+}
+
+// own blocks: [0, kWeightBlocks) weight roles | first-layer blocks | (k == 0, when asked for) one bookkeeping block
 template <class L>
-__device__ __forceinline__ void bwd_b_role(const SplitArgs& p, float* smem, int bx, int k) {
+__device__ __forceinline__ void bwd_b_role(const SplitArgs& p, float* smem, int bx, int k, int own_blocks) {
+    if ((p.prep_step || p.clock_out) && bx == own_blocks - 1) {
+        if (k == 0) bwd_b_bookkeeping(p);
+        return;
+    }
     if (bx < kWeightBlocks) {
         gradmax_flush(p.gradmax, ns_weight_role(p.critic[k], p.critic_grad[k], p.h1[k], p.x0[k], p.dq[k], 1, false, p.B, bx, smem));
         return;
@@ -622,7 +647,7 @@ __device__ __forceinline__ void bwd_b_role(const SplitArgs& p, float* smem, int 
 template <class L>
 __global__ __launch_bounds__(kThreads) void split_critic_bwd_b_kernel(SplitArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[4 * 16 * 16];
-    bwd_b_role<L>(p, smem, blockIdx.x, blockIdx.y);
+    bwd_b_role<L>(p, smem, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 // bwd_b + explore / project / step / scatter of the lanes: grid (own_blocks + lane blocks, K); the extra x-blocks of plane 0
@@ -631,7 +656,7 @@ template <class L>
 __global__ __launch_bounds__(kThreads) void split_critic_bwd_b_ride_kernel(SplitArgs p, CartConsts c, RideArgs<typename L::Env> r,
                                                                            int own_blocks) {
     __shared__ __attribute__((aligned(16))) float smem[4 * 16 * 16];
-    if ((int)blockIdx.x < own_blocks) bwd_b_role<L>(p, smem, blockIdx.x, blockIdx.y);
+    if ((int)blockIdx.x < own_blocks) bwd_b_role<L>(p, smem, blockIdx.x, blockIdx.y, own_blocks);
     else if (blockIdx.y == 0) ride_tail<typename L::Env>(r, c, smem, blockIdx.x - own_blocks, gridDim.x - own_blocks);
 }
 
@@ -1089,6 +1114,8 @@ int to_args(const rpo_split_update* u, unsigned need, SplitArgs& a, CartConsts& 
     a.lag_partial = u->lag_partial; a.lag_out = u->lag_out; a.da_part = u->da_part; a.dout = u->dout;
     a.shared_embedding = u->shared_embedding;
     a.rollout_ctrl = u->rollout_ctrl; a.rollout_stats = u->rollout_stats; a.rollout_stats_cap = u->rollout_stats_cap;
+    a.prep_step = u->prep_step; a.prep_beta1 = u->prep_beta1; a.prep_beta2 = u->prep_beta2; a.clock_out = u->clock_out;
+    a.gradmax_reset = u->gradmax_reset;
     return 0;
 }
 
@@ -1169,7 +1196,7 @@ int rpo_split_critic_bwd_b(const rpo_split_update* u, void* stream) {
     for (int k = 0; k < K; ++k)
         if (!a.dx0[k] || !a.dq[k] || !a.x0[k] || !a.h1[k]) return RPO_ERR_NULL;
     const Mlp& m = a.critic[0];
-    const int blocks = kWeightBlocks + mlp_fl_blocks(m.E * (m.S + 1 + m.A + 1));
+    const int blocks = kWeightBlocks + mlp_fl_blocks(m.E * (m.S + 1 + m.A + 1)) + ((a.prep_step || a.clock_out) ? 1 : 0);
     if (u->env == 0) hipLaunchKernelGGL(split_critic_bwd_b_kernel<CartRow>, dim3(blocks, K), dim3(kThreads), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(split_critic_bwd_b_kernel<PendRow>, dim3(blocks, K), dim3(kThreads), 0, (hipStream_t)stream, a);
     RPO_LAUNCH_CHECK();
@@ -1284,7 +1311,7 @@ int rpo_split_critic_bwd_b_ride(const rpo_split_update* u, const rpo_rollout_rid
     for (int k = 0; k < K; ++k)
         if (!a.dx0[k] || !a.dq[k] || !a.x0[k] || !a.h1[k]) return RPO_ERR_NULL;
     const Mlp& m = a.critic[0];
-    const int own = kWeightBlocks + mlp_fl_blocks(m.E * (m.S + 1 + m.A + 1));
+    const int own = kWeightBlocks + mlp_fl_blocks(m.E * (m.S + 1 + m.A + 1)) + ((a.prep_step || a.clock_out) ? 1 : 0);
     const dim3 grid(own + (r->n_envs + kThreads - 1) / kThreads, K);
     if (u->env == 0)
         hipLaunchKernelGGL(split_critic_bwd_b_ride_kernel<CartRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c,

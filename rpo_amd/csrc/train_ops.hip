@@ -86,6 +86,8 @@ struct AdamArgs {
     long long n2;
     int polyak_only;
     long long* clock;    // NULL, or a device counter advanced by one when the launch has finished (update clock)
+    int prepared;        // 1: the launch before this one advanced step_dev[0] / cached the corrections (rpo_adam_prepare
+                         //    semantics, see rpo_hip.h): no bookkeeping here, hence no last-workgroup detection at all
 };
 
 __device__ __forceinline__ void adam_body(const AdamArgs& p) {
@@ -98,10 +100,10 @@ __device__ __forceinline__ void adam_body(const AdamArgs& p) {
     // precision pow() calls are ~1 us of every thread's critical path, so the workgroup that finishes a step last leaves
     // the corrections of the NEXT step behind the arrival word (step_dev + 4: {1 - beta1^t, sqrt(1 - beta2^t)} as doubles,
     // 0.0 = not cached yet): same functions, same arguments, same bits -- computed once instead of 34 000 times.
-    const int step = p.step_dev[0] + 1;
+    const int step = p.prepared ? p.step_dev[0] : p.step_dev[0] + 1;
     double* cache = reinterpret_cast<double*>(p.step_dev + 4);
     double bc1 = cache[0], bc2s = cache[1];
-    if (bc1 == 0.0) {
+    if (bc1 == 0.0 || p.step_dev[1] != step) {                  // step_dev[1]: the step the cached corrections belong to
         bc1 = 1.0 - pow((double)p.beta1, (double)step);
         bc2s = sqrt(1.0 - pow((double)p.beta2, (double)step));
     }
@@ -132,6 +134,7 @@ __device__ __forceinline__ void adam_body(const AdamArgs& p) {
         if (p.target) p.target[i] = p.target[i] * (1.0f - p.tau) + w * p.tau;   // soft_update, ddpg_pa.py:77-86
         if (p.target2 && i < p.n2) p.target2[i] = p.target2[i] * (1.0f - p.tau) + w * p.tau;
     }
+    if (p.prepared) return;
     __syncthreads();
     if (threadIdx.x == 0) {
         // last workgroup of the launch: two-level arrival (sub-counter b % 16, then the top word) once the grid is wide
@@ -155,6 +158,7 @@ __device__ __forceinline__ void adam_body(const AdamArgs& p) {
             p.step_dev[0] = step;
             cache[0] = 1.0 - pow((double)p.beta1, (double)(step + 1));
             cache[1] = sqrt(1.0 - pow((double)p.beta2, (double)(step + 1)));
+            p.step_dev[1] = step + 1;
             if (p.reset_gradmax && p.gradmax)
                 for (int j = 0; j < RPO_GRADMAX_SLOTS; ++j) p.gradmax[j * (RPO_GRADMAX_LEN / RPO_GRADMAX_SLOTS)] = 0.0f;
             if (p.clock) p.clock[0] += 1;
@@ -232,13 +236,6 @@ int rpo_td_huber(int n, const float* q1, const float* q2, const float* qn1, cons
     return 0;
 }
 
-static int adam_grid(long long n) {
-    const char* e = getenv("RPO_ADAM_GRID");
-    const int cap = e ? atoi(e) : 0;
-    const int g = rpo_grid_for(n);
-    return (cap > 0 && g > cap) ? cap : g;
-}
-
 int rpo_absmax(long long n, const float* x, float* max_out, void* stream) {
     if (n <= 0) return RPO_ERR_ARG;
     if (!x || !max_out) return RPO_ERR_NULL;
@@ -252,7 +249,7 @@ int rpo_absmax(long long n, const float* x, float* max_out, void* stream) {
 int rpo_adam_step(long long n, float* param, float* grad, float* exp_avg, float* exp_avg_sq, int* step_dev,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int maximize, float clip_thres,
                   float* gradmax, int reset_gradmax, int zero_grad, int clamp_min0, float* target, float tau,
-                  long long* clock, void* stream) {
+                  long long* clock, int prepared, void* stream) {
     if (n <= 0) return RPO_ERR_ARG;
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return RPO_ERR_NULL;
     if (clip_thres > 0.0f && !gradmax) return RPO_ERR_NULL;
@@ -260,8 +257,8 @@ int rpo_adam_step(long long n, float* param, float* grad, float* exp_avg, float*
     // arrive (8 B), cached bias corrections of the next step (2 doubles), ..., 16 sub-counters from word 32 on}
     AdamArgs a{n, param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, weight_decay, maximize,
                clip_thres, gradmax, reset_gradmax, zero_grad, clamp_min0, target, tau,
-               reinterpret_cast<long long*>(step_dev + 2), nullptr, 0, 0, clock};
-    hipLaunchKernelGGL(adam_kernel, dim3(adam_grid(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, a);
+               reinterpret_cast<long long*>(step_dev + 2), nullptr, 0, 0, clock, prepared ? 1 : 0};
+    hipLaunchKernelGGL(adam_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, a);
     RPO_LAUNCH_CHECK();
     return 0;
 }
@@ -284,10 +281,10 @@ int rpo_adam_step_multi(int count, const rpo_adam_seg* segs, long long* clock, v
         a.seg[k] = AdamArgs{g.n, g.param, g.grad, g.exp_avg, g.exp_avg_sq, g.step_dev, g.lr, g.beta1, g.beta2, g.eps,
                             g.weight_decay, g.maximize, g.clip_thres, g.gradmax, g.reset_gradmax, g.zero_grad, g.clamp_min0,
                             g.target, g.tau, g.polyak_only ? nullptr : reinterpret_cast<long long*>(g.step_dev + 2),
-                            g.target2, g.n2, g.polyak_only, (k == 0 && !g.polyak_only) ? clock : nullptr};
+                            g.target2, g.n2, g.polyak_only, (k == 0 && !g.polyak_only) ? clock : nullptr, 0};
         n_max = g.n > n_max ? g.n : n_max;
     }
-    hipLaunchKernelGGL(adam_multi_kernel, dim3(adam_grid(n_max), count), dim3(RPO_BLOCK), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(rpo_grid_for(n_max), count), dim3(RPO_BLOCK), 0, (hipStream_t)stream, a);
     RPO_LAUNCH_CHECK();
     return 0;
 }

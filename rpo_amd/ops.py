@@ -117,14 +117,15 @@ def absmax(x, max_out):
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
               maximize=False, clip_thres=0.0, gradmax=None, reset_gradmax=True, clamp_min0=False, target=None,
-              tau=0.0, zero_grad=False, clock=None):
+              tau=0.0, zero_grad=False, clock=None, prepared=False):
     if step_dev.numel() < CONST["RPO_ADAM_STATE_LEN"]:
         raise RpoHipError("step_dev must be int32[RPO_ADAM_STATE_LEN]: {step, pad, arrival word, cached bias corrections, "
                           "sub-counters} (include/rpo_hip.h)")
     check(_lib.load().rpo_adam_step(param.numel(), _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq),
                                     _p(step_dev, torch.int32), lr, beta1, beta2, eps, weight_decay, int(maximize),
                                     clip_thres, _p(gradmax, allow_none=True), int(reset_gradmax), int(zero_grad), int(clamp_min0),
-                                    _p(target, allow_none=True), tau, _p(clock, torch.int64, allow_none=True), _stream()),
+                                    _p(target, allow_none=True), tau, _p(clock, torch.int64, allow_none=True), int(prepared),
+                                    _stream()),
           "rpo_adam_step")
 
 
@@ -719,7 +720,8 @@ class _SplitUpdateStruct(ctypes.Structure):
                                         "noise_out", "raw", "actions", "g_act", "lag_partial", "lag_out", "da_part",
                                         "dout")] +
         [("shared_embedding", ctypes.c_int), ("rollout_ctrl", ctypes.c_void_p), ("rollout_stats", ctypes.c_void_p),
-         ("rollout_stats_cap", ctypes.c_int)])
+         ("rollout_stats_cap", ctypes.c_int), ("prep_step", ctypes.c_void_p), ("prep_beta1", ctypes.c_float),
+         ("prep_beta2", ctypes.c_float), ("clock_out", ctypes.c_void_p), ("gradmax_reset", ctypes.c_void_p)])
 
 
 class _RolloutRiderStruct(ctypes.Structure):
@@ -792,8 +794,8 @@ class SplitUpdate(object):
     def set(self, **fields):
         for k, v in fields.items():
             if isinstance(v, torch.Tensor):
-                dt = torch.int64 if k in ("idx_out", "idx_in", "ctrl", "rollout_ctrl") else \
-                    (torch.int32 if k == "proj_iters" else torch.float32)
+                dt = torch.int64 if k in ("idx_out", "idx_in", "ctrl", "rollout_ctrl", "clock_out") else \
+                    (torch.int32 if k in ("proj_iters", "prep_step") else torch.float32)
                 self._held[k] = v                                   # keeps the buffer alive while the struct points at it
                 setattr(self.st, k, _p(v, dt).value)
             else:

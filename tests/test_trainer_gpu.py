@@ -626,3 +626,31 @@ def test_deferred_rollout_clock_equals_own_clock(hip, algo, envname, monkeypatch
     assert torch.equal(a.vec.internal, b.vec.internal) and torch.equal(a.buffer.rows, b.buffer.rows)
     assert torch.equal(a.agent.flat.data, b.agent.flat.data)
     assert torch.equal(a.vec.stats, b.vec.stats)                  # incl. the cleared rows ahead of the step counter
+
+
+@pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "cart"), ("ddpg", "pendulum")])
+def test_prepared_critic_step_equals_self_advancing(hip, algo, envname, monkeypatch):
+    """The critic's rpo_adam_step(prepared=1) does no bookkeeping: bwd_b advanced its step counter, left the bias
+    corrections and (on iterations without a policy step) advanced the update clock, the next fwd_a zeroes gradmax.
+    Parameters, moments, step counters and clocks equal those of the launch that counts its workgroups in and does all of
+    that itself."""
+    dev = torch.device("cuda")
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
+    a = _run(algo, envname, hip, dev, 45, 300, use_graph=True)
+    monkeypatch.setenv("RPO_PREPARED_ADAM", "0")
+    b = _run(algo, envname, hip, dev, 45, 300, use_graph=True)
+    for x, y in ((a, b),):
+        assert torch.equal(x.agent.flat.data, y.agent.flat.data) and torch.equal(x.agent.critic_target_flat, y.agent.critic_target_flat)
+        for o in ("critic_optim", "actor_optim"):
+            ox, oy = getattr(x.agent, o), getattr(y.agent, o)
+            assert torch.equal(ox.exp_avg, oy.exp_avg) and torch.equal(ox.exp_avg_sq, oy.exp_avg_sq)
+            assert int(ox.step_dev[0]) == int(oy.step_dev[0]) > 0
+            assert int(ox.step_dev[2]) == 0 and int(ox.step_dev[32:].abs().max()) == 0      # arrival counters at rest
+        assert int(x.agent.critic_optim.step_dev[0]) == 45
+        assert torch.equal(x._uctrl, y._uctrl) and torch.equal(x.vec.ctrl, y.vec.ctrl)
+        assert torch.equal(x.buffer.rows, y.buffer.rows) and torch.equal(x.vec.internal, y.vec.internal)
+    # the prepared launch leaves gradmax to the next fwd_a; the self-advancing one zeroes it itself
+    assert float(b.agent.critic_optim.gradmax.abs().max()) == 0.0 and float(a.agent.critic_optim.gradmax.max()) > 0.0
+    a.run_steps(1)
+    torch.cuda.synchronize()
+    assert int(a.agent.critic_optim.step_dev[0]) == 46
