@@ -523,6 +523,7 @@ typedef struct {
     unsigned long long seed;
     float* part;                 /* [8, n_envs, 2] head partials of the actor between the forward stages and the step */
     int lane_begin, lane_end;    /* forward stages: the lanes of this launch (multiples of 16; lane_end may be n_envs) */
+    int defer_clock;             /* step stage: as in rpo_*_rollout -- 1: ctrl[RPO_CTRL_T] is advanced by the next fwd_a */
 } rpo_rollout_rider;
 
 int rpo_split_critic_fwd_a_ride(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream);

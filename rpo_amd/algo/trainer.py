@@ -642,8 +642,11 @@ class RPOTrainerBase(object):
         gm = self._critic_gradmax()
         su.set(gradmax=gm)
         su.run("critic_bwd_a")
+        if ride is not None:
+            ride.set(defer_clock=int(self._defer_ok))           # ... whose step counter the next update's fwd_a advances
         su.run("critic_bwd_b", rider=ride)                      # + explore / project / step / scatter of every lane
         if ride is not None:
+            self._clock_pending = bool(self._defer_ok)
             self.vec.steps_host += 1
         self._gradmax_ready = gm is not None
         from .rpo_ddpg import _LazySum

@@ -262,6 +262,7 @@ struct RideArgs {
     float scale, base;
     int gauss, n;
     int lane0, lane1;             // forward stages: the lanes of this launch (multiples of 16, or n)
+    int defer_clock;              // step stage: the next fwd_a advances ctrl[T] (rpo_split_update.rollout_ctrl)
     typename ENV::ActArgs act;
     typename ENV::StepArgs step;
     float* part;                  // [8, n, 2]
@@ -339,7 +340,7 @@ __device__ __forceinline__ void ride_tail(const RideArgs<ENV>& r, const CartCons
             else if (v != 0.0f) atomicAdd(srow + slot[tid], v);
         }
     }
-    rpo_step_epilogue_at(r.step.ctrl, t, r.step.stats, r.step.stats_cap, blk, nblk);
+    if (!r.defer_clock) rpo_step_epilogue_at(r.step.ctrl, t, r.step.stats, r.step.stats_cap, blk, nblk);
 }
 
 // fwd_a / fwd_b + the actor forward of a lane range: grid (8 column groups, row tiles of the batch, roles + planes of lane
@@ -1241,7 +1242,7 @@ template <class ENV>
 RideArgs<ENV> ride_args(const SplitArgs& a, const rpo_rollout_rider* r) {
     RideArgs<ENV> o{};
     o.actor = a.actor; o.scale = r->scale; o.base = r->base; o.gauss = r->gauss ? 1 : 0; o.n = r->n_envs; o.part = r->part;
-    o.lane0 = r->lane_begin; o.lane1 = r->lane_end;
+    o.lane0 = r->lane_begin; o.lane1 = r->lane_end; o.defer_clock = r->defer_clock ? 1 : 0;
     ride_env(r, o);
     return o;
 }

@@ -736,7 +736,7 @@ class _RolloutRiderStruct(ctypes.Structure):
                 ("corr_lr", ctypes.c_float), ("corr_eps", ctypes.c_float), ("corr_momentum", ctypes.c_float),
                 ("max_episode_steps", ctypes.c_int), ("auto_reset", ctypes.c_int), ("viol_thresh", ctypes.c_float),
                 ("env_id_base", ctypes.c_uint), ("seed", ctypes.c_ulonglong), ("part", ctypes.c_void_p),
-                ("lane_begin", ctypes.c_int), ("lane_end", ctypes.c_int)]
+                ("lane_begin", ctypes.c_int), ("lane_end", ctypes.c_int), ("defer_clock", ctypes.c_int)]
 
 
 class RolloutRider(object):
