@@ -340,6 +340,8 @@ typedef struct {
     float* target2;
     long long n2;
     int polyak_only;
+    int prepared;                /* as in rpo_adam_step (per slice; with every stepped slice prepared the launch counts no
+                                    workgroups in and `clock` is ignored) */
 } rpo_adam_seg;
 int rpo_adam_step_multi(int count, const rpo_adam_seg* segs, long long* clock, void* stream);
 
@@ -472,6 +474,9 @@ typedef struct {
      * when the critic step is the iteration's last optimiser launch).  gradmax_reset (fwd_a): NULL, or the gradmax buffer a
      * prepared Adam launch of the PREVIOUS update consumed: fwd_a zeroes its slots before this update's backward fills them. */
     int* prep_step; float prep_beta1, prep_beta2; long long* clock_out; float* gradmax_reset;
+    /* pol_e: the same bookkeeping for up to three slices of the rpo_adam_step_multi launch behind the policy step (actor,
+     * multipliers, log alpha); clock_out is advanced by pol_e when set for that stage.  gradmax_reset2 (fwd_a): the actor's. */
+    int* prep2_step[3]; float prep2_beta1[3], prep2_beta2[3]; float* gradmax_reset2;
 } rpo_split_update;
 
 int rpo_split_critic_fwd_a(const rpo_split_update* u, void* stream);

@@ -125,17 +125,25 @@ class FusedAdam(object):
                     target2=target2, n2=n2)
 
     @staticmethod
-    def step_many(backend, segs, clock=None):
+    def step_many(backend, segs, clock=None, prepared=False):
         """Several non-overlapping slices (``segment()`` dicts or ``dict(polyak_only=True, param=, target=, tau=)``) in
-        one launch where the backend has rpo_adam_step_multi; one launch each otherwise.  ``clock`` rides on slice 0."""
+        one launch where the backend has rpo_adam_step_multi; one launch each otherwise.  ``clock`` rides on slice 0.
+        ``prepared``: see ``step`` (every stepped slice; the clock was advanced by the preparing launch)."""
+        if prepared:
+            clock = None
         if hasattr(backend, "adam_step_multi") and 1 < len(segs) <= 4:
-            return backend.adam_step_multi(segs, **({} if clock is None else dict(clock=clock)))
+            kw = {} if clock is None else dict(clock=clock)
+            if prepared:
+                kw["prepared"] = True
+            return backend.adam_step_multi(segs, **kw)
         for i, g in enumerate(segs):
             if g.get("polyak_only"):
                 backend.polyak(g["param"], g["target"], g["tau"])
                 continue
             g = dict(g)
             param, t2, n2 = g.pop("param"), g.pop("target2", None), g.pop("n2", 0)
+            if prepared:
+                g["prepared"] = True
             if clock is not None and i == 0:
                 g["clock"] = clock
             backend.adam_step(param, g.pop("grad"), g.pop("exp_avg"), g.pop("exp_avg_sq"), g.pop("step_dev"), g.pop("lr"),

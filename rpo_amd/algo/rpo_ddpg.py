@@ -303,4 +303,5 @@ class RPODDPG(RPOTrainerBase):
             segs.append(ag.nju_optim.segment())                    # lambda is never stepped (rpo_ddpg.py:202)
         if sh > 0 and c > 0:
             segs.append(dict(polyak_only=True, param=fl.param((0, c)), target=ag.critic_target_flat[:c], tau=ag.tau))
-        FusedAdam.step_many(self.backend, segs, clock=self._clock(True))
+        prepared, self._actor_prepared = getattr(self, "_actor_prepared", False), False
+        FusedAdam.step_many(self.backend, segs, clock=self._clock(True), prepared=prepared)

@@ -317,6 +317,7 @@ class RPOSAC(RPOTrainerBase):
             segs.append(ag.nju_optim.segment())
         if self.automatic_entropy_tuning:
             segs.append(ag.alpha_optim.segment())               # rpo_sac.py:210-216, gradient left by _actor_update
-        FusedAdam.step_many(self.backend, segs, clock=self._clock(True))   # actor Adam | DualAdam (| log_alpha): one launch
+        prepared, self._actor_prepared = getattr(self, "_actor_prepared", False), False
+        FusedAdam.step_many(self.backend, segs, clock=self._clock(True), prepared=prepared)   # actor Adam | DualAdam (| log_alpha): one launch
         if not self._fused_polyak:
             ag.soft_update()

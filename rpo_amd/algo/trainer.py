@@ -243,6 +243,7 @@ class RPOTrainerBase(object):
         self._uctrl, self._uclock_ok, self._after_front, self._ovl_stream = self.vec.ctrl, True, None, None
         self._ride, self._rider_cache, self._ride_cut = None, None, 0
         self._clock_pending, self._iter_actor_step, self._critic_prepared, self._gradmax_stale = False, None, False, False
+        self._actor_prepared, self._actor_gradmax_stale = False, False
         self._bump = self.updates_per_step == 1
         if self.fused is not None and device.type == "cuda" and getattr(self.backend, "ADAM_CLOCK", False):
             self._uctrl, self._uclock_ok = torch.zeros_like(self.vec.ctrl), False
@@ -421,6 +422,16 @@ class RPOTrainerBase(object):
     def _actor_step(self, actor_out):
         raise NotImplementedError
 
+    def _policy_optims(self):
+        """The optimisers `_actor_step` steps, in the order of its slices (the prepared launch's bookkeeping list)."""
+        ag = self.agent
+        out = [ag.actor_optim]
+        if not self.fixed:
+            out.append(ag.nju_optim)
+        if getattr(self, "automatic_entropy_tuning", False):
+            out.append(ag.alpha_optim)
+        return out
+
     def _iteration(self, warm, do_train, actor_step, rollout=True):
         segs = self._segments(warm, do_train, actor_step, rollout)
         if do_train:
@@ -594,7 +605,17 @@ class RPOTrainerBase(object):
         fuse_max = self._self_cleaning and not self.dist.on and opt.clip_thres and opt.clip_thres != float("inf")
         su.set(gradmax=opt.gradmax if fuse_max else None)
         su.run("policy_d")
+        # "prepared" optimiser launch behind the policy step (as for the critic's, `_critic_update_split`): pol_e advances the
+        # step counters of the slices `_actor_step` will step and the update clock; the next fwd_a zeroes the actor's gradmax
+        # (only when the critic update runs through the split stages too: its fwd_a is what zeroes the gradmax afterwards)
+        prep = bool(fuse_max) and bool(getattr(self, "_pipelines", False)) and bool(_env_int("RPO_PREPARED_ADAM", 1))
+        optims = [o for o in self._policy_optims() if o is not None] if prep else []
+        su.set_prep2([(o.step_dev, o.betas[0], o.betas[1]) for o in optims])
+        su.set(clock_out=self._clock(True) if prep else None)
         su.run("policy_e")
+        su.set(clock_out=None)
+        self._actor_prepared = prep
+        self._actor_gradmax_stale = prep
         su.set(noise_salt=_SALT_CRITIC, eps_in=None, logp=crit_logp)
         self._actor_gradmax_ready = bool(fuse_max)
         f = self.fused
@@ -621,8 +642,9 @@ class RPOTrainerBase(object):
         self._critic_prepared = bool(prep)
         clock_out = self._clock(not actor_step) if prep else None
         su.set(prep_step=opt.step_dev if prep else None, prep_beta1=opt.betas[0], prep_beta2=opt.betas[1],
-               clock_out=clock_out, gradmax_reset=opt.gradmax if self._gradmax_stale else None)
-        self._gradmax_stale = bool(prep)
+               clock_out=clock_out, gradmax_reset=opt.gradmax if self._gradmax_stale else None,
+               gradmax_reset2=self.agent.actor_optim.gradmax if self._actor_gradmax_stale else None)
+        self._gradmax_stale, self._actor_gradmax_stale = bool(prep), False
         pending, self._clock_pending = self._clock_pending, False   # a rollout left its clock to this update's first launch
         su.set(rollout_ctrl=self.vec.ctrl if pending else None, rollout_stats=self.vec.stats if pending else None,
                rollout_stats_cap=self.vec.stats.shape[0] if pending else 0)

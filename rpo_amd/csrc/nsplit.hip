@@ -92,6 +92,7 @@ struct SplitArgs {
     int shared_embedding;
     long long* rollout_ctrl; float* rollout_stats; int rollout_stats_cap;
     int* prep_step; float prep_beta1, prep_beta2; long long* clock_out; float* gradmax_reset;
+    int* prep2_step[3]; float prep2_beta1[3], prep2_beta2[3]; float* gradmax_reset2;
 };
 
 // ReplayBuffer.sample (buffer.py:31-34): counter-based draw + gather of the tile's 16 rows (same draw in every workgroup
@@ -157,8 +158,10 @@ __device__ __forceinline__ void fwd_a_role(const SplitArgs& p, NsLds<128>& lds, 
         }
         if (threadIdx.x == 0) p.rollout_ctrl[RPO_CTRL_T] = tr + 1;
     }
-    if (p.gradmax_reset && role == 0 && g == 0 && row0 == 0 && threadIdx.x < RPO_GRADMAX_SLOTS)
-        p.gradmax_reset[threadIdx.x * (RPO_GRADMAX_LEN / RPO_GRADMAX_SLOTS)] = 0.0f;   // on behalf of the previous (prepared) Adam launch
+    if (role == 0 && g == 0 && row0 == 0 && threadIdx.x < RPO_GRADMAX_SLOTS) {   // on behalf of earlier (prepared) Adam launches
+        if (p.gradmax_reset) p.gradmax_reset[threadIdx.x * (RPO_GRADMAX_LEN / RPO_GRADMAX_SLOTS)] = 0.0f;
+        if (p.gradmax_reset2) p.gradmax_reset2[threadIdx.x * (RPO_GRADMAX_LEN / RPO_GRADMAX_SLOTS)] = 0.0f;
+    }
     const Mlp& net = role == 0 ? (p.twin ? p.actor : p.actor_target) : p.critic[role - 1];
     NsWeights<128> w;
     ns_load_weights<128, 256>(net, g, w);
@@ -609,16 +612,18 @@ __global__ __launch_bounds__(kThreads) void split_critic_bwd_a_kernel(SplitArgs 
 // and leaves the bias corrections of that step -- nothing in this launch reads them -- and, when the critic step is the
 // last optimiser launch of the iteration, the update clock (bwd_a / bwd_b do not read it).  The Adam launch then has no
 // bookkeeping left and needs no last-workgroup detection (two atomic round trips, 2.3 us).
+__device__ __forceinline__ void adam_prepare(int* step_dev, float beta1, float beta2) {
+    const int s = step_dev[0] + 1;
+    double* cache = reinterpret_cast<double*>(step_dev + 4);
+    cache[0] = 1.0 - pow((double)beta1, (double)s);
+    cache[1] = sqrt(1.0 - pow((double)beta2, (double)s));
+    step_dev[1] = s;
+    step_dev[0] = s;
+}
+
 __device__ __forceinline__ void bwd_b_bookkeeping(const SplitArgs& p) {
     if (threadIdx.x != 0) return;
-    if (p.prep_step) {
-        const int s = p.prep_step[0] + 1;
-        double* cache = reinterpret_cast<double*>(p.prep_step + 4);
-        cache[0] = 1.0 - pow((double)p.prep_beta1, (double)s);
-        cache[1] = sqrt(1.0 - pow((double)p.prep_beta2, (double)s));
-        p.prep_step[1] = s;
-        p.prep_step[0] = s;
-    }
+    if (p.prep_step) adam_prepare(p.prep_step, p.prep_beta1, p.prep_beta2);
     if (p.clock_out) p.clock_out[0] += 1;
 }
 
@@ -1027,6 +1032,9 @@ __global__ __launch_bounds__(kThreads) void split_policy_e_kernel(SplitArgs p, i
             else if (tid == 7) { if (!p.twin) p.lag_out[1] = inv_b * sacc; }
             else if (tid - 1 < ENV::NI) p.nu_grad[tid - 1] += inv_b * sacc;
         }
+        // bookkeeping for the rpo_adam_step_multi(prepared) launch behind the policy step (nothing in this launch reads it)
+        if (tid >= 64 && tid < 67 && p.prep2_step[tid - 64]) adam_prepare(p.prep2_step[tid - 64], p.prep2_beta1[tid - 64], p.prep2_beta2[tid - 64]);
+        if (tid == 128 && p.clock_out) p.clock_out[0] += 1;
         return;
     }
     BwdArgs a{};
@@ -1116,7 +1124,8 @@ int to_args(const rpo_split_update* u, unsigned need, SplitArgs& a, CartConsts& 
     a.shared_embedding = u->shared_embedding;
     a.rollout_ctrl = u->rollout_ctrl; a.rollout_stats = u->rollout_stats; a.rollout_stats_cap = u->rollout_stats_cap;
     a.prep_step = u->prep_step; a.prep_beta1 = u->prep_beta1; a.prep_beta2 = u->prep_beta2; a.clock_out = u->clock_out;
-    a.gradmax_reset = u->gradmax_reset;
+    a.gradmax_reset = u->gradmax_reset; a.gradmax_reset2 = u->gradmax_reset2;
+    for (int j = 0; j < 3; ++j) { a.prep2_step[j] = u->prep2_step[j]; a.prep2_beta1[j] = u->prep2_beta1[j]; a.prep2_beta2[j] = u->prep2_beta2[j]; }
     return 0;
 }
 

@@ -281,7 +281,7 @@ int rpo_adam_step_multi(int count, const rpo_adam_seg* segs, long long* clock, v
         a.seg[k] = AdamArgs{g.n, g.param, g.grad, g.exp_avg, g.exp_avg_sq, g.step_dev, g.lr, g.beta1, g.beta2, g.eps,
                             g.weight_decay, g.maximize, g.clip_thres, g.gradmax, g.reset_gradmax, g.zero_grad, g.clamp_min0,
                             g.target, g.tau, g.polyak_only ? nullptr : reinterpret_cast<long long*>(g.step_dev + 2),
-                            g.target2, g.n2, g.polyak_only, (k == 0 && !g.polyak_only) ? clock : nullptr, 0};
+                            g.target2, g.n2, g.polyak_only, (k == 0 && !g.polyak_only) ? clock : nullptr, g.prepared ? 1 : 0};
         n_max = g.n > n_max ? g.n : n_max;
     }
     hipLaunchKernelGGL(adam_multi_kernel, dim3(rpo_grid_for(n_max), count), dim3(RPO_BLOCK), 0, (hipStream_t)stream, a);

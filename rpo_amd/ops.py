@@ -136,10 +136,11 @@ class _AdamSegStruct(ctypes.Structure):
                 ("weight_decay", ctypes.c_float), ("maximize", ctypes.c_int), ("clip_thres", ctypes.c_float),
                 ("gradmax", ctypes.c_void_p), ("reset_gradmax", ctypes.c_int), ("zero_grad", ctypes.c_int),
                 ("clamp_min0", ctypes.c_int), ("target", ctypes.c_void_p), ("tau", ctypes.c_float),
-                ("target2", ctypes.c_void_p), ("n2", ctypes.c_longlong), ("polyak_only", ctypes.c_int)]
+                ("target2", ctypes.c_void_p), ("n2", ctypes.c_longlong), ("polyak_only", ctypes.c_int),
+                ("prepared", ctypes.c_int)]
 
 
-def adam_step_multi(segs, clock=None):
+def adam_step_multi(segs, clock=None, prepared=False):
     """One launch for up to four non-overlapping optimiser slices (rpo_adam_step_multi).  Each entry is a dict with the
     keyword arguments of ``adam_step`` (+ ``target2`` / ``n2``), or ``dict(polyak_only=True, param=, target=, tau=)``."""
     arr = (_AdamSegStruct * len(segs))()
@@ -158,6 +159,7 @@ def adam_step_multi(segs, clock=None):
         a.weight_decay, a.maximize, a.clip_thres = g.get("weight_decay", 0.0), int(g.get("maximize", False)), g.get("clip_thres", 0.0)
         a.gradmax, a.reset_gradmax = vp(g.get("gradmax")), int(g.get("reset_gradmax", True))
         a.zero_grad, a.clamp_min0 = int(g.get("zero_grad", False)), int(g.get("clamp_min0", False))
+        a.prepared = int(bool(prepared))
     check(_lib.load().rpo_adam_step_multi(len(segs), arr, _p(clock, torch.int64, allow_none=True), _stream()),
           "rpo_adam_step_multi")
 
@@ -721,7 +723,9 @@ class _SplitUpdateStruct(ctypes.Structure):
                                         "dout")] +
         [("shared_embedding", ctypes.c_int), ("rollout_ctrl", ctypes.c_void_p), ("rollout_stats", ctypes.c_void_p),
          ("rollout_stats_cap", ctypes.c_int), ("prep_step", ctypes.c_void_p), ("prep_beta1", ctypes.c_float),
-         ("prep_beta2", ctypes.c_float), ("clock_out", ctypes.c_void_p), ("gradmax_reset", ctypes.c_void_p)])
+         ("prep_beta2", ctypes.c_float), ("clock_out", ctypes.c_void_p), ("gradmax_reset", ctypes.c_void_p),
+         ("prep2_step", ctypes.c_void_p * 3), ("prep2_beta1", ctypes.c_float * 3), ("prep2_beta2", ctypes.c_float * 3),
+         ("gradmax_reset2", ctypes.c_void_p)])
 
 
 class _RolloutRiderStruct(ctypes.Structure):
@@ -801,6 +805,17 @@ class SplitUpdate(object):
             else:
                 self._held.pop(k, None)
                 setattr(self.st, k, v)
+
+    def set_prep2(self, optims):
+        """pol_e's bookkeeping list: up to three (step_dev, beta1, beta2) of the slices of the Adam launch behind it."""
+        optims = list(optims)
+        self._held["prep2"] = [o[0] for o in optims]
+        for j in range(3):
+            if j < len(optims):
+                self.st.prep2_step[j] = _p(optims[j][0], torch.int32).value
+                self.st.prep2_beta1[j], self.st.prep2_beta2[j] = optims[j][1], optims[j][2]
+            else:
+                self.st.prep2_step[j] = None
 
     def run(self, stage, rider=None):
         """``rider``: a RolloutRider whose share of the next vector step rides on this launch (critic_fwd_a / critic_fwd_b:
