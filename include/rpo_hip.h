@@ -477,6 +477,9 @@ typedef struct {
     /* pol_e: the same bookkeeping for up to three slices of the rpo_adam_step_multi launch behind the policy step (actor,
      * multipliers, log alpha); clock_out is advanced by pol_e when set for that stage.  gradmax_reset2 (fwd_a): the actor's. */
     int* prep2_step[3]; float prep2_beta1[3], prep2_beta2[3]; float* gradmax_reset2;
+    /* bwd_b / pol_e: NULL, or the update's ctrl buffer: ctrl[RPO_CTRL_UPDATES] += 1 when the stage is the last one of the
+     * update that reads it (several updates per vector step: the next update draws with the next sub-index) */
+    long long* updates_out;
 } rpo_split_update;
 
 int rpo_split_critic_fwd_a(const rpo_split_update* u, void* stream);

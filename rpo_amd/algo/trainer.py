@@ -244,6 +244,7 @@ class RPOTrainerBase(object):
         self._ride, self._rider_cache, self._ride_cut = None, None, 0
         self._clock_pending, self._iter_actor_step, self._critic_prepared, self._gradmax_stale = False, None, False, False
         self._actor_prepared, self._actor_gradmax_stale = False, False
+        self._bump_updates_now, self._updates_out = False, None
         self._bump = self.updates_per_step == 1
         if self.fused is not None and device.type == "cuda" and getattr(self.backend, "ADAM_CLOCK", False):
             self._uctrl, self._uclock_ok = torch.zeros_like(self.vec.ctrl), False
@@ -387,6 +388,7 @@ class RPOTrainerBase(object):
                 self._rollout(warm, defer_clock=True)
             self._last_cols = self._sample()
             self._iter_actor_step = actor_step
+            self._bump_updates_now = self._updates_inkernel      # (updates_per_step > 1: for the first extra update)
             self._critic_update(self._last_cols)
         segs.append((s1, [fl.gradient(fl.critic_range)]))
         if actor_step:
@@ -468,8 +470,18 @@ class RPOTrainerBase(object):
         if tail is not None:
             self._graphs.run(tail[0], tail[1])
 
+    @property
+    def _updates_inkernel(self):
+        """Several updates per vector step: ctrl[RPO_CTRL_UPDATES] is advanced by the update's own last stage (column-split
+        critic AND policy stages) instead of a torch launch between two updates."""
+        return bool(self.updates_per_step > 1 and getattr(self, "_pipelines", False) and getattr(self, "_actor_pipeline", False)
+                    and self._split_state() is not None and _env_int("RPO_UPDATES_INKERNEL", 1))
+
     def _extra_body(self, actor_step):
-        self._uctrl[hip_ops.CONST["RPO_CTRL_UPDATES"]] += 1
+        if self._updates_inkernel:
+            self._bump_updates_now = True                       # (the previous update advanced the counter for this one)
+        else:
+            self._uctrl[hip_ops.CONST["RPO_CTRL_UPDATES"]] += 1
         cols = self._sample()
         self._iter_actor_step = actor_step
         self._critic_update(cols)
@@ -611,9 +623,10 @@ class RPOTrainerBase(object):
         prep = bool(fuse_max) and bool(getattr(self, "_pipelines", False)) and bool(_env_int("RPO_PREPARED_ADAM", 1))
         optims = [o for o in self._policy_optims() if o is not None] if prep else []
         su.set_prep2([(o.step_dev, o.betas[0], o.betas[1]) for o in optims])
-        su.set(clock_out=self._clock(True) if prep else None)
+        su.set(clock_out=self._clock(True) if prep else None, updates_out=self._updates_out)
         su.run("policy_e")
-        su.set(clock_out=None)
+        su.set(clock_out=None, updates_out=None)
+        self._updates_out = None
         self._actor_prepared = prep
         self._actor_gradmax_stale = prep
         su.set(noise_salt=_SALT_CRITIC, eps_in=None, logp=crit_logp)
@@ -641,6 +654,11 @@ class RPOTrainerBase(object):
         prep = actor_step is not None and not self.dist.on and _env_int("RPO_PREPARED_ADAM", 1) and self._critic_gradmax() is not None
         self._critic_prepared = bool(prep)
         clock_out = self._clock(not actor_step) if prep else None
+        # several updates per vector step: the last stage of this update that reads ctrl[RPO_CTRL_UPDATES] advances it for
+        # the next one (bwd_b, or pol_e behind a policy step) when the caller asked for it (`_extra_body`, `_segments`)
+        bump_updates, self._bump_updates_now = self._bump_updates_now, False
+        self._updates_out = self._uctrl if bump_updates else None
+        su.set(updates_out=self._updates_out if not actor_step else None)
         su.set(prep_step=opt.step_dev if prep else None, prep_beta1=opt.betas[0], prep_beta2=opt.betas[1],
                clock_out=clock_out, gradmax_reset=opt.gradmax if self._gradmax_stale else None,
                gradmax_reset2=self.agent.actor_optim.gradmax if self._actor_gradmax_stale else None)

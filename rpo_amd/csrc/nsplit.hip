@@ -93,6 +93,7 @@ struct SplitArgs {
     long long* rollout_ctrl; float* rollout_stats; int rollout_stats_cap;
     int* prep_step; float prep_beta1, prep_beta2; long long* clock_out; float* gradmax_reset;
     int* prep2_step[3]; float prep2_beta1[3], prep2_beta2[3]; float* gradmax_reset2;
+    long long* updates_out;
 };
 
 // ReplayBuffer.sample (buffer.py:31-34): counter-based draw + gather of the tile's 16 rows (same draw in every workgroup
@@ -625,12 +626,13 @@ __device__ __forceinline__ void bwd_b_bookkeeping(const SplitArgs& p) {
     if (threadIdx.x != 0) return;
     if (p.prep_step) adam_prepare(p.prep_step, p.prep_beta1, p.prep_beta2);
     if (p.clock_out) p.clock_out[0] += 1;
+    if (p.updates_out) p.updates_out[RPO_CTRL_UPDATES] += 1;
 }
 
 // own blocks: [0, kWeightBlocks) weight roles | first-layer blocks | (k == 0, when asked for) one bookkeeping block
 template <class L>
 __device__ __forceinline__ void bwd_b_role(const SplitArgs& p, float* smem, int bx, int k, int own_blocks) {
-    if ((p.prep_step || p.clock_out) && bx == own_blocks - 1) {
+    if ((p.prep_step || p.clock_out || p.updates_out) && bx == own_blocks - 1) {
         if (k == 0) bwd_b_bookkeeping(p);
         return;
     }
@@ -1035,6 +1037,7 @@ __global__ __launch_bounds__(kThreads) void split_policy_e_kernel(SplitArgs p, i
         // bookkeeping for the rpo_adam_step_multi(prepared) launch behind the policy step (nothing in this launch reads it)
         if (tid >= 64 && tid < 67 && p.prep2_step[tid - 64]) adam_prepare(p.prep2_step[tid - 64], p.prep2_beta1[tid - 64], p.prep2_beta2[tid - 64]);
         if (tid == 128 && p.clock_out) p.clock_out[0] += 1;
+        if (tid == 192 && p.updates_out) p.updates_out[RPO_CTRL_UPDATES] += 1;
         return;
     }
     BwdArgs a{};
@@ -1124,7 +1127,7 @@ int to_args(const rpo_split_update* u, unsigned need, SplitArgs& a, CartConsts& 
     a.shared_embedding = u->shared_embedding;
     a.rollout_ctrl = u->rollout_ctrl; a.rollout_stats = u->rollout_stats; a.rollout_stats_cap = u->rollout_stats_cap;
     a.prep_step = u->prep_step; a.prep_beta1 = u->prep_beta1; a.prep_beta2 = u->prep_beta2; a.clock_out = u->clock_out;
-    a.gradmax_reset = u->gradmax_reset; a.gradmax_reset2 = u->gradmax_reset2;
+    a.gradmax_reset = u->gradmax_reset; a.gradmax_reset2 = u->gradmax_reset2; a.updates_out = u->updates_out;
     for (int j = 0; j < 3; ++j) { a.prep2_step[j] = u->prep2_step[j]; a.prep2_beta1[j] = u->prep2_beta1[j]; a.prep2_beta2[j] = u->prep2_beta2[j]; }
     return 0;
 }
@@ -1206,7 +1209,7 @@ int rpo_split_critic_bwd_b(const rpo_split_update* u, void* stream) {
     for (int k = 0; k < K; ++k)
         if (!a.dx0[k] || !a.dq[k] || !a.x0[k] || !a.h1[k]) return RPO_ERR_NULL;
     const Mlp& m = a.critic[0];
-    const int blocks = kWeightBlocks + mlp_fl_blocks(m.E * (m.S + 1 + m.A + 1)) + ((a.prep_step || a.clock_out) ? 1 : 0);
+    const int blocks = kWeightBlocks + mlp_fl_blocks(m.E * (m.S + 1 + m.A + 1)) + ((a.prep_step || a.clock_out || a.updates_out) ? 1 : 0);
     if (u->env == 0) hipLaunchKernelGGL(split_critic_bwd_b_kernel<CartRow>, dim3(blocks, K), dim3(kThreads), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(split_critic_bwd_b_kernel<PendRow>, dim3(blocks, K), dim3(kThreads), 0, (hipStream_t)stream, a);
     RPO_LAUNCH_CHECK();
@@ -1321,7 +1324,7 @@ int rpo_split_critic_bwd_b_ride(const rpo_split_update* u, const rpo_rollout_rid
     for (int k = 0; k < K; ++k)
         if (!a.dx0[k] || !a.dq[k] || !a.x0[k] || !a.h1[k]) return RPO_ERR_NULL;
     const Mlp& m = a.critic[0];
-    const int own = kWeightBlocks + mlp_fl_blocks(m.E * (m.S + 1 + m.A + 1)) + ((a.prep_step || a.clock_out) ? 1 : 0);
+    const int own = kWeightBlocks + mlp_fl_blocks(m.E * (m.S + 1 + m.A + 1)) + ((a.prep_step || a.clock_out || a.updates_out) ? 1 : 0);
     const dim3 grid(own + (r->n_envs + kThreads - 1) / kThreads, K);
     if (u->env == 0)
         hipLaunchKernelGGL(split_critic_bwd_b_ride_kernel<CartRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c,

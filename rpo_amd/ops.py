@@ -725,7 +725,7 @@ class _SplitUpdateStruct(ctypes.Structure):
          ("rollout_stats_cap", ctypes.c_int), ("prep_step", ctypes.c_void_p), ("prep_beta1", ctypes.c_float),
          ("prep_beta2", ctypes.c_float), ("clock_out", ctypes.c_void_p), ("gradmax_reset", ctypes.c_void_p),
          ("prep2_step", ctypes.c_void_p * 3), ("prep2_beta1", ctypes.c_float * 3), ("prep2_beta2", ctypes.c_float * 3),
-         ("gradmax_reset2", ctypes.c_void_p)])
+         ("gradmax_reset2", ctypes.c_void_p), ("updates_out", ctypes.c_void_p)])
 
 
 class _RolloutRiderStruct(ctypes.Structure):
@@ -798,7 +798,7 @@ class SplitUpdate(object):
     def set(self, **fields):
         for k, v in fields.items():
             if isinstance(v, torch.Tensor):
-                dt = torch.int64 if k in ("idx_out", "idx_in", "ctrl", "rollout_ctrl", "clock_out") else \
+                dt = torch.int64 if k in ("idx_out", "idx_in", "ctrl", "rollout_ctrl", "clock_out", "updates_out") else \
                     (torch.int32 if k in ("proj_iters", "prep_step") else torch.float32)
                 self._held[k] = v                                   # keeps the buffer alive while the struct points at it
                 setattr(self.st, k, _p(v, dt).value)

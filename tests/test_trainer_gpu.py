@@ -155,6 +155,14 @@ def test_multi_update_graph_in_utd_mode(hip, algo, monkeypatch):
     assert torch.equal(a.agent.critic_target_flat, c.agent.critic_target_flat)
     assert int(a.agent.critic_optim.step_dev[0]) == 6 * 23
     assert int(a.agent.actor_optim.step_dev[0]) == int(c.agent.actor_optim.step_dev[0]) >= 6 * 23 // 4 - 1
+    # ctrl[RPO_CTRL_UPDATES] (the Philox sub-index of the k-th update of a vector step) is advanced by the update's own last
+    # stage; a torch launch between two updates (RPO_UPDATES_INKERNEL=0) gives the same draws
+    assert a._updates_inkernel and int(a._uctrl[hip.CONST["RPO_CTRL_UPDATES"]]) == 0
+    monkeypatch.setenv("RPO_UPDATES_INKERNEL", "0")
+    d = _run(algo, "cart", hip, dev, 6, 64, use_graph=True, updates_per_step=23)
+    assert not d._updates_inkernel
+    assert torch.equal(a.agent.flat.data, d.agent.flat.data) and torch.equal(a.agent.critic_target_flat, d.agent.critic_target_flat)
+    assert torch.equal(a.agent.nju.weight, d.agent.nju.weight) and torch.equal(a._uctrl, d._uctrl)
 
 
 @pytest.mark.parametrize("algo,envname", CASES)
