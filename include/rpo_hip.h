@@ -480,10 +480,16 @@ typedef struct {
     /* bwd_b / pol_e: NULL, or the update's ctrl buffer: ctrl[RPO_CTRL_UPDATES] += 1 when the stage is the last one of the
      * update that reads it (several updates per vector step: the next update draws with the next sub-index) */
     long long* updates_out;
+    /* policy step: head partials of pi(s) between pol_a and pol_b, [8, batch, 2]; NULL: part_pi is used.  A buffer of its
+     * own lets pol_a run INSIDE fwd_b's launch (rpo_split_critic_fwd_b_pol) while fwd_b still reads part_pi. */
+    float* part_pol;
 } rpo_split_update;
 
 int rpo_split_critic_fwd_a(const rpo_split_update* u, void* stream);
 int rpo_split_critic_fwd_b(const rpo_split_update* u, void* stream);
+/* fwd_b + pol_a in one launch (policy iterations, no shared state embedding: the policy slabs on the batch states need
+ * nothing the critic update produces); the caller then skips rpo_split_policy_a.  Requires part_pol. */
+int rpo_split_critic_fwd_b_pol(const rpo_split_update* u, void* stream);
 int rpo_split_pend_head_project(const rpo_split_update* u, void* stream);
 int rpo_split_critic_bwd_a(const rpo_split_update* u, void* stream);
 int rpo_split_critic_bwd_b(const rpo_split_update* u, void* stream);

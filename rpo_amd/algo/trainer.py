@@ -244,7 +244,7 @@ class RPOTrainerBase(object):
         self._ride, self._rider_cache, self._ride_cut = None, None, 0
         self._clock_pending, self._iter_actor_step, self._critic_prepared, self._gradmax_stale = False, None, False, False
         self._actor_prepared, self._actor_gradmax_stale = False, False
-        self._bump_updates_now, self._updates_out = False, None
+        self._bump_updates_now, self._updates_out, self._pol_a_done = False, None, False
         self._bump = self.updates_per_step == 1
         if self.fused is not None and device.type == "cuda" and getattr(self.backend, "ADAM_CLOCK", False):
             self._uctrl, self._uclock_ok = torch.zeros_like(self.vec.ctrl), False
@@ -575,7 +575,8 @@ class RPOTrainerBase(object):
             corr_lr=self.corr_lr, corr_eps=self.corr_eps, corr_momentum=self.corr_momentum,
             alpha=float(getattr(ag, "alpha", 0.0)), gamma=ag.gamma, eps_start=self.eps_start, eps_end=self.eps,
             eps_decay=self.decay_value,
-            part_pi=b("split.part_pi", 8, B, 2), part_q1=b("split.part_q1", 8, B, 2), part_qn1=b("split.part_qn1", 8, B, 2),
+            part_pi=b("split.part_pi", 8, B, 2), part_pol=b("split.part_pol", 8, B, 2),
+            part_q1=b("split.part_q1", 8, B, 2), part_qn1=b("split.part_qn1", 8, B, 2),
             x0_1=b(c1 + ".x0", B, d[c1].ein), h1_1=b(c1 + ".h1", B, d[c1].H), dq1=b("dq1" if self.sac else "dq", B, 1),
             dx0_1=b(c1 + ".dx0", B, d[c1].ein), loss_partial=b("split.loss_parts", 2, T),
             next_actions=b("split.next_actions", B, 2), logp=b("crit.logp", B))
@@ -609,7 +610,9 @@ class RPOTrainerBase(object):
             noise_in = self._noise_b.view(-1)
         crit_logp, pi_logp = self._split_logp
         su.set(noise_salt=_SALT_ACTOR, eps_in=noise_in, logp=pi_logp)
-        su.run("policy_a")
+        early, self._pol_a_done = self._pol_a_done, False
+        if not early:                                             # (else: done inside fwd_b's launch of this iteration)
+            su.run("policy_a")
         su.run("policy_b")
         su.run("policy_c")
         self._zero_grads()
@@ -677,7 +680,12 @@ class RPOTrainerBase(object):
             su.run("pend_head_project")
         if ride is not None:
             ride.set(lane_begin=cut, lane_end=n)
-        su.run("critic_fwd_b", rider=ride)                      # + actor forward of lanes [cut, n)
+        # policy iteration without a shared embedding: the policy slabs on the batch states (pol_a) need nothing the critic
+        # update produces -- they are an extra plane of fwd_b's launch instead of a launch behind the critic step
+        early = bool(actor_step) and ride is None and self.agent.flat.sizes[1] == 0 and getattr(self, "_actor_pipeline", False) \
+            and bool(_env_int("RPO_POL_A_EARLY", 1))
+        self._pol_a_done = early
+        su.run("critic_fwd_b_pol" if early else "critic_fwd_b", rider=ride)   # (+ actor forward of lanes [cut, n))
         self._zero_grads()
         gm = self._critic_gradmax()
         su.set(gradmax=gm)

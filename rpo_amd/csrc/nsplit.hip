@@ -94,6 +94,7 @@ struct SplitArgs {
     int* prep_step; float prep_beta1, prep_beta2; long long* clock_out; float* gradmax_reset;
     int* prep2_step[3]; float prep2_beta1[3], prep2_beta2[3]; float* gradmax_reset2;
     long long* updates_out;
+    float* part_pol;              // policy step: head partials of pi(s) (pol_a -> pol_b); NULL: part_pi is reused
 };
 
 // ReplayBuffer.sample (buffer.py:31-34): counter-based draw + gather of the tile's 16 rows (same draw in every workgroup
@@ -758,17 +759,36 @@ __device__ __forceinline__ float explore_clip(float ap_det, float eps_t, float e
 }
 
 // ---- pol_a: pi hidden slabs on the batch states, pre-activations saved.  grid (row tiles, 8)
+__device__ __forceinline__ float* pol_part(const SplitArgs& p) { return p.part_pol ? p.part_pol : p.part_pi; }
+
 template <class L>
-__global__ __launch_bounds__(kNsThreads) void split_policy_a_kernel(SplitArgs p) {
-    __shared__ NsLds<128> lds;
-    __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
-    const int row0 = blockIdx.y * kRows, g = blockIdx.x;
+__device__ __forceinline__ void pol_a_role(const SplitArgs& p, NsLds<128>& lds, float4* tile, int row0, int g) {
     NsWeights<128> w;
     ns_load_weights<128, 256>(p.actor, g, w);
     ns_load_tile<L>(p, tile, row0);
     __syncthreads();
     ns_stage<L>(lds, reinterpret_cast<const float*>(tile), false, false);
-    ns_hidden<128, 256>(p.actor, w, lds, g, row0, p.B, p.part_pi, p.x0_a, p.h1_a);
+    ns_hidden<128, 256>(p.actor, w, lds, g, row0, p.B, pol_part(p), p.x0_a, p.h1_a);
+}
+
+template <class L>
+__global__ __launch_bounds__(kNsThreads) void split_policy_a_kernel(SplitArgs p) {
+    __shared__ NsLds<128> lds;
+    __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
+    pol_a_role<L>(p, lds, tile, blockIdx.y * kRows, blockIdx.x);
+}
+
+// fwd_b + pol_a: on a policy iteration of a configuration WITHOUT a shared state embedding the policy slabs on the batch
+// states need nothing the critic update produces (the batch was gathered by fwd_a, the critic step does not touch the
+// actor), so they are an extra plane of fwd_b's grid instead of a launch of their own behind the critic step.  Their head
+// partials go to part_pol: fwd_b's own prologue still reads part_pi.
+template <class L, int PROJ>
+__global__ __launch_bounds__(kNsThreads) void split_critic_fwd_b_pol_kernel(SplitArgs p, CartConsts c) {
+    __shared__ NsLds<128> lds;
+    __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
+    const int K = p.twin ? 2 : 1;
+    if ((int)blockIdx.z < K) fwd_b_role<L, PROJ>(p, c, lds, tile, blockIdx.y * kRows, blockIdx.x, blockIdx.z);
+    else pol_a_role<L>(p, lds, tile, blockIdx.y * kRows, blockIdx.x);
 }
 
 // ---- pol_b: head -> exploration noise + clip (RPODDPG) / rsample + clip + log pi (RPOSAC) -> Complete -> Lagrangian row
@@ -805,11 +825,11 @@ __global__ __launch_bounds__(kNsThreads) void split_policy_b_kernel(SplitArgs p,
             }
             float ap, logp = 0.0f, rm = 0.0f, rl = 0.0f, ap_det = 0.0f;
             if (p.twin) {
-                rm = ns_head(p.part_pi, B, i, 0, p.actor.b1[0]);
-                rl = ns_head(p.part_pi, B, i, 1, p.actor.b1b[0]);
+                rm = ns_head(pol_part(p), B, i, 0, p.actor.b1[0]);
+                rl = ns_head(pol_part(p), B, i, 1, p.actor.b1b[0]);
                 ap = rpo_head_dev::gauss_head_row(rm, rl, e, p.scale, p.base, p.box_lo, p.box_hi, 0, &logp);
             } else {
-                const float v = ns_head(p.part_pi, B, i, 0, p.actor.b1[0]);
+                const float v = ns_head(pol_part(p), B, i, 0, p.actor.b1[0]);
                 ap_det = p.scale * tanhf(v) + p.base;
                 const float eps_t = fmaxf(p.eps_end, p.eps_start - p.eps_decay * (float)t);
                 ap = explore_clip(ap_det, eps_t, e, p.box_lo, p.box_hi);
@@ -1128,6 +1148,7 @@ int to_args(const rpo_split_update* u, unsigned need, SplitArgs& a, CartConsts& 
     a.rollout_ctrl = u->rollout_ctrl; a.rollout_stats = u->rollout_stats; a.rollout_stats_cap = u->rollout_stats_cap;
     a.prep_step = u->prep_step; a.prep_beta1 = u->prep_beta1; a.prep_beta2 = u->prep_beta2; a.clock_out = u->clock_out;
     a.gradmax_reset = u->gradmax_reset; a.gradmax_reset2 = u->gradmax_reset2; a.updates_out = u->updates_out;
+    a.part_pol = u->part_pol;
     for (int j = 0; j < 3; ++j) { a.prep2_step[j] = u->prep2_step[j]; a.prep2_beta1[j] = u->prep2_beta1[j]; a.prep2_beta2[j] = u->prep2_beta2[j]; }
     return 0;
 }
@@ -1165,6 +1186,26 @@ int rpo_split_critic_fwd_b(const rpo_split_update* u, void* stream) {
     } else {
         if (!a.next_actions) return RPO_ERR_NULL;
         hipLaunchKernelGGL((split_critic_fwd_b_kernel<PendRow, 0>), grid, dim3(kNsThreads), 0, (hipStream_t)stream, a, c);
+    }
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_split_critic_fwd_b_pol(const rpo_split_update* u, void* stream) {
+    SplitArgs a; CartConsts c;
+    if (int e = to_args(u, (u && u->env == 0 ? 1u : 0u) | 4u | 32u, a, c)) return e;
+    const int K = a.twin ? 2 : 1;
+    if (u->shared_embedding) return RPO_ERR_ARG;                  // the critic step would change the policy's first layer
+    if (!a.batch_out || !a.ctrl || !a.part_pol || !a.x0_a || !a.h1_a) return RPO_ERR_NULL;
+    for (int k = 0; k < K; ++k)
+        if (!a.part_qn[k]) return RPO_ERR_NULL;
+    const dim3 grid(kNsGroups, (a.B + kRows - 1) / kRows, K + 1);
+    if (u->env == 0) {
+        if (!a.part_pi || (a.twin && !a.logp) || a.max_steps < 0) return RPO_ERR_NULL;
+        hipLaunchKernelGGL((split_critic_fwd_b_pol_kernel<CartRow, 1>), grid, dim3(kNsThreads), 0, (hipStream_t)stream, a, c);
+    } else {
+        if (!a.next_actions) return RPO_ERR_NULL;
+        hipLaunchKernelGGL((split_critic_fwd_b_pol_kernel<PendRow, 0>), grid, dim3(kNsThreads), 0, (hipStream_t)stream, a, c);
     }
     RPO_LAUNCH_CHECK();
     return 0;
@@ -1343,7 +1384,7 @@ extern "C" {
 int rpo_split_policy_a(const rpo_split_update* u, void* stream) {
     SplitArgs a; CartConsts c;
     if (int e = to_args(u, 32u, a, c)) return e;
-    if (!a.batch_out || !a.part_pi || !a.x0_a || !a.h1_a) return RPO_ERR_NULL;
+    if (!a.batch_out || (!a.part_pi && !a.part_pol) || !a.x0_a || !a.h1_a) return RPO_ERR_NULL;
     const dim3 grid(kNsGroups, (a.B + kRows - 1) / kRows);
     if (u->env == 0) hipLaunchKernelGGL(split_policy_a_kernel<CartRow>, grid, dim3(kNsThreads), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(split_policy_a_kernel<PendRow>, grid, dim3(kNsThreads), 0, (hipStream_t)stream, a);
@@ -1355,7 +1396,7 @@ int rpo_split_policy_b(const rpo_split_update* u, void* stream) {
     SplitArgs a; CartConsts c;
     if (int e = to_args(u, 32u | 2u, a, c)) return e;
     const int K = a.twin ? 2 : 1;
-    if (!a.batch_out || !a.ctrl || !a.part_pi || !a.nu || !a.noise_out || !a.actions || !a.g_act || !a.lag_partial) return RPO_ERR_NULL;
+    if (!a.batch_out || !a.ctrl || (!a.part_pi && !a.part_pol) || !a.nu || !a.noise_out || !a.actions || !a.g_act || !a.lag_partial) return RPO_ERR_NULL;
     if (a.twin ? (!a.raw || !a.logp) : !a.ap_det) return RPO_ERR_NULL;
     for (int k = 0; k < K; ++k)
         if (!a.part_q[k] || !a.x0[k] || !a.h1[k]) return RPO_ERR_NULL;

@@ -725,7 +725,7 @@ class _SplitUpdateStruct(ctypes.Structure):
          ("rollout_stats_cap", ctypes.c_int), ("prep_step", ctypes.c_void_p), ("prep_beta1", ctypes.c_float),
          ("prep_beta2", ctypes.c_float), ("clock_out", ctypes.c_void_p), ("gradmax_reset", ctypes.c_void_p),
          ("prep2_step", ctypes.c_void_p * 3), ("prep2_beta1", ctypes.c_float * 3), ("prep2_beta2", ctypes.c_float * 3),
-         ("gradmax_reset2", ctypes.c_void_p), ("updates_out", ctypes.c_void_p)])
+         ("gradmax_reset2", ctypes.c_void_p), ("updates_out", ctypes.c_void_p), ("part_pol", ctypes.c_void_p)])
 
 
 class _RolloutRiderStruct(ctypes.Structure):
@@ -768,7 +768,7 @@ class SplitUpdate(object):
     """Arguments of the column-split update stages (rpo_split_*), built once per trainer: every pointer refers to a static
     device buffer, so the struct is reused for every launch (and every hipGraph capture)."""
 
-    STAGES = ("critic_fwd_a", "critic_fwd_b", "pend_head_project", "critic_bwd_a", "critic_bwd_b", "policy_a", "policy_b",
+    STAGES = ("critic_fwd_a", "critic_fwd_b", "critic_fwd_b_pol", "pend_head_project", "critic_bwd_a", "critic_bwd_b", "policy_a", "policy_b",
               "policy_c", "policy_d", "policy_e")
 
     def __init__(self, env_kernels, descs, twin, batch, fields):

@@ -82,7 +82,7 @@ def test_struct_layouts_match_the_compiler(tmp_path):
 
 def test_split_update_stages_validate_arguments():
     lib = _lib.load()
-    for stage in ("critic_fwd_a", "critic_fwd_b", "pend_head_project", "critic_bwd_a", "critic_bwd_b", "policy_a",
+    for stage in ("critic_fwd_a", "critic_fwd_b", "critic_fwd_b_pol", "pend_head_project", "critic_bwd_a", "critic_bwd_b", "policy_a",
                   "policy_b", "policy_c", "policy_d", "policy_e"):
         assert getattr(lib, "rpo_split_" + stage)(None, None) == _lib.CONST["RPO_ERR_NULL"]
     for stage in ("critic_fwd_a_ride", "critic_fwd_b_ride", "critic_bwd_b_ride"):            # the riding rollout halves: both structs are required

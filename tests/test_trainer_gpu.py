@@ -662,3 +662,20 @@ def test_prepared_critic_step_equals_self_advancing(hip, algo, envname, monkeypa
     a.run_steps(1)
     torch.cuda.synchronize()
     assert int(a.agent.critic_optim.step_dev[0]) == 46
+
+
+@pytest.mark.parametrize("algo,envname", [("sac", "cart"), ("ddpg", "pendulum"), ("sac", "pendulum")])
+def test_policy_slabs_inside_the_critic_forward_launch(hip, algo, envname, monkeypatch):
+    """Policy iterations without a shared embedding: pol_a (the policy's hidden slabs on the batch states) runs as an extra
+    plane of fwd_b's launch (rpo_split_critic_fwd_b_pol, partials to part_pol) instead of behind the critic step -- it reads
+    the gathered batch and the actor, which the critic step does not touch.  Same bits as the separate launch."""
+    dev = torch.device("cuda")
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
+    a = _run(algo, envname, hip, dev, 45, 300, use_graph=True)
+    assert a.agent.flat.sizes[1] == 0
+    monkeypatch.setenv("RPO_POL_A_EARLY", "0")
+    b = _run(algo, envname, hip, dev, 45, 300, use_graph=True)
+    assert torch.equal(a.agent.flat.data, b.agent.flat.data) and torch.equal(a.agent.nju.weight, b.agent.nju.weight)
+    assert torch.equal(a.agent.actor_optim.exp_avg_sq, b.agent.actor_optim.exp_avg_sq)
+    assert torch.equal(a.buffer.rows, b.buffer.rows) and torch.equal(a.vec.internal, b.vec.internal)
+    assert float(a.last_losses["actor"]) == float(b.last_losses["actor"])
