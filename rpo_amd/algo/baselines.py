@@ -5,7 +5,7 @@ sac_lag.py) -- no equation solver, no projection; the constraints enter only thr
 
 They share the vectorised envs, the replay ring, the flat parameter buffer and the fused optimiser kernels with the RPO
 trainers ("cheap once the envs exist"); the networks run through the torch modules and autograd
-(the baselines are not part of the hot path that is tuned and benchmarked) and the loop runs eagerly.  Same constructor
+(the baselines are not part of the hot path that is tuned and benchmarked); the iterations are hipGraph-captured.  Same constructor
 arguments as the reference (ddpg_lag.py:13-21, sac_lag.py:12-20) plus the vectorisation keywords of the RPO trainers.
 """
 import torch
@@ -20,8 +20,13 @@ class _LagrangianBase(RPOTrainerBase):
     """process_action is the identity (ddpg_lag.py:72-75); both multipliers are stepped (ddpg_lag.py:196-198)."""
 
     def _setup_la(self, env, work_dir, name, logger, agent, hp, device, num_envs, seed, backend, shape):
-        # torch modules + autograd, eager loop: the baselines are comparison points, not part of the tuned hot path
-        self._setup(env, work_dir, name, logger, agent, hp, device, num_envs, seed, backend, use_graph=False, fused=False)
+        # torch modules + autograd: the baselines are comparison points, not part of the tuned hot path.  Their iterations
+        # are hipGraph-captured like the RPO trainers' (windows of RPO_GRAPH_CYCLE iterations) whenever nothing in them
+        # depends on host state: not with `shape` (the reward shaping indexes the ring by the host's position) and not with
+        # the automatic entropy tuning (alpha is read back to the host for the TD kernel)
+        graph_ok = not shape and not getattr(self, "automatic_entropy_tuning", False)
+        self._setup(env, work_dir, name, logger, agent, hp, device, num_envs, seed, backend,
+                    use_graph=None if graph_ok else False, fused=False)
         self.shape = shape
         A = self.kernels.action_dim
         self._noise_b = torch.zeros(self.batch_size, A, device=device)

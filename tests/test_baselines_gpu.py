@@ -82,3 +82,34 @@ def test_baselines_run_on_all_envs(algo, envname):
         assert bool(torch.isfinite(p).all())
     res = tr.eval()
     assert len(res) == 10 and np.isfinite(res).all()
+
+
+@pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "pendulum")])
+def test_baseline_graph_windows_equal_eager(algo, envname, monkeypatch):
+    """The baselines' iterations (torch modules + autograd + the fused optimiser / env kernels) are captured in hipGraphs
+    like the RPO trainers': windows of 8 iterations, single iterations for the ragged parts -- same bits as eager launches."""
+    from rpo_amd import gym_shim
+    from rpo_amd.algo import DDPG_LA, SAC_LA
+    from rpo_amd.env import CartSafeEnv, SpringPendulumEnv
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
+    out = []
+    for graph in ("1", "0"):
+        monkeypatch.setenv("RPO_GRAPH", graph)
+        torch.manual_seed(1)
+        env = gym_shim.TimeLimit((CartSafeEnv if envname == "cart" else SpringPendulumEnv)(device="cuda"), 200)
+        kw = dict(automatic_entropy_tuning=False, alpha=0.05) if algo == "sac" else {}
+        tr = (DDPG_LA if algo == "ddpg" else SAC_LA)(
+            env, "/tmp/rpo_la", name="la", logger=None, warmup=0, batch_size=64, capacity=128, embed_dim=64, hidden_dim=64,
+            policy_fre=2, max_epochs=100, init_nju=0.1, init_lamb=0.1, lr_dual=0.05, value_type="add", shared_param=True,
+            num_envs=32, seed=3, **kw)
+        tr.vec.reset()
+        tr.run_steps(70)
+        torch.cuda.synchronize()
+        out.append(tr)
+    a, b = out
+    assert a._graphs.enabled and any(k[0] == "cycle" and e["graph"] is not None for k, e in a._graphs.entries.items()
+                                     if isinstance(k, tuple))
+    assert not b._graphs.enabled
+    assert torch.equal(a.agent.flat.data, b.agent.flat.data) and torch.equal(a.buffer.rows, b.buffer.rows)
+    assert torch.equal(a.agent.nju.weight, b.agent.nju.weight) and torch.equal(a.agent.lamb.weight, b.agent.lamb.weight)
+    assert torch.equal(a.vec.internal, b.vec.internal) and int(a.vec.ctrl[0]) == 70
