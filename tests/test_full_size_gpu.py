@@ -95,7 +95,7 @@ def test_pendulum_sac_4096_lanes_properties():
     np.testing.assert_array_equal(st[:, S["viol_count"]], viol.sum(dim=1).cpu().numpy().astype(np.float32))
     np.testing.assert_allclose(st[:, S["reward_sum"]], cols["reward"][:, :, 0].sum(dim=1).cpu().numpy(), rtol=1e-5)
     np.testing.assert_array_equal(st[:, S["episodes"]], cols["done"][:, :, 0].sum(dim=1).cpu().numpy())
-    assert abs(g.viol_rate - float(viol.float().mean())) < 1e-9 and g.env_steps == T * n
+    assert abs(g.viol_rate - float(viol.double().mean())) < 1e-9 and g.env_steps == T * n
     # hipGraph windows == eager launches, at this size
     e, _ = run("pen_sac", n, use_graph=False)
     assert torch.equal(g.buffer.rows, e.buffer.rows) and torch.equal(g.agent.flat.data, e.agent.flat.data)
@@ -174,3 +174,35 @@ def test_evopf_ddpg_1024_lanes_properties():
         v.step(v.action)
     assert torch.equal(whole.internal, torch.cat([h.internal for h in halves]))
     assert torch.equal(whole.action, torch.cat([h.action for h in halves]))
+
+
+def test_cart_sac_4096_lanes_ridden_windows_equal_eager():
+    """Config 4's algorithm at its per-GPU size (CartSafe-v0 RPOSAC, 4096 lanes, scripts/cart_exp_sac.py): the hipGraph
+    windows in which the rollout rides on the critic update's launches (rpo_split_*_ride) leave the same ring, lanes and
+    parameters as eager launches in the serial order; the ring is a chain of the stepped transitions; the device-side
+    statistics equal what the ring rows give."""
+    from rpo_amd import ops
+    n = 4096
+    g, first = run("cart_sac", n, use_graph=True)
+    assert g._ride_ok(True) and any(len(k) == 4 and k[3] == "ride" and e["graph"] is not None
+                                    for k, e in g._graphs.entries.items() if isinstance(k, tuple))
+    e, _ = run("cart_sac", n, use_graph=False)
+    assert torch.equal(g.buffer.rows, e.buffer.rows) and torch.equal(g.agent.flat.data, e.agent.flat.data)
+    assert torch.equal(g.vec.internal, e.vec.internal) and torch.equal(g.agent.nju.weight, e.agent.nju.weight)
+    assert torch.equal(g.vec.ep_len, e.vec.ep_len) and torch.equal(g.vec.ep_count, e.vec.ep_count)
+    rows, cols = ring(g)
+    assert bool(torch.isfinite(rows).all()) and float(g.buffer.rows[T * n:].abs().max()) == 0.0
+    assert int(g.vec.ctrl[0]) == T and int(g._uctrl[0]) == T + 1
+
+    def reset_ok(s):                                             # cartpole.py reset: every state entry uniform in (-0.05, 0.05)
+        return (s.abs() <= 0.05 + 1e-6).all(dim=1)
+    assert check_chain(cols, reset_ok) > 0
+    # the equality holds for every stored action (Complete + Proj), violations == the constraint kernel on (state, action)
+    assert float(cols["eq_viol"].abs().max()) < 2e-5
+    S = ops.STAT
+    st = ops.reduce_stats(g.vec.stats[:T]).cpu().numpy()
+    viol = (torch.maximum(cols["ineq_viol"].max(dim=2).values, cols["eq_viol"].abs().max(dim=2).values) > 1e-3)
+    np.testing.assert_array_equal(st[:, S["viol_count"]], viol.sum(dim=1).cpu().numpy().astype(np.float32))
+    np.testing.assert_array_equal(st[:, S["episodes"]], cols["done"][:, :, 0].sum(dim=1).cpu().numpy())
+    np.testing.assert_allclose(st[:, S["reward_sum"]], cols["reward"][:, :, 0].sum(dim=1).cpu().numpy(), rtol=1e-6)
+    assert abs(g.viol_rate - float(viol.double().mean())) < 1e-9 and g.env_steps == T * n
