@@ -368,12 +368,19 @@ KERNEL_OF = {
 def pmc_traffic(kernel, lanes):
     """HBM bytes per launch from the committed rocprofv3 PMC collections (profiles/r0*_pmc_traffic.json; recipe and the
     gfx950 FETCH_SIZE correction are described there).  None when that (kernel, size) was not collected."""
+    base = kernel.split("<")[0]
     for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f)["kernels"][kernel][str(lanes)]["traffic_bytes"]
+                table = json.load(f)["kernels"]
         except (OSError, KeyError, ValueError):
             continue
+        for key, sizes in table.items():                        # (the tables key kernels with or without template arguments)
+            if key.split("<")[0] != base or str(lanes) not in sizes:
+                continue
+            if "Pend" in kernel and "Pend" not in key:          # (the counters were collected on the CartSafe workloads)
+                continue
+            return sizes[str(lanes)]["traffic_bytes"]
     return None
 
 

@@ -66,5 +66,25 @@ def probe_iter(iters=24):
     torch.cuda.synchronize()
 
 
+def probe_ride(periods=6):
+    """policy_fre periods of the cart-SAC bench trainer as its graph windows issue them (the rollout riding on the critic
+    update's launches), eagerly."""
+    from bench import make_trainer
+    tr = make_trainer(4096, torch.device("cuda"), 10 ** 9, capacity=64, workload="cart_sac")
+    tr._graphs.enabled = False
+    tr.vec.reset()
+    tr.run_steps(tr.policy_fre)
+    assert tr._ride_ok(True)
+    for _ in range(periods):
+        t0 = tr._t
+        tr._sync_uclock(rollout_pending=True)
+        tr._uclock_ok = True
+        tr._ridden_window(t0, tr.policy_fre)
+        for i in range(tr.policy_fre):
+            tr._advance_host(t0 + i + 1)
+        tr._updates += tr.policy_fre
+    torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
-    {"step": probe_step, "mlp": probe_mlp, "iter": probe_iter}[sys.argv[1] if len(sys.argv) > 1 else "step"]()
+    {"step": probe_step, "mlp": probe_mlp, "iter": probe_iter, "ride": probe_ride}[sys.argv[1] if len(sys.argv) > 1 else "step"]()

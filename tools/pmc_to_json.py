@@ -16,6 +16,7 @@ UNITS = [  # (kernel substring, threads per unit or explicit map)
     ("cartsafe_step_kernel", lambda g: g if g <= 4096 else 1 << 20),
     ("cartsafe_act_project_kernel", lambda g: g if g <= 4096 else 1 << 20),
     ("replay_sample_gather_kernel", lambda g: 256 if g <= 4096 else 1 << 20),
+    ("_ride_kernel", lambda g: 4096),                           # update stage at batch 256 + riders for 4096 lanes
 ]
 
 
@@ -46,6 +47,8 @@ def main(out_path, files):
                 if sub in name:
                     units = fn(grid)
             wkb = write[(name, grid)][1]
+            if str(units) in kernels.get(short(name), {}):      # earlier files win (cart-DDPG iterations before the cart-SAC ride probe)
+                continue
             kernels.setdefault(short(name), {})[str(units)] = {
                 "grid_threads": grid, "launches": n, "fetch_kb_raw": round(fkb, 1), "write_kb": round(wkb, 1),
                 "traffic_bytes": int(round((2 * fkb + wkb) * 1024))}
