@@ -417,7 +417,10 @@ __device__ __forceinline__ float ns_dw0_tile(const Mlp& net, float* gW0, const f
                                              int blk, float* smem) {
     constexpr int EIN = 128, H = 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    const int jt = blk / (EIN / 16), et = blk - jt * (EIN / 16);
+    // block -> tile so that block b (XCD b % 8) works on hidden columns [32 (b % 8), +32): the two column tiles that share
+    // h1's 128-byte lines; an XCD's L2 then fetches 1/8 of h1 (32 KB) + all of x0 (131 KB) instead of all of h1 + 1/8 of x0
+    const int xq = blk & 7, yq = blk >> 3, jt = 2 * xq + (yq >> 3), et = yq & 7;
+    static_assert(EIN / 16 == 8 && H / 16 == 16, "tile decode");
     const int j = jt * 16 + li, e = et * 16 + li;
     const int nk = (B + 3) / 4, ks_lo = (nk * wave) / 4, ks_hi = (nk * (wave + 1)) / 4, last = B - 1;
     // everything is requested up front, straight-line (rows past the wave's range are clamped and zeroed below)
@@ -544,7 +547,9 @@ __device__ __forceinline__ float ns_weight_role(const Mlp& net, const MlpGrad& g
 
 // ---- bwd_a: TD target + Huber (from the slab partials) -> dh = dLoss/dQ * W1 * 1[h1 > 0] (on the fly) -> dx0 of one
 //      (critic k, row tile, 16 first-layer columns); the column-group-0 workgroup of a tile leaves dLoss/dQ and the loss share.
-//      blocks (critic, row tile, column group), 256 threads.
+//      blocks (critic, column group, row tile), 256 threads -- the ROW TILE is the fastest index here: block b lands on XCD
+//      b % 8, and what the 8 column-group blocks of a tile share is the tile's h1 rows (16 KB each, the launch's largest
+//      operand): with the tile fastest an XCD's L2 fetches the rows of its own tiles once instead of every XCD fetching all.
 constexpr int kBwdASmem = kRows * (256 + 4) + 16 + 4 * 16 * 16;
 
 template <class L>
@@ -553,7 +558,7 @@ __device__ __forceinline__ void bwd_a_role(const SplitArgs& p, float* smem, int 
     const int T = (p.B + kRows - 1) / kRows, B = p.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     {
-        const int k = b / (T * kNsGroups), rem = b - k * T * kNsGroups, tile = rem / kNsGroups, g = rem - tile * kNsGroups;
+        const int k = b / (T * kNsGroups), rem = b - k * T * kNsGroups, g = rem / T, tile = rem - g * T;   // row tile fastest: see bwd_a
         const int row0 = tile * kRows;
         const Mlp& net = p.critic[k];
         float* dh_s = smem;                                       // [16][LDH]
@@ -881,7 +886,7 @@ __device__ __forceinline__ float ns_policy_dq(const SplitArgs& p, int k, int i, 
 }
 
 // ---- pol_c: the critics' rows pass inside the actor loss: dx0 column groups (no parameter gradients of their own) and,
-//      per group, its share of d(-Q)/d action = dx0 Wa.  blocks (critic, row tile, column group), 256 threads.
+//      per group, its share of d(-Q)/d action = dx0 Wa.  blocks (critic, column group, row tile), 256 threads (as bwd_a).
 __global__ __launch_bounds__(kThreads) void split_policy_c_kernel(SplitArgs p) {
     constexpr int EIN = 128, H = 256, LDH = H + 4;
     __shared__ __attribute__((aligned(16))) float dh_s[kRows * LDH];
@@ -890,7 +895,7 @@ __global__ __launch_bounds__(kThreads) void split_policy_c_kernel(SplitArgs p) {
     const int T = (p.B + kRows - 1) / kRows, B = p.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     const int b = blockIdx.x;
-    const int k = b / (T * kNsGroups), rem = b - k * T * kNsGroups, tile = rem / kNsGroups, g = rem - tile * kNsGroups;
+    const int k = b / (T * kNsGroups), rem = b - k * T * kNsGroups, g = rem / T, tile = rem - g * T;   // row tile fastest: see bwd_a
     const int row0 = tile * kRows;
     const Mlp& net = p.critic[k];
     const int jw = wave * (H / 4), e = g * 16 + li;
