@@ -706,7 +706,9 @@ def roofline(clinic, workload):
     d = in_iter[dom]
     kernel = KERNEL_OF.get(dom.split("[")[0], dom)
     r = {"bound": d["bound"], "kernel": kernel, "entry_point": dom, "achieved": d["rate"], "peak": d["peak"],
-         "unit": d["unit"], "frac": d["frac"], "traffic": pmc_traffic(kernel, d["n"]), "launch_us": d["us"],
+         "unit": d["unit"], "frac": d["frac"],
+         # (the PMC counters were collected on the CartSafe workloads: cart-DDPG iterations, cart-SAC ridden periods)
+         "traffic": pmc_traffic(kernel, d["n"]) if workload.startswith("cart") else None, "launch_us": d["us"],
          "units_per_launch": d["n"],
          "algorithmic_%s_per_launch" % ("bytes" if d["bound"] == "hbm" else "flops"): d["work"],
          "note": "dominant launch of the iteration at the bench size (latency-bound: %d units per launch); "
