@@ -97,7 +97,7 @@ extern "C" {
 #define RPO_GRADMAX_LEN 512    /* 16 slots 128 bytes apart (slot j at [32 j]), a producing workgroup maxes into slot
                                   (block index) % 16 and the norm is the maximum over the slots -- several hundred atomics on
                                   ONE cache line are served one after the other (2.9 us behind a 448-workgroup backward);
-                                  rpo_absmax writes slot 0; rpo_adam_step* read all slots and zero them (reset_gradmax) */
+                                  rpo_absmax_slots spreads likewise (rpo_absmax writes word 0); rpo_adam_step* read all slots and zero them (reset_gradmax) */
 #define RPO_ADAM_STATE_LEN 544 /* int32 words of an optimiser state buffer (`step_dev` of rpo_adam_step*) */
 #define RPO_STATS_SUB 16    /* sub-rows per statistics row: workgroup b adds into sub-row b % 16; the reader sums them */
 #define RPO_STATS_LEN 16
@@ -290,6 +290,9 @@ int rpo_td_huber(int n, const float* q1, const float* q2, const float* qn1, cons
 /* max_out[0] = max(max_out[0], max_i |x_i|) -- the "inf" norm of clip_grad_norm_ (rpo_ddpg.py:180,193).
  * max_out must hold a non-negative float (0 before the first call of an update). */
 int rpo_absmax(long long n, const float* x, float* max_out, void* stream);
+/* The same into a gradmax buffer [RPO_GRADMAX_LEN]: workgroup b maxes into slot b % 16 (the norm is the maximum over the
+ * slots, as rpo_adam_step* read it) -- a wide launch does not queue its atomics on one word. */
+int rpo_absmax_slots(long long n, const float* x, float* gradmax, void* stream);
 
 /* clip_grad_norm_(inf) + torch.optim.Adam step (+ optional DualAdam clamp, model/dual.py:37-45) (+ optional Polyak
  * target update, agent/ddpg_pa.py:77-86), one pass over the flat buffer:

@@ -649,12 +649,13 @@ class RPOTrainerBase(object):
             eps_in = self._noise_b.view(-1)
         buf = self.buffer
         su.set(idx_in=idx_in, eps_in=eps_in, rows=buf.rows, cap_steps=buf.capacity, n_envs=buf.n_envs)   # (tests swap the ring)
-        # "prepared" critic step (single GPU, in-backward inf-norm, the caller said whether a policy step follows): bwd_b
+        # "prepared" critic step (the caller said whether a policy step follows): bwd_b
         # advances the optimiser's step counter (and the update clock when the critic step ends the iteration), the NEXT
         # fwd_a zeroes gradmax -- the Adam launch in between does no bookkeeping and counts no workgroups in
         opt = self.agent.critic_optim
         actor_step, self._iter_actor_step = self._iter_actor_step, None
-        prep = actor_step is not None and not self.dist.on and _env_int("RPO_PREPARED_ADAM", 1) and self._critic_gradmax() is not None
+        # (data-parallel runs too: the inf-norm then comes from rpo_absmax_slots behind the all-reduce, into the same slots)
+        prep = actor_step is not None and bool(_env_int("RPO_PREPARED_ADAM", 1))
         self._critic_prepared = bool(prep)
         clock_out = self._clock(not actor_step) if prep else None
         # several updates per vector step: the last stage of this update that reads ctrl[RPO_CTRL_UPDATES] advances it for

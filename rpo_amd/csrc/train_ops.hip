@@ -43,7 +43,7 @@ __global__ __launch_bounds__(RPO_BLOCK) void td_huber_kernel(
 
 // ------------------------------------------------------------------------------------------------- inf-norm
 __global__ __launch_bounds__(RPO_BLOCK) void absmax_kernel(long long n, const float* __restrict__ x,
-                                                           float* __restrict__ max_out) {
+                                                           float* __restrict__ max_out, int slotted) {
     __shared__ float red[RPO_BLOCK / RPO_WAVE];
     float m = 0.0f;
     const long long n4 = n / 4;
@@ -60,7 +60,9 @@ __global__ __launch_bounds__(RPO_BLOCK) void absmax_kernel(long long n, const fl
     if (threadIdx.x == 0) {
         for (int w = 1; w < RPO_BLOCK / RPO_WAVE; ++w) m = fmaxf(m, red[w]);
         m = fmaxf(m, red[0]);
-        if (m > 0.0f) rpo_atomic_max_nonneg(max_out, m);
+        // slotted: a gradmax buffer (RPO_GRADMAX_LEN) -- the workgroups spread over its 16 slots instead of queueing on one word
+        float* dst = slotted ? max_out + (blockIdx.x % RPO_GRADMAX_SLOTS) * (RPO_GRADMAX_LEN / RPO_GRADMAX_SLOTS) : max_out;
+        if (m > 0.0f) rpo_atomic_max_nonneg(dst, m);
     }
 }
 
@@ -241,7 +243,17 @@ int rpo_absmax(long long n, const float* x, float* max_out, void* stream) {
     if (!x || !max_out) return RPO_ERR_NULL;
     if ((reinterpret_cast<uintptr_t>(x) & 15u) != 0) return RPO_ERR_ARG;
     hipLaunchKernelGGL(absmax_kernel, dim3(rpo_grid_for(n / 4 + 1)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, x,
-                       max_out);
+                       max_out, 0);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_absmax_slots(long long n, const float* x, float* gradmax, void* stream) {
+    if (n <= 0) return RPO_ERR_ARG;
+    if (!x || !gradmax) return RPO_ERR_NULL;
+    if ((reinterpret_cast<uintptr_t>(x) & 15u) != 0) return RPO_ERR_ARG;
+    hipLaunchKernelGGL(absmax_kernel, dim3(rpo_grid_for(n / 4 + 1)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, x,
+                       gradmax, 1);
     RPO_LAUNCH_CHECK();
     return 0;
 }

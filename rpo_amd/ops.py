@@ -112,7 +112,11 @@ def td_huber(q1, q2, qn1, qn2, logp, alpha, reward, done, gamma, loss_out, grad_
 
 
 def absmax(x, max_out):
-    check(_lib.load().rpo_absmax(x.numel(), _p(x), _p(max_out), _stream()), "rpo_absmax")
+    """max |x| into max_out[0], or -- when max_out is a gradmax buffer (RPO_GRADMAX_LEN) -- spread over its slots."""
+    if max_out.numel() >= CONST["RPO_GRADMAX_LEN"]:
+        check(_lib.load().rpo_absmax_slots(x.numel(), _p(x), _p(max_out), _stream()), "rpo_absmax_slots")
+    else:
+        check(_lib.load().rpo_absmax(x.numel(), _p(x), _p(max_out), _stream()), "rpo_absmax")
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
