@@ -66,6 +66,13 @@ __device__ __forceinline__ float rpo_normal(uint32_t a, uint32_t b) {
 // (and matches the unfused numpy / torch-CPU arithmetic of the reference).
 #define RPO_FP_STRICT _Pragma("clang fp contract(off)")
 
+// take_action's exploration (agent/ddpg_pa.py:108-110): clip(ap + eps_t * noise, lo, hi), unfused like the
+// RPO_NOISE_PHILOX / RPO_NOISE_EXPLICIT branches of the *_explore_project functions
+__device__ __forceinline__ float rpo_explore_clip(float ap, float eps_t, float noise, float lo, float hi) {
+    RPO_FP_STRICT
+    return fminf(fmaxf(ap + eps_t * noise, lo), hi);
+}
+
 __device__ __forceinline__ float rpo_wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, RPO_WAVE);

@@ -55,6 +55,16 @@ __global__ __launch_bounds__(kFwdThreads) void rollout_kernel(RolloutArgs<ENV> p
     RpoEpisode ep{0, 0.0f, 0u};                                  // requested before the MLP: needed only at the very end
     if (tid < kLanes && row0 + tid < n) ep = ENV::episode(p.step, row0 + tid);
     ENV::stage_obs(p.step, row0, kLanes, lds.in_s, kInS);
+    // The lane's N(0,1) draw (exploration noise / rsample) depends on nothing the MLP produces: ~160 dependent VALU
+    // instructions that would otherwise head the per-lane chain behind the MLP run in the shadow of its weight loads.
+    float draw = 0.0f;
+    const bool philox_noise = !p.gauss && p.act.noise_mode == RPO_NOISE_PHILOX;
+    if (tid < kLanes && row0 + tid < n && (p.gauss || philox_noise)) {
+        const rpo_u4 u = p.gauss ? rpo_philox(p.act.seed, p.act.env_id_base + (uint32_t)(row0 + tid), (uint32_t)t, RPO_STREAM_POLICY,
+                                              (uint32_t)p.step.ctrl[RPO_CTRL_UPDATES])
+                                 : rpo_philox(p.act.seed, p.act.env_id_base + (uint32_t)(row0 + tid), (uint32_t)t, RPO_STREAM_ACT);
+        draw = rpo_normal(u.x, u.y);
+    }
     mlp_tile_forward<EIN, H, RT, Lds>(p.actor, lds, row0, n, nullptr, nullptr, p.gauss ? 0 : 1, p.scale, p.base);
 
     float st[kStats];
@@ -68,13 +78,15 @@ __global__ __launch_bounds__(kFwdThreads) void rollout_kernel(RolloutArgs<ENV> p
         if (p.gauss) {
             // rsample of the squashed Gaussian (model/policy.py:58-66) with the Philox stream of the policy draw,
             // then the box clip of take_action (agent/sac_pa.py:111); p.act.noise_mode is RPO_NOISE_NONE
-            const rpo_u4 u = rpo_philox(p.act.seed, p.act.env_id_base + (uint32_t)i, (uint32_t)t, RPO_STREAM_POLICY,
-                                        (uint32_t)p.step.ctrl[RPO_CTRL_UPDATES]);
-            ap = rpo_head_dev::gauss_head_row(ap, lds.out[tid * 2 + 1], rpo_normal(u.x, u.y), p.scale, p.base,
-                                              p.act.box_lo, p.act.box_hi, 0, nullptr);
+            ap = rpo_head_dev::gauss_head_row(ap, lds.out[tid * 2 + 1], draw, p.scale, p.base, p.act.box_lo, p.act.box_hi, 0, nullptr);
         }
         int k;
-        const float2 a = ENV::project(p.act, c, lds.in_s + tid * kInS, i, ap, eps_t, t, k);
+        typename ENV::ActArgs act = p.act;
+        if (philox_noise) {                                      // the draw above, applied with the arithmetic of *_explore_project
+            ap = rpo_explore_clip(ap, eps_t, draw, p.act.box_lo, p.act.box_hi);
+            act.noise_mode = RPO_NOISE_NONE;
+        }
+        const float2 a = ENV::project(act, c, lds.in_s + tid * kInS, i, ap, eps_t, t, k);
         iters_f = (float)k;
         reinterpret_cast<float2*>(p.act.action)[i] = a;
         const long long ring_base = p.step.rows ? (t % p.step.cap_steps) * (long long)n : 0;
