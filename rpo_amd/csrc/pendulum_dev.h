@@ -212,7 +212,7 @@ __device__ __forceinline__ void project_batchref_body(int n, const float* o, flo
                                                       float corr_eps, float corr_momentum, float* lds) {
     RPO_FP_STRICT
     float* dgp_s = lds;
-    int* flag = reinterpret_cast<int*>(lds + n);
+    int* flag = reinterpret_cast<int*>(lds + n);                // two flags, used alternately: iteration k raises flag[k & 1]
     const int i = threadIdx.x / LPS, q = threadIdx.x % LPS;
     const bool live = i < n;
     Eq e = {0.0f, 1.0f, 1.0f, 0.0f};
@@ -222,18 +222,19 @@ __device__ __forceinline__ void project_batchref_body(int n, const float* o, flo
         ax = ap_i;
         ay = (e.b - ax * e.C_p) * e.C_o_inv;                       // complete_partial :256-262
     }
+    if (threadIdx.x < 2) flag[threadIdx.x] = 0;
+    __syncthreads();
     int k = 0;
     for (; k < max_steps; ++k) {
-        if (threadIdx.x == 0) *flag = 0;
-        __syncthreads();
         if (live && q == 0) {
             const float h = e.b - (ax * e.C_p + ay * e.C_o);
             const float g = ax * ax + ay * ay - kMaxSum;
-            if (fabsf(h) > corr_eps || g > corr_eps) atomicOr(flag, 1);
+            if (fabsf(h) > corr_eps || g > corr_eps) atomicOr(flag + (k & 1), 1);
             dgp_s[i] = 2.0f * ax - 2.0f * ay * (e.C_o_inv * e.C_p);                  // :334-335
         }
+        if (threadIdx.x == 0) flag[(k + 1) & 1] = 0;             // nobody reads it before the next barrier pair
         __syncthreads();
-        if (k > 0 && *flag == 0) break;                            // batch-global stop test, rpo_ddpg.py:271-272
+        if (k > 0 && flag[k & 1] == 0) break;                      // batch-global stop test, rpo_ddpg.py:271-272
         {
             const float bgp = kMaxSum - (e.b * e.C_o_inv) * (2.0f * ay);             // :336
             float g0 = 0.0f, g1 = 0.0f;
@@ -256,7 +257,7 @@ __device__ __forceinline__ void project_batchref_body(int n, const float* o, flo
             ax -= sx; ay -= sy;
             ox = sx; oy = sy;
         }
-        __syncthreads();
+        __syncthreads();                                           // every lane has read dgp_s before the next round rewrites it
     }
     if (live && q == 0) reinterpret_cast<float2*>(action)[i] = make_float2(ax, ay);
     if (threadIdx.x == 0 && iters_out) *iters_out = k;
