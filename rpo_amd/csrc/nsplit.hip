@@ -985,7 +985,7 @@ __global__ __launch_bounds__(kThreads) void split_policy_d_kernel(SplitArgs p, C
     const Mlp& net = p.actor;
     const int b = blockIdx.x;
     {
-        const int tile = b / kNsGroups, g = b - tile * kNsGroups, row0 = tile * kRows;
+        const int T = (B + kRows - 1) / kRows, g = b / T, tile = b - g * T, row0 = tile * kRows;   // row tile fastest: see bwd_a
         float* dh_s = smem;
         float* do_s = smem + kRows * LDH;                          // [16][2]
         float* wpart = do_s + 32;
