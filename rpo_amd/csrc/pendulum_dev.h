@@ -237,18 +237,25 @@ __device__ __forceinline__ void project_batchref_body(int n, const float* o, flo
         if (k > 0 && flag[k & 1] == 0) break;                      // batch-global stop test, rpo_ddpg.py:271-272
         {
             const float bgp = kMaxSum - (e.b * e.C_o_inv) * (2.0f * ay);             // :336
-            float g0 = 0.0f, g1 = 0.0f;
-            int j = q;
-            for (; j + LPS < n; j += 2 * LPS) {                    // [B,1] @ [1,B] coupling, :337-339
-                const float d0 = dgp_s[j], d1 = dgp_s[j + LPS];
-                g0 += (ax * d0 - bgp > 0.0f) ? d0 : 0.0f;
-                g1 += (ax * d1 - bgp > 0.0f) ? d1 : 0.0f;
+            // [B,1] @ [1,B] coupling, :337-339.  Lane q of a sample sums the contiguous quarter j in [q c, (q + 1) c), c = the
+            // chunk length rounded to 4: one 16-byte LDS read feeds four terms (the strided form read every term on its own,
+            // and this loop is instruction-issue-bound on ONE compute unit), four accumulators added pairwise.
+            const int chunk = ((n + LPS - 1) / LPS + 3) & ~3, j0 = q * chunk;
+            const int j1 = (j0 + chunk < n) ? j0 + chunk : n;
+            float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
+            int j = j0;
+            for (; j + 4 <= j1; j += 4) {
+                const float4 d = *reinterpret_cast<const float4*>(dgp_s + j);
+                g0 += (ax * d.x - bgp > 0.0f) ? d.x : 0.0f;
+                g1 += (ax * d.y - bgp > 0.0f) ? d.y : 0.0f;
+                g2 += (ax * d.z - bgp > 0.0f) ? d.z : 0.0f;
+                g3 += (ax * d.w - bgp > 0.0f) ? d.w : 0.0f;
             }
-            if (j < n) {
+            for (; j < j1; ++j) {
                 const float d0 = dgp_s[j];
                 g0 += (ax * d0 - bgp > 0.0f) ? d0 : 0.0f;
             }
-            float grad = g0 + g1;
+            float grad = (g0 + g1) + (g2 + g3);
 #pragma unroll
             for (int off = 1; off < LPS; off <<= 1) grad += __shfl_xor(grad, off, 64);    // same value in the LPS lanes
             const float gy = -(grad * e.C_p) * e.C_o_inv;                            // :342
