@@ -637,6 +637,33 @@ class RPOTrainerBase(object):
         f = self.fused
         return f.buf("actor.lag", 2), f.buf("actor.parts", (B + 15) // 16, 8), pi_logp
 
+    def _set_hand_overs(self, su, actor_step):
+        """What this critic update does on behalf of other launches, and what it leaves to later ones (every
+        hand-over relies on stream order only -- a later launch starts after every workgroup of an earlier one has finished):
+
+          fwd_a   advances the step counter of the rollout launched right before (`_clock_pending`: defer_clock) and zeroes
+                  the gradmax buffers the previous update's prepared Adam launches consumed (`_gradmax_stale`)
+          bwd_b   prepares the critic's Adam launch (step counter, bias corrections), advances the update clock when no
+                  policy step follows, and the update sub-index when several updates share a vector step
+
+        ``actor_step``: whether a policy step follows this critic update (None: the caller did not say -> no hand-overs,
+        the optimiser launches keep their own bookkeeping)."""
+        opt = self.agent.critic_optim
+        # (data-parallel runs too: the inf-norm then comes from rpo_absmax_slots behind the all-reduce, into the same slots)
+        prep = actor_step is not None and bool(_env_int("RPO_PREPARED_ADAM", 1))
+        self._critic_prepared = bool(prep)
+        bump_updates, self._bump_updates_now = self._bump_updates_now, False
+        self._updates_out = self._uctrl if bump_updates else None          # (pol_e does it behind a policy step)
+        pending, self._clock_pending = self._clock_pending, False
+        su.set(prep_step=opt.step_dev if prep else None, prep_beta1=opt.betas[0], prep_beta2=opt.betas[1],
+               clock_out=self._clock(not actor_step) if prep else None,
+               updates_out=self._updates_out if not actor_step else None,
+               gradmax_reset=opt.gradmax if self._gradmax_stale else None,
+               gradmax_reset2=self.agent.actor_optim.gradmax if self._actor_gradmax_stale else None,
+               rollout_ctrl=self.vec.ctrl if pending else None, rollout_stats=self.vec.stats if pending else None,
+               rollout_stats_cap=self.vec.stats.shape[0] if pending else 0)
+        self._gradmax_stale, self._actor_gradmax_stale = bool(prep), False
+
     def _critic_update_split(self, su):
         """Critic update through the column-split stages: fwd_a | (pend: head + batch projection) | fwd_b | bwd_a | bwd_b."""
         inject = self._idx_inject is not None                   # tests replay the reference's draws
@@ -649,27 +676,8 @@ class RPOTrainerBase(object):
             eps_in = self._noise_b.view(-1)
         buf = self.buffer
         su.set(idx_in=idx_in, eps_in=eps_in, rows=buf.rows, cap_steps=buf.capacity, n_envs=buf.n_envs)   # (tests swap the ring)
-        # "prepared" critic step (the caller said whether a policy step follows): bwd_b
-        # advances the optimiser's step counter (and the update clock when the critic step ends the iteration), the NEXT
-        # fwd_a zeroes gradmax -- the Adam launch in between does no bookkeeping and counts no workgroups in
-        opt = self.agent.critic_optim
         actor_step, self._iter_actor_step = self._iter_actor_step, None
-        # (data-parallel runs too: the inf-norm then comes from rpo_absmax_slots behind the all-reduce, into the same slots)
-        prep = actor_step is not None and bool(_env_int("RPO_PREPARED_ADAM", 1))
-        self._critic_prepared = bool(prep)
-        clock_out = self._clock(not actor_step) if prep else None
-        # several updates per vector step: the last stage of this update that reads ctrl[RPO_CTRL_UPDATES] advances it for
-        # the next one (bwd_b, or pol_e behind a policy step) when the caller asked for it (`_extra_body`, `_segments`)
-        bump_updates, self._bump_updates_now = self._bump_updates_now, False
-        self._updates_out = self._uctrl if bump_updates else None
-        su.set(updates_out=self._updates_out if not actor_step else None)
-        su.set(prep_step=opt.step_dev if prep else None, prep_beta1=opt.betas[0], prep_beta2=opt.betas[1],
-               clock_out=clock_out, gradmax_reset=opt.gradmax if self._gradmax_stale else None,
-               gradmax_reset2=self.agent.actor_optim.gradmax if self._actor_gradmax_stale else None)
-        self._gradmax_stale, self._actor_gradmax_stale = bool(prep), False
-        pending, self._clock_pending = self._clock_pending, False   # a rollout left its clock to this update's first launch
-        su.set(rollout_ctrl=self.vec.ctrl if pending else None, rollout_stats=self.vec.stats if pending else None,
-               rollout_stats_cap=self.vec.stats.shape[0] if pending else 0)
+        self._set_hand_overs(su, actor_step)
         ride = self._ride                                       # ridden windows: the next vector step rides along
         if ride is not None:
             n, cut = self.vec.internal.shape[0], self._ride_cut
