@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Soak run: many iterations of a bench workload through the graph windows, then consistency checks of every device-side
+counter the cross-launch hand-overs maintain (rollout clock, update clock, optimiser step counters, arrival words at rest,
+gradmax slots) and of the parameters / statistics.    python tools/soak.py [workload] [steps]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("RPO_VERBOSE", "0")
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+
+def main():
+    workload = sys.argv[1] if len(sys.argv) > 1 else "cart_ddpg"
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
+    dev = torch.device("cuda")
+    n = bench.envs_per_gpu(workload)
+    tr = bench.make_trainer(n, dev, 10 ** 9, workload=workload)
+    tr.vec.reset()
+    tr.run_steps(steps)
+    tr._harvest(final=True)
+    torch.cuda.synchronize()
+    ag = tr.agent
+    T = hip_T = int(tr.vec.ctrl[0])
+    assert T == steps == tr._t, (T, steps, tr._t)
+    if tr._uctrl is not tr.vec.ctrl:
+        assert int(tr._uctrl[0]) == steps + 1, int(tr._uctrl[0])
+    assert int(tr.vec.ctrl[1]) == 0 and int(tr.vec.ctrl[16:].abs().max()) == 0          # arrival counters at rest
+    assert int(ag.critic_optim.step_dev[0]) == steps - tr.warmup + (1 if tr.warmup else 0) or int(ag.critic_optim.step_dev[0]) == steps
+    assert int(ag.actor_optim.step_dev[0]) == steps // tr.policy_fre
+    for opt in (ag.critic_optim, ag.actor_optim):
+        assert int(opt.step_dev[2]) == 0 and int(opt.step_dev[32:].abs().max()) == 0
+    for p in (ag.flat.data, ag.nju.weight, ag.critic_target_flat):
+        assert bool(torch.isfinite(p).all())
+    assert tr.env_steps == steps * n and 0.0 <= tr.viol_rate <= 1.0
+    print("%s: %d steps ok; violation rate %.5f, ride %s, prepared Adam, |params| max %.3f" % (
+        workload, steps, tr.viol_rate, bool(getattr(tr, "_ride_ok", lambda d: False)(True)), float(ag.flat.data.abs().max())))
+
+
+if __name__ == "__main__":
+    main()
