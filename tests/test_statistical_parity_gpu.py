@@ -1,7 +1,8 @@
 """Statistical parity with the reference's CPU runs (north_star: returns and constraint-violation rate).
 
 tests/golden/training_stats_*.npz hold the statistics of 3000-iteration training runs of the unmodified reference
-(scripts/cart_exp.py: 96 seeds; scripts/pen_exp_sac.py: 24 seeds; tests/golden/make_golden.py stats).  The same runs are
+(scripts/cart_exp.py: 384 seeds; scripts/pen_exp_sac.py: 24 seeds; scripts/cart_exp_sac.py: 96 seeds;
+tests/golden/make_golden.py stats).  The same runs are
 repeated here with the shipped trainers at num_envs = 1 -- the reference's cadence, step for step -- on the HIP kernels,
 on TWICE as many seeds (GPU runs are cheap).  Random streams differ (Philox vs numpy/torch global generators) and
 trajectories are chaotic, so the comparison is between seed-averaged statistics: violation rate = fraction of env steps
@@ -28,8 +29,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.timeout(1500, method="thread")
-@pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "pendulum")])
-def test_training_statistics_match_reference(golden, algo, envname):
+# (algo, env, largest standard error of the violation-rate difference the case must reach).  cart-RPOSAC (config 4's
+# algorithm, scripts/cart_exp_sac.py, 96 reference seeds) has a seed-to-seed spread of 7.4e-3 -- more than twice
+# cart-RPODDPG's -- so its comparison resolves 1e-3 at one sigma only; it is a consistency check at that resolution.
+@pytest.mark.parametrize("algo,envname,se_max", [("ddpg", "cart", 5e-4), ("sac", "pendulum", 5e-4), ("sac", "cart", 1e-3)])
+def test_training_statistics_match_reference(golden, algo, envname, se_max):
     from rpo_amd import ops
     from rpo_amd.utils.logger import Logger
     g = golden("training_stats_%s_%s" % (algo, envname))
@@ -66,7 +70,7 @@ def test_training_statistics_match_reference(golden, algo, envname):
         json.dump(out, f, indent=1)
     print(json.dumps(out))
     d_viol = abs(got[:, 1].mean() - ref[:, 1].mean())
-    assert se(1) <= 5e-4, se(1)                                   # the comparison resolves 1e-3 at two sigma
+    assert se(1) <= se_max, se(1)                                 # 5e-4: the comparison resolves 1e-3 at two sigma
     assert d_viol <= 1e-3 + 2 * se(1), (d_viol, se(1))
     d_ineq = abs(got[:, 2].mean() - ref[:, 2].mean())
     assert d_ineq <= 0.15 * ref[:, 2].mean() + 2 * se(2) + 1e-5, (d_ineq, se(2))
