@@ -463,7 +463,7 @@ def gen_training_stats(steps=3000, n_seeds=None, workers=8):
     ~3.4e-4: together with a larger number of GPU runs the comparison resolves the north_star's 1e-3 at two sigma.
     SpringPendulum-RPOSAC violates ~5e-4 of the steps with a spread of ~5e-4: 24 seeds are ample."""
     import multiprocessing as mp
-    plan = n_seeds or {("ddpg", "cart"): 384, ("sac", "pendulum"): 24, ("sac", "cart"): 96}
+    plan = n_seeds or {("ddpg", "cart"): 384, ("sac", "pendulum"): 24, ("sac", "cart"): 96, ("ddpg", "pendulum"): 48}
     for (algo, envname), count in plan.items():
         jobs = [(algo, envname, seed, steps) for seed in range(count)]
         with mp.get_context("fork").Pool(workers) as pool:
