@@ -66,6 +66,26 @@ __device__ __forceinline__ float rpo_normal(uint32_t a, uint32_t b) {
 // (and matches the unfused numpy / torch-CPU arithmetic of the reference).
 #define RPO_FP_STRICT _Pragma("clang fp contract(off)")
 
+// Sum over the 16 lanes of a DPP row, valid in the row's lane 0 (lane & 15 == 0), with the association of the xor
+// butterfly v += shfl_xor(v, 1 | 2 | 4 | 8) at that lane -- ((v0 + v1) + (v2 + v3)) per quad, then (Q0 + Q1) + (Q2 + Q3) --
+// so it is a bitwise drop-in wherever only lane 0 of a row keeps the result.  __shfl_xor is a ds_bpermute + s_waitcnt per
+// step (32 of them in series cost 1.7 us at the end of every MLP slab); these are four VALU instructions.
+template <int CTRL>
+__device__ __forceinline__ float rpo_dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float rpo_quad_sum(float v) {        // every lane of the quad ends with the quad's sum
+    v += rpo_dpp_mov<0xB1>(v);                                   // quad_perm:[1,0,3,2]  (== shfl_xor 1)
+    v += rpo_dpp_mov<0x4E>(v);                                   // quad_perm:[2,3,0,1]  (== shfl_xor 2)
+    return v;
+}
+__device__ __forceinline__ float rpo_row16_sum_lane0(float v) {
+    v = rpo_quad_sum(v);
+    v += rpo_dpp_mov<0x104>(v);                                  // row_shl:4: lane l reads lane l + 4 (0 beyond the row)
+    v += rpo_dpp_mov<0x108>(v);                                  // row_shl:8
+    return v;
+}
+
 // take_action's exploration (agent/ddpg_pa.py:108-110): clip(ap + eps_t * noise, lo, hi), unfused like the
 // RPO_NOISE_PHILOX / RPO_NOISE_EXPLICIT branches of the *_explore_project functions
 __device__ __forceinline__ float rpo_explore_clip(float ap, float eps_t, float noise, float lo, float hi) {

@@ -267,7 +267,7 @@ __device__ __forceinline__ void tile_compute(const Mlp& net, const TileWeights<E
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float v = po[o][i];
-                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                v = rpo_row16_sum_lane0(v);                      // (same association as the xor butterfly, at li == 0)
                 if (li == 0) part[(wave * ROWS + rt * kRows + lg * 4 + i) * 2 + o] = v;
             }
     }

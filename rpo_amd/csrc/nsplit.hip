@@ -936,8 +936,7 @@ __global__ __launch_bounds__(kThreads) void split_policy_c_kernel(SplitArgs p) {
         if (live) p.dx0[k][xo] = v;
         // this group's share of d/d action: sum over its 16 columns (fixed butterfly), 2 action components
         float d0 = v * wa2.x, d1 = v * wa2.y;
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) { d0 += __shfl_xor(d0, off, 64); d1 += __shfl_xor(d1, off, 64); }
+        d0 = rpo_row16_sum_lane0(d0); d1 = rpo_row16_sum_lane0(d1);   // (xor-butterfly association at ee == 0)
         if (ee == 0 && live)
             reinterpret_cast<float2*>(p.da_part)[((size_t)k * kNsGroups + g) * B + row0 + r] = make_float2(d0, d1);
     }

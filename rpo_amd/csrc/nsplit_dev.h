@@ -124,7 +124,7 @@ __device__ __forceinline__ void ns_hidden(const Mlp& net, const NsWeights<EIN>& 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float v = fmaf(hr[i], o == 0 ? w.w1av : w.w1bv, lds.xch[(o * 4 + i) * 64 + lane]);
-                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                v = rpo_row16_sum_lane0(v);                      // (same association as the xor butterfly, at li == 0)
                 const int row = row0 + lg * 4 + i;
                 if (li == 0 && row < n && o < net.n_out) part[((size_t)g * n + row) * 2 + o] = v;
             }

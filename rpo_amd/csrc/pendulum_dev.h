@@ -256,8 +256,8 @@ __device__ __forceinline__ void project_batchref_body(int n, const float* o, flo
                 g0 += (ax * d0 - bgp > 0.0f) ? d0 : 0.0f;
             }
             float grad = (g0 + g1) + (g2 + g3);
-#pragma unroll
-            for (int off = 1; off < LPS; off <<= 1) grad += __shfl_xor(grad, off, 64);    // same value in the LPS lanes
+            static_assert(LPS == 1 || LPS == 4, "lanes per sample");
+            if (LPS == 4) grad = rpo_quad_sum(grad);               // same value in the 4 lanes (== the xor butterfly, DPP)
             const float gy = -(grad * e.C_p) * e.C_o_inv;                            // :342
             const float sx = corr_lr * grad + corr_momentum * ox;
             const float sy = corr_lr * gy + corr_momentum * oy;
