@@ -86,6 +86,47 @@ __device__ __forceinline__ float rpo_row16_sum_lane0(float v) {
     return v;
 }
 
+// The same with the association of rpo_wave_sum (offsets 8, 4, 2, 1 in that order; its steps 32 and 16 only add the other
+// rows): a bitwise drop-in for rpo_wave_sum(v) where only lanes 0..15 of the wave hold non-zero values and lane 0 keeps
+// the result -- the 16 per-row terms of a tile (losses, Lagrangian partials).
+__device__ __forceinline__ float rpo_row16_sum_desc_lane0(float v) {
+    v += rpo_dpp_mov<0x108>(v);                                  // row_shl:8
+    v += rpo_dpp_mov<0x104>(v);                                  // row_shl:4
+    v += rpo_dpp_mov<0x4E>(v);                                   // quad_perm:[2,3,0,1]
+    v += rpo_dpp_mov<0xB1>(v);                                   // quad_perm:[1,0,3,2]
+    return v;
+}
+
+// K statistics of the 16 lanes of row 0 (lanes 0..15; the rest of the wave holds zeros), the results in EVERY lane: the
+// DPP form of rpo_wave_reduce_many<K, 8> (same offsets in the same order -> same bits), without its LDS round trips.
+template <int K>
+__device__ __forceinline__ void rpo_row16_reduce_many(float (&v)[K], unsigned max_mask) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float x = v[k];
+        if ((max_mask >> k) & 1u) {
+            x = fmaxf(x, rpo_dpp_mov<0x108>(x)); x = fmaxf(x, rpo_dpp_mov<0x104>(x));
+            x = fmaxf(x, rpo_dpp_mov<0x4E>(x)); x = fmaxf(x, rpo_dpp_mov<0xB1>(x));
+        } else {
+            x = rpo_row16_sum_desc_lane0(x);
+        }
+        v[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0));
+    }
+}
+
+// Maximum of non-negative values over the wave, the same in every lane (order-independent, exact): DPP inside the rows,
+// v_readlane across them -- no LDS round trips (rpo_wave_max: six ds_bpermute + wait in series).
+__device__ __forceinline__ float rpo_wave_max_nonneg(float v) {
+    v = fmaxf(v, rpo_dpp_mov<0x108>(v));
+    v = fmaxf(v, rpo_dpp_mov<0x104>(v));
+    v = fmaxf(v, rpo_dpp_mov<0x4E>(v));
+    v = fmaxf(v, rpo_dpp_mov<0xB1>(v));                          // lane 0 of each row: the row's maximum (0 beyond the row)
+    const int b = __float_as_int(v);
+    const float m0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), m1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+    const float m2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), m3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+}
+
 // take_action's exploration (agent/ddpg_pa.py:108-110): clip(ap + eps_t * noise, lo, hi), unfused like the
 // RPO_NOISE_PHILOX / RPO_NOISE_EXPLICIT branches of the *_explore_project functions
 __device__ __forceinline__ float rpo_explore_clip(float ap, float eps_t, float noise, float lo, float hi) {

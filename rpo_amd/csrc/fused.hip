@@ -101,7 +101,8 @@ __global__ __launch_bounds__(kFwdThreads) void rollout_kernel(RolloutArgs<ENV> p
 #pragma unroll
         for (int k = 0; k < kStats; ++k) red[k] = st[k];
         red[kStats] = iters_f;
-        rpo_wave_reduce_many<kStats + 1, (kLanes <= 16 ? 8 : 32)>(red, 3u << 8);   // (lanes 0..15 end with the results)
+        if (kLanes <= 16) rpo_row16_reduce_many(red, 3u << 8);  // (only lanes 0..15 hold data: DPP, no LDS round trips)
+        else rpo_wave_reduce_many<kStats + 1, 32>(red, 3u << 8);
         rpo_stats_commit(red, 3u << 8, slot, srow);
     }
     if (!p.defer_clock) rpo_step_epilogue(p.step.ctrl, t, p.step.stats, p.step.stats_cap);

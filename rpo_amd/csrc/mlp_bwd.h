@@ -67,7 +67,7 @@ __device__ __forceinline__ void mlp_bwd_rows_body(const BwdArgs& p) {
                 t.dq_out[i] = dq;
             }
             if (tid < kRows) { dout_s[tid * 2] = dq; dout_s[tid * 2 + 1] = 0.0f; }
-            const float sum = rpo_wave_sum(hub);
+            const float sum = rpo_row16_sum_desc_lane0(hub);     // (== rpo_wave_sum: only lanes 0..15 hold terms)
             if (tid == 0) p.td.loss_partial[blockIdx.x] = sum;
         }
     } else if (!wide_head) {
@@ -485,7 +485,7 @@ __device__ __forceinline__ float mlp_bwd_weights_body(const BwdArgs& p) {
 __device__ __forceinline__ void gradmax_flush(float* gradmax, float v) {
     __shared__ float red[kThreads / 64];
     if (gradmax == nullptr) return;
-    v = rpo_wave_max(v);
+    v = rpo_wave_max_nonneg(v);                                  // (gradient magnitudes)
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -581,7 +581,7 @@ __device__ __forceinline__ void bwd_a_role(const SplitArgs& p, float* smem, int 
                 if (g == 0) p.dq[k][row0 + tid] = dq;
             }
             if (tid < kRows) dq_s[tid] = dq;
-            const float sum = rpo_wave_sum(hub);
+            const float sum = rpo_row16_sum_desc_lane0(hub);     // (== rpo_wave_sum: only lanes 0..15 hold terms)
             if (tid == 0 && g == 0) p.loss_partial[k * T + tile] = sum;
         }
         __syncthreads();
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(kThreads) void split_policy_c_kernel(SplitArgs p) {
         float dq = 0.0f, term = 0.0f;
         if (tid < kRows && row0 + tid < B) dq = ns_policy_dq(p, k, row0 + tid, &term);
         if (tid < kRows) dq_s[tid] = dq;
-        const float sum = rpo_wave_sum(term);
+        const float sum = rpo_row16_sum_desc_lane0(term);        // (== rpo_wave_sum: only lanes 0..15 hold terms)
         if (tid == 0 && g == 0 && k == 0) p.lag_partial[tile * 8 + 7] = sum;
     }
     __syncthreads();
