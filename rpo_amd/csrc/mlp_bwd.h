@@ -460,8 +460,7 @@ __device__ __forceinline__ float mlp_bwd_weights_body(const BwdArgs& p) {
                 s0 += p.dout[(size_t)b2 * net.n_out];
                 if (net.n_out > 1) s1 += p.dout[(size_t)b2 * net.n_out + 1];
             }
-            s0 = rpo_wave_sum(s0);
-            s1 = rpo_wave_sum(s1);
+            { float ss[2] = {s0, s1}; rpo_wave_reduce_many(ss, 0u); s0 = ss[0]; s1 = ss[1]; }
             if (o == 0) { partial[part][0][0] = s0; partial[part][1][0] = s1; }
             __syncthreads();
             if (tid == 0) {

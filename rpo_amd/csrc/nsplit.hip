@@ -328,10 +328,20 @@ __device__ __forceinline__ void ride_tail(const RideArgs<ENV>& r, const CartCons
         // sums 0..7, maxima 8..9 (rollout_kernel's slots), then the projection-iteration sum; every block owns a sub-row
         float* srow = rpo_stats_row_at(r.step.stats, r.step.stats_cap, t, blk);
         const int lane = tid & (RPO_WAVE - 1), wave = tid / RPO_WAVE;
-        rpo_wave_reduce_many(st, 3u << 8);
 #pragma unroll
-        for (int k = 0; k <= kStats; ++k)
-            if (lane == 0) smem[wave * (kStats + 1) + k] = st[k];
+        for (int k = 0; k <= kStats; ++k) {                          // DPP inside the rows, v_readlane across them: no LDS round trips
+            const bool mx = k == 8 || k == 9;
+            float x = st[k];
+            if (mx) {
+                x = rpo_wave_max_nonneg(x);
+            } else {
+                x = rpo_row16_sum_desc_lane0(x);
+                const int b = __float_as_int(x);
+                x = (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
+                    (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
+            }
+            if (lane == 0) smem[wave * (kStats + 1) + k] = x;
+        }
         __syncthreads();
         if (tid <= kStats) {
             const int slot[kStats + 1] = {RPO_STAT_REWARD_SUM, RPO_STAT_EPISODES, RPO_STAT_RETURN_SUM, RPO_STAT_LENGTH_SUM,
@@ -518,8 +528,7 @@ __device__ __forceinline__ float ns_hv_block(const Mlp& net, const MlpGrad& gr, 
             s0 += dglob[(size_t)b2 * dstride];
             if (two) s1 += dglob[(size_t)b2 * dstride + 1];
         }
-        s0 = rpo_wave_sum(s0);
-        s1 = rpo_wave_sum(s1);
+        { float ss[2] = {s0, s1}; rpo_wave_reduce_many(ss, 0u); s0 = ss[0]; s1 = ss[1]; }   // (both butterflies step by step)
         float* red = smem + 256;
         if ((tid & 63) == 0) { red[(tid >> 6) * 2] = s0; red[(tid >> 6) * 2 + 1] = s1; }
         __syncthreads();
@@ -861,10 +870,11 @@ __global__ __launch_bounds__(kNsThreads) void split_policy_b_kernel(SplitArgs p,
         lds.in_a[tid * 8 + 1] = act.y;
     }
     if (writer && tid < 64) {
-        rpo_wave_reduce_many(vals, 0u);
 #pragma unroll
-        for (int q = 0; q < 7; ++q)
-            if (tid == 0) p.lag_partial[blockIdx.y * 8 + q] = vals[q];
+        for (int q = 0; q < 7; ++q) {                                // (== rpo_wave_sum: only lanes 0..15 hold terms)
+            const float sum = rpo_row16_sum_desc_lane0(vals[q]);
+            if (tid == 0) p.lag_partial[blockIdx.y * 8 + q] = sum;
+        }
     }
     ns_hidden<128, 256>(net, w, lds, g, row0, B, p.part_q[k], p.x0[k], p.h1[k]);
 }
