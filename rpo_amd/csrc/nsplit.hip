@@ -24,6 +24,16 @@ bool split_ok(const Mlp& m) {
            m.W1 && (m.A == 0 || m.Wa) && (m.n_out == 1 || m.W1b);
 }
 
+// (row tile, column group) of a slab workgroup.  The launch grid is (8 groups, T tiles, planes); inside a plane the
+// hardware numbers workgroups x-fastest and workgroup b lands on XCD b % 8.  Here the ROW TILE is the fastest index of that
+// numbering: all 8 column groups of a tile -- and every later launch's workgroups for that tile -- run on the XCD
+// tile % 8, so what one launch leaves for the next (partials, saved activations) is produced and consumed by the same L2.
+struct NsBlock { int tile, g; };
+__device__ __forceinline__ NsBlock ns_block() {
+    const int lin = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y, T = (int)gridDim.y;
+    return NsBlock{lin % T, lin / T};
+}
+
 // ------------------------------------------------------------------------------------------- stand-alone split forward
 struct SplitFwdArgs {
     Mlp net;
@@ -40,7 +50,8 @@ struct SplitFwdArgs4 { SplitFwdArgs net[4]; };
 __global__ __launch_bounds__(kNsThreads) void mlp_forward_split_kernel(SplitFwdArgs4 all) {
     __shared__ NsLds<128> lds;
     const SplitFwdArgs& p = all.net[blockIdx.z];
-    const int row0 = blockIdx.y * kRows, g = blockIdx.x, tid = threadIdx.x;      // g fastest: block -> XCD g (see fwd_a)
+    const NsBlock nb = ns_block();
+    const int row0 = nb.tile * kRows, g = nb.g, tid = threadIdx.x;
     NsWeights<128> w;
     ns_load_weights<128, 256>(p.net, g, w);
     if (tid < kRows * 8) {
@@ -182,7 +193,8 @@ __global__ __launch_bounds__(kNsThreads) void split_critic_fwd_a_kernel(SplitArg
     // the column group is the FASTEST grid dimension: workgroup b lands on XCD b % 8 == g, so each XCD's L2 fetches only the
     // 1/8 slice of W0 its groups read (with the row tile fastest every XCD pulled every network's whole W0 per launch:
     // 3.0 MB of traffic for ~0.35 MB of unique bytes, profiles/r02_pmc_traffic.json)
-    fwd_a_role<L>(p, lds, tile, blockIdx.y * kRows, blockIdx.x, blockIdx.z);
+    const NsBlock nb = ns_block();
+    fwd_a_role<L>(p, lds, tile, nb.tile * kRows, nb.g, blockIdx.z);
 }
 
 // The policy head of row i from the slab partials: tanh box (RPODDPG, model/policy.py:30-31) or rsample of the squashed
@@ -248,7 +260,8 @@ template <class L, int PROJ>
 __global__ __launch_bounds__(kNsThreads) void split_critic_fwd_b_kernel(SplitArgs p, CartConsts c) {
     __shared__ NsLds<128> lds;
     __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
-    fwd_b_role<L, PROJ>(p, c, lds, tile, blockIdx.y * kRows, blockIdx.x, blockIdx.z);
+    const NsBlock nb = ns_block();
+    fwd_b_role<L, PROJ>(p, c, lds, tile, nb.tile * kRows, nb.g, blockIdx.z);
 }
 
 // ============================================================================== rollout stages riding on update launches
@@ -365,8 +378,9 @@ __global__ __launch_bounds__(kNsThreads) void split_critic_fwd_a_ride_kernel(Spl
     __shared__ NsLds<128> lds;
     __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
     const int roles = (p.twin ? 2 : 1) + 1;
-    if ((int)blockIdx.z < roles) fwd_a_role<L>(p, lds, tile, blockIdx.y * kRows, blockIdx.x, blockIdx.z);
-    else ride_forward<typename L::Env>(r, lds, ((int)blockIdx.z - roles) * (int)gridDim.y + (int)blockIdx.y, blockIdx.x);
+    const NsBlock nb = ns_block();
+    if ((int)blockIdx.z < roles) fwd_a_role<L>(p, lds, tile, nb.tile * kRows, nb.g, blockIdx.z);
+    else ride_forward<typename L::Env>(r, lds, ((int)blockIdx.z - roles) * (int)gridDim.y + nb.tile, nb.g);
 }
 
 template <class L, int PROJ>
@@ -374,8 +388,9 @@ __global__ __launch_bounds__(kNsThreads) void split_critic_fwd_b_ride_kernel(Spl
     __shared__ NsLds<128> lds;
     __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
     const int K = p.twin ? 2 : 1;
-    if ((int)blockIdx.z < K) fwd_b_role<L, PROJ>(p, c, lds, tile, blockIdx.y * kRows, blockIdx.x, blockIdx.z);
-    else ride_forward<typename L::Env>(r, lds, ((int)blockIdx.z - K) * (int)gridDim.y + (int)blockIdx.y, blockIdx.x);
+    const NsBlock nb = ns_block();
+    if ((int)blockIdx.z < K) fwd_b_role<L, PROJ>(p, c, lds, tile, nb.tile * kRows, nb.g, blockIdx.z);
+    else ride_forward<typename L::Env>(r, lds, ((int)blockIdx.z - K) * (int)gridDim.y + nb.tile, nb.g);
 }
 
 // ---- SpringPendulum: head of the policy + the reference's batch-coupled projection (pendulum.py:337-339), one workgroup
@@ -789,7 +804,8 @@ template <class L>
 __global__ __launch_bounds__(kNsThreads) void split_policy_a_kernel(SplitArgs p) {
     __shared__ NsLds<128> lds;
     __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
-    pol_a_role<L>(p, lds, tile, blockIdx.y * kRows, blockIdx.x);
+    const NsBlock nb = ns_block();
+    pol_a_role<L>(p, lds, tile, nb.tile * kRows, nb.g);
 }
 
 // fwd_b + pol_a: on a policy iteration of a configuration WITHOUT a shared state embedding the policy slabs on the batch
@@ -801,8 +817,9 @@ __global__ __launch_bounds__(kNsThreads) void split_critic_fwd_b_pol_kernel(Spli
     __shared__ NsLds<128> lds;
     __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
     const int K = p.twin ? 2 : 1;
-    if ((int)blockIdx.z < K) fwd_b_role<L, PROJ>(p, c, lds, tile, blockIdx.y * kRows, blockIdx.x, blockIdx.z);
-    else pol_a_role<L>(p, lds, tile, blockIdx.y * kRows, blockIdx.x);
+    const NsBlock nb = ns_block();
+    if ((int)blockIdx.z < K) fwd_b_role<L, PROJ>(p, c, lds, tile, nb.tile * kRows, nb.g, blockIdx.z);
+    else pol_a_role<L>(p, lds, tile, nb.tile * kRows, nb.g);
 }
 
 // ---- pol_b: head -> exploration noise + clip (RPODDPG) / rsample + clip + log pi (RPOSAC) -> Complete -> Lagrangian row
@@ -813,7 +830,8 @@ __global__ __launch_bounds__(kNsThreads) void split_policy_b_kernel(SplitArgs p,
     typedef typename ENV::L L;
     __shared__ NsLds<128> lds;
     __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
-    const int row0 = blockIdx.y * kRows, g = blockIdx.x, k = blockIdx.z, tid = threadIdx.x, B = p.B;
+    const NsBlock nb = ns_block();
+    const int row0 = nb.tile * kRows, g = nb.g, k = blockIdx.z, tid = threadIdx.x, B = p.B;
     const Mlp& net = p.critic[k];
     NsWeights<128> w;
     ns_load_weights<128, 256>(net, g, w);
@@ -873,7 +891,7 @@ __global__ __launch_bounds__(kNsThreads) void split_policy_b_kernel(SplitArgs p,
 #pragma unroll
         for (int q = 0; q < 7; ++q) {                                // (== rpo_wave_sum: only lanes 0..15 hold terms)
             const float sum = rpo_row16_sum_desc_lane0(vals[q]);
-            if (tid == 0) p.lag_partial[blockIdx.y * 8 + q] = sum;
+            if (tid == 0) p.lag_partial[nb.tile * 8 + q] = sum;
         }
     }
     ns_hidden<128, 256>(net, w, lds, g, row0, B, p.part_q[k], p.x0[k], p.h1[k]);
