@@ -486,10 +486,24 @@ typedef struct {
     /* policy step: head partials of pi(s) between pol_a and pol_b, [8, batch, 2]; NULL: part_pi is used.  A buffer of its
      * own lets pol_a run INSIDE fwd_b's launch (rpo_split_critic_fwd_b_pol) while fwd_b still reads part_pi. */
     float* part_pol;
+    /* rpo_split_critic_front: [(3 * ceil(batch / 16) + 1) * 32] words (one 128-byte line per arrival word), 128-byte
+     * aligned, zero before the first launch (every launch leaves them zero); word [3 * ceil(batch / 16) * 32] is set to 1 if a
+     * workgroup ever gave up waiting for its tile's producers (never, on a healthy device). */
+    unsigned* tile_sync;
 } rpo_split_update;
 
 int rpo_split_critic_fwd_a(const rpo_split_update* u, void* stream);
 int rpo_split_critic_fwd_b(const rpo_split_update* u, void* stream);
+/* CartSafe-v0 only: rpo_split_critic_fwd_a + rpo_split_critic_fwd_b + rpo_split_critic_bwd_a as ONE launch -- the later
+ * stages' workgroups are extra planes of the grid that wait (tile_sync) for the workgroups of their own row tile instead of
+ * for a launch boundary (the three stages hand over row-tile-local data only; bwd_b needs every row and stays a launch).  Same
+ * values bit for bit (rpo_ddpg.py:163-185 / rpo_sac.py:167-196 up to the TD target's inputs).  Requires that the
+ * dispatcher places all workgroups of a row tile on one XCD (rpo_xcc_probe). */
+int rpo_split_critic_front(const rpo_split_update* u, void* stream);
+/* out[x + gx * (y + gy * z)] = the XCD (XCC_ID) workgroup (x, y, z) of a (gx, gy, gz) grid of `threads`-thread workgroups ran
+ * on.  rpo_split_critic_front hands data from workgroup to workgroup through ONE XCD's L2; its caller checks with this probe
+ * (same grid: 8, ceil(batch / 16), 1 + 3 K; 256 threads) that all workgroups of a row tile share an XCD. */
+int rpo_xcc_probe(int gx, int gy, int gz, int threads, int* out, void* stream);
 /* fwd_b + pol_a in one launch (policy iterations, no shared state embedding: the policy slabs on the batch states need
  * nothing the critic update produces); the caller then skips rpo_split_policy_a.  Requires part_pol. */
 int rpo_split_critic_fwd_b_pol(const rpo_split_update* u, void* stream);

@@ -579,7 +579,8 @@ class RPOTrainerBase(object):
             part_q1=b("split.part_q1", 8, B, 2), part_qn1=b("split.part_qn1", 8, B, 2),
             x0_1=b(c1 + ".x0", B, d[c1].ein), h1_1=b(c1 + ".h1", B, d[c1].H), dq1=b("dq1" if self.sac else "dq", B, 1),
             dx0_1=b(c1 + ".dx0", B, d[c1].ein), loss_partial=b("split.loss_parts", 2, T),
-            next_actions=b("split.next_actions", B, 2), logp=b("crit.logp", B))
+            next_actions=b("split.next_actions", B, 2), logp=b("crit.logp", B),
+            tile_sync=torch.zeros((3 * T + 1) * 32, dtype=torch.int32, device=self.device))
         if self.sac:
             fields.update(part_q2=b("split.part_q2", 8, B, 2), part_qn2=b("split.part_qn2", 8, B, 2),
                           x0_2=b("critic2.x0", B, d["critic2"].ein), h1_2=b("critic2.h1", B, d["critic2"].H),
@@ -596,6 +597,8 @@ class RPOTrainerBase(object):
         else:
             fields.update(ap_det=b("act.ap_det", B))
         self._split_cache = be.SplitUpdate(k, descs, self.sac, B, fields)
+        self._front_cache = bool(_env_int("RPO_FRONT", 1)) and isinstance(k, be.CartSafeKernels) and \
+            hasattr(be, "front_launch_ok") and be.front_launch_ok(B, self.sac)
         self._split_loss = fields["loss_partial"]
         self._split_logp = (fields["logp"], b("pi.logp", B))          # log pi(a'|s') of the critic update | log pi(a|s)
         return self._split_cache
@@ -682,6 +685,15 @@ class RPOTrainerBase(object):
         if ride is not None:
             n, cut = self.vec.internal.shape[0], self._ride_cut
             ride.set(lane_begin=0, lane_end=cut)
+        # CartSafe, nothing riding: fwd_a, fwd_b and bwd_a are one launch (the later stages' workgroups wait inside it for the
+        # workgroups of their own row tile, rpo_split_critic_front) -- same values, two launch boundaries less
+        early = bool(actor_step) and ride is None and self.agent.flat.sizes[1] == 0 and getattr(self, "_actor_pipeline", False) \
+            and bool(_env_int("RPO_POL_A_EARLY", 1))
+        if su.st.env == 0 and ride is None and not early and self._after_front is None and self._front_ok():
+            self._pol_a_done = False
+            su.run("critic_front")
+            self._critic_update_split_back(su, ride, bwd_a=False)
+            return
         su.run("critic_fwd_a", rider=ride)                      # + actor forward of lanes [0, cut)
         if self._after_front is not None:                       # overlapped windows: the next rollout forks off here
             self._after_front()
@@ -691,14 +703,21 @@ class RPOTrainerBase(object):
             ride.set(lane_begin=cut, lane_end=n)
         # policy iteration without a shared embedding: the policy slabs on the batch states (pol_a) need nothing the critic
         # update produces -- they are an extra plane of fwd_b's launch instead of a launch behind the critic step
-        early = bool(actor_step) and ride is None and self.agent.flat.sizes[1] == 0 and getattr(self, "_actor_pipeline", False) \
-            and bool(_env_int("RPO_POL_A_EARLY", 1))
         self._pol_a_done = early
         su.run("critic_fwd_b_pol" if early else "critic_fwd_b", rider=ride)   # (+ actor forward of lanes [cut, n))
+        self._critic_update_split_back(su, ride)
+
+    def _front_ok(self):
+        """rpo_split_critic_front usable here (``RPO_FRONT=0``: never): see ops.front_launch_ok."""
+        return self._front_cache                                 # (probed in _split_state, outside any graph capture)
+
+    def _critic_update_split_back(self, su, ride, bwd_a=True):
+        """bwd_a | bwd_b of the column-split critic update (``bwd_a=False``: it was part of the front launch)."""
         self._zero_grads()
         gm = self._critic_gradmax()
         su.set(gradmax=gm)
-        su.run("critic_bwd_a")
+        if bwd_a:
+            su.run("critic_bwd_a")
         if ride is not None:
             ride.set(defer_clock=int(self._defer_ok))           # ... whose step counter the next update's fwd_a advances
         su.run("critic_bwd_b", rider=ride)                      # + explore / project / step / scatter of every lane

@@ -106,7 +106,73 @@ struct SplitArgs {
     int* prep2_step[3]; float prep2_beta1[3], prep2_beta2[3]; float* gradmax_reset2;
     long long* updates_out;
     float* part_pol;              // policy step: head partials of pi(s) (pol_a -> pol_b); NULL: part_pi is reused
+    unsigned* tile_sync;          // fused front launch: per-tile arrival words (ns_tile_arrive / ns_tile_wait)
 };
+
+// ---- Hand-over between workgroups of ONE launch (the fused front of the critic update, rpo_split_critic_front).
+// What a row tile's stages pass on -- head partials of the 8 column groups, the gathered rows, saved activations -- is
+// produced and consumed by the workgroups of that tile only, so the stages need no launch boundary between them, only a
+// per-tile arrival word.  Consumers are workgroups with HIGHER block ids (dispatched after every producer, so a waiting
+// workgroup can never keep a producer off the chip); they request their weights first and then poll the word.
+//
+// Scope.  With the row tile fastest in the block numbering (ns_block) and T % 8 == 0 every workgroup of a tile, in every
+// plane, runs on XCD tile % 8: producer and consumer share ONE L2.  The hand-over therefore stays inside that L2 -- stores
+// are complete there once vmcnt is 0 (the vector L1 writes through), the arrival is an atomic executed in that L2, the
+// consumer polls it with a returning atomic (never served by its L1) and drops its L1 before reading the data.  Device-scope
+// fences instead (buffer_wbl2 / buffer_inv sc1: write back and invalidate the WHOLE L2, by 256 waves of the launch) made the
+// fused launch 8 us slower than the two launches it replaces.  The placement is a property of the dispatcher, so the host
+// checks it once per process with a probe launch of the same grid (rpo_xcc_probe; rpo_amd/ops.py front_launch_ok) and keeps
+// the separate launches if any tile's workgroups are spread over XCDs.
+//
+// tile_sync layout: word [(stage * T + tile) * kNsSyncStride], stage 0 / 1 = arrival counts, stage 2 = consumers that have passed their waits
+// (the last one zeroes the tile's words: the buffer is all zeros again when the launch ends); word [3 * T * kNsSyncStride] = 1 if a wait
+// ever gave up (kNsSpinMax polls: a lost producer must not hang the device; the tests check the word).
+constexpr int kNsSpinMax = 1 << 18;
+// one 128-byte line per arrival word: with the 16 tiles' words in ONE line the polls and arrivals of the whole launch queued on
+// one L2 channel per XCD and the waits took 7.8 us (measured) instead of the ~3 us the producers need
+constexpr int kNsSyncStride = 32;
+
+__device__ __forceinline__ void ns_tile_arrive(unsigned* word) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every wave: its stores have reached the XCD's L2 ...
+    __syncthreads();                                             // ... before the workgroup's one arrival
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ unsigned ns_poll(unsigned* word) {     // returning atomic: executed in the L2, not a cached load
+    unsigned v;
+    asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(word), "v"(0u) : "memory");
+    return v;
+}
+
+__device__ __forceinline__ void ns_tile_wait(unsigned* word, unsigned need, unsigned* gave_up) {
+    if (threadIdx.x == 0) {
+        int polls = 0;
+        while (ns_poll(word) < need) {
+            if (++polls >= kNsSpinMax) { *gave_up = 1u; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    asm volatile("buffer_inv sc0" ::: "memory");                 // the vector L1 of this CU holds nothing older than the arrival
+}
+
+// a consumer of the tile (`n_consumers` in all) has passed its waits: the last one clears the tile's words
+__device__ __forceinline__ void ns_tile_passed(unsigned* sync, int T, int tile, unsigned n_consumers) {
+    if (threadIdx.x == 0 &&
+        __hip_atomic_fetch_add(sync + (2 * T + tile) * kNsSyncStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ==
+            n_consumers - 1u) {
+        sync[tile * kNsSyncStride] = 0u; sync[(T + tile) * kNsSyncStride] = 0u; sync[(2 * T + tile) * kNsSyncStride] = 0u;
+    }
+}
+
+// XCD of every workgroup of a grid (see above): out[linear block id] = XCC_ID
+__global__ void xcc_probe_kernel(int* out) {
+    if (threadIdx.x == 0) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        out[(size_t)blockIdx.x + (size_t)gridDim.x * ((size_t)blockIdx.y + (size_t)gridDim.y * blockIdx.z)] = (int)(id & 15u);
+    }
+}
 
 // ReplayBuffer.sample (buffer.py:31-34): counter-based draw + gather of the tile's 16 rows (same draw in every workgroup
 // of the tile; `publish` stores the gathered rows / indices once).
@@ -190,9 +256,9 @@ template <class L>
 __global__ __launch_bounds__(kNsThreads) void split_critic_fwd_a_kernel(SplitArgs p) {
     __shared__ NsLds<128> lds;
     __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
-    // the column group is the FASTEST grid dimension: workgroup b lands on XCD b % 8 == g, so each XCD's L2 fetches only the
-    // 1/8 slice of W0 its groups read (with the row tile fastest every XCD pulled every network's whole W0 per launch:
-    // 3.0 MB of traffic for ~0.35 MB of unique bytes, profiles/r02_pmc_traffic.json)
+    // row tile fastest (ns_block): every XCD's L2 pulls each network's whole W0 per launch (more fetched bytes than with the
+    // column group fastest, where an XCD fetched only its 1/8 slice), but what the chain hands from launch to launch for a
+    // tile stays in the L2 that produced it -- the chain is latency-bound, not byte-bound: -7 % per iteration (A/B)
     const NsBlock nb = ns_block();
     fwd_a_role<L>(p, lds, tile, nb.tile * kRows, nb.g, blockIdx.z);
 }
@@ -222,11 +288,15 @@ __device__ __forceinline__ float ns_policy_head(const SplitArgs& p, int i, long 
 //      come from rpo_split_pend_head_project.
 template <class L, int PROJ>
 __device__ __forceinline__ void fwd_b_role(const SplitArgs& p, const CartConsts& c, NsLds<128>& lds, float4* tile, int row0, int g,
-                                           int k) {
+                                           int k, unsigned* wait_word = nullptr, unsigned wait_need = 0u) {
     const int tid = threadIdx.x;
     const Mlp& net = p.critic_target[k];
     NsWeights<128> w;
     ns_load_weights<128, 256>(net, g, w);
+    if (wait_word) {                                             // fused front: the tile's policy slabs of THIS launch
+        const int T = (p.B + kRows - 1) / kRows;
+        ns_tile_wait(wait_word, wait_need, p.tile_sync + 3 * T * kNsSyncStride);
+    }
     ns_load_tile<L>(p, tile, row0);
     __syncthreads();
     ns_stage<L>(lds, reinterpret_cast<const float*>(tile), true, false);
@@ -577,7 +647,7 @@ __device__ __forceinline__ float ns_weight_role(const Mlp& net, const MlpGrad& g
 constexpr int kBwdASmem = kRows * (256 + 4) + 16 + 4 * 16 * 16;
 
 template <class L>
-__device__ __forceinline__ void bwd_a_role(const SplitArgs& p, float* smem, int b) {
+__device__ __forceinline__ void bwd_a_role(const SplitArgs& p, float* smem, int b, bool fused = false) {
     constexpr int EIN = 128, H = 256, LDH = H + 4;
     const int T = (p.B + kRows - 1) / kRows, B = p.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
@@ -593,9 +663,15 @@ __device__ __forceinline__ void bwd_a_role(const SplitArgs& p, float* smem, int 
         float wv[H / 16], hv[kRows];
 #pragma unroll
         for (int ks = 0; ks < H / 16; ++ks) wv[ks] = net.W0[(size_t)(jw + ks * 4 + lg) * EIN + e];
+        const float w1a = net.W1[tid];                            // 256 threads = 256 hidden columns
+        if (fused) {
+            // fused front: the tile's critic slabs (fwd_a) and target slabs (fwd_b) of THIS launch: 8 arrivals per network
+            const unsigned need = (unsigned)(2 * kNsGroups * (p.twin ? 2 : 1));
+            ns_tile_wait(p.tile_sync + (T + tile) * kNsSyncStride, need, p.tile_sync + 3 * T * kNsSyncStride);
+            ns_tile_passed(p.tile_sync, T, tile, need);          // (as many consumers as arrivals: fwd_b's + bwd_a's workgroups)
+        }
 #pragma unroll
         for (int r = 0; r < kRows; ++r) hv[r] = row0 + r < B ? p.h1[k][(size_t)(row0 + r) * H + tid] : 0.0f;
-        const float w1a = net.W1[tid];                            // 256 threads = 256 hidden columns
         const size_t xo = (size_t)(row0 + (tid >> 4)) * EIN + g * 16 + (tid & 15);
         const float x0v = row0 + (tid >> 4) < B ? p.x0[k][xo] : 0.0f;   // mask of this thread's output, requested early
         if (tid < 64) {
@@ -634,6 +710,38 @@ template <class L>
 __global__ __launch_bounds__(kThreads) void split_critic_bwd_a_kernel(SplitArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[kBwdASmem];
     bwd_a_role<L>(p, smem, blockIdx.x);
+}
+
+// ---- fused front of the critic update (CartSafe): fwd_a, fwd_b and bwd_a in ONE launch -- the three stages whose hand-overs
+//      stay inside a row tile.  grid (8, T, 1 + 3 K) of 256-thread workgroups (bwd_a's shape; the forward roles use two of
+//      the four waves, the other two leave at once):
+//        planes [0, 1 + K)          fwd_a's roles; the policy arrives at the tile's word 0, the critics at word 1
+//        planes [1 + K, 1 + 2 K)    fwd_b's target critics: wait for word 0 == 8, arrive at word 1
+//        planes [1 + 2 K, 1 + 3 K)  bwd_a of critic k: waits for word 1 == 16 K behind its W0 requests
+//      Same code, same values as the three launches.
+template <class L>
+__global__ __launch_bounds__(kThreads) void split_critic_front_kernel(SplitArgs p, CartConsts c) {
+    __shared__ __attribute__((aligned(16))) float smem[kBwdASmem];
+    static_assert(sizeof(NsLds<128>) + sizeof(float4) * kRows * L::CH <= sizeof(float) * kBwdASmem, "forward roles fit");
+    static_assert(sizeof(NsLds<128>) % 16 == 0, "tile alignment");
+    const int K = p.twin ? 2 : 1, T = (int)gridDim.y, z = (int)blockIdx.z;
+    if (z >= 1 + 2 * K) {
+        bwd_a_role<L>(p, smem, (z - 1 - 2 * K) * T * kNsGroups + (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y, true);
+        return;
+    }
+    if (threadIdx.x >= kNsThreads) return;                       // (whole waves: the barriers below count the two that stay)
+    NsLds<128>& lds = *reinterpret_cast<NsLds<128>*>(smem);
+    float4* tile = reinterpret_cast<float4*>(reinterpret_cast<char*>(smem) + sizeof(NsLds<128>));
+    const NsBlock nb = ns_block();
+    unsigned* sync = p.tile_sync;
+    if (z < 1 + K) {
+        fwd_a_role<L>(p, lds, tile, nb.tile * kRows, nb.g, z);
+        ns_tile_arrive(sync + ((z == 0 ? 0 : T) + nb.tile) * kNsSyncStride);
+    } else {
+        fwd_b_role<L, 1>(p, c, lds, tile, nb.tile * kRows, nb.g, z - 1 - K, sync + nb.tile * kNsSyncStride, (unsigned)kNsGroups);
+        ns_tile_arrive(sync + (T + nb.tile) * kNsSyncStride);
+        ns_tile_passed(sync, T, nb.tile, (unsigned)(2 * kNsGroups * K));
+    }
 }
 
 // ---- bwd_b: every parameter gradient of critic k = blockIdx.y.  blocks [0, 36): dW0 tiles and hidden-layer vectors from
@@ -1180,7 +1288,7 @@ int to_args(const rpo_split_update* u, unsigned need, SplitArgs& a, CartConsts& 
     a.rollout_ctrl = u->rollout_ctrl; a.rollout_stats = u->rollout_stats; a.rollout_stats_cap = u->rollout_stats_cap;
     a.prep_step = u->prep_step; a.prep_beta1 = u->prep_beta1; a.prep_beta2 = u->prep_beta2; a.clock_out = u->clock_out;
     a.gradmax_reset = u->gradmax_reset; a.gradmax_reset2 = u->gradmax_reset2; a.updates_out = u->updates_out;
-    a.part_pol = u->part_pol;
+    a.part_pol = u->part_pol; a.tile_sync = u->tile_sync;
     for (int j = 0; j < 3; ++j) { a.prep2_step[j] = u->prep2_step[j]; a.prep2_beta1[j] = u->prep2_beta1[j]; a.prep2_beta2[j] = u->prep2_beta2[j]; }
     return 0;
 }
@@ -1219,6 +1327,30 @@ int rpo_split_critic_fwd_b(const rpo_split_update* u, void* stream) {
         if (!a.next_actions) return RPO_ERR_NULL;
         hipLaunchKernelGGL((split_critic_fwd_b_kernel<PendRow, 0>), grid, dim3(kNsThreads), 0, (hipStream_t)stream, a, c);
     }
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_xcc_probe(int gx, int gy, int gz, int threads, int* out, void* stream) {
+    if (gx <= 0 || gy <= 0 || gz <= 0 || threads <= 0 || threads > 1024) return RPO_ERR_ARG;
+    if (!out) return RPO_ERR_NULL;
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(gx, gy, gz), dim3(threads), 0, (hipStream_t)stream, out);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_split_critic_front(const rpo_split_update* u, void* stream) {
+    SplitArgs a; CartConsts c;
+    if (!u || u->env != 0) return RPO_ERR_ARG;
+    if (int e = to_args(u, 1u | 2u | 4u, a, c)) return e;
+    const int K = a.twin ? 2 : 1;
+    if (!a.rows || !a.batch_out || !a.ctrl || !a.part_pi || !a.tile_sync || a.cap_steps <= 0 || a.n_envs <= 0) return RPO_ERR_NULL;
+    if (a.rollout_ctrl && a.rollout_stats && a.rollout_stats_cap <= 0) return RPO_ERR_ARG;
+    if ((a.twin && !a.logp) || a.max_steps < 0 || !a.loss_partial) return RPO_ERR_NULL;
+    for (int k = 0; k < K; ++k)
+        if (!a.part_q[k] || !a.x0[k] || !a.h1[k] || !a.part_qn[k] || !a.dq[k] || !a.dx0[k]) return RPO_ERR_NULL;
+    const dim3 grid(kNsGroups, (a.B + kRows - 1) / kRows, 1 + 3 * K);
+    hipLaunchKernelGGL(split_critic_front_kernel<CartRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c);
     RPO_LAUNCH_CHECK();
     return 0;
 }

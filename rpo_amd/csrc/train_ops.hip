@@ -98,6 +98,22 @@ __device__ __forceinline__ void adam_body(const AdamArgs& p) {
             p.target[i] = p.target[i] * (1.0f - p.tau) + p.param[i] * p.tau;
         return;
     }
+    // The element's operands are requested FIRST: the step counter / cached corrections / gradmax slots below are each a
+    // memory round trip of their own (written by the launch before, usually by another XCD), and with the loads behind them
+    // the launch was five dependent round trips long (4.8 us in the chain for 138 KB); now they all fly together.
+    const long long i0 = (long long)blockIdx.x * RPO_BLOCK + threadIdx.x, stride = (long long)gridDim.x * RPO_BLOCK;
+    float g0 = 0.0f, w0 = 0.0f, m0 = 0.0f, v0 = 0.0f, t0 = 0.0f, t20 = 0.0f;
+    if (i0 < p.n) {
+        g0 = p.grad[i0]; w0 = p.param[i0]; m0 = p.m[i0]; v0 = p.v[i0];
+        if (p.target) t0 = p.target[i0];
+        if (p.target2 && i0 < p.n2) t20 = p.target2[i0];
+    }
+    asm volatile("" ::: "memory");                          // keeps the requests above this line (the compiler sinks them otherwise)
+    float gm = 0.0f;                                        // the norm is the maximum over the slots (RPO_GRADMAX_SLOTS)
+    if (p.clip_thres > 0.0f) {
+#pragma unroll
+        for (int j = 0; j < RPO_GRADMAX_SLOTS; ++j) gm = fmaxf(gm, p.gradmax[j * (RPO_GRADMAX_LEN / RPO_GRADMAX_SLOTS)]);
+    }
     // torch.optim.Adam (single-tensor path): bias corrections in double like torch's Python floats.  The two double-
     // precision pow() calls are ~1 us of every thread's critical path, so the workgroup that finishes a step last leaves
     // the corrections of the NEXT step behind the arrival word (step_dev + 4: {1 - beta1^t, sqrt(1 - beta2^t)} as doubles,
@@ -111,30 +127,30 @@ __device__ __forceinline__ void adam_body(const AdamArgs& p) {
     }
     const float step_size = (float)((double)p.lr / bc1);
     const float bc2_sqrt = (float)bc2s;
-    float coef = 1.0f;
-    if (p.clip_thres > 0.0f) {   // clip_grad_norm_(..., norm_type=inf): clip_coef clamped to 1, always applied
-        float gm = 0.0f;                                    // the norm is the maximum over the slots (RPO_GRADMAX_SLOTS)
-#pragma unroll
-        for (int j = 0; j < RPO_GRADMAX_SLOTS; ++j) gm = fmaxf(gm, p.gradmax[j * (RPO_GRADMAX_LEN / RPO_GRADMAX_SLOTS)]);
-        coef = fminf(p.clip_thres / (gm + 1e-6f), 1.0f);
-    }
+    // clip_grad_norm_(..., norm_type=inf): clip_coef clamped to 1, always applied
+    const float coef = p.clip_thres > 0.0f ? fminf(p.clip_thres / (gm + 1e-6f), 1.0f) : 1.0f;
     const float omb1 = 1.0f - p.beta1, omb2 = 1.0f - p.beta2;
-    for (long long i = (long long)blockIdx.x * RPO_BLOCK + threadIdx.x; i < p.n; i += (long long)gridDim.x * RPO_BLOCK) {
-        float g = p.grad[i] * coef;
+    for (long long i = i0; i < p.n; i += stride) {
+        if (i != i0) {
+            g0 = p.grad[i]; w0 = p.param[i]; m0 = p.m[i]; v0 = p.v[i];
+            if (p.target) t0 = p.target[i];
+            if (p.target2 && i < p.n2) t20 = p.target2[i];
+        }
+        float g = g0 * coef;
         if (p.zero_grad) p.grad[i] = 0.0f;            // the gradient is consumed: the next backward accumulates from zero
         else if (p.clip_thres > 0.0f) p.grad[i] = g;  // clip_grad_norm_ scales the gradients in place
         if (p.maximize) g = -g;
-        float w = p.param[i];
+        float w = w0;
         if (p.weight_decay != 0.0f) g += p.weight_decay * w;
-        float m = p.m[i], v = p.v[i];
+        float m = m0, v = v0;
         m = m + (g - m) * omb1;                       // exp_avg.lerp_(grad, 1 - beta1)
         v = v * p.beta2 + omb2 * g * g;               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
         const float denom = sqrtf(v) / bc2_sqrt + p.eps;
         w = w - step_size * (m / denom);              // param.addcdiv_(exp_avg, denom, value=-step_size)
         if (p.clamp_min0) w = fmaxf(w, 0.0f);         // DualAdam, model/dual.py:41-43
         p.param[i] = w; p.m[i] = m; p.v[i] = v;
-        if (p.target) p.target[i] = p.target[i] * (1.0f - p.tau) + w * p.tau;   // soft_update, ddpg_pa.py:77-86
-        if (p.target2 && i < p.n2) p.target2[i] = p.target2[i] * (1.0f - p.tau) + w * p.tau;
+        if (p.target) p.target[i] = t0 * (1.0f - p.tau) + w * p.tau;   // soft_update, ddpg_pa.py:77-86
+        if (p.target2 && i < p.n2) p.target2[i] = t20 * (1.0f - p.tau) + w * p.tau;
     }
     if (p.prepared) return;
     __syncthreads();

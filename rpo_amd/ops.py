@@ -572,6 +572,28 @@ def mlp_split_supported(desc):
     return bool(_lib.load().rpo_mlp_split_supported(ctypes.byref(net)))
 
 
+_FRONT_OK = {}
+
+
+def front_launch_ok(batch, twin):
+    """Whether rpo_split_critic_front may be used for this batch: its workgroups hand data over through ONE XCD's L2, which
+    needs every workgroup of a row tile -- in every plane of the launch -- on the same XCD.  That is a property of the
+    dispatcher (workgroups go to the XCDs round-robin in block order), checked once per process and shape with a probe
+    launch of the same grid (rpo_xcc_probe)."""
+    key = (int(batch), bool(twin))
+    if key not in _FRONT_OK:
+        T, planes = (batch + 15) // 16, 1 + 3 * (2 if twin else 1)
+        out = torch.full((planes, T, 8), -1, dtype=torch.int32, device="cuda")
+        check(_lib.load().rpo_xcc_probe(8, T, planes, 256, _p(out, torch.int32), _stream()), "rpo_xcc_probe")
+        ids = out.cpu().view(planes, 8 * T)                       # linear block id inside a plane: x + 8 y
+        tile = torch.arange(8 * T) % T                            # ns_block: the row tile is the fastest index
+        ok = bool((ids >= 0).all())
+        for t in range(T):
+            ok = ok and len(torch.unique(ids[:, tile == t])) == 1
+        _FRONT_OK[key] = ok
+    return _FRONT_OK[key]
+
+
 def mlp_forward_split(calls):
     """Column-split hidden layers of 1..4 networks in one launch: calls = [(desc, s, a, part [8, n, 2], x0_save,
     h1_save), ...]; the head outputs are completed by ``mlp_split_head`` or by the consumer kernel's prologue."""
@@ -729,7 +751,8 @@ class _SplitUpdateStruct(ctypes.Structure):
          ("rollout_stats_cap", ctypes.c_int), ("prep_step", ctypes.c_void_p), ("prep_beta1", ctypes.c_float),
          ("prep_beta2", ctypes.c_float), ("clock_out", ctypes.c_void_p), ("gradmax_reset", ctypes.c_void_p),
          ("prep2_step", ctypes.c_void_p * 3), ("prep2_beta1", ctypes.c_float * 3), ("prep2_beta2", ctypes.c_float * 3),
-         ("gradmax_reset2", ctypes.c_void_p), ("updates_out", ctypes.c_void_p), ("part_pol", ctypes.c_void_p)])
+         ("gradmax_reset2", ctypes.c_void_p), ("updates_out", ctypes.c_void_p), ("part_pol", ctypes.c_void_p),
+         ("tile_sync", ctypes.c_void_p)])
 
 
 class _RolloutRiderStruct(ctypes.Structure):
@@ -772,7 +795,7 @@ class SplitUpdate(object):
     """Arguments of the column-split update stages (rpo_split_*), built once per trainer: every pointer refers to a static
     device buffer, so the struct is reused for every launch (and every hipGraph capture)."""
 
-    STAGES = ("critic_fwd_a", "critic_fwd_b", "critic_fwd_b_pol", "pend_head_project", "critic_bwd_a", "critic_bwd_b", "policy_a", "policy_b",
+    STAGES = ("critic_fwd_a", "critic_fwd_b", "critic_front", "critic_fwd_b_pol", "pend_head_project", "critic_bwd_a", "critic_bwd_b", "policy_a", "policy_b",
               "policy_c", "policy_d", "policy_e")
 
     def __init__(self, env_kernels, descs, twin, batch, fields):
@@ -803,7 +826,7 @@ class SplitUpdate(object):
         for k, v in fields.items():
             if isinstance(v, torch.Tensor):
                 dt = torch.int64 if k in ("idx_out", "idx_in", "ctrl", "rollout_ctrl", "clock_out", "updates_out") else \
-                    (torch.int32 if k in ("proj_iters", "prep_step") else torch.float32)
+                    (torch.int32 if k in ("proj_iters", "prep_step", "tile_sync") else torch.float32)
                 self._held[k] = v                                   # keeps the buffer alive while the struct points at it
                 setattr(self.st, k, _p(v, dt).value)
             else:

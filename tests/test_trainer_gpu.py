@@ -679,3 +679,30 @@ def test_policy_slabs_inside_the_critic_forward_launch(hip, algo, envname, monke
     assert torch.equal(a.agent.actor_optim.exp_avg_sq, b.agent.actor_optim.exp_avg_sq)
     assert torch.equal(a.buffer.rows, b.buffer.rows) and torch.equal(a.vec.internal, b.vec.internal)
     assert float(a.last_losses["actor"]) == float(b.last_losses["actor"])
+
+
+@pytest.mark.parametrize("algo,shared", [("ddpg", True), ("ddpg", False), ("sac", False)])
+def test_fused_front_launch_equals_separate_launches(hip, algo, shared, monkeypatch):
+    """CartSafe critic update: fwd_a, fwd_b and bwd_a as ONE launch (rpo_split_critic_front: the later stages wait inside the
+    launch for the 8 policy workgroups of their own row tile) leaves the same bits as the two launches, eagerly and
+    replayed from graph windows, no wait ever gives up and the arrival words are zero again after every launch."""
+    dev = torch.device("cuda")
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
+    monkeypatch.setenv("RPO_RIDE", "0")                        # (a riding rollout keeps the separate launches)
+    extra = dict(shared_param=shared) if algo == "ddpg" else {}
+    runs = {}
+    for front in ("0", "1"):
+        monkeypatch.setenv("RPO_FRONT", front)
+        for graph in (False, True):
+            runs[front, graph] = _run(algo, "cart", hip, dev, 45, 300, use_graph=graph, **extra)
+    a = runs["0", False]
+    for key in (("1", False), ("1", True), ("0", True)):
+        b = runs[key]
+        assert torch.equal(a.agent.flat.data, b.agent.flat.data), key
+        assert torch.equal(a.agent.critic_target_flat, b.agent.critic_target_flat), key
+        assert torch.equal(a.agent.critic_optim.exp_avg_sq, b.agent.critic_optim.exp_avg_sq), key
+        assert torch.equal(a.buffer.rows, b.buffer.rows) and torch.equal(a.vec.internal, b.vec.internal), key
+        assert float(a.last_losses["critic"]) == float(b.last_losses["critic"]), key
+    assert runs["1", True]._front_ok() and runs["1", False]._front_ok() and not runs["0", True]._front_ok()
+    sync = runs["1", True]._split_state()._held["tile_sync"]
+    assert int(sync.abs().sum()) == 0
