@@ -685,13 +685,15 @@ class RPOTrainerBase(object):
         if ride is not None:
             n, cut = self.vec.internal.shape[0], self._ride_cut
             ride.set(lane_begin=0, lane_end=cut)
-        # CartSafe, nothing riding: fwd_a, fwd_b and bwd_a are one launch (the later stages' workgroups wait inside it for the
+        # CartSafe: fwd_a, fwd_b and bwd_a are one launch (the later stages' workgroups wait inside it for the
         # workgroups of their own row tile, rpo_split_critic_front) -- same values, two launch boundaries less
         early = bool(actor_step) and ride is None and self.agent.flat.sizes[1] == 0 and getattr(self, "_actor_pipeline", False) \
             and bool(_env_int("RPO_POL_A_EARLY", 1))
-        if su.st.env == 0 and ride is None and not early and self._after_front is None and self._front_ok():
-            self._pol_a_done = False
-            su.run("critic_front")
+        if su.st.env == 0 and self._after_front is None and self._front_ok():
+            self._pol_a_done = early
+            if ride is not None:
+                ride.set(lane_begin=0, lane_end=n)              # the whole actor forward of the next step rides along
+            su.run("critic_front_pol" if early else "critic_front", rider=ride)   # (pol_a as one more plane, see below)
             self._critic_update_split_back(su, ride, bwd_a=False)
             return
         su.run("critic_fwd_a", rider=ride)                      # + actor forward of lanes [0, cut)

@@ -647,7 +647,7 @@ __device__ __forceinline__ float ns_weight_role(const Mlp& net, const MlpGrad& g
 constexpr int kBwdASmem = kRows * (256 + 4) + 16 + 4 * 16 * 16;
 
 template <class L>
-__device__ __forceinline__ void bwd_a_role(const SplitArgs& p, float* smem, int b, bool fused = false) {
+__device__ __forceinline__ void bwd_a_role(const SplitArgs& p, float* smem, int b, unsigned fused_consumers = 0u) {
     constexpr int EIN = 128, H = 256, LDH = H + 4;
     const int T = (p.B + kRows - 1) / kRows, B = p.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
@@ -664,11 +664,11 @@ __device__ __forceinline__ void bwd_a_role(const SplitArgs& p, float* smem, int 
 #pragma unroll
         for (int ks = 0; ks < H / 16; ++ks) wv[ks] = net.W0[(size_t)(jw + ks * 4 + lg) * EIN + e];
         const float w1a = net.W1[tid];                            // 256 threads = 256 hidden columns
-        if (fused) {
+        if (fused_consumers) {
             // fused front: the tile's critic slabs (fwd_a) and target slabs (fwd_b) of THIS launch: 8 arrivals per network
             const unsigned need = (unsigned)(2 * kNsGroups * (p.twin ? 2 : 1));
             ns_tile_wait(p.tile_sync + (T + tile) * kNsSyncStride, need, p.tile_sync + 3 * T * kNsSyncStride);
-            ns_tile_passed(p.tile_sync, T, tile, need);          // (as many consumers as arrivals: fwd_b's + bwd_a's workgroups)
+            ns_tile_passed(p.tile_sync, T, tile, fused_consumers);
         }
 #pragma unroll
         for (int r = 0; r < kRows; ++r) hv[r] = row0 + r < B ? p.h1[k][(size_t)(row0 + r) * H + tid] : 0.0f;
@@ -710,38 +710,6 @@ template <class L>
 __global__ __launch_bounds__(kThreads) void split_critic_bwd_a_kernel(SplitArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[kBwdASmem];
     bwd_a_role<L>(p, smem, blockIdx.x);
-}
-
-// ---- fused front of the critic update (CartSafe): fwd_a, fwd_b and bwd_a in ONE launch -- the three stages whose hand-overs
-//      stay inside a row tile.  grid (8, T, 1 + 3 K) of 256-thread workgroups (bwd_a's shape; the forward roles use two of
-//      the four waves, the other two leave at once):
-//        planes [0, 1 + K)          fwd_a's roles; the policy arrives at the tile's word 0, the critics at word 1
-//        planes [1 + K, 1 + 2 K)    fwd_b's target critics: wait for word 0 == 8, arrive at word 1
-//        planes [1 + 2 K, 1 + 3 K)  bwd_a of critic k: waits for word 1 == 16 K behind its W0 requests
-//      Same code, same values as the three launches.
-template <class L>
-__global__ __launch_bounds__(kThreads) void split_critic_front_kernel(SplitArgs p, CartConsts c) {
-    __shared__ __attribute__((aligned(16))) float smem[kBwdASmem];
-    static_assert(sizeof(NsLds<128>) + sizeof(float4) * kRows * L::CH <= sizeof(float) * kBwdASmem, "forward roles fit");
-    static_assert(sizeof(NsLds<128>) % 16 == 0, "tile alignment");
-    const int K = p.twin ? 2 : 1, T = (int)gridDim.y, z = (int)blockIdx.z;
-    if (z >= 1 + 2 * K) {
-        bwd_a_role<L>(p, smem, (z - 1 - 2 * K) * T * kNsGroups + (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y, true);
-        return;
-    }
-    if (threadIdx.x >= kNsThreads) return;                       // (whole waves: the barriers below count the two that stay)
-    NsLds<128>& lds = *reinterpret_cast<NsLds<128>*>(smem);
-    float4* tile = reinterpret_cast<float4*>(reinterpret_cast<char*>(smem) + sizeof(NsLds<128>));
-    const NsBlock nb = ns_block();
-    unsigned* sync = p.tile_sync;
-    if (z < 1 + K) {
-        fwd_a_role<L>(p, lds, tile, nb.tile * kRows, nb.g, z);
-        ns_tile_arrive(sync + ((z == 0 ? 0 : T) + nb.tile) * kNsSyncStride);
-    } else {
-        fwd_b_role<L, 1>(p, c, lds, tile, nb.tile * kRows, nb.g, z - 1 - K, sync + nb.tile * kNsSyncStride, (unsigned)kNsGroups);
-        ns_tile_arrive(sync + (T + nb.tile) * kNsSyncStride);
-        ns_tile_passed(sync, T, nb.tile, (unsigned)(2 * kNsGroups * K));
-    }
 }
 
 // ---- bwd_b: every parameter gradient of critic k = blockIdx.y.  blocks [0, 36): dW0 tiles and hidden-layer vectors from
@@ -899,9 +867,14 @@ __device__ __forceinline__ float explore_clip(float ap_det, float eps_t, float e
 __device__ __forceinline__ float* pol_part(const SplitArgs& p) { return p.part_pol ? p.part_pol : p.part_pi; }
 
 template <class L>
-__device__ __forceinline__ void pol_a_role(const SplitArgs& p, NsLds<128>& lds, float4* tile, int row0, int g) {
+__device__ __forceinline__ void pol_a_role(const SplitArgs& p, NsLds<128>& lds, float4* tile, int row0, int g,
+                                           unsigned* wait_word = nullptr, unsigned wait_need = 0u) {
     NsWeights<128> w;
     ns_load_weights<128, 256>(p.actor, g, w);
+    if (wait_word) {                                             // fused front: the tile's gathered rows of THIS launch
+        const int T = (p.B + kRows - 1) / kRows;
+        ns_tile_wait(wait_word, wait_need, p.tile_sync + 3 * T * kNsSyncStride);
+    }
     ns_load_tile<L>(p, tile, row0);
     __syncthreads();
     ns_stage<L>(lds, reinterpret_cast<const float*>(tile), false, false);
@@ -928,6 +901,63 @@ __global__ __launch_bounds__(kNsThreads) void split_critic_fwd_b_pol_kernel(Spli
     const NsBlock nb = ns_block();
     if ((int)blockIdx.z < K) fwd_b_role<L, PROJ>(p, c, lds, tile, nb.tile * kRows, nb.g, blockIdx.z);
     else pol_a_role<L>(p, lds, tile, nb.tile * kRows, nb.g);
+}
+
+// ---- fused front of the critic update (CartSafe): fwd_a, fwd_b and bwd_a in ONE launch -- the three stages whose hand-overs
+//      stay inside a row tile.  grid (8, T, planes) of 256-thread workgroups (bwd_a's shape; the forward roles use two of the
+//      four waves, the other two leave at once):
+//        planes [0, 1 + K)          fwd_a's roles; the policy arrives at the tile's word 0, the critics at word 1
+//        planes [1 + K, 1 + 2 K)    fwd_b's target critics: wait for word 0 == 8, arrive at word 1
+//        planes [1 + 2 K, 1 + 3 K)  bwd_a of critic k: waits for word 1 == 16 K behind its W0 requests
+//        plane  1 + 3 K (pol = 1)   pol_a of a policy iteration without a shared embedding (see fwd_b_pol): waits for word 0
+//      Same code, same values as the launches it replaces.  Returns false for planes beyond its own.
+template <class L>
+__device__ __forceinline__ bool front_role(const SplitArgs& p, const CartConsts& c, float* smem, int pol) {
+    const int K = p.twin ? 2 : 1, T = (int)gridDim.y, z = (int)blockIdx.z;
+    if (z > 3 * K + pol) return false;
+    const unsigned consumers = (unsigned)(kNsGroups * (2 * K + pol));
+    if (z >= 1 + 2 * K && z < 1 + 3 * K) {
+        bwd_a_role<L>(p, smem, (z - 1 - 2 * K) * T * kNsGroups + (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y, consumers);
+        return true;
+    }
+    if (threadIdx.x >= kNsThreads) return true;                  // (whole waves: the barriers below count the two that stay)
+    NsLds<128>& lds = *reinterpret_cast<NsLds<128>*>(smem);
+    float4* tile = reinterpret_cast<float4*>(reinterpret_cast<char*>(smem) + sizeof(NsLds<128>));
+    const NsBlock nb = ns_block();
+    unsigned* sync = p.tile_sync;
+    if (z < 1 + K) {
+        fwd_a_role<L>(p, lds, tile, nb.tile * kRows, nb.g, z);
+        ns_tile_arrive(sync + ((z == 0 ? 0 : T) + nb.tile) * kNsSyncStride);
+    } else if (z < 1 + 2 * K) {
+        fwd_b_role<L, 1>(p, c, lds, tile, nb.tile * kRows, nb.g, z - 1 - K, sync + nb.tile * kNsSyncStride, (unsigned)kNsGroups);
+        ns_tile_arrive(sync + (T + nb.tile) * kNsSyncStride);
+        ns_tile_passed(sync, T, nb.tile, consumers);
+    } else {
+        pol_a_role<L>(p, lds, tile, nb.tile * kRows, nb.g, sync + nb.tile * kNsSyncStride, (unsigned)kNsGroups);
+        ns_tile_passed(sync, T, nb.tile, consumers);
+    }
+    return true;
+}
+
+constexpr int kFrontSmem = kBwdASmem;
+static_assert(sizeof(NsLds<128>) + sizeof(float4) * kRows * 6 <= sizeof(float) * kFrontSmem, "forward roles fit");
+static_assert(sizeof(NsLds<128>) % 16 == 0, "tile alignment");
+
+template <class L>
+__global__ __launch_bounds__(kThreads) void split_critic_front_kernel(SplitArgs p, CartConsts c, int pol) {
+    __shared__ __attribute__((aligned(16))) float smem[kFrontSmem];
+    front_role<L>(p, c, smem, pol);
+}
+
+// front + the actor forward of lanes [lane0, lane1) of the NEXT vector step (ride_forward) in the planes behind its own
+template <class L>
+__global__ __launch_bounds__(kThreads) void split_critic_front_ride_kernel(SplitArgs p, CartConsts c, RideArgs<typename L::Env> r) {
+    __shared__ __attribute__((aligned(16))) float smem[kFrontSmem];
+    if (front_role<L>(p, c, smem, 0)) return;
+    if (threadIdx.x >= kNsThreads) return;
+    const NsBlock nb = ns_block();
+    const int own = 1 + 3 * (p.twin ? 2 : 1);
+    ride_forward<typename L::Env>(r, *reinterpret_cast<NsLds<128>*>(smem), ((int)blockIdx.z - own) * (int)gridDim.y + nb.tile, nb.g);
 }
 
 // ---- pol_b: head -> exploration noise + clip (RPODDPG) / rsample + clip + log pi (RPOSAC) -> Complete -> Lagrangian row
@@ -1339,21 +1369,33 @@ int rpo_xcc_probe(int gx, int gy, int gz, int threads, int* out, void* stream) {
     return 0;
 }
 
-int rpo_split_critic_front(const rpo_split_update* u, void* stream) {
-    SplitArgs a; CartConsts c;
+static int front_args(const rpo_split_update* u, unsigned need, SplitArgs& a, CartConsts& c) {
     if (!u || u->env != 0) return RPO_ERR_ARG;
-    if (int e = to_args(u, 1u | 2u | 4u, a, c)) return e;
+    if (int e = to_args(u, 1u | 2u | 4u | need, a, c)) return e;
     const int K = a.twin ? 2 : 1;
     if (!a.rows || !a.batch_out || !a.ctrl || !a.part_pi || !a.tile_sync || a.cap_steps <= 0 || a.n_envs <= 0) return RPO_ERR_NULL;
     if (a.rollout_ctrl && a.rollout_stats && a.rollout_stats_cap <= 0) return RPO_ERR_ARG;
     if ((a.twin && !a.logp) || a.max_steps < 0 || !a.loss_partial) return RPO_ERR_NULL;
     for (int k = 0; k < K; ++k)
         if (!a.part_q[k] || !a.x0[k] || !a.h1[k] || !a.part_qn[k] || !a.dq[k] || !a.dx0[k]) return RPO_ERR_NULL;
-    const dim3 grid(kNsGroups, (a.B + kRows - 1) / kRows, 1 + 3 * K);
-    hipLaunchKernelGGL(split_critic_front_kernel<CartRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c);
+    return 0;
+}
+
+static int front_launch(const rpo_split_update* u, int pol, void* stream) {
+    SplitArgs a; CartConsts c;
+    if (int e = front_args(u, pol ? 32u : 0u, a, c)) return e;
+    if (pol) {
+        if (u->shared_embedding) return RPO_ERR_ARG;              // the critic step would change the policy's first layer
+        if (!a.part_pol || !a.x0_a || !a.h1_a) return RPO_ERR_NULL;
+    }
+    const dim3 grid(kNsGroups, (a.B + kRows - 1) / kRows, 1 + 3 * (a.twin ? 2 : 1) + pol);
+    hipLaunchKernelGGL(split_critic_front_kernel<CartRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c, pol);
     RPO_LAUNCH_CHECK();
     return 0;
 }
+
+int rpo_split_critic_front(const rpo_split_update* u, void* stream) { return front_launch(u, 0, stream); }
+int rpo_split_critic_front_pol(const rpo_split_update* u, void* stream) { return front_launch(u, 1, stream); }
 
 int rpo_split_critic_fwd_b_pol(const rpo_split_update* u, void* stream) {
     SplitArgs a; CartConsts c;
@@ -1516,6 +1558,20 @@ int rpo_split_critic_fwd_b_ride(const rpo_split_update* u, const rpo_rollout_rid
         hipLaunchKernelGGL((split_critic_fwd_b_ride_kernel<PendRow, 0>), grid, dim3(kNsThreads), 0, (hipStream_t)stream, a, c,
                            ride_args<PendEnv>(a, r));
     }
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_split_critic_front_ride(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream) {
+    if (int e = ride_check(u, r)) return e;
+    if (int e = ride_range(r)) return e;
+    SplitArgs a; CartConsts c;
+    if (int e = front_args(u, 32u, a, c)) return e;
+    const int K = a.twin ? 2 : 1, T = (a.B + kRows - 1) / kRows;
+    const int lane_wgs = (r->lane_end - r->lane_begin + kRows - 1) / kRows;
+    const dim3 grid(kNsGroups, T, 1 + 3 * K + (lane_wgs + T - 1) / T);
+    hipLaunchKernelGGL(split_critic_front_ride_kernel<CartRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c,
+                       ride_args<CartEnv>(a, r));
     RPO_LAUNCH_CHECK();
     return 0;
 }

@@ -582,7 +582,7 @@ def front_launch_ok(batch, twin):
     launch of the same grid (rpo_xcc_probe)."""
     key = (int(batch), bool(twin))
     if key not in _FRONT_OK:
-        T, planes = (batch + 15) // 16, 1 + 3 * (2 if twin else 1)
+        T, planes = (batch + 15) // 16, 1 + 3 * (2 if twin else 1) + 1          # (+ the policy plane / the first riding plane)
         out = torch.full((planes, T, 8), -1, dtype=torch.int32, device="cuda")
         check(_lib.load().rpo_xcc_probe(8, T, planes, 256, _p(out, torch.int32), _stream()), "rpo_xcc_probe")
         ids = out.cpu().view(planes, 8 * T)                       # linear block id inside a plane: x + 8 y
@@ -795,7 +795,7 @@ class SplitUpdate(object):
     """Arguments of the column-split update stages (rpo_split_*), built once per trainer: every pointer refers to a static
     device buffer, so the struct is reused for every launch (and every hipGraph capture)."""
 
-    STAGES = ("critic_fwd_a", "critic_fwd_b", "critic_front", "critic_fwd_b_pol", "pend_head_project", "critic_bwd_a", "critic_bwd_b", "policy_a", "policy_b",
+    STAGES = ("critic_fwd_a", "critic_fwd_b", "critic_front", "critic_front_pol", "critic_fwd_b_pol", "pend_head_project", "critic_bwd_a", "critic_bwd_b", "policy_a", "policy_b",
               "policy_c", "policy_d", "policy_e")
 
     def __init__(self, env_kernels, descs, twin, batch, fields):

@@ -681,14 +681,16 @@ def test_policy_slabs_inside_the_critic_forward_launch(hip, algo, envname, monke
     assert float(a.last_losses["actor"]) == float(b.last_losses["actor"])
 
 
-@pytest.mark.parametrize("algo,shared", [("ddpg", True), ("ddpg", False), ("sac", False)])
-def test_fused_front_launch_equals_separate_launches(hip, algo, shared, monkeypatch):
+@pytest.mark.parametrize("algo,shared,ride", [("ddpg", True, "0"), ("ddpg", False, "0"), ("sac", False, "0"), ("sac", False, "1"),
+                                              ("ddpg", False, "1")])
+def test_fused_front_launch_equals_separate_launches(hip, algo, shared, ride, monkeypatch):
     """CartSafe critic update: fwd_a, fwd_b and bwd_a as ONE launch (rpo_split_critic_front: the later stages wait inside the
-    launch for the 8 policy workgroups of their own row tile) leaves the same bits as the two launches, eagerly and
-    replayed from graph windows, no wait ever gives up and the arrival words are zero again after every launch."""
+    launch for the workgroups of their own row tile; _pol: pol_a of a policy iteration as one more plane; _ride: the actor
+    forward of the next vector step in the planes behind) leaves the same bits as the separate launches, eagerly and replayed
+    from graph windows; no wait ever gives up and the arrival words are zero again after every launch."""
     dev = torch.device("cuda")
     monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
-    monkeypatch.setenv("RPO_RIDE", "0")                        # (a riding rollout keeps the separate launches)
+    monkeypatch.setenv("RPO_RIDE", ride)                       # (rides in the graph windows only)
     extra = dict(shared_param=shared) if algo == "ddpg" else {}
     runs = {}
     for front in ("0", "1"):
@@ -701,8 +703,10 @@ def test_fused_front_launch_equals_separate_launches(hip, algo, shared, monkeypa
         assert torch.equal(a.agent.flat.data, b.agent.flat.data), key
         assert torch.equal(a.agent.critic_target_flat, b.agent.critic_target_flat), key
         assert torch.equal(a.agent.critic_optim.exp_avg_sq, b.agent.critic_optim.exp_avg_sq), key
+        assert torch.equal(a.agent.nju.weight, b.agent.nju.weight), key
         assert torch.equal(a.buffer.rows, b.buffer.rows) and torch.equal(a.vec.internal, b.vec.internal), key
         assert float(a.last_losses["critic"]) == float(b.last_losses["critic"]), key
     assert runs["1", True]._front_ok() and runs["1", False]._front_ok() and not runs["0", True]._front_ok()
+    assert runs["1", True]._ride_ok(True) == (ride == "1")
     sync = runs["1", True]._split_state()._held["tile_sync"]
     assert int(sync.abs().sum()) == 0
