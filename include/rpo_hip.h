@@ -503,6 +503,10 @@ int rpo_split_critic_front(const rpo_split_update* u, void* stream);
 /* ... + rpo_split_policy_a as one more plane (policy iteration without a shared embedding, like rpo_split_critic_fwd_b_pol:
  * the caller then skips rpo_split_policy_a; requires part_pol) */
 int rpo_split_critic_front_pol(const rpo_split_update* u, void* stream);
+/* SpringPendulum-v0: rpo_split_critic_fwd_b + rpo_split_critic_bwd_a as ONE launch in the same way (the batch-coupled
+ * projection, rpo_split_pend_head_project, needs every row and keeps fwd_a a launch of its own); _pol: + rpo_split_policy_a. */
+int rpo_split_critic_mid(const rpo_split_update* u, void* stream);
+int rpo_split_critic_mid_pol(const rpo_split_update* u, void* stream);
 /* out[x + gx * (y + gy * z)] = the XCD (XCC_ID) workgroup (x, y, z) of a (gx, gy, gz) grid of `threads`-thread workgroups ran
  * on.  rpo_split_critic_front hands data from workgroup to workgroup through ONE XCD's L2; its caller checks with this probe
  * (same grid: 8, ceil(batch / 16), 1 + 3 K; 256 threads) that all workgroups of a row tile share an XCD. */
@@ -566,6 +570,8 @@ int rpo_split_critic_bwd_b_ride(const rpo_split_update* u, const rpo_rollout_rid
 /* CartSafe-v0: rpo_split_critic_front with the actor forward of lanes [lane_begin, lane_end) riding in the planes behind its
  * own (replaces fwd_a_ride + fwd_b_ride + bwd_a; bwd_b_ride follows with the lanes' step). */
 int rpo_split_critic_front_ride(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream);
+/* SpringPendulum-v0: rpo_split_critic_mid with riding planes (replaces fwd_b_ride + bwd_a). */
+int rpo_split_critic_mid_ride(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream);
 
 /* Backward of the same rows given dout [n, n_out] (two launches).  Parameter gradients are ACCUMULATED (+=) into
  * grad_host's buffers (the shared state embedding of shared_param=True receives contributions from two networks,

@@ -597,8 +597,7 @@ class RPOTrainerBase(object):
         else:
             fields.update(ap_det=b("act.ap_det", B))
         self._split_cache = be.SplitUpdate(k, descs, self.sac, B, fields)
-        self._front_cache = bool(_env_int("RPO_FRONT", 1)) and isinstance(k, be.CartSafeKernels) and \
-            hasattr(be, "front_launch_ok") and be.front_launch_ok(B, self.sac)
+        self._front_cache = bool(_env_int("RPO_FRONT", 1)) and hasattr(be, "front_launch_ok") and be.front_launch_ok(B, self.sac)
         self._split_loss = fields["loss_partial"]
         self._split_logp = (fields["logp"], b("pi.logp", B))          # log pi(a'|s') of the critic update | log pi(a|s)
         return self._split_cache
@@ -706,6 +705,10 @@ class RPOTrainerBase(object):
         # policy iteration without a shared embedding: the policy slabs on the batch states (pol_a) need nothing the critic
         # update produces -- they are an extra plane of fwd_b's launch instead of a launch behind the critic step
         self._pol_a_done = early
+        if su.st.env == 1 and self._front_ok():                 # SpringPendulum: fwd_b and bwd_a are one launch
+            su.run("critic_mid_pol" if early else "critic_mid", rider=ride)
+            self._critic_update_split_back(su, ride, bwd_a=False)
+            return
         su.run("critic_fwd_b_pol" if early else "critic_fwd_b", rider=ride)   # (+ actor forward of lanes [cut, n))
         self._critic_update_split_back(su, ride)
 

@@ -647,7 +647,8 @@ __device__ __forceinline__ float ns_weight_role(const Mlp& net, const MlpGrad& g
 constexpr int kBwdASmem = kRows * (256 + 4) + 16 + 4 * 16 * 16;
 
 template <class L>
-__device__ __forceinline__ void bwd_a_role(const SplitArgs& p, float* smem, int b, unsigned fused_consumers = 0u) {
+__device__ __forceinline__ void bwd_a_role(const SplitArgs& p, float* smem, int b, unsigned fused_consumers = 0u,
+                                           unsigned fused_need = 0u) {
     constexpr int EIN = 128, H = 256, LDH = H + 4;
     const int T = (p.B + kRows - 1) / kRows, B = p.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
@@ -665,9 +666,8 @@ __device__ __forceinline__ void bwd_a_role(const SplitArgs& p, float* smem, int 
         for (int ks = 0; ks < H / 16; ++ks) wv[ks] = net.W0[(size_t)(jw + ks * 4 + lg) * EIN + e];
         const float w1a = net.W1[tid];                            // 256 threads = 256 hidden columns
         if (fused_consumers) {
-            // fused front: the tile's critic slabs (fwd_a) and target slabs (fwd_b) of THIS launch: 8 arrivals per network
-            const unsigned need = (unsigned)(2 * kNsGroups * (p.twin ? 2 : 1));
-            ns_tile_wait(p.tile_sync + (T + tile) * kNsSyncStride, need, p.tile_sync + 3 * T * kNsSyncStride);
+            // fused front / mid: the tile's critic slabs (fwd_a) and / or target slabs (fwd_b) of THIS launch, 8 arrivals per network
+            ns_tile_wait(p.tile_sync + (T + tile) * kNsSyncStride, fused_need, p.tile_sync + 3 * T * kNsSyncStride);
             ns_tile_passed(p.tile_sync, T, tile, fused_consumers);
         }
 #pragma unroll
@@ -917,7 +917,8 @@ __device__ __forceinline__ bool front_role(const SplitArgs& p, const CartConsts&
     if (z > 3 * K + pol) return false;
     const unsigned consumers = (unsigned)(kNsGroups * (2 * K + pol));
     if (z >= 1 + 2 * K && z < 1 + 3 * K) {
-        bwd_a_role<L>(p, smem, (z - 1 - 2 * K) * T * kNsGroups + (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y, consumers);
+        bwd_a_role<L>(p, smem, (z - 1 - 2 * K) * T * kNsGroups + (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y, consumers,
+                      (unsigned)(2 * kNsGroups * K));
         return true;
     }
     if (threadIdx.x >= kNsThreads) return true;                  // (whole waves: the barriers below count the two that stay)
@@ -958,6 +959,47 @@ __global__ __launch_bounds__(kThreads) void split_critic_front_ride_kernel(Split
     const NsBlock nb = ns_block();
     const int own = 1 + 3 * (p.twin ? 2 : 1);
     ride_forward<typename L::Env>(r, *reinterpret_cast<NsLds<128>*>(smem), ((int)blockIdx.z - own) * (int)gridDim.y + nb.tile, nb.g);
+}
+
+// ---- SpringPendulum: the batch-coupled projection (one workgroup, every row) sits between fwd_a and fwd_b, so only fwd_b and
+//      bwd_a share a launch ("mid"): planes [0, K) fwd_b's target critics (arrive at word 1), [K, 2 K) bwd_a (waits for
+//      word 1 == 8 K), plane 2 K (pol = 1) pol_a (the gathered rows are an earlier launch's: no wait).
+template <class L>
+__device__ __forceinline__ bool mid_role(const SplitArgs& p, const CartConsts& c, float* smem, int pol) {
+    const int K = p.twin ? 2 : 1, T = (int)gridDim.y, z = (int)blockIdx.z;
+    if (z >= 2 * K + pol) return false;
+    if (z >= K && z < 2 * K) {
+        bwd_a_role<L>(p, smem, (z - K) * T * kNsGroups + (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y,
+                      (unsigned)(kNsGroups * K), (unsigned)(kNsGroups * K));
+        return true;
+    }
+    if (threadIdx.x >= kNsThreads) return true;
+    NsLds<128>& lds = *reinterpret_cast<NsLds<128>*>(smem);
+    float4* tile = reinterpret_cast<float4*>(reinterpret_cast<char*>(smem) + sizeof(NsLds<128>));
+    const NsBlock nb = ns_block();
+    if (z < K) {
+        fwd_b_role<L, 0>(p, c, lds, tile, nb.tile * kRows, nb.g, z);
+        ns_tile_arrive(p.tile_sync + (T + nb.tile) * kNsSyncStride);
+    } else {
+        pol_a_role<L>(p, lds, tile, nb.tile * kRows, nb.g);
+    }
+    return true;
+}
+
+template <class L>
+__global__ __launch_bounds__(kThreads) void split_critic_mid_kernel(SplitArgs p, CartConsts c, int pol) {
+    __shared__ __attribute__((aligned(16))) float smem[kFrontSmem];
+    mid_role<L>(p, c, smem, pol);
+}
+
+template <class L>
+__global__ __launch_bounds__(kThreads) void split_critic_mid_ride_kernel(SplitArgs p, CartConsts c, RideArgs<typename L::Env> r) {
+    __shared__ __attribute__((aligned(16))) float smem[kFrontSmem];
+    if (mid_role<L>(p, c, smem, 0)) return;
+    if (threadIdx.x >= kNsThreads) return;
+    const NsBlock nb = ns_block();
+    ride_forward<typename L::Env>(r, *reinterpret_cast<NsLds<128>*>(smem), ((int)blockIdx.z - 2 * (p.twin ? 2 : 1)) * (int)gridDim.y + nb.tile,
+                                  nb.g);
 }
 
 // ---- pol_b: head -> exploration noise + clip (RPODDPG) / rsample + clip + log pi (RPOSAC) -> Complete -> Lagrangian row
@@ -1397,6 +1439,32 @@ static int front_launch(const rpo_split_update* u, int pol, void* stream) {
 int rpo_split_critic_front(const rpo_split_update* u, void* stream) { return front_launch(u, 0, stream); }
 int rpo_split_critic_front_pol(const rpo_split_update* u, void* stream) { return front_launch(u, 1, stream); }
 
+static int mid_args(const rpo_split_update* u, unsigned need, SplitArgs& a, CartConsts& c) {
+    if (!u || u->env != 1) return RPO_ERR_ARG;
+    if (int e = to_args(u, 2u | 4u | need, a, c)) return e;
+    const int K = a.twin ? 2 : 1;
+    if (!a.batch_out || !a.ctrl || !a.next_actions || !a.tile_sync || !a.loss_partial || (a.twin && !a.logp)) return RPO_ERR_NULL;
+    for (int k = 0; k < K; ++k)
+        if (!a.part_q[k] || !a.x0[k] || !a.h1[k] || !a.part_qn[k] || !a.dq[k] || !a.dx0[k]) return RPO_ERR_NULL;
+    return 0;
+}
+
+static int mid_launch(const rpo_split_update* u, int pol, void* stream) {
+    SplitArgs a; CartConsts c;
+    if (int e = mid_args(u, pol ? 32u : 0u, a, c)) return e;
+    if (pol) {
+        if (u->shared_embedding) return RPO_ERR_ARG;
+        if (!a.part_pol || !a.x0_a || !a.h1_a) return RPO_ERR_NULL;
+    }
+    const dim3 grid(kNsGroups, (a.B + kRows - 1) / kRows, 2 * (a.twin ? 2 : 1) + pol);
+    hipLaunchKernelGGL(split_critic_mid_kernel<PendRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c, pol);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_split_critic_mid(const rpo_split_update* u, void* stream) { return mid_launch(u, 0, stream); }
+int rpo_split_critic_mid_pol(const rpo_split_update* u, void* stream) { return mid_launch(u, 1, stream); }
+
 int rpo_split_critic_fwd_b_pol(const rpo_split_update* u, void* stream) {
     SplitArgs a; CartConsts c;
     if (int e = to_args(u, (u && u->env == 0 ? 1u : 0u) | 4u | 32u, a, c)) return e;
@@ -1572,6 +1640,20 @@ int rpo_split_critic_front_ride(const rpo_split_update* u, const rpo_rollout_rid
     const dim3 grid(kNsGroups, T, 1 + 3 * K + (lane_wgs + T - 1) / T);
     hipLaunchKernelGGL(split_critic_front_ride_kernel<CartRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c,
                        ride_args<CartEnv>(a, r));
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_split_critic_mid_ride(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream) {
+    if (int e = ride_check(u, r)) return e;
+    if (int e = ride_range(r)) return e;
+    SplitArgs a; CartConsts c;
+    if (int e = mid_args(u, 32u, a, c)) return e;
+    const int K = a.twin ? 2 : 1, T = (a.B + kRows - 1) / kRows;
+    const int lane_wgs = (r->lane_end - r->lane_begin + kRows - 1) / kRows;
+    const dim3 grid(kNsGroups, T, 2 * K + (lane_wgs + T - 1) / T);
+    hipLaunchKernelGGL(split_critic_mid_ride_kernel<PendRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c,
+                       ride_args<PendEnv>(a, r));
     RPO_LAUNCH_CHECK();
     return 0;
 }

@@ -795,7 +795,7 @@ class SplitUpdate(object):
     """Arguments of the column-split update stages (rpo_split_*), built once per trainer: every pointer refers to a static
     device buffer, so the struct is reused for every launch (and every hipGraph capture)."""
 
-    STAGES = ("critic_fwd_a", "critic_fwd_b", "critic_front", "critic_front_pol", "critic_fwd_b_pol", "pend_head_project", "critic_bwd_a", "critic_bwd_b", "policy_a", "policy_b",
+    STAGES = ("critic_fwd_a", "critic_fwd_b", "critic_front", "critic_front_pol", "critic_mid", "critic_mid_pol", "critic_fwd_b_pol", "pend_head_project", "critic_bwd_a", "critic_bwd_b", "policy_a", "policy_b",
               "policy_c", "policy_d", "policy_e")
 
     def __init__(self, env_kernels, descs, twin, batch, fields):

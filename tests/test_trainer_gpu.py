@@ -681,13 +681,16 @@ def test_policy_slabs_inside_the_critic_forward_launch(hip, algo, envname, monke
     assert float(a.last_losses["actor"]) == float(b.last_losses["actor"])
 
 
-@pytest.mark.parametrize("algo,shared,ride", [("ddpg", True, "0"), ("ddpg", False, "0"), ("sac", False, "0"), ("sac", False, "1"),
-                                              ("ddpg", False, "1")])
-def test_fused_front_launch_equals_separate_launches(hip, algo, shared, ride, monkeypatch):
+@pytest.mark.parametrize("algo,envname,shared,ride", [
+    ("ddpg", "cart", True, "0"), ("ddpg", "cart", False, "0"), ("sac", "cart", False, "0"), ("sac", "cart", False, "1"),
+    ("ddpg", "cart", False, "1"), ("sac", "pendulum", False, "0"), ("sac", "pendulum", False, "1"), ("ddpg", "pendulum", False, "1"),
+    ("ddpg", "pendulum", True, "0")])
+def test_fused_front_launch_equals_separate_launches(hip, algo, envname, shared, ride, monkeypatch):
     """CartSafe critic update: fwd_a, fwd_b and bwd_a as ONE launch (rpo_split_critic_front: the later stages wait inside the
     launch for the workgroups of their own row tile; _pol: pol_a of a policy iteration as one more plane; _ride: the actor
     forward of the next vector step in the planes behind) leaves the same bits as the separate launches, eagerly and replayed
-    from graph windows; no wait ever gives up and the arrival words are zero again after every launch."""
+    from graph windows; no wait ever gives up and the arrival words are zero again after every launch.  SpringPendulum: fwd_b
+    and bwd_a (rpo_split_critic_mid*; the batch-coupled projection in between keeps fwd_a a launch of its own)."""
     dev = torch.device("cuda")
     monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
     monkeypatch.setenv("RPO_RIDE", ride)                       # (rides in the graph windows only)
@@ -696,7 +699,7 @@ def test_fused_front_launch_equals_separate_launches(hip, algo, shared, ride, mo
     for front in ("0", "1"):
         monkeypatch.setenv("RPO_FRONT", front)
         for graph in (False, True):
-            runs[front, graph] = _run(algo, "cart", hip, dev, 45, 300, use_graph=graph, **extra)
+            runs[front, graph] = _run(algo, envname, hip, dev, 45, 300, use_graph=graph, **extra)
     a = runs["0", False]
     for key in (("1", False), ("1", True), ("0", True)):
         b = runs[key]
