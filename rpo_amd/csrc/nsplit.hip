@@ -293,20 +293,23 @@ __device__ __forceinline__ void fwd_b_role(const SplitArgs& p, const CartConsts&
     const Mlp& net = p.critic_target[k];
     NsWeights<128> w;
     ns_load_weights<128, 256>(net, g, w);
-    if (wait_word) {                                             // fused front: the tile's policy slabs of THIS launch
-        const int T = (p.B + kRows - 1) / kRows;
-        ns_tile_wait(wait_word, wait_need, p.tile_sync + 3 * T * kNsSyncStride);
-    }
-    ns_load_tile<L>(p, tile, row0);
+    const long long t = p.ctrl[RPO_CTRL_T];
+    // fused front: the rows are gathered HERE too (same draw, same rows as fwd_a's workgroups of this launch, which publish
+    // them) -- the gather and the staging run while the tile's policy slabs are still being computed; only the head needs them
+    if (wait_word) ns_sample<L>(p, tile, row0, t, false);
+    else ns_load_tile<L>(p, tile, row0);
     __syncthreads();
     ns_stage<L>(lds, reinterpret_cast<const float*>(tile), true, false);
     __syncthreads();                                             // (ns_stage zeroed in_a: order it before the writes below)
+    if (wait_word) {                                             // the tile's policy slabs of THIS launch
+        const int T = (p.B + kRows - 1) / kRows;
+        ns_tile_wait(wait_word, wait_need, p.tile_sync + 3 * T * kNsSyncStride);
+    }
     if (tid < kRows) {
         const int i = row0 + tid;
         float2 act = make_float2(0.0f, 0.0f);
         if (i < p.B) {
             if (PROJ) {
-                const long long t = p.ctrl[RPO_CTRL_T];
                 float logp = 0.0f;
                 const float ap = ns_policy_head(p, i, t, &logp);
                 rpo_cart_dev::ActArgs a{};
