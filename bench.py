@@ -231,6 +231,12 @@ def launch_models(tr, workload):
         "split_critic_fwd_a_ride": ("mfma", n, (B * (fa + twin * fc) + (n // 2) * fa) / float(n)),
         "split_critic_fwd_b_ride": ("mfma", n, (B * twin * fc + (n - n // 2) * fa) / float(n)),
         "split_critic_bwd_b_ride": ("hbm", n, step_bytes),
+        # fused front (fwd_a + fwd_b + bwd_a in one launch; SpringPendulum "mid": fwd_b + bwd_a), with pol_a / the whole actor
+        # forward of the next step as extra planes
+        "split_critic_front": ("mfma", B, fa + 4 * twin * fc), "split_critic_front_pol": ("mfma", B, 2 * fa + 4 * twin * fc),
+        "split_critic_front_ride": ("mfma", n, (B * (fa + 4 * twin * fc) + n * fa) / float(n)),
+        "split_critic_mid": ("mfma", B, 3 * twin * fc), "split_critic_mid_pol": ("mfma", B, fa + 3 * twin * fc),
+        "split_critic_mid_ride": ("mfma", n, (B * 3 * twin * fc + (n - n // 2) * fa) / float(n)),
     }
     return m
 
@@ -362,6 +368,9 @@ KERNEL_OF = {
     "split_pend_head_project": "split_pend_head_project_kernel",
     "split_critic_fwd_a_ride": "split_critic_fwd_a_ride_kernel", "split_critic_fwd_b_ride": "split_critic_fwd_b_ride_kernel",
     "split_critic_bwd_b_ride": "split_critic_bwd_b_ride_kernel",
+    "split_critic_front": "split_critic_front_kernel", "split_critic_front_pol": "split_critic_front_kernel",
+    "split_critic_front_ride": "split_critic_front_ride_kernel", "split_critic_mid": "split_critic_mid_kernel",
+    "split_critic_mid_pol": "split_critic_mid_kernel", "split_critic_mid_ride": "split_critic_mid_ride_kernel",
 }
 
 

@@ -613,10 +613,13 @@ class RPOTrainerBase(object):
         crit_logp, pi_logp = self._split_logp
         su.set(noise_salt=_SALT_ACTOR, eps_in=noise_in, logp=pi_logp)
         early, self._pol_a_done = self._pol_a_done, False
-        if not early:                                             # (else: done inside fwd_b's launch of this iteration)
-            su.run("policy_a")
-        su.run("policy_b")
-        su.run("policy_c")
+        if self._front_ok():                                      # pol_a (unless done early), pol_b and pol_c as one launch
+            su.run("policy_front_bc" if early else "policy_front")
+        else:
+            if not early:                                         # (else: done inside fwd_b's launch of this iteration)
+                su.run("policy_a")
+            su.run("policy_b")
+            su.run("policy_c")
         self._zero_grads()
         opt = ag.actor_optim
         fuse_max = self._self_cleaning and not self.dist.on and opt.clip_thres and opt.clip_thres != float("inf")

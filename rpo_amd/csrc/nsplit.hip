@@ -1009,19 +1009,21 @@ __global__ __launch_bounds__(kThreads) void split_critic_mid_ride_kernel(SplitAr
 //      terms -> Q_k hidden slabs on (s, a_pi), pre-activations saved.  grid (row tiles, 8, critics); workgroup
 //      (tile, 0, 0) publishes the per-row outputs and the tile's Lagrangian partial sums.
 template <class ENV>
-__global__ __launch_bounds__(kNsThreads) void split_policy_b_kernel(SplitArgs p, CartConsts c) {
+__device__ __forceinline__ void pol_b_role(const SplitArgs& p, const CartConsts& c, NsLds<128>& lds, float4* tile, int tile_i, int g,
+                                           int k, unsigned* wait_word = nullptr, unsigned wait_need = 0u) {
     typedef typename ENV::L L;
-    __shared__ NsLds<128> lds;
-    __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
-    const NsBlock nb = ns_block();
-    const int row0 = nb.tile * kRows, g = nb.g, k = blockIdx.z, tid = threadIdx.x, B = p.B;
+    const int row0 = tile_i * kRows, tid = threadIdx.x, B = p.B;
     const Mlp& net = p.critic[k];
     NsWeights<128> w;
     ns_load_weights<128, 256>(net, g, w);
-    ns_load_tile<L>(p, tile, row0);
+    ns_load_tile<L>(p, tile, row0);                              // (gathered by the critic update: an earlier launch)
     __syncthreads();
     ns_stage<L>(lds, reinterpret_cast<const float*>(tile), false, false);
     __syncthreads();
+    if (wait_word) {                                             // fused policy front: the tile's policy slabs of THIS launch
+        const int T = (B + kRows - 1) / kRows;
+        ns_tile_wait(wait_word, wait_need, p.tile_sync + 3 * T * kNsSyncStride);
+    }
     const bool writer = g == 0 && k == 0;
     float vals[7] = {0, 0, 0, 0, 0, 0, 0};
     if (tid < kRows) {
@@ -1074,10 +1076,18 @@ __global__ __launch_bounds__(kNsThreads) void split_policy_b_kernel(SplitArgs p,
 #pragma unroll
         for (int q = 0; q < 7; ++q) {                                // (== rpo_wave_sum: only lanes 0..15 hold terms)
             const float sum = rpo_row16_sum_desc_lane0(vals[q]);
-            if (tid == 0) p.lag_partial[nb.tile * 8 + q] = sum;
+            if (tid == 0) p.lag_partial[tile_i * 8 + q] = sum;
         }
     }
     ns_hidden<128, 256>(net, w, lds, g, row0, B, p.part_q[k], p.x0[k], p.h1[k]);
+}
+
+template <class ENV>
+__global__ __launch_bounds__(kNsThreads) void split_policy_b_kernel(SplitArgs p, CartConsts c) {
+    __shared__ NsLds<128> lds;
+    __shared__ __attribute__((aligned(16))) float4 tile[kRows * ENV::L::CH];
+    const NsBlock nb = ns_block();
+    pol_b_role<ENV>(p, c, lds, tile, nb.tile, nb.g, blockIdx.z);
 }
 
 // dLoss/dQ_k of row i in the actor loss: -1/B (RPODDPG, rpo_ddpg.py:317) or the split of d(-min(Q1, Q2)) with ties
@@ -1098,14 +1108,14 @@ __device__ __forceinline__ float ns_policy_dq(const SplitArgs& p, int k, int i, 
 
 // ---- pol_c: the critics' rows pass inside the actor loss: dx0 column groups (no parameter gradients of their own) and,
 //      per group, its share of d(-Q)/d action = dx0 Wa.  blocks (critic, column group, row tile), 256 threads (as bwd_a).
-__global__ __launch_bounds__(kThreads) void split_policy_c_kernel(SplitArgs p) {
+__device__ __forceinline__ void pol_c_role(const SplitArgs& p, float* smem, int b, unsigned fused_consumers = 0u,
+                                           unsigned fused_need = 0u) {
     constexpr int EIN = 128, H = 256, LDH = H + 4;
-    __shared__ __attribute__((aligned(16))) float dh_s[kRows * LDH];
-    __shared__ float dq_s[kRows];
-    __shared__ float wpart[4 * 16 * 16];
+    float* dh_s = smem;                                           // [16][LDH]
+    float* dq_s = smem + kRows * LDH;                             // [16]
+    float* wpart = dq_s + 16;                                     // [4][16][16]
     const int T = (p.B + kRows - 1) / kRows, B = p.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    const int b = blockIdx.x;
     const int k = b / (T * kNsGroups), rem = b - k * T * kNsGroups, g = rem / T, tile = rem - g * T;   // row tile fastest: see bwd_a
     const int row0 = tile * kRows;
     const Mlp& net = p.critic[k];
@@ -1113,12 +1123,16 @@ __global__ __launch_bounds__(kThreads) void split_policy_c_kernel(SplitArgs p) {
     float wv[H / 16], hv[kRows];
 #pragma unroll
     for (int ks = 0; ks < H / 16; ++ks) wv[ks] = net.W0[(size_t)(jw + ks * 4 + lg) * EIN + e];
+    const float w1a = net.W1[tid];
+    const float2 wa2 = *reinterpret_cast<const float2*>(&net.Wa[(g * 16 + (tid & 15)) * 2]);
+    if (fused_consumers) {                                       // fused policy front: the tile's Q slabs (pol_b) of THIS launch
+        ns_tile_wait(p.tile_sync + (T + tile) * kNsSyncStride, fused_need, p.tile_sync + 3 * T * kNsSyncStride);
+        ns_tile_passed(p.tile_sync, T, tile, fused_consumers);
+    }
 #pragma unroll
     for (int r = 0; r < kRows; ++r) hv[r] = row0 + r < B ? p.h1[k][(size_t)(row0 + r) * H + tid] : 0.0f;
-    const float w1a = net.W1[tid];
     const size_t xo = (size_t)(row0 + (tid >> 4)) * EIN + g * 16 + (tid & 15);
     const float x0v = row0 + (tid >> 4) < B ? p.x0[k][xo] : 0.0f;
-    const float2 wa2 = *reinterpret_cast<const float2*>(&net.Wa[(g * 16 + (tid & 15)) * 2]);
     if (tid < 64) {
         float dq = 0.0f, term = 0.0f;
         if (tid < kRows && row0 + tid < B) dq = ns_policy_dq(p, k, row0 + tid, &term);
@@ -1150,6 +1164,44 @@ __global__ __launch_bounds__(kThreads) void split_policy_c_kernel(SplitArgs p) {
         d0 = rpo_row16_sum_lane0(d0); d1 = rpo_row16_sum_lane0(d1);   // (xor-butterfly association at ee == 0)
         if (ee == 0 && live)
             reinterpret_cast<float2*>(p.da_part)[((size_t)k * kNsGroups + g) * B + row0 + r] = make_float2(d0, d1);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void split_policy_c_kernel(SplitArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[kBwdASmem];
+    pol_c_role(p, smem, blockIdx.x);
+}
+
+// ---- fused front of the policy step: pol_a, pol_b and pol_c in ONE launch (the hand-overs between them stay inside a row
+//      tile, like those of the critic update's front).  grid (8, T, with_a + 2 K) of 256-thread workgroups:
+//        plane  0 (with_a = 1)              pol_a: the policy's slabs on the batch states; arrives at the tile's word 0
+//        planes [with_a, with_a + K)        pol_b of critic k: waits for word 0 == 8 (with_a), arrives at word 1
+//        planes [with_a + K, with_a + 2 K)  pol_c of critic k: waits for word 1 == 8 K
+//      with_a = 0: pol_a ran inside the critic update's launch (front_pol / fwd_b_pol / mid_pol).
+template <class ENV>
+__global__ __launch_bounds__(kThreads) void split_policy_front_kernel(SplitArgs p, CartConsts c, int with_a) {
+    typedef typename ENV::L L;
+    __shared__ __attribute__((aligned(16))) float smem[kFrontSmem];
+    const int K = p.twin ? 2 : 1, T = (int)gridDim.y, z = (int)blockIdx.z;
+    const unsigned consumers = (unsigned)(kNsGroups * K * (1 + with_a));     // pol_c's workgroups (+ pol_b's when they wait)
+    if (z >= with_a + K) {
+        pol_c_role(p, smem, (z - with_a - K) * T * kNsGroups + (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y, consumers,
+                   (unsigned)(kNsGroups * K));
+        return;
+    }
+    if (threadIdx.x >= kNsThreads) return;
+    NsLds<128>& lds = *reinterpret_cast<NsLds<128>*>(smem);
+    float4* tile = reinterpret_cast<float4*>(reinterpret_cast<char*>(smem) + sizeof(NsLds<128>));
+    const NsBlock nb = ns_block();
+    unsigned* sync = p.tile_sync;
+    if (z < with_a) {
+        pol_a_role<L>(p, lds, tile, nb.tile * kRows, nb.g);
+        ns_tile_arrive(sync + nb.tile * kNsSyncStride);
+    } else {
+        pol_b_role<ENV>(p, c, lds, tile, nb.tile, nb.g, z - with_a, with_a ? sync + nb.tile * kNsSyncStride : nullptr,
+                        (unsigned)kNsGroups);
+        ns_tile_arrive(sync + (T + nb.tile) * kNsSyncStride);
+        if (with_a) ns_tile_passed(sync, T, nb.tile, consumers);
     }
 }
 
@@ -1711,6 +1763,28 @@ int rpo_split_policy_b(const rpo_split_update* u, void* stream) {
     RPO_LAUNCH_CHECK();
     return 0;
 }
+
+static int policy_front_launch(const rpo_split_update* u, int with_a, void* stream) {
+    SplitArgs a; CartConsts c;
+    if (!u) return RPO_ERR_NULL;
+    if (int e = to_args(u, 32u | 2u, a, c)) return e;
+    const int K = a.twin ? 2 : 1;
+    if (!a.batch_out || !a.ctrl || (!a.part_pi && !a.part_pol) || !a.nu || !a.noise_out || !a.actions || !a.g_act || !a.lag_partial ||
+        !a.tile_sync || !a.da_part)
+        return RPO_ERR_NULL;
+    if (a.twin ? (!a.raw || !a.logp) : !a.ap_det) return RPO_ERR_NULL;
+    if (with_a && (!a.x0_a || !a.h1_a)) return RPO_ERR_NULL;
+    for (int k = 0; k < K; ++k)
+        if (!a.part_q[k] || !a.x0[k] || !a.h1[k] || !a.dx0[k]) return RPO_ERR_NULL;
+    const dim3 grid(kNsGroups, (a.B + kRows - 1) / kRows, with_a + 2 * K);
+    if (u->env == 0) hipLaunchKernelGGL(split_policy_front_kernel<CartPol>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c, with_a);
+    else hipLaunchKernelGGL(split_policy_front_kernel<PendPol>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c, with_a);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_split_policy_front(const rpo_split_update* u, void* stream) { return policy_front_launch(u, 1, stream); }
+int rpo_split_policy_front_bc(const rpo_split_update* u, void* stream) { return policy_front_launch(u, 0, stream); }
 
 int rpo_split_policy_c(const rpo_split_update* u, void* stream) {
     SplitArgs a; CartConsts c;

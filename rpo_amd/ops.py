@@ -796,7 +796,7 @@ class SplitUpdate(object):
     device buffer, so the struct is reused for every launch (and every hipGraph capture)."""
 
     STAGES = ("critic_fwd_a", "critic_fwd_b", "critic_front", "critic_front_pol", "critic_mid", "critic_mid_pol", "critic_fwd_b_pol", "pend_head_project", "critic_bwd_a", "critic_bwd_b", "policy_a", "policy_b",
-              "policy_c", "policy_d", "policy_e")
+              "policy_c", "policy_d", "policy_e", "policy_front", "policy_front_bc")
 
     def __init__(self, env_kernels, descs, twin, batch, fields):
         """descs: name -> MlpDesc for actor, actor_target (RPODDPG), critic1, critic2, critic_target1, critic_target2;
