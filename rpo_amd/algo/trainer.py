@@ -715,6 +715,15 @@ class RPOTrainerBase(object):
         su.run("critic_fwd_b_pol" if early else "critic_fwd_b", rider=ride)   # (+ actor forward of lanes [cut, n))
         self._critic_update_split_back(su, ride)
 
+    def _check_tile_sync(self):
+        """The fused front launches raise the last word of ``tile_sync`` when a workgroup gave up waiting for its row tile's
+        producers (nsplit.hip, kNsSpinMax): the values of that launch are then undefined -- fail loudly instead of training on."""
+        su = getattr(self, "_split_cache", None)
+        sync = su._held.get("tile_sync") if su else None
+        if sync is not None and getattr(self, "_front_cache", False) and int(sync[-32]) != 0:
+            raise RuntimeError("rpo_split_*_front: a workgroup gave up waiting for its row tile (tile_sync flag set); "
+                               "rerun with RPO_FRONT=0")
+
     def _front_ok(self):
         """rpo_split_critic_front usable here (``RPO_FRONT=0``: never): see ops.front_launch_ok."""
         return self._front_cache                                 # (probed in _split_state, outside any graph capture)
@@ -976,6 +985,7 @@ class RPOTrainerBase(object):
             for k in ("max_ineq_max", "max_eq_max"):
                 rows[:, hip_ops.STAT[k]] = mx[:, hip_ops.STAT[k]]
         rows = rows.cpu().numpy().astype(np.float64)
+        self._check_tile_sync()                                   # (the copy above already waited for the device)
         S = hip_ops.STAT
         n = float(self.num_envs)
         # whole-array bookkeeping (a Python loop over the rows kept the GPU idle for ~12 us per iteration at 4096 lanes)

@@ -12,7 +12,7 @@ timeout 1500 python3 -m pytest tests -q -m gpu > $OUT/pytest_gpu.log 2>&1
 tail -1 $OUT/pytest_gpu.log
 timeout 900 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 for W in cart_sac pen_ddpg pen_sac evopf_ddpg evopf_sac; do
-  timeout 900 python3 bench.py --workload $W > $OUT/bench_$W.json 2> $OUT/bench_$W.err
+  timeout 900 python3 bench.py --workload $W > $OUT/bench_line_$W.json 2> $OUT/bench_line_$W.err
 done
 bash tools/collect_profiles.sh $R > $OUT/collect_profiles.log 2>&1
 cp -r gpurun_out/prof_$R/* $OUT/ 2>/dev/null
