@@ -33,11 +33,15 @@ def main():
     assert int(ag.actor_optim.step_dev[0]) == steps // tr.policy_fre
     for opt in (ag.critic_optim, ag.actor_optim):
         assert int(opt.step_dev[2]) == 0 and int(opt.step_dev[32:].abs().max()) == 0
+    su = getattr(tr, "_split_cache", None)
+    front = bool(getattr(tr, "_front_cache", False))
+    if su and su._held.get("tile_sync") is not None:                                 # fused front launches: words at rest, no wait gave up
+        assert int(su._held["tile_sync"].abs().max()) == 0
     for p in (ag.flat.data, ag.nju.weight, ag.critic_target_flat):
         assert bool(torch.isfinite(p).all())
     assert tr.env_steps == steps * n and 0.0 <= tr.viol_rate <= 1.0
-    print("%s: %d steps ok; violation rate %.5f, ride %s, prepared Adam, |params| max %.3f" % (
-        workload, steps, tr.viol_rate, bool(getattr(tr, "_ride_ok", lambda d: False)(True)), float(ag.flat.data.abs().max())))
+    print("%s: %d steps ok; violation rate %.5f, ride %s, fused front %s, prepared Adam, |params| max %.3f" % (
+        workload, steps, tr.viol_rate, bool(getattr(tr, "_ride_ok", lambda d: False)(True)), front, float(ag.flat.data.abs().max())))
 
 
 if __name__ == "__main__":
