@@ -1467,7 +1467,8 @@ int rpo_xcc_probe(int gx, int gy, int gz, int threads, int* out, void* stream) {
 }
 
 static int front_args(const rpo_split_update* u, unsigned need, SplitArgs& a, CartConsts& c) {
-    if (!u || u->env != 0) return RPO_ERR_ARG;
+    if (!u) return RPO_ERR_NULL;
+    if (u->env != 0) return RPO_ERR_ARG;
     if (int e = to_args(u, 1u | 2u | 4u | need, a, c)) return e;
     const int K = a.twin ? 2 : 1;
     if (!a.rows || !a.batch_out || !a.ctrl || !a.part_pi || !a.tile_sync || a.cap_steps <= 0 || a.n_envs <= 0) return RPO_ERR_NULL;
@@ -1495,7 +1496,8 @@ int rpo_split_critic_front(const rpo_split_update* u, void* stream) { return fro
 int rpo_split_critic_front_pol(const rpo_split_update* u, void* stream) { return front_launch(u, 1, stream); }
 
 static int mid_args(const rpo_split_update* u, unsigned need, SplitArgs& a, CartConsts& c) {
-    if (!u || u->env != 1) return RPO_ERR_ARG;
+    if (!u) return RPO_ERR_NULL;
+    if (u->env != 1) return RPO_ERR_ARG;
     if (int e = to_args(u, 2u | 4u | need, a, c)) return e;
     const int K = a.twin ? 2 : 1;
     if (!a.batch_out || !a.ctrl || !a.next_actions || !a.tile_sync || !a.loss_partial || (a.twin && !a.logp)) return RPO_ERR_NULL;

@@ -578,3 +578,22 @@ def test_adam_step_multi_equals_single_launches(ops):
         for key in a[name]:
             assert torch.equal(a[name][key], b[name][key]), (name, key)
     assert int(b["p"]["step"][0]) == 3 and int(b["d"]["step"][0]) == 3 and int(b["p"]["step"][2]) == 0
+
+
+def test_xcc_probe_and_front_placement(ops):
+    """rpo_xcc_probe reports the XCD of every workgroup; the fused front launches (rpo_split_critic_front*) are
+    used only where every workgroup of a row tile -- in all planes -- shares one.  On an 8-XCD MI355X the dispatcher deals
+    workgroups round-robin in block order: 16 row tiles (batch 256) keep a tile on XCD tile % 8, 7 row tiles (batch 100) do not."""
+    import ctypes
+    from rpo_amd import _lib
+    out = torch.full((5, 16, 8), -1, dtype=torch.int32, device="cuda")
+    rc = _lib.load().rpo_xcc_probe(8, 16, 5, 256, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    ids = out.cpu().view(5, 128)
+    n_xcd = int(ids.max()) + 1
+    assert int(ids.min()) >= 0 and n_xcd in (1, 2, 4, 8)
+    assert ops.front_launch_ok(256, False) and ops.front_launch_ok(256, True)
+    if n_xcd == 8:
+        lin = torch.arange(128)
+        assert all(len(torch.unique(ids[:, lin % 16 == t])) == 1 for t in range(16))
+        assert not ops.front_launch_ok(100, False)              # 7 tiles: a tile's column groups land on different XCDs

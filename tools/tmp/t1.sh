@@ -1,2 +1,2 @@
-timeout 600 python -m pytest tests/test_trainer_gpu.py tests/test_train_step_golden.py -q -x -m gpu 2>&1 | tail -4
-for W in cart_ddpg cart_sac pen_sac pen_ddpg; do echo "== $W"; timeout 300 python bench.py --no-cpu-baseline --no-clinic --no-extras --workload $W --steps 4000 --warmup 300 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; done
+timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -m gpu -k "xcc or adam" 2>&1 | tail -3
+timeout 600 python -m pytest tests/test_trainer_gpu.py -q -x -m gpu -k "ragged or fused_front" 2>&1 | tail -3
