@@ -132,10 +132,11 @@ constexpr int kNsSpinMax = 1 << 18;
 // one L2 channel per XCD and the waits took 7.8 us (measured) instead of the ~3 us the producers need
 constexpr int kNsSyncStride = 32;
 
-__device__ __forceinline__ void ns_tile_arrive(unsigned* word) {
+// (a word holds two 16-bit counts: `inc` = 1 for the low one, 1 << 16 for the high one)
+__device__ __forceinline__ void ns_tile_arrive(unsigned* word, unsigned inc = 1u) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every wave: its stores have reached the XCD's L2 ...
     __syncthreads();                                             // ... before the workgroup's one arrival
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(word, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 __device__ __forceinline__ unsigned ns_poll(unsigned* word) {     // returning atomic: executed in the L2, not a cached load
@@ -144,10 +145,10 @@ __device__ __forceinline__ unsigned ns_poll(unsigned* word) {     // returning a
     return v;
 }
 
-__device__ __forceinline__ void ns_tile_wait(unsigned* word, unsigned need, unsigned* gave_up) {
+__device__ __forceinline__ void ns_tile_wait(unsigned* word, unsigned need, unsigned* gave_up, int shift = 0) {
     if (threadIdx.x == 0) {
         int polls = 0;
-        while (ns_poll(word) < need) {
+        while (((ns_poll(word) >> shift) & 0xffffu) < need) {
             if (++polls >= kNsSpinMax) { *gave_up = 1u; break; }
             __builtin_amdgcn_s_sleep(1);
         }
@@ -651,7 +652,7 @@ constexpr int kBwdASmem = kRows * (256 + 4) + 16 + 4 * 16 * 16;
 
 template <class L>
 __device__ __forceinline__ void bwd_a_role(const SplitArgs& p, float* smem, int b, unsigned fused_consumers = 0u,
-                                           unsigned fused_need = 0u) {
+                                           unsigned fused_need = 0u, unsigned fused_need_critics = 0u) {
     constexpr int EIN = 128, H = 256, LDH = H + 4;
     const int T = (p.B + kRows - 1) / kRows, B = p.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
@@ -668,15 +669,19 @@ __device__ __forceinline__ void bwd_a_role(const SplitArgs& p, float* smem, int 
 #pragma unroll
         for (int ks = 0; ks < H / 16; ++ks) wv[ks] = net.W0[(size_t)(jw + ks * 4 + lg) * EIN + e];
         const float w1a = net.W1[tid];                            // 256 threads = 256 hidden columns
-        if (fused_consumers) {
-            // fused front / mid: the tile's critic slabs (fwd_a) and / or target slabs (fwd_b) of THIS launch, 8 arrivals per network
-            ns_tile_wait(p.tile_sync + (T + tile) * kNsSyncStride, fused_need, p.tile_sync + 3 * T * kNsSyncStride);
-            ns_tile_passed(p.tile_sync, T, tile, fused_consumers);
-        }
+        // fused front: the tile's critic slabs of THIS launch (fwd_a's critic planes: the high count of word 1) -- their saved
+        // activations are requested while fwd_b's workgroups are still at work
+        if (fused_consumers && fused_need_critics)
+            ns_tile_wait(p.tile_sync + (T + tile) * kNsSyncStride, fused_need_critics, p.tile_sync + 3 * T * kNsSyncStride, 16);
 #pragma unroll
         for (int r = 0; r < kRows; ++r) hv[r] = row0 + r < B ? p.h1[k][(size_t)(row0 + r) * H + tid] : 0.0f;
         const size_t xo = (size_t)(row0 + (tid >> 4)) * EIN + g * 16 + (tid & 15);
         const float x0v = row0 + (tid >> 4) < B ? p.x0[k][xo] : 0.0f;   // mask of this thread's output, requested early
+        if (fused_consumers) {
+            // fused front / mid: the tile's target slabs (fwd_b) of THIS launch, 8 arrivals per network (the low count)
+            ns_tile_wait(p.tile_sync + (T + tile) * kNsSyncStride, fused_need, p.tile_sync + 3 * T * kNsSyncStride);
+            ns_tile_passed(p.tile_sync, T, tile, fused_consumers);
+        }
         if (tid < 64) {
             float dq = 0.0f, hub = 0.0f;
             if (tid < kRows && row0 + tid < B) {
@@ -909,9 +914,10 @@ __global__ __launch_bounds__(kNsThreads) void split_critic_fwd_b_pol_kernel(Spli
 // ---- fused front of the critic update (CartSafe): fwd_a, fwd_b and bwd_a in ONE launch -- the three stages whose hand-overs
 //      stay inside a row tile.  grid (8, T, planes) of 256-thread workgroups (bwd_a's shape; the forward roles use two of the
 //      four waves, the other two leave at once):
-//        planes [0, 1 + K)          fwd_a's roles; the policy arrives at the tile's word 0, the critics at word 1
+//        planes [0, 1 + K)          fwd_a's roles; the policy arrives at the tile's word 0, the critics at word 1 (high count)
 //        planes [1 + K, 1 + 2 K)    fwd_b's target critics: wait for word 0 == 8, arrive at word 1
-//        planes [1 + 2 K, 1 + 3 K)  bwd_a of critic k: waits for word 1 == 16 K behind its W0 requests
+//        planes [1 + 2 K, 1 + 3 K)  bwd_a of critic k: behind its W0 requests waits for the critics' 8 K arrivals, requests the
+//                                   saved activations, then waits for fwd_b's 8 K arrivals (word 1, low count)
 //        plane  1 + 3 K (pol = 1)   pol_a of a policy iteration without a shared embedding (see fwd_b_pol): waits for word 0
 //      Same code, same values as the launches it replaces.  Returns false for planes beyond its own.
 template <class L>
@@ -921,7 +927,7 @@ __device__ __forceinline__ bool front_role(const SplitArgs& p, const CartConsts&
     const unsigned consumers = (unsigned)(kNsGroups * (2 * K + pol));
     if (z >= 1 + 2 * K && z < 1 + 3 * K) {
         bwd_a_role<L>(p, smem, (z - 1 - 2 * K) * T * kNsGroups + (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y, consumers,
-                      (unsigned)(2 * kNsGroups * K));
+                      (unsigned)(kNsGroups * K), (unsigned)(kNsGroups * K));
         return true;
     }
     if (threadIdx.x >= kNsThreads) return true;                  // (whole waves: the barriers below count the two that stay)
@@ -931,7 +937,8 @@ __device__ __forceinline__ bool front_role(const SplitArgs& p, const CartConsts&
     unsigned* sync = p.tile_sync;
     if (z < 1 + K) {
         fwd_a_role<L>(p, lds, tile, nb.tile * kRows, nb.g, z);
-        ns_tile_arrive(sync + ((z == 0 ? 0 : T) + nb.tile) * kNsSyncStride);
+        if (z == 0) ns_tile_arrive(sync + nb.tile * kNsSyncStride);
+        else ns_tile_arrive(sync + (T + nb.tile) * kNsSyncStride, 1u << 16);
     } else if (z < 1 + 2 * K) {
         fwd_b_role<L, 1>(p, c, lds, tile, nb.tile * kRows, nb.g, z - 1 - K, sync + nb.tile * kNsSyncStride, (unsigned)kNsGroups);
         ns_tile_arrive(sync + (T + nb.tile) * kNsSyncStride);
