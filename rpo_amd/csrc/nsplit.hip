@@ -302,7 +302,9 @@ __device__ __forceinline__ void fwd_b_role(const SplitArgs& p, const CartConsts&
     __syncthreads();
     ns_stage<L>(lds, reinterpret_cast<const float*>(tile), true, false);
     __syncthreads();                                             // (ns_stage zeroed in_a: order it before the writes below)
+    float pre[kRows];
     if (wait_word) {                                             // the tile's policy slabs of THIS launch
+        ns_layer1_state<128>(net, w, lds, pre);                  // (the state half of layer 1 does not need them either)
         const int T = (p.B + kRows - 1) / kRows;
         ns_tile_wait(wait_word, wait_need, p.tile_sync + 3 * T * kNsSyncStride);
     }
@@ -327,7 +329,7 @@ __device__ __forceinline__ void fwd_b_role(const SplitArgs& p, const CartConsts&
         lds.in_a[tid * 8] = act.x;
         lds.in_a[tid * 8 + 1] = act.y;
     }
-    ns_hidden<128, 256>(net, w, lds, g, row0, p.B, p.part_qn[k], nullptr, nullptr);
+    ns_hidden<128, 256>(net, w, lds, g, row0, p.B, p.part_qn[k], nullptr, nullptr, wait_word ? pre : nullptr);
 }
 
 template <class L, int PROJ>
@@ -1027,7 +1029,9 @@ __device__ __forceinline__ void pol_b_role(const SplitArgs& p, const CartConsts&
     __syncthreads();
     ns_stage<L>(lds, reinterpret_cast<const float*>(tile), false, false);
     __syncthreads();
+    float pre[kRows];
     if (wait_word) {                                             // fused policy front: the tile's policy slabs of THIS launch
+        ns_layer1_state<128>(net, w, lds, pre);
         const int T = (B + kRows - 1) / kRows;
         ns_tile_wait(wait_word, wait_need, p.tile_sync + 3 * T * kNsSyncStride);
     }
@@ -1086,7 +1090,7 @@ __device__ __forceinline__ void pol_b_role(const SplitArgs& p, const CartConsts&
             if (tid == 0) p.lag_partial[tile_i * 8 + q] = sum;
         }
     }
-    ns_hidden<128, 256>(net, w, lds, g, row0, B, p.part_q[k], p.x0[k], p.h1[k]);
+    ns_hidden<128, 256>(net, w, lds, g, row0, B, p.part_q[k], p.x0[k], p.h1[k], wait_word ? pre : nullptr);
 }
 
 template <class ENV>

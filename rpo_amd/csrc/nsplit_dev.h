@@ -56,14 +56,11 @@ __device__ __forceinline__ void ns_load_weights(const Mlp& net, int g, NsWeights
 // Hidden slab of column group g for the 16 rows staged in lds.in_s / lds.in_a (the caller wrote them; this function
 // synchronises before reading).  Writes part[(g * n + row) * 2 + o] for rows < n (o < n_out), h1_save columns of the
 // group, x0_save (group 0 only).  S, A <= 8, "add" critics / actors with EIN = E = 128.
-template <int EIN, int H>
-__device__ __forceinline__ void ns_hidden(const Mlp& net, const NsWeights<EIN>& w, NsLds<EIN>& lds, int g, int row0, int n,
-                                          float* part, float* x0_save, float* h1_save) {
-    constexpr int LDX = EIN + 4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    __syncthreads();
-    // ---- layer 1 (VALU): thread = column e, all 16 rows; same fmaf order as tile_compute (state inputs, then action)
-    float acc1[kRows];
+// The state half of layer 1 (bias, then the state inputs in order) of the rows staged in lds.in_s: what ns_hidden starts
+// with.  A caller whose ACTION inputs arrive late (a consumer inside a fused launch) runs this before it waits and hands
+// the accumulators to ns_hidden (`pre`): same operations in the same order.  The caller synchronises before (staging).
+template <int EIN>
+__device__ __forceinline__ void ns_layer1_state(const Mlp& net, const NsWeights<EIN>& w, const NsLds<EIN>& lds, float (&acc1)[kRows]) {
 #pragma unroll
     for (int r = 0; r < kRows; ++r) acc1[r] = w.bias;
 #pragma unroll
@@ -72,6 +69,22 @@ __device__ __forceinline__ void ns_hidden(const Mlp& net, const NsWeights<EIN>& 
 #pragma unroll
             for (int r = 0; r < kRows; ++r) acc1[r] = fmaf(lds.in_s[r * 8 + u], w.ws0[u], acc1[r]);
         }
+    }
+}
+
+template <int EIN, int H>
+__device__ __forceinline__ void ns_hidden(const Mlp& net, const NsWeights<EIN>& w, NsLds<EIN>& lds, int g, int row0, int n,
+                                          float* part, float* x0_save, float* h1_save, const float* pre = nullptr) {
+    constexpr int LDX = EIN + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    __syncthreads();
+    // ---- layer 1 (VALU): thread = column e, all 16 rows; same fmaf order as tile_compute (state inputs, then action)
+    float acc1[kRows];
+    if (pre) {
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) acc1[r] = pre[r];
+    } else {
+        ns_layer1_state<EIN>(net, w, lds, acc1);
     }
     if (net.A > 0) {
 #pragma unroll
