@@ -522,7 +522,7 @@ int rpo_split_policy_b(const rpo_split_update* u, void* stream);
 int rpo_split_policy_c(const rpo_split_update* u, void* stream);
 int rpo_split_policy_d(const rpo_split_update* u, void* stream);
 int rpo_split_policy_e(const rpo_split_update* u, void* stream);
-/* rpo_split_policy_a + _b + _c as ONE launch, like rpo_split_critic_front (tile_sync; both envs: the actor loss completes the
+/* rpo_split_policy_a + _b + _c + _d as ONE launch, like rpo_split_critic_front (tile_sync; both envs: the actor loss completes the
  * action without projection steps, rpo_ddpg.py:307-312, so nothing couples the rows); _bc: pol_a already ran inside the
  * critic update's launch (rpo_split_critic_front_pol / _fwd_b_pol / _mid_pol).  Same values bit for bit. */
 int rpo_split_policy_front(const rpo_split_update* u, void* stream);

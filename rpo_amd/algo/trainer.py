@@ -613,7 +613,8 @@ class RPOTrainerBase(object):
         crit_logp, pi_logp = self._split_logp
         su.set(noise_salt=_SALT_ACTOR, eps_in=noise_in, logp=pi_logp)
         early, self._pol_a_done = self._pol_a_done, False
-        if self._front_ok():                                      # pol_a (unless done early), pol_b and pol_c as one launch
+        front = self._front_ok()
+        if front:                                                 # pol_a (unless done early), pol_b, pol_c and pol_d as one launch
             su.run("policy_front_bc" if early else "policy_front")
         else:
             if not early:                                         # (else: done inside fwd_b's launch of this iteration)
@@ -624,7 +625,8 @@ class RPOTrainerBase(object):
         opt = ag.actor_optim
         fuse_max = self._self_cleaning and not self.dist.on and opt.clip_thres and opt.clip_thres != float("inf")
         su.set(gradmax=opt.gradmax if fuse_max else None)
-        su.run("policy_d")
+        if not front:
+            su.run("policy_d")
         # "prepared" optimiser launch behind the policy step (as for the critic's, `_critic_update_split`): pol_e advances the
         # step counters of the slices `_actor_step` will step and the update clock; the next fwd_a zeroes the actor's gradmax
         # (only when the critic update runs through the split stages too: its fwd_a is what zeroes the gradmax afterwards)

@@ -1183,38 +1183,6 @@ __global__ __launch_bounds__(kThreads) void split_policy_c_kernel(SplitArgs p) {
     pol_c_role(p, smem, blockIdx.x);
 }
 
-// ---- fused front of the policy step: pol_a, pol_b and pol_c in ONE launch (the hand-overs between them stay inside a row
-//      tile, like those of the critic update's front).  grid (8, T, with_a + 2 K) of 256-thread workgroups:
-//        plane  0 (with_a = 1)              pol_a: the policy's slabs on the batch states; arrives at the tile's word 0
-//        planes [with_a, with_a + K)        pol_b of critic k: waits for word 0 == 8 (with_a), arrives at word 1
-//        planes [with_a + K, with_a + 2 K)  pol_c of critic k: waits for word 1 == 8 K
-//      with_a = 0: pol_a ran inside the critic update's launch (front_pol / fwd_b_pol / mid_pol).
-template <class ENV>
-__global__ __launch_bounds__(kThreads) void split_policy_front_kernel(SplitArgs p, CartConsts c, int with_a) {
-    typedef typename ENV::L L;
-    __shared__ __attribute__((aligned(16))) float smem[kFrontSmem];
-    const int K = p.twin ? 2 : 1, T = (int)gridDim.y, z = (int)blockIdx.z;
-    const unsigned consumers = (unsigned)(kNsGroups * K * (1 + with_a));     // pol_c's workgroups (+ pol_b's when they wait)
-    if (z >= with_a + K) {
-        pol_c_role(p, smem, (z - with_a - K) * T * kNsGroups + (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y, consumers,
-                   (unsigned)(kNsGroups * K));
-        return;
-    }
-    if (threadIdx.x >= kNsThreads) return;
-    NsLds<128>& lds = *reinterpret_cast<NsLds<128>*>(smem);
-    float4* tile = reinterpret_cast<float4*>(reinterpret_cast<char*>(smem) + sizeof(NsLds<128>));
-    const NsBlock nb = ns_block();
-    unsigned* sync = p.tile_sync;
-    if (z < with_a) {
-        pol_a_role<L>(p, lds, tile, nb.tile * kRows, nb.g);
-        ns_tile_arrive(sync + nb.tile * kNsSyncStride);
-    } else {
-        pol_b_role<ENV>(p, c, lds, tile, nb.tile, nb.g, z - with_a, with_a ? sync + nb.tile * kNsSyncStride : nullptr,
-                        (unsigned)kNsGroups);
-        ns_tile_arrive(sync + (T + nb.tile) * kNsSyncStride);
-        if (with_a) ns_tile_passed(sync, T, nb.tile, consumers);
-    }
-}
 
 // d loss / d (actor head outputs) of row i: sum of the critics' d/d action shares + the Lagrangian's -> autograd through
 // Complete -> head backward (rpo_ddpg.py:307-324, rpo_sac.py:321-339)
@@ -1250,13 +1218,12 @@ __device__ __forceinline__ float2 ns_policy_dout(const SplitArgs& p, const CartC
 // ---- pol_d: d loss / d (actor head outputs) of the tile's rows -> actor dx0 of one (row tile, 16 first-layer columns);
 //      the column-group-0 workgroup of a tile leaves the rows' head gradients for pol_e.  blocks (row tile, group).
 template <class ENV>
-__global__ __launch_bounds__(kThreads) void split_policy_d_kernel(SplitArgs p, CartConsts c) {
+__device__ __forceinline__ void pol_d_role(const SplitArgs& p, const CartConsts& c, float* smem, int b, unsigned fused_consumers = 0u,
+                                           unsigned fused_need_a = 0u, unsigned fused_need_c = 0u) {
     constexpr int EIN = 128, H = 256, LDH = H + 4;
-    __shared__ __attribute__((aligned(16))) float smem[kRows * LDH + 32 + 4 * 16 * 16];
     const int B = p.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     const Mlp& net = p.actor;
-    const int b = blockIdx.x;
     {
         const int T = (B + kRows - 1) / kRows, g = b / T, tile = b - g * T, row0 = tile * kRows;   // row tile fastest: see bwd_a
         float* dh_s = smem;
@@ -1266,12 +1233,20 @@ __global__ __launch_bounds__(kThreads) void split_policy_d_kernel(SplitArgs p, C
         float wv[H / 16], hv[kRows];
 #pragma unroll
         for (int ks = 0; ks < H / 16; ++ks) wv[ks] = net.W0[(size_t)(jw + ks * 4 + lg) * EIN + e];
+        const float w1a = net.W1[tid], w1b = net.n_out > 1 ? net.W1b[tid] : 0.0f;
+        unsigned* gave_up = p.tile_sync ? p.tile_sync + 3 * T * kNsSyncStride : nullptr;
+        // fused policy front: the policy's saved activations are pol_a's (word 0, low count; an earlier launch when pol_a ran
+        // early) -- requested before the wait for pol_c's workgroups of the tile (word 0, high count)
+        if (fused_consumers && fused_need_a) ns_tile_wait(p.tile_sync + tile * kNsSyncStride, fused_need_a, gave_up);
 #pragma unroll
         for (int r = 0; r < kRows; ++r) hv[r] = row0 + r < B ? p.h1_a[(size_t)(row0 + r) * H + tid] : 0.0f;
-        const float w1a = net.W1[tid], w1b = net.n_out > 1 ? net.W1b[tid] : 0.0f;
         const size_t xo = (size_t)(row0 + (tid >> 4)) * EIN + g * 16 + (tid & 15);
         const bool xlive = row0 + (tid >> 4) < B;
         const float x0v = xlive ? p.x0_a[xo] : 0.0f;
+        if (fused_consumers) {
+            ns_tile_wait(p.tile_sync + tile * kNsSyncStride, fused_need_c, gave_up, 16);
+            ns_tile_passed(p.tile_sync, T, tile, fused_consumers);
+        }
         float cdx = 0.0f;                                          // the critics' dx0 under a shared state embedding
         if (xlive && p.shared_embedding) cdx = p.twin ? p.dx0[0][xo] + p.dx0[1][xo] : p.dx0[0][xo];
         if (tid < kRows) {
@@ -1306,6 +1281,55 @@ __global__ __launch_bounds__(kThreads) void split_policy_d_kernel(SplitArgs p, C
                 p.dx0_a[xo] = v;
             }
         }
+    }
+}
+
+constexpr int kPolDSmem = kRows * (256 + 4) + 32 + 4 * 16 * 16;
+
+template <class ENV>
+__global__ __launch_bounds__(kThreads) void split_policy_d_kernel(SplitArgs p, CartConsts c) {
+    __shared__ __attribute__((aligned(16))) float smem[kPolDSmem];
+    pol_d_role<ENV>(p, c, smem, blockIdx.x);
+}
+
+// ---- fused front of the policy step: pol_a, pol_b, pol_c and pol_d in ONE launch (the hand-overs between them stay inside a
+//      row tile, like those of the critic update's front).  grid (8, T, with_a + 2 K + 1) of 256-thread workgroups:
+//        plane  0 (with_a = 1)              pol_a: the policy's slabs on the batch states; arrives at the tile's word 0 (low count)
+//        planes [with_a, with_a + K)        pol_b of critic k: waits for word 0 low == 8 (with_a), arrives at word 1
+//        planes [with_a + K, with_a + 2 K)  pol_c of critic k: waits for word 1 == 8 K, arrives at word 0 (high count)
+//        plane  with_a + 2 K                pol_d: waits for pol_a (with_a), requests its activations, waits for word 0 high == 8 K
+//      with_a = 0: pol_a ran inside the critic update's launch (front_pol / fwd_b_pol / mid_pol).
+constexpr int kPolFrontSmem = kPolDSmem > kFrontSmem ? kPolDSmem : kFrontSmem;
+
+template <class ENV>
+__global__ __launch_bounds__(kThreads) void split_policy_front_kernel(SplitArgs p, CartConsts c, int with_a) {
+    typedef typename ENV::L L;
+    __shared__ __attribute__((aligned(16))) float smem[kPolFrontSmem];
+    const int K = p.twin ? 2 : 1, T = (int)gridDim.y, z = (int)blockIdx.z;
+    const int lin = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
+    const unsigned consumers = (unsigned)(kNsGroups * (K * (1 + with_a) + 1));   // pol_c's + pol_d's workgroups (+ pol_b's when they wait)
+    if (z == with_a + 2 * K) {
+        pol_d_role<ENV>(p, c, smem, lin, consumers, with_a ? (unsigned)kNsGroups : 0u, (unsigned)(kNsGroups * K));
+        return;
+    }
+    if (z >= with_a + K) {
+        pol_c_role(p, smem, (z - with_a - K) * T * kNsGroups + lin, consumers, (unsigned)(kNsGroups * K));
+        ns_tile_arrive(p.tile_sync + (lin % T) * kNsSyncStride, 1u << 16);
+        return;
+    }
+    if (threadIdx.x >= kNsThreads) return;
+    NsLds<128>& lds = *reinterpret_cast<NsLds<128>*>(smem);
+    float4* tile = reinterpret_cast<float4*>(reinterpret_cast<char*>(smem) + sizeof(NsLds<128>));
+    const NsBlock nb = ns_block();
+    unsigned* sync = p.tile_sync;
+    if (z < with_a) {
+        pol_a_role<L>(p, lds, tile, nb.tile * kRows, nb.g);
+        ns_tile_arrive(sync + nb.tile * kNsSyncStride);
+    } else {
+        pol_b_role<ENV>(p, c, lds, tile, nb.tile, nb.g, z - with_a, with_a ? sync + nb.tile * kNsSyncStride : nullptr,
+                        (unsigned)kNsGroups);
+        ns_tile_arrive(sync + (T + nb.tile) * kNsSyncStride);
+        if (with_a) ns_tile_passed(sync, T, nb.tile, consumers);
     }
 }
 
@@ -1789,7 +1813,8 @@ static int policy_front_launch(const rpo_split_update* u, int with_a, void* stre
     if (with_a && (!a.x0_a || !a.h1_a)) return RPO_ERR_NULL;
     for (int k = 0; k < K; ++k)
         if (!a.part_q[k] || !a.x0[k] || !a.h1[k] || !a.dx0[k]) return RPO_ERR_NULL;
-    const dim3 grid(kNsGroups, (a.B + kRows - 1) / kRows, with_a + 2 * K);
+    if (!a.dx0_a || !a.dout || !a.x0_a || !a.h1_a) return RPO_ERR_NULL;
+    const dim3 grid(kNsGroups, (a.B + kRows - 1) / kRows, with_a + 2 * K + 1);
     if (u->env == 0) hipLaunchKernelGGL(split_policy_front_kernel<CartPol>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c, with_a);
     else hipLaunchKernelGGL(split_policy_front_kernel<PendPol>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c, with_a);
     RPO_LAUNCH_CHECK();
