@@ -376,6 +376,20 @@ __device__ __forceinline__ void ride_forward(const RideArgs<ENV>& r, NsLds<128>&
     ns_hidden<128, 256>(r.actor, w, lds, g, row0, r.n, r.part, nullptr, nullptr);
 }
 
+// the same for a 256-thread workgroup: waves 0-1 take lane tile 2 wg, waves 2-3 lane tile 2 wg + 1 (two independent slab units
+// with an NsLds each -- half the workgroups to dispatch for the same lanes, and no waves that leave at once; both halves run
+// the same code, so the workgroup barriers inside ns_hidden line up; a half whose tile is past the range leaves as a whole)
+template <class ENV>
+__device__ __forceinline__ void ride_forward_pair(const RideArgs<ENV>& r, NsLds<128>* lds2, int wg, int g) {
+    const int half = (int)threadIdx.x >> 7, row0 = r.lane0 + (2 * wg + half) * kRows;
+    if (row0 >= r.lane1) return;
+    NsLds<128>& lds = lds2[half];
+    NsWeights<128> w;
+    ns_load_weights<128, 256>(r.actor, g, w);
+    ENV::stage_obs(r.step, row0, kRows, lds.in_s, 8, (int)threadIdx.x & (kNsThreads - 1));
+    ns_hidden<128, 256>(r.actor, w, lds, g, row0, r.n, r.part, nullptr, nullptr);
+}
+
 // blocks `blk` of `nblk` (kThreads lanes each); smem: 4 * 11 floats
 template <class ENV>
 __device__ __forceinline__ void ride_tail(const RideArgs<ENV>& r, const CartConsts& cc, float* smem, unsigned blk, unsigned nblk) {
@@ -952,7 +966,7 @@ __device__ __forceinline__ bool front_role(const SplitArgs& p, const CartConsts&
     return true;
 }
 
-constexpr int kFrontSmem = kBwdASmem;
+constexpr int kFrontSmem = kBwdASmem > (int)(2 * sizeof(NsLds<128>) / sizeof(float)) ? kBwdASmem : (int)(2 * sizeof(NsLds<128>) / sizeof(float));
 static_assert(sizeof(NsLds<128>) + sizeof(float4) * kRows * 6 <= sizeof(float) * kFrontSmem, "forward roles fit");
 static_assert(sizeof(NsLds<128>) % 16 == 0, "tile alignment");
 
@@ -967,10 +981,9 @@ template <class L>
 __global__ __launch_bounds__(kThreads) void split_critic_front_ride_kernel(SplitArgs p, CartConsts c, RideArgs<typename L::Env> r) {
     __shared__ __attribute__((aligned(16))) float smem[kFrontSmem];
     if (front_role<L>(p, c, smem, 0)) return;
-    if (threadIdx.x >= kNsThreads) return;
     const NsBlock nb = ns_block();
     const int own = 1 + 3 * (p.twin ? 2 : 1);
-    ride_forward<typename L::Env>(r, *reinterpret_cast<NsLds<128>*>(smem), ((int)blockIdx.z - own) * (int)gridDim.y + nb.tile, nb.g);
+    ride_forward_pair<typename L::Env>(r, reinterpret_cast<NsLds<128>*>(smem), ((int)blockIdx.z - own) * (int)gridDim.y + nb.tile, nb.g);
 }
 
 // ---- SpringPendulum: the batch-coupled projection (one workgroup, every row) sits between fwd_a and fwd_b, so only fwd_b and
@@ -1008,10 +1021,9 @@ template <class L>
 __global__ __launch_bounds__(kThreads) void split_critic_mid_ride_kernel(SplitArgs p, CartConsts c, RideArgs<typename L::Env> r) {
     __shared__ __attribute__((aligned(16))) float smem[kFrontSmem];
     if (mid_role<L>(p, c, smem, 0)) return;
-    if (threadIdx.x >= kNsThreads) return;
     const NsBlock nb = ns_block();
-    ride_forward<typename L::Env>(r, *reinterpret_cast<NsLds<128>*>(smem), ((int)blockIdx.z - 2 * (p.twin ? 2 : 1)) * (int)gridDim.y + nb.tile,
-                                  nb.g);
+    ride_forward_pair<typename L::Env>(r, reinterpret_cast<NsLds<128>*>(smem), ((int)blockIdx.z - 2 * (p.twin ? 2 : 1)) * (int)gridDim.y + nb.tile,
+                                       nb.g);
 }
 
 // ---- pol_b: head -> exploration noise + clip (RPODDPG) / rsample + clip + log pi (RPOSAC) -> Complete -> Lagrangian row
@@ -1728,7 +1740,7 @@ int rpo_split_critic_front_ride(const rpo_split_update* u, const rpo_rollout_rid
     SplitArgs a; CartConsts c;
     if (int e = front_args(u, 32u, a, c)) return e;
     const int K = a.twin ? 2 : 1, T = (a.B + kRows - 1) / kRows;
-    const int lane_wgs = (r->lane_end - r->lane_begin + kRows - 1) / kRows;
+    const int lane_wgs = ((r->lane_end - r->lane_begin + kRows - 1) / kRows + 1) / 2;      // two lane tiles per workgroup
     const dim3 grid(kNsGroups, T, 1 + 3 * K + (lane_wgs + T - 1) / T);
     hipLaunchKernelGGL(split_critic_front_ride_kernel<CartRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c,
                        ride_args<CartEnv>(a, r));
@@ -1742,7 +1754,7 @@ int rpo_split_critic_mid_ride(const rpo_split_update* u, const rpo_rollout_rider
     SplitArgs a; CartConsts c;
     if (int e = mid_args(u, 32u, a, c)) return e;
     const int K = a.twin ? 2 : 1, T = (a.B + kRows - 1) / kRows;
-    const int lane_wgs = (r->lane_end - r->lane_begin + kRows - 1) / kRows;
+    const int lane_wgs = ((r->lane_end - r->lane_begin + kRows - 1) / kRows + 1) / 2;      // two lane tiles per workgroup
     const dim3 grid(kNsGroups, T, 2 * K + (lane_wgs + T - 1) / T);
     hipLaunchKernelGGL(split_critic_mid_ride_kernel<PendRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c,
                        ride_args<PendEnv>(a, r));

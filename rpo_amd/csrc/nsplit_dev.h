@@ -36,7 +36,7 @@ struct NsWeights {
 template <int EIN, int H>
 __device__ __forceinline__ void ns_load_weights(const Mlp& net, int g, NsWeights<EIN>& w) {
     static_assert(EIN == kNsThreads, "one first-layer column per thread");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int tid = threadIdx.x & (kNsThreads - 1), lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;   // (two slab units may share a 256-thread workgroup)
     const int e = tid;
     w.bias = net.bs[e] + (net.A > 0 ? net.ba[e] : 0.0f);
 #pragma unroll
@@ -76,7 +76,7 @@ template <int EIN, int H>
 __device__ __forceinline__ void ns_hidden(const Mlp& net, const NsWeights<EIN>& w, NsLds<EIN>& lds, int g, int row0, int n,
                                           float* part, float* x0_save, float* h1_save, const float* pre = nullptr) {
     constexpr int LDX = EIN + 4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int tid = threadIdx.x & (kNsThreads - 1), lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;   // (two slab units may share a 256-thread workgroup)
     __syncthreads();
     // ---- layer 1 (VALU): thread = column e, all 16 rows; same fmaf order as tile_compute (state inputs, then action)
     float acc1[kRows];

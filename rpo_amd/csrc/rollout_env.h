@@ -12,8 +12,8 @@ struct CartEnv {
     typedef rpo_cart_dev::ActArgs ActArgs;
     typedef rpo_cart_dev::CartConsts Consts;
     static constexpr int OBS = 6;
-    __device__ static __forceinline__ void stage_obs(const StepArgs& p, int row0, int rows, float* in_s, int stride) {
-        const int tid = threadIdx.x;
+    __device__ static __forceinline__ void stage_obs(const StepArgs& p, int row0, int rows, float* in_s, int stride, int tid_in = -1) {
+        const int tid = tid_in < 0 ? (int)threadIdx.x : tid_in;
         if (tid < rows * 6) {                                  // CartSafe observes its state directly
             const int r = tid / 6, i = tid - r * 6;
             in_s[r * stride + i] = (row0 + r < p.n) ? p.state[(size_t)(row0 + r) * 6 + i] : 0.0f;
@@ -54,8 +54,8 @@ struct PendEnv {
     typedef rpo_pend_dev::ActArgs ActArgs;
     struct Consts { int unused; };
     static constexpr int OBS = 5;
-    __device__ static __forceinline__ void stage_obs(const StepArgs& p, int row0, int rows, float* in_s, int stride) {
-        const int tid = threadIdx.x;
+    __device__ static __forceinline__ void stage_obs(const StepArgs& p, int row0, int rows, float* in_s, int stride, int tid_in = -1) {
+        const int tid = tid_in < 0 ? (int)threadIdx.x : tid_in;
         if (tid < rows) {                                      // obs = (cos, sin, theta_dot, l, l_dot) of the internal state
             float4 s = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
             if (row0 + tid < p.n) s = reinterpret_cast<const float4*>(p.internal)[row0 + tid];
