@@ -464,13 +464,17 @@ __device__ __forceinline__ void ride_tail(const RideArgs<ENV>& r, const CartCons
 // fwd_a / fwd_b + the actor forward of a lane range: grid (8 column groups, row tiles of the batch, roles + planes of lane
 // tiles); the update's own workgroups come first in dispatch order
 template <class L>
-__global__ __launch_bounds__(kNsThreads) void split_critic_fwd_a_ride_kernel(SplitArgs p, RideArgs<typename L::Env> r) {
-    __shared__ NsLds<128> lds;
+__global__ __launch_bounds__(kThreads) void split_critic_fwd_a_ride_kernel(SplitArgs p, RideArgs<typename L::Env> r) {
+    // 256-thread workgroups: the riders work in pairs (ride_forward_pair); the update's own roles use two of the four waves
+    __shared__ NsLds<128> lds[2];
     __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
     const int roles = (p.twin ? 2 : 1) + 1;
     const NsBlock nb = ns_block();
-    if ((int)blockIdx.z < roles) fwd_a_role<L>(p, lds, tile, nb.tile * kRows, nb.g, blockIdx.z);
-    else ride_forward<typename L::Env>(r, lds, ((int)blockIdx.z - roles) * (int)gridDim.y + nb.tile, nb.g);
+    if ((int)blockIdx.z < roles) {
+        if (threadIdx.x < kNsThreads) fwd_a_role<L>(p, lds[0], tile, nb.tile * kRows, nb.g, blockIdx.z);
+    } else {
+        ride_forward_pair<typename L::Env>(r, lds, ((int)blockIdx.z - roles) * (int)gridDim.y + nb.tile, nb.g);
+    }
 }
 
 template <class L, int PROJ>
@@ -1700,12 +1704,12 @@ int rpo_split_critic_fwd_a_ride(const rpo_split_update* u, const rpo_rollout_rid
     if (a.rollout_ctrl && a.rollout_stats && a.rollout_stats_cap <= 0) return RPO_ERR_ARG;
     for (int k = 0; k < K; ++k)
         if (!a.part_q[k] || !a.x0[k] || !a.h1[k]) return RPO_ERR_NULL;
-    const int lane_wgs = (r->lane_end - r->lane_begin + kRows - 1) / kRows;
+    const int lane_wgs = ((r->lane_end - r->lane_begin + kRows - 1) / kRows + 1) / 2;      // two lane tiles per workgroup
     const dim3 grid(kNsGroups, T, 1 + K + (lane_wgs + T - 1) / T);
     if (u->env == 0)
-        hipLaunchKernelGGL(split_critic_fwd_a_ride_kernel<CartRow>, grid, dim3(kNsThreads), 0, (hipStream_t)stream, a, ride_args<CartEnv>(a, r));
+        hipLaunchKernelGGL(split_critic_fwd_a_ride_kernel<CartRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, ride_args<CartEnv>(a, r));
     else
-        hipLaunchKernelGGL(split_critic_fwd_a_ride_kernel<PendRow>, grid, dim3(kNsThreads), 0, (hipStream_t)stream, a, ride_args<PendEnv>(a, r));
+        hipLaunchKernelGGL(split_critic_fwd_a_ride_kernel<PendRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, ride_args<PendEnv>(a, r));
     RPO_LAUNCH_CHECK();
     return 0;
 }
