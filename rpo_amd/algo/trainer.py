@@ -958,8 +958,16 @@ class RPOTrainerBase(object):
         steady state of a graph run (single rank, or data-parallel over RCCL whose collectives are captured too; training:
         the window starts on a policy_fre boundary; or rollouts only), when neither an evaluation nor the statistics harvest falls inside it; otherwise 1."""
         L = self._cycle
-        if L <= 1 or left < L or warm or (self.dist.on and not self.dist.in_graph) or not self._graphs.enabled:
+        if L <= 1 or warm or (self.dist.on and not self.dist.in_graph) or not self._graphs.enabled:
             return 1
+        if left < L:
+            # the tail of a run: single iterations, or (RPO_TAIL_WINDOWS=1) one shorter window of whole policy_fre periods -- a
+            # hipGraph of its own per length, worth it for callers that repeat the same short run (bench.py --steps 20)
+            if not _env_int("RPO_TAIL_WINDOWS", 0):
+                return 1
+            L = left // self.policy_fre * self.policy_fre if do_train else left
+            if L < 2:
+                return 1
         if do_train and (t < self.warmup or t % self.policy_fre or self.updates_per_step > 1):
             return 1
         if eval and (t // self.eval_fre + 1) * self.eval_fre <= t + L:      # the evaluation splits its own iteration

@@ -713,3 +713,27 @@ def test_fused_front_launch_equals_separate_launches(hip, algo, envname, shared,
     assert runs["1", True]._ride_ok(True) == (ride == "1")
     sync = runs["1", True]._split_state()._held["tile_sync"]
     assert int(sync.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "cart")])
+def test_tail_windows_equal_eager(hip, algo, envname, monkeypatch):
+    """RPO_TAIL_WINDOWS=1: the last < RPO_GRAPH_CYCLE iterations of a run_steps call are one shorter graph window (whole
+    policy_fre periods) instead of single-iteration graphs -- same launches in the same order: six calls of 20 iterations
+    (a 16-iteration window + a 4-iteration one each, both captured by then) equal 120 eager iterations bit for bit."""
+    dev = torch.device("cuda")
+    monkeypatch.setenv("RPO_TAIL_WINDOWS", "1")
+    runs = []
+    for graph in (False, True):
+        torch.manual_seed(5)
+        tr = build_trainer(algo, envname, hip, dev, num_envs=300, use_graph=graph)
+        tr.vec.reset()
+        for _ in range(6):
+            tr.run_steps(20)
+        torch.cuda.synchronize()
+        runs.append(tr)
+    a, b = runs
+    keys = [k for k, e in b._graphs.entries.items() if e["graph"] is not None]
+    assert any(k[:2] == ("cycle", 4) for k in keys) and any(k[:2] == ("cycle", 16) for k in keys), keys
+    assert torch.equal(a.agent.flat.data, b.agent.flat.data) and torch.equal(a.agent.nju.weight, b.agent.nju.weight)
+    assert torch.equal(a.buffer.rows, b.buffer.rows) and torch.equal(a.vec.internal, b.vec.internal)
+    assert int(b.vec.ctrl[0]) == 120 == int(a.vec.ctrl[0])
