@@ -1,4 +1,5 @@
-# A/B of two builds of the library on one box: tools/tmp/ab.sh "<workloads>" "<pytest args>"
+# A/B of two builds of the library on one box (through gpurun): build the old tree, cp librpo_hip.so rpo_amd/csrc/librpo_old.so.bak,
+# build the new one, cp it to librpo_new.so.bak, then:  bash tools/ab.sh "<workloads>" "<pytest args>"
 WL=${1:-cart_ddpg cart_sac}
 cd rpo_amd/csrc
 for round in 1 2; do
