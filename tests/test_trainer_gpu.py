@@ -737,3 +737,21 @@ def test_tail_windows_equal_eager(hip, algo, envname, monkeypatch):
     assert torch.equal(a.agent.flat.data, b.agent.flat.data) and torch.equal(a.agent.nju.weight, b.agent.nju.weight)
     assert torch.equal(a.buffer.rows, b.buffer.rows) and torch.equal(a.vec.internal, b.vec.internal)
     assert int(b.vec.ctrl[0]) == 120 == int(a.vec.ctrl[0])
+
+
+@pytest.mark.parametrize("algo,envname,batch", [("ddpg", "cart", 250), ("sac", "cart", 128), ("sac", "pendulum", 250)])
+def test_fused_front_with_other_batch_sizes(hip, algo, envname, batch, monkeypatch):
+    """The fused launches at batch sizes other than 256: 250 rows (16 row tiles, the last one partly empty: its masked rows
+    still count their workgroups' arrivals) and 128 rows (8 tiles: one per XCD).  Same bits as the separate launches."""
+    dev = torch.device("cuda")
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
+    runs = {}
+    for front in ("0", "1"):
+        monkeypatch.setenv("RPO_FRONT", front)
+        runs[front] = _run(algo, envname, hip, dev, 45, 300, use_graph=True, batch_size=batch)
+    a, b = runs["0"], runs["1"]
+    assert b._front_ok() and not a._front_ok()
+    assert torch.equal(a.agent.flat.data, b.agent.flat.data) and torch.equal(a.agent.nju.weight, b.agent.nju.weight)
+    assert torch.equal(a.agent.critic_target_flat, b.agent.critic_target_flat)
+    assert torch.equal(a.buffer.rows, b.buffer.rows) and torch.equal(a.vec.internal, b.vec.internal)
+    assert int(b._split_state()._held["tile_sync"].abs().sum()) == 0
