@@ -594,7 +594,28 @@ __device__ __forceinline__ float ns_hv_block(const Mlp& net, const MlpGrad& gr, 
         const int j = rb * 16 + o;
         const float w1a = net.W1[j], w1b = two ? net.W1b[j] : 0.0f;
         float gb0 = 0.0f, gw1a = 0.0f, gw1b = 0.0f;
-        for (int c0 = b_lo; c0 < b_hi; c0 += 32) {                 // 32 rows of loads in flight, straight-line inside
+        // scalar heads (the critics): 64 rows of loads in flight -- the whole range of a part at batch 256 in ONE round trip
+        // (these 16 blocks are the longest role of bwd_b: leaving them out made the launch 1.3 us shorter, the 128 dW0 tiles
+        // 0.1 us); same sequential chain over the rows
+        for (int c0 = b_lo; !two && c0 < b_hi; c0 += 64) {
+            float hv[64], d0[64];
+#pragma unroll
+            for (int u = 0; u < 64; ++u) {
+                const int bb = c0 + u < b_hi ? c0 + u : b_hi - 1;
+                hv[u] = h1[(size_t)bb * H + j];
+                d0[u] = dglob[(size_t)bb * dstride];
+            }
+#pragma unroll
+            for (int u = 0; u < 64; ++u) {
+                const bool ok = c0 + u < b_hi;
+                const float h = ok ? hv[u] : 0.0f, a0 = ok ? d0[u] : 0.0f;
+                gb0 += ns_dh(h, a0, 0.0f, w1a, w1b);
+                const float hr = fmaxf(h, 0.0f);
+                gw1a = fmaf(a0, hr, gw1a);
+                gw1b = fmaf(0.0f, hr, gw1b);
+            }
+        }
+        for (int c0 = b_lo; two && c0 < b_hi; c0 += 32) {          // 32 rows of loads in flight, straight-line inside
             float hv[32], d0[32], d1[32];
 #pragma unroll
             for (int u = 0; u < 32; ++u) {
