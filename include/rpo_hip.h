@@ -233,6 +233,8 @@ int rpo_pendulum_act_project(int n, const float* obs, int obs_stride, const floa
                              float corr_eps, float corr_momentum, unsigned long long seed, unsigned env_id_base,
                              const long long* ctrl, float* stats, int stats_cap, void* stream);
 
+#define RPO_PROJ_WS_WORDS 528
+#define RPO_PROJ_WS_GAVE_UP 521
 /* complete_partial + the reference's LITERAL batched grad_steps on a training batch (n <= 1024): batch-global stop
  * test (rpo_ddpg.py:271-272) and the sample-coupled ineq_partial_grad of pendulum.py:337-339, grad_i = sum_j
  * 1[a_x,i * dgp_j - bgp_i > 0] * dgp_j.  Used for the TD-target projection of critic_loss
@@ -240,6 +242,12 @@ int rpo_pendulum_act_project(int n, const float* obs, int obs_stride, const floa
 int rpo_pendulum_project_batchref(int n, const float* obs, int obs_stride, const float* ap, float* action,
                                   int* iters_out, int max_steps, float corr_lr, float corr_eps, float corr_momentum,
                                   void* stream);
+/* The same on eight workgroups (n <= 256, max_steps <= 30): each owns 32 rows, and the batch's dgp values are all-gathered
+ * once per GRG iteration through tagged 8-byte granules in `ws` (RPO_PROJ_WS_WORDS 64-bit words, 128-byte aligned, zero before
+ * the first launch; see rpo_split_update.proj_ws for store_mode and the gave-up word).  Same bits as the call above. */
+int rpo_pendulum_project_batchref_ws(int n, const float* obs, int obs_stride, const float* ap, float* action, int* iters_out,
+                                     int max_steps, float corr_lr, float corr_eps, float corr_momentum,
+                                     unsigned long long* ws, int store_mode, void* stream);
 
 /* grad_ap[i] = grad_action[i,0] - grad_action[i,1] * sin/cos (autograd through pendulum.py:256-262). */
 int rpo_pendulum_complete_bwd(int n, const float* obs, int obs_stride, const float* grad_action, float* grad_ap,
@@ -490,7 +498,15 @@ typedef struct {
      * aligned, zero before the first launch (every launch leaves them zero); word [3 * ceil(batch / 16) * 32] is set to 1 if a
      * workgroup ever gave up waiting for its tile's producers (never, on a healthy device). */
     unsigned* tile_sync;
+    /* rpo_split_pend_head_project: NULL (one workgroup), or RPO_PROJ_WS_WORDS 64-bit words, 128-byte aligned, zero before the
+     * first launch: the batch-coupled projection then runs on eight workgroups that all-gather the batch's dgp values once
+     * per GRG iteration through tagged 8-byte granules in this buffer (batch <= 256, max_steps <= 30; same bits).  Word
+     * RPO_PROJ_WS_GAVE_UP is set to 1 if a workgroup ever gave up waiting for another one's granules (never, on a healthy
+     * device).  proj_store_mode: 0 = agent-scope granule stores; 1 = plain stores when the eight workgroups find themselves on
+     * one XCD (checked inside every launch; the polling loads are served by that XCD's L2), agent-scope otherwise. */
+    unsigned long long* proj_ws; int proj_store_mode;
 } rpo_split_update;
+
 
 int rpo_split_critic_fwd_a(const rpo_split_update* u, void* stream);
 int rpo_split_critic_fwd_b(const rpo_split_update* u, void* stream);

@@ -596,6 +596,12 @@ class RPOTrainerBase(object):
             fields.update(raw=b("pi.raw", B, 2))
         else:
             fields.update(ap_det=b("act.ap_det", B))
+        if isinstance(k, be.PendulumKernels) and _env_int("RPO_PROJ_MULTI", 1) and B <= 256 and self.max_steps <= 30:
+            # the batch-coupled projection on eight workgroups (rpo_split_pend_head_project); workspace of
+            # RPO_PROJ_WS_WORDS 64-bit words.  RPO_PROJ_STORE: 0 agent-scope granule stores, 1 (default) plain stores when the
+            # eight workgroups share an XCD (checked inside every launch)
+            fields.update(proj_ws=torch.zeros(hip_ops.PROJ_WS_WORDS, dtype=torch.int64, device=self.device),
+                          proj_store_mode=_env_int("RPO_PROJ_STORE", 1))
         self._split_cache = be.SplitUpdate(k, descs, self.sac, B, fields)
         self._front_cache = bool(_env_int("RPO_FRONT", 1)) and hasattr(be, "front_launch_ok") and be.front_launch_ok(B, self.sac)
         self._split_loss = fields["loss_partial"]
@@ -725,6 +731,10 @@ class RPOTrainerBase(object):
         if sync is not None and getattr(self, "_front_cache", False) and int(sync[-32]) != 0:
             raise RuntimeError("rpo_split_*_front: a workgroup gave up waiting for its row tile (tile_sync flag set); "
                                "rerun with RPO_FRONT=0")
+        ws = su._held.get("proj_ws") if su else None
+        if ws is not None and int(ws[hip_ops.PROJ_WS_GAVE_UP]) != 0:
+            raise RuntimeError("rpo_split_pend_head_project: a workgroup gave up waiting for another one's granules "
+                               "(workspace flag set); rerun with RPO_PROJ_MULTI=0")
 
     def _front_ok(self):
         """rpo_split_critic_front usable here (``RPO_FRONT=0``: never): see ops.front_launch_ok."""

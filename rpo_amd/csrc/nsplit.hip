@@ -503,6 +503,139 @@ __global__ __launch_bounds__(1024) void split_pend_head_project_kernel(SplitArgs
                                              p.corr_momentum, lds);
 }
 
+// B <= 256: thread i < B takes the head of row i, then the register-tiled projection (project_batchref_wide)
+__global__ __launch_bounds__(1024) void split_pend_head_project_wide_kernel(SplitArgs p) {
+    __shared__ __attribute__((aligned(16))) float lds[rpo_pend_dev::kWideLds];
+    const int i = threadIdx.x;
+    float ap = 0.0f;
+    if (i < p.B) {
+        float logp = 0.0f;
+        ap = ns_policy_head(p, i, p.ctrl[RPO_CTRL_T], &logp);
+        if (p.twin) p.logp[i] = logp;
+    }
+    rpo_pend_dev::project_batchref_wide(p.B, p.batch_out + PendRow::NS_OFF, RPO_PEND_ROW, ap, p.next_actions, p.proj_iters,
+                                        p.max_steps, p.corr_lr, p.corr_eps, p.corr_momentum, lds);
+}
+
+// ---- The same on EIGHT workgroups (B <= 256, max_steps <= kPmMaxSteps): workgroup w owns the samples [32 w, 32 w + 32) --
+// 16 lanes per sample, the values j = 64 q + 4 c + m of project_batchref_wide, so the bits are its bits -- and the n^2
+// predicate sum of a GRG iteration is 1/8 per compute unit (the one-workgroup form is bound by the vector ALU of ONE CU:
+// 2.3 us per iteration).  Every iteration is an all-gather of the 256 dgp values (+ the rows' stop bits) between the
+// workgroups, done with 8-byte {tag, value} granules in `ws`: the data IS the flag (a reader takes a granule only when it
+// carries the tag of this launch and iteration), so no fences, no arrival counter, and nothing stale can be consumed
+// whatever the placement.  Granule stores are agent-scope (write-through `sc1`) unless the workgroups find themselves on
+// ONE XCD (they exchange HW_REG_XCC_ID through such granules first): then plain stores, which stay in that XCD's L2 where
+// the `sc1` polling loads are served -- a speed choice only, taken inside the launch it applies to.
+// ws (u64 words, zero before the first launch): [2][256] dgp granules (by iteration parity) | [8] XCC granules | epoch |
+// gave-up flag.  Tags are epoch * 32 + 1 (XCC) / + 2 + k (iteration k); workgroup 0 advances the epoch when it is done
+// (it has then seen every other workgroup's last granule, so every workgroup has read the epoch).
+constexpr int kPmGroups = 8, kPmRows = 32, kPmThreads = kPmRows * 16, kPmMaxSteps = 30, kPmSpinMax = 1 << 16;
+constexpr int kPmXcc = 512, kPmEpoch = 520, kPmGaveUp = 521, kPmWords = 528;
+
+__device__ __forceinline__ void pm_store(unsigned long long* g, unsigned long long v, bool local) {
+    if (local) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(g), "v"(v) : "memory");
+    else __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long pm_load(unsigned long long* g) {
+    return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// (ap_in != NULL: the basic actions are given and the observations are rows of `obs` -- rpo_pendulum_project_batchref_ws)
+__global__ __launch_bounds__(kPmThreads) void split_pend_head_project_multi_kernel(SplitArgs p, unsigned long long* ws, int store_mode,
+                                                                                   const float* ap_in, const float* obs,
+                                                                                   int obs_stride) {
+    using namespace rpo_pend_dev;
+    if (blockIdx.x & 7) return;                                  // block b runs on XCD b % 8: the eight workers are blocks 0, 8, ..
+    const int wg = blockIdx.x >> 3, tid = threadIdx.x, c = tid & 15, sl = tid >> 4, n = p.B;
+    __shared__ __attribute__((aligned(16))) float lds[6 * kPmRows + 2 * 256 + 8];
+    float* st = lds;
+    float* dbuf = lds + 6 * kPmRows;
+    int* flags = reinterpret_cast<int*>(lds + 6 * kPmRows + 2 * 256);   // [0] stop word, [1] plain stores allowed, [2] gave up
+    const unsigned epoch = (unsigned)pm_load(ws + kPmEpoch) & 0x3ffffffu;   // (31-bit tags)
+    const unsigned long long tag0 = (unsigned long long)epoch * 32ull + 1ull;
+    if (tid == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        pm_store(ws + kPmXcc + wg, (tag0 << 32) | (xcc & 15u), false);
+        flags[0] = 0; flags[2] = 0;
+    }
+    if (tid < kPmRows) {                                         // head of the policy for the workgroup's rows, Complete
+        const int i = wg * kPmRows + tid;
+        Eq e = {0.0f, 1.0f, 1.0f, 0.0f};
+        float ax = 0.0f, ay = 0.0f;
+        if (i < n) {
+            const float* o;
+            if (ap_in) {
+                ax = ap_in[i];
+                o = obs + (size_t)i * obs_stride;
+            } else {
+                float logp = 0.0f;
+                ax = ns_policy_head(p, i, p.ctrl[RPO_CTRL_T], &logp);
+                if (p.twin) p.logp[i] = logp;
+                o = p.batch_out + (size_t)i * RPO_PEND_ROW + PendRow::NS_OFF;
+            }
+            e = set_eq(o[0], o[1], o[2], o[3], o[4]);
+            ay = pb_complete(e, ax);
+        }
+        st[tid] = ax; st[kPmRows + tid] = ay; st[2 * kPmRows + tid] = e.C_p; st[3 * kPmRows + tid] = e.C_o;
+        st[4 * kPmRows + tid] = e.C_o_inv; st[5 * kPmRows + tid] = e.b;
+    }
+    if (tid >= 64 && tid < 128) {                                // one wave: are the eight workgroups on one XCD?
+        const int l = tid - 64;
+        unsigned long long x = 0;
+        bool ok = true;
+        for (int spins = 0;; ++spins) {
+            if (l < kPmGroups) { x = pm_load(ws + kPmXcc + l); ok = (x >> 32) == tag0; }
+            if (__all(ok)) break;
+            if (spins >= kPmSpinMax) { if (l == 0) flags[2] = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const unsigned mine = (unsigned)x & 15u, first = (unsigned)__builtin_amdgcn_readfirstlane((int)mine);
+        const bool same = __all(l >= kPmGroups || (ok && mine == first));
+        if (l == 0) flags[1] = (store_mode == 2 || (store_mode == 1 && same)) ? 1 : 0;
+    }
+    __syncthreads();
+    const bool local = flags[1] != 0;
+    PbSample sm;
+    pb_init(sm, st[sl], st[kPmRows + sl], st[2 * kPmRows + sl], st[3 * kPmRows + sl], st[4 * kPmRows + sl], st[5 * kPmRows + sl]);
+    const int me = wg * kPmRows + sl;                            // this thread's sample (16 lanes each)
+    int k = 0;
+    for (; k < p.max_steps; ++k) {
+        const unsigned long long tag = tag0 + 1ull + (unsigned long long)k;
+        unsigned long long* gk = ws + (k & 1) * 256;
+        float dg;
+        const bool viol = pb_pre(sm, p.corr_eps, dg);
+        if (c == 0)                                              // granule: stop bit | 31-bit tag | dgp
+            pm_store(gk + me, ((unsigned long long)(viol ? 1u : 0u) << 63) | (tag << 32) |
+                                  (unsigned long long)__float_as_uint(me < n ? dg : 0.0f), local);
+        float* dk = dbuf + (k & 1) * 256;
+        if (tid < 256) {                                         // four waves gather the 256 granules of this iteration
+            unsigned long long x = 0;
+            bool ok = false;
+            for (int spins = 0;; ++spins) {
+                x = pm_load(gk + tid);
+                ok = ((x >> 32) & 0x7fffffffull) == tag;
+                if (__all(ok)) break;
+                if (spins >= kPmSpinMax) { flags[2] = 1; break; }
+            }
+            dk[tid] = __uint_as_float((unsigned)x);
+            if (__any(ok && (x >> 63))) flags[0] = k + 1;        // (every writer of this iteration stores the same value)
+        }
+        __syncthreads();
+        if ((k > 0 && flags[0] < k + 1) || flags[2]) break;      // batch-global stop test, rpo_ddpg.py:271-272
+        float dv[16];
+        pb_load16(dk, c, dv);
+        const float grad = rpo_row16_allsum(pb_partial(sm.ax, pb_bgp(sm), dv));
+        pb_step(sm, grad, p.corr_lr, p.corr_momentum);
+    }
+    if (c == 0 && me < n) reinterpret_cast<float2*>(p.next_actions)[me] = make_float2(sm.ax, sm.ay);
+    if (wg == 0 && tid == 0) {
+        if (p.proj_iters) *p.proj_iters = k;
+        if (flags[2]) __hip_atomic_store(ws + kPmGaveUp, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ws + kPmEpoch, (unsigned long long)(epoch + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ---- TD target + Huber for row i of critic k from the slab partials (rpo_ddpg.py:331-335, rpo_sac.py:346-353)
 template <class L>
 __device__ __forceinline__ float ns_td_row(const SplitArgs& p, int k, int i, float* hub) {
@@ -1620,13 +1753,32 @@ int rpo_split_pend_head_project(const rpo_split_update* u, void* stream) {
     if (u->env != 1 || a.max_steps < 0) return RPO_ERR_ARG;
     if (!a.batch_out || !a.ctrl || !a.part_pi || !a.next_actions || (a.twin && !a.logp)) return RPO_ERR_NULL;
     const size_t lds = ((size_t)a.B + 4) * sizeof(float);
-    if (a.B <= 256) {
-        const int threads = (a.B * 4 + RPO_WAVE - 1) / RPO_WAVE * RPO_WAVE;
-        hipLaunchKernelGGL(split_pend_head_project_kernel<4>, dim3(1), dim3(threads), lds, (hipStream_t)stream, a);
+    static_assert(kPmWords == RPO_PROJ_WS_WORDS && kPmGaveUp == RPO_PROJ_WS_GAVE_UP, "workspace layout");
+    if (u->proj_ws && a.B <= 256 && a.max_steps <= kPmMaxSteps) {
+        if (((uintptr_t)u->proj_ws & 127u) || u->proj_store_mode < 0 || u->proj_store_mode > 2) return RPO_ERR_ARG;
+        hipLaunchKernelGGL(split_pend_head_project_multi_kernel, dim3(8 * kPmGroups), dim3(kPmThreads), 0, (hipStream_t)stream, a,
+                           u->proj_ws, u->proj_store_mode, (const float*)nullptr, (const float*)nullptr, 0);
+    } else if (a.B <= 256) {
+        hipLaunchKernelGGL(split_pend_head_project_wide_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
     } else {
         const int threads = (a.B + RPO_WAVE - 1) / RPO_WAVE * RPO_WAVE;
         hipLaunchKernelGGL(split_pend_head_project_kernel<1>, dim3(1), dim3(threads), lds, (hipStream_t)stream, a);
     }
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_pendulum_project_batchref_ws(int n, const float* obs, int obs_stride, const float* ap, float* action, int* iters_out,
+                                     int max_steps, float corr_lr, float corr_eps, float corr_momentum,
+                                     unsigned long long* ws, int store_mode, void* stream) {
+    if (n <= 0 || n > 256 || max_steps < 0 || max_steps > kPmMaxSteps || obs_stride < RPO_PEND_OBS_DIM) return RPO_ERR_ARG;
+    if (!obs || !ap || !action || !ws) return RPO_ERR_NULL;
+    if (((uintptr_t)ws & 127u) || store_mode < 0 || store_mode > 2) return RPO_ERR_ARG;
+    SplitArgs a{};
+    a.B = n; a.next_actions = action; a.proj_iters = iters_out; a.max_steps = max_steps; a.corr_lr = corr_lr;
+    a.corr_eps = corr_eps; a.corr_momentum = corr_momentum;
+    hipLaunchKernelGGL(split_pend_head_project_multi_kernel, dim3(8 * kPmGroups), dim3(kPmThreads), 0, (hipStream_t)stream, a, ws,
+                       store_mode, ap, obs, obs_stride);
     RPO_LAUNCH_CHECK();
     return 0;
 }

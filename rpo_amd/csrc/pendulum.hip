@@ -100,6 +100,15 @@ __global__ __launch_bounds__(1024) void pendulum_project_batchref_kernel(
                                max_steps, corr_lr, corr_eps, corr_momentum, lds);
 }
 
+// n <= 256: the register-tiled form (project_batchref_wide), always a full 1024-thread workgroup
+__global__ __launch_bounds__(1024) void pendulum_project_batchref_wide_kernel(
+    int n, const float* __restrict__ obs, int obs_stride, const float* __restrict__ ap, float* __restrict__ action,
+    int* __restrict__ iters_out, int max_steps, float corr_lr, float corr_eps, float corr_momentum) {
+    __shared__ __attribute__((aligned(16))) float lds[kWideLds];
+    project_batchref_wide(n, obs, obs_stride, (int)threadIdx.x < n ? ap[threadIdx.x] : 0.0f, action, iters_out, max_steps,
+                          corr_lr, corr_eps, corr_momentum, lds);
+}
+
 __global__ __launch_bounds__(RPO_BLOCK) void pendulum_complete_bwd_kernel(int n, const float* __restrict__ obs,
                                                                           int obs_stride,
                                                                           const float* __restrict__ ga,
@@ -219,9 +228,8 @@ int rpo_pendulum_project_batchref(int n, const float* obs, int obs_stride, const
     if (n <= 0 || n > 1024 || max_steps < 0 || obs_stride < RPO_PEND_OBS_DIM) return RPO_ERR_ARG;
     if (!obs || !ap || !action) return RPO_ERR_NULL;
     const size_t lds = ((size_t)n + 4) * sizeof(float);
-    if (n <= 256) {                                                // 4 lanes per sample (see project_batchref_body)
-        const int threads = (n * 4 + RPO_WAVE - 1) / RPO_WAVE * RPO_WAVE;
-        hipLaunchKernelGGL(pendulum_project_batchref_kernel<4>, dim3(1), dim3(threads), lds, (hipStream_t)stream, n, obs,
+    if (n <= 256) {                                                // four samples x 16 values per thread (project_batchref_wide)
+        hipLaunchKernelGGL(pendulum_project_batchref_wide_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, obs,
                            obs_stride, ap, action, iters_out, max_steps, corr_lr, corr_eps, corr_momentum);
     } else {
         const int threads = (n + RPO_WAVE - 1) / RPO_WAVE * RPO_WAVE;

@@ -270,6 +270,143 @@ __device__ __forceinline__ void project_batchref_body(int n, const float* o, flo
     if (threadIdx.x == 0 && iters_out) *iters_out = k;
 }
 
+// The same for n <= 256 on a 1024-thread workgroup, laid out for the vector ALU (the n^2 predicate sum is issue-bound on the
+// ONE compute unit that owns the batch; the LPS form above spent 3 us per GRG iteration, 2/3 of it in LDS traffic -- every
+// thread read 64 values per iteration -- and in two 16-wave barriers):
+//   * thread (g = tid / 16, c = tid % 16) owns the FOUR samples 4 g .. 4 g + 3 against the 16 values j = 64 q + 4 c + m
+//     (q, m < 4): 4 ds_read_b128 per iteration instead of 16, each value used for four samples from a register;
+//   * the 16 partial sums of a sample meet in a DPP butterfly inside the row (quad_perm, row_half_mirror, row_mirror: every
+//     lane ends with the same bits), and all 16 lanes step their four samples redundantly -- the state stays in registers;
+//   * one barrier per iteration: dgp is double-buffered, and the batch-global stop test (rpo_ddpg.py:271-272) is one
+//     monotone word -- iteration k stores k + 1 when a row is infeasible, readers test >= k + 1 (a later iteration only
+//     exists if this one went on, so a fast wave's k + 2 means the same as k + 1).
+// The predicate is evaluated as fl(a_x,i * dgp_j) > bgp_i: with gradual underflow (f32 denormals are on in this build, as
+// in torch on the CPU) fl(t - b) > 0 <=> t > b, so the selected set is exactly the reference's clamp(... - bgp, 0) > 0.
+// The sum's order differs from the LPS form's (and from the reference's BLAS matmul, which has none to follow).
+// Thread tid < n brings the basic action of sample tid (`ap_mine`) and reads its observation; lds: 8 * 256 + 4 floats.
+constexpr int kWideLds = 8 * 256 + 4;
+
+__device__ __forceinline__ float rpo_row16_allsum(float v) {      // sum over the 16 lanes of a DPP row, in EVERY lane
+    v += rpo_dpp_mov<0xB1>(v);                                   // quad_perm:[1,0,3,2]
+    v += rpo_dpp_mov<0x4E>(v);                                   // quad_perm:[2,3,0,1]
+    v += rpo_dpp_mov<0x141>(v);                                  // row_half_mirror: the neighbouring quad's sum
+    v += rpo_dpp_mov<0x140>(v);                                  // row_mirror: the other half's sum
+    return v;
+}
+
+// One sample's state in the batched projection, and the pieces of a GRG iteration -- shared by the one-workgroup form below
+// and the eight-workgroup form of nsplit.hip (split_pend_head_project_multi_kernel), which must round identically.
+struct PbSample { float ax, ay, ox, oy, Cp, Co, Ci, bb, cc, bc; };
+
+__device__ __forceinline__ void pb_init(PbSample& s, float ax, float ay, float Cp, float Co, float Ci, float bb) {
+    RPO_FP_STRICT
+    s.ax = ax; s.ay = ay; s.ox = 0.0f; s.oy = 0.0f; s.Cp = Cp; s.Co = Co; s.Ci = Ci; s.bb = bb;
+    s.cc = Ci * Cp;                                                // :334-335 (C_o_inv C_p)
+    s.bc = bb * Ci;                                                // :336 (b C_o_inv)
+}
+__device__ __forceinline__ float pb_complete(const Eq& e, float ax) {
+    RPO_FP_STRICT
+    return (e.b - ax * e.C_p) * e.C_o_inv;                         // complete_partial :256-262
+}
+// stop test of the row (rpo_ddpg.py:271-272) and its dgp (pendulum.py:334-335) at the current action
+__device__ __forceinline__ bool pb_pre(const PbSample& s, float corr_eps, float& dgp) {
+    RPO_FP_STRICT
+    const float h = s.bb - (s.ax * s.Cp + s.ay * s.Co);
+    const float g = s.ax * s.ax + s.ay * s.ay - kMaxSum;
+    dgp = 2.0f * s.ax - 2.0f * s.ay * s.cc;
+    return fabsf(h) > corr_eps || g > corr_eps;
+}
+__device__ __forceinline__ float pb_bgp(const PbSample& s) {
+    RPO_FP_STRICT
+    return kMaxSum - s.bc * (2.0f * s.ay);                         // :336
+}
+// the thread's 16 values of the row sum, j = 64 q + 4 c + m in the order (q, m): d = the dgp array of this iteration
+__device__ __forceinline__ void pb_load16(const float* d, int c, float (&dv)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = reinterpret_cast<const float4*>(d)[q * 16 + c];
+        dv[4 * q] = v.x; dv[4 * q + 1] = v.y; dv[4 * q + 2] = v.z; dv[4 * q + 3] = v.w;
+    }
+}
+__device__ __forceinline__ float pb_partial(float ax, float bgp, const float (&dv)[16]) {
+    RPO_FP_STRICT
+    float g = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) g += (ax * dv[u] > bgp) ? dv[u] : 0.0f;   // [B,1] @ [1,B] coupling, :337-339
+    return g;
+}
+__device__ __forceinline__ void pb_step(PbSample& s, float grad, float corr_lr, float corr_momentum) {
+    RPO_FP_STRICT
+    const float gy = -(grad * s.Cp) * s.Ci;                        // :342
+    const float sx = corr_lr * grad + corr_momentum * s.ox;
+    const float sy = corr_lr * gy + corr_momentum * s.oy;
+    s.ax -= sx; s.ay -= sy;
+    s.ox = sx; s.oy = sy;
+}
+
+__device__ __forceinline__ void project_batchref_wide(int n, const float* __restrict__ obs, int obs_stride, float ap_mine,
+                                                      float* __restrict__ action, int* __restrict__ iters_out,
+                                                      int max_steps, float corr_lr, float corr_eps, float corr_momentum,
+                                                      float* lds) {
+    RPO_FP_STRICT
+    // lds: ax | ay | C_p | C_o | C_o_inv | b (256 each), dgp[2][256], stop word
+    float* st = lds;
+    float* dbuf = lds + 6 * 256;
+    int* stop = reinterpret_cast<int*>(lds + 8 * 256);      // (plain LDS accesses: the barriers order them)
+    const int tid = threadIdx.x, c = tid & 15, grp = tid >> 4;
+    if (tid < 256) {
+        Eq e = {0.0f, 1.0f, 1.0f, 0.0f};
+        float ax = 0.0f, ay = 0.0f;
+        if (tid < n) {
+            const float* o = obs + (size_t)tid * obs_stride;
+            e = set_eq(o[0], o[1], o[2], o[3], o[4]);
+            ax = ap_mine;
+            ay = pb_complete(e, ax);
+        }
+        st[tid] = ax; st[256 + tid] = ay; st[512 + tid] = e.C_p; st[768 + tid] = e.C_o; st[1024 + tid] = e.C_o_inv;
+        st[1280 + tid] = e.b;
+    }
+    if (tid == 0) *stop = 0;
+    __syncthreads();
+    PbSample sm[4];
+    {
+        float v[6][4];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const float4 x = reinterpret_cast<const float4*>(st + 256 * a)[grp];
+            v[a][0] = x.x; v[a][1] = x.y; v[a][2] = x.z; v[a][3] = x.w;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pb_init(sm[s], v[0][s], v[1][s], v[2][s], v[3][s], v[4][s], v[5][s]);
+    }
+    const int mine = 4 * grp + c;                                  // lanes c < 4 publish dgp of sample 4 grp + c
+    int k = 0;
+    for (; k < max_steps; ++k) {
+        bool viol = false;
+        float dg[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) viol = pb_pre(sm[s], corr_eps, dg[s]) || viol;
+        float* dk = dbuf + (k & 1) * 256;
+        if (c < 4) dk[mine] = mine < n ? (c == 0 ? dg[0] : c == 1 ? dg[1] : c == 2 ? dg[2] : dg[3]) : 0.0f;
+        if (viol) *stop = k + 1;                                   // (every writer of this iteration stores the same value)
+        __syncthreads();
+        if (k > 0 && *stop < k + 1) break;                         // batch-global stop test, rpo_ddpg.py:271-272
+        float dv[16];
+        pb_load16(dk, c, dv);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float grad = rpo_row16_allsum(pb_partial(sm[s].ax, pb_bgp(sm[s]), dv));
+            pb_step(sm[s], grad, corr_lr, corr_momentum);
+        }
+    }
+    if (c == 0) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (4 * grp + s < n) reinterpret_cast<float2*>(action)[4 * grp + s] = make_float2(sm[s].ax, sm[s].ay);
+    }
+    if (tid == 0 && iters_out) *iters_out = k;
+}
+
 // One row of nu . relu(g(a)) with g = |a|^2 - 32 (pendulum.py:302-311; rpo_sac.py:326-335): returns nu0 * relu(g),
 // `dist` = relu(g) (d/d nu) and (g0, g1) = scale * d/d action.  Shared by rpo_pendulum_lagrangian and the fused pipelines.
 __device__ __forceinline__ float lagrangian_row(float ax, float ay, float nu0, float scale, float& dist, float& g0, float& g1) {

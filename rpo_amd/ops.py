@@ -22,6 +22,8 @@ ADAM_CLOCK = True           # rpo_adam_step / _multi take the update-clock argum
 STATS_LEN = CONST["RPO_STATS_LEN"]
 STATS_SUB = CONST["RPO_STATS_SUB"]
 CTRL_LEN = CONST["RPO_CTRL_LEN"]
+PROJ_WS_WORDS = CONST["RPO_PROJ_WS_WORDS"]
+PROJ_WS_GAVE_UP = CONST["RPO_PROJ_WS_GAVE_UP"]
 STAT = {k[len("RPO_STAT_"):].lower(): v for k, v in CONST.items()
         if k.startswith("RPO_STAT_") and k not in ("RPO_STATS_LEN", "RPO_STATS_SUB")}
 
@@ -452,6 +454,14 @@ class PendulumKernels(object):
                                                         corr_eps, corr_momentum, _stream()),
               "rpo_pendulum_project_batchref")
 
+    def project_batchref_ws(self, obs, ap, action, iters_out, max_steps, corr_lr, corr_eps, corr_momentum, ws, store_mode=1):
+        """project_batchref on eight workgroups; ws: zero-initialised int64[PROJ_WS_WORDS] workspace (kept by the caller)."""
+        op, ostride = _row_view(obs, 5)
+        check(_lib.load().rpo_pendulum_project_batchref_ws(action.shape[0], op, ostride, _p(ap), _p(action),
+                                                           _p(iters_out, torch.int32, allow_none=True), max_steps, corr_lr,
+                                                           corr_eps, corr_momentum, _p(ws, torch.int64), store_mode, _stream()),
+              "rpo_pendulum_project_batchref_ws")
+
     def complete_bwd(self, obs, grad_action, grad_ap, action=None):
         op, ostride = _row_view(obs, 5)
         check(_lib.load().rpo_pendulum_complete_bwd(grad_action.shape[0], op, ostride, _p(grad_action), _p(grad_ap),
@@ -752,7 +762,7 @@ class _SplitUpdateStruct(ctypes.Structure):
          ("prep_beta2", ctypes.c_float), ("clock_out", ctypes.c_void_p), ("gradmax_reset", ctypes.c_void_p),
          ("prep2_step", ctypes.c_void_p * 3), ("prep2_beta1", ctypes.c_float * 3), ("prep2_beta2", ctypes.c_float * 3),
          ("gradmax_reset2", ctypes.c_void_p), ("updates_out", ctypes.c_void_p), ("part_pol", ctypes.c_void_p),
-         ("tile_sync", ctypes.c_void_p)])
+         ("tile_sync", ctypes.c_void_p), ("proj_ws", ctypes.c_void_p), ("proj_store_mode", ctypes.c_int)])
 
 
 class _RolloutRiderStruct(ctypes.Structure):
@@ -827,6 +837,8 @@ class SplitUpdate(object):
             if isinstance(v, torch.Tensor):
                 dt = torch.int64 if k in ("idx_out", "idx_in", "ctrl", "rollout_ctrl", "clock_out", "updates_out") else \
                     (torch.int32 if k in ("proj_iters", "prep_step", "tile_sync") else torch.float32)
+                if k == "proj_ws":
+                    dt = torch.int64
                 self._held[k] = v                                   # keeps the buffer alive while the struct points at it
                 setattr(self.st, k, _p(v, dt).value)
             else:

@@ -463,12 +463,21 @@ def gen_training_stats(steps=3000, n_seeds=None, workers=8):
     ~3.4e-4: together with a larger number of GPU runs the comparison resolves the north_star's 1e-3 at two sigma.
     SpringPendulum-RPOSAC violates ~5e-4 of the steps with a spread of ~5e-4: 24 seeds are ample."""
     import multiprocessing as mp
-    plan = n_seeds or {("ddpg", "cart"): 384, ("sac", "pendulum"): 24, ("sac", "cart"): 96, ("ddpg", "pendulum"): 48}
+    plan = n_seeds or {("ddpg", "cart"): 384, ("sac", "pendulum"): 24, ("sac", "cart"): 96, ("ddpg", "pendulum"): 192}
+    only = os.environ.get("RPO_STATS_ONLY")                    # e.g. "ddpg:pendulum" -- regenerate one case
+    if only:
+        plan = {k: v for k, v in plan.items() if "%s:%s" % k in only.split(",")}
+    workers = int(os.environ.get("RPO_STATS_WORKERS", workers))
+    extend = int(os.environ.get("RPO_STATS_EXTEND", "0"))       # > 0: keep the recorded seeds, add seeds up to this count
     for (algo, envname), count in plan.items():
-        jobs = [(algo, envname, seed, steps) for seed in range(count)]
+        have = np.zeros((0, 7))
+        if extend:
+            have = np.load(os.path.join(HERE, "training_stats_%s_%s.npz" % (algo, envname)))["stats"]
+            count = max(extend, len(have))
+        jobs = [(algo, envname, seed, steps) for seed in range(len(have), count)]
         with mp.get_context("fork").Pool(workers) as pool:
             rows = pool.map(_stats_run, jobs, chunksize=1)
-        rows = np.array(rows)
+        rows = np.concatenate([have, np.array(rows).reshape(-1, 7)])
         print(algo, envname, "mean", rows.mean(0), "se", rows.std(0) / np.sqrt(len(rows)))
         save("training_stats_%s_%s" % (algo, envname), stats=rows, steps=steps,
              columns=np.array(["logged_steps", "viol_rate", "mean_max_ineq", "mean_max_eq", "mean_return_per_step",

@@ -329,6 +329,67 @@ def test_pendulum_act_project_matches_reference(ops, golden):
     assert torch.equal(a2, action)
 
 
+@pytest.mark.parametrize("n", [1, 3, 17, 100, 255, 256, 300, 1000])
+def test_pendulum_batched_projection_matches_reference_arithmetic(ops, golden, n):
+    """rpo_pendulum_project_batchref = RPODDPG.grad_steps on a batch, literally (rpo_ddpg.py:266-286 with the [B,1] @ [1,B]
+    coupling of pendulum.py:337-339).  After ONE iteration the selected set 1[a_x,i dgp_j - bgp_i > 0] is a function of the
+    inputs alone, so kernel and oracle must agree to summation round-off (the reference's own sum is a BLAS matmul without a
+    defined order); over 10 iterations a 1-ulp difference can flip a predicate that sits on its threshold, which moves
+    that row by one lr * dgp_j ~ 1e-2 -- the tolerance the CPU test of the oracle against the reference uses as well.
+    n <= 256 runs the register-tiled workgroup (project_batchref_wide), larger batches one thread per sample."""
+    g = golden("pendulum_grad_steps")
+    rng = np.random.default_rng(n)
+    pick = rng.integers(0, 256, n)
+    obs_n = g["obs32"][pick].astype(np.float32)
+    ap_n = (g["ap"].reshape(-1)[pick] + rng.normal(0, 0.5, n)).astype(np.float32)
+    k = ops.PendulumKernels()
+    obs, ap = dev(obs_n), dev(ap_n)
+    action = torch.zeros(n, 2, device=DEV)
+    iters = torch.zeros(1, dtype=torch.int32, device=DEV)
+    a0 = pd.complete_partial(obs_n, ap_n)
+    k.project_batchref(obs, ap, action, iters, 0, 2e-3, 1e-5, 0.0)
+    np.testing.assert_allclose(action.cpu().numpy(), a0, rtol=2e-6, atol=2e-6)
+    for lr in (2e-3, 0.05):
+        want, it = pd.grad_steps(obs_n, a0, lr=lr, max_steps=1, batch_global_stop=True, batched_reference=True)
+        k.project_batchref(obs, ap, action, iters, 1, lr, 1e-5, 0.0)
+        scale = np.abs(want).max() + 1.0
+        np.testing.assert_allclose(action.cpu().numpy(), want, rtol=0, atol=4e-6 * scale * max(1.0, lr * n))
+        assert int(iters.item()) == 1
+    lr10 = 2e-3 * min(1.0, 256.0 / n)                            # (the coupled step grows with the batch: keep it contracting)
+    want, it = pd.grad_steps(obs_n, a0, lr=lr10, max_steps=10, batch_global_stop=True, batched_reference=True)
+    k.project_batchref(obs, ap, action, iters, 10, lr10, 1e-5, 0.0)
+    got = action.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-3, atol=2e-2)
+    assert (np.abs(got - want).max(axis=1) < 1e-4).mean() > 0.9
+    assert int(iters.item()) == int(it.max())
+    # momentum, and the batch-global stop: a feasible batch stops after its first iteration
+    want, it = pd.grad_steps(obs_n, a0, lr=lr10, max_steps=10, momentum=0.5, batch_global_stop=True, batched_reference=True)
+    k.project_batchref(obs, ap, action, iters, 10, lr10, 1e-5, 0.5)
+    np.testing.assert_allclose(action.cpu().numpy(), want, rtol=1e-3, atol=4e-2)
+    small = dev(np.zeros(n, dtype=np.float32))
+    want, it = pd.grad_steps(obs_n, pd.complete_partial(obs_n, np.zeros(n, np.float32)), lr=0.0, max_steps=10,
+                             batch_global_stop=True, batched_reference=True)
+    k.project_batchref(obs, small, action, iters, 10, 0.0, 1e-5, 0.0)
+    assert int(iters.item()) == int(it.max())
+    if n == 256:                                                  # the reference's own batched result
+        k.project_batchref(dev(g["obs32"]), dev(g["ap"].reshape(-1)), action, iters, 10, 2e-3, 1e-5, 0.0)
+        np.testing.assert_allclose(action.cpu().numpy(), g["train_batched"], rtol=1e-3, atol=1e-2)
+    if n <= 256:
+        # the eight-workgroup form (tagged-granule all-gather per GRG iteration) gives the same bits, with agent-scope granule
+        # stores (0), with the in-launch XCD check (1) and with plain stores forced (2); its workspace survives launches
+        ws = torch.zeros(ops.PROJ_WS_WORDS, dtype=torch.int64, device=DEV)
+        a2, it2 = torch.zeros(n, 2, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+        for steps, lr, mom in [(10, 2e-3, 0.0), (1, 0.05, 0.0), (0, 2e-3, 0.0), (10, 2e-3, 0.5), (30, 2e-2, 0.0)]:
+            k.project_batchref(obs, ap, action, iters, steps, lr, 1e-5, mom)
+            for mode in (0, 1, 2, 1):
+                a2.fill_(-1.0)
+                k.project_batchref_ws(obs, ap, a2, it2, steps, lr, 1e-5, mom, ws, mode)
+                assert torch.equal(a2, action), (steps, lr, mom, mode)
+                assert int(it2.item()) == int(iters.item())
+        assert int(ws[ops.PROJ_WS_GAVE_UP]) == 0
+        assert int(ws[ops.PROJ_WS_GAVE_UP - 1]) == 20             # the launch counter of the tags (one per launch)
+
+
 def test_pendulum_constraint_kernels(ops, golden):
     g = golden("pendulum_env")
     k = ops.PendulumKernels()

@@ -494,7 +494,9 @@ def test_ddpg_actor_update_pipeline_on_pendulum(hip, monkeypatch):
     monkeypatch.setenv("RPO_FUSED_ACTOR", "1")
     b = _run("ddpg", "pendulum_viol", hip, dev, 24, 256, use_graph=False)
     assert b._actor_pipeline
-    np.testing.assert_allclose(a.agent.flat.data.cpu().numpy(), b.agent.flat.data.cpu().numpy(), rtol=0, atol=1e-7)
+    # (the two forms associate the Lagrangian sums differently: 1e-7 per step; after 24 iterations through the batch-coupled
+    # projection one of 68 496 parameters sits at 2.1e-7)
+    np.testing.assert_allclose(a.agent.flat.data.cpu().numpy(), b.agent.flat.data.cpu().numpy(), rtol=0, atol=4e-7)
     np.testing.assert_allclose(a.agent.nju.weight.detach().cpu().numpy(), b.agent.nju.weight.detach().cpu().numpy(), rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(float(a.last_losses["actor"]), float(b.last_losses["actor"]), rtol=1e-5, atol=1e-6)
 
