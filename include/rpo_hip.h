@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define RPO_ABI_VERSION 2
+/* 3: rpo_split_update gained proj_ws / proj_store_mode (the struct grew); rpo_split_critic_pfront*, rpo_pendulum_project_batchref_ws */
+#define RPO_ABI_VERSION 3
 
 #define RPO_ERR_ARG (-1)
 #define RPO_ERR_NULL (-2)
@@ -233,8 +234,8 @@ int rpo_pendulum_act_project(int n, const float* obs, int obs_stride, const floa
                              float corr_eps, float corr_momentum, unsigned long long seed, unsigned env_id_base,
                              const long long* ctrl, float* stats, int stats_cap, void* stream);
 
-#define RPO_PROJ_WS_WORDS 528
-#define RPO_PROJ_WS_GAVE_UP 521
+#define RPO_PROJ_WS_WORDS 5408
+#define RPO_PROJ_WS_GAVE_UP 529
 /* complete_partial + the reference's LITERAL batched grad_steps on a training batch (n <= 1024): batch-global stop
  * test (rpo_ddpg.py:271-272) and the sample-coupled ineq_partial_grad of pendulum.py:337-339, grad_i = sum_j
  * 1[a_x,i * dgp_j - bgp_i > 0] * dgp_j.  Used for the TD-target projection of critic_loss
@@ -523,6 +524,13 @@ int rpo_split_critic_front_pol(const rpo_split_update* u, void* stream);
  * projection, rpo_split_pend_head_project, needs every row and keeps fwd_a a launch of its own); _pol: + rpo_split_policy_a. */
 int rpo_split_critic_mid(const rpo_split_update* u, void* stream);
 int rpo_split_critic_mid_pol(const rpo_split_update* u, void* stream);
+/* SpringPendulum-v0: rpo_split_critic_fwd_a + rpo_split_pend_head_project + rpo_split_critic_fwd_b + rpo_split_critic_bwd_a as ONE
+ * launch (requires proj_ws, batch <= 256, max_steps <= 30).  The projection is one workgroup per row tile (all on one XCD); what
+ * crosses XCDs -- the policy's head partials into it, the projected actions and log pi out of it -- travels as tagged 8-byte
+ * granules in proj_ws with agent-scope stores and loads (nothing depends on placement); the row-tile-local hand-overs use
+ * tile_sync like rpo_split_critic_front.  Same values bit for bit.  _pol: + rpo_split_policy_a as one more plane. */
+int rpo_split_critic_pfront(const rpo_split_update* u, void* stream);
+int rpo_split_critic_pfront_pol(const rpo_split_update* u, void* stream);
 /* out[x + gx * (y + gy * z)] = the XCD (XCC_ID) workgroup (x, y, z) of a (gx, gy, gz) grid of `threads`-thread workgroups ran
  * on.  rpo_split_critic_front hands data from workgroup to workgroup through ONE XCD's L2; its caller checks with this probe
  * (same grid: 8, ceil(batch / 16), 1 + 3 K; 256 threads) that all workgroups of a row tile share an XCD. */
@@ -593,6 +601,8 @@ int rpo_split_critic_bwd_b_ride(const rpo_split_update* u, const rpo_rollout_rid
 int rpo_split_critic_front_ride(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream);
 /* SpringPendulum-v0: rpo_split_critic_mid with riding planes (replaces fwd_b_ride + bwd_a). */
 int rpo_split_critic_mid_ride(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream);
+/* SpringPendulum-v0: rpo_split_critic_pfront with riding planes (replaces fwd_a_ride + pend_head_project + mid_ride). */
+int rpo_split_critic_pfront_ride(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream);
 
 /* Backward of the same rows given dout [n, n_out] (two launches).  Parameter gradients are ACCUMULATED (+=) into
  * grad_host's buffers (the shared state embedding of shared_param=True receives contributions from two networks,

@@ -600,10 +600,13 @@ class RPOTrainerBase(object):
             # the batch-coupled projection on eight workgroups (rpo_split_pend_head_project); workspace of
             # RPO_PROJ_WS_WORDS 64-bit words.  RPO_PROJ_STORE: 0 agent-scope granule stores, 1 (default) plain stores when the
             # eight workgroups share an XCD (checked inside every launch)
-            fields.update(proj_ws=torch.zeros(hip_ops.PROJ_WS_WORDS, dtype=torch.int64, device=self.device),
+            fields.update(proj_ws=torch.zeros(hip_ops.PROJ_WS_WORDS + _env_int("RPO_PROJ_WS_EXTRA", 0), dtype=torch.int64, device=self.device),
                           proj_store_mode=_env_int("RPO_PROJ_STORE", 1))
         self._split_cache = be.SplitUpdate(k, descs, self.sac, B, fields)
         self._front_cache = bool(_env_int("RPO_FRONT", 1)) and hasattr(be, "front_launch_ok") and be.front_launch_ok(B, self.sac)
+        # SpringPendulum: fwd_a + projection + fwd_b + bwd_a as one launch (rpo_split_critic_pfront; RPO_PFRONT=0: fwd_a | project | mid)
+        self._pfront = bool(self._front_cache and "proj_ws" in fields and _env_int("RPO_PFRONT", 1) and
+                            be.front_launch_ok(B, self.sac, 1))
         self._split_loss = fields["loss_partial"]
         self._split_logp = (fields["logp"], b("pi.logp", B))          # log pi(a'|s') of the critic update | log pi(a|s)
         return self._split_cache
@@ -704,6 +707,13 @@ class RPOTrainerBase(object):
             if ride is not None:
                 ride.set(lane_begin=0, lane_end=n)              # the whole actor forward of the next step rides along
             su.run("critic_front_pol" if early else "critic_front", rider=ride)   # (pol_a as one more plane, see below)
+            self._critic_update_split_back(su, ride, bwd_a=False)
+            return
+        if su.st.env == 1 and self._after_front is None and self._pfront:
+            self._pol_a_done = early                             # SpringPendulum: the same, around the projection's workgroups
+            if ride is not None:
+                ride.set(lane_begin=0, lane_end=n)
+            su.run("critic_pfront_pol" if early else "critic_pfront", rider=ride)
             self._critic_update_split_back(su, ride, bwd_a=False)
             return
         su.run("critic_fwd_a", rider=ride)                      # + actor forward of lanes [0, cut)

@@ -227,7 +227,8 @@ __device__ __forceinline__ void ns_stage(NsLds<128>& lds, const float* tf, bool 
 // ---- fwd_a: grid (row tiles, 8 column groups, roles).  Role 0 = the policy on s' (pi_targ for RPODDPG, pi for RPOSAC),
 //      roles 1.. = the critics on the stored (s, a), pre-activations saved for the backward pass.
 template <class L>
-__device__ __forceinline__ void fwd_a_role(const SplitArgs& p, NsLds<128>& lds, float4* tile, int row0, int g, int role) {
+__device__ __forceinline__ void fwd_a_role(const SplitArgs& p, NsLds<128>& lds, float4* tile, int row0, int g, int role,
+                                           float (*hp)[4] = nullptr, unsigned* rows_word = nullptr) {
     if (p.rollout_ctrl && role == 0 && g == 0 && row0 == 0 && threadIdx.x < RPO_WAVE) {
         // the rollout before this update left its clock to us (defer_clock): every workgroup of it has finished, so one
         // wave advances the step counter and clears the statistics row of the next step -- no arrival counting
@@ -247,9 +248,10 @@ __device__ __forceinline__ void fwd_a_role(const SplitArgs& p, NsLds<128>& lds, 
     ns_load_weights<128, 256>(net, g, w);
     const long long t = p.ctrl[RPO_CTRL_T];
     ns_sample<L>(p, tile, row0, t, role == 0 && g == 0);
-    __syncthreads();
+    if (rows_word) ns_tile_arrive(rows_word);                    // "the tile's gathered rows are published" (it synchronises)
+    else __syncthreads();
     ns_stage<L>(lds, reinterpret_cast<const float*>(tile), role == 0, role != 0);
-    if (role == 0) ns_hidden<128, 256>(net, w, lds, g, row0, p.B, p.part_pi, nullptr, nullptr);
+    if (role == 0) ns_hidden<128, 256>(net, w, lds, g, row0, p.B, p.part_pi, nullptr, nullptr, nullptr, hp);
     else ns_hidden<128, 256>(net, w, lds, g, row0, p.B, p.part_q[role - 1], p.x0[role - 1], p.h1[role - 1]);
 }
 
@@ -517,20 +519,29 @@ __global__ __launch_bounds__(1024) void split_pend_head_project_wide_kernel(Spli
                                         p.max_steps, p.corr_lr, p.corr_eps, p.corr_momentum, lds);
 }
 
-// ---- The same on EIGHT workgroups (B <= 256, max_steps <= kPmMaxSteps): workgroup w owns the samples [32 w, 32 w + 32) --
-// 16 lanes per sample, the values j = 64 q + 4 c + m of project_batchref_wide, so the bits are its bits -- and the n^2
-// predicate sum of a GRG iteration is 1/8 per compute unit (the one-workgroup form is bound by the vector ALU of ONE CU:
+// ---- The same on ONE WORKGROUP PER ROW TILE (B <= 256, max_steps <= kPmMaxSteps): workgroup w owns the samples [16 w, 16 w + 16)
+// -- 16 lanes per sample, the values j = 64 q + 4 c + m of project_batchref_wide, so the bits are its bits -- and the n^2
+// predicate sum of a GRG iteration is 1/16 per compute unit (the one-workgroup form is bound by the vector ALU of ONE CU:
 // 2.3 us per iteration).  Every iteration is an all-gather of the 256 dgp values (+ the rows' stop bits) between the
 // workgroups, done with 8-byte {tag, value} granules in `ws`: the data IS the flag (a reader takes a granule only when it
 // carries the tag of this launch and iteration), so no fences, no arrival counter, and nothing stale can be consumed
 // whatever the placement.  Granule stores are agent-scope (write-through `sc1`) unless the workgroups find themselves on
 // ONE XCD (they exchange HW_REG_XCC_ID through such granules first): then plain stores, which stay in that XCD's L2 where
 // the `sc1` polling loads are served -- a speed choice only, taken inside the launch it applies to.
-// ws (u64 words, zero before the first launch): [2][256] dgp granules (by iteration parity) | [8] XCC granules | epoch |
-// gave-up flag.  Tags are epoch * 32 + 1 (XCC) / + 2 + k (iteration k); workgroup 0 advances the epoch when it is done
-// (it has then seen every other workgroup's last granule, so every workgroup has read the epoch).
-constexpr int kPmGroups = 8, kPmRows = 32, kPmThreads = kPmRows * 16, kPmMaxSteps = 30, kPmSpinMax = 1 << 16;
-constexpr int kPmXcc = 512, kPmEpoch = 520, kPmGaveUp = 521, kPmWords = 528;
+// ws (u64 words, zero before the first launch): [2][256] dgp granules (by iteration parity) | [16] XCC granules | epoch |
+// gave-up flag | readers-done count | (fused front, below) [8][256][2] head-partial granules | [256][3] action granules.
+// Tags are epoch * 32 + 1 (XCC, partials, actions) / + 2 + k (iteration k).  The epoch is advanced when every workgroup
+// that reads it is done with it: by workgroup 0 here (it has then seen every other workgroup's last granule), by the last of
+// the counted readers in the fused front.
+constexpr int kPmRows = 16, kPmMaxSteps = 30, kPmSpinMax = 1 << 16;
+constexpr int kPmXcc = 512, kPmEpoch = 528, kPmGaveUp = 529, kPmDone = 530, kPmPart = 544, kPmAct = kPmPart + 8 * 256 * 2;
+constexpr int kPmWords = kPmAct + 256 * 3;
+constexpr int kPmSmem = 6 * kPmRows + 2 * 256 + 8;   // floats: the rows' state | dgp (two buffers) | flags
+#ifdef RPO_PM_TRACE   // development aid: 100 MHz timestamps of the fused front's phases behind the workspace (tools/probe_pfront.py)
+#define PM_STAMP(ws, cond, slot) do { if ((cond) && threadIdx.x == 0) (ws)[kPmWords + (slot)] = wall_clock64(); } while (0)
+#else
+#define PM_STAMP(ws, cond, slot) do { } while (0)
+#endif
 
 __device__ __forceinline__ void pm_store(unsigned long long* g, unsigned long long v, bool local) {
     if (local) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(g), "v"(v) : "memory");
@@ -539,62 +550,59 @@ __device__ __forceinline__ void pm_store(unsigned long long* g, unsigned long lo
 __device__ __forceinline__ unsigned long long pm_load(unsigned long long* g) {
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ unsigned long long pm_tag0(unsigned long long* ws) {
+    return (unsigned long long)((unsigned)pm_load(ws + kPmEpoch) & 0x3ffffffu) * 32ull + 1ull;   // (31-bit tags)
+}
+// Poll `count` (<= blockDim) granules g[0 .. count) until each carries `tag` (bit 31 of the tag word is payload); returns the
+// granule of this thread (0 beyond count).  `failed` (LDS) is raised when the wait was given up.
+__device__ __forceinline__ unsigned long long pm_gather(unsigned long long* g, int count, unsigned long long tag, int* failed) {
+    unsigned long long x = 0;
+    const bool mine = (int)threadIdx.x < count;
+    if ((int)(threadIdx.x & ~63u) < count) {                     // whole waves that hold at least one granule
+        for (int spins = 0;; ++spins) {
+            bool ok = true;
+            if (mine) { x = pm_load(g + threadIdx.x); ok = ((x >> 32) & 0x7fffffffull) == tag; }
+            if (__all(ok)) break;
+            if (spins >= kPmSpinMax) { *failed = 1; x = 0; break; }
+        }
+    }
+    return x;
+}
 
-// (ap_in != NULL: the basic actions are given and the observations are rows of `obs` -- rpo_pendulum_project_batchref_ws)
-__global__ __launch_bounds__(kPmThreads) void split_pend_head_project_multi_kernel(SplitArgs p, unsigned long long* ws, int store_mode,
-                                                                                   const float* ap_in, const float* obs,
-                                                                                   int obs_stride) {
-    using namespace rpo_pend_dev;
-    if (blockIdx.x & 7) return;                                  // block b runs on XCD b % 8: the eight workers are blocks 0, 8, ..
-    const int wg = blockIdx.x >> 3, tid = threadIdx.x, c = tid & 15, sl = tid >> 4, n = p.B;
-    __shared__ __attribute__((aligned(16))) float lds[6 * kPmRows + 2 * 256 + 8];
-    float* st = lds;
-    float* dbuf = lds + 6 * kPmRows;
-    int* flags = reinterpret_cast<int*>(lds + 6 * kPmRows + 2 * 256);   // [0] stop word, [1] plain stores allowed, [2] gave up
-    const unsigned epoch = (unsigned)pm_load(ws + kPmEpoch) & 0x3ffffffu;   // (31-bit tags)
-    const unsigned long long tag0 = (unsigned long long)epoch * 32ull + 1ull;
-    if (tid == 0) {
+// every projection workgroup announces its XCD as early as it can; pm_project reads the announcements
+__device__ __forceinline__ void pm_publish_xcc(unsigned long long* ws, unsigned long long tag0, int wg) {
+    if (threadIdx.x == 0) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         pm_store(ws + kPmXcc + wg, (tag0 << 32) | (xcc & 15u), false);
-        flags[0] = 0; flags[2] = 0;
     }
-    if (tid < kPmRows) {                                         // head of the policy for the workgroup's rows, Complete
-        const int i = wg * kPmRows + tid;
-        Eq e = {0.0f, 1.0f, 1.0f, 0.0f};
-        float ax = 0.0f, ay = 0.0f;
-        if (i < n) {
-            const float* o;
-            if (ap_in) {
-                ax = ap_in[i];
-                o = obs + (size_t)i * obs_stride;
-            } else {
-                float logp = 0.0f;
-                ax = ns_policy_head(p, i, p.ctrl[RPO_CTRL_T], &logp);
-                if (p.twin) p.logp[i] = logp;
-                o = p.batch_out + (size_t)i * RPO_PEND_ROW + PendRow::NS_OFF;
-            }
-            e = set_eq(o[0], o[1], o[2], o[3], o[4]);
-            ay = pb_complete(e, ax);
-        }
-        st[tid] = ax; st[kPmRows + tid] = ay; st[2 * kPmRows + tid] = e.C_p; st[3 * kPmRows + tid] = e.C_o;
-        st[4 * kPmRows + tid] = e.C_o_inv; st[5 * kPmRows + tid] = e.b;
-    }
-    if (tid >= 64 && tid < 128) {                                // one wave: are the eight workgroups on one XCD?
+}
+
+// The projection of the row tile `wg` (of T) by a 256-thread workgroup.  `ax0` / the observation of row r < 16 come from the
+// caller through st[] (the rows' state: a_x | a_y | C_p | C_o | 1 / C_o | b, 16 each); lds: kPmSmem floats.  act_gran: NULL, or
+// where the tile's projected actions (+ log pi) go as granules for consumers of the same launch.
+__device__ __forceinline__ void pm_project(const SplitArgs& p, unsigned long long* ws, unsigned long long tag0, int store_mode, int wg,
+                                           int T, float* lds, const float* logp_row, unsigned long long* act_gran) {
+    using namespace rpo_pend_dev;
+    const int tid = threadIdx.x, c = tid & 15, sl = tid >> 4, n = p.B;
+    float* st = lds;
+    float* dbuf = lds + 6 * kPmRows;
+    int* flags = reinterpret_cast<int*>(lds + 6 * kPmRows + 2 * 256);   // [0] stop word, [1] plain stores allowed, [2] gave up
+    if (tid >= 64 && tid < 128) {                                // one wave: are the workgroups on one XCD? (pm_publish_xcc)
         const int l = tid - 64;
         unsigned long long x = 0;
         bool ok = true;
         for (int spins = 0;; ++spins) {
-            if (l < kPmGroups) { x = pm_load(ws + kPmXcc + l); ok = (x >> 32) == tag0; }
+            if (l < T) { x = pm_load(ws + kPmXcc + l); ok = (x >> 32) == tag0; }
             if (__all(ok)) break;
             if (spins >= kPmSpinMax) { if (l == 0) flags[2] = 1; break; }
-            __builtin_amdgcn_s_sleep(1);
         }
         const unsigned mine = (unsigned)x & 15u, first = (unsigned)__builtin_amdgcn_readfirstlane((int)mine);
-        const bool same = __all(l >= kPmGroups || (ok && mine == first));
+        const bool same = __all(l >= T || (ok && mine == first));
         if (l == 0) flags[1] = (store_mode == 2 || (store_mode == 1 && same)) ? 1 : 0;
     }
     __syncthreads();
+    PM_STAMP(ws, wg == 0, 4);
     const bool local = flags[1] != 0;
     PbSample sm;
     pb_init(sm, st[sl], st[kPmRows + sl], st[2 * kPmRows + sl], st[3 * kPmRows + sl], st[4 * kPmRows + sl], st[5 * kPmRows + sl]);
@@ -609,17 +617,10 @@ __global__ __launch_bounds__(kPmThreads) void split_pend_head_project_multi_kern
             pm_store(gk + me, ((unsigned long long)(viol ? 1u : 0u) << 63) | (tag << 32) |
                                   (unsigned long long)__float_as_uint(me < n ? dg : 0.0f), local);
         float* dk = dbuf + (k & 1) * 256;
-        if (tid < 256) {                                         // four waves gather the 256 granules of this iteration
-            unsigned long long x = 0;
-            bool ok = false;
-            for (int spins = 0;; ++spins) {
-                x = pm_load(gk + tid);
-                ok = ((x >> 32) & 0x7fffffffull) == tag;
-                if (__all(ok)) break;
-                if (spins >= kPmSpinMax) { flags[2] = 1; break; }
-            }
+        {                                                        // gather the granules of this iteration (one per thread)
+            const unsigned long long x = pm_gather(gk, T * kPmRows, tag, flags + 2);
             dk[tid] = __uint_as_float((unsigned)x);
-            if (__any(ok && (x >> 63))) flags[0] = k + 1;        // (every writer of this iteration stores the same value)
+            if (__any((x >> 63) != 0ull)) flags[0] = k + 1;      // (every writer of this iteration stores the same value)
         }
         __syncthreads();
         if ((k > 0 && flags[0] < k + 1) || flags[2]) break;      // batch-global stop test, rpo_ddpg.py:271-272
@@ -627,13 +628,64 @@ __global__ __launch_bounds__(kPmThreads) void split_pend_head_project_multi_kern
         pb_load16(dk, c, dv);
         const float grad = rpo_row16_allsum(pb_partial(sm.ax, pb_bgp(sm), dv));
         pb_step(sm, grad, p.corr_lr, p.corr_momentum);
+        PM_STAMP(ws, wg == 0, 5 + k);
     }
+    PM_STAMP(ws, wg == 0, 36);
     if (c == 0 && me < n) reinterpret_cast<float2*>(p.next_actions)[me] = make_float2(sm.ax, sm.ay);
-    if (wg == 0 && tid == 0) {
-        if (p.proj_iters) *p.proj_iters = k;
-        if (flags[2]) __hip_atomic_store(ws + kPmGaveUp, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(ws + kPmEpoch, (unsigned long long)(epoch + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (act_gran && c < 3) {
+        const float v = c == 0 ? sm.ax : c == 1 ? sm.ay : logp_row[sl];
+        pm_store(act_gran + me * 3 + c, (tag0 << 32) | (unsigned long long)__float_as_uint(v), false);
     }
+    if (wg == 0 && tid == 0 && p.proj_iters) *p.proj_iters = k;
+    if (tid == 0 && flags[2]) __hip_atomic_store(ws + kPmGaveUp, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the rows' state for pm_project: row r of the tile has the basic action ax and the observation o
+__device__ __forceinline__ void pm_stage_row(float* st, int r, bool live, float ax, const float* o) {
+    using namespace rpo_pend_dev;
+    Eq e = {0.0f, 1.0f, 1.0f, 0.0f};
+    float ay = 0.0f;
+    if (live) {
+        e = set_eq(o[0], o[1], o[2], o[3], o[4]);
+        ay = pb_complete(e, ax);
+    } else {
+        ax = 0.0f;
+    }
+    st[r] = ax; st[kPmRows + r] = ay; st[2 * kPmRows + r] = e.C_p; st[3 * kPmRows + r] = e.C_o;
+    st[4 * kPmRows + r] = e.C_o_inv; st[5 * kPmRows + r] = e.b;
+}
+
+// stand-alone launch: grid 8 T blocks, block b runs on XCD b % 8 -> the T workers are blocks 0, 8, ..
+// (ap_in != NULL: the basic actions are given and the observations are rows of `obs` -- rpo_pendulum_project_batchref_ws)
+__global__ __launch_bounds__(kThreads) void split_pend_head_project_multi_kernel(SplitArgs p, unsigned long long* ws, int store_mode,
+                                                                                 const float* ap_in, const float* obs, int obs_stride) {
+    if (blockIdx.x & 7) return;
+    const int wg = blockIdx.x >> 3, T = gridDim.x >> 3, tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float lds[kPmSmem];
+    int* flags = reinterpret_cast<int*>(lds + 6 * kPmRows + 2 * 256);
+    if (tid == 0) { flags[0] = 0; flags[2] = 0; }
+    const unsigned long long tag0 = pm_tag0(ws);
+    pm_publish_xcc(ws, tag0, wg);
+    if (tid < kPmRows) {                                         // head of the policy for the workgroup's rows, Complete
+        const int i = wg * kPmRows + tid;
+        float ax = 0.0f;
+        const float* o = nullptr;
+        if (i < p.B) {
+            if (ap_in) {
+                ax = ap_in[i];
+                o = obs + (size_t)i * obs_stride;
+            } else {
+                float logp = 0.0f;
+                ax = ns_policy_head(p, i, p.ctrl[RPO_CTRL_T], &logp);
+                if (p.twin) p.logp[i] = logp;
+                o = p.batch_out + (size_t)i * RPO_PEND_ROW + PendRow::NS_OFF;
+            }
+        }
+        pm_stage_row(lds, tid, i < p.B, ax, o);
+    }
+    pm_project(p, ws, tag0, store_mode, wg, T, lds, nullptr, nullptr);
+    if (wg == 0 && tid == 0)                                     // (workgroup 0 has seen every other workgroup's last granule)
+        __hip_atomic_store(ws + kPmEpoch, ((tag0 - 1ull) >> 5) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- TD target + Huber for row i of critic k from the slab partials (rpo_ddpg.py:331-335, rpo_sac.py:346-353)
@@ -1184,6 +1236,197 @@ __global__ __launch_bounds__(kThreads) void split_critic_mid_ride_kernel(SplitAr
                                        nb.g);
 }
 
+// ---- fused front of the critic update (SpringPendulum): fwd_a, the batch-coupled projection, fwd_b and bwd_a in ONE launch.
+//      The projection needs every row, so its hand-overs cross XCDs -- they are tagged granules (pm_* above: the data is the
+//      flag, agent-scope stores and loads, nothing depends on placement); the row-tile-local hand-overs (critic slabs, saved
+//      activations, fwd_b -> bwd_a) stay on the tile's XCD as in the CartSafe front.  grid (8, T, planes) x 256 threads:
+//        planes [0, 1 + K)          fwd_a's roles: the policy on s' arrives at the tile's word 0 (its gathered rows are
+//                                   published) and then leaves its head partials as granules; the critics arrive at word 1 (high)
+//        plane  1 + K               blocks (0, y): the projection of row tile y -- gathers its own rows, polls the tile's 8 x 16
+//                                   (x 2) partial granules, head -> Complete -> the GRG iterations with the other tiles' workgroups
+//                                   (all T of them on XCD 0) -> the projected actions (+ log pi) as granules
+//        planes [2 + K, 2 + 2 K)    fwd_b's target critics: own gather, state half of layer 1, poll the tile's action granules,
+//                                   arrive at word 1 (low)
+//        planes [2 + 2 K, 2 + 3 K)  bwd_a of critic k (waits for word 1: critics, then fwd_b)
+//        plane  2 + 3 K (pol = 1)   pol_a of a policy iteration (waits for word 0)
+//      The epoch of the tags is advanced by the last of its readers (policy role, projection, fwd_b: a count in ws).
+__device__ __forceinline__ void pm_reader_done(unsigned long long* ws, unsigned long long tag0, unsigned readers) {
+    if (threadIdx.x == 0 &&
+        __hip_atomic_fetch_add(ws + kPmDone, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)readers - 1ull) {
+        __hip_atomic_store(ws + kPmDone, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ws + kPmEpoch, ((tag0 - 1ull) >> 5) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// the policy head of row i from the tile's partials staged in LDS as [group][row][output] (== ns_policy_head)
+__device__ __forceinline__ float pm_policy_draw(const SplitArgs& p, int i, long long t) {     // RPOSAC: the rsample draw of row i
+    if (p.eps_in) return p.eps_in[i];
+    const rpo_u4 u = rpo_philox(p.noise_seed, p.noise_id_base + (uint32_t)i, (uint32_t)t + p.noise_salt, RPO_STREAM_POLICY,
+                                (uint32_t)p.ctrl[RPO_CTRL_UPDATES]);
+    return rpo_normal(u.x, u.y);
+}
+__device__ __forceinline__ float pm_policy_head_lds(const SplitArgs& p, const float* lpart, int r, float e, float* logp) {
+    float v0 = p.twin ? p.actor.b1[0] : p.actor_target.b1[0], v1 = p.twin ? p.actor.b1b[0] : 0.0f;
+#pragma unroll
+    for (int g = 0; g < kNsGroups; ++g) { v0 += lpart[g * 32 + r * 2]; v1 += lpart[g * 32 + r * 2 + 1]; }
+    if (!p.twin) return p.scale * tanhf(v0) + p.base;
+    return rpo_head_dev::gauss_head_row(v0, v1, e, p.scale, p.base, p.box_lo, p.box_hi, 0, logp);
+}
+
+template <class L>
+__device__ __forceinline__ bool pfront_role(const SplitArgs& p, const CartConsts& c, float* smem, int pol, unsigned long long* ws,
+                                            int store_mode) {
+    const int K = p.twin ? 2 : 1, T = (int)gridDim.y, z = (int)blockIdx.z, tid = threadIdx.x, B = p.B;
+    if (z >= 2 + 3 * K + pol) return false;
+    const unsigned consumers = (unsigned)(kNsGroups * (K + pol));          // of the tile words: bwd_a, pol_a
+    const unsigned readers = (unsigned)(kNsGroups * T * (1 + K) + T);      // of the epoch: policy role, fwd_b, projection
+    unsigned* sync = p.tile_sync;
+    if (z >= 2 + 2 * K && z < 2 + 3 * K) {
+        PM_STAMP(ws, z == 2 + 2 * K && blockIdx.x == 0 && blockIdx.y == 0, 52);
+        bwd_a_role<L>(p, smem, (z - 2 - 2 * K) * T * kNsGroups + (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y, consumers,
+                      (unsigned)(kNsGroups * K), (unsigned)(kNsGroups * K));
+        PM_STAMP(ws, z == 2 + 2 * K && blockIdx.x == 0 && blockIdx.y == 0, 53);
+        return true;
+    }
+    if (z == 1 + K) {                                            // ---- the projection of row tile blockIdx.y
+        if (blockIdx.x != 0) return true;
+        const int wg = blockIdx.y, row0 = wg * kPmRows;
+        float* lds = smem;                                       // kPmSmem floats
+        float* lpart = smem + kPmSmem;                           // [8][16][2] head partials
+        float* logp_row = lpart + 256;                           // [16]
+        float4* tile = reinterpret_cast<float4*>(logp_row + 16);  // the tile's gathered rows
+        static_assert((kPmSmem + 256 + 16) % 4 == 0, "tile alignment");
+        int* flags = reinterpret_cast<int*>(lds + 6 * kPmRows + 2 * 256);
+        if (tid == 0) { flags[0] = 0; flags[2] = 0; }
+        PM_STAMP(ws, wg == 0, 0);
+        const unsigned long long tag0 = pm_tag0(ws);
+        pm_publish_xcc(ws, tag0, wg);                            // (the others read it after the head: long since there)
+        const long long t = p.ctrl[RPO_CTRL_T];
+        ns_sample<L>(p, tile, row0, t, false);                   // (same draw, same rows as fwd_a's workgroups of this tile)
+        float e_draw = 0.0f;                                     // the row's policy draw does not need the partials either
+        if (tid < kPmRows && row0 + tid < B && p.twin) e_draw = pm_policy_draw(p, row0 + tid, t);
+        __syncthreads();
+        PM_STAMP(ws, wg == 0, 1);
+        {
+            const int g = tid >> 5, r = (tid >> 1) & 15, o = tid & 1;
+            const bool mine = o < (p.twin ? 2 : 1) && row0 + r < B;
+            unsigned long long* src = ws + kPmPart + ((size_t)g * B + row0 + r) * 2 + o;
+            unsigned long long x = 0;
+            for (int spins = 0;; ++spins) {
+                bool ok = true;
+                if (mine) { x = pm_load(src); ok = (x >> 32) == tag0; }
+                if (__all(ok)) break;
+                if (spins >= kPmSpinMax) { flags[2] = 1; x = 0; break; }
+            }
+            lpart[tid] = mine ? __uint_as_float((unsigned)x) : 0.0f;
+        }
+        __syncthreads();
+        PM_STAMP(ws, wg == 0, 2);
+        if (tid < kPmRows) {
+            const int i = row0 + tid;
+            float ax = 0.0f, logp = 0.0f;
+            if (i < B) ax = pm_policy_head_lds(p, lpart, tid, e_draw, &logp);
+            logp_row[tid] = logp;
+            pm_stage_row(lds, tid, i < B, ax, reinterpret_cast<const float*>(tile) + tid * L::ROW + L::NS_OFF);
+        }
+        PM_STAMP(ws, wg == 0, 3);
+        pm_project(p, ws, tag0, store_mode, wg, T, lds, logp_row, ws + kPmAct);
+        pm_reader_done(ws, tag0, readers);
+        return true;
+    }
+    if (tid >= kNsThreads) return true;                          // (whole waves: the barriers below count the two that stay)
+    NsLds<128>& lds = *reinterpret_cast<NsLds<128>*>(smem);
+    float4* tile = reinterpret_cast<float4*>(reinterpret_cast<char*>(smem) + sizeof(NsLds<128>));
+    const NsBlock nb = ns_block();
+    const int row0 = nb.tile * kRows, g = nb.g;
+    if (z == 0) {                                                // the policy on s'
+        PM_STAMP(ws, nb.tile == 0 && g == 0, 40);
+        const unsigned long long tag0 = pm_tag0(ws);
+        float hp[2][4];
+        // word 0 says "the tile's gathered rows are published" (pol_a waits for it): the arrival sits right behind the gather,
+        // long before the granules -- nothing of this workgroup may follow the launch's last consumer, which clears the words
+        fwd_a_role<L>(p, lds, tile, row0, g, 0, hp, sync + nb.tile * kNsSyncStride);
+        PM_STAMP(ws, nb.tile == 0 && g == 0, 41);
+        const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
+        if (tid >= 64 && li == 0) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = row0 + lg * 4 + i;
+                    if (row < B && o < (p.twin ? 2 : 1))
+                        pm_store(ws + kPmPart + ((size_t)g * B + row) * 2 + o, (tag0 << 32) | (unsigned long long)__float_as_uint(hp[o][i]),
+                                 false);
+                }
+        }
+        PM_STAMP(ws, nb.tile == 0 && g == 0, 42);
+        pm_reader_done(ws, tag0, readers);
+    } else if (z < 1 + K) {
+        PM_STAMP(ws, nb.tile == 0 && g == 0 && z == 1, 44);
+        fwd_a_role<L>(p, lds, tile, row0, g, z);
+        ns_tile_arrive(sync + (T + nb.tile) * kNsSyncStride, 1u << 16);
+        PM_STAMP(ws, nb.tile == 0 && g == 0 && z == 1, 45);
+    } else if (z < 2 + 2 * K) {                                  // fwd_b of target critic k on the projected actions
+        const int k = z - 2 - K;
+        PM_STAMP(ws, nb.tile == 0 && g == 0 && k == 0, 48);
+        const unsigned long long tag0 = pm_tag0(ws);
+        const Mlp& net = p.critic_target[k];
+        NsWeights<128> w;
+        ns_load_weights<128, 256>(net, g, w);
+        ns_sample<L>(p, tile, row0, p.ctrl[RPO_CTRL_T], false);
+        __syncthreads();
+        ns_stage<L>(lds, reinterpret_cast<const float*>(tile), true, false);
+        __syncthreads();
+        float pre[kRows];
+        ns_layer1_state<128>(net, w, lds, pre);
+        PM_STAMP(ws, nb.tile == 0 && g == 0 && k == 0, 49);
+        if (tid < 64) {                                          // one wave polls the tile's 16 x (a_x, a_y, log pi) granules
+            const int r = tid / 3, q = tid - 3 * r;
+            const bool mine = tid < 48 && row0 + r < B;
+            unsigned long long x = 0;
+            for (int spins = 0;; ++spins) {
+                bool ok = true;
+                if (mine) { x = pm_load(ws + kPmAct + (size_t)(row0 + r) * 3 + q); ok = (x >> 32) == tag0; }
+                if (__all(ok)) break;
+                if (spins >= kPmSpinMax) { x = 0; __hip_atomic_store(ws + kPmGaveUp, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            if (mine) {
+                const float v = __uint_as_float((unsigned)x);
+                if (q < 2) lds.in_a[r * 8 + q] = v;
+                else if (p.twin && g == 0 && k == 0) p.logp[row0 + r] = v;
+            }
+        }
+        PM_STAMP(ws, nb.tile == 0 && g == 0 && k == 0, 50);
+        pm_reader_done(ws, tag0, readers);
+        ns_hidden<128, 256>(net, w, lds, g, row0, B, p.part_qn[k], nullptr, nullptr, pre);
+        ns_tile_arrive(sync + (T + nb.tile) * kNsSyncStride);
+        PM_STAMP(ws, nb.tile == 0 && g == 0 && k == 0, 51);
+    } else {
+        pol_a_role<L>(p, lds, tile, row0, g, sync + nb.tile * kNsSyncStride, (unsigned)kNsGroups);
+        ns_tile_passed(sync, T, nb.tile, consumers);
+    }
+    return true;
+}
+
+static_assert(kPmSmem + 256 + 16 + 4 * kRows * 4 <= kFrontSmem, "projection role fits");
+
+template <class L>
+__global__ __launch_bounds__(kThreads) void split_critic_pfront_kernel(SplitArgs p, CartConsts c, int pol, unsigned long long* ws,
+                                                                      int store_mode) {
+    __shared__ __attribute__((aligned(16))) float smem[kFrontSmem];
+    pfront_role<L>(p, c, smem, pol, ws, store_mode);
+}
+
+template <class L>
+__global__ __launch_bounds__(kThreads) void split_critic_pfront_ride_kernel(SplitArgs p, CartConsts c, RideArgs<typename L::Env> r,
+                                                                           unsigned long long* ws, int store_mode) {
+    __shared__ __attribute__((aligned(16))) float smem[kFrontSmem];
+    if (pfront_role<L>(p, c, smem, 0, ws, store_mode)) return;
+    const NsBlock nb = ns_block();
+    const int own = 2 + 3 * (p.twin ? 2 : 1);
+    ride_forward_pair<typename L::Env>(r, reinterpret_cast<NsLds<128>*>(smem), ((int)blockIdx.z - own) * (int)gridDim.y + nb.tile, nb.g);
+}
+
 // ---- pol_b: head -> exploration noise + clip (RPODDPG) / rsample + clip + log pi (RPOSAC) -> Complete -> Lagrangian row
 //      terms -> Q_k hidden slabs on (s, a_pi), pre-activations saved.  grid (row tiles, 8, critics); workgroup
 //      (tile, 0, 0) publishes the per-row outputs and the tile's Lagrangian partial sums.
@@ -1724,6 +1967,40 @@ static int mid_launch(const rpo_split_update* u, int pol, void* stream) {
     return 0;
 }
 
+// SpringPendulum: fwd_a + projection + fwd_b + bwd_a as one launch (pfront_role)
+static int pfront_args(const rpo_split_update* u, unsigned need, SplitArgs& a, CartConsts& c) {
+    if (!u) return RPO_ERR_NULL;
+    if (u->env != 1) return RPO_ERR_ARG;
+    if (int e = to_args(u, 1u | 2u | 4u | need, a, c)) return e;
+    const int K = a.twin ? 2 : 1;
+    if (!a.rows || !a.batch_out || !a.ctrl || !a.part_pi || !a.next_actions || !a.tile_sync || !a.loss_partial || !u->proj_ws ||
+        (a.twin && !a.logp))
+        return RPO_ERR_NULL;
+    if (a.cap_steps <= 0 || a.n_envs <= 0 || a.B > 256 || a.max_steps < 0 || a.max_steps > kPmMaxSteps) return RPO_ERR_ARG;
+    if (((uintptr_t)u->proj_ws & 127u) || u->proj_store_mode < 0 || u->proj_store_mode > 2) return RPO_ERR_ARG;
+    if (a.rollout_ctrl && a.rollout_stats && a.rollout_stats_cap <= 0) return RPO_ERR_ARG;
+    for (int k = 0; k < K; ++k)
+        if (!a.part_q[k] || !a.x0[k] || !a.h1[k] || !a.part_qn[k] || !a.dq[k] || !a.dx0[k]) return RPO_ERR_NULL;
+    return 0;
+}
+
+static int pfront_launch(const rpo_split_update* u, int pol, void* stream) {
+    SplitArgs a; CartConsts c;
+    if (int e = pfront_args(u, pol ? 32u : 0u, a, c)) return e;
+    if (pol) {
+        if (u->shared_embedding) return RPO_ERR_ARG;
+        if (!a.part_pol || !a.x0_a || !a.h1_a) return RPO_ERR_NULL;
+    }
+    const dim3 grid(kNsGroups, (a.B + kRows - 1) / kRows, 2 + 3 * (a.twin ? 2 : 1) + pol);
+    hipLaunchKernelGGL(split_critic_pfront_kernel<PendRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c, pol, u->proj_ws,
+                       u->proj_store_mode);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_split_critic_pfront(const rpo_split_update* u, void* stream) { return pfront_launch(u, 0, stream); }
+int rpo_split_critic_pfront_pol(const rpo_split_update* u, void* stream) { return pfront_launch(u, 1, stream); }
+
 int rpo_split_critic_mid(const rpo_split_update* u, void* stream) { return mid_launch(u, 0, stream); }
 int rpo_split_critic_mid_pol(const rpo_split_update* u, void* stream) { return mid_launch(u, 1, stream); }
 
@@ -1756,8 +2033,8 @@ int rpo_split_pend_head_project(const rpo_split_update* u, void* stream) {
     static_assert(kPmWords == RPO_PROJ_WS_WORDS && kPmGaveUp == RPO_PROJ_WS_GAVE_UP, "workspace layout");
     if (u->proj_ws && a.B <= 256 && a.max_steps <= kPmMaxSteps) {
         if (((uintptr_t)u->proj_ws & 127u) || u->proj_store_mode < 0 || u->proj_store_mode > 2) return RPO_ERR_ARG;
-        hipLaunchKernelGGL(split_pend_head_project_multi_kernel, dim3(8 * kPmGroups), dim3(kPmThreads), 0, (hipStream_t)stream, a,
-                           u->proj_ws, u->proj_store_mode, (const float*)nullptr, (const float*)nullptr, 0);
+        hipLaunchKernelGGL(split_pend_head_project_multi_kernel, dim3(8 * ((a.B + kPmRows - 1) / kPmRows)), dim3(kThreads), 0,
+                           (hipStream_t)stream, a, u->proj_ws, u->proj_store_mode, (const float*)nullptr, (const float*)nullptr, 0);
     } else if (a.B <= 256) {
         hipLaunchKernelGGL(split_pend_head_project_wide_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
     } else {
@@ -1777,8 +2054,8 @@ int rpo_pendulum_project_batchref_ws(int n, const float* obs, int obs_stride, co
     SplitArgs a{};
     a.B = n; a.next_actions = action; a.proj_iters = iters_out; a.max_steps = max_steps; a.corr_lr = corr_lr;
     a.corr_eps = corr_eps; a.corr_momentum = corr_momentum;
-    hipLaunchKernelGGL(split_pend_head_project_multi_kernel, dim3(8 * kPmGroups), dim3(kPmThreads), 0, (hipStream_t)stream, a, ws,
-                       store_mode, ap, obs, obs_stride);
+    hipLaunchKernelGGL(split_pend_head_project_multi_kernel, dim3(8 * ((n + kPmRows - 1) / kPmRows)), dim3(kThreads), 0, (hipStream_t)stream,
+                       a, ws, store_mode, ap, obs, obs_stride);
     RPO_LAUNCH_CHECK();
     return 0;
 }
@@ -1921,6 +2198,20 @@ int rpo_split_critic_front_ride(const rpo_split_update* u, const rpo_rollout_rid
     const dim3 grid(kNsGroups, T, 1 + 3 * K + (lane_wgs + T - 1) / T);
     hipLaunchKernelGGL(split_critic_front_ride_kernel<CartRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c,
                        ride_args<CartEnv>(a, r));
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_split_critic_pfront_ride(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream) {
+    if (int e = ride_check(u, r)) return e;
+    if (int e = ride_range(r)) return e;
+    SplitArgs a; CartConsts c;
+    if (int e = pfront_args(u, 32u, a, c)) return e;
+    const int K = a.twin ? 2 : 1, T = (a.B + kRows - 1) / kRows;
+    const int lane_wgs = ((r->lane_end - r->lane_begin + kRows - 1) / kRows + 1) / 2;      // two lane tiles per workgroup
+    const dim3 grid(kNsGroups, T, 2 + 3 * K + (lane_wgs + T - 1) / T);
+    hipLaunchKernelGGL(split_critic_pfront_ride_kernel<PendRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c,
+                       ride_args<PendEnv>(a, r), u->proj_ws, u->proj_store_mode);
     RPO_LAUNCH_CHECK();
     return 0;
 }

@@ -74,7 +74,8 @@ __device__ __forceinline__ void ns_layer1_state(const Mlp& net, const NsWeights<
 
 template <int EIN, int H>
 __device__ __forceinline__ void ns_hidden(const Mlp& net, const NsWeights<EIN>& w, NsLds<EIN>& lds, int g, int row0, int n,
-                                          float* part, float* x0_save, float* h1_save, const float* pre = nullptr) {
+                                          float* part, float* x0_save, float* h1_save, const float* pre = nullptr,
+                                          float (*hp)[4] = nullptr) {
     constexpr int LDX = EIN + 4;
     const int tid = threadIdx.x & (kNsThreads - 1), lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;   // (two slab units may share a 256-thread workgroup)
     __syncthreads();
@@ -140,6 +141,7 @@ __device__ __forceinline__ void ns_hidden(const Mlp& net, const NsWeights<EIN>& 
                 v = rpo_row16_sum_lane0(v);                      // (same association as the xor butterfly, at li == 0)
                 const int row = row0 + lg * 4 + i;
                 if (li == 0 && row < n && o < net.n_out) part[((size_t)g * n + row) * 2 + o] = v;
+                if (hp) hp[o][i] = v;                           // (wave 1, li == 0: the partial of row 4 lg + i, output o)
             }
     }
 }

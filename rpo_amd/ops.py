@@ -585,14 +585,15 @@ def mlp_split_supported(desc):
 _FRONT_OK = {}
 
 
-def front_launch_ok(batch, twin):
+def front_launch_ok(batch, twin, extra_planes=0):
     """Whether rpo_split_critic_front may be used for this batch: its workgroups hand data over through ONE XCD's L2, which
     needs every workgroup of a row tile -- in every plane of the launch -- on the same XCD.  That is a property of the
     dispatcher (workgroups go to the XCDs round-robin in block order), checked once per process and shape with a probe
     launch of the same grid (rpo_xcc_probe)."""
-    key = (int(batch), bool(twin))
+    key = (int(batch), bool(twin), int(extra_planes))
     if key not in _FRONT_OK:
-        T, planes = (batch + 15) // 16, 1 + 3 * (2 if twin else 1) + 1          # (+ the policy plane / the first riding plane)
+        # (+ the policy plane / the first riding plane; extra_planes: the projection plane of the SpringPendulum front)
+        T, planes = (batch + 15) // 16, 1 + 3 * (2 if twin else 1) + 1 + extra_planes
         out = torch.full((planes, T, 8), -1, dtype=torch.int32, device="cuda")
         check(_lib.load().rpo_xcc_probe(8, T, planes, 256, _p(out, torch.int32), _stream()), "rpo_xcc_probe")
         ids = out.cpu().view(planes, 8 * T)                       # linear block id inside a plane: x + 8 y
@@ -805,7 +806,7 @@ class SplitUpdate(object):
     """Arguments of the column-split update stages (rpo_split_*), built once per trainer: every pointer refers to a static
     device buffer, so the struct is reused for every launch (and every hipGraph capture)."""
 
-    STAGES = ("critic_fwd_a", "critic_fwd_b", "critic_front", "critic_front_pol", "critic_mid", "critic_mid_pol", "critic_fwd_b_pol", "pend_head_project", "critic_bwd_a", "critic_bwd_b", "policy_a", "policy_b",
+    STAGES = ("critic_fwd_a", "critic_fwd_b", "critic_front", "critic_front_pol", "critic_mid", "critic_mid_pol", "critic_pfront", "critic_pfront_pol", "critic_fwd_b_pol", "pend_head_project", "critic_bwd_a", "critic_bwd_b", "policy_a", "policy_b",
               "policy_c", "policy_d", "policy_e", "policy_front", "policy_front_bc")
 
     def __init__(self, env_kernels, descs, twin, batch, fields):

@@ -84,10 +84,10 @@ def test_split_update_stages_validate_arguments():
     lib = _lib.load()
     for stage in ("critic_fwd_a", "critic_fwd_b", "critic_fwd_b_pol", "pend_head_project", "critic_bwd_a", "critic_bwd_b", "policy_a",
                   "policy_b", "policy_c", "policy_d", "policy_e", "critic_front", "critic_front_pol", "critic_mid", "critic_mid_pol",
-                  "policy_front", "policy_front_bc"):
+                  "critic_pfront", "critic_pfront_pol", "policy_front", "policy_front_bc"):
         assert getattr(lib, "rpo_split_" + stage)(None, None) == _lib.CONST["RPO_ERR_NULL"]
     assert lib.rpo_xcc_probe(8, 16, 4, 256, None, None) == _lib.CONST["RPO_ERR_NULL"]
     assert lib.rpo_xcc_probe(0, 16, 4, 256, None, None) == _lib.CONST["RPO_ERR_ARG"]
-    for stage in ("critic_fwd_a_ride", "critic_fwd_b_ride", "critic_bwd_b_ride", "critic_front_ride", "critic_mid_ride"):            # the riding rollout halves: both structs are required
+    for stage in ("critic_fwd_a_ride", "critic_fwd_b_ride", "critic_bwd_b_ride", "critic_front_ride", "critic_mid_ride", "critic_pfront_ride"):            # the riding rollout halves: both structs are required
         assert getattr(lib, "rpo_split_" + stage)(None, None, None) == _lib.CONST["RPO_ERR_NULL"]
-    assert _lib.CONST["RPO_ABI_VERSION"] == 2
+    assert _lib.CONST["RPO_ABI_VERSION"] == 3

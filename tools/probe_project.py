@@ -44,7 +44,7 @@ def main():
                 continue
             want = action.clone()
             for mode in (0, 1, 2):
-                ws = torch.zeros(528, dtype=torch.int64, device="cuda")
+                ws = torch.zeros(5408, dtype=torch.int64, device="cuda")
                 s = torch.cuda.Stream()
                 with torch.cuda.stream(s):
                     for _ in range(3):
@@ -65,7 +65,7 @@ def main():
                     s.synchronize()
                 print("   8 workgroups, store mode %d: %.2f us per launch, iters=%d, bits equal: %s, gave up: %d, epoch %d" % (
                     mode, e0.elapsed_time(e1) * 1e3 / 500, int(iters.item()), same and bool(torch.equal(action, want)),
-                    int(ws[521]), int(ws[520])), flush=True)
+                    int(ws[529]), int(ws[528])), flush=True)
 
 
 if __name__ == "__main__":
