@@ -79,12 +79,12 @@ def workload_hp(workload):
 
 
 def make_trainer(n_envs, device, max_epochs, capacity=None, workload="cart_ddpg", updates_per_step=None, backend=None,
-                 **extra):
+                 torch_seed=123, **extra):
     from rpo_amd import gym_shim
     from rpo_amd.algo import RPODDPG, RPOSAC
     from rpo_amd.env import CartSafeEnv, EVOPFEnv, SpringPendulumEnv
     np.random.seed(123)
-    torch.manual_seed(123)                  # identical replicas on every rank (the trainer broadcasts rank 0's anyway)
+    torch.manual_seed(torch_seed)           # identical replicas on every rank (the trainer broadcasts rank 0's anyway)
     envname, algo, hp = workload_hp(workload)
     kw = {} if backend is None else dict(backend=backend, device=device)
     if envname == "evopf":
@@ -237,6 +237,9 @@ def launch_models(tr, workload):
         "split_critic_front_ride": ("mfma", n, (B * (fa + 4 * twin * fc) + n * fa) / float(n)),
         "split_critic_mid": ("mfma", B, 3 * twin * fc), "split_critic_mid_pol": ("mfma", B, fa + 3 * twin * fc),
         "split_critic_mid_ride": ("mfma", n, (B * 3 * twin * fc + (n - n // 2) * fa) / float(n)),
+        # SpringPendulum fused front: fwd_a + the batch-coupled projection (one workgroup per row tile) + fwd_b + bwd_a
+        "split_critic_pfront": ("mfma", B, fa + 4 * twin * fc), "split_critic_pfront_pol": ("mfma", B, 2 * fa + 4 * twin * fc),
+        "split_critic_pfront_ride": ("mfma", n, (B * (fa + 4 * twin * fc) + n * fa) / float(n)),
     }
     return m
 
@@ -371,6 +374,8 @@ KERNEL_OF = {
     "split_critic_front": "split_critic_front_kernel", "split_critic_front_pol": "split_critic_front_kernel",
     "split_critic_front_ride": "split_critic_front_ride_kernel", "split_critic_mid": "split_critic_mid_kernel",
     "split_critic_mid_pol": "split_critic_mid_kernel", "split_critic_mid_ride": "split_critic_mid_ride_kernel",
+    "split_critic_pfront": "split_critic_pfront_kernel", "split_critic_pfront_pol": "split_critic_pfront_kernel",
+    "split_critic_pfront_ride": "split_critic_pfront_ride_kernel",
 }
 
 
@@ -598,6 +603,11 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the rollout-only / UTD-matched / cart_sac legs")
     ap.add_argument("--workload", default="cart_ddpg", choices=sorted(WORKLOADS),
                     help="cart_ddpg is the headline (BASELINE.json configs[1]); the others are extra measurements")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="one GPU: run the data-parallel code path over a ONE-rank RCCL group (the gradient all-reduce and the "
+                         "rpo_absmax_slots launch inside the graph windows): the measured intercept of the 1 -> N expectation")
+    ap.add_argument("--n1-seeds", type=int, default=384,
+                    help="headline extras: seeds of the num_envs = 1 violation-rate figure (0: skip)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -619,11 +629,20 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if world == 1:
+            s0 = socket.socket()
+            s0.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(s0.getsockname()[1]))
+            s0.close()
+            os.environ["RPO_DIST_FORCE"] = "1"
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
         log("rank %d/%d on cuda:%d: process group up, backend %s (RCCL), %d ranks" % (
             rank, world, local_rank, dist.get_backend(), dist.get_world_size()))
+    rccl_ranks = dist.get_world_size() if dist.is_initialized() else 0
 
     EPG = envs_per_gpu(args.workload)
     n_total = EPG * world
@@ -651,8 +670,20 @@ def main():
                    "parallelism": "dp%d (env shards, one RCCL all-reduce of the flat gradient bucket per update, "
                                   "captured inside the iteration's hipGraph)" % world,
                    "hip_graph": bool(tr._graphs.enabled), "graph_window_iterations": tr._cycle,
-                   "collectives_in_graph": bool(tr.dist.in_graph)},
-        "constraint_violation_rate": tr.viol_rate,
+                   # what RCCL saw (0: no process group -- the single-process run has no collective at all), and the
+                   # collectives of the data-parallel iteration: one all-reduce of the critic's flat gradient slice per update,
+                   # one more (actor slice + multipliers [+ log alpha] in one bucket) on every policy_fre-th
+                   "rccl_ranks": rccl_ranks, "data_parallel_path": bool(tr.dist.on),
+                   "collectives_per_update": (1.0 + 1.0 / tr.policy_fre) if tr.dist.on else 0.0,
+                   "collectives_in_graph": bool(tr.dist.on and tr.dist.in_graph),
+                   "allreduce_bytes": {"critic_update": 4 * int(tr.agent.flat.gradient(tr.agent.flat.critic_range).numel()),
+                                       "policy_step": 4 * int(sum(t.numel() for t in [tr.agent.flat.gradient(tr.agent.flat.policy_bucket)]))}
+                   if tr.dist.on else None},
+        # NOT the reference's quantity: the fraction of (env, vector step) pairs with max(max_ineq, max_eq) > 1e-3 over the
+        # first `constraint_violation_window` of THIS run, in which the policy receives one update per VECTOR step (1 / 4096 of
+        # the reference's learning per env step) -- it mostly measures how early in training the window sits.  The figure that
+        # is comparable with the reference's 3000-step single-env runs is constraint_violation_rate_n1 below.
+        "constraint_violation_rate_vector_cadence": tr.viol_rate,
         "constraint_violation_window": "%d vector steps x %d envs" % (tr._t, n_total),
         "mean_projection_iters": tr.proj_iters_mean,
     }
@@ -670,6 +701,15 @@ def main():
         torch.cuda.empty_cache()
         tr = None
 
+    if extras and headline and world == 1 and args.n1_seeds > 0:
+        result.update(violation_rate_n1(device, args.n1_seeds))
+    if not args.no_clinic and world > 1:
+        # every rank runs the clinic (its recorded iterations contain the collectives); rank 0's figures are printed
+        if tr is None:
+            tr = prepared_trainer(n_total, device, args.workload)
+        if tr.fused is not None:
+            result["roofline"] = roofline(kernel_clinic(tr, args.workload), args.workload)
+            result["roofline"]["note"] += "; rank 0's launches of the %d-rank run" % world
     if rank == 0 and world == 1:
         if extras:
             # (i) rollout-only throughput next to the headline, so that the cadence is visible
@@ -711,9 +751,44 @@ def main():
                 result["utd_matched_over_cpu_single_core"] = result["utd_matched_env_steps_per_s"] / cpu["single_core_value"]
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def violation_rate_n1(device, seeds, steps=3000):
+    """The constraint-violation rate in the REFERENCE's setting (rpo_ddpg.py:120-123,137; threshold cartpole.py:326-330):
+    num_envs = 1, one update per env step, `steps` iterations of scripts/cart_exp.py per seed, averaged over `seeds` runs of
+    the shipped trainer on the HIP kernels -- next to the same statistic of the unmodified reference's runs (384 seeds,
+    tests/golden/training_stats_ddpg_cart.npz, recorded by tests/golden/make_golden.py stats).  north_star: |delta| <= 1e-3."""
+    from rpo_amd.utils.logger import Logger
+    rates = []
+    t0 = time.perf_counter()
+    for seed in range(seeds):
+        # (its own initial weights AND its own Philox seed per run, like tests/test_statistical_parity_gpu.py)
+        tr = make_trainer(1, device, steps, capacity=steps, workload="cart_ddpg", torch_seed=123 + seed, seed=5000 + seed)
+        tr.logger = Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=steps)
+        tr.run(eval=False)
+        n = tr.logger.pointer
+        mi, me = tr.logger.tracker["max_ineq"][:n], tr.logger.tracker["max_eq"][:n]
+        rates.append(float((np.maximum(mi, me) > 1e-3).mean()))
+        del tr
+    rates = np.asarray(rates)
+    out = {"constraint_violation_rate_n1": float(rates.mean()),
+           "constraint_violation_rate_n1_se": float(rates.std(ddof=1) / np.sqrt(len(rates))),
+           "constraint_violation_rate_n1_protocol": "%d seeds x %d iterations at num_envs = 1 (reference cadence), %.0f s" % (
+               seeds, steps, time.perf_counter() - t0)}
+    try:
+        ref = np.load(os.path.join(ROOT, "tests", "golden", "training_stats_ddpg_cart.npz"))["stats"][:, 1]
+        se = float(np.sqrt(ref.var(ddof=1) / len(ref) + rates.var(ddof=1) / len(rates)))
+        out.update({"constraint_violation_rate_reference": float(ref.mean()),
+                    "constraint_violation_rate_reference_se": float(ref.std(ddof=1) / np.sqrt(len(ref))),
+                    "constraint_violation_rate_reference_seeds": int(len(ref)),
+                    "constraint_violation_rate_n1_minus_reference": float(rates.mean() - ref.mean()),
+                    "constraint_violation_rate_difference_se": se})
+    except (OSError, KeyError):
+        pass
+    return out
 
 
 def roofline(clinic, workload):

@@ -506,6 +506,10 @@ typedef struct {
      * device).  proj_store_mode: 0 = agent-scope granule stores; 1 = plain stores when the eight workgroups find themselves on
      * one XCD (checked inside every launch; the polling loads are served by that XCD's L2), agent-scope otherwise. */
     unsigned long long* proj_ws; int proj_store_mode;
+    /* tests only (0 in production): bit 0 -- in the fused front launches the policy workgroup of row tile 0, column group 0
+     * withholds its hand-over (arrival / granules), so that its consumers run into their bounded wait and raise the gave-up
+     * word: the failure path must be loud and must leave the device usable. */
+    int debug;
 } rpo_split_update;
 
 

@@ -674,8 +674,14 @@ class RPOTrainerBase(object):
         su.set(prep_step=opt.step_dev if prep else None, prep_beta1=opt.betas[0], prep_beta2=opt.betas[1],
                clock_out=self._clock(not actor_step) if prep else None,
                updates_out=self._updates_out if not actor_step else None,
-               gradmax_reset=opt.gradmax if self._gradmax_stale else None,
-               gradmax_reset2=self.agent.actor_optim.gradmax if self._actor_gradmax_stale else None,
+               # Prepared optimiser launches no longer zero their gradmax slots: fwd_a does, for BOTH optimisers and on
+               # every prepared update -- not only when a host flag says a prepared launch ran before.  The pointers are
+               # frozen into the hipGraph at capture, and a replay does not re-run this Python: with the flags, a graph
+               # captured at a position of the policy_fre period that follows a critic-only iteration (policy_fre 3 or 5)
+               # never cleared the actor's slots, and clip_grad_norm_ saw a running maximum.  Both buffers are filled only
+               # after fwd_a of the same update, so the extra zeroing is harmless.
+               gradmax_reset=opt.gradmax if (prep or self._gradmax_stale) else None,
+               gradmax_reset2=self.agent.actor_optim.gradmax if (prep or self._actor_gradmax_stale) else None,
                rollout_ctrl=self.vec.ctrl if pending else None, rollout_stats=self.vec.stats if pending else None,
                rollout_stats_cap=self.vec.stats.shape[0] if pending else 0)
         self._gradmax_stale, self._actor_gradmax_stale = bool(prep), False
@@ -733,18 +739,53 @@ class RPOTrainerBase(object):
         su.run("critic_fwd_b_pol" if early else "critic_fwd_b", rider=ride)   # (+ actor forward of lanes [cut, n))
         self._critic_update_split_back(su, ride)
 
-    def _check_tile_sync(self):
-        """The fused front launches raise the last word of ``tile_sync`` when a workgroup gave up waiting for its row tile's
-        producers (nsplit.hip, kNsSpinMax): the values of that launch are then undefined -- fail loudly instead of training on."""
+    def _handover_flags(self):
+        """Device words the in-launch hand-overs raise when a wait was given up: (tile_sync's last word, proj_ws's)."""
         su = getattr(self, "_split_cache", None)
         sync = su._held.get("tile_sync") if su else None
-        if sync is not None and getattr(self, "_front_cache", False) and int(sync[-32]) != 0:
-            raise RuntimeError("rpo_split_*_front: a workgroup gave up waiting for its row tile (tile_sync flag set); "
-                               "rerun with RPO_FRONT=0")
         ws = su._held.get("proj_ws") if su else None
-        if ws is not None and int(ws[hip_ops.PROJ_WS_GAVE_UP]) != 0:
-            raise RuntimeError("rpo_split_pend_head_project: a workgroup gave up waiting for another one's granules "
-                               "(workspace flag set); rerun with RPO_PROJ_MULTI=0")
+        return (sync[-32:-31] if sync is not None and getattr(self, "_front_cache", False) else None,
+                ws[hip_ops.PROJ_WS_GAVE_UP:hip_ops.PROJ_WS_GAVE_UP + 1] if ws is not None else None)
+
+    def _raise_handover(self, front, proj):
+        if front:
+            raise RuntimeError("rpo_split_*_front: a workgroup gave up waiting for its row tile (tile_sync flag set); the "
+                               "values of that launch are undefined -- rerun with RPO_FRONT=0")
+        if proj:
+            raise RuntimeError("rpo_split_pend_head_project / rpo_split_critic_pfront: a workgroup gave up waiting for another "
+                               "one's granules (workspace flag set); the values of that launch are undefined -- rerun with "
+                               "RPO_PROJ_MULTI=0")
+
+    def _check_tile_sync(self):
+        """The fused front launches raise a flag word when a workgroup gave up waiting for its producers (nsplit.hip,
+        kNsSpinMax / kPmSpinMax): the values of that launch are then undefined -- fail loudly instead of training on.
+        (Synchronising read: harvest, save(), the end of run().)"""
+        f, g = self._handover_flags()
+        self._raise_handover(f is not None and int(f[0]) != 0, g is not None and int(g[0]) != 0)
+
+    def _poll_handover(self):
+        """The same without waiting for the device: after every graph window the two flag words are copied to pinned host
+        memory asynchronously; a copy that has landed is inspected before the next window is launched, so a lost producer
+        stops the run within about one window instead of at the next statistics harvest."""
+        f, g = self._handover_flags()
+        if f is None and g is None:
+            return
+        st = getattr(self, "_handover_poll", None)
+        if st is None:
+            st = self._handover_poll = dict(host=torch.zeros(2, dtype=torch.int64).pin_memory(), event=None,
+                                            dev=torch.zeros(2, dtype=torch.int64, device=self.device))
+        if st["event"] is not None:
+            if not st["event"].query():
+                return                                            # the previous copy is still in flight: look again later
+            st["event"] = None
+            self._raise_handover(int(st["host"][0]) != 0, int(st["host"][1]) != 0)
+        if f is not None:
+            st["dev"][0:1].copy_(f)
+        if g is not None:
+            st["dev"][1:2].copy_(g)
+        st["host"].copy_(st["dev"], non_blocking=True)
+        st["event"] = torch.cuda.Event()
+        st["event"].record()
 
     def _front_ok(self):
         """rpo_split_critic_front usable here (``RPO_FRONT=0``: never): see ops.front_launch_ok."""
@@ -834,6 +875,8 @@ class RPOTrainerBase(object):
                     self._graphs.run(("cycle", L, do_train), lambda: [self._run_segments(self._segments(
                         False, do_train, do_train and (t + i + 1) % self.policy_fre == 0)) for i in range(L)])
                 self._updates += L if do_train else 0
+                if do_train:
+                    self._poll_handover()
             else:
                 self._iteration(warm, do_train, actor_step)
                 if do_train:
@@ -1121,6 +1164,9 @@ class RPOTrainerBase(object):
         (``replay=True``) the filled part of this rank's replay shard.  One directory per rank when data-parallel."""
         d = self._ckpt_dir()
         os.makedirs(d, exist_ok=True)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+            self._check_tile_sync()                                 # never checkpoint parameters of undefined origin
         self.agent.save_model(d)
         self._harvest()
         v, b = self.vec, self.buffer

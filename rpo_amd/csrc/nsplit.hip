@@ -107,6 +107,7 @@ struct SplitArgs {
     long long* updates_out;
     float* part_pol;              // policy step: head partials of pi(s) (pol_a -> pol_b); NULL: part_pi is reused
     unsigned* tile_sync;          // fused front launch: per-tile arrival words (ns_tile_arrive / ns_tile_wait)
+    int debug;                    // tests: bit 0 = the policy workgroup (tile 0, group 0) of a fused front withholds its hand-over
 };
 
 // ---- Hand-over between workgroups of ONE launch (the fused front of the critic update, rpo_split_critic_front).
@@ -1163,7 +1164,7 @@ __device__ __forceinline__ bool front_role(const SplitArgs& p, const CartConsts&
     unsigned* sync = p.tile_sync;
     if (z < 1 + K) {
         fwd_a_role<L>(p, lds, tile, nb.tile * kRows, nb.g, z);
-        if (z == 0) ns_tile_arrive(sync + nb.tile * kNsSyncStride);
+        if (z == 0) { if (!((p.debug & 1) && nb.tile == 0 && nb.g == 0)) ns_tile_arrive(sync + nb.tile * kNsSyncStride); }
         else ns_tile_arrive(sync + (T + nb.tile) * kNsSyncStride, 1u << 16);
     } else if (z < 1 + 2 * K) {
         fwd_b_role<L, 1>(p, c, lds, tile, nb.tile * kRows, nb.g, z - 1 - K, sync + nb.tile * kNsSyncStride, (unsigned)kNsGroups);
@@ -1348,7 +1349,7 @@ __device__ __forceinline__ bool pfront_role(const SplitArgs& p, const CartConsts
         fwd_a_role<L>(p, lds, tile, row0, g, 0, hp, sync + nb.tile * kNsSyncStride);
         PM_STAMP(ws, nb.tile == 0 && g == 0, 41);
         const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
-        if (tid >= 64 && li == 0) {
+        if (tid >= 64 && li == 0 && !((p.debug & 1) && nb.tile == 0 && g == 0)) {
 #pragma unroll
             for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -1863,7 +1864,7 @@ int to_args(const rpo_split_update* u, unsigned need, SplitArgs& a, CartConsts& 
     a.rollout_ctrl = u->rollout_ctrl; a.rollout_stats = u->rollout_stats; a.rollout_stats_cap = u->rollout_stats_cap;
     a.prep_step = u->prep_step; a.prep_beta1 = u->prep_beta1; a.prep_beta2 = u->prep_beta2; a.clock_out = u->clock_out;
     a.gradmax_reset = u->gradmax_reset; a.gradmax_reset2 = u->gradmax_reset2; a.updates_out = u->updates_out;
-    a.part_pol = u->part_pol; a.tile_sync = u->tile_sync;
+    a.part_pol = u->part_pol; a.tile_sync = u->tile_sync; a.debug = u->debug;
     for (int j = 0; j < 3; ++j) { a.prep2_step[j] = u->prep2_step[j]; a.prep2_beta1[j] = u->prep2_beta1[j]; a.prep2_beta2[j] = u->prep2_beta2[j]; }
     return 0;
 }

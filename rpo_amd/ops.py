@@ -763,7 +763,7 @@ class _SplitUpdateStruct(ctypes.Structure):
          ("prep_beta2", ctypes.c_float), ("clock_out", ctypes.c_void_p), ("gradmax_reset", ctypes.c_void_p),
          ("prep2_step", ctypes.c_void_p * 3), ("prep2_beta1", ctypes.c_float * 3), ("prep2_beta2", ctypes.c_float * 3),
          ("gradmax_reset2", ctypes.c_void_p), ("updates_out", ctypes.c_void_p), ("part_pol", ctypes.c_void_p),
-         ("tile_sync", ctypes.c_void_p), ("proj_ws", ctypes.c_void_p), ("proj_store_mode", ctypes.c_int)])
+         ("tile_sync", ctypes.c_void_p), ("proj_ws", ctypes.c_void_p), ("proj_store_mode", ctypes.c_int), ("debug", ctypes.c_int)])
 
 
 class _RolloutRiderStruct(ctypes.Structure):

@@ -206,3 +206,143 @@ def test_cart_sac_4096_lanes_ridden_windows_equal_eager():
     np.testing.assert_array_equal(st[:, S["episodes"]], cols["done"][:, :, 0].sum(dim=1).cpu().numpy())
     np.testing.assert_allclose(st[:, S["reward_sum"]], cols["reward"][:, :, 0].sum(dim=1).cpu().numpy(), rtol=1e-6)
     assert abs(g.viol_rate - float(viol.double().mean())) < 1e-9 and g.env_steps == T * n
+
+
+def test_cart_ddpg_4096_lanes_properties(monkeypatch):
+    """Config 2, the headline (CartSafe-v0 RPODDPG, 4096 lanes, scripts/cart_exp.py with its shared state embedding): the one
+    configuration where the rollout does NOT ride and the policy front takes pol_a itself.  80 iterations through the
+    shipped trainer with the bench's hyper-parameters: ring chain, statistics == ring, hipGraph windows == eager launches,
+    fused front launches (RPO_FRONT=1) == separate launches (RPO_FRONT=0), bit for bit."""
+    from rpo_amd import ops
+    n = 4096
+    g, first = run("cart_ddpg", n, use_graph=True)
+    assert g.fused is not None and g._split_state() is not None and g.agent.flat.sizes[1] > 0      # shared embedding
+    assert not g._ride_ok(True) and g._front_ok()
+    assert any(k[0] == "cycle" and e["graph"] is not None for k, e in g._graphs.entries.items() if isinstance(k, tuple))
+    rows, cols = ring(g)
+    assert bool(torch.isfinite(rows).all()) and float(g.buffer.rows[T * n:].abs().max()) == 0.0
+    assert int(g.vec.ctrl[0]) == T
+
+    def reset_ok(s):                                             # cartpole.py:233: every state entry uniform in (-0.05, 0.05)
+        return (s.abs() <= 0.05 + 1e-6).all(dim=1)
+    assert check_chain(cols, reset_ok) > 0
+    assert float(cols["eq_viol"].abs().max()) < 2e-5             # Complete + Proj keep the equality (cartpole.py:369-376)
+    S = ops.STAT
+    st = ops.reduce_stats(g.vec.stats[:T]).cpu().numpy()
+    viol = (torch.maximum(cols["ineq_viol"].max(dim=2).values, cols["eq_viol"].abs().max(dim=2).values) > 1e-3)
+    np.testing.assert_array_equal(st[:, S["viol_count"]], viol.sum(dim=1).cpu().numpy().astype(np.float32))
+    np.testing.assert_array_equal(st[:, S["episodes"]], cols["done"][:, :, 0].sum(dim=1).cpu().numpy())
+    np.testing.assert_allclose(st[:, S["reward_sum"]], cols["reward"][:, :, 0].sum(dim=1).cpu().numpy(), rtol=1e-6)
+    assert abs(g.viol_rate - float(viol.double().mean())) < 1e-9 and g.env_steps == T * n
+    e, _ = run("cart_ddpg", n, use_graph=False)
+    monkeypatch.setenv("RPO_FRONT", "0")
+    s, _ = run("cart_ddpg", n, use_graph=True)
+    assert not s._front_ok()
+    for other in (e, s):
+        assert torch.equal(g.buffer.rows, other.buffer.rows) and torch.equal(g.agent.flat.data, other.agent.flat.data)
+        assert torch.equal(g.vec.internal, other.vec.internal) and torch.equal(g.agent.nju.weight, other.agent.nju.weight)
+        assert torch.equal(g.agent.critic_target_flat, other.agent.critic_target_flat)
+        assert torch.equal(g.agent.critic_optim.exp_avg_sq, other.agent.critic_optim.exp_avg_sq)
+
+
+def _forced_rccl_worker(rank, port, out_dir, n, iters):
+    """Config 4's per-rank workload (CartSafe-v0 RPOSAC, 4096 lanes per GPU) on the data-parallel code path over RCCL with a
+    forced one-rank group: the gradient all-reduces are captured inside the ridden 16-iteration windows."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RPO_VERBOSE="0", RPO_DIST_FORCE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import bench
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    tr = bench.make_trainer(n, torch.device("cuda", 0), 10 ** 9, capacity=96, workload="cart_sac", use_graph=True)
+    assert tr.dist.on and tr.dist.in_graph and tr._ride_ok(True)
+    tr.vec.reset()
+    tr.run_steps(iters)
+    tr._harvest(final=True)
+    torch.cuda.synchronize()
+    captured = [k for k, e in tr._graphs.entries.items() if e["graph"] is not None]
+    assert ("cycle", 16, True, "ride") in captured, captured
+    torch.save(dict(flat=tr.agent.flat.data.cpu(), nju=tr.agent.nju.weight.data.cpu(), state=tr.vec.internal.cpu(),
+                    rows=tr.buffer.rows[:16 * n].cpu(), uctrl=int(tr._uctrl[0]), env_steps=float(tr.env_steps)),
+               os.path.join(out_dir, "forced.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cart_sac_4096_lanes_forced_rccl_in_ridden_windows(tmp_path):
+    """SCALE config (CartSafe-v0 RPOSAC, 4096 lanes per rank, RCCL gradient all-reduce): what ONE GPU can check -- the
+    data-parallel iteration with its collectives captured inside the ridden hipGraph windows (RPO_DIST_FORCE: a one-rank
+    RCCL group, the mean over ranks is the identity) leaves the same parameters, lanes and ring as the plain single-process
+    run, bit for bit; the inf-norm then comes from rpo_absmax_slots behind the all-reduce instead of the backward kernels."""
+    import socket
+    import time
+    import torch.multiprocessing as mp
+    n = 4096
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.spawn(_forced_rccl_worker, args=(port, str(tmp_path), n, T), nprocs=1, join=False)
+    deadline = time.time() + 300
+    while not ctx.join(timeout=5):
+        if time.time() > deadline:
+            for proc in ctx.processes:
+                if proc.is_alive():
+                    proc.kill()
+            pytest.fail("the forced-RCCL rank did not finish")
+    r = torch.load(os.path.join(str(tmp_path), "forced.pt"), weights_only=False)
+    g, _ = run("cart_sac", n, use_graph=True)
+    assert torch.equal(g.agent.flat.data.cpu(), r["flat"]) and torch.equal(g.agent.nju.weight.data.cpu(), r["nju"])
+    assert torch.equal(g.vec.internal.cpu(), r["state"]) and torch.equal(g.buffer.rows[:16 * n].cpu(), r["rows"])
+    assert int(g._uctrl[0]) == r["uctrl"] and g.env_steps == r["env_steps"] == T * n
+
+
+@pytest.mark.parametrize("workload", ["cart_ddpg", "pen_sac"])
+def test_lost_producer_fails_loudly_and_leaves_the_device_usable(workload, monkeypatch):
+    """The in-launch hand-overs of the fused fronts wait with a bound (kNsSpinMax / kPmSpinMax polls).  A test-only debug
+    bit makes ONE producer workgroup withhold its hand-over: the consumers give up, raise the flag word, and the trainer
+    turns that into a RuntimeError -- at the next statistics harvest, at save(), and (asynchronously) within about one graph
+    window.  The launch itself completes, leaves its hand-over words clean, and the device runs the next trainer normally."""
+    import bench
+    from rpo_amd import ops
+    os.environ["RPO_VERBOSE"] = "0"
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "4")
+    tr = bench.make_trainer(256, DEV, 10 ** 9, capacity=64, workload=workload, use_graph=False)
+    tr.vec.reset()
+    tr.run_steps(8)
+    tr._harvest(final=True)                                      # healthy: no flag
+    su = tr._split_state()
+    assert su is not None and tr._front_ok() and (workload != "pen_sac" or tr._pfront)
+    su.set(debug=1)
+    tr.run_steps(1)
+    torch.cuda.synchronize()                                     # the launch with the lost producer completes
+    front, proj = tr._handover_flags()
+    assert int((front if workload == "cart_ddpg" else proj)[0]) == 1
+    with pytest.raises(RuntimeError, match="gave up"):
+        tr._harvest(final=True)
+    with pytest.raises(RuntimeError, match="gave up"):
+        tr.save(replay=False)
+    # every hand-over word except the flag is back at zero, the granule epoch moved on, the readers' count is zero
+    sync = su._held["tile_sync"].clone()
+    sync[-32] = 0
+    assert int(sync.abs().sum()) == 0
+    if workload == "pen_sac":
+        ws = su._held["proj_ws"]
+        assert int(ws[ops.PROJ_WS_GAVE_UP + 1]) == 0 and int(ws[ops.PROJ_WS_GAVE_UP - 1]) == 9
+    # the asynchronous poll of the graph windows raises too
+    g = bench.make_trainer(256, DEV, 10 ** 9, capacity=64, workload=workload, use_graph=True)
+    g.vec.reset()
+    g.run_steps(40)
+    g._split_state().set(debug=1)
+    g._graphs.entries.clear()                                    # (the struct is read at capture: capture again with the bit)
+    with pytest.raises(RuntimeError, match="gave up"):
+        for _ in range(40):
+            g.run_steps(4)
+            torch.cuda.synchronize()
+    # ... and the device is fine: a fresh trainer runs, finite and flag-free
+    h = bench.make_trainer(256, DEV, 10 ** 9, capacity=64, workload=workload, use_graph=True)
+    h.vec.reset()
+    h.run_steps(40)
+    h._harvest(final=True)
+    assert bool(torch.isfinite(h.vec.internal).all()) and bool(torch.isfinite(h.agent.flat.data).all())

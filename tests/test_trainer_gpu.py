@@ -74,6 +74,31 @@ def test_graph_replay_equals_eager(hip, algo, envname, fused):
     _stats_equal(a, b, 24)
 
 
+@pytest.mark.parametrize("policy_fre", [3, 5, 2])
+@pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "pendulum")])
+def test_graph_replay_equals_eager_for_other_policy_periods(hip, algo, envname, policy_fre, monkeypatch):
+    """policy_fre 3 / 5 / 2: the single-iteration hipGraph of a critic-only iteration is captured at a position of the period
+    that depends on policy_fre (the 4th execution of its key); what its first launch does on behalf of the optimiser
+    launches (zeroing the inf-norm slots of BOTH optimisers) must not depend on where it was captured.  Graph replays
+    (single iterations, then windows) against eager launches, bit for bit, incl. the optimiser moments that the clip enters."""
+    dev = torch.device("cuda")
+    out = []
+    for cyc, use_graph in (("1", True), ("16", True), ("1", False)):
+        monkeypatch.setenv("RPO_GRAPH_CYCLE", cyc)
+        # (clip_thres far below the gradients' inf-norm: every optimiser step is clipped, so a stale maximum changes the bits)
+        out.append(_run(algo, envname, hip, dev, 64, 256, use_graph=use_graph, policy_fre=policy_fre, clip_thres=1e-3))
+    a, b, c = out
+    assert any(e["graph"] is not None for e in a._graphs.entries.values())
+    assert any(k[0] == "cycle" and e["graph"] is not None for k, e in b._graphs.entries.items())
+    for other in (a, b):
+        assert torch.equal(other.agent.flat.data, c.agent.flat.data)
+        assert torch.equal(other.agent.critic_target_flat, c.agent.critic_target_flat)
+        assert torch.equal(other.agent.nju.weight, c.agent.nju.weight)
+        assert torch.equal(other.agent.actor_optim.exp_avg, c.agent.actor_optim.exp_avg)
+        assert torch.equal(other.agent.critic_optim.exp_avg_sq, c.agent.critic_optim.exp_avg_sq)
+        assert torch.equal(other.buffer.rows, c.buffer.rows)
+
+
 @pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "cart"), ("ddpg", "pendulum")])
 def test_multi_iteration_graph_equals_single_iteration_graphs(hip, algo, envname, monkeypatch):
     """RPO_GRAPH_CYCLE: one hipGraph per 8 iterations (two policy_fre periods) against one graph per iteration and
