@@ -383,7 +383,7 @@ def pmc_traffic(kernel, lanes):
     """HBM bytes per launch from the committed rocprofv3 PMC collections (profiles/r0*_pmc_traffic.json; recipe and the
     gfx950 FETCH_SIZE correction are described there).  None when that (kernel, size) was not collected."""
     base = kernel.split("<")[0]
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 table = json.load(f)["kernels"]

@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-/* 3: rpo_split_update gained proj_ws / proj_store_mode (the struct grew); rpo_split_critic_pfront*, rpo_pendulum_project_batchref_ws */
+/* 3: rpo_split_update gained proj_ws / proj_store_mode / debug (the struct grew); rpo_split_critic_pfront*,
+ * rpo_pendulum_project_batchref_ws; rpo_evopf_complete_bwd takes grad_action2, rpo_evopf_lagrangian takes overwrite */
 #define RPO_ABI_VERSION 3
 
 #define RPO_ERR_ARG (-1)
@@ -682,8 +683,8 @@ int rpo_evopf_gauss_head_bwd(int n, const float* state, int state_stride, const 
 
 /* PFFunction.backward (evopf.py:857-910): grad_ap [n,14] = dL/dz given grad_action [n,43] = dL/dy and the completed
  * action; the Jacobians are re-evaluated at that action (the reference keeps those of the last Newton point). */
-int rpo_evopf_complete_bwd(int n, const float* action, const float* grad_action, float* grad_ap, const float* consts_dev,
-                           void* stream);
+int rpo_evopf_complete_bwd(int n, const float* action, const float* grad_action, const float* grad_action2, float* grad_ap,
+                           const float* consts_dev, void* stream);   /* grad_action2: NULL, or a second [n,43] term added to dL/dy */
 
 /* eq_resid [n,28] (evopf.py:520-546) and ineq_resid [n,58] (signed, :548-563); either output may be NULL. */
 int rpo_evopf_resid(int n, const float* state, int state_stride, const float* action, float* eq_out, float* ineq_out,
@@ -702,7 +703,8 @@ int rpo_evopf_eq_vjp(int n, const float* action, const float* grad_eq, float* gr
 /* scale * sum_b sum_j nu_j relu(g_j(s_b, a_b)) accumulated into loss_out, d/d action into grad_action [n,43] (written),
  * d/d nu accumulated into grad_nu [58] (rpo_ddpg.py:312-319, dual.py:63-65). */
 int rpo_evopf_lagrangian(int n, const float* state, int state_stride, const float* action, const float* nu, float scale, float* loss_out,
-                         float* grad_action, float* grad_nu, const float* consts_dev, void* stream);
+                         float* grad_action, float* grad_nu, const float* consts_dev, int overwrite, void* stream);
+/* (overwrite != 0: loss_out is written instead of accumulated -- one launch instead of a fill + this one; grad_nu accumulates) */
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused pipelines of one RPO iteration (rpo_amd/csrc/fused.hip): the row-local stages chained

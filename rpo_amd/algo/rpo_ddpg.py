@@ -225,17 +225,24 @@ class RPODDPG(RPOTrainerBase):
         actions = self._complete_only(state, ap_det, noise)
         q = f.forward("critic", state, actions, f.buf("q", B, 1), save=True)
         lag, g_act = f.buf("loss_lag", 1), f.buf("g_act", B, k.action_dim)
-        lag.zero_()
+        # (EVOPF kernels write the loss term and add the Lagrangian's d/d action themselves: no torch launch in the step)
+        fa = bool(getattr(k, "fused_adds", False))
+        if not fa:
+            lag.zero_()
         self._zero_grads()                 # parameters AND multipliers (they live in the same flat buffer)
-        k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1), obs=state)
+        k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1), obs=state,
+                     **(dict(overwrite=True) if fa else {}))
         dq = self._const_dq(B)                                 # d mean(-Q) / dQ: a constant, filled once
         da = f.buf("da", B, k.action_dim)
         shared = ag.flat.sizes[1] > 0      # shared embedding: the critic path contributes to its gradient
         f.backward("critic", state, actions, dq, da=da, param_grads=shared, first_layer_state_only=True)
-        da.add_(g_act)
         P = k.partial_dim
         dap, do = f.buf("dap", B * P), f.buf("do", B, P)
-        k.complete_bwd(state, da, dap, action=actions)
+        if fa:
+            k.complete_bwd(state, da, dap, action=actions, grad_action2=g_act)
+        else:
+            da.add_(g_act)
+            k.complete_bwd(state, da, dap, action=actions)
         if self._box_affine is None:       # state-dependent box: the env's kernel knows it
             k.tanh_box_bwd(state, ap_det, noise, self.eps_start, self.eps, self.decay_value, self._uctrl, dap, do.view(-1))
         else:

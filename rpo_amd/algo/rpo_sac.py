@@ -243,9 +243,12 @@ class RPOSAC(RPOTrainerBase):
         q1 = f.forward("critic1", state, actions, f.buf("q1", B, 1), save=True)
         q2 = f.forward("critic2", state, actions, f.buf("q2", B, 1), save=True)
         lag, g_act = f.buf("loss_lag", 1), f.buf("g_act", B, k.action_dim)
-        lag.zero_()
+        fa = bool(getattr(k, "fused_adds", False))             # (EVOPF kernels: see RPODDPG._actor_update)
+        if not fa:
+            lag.zero_()
         self._zero_grads()                 # parameters AND multipliers (they live in the same flat buffer)
-        k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1), obs=state)
+        k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1), obs=state,
+                     **(dict(overwrite=True) if fa else {}))
         # d(-min(q1, q2))/dq: the smaller one takes the gradient, ties are split (torch.min's backward)
         w1 = (q1 < q2).to(torch.float32) + 0.5 * (q1 == q2).to(torch.float32)
         dq1, dq2 = f.buf("dq1", B, 1), f.buf("dq2", B, 1)
@@ -255,10 +258,14 @@ class RPOSAC(RPOTrainerBase):
         shared = ag.flat.sizes[1] > 0
         f.backward_pair("critic1", "critic2", state, actions, dq1, dq2, da1, da2, param_grads=shared,
                         first_layer_state_only=True)
-        da1.add_(da2).add_(g_act)
         P = k.partial_dim
         dap, draw = f.buf("dap", B * P), f.buf("draw", B, 2 * P)
-        k.complete_bwd(state, da1, dap, action=actions)
+        if fa:
+            da1.add_(da2)
+            k.complete_bwd(state, da1, dap, action=actions, grad_action2=g_act)
+        else:
+            da1.add_(da2).add_(g_act)
+            k.complete_bwd(state, da1, dap, action=actions)
         if self._box_affine is None:
             k.gauss_head_bwd(state, raw, eps.view(-1), dap, float(ag.alpha) / B, draw)
         else:

@@ -200,6 +200,7 @@ __global__ __launch_bounds__(RPO_WAVE) void evopf_act_project_kernel(ActArgs p) 
 // those of the last Newton point, one update of size < tol earlier).  grad_ap [n,14] = dL/dz.
 __global__ __launch_bounds__(RPO_WAVE) void evopf_complete_bwd_kernel(int n, const float* __restrict__ action,
                                                                       const float* __restrict__ grad_action,
+                                                                      const float* __restrict__ grad_action2,
                                                                       float* __restrict__ grad_ap,
                                                                       const float* __restrict__ consts) {
     RPO_FP_STRICT
@@ -207,7 +208,10 @@ __global__ __launch_bounds__(RPO_WAVE) void evopf_complete_bwd_kernel(int n, con
     const int i = blockIdx.x, tid = threadIdx.x;
     load_consts(w, consts);
     load_row(w.a, action + (size_t)i * NY, NY);
-    load_row(w.dir, grad_action + (size_t)i * NY, NY);                   // dl_dy
+    // dl_dy (= grad_action [+ grad_action2]: d(-Q)/da from the critic + the Lagrangian term, rpo_ddpg.py:319, added here
+    // instead of by a launch of their own -- the same float addition)
+    for (int j = tid; j < NY; j += RPO_WAVE)
+        w.dir[j] = grad_action2 ? grad_action[(size_t)i * NY + j] + grad_action2[(size_t)i * NY + j] : grad_action[(size_t)i * NY + j];
     sync();
     flows(w);
     // step 3 (:865-880): dl/d(vm, va) through pg_slack = -eq[0] and qg_j = -eq[14 + spv_j]
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(RPO_BLOCK) void evopf_lagrangian_kernel(int n, cons
                                                                      float* __restrict__ loss_out,
                                                                      float* __restrict__ grad_action,
                                                                      float* __restrict__ grad_nu,
-                                                                     const float* __restrict__ consts) {
+                                                                     const float* __restrict__ consts, int overwrite) {
     RPO_FP_STRICT
     __shared__ float red[RPO_BLOCK / RPO_WAVE][2 * RPO_WAVE];
     const int v = threadIdx.x & (RPO_WAVE - 1), q = threadIdx.x / RPO_WAVE;
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(RPO_BLOCK) void evopf_lagrangian_kernel(int n, cons
         for (int w = 0; w < RPO_BLOCK / RPO_WAVE; ++w) { su += red[w][v]; sl += red[w][RPO_WAVE + v]; }
         if (grad_nu && up >= 0) { grad_nu[up] += scale * su; grad_nu[lo] += scale * sl; }   // one writer per address
         const float total = rpo_wave_sum(nu_up * su + nu_lo * sl);
-        if (v == 0 && loss_out) *loss_out += scale * total;
+        if (v == 0 && loss_out) *loss_out = overwrite ? 0.0f + scale * total : *loss_out + scale * total;
     }
 }
 
@@ -517,12 +521,12 @@ int rpo_evopf_gauss_head_bwd(int n, const float* state, int state_stride, const 
     return 0;
 }
 
-int rpo_evopf_complete_bwd(int n, const float* action, const float* grad_action, float* grad_ap, const float* consts_dev,
-                           void* stream) {
+int rpo_evopf_complete_bwd(int n, const float* action, const float* grad_action, const float* grad_action2, float* grad_ap,
+                           const float* consts_dev, void* stream) {
     if (int e = check_common(n, action, grad_action, consts_dev)) return e;
     if (!grad_ap) return RPO_ERR_NULL;
     hipLaunchKernelGGL(evopf_complete_bwd_kernel, dim3(n), dim3(RPO_WAVE), 0, (hipStream_t)stream, n, action, grad_action,
-                       grad_ap, consts_dev);
+                       grad_action2, grad_ap, consts_dev);
     RPO_LAUNCH_CHECK();
     return 0;
 }
@@ -557,11 +561,11 @@ int rpo_evopf_eq_vjp(int n, const float* action, const float* grad_eq, float* gr
 }
 
 int rpo_evopf_lagrangian(int n, const float* state, int state_stride, const float* action, const float* nu, float scale, float* loss_out,
-                         float* grad_action, float* grad_nu, const float* consts_dev, void* stream) {
+                         float* grad_action, float* grad_nu, const float* consts_dev, int overwrite, void* stream) {
     if (int e = check_common(n, state, action, consts_dev)) return e;
     if (!nu) return RPO_ERR_NULL;
     hipLaunchKernelGGL(evopf_lagrangian_kernel, dim3(1), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, state, state_stride,
-                       action, nu, scale, loss_out, grad_action, grad_nu, consts_dev);
+                       action, nu, scale, loss_out, grad_action, grad_nu, consts_dev, overwrite);
     RPO_LAUNCH_CHECK();
     return 0;
 }

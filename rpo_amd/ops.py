@@ -345,9 +345,11 @@ class EvopfKernels(object):
         check(_lib.load().rpo_evopf_gauss_head_bwd(draw.numel() // (2 * self.partial_dim), sp, ss, _p(raw), _p(eps), _p(dap), dlogp, _p(draw),
                                                    self._c(raw), _stream()), "rpo_evopf_gauss_head_bwd")
 
-    def complete_bwd(self, obs, grad_action, grad_ap, action=None):
-        check(_lib.load().rpo_evopf_complete_bwd(grad_action.shape[0], _p(action), _p(grad_action), _p(grad_ap),
-                                                 self._c(action), _stream()), "rpo_evopf_complete_bwd")
+    def complete_bwd(self, obs, grad_action, grad_ap, action=None, grad_action2=None):
+        """grad_action2: a second dL/dy term, added inside the kernel (the caller saves an elementwise launch)."""
+        check(_lib.load().rpo_evopf_complete_bwd(grad_action.shape[0], _p(action), _p(grad_action),
+                                                 _p(grad_action2, allow_none=True), _p(grad_ap), self._c(action), _stream()),
+              "rpo_evopf_complete_bwd")
 
     def resid(self, obs, action, eq_out, ineq_out):
         sp, ss = _row_view(obs, self.obs_dim)
@@ -363,12 +365,14 @@ class EvopfKernels(object):
         check(_lib.load().rpo_evopf_eq_vjp(action.shape[0], _p(action), _p(grad_eq), _p(grad_action), int(autograd_sign),
                                            self._c(action), _stream()), "rpo_evopf_eq_vjp")
 
-    def lagrangian(self, action, nu, scale, loss_out, grad_action, grad_nu, obs=None):
+    def lagrangian(self, action, nu, scale, loss_out, grad_action, grad_nu, obs=None, overwrite=False):
+        """overwrite: loss_out is written, not accumulated (the caller saves the fill launch before it)."""
         sp, ss = _row_view(obs, self.obs_dim)
         check(_lib.load().rpo_evopf_lagrangian(action.shape[0], sp, ss, _p(action), _p(nu), scale,
                                                _p(loss_out, allow_none=True), _p(grad_action, allow_none=True),
-                                               _p(grad_nu, allow_none=True), self._c(action), _stream()),
+                                               _p(grad_nu, allow_none=True), self._c(action), int(bool(overwrite)), _stream()),
               "rpo_evopf_lagrangian")
+    fused_adds = True      # complete_bwd(grad_action2=...) and lagrangian(overwrite=...) exist: no torch launches between them
 
 
 class PendulumKernels(object):

@@ -4,13 +4,19 @@
 #   3. tools/collect_profiles.sh (rocprofv3 kernel stats / timelines of the bench commands, PMC traffic passes).
 # Everything lands in gpurun_out/evidence_rNN/; copy what is to be judged into profiles/.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 OUT=$PWD/gpurun_out/evidence_$R
 mkdir -p $OUT
 export RPO_VERBOSE=0
 timeout 1500 python3 -m pytest tests -q -m gpu > $OUT/pytest_gpu.log 2>&1
 tail -1 $OUT/pytest_gpu.log
 timeout 900 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout 600 python3 bench.py --steps 20 --warmup 5 --no-extras --no-clinic --no-cpu-baseline > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err
+# the data-parallel code path over a ONE-rank RCCL group: all-reduce + rpo_absmax_slots inside the graph windows (intercept of 1 -> N)
+for W in cart_sac cart_ddpg; do
+  timeout 600 python3 bench.py --force-dist --workload $W --no-extras --no-clinic --no-cpu-baseline 2> $OUT/bench_force_dist_$W.err | grep '^{' > $OUT/bench_force_dist_$W.json
+done
+timeout 300 python3 tools/probe_project.py > $OUT/probe_project.txt 2>&1
 for W in cart_sac pen_ddpg pen_sac evopf_ddpg evopf_sac; do
   timeout 900 python3 bench.py --workload $W > $OUT/bench_line_$W.json 2> $OUT/bench_line_$W.err
 done

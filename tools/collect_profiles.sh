@@ -4,13 +4,13 @@
 #   windows, and HBM traffic counters (FETCH_SIZE / WRITE_SIZE in separate passes) of eager iterations.
 # Everything lands in gpurun_out/prof_rNN/ as text; copy what is to be judged into profiles/.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 OUT=$PWD/gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp RPO_VERBOSE=0
 ROOT=$PWD
 cd /tmp
-for W in cart_ddpg cart_sac pen_sac evopf_ddpg; do
+for W in cart_ddpg cart_sac pen_sac pen_ddpg evopf_ddpg; do
   rm -rf /tmp/p_$W
   rocprofv3 --kernel-trace --stats -d /tmp/p_$W -o t -- python3 $ROOT/bench.py --no-cpu-baseline --no-clinic --no-extras \
       --workload $W --steps 2000 --warmup 200 > $OUT/bench_$W.json 2> $OUT/bench_$W.err
