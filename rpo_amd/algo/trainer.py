@@ -296,8 +296,8 @@ class RPOTrainerBase(object):
     def _defer_ok(self):
         """A rollout that is followed by the column-split critic update may leave its step counter to that update's first
         launch (rpo_*_rollout(defer_clock=1), rpo_split_update.rollout_ctrl): saves the arrival counting behind the
-        rollout's last workgroup.  ``RPO_DEFER_CLOCK=0`` keeps the counter in the rollout."""
-        return bool(getattr(self, "_pipelines", False) and self._split_state() is not None and _env_int("RPO_DEFER_CLOCK", 1))
+        rollout's last workgroup."""
+        return bool(getattr(self, "_pipelines", False) and self._split_state() is not None)
 
     def _rollout(self, warm, defer_clock=False):
         """``defer_clock``: the caller runs the column-split critic update next, whose first launch advances the step
@@ -475,7 +475,7 @@ class RPOTrainerBase(object):
         """Several updates per vector step: ctrl[RPO_CTRL_UPDATES] is advanced by the update's own last stage (column-split
         critic AND policy stages) instead of a torch launch between two updates."""
         return bool(self.updates_per_step > 1 and getattr(self, "_pipelines", False) and getattr(self, "_actor_pipeline", False)
-                    and self._split_state() is not None and _env_int("RPO_UPDATES_INKERNEL", 1))
+                    and self._split_state() is not None)
 
     def _extra_body(self, actor_step):
         if self._updates_inkernel:
@@ -639,7 +639,7 @@ class RPOTrainerBase(object):
         # "prepared" optimiser launch behind the policy step (as for the critic's, `_critic_update_split`): pol_e advances the
         # step counters of the slices `_actor_step` will step and the update clock; the next fwd_a zeroes the actor's gradmax
         # (only when the critic update runs through the split stages too: its fwd_a is what zeroes the gradmax afterwards)
-        prep = bool(fuse_max) and bool(getattr(self, "_pipelines", False)) and bool(_env_int("RPO_PREPARED_ADAM", 1))
+        prep = bool(fuse_max) and bool(getattr(self, "_pipelines", False))
         optims = [o for o in self._policy_optims() if o is not None] if prep else []
         su.set_prep2([(o.step_dev, o.betas[0], o.betas[1]) for o in optims])
         su.set(clock_out=self._clock(True) if prep else None, updates_out=self._updates_out)
@@ -666,7 +666,7 @@ class RPOTrainerBase(object):
         the optimiser launches keep their own bookkeeping)."""
         opt = self.agent.critic_optim
         # (data-parallel runs too: the inf-norm then comes from rpo_absmax_slots behind the all-reduce, into the same slots)
-        prep = actor_step is not None and bool(_env_int("RPO_PREPARED_ADAM", 1))
+        prep = actor_step is not None
         self._critic_prepared = bool(prep)
         bump_updates, self._bump_updates_now = self._bump_updates_now, False
         self._updates_out = self._uctrl if bump_updates else None          # (pol_e does it behind a policy step)
@@ -706,8 +706,7 @@ class RPOTrainerBase(object):
             ride.set(lane_begin=0, lane_end=cut)
         # CartSafe: fwd_a, fwd_b and bwd_a are one launch (the later stages' workgroups wait inside it for the
         # workgroups of their own row tile, rpo_split_critic_front) -- same values, two launch boundaries less
-        early = bool(actor_step) and ride is None and self.agent.flat.sizes[1] == 0 and getattr(self, "_actor_pipeline", False) \
-            and bool(_env_int("RPO_POL_A_EARLY", 1))
+        early = bool(actor_step) and ride is None and self.agent.flat.sizes[1] == 0 and getattr(self, "_actor_pipeline", False)
         if su.st.env == 0 and self._after_front is None and self._front_ok():
             self._pol_a_done = early
             if ride is not None:
@@ -764,26 +763,29 @@ class RPOTrainerBase(object):
         self._raise_handover(f is not None and int(f[0]) != 0, g is not None and int(g[0]) != 0)
 
     def _poll_handover(self):
-        """The same without waiting for the device: after every graph window the two flag words are copied to pinned host
-        memory asynchronously; a copy that has landed is inspected before the next window is launched, so a lost producer
-        stops the run within about one window instead of at the next statistics harvest."""
-        f, g = self._handover_flags()
-        if f is None and g is None:
-            return
+        """The same without waiting for the device: after every FOURTH graph window the flag words are copied to pinned host
+        memory asynchronously (plain device-to-host copies, no kernel; every window cost 1.4 us per iteration in the kernel
+        trace); a copy that has landed is inspected before a later window is launched, so a lost producer stops the run
+        within a few windows instead of at the next statistics harvest."""
         st = getattr(self, "_handover_poll", None)
         if st is None:
-            st = self._handover_poll = dict(host=torch.zeros(2, dtype=torch.int64).pin_memory(), event=None,
-                                            dev=torch.zeros(2, dtype=torch.int64, device=self.device))
+            f, g = self._handover_flags()
+            st = self._handover_poll = dict(flags=[x for x in (f, g) if x is not None], event=None, calls=0)
+            st["host"] = [torch.zeros(1, dtype=x.dtype).pin_memory() for x in st["flags"]]
+            st["which"] = [x is f for x in st["flags"]]
+        if not st["flags"]:
+            return
         if st["event"] is not None:
             if not st["event"].query():
                 return                                            # the previous copy is still in flight: look again later
             st["event"] = None
-            self._raise_handover(int(st["host"][0]) != 0, int(st["host"][1]) != 0)
-        if f is not None:
-            st["dev"][0:1].copy_(f)
-        if g is not None:
-            st["dev"][1:2].copy_(g)
-        st["host"].copy_(st["dev"], non_blocking=True)
+            vals = {bool(w): int(h[0]) for w, h in zip(st["which"], st["host"])}
+            self._raise_handover(vals.get(True, 0) != 0, vals.get(False, 0) != 0)
+        st["calls"] += 1
+        if st["calls"] % 4 != 1:
+            return
+        for h, x in zip(st["host"], st["flags"]):
+            h.copy_(x, non_blocking=True)
         st["event"] = torch.cuda.Event()
         st["event"].record()
 
@@ -929,9 +931,9 @@ class RPOTrainerBase(object):
                 max_episode_steps=v.max_episode_steps, auto_reset=1, viol_thresh=v.viol_thresh, seed=self.seed,
                 env_id_base=v.env_id_base, part=self.fused.buf("ride.part", 8, v.internal.shape[0], 2))
         self._rider_cache.set(rows=buf.rows, cap_steps=buf.capacity)
-        # lanes whose actor forward rides on fwd_a; the rest ride on fwd_b (RPO_RIDE_SPLIT = share of fwd_a in percent)
+        # separate launches (no fused front): half of the lanes' actor forward rides on fwd_a, the rest on fwd_b
         n = v.internal.shape[0]
-        self._ride_cut = min(n, (n * _env_int("RPO_RIDE_SPLIT", 50) // 100 + 15) // 16 * 16)
+        self._ride_cut = min(n, (n // 2 + 15) // 16 * 16)
         return self._rider_cache
 
     def _ridden_window(self, t, L):

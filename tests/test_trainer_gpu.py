@@ -181,13 +181,8 @@ def test_multi_update_graph_in_utd_mode(hip, algo, monkeypatch):
     assert int(a.agent.critic_optim.step_dev[0]) == 6 * 23
     assert int(a.agent.actor_optim.step_dev[0]) == int(c.agent.actor_optim.step_dev[0]) >= 6 * 23 // 4 - 1
     # ctrl[RPO_CTRL_UPDATES] (the Philox sub-index of the k-th update of a vector step) is advanced by the update's own last
-    # stage; a torch launch between two updates (RPO_UPDATES_INKERNEL=0) gives the same draws
+    # stage and is back at zero when the vector step is over
     assert a._updates_inkernel and int(a._uctrl[hip.CONST["RPO_CTRL_UPDATES"]]) == 0
-    monkeypatch.setenv("RPO_UPDATES_INKERNEL", "0")
-    d = _run(algo, "cart", hip, dev, 6, 64, use_graph=True, updates_per_step=23)
-    assert not d._updates_inkernel
-    assert torch.equal(a.agent.flat.data, d.agent.flat.data) and torch.equal(a.agent.critic_target_flat, d.agent.critic_target_flat)
-    assert torch.equal(a.agent.nju.weight, d.agent.nju.weight) and torch.equal(a._uctrl, d._uctrl)
 
 
 @pytest.mark.parametrize("algo,envname", CASES)
@@ -642,70 +637,6 @@ def test_ridden_rollout_equals_serial(hip, algo, envname, monkeypatch):
     # a shared state embedding (scripts/cart_exp.py): the critic step changes the policy, nothing rides
     f = build_trainer("ddpg", "cart", hip, dev, num_envs=64, use_graph=True)
     assert f.agent.flat.sizes[1] > 0 and not f._ride_ok(True)
-
-
-@pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "pendulum")])
-def test_deferred_rollout_clock_equals_own_clock(hip, algo, envname, monkeypatch):
-    """rpo_*_rollout(defer_clock=1) leaves ctrl[RPO_CTRL_T] and the clearing of the next statistics row to the first launch
-    of the column-split update that follows (rpo_split_update.rollout_ctrl): same steps, same statistics, same parameters
-    as the rollout counting its own workgroups in."""
-    dev = torch.device("cuda")
-    monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
-    a = _run(algo, envname, hip, dev, 45, 300, use_graph=True)
-    assert a._defer_ok
-    monkeypatch.setenv("RPO_DEFER_CLOCK", "0")
-    b = _run(algo, envname, hip, dev, 45, 300, use_graph=True)
-    assert not b._defer_ok
-    assert int(a.vec.ctrl[0]) == int(b.vec.ctrl[0]) == 45 and not a._clock_pending
-    assert torch.equal(a.vec.ctrl, b.vec.ctrl)                    # arrival counters back at zero either way
-    assert torch.equal(a.vec.internal, b.vec.internal) and torch.equal(a.buffer.rows, b.buffer.rows)
-    assert torch.equal(a.agent.flat.data, b.agent.flat.data)
-    assert torch.equal(a.vec.stats, b.vec.stats)                  # incl. the cleared rows ahead of the step counter
-
-
-@pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "cart"), ("ddpg", "pendulum")])
-def test_prepared_critic_step_equals_self_advancing(hip, algo, envname, monkeypatch):
-    """The critic's rpo_adam_step(prepared=1) does no bookkeeping: bwd_b advanced its step counter, left the bias
-    corrections and (on iterations without a policy step) advanced the update clock, the next fwd_a zeroes gradmax.
-    Parameters, moments, step counters and clocks equal those of the launch that counts its workgroups in and does all of
-    that itself."""
-    dev = torch.device("cuda")
-    monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
-    a = _run(algo, envname, hip, dev, 45, 300, use_graph=True)
-    monkeypatch.setenv("RPO_PREPARED_ADAM", "0")
-    b = _run(algo, envname, hip, dev, 45, 300, use_graph=True)
-    for x, y in ((a, b),):
-        assert torch.equal(x.agent.flat.data, y.agent.flat.data) and torch.equal(x.agent.critic_target_flat, y.agent.critic_target_flat)
-        for o in ("critic_optim", "actor_optim"):
-            ox, oy = getattr(x.agent, o), getattr(y.agent, o)
-            assert torch.equal(ox.exp_avg, oy.exp_avg) and torch.equal(ox.exp_avg_sq, oy.exp_avg_sq)
-            assert int(ox.step_dev[0]) == int(oy.step_dev[0]) > 0
-            assert int(ox.step_dev[2]) == 0 and int(ox.step_dev[32:].abs().max()) == 0      # arrival counters at rest
-        assert int(x.agent.critic_optim.step_dev[0]) == 45
-        assert torch.equal(x._uctrl, y._uctrl) and torch.equal(x.vec.ctrl, y.vec.ctrl)
-        assert torch.equal(x.buffer.rows, y.buffer.rows) and torch.equal(x.vec.internal, y.vec.internal)
-    # the prepared launch leaves gradmax to the next fwd_a; the self-advancing one zeroes it itself
-    assert float(b.agent.critic_optim.gradmax.abs().max()) == 0.0 and float(a.agent.critic_optim.gradmax.max()) > 0.0
-    a.run_steps(1)
-    torch.cuda.synchronize()
-    assert int(a.agent.critic_optim.step_dev[0]) == 46
-
-
-@pytest.mark.parametrize("algo,envname", [("sac", "cart"), ("ddpg", "pendulum"), ("sac", "pendulum")])
-def test_policy_slabs_inside_the_critic_forward_launch(hip, algo, envname, monkeypatch):
-    """Policy iterations without a shared embedding: pol_a (the policy's hidden slabs on the batch states) runs as an extra
-    plane of fwd_b's launch (rpo_split_critic_fwd_b_pol, partials to part_pol) instead of behind the critic step -- it reads
-    the gathered batch and the actor, which the critic step does not touch.  Same bits as the separate launch."""
-    dev = torch.device("cuda")
-    monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
-    a = _run(algo, envname, hip, dev, 45, 300, use_graph=True)
-    assert a.agent.flat.sizes[1] == 0
-    monkeypatch.setenv("RPO_POL_A_EARLY", "0")
-    b = _run(algo, envname, hip, dev, 45, 300, use_graph=True)
-    assert torch.equal(a.agent.flat.data, b.agent.flat.data) and torch.equal(a.agent.nju.weight, b.agent.nju.weight)
-    assert torch.equal(a.agent.actor_optim.exp_avg_sq, b.agent.actor_optim.exp_avg_sq)
-    assert torch.equal(a.buffer.rows, b.buffer.rows) and torch.equal(a.vec.internal, b.vec.internal)
-    assert float(a.last_losses["actor"]) == float(b.last_losses["actor"])
 
 
 @pytest.mark.parametrize("algo,envname,shared,ride", [
