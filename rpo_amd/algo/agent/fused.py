@@ -102,6 +102,13 @@ class FusedNets(object):
                                                 1, cat)))
         return out
 
+    def enable_splitk(self, flat_floats, slices=64):
+        """Large update batches (>= RPO_SPLITK_FROM rows): give every trainable network a scratch buffer for the split-K
+        weights pass of the backward kernels (`slices` copies of at most the whole flat gradient buffer each)."""
+        for name, d in self.descs.items():
+            if "target" not in name and d.splitk is None:
+                d.splitk = torch.zeros(int(slices) * int(flat_floats), device=self.device)
+
     # ------------------------------------------------------------------------------------------ execution
     def buf(self, key, *shape):
         k = (key,) + shape

@@ -218,6 +218,10 @@ class RPOTrainerBase(object):
         # hand-written f32-MFMA MLP kernels for actor / critics (RPO_FUSED_MLP=0: the torch modules + autograd)
         want_fused = bool(_env_int("RPO_FUSED_MLP", 1)) if fused is None else bool(fused)
         self.fused = FusedNets.build(agent, self.backend, device) if want_fused else None
+        if self.fused is not None and self.batch_size >= hip_ops.CONST.get("RPO_SPLITK_FROM", 1 << 30) and device.type == "cuda":
+            # one LARGE batch per update (batch 256 * N): the parameter-gradient reductions of the backward
+            # kernels split the batch over the chip (rpo_mlp_grad.splitk_scratch)
+            self.fused.enable_splitk(agent.flat.grad.numel())
         # updates per vector step: 1 = the reference's loop cadence (rpo_ddpg.py:160-161); num_envs = "UTD-matched":
         # as many batch-`batch_size` updates per env step as the reference performs (metric iii)
         self.updates_per_step = max(1, int(updates_per_step) if updates_per_step is not None

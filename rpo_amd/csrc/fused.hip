@@ -1079,6 +1079,10 @@ int rpo_ddpg_actor_backward(int env, const rpo_mlp* actor_host, const rpo_mlp_gr
     RPO_LAUNCH_CHECK();
     const int fl_outputs = actor.E * (actor.S + 1);
     const int grid_w = (actor.H / 16) * (128 / 64) + actor.H / 64 + mlp_fl_blocks(fl_outputs);
+    {
+        const SplitK sk = splitk_plan(p.actor, actor_grad_host->splitk_scratch, actor_grad_host->splitk_floats);
+        if (sk.Z > 0) return launch_weights_splitk<128, 256>(p.actor, sk, grid_w, (hipStream_t)stream);     // large batches
+    }
     hipLaunchKernelGGL((actor_weights_kernel<128, 256>), dim3(grid_w), dim3(kThreads), 0, (hipStream_t)stream, p.actor);
     RPO_LAUNCH_CHECK();
     return 0;
@@ -1176,6 +1180,10 @@ int rpo_sac_actor_backward(int env, const rpo_mlp* actor_host, const rpo_mlp_gra
     RPO_LAUNCH_CHECK();
     const int fl_outputs = actor.E * (actor.S + 1);
     const int grid_w = (actor.H / 16) * (128 / 64) + actor.H / 64 + mlp_fl_blocks(fl_outputs);
+    {
+        const SplitK sk = splitk_plan(p.actor, actor_grad_host->splitk_scratch, actor_grad_host->splitk_floats);
+        if (sk.Z > 0) return launch_weights_splitk<128, 256>(p.actor, sk, grid_w, (hipStream_t)stream);     // large batches
+    }
     hipLaunchKernelGGL((actor_weights_kernel<128, 256>), dim3(grid_w), dim3(kThreads), 0, (hipStream_t)stream, p.actor);
     RPO_LAUNCH_CHECK();
     return 0;

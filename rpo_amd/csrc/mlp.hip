@@ -328,6 +328,8 @@ int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int
                            args);                                                                                   \
         RPO_LAUNCH_CHECK();                                                                                         \
         if (param_grads) {                                                                                          \
+            const SplitK sk = splitk_plan(args, grad_host->splitk_scratch, grad_host->splitk_floats);                 \
+            if (sk.Z > 0) return launch_weights_splitk<EIN_, H_>(args, sk, grid_w, (hipStream_t)stream);            \
             hipLaunchKernelGGL((mlp_bwd_weights_kernel<EIN_, H_>), dim3(grid_w), dim3(kThreads), 0,                 \
                                (hipStream_t)stream, args);                                                          \
             RPO_LAUNCH_CHECK();                                                                                     \
@@ -366,6 +368,13 @@ int rpo_mlp_backward_pair(const rpo_mlp* net1_host, const rpo_mlp_grad* grad1_ho
                            args);                                                                                      \
         RPO_LAUNCH_CHECK();                                                                                            \
         if (param_grads) {                                                                                             \
+            /* large batches: one split-K weights pass per network (each half of the scratch buffer... its own) */     \
+            const SplitK k1 = splitk_plan(args.net[0], grad1_host->splitk_scratch, grad1_host->splitk_floats);         \
+            const SplitK k2 = splitk_plan(args.net[1], grad2_host->splitk_scratch, grad2_host->splitk_floats);         \
+            if (k1.Z > 0 && k2.Z > 0 && grad1_host->splitk_scratch != grad2_host->splitk_scratch) {                    \
+                if (int e = launch_weights_splitk<EIN_, H_>(args.net[0], k1, grid_w, (hipStream_t)stream)) return e;   \
+                return launch_weights_splitk<EIN_, H_>(args.net[1], k2, grid_w, (hipStream_t)stream);                  \
+            }                                                                                                          \
             hipLaunchKernelGGL((mlp_bwd_weights_kernel2<EIN_, H_>), dim3(grid_w, 2), dim3(kThreads), 0,                \
                                (hipStream_t)stream, args);                                                             \
             RPO_LAUNCH_CHECK();                                                                                        \

@@ -495,4 +495,98 @@ __device__ __forceinline__ void gradmax_flush(float* gradmax, float v) {
         if (m > 0.0f) rpo_atomic_max_nonneg(gradmax + (b % RPO_GRADMAX_SLOTS) * (RPO_GRADMAX_LEN / RPO_GRADMAX_SLOTS), m);
     }
 }
+// ------------------------------------------------------------------------------------ weights pass for LARGE batches
+// mlp_bwd_weights_body gives every output element ONE owner that walks the whole batch: ~50 workgroups, fine at batch 256
+// (latency-bound anyway) and 36 ms at 2^20 rows.  Split-K form: grid (the same blocks, Z batch slices); slice z runs the same
+// body on rows [n z / Z, n (z + 1) / Z) (multiples of 4) and accumulates into ITS copy of the network's gradient span inside a
+// zeroed scratch buffer; splitk_reduce adds the Z copies in order onto the gradient and takes the inf-norm of what it wrote.
+// One owner per element in both launches, fixed orders: bitwise reproducible (not bitwise the Z = 1 result: other association).
+struct SplitK {
+    float* scratch;        // [Z][span]
+    float* lo;             // lowest address of the network's gradient tensors (the span starts here)
+    long long span;        // floats from `lo` to the end of the highest tensor
+    int Z;
+};
+
+template <int EIN, int H>
+__global__ __launch_bounds__(kThreads) void mlp_bwd_weights_splitk_kernel(BwdArgs p, SplitK k) {
+    const int z = blockIdx.y;
+    const long long r0 = (((long long)p.n * z) / k.Z) & ~3LL;
+    const long long r1 = z + 1 == k.Z ? (long long)p.n : ((((long long)p.n * (z + 1)) / k.Z) & ~3LL);
+    if (r1 <= r0) return;
+    BwdArgs q = p;
+    q.n = (int)(r1 - r0);
+    q.s += r0 * p.s_stride;
+    if (q.a) q.a += r0 * p.a_stride;
+    q.x0 += r0 * EIN; q.h1 += r0 * H; q.dh += r0 * H; q.dx0 += r0 * EIN;
+    q.dout += r0 * (p.net.hd > 1 ? p.net.n_out * p.net.hd : p.net.n_out);
+    q.gradmax = nullptr;
+    float* base = k.scratch + (long long)z * k.span;
+#define RPO_SK(F) q.g.F = p.g.F ? base + (p.g.F - k.lo) : nullptr
+    RPO_SK(Ws); RPO_SK(bs); RPO_SK(Wa); RPO_SK(ba); RPO_SK(W0); RPO_SK(b0); RPO_SK(W1); RPO_SK(b1); RPO_SK(W1b); RPO_SK(b1b);
+#undef RPO_SK
+    mlp_bwd_weights_body<EIN, H>(q);
+}
+
+template <int DUMMY>
+__global__ __launch_bounds__(RPO_BLOCK) void splitk_reduce_kernel(SplitK k, float* gradmax) {
+    __shared__ float red[RPO_BLOCK / RPO_WAVE];
+    float gmax = 0.0f;
+    for (long long i = (long long)blockIdx.x * RPO_BLOCK + threadIdx.x; i < k.span; i += (long long)gridDim.x * RPO_BLOCK) {
+        float s = k.scratch[i];
+        for (int z = 1; z < k.Z; ++z) s += k.scratch[(long long)z * k.span + i];    // slices in order
+        if (s != 0.0f) {                                         // (positions inside the span that belong to other tensors stay 0)
+            const float nv = k.lo[i] + s;
+            k.lo[i] = nv;
+            gmax = fmaxf(gmax, fabsf(nv));
+        }
+    }
+    if (gradmax == nullptr) return;
+    gmax = rpo_wave_max_nonneg(gmax);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = red[0];
+        for (int w = 1; w < RPO_BLOCK / RPO_WAVE; ++w) m = fmaxf(m, red[w]);
+        if (m > 0.0f) rpo_atomic_max_nonneg(gradmax + (blockIdx.x % RPO_GRADMAX_SLOTS) * (RPO_GRADMAX_LEN / RPO_GRADMAX_SLOTS), m);
+    }
+}
+
+// Host side: the split-K plan for `args` (Z = 0: not applicable -- small batch, no scratch, or scratch too small)
+static inline SplitK splitk_plan(const BwdArgs& a, float* scratch, long long scratch_floats) {
+    SplitK k{nullptr, nullptr, 0, 0};
+    if (!scratch || a.n < RPO_SPLITK_FROM || !a.param_grads) return k;
+    const Mlp& net = a.net;
+    const long long ein = net.cat ? 2 * net.E : net.E, heads = net.hd > 1 ? net.hd : 1;
+    const float* ptr[10] = {a.g.Ws, a.g.bs, a.g.Wa, a.g.ba, a.g.W0, a.g.b0, a.g.W1, a.g.b1, a.g.W1b, a.g.b1b};
+    const long long len[10] = {(long long)net.E * net.S, net.E, (long long)net.E * net.A, net.E, (long long)net.H * ein, net.H,
+                               heads * net.H, heads, heads * net.H, heads};
+    const float *lo = nullptr, *hi = nullptr;
+    for (int i = 0; i < 10; ++i) {
+        if (!ptr[i] || len[i] == 0) continue;
+        if (!lo || ptr[i] < lo) lo = ptr[i];
+        if (!hi || ptr[i] + len[i] > hi) hi = ptr[i] + len[i];
+    }
+    if (!lo) return k;
+    const long long span = hi - lo;
+    long long Z = a.n / 8192;
+    if (Z > 64) Z = 64;
+    if (Z * span > scratch_floats) Z = scratch_floats / span;
+    if (Z < 2) return k;
+    k.scratch = scratch; k.lo = const_cast<float*>(lo); k.span = span; k.Z = (int)Z;
+    return k;
+}
+
+template <int EIN, int H>
+static inline int launch_weights_splitk(const BwdArgs& args, const SplitK& k, int grid_w, hipStream_t stream) {
+    if (hipMemsetAsync(k.scratch, 0, (size_t)k.Z * (size_t)k.span * sizeof(float), stream) != hipSuccess) return RPO_ERR_ARG;
+    hipLaunchKernelGGL((mlp_bwd_weights_splitk_kernel<EIN, H>), dim3(grid_w, k.Z), dim3(kThreads), 0, stream, args, k);
+    RPO_LAUNCH_CHECK();
+    long long blocks = (k.span + RPO_BLOCK - 1) / RPO_BLOCK;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3((unsigned)blocks), dim3(RPO_BLOCK), 0, stream, k, args.gradmax);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace rpo_mlp_dev

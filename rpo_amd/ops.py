@@ -495,7 +495,8 @@ class _MlpStruct(ctypes.Structure):
 
 
 class _MlpGradStruct(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in ("Ws", "bs", "Wa", "ba", "W0", "b0", "W1", "b1", "W1b", "b1b")]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("Ws", "bs", "Wa", "ba", "W0", "b0", "W1", "b1", "W1b", "b1b")] + \
+               [("splitk_scratch", ctypes.c_void_p), ("splitk_floats", ctypes.c_longlong)]
 
 
 class _TdStruct(ctypes.Structure):
@@ -552,8 +553,14 @@ class MlpDesc(object):
         return _MlpStruct(*[self._ptr(self.tensors[k]) for k in self.FIELDS], self.S, self.A, self.E, self.H, self.n_out,
                           self.cat, self.head_dim)
 
+    #: scratch of the split-K weights pass (large batches, include/rpo_hip.h rpo_mlp_grad): a float32 tensor or None
+    splitk = None
+
     def grad_struct(self):
-        return _MlpGradStruct(*[None if self.tensors[k] is None else self._ptr(self.tensors[k].grad) for k in self.FIELDS])
+        st = _MlpGradStruct(*[None if self.tensors[k] is None else self._ptr(self.tensors[k].grad) for k in self.FIELDS])
+        if self.splitk is not None:
+            st.splitk_scratch, st.splitk_floats = _p(self.splitk).value, int(self.splitk.numel())
+        return st
 
 
 def mlp_forward(desc, s, a, out, x0_save=None, h1_save=None, out_mode=0, scale=1.0, base=0.0):
