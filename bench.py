@@ -736,6 +736,34 @@ def main():
             result["utd_matched_updates_per_s"] = EPG * 4 / dt
             result["utd_matched_us_per_update"] = dt / (EPG * 4) * 1e6
             del utd
+            if headline:
+                # (iii') the same number of sampled transitions per env step as ONE large batch per vector step (SURVEY 8d-iii:
+                # "batch 256 * N per vector step"): batch 256 * 4096 = 2^20 through the generic MLP kernels (64-row tiles,
+                # split-K weights pass) -- one optimiser step per vector step instead of 4096 sequential ones, so it is an
+                # EXTRA mode with other learning dynamics, not a replacement of the exact-cadence default
+                torch.cuda.empty_cache()
+                lb = make_trainer(EPG, device, 10 ** 9, capacity=64, workload=args.workload, batch_size=256 * EPG)
+                lb.vec.reset()
+                lb.run_steps(5 * max(lb._cycle, 4))
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                lb.run_steps(2 * max(lb._cycle, 4))
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t3) / (2 * max(lb._cycle, 4))
+                result["large_batch"] = {
+                    "update_batch": 256 * EPG, "ms_per_step": dt * 1e3, "env_steps_per_s": EPG / dt,
+                    "sampled_transitions_per_s": 256 * EPG / dt,
+                    "over_utd_matched": (EPG / dt) / result["utd_matched_env_steps_per_s"],
+                    "note": "one batch-%d update per vector step: 256 sampled transitions per env step like the reference, one "
+                            "optimiser step per vector step (not %d)" % (256 * EPG, EPG)}
+                if not args.no_clinic:
+                    log("kernel clinic of the large-batch update:")
+                    cl = kernel_clinic(lb, args.workload)
+                    result["large_batch"]["kernels"] = {
+                        k: {kk: vv for kk, vv in v.items() if kk in ("us", "rate", "unit", "frac", "bound", "n", "launches_per_period")}
+                        for k, v in cl.items() if "@1M" not in k and v.get("n", 0) == 256 * EPG}
+                del lb
+                torch.cuda.empty_cache()
         if not args.no_clinic:
             if tr is None:
                 tr = prepared_trainer(n_total, device, args.workload)
@@ -744,6 +772,9 @@ def main():
                 result["roofline"] = roofline(kernel_clinic(tr, args.workload), args.workload)
         if cpu is not None:
             result["cpu_baseline"] = cpu
+            if "large_batch" in result:
+                result["large_batch"]["over_cpu"] = result["large_batch"]["env_steps_per_s"] / cpu["value"]
+                result["large_batch"]["over_cpu_single_core"] = result["large_batch"]["env_steps_per_s"] / cpu["single_core_value"]
             result["gpu_over_cpu"] = value / cpu["value"]
             result["gpu_over_cpu_single_core"] = value / cpu["single_core_value"]
             if "utd_matched_env_steps_per_s" in result:

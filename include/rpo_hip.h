@@ -380,7 +380,7 @@ typedef struct {
 typedef struct {
     float *Ws, *bs, *Wa, *ba, *W0, *b0, *W1, *b1, *W1b, *b1b;
     /* Large batches (n >= RPO_SPLITK_FROM rows): NULL, or a scratch buffer of splitk_floats floats.  The weights pass of the
-     * backward kernels then splits the batch over up to 64 slices -- every slice accumulates its share of every parameter
+     * backward kernels then splits the batch over up to 256 slices -- every slice accumulates its share of every parameter
      * gradient into its own copy of the network's gradient span inside this buffer (one owner per element, fixed order) and a
      * second launch adds the slices in order: the batch reductions use the width of the chip instead of ~50 workgroups
      * (36 ms -> ~2 ms at 2^20 rows), still bitwise reproducible.  Needs >= 2 x (the span of the gradient tensors, in floats). */

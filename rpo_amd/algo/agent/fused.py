@@ -102,7 +102,7 @@ class FusedNets(object):
                                                 1, cat)))
         return out
 
-    def enable_splitk(self, flat_floats, slices=64):
+    def enable_splitk(self, flat_floats, slices=256):
         """Large update batches (>= RPO_SPLITK_FROM rows): give every trainable network a scratch buffer for the split-K
         weights pass of the backward kernels (`slices` copies of at most the whole flat gradient buffer each)."""
         for name, d in self.descs.items():

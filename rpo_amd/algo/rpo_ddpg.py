@@ -101,7 +101,7 @@ class RPODDPG(RPOTrainerBase):
         k = self.kernels
         return (self.fused is not None and (hasattr(k, "ddpg_critic_forward") or hasattr(k, "ddpg_critic_front"))
                 and "actor_target" in self.fused.descs and "critic" in self.fused.descs
-                and _env_int("RPO_FUSED_CRITIC", 1))
+                and _env_int("RPO_FUSED_CRITIC", 1) and not self._large_batch)
 
     def _sample(self):
         if self._pipelines:
@@ -169,7 +169,7 @@ class RPODDPG(RPOTrainerBase):
         return (hasattr(self.backend, "ddpg_actor_forward") and "actor" in d and "critic" in d and d["actor"].E == 128
                 and d["critic"].E == 128 and not d["critic"].cat and self._box_affine is not None
                 and self.kernels.partial_dim == 1 and self.kernels.action_dim == 2
-                and _env_int("RPO_FUSED_ACTOR", 1))
+                and _env_int("RPO_FUSED_ACTOR", 1) and not self._large_batch)
 
     def _actor_update_pipeline(self, cols):
         """The policy step in two launches + the actor's weights pass (fused.hip)."""

@@ -99,7 +99,7 @@ class RPOSAC(RPOTrainerBase):
     def _pipelines(self):
         k = self.kernels
         return (self.fused is not None and (hasattr(k, "sac_critic_forward") or hasattr(k, "sac_critic_front"))
-                and "critic1" in self.fused.descs and "actor" in self.fused.descs and _env_int("RPO_FUSED_CRITIC", 1))
+                and "critic1" in self.fused.descs and "actor" in self.fused.descs and _env_int("RPO_FUSED_CRITIC", 1) and not self._large_batch)
 
     def _sample(self):
         if self._pipelines:
@@ -174,7 +174,8 @@ class RPOSAC(RPOTrainerBase):
         d = self.fused.descs if self.fused is not None else {}
         return (hasattr(self.backend, "sac_actor_forward") and "actor" in d and "critic1" in d and d["actor"].E == 128
                 and d["critic1"].E == 128 and not d["critic1"].cat and self._box_affine is not None
-                and self.kernels.partial_dim == 1 and self.kernels.action_dim == 2 and _env_int("RPO_FUSED_ACTOR", 1))
+                and self.kernels.partial_dim == 1 and self.kernels.action_dim == 2 and _env_int("RPO_FUSED_ACTOR", 1)
+                and not self._large_batch)
 
     def _actor_update_pipeline(self, cols):
         """The policy step in two launches + the actor's weights pass (fused.hip)."""

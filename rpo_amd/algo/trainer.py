@@ -215,6 +215,10 @@ class RPOTrainerBase(object):
         # projection of training batches: the reference's literal batched semantics (default) or row-wise
         # (RPO_ROWWISE_PROJECTION=1); rollouts are always per lane == the reference's B = 1 calls
         self.batch_reference = not bool(_env_int("RPO_ROWWISE_PROJECTION", 0))
+        if self.batch_size > 1024:
+            # the reference's batched projection couples every sample of a SpringPendulum batch with every other (n^2 terms
+            # per GRG iteration): defined up to 1024 rows here; larger batches are projected row by row
+            self.batch_reference = False
         # hand-written f32-MFMA MLP kernels for actor / critics (RPO_FUSED_MLP=0: the torch modules + autograd)
         want_fused = bool(_env_int("RPO_FUSED_MLP", 1)) if fused is None else bool(fused)
         self.fused = FusedNets.build(agent, self.backend, device) if want_fused else None
@@ -290,6 +294,14 @@ class RPOTrainerBase(object):
 
     #: RPOSAC samples the squashed Gaussian inside the rollout pipeline; RPODDPG adds exploration noise to the actor
     _gauss_policy = False
+
+    @property
+    def _large_batch(self):
+        """One LARGE batch per update (batch_size >= RPO_SPLITK_FROM, e.g. 256 * num_envs: as many sampled transitions per
+        env step as the reference consumes): the update runs through the generic MLP kernels -- 64-row tiles
+        in the forward (0.48 of the f32 MFMA peak at 2^20 rows), split-K weights pass in the backward -- instead of the
+        batch-256 pipelines, whose 16-row tiles each stream the whole weight matrix."""
+        return self.batch_size >= hip_ops.CONST.get("RPO_SPLITK_FROM", 1 << 30)
 
     @property
     def _rollout_pipeline(self):

@@ -253,16 +253,17 @@ __device__ __forceinline__ float mlp_bwd_first_layer(const BwdArgs& p, int fl_bl
 // workgroup accumulates the first-layer gradients dWs / dbs / dWa / dba from dx0, and the last one db0 / dW1 / db1.
 // Every output element has exactly one owner and a fixed summation order: the backward pass is bitwise reproducible.
 template <int EIN, int H>
-__device__ __forceinline__ float mlp_bwd_weights_body(const BwdArgs& p) {
+__device__ __forceinline__ float mlp_bwd_weights_body(const BwdArgs& p, int vblock = -1) {
     float gmax = 0.0f;                                          // largest |gradient element| this thread wrote
     const Mlp& net = p.net;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bx = vblock < 0 ? (int)blockIdx.x : vblock;        // (the split-K launch numbers its blocks differently)
     constexpr int GEMM_BLOCKS = (H / 16) * (EIN / 64);           // one 16 x 64 tile of dW0 per workgroup
-    if ((int)blockIdx.x < GEMM_BLOCKS) {
+    if (bx < GEMM_BLOCKS) {
         if (!p.param_grads || p.first_layer_state_only) return gmax;
         // the 4 waves split the batch (K) and combine through LDS in a fixed order
         __shared__ __attribute__((aligned(16))) float tile[4][16 * 64];
-        const int jt = blockIdx.x / (EIN / 64), et = blockIdx.x - jt * (EIN / 64);
+        const int jt = bx / (EIN / 64), et = bx - jt * (EIN / 64);
         const int li = lane & 15, lg = lane >> 4;
         const int j = jt * 16 + li, e0 = et * 64 + li * 4;
         f32x4 acc[4];
@@ -331,7 +332,7 @@ __device__ __forceinline__ float mlp_bwd_weights_body(const BwdArgs& p) {
     __shared__ float partial[4][3][64];
     const int o = tid & 63, part = tid >> 6;
     const int b_lo = (int)(((long long)p.n * part) / 4), b_hi = (int)(((long long)p.n * (part + 1)) / 4);
-    const int rb = (int)blockIdx.x - GEMM_BLOCKS;
+    const int rb = bx - GEMM_BLOCKS;
     constexpr int HV_BLOCKS = H / 64;
     const int hv_blocks = net.hd > 1 ? H / 16 : HV_BLOCKS;
     if (rb < hv_blocks && net.hd > 1) {
@@ -508,6 +509,112 @@ struct SplitK {
     int Z;
 };
 
+// dW0 tile of 64 hidden rows x 64 input columns over the slice's rows: wave w owns hidden rows [16 w, 16 w + 16) for the WHOLE
+// slice (the batch is already split by the grid), so the four waves read the same x0 values (one L1 line each) and a slice's x0
+// is fetched by 4 workgroups instead of 16.  One owner per element, k-steps in order.
+template <int EIN, int H>
+__device__ __forceinline__ void splitk_dw0_tile64(const BwdArgs& p, int blk) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int jt = blk / (EIN / 64), et = blk - jt * (EIN / 64);
+    const int j = jt * 64 + wave * 16 + li, e0 = et * 64 + li * 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int nk = (p.n + 3) / 4, last = p.n - 1;
+    int ks = 0;
+    for (; ks + 16 <= nk; ks += 16) {                            // 16 k-steps of loads in flight before their MFMAs
+        float av[16];
+        float4 bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int b = (ks + u) * 4 + lg, bc = b < last ? b : last;
+            av[u] = p.dh[(size_t)bc * H + j];
+            bv[u] = *reinterpret_cast<const float4*>(&p.x0[(size_t)bc * EIN + e0]);
+            if (b > last) av[u] = 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            acc[0] = mfma4(av[u], fmaxf(bv[u].x, 0.0f), acc[0]);
+            acc[1] = mfma4(av[u], fmaxf(bv[u].y, 0.0f), acc[1]);
+            acc[2] = mfma4(av[u], fmaxf(bv[u].z, 0.0f), acc[2]);
+            acc[3] = mfma4(av[u], fmaxf(bv[u].w, 0.0f), acc[3]);
+        }
+    }
+    for (; ks < nk; ++ks) {
+        const int b = ks * 4 + lg, bc = b < last ? b : last;
+        float av = p.dh[(size_t)bc * H + j];
+        const float4 b4 = *reinterpret_cast<const float4*>(&p.x0[(size_t)bc * EIN + e0]);
+        if (b > last) av = 0.0f;
+        acc[0] = mfma4(av, fmaxf(b4.x, 0.0f), acc[0]);
+        acc[1] = mfma4(av, fmaxf(b4.y, 0.0f), acc[1]);
+        acc[2] = mfma4(av, fmaxf(b4.z, 0.0f), acc[2]);
+        acc[3] = mfma4(av, fmaxf(b4.w, 0.0f), acc[3]);
+    }
+    // acc[c][i] = dW0[j = 64 jt + 16 wave + 4 lg + i][e = 64 et + 4 li + c] of this slice
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float4* dst = reinterpret_cast<float4*>(&p.g.W0[(size_t)(jt * 64 + wave * 16 + lg * 4 + i) * EIN + e0]);
+        float4 cur = *dst;
+        cur.x += acc[0][i]; cur.y += acc[1][i]; cur.z += acc[2][i]; cur.w += acc[3][i];
+        *dst = cur;
+    }
+}
+
+// First-layer gradients of the slice: a workgroup owns 16 columns e of x0 and EVERY input of them (state inputs + bias, action
+// inputs + bias: up to 16 + 16 outputs per column), so the slice's dx0 is read once instead of once per input.  Thread = (column
+// e, 16 row phases); the 16 phase sums are added in order.  Scalar-input networks only (S + 1, A + 1 <= 16).
+template <int EIN>
+__device__ __forceinline__ void splitk_first_layer_cols(const BwdArgs& p, int eb, bool action_half) {
+    __shared__ float part[16][16][17];
+    const Mlp& net = p.net;
+    const int tid = threadIdx.x, ec = tid & 15, ph = tid >> 4;
+    const int width = action_half ? net.A : net.S, e = eb * 16 + ec;
+    const int col = (action_half && net.cat) ? net.E + e : e;
+    const float* in = action_half ? p.a : p.s;
+    const int stride = action_half ? p.a_stride : p.s_stride;
+    float acc[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) acc[i] = 0.0f;
+    constexpr int U = 8;                                          // rows of loads in flight per thread
+    int b = ph;
+    for (; b + 16 * (U - 1) < p.n; b += 16 * U) {
+        float d[U], x[U][16];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            d[u] = p.dx0[(size_t)(b + 16 * u) * EIN + col];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[u][i] = i < width ? in[(size_t)(b + 16 * u) * stride + i] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                             // (rows in order: the same chain as one row at a time)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i < width) acc[i] = fmaf(d[u], x[u][i], acc[i]);
+            acc[16] += d[u];                                      // the bias
+        }
+    }
+    for (; b < p.n; b += 16) {
+        const float d = p.dx0[(size_t)b * EIN + col];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < width) acc[i] = fmaf(d, in[(size_t)b * stride + i], acc[i]);
+        acc[16] += d;
+    }
+#pragma unroll
+    for (int i = 0; i < 17; ++i) part[ph][ec][i] = acc[i];
+    __syncthreads();
+    for (int idx = tid; idx < 16 * (width + 1); idx += kThreads) {
+        const int c2 = idx / (width + 1), i = idx - c2 * (width + 1), src = i < width ? i : 16;
+        float tot = part[0][c2][src];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) tot += part[q][c2][src];
+        const int e2 = eb * 16 + c2;
+        float* dst = i < width ? (action_half ? &p.g.Wa[e2 * net.A + i] : &p.g.Ws[e2 * net.S + i])
+                               : (action_half ? &p.g.ba[e2] : &p.g.bs[e2]);
+        *dst += tot;
+    }
+}
+
 template <int EIN, int H>
 __global__ __launch_bounds__(kThreads) void mlp_bwd_weights_splitk_kernel(BwdArgs p, SplitK k) {
     const int z = blockIdx.y;
@@ -525,7 +632,21 @@ __global__ __launch_bounds__(kThreads) void mlp_bwd_weights_splitk_kernel(BwdArg
 #define RPO_SK(F) q.g.F = p.g.F ? base + (p.g.F - k.lo) : nullptr
     RPO_SK(Ws); RPO_SK(bs); RPO_SK(Wa); RPO_SK(ba); RPO_SK(W0); RPO_SK(b0); RPO_SK(W1); RPO_SK(b1); RPO_SK(W1b); RPO_SK(b1b);
 #undef RPO_SK
-    mlp_bwd_weights_body<EIN, H>(q);
+    // blocks: [0, G64) dW0 tiles of 64 x 64 | [G64, G64 + HV) hidden-layer vectors (the body's blocks) | first layer
+    constexpr int G64 = (H / 64) * (EIN / 64), G16 = (H / 16) * (EIN / 64);
+    const int hv = p.net.hd > 1 ? H / 16 : H / 64, bx = blockIdx.x;
+    const bool narrow = p.net.S + 1 <= 16 && p.net.A + 1 <= 16 && p.net.hd <= 1;
+    if (bx < G64) {
+        if (p.param_grads && !p.first_layer_state_only) splitk_dw0_tile64<EIN, H>(q, bx);
+        return;
+    }
+    if (bx < G64 + hv || !narrow) {                              // (wide first layers keep the body's output-owned blocks)
+        mlp_bwd_weights_body<EIN, H>(q, bx - G64 + G16);
+        return;
+    }
+    const int fb = bx - G64 - hv, eblocks = p.net.E / 16;
+    if (fb < eblocks) splitk_first_layer_cols<EIN>(q, fb, false);
+    else if (fb < 2 * eblocks && p.net.A > 0 && !p.first_layer_state_only) splitk_first_layer_cols<EIN>(q, fb - eblocks, true);
 }
 
 template <int DUMMY>
@@ -569,8 +690,8 @@ static inline SplitK splitk_plan(const BwdArgs& a, float* scratch, long long scr
     }
     if (!lo) return k;
     const long long span = hi - lo;
-    long long Z = a.n / 8192;
-    if (Z > 64) Z = 64;
+    long long Z = a.n / 4096;                                    // (per thread of the hidden-vector blocks: 1024 rows)
+    if (Z > 256) Z = 256;
     if (Z * span > scratch_floats) Z = scratch_floats / span;
     if (Z < 2) return k;
     k.scratch = scratch; k.lo = const_cast<float*>(lo); k.span = span; k.Z = (int)Z;
@@ -580,6 +701,12 @@ static inline SplitK splitk_plan(const BwdArgs& a, float* scratch, long long scr
 template <int EIN, int H>
 static inline int launch_weights_splitk(const BwdArgs& args, const SplitK& k, int grid_w, hipStream_t stream) {
     if (hipMemsetAsync(k.scratch, 0, (size_t)k.Z * (size_t)k.span * sizeof(float), stream) != hipSuccess) return RPO_ERR_ARG;
+    // (grid_w counts the plain pass's blocks: its (H / 16) (EIN / 64) dW0 tiles become (H / 64) (EIN / 64); a narrow first
+    // layer becomes E / 16 column blocks per input half)
+    const Mlp& net = args.net;
+    const int g16 = (H / 16) * (EIN / 64), g64 = (H / 64) * (EIN / 64), hv = net.hd > 1 ? H / 16 : H / 64;
+    const bool narrow = net.S + 1 <= 16 && net.A + 1 <= 16 && net.hd <= 1;
+    grid_w = narrow ? g64 + hv + (net.E / 16) * (net.A > 0 ? 2 : 1) : grid_w - g16 + g64;
     hipLaunchKernelGGL((mlp_bwd_weights_splitk_kernel<EIN, H>), dim3(grid_w, k.Z), dim3(kThreads), 0, stream, args, k);
     RPO_LAUNCH_CHECK();
     long long blocks = (k.span + RPO_BLOCK - 1) / RPO_BLOCK;

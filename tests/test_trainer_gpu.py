@@ -713,3 +713,31 @@ def test_fused_front_with_other_batch_sizes(hip, algo, envname, batch, monkeypat
     assert torch.equal(a.agent.critic_target_flat, b.agent.critic_target_flat)
     assert torch.equal(a.buffer.rows, b.buffer.rows) and torch.equal(a.vec.internal, b.vec.internal)
     assert int(b._split_state()._held["tile_sync"].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "cart"), ("sac", "pendulum")])
+def test_large_batch_update_mode(hip, algo, envname):
+    """batch_size >= RPO_SPLITK_FROM (one batch of 256 * N per vector step): the update runs through the generic
+    MLP kernels with the split-K weights pass; SpringPendulum batches beyond 1024 rows are projected row by row.  hipGraph
+    windows == eager launches bit for bit (every reduction has a fixed order), parameters move and stay finite, and the
+    first critic update equals the same update through the plain one-owner weights pass to summation round-off."""
+    dev = torch.device("cuda")
+    B = hip.CONST["RPO_SPLITK_FROM"]
+    a = _run(algo, envname, hip, dev, 24, 512, use_graph=True, batch_size=B, capacity=64)
+    b = _run(algo, envname, hip, dev, 24, 512, use_graph=False, batch_size=B, capacity=64)
+    assert a._large_batch and not a._pipelines and not a._actor_pipeline and a._split_state() is None
+    assert all(d.splitk is not None for n, d in a.fused.descs.items() if "target" not in n)
+    assert envname != "pendulum" or not a.batch_reference
+    assert torch.equal(a.agent.flat.data, b.agent.flat.data) and torch.equal(a.buffer.rows, b.buffer.rows)
+    assert torch.equal(a.agent.critic_target_flat, b.agent.critic_target_flat) and torch.equal(a.agent.nju.weight, b.agent.nju.weight)
+    assert bool(torch.isfinite(a.agent.flat.data).all()) and int(a.agent.critic_optim.step_dev[0]) == 24
+    # one update with / without the scratch buffers (same sampled batch: same seed, same clock)
+    c = _run(algo, envname, hip, dev, 1, 512, use_graph=False, batch_size=B, capacity=64)
+    torch.manual_seed(5)
+    d = build_trainer(algo, envname, hip, dev, num_envs=512, use_graph=False, batch_size=B, capacity=64)
+    for desc in d.fused.descs.values():
+        desc.splitk = None
+    d.vec.reset()
+    d.run_steps(1)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(c.agent.flat.data.cpu().numpy(), d.agent.flat.data.cpu().numpy(), rtol=0, atol=2e-6)
