@@ -1,7 +1,7 @@
 """Statistical parity with the reference's CPU runs (north_star: returns and constraint-violation rate).
 
 tests/golden/training_stats_*.npz hold the statistics of 3000-iteration training runs of the unmodified reference
-(scripts/cart_exp.py: 384 seeds; scripts/pen_exp_sac.py: 24 seeds; scripts/cart_exp_sac.py: 96 seeds; scripts/pen_exp.py: 48 seeds;
+(scripts/cart_exp.py: 384 seeds; scripts/pen_exp_sac.py: 24 seeds; scripts/cart_exp_sac.py: 96 seeds; scripts/pen_exp.py: 576 seeds;
 tests/golden/make_golden.py stats).  The same runs are
 repeated here with the shipped trainers at num_envs = 1 -- the reference's cadence, step for step -- on the HIP kernels,
 on TWICE as many seeds (GPU runs are cheap).  Random streams differ (Philox vs numpy/torch global generators) and
@@ -13,7 +13,9 @@ difference of the two means is ~4e-4 with 96 + 192 seeds: the north_star's 1e-3 
 (a) that resolution (SE of the difference <= 5e-4) and (b) |rate_gpu - rate_ref| <= 1e-3 + 2 SE, i.e. that a difference
 of 1e-3 is not excluded at two sigma (measured: 1.1e-3 +- 0.5e-3).  The mean of the
 per-step maximum inequality violation must agree within 15 % + 2 SE (a 70 % gap, as an earlier 5-seed version of this
-test could not tell apart, is ~10 SE here), the mean episodic return within 10 % + 2 SE.  The equality constraint must
+test could not tell apart, is ~10 SE here), the mean episodic return within 5 % + 2 SE (round 3; with 48 reference
+seeds pendulum-RPODDPG had shown -13 % at 1.4 sigma: with 576 against 1152 the difference is +0.6 %, z = 0.2 -- the first 192
+reference seeds average 36.9, the next 192 30.8).  The equality constraint must
 hold to float32 round-off on every step of every run.
 """
 import json
@@ -77,7 +79,7 @@ def test_training_statistics_match_reference(golden, algo, envname, se_max):
     assert d_ineq <= 0.15 * ref[:, 2].mean() + 2 * se(2) + 1e-5, (d_ineq, se(2))
     for col in (4, 5):                                           # episodic return, whole run and second half
         d = abs(got[:, col].mean() - ref[:, col].mean())
-        assert d <= 0.10 * ref[:, col].mean() + 2 * se(col), (col, d, se(col))
+        assert d <= 0.05 * ref[:, col].mean() + 2 * se(col), (col, d, se(col))
     assert got[:, 0].min() > 0.9 * steps                         # the logger received (almost) every step
 
 
