@@ -226,7 +226,7 @@ def launch_models(tr, workload):
         "split_critic_fwd_a": ("mfma", B, fa + twin * fc), "split_critic_fwd_b": ("mfma", B, twin * fc),
         "split_pend_head_project": ("hbm", B, 4 * S + 4 * P + 4 * A + 4),
         "split_critic_bwd_a": ("mfma", B, 2 * twin * fc), "split_critic_bwd_b": ("mfma", B, twin * 2 * 128 * (S + A + 2)),
-        # ... with the next vector step riding along (DESIGN 4c): the stage's own flops + the actor forward of half the lanes
+        # ... with the next vector step riding along (DESIGN 4.1): the stage's own flops + the actor forward of half the lanes
         # each (fwd_a / fwd_b); bwd_b + the step of every lane is priced by the step's bytes
         "split_critic_fwd_a_ride": ("mfma", n, (B * (fa + twin * fc) + (n // 2) * fa) / float(n)),
         "split_critic_fwd_b_ride": ("mfma", n, (B * twin * fc + (n - n // 2) * fa) / float(n)),

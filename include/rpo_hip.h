@@ -244,7 +244,7 @@ int rpo_pendulum_act_project(int n, const float* obs, int obs_stride, const floa
 int rpo_pendulum_project_batchref(int n, const float* obs, int obs_stride, const float* ap, float* action,
                                   int* iters_out, int max_steps, float corr_lr, float corr_eps, float corr_momentum,
                                   void* stream);
-/* The same on eight workgroups (n <= 256, max_steps <= 30): each owns 32 rows, and the batch's dgp values are all-gathered
+/* The same on one workgroup per 16 rows (n <= 256, max_steps <= 30): the batch's dgp values are all-gathered
  * once per GRG iteration through tagged 8-byte granules in `ws` (RPO_PROJ_WS_WORDS 64-bit words, 128-byte aligned, zero before
  * the first launch; see rpo_split_update.proj_ws for store_mode and the gave-up word).  Same bits as the call above. */
 int rpo_pendulum_project_batchref_ws(int n, const float* obs, int obs_stride, const float* ap, float* action, int* iters_out,
@@ -508,10 +508,10 @@ typedef struct {
      * workgroup ever gave up waiting for its tile's producers (never, on a healthy device). */
     unsigned* tile_sync;
     /* rpo_split_pend_head_project: NULL (one workgroup), or RPO_PROJ_WS_WORDS 64-bit words, 128-byte aligned, zero before the
-     * first launch: the batch-coupled projection then runs on eight workgroups that all-gather the batch's dgp values once
+     * first launch: the batch-coupled projection then runs on one workgroup per row tile; they all-gather the batch's dgp values once
      * per GRG iteration through tagged 8-byte granules in this buffer (batch <= 256, max_steps <= 30; same bits).  Word
      * RPO_PROJ_WS_GAVE_UP is set to 1 if a workgroup ever gave up waiting for another one's granules (never, on a healthy
-     * device).  proj_store_mode: 0 = agent-scope granule stores; 1 = plain stores when the eight workgroups find themselves on
+     * device).  proj_store_mode: 0 = agent-scope granule stores; 1 = plain stores when the workgroups find themselves on
      * one XCD (checked inside every launch; the polling loads are served by that XCD's L2), agent-scope otherwise. */
     unsigned long long* proj_ws; int proj_store_mode;
     /* tests only (0 in production): bit 0 -- in the fused front launches the policy workgroup of row tile 0, column group 0

@@ -613,9 +613,9 @@ class RPOTrainerBase(object):
         else:
             fields.update(ap_det=b("act.ap_det", B))
         if isinstance(k, be.PendulumKernels) and _env_int("RPO_PROJ_MULTI", 1) and B <= 256 and self.max_steps <= 30:
-            # the batch-coupled projection on eight workgroups (rpo_split_pend_head_project); workspace of
+            # the batch-coupled projection on one workgroup per row tile (rpo_split_pend_head_project); workspace of
             # RPO_PROJ_WS_WORDS 64-bit words.  RPO_PROJ_STORE: 0 agent-scope granule stores, 1 (default) plain stores when the
-            # eight workgroups share an XCD (checked inside every launch)
+            # workgroups share an XCD (checked inside every launch)
             fields.update(proj_ws=torch.zeros(hip_ops.PROJ_WS_WORDS + _env_int("RPO_PROJ_WS_EXTRA", 0), dtype=torch.int64, device=self.device),
                           proj_store_mode=_env_int("RPO_PROJ_STORE", 1))
         self._split_cache = be.SplitUpdate(k, descs, self.sac, B, fields)
@@ -670,7 +670,7 @@ class RPOTrainerBase(object):
         return f.buf("actor.lag", 2), f.buf("actor.parts", (B + 15) // 16, 8), pi_logp
 
     def _set_hand_overs(self, su, actor_step):
-        """What this critic update does on behalf of other launches, and what it leaves to later ones (DESIGN 4c; every
+        """What this critic update does on behalf of other launches, and what it leaves to later ones (DESIGN 4.1; every
         hand-over relies on stream order only -- a later launch starts after every workgroup of an earlier one has finished):
 
           fwd_a   advances the step counter of the rollout launched right before (`_clock_pending`: defer_clock) and zeroes

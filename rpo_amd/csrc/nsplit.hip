@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kNsThreads) void split_critic_fwd_a_kernel(SplitArg
     __shared__ __attribute__((aligned(16))) float4 tile[kRows * L::CH];
     // row tile fastest (ns_block): every XCD's L2 pulls each network's whole W0 per launch (more fetched bytes than with the
     // column group fastest, where an XCD fetched only its 1/8 slice), but what the chain hands from launch to launch for a
-    // tile stays in the L2 that produced it -- the chain is latency-bound, not byte-bound: -7 % per iteration (A/B)
+    // tile stays in the L2 that produced it -- the chain is latency-bound, not byte-bound: -7 % per iteration (A/B, DESIGN A.3)
     const NsBlock nb = ns_block();
     fwd_a_role<L>(p, lds, tile, nb.tile * kRows, nb.g, blockIdx.z);
 }

@@ -459,7 +459,7 @@ class PendulumKernels(object):
               "rpo_pendulum_project_batchref")
 
     def project_batchref_ws(self, obs, ap, action, iters_out, max_steps, corr_lr, corr_eps, corr_momentum, ws, store_mode=1):
-        """project_batchref on eight workgroups; ws: zero-initialised int64[PROJ_WS_WORDS] workspace (kept by the caller)."""
+        """project_batchref on one workgroup per 16 rows; ws: zero-initialised int64[PROJ_WS_WORDS] workspace (kept by the caller)."""
         op, ostride = _row_view(obs, 5)
         check(_lib.load().rpo_pendulum_project_batchref_ws(action.shape[0], op, ostride, _p(ap), _p(action),
                                                            _p(iters_out, torch.int32, allow_none=True), max_steps, corr_lr,

@@ -642,7 +642,7 @@ def test_adam_step_multi_equals_single_launches(ops):
 
 
 def test_xcc_probe_and_front_placement(ops):
-    """rpo_xcc_probe reports the XCD of every workgroup; the fused front launches (rpo_split_critic_front*, DESIGN 4d) are
+    """rpo_xcc_probe reports the XCD of every workgroup; the fused front launches (rpo_split_critic_front*, DESIGN 4.3) are
     used only where every workgroup of a row tile -- in all planes -- shares one.  On an 8-XCD MI355X the dispatcher deals
     workgroups round-robin in block order: 16 row tiles (batch 256) keep a tile on XCD tile % 8, 7 row tiles (batch 100) do not."""
     import ctypes
