@@ -123,6 +123,10 @@ class FusedNets(object):
         n = out.shape[0]
         x0 = self.buf(name + ".x0", n, d.ein) if save else None
         h1 = self.buf(name + ".h1", n, d.H) if save else None
+        if not save and d.E == 256 and n <= 16384:
+            # wide networks run layer by layer (rpo_amd/csrc/mlp_gemm.h): the pre-activations travel through memory, so an
+            # inference call brings scratch for them too (buffers of their own: a saved forward may still be pending)
+            x0, h1 = self.buf(name + ".x0i", n, d.ein), self.buf(name + ".h1i", n, d.H)
         mode, scale, base = (1, tanh_box[0], tanh_box[1]) if tanh_box is not None else (0, 1.0, 0.0)
         self.backend.mlp_forward(d, s, a, out, x0, h1, mode, scale, base)
         return out
@@ -138,8 +142,9 @@ class FusedNets(object):
         packed = []
         for (name, s, a, out, save), d in zip(calls, descs):
             n = out.shape[0]
-            packed.append((d, s, a, out, self.buf(name + ".x0", n, d.ein) if save else None,
-                           self.buf(name + ".h1", n, d.H) if save else None))
+            wide = (not save) and d.E == 256 and n <= 16384       # (see forward)
+            packed.append((d, s, a, out, self.buf(name + (".x0" if save else ".x0i"), n, d.ein) if (save or wide) else None,
+                           self.buf(name + (".h1" if save else ".h1i"), n, d.H) if (save or wide) else None))
         self.backend.mlp_forward_multi(packed)
         return [c[3] for c in calls]
 

@@ -14,8 +14,11 @@
 //   backward  dx0[r][e] = sum_j dh[r][j] W0[j][e]  N-contiguous: a float4 along e serves 4 interleaved output tiles
 //             (tile c, column n <-> e = 4n + c) that share the A operand;
 //   weights   dW0[j][e] = sum_b dh[b][j] x1[b][e]  both operands contiguous in their M / N index.
+#include <stdlib.h>
+
 #include "heads_dev.h"
 #include "mlp_bwd.h"
+#include "mlp_gemm.h"
 #include "mlp_tile.h"
 
 namespace {
@@ -200,6 +203,10 @@ int rpo_mlp_forward(const rpo_mlp* net_host, int n, const float* s, int s_stride
     if (!s || !out || (net.A > 0 && !a)) return RPO_ERR_NULL;
     const int ein = net.cat ? 2 * net.E : net.E;
     FwdArgs args{net, n, s, s_stride, a, a_stride, out, x0_save, h1_save, out_mode, scale, base};
+    if (gemm_path_ok(net, n, x0_save, h1_save, out_mode)) {     // wide networks: one small GEMM launch per layer (mlp_gemm.h)
+        const GemmFwd f{net, n, s, s_stride, a, a_stride, out, x0_save, h1_save};
+        return gemm_forward(&f, 1, (hipStream_t)stream);
+    }
     if (net.hd > 1) {
         if (out_mode != 0) return RPO_ERR_ARG;
 #define RPO_MLP_FWD_WIDE(EIN_, H_)                                                                                    \
@@ -297,6 +304,16 @@ int rpo_mlp_forward_multi(int count, const rpo_mlp* const* nets, int n, const fl
     }
     const Mlp& net = args.net[0].net;
     const int ein = net.cat ? 2 * net.E : net.E;
+    {
+        bool saved = true;
+        for (int k = 0; k < count; ++k) saved = saved && x0_save[k] && h1_save[k];
+        if (saved && gemm_fits(net, count) && gemm_path_ok(net, n, x0_save[0], h1_save[0], 0)) {
+            GemmFwd f[4];
+            for (int k = 0; k < count; ++k)
+                f[k] = GemmFwd{args.net[k].net, n, s[k], s_stride[k], a[k], a_stride[k], out[k], x0_save[k], h1_save[k]};
+            return gemm_forward(f, count, (hipStream_t)stream);
+        }
+    }
 #define RPO_MLP_FWD_MULTI(EIN_, H_)                                                                                  \
     if (ein == EIN_ && net.H == H_) {                                                                                \
         hipLaunchKernelGGL((mlp_forward_multi_kernel<EIN_, H_>), dim3((n + kRows - 1) / kRows, count),               \
@@ -322,10 +339,14 @@ int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int
     const int ein = net.cat ? 2 * net.E : net.E;
     const int grid_rows = (n + kRows - 1) / kRows;
     const int grid_w = bwd_weights_grid(net, first_layer_state_only);
+    const bool gemm_rows = gemm_path_ok(net, n, x0, h1, 0);       // wide networks: dh | dx0 | da as GEMM launches (mlp_gemm.h)
+    if (gemm_rows)
+        if (int e = gemm_backward_rows(&args, 1, (hipStream_t)stream)) return e;
 #define RPO_MLP_BWD(EIN_, H_)                                                                                       \
     if (ein == EIN_ && net.H == H_) {                                                                               \
-        hipLaunchKernelGGL((mlp_bwd_rows_kernel<EIN_, H_>), dim3(grid_rows), dim3(kThreads), 0, (hipStream_t)stream, \
-                           args);                                                                                   \
+        if (!gemm_rows)                                                                                             \
+            hipLaunchKernelGGL((mlp_bwd_rows_kernel<EIN_, H_>), dim3(grid_rows), dim3(kThreads), 0, (hipStream_t)stream, \
+                               args);                                                                               \
         RPO_LAUNCH_CHECK();                                                                                         \
         if (param_grads) {                                                                                          \
             const SplitK sk = splitk_plan(args, grad_host->splitk_scratch, grad_host->splitk_floats);                 \
@@ -362,10 +383,14 @@ int rpo_mlp_backward_pair(const rpo_mlp* net1_host, const rpo_mlp_grad* grad1_ho
     const int ein = n1.cat ? 2 * n1.E : n1.E;
     const int grid_rows = (n + kRows - 1) / kRows;
     const int grid_w = bwd_weights_grid(n1, first_layer_state_only);
+    const bool gemm_rows = gemm_path_ok(n1, n, x0_1, h1_1, 0) && x0_2 && h1_2 && gemm_fits(n1, 2);
+    if (gemm_rows)
+        if (int e = gemm_backward_rows(args.net, 2, (hipStream_t)stream)) return e;
 #define RPO_MLP_BWD2(EIN_, H_)                                                                                         \
     if (ein == EIN_ && n1.H == H_) {                                                                                   \
-        hipLaunchKernelGGL((mlp_bwd_rows_kernel2<EIN_, H_>), dim3(grid_rows, 2), dim3(kThreads), 0, (hipStream_t)stream, \
-                           args);                                                                                      \
+        if (!gemm_rows)                                                                                                \
+            hipLaunchKernelGGL((mlp_bwd_rows_kernel2<EIN_, H_>), dim3(grid_rows, 2), dim3(kThreads), 0, (hipStream_t)stream, \
+                               args);                                                                                  \
         RPO_LAUNCH_CHECK();                                                                                            \
         if (param_grads) {                                                                                             \
             /* large batches: one split-K weights pass per network (each half of the scratch buffer... its own) */     \

@@ -102,8 +102,16 @@ def test_mlp_forward_backward_match_torch(kind, S, A, E, H, n):
     ops.mlp_forward(d, s, a, out, x0, h1)
     np.testing.assert_allclose(out.cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, atol=2e-6)
     out2 = torch.empty(n, n_out, device=DEV)
-    ops.mlp_forward(d, s, a, out2)                       # inference form (nothing saved) gives the same bits
-    assert torch.equal(out, out2)
+    if E == 256:
+        # wide networks run layer by layer (mlp_gemm.h) whenever the caller brings buffers for the pre-activations -- the
+        # trainer always does; without them the row-tile kernel answers, to float32 round-off of the other summation order
+        ops.mlp_forward(d, s, a, out2, torch.empty_like(x0), torch.empty_like(h1))
+        assert torch.equal(out, out2)
+        ops.mlp_forward(d, s, a, out2)
+        np.testing.assert_allclose(out2.cpu().numpy(), out.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    else:
+        ops.mlp_forward(d, s, a, out2)                   # inference form (nothing saved) gives the same bits
+        assert torch.equal(out, out2)
 
     dout = torch.randn(n, n_out, device=DEV) / n
     ref.backward(dout)
