@@ -37,11 +37,17 @@ def main():
     front = bool(getattr(tr, "_front_cache", False))
     if su and su._held.get("tile_sync") is not None:                                 # fused front launches: words at rest, no wait gave up
         assert int(su._held["tile_sync"].abs().max()) == 0
+    ws = su._held.get("proj_ws") if su else None
+    pfront = bool(getattr(tr, "_pfront", False))
+    if ws is not None:                                          # granule workspace of the batch-coupled projection: no wait gave
+        from rpo_amd import ops                                 # up, the readers' count at rest, one epoch per launch
+        assert int(ws[ops.PROJ_WS_GAVE_UP]) == 0 and int(ws[ops.PROJ_WS_GAVE_UP + 1]) == 0
+        assert int(ws[ops.PROJ_WS_GAVE_UP - 1]) == int(ag.critic_optim.step_dev[0]), (int(ws[ops.PROJ_WS_GAVE_UP - 1]), steps)
     for p in (ag.flat.data, ag.nju.weight, ag.critic_target_flat):
         assert bool(torch.isfinite(p).all())
     assert tr.env_steps == steps * n and 0.0 <= tr.viol_rate <= 1.0
-    print("%s: %d steps ok; violation rate %.5f, ride %s, fused front %s, prepared Adam, |params| max %.3f" % (
-        workload, steps, tr.viol_rate, bool(getattr(tr, "_ride_ok", lambda d: False)(True)), front, float(ag.flat.data.abs().max())))
+    print("%s: %d steps ok; violation rate %.5f, ride %s, fused front %s, pendulum front with granules %s, prepared Adam, |params| max %.3f" % (
+        workload, steps, tr.viol_rate, bool(getattr(tr, "_ride_ok", lambda d: False)(True)), front, pfront, float(ag.flat.data.abs().max())))
 
 
 if __name__ == "__main__":
