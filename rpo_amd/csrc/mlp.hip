@@ -342,6 +342,13 @@ int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int
     const bool gemm_rows = gemm_path_ok(net, n, x0, h1, 0);       // wide networks: dh | dx0 | da as GEMM launches (mlp_gemm.h)
     if (gemm_rows)
         if (int e = gemm_backward_rows(&args, 1, (hipStream_t)stream)) return e;
+    if (param_grads && ein == 128 && net.H == 256) {              // large batches: rows + weights in ONE pass over the activations
+        const SplitK sk = splitk_plan(args, grad_host->splitk_scratch, grad_host->splitk_floats);
+        if (sk.Z > 0) {
+            const int r = launch_onepass<128, 256>(args, sk, (hipStream_t)stream);
+            if (r >= 0) return r;
+        }
+    }
 #define RPO_MLP_BWD(EIN_, H_)                                                                                       \
     if (ein == EIN_ && net.H == H_) {                                                                               \
         if (!gemm_rows)                                                                                             \
@@ -386,6 +393,15 @@ int rpo_mlp_backward_pair(const rpo_mlp* net1_host, const rpo_mlp_grad* grad1_ho
     const bool gemm_rows = gemm_path_ok(n1, n, x0_1, h1_1, 0) && x0_2 && h1_2 && gemm_fits(n1, 2);
     if (gemm_rows)
         if (int e = gemm_backward_rows(args.net, 2, (hipStream_t)stream)) return e;
+    if (param_grads && ein == 128 && n1.H == 256 && grad1_host->splitk_scratch != grad2_host->splitk_scratch) {   // (see rpo_mlp_backward)
+        const SplitK k1 = splitk_plan(args.net[0], grad1_host->splitk_scratch, grad1_host->splitk_floats);
+        const SplitK k2 = splitk_plan(args.net[1], grad2_host->splitk_scratch, grad2_host->splitk_floats);
+        if (k1.Z > 0 && k2.Z > 0) {
+            const int r = launch_onepass<128, 256>(args.net[0], k1, (hipStream_t)stream);
+            if (r > 0) return r;
+            if (r == 0) return launch_onepass<128, 256>(args.net[1], k2, (hipStream_t)stream);
+        }
+    }
 #define RPO_MLP_BWD2(EIN_, H_)                                                                                         \
     if (ein == EIN_ && n1.H == H_) {                                                                                   \
         if (!gemm_rows)                                                                                                \

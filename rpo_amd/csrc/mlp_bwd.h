@@ -1,6 +1,7 @@
 // Backward pass of the MLP tile (see mlp.hip for the operand-layout notes): device bodies shared by the stand-alone
 // kernels (mlp.hip) and the fused actor-update pipeline (fused.hip).
 #pragma once
+#include <stdlib.h>
 #include "mlp_tile.h"
 #include "heads_dev.h"
 
@@ -673,6 +674,232 @@ __global__ __launch_bounds__(RPO_BLOCK) void splitk_reduce_kernel(SplitK k, floa
     }
 }
 
+// ---- ONE pass over the saved activations for large batches of the 128 -> 256 scalar-head networks (critic / actor updates
+// of the classic-control envs in the large-batch mode): rows pass + every parameter-gradient reduction in one persistent
+// kernel.  The two-pass form writes dh and dx0 (1.5 GB at 2^20 rows) and reads h1 / x0 / dh / dx0 back two to four times over;
+// here a workgroup walks ITS slice of the batch 16 rows at a time and
+//   * keeps its B operands of dx0 = dh W0 in registers for the whole slice (128 floats per thread: the W0 slice of the wave's
+//     32 output columns),
+//   * accumulates dW0 += dh^T relu(x0) in 128 accumulator registers per thread (wave w owns hidden rows [64 w, 64 w + 64)),
+//   * keeps db0 / dW1 (thread = hidden column) and the first-layer gradients (thread = embedding column) in registers,
+// and writes them once, into its copy of the gradient span (the scratch of the split-K pass; splitk_reduce adds the copies in
+// order).  h1 and x0 are read once, nothing else touches HBM: 1.5 GB instead of ~9 GB per 2^20 rows.  Next tile's h1 / x0 are
+// requested while the current tile's 256 MFMAs per wave run.  One owner per element, tiles in order: bitwise reproducible.
+// Two groups of four waves share a workgroup (two waves per SIMD, ~200 registers each -- one group holding both the dW0
+// accumulators and the W0 slice needs > 512 registers per thread and spilled):
+//   W waves  stage the tile's x0 in LDS (requested one tile ahead) and run dW0 += dh^T relu(x0) (128 MFMAs per wave per tile);
+//   X waves  request h1 / head gradients / inputs one tile ahead, form dh (thread = hidden column; db0, dW1 along the way),
+//            run dx0 = (dh W0) * 1[x0 > 0] (128 MFMAs per wave per tile) and the first-layer sums (thread = (input half, e)).
+// The vector work of one group runs under the other's MFMAs.
+constexpr int kOnepassThreads = 512;
+
+template <int EIN, int H>
+__global__ __launch_bounds__(kOnepassThreads) void mlp_bwd_onepass_kernel(BwdArgs p, SplitK k) {
+    static_assert(EIN == 128 && H == 256, "one thread per hidden column, two per embedding column");
+    constexpr int LDH = H + 4, LDX = EIN + 4, NT = 256;
+    __shared__ __attribute__((aligned(16))) float dh_s[kRows * LDH];
+    __shared__ __attribute__((aligned(16))) float x0_s[kRows * LDX];
+    __shared__ __attribute__((aligned(16))) float dx_s[kRows * LDX];
+    __shared__ __attribute__((aligned(16))) float in_sb[2][kRows * 8], in_ab[2][kRows * 8], dout_s[kRows * 2];   // (inputs by tile parity)
+    const Mlp& net = p.net;
+    const bool xgrp = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= NT;   // (wave-uniform: a scalar branch, the groups' registers do not interfere)
+    const int tid = threadIdx.x & (NT - 1), lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int z = blockIdx.x, Z = gridDim.x;
+    const long long tiles = ((long long)p.n + kRows - 1) / kRows;
+    const long long t_lo = tiles * z / Z, t_hi = tiles * (z + 1) / Z;
+    if (t_hi <= t_lo) return;
+    const bool two = net.n_out > 1, has_a = net.A > 0;
+    float* base = k.scratch + (long long)z * k.span;
+#define RPO_SK(F) (base + (p.g.F - k.lo))
+    if (!xgrp) {
+        // ================================================================ W waves: x0 staging + dW0
+        f32x4 accw[4][8];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) accw[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        float xn[kRows * EIN / NT];
+        float tq = 0.0f, tqn1 = 0.0f, tqn2 = 0.0f, tlp = 0.0f, trw = 0.0f, tdn = 0.0f, tdo = 0.0f, tin_s = 0.0f, tin_a = 0.0f;   // small operands
+        auto request = [&](long long tile) {
+            const long long m0 = tile * kRows;
+            if (tid < kRows && p.td.q) {                             // the TD prologue's operands of row m0 + tid
+                const TdArgs& t = p.td;
+                const long long i = m0 + tid < p.n ? m0 + tid : p.n - 1;
+                tq = t.q[i]; tqn1 = t.qn1[i]; tqn2 = t.qn2 ? t.qn2[i] : 0.0f; tlp = t.logp ? t.logp[i] : 0.0f;
+                trw = t.reward[(size_t)i * t.reward_stride]; tdn = t.done[(size_t)i * t.done_stride];
+            } else if (tid < kRows * 2 && !p.td.q) {
+                const int r = tid >> 1, o = tid & 1;
+                const long long m = m0 + r < p.n ? m0 + r : p.n - 1;
+                tdo = o < net.n_out ? p.dout[(size_t)m * net.n_out + o] : 0.0f;
+            } else if (tid >= 64 && tid < 64 + kRows * 8) {
+                const int q = tid - 64, r = q >> 3, i = q & 7;
+                const long long m = m0 + r < p.n ? m0 + r : p.n - 1;
+                tin_s = i < net.S ? p.s[(size_t)m * p.s_stride + i] : 0.0f;
+                tin_a = (has_a && i < net.A) ? p.a[(size_t)m * p.a_stride + i] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < kRows * EIN / NT; ++u) {
+                const int idx = tid + u * NT, r = idx / EIN, e = idx - r * EIN;
+                const long long m = m0 + r < p.n ? m0 + r : p.n - 1;
+                xn[u] = p.x0[(size_t)m * EIN + e];
+            }
+        };
+        request(t_lo);
+        for (long long tile = t_lo; tile < t_hi; ++tile) {
+            const long long m0 = tile * kRows;
+#pragma unroll
+            for (int u = 0; u < kRows * EIN / NT; ++u) {
+                const int idx = tid + u * NT, r = idx / EIN, e = idx - r * EIN;
+                x0_s[r * LDX + e] = m0 + r < p.n ? xn[u] : 0.0f;
+            }
+            // ---- the tile's head gradients (given, or the TD target + Huber prologue of the critic update) and inputs
+            if (tid < 64) {                                            // (operands requested one tile ahead: `request`)
+                if (p.td.q) {
+                    const TdArgs& t = p.td;
+                    const long long i = m0 + tid;
+                    float dq = 0.0f, hub = 0.0f;
+                    if (tid < kRows && i < p.n) {
+                        const float qn = rpo_head_dev::td_next_value(tqn1, tqn2, t.qn2 != nullptr, tlp, t.logp != nullptr, t.alpha);
+                        const float y = rpo_head_dev::td_target(trw, tdn, t.gamma, qn);
+                        dq = rpo_head_dev::td_huber_row(tq, y, 1.0f / (float)p.n, &hub);
+                        t.dq_out[i] = dq;
+                    }
+                    if (tid < kRows) { dout_s[tid * 2] = dq; dout_s[tid * 2 + 1] = 0.0f; }
+                    const float sum = rpo_row16_sum_desc_lane0(hub);
+                    if (tid == 0) t.loss_partial[tile] = sum;
+                } else if (tid < kRows * 2) {
+                    dout_s[tid] = m0 + (tid >> 1) < p.n ? tdo : 0.0f;
+                }
+            } else if (tid < 64 + kRows * 8) {
+                const int q = tid - 64, r = q >> 3;
+                const bool live = m0 + r < p.n;
+                in_sb[tile & 1][q] = live ? tin_s : 0.0f;
+                in_ab[tile & 1][q] = live ? tin_a : 0.0f;
+            }
+        if (tile + 1 < t_hi) request(tile + 1);
+            __syncthreads();                                         // B1: x0_s, dout_s, the inputs
+            __syncthreads();                                         // B2: dh_s
+#pragma unroll
+            for (int ks = 0; ks < kRows / 4; ++ks) {                 // dW0 += dh^T relu(x0): hidden rows [64 wave, 64 wave + 64)
+                float av[4], bv[8];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) av[mt] = dh_s[(ks * 4 + lg) * LDH + wave * 64 + mt * 16 + li];
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) bv[nt] = fmaxf(x0_s[(ks * 4 + lg) * LDX + nt * 16 + li], 0.0f);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 8; ++nt) accw[mt][nt] = mfma4(av[mt], bv[nt], accw[mt][nt]);
+            }
+            __syncthreads();                                         // B3: dx_s written, x0_s / dh_s free
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    RPO_SK(W0)[(size_t)(wave * 64 + mt * 16 + lg * 4 + i) * EIN + nt * 16 + li] = accw[mt][nt][i];
+        return;
+    }
+    // ==================================================================== X waves: dh, dx0, hidden vectors, first layer
+    float w0r[2][H / 4];                                           // B operands of dx0 = dh W0: columns n = 32 wave + 16 t + li, k = 4 ks + lg
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < H / 4; ++ks) w0r[t][ks] = net.W0[(size_t)(ks * 4 + lg) * EIN + wave * 32 + t * 16 + li];
+    const float w1a = net.W1[tid], w1b = two ? net.W1b[tid] : 0.0f;
+    float gb0 = 0.0f, gw1a = 0.0f, gw1b = 0.0f, gfl[9], gb1a = 0.0f, gb1b = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gfl[i] = 0.0f;
+    const int e_own = tid & (EIN - 1);                           // threads [0, 128): state inputs of column e; [128, 256): action inputs
+    const bool act_half = tid >= EIN;
+    float hn[kRows];
+    auto request = [&](long long tile) {
+        const long long m0 = tile * kRows;
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            const long long m = m0 + r < p.n ? m0 + r : p.n - 1;
+            hn[r] = p.h1[(size_t)m * H + tid];
+        }
+    };
+    request(t_lo);
+    for (long long tile = t_lo; tile < t_hi; ++tile) {
+        const long long m0 = tile * kRows;
+        __syncthreads();                                             // B1
+        // ---- dh (thread = hidden column), db0 / dW1 along the way
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            const bool live = m0 + r < p.n;
+            const float h = live ? hn[r] : 0.0f, da_ = dout_s[r * 2], db_ = dout_s[r * 2 + 1];
+            const float d = (h > 0.0f) ? fmaf(db_, w1b, da_ * w1a) : 0.0f;
+            dh_s[r * LDH + tid] = d;
+            gb0 += d;
+            const float hr = fmaxf(h, 0.0f);
+            gw1a = fmaf(da_, hr, gw1a);
+            gw1b = fmaf(db_, hr, gw1b);
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);    // (bounds the temporaries: the W0 slice must stay in registers)
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) { gb1a += dout_s[r * 2]; gb1b += dout_s[r * 2 + 1]; }
+        }
+        if (tile + 1 < t_hi) request(tile + 1);                      // (lands under the MFMA phase and the first-layer sums)
+        __syncthreads();                                             // B2
+        // ---- dx0 = (dh W0) * 1[x0 > 0]: wave w owns columns [32 w, 32 w + 32)
+        f32x4 ax[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+#pragma unroll                                                  // (fully: w0r must be indexed statically to stay in registers;
+        for (int kc = 0; kc < H / 32; ++kc) {                    //  fenced in eights so the scheduler does not hoist all 64 LDS reads)
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int ks = kc * 8 + kk;
+                const float av = dh_s[li * LDH + ks * 4 + lg];
+                ax[0] = mfma4(av, w0r[0][ks], ax[0]);
+                ax[1] = mfma4(av, w0r[1][ks], ax[1]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = lg * 4 + i, n = wave * 32 + t * 16 + li;
+                dx_s[r * LDX + n] = x0_s[r * LDX + n] > 0.0f ? ax[t][i] : 0.0f;
+            }
+        __syncthreads();                                             // B3
+        // ---- first-layer gradients: thread (half, e) adds dx0[r][e] x its inputs, rows in order
+        if (!act_half || has_a) {
+            const float4* in = reinterpret_cast<const float4*>(act_half ? in_ab[tile & 1] : in_sb[tile & 1]);
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) {
+                const float d = dx_s[r * LDX + e_own];
+                const float4 i0 = in[r * 2], i1 = in[r * 2 + 1];         // (the same address in every lane: broadcast reads)
+                gfl[0] = fmaf(d, i0.x, gfl[0]); gfl[1] = fmaf(d, i0.y, gfl[1]); gfl[2] = fmaf(d, i0.z, gfl[2]); gfl[3] = fmaf(d, i0.w, gfl[3]);
+                gfl[4] = fmaf(d, i1.x, gfl[4]); gfl[5] = fmaf(d, i1.y, gfl[5]); gfl[6] = fmaf(d, i1.z, gfl[6]); gfl[7] = fmaf(d, i1.w, gfl[7]);
+                gfl[8] += d;
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // (dx_s is rewritten two barriers from here, the inputs live in the other parity's buffer)
+    }
+    // ---- the slice's sums into its copy of the gradient span
+    RPO_SK(b0)[tid] = gb0;
+    RPO_SK(W1)[tid] = gw1a;
+    if (two) RPO_SK(W1b)[tid] = gw1b;
+    if (tid == 0) { RPO_SK(b1)[0] = gb1a; if (two) RPO_SK(b1b)[0] = gb1b; }
+    if (!act_half) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < net.S) RPO_SK(Ws)[e_own * net.S + i] = gfl[i];
+        RPO_SK(bs)[e_own] = gfl[8];
+    } else if (has_a) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < net.A) RPO_SK(Wa)[e_own * net.A + i] = gfl[i];
+        RPO_SK(ba)[e_own] = gfl[8];
+    }
+#undef RPO_SK
+}
+
 // Host side: the split-K plan for `args` (Z = 0: not applicable -- small batch, no scratch, or scratch too small)
 static inline SplitK splitk_plan(const BwdArgs& a, float* scratch, long long scratch_floats) {
     SplitK k{nullptr, nullptr, 0, 0};
@@ -696,6 +923,26 @@ static inline SplitK splitk_plan(const BwdArgs& a, float* scratch, long long scr
     if (Z < 2) return k;
     k.scratch = scratch; k.lo = const_cast<float*>(lo); k.span = span; k.Z = (int)Z;
     return k;
+}
+
+// The one-pass form applies to the scalar-head 128 -> 256 networks with up to 8 state / action inputs when every parameter
+// gradient is wanted and the action-input gradient is not (critic update, actor update); returns < 0 when it does not apply.
+template <int EIN, int H>
+static inline int launch_onepass(const BwdArgs& args, const SplitK& k, hipStream_t stream) {
+    const Mlp& net = args.net;
+    if (EIN != 128 || H != 256 || net.cat || net.hd > 1 || net.S > 8 || net.A > 8 || !args.param_grads || args.first_layer_state_only ||
+        args.da || k.Z < 2)
+        return -1;
+    const char* e = getenv("RPO_BWD_ONEPASS");
+    if (e && e[0] == '0') return -1;
+    if (hipMemsetAsync(k.scratch, 0, (size_t)k.Z * (size_t)k.span * sizeof(float), stream) != hipSuccess) return RPO_ERR_ARG;
+    hipLaunchKernelGGL((mlp_bwd_onepass_kernel<128, 256>), dim3(k.Z), dim3(kOnepassThreads), 0, stream, args, k);
+    RPO_LAUNCH_CHECK();
+    long long blocks = (k.span + RPO_BLOCK - 1) / RPO_BLOCK;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3((unsigned)blocks), dim3(RPO_BLOCK), 0, stream, k, args.gradmax);
+    RPO_LAUNCH_CHECK();
+    return 0;
 }
 
 template <int EIN, int H>
