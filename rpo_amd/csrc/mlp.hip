@@ -73,6 +73,10 @@ template <int EIN, int H>
 __global__ __launch_bounds__(kFwdThreads) void mlp_forward_multi_kernel(FwdArgs4 p) {
     mlp_forward_body<EIN, H, 1, kInS, kInA>(p.net[blockIdx.y]);
 }
+template <int H>
+__global__ __launch_bounds__(kFwdThreads) void mlp_forward_multi64_kernel(FwdArgs4 p) {     // 64 rows per workgroup (large n)
+    mlp_forward_body<128, H, 4, 8, 8>(p.net[blockIdx.y]);
+}
 
 // Multi-output networks (hd > 1, e.g. the 14 basic actions of EVOPF-v0): same tile, MFMA head, raw outputs
 // [n, n_out * hd] (head-major); the state-dependent tanh box of such actors is applied by the env's own kernels.
@@ -313,6 +317,12 @@ int rpo_mlp_forward_multi(int count, const rpo_mlp* const* nets, int n, const fl
                 f[k] = GemmFwd{args.net[k].net, n, s[k], s_stride[k], a[k], a_stride[k], out[k], x0_save[k], h1_save[k]};
             return gemm_forward(f, count, (hipStream_t)stream);
         }
+    }
+    if (n >= 64 * 192 && net.S <= 8 && net.A <= 8 && ein == 128 && net.H == 256) {   // as rpo_mlp_forward: 64-row tiles
+        hipLaunchKernelGGL((mlp_forward_multi64_kernel<256>), dim3((n + 63) / 64, count), dim3(kFwdThreads), 0,
+                           (hipStream_t)stream, args);
+        RPO_LAUNCH_CHECK();
+        return 0;
     }
 #define RPO_MLP_FWD_MULTI(EIN_, H_)                                                                                  \
     if (ein == EIN_ && net.H == H_) {                                                                                \

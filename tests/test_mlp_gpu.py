@@ -238,6 +238,27 @@ def test_mlp_tanh_box_epilogue():
     np.testing.assert_allclose(out.cpu().numpy(), net(s).detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
+def test_forward_multi_large_n_equals_single_launches():
+    """From 12288 rows both entry points move to 64-row tiles: same bits as the single launches."""
+    from rpo_amd import ops
+    torch.manual_seed(5)
+    S, A, E, H, n = 6, 2, 128, 256, 20011
+    nets = [aligned_params(SharedValueAdd(S, A, StateEmbedding(S, E, H), ActionEmbedding(A, E, H), E, H)) for _ in range(3)]
+    descs = [desc_for(ops, m, "add", S, A, E, H) for m in nets]
+    wide = torch.randn(n, 16, device=DEV)
+    ins = [(wide[:, 0:6], wide[:, 6:8]), (wide[:, 8:14], wide[:, 14:16]), (wide[:, 0:6], wide[:, 14:16])]
+    new = lambda: (torch.empty(n, 1, device=DEV), torch.empty(n, E, device=DEV), torch.empty(n, H, device=DEV))
+    single, multi = [new() for _ in range(3)], [new() for _ in range(3)]
+    for d, (s, a), m in zip(descs, ins, single):
+        ops.mlp_forward(d, s, a, *m)
+    ops.mlp_forward_multi([(d, s, a) + m for d, (s, a), m in zip(descs, ins, multi)])
+    for one, many in zip(single, multi):
+        for x, y in zip(one, many):
+            assert torch.equal(x, y)
+    ref = nets[1](ins[1][0], ins[1][1]).detach()
+    np.testing.assert_allclose(multi[1][0].cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
 def test_forward_multi_equals_single_launches():
     """rpo_mlp_forward_multi (gridDim.y = network): four same-shaped critics on two different input pairs, bitwise equal to
     four rpo_mlp_forward launches, pre-activations included; and the TD prologue of rpo_mlp_backward (rpo_td) against

@@ -18,10 +18,10 @@ def main(workload="cart_ddpg", batch=1 << 20, lanes=4096):
     batch, lanes = int(batch), int(lanes)
     tr = bench.make_trainer(lanes, torch.device("cuda"), 10 ** 9, capacity=64, workload=workload, batch_size=batch, use_graph=False)
     tr.vec.reset()
-    tr.run_steps(3)
+    tr.run_steps(3 * max(tr._cycle, 4))                       # (past the first actor update: its buffers are allocated)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 8
+    n = 2 * max(tr._cycle, 4)
     tr.run_steps(n)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
