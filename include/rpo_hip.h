@@ -39,8 +39,7 @@ extern "C" {
 
 /* 3: rpo_split_update gained proj_ws / proj_store_mode / debug (the struct grew); rpo_split_critic_pfront*,
  * rpo_pendulum_project_batchref_ws; rpo_evopf_complete_bwd takes grad_action2, rpo_evopf_lagrangian takes overwrite */
-/* 4: rpo_split_update gained fold_seg / fold_count / fold_ws (the struct grew). */
-#define RPO_ABI_VERSION 4
+#define RPO_ABI_VERSION 3
 
 #define RPO_ERR_ARG (-1)
 #define RPO_ERR_NULL (-2)
@@ -519,22 +518,7 @@ typedef struct {
      * withholds its hand-over (arrival / granules), so that its consumers run into their bounded wait and raise the gave-up
      * word: the failure path must be loud and must leave the device usable. */
     int debug;
-    /* bwd_b / pol_e: fold_count = 0, or the optimiser step that would follow the stage as its own launch (rpo_adam_step /
-     * rpo_adam_step_multi: the same slices, fields and arithmetic -- `prepared` is ignored, the stage does the bookkeeping of a
-     * plain step itself) done INSIDE the stage's launch: its workgroups publish the largest |gradient element| they wrote
-     * in tagged 8-byte granules (fold_ws, agent-scope stores), wait for everyone's, and step the elements of 256-element
-     * blocks -- the inf-norm of clip_grad_norm_ needs every gradient before any element can move, so this is a barrier
-     * across the launch (all of its <= RPO_FOLD_MAX_BLOCKS workgroups are resident: the caller must not fold when that
-     * cannot be guaranteed).  Slice 0's norm is max(the launch's own gradients, its gradmax slots as left by EARLIER launches);
-     * other stepped slices must have clip_thres == 0.  Gradient elements travel with agent-scope stores / loads; nothing
-     * depends on placement.  Same bits as the separate launch.  fold_ws: RPO_FOLD_WS_WORDS 64-bit words, 128-byte aligned,
-     * zero before the first launch; word RPO_FOLD_WS_GAVE_UP is set to 1 if a workgroup ever gave up waiting (never, on a
-     * healthy device).  Not for data-parallel runs (the all-reduce sits between the backward and the step). */
-    rpo_adam_seg fold_seg[4]; int fold_count; unsigned long long* fold_ws;
 } rpo_split_update;
-#define RPO_FOLD_WS_WORDS 16400
-#define RPO_FOLD_WS_GAVE_UP 1
-#define RPO_FOLD_MAX_BLOCKS 1024
 
 
 int rpo_split_critic_fwd_a(const rpo_split_update* u, void* stream);

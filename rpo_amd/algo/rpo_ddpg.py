@@ -287,40 +287,28 @@ class RPODDPG(RPOTrainerBase):
     # The Polyak updates of a policy step (rpo_ddpg.py:205) ride in the Adam launches that produce the parameters they
     # average -- same arithmetic, two launches fewer.  With a shared state embedding the critic's target must see the
     # embedding AFTER the actor's step, so its update stays a separate launch at the end.
-    def _critic_segment(self, actor_step):
-        """The critic's optimiser step as a slice (the form a folded step takes: rpo_split_update.fold_seg)."""
-        ag = self.agent
-        fuse = actor_step and ag.flat.sizes[1] == 0
-        return ag.critic_optim.segment(target=ag.critic_target_flat if fuse else None, tau=ag.tau, gradmax_ready=True)
-
     def _critic_step(self, actor_step):
         ag = self.agent
         fuse = actor_step and ag.flat.sizes[1] == 0
         prepared, self._critic_prepared = getattr(self, "_critic_prepared", False), False
-        folded, self._critic_folded = getattr(self, "_critic_folded", False), False
-        if not folded:                                           # (else: done inside bwd_b's launch)
-            ag.critic_optim.step(target=ag.critic_target_flat if fuse else None, tau=ag.tau,
-                                 gradmax_ready=self._gradmax_ready, clock=self._clock(not actor_step), prepared=prepared)
+        ag.critic_optim.step(target=ag.critic_target_flat if fuse else None, tau=ag.tau,
+                             gradmax_ready=self._gradmax_ready, clock=self._clock(not actor_step), prepared=prepared)
         self._gradmax_ready = False
 
-    def _actor_segments(self, gradmax_ready):
+    def _actor_step(self, actor_out):
         # actor Adam (+ Polyak of the actor target) | multiplier DualAdam | Polyak of the critic target: one launch.
         # With a shared state embedding the actor's step moves the critic's copy of it too, so the shared part of the
         # critic target follows inside the actor's slice (target2) and only the critic-only part is a slice of its own.
         ag, fl = self.agent, self.agent.flat
         c = fl.actor_range[0]                                  # [critic-only | shared | actor-only], padded offsets
         sh = fl.critic_range[1] - c if fl.sizes[1] > 0 else 0
-        segs = [ag.actor_optim.segment(target=ag.actor_target_flat, tau=ag.tau, gradmax_ready=gradmax_ready,
+        segs = [ag.actor_optim.segment(target=ag.actor_target_flat, tau=ag.tau,
+                                       gradmax_ready=getattr(self, "_actor_gradmax_ready", False),
                                        target2=ag.critic_target_flat[c:c + sh] if sh > 0 else None, n2=sh)]
+        self._actor_gradmax_ready = False
         if not self.fixed:
             segs.append(ag.nju_optim.segment())                    # lambda is never stepped (rpo_ddpg.py:202)
         if sh > 0 and c > 0:
             segs.append(dict(polyak_only=True, param=fl.param((0, c)), target=ag.critic_target_flat[:c], tau=ag.tau))
-        return segs
-
-    def _actor_step(self, actor_out):
-        folded, self._actor_folded = getattr(self, "_actor_folded", False), False
         prepared, self._actor_prepared = getattr(self, "_actor_prepared", False), False
-        ready, self._actor_gradmax_ready = getattr(self, "_actor_gradmax_ready", False), False
-        if not folded:                                           # (else: done inside pol_e's launch)
-            FusedAdam.step_many(self.backend, self._actor_segments(ready), clock=self._clock(True), prepared=prepared)
+        FusedAdam.step_many(self.backend, segs, clock=self._clock(True), prepared=prepared)

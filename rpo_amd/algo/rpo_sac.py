@@ -309,39 +309,23 @@ class RPOSAC(RPOTrainerBase):
         self._fused_polyak = ag.flat.sizes[1] == 0
         ready, self._gradmax_ready = self._gradmax_ready, False
         prepared, self._critic_prepared = getattr(self, "_critic_prepared", False), False
-        folded, self._critic_folded = getattr(self, "_critic_folded", False), False
         if self._fused_polyak:
-            if not folded:                                       # (else: done inside bwd_b's launch)
-                ag.critic_optim.step(target=ag.critic_target_flat, tau=ag.tau, gradmax_ready=ready, clock=self._clock(not actor_step),
-                                     prepared=prepared)
+            ag.critic_optim.step(target=ag.critic_target_flat, tau=ag.tau, gradmax_ready=ready, clock=self._clock(not actor_step),
+                                 prepared=prepared)
             return
-        if not folded:
-            ag.critic_optim.step(gradmax_ready=ready, clock=self._clock(not actor_step), prepared=prepared)
+        ag.critic_optim.step(gradmax_ready=ready, clock=self._clock(not actor_step), prepared=prepared)
         if not actor_step:
             ag.soft_update()
 
-    def _critic_segment(self, actor_step):
-        """The critics' optimiser step as a slice (the form a folded step takes: rpo_split_update.fold_seg)."""
+    def _actor_step(self, actor_out):
         ag = self.agent
-        if ag.flat.sizes[1] == 0:
-            return ag.critic_optim.segment(target=ag.critic_target_flat, tau=ag.tau, gradmax_ready=True)
-        return ag.critic_optim.segment(gradmax_ready=True)
-
-    def _actor_segments(self, gradmax_ready):
-        ag = self.agent
-        segs = [ag.actor_optim.segment(gradmax_ready=gradmax_ready)]
+        segs = [ag.actor_optim.segment(gradmax_ready=getattr(self, "_actor_gradmax_ready", False))]
+        self._actor_gradmax_ready = False
         if not self.fixed:
             segs.append(ag.nju_optim.segment())
         if self.automatic_entropy_tuning:
             segs.append(ag.alpha_optim.segment())               # rpo_sac.py:210-216, gradient left by _actor_update
-        return segs
-
-    def _actor_step(self, actor_out):
-        ag = self.agent
-        folded, self._actor_folded = getattr(self, "_actor_folded", False), False
         prepared, self._actor_prepared = getattr(self, "_actor_prepared", False), False
-        ready, self._actor_gradmax_ready = getattr(self, "_actor_gradmax_ready", False), False
-        if not folded:                                           # actor Adam | DualAdam (| log_alpha): one launch, or inside pol_e's
-            FusedAdam.step_many(self.backend, self._actor_segments(ready), clock=self._clock(True), prepared=prepared)
+        FusedAdam.step_many(self.backend, segs, clock=self._clock(True), prepared=prepared)   # actor Adam | DualAdam (| log_alpha): one launch
         if not self._fused_polyak:
             ag.soft_update()

@@ -252,7 +252,6 @@ class RPOTrainerBase(object):
         self._ride, self._rider_cache, self._ride_cut = None, None, 0
         self._clock_pending, self._iter_actor_step, self._critic_prepared, self._gradmax_stale = False, None, False, False
         self._actor_prepared, self._actor_gradmax_stale = False, False
-        self._critic_folded, self._actor_folded, self._fold, self._fold_ws, self._fold_actor_step = False, False, False, None, None
         self._bump_updates_now, self._updates_out, self._pol_a_done = False, None, False
         self._bump = self.updates_per_step == 1
         if self.fused is not None and device.type == "cuda" and getattr(self.backend, "ADAM_CLOCK", False):
@@ -620,10 +619,6 @@ class RPOTrainerBase(object):
             fields.update(proj_ws=torch.zeros(hip_ops.PROJ_WS_WORDS + _env_int("RPO_PROJ_WS_EXTRA", 0), dtype=torch.int64, device=self.device),
                           proj_store_mode=_env_int("RPO_PROJ_STORE", 1))
         self._split_cache = be.SplitUpdate(k, descs, self.sac, B, fields)
-        # the optimiser steps inside bwd_b / pol_e (rpo_split_update.fold_seg; RPO_FOLD_ADAM=0: the separate prepared
-        # launches -- which data-parallel runs keep: their all-reduce sits between the backward and the step)
-        self._fold = bool(_env_int("RPO_FOLD_ADAM", 1)) and not self.dist.on and hasattr(self._split_cache, "set_fold")
-        self._fold_ws = torch.zeros(hip_ops.FOLD_WS_WORDS, dtype=torch.int64, device=self.device) if self._fold else None
         self._front_cache = bool(_env_int("RPO_FRONT", 1)) and hasattr(be, "front_launch_ok") and be.front_launch_ok(B, self.sac)
         # SpringPendulum: fwd_a + projection + fwd_b + bwd_a as one launch (rpo_split_critic_pfront; RPO_PFRONT=0: fwd_a | project | mid)
         self._pfront = bool(self._front_cache and "proj_ws" in fields and _env_int("RPO_PFRONT", 1) and
@@ -662,19 +657,12 @@ class RPOTrainerBase(object):
         # (only when the critic update runs through the split stages too: its fwd_a is what zeroes the gradmax afterwards)
         prep = bool(fuse_max) and bool(getattr(self, "_pipelines", False))
         optims = [o for o in self._policy_optims() if o is not None] if prep else []
-        fold = prep and self._fold and all(not (o.clip_thres and o.clip_thres != float("inf")) for o in optims[1:])
-        if fold:                                                  # the policy step's optimiser slices inside pol_e's launch
-            su.set_fold(self._actor_segments(gradmax_ready=True), self._fold_ws)
-            optims = []
         su.set_prep2([(o.step_dev, o.betas[0], o.betas[1]) for o in optims])
         su.set(clock_out=self._clock(True) if prep else None, updates_out=self._updates_out)
         su.run("policy_e")
         su.set(clock_out=None, updates_out=None)
-        if fold:
-            su.set_fold([])
         self._updates_out = None
-        self._actor_prepared = prep and not fold
-        self._actor_folded = fold
+        self._actor_prepared = prep
         self._actor_gradmax_stale = prep
         su.set(noise_salt=_SALT_CRITIC, eps_in=None, logp=crit_logp)
         self._actor_gradmax_ready = bool(fuse_max)
@@ -727,7 +715,6 @@ class RPOTrainerBase(object):
         buf = self.buffer
         su.set(idx_in=idx_in, eps_in=eps_in, rows=buf.rows, cap_steps=buf.capacity, n_envs=buf.n_envs)   # (tests swap the ring)
         actor_step, self._iter_actor_step = self._iter_actor_step, None
-        self._fold_actor_step = actor_step
         self._set_hand_overs(su, actor_step)
         ride = self._ride                                       # ridden windows: the next vector step rides along
         if ride is not None:
@@ -772,16 +759,10 @@ class RPOTrainerBase(object):
         su = getattr(self, "_split_cache", None)
         sync = su._held.get("tile_sync") if su else None
         ws = su._held.get("proj_ws") if su else None
-        fw = self._fold_ws
         return (sync[-32:-31] if sync is not None and getattr(self, "_front_cache", False) else None,
-                ws[hip_ops.PROJ_WS_GAVE_UP:hip_ops.PROJ_WS_GAVE_UP + 1] if ws is not None else None,
-                fw[hip_ops.FOLD_WS_GAVE_UP:hip_ops.FOLD_WS_GAVE_UP + 1] if fw is not None else None)
+                ws[hip_ops.PROJ_WS_GAVE_UP:hip_ops.PROJ_WS_GAVE_UP + 1] if ws is not None else None)
 
-    def _raise_handover(self, front, proj, fold=False):
-        if fold:
-            raise RuntimeError("rpo_split_critic_bwd_b / rpo_split_policy_e: a workgroup gave up waiting at the barrier in front "
-                               "of the folded optimiser step (workspace flag set); the parameters of that step are undefined -- "
-                               "rerun with RPO_FOLD_ADAM=0")
+    def _raise_handover(self, front, proj):
         if front:
             raise RuntimeError("rpo_split_*_front: a workgroup gave up waiting for its row tile (tile_sync flag set); the "
                                "values of that launch are undefined -- rerun with RPO_FRONT=0")
@@ -794,8 +775,8 @@ class RPOTrainerBase(object):
         """The fused front launches raise a flag word when a workgroup gave up waiting for its producers (nsplit.hip,
         kNsSpinMax / kPmSpinMax): the values of that launch are then undefined -- fail loudly instead of training on.
         (Synchronising read: harvest, save(), the end of run().)"""
-        f, g, h = self._handover_flags()
-        self._raise_handover(f is not None and int(f[0]) != 0, g is not None and int(g[0]) != 0, h is not None and int(h[0]) != 0)
+        f, g = self._handover_flags()
+        self._raise_handover(f is not None and int(f[0]) != 0, g is not None and int(g[0]) != 0)
 
     def _poll_handover(self):
         """The same without waiting for the device: after every FOURTH graph window the flag words are copied to pinned host
@@ -804,18 +785,18 @@ class RPOTrainerBase(object):
         within a few windows instead of at the next statistics harvest."""
         st = getattr(self, "_handover_poll", None)
         if st is None:
-            f, g, h = self._handover_flags()
-            st = self._handover_poll = dict(flags=[x for x in (f, g, h) if x is not None], event=None, calls=0)
+            f, g = self._handover_flags()
+            st = self._handover_poll = dict(flags=[x for x in (f, g) if x is not None], event=None, calls=0)
             st["host"] = [torch.zeros(1, dtype=x.dtype).pin_memory() for x in st["flags"]]
-            st["which"] = [0 if x is f else (1 if x is g else 2) for x in st["flags"]]
+            st["which"] = [x is f for x in st["flags"]]
         if not st["flags"]:
             return
         if st["event"] is not None:
             if not st["event"].query():
                 return                                            # the previous copy is still in flight: look again later
             st["event"] = None
-            vals = {w: int(h[0]) for w, h in zip(st["which"], st["host"])}
-            self._raise_handover(vals.get(0, 0) != 0, vals.get(1, 0) != 0, vals.get(2, 0) != 0)
+            vals = {bool(w): int(h[0]) for w, h in zip(st["which"], st["host"])}
+            self._raise_handover(vals.get(True, 0) != 0, vals.get(False, 0) != 0)
         st["calls"] += 1
         if st["calls"] % 4 != 1:
             return
@@ -837,14 +818,7 @@ class RPOTrainerBase(object):
             su.run("critic_bwd_a")
         if ride is not None:
             ride.set(defer_clock=int(self._defer_ok))           # ... whose step counter the next update's fwd_a advances
-        fold = self._fold and self._critic_prepared and gm is not None
-        if fold:                                                # the critic's optimiser step inside bwd_b's launch
-            su.set(prep_step=None)
-            su.set_fold([self._critic_segment(self._fold_actor_step)], self._fold_ws)
-            self._critic_prepared, self._critic_folded = False, True
         su.run("critic_bwd_b", rider=ride)                      # + explore / project / step / scatter of every lane
-        if fold:
-            su.set_fold([])
         if ride is not None:
             self._clock_pending = bool(self._defer_ok)
             self.vec.steps_host += 1

@@ -189,12 +189,6 @@ constexpr int kFlWideFrom = 4096;
 __host__ __device__ constexpr int mlp_fl_out(int outputs) { return outputs > kFlWideFrom ? 64 : 16; }
 __host__ __device__ constexpr int mlp_fl_blocks(int outputs) { return (outputs + mlp_fl_out(outputs) - 1) / mlp_fl_out(outputs); }
 
-// A gradient element leaves its owner through an agent-scope store (write-through, `sc1`): launches that step the optimiser
-// behind an in-launch barrier (nsplit.hip, fold_adam) read it from another XCD before the launch ends.
-__device__ __forceinline__ void grad_store(float* dst, float v) {
-    __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 template <int EIN, int OUT>
 __device__ __forceinline__ float mlp_bwd_first_layer_impl(const BwdArgs& p, int fl_block) {
     constexpr int SL = kThreads / OUT, CH = OUT == 16 ? 16 : 8;    // batch slices; rows of loads in flight per slice
@@ -241,7 +235,7 @@ __device__ __forceinline__ float mlp_bwd_first_layer_impl(const BwdArgs& p, int 
         for (int sl = 1; sl < SL; ++sl) tot += fl_partial[sl][o];
         float* dst = (i < width) ? (is_a ? &p.g.Wa[e * net.A + i] : &p.g.Ws[e * net.S + i]) : (is_a ? &p.g.ba[e] : &p.g.bs[e]);
         const float nv = *dst + tot;
-        grad_store(dst, nv);
+        *dst = nv;
         gmax = fabsf(nv);
     }
     return gmax;
@@ -489,20 +483,15 @@ __device__ __forceinline__ float mlp_bwd_weights_body(const BwdArgs& p, int vblo
 
 // max over the workgroup of the gradient magnitudes its threads wrote -> one atomic max into one of the gradmax slots
 // (order independent: exact)
-// (thread 0's return value is the workgroup's maximum)
-__device__ __forceinline__ float gradmax_block(float v) {
+__device__ __forceinline__ void gradmax_flush(float* gradmax, float v) {
     __shared__ float red[kThreads / 64];
+    if (gradmax == nullptr) return;
     v = rpo_wave_max_nonneg(v);                                  // (gradient magnitudes)
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    float m = red[0];
-    for (int w = 1; w < kThreads / 64; ++w) m = fmaxf(m, red[w]);
-    return m;
-}
-__device__ __forceinline__ void gradmax_flush(float* gradmax, float v) {
-    if (gradmax == nullptr) return;
-    const float m = gradmax_block(v);
     if (threadIdx.x == 0) {
+        float m = red[0];
+        for (int w = 1; w < kThreads / 64; ++w) m = fmaxf(m, red[w]);
         // slot (workgroup index) % 16, 64 bytes apart: same-line atomics of a wide launch queue up behind each other
         const unsigned b = blockIdx.x + blockIdx.y * gridDim.x;
         if (m > 0.0f) rpo_atomic_max_nonneg(gradmax + (b % RPO_GRADMAX_SLOTS) * (RPO_GRADMAX_LEN / RPO_GRADMAX_SLOTS), m);

@@ -8,7 +8,6 @@
 #include "heads_dev.h"
 #include "mlp_bwd.h"
 #include "nsplit_dev.h"
-#include "adam_dev.h"
 #include "pendulum_dev.h"
 #include "rollout_env.h"
 
@@ -109,12 +108,6 @@ struct SplitArgs {
     float* part_pol;              // policy step: head partials of pi(s) (pol_a -> pol_b); NULL: part_pi is reused
     unsigned* tile_sync;          // fused front launch: per-tile arrival words (ns_tile_arrive / ns_tile_wait)
     int debug;                    // tests: bit 0 = the policy workgroup (tile 0, group 0) of a fused front withholds its hand-over
-};
-// bwd_b / pol_e: the optimiser step inside the launch (rpo_split_update.fold_seg).  A kernel argument of its own: inside SplitArgs
-// the compiler stopped reading the (then 2.1 KB) struct from the kernarg segment and copied it to scratch first -- and a launch
-// with a private segment costs ~15 us more to dispatch.
-struct FoldArgs {
-    rpo_adam_dev::AdamArgs seg[4]; int count; unsigned long long* ws;
 };
 
 // ---- Hand-over between workgroups of ONE launch (the fused front of the critic update, rpo_split_critic_front).
@@ -769,7 +762,7 @@ __device__ __forceinline__ float ns_dw0_tile(const Mlp& net, float* gW0, const f
     const int r = tid >> 4, c = tid & 15;
     const float nv = cur + (((smem[(0 * 16 + r) * 16 + c] + smem[(1 * 16 + r) * 16 + c]) + smem[(2 * 16 + r) * 16 + c]) +
                             smem[(3 * 16 + r) * 16 + c]);
-    grad_store(dst, nv);
+    *dst = nv;
     return fabsf(nv);
 }
 
@@ -834,12 +827,12 @@ __device__ __forceinline__ float ns_hv_block(const Mlp& net, const MlpGrad& gr, 
         const int o = tid, j = rb * 16 + o;
         const float nb0 = gr.b0[j] + (((partial[0][0][o] + partial[1][0][o]) + partial[2][0][o]) + partial[3][0][o]);
         const float nw1 = gr.W1[j] + (((partial[0][1][o] + partial[1][1][o]) + partial[2][1][o]) + partial[3][1][o]);
-        grad_store(&gr.b0[j], nb0);
-        grad_store(&gr.W1[j], nw1);
+        gr.b0[j] = nb0;
+        gr.W1[j] = nw1;
         gmax = fmaxf(fabsf(nb0), fabsf(nw1));
         if (two) {
             const float nw1b = gr.W1b[j] + (((partial[0][2][o] + partial[1][2][o]) + partial[2][2][o]) + partial[3][2][o]);
-            grad_store(&gr.W1b[j], nw1b);
+            gr.W1b[j] = nw1b;
             gmax = fmaxf(gmax, fabsf(nw1b));
         }
     }
@@ -857,11 +850,11 @@ __device__ __forceinline__ float ns_hv_block(const Mlp& net, const MlpGrad& gr, 
         __syncthreads();
         if (tid == 0) {
             const float nb1 = gr.b1[0] + (((red[0] + red[2]) + red[4]) + red[6]);
-            grad_store(&gr.b1[0], nb1);
+            gr.b1[0] = nb1;
             gmax = fmaxf(gmax, fabsf(nb1));
             if (two) {
                 const float nb1b = gr.b1b[0] + (((red[1] + red[3]) + red[5]) + red[7]);
-                grad_store(&gr.b1b[0], nb1b);
+                gr.b1b[0] = nb1b;
                 gmax = fmaxf(gmax, fabsf(nb1b));
             }
         }
@@ -977,180 +970,15 @@ __device__ __forceinline__ void bwd_b_bookkeeping(const SplitArgs& p) {
     if (p.updates_out) p.updates_out[RPO_CTRL_UPDATES] += 1;
 }
 
-// ---- The optimiser step INSIDE the launch that writes the gradients (rpo_split_update.fold_seg; bwd_b, pol_e).
-// clip_grad_norm_(inf) needs every gradient element before any parameter can move: a barrier across the launch.  Workgroup
-// `lin` of the `nb` participants publishes {tag | largest |gradient| it wrote} in ITS 8-byte granule (one agent-scope store;
-// the gradient elements themselves left through grad_store), polls everyone's granules until they carry this launch's tag
-// (tag = epoch word + 1, advanced by workgroup 0 once it has passed: no granule is ever reset), takes the maximum, and steps
-// the elements [256 lin, 256 lin + 256) (+ 256 nb ...) of every slice -- the arithmetic of adam_body (adam_dev.h), the
-// gradient read with an agent-scope load, the other operands requested while the barrier is still filling.  Workgroup 0 does
-// the bookkeeping of a plain (not "prepared") rpo_adam_step afterwards: nobody reads the step counter after publishing.
-// Nothing depends on placement; a lost workgroup raises the gave-up word after kFoldSpinMax polls instead of hanging.
-#ifndef RPO_FOLD_STRIDE
-#define RPO_FOLD_STRIDE 1
-#endif
-constexpr int kFoldEpoch = 0, kFoldGaveUp = RPO_FOLD_WS_GAVE_UP, kFoldSlot0 = 16, kFoldSpinMax = 1 << 16, kFoldStride = RPO_FOLD_STRIDE;
-static_assert(kFoldSlot0 + RPO_FOLD_MAX_BLOCKS * kFoldStride <= RPO_FOLD_WS_WORDS, "fold workspace");
-
-// slice S of the folded step (a template parameter: the kernel argument is never indexed dynamically -- that would put the
-// whole struct in scratch, and a launch with a private segment costs ~15 us more to dispatch)
-template <int S>
-__device__ __forceinline__ void fold_step(const FoldArgs& f, int count, long long i0, long long stride, float mx,
-                                          const float (&gslot)[4], const int (&step)[4], const int (&cstep)[4],
-                                          const double (&bc1)[4], const double (&bc2)[4], const float (&w0)[4],
-                                          const float (&m0)[4], const float (&v0)[4], const float (&t0)[4], const float (&t20)[4]) {
-    using namespace rpo_adam_dev;
-    if (S >= count) return;
-    const AdamArgs& a = f.seg[S];
-    if (a.polyak_only) {
-        for (long long i = i0; i < a.n; i += stride) {
-            const float t = i == i0 ? t0[S] : a.target[i], w = i == i0 ? w0[S] : a.param[i];
-            a.target[i] = t * (1.0f - a.tau) + w * a.tau;
-        }
-        return;
-    }
-    const AdamCoef k = adam_coefs_at(a, S == 0 ? fmaxf(mx, gslot[S]) : gslot[S], step[S], cstep[S], bc1[S], bc2[S]);
-    for (long long i = i0; i < a.n; i += stride) {
-        float w = w0[S], m = m0[S], vv = v0[S], t = t0[S], t2 = t20[S];
-        if (i != i0) {
-            w = a.param[i]; m = a.m[i]; vv = a.v[i];
-            t = a.target ? a.target[i] : 0.0f;
-            t2 = (a.target2 && i < a.n2) ? a.target2[i] : 0.0f;
-        }
-        const float g = __hip_atomic_load(&a.grad[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        adam_elem(a, k, i, g, w, m, vv, t, t2);
-    }
-}
-
-template <int S>
-__device__ __forceinline__ void fold_read_state(const FoldArgs& f, int count, int (&step)[4], int (&cstep)[4], double (&bc1)[4],
-                                                double (&bc2)[4], float (&gslot)[4]) {
-    step[S] = cstep[S] = 0; bc1[S] = bc2[S] = 0.0; gslot[S] = 0.0f;
-    if (S < count && !f.seg[S].polyak_only) {
-        const rpo_adam_dev::AdamArgs& a = f.seg[S];
-        step[S] = a.step_dev[0] + 1;
-        cstep[S] = a.step_dev[1];
-        const double* cache = reinterpret_cast<const double*>(a.step_dev + 4);
-        bc1[S] = cache[0]; bc2[S] = cache[1];
-        if (a.clip_thres > 0.0f && a.gradmax) {
-#pragma unroll
-            for (int j = 0; j < RPO_GRADMAX_SLOTS; ++j) gslot[S] = fmaxf(gslot[S], a.gradmax[j * (RPO_GRADMAX_LEN / RPO_GRADMAX_SLOTS)]);
-        }
-    }
-}
-
-template <int S>
-__device__ __forceinline__ void fold_request(const FoldArgs& f, int count, long long i0, float (&w0)[4], float (&m0)[4],
-                                             float (&v0)[4], float (&t0)[4], float (&t20)[4]) {
-    w0[S] = m0[S] = v0[S] = t0[S] = t20[S] = 0.0f;
-    if (S < count && i0 < f.seg[S].n) {
-        const rpo_adam_dev::AdamArgs& a = f.seg[S];
-        w0[S] = a.param[i0];
-        if (a.target) t0[S] = a.target[i0];
-        if (!a.polyak_only) {
-            m0[S] = a.m[i0]; v0[S] = a.v[i0];
-            if (a.target2 && i0 < a.n2) t20[S] = a.target2[i0];
-        }
-    }
-}
-
-__device__ __forceinline__ void fold_adam(const FoldArgs& f, int lin, int nb, float v) {
-    using namespace rpo_adam_dev;
-    __shared__ float fold_red[kThreads / 64];
-    const int tid = threadIdx.x, count = f.count;
-    unsigned long long* ws = f.ws;
-    // -- what later writers of THIS launch change (workgroup 0's bookkeeping): read before publishing
-    const unsigned tag = (unsigned)ws[kFoldEpoch] + 1u;
-    int step[4], cstep[4];
-    double bc1[4], bc2[4];
-    float gslot[4];
-    fold_read_state<0>(f, count, step, cstep, bc1, bc2, gslot);
-    fold_read_state<1>(f, count, step, cstep, bc1, bc2, gslot);
-    fold_read_state<2>(f, count, step, cstep, bc1, bc2, gslot);
-    fold_read_state<3>(f, count, step, cstep, bc1, bc2, gslot);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the loads above and this thread's gradient stores are complete
-    const float mine = gradmax_block(v);                         // (__syncthreads: ... and every other thread's of the workgroup)
-    if (tid == 0)
-        __hip_atomic_store(&ws[kFoldSlot0 + lin * kFoldStride], ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(mine),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // -- operands nobody else writes: requested now, they arrive while the barrier fills
-    const long long i0 = (long long)lin * kThreads + tid, stride = (long long)nb * kThreads;
-    float w0[4], m0[4], v0[4], t0[4], t20[4];
-    fold_request<0>(f, count, i0, w0, m0, v0, t0, t20);
-    fold_request<1>(f, count, i0, w0, m0, v0, t0, t20);
-    fold_request<2>(f, count, i0, w0, m0, v0, t0, t20);
-    fold_request<3>(f, count, i0, w0, m0, v0, t0, t20);
-    // -- the barrier
-    float mx = 0.0f;
-    for (int spin = 0;; ++spin) {
-#ifdef RPO_FOLD_NOWAIT
-        break;
-#endif
-        bool ok = true;
-        mx = 0.0f;
-        for (int b = tid; b < nb; b += kThreads) {
-            const unsigned long long g = __hip_atomic_load(&ws[kFoldSlot0 + b * kFoldStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)(g >> 32) != tag) ok = false;
-            else mx = fmaxf(mx, __uint_as_float((unsigned)g));
-        }
-        if (__syncthreads_and(ok)) break;
-        if (spin >= kFoldSpinMax) {                              // (uniform) a lost workgroup: loud, not a hang
-            if (tid == 0) __hip_atomic_store(&ws[kFoldGaveUp], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-    }
-    mx = rpo_wave_max_nonneg(mx);
-    if ((tid & 63) == 0) fold_red[tid >> 6] = mx;
-    __syncthreads();
-    mx = fold_red[0];
-#pragma unroll
-    for (int w = 1; w < kThreads / 64; ++w) mx = fmaxf(mx, fold_red[w]);
-    // -- the step
-    fold_step<0>(f, count, i0, stride, mx, gslot, step, cstep, bc1, bc2, w0, m0, v0, t0, t20);
-    fold_step<1>(f, count, i0, stride, mx, gslot, step, cstep, bc1, bc2, w0, m0, v0, t0, t20);
-    fold_step<2>(f, count, i0, stride, mx, gslot, step, cstep, bc1, bc2, w0, m0, v0, t0, t20);
-    fold_step<3>(f, count, i0, stride, mx, gslot, step, cstep, bc1, bc2, w0, m0, v0, t0, t20);
-    // -- bookkeeping (workgroup 0 has seen everyone's granule: nobody reads the words below any more in this launch)
-    if (lin == 0 && tid < count) {
-        // (selected field by field: indexing the kernel argument with a thread index would put the whole struct in scratch)
-        int* sd = nullptr; float b1 = 0.0f, b2 = 0.0f; float* gmx = nullptr;
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            if (tid == s && !f.seg[s].polyak_only) {
-                sd = f.seg[s].step_dev; b1 = f.seg[s].beta1; b2 = f.seg[s].beta2;
-                gmx = f.seg[s].reset_gradmax ? f.seg[s].gradmax : nullptr;
-            }
-        if (sd) {
-            const int st = sd[0] + 1;
-            double* cache = reinterpret_cast<double*>(sd + 4);
-            sd[0] = st;
-            cache[0] = 1.0 - pow((double)b1, (double)(st + 1));
-            cache[1] = sqrt(1.0 - pow((double)b2, (double)(st + 1)));
-            sd[1] = st + 1;
-            if (gmx)
-                for (int j = 0; j < RPO_GRADMAX_SLOTS; ++j) gmx[j * (RPO_GRADMAX_LEN / RPO_GRADMAX_SLOTS)] = 0.0f;
-        }
-    }
-    if (lin == 0 && tid == 0) ws[kFoldEpoch] = (unsigned long long)tag;
-}
-
-// The largest |gradient| of the workgroup goes to the gradmax slots -- or, with a folded optimiser step, through the barrier.
-__device__ __forceinline__ void grads_done(const SplitArgs& p, const FoldArgs& f, int lin, int nb, float v) {
-    if (f.count > 0) fold_adam(f, lin, nb, v);
-    else gradmax_flush(p.gradmax, v);
-}
-
 // own blocks: [0, kWeightBlocks) weight roles | first-layer blocks | (k == 0, when asked for) one bookkeeping block
 template <class L>
-__device__ __forceinline__ void bwd_b_role(const SplitArgs& p, const FoldArgs& f, float* smem, int bx, int k, int own_blocks) {
-    const int lin = k * own_blocks + bx, nb = own_blocks * (p.twin ? 2 : 1);
+__device__ __forceinline__ void bwd_b_role(const SplitArgs& p, float* smem, int bx, int k, int own_blocks) {
     if ((p.prep_step || p.clock_out || p.updates_out) && bx == own_blocks - 1) {
         if (k == 0) bwd_b_bookkeeping(p);
-        if (f.count > 0) fold_adam(f, lin, nb, 0.0f);
         return;
     }
     if (bx < kWeightBlocks) {
-        grads_done(p, f, lin, nb, ns_weight_role(p.critic[k], p.critic_grad[k], p.h1[k], p.x0[k], p.dq[k], 1, false, p.B, bx, smem));
+        gradmax_flush(p.gradmax, ns_weight_role(p.critic[k], p.critic_grad[k], p.h1[k], p.x0[k], p.dq[k], 1, false, p.B, bx, smem));
         return;
     }
     BwdArgs a{};
@@ -1162,22 +990,22 @@ __device__ __forceinline__ void bwd_b_role(const SplitArgs& p, const FoldArgs& f
     a.dx0 = p.dx0[k];
     a.param_grads = 1;
     a.first_layer_state_only = 0;
-    grads_done(p, f, lin, nb, mlp_bwd_first_layer<128>(a, bx - kWeightBlocks));
+    gradmax_flush(p.gradmax, mlp_bwd_first_layer<128>(a, bx - kWeightBlocks));
 }
 
 template <class L>
-__global__ __launch_bounds__(kThreads) void split_critic_bwd_b_kernel(SplitArgs p, FoldArgs f) {
+__global__ __launch_bounds__(kThreads) void split_critic_bwd_b_kernel(SplitArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[4 * 16 * 16];
-    bwd_b_role<L>(p, f, smem, blockIdx.x, blockIdx.y, gridDim.x);
+    bwd_b_role<L>(p, smem, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 // bwd_b + explore / project / step / scatter of the lanes: grid (own_blocks + lane blocks, K); the extra x-blocks of plane 0
 // step 256 lanes each (those of plane 1 leave at once)
 template <class L>
 __global__ __launch_bounds__(kThreads) void split_critic_bwd_b_ride_kernel(SplitArgs p, CartConsts c, RideArgs<typename L::Env> r,
-                                                                           int own_blocks, FoldArgs f) {
+                                                                           int own_blocks) {
     __shared__ __attribute__((aligned(16))) float smem[4 * 16 * 16];
-    if ((int)blockIdx.x < own_blocks) bwd_b_role<L>(p, f, smem, blockIdx.x, blockIdx.y, own_blocks);
+    if ((int)blockIdx.x < own_blocks) bwd_b_role<L>(p, smem, blockIdx.x, blockIdx.y, own_blocks);
     else if (blockIdx.y == 0) ride_tail<typename L::Env>(r, c, smem, blockIdx.x - own_blocks, gridDim.x - own_blocks);
 }
 
@@ -1923,12 +1751,12 @@ __global__ __launch_bounds__(kThreads) void split_policy_front_kernel(SplitArgs 
 //      gradients (left by pol_d) and the saved activations; then the first-layer gradients from dx0_a; one more workgroup
 //      folds the Lagrangian partials (value, d/d nu).
 template <class ENV>
-__global__ __launch_bounds__(kThreads) void split_policy_e_kernel(SplitArgs p, int fl_blocks, FoldArgs f) {
+__global__ __launch_bounds__(kThreads) void split_policy_e_kernel(SplitArgs p, int fl_blocks) {
     typedef typename ENV::L L;
     __shared__ __attribute__((aligned(16))) float smem[4 * 16 * 16];
-    const int lin = blockIdx.x, nb = gridDim.x;
     if (blockIdx.x < kWeightBlocks) {
-        grads_done(p, f, lin, nb, ns_weight_role(p.actor, p.actor_grad, p.h1_a, p.x0_a, p.dout, 2, p.actor.n_out > 1, p.B, blockIdx.x, smem));
+        gradmax_flush(p.gradmax, ns_weight_role(p.actor, p.actor_grad, p.h1_a, p.x0_a, p.dout, 2, p.actor.n_out > 1, p.B,
+                                                blockIdx.x, smem));
         return;
     }
     const int fb = blockIdx.x - kWeightBlocks;
@@ -1940,13 +1768,12 @@ __global__ __launch_bounds__(kThreads) void split_policy_e_kernel(SplitArgs p, i
             const float inv_b = 1.0f / (float)p.B;
             if (tid == 0) p.lag_out[0] = inv_b * sacc;
             else if (tid == 7) { if (!p.twin) p.lag_out[1] = inv_b * sacc; }
-            else if (tid - 1 < ENV::NI) grad_store(&p.nu_grad[tid - 1], p.nu_grad[tid - 1] + inv_b * sacc);
+            else if (tid - 1 < ENV::NI) p.nu_grad[tid - 1] += inv_b * sacc;
         }
         // bookkeeping for the rpo_adam_step_multi(prepared) launch behind the policy step (nothing in this launch reads it)
         if (tid >= 64 && tid < 67 && p.prep2_step[tid - 64]) adam_prepare(p.prep2_step[tid - 64], p.prep2_beta1[tid - 64], p.prep2_beta2[tid - 64]);
         if (tid == 128 && p.clock_out) p.clock_out[0] += 1;
         if (tid == 192 && p.updates_out) p.updates_out[RPO_CTRL_UPDATES] += 1;
-        if (f.count > 0) fold_adam(f, lin, nb, 0.0f);             // (the multiplier gradients are not clipped)
         return;
     }
     BwdArgs a{};
@@ -1956,7 +1783,7 @@ __global__ __launch_bounds__(kThreads) void split_policy_e_kernel(SplitArgs p, i
     a.s = p.batch_out; a.s_stride = L::ROW;
     a.dx0 = p.dx0_a;
     a.param_grads = 1;
-    grads_done(p, f, lin, nb, mlp_bwd_first_layer<128>(a, fb));
+    gradmax_flush(p.gradmax, mlp_bwd_first_layer<128>(a, fb));
 }
 
 }  // namespace
@@ -1966,31 +1793,6 @@ namespace {
 MlpGrad grad_dev(const rpo_mlp_grad* g) {
     if (!g) return MlpGrad{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     return MlpGrad{g->Ws, g->bs, g->Wa, g->ba, g->W0, g->b0, g->W1, g->b1, g->W1b, g->b1b};
-}
-
-// The folded optimiser step of bwd_b / pol_e (rpo_split_update.fold_seg); `blocks`: the launch's barrier participants.
-int to_fold(const rpo_split_update* u, int blocks, FoldArgs& f) {
-    f = FoldArgs{};
-    if (u->fold_count == 0) return 0;
-    if (u->fold_count < 0 || u->fold_count > 4 || blocks > RPO_FOLD_MAX_BLOCKS) return RPO_ERR_ARG;
-    if (!u->fold_ws) return RPO_ERR_NULL;
-    for (int s = 0; s < u->fold_count; ++s) {
-        const rpo_adam_seg& g = u->fold_seg[s];
-        if (g.n <= 0 || g.n2 < 0 || g.n2 > g.n) return RPO_ERR_ARG;
-        if (!g.param) return RPO_ERR_NULL;
-        if (g.polyak_only) {
-            if (!g.target) return RPO_ERR_NULL;
-        } else {
-            if (!g.grad || !g.exp_avg || !g.exp_avg_sq || !g.step_dev) return RPO_ERR_NULL;
-            if (s > 0 && g.clip_thres > 0.0f) return RPO_ERR_ARG;              // the barrier carries slice 0's norm only
-        }
-        f.seg[s] = rpo_adam_dev::AdamArgs{g.n, g.param, g.grad, g.exp_avg, g.exp_avg_sq, g.step_dev, g.lr, g.beta1, g.beta2,
-                                          g.eps, g.weight_decay, g.maximize, g.clip_thres, g.gradmax, g.reset_gradmax,
-                                          g.zero_grad, g.clamp_min0, g.target, g.tau, nullptr, g.target2, g.n2,
-                                          g.polyak_only, nullptr, 0};
-    }
-    f.count = u->fold_count; f.ws = u->fold_ws;
-    return 0;
 }
 
 // Resolve and validate the parts of rpo_split_update a stage needs.  need: bit 0 policy net, 1 critics, 2 target
@@ -2282,10 +2084,8 @@ int rpo_split_critic_bwd_b(const rpo_split_update* u, void* stream) {
         if (!a.dx0[k] || !a.dq[k] || !a.x0[k] || !a.h1[k]) return RPO_ERR_NULL;
     const Mlp& m = a.critic[0];
     const int blocks = kWeightBlocks + mlp_fl_blocks(m.E * (m.S + 1 + m.A + 1)) + ((a.prep_step || a.clock_out || a.updates_out) ? 1 : 0);
-    FoldArgs f;
-    if (int e = to_fold(u, blocks * K, f)) return e;
-    if (u->env == 0) hipLaunchKernelGGL(split_critic_bwd_b_kernel<CartRow>, dim3(blocks, K), dim3(kThreads), 0, (hipStream_t)stream, a, f);
-    else hipLaunchKernelGGL(split_critic_bwd_b_kernel<PendRow>, dim3(blocks, K), dim3(kThreads), 0, (hipStream_t)stream, a, f);
+    if (u->env == 0) hipLaunchKernelGGL(split_critic_bwd_b_kernel<CartRow>, dim3(blocks, K), dim3(kThreads), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(split_critic_bwd_b_kernel<PendRow>, dim3(blocks, K), dim3(kThreads), 0, (hipStream_t)stream, a);
     RPO_LAUNCH_CHECK();
     return 0;
 }
@@ -2442,14 +2242,12 @@ int rpo_split_critic_bwd_b_ride(const rpo_split_update* u, const rpo_rollout_rid
     const Mlp& m = a.critic[0];
     const int own = kWeightBlocks + mlp_fl_blocks(m.E * (m.S + 1 + m.A + 1)) + ((a.prep_step || a.clock_out || a.updates_out) ? 1 : 0);
     const dim3 grid(own + (r->n_envs + kThreads - 1) / kThreads, K);
-    FoldArgs f;
-    if (int e = to_fold(u, own * K, f)) return e;
     if (u->env == 0)
         hipLaunchKernelGGL(split_critic_bwd_b_ride_kernel<CartRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c,
-                           ride_args<CartEnv>(a, r), own, f);
+                           ride_args<CartEnv>(a, r), own);
     else
         hipLaunchKernelGGL(split_critic_bwd_b_ride_kernel<PendRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c,
-                           ride_args<PendEnv>(a, r), own, f);
+                           ride_args<PendEnv>(a, r), own);
     RPO_LAUNCH_CHECK();
     return 0;
 }
@@ -2540,10 +2338,8 @@ int rpo_split_policy_e(const rpo_split_update* u, void* stream) {
     if (int e = to_args(u, 32u | 16u, a, c)) return e;
     if (!a.batch_out || !a.dx0_a || !a.lag_partial || !a.lag_out || !a.nu_grad || !a.dout || !a.x0_a || !a.h1_a) return RPO_ERR_NULL;
     const int fl_blocks = mlp_fl_blocks(a.actor.E * (a.actor.S + 1));
-    FoldArgs f;
-    if (int e = to_fold(u, kWeightBlocks + fl_blocks + 1, f)) return e;
-    if (u->env == 0) hipLaunchKernelGGL(split_policy_e_kernel<CartPol>, dim3(kWeightBlocks + fl_blocks + 1), dim3(kThreads), 0, (hipStream_t)stream, a, fl_blocks, f);
-    else hipLaunchKernelGGL(split_policy_e_kernel<PendPol>, dim3(kWeightBlocks + fl_blocks + 1), dim3(kThreads), 0, (hipStream_t)stream, a, fl_blocks, f);
+    if (u->env == 0) hipLaunchKernelGGL(split_policy_e_kernel<CartPol>, dim3(kWeightBlocks + fl_blocks + 1), dim3(kThreads), 0, (hipStream_t)stream, a, fl_blocks);
+    else hipLaunchKernelGGL(split_policy_e_kernel<PendPol>, dim3(kWeightBlocks + fl_blocks + 1), dim3(kThreads), 0, (hipStream_t)stream, a, fl_blocks);
     RPO_LAUNCH_CHECK();
     return 0;
 }

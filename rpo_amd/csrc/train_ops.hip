@@ -4,7 +4,6 @@
 // All are single-pass streaming kernels with wave64 shuffle reductions.
 #include "common.h"
 #include "heads_dev.h"
-#include "adam_dev.h"
 
 namespace {
 
@@ -68,8 +67,30 @@ __global__ __launch_bounds__(RPO_BLOCK) void absmax_kernel(long long n, const fl
 }
 
 // -------------------------------------------------------------------------------------- clip + Adam + Polyak
-// (AdamArgs, adam_coefs, adam_elem: adam_dev.h -- shared with the update launches that step their own gradients)
-using namespace rpo_adam_dev;
+struct AdamArgs {
+    long long n;
+    float* param;
+    float* grad;
+    float* m;
+    float* v;
+    int* step_dev;
+    float lr, beta1, beta2, eps, weight_decay;
+    int maximize;
+    float clip_thres;
+    float* gradmax;
+    int reset_gradmax;
+    int zero_grad;
+    int clamp_min0;
+    float* target;
+    float tau;
+    long long* arrive;   // scratch word for the "last workgroup" epilogue (step counter / gradmax reset)
+    float* target2;      // second Polyak target for elements [0, n2)
+    long long n2;
+    int polyak_only;
+    long long* clock;    // NULL, or a device counter advanced by one when the launch has finished (update clock)
+    int prepared;        // 1: the launch before this one advanced step_dev[0] / cached the corrections (rpo_adam_prepare
+                         //    semantics, see rpo_hip.h): no bookkeeping here, hence no last-workgroup detection at all
+};
 
 __device__ __forceinline__ void adam_body(const AdamArgs& p) {
     if (p.polyak_only) {
@@ -93,18 +114,45 @@ __device__ __forceinline__ void adam_body(const AdamArgs& p) {
 #pragma unroll
         for (int j = 0; j < RPO_GRADMAX_SLOTS; ++j) gm = fmaxf(gm, p.gradmax[j * (RPO_GRADMAX_LEN / RPO_GRADMAX_SLOTS)]);
     }
-    const AdamCoef k = adam_coefs(p, gm);
+    // torch.optim.Adam (single-tensor path): bias corrections in double like torch's Python floats.  The two double-
+    // precision pow() calls are ~1 us of every thread's critical path, so the workgroup that finishes a step last leaves
+    // the corrections of the NEXT step behind the arrival word (step_dev + 4: {1 - beta1^t, sqrt(1 - beta2^t)} as doubles,
+    // 0.0 = not cached yet): same functions, same arguments, same bits -- computed once instead of 34 000 times.
+    const int step = p.prepared ? p.step_dev[0] : p.step_dev[0] + 1;
+    double* cache = reinterpret_cast<double*>(p.step_dev + 4);
+    double bc1 = cache[0], bc2s = cache[1];
+    if (bc1 == 0.0 || p.step_dev[1] != step) {                  // step_dev[1]: the step the cached corrections belong to
+        bc1 = 1.0 - pow((double)p.beta1, (double)step);
+        bc2s = sqrt(1.0 - pow((double)p.beta2, (double)step));
+    }
+    const float step_size = (float)((double)p.lr / bc1);
+    const float bc2_sqrt = (float)bc2s;
+    // clip_grad_norm_(..., norm_type=inf): clip_coef clamped to 1, always applied
+    const float coef = p.clip_thres > 0.0f ? fminf(p.clip_thres / (gm + 1e-6f), 1.0f) : 1.0f;
+    const float omb1 = 1.0f - p.beta1, omb2 = 1.0f - p.beta2;
     for (long long i = i0; i < p.n; i += stride) {
         if (i != i0) {
             g0 = p.grad[i]; w0 = p.param[i]; m0 = p.m[i]; v0 = p.v[i];
             if (p.target) t0 = p.target[i];
             if (p.target2 && i < p.n2) t20 = p.target2[i];
         }
-        adam_elem(p, k, i, g0, w0, m0, v0, t0, t20);
+        float g = g0 * coef;
+        if (p.zero_grad) p.grad[i] = 0.0f;            // the gradient is consumed: the next backward accumulates from zero
+        else if (p.clip_thres > 0.0f) p.grad[i] = g;  // clip_grad_norm_ scales the gradients in place
+        if (p.maximize) g = -g;
+        float w = w0;
+        if (p.weight_decay != 0.0f) g += p.weight_decay * w;
+        float m = m0, v = v0;
+        m = m + (g - m) * omb1;                       // exp_avg.lerp_(grad, 1 - beta1)
+        v = v * p.beta2 + omb2 * g * g;               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float denom = sqrtf(v) / bc2_sqrt + p.eps;
+        w = w - step_size * (m / denom);              // param.addcdiv_(exp_avg, denom, value=-step_size)
+        if (p.clamp_min0) w = fmaxf(w, 0.0f);         // DualAdam, model/dual.py:41-43
+        p.param[i] = w; p.m[i] = m; p.v[i] = v;
+        if (p.target) p.target[i] = t0 * (1.0f - p.tau) + w * p.tau;   // soft_update, ddpg_pa.py:77-86
+        if (p.target2 && i < p.n2) p.target2[i] = t20 * (1.0f - p.tau) + w * p.tau;
     }
     if (p.prepared) return;
-    const int step = p.step_dev[0] + 1;
-    double* cache = reinterpret_cast<double*>(p.step_dev + 4);
     __syncthreads();
     if (threadIdx.x == 0) {
         // last workgroup of the launch: two-level arrival (sub-counter b % 16, then the top word) once the grid is wide

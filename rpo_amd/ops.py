@@ -24,8 +24,6 @@ STATS_SUB = CONST["RPO_STATS_SUB"]
 CTRL_LEN = CONST["RPO_CTRL_LEN"]
 PROJ_WS_WORDS = CONST["RPO_PROJ_WS_WORDS"]
 PROJ_WS_GAVE_UP = CONST["RPO_PROJ_WS_GAVE_UP"]
-FOLD_WS_WORDS = CONST["RPO_FOLD_WS_WORDS"]
-FOLD_WS_GAVE_UP = CONST["RPO_FOLD_WS_GAVE_UP"]
 STAT = {k[len("RPO_STAT_"):].lower(): v for k, v in CONST.items()
         if k.startswith("RPO_STAT_") and k not in ("RPO_STATS_LEN", "RPO_STATS_SUB")}
 
@@ -148,32 +146,26 @@ class _AdamSegStruct(ctypes.Structure):
                 ("prepared", ctypes.c_int)]
 
 
-def _fill_adam_seg(a, g, prepared=False):
-    """One rpo_adam_seg from a ``FusedAdam.segment()`` dict (or ``dict(polyak_only=True, param=, target=, tau=)``)."""
-    vp = lambda t, dt=torch.float32: None if t is None else _p(t, dt).value                      # noqa: E731
-    a.n, a.param, a.tau = g["param"].numel(), vp(g["param"]), g.get("tau", 0.0)
-    a.target, a.target2, a.n2 = vp(g.get("target")), vp(g.get("target2")), int(g.get("n2", 0))
-    a.polyak_only = int(bool(g.get("polyak_only", False)))
-    if a.polyak_only:
-        a.grad = a.exp_avg = a.exp_avg_sq = a.step_dev = a.gradmax = None
-        return
-    a.grad, a.exp_avg, a.exp_avg_sq = vp(g["grad"]), vp(g["exp_avg"]), vp(g["exp_avg_sq"])
-    if g["step_dev"].numel() < CONST["RPO_ADAM_STATE_LEN"]:
-        raise RpoHipError("step_dev must be int32[RPO_ADAM_STATE_LEN] (include/rpo_hip.h)")
-    a.step_dev = vp(g["step_dev"], torch.int32)
-    a.lr, a.beta1, a.beta2, a.eps = g["lr"], g.get("beta1", 0.9), g.get("beta2", 0.999), g.get("eps", 1e-8)
-    a.weight_decay, a.maximize, a.clip_thres = g.get("weight_decay", 0.0), int(g.get("maximize", False)), g.get("clip_thres", 0.0)
-    a.gradmax, a.reset_gradmax = vp(g.get("gradmax")), int(g.get("reset_gradmax", True))
-    a.zero_grad, a.clamp_min0 = int(g.get("zero_grad", False)), int(g.get("clamp_min0", False))
-    a.prepared = int(bool(prepared))
-
-
 def adam_step_multi(segs, clock=None, prepared=False):
     """One launch for up to four non-overlapping optimiser slices (rpo_adam_step_multi).  Each entry is a dict with the
     keyword arguments of ``adam_step`` (+ ``target2`` / ``n2``), or ``dict(polyak_only=True, param=, target=, tau=)``."""
     arr = (_AdamSegStruct * len(segs))()
+    vp = lambda t, dt=torch.float32: None if t is None else _p(t, dt).value                      # noqa: E731
     for a, g in zip(arr, segs):
-        _fill_adam_seg(a, g, prepared)
+        a.n, a.param, a.tau = g["param"].numel(), vp(g["param"]), g.get("tau", 0.0)
+        a.target, a.target2, a.n2 = vp(g.get("target")), vp(g.get("target2")), int(g.get("n2", 0))
+        a.polyak_only = int(bool(g.get("polyak_only", False)))
+        if a.polyak_only:
+            continue
+        a.grad, a.exp_avg, a.exp_avg_sq = vp(g["grad"]), vp(g["exp_avg"]), vp(g["exp_avg_sq"])
+        if g["step_dev"].numel() < CONST["RPO_ADAM_STATE_LEN"]:
+            raise RpoHipError("step_dev must be int32[RPO_ADAM_STATE_LEN] (include/rpo_hip.h)")
+        a.step_dev = vp(g["step_dev"], torch.int32)
+        a.lr, a.beta1, a.beta2, a.eps = g["lr"], g.get("beta1", 0.9), g.get("beta2", 0.999), g.get("eps", 1e-8)
+        a.weight_decay, a.maximize, a.clip_thres = g.get("weight_decay", 0.0), int(g.get("maximize", False)), g.get("clip_thres", 0.0)
+        a.gradmax, a.reset_gradmax = vp(g.get("gradmax")), int(g.get("reset_gradmax", True))
+        a.zero_grad, a.clamp_min0 = int(g.get("zero_grad", False)), int(g.get("clamp_min0", False))
+        a.prepared = int(bool(prepared))
     check(_lib.load().rpo_adam_step_multi(len(segs), arr, _p(clock, torch.int64, allow_none=True), _stream()),
           "rpo_adam_step_multi")
 
@@ -782,8 +774,7 @@ class _SplitUpdateStruct(ctypes.Structure):
          ("prep_beta2", ctypes.c_float), ("clock_out", ctypes.c_void_p), ("gradmax_reset", ctypes.c_void_p),
          ("prep2_step", ctypes.c_void_p * 3), ("prep2_beta1", ctypes.c_float * 3), ("prep2_beta2", ctypes.c_float * 3),
          ("gradmax_reset2", ctypes.c_void_p), ("updates_out", ctypes.c_void_p), ("part_pol", ctypes.c_void_p),
-         ("tile_sync", ctypes.c_void_p), ("proj_ws", ctypes.c_void_p), ("proj_store_mode", ctypes.c_int), ("debug", ctypes.c_int),
-         ("fold_seg", _AdamSegStruct * 4), ("fold_count", ctypes.c_int), ("fold_ws", ctypes.c_void_p)])
+         ("tile_sync", ctypes.c_void_p), ("proj_ws", ctypes.c_void_p), ("proj_store_mode", ctypes.c_int), ("debug", ctypes.c_int)])
 
 
 class _RolloutRiderStruct(ctypes.Structure):
@@ -876,20 +867,6 @@ class SplitUpdate(object):
                 self.st.prep2_beta1[j], self.st.prep2_beta2[j] = optims[j][1], optims[j][2]
             else:
                 self.st.prep2_step[j] = None
-
-    def set_fold(self, segs, ws=None):
-        """The optimiser step folded into the NEXT critic_bwd_b / policy_e launch (rpo_split_update.fold_seg): ``segs`` as for
-        ``adam_step_multi`` (at most four), ``ws`` the zero-initialised int64[FOLD_WS_WORDS] workspace; ``segs`` empty: none."""
-        segs = list(segs or ())
-        if len(segs) > 4:
-            raise RpoHipError("at most four folded optimiser slices")
-        self._held["fold"] = [[v for v in g.values() if isinstance(v, torch.Tensor)] for g in segs]
-        for a, g in zip(self.st.fold_seg, segs):
-            _fill_adam_seg(a, g)
-        self.st.fold_count = len(segs)
-        if segs:
-            self._held["fold_ws"] = ws
-            self.st.fold_ws = _p(ws, torch.int64).value
 
     def run(self, stage, rider=None):
         """``rider``: a RolloutRider whose share of the next vector step rides on this launch (critic_fwd_a / critic_fwd_b:

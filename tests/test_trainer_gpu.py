@@ -673,43 +673,6 @@ def test_fused_front_launch_equals_separate_launches(hip, algo, envname, shared,
     assert int(sync.abs().sum()) == 0
 
 
-@pytest.mark.parametrize("algo,envname,shared,ride", [
-    ("ddpg", "cart", True, "0"), ("ddpg", "cart", False, "1"), ("sac", "cart", False, "1"), ("sac", "cart", False, "0"),
-    ("sac", "pendulum", False, "1"), ("ddpg", "pendulum", True, "0")])
-def test_folded_optimiser_steps_equal_separate_launches(hip, algo, envname, shared, ride, monkeypatch):
-    """The optimiser steps inside bwd_b / pol_e (rpo_split_update.fold_seg: a barrier across the launch carries the inf-norm,
-    its workgroups step 256-element blocks) leave the same bits as the prepared rpo_adam_step / rpo_adam_step_multi launches
-    behind them -- parameters, moments, step counters, Polyak targets, multipliers --, eagerly and replayed from graph windows,
-    with and without the riding rollout; no workgroup ever gives up at the barrier."""
-    dev = torch.device("cuda")
-    monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
-    monkeypatch.setenv("RPO_RIDE", ride)
-    extra = dict(shared_param=shared) if algo == "ddpg" else {}
-    runs = {}
-    for fold in ("0", "1"):
-        monkeypatch.setenv("RPO_FOLD_ADAM", fold)
-        for graph in (False, True):
-            runs[fold, graph] = _run(algo, envname, hip, dev, 45, 300, use_graph=graph, **extra)
-    a = runs["0", False]
-    assert not a._fold and runs["1", True]._fold
-    for key in (("1", False), ("1", True), ("0", True)):
-        b = runs[key]
-        assert torch.equal(a.agent.flat.data, b.agent.flat.data), key
-        assert torch.equal(a.agent.flat.grad, b.agent.flat.grad), key
-        assert torch.equal(a.agent.critic_target_flat, b.agent.critic_target_flat), key
-        for opt in ("critic_optim", "actor_optim", "nju_optim"):
-            oa, ob = getattr(a.agent, opt), getattr(b.agent, opt)
-            assert torch.equal(oa.exp_avg, ob.exp_avg) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq), (key, opt)
-            assert int(oa.step_dev[0]) == int(ob.step_dev[0]) > 0, (key, opt)
-        assert torch.equal(a.agent.nju.weight, b.agent.nju.weight), key
-        assert torch.equal(a.buffer.rows, b.buffer.rows) and torch.equal(a.vec.internal, b.vec.internal), key
-        assert float(a.last_losses["critic"]) == float(b.last_losses["critic"]), key
-    for key in (("1", False), ("1", True)):
-        ws = runs[key]._fold_ws
-        assert int(ws[0]) > 40 and int(ws[1]) == 0, (key, ws[:2])      # epochs counted, nobody gave up
-        runs[key]._check_tile_sync()
-
-
 @pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "cart")])
 def test_tail_windows_equal_eager(hip, algo, envname, monkeypatch):
     """RPO_TAIL_WINDOWS=1: the last < RPO_GRAPH_CYCLE iterations of a run_steps call are one shorter graph window (whole
