@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["cartsafe.hip", "pendulum.hip", "evopf.hip", "replay.hip", "train_ops.hip", "mlp.hip", "fused.hip", "nsplit.hip"]
-HEADERS = ["common.h", "mlp_tile.h", "mlp_bwd.h", "mlp_gemm.h", "nsplit_dev.h", "rollout_env.h", "cartsafe_dev.h", "pendulum_dev.h", "heads_dev.h", "evopf_dev.h", os.path.join("..", "..", "include", "rpo_hip.h")]
+HEADERS = sorted(f for f in os.listdir(HERE) if f.endswith(".h")) + [os.path.join("..", "..", "include", "rpo_hip.h")]   # (every header: a stale object is worse than a rebuild)
 TARGET = os.path.join(HERE, "librpo_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("HIPCC_EXTRA", "").split()
