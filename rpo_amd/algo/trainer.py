@@ -116,10 +116,13 @@ class _GraphCache(object):
     """Eager for the first ``warm`` calls of a key (on a side stream, as hipGraph capture of autograd wants), then
     captured once and replayed.  Every call performs the work exactly once."""
 
-    def __init__(self, enabled, warm=3):
+    def __init__(self, enabled, warm=3, snapshot=None, restore=None):
         self.enabled, self.warm = enabled, warm
         self.entries = {}
         self.side = None
+        # host state `fn` changes while it is being captured (hand-over flags, launch arguments): an aborted capture has
+        # run the Python but no launch -- the eager re-run must start from the state the capture started from
+        self.snapshot, self.restore = snapshot, restore
 
     def run(self, key, fn):
         if not self.enabled:
@@ -139,6 +142,7 @@ class _GraphCache(object):
             cur.wait_stream(self.side)
             return
         g = torch.cuda.CUDAGraph()
+        state = self.snapshot() if self.snapshot is not None else None
         try:
             # thread-local capture mode: the collective backend's watchdog thread may touch the HIP runtime meanwhile
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
@@ -148,6 +152,8 @@ class _GraphCache(object):
             warnings.warn("hipGraph capture failed (%s: %s); continuing with eager launches" % (type(exc).__name__, exc))
             self.enabled = False
             torch.cuda.synchronize()
+            if self.restore is not None:
+                self.restore(state)
             fn()                                                # nothing ran during the aborted capture
             return
         e["graph"] = g
@@ -208,7 +214,7 @@ class RPOTrainerBase(object):
         self._box_lo, self._box_hi = self.base_env.partial_box
         if use_graph is None:
             use_graph = bool(_env_int("RPO_GRAPH", 1)) and device.type == "cuda"
-        self._graphs = _GraphCache(use_graph)
+        self._graphs = _GraphCache(use_graph, snapshot=self._host_state, restore=self._set_host_state)
         self._tail = None           # data-parallel runs: deferred last segment of the previous iteration
         self._last_cols = self._last_actor_out = None
         self._cycle = _env_int("RPO_GRAPH_CYCLE", 16) // max(1, self.policy_fre) * max(1, self.policy_fre)
@@ -753,6 +759,37 @@ class RPOTrainerBase(object):
             return
         su.run("critic_fwd_b_pol" if early else "critic_fwd_b", rider=ride)   # (+ actor forward of lanes [cut, n))
         self._critic_update_split_back(su, ride)
+
+    _HOST_STATE = ("_clock_pending", "_iter_actor_step", "_critic_prepared", "_gradmax_stale", "_actor_prepared",
+                   "_actor_gradmax_stale", "_pol_a_done", "_gradmax_ready", "_actor_gradmax_ready", "_bump_updates_now",
+                   "_updates_out", "_last_cols", "_last_actor_out")
+
+    def _host_state(self):
+        """What an iteration's Python changes on the HOST besides launching (hand-over flags, the argument struct of the
+        column-split stages, the host mirror of the step counter): `_GraphCache` restores it when a capture is aborted."""
+        import ctypes
+        st = {k: getattr(self, k) for k in self._HOST_STATE if hasattr(self, k)}
+        st["steps_host"] = self.vec.steps_host
+        su = getattr(self, "_split_cache", None)
+        if su:
+            st["su"] = (ctypes.string_at(ctypes.addressof(su.st), ctypes.sizeof(su.st)), dict(su._held))
+        rc = getattr(self, "_rider_cache", None)
+        if rc is not None and hasattr(rc, "st"):
+            st["rider"] = ctypes.string_at(ctypes.addressof(rc.st), ctypes.sizeof(rc.st))
+        return st
+
+    def _set_host_state(self, st):
+        import ctypes
+        st = dict(st)
+        self.vec.steps_host = st.pop("steps_host")
+        su_state, rider = st.pop("su", None), st.pop("rider", None)
+        if su_state is not None:
+            ctypes.memmove(ctypes.addressof(self._split_cache.st), su_state[0], len(su_state[0]))
+            self._split_cache._held = dict(su_state[1])
+        if rider is not None:
+            ctypes.memmove(ctypes.addressof(self._rider_cache.st), rider, len(rider))
+        for k, v in st.items():
+            setattr(self, k, v)
 
     def _handover_flags(self):
         """Device words the in-launch hand-overs raise when a wait was given up: (tile_sync's last word, proj_ws's)."""

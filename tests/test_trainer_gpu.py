@@ -673,6 +673,37 @@ def test_fused_front_launch_equals_separate_launches(hip, algo, envname, shared,
     assert int(sync.abs().sum()) == 0
 
 
+@pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "cart"), ("sac", "pendulum")])
+def test_aborted_graph_capture_falls_back_to_eager_from_a_clean_state(hip, algo, envname, monkeypatch):
+    """A hipGraph capture that fails has run the iteration's Python -- hand-over flags, the stages' argument struct, the host
+    step counter -- but no launch.  `_GraphCache` restores that host state before the eager re-run: a run whose first capture
+    dies in the middle of a window equals an eager run bit for bit (and warns).  (The flags are recomputed by every iteration's
+    `_set_hand_overs`, so today's schedules also survive without the restore -- checked by hand; the snapshot keeps that from
+    depending on which flag a future schedule forgets to recompute.)"""
+    dev = torch.device("cuda")
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
+    a = _run(algo, envname, hip, dev, 45, 300, use_graph=False)
+    orig, seen = hip.SplitUpdate.run, [0]
+
+    def failing_run(self, stage, rider=None):
+        # the capture dies in the MIDDLE of a window: behind a critic update's front launch, in front of its bwd_b
+        if torch.cuda.is_current_stream_capturing() and stage == "critic_bwd_b":
+            seen[0] += 1
+            if seen[0] == 3:
+                raise RuntimeError("forced capture failure")
+        return orig(self, stage, rider)
+    monkeypatch.setattr(hip.SplitUpdate, "run", failing_run)
+    with pytest.warns(UserWarning, match="hipGraph capture failed"):
+        b = _run(algo, envname, hip, dev, 45, 300, use_graph=True)
+    assert not b._graphs.enabled
+    assert torch.equal(a.agent.flat.data, b.agent.flat.data)
+    assert torch.equal(a.agent.critic_target_flat, b.agent.critic_target_flat)
+    assert torch.equal(a.agent.critic_optim.exp_avg_sq, b.agent.critic_optim.exp_avg_sq)
+    assert int(a.agent.critic_optim.step_dev[0]) == int(b.agent.critic_optim.step_dev[0])
+    assert torch.equal(a.buffer.rows, b.buffer.rows) and torch.equal(a.vec.internal, b.vec.internal)
+    assert int(a.vec.ctrl[0]) == int(b.vec.ctrl[0]) == 45
+
+
 @pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "cart")])
 def test_tail_windows_equal_eager(hip, algo, envname, monkeypatch):
     """RPO_TAIL_WINDOWS=1: the last < RPO_GRAPH_CYCLE iterations of a run_steps call are one shorter graph window (whole
