@@ -17,6 +17,9 @@ for W in cart_sac cart_ddpg; do
   timeout 600 python3 bench.py --force-dist --workload $W --no-extras --no-clinic --no-cpu-baseline 2> $OUT/bench_force_dist_$W.err | grep '^{' > $OUT/bench_force_dist_$W.json
 done
 timeout 300 python3 tools/probe_project.py > $OUT/probe_project.txt 2>&1
+for W in cart_ddpg cart_sac; do
+  timeout 600 python3 tools/probe_large_batch.py $W 1048576 4096 2>&1 | grep -v "@1M\|amdgpu.ids" > $OUT/probe_large_batch_$W.txt
+done
 for W in cart_sac pen_ddpg pen_sac evopf_ddpg evopf_sac; do
   timeout 900 python3 bench.py --workload $W > $OUT/bench_line_$W.json 2> $OUT/bench_line_$W.err
 done
