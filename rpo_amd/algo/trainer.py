@@ -116,13 +116,16 @@ class _GraphCache(object):
     """Eager for the first ``warm`` calls of a key (on a side stream, as hipGraph capture of autograd wants), then
     captured once and replayed.  Every call performs the work exactly once."""
 
-    def __init__(self, enabled, warm=3, snapshot=None, restore=None):
+    def __init__(self, enabled, warm=3, owner=None):
         self.enabled, self.warm = enabled, warm
         self.entries = {}
         self.side = None
         # host state `fn` changes while it is being captured (hand-over flags, launch arguments): an aborted capture has
         # run the Python but no launch -- the eager re-run must start from the state the capture started from
-        self.snapshot, self.restore = snapshot, restore
+        # (owner._host_state / _set_host_state).  A WEAK reference: a trainer <-> cache cycle would leave the trainer's
+        # hipGraphs to the cyclic collector, which may run -- and destroy them -- in the middle of a later capture.
+        import weakref
+        self._owner = weakref.ref(owner) if owner is not None else None
 
     def run(self, key, fn):
         if not self.enabled:
@@ -142,20 +145,28 @@ class _GraphCache(object):
             cur.wait_stream(self.side)
             return
         g = torch.cuda.CUDAGraph()
-        state = self.snapshot() if self.snapshot is not None else None
-        try:
+        owner = self._owner() if self._owner is not None else None
+        state = owner._host_state() if owner is not None else None
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.disable()                                            # (a collection inside the capture could destroy an older hipGraph:
+        try:                                                    #  "operation not permitted when stream is capturing", fatal)
             # thread-local capture mode: the collective backend's watchdog thread may touch the HIP runtime meanwhile
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 fn()
         except Exception as exc:                                # noqa: BLE001  (capture is an optimisation, not a need)
+            if gc_was_on:
+                gc.enable()
             import warnings
             warnings.warn("hipGraph capture failed (%s: %s); continuing with eager launches" % (type(exc).__name__, exc))
             self.enabled = False
             torch.cuda.synchronize()
-            if self.restore is not None:
-                self.restore(state)
+            if owner is not None:
+                owner._set_host_state(state)
             fn()                                                # nothing ran during the aborted capture
             return
+        if gc_was_on:
+            gc.enable()
         e["graph"] = g
         g.replay()
 
@@ -214,7 +225,7 @@ class RPOTrainerBase(object):
         self._box_lo, self._box_hi = self.base_env.partial_box
         if use_graph is None:
             use_graph = bool(_env_int("RPO_GRAPH", 1)) and device.type == "cuda"
-        self._graphs = _GraphCache(use_graph, snapshot=self._host_state, restore=self._set_host_state)
+        self._graphs = _GraphCache(use_graph, owner=self)
         self._tail = None           # data-parallel runs: deferred last segment of the previous iteration
         self._last_cols = self._last_actor_out = None
         self._cycle = _env_int("RPO_GRAPH_CYCLE", 16) // max(1, self.policy_fre) * max(1, self.policy_fre)
