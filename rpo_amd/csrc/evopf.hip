@@ -156,6 +156,11 @@ struct ActArgs {
 // EVOPFEnv.update evopf.py:769-783) -> complete_partial -> grad_steps, one lane per wave.
 __global__ __launch_bounds__(RPO_WAVE) void evopf_act_project_kernel(ActArgs p) {
     __shared__ Ws w;
+    // A projection of a sampled BATCH (<= 512 rows: the target actions of the critic update, on the iteration's critical path)
+    // shares the chip with the 1024-lane projection of the next rollout (one wave per SIMD, the other branch of the window,
+    // which has slack): its waves then sit on SIMDs that already hold a wave, and both are bound by instruction issue.  Raised
+    // priority gives the batch's waves the issue slots: 171 -> 1xx us measured for it, the rollout's waves on those SIMDs lag.
+    if (gridDim.x <= 512) __builtin_amdgcn_s_setprio(3);
     const int i = blockIdx.x, tid = threadIdx.x;
     const long long t = p.ctrl ? p.ctrl[RPO_CTRL_T] : 0;
     load_consts(w, p.consts);

@@ -139,6 +139,9 @@ __device__ __forceinline__ void gemm_stage(float* a_s, int ldk, int kw, const fl
 template <bool W_NK, int CH>
 __global__ __launch_bounds__(kGemmThreads) void mlp_gemm_kernel(GemmArgs4 all, int vec_a, int vec_w) {
     const GemmArgs& p = all.g[blockIdx.z];
+    // These launches are the update branch of the EVOPF windows: a few hundred waves next to the 1024 resident, issue-bound waves
+    // of the rollout's projection on the other branch (which has slack).  Raised priority gives them the issue slots.
+    __builtin_amdgcn_s_setprio(2);
     extern __shared__ __attribute__((aligned(16))) float a_s[];   // [16][ldk] (+ [16][ldk2])
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     const int m0 = blockIdx.y * kRows, n = (blockIdx.x * 4 + wave) * 16 + li;
