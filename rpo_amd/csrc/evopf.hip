@@ -8,17 +8,24 @@ using namespace rpo_evopf_dev;
 namespace {
 
 __device__ __forceinline__ void load_row(float* dst, const float* __restrict__ src, int n) {
-    for (int i = threadIdx.x; i < n; i += RPO_WAVE) dst[i] = src[i];
+    for (int i = lane_id(); i < n; i += RPO_WAVE) dst[i] = src[i];
 }
 
+// Env lanes per workgroup of the one-wave-per-lane kernels: four waves = one on each SIMD of a CU.  As 64-thread workgroups the
+// dispatcher packed several waves onto one SIMD while others stayed empty -- and two issue-bound waves on a SIMD run at 3/4 of
+// the speed each: the 1024-lane projection took 171 us inside the training windows and 123 us in this form.
+constexpr int kActWaves = 4;
+
 // ------------------------------------------------------------------------------------------------------- reset
-__global__ __launch_bounds__(RPO_WAVE) void evopf_reset_kernel(int n, float* __restrict__ state, int* __restrict__ ep_len,
+__global__ __launch_bounds__(RPO_WAVE * kActWaves) void evopf_reset_kernel(int n, float* __restrict__ state, int* __restrict__ ep_len,
                                                                float* __restrict__ ep_ret,
                                                                const unsigned* __restrict__ ep_count,
                                                                const float* __restrict__ consts, uint64_t seed,
                                                                uint32_t env_id_base) {
-    __shared__ Ws w;
-    const int i = blockIdx.x, tid = threadIdx.x;
+    __shared__ Ws wss[kActWaves];
+    Ws& w = wss[threadIdx.x / RPO_WAVE];
+    const int i = blockIdx.x * kActWaves + threadIdx.x / RPO_WAVE, tid = lane_id();
+    if (i >= n) return;
     load_consts(w, consts);
     sync();
     episode_obs(w, w.s, seed, env_id_base + (uint32_t)i, ep_count ? ep_count[i] : 0u, 0);
@@ -51,12 +58,9 @@ struct StepArgs {
 
 // EVOPFEnv.step (evopf.py:348-366) + Battery.step (:74-102) + the bookkeeping of the run loop (rpo_ddpg.py:120-145):
 // violations of the pre-step observation, reward, next hour of the episode data, replay scatter, statistics, auto-reset.
-__global__ __launch_bounds__(RPO_WAVE) void evopf_step_kernel(StepArgs p) {
+__device__ __forceinline__ void evopf_step_lane(const StepArgs& p, Ws& w, float* row, int i, long long t) {
     RPO_FP_STRICT
-    __shared__ Ws w;
-    __shared__ __align__(16) float row[RPO_EVOPF_ROW];
-    const int i = blockIdx.x, tid = threadIdx.x;
-    const long long t = p.ctrl ? p.ctrl[RPO_CTRL_T] : 0;
+    const int tid = lane_id();
     load_consts(w, p.consts);
     load_row(w.s, p.state + (size_t)i * NS, NS);
     load_row(w.a, p.action + (size_t)i * NY, NY);
@@ -125,6 +129,14 @@ __global__ __launch_bounds__(RPO_WAVE) void evopf_step_kernel(StepArgs p) {
                               RPO_STAT_LENGTH_SUM, RPO_STAT_TERMINATED};
         rpo_stats_commit(vals, 3u << 4, slot, rpo_stats_row(p.stats, p.stats_cap, t));
     }
+}
+
+__global__ __launch_bounds__(RPO_WAVE * kActWaves) void evopf_step_kernel(StepArgs p) {
+    __shared__ Ws wss[kActWaves];
+    __shared__ __align__(16) float rows_s[kActWaves][RPO_EVOPF_ROW];
+    const int wave = threadIdx.x / RPO_WAVE, i = blockIdx.x * kActWaves + wave;
+    const long long t = p.ctrl ? p.ctrl[RPO_CTRL_T] : 0;
+    if (i < p.n) evopf_step_lane(p, wss[wave], rows_s[wave], i, t);   // (every wave reaches the epilogue's workgroup barrier)
     rpo_step_epilogue(p.ctrl, t, p.stats, p.stats_cap);
 }
 
@@ -154,14 +166,16 @@ struct ActArgs {
 
 // take_action's exploration + clip to the state-dependent box (agent/ddpg_pa.py:101-112, model/utils.py:53-62,90-101,
 // EVOPFEnv.update evopf.py:769-783) -> complete_partial -> grad_steps, one lane per wave.
-__global__ __launch_bounds__(RPO_WAVE) void evopf_act_project_kernel(ActArgs p) {
-    __shared__ Ws w;
+__global__ __launch_bounds__(RPO_WAVE * kActWaves) void evopf_act_project_kernel(ActArgs p) {
+    __shared__ Ws wss[kActWaves];
+    Ws& w = wss[threadIdx.x / RPO_WAVE];
     // A projection of a sampled BATCH (<= 512 rows: the target actions of the critic update, on the iteration's critical path)
     // shares the chip with the 1024-lane projection of the next rollout (one wave per SIMD, the other branch of the window,
     // which has slack): its waves then sit on SIMDs that already hold a wave, and both are bound by instruction issue.  Raised
     // priority gives the batch's waves the issue slots: 171 -> 1xx us measured for it, the rollout's waves on those SIMDs lag.
-    if (gridDim.x <= 512) __builtin_amdgcn_s_setprio(3);
-    const int i = blockIdx.x, tid = threadIdx.x;
+    if (gridDim.x * kActWaves <= 512) __builtin_amdgcn_s_setprio(3);
+    const int i = blockIdx.x * kActWaves + threadIdx.x / RPO_WAVE, tid = lane_id();
+    if (i >= p.n) return;                                        // (waves never meet at a workgroup barrier)
     const long long t = p.ctrl ? p.ctrl[RPO_CTRL_T] : 0;
     load_consts(w, p.consts);
     load_row(w.s, p.state + (size_t)i * p.state_stride, NS);
@@ -203,14 +217,16 @@ __global__ __launch_bounds__(RPO_WAVE) void evopf_act_project_kernel(ActArgs p) 
 
 // PFFunction.backward (evopf.py:857-910) with the Jacobians re-evaluated at the completed action (the reference keeps
 // those of the last Newton point, one update of size < tol earlier).  grad_ap [n,14] = dL/dz.
-__global__ __launch_bounds__(RPO_WAVE) void evopf_complete_bwd_kernel(int n, const float* __restrict__ action,
+__global__ __launch_bounds__(RPO_WAVE * kActWaves) void evopf_complete_bwd_kernel(int n, const float* __restrict__ action,
                                                                       const float* __restrict__ grad_action,
                                                                       const float* __restrict__ grad_action2,
                                                                       float* __restrict__ grad_ap,
                                                                       const float* __restrict__ consts) {
     RPO_FP_STRICT
-    __shared__ Ws w;
-    const int i = blockIdx.x, tid = threadIdx.x;
+    __shared__ Ws wss[kActWaves];
+    Ws& w = wss[threadIdx.x / RPO_WAVE];
+    const int i = blockIdx.x * kActWaves + threadIdx.x / RPO_WAVE, tid = lane_id();
+    if (i >= n) return;
     load_consts(w, consts);
     load_row(w.a, action + (size_t)i * NY, NY);
     // dl_dy (= grad_action [+ grad_action2]: d(-Q)/da from the critic + the Lagrangian term, rpo_ddpg.py:319, added here
@@ -255,12 +271,14 @@ __global__ __launch_bounds__(RPO_WAVE) void evopf_complete_bwd_kernel(int n, con
     }
 }
 
-__global__ __launch_bounds__(RPO_WAVE) void evopf_resid_kernel(int n, const float* __restrict__ state, int state_stride,
+__global__ __launch_bounds__(RPO_WAVE * kActWaves) void evopf_resid_kernel(int n, const float* __restrict__ state, int state_stride,
                                                                const float* __restrict__ action, float* __restrict__ eq_out,
                                                                float* __restrict__ ineq_out,
                                                                const float* __restrict__ consts) {
-    __shared__ Ws w;
-    const int i = blockIdx.x, tid = threadIdx.x;
+    __shared__ Ws wss[kActWaves];
+    Ws& w = wss[threadIdx.x / RPO_WAVE];
+    const int i = blockIdx.x * kActWaves + threadIdx.x / RPO_WAVE, tid = lane_id();
+    if (i >= n) return;
     load_consts(w, consts);
     load_row(w.s, state + (size_t)i * state_stride, NS);
     load_row(w.a, action + (size_t)i * NY, NY);
@@ -272,11 +290,13 @@ __global__ __launch_bounds__(RPO_WAVE) void evopf_resid_kernel(int n, const floa
     if (ineq_out && tid < NINEQ) ineq_out[(size_t)i * NINEQ + tid] = w.ineq[tid];
 }
 
-__global__ __launch_bounds__(RPO_WAVE) void evopf_ipg_kernel(int n, const float* __restrict__ state, int state_stride,
+__global__ __launch_bounds__(RPO_WAVE * kActWaves) void evopf_ipg_kernel(int n, const float* __restrict__ state, int state_stride,
                                                              const float* __restrict__ action, float* __restrict__ step_out,
                                                              const float* __restrict__ consts) {
-    __shared__ Ws w;
-    const int i = blockIdx.x, tid = threadIdx.x;
+    __shared__ Ws wss[kActWaves];
+    Ws& w = wss[threadIdx.x / RPO_WAVE];
+    const int i = blockIdx.x * kActWaves + threadIdx.x / RPO_WAVE, tid = lane_id();
+    if (i >= n) return;
     load_consts(w, consts);
     load_row(w.s, state + (size_t)i * state_stride, NS);
     load_row(w.a, action + (size_t)i * NY, NY);
@@ -452,7 +472,7 @@ int rpo_evopf_reset(int n_envs, float* state, int* ep_len, float* ep_ret, const 
                     const float* consts_dev, unsigned long long seed, unsigned env_id_base, void* stream) {
     if (int e = check_common(n_envs, state, ep_len, consts_dev)) return e;
     if (!ep_ret) return RPO_ERR_NULL;
-    hipLaunchKernelGGL(evopf_reset_kernel, dim3(n_envs), dim3(RPO_WAVE), 0, (hipStream_t)stream, n_envs, state, ep_len,
+    hipLaunchKernelGGL(evopf_reset_kernel, dim3((n_envs + kActWaves - 1) / kActWaves), dim3(RPO_WAVE * kActWaves), 0, (hipStream_t)stream, n_envs, state, ep_len,
                        ep_ret, ep_count, consts_dev, (uint64_t)seed, (uint32_t)env_id_base);
     RPO_LAUNCH_CHECK();
     return 0;
@@ -467,7 +487,7 @@ int rpo_evopf_step(int n_envs, float* state, const float* action, int* ep_len, f
     if (max_episode_steps <= 0 || (rows && cap_steps <= 0) || (stats && stats_cap <= 0)) return RPO_ERR_ARG;
     StepArgs p{n_envs, state, action, ep_len, ep_ret, ep_count, rows, cap_steps, stats, stats_cap, ctrl, max_episode_steps,
                auto_reset, viol_thresh, consts_dev, (uint64_t)seed, (uint32_t)env_id_base};
-    hipLaunchKernelGGL(evopf_step_kernel, dim3(n_envs), dim3(RPO_WAVE), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(evopf_step_kernel, dim3((n_envs + kActWaves - 1) / kActWaves), dim3(RPO_WAVE * kActWaves), 0, (hipStream_t)stream, p);
     RPO_LAUNCH_CHECK();
     return 0;
 }
@@ -486,7 +506,7 @@ int rpo_evopf_act_project(int n, const float* state, int state_stride, const flo
     ActArgs p{n, state, state_stride, ap_raw, noise, action, iters, noise_mode, ap_is_raw, eps_start, eps_end, eps_decay, max_steps, corr_lr,
               corr_eps, corr_momentum, newton_tol, newton_max_iters, consts_dev, (uint64_t)seed, (uint32_t)env_id_base, ctrl,
               stats, stats_cap};
-    hipLaunchKernelGGL(evopf_act_project_kernel, dim3(n), dim3(RPO_WAVE), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(evopf_act_project_kernel, dim3((n + kActWaves - 1) / kActWaves), dim3(RPO_WAVE * kActWaves), 0, (hipStream_t)stream, p);
     RPO_LAUNCH_CHECK();
     return 0;
 }
@@ -530,7 +550,7 @@ int rpo_evopf_complete_bwd(int n, const float* action, const float* grad_action,
                            const float* consts_dev, void* stream) {
     if (int e = check_common(n, action, grad_action, consts_dev)) return e;
     if (!grad_ap) return RPO_ERR_NULL;
-    hipLaunchKernelGGL(evopf_complete_bwd_kernel, dim3(n), dim3(RPO_WAVE), 0, (hipStream_t)stream, n, action, grad_action,
+    hipLaunchKernelGGL(evopf_complete_bwd_kernel, dim3((n + kActWaves - 1) / kActWaves), dim3(RPO_WAVE * kActWaves), 0, (hipStream_t)stream, n, action, grad_action,
                        grad_action2, grad_ap, consts_dev);
     RPO_LAUNCH_CHECK();
     return 0;
@@ -539,7 +559,7 @@ int rpo_evopf_complete_bwd(int n, const float* action, const float* grad_action,
 int rpo_evopf_resid(int n, const float* state, int state_stride, const float* action, float* eq_out, float* ineq_out,
                     const float* consts_dev, void* stream) {
     if (int e = check_common(n, state, action, consts_dev)) return e;
-    hipLaunchKernelGGL(evopf_resid_kernel, dim3(n), dim3(RPO_WAVE), 0, (hipStream_t)stream, n, state, state_stride, action, eq_out,
+    hipLaunchKernelGGL(evopf_resid_kernel, dim3((n + kActWaves - 1) / kActWaves), dim3(RPO_WAVE * kActWaves), 0, (hipStream_t)stream, n, state, state_stride, action, eq_out,
                        ineq_out, consts_dev);
     RPO_LAUNCH_CHECK();
     return 0;
@@ -549,7 +569,7 @@ int rpo_evopf_ineq_partial_grad(int n, const float* state, int state_stride, con
                                 void* stream) {
     if (int e = check_common(n, state, action, consts_dev)) return e;
     if (!step_out) return RPO_ERR_NULL;
-    hipLaunchKernelGGL(evopf_ipg_kernel, dim3(n), dim3(RPO_WAVE), 0, (hipStream_t)stream, n, state, state_stride, action, step_out,
+    hipLaunchKernelGGL(evopf_ipg_kernel, dim3((n + kActWaves - 1) / kActWaves), dim3(RPO_WAVE * kActWaves), 0, (hipStream_t)stream, n, state, state_stride, action, step_out,
                        consts_dev);
     RPO_LAUNCH_CHECK();
     return 0;

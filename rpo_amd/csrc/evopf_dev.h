@@ -64,9 +64,12 @@ struct Ws {                       // per-wave workspace in LDS
     float vec[64];                // scratch
 };
 
-// Workgroup == one wavefront (every kernel that uses Ws is launched with 64 threads): the LDS instructions of a wave
+// One wavefront per Ws (the kernels index their workspace by wave): the LDS instructions of a wave
 // execute in issue order, so a cross-lane hand-over through LDS needs neither s_barrier nor the s_waitcnt 0 that
 // __syncthreads() implies -- only that the compiler keeps stores and loads in program order (act_project 133.8 -> 131.5 us).
+// Lane of the wave (a workgroup may hold several waves, each solving its own env lane with its own Ws)
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (RPO_WAVE - 1)); }
+
 __device__ __forceinline__ void sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -74,7 +77,7 @@ __device__ __forceinline__ void sync() {
 }
 
 __device__ __forceinline__ void load_consts(Ws& w, const float* __restrict__ consts) {
-    for (int i = threadIdx.x; i < RPO_EVOPF_CONSTS_LEN; i += RPO_WAVE) w.c[i] = consts[i];
+    for (int i = lane_id(); i < RPO_EVOPF_CONSTS_LEN; i += RPO_WAVE) w.c[i] = consts[i];
 }
 __device__ __forceinline__ float Yr(const Ws& w, int i, int k) { return w.c[RPO_EVOPF_C_YR + i * NB + k]; }
 __device__ __forceinline__ float Yi(const Ws& w, int i, int k) { return w.c[RPO_EVOPF_C_YI + i * NB + k]; }
@@ -95,7 +98,7 @@ __device__ __forceinline__ void partial_box(const Ws& w, int j, float& lo, float
 
 // cos / sin / rectangular voltages and the two admittance products of eq_resid / eq_jac (evopf.py:523-528,623-630)
 __device__ __forceinline__ void flows(Ws& w) {
-    const int tid = threadIdx.x;
+    const int tid = lane_id();
     if (tid < NB) {
         float sn, cs;
         sincosf(w.a[VA0 + tid], &sn, &cs);
@@ -116,7 +119,7 @@ __device__ __forceinline__ void flows(Ws& w) {
 
 // eq_resid (evopf.py:520-546) of (w.s, w.a) into w.eq; flows() must be current
 __device__ __forceinline__ void eq_resid(Ws& w) {
-    const int tid = threadIdx.x;
+    const int tid = lane_id();
     if (tid < NEQ) {
         const int i = tid < NB ? tid : tid - NB;
         const int g = kGenOfBus[i];
@@ -134,7 +137,7 @@ __device__ __forceinline__ void eq_resid(Ws& w) {
 // ineq_resid (evopf.py:548-563) into w.ineq (signed)
 __device__ __forceinline__ void ineq_resid(Ws& w) {
     RPO_FP_STRICT
-    const int tid = threadIdx.x;
+    const int tid = lane_id();
     if (tid < NINEQ) {
         float r;
         if (tid < 5) r = w.a[PG0 + tid] - w.c[RPO_EVOPF_C_PMAX + tid];
@@ -236,7 +239,7 @@ __device__ __forceinline__ float jac_row_entry(const Ws& w, const RowCoef& c, in
 // rows e_0 .. e_{K0-1} within the first K0 columns, and the other rows zero there.
 template <int N, int NC, int K0>
 __device__ __forceinline__ void gauss_jordan_rows(float (&row)[NC], int& mycol, float& mypiv) {
-    const int lane = threadIdx.x;
+    const int lane = lane_id();
     bool used = lane < K0 || lane >= N;
     mycol = lane < K0 ? lane : 0;
     mypiv = 1.0f;
@@ -257,7 +260,7 @@ __device__ __forceinline__ void gauss_jordan_rows(float (&row)[NC], int& mycol, 
 // threads 0..13 hold z[tid] in `zj`): Newton on (vm_pq, va_pv, va_pq) with the lane's own stop test, then qg and the
 // slack generation from the remaining equations.  Leaves flows()/eq of the completed action current.
 __device__ __forceinline__ int complete_partial(Ws& w, float zj, float tol, int max_iters) {
-    const int tid = threadIdx.x;
+    const int tid = lane_id();
     if (tid < NY) {
         float v = 0.0f;                                        // qg and the slack pg start at zero (:806-807)
         if (tid >= VM0 && tid < VA0) v = w.c[RPO_EVOPF_C_VM_INIT + tid - VM0];       // load-bus guesses (:802)
@@ -304,7 +307,7 @@ __device__ __forceinline__ int complete_partial(Ws& w, float zj, float tol, int 
 
 // ineq_partial_grad (evopf.py:596-612) of (w.s, w.a) into w.dir[43]; flows() must be current.
 __device__ __forceinline__ void ineq_partial_grad(Ws& w) {
-    const int tid = threadIdx.x;
+    const int tid = lane_id();
     // thread r owns equation kRowOrder[r] of [J_other | J_partial]
     float row[NY];
     {
@@ -352,7 +355,7 @@ __device__ __forceinline__ void ineq_partial_grad(Ws& w) {
 
 // grad_steps (rpo_ddpg.py:266-305, corr_mode 0) on w.a with the lane's own stop test; returns the iteration count
 __device__ __forceinline__ int grad_steps(Ws& w, int max_steps, float lr, float corr_eps, float momentum) {
-    const int tid = threadIdx.x;
+    const int tid = lane_id();
     if (tid < NY) w.old[tid] = 0.0f;
     int k = 0;
     for (; k < max_steps; ++k) {
@@ -380,7 +383,7 @@ __device__ __forceinline__ int grad_steps(Ws& w, int max_steps, float lr, float 
 // t >= 24 (the loaders' `done`, demand.py:71 / price.py:51).
 __device__ __forceinline__ void episode_obs(Ws& w, float* out, uint64_t seed, uint32_t env_id, uint32_t episode, int t) {
     RPO_FP_STRICT
-    const int tid = threadIdx.x;
+    const int tid = lane_id();
     const bool over = t >= T;
     // demand: 11 Exp(1) draws (Dirichlet) + 14 power factors from 7 Philox blocks; word index = tid
     if (tid < 28) {
