@@ -251,8 +251,21 @@ __device__ __forceinline__ void gauss_jordan_rows(float (&row)[NC], int& mycol, 
         const bool is_p = lane == p;
         const float f = is_p ? 0.0f : -row[k] * (1.0f / piv);
         if (is_p) { used = true; mycol = k; mypiv = piv; }
+        // two columns per instruction (v_pk_fma_f32: the same IEEE fma per component; the pivot row's pair sits in an SGPR pair).
+        // Pairs are (even, odd) columns whatever k is: 64-bit register operands must be even-aligned, a pairing that moved with
+        // k made the compiler re-pack the row with v_pk_mov_b32 at every pivot.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 f2 = {f, f};
+        const int start = (k + 2) & ~1;                              // first even column behind the pivot column
+        if ((k + 1) & 1) row[k + 1] = fmaf(f, lane_bcast(row[k + 1], p), row[k + 1]);
 #pragma unroll
-        for (int c = k + 1; c < NC; ++c) row[c] = fmaf(f, lane_bcast(row[c], p), row[c]);
+        for (int c = start; c + 1 < NC; c += 2) {
+            const f32x2 pv = {lane_bcast(row[c], p), lane_bcast(row[c + 1], p)};
+            f32x2 rv = {row[c], row[c + 1]};
+            rv = __builtin_elementwise_fma(f2, pv, rv);
+            row[c] = rv.x; row[c + 1] = rv.y;
+        }
+        if ((NC & 1) && start < NC) row[NC - 1] = fmaf(f, lane_bcast(row[NC - 1], p), row[NC - 1]);
     }
 }
 
