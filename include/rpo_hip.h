@@ -547,6 +547,10 @@ int rpo_split_critic_pfront_pol(const rpo_split_update* u, void* stream);
  * on.  rpo_split_critic_front hands data from workgroup to workgroup through ONE XCD's L2; its caller checks with this probe
  * (same grid: 8, ceil(batch / 16), 1 + 3 K; 256 threads) that all workgroups of a row tile share an XCD. */
 int rpo_xcc_probe(int gx, int gy, int gz, int threads, int* out, void* stream);
+/* Diagnostic (tools/hw_probe.py): out[...] = (XCC_ID << 16) | HW_ID[15:0] (wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13) of
+ * the first wave of every workgroup of a grid whose workgroups hold lds_bytes of LDS and stay resident for `spin` sleep rounds:
+ * how many workgroups the dispatcher stacks on one CU / SIMD while others are empty. */
+int rpo_hw_probe(int gx, int gy, int gz, int threads, int lds_bytes, int spin, int* out, void* stream);
 /* fwd_b + pol_a in one launch (policy iterations, no shared state embedding: the policy slabs on the batch states need
  * nothing the critic update produces); the caller then skips rpo_split_policy_a.  Requires part_pol. */
 int rpo_split_critic_fwd_b_pol(const rpo_split_update* u, void* stream);

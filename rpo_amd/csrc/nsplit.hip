@@ -176,6 +176,22 @@ __global__ void xcc_probe_kernel(int* out) {
     }
 }
 
+// Diagnostic: where the dispatcher puts the workgroups of a grid that is resident all at once.  Every workgroup records
+// (XCC_ID << 16) | HW_ID[15:0] of its first wave (HW_ID: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13) and then
+// idles for `spin` s_sleep rounds so that the grid's workgroups coexist like those of a 5-10 us launch.
+__global__ void hw_probe_kernel(int* out, int spin) {
+    extern __shared__ float hw_probe_lds[];
+    if (threadIdx.x == 0) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        out[(size_t)blockIdx.x + (size_t)gridDim.x * ((size_t)blockIdx.y + (size_t)gridDim.y * blockIdx.z)] =
+            (int)(((xcc & 15u) << 16) | (hw & 0xffffu));
+        hw_probe_lds[0] = 0.0f;
+    }
+    for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(64);
+}
+
 // ReplayBuffer.sample (buffer.py:31-34): counter-based draw + gather of the tile's 16 rows (same draw in every workgroup
 // of the tile; `publish` stores the gathered rows / indices once).
 template <class L>
@@ -1911,6 +1927,14 @@ int rpo_xcc_probe(int gx, int gy, int gz, int threads, int* out, void* stream) {
     if (gx <= 0 || gy <= 0 || gz <= 0 || threads <= 0 || threads > 1024) return RPO_ERR_ARG;
     if (!out) return RPO_ERR_NULL;
     hipLaunchKernelGGL(xcc_probe_kernel, dim3(gx, gy, gz), dim3(threads), 0, (hipStream_t)stream, out);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_hw_probe(int gx, int gy, int gz, int threads, int lds_bytes, int spin, int* out, void* stream) {
+    if (gx <= 0 || gy <= 0 || gz <= 0 || threads <= 0 || threads > 1024 || lds_bytes < 4 || lds_bytes > 65536 || spin < 0) return RPO_ERR_ARG;
+    if (!out) return RPO_ERR_NULL;
+    hipLaunchKernelGGL(hw_probe_kernel, dim3(gx, gy, gz), dim3(threads), lds_bytes, (hipStream_t)stream, out, spin);
     RPO_LAUNCH_CHECK();
     return 0;
 }
