@@ -117,6 +117,12 @@ class FusedNets(object):
             t = self._scratch[k] = torch.zeros(*shape, device=self.device)
         return t
 
+    def _inference_scratch(self, name, n, d):
+        """Pre-activation scratch of an inference forward of a wide network -- one pair per STREAM: the overlapped windows run
+        the rollout's actor forward on a second stream beside the update's forward of the same network (RPOSAC)."""
+        sid = torch.cuda.current_stream().cuda_stream if self.device.type == "cuda" else 0
+        return self.buf(name + ".x0i@%x" % sid, n, d.ein), self.buf(name + ".h1i@%x" % sid, n, d.H)
+
     def forward(self, name, s, a, out, save=False, tanh_box=None):
         """out [n, n_out]; ``save``: keep the pre-activations for ``backward``; ``tanh_box`` = (scale, base)."""
         d = self.descs[name]
@@ -126,7 +132,7 @@ class FusedNets(object):
         if not save and d.E == 256 and n <= 16384:
             # wide networks run layer by layer (rpo_amd/csrc/mlp_gemm.h): the pre-activations travel through memory, so an
             # inference call brings scratch for them too (buffers of their own: a saved forward may still be pending)
-            x0, h1 = self.buf(name + ".x0i", n, d.ein), self.buf(name + ".h1i", n, d.H)
+            x0, h1 = self._inference_scratch(name, n, d)
         mode, scale, base = (1, tanh_box[0], tanh_box[1]) if tanh_box is not None else (0, 1.0, 0.0)
         self.backend.mlp_forward(d, s, a, out, x0, h1, mode, scale, base)
         return out
@@ -143,8 +149,9 @@ class FusedNets(object):
         for (name, s, a, out, save), d in zip(calls, descs):
             n = out.shape[0]
             wide = (not save) and d.E == 256 and n <= 16384       # (see forward)
-            packed.append((d, s, a, out, self.buf(name + (".x0" if save else ".x0i"), n, d.ein) if (save or wide) else None,
-                           self.buf(name + (".h1" if save else ".h1i"), n, d.H) if (save or wide) else None))
+            x0i, h1i = self._inference_scratch(name, n, d) if wide else (None, None)
+            packed.append((d, s, a, out, self.buf(name + ".x0", n, d.ein) if save else x0i,
+                           self.buf(name + ".h1", n, d.H) if save else h1i))
         self.backend.mlp_forward_multi(packed)
         return [c[3] for c in calls]
 
