@@ -351,17 +351,33 @@ __global__ __launch_bounds__(RPO_BLOCK) void evopf_lagrangian_kernel(int n, cons
     const float nu_up = up >= 0 ? nu[up] : 0.0f, nu_lo = lo >= 0 ? nu[lo] : 0.0f;
     float acc_up = 0.0f, acc_lo = 0.0f;
     if (v < NY) {
-        for (int b = q; b < n; b += RPO_BLOCK / RPO_WAVE) {
-            float g = 0.0f;
-            if (up >= 0) {
-                const float a = action[(size_t)b * NY + v];
-                if (v >= PE0) battery_bounds(state[(size_t)b * state_stride + 2 * NB + v - PE0], hi_b, lo_b);
-                const float ru = a - hi_b, rl = lo_b - a;
-                acc_up += fmaxf(ru, 0.0f);
-                acc_lo += fmaxf(rl, 0.0f);
-                g = (ru > 0.0f ? nu_up : 0.0f) - (rl > 0.0f ? nu_lo : 0.0f);      // ineq_jac^T (nu * 1[g > 0]), :663-707
+        // 64 rows of loads in flight (a whole batch of 256 in one round trip), then the rows in order (the sums keep their association; one dependent round trip per
+        // row made this one-workgroup launch 25 us at batch 256)
+        constexpr int W = RPO_BLOCK / RPO_WAVE, CH = 64;
+        for (int b0 = q; b0 < n; b0 += W * CH) {
+            float av[CH], sv[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int b = b0 + u * W, bc = b < n ? b : n - 1;
+                av[u] = up >= 0 ? action[(size_t)bc * NY + v] : 0.0f;
+                sv[u] = v >= PE0 ? state[(size_t)bc * state_stride + 2 * NB + v - PE0] : 0.0f;
             }
-            if (grad_action) grad_action[(size_t)b * NY + v] = scale * g;
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int b = b0 + u * W;
+                if (b < n) {
+                    float g = 0.0f;
+                    if (up >= 0) {
+                        const float a = av[u];
+                        if (v >= PE0) battery_bounds(sv[u], hi_b, lo_b);
+                        const float ru = a - hi_b, rl = lo_b - a;
+                        acc_up += fmaxf(ru, 0.0f);
+                        acc_lo += fmaxf(rl, 0.0f);
+                        g = (ru > 0.0f ? nu_up : 0.0f) - (rl > 0.0f ? nu_lo : 0.0f);      // ineq_jac^T (nu * 1[g > 0]), :663-707
+                    }
+                    if (grad_action) grad_action[(size_t)b * NY + v] = scale * g;
+                }
+            }
         }
     }
     red[q][v] = acc_up;
