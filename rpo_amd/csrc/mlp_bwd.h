@@ -191,7 +191,7 @@ __host__ __device__ constexpr int mlp_fl_blocks(int outputs) { return (outputs +
 
 template <int EIN, int OUT>
 __device__ __forceinline__ float mlp_bwd_first_layer_impl(const BwdArgs& p, int fl_block) {
-    constexpr int SL = kThreads / OUT, CH = OUT == 16 ? 16 : 8;    // batch slices; rows of loads in flight per slice
+    constexpr int SL = kThreads / OUT, CH = 16;                    // batch slices; rows of loads in flight per slice
     __shared__ float fl_partial[SL][OUT];
     const Mlp& net = p.net;
     const int tid = threadIdx.x;
@@ -342,37 +342,43 @@ __device__ __forceinline__ float mlp_bwd_weights_body(const BwdArgs& p, int vblo
         // output): H/16 workgroups x 16 batch slices keep the exposed load latency to n/16 rows per thread.
         if (p.first_layer_state_only) return gmax;
         __shared__ float wide[16][kWideOut + 1][16];
+        static_assert(256 * kWideOut <= 16 * (kWideOut + 1) * 16, "the staged head gradients live in `wide`");
+        float* dout_s = &wide[0][0][0];                            // the head gradients of (up to) 256 rows, staged once per pass
         const int outs = net.n_out * net.hd;
         const int jj = tid & 15, slice = tid >> 4;
         const int j = rb * 16 + jj;
-        const int lo = (int)(((long long)p.n * slice) / 16), hi = (int)(((long long)p.n * (slice + 1)) / 16);
         float gb0 = 0.0f, gw[kWideOut];
 #pragma unroll
         for (int q = 0; q < kWideOut; ++q) gw[q] = 0.0f;
-        int bb = lo;
-        for (; bb + 4 <= hi; bb += 4) {
-            float d[4], h[4];
+        // Passes of 256 rows: thread (jj, slice) owns rows [16 slice, 16 slice + 16) of the pass -- for n <= 256 the same rows in
+        // the same order as a 16-way split of the batch.  Its 16 rows of dh / h1 are requested together and the pass's head
+        // gradients are staged in LDS by the whole workgroup (they were 16 x outs dependent global loads per thread: this role
+        // was 21 of the launch's 22 us at batch 256 with 14 outputs).
+        for (int base = 0; base < p.n; base += 256) {
+            const int rows = p.n - base < 256 ? p.n - base : 256;
+            __syncthreads();
+            for (int idx = tid; idx < rows * outs; idx += kThreads) dout_s[idx] = p.dout[(size_t)base * outs + idx];
+            const int lo = (int)(((long long)rows * slice) / 16), hi = (int)(((long long)rows * (slice + 1)) / 16);
+            float d[16], h[16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                d[u] = p.dh[(size_t)(bb + u) * H + j];
-                h[u] = fmaxf(p.h1[(size_t)(bb + u) * H + j], 0.0f);
+            for (int u = 0; u < 16; ++u) {
+                const int r = lo + u < hi ? lo + u : (hi > lo ? hi - 1 : 0);
+                d[u] = p.dh[(size_t)(base + r) * H + j];
+                h[u] = fmaxf(p.h1[(size_t)(base + r) * H + j], 0.0f);
             }
+            __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                gb0 += d[u];
-                const float* drow = p.dout + (size_t)(bb + u) * outs;
+            for (int u = 0; u < 16; ++u) {
+                if (lo + u < hi) {
+                    gb0 += d[u];
+                    const float* drow = dout_s + (lo + u) * outs;
 #pragma unroll
-                for (int q = 0; q < kWideOut; ++q)
-                    if (q < outs) gw[q] = fmaf(drow[q], h[u], gw[q]);
+                    for (int q = 0; q < kWideOut; ++q)
+                        if (q < outs) gw[q] = fmaf(drow[q], h[u], gw[q]);
+                }
             }
         }
-        for (; bb < hi; ++bb) {
-            gb0 += p.dh[(size_t)bb * H + j];
-            const float hr = fmaxf(p.h1[(size_t)bb * H + j], 0.0f);
-#pragma unroll
-            for (int q = 0; q < kWideOut; ++q)
-                if (q < outs) gw[q] = fmaf(p.dout[(size_t)bb * outs + q], hr, gw[q]);
-        }
+        __syncthreads();                                           // (`wide` held the staged head gradients until here)
         wide[slice][kWideOut][jj] = gb0;
 #pragma unroll
         for (int q = 0; q < kWideOut; ++q) wide[slice][q][jj] = gw[q];
@@ -395,8 +401,17 @@ __device__ __forceinline__ float mlp_bwd_weights_body(const BwdArgs& p, int vblo
             const int q = tid & 31, sl8 = tid >> 5;
             const int l8 = (int)(((long long)p.n * sl8) / 8), h8 = (int)(((long long)p.n * (sl8 + 1)) / 8);
             float s0 = 0.0f;
-            if (q < outs)
-                for (int b2 = l8; b2 < h8; ++b2) s0 += p.dout[(size_t)b2 * outs + q];
+            if (q < outs) {
+                int b2 = l8;
+                for (; b2 + 32 <= h8; b2 += 32) {                  // 32 rows of loads in flight (a slice of batch 256), summed in order
+                    float dv[32];
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) dv[u] = p.dout[(size_t)(b2 + u) * outs + q];
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) s0 += dv[u];
+                }
+                for (; b2 < h8; ++b2) s0 += p.dout[(size_t)b2 * outs + q];
+            }
             red[sl8 * 32 + q] = s0;
             __syncthreads();
             if (tid < outs) {
