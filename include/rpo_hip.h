@@ -38,7 +38,8 @@ extern "C" {
 #endif
 
 /* 3: rpo_split_update gained proj_ws / proj_store_mode / debug (the struct grew); rpo_split_critic_pfront*,
- * rpo_pendulum_project_batchref_ws; rpo_evopf_complete_bwd takes grad_action2, rpo_evopf_lagrangian takes overwrite */
+ * rpo_pendulum_project_batchref_ws; rpo_evopf_complete_bwd takes grad_action_b / grad_action2, rpo_evopf_lagrangian takes overwrite;
+ * rpo_min_q_bwd, rpo_hw_probe */
 #define RPO_ABI_VERSION 3
 
 #define RPO_ERR_ARG (-1)
@@ -296,6 +297,10 @@ int rpo_td_huber(int n, const float* q1, const float* q2, const float* qn1, cons
 /* ---------------------------------------------------------------------------------------------------------------
  * Optimiser plumbing of RPODDPG.train (rpo_ddpg.py:178-205) on flat float32 parameter buffers
  * ------------------------------------------------------------------------------------------------------------- */
+
+/* d(-min(q1, q2))/dq scaled (the actor loss of RPOSAC, rpo_sac.py:335): the smaller one takes the gradient, ties are split like
+ * torch.min's backward: w = [q1 < q2] + 0.5 [q1 == q2]; dq1 = w * scale, dq2 = (1 - w) * scale. */
+int rpo_min_q_bwd(int n, const float* q1, const float* q2, float scale, float* dq1, float* dq2, void* stream);
 
 /* max_out[0] = max(max_out[0], max_i |x_i|) -- the "inf" norm of clip_grad_norm_ (rpo_ddpg.py:180,193).
  * max_out must hold a non-negative float (0 before the first call of an update). */
@@ -694,8 +699,10 @@ int rpo_evopf_gauss_head_bwd(int n, const float* state, int state_stride, const 
 
 /* PFFunction.backward (evopf.py:857-910): grad_ap [n,14] = dL/dz given grad_action [n,43] = dL/dy and the completed
  * action; the Jacobians are re-evaluated at that action (the reference keeps those of the last Newton point). */
-int rpo_evopf_complete_bwd(int n, const float* action, const float* grad_action, const float* grad_action2, float* grad_ap,
-                           const float* consts_dev, void* stream);   /* grad_action2: NULL, or a second [n,43] term added to dL/dy */
+int rpo_evopf_complete_bwd(int n, const float* action, const float* grad_action, const float* grad_action_b, const float* grad_action2,
+                           float* grad_ap, const float* consts_dev, void* stream);
+/*   dL/dy = (grad_action [+ grad_action_b]) [+ grad_action2]: grad_action_b (NULL, or the second twin critic's [n,43] term) and
+ *   grad_action2 (NULL, or the Lagrangian's) are added inside the kernel, in that order. */
 
 /* eq_resid [n,28] (evopf.py:520-546) and ineq_resid [n,58] (signed, :548-563); either output may be NULL. */
 int rpo_evopf_resid(int n, const float* state, int state_stride, const float* action, float* eq_out, float* ineq_out,

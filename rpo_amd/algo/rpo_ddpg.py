@@ -249,7 +249,12 @@ class RPODDPG(RPOTrainerBase):
             scale, base = self._box_affine
             self.backend.tanh_box_bwd(dap, ap_det, noise, self.eps_start, self.eps, self.decay_value, self._uctrl,
                                       self._box_lo, self._box_hi, scale, base, do.view(-1))
-        f.backward("actor", state, None, do)
+        # (no shared embedding: every gradient of the actor's slice is written by this backward -- it leaves the inf-norm for
+        #  clip_grad_norm_, no rpo_absmax launch)
+        opt = ag.actor_optim
+        fuse_max = self._self_cleaning and not self.dist.on and opt.clip_thres and opt.clip_thres != float("inf") and not shared
+        f.backward("actor", state, None, do, gradmax=opt.gradmax if fuse_max else None)
+        self._actor_gradmax_ready = bool(fuse_max)
         loss = _LazyMeanDiff(lag, q)                          # lag[0] - mean(Q), reduced only when somebody looks
         self.last_losses["actor"] = loss
         return loss

@@ -24,6 +24,20 @@ class _LazySumPair(object):
         return float(self.detach())
 
 
+class _LazySacLoss(object):
+    """Lagrangian term (one device word) + mean(alpha log pi - min(Q1, Q2)) over buffers that stay valid until the next policy
+    step: no reduction launches inside the iteration."""
+
+    def __init__(self, lag, alpha, logp, q1, q2):
+        self.lag, self.alpha, self.logp, self.q1, self.q2 = lag, alpha, logp, q1, q2
+
+    def __float__(self):
+        return float(self.detach())
+
+    def detach(self):
+        return self.lag[0] + (self.alpha * self.logp.view(-1, 1) - torch.min(self.q1, self.q2)).mean()
+
+
 class RPOSAC(RPOTrainerBase):
     sac = True
 
@@ -251,10 +265,13 @@ class RPOSAC(RPOTrainerBase):
         k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1), obs=state,
                      **(dict(overwrite=True) if fa else {}))
         # d(-min(q1, q2))/dq: the smaller one takes the gradient, ties are split (torch.min's backward)
-        w1 = (q1 < q2).to(torch.float32) + 0.5 * (q1 == q2).to(torch.float32)
         dq1, dq2 = f.buf("dq1", B, 1), f.buf("dq2", B, 1)
-        torch.mul(w1, -1.0 / B, out=dq1)
-        torch.mul(1.0 - w1, -1.0 / B, out=dq2)
+        if hasattr(self.backend, "min_q_bwd"):
+            self.backend.min_q_bwd(q1, q2, -1.0 / B, dq1, dq2)
+        else:
+            w1 = (q1 < q2).to(torch.float32) + 0.5 * (q1 == q2).to(torch.float32)
+            torch.mul(w1, -1.0 / B, out=dq1)
+            torch.mul(1.0 - w1, -1.0 / B, out=dq2)
         da1, da2 = f.buf("da1", B, k.action_dim), f.buf("da2", B, k.action_dim)
         shared = ag.flat.sizes[1] > 0
         f.backward_pair("critic1", "critic2", state, actions, dq1, dq2, da1, da2, param_grads=shared,
@@ -262,8 +279,7 @@ class RPOSAC(RPOTrainerBase):
         P = k.partial_dim
         dap, draw = f.buf("dap", B * P), f.buf("draw", B, 2 * P)
         if fa:
-            da1.add_(da2)
-            k.complete_bwd(state, da1, dap, action=actions, grad_action2=g_act)
+            k.complete_bwd(state, da1, dap, action=actions, grad_action_b=da2, grad_action2=g_act)
         else:
             da1.add_(da2).add_(g_act)
             k.complete_bwd(state, da1, dap, action=actions)
@@ -273,8 +289,13 @@ class RPOSAC(RPOTrainerBase):
             scale, base = self._box_affine
             self.backend.gauss_head_bwd(raw, eps.view(-1), dap, float(ag.alpha) / B, scale, base, self._box_lo,
                                         self._box_hi, draw)
-        f.backward("actor", state, None, draw)
-        loss = lag[0] + (float(ag.alpha) * logp.view(-1, 1) - torch.min(q1, q2)).mean()
+        # (no shared embedding: every gradient of the actor's slice is written by this backward -- it leaves the inf-norm for
+        #  clip_grad_norm_, no rpo_absmax launch)
+        opt = ag.actor_optim
+        fuse_max = self._self_cleaning and not self.dist.on and opt.clip_thres and opt.clip_thres != float("inf") and not shared
+        f.backward("actor", state, None, draw, gradmax=opt.gradmax if fuse_max else None)
+        self._actor_gradmax_ready = bool(fuse_max)
+        loss = _LazySacLoss(lag, float(ag.alpha), logp, q1, q2)   # reduced only when somebody looks (five launches otherwise)
         self.last_losses["actor"] = loss
         return loss, logp.view(-1, 1)
 

@@ -219,6 +219,7 @@ __global__ __launch_bounds__(RPO_WAVE * kActWaves) void evopf_act_project_kernel
 // those of the last Newton point, one update of size < tol earlier).  grad_ap [n,14] = dL/dz.
 __global__ __launch_bounds__(RPO_WAVE * kActWaves) void evopf_complete_bwd_kernel(int n, const float* __restrict__ action,
                                                                       const float* __restrict__ grad_action,
+                                                                      const float* __restrict__ grad_action_b,
                                                                       const float* __restrict__ grad_action2,
                                                                       float* __restrict__ grad_ap,
                                                                       const float* __restrict__ consts) {
@@ -229,10 +230,15 @@ __global__ __launch_bounds__(RPO_WAVE * kActWaves) void evopf_complete_bwd_kerne
     if (i >= n) return;
     load_consts(w, consts);
     load_row(w.a, action + (size_t)i * NY, NY);
-    // dl_dy (= grad_action [+ grad_action2]: d(-Q)/da from the critic + the Lagrangian term, rpo_ddpg.py:319, added here
-    // instead of by a launch of their own -- the same float addition)
-    for (int j = tid; j < NY; j += RPO_WAVE)
-        w.dir[j] = grad_action2 ? grad_action[(size_t)i * NY + j] + grad_action2[(size_t)i * NY + j] : grad_action[(size_t)i * NY + j];
+    // dl_dy = (grad_action [+ grad_action_b]) [+ grad_action2]: d(-Q)/da from the critic (twin critics: the two terms) + the
+    // Lagrangian term, rpo_ddpg.py:319 / rpo_sac.py:331-337, added here instead of by launches of their own -- the same float
+    // additions in the same order
+    for (int j = tid; j < NY; j += RPO_WAVE) {
+        float v = grad_action[(size_t)i * NY + j];
+        if (grad_action_b) v = v + grad_action_b[(size_t)i * NY + j];
+        if (grad_action2) v = v + grad_action2[(size_t)i * NY + j];
+        w.dir[j] = v;
+    }
     sync();
     flows(w);
     // step 3 (:865-880): dl/d(vm, va) through pg_slack = -eq[0] and qg_j = -eq[14 + spv_j]
@@ -562,12 +568,12 @@ int rpo_evopf_gauss_head_bwd(int n, const float* state, int state_stride, const 
     return 0;
 }
 
-int rpo_evopf_complete_bwd(int n, const float* action, const float* grad_action, const float* grad_action2, float* grad_ap,
-                           const float* consts_dev, void* stream) {
+int rpo_evopf_complete_bwd(int n, const float* action, const float* grad_action, const float* grad_action_b, const float* grad_action2,
+                           float* grad_ap, const float* consts_dev, void* stream) {
     if (int e = check_common(n, action, grad_action, consts_dev)) return e;
     if (!grad_ap) return RPO_ERR_NULL;
     hipLaunchKernelGGL(evopf_complete_bwd_kernel, dim3((n + kActWaves - 1) / kActWaves), dim3(RPO_WAVE * kActWaves), 0, (hipStream_t)stream, n, action, grad_action,
-                       grad_action2, grad_ap, consts_dev);
+                       grad_action_b, grad_action2, grad_ap, consts_dev);
     RPO_LAUNCH_CHECK();
     return 0;
 }

@@ -191,6 +191,16 @@ struct AdamArgs4 {
 };
 __global__ __launch_bounds__(RPO_BLOCK) void adam_multi_kernel(AdamArgs4 p) { adam_body(p.seg[blockIdx.y]); }
 
+__global__ __launch_bounds__(RPO_BLOCK) void min_q_bwd_kernel(int n, const float* __restrict__ q1, const float* __restrict__ q2,
+                                                              float scale, float* __restrict__ dq1, float* __restrict__ dq2) {
+    for (int i = blockIdx.x * RPO_BLOCK + threadIdx.x; i < n; i += gridDim.x * RPO_BLOCK) {
+        const float a = q1[i], b = q2[i];
+        const float w = (a < b ? 1.0f : 0.0f) + 0.5f * (a == b ? 1.0f : 0.0f);
+        dq1[i] = w * scale;
+        dq2[i] = (1.0f - w) * scale;
+    }
+}
+
 __global__ __launch_bounds__(RPO_BLOCK) void polyak_kernel(long long n, const float* __restrict__ param,
                                                            float* __restrict__ target, float tau) {
     for (long long i = (long long)blockIdx.x * RPO_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * RPO_BLOCK)
@@ -313,6 +323,14 @@ int rpo_adam_step_multi(int count, const rpo_adam_seg* segs, long long* clock, v
         n_max = g.n > n_max ? g.n : n_max;
     }
     hipLaunchKernelGGL(adam_multi_kernel, dim3(rpo_grid_for(n_max), count), dim3(RPO_BLOCK), 0, (hipStream_t)stream, a);
+    RPO_LAUNCH_CHECK();
+    return 0;
+}
+
+int rpo_min_q_bwd(int n, const float* q1, const float* q2, float scale, float* dq1, float* dq2, void* stream) {
+    if (n <= 0) return RPO_ERR_ARG;
+    if (!q1 || !q2 || !dq1 || !dq2) return RPO_ERR_NULL;
+    hipLaunchKernelGGL(min_q_bwd_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, q1, q2, scale, dq1, dq2);
     RPO_LAUNCH_CHECK();
     return 0;
 }

@@ -170,6 +170,11 @@ def adam_step_multi(segs, clock=None, prepared=False):
           "rpo_adam_step_multi")
 
 
+def min_q_bwd(q1, q2, scale, dq1, dq2):
+    """d(-min(q1, q2))/dq * (-scale): see rpo_min_q_bwd."""
+    check(_lib.load().rpo_min_q_bwd(q1.numel(), _p(q1), _p(q2), scale, _p(dq1), _p(dq2), _stream()), "rpo_min_q_bwd")
+
+
 def polyak(param, target, tau):
     check(_lib.load().rpo_polyak(param.numel(), _p(param), _p(target), tau, _stream()), "rpo_polyak")
 
@@ -345,9 +350,10 @@ class EvopfKernels(object):
         check(_lib.load().rpo_evopf_gauss_head_bwd(draw.numel() // (2 * self.partial_dim), sp, ss, _p(raw), _p(eps), _p(dap), dlogp, _p(draw),
                                                    self._c(raw), _stream()), "rpo_evopf_gauss_head_bwd")
 
-    def complete_bwd(self, obs, grad_action, grad_ap, action=None, grad_action2=None):
-        """grad_action2: a second dL/dy term, added inside the kernel (the caller saves an elementwise launch)."""
-        check(_lib.load().rpo_evopf_complete_bwd(grad_action.shape[0], _p(action), _p(grad_action),
+    def complete_bwd(self, obs, grad_action, grad_ap, action=None, grad_action2=None, grad_action_b=None):
+        """grad_action_b (the second twin critic's term) / grad_action2 (the Lagrangian's): more dL/dy terms, added inside the
+        kernel in that order (the caller saves the elementwise launches)."""
+        check(_lib.load().rpo_evopf_complete_bwd(grad_action.shape[0], _p(action), _p(grad_action), _p(grad_action_b, allow_none=True),
                                                  _p(grad_action2, allow_none=True), _p(grad_ap), self._c(action), _stream()),
               "rpo_evopf_complete_bwd")
 

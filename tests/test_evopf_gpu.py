@@ -208,6 +208,33 @@ def test_step_matches_reference_fixture(env):
     np.testing.assert_allclose(row[:, c["ineq_viol"][0]:c["ineq_viol"][1]], fx["ineq_viol"], atol=2e-6)
 
 
+def test_equation_solver_backward_adds_its_terms_in_the_kernel(env):
+    """rpo_evopf_complete_bwd(grad_action_b, grad_action2): dL/dy = (grad_action + grad_action_b) + grad_action2 inside the kernel
+    == the same sums made by elementwise launches first, bit for bit (ragged n: the last workgroup is partly empty); and
+    rpo_min_q_bwd == torch.min's backward of -min(q1, q2) / B, ties split."""
+    from rpo_amd import ops
+    s, rng = states(37, seed=12)
+    a = dev(oe.complete_partial(s.astype(np.float64), partials(s, rng).astype(np.float64)).astype(np.float32))
+    g1, g2, g3 = (dev(rng.randn(37, 43).astype(np.float32)) for _ in range(3))
+    k = env.kernels
+    want, got = torch.zeros(37 * 14, device="cuda"), torch.zeros(37 * 14, device="cuda")
+    k.complete_bwd(None, (g1 + g2) + g3, want, action=a)
+    k.complete_bwd(None, g1, got, action=a, grad_action_b=g2, grad_action2=g3)
+    assert torch.equal(want, got) and float(got.abs().max()) > 0
+    k.complete_bwd(None, g1 + g3, want, action=a)
+    k.complete_bwd(None, g1, got, action=a, grad_action2=g3)
+    assert torch.equal(want, got)
+    q1 = dev(rng.randn(300, 1).astype(np.float32))
+    q2 = q1.clone()
+    q2[::3] += 0.5
+    q2[1::3] -= 0.5                                                 # a third each: q1 smaller, q2 smaller, equal
+    dq1, dq2 = torch.empty(300, 1, device="cuda"), torch.empty(300, 1, device="cuda")
+    ops.min_q_bwd(q1, q2, -1.0 / 300, dq1, dq2)
+    a1, a2 = q1.clone().requires_grad_(True), q2.clone().requires_grad_(True)
+    (-torch.min(a1, a2)).mean().backward()
+    assert torch.equal(dq1, a1.grad) and torch.equal(dq2, a2.grad)
+
+
 def test_lagrangian(env):
     s, rng = states(256, seed=6)
     a = (oe.complete_partial(s.astype(np.float64), partials(s, rng).astype(np.float64)) + 0.05 * rng.randn(256, 43)).astype(np.float32)
