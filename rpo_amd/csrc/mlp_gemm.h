@@ -32,7 +32,8 @@ struct GemmArgs {
                                                // Huber loss of the tile's rows (the prologue of mlp_bwd_rows_body): dLoss/dQ into the
                                                // A tile, and (column block 0) into td.dq_out with the tile's loss share
 };
-struct GemmArgs4 { GemmArgs g[4]; };
+constexpr int kGemmProblems = 8;               // problems per launch (blockIdx.z): RPOSAC's four critics x {state, action} halves
+struct GemmArgs4 { GemmArgs g[kGemmProblems]; };
 
 constexpr int kGemmThreads = 256, kGemmCols = 64, kGemmMaxK = 512;
 
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(kGemmThreads) void mlp_gemm_kernel(GemmArgs4 all, i
 
 template <bool W_NK>
 static inline int gemm_launch(const GemmArgs* g, int count, hipStream_t stream) {
+    if (count < 1 || count > kGemmProblems) return RPO_ERR_ARG;
     GemmArgs4 all{};
     int maxN = 0, maxM = 0, maxK = 0;
     bool vec_a = true, vec_w = W_NK;
@@ -242,6 +244,11 @@ static inline bool gemm_path_ok(const Mlp& net, int n, const void* x0, const voi
     return gemm_path_enabled() && net.E == 256 && net.H == 256 && x0 && h1 && out_mode == 0 && n <= 16384;
 }
 
+// whether `count` (<= 4) networks of this shape fit the problems of one launch (second heads / action halves are problems too)
+static inline bool gemm_fits(const Mlp& net, int count) {
+    return count <= 4 && count * (net.cat ? 2 : 1) <= kGemmProblems && count * (net.n_out > 1 ? 2 : 1) <= kGemmProblems;
+}
+
 // forward of `count` same-shaped networks: three launches (first layer | hidden layer | heads)
 struct GemmFwd { Mlp net; int n; const float* s; int s_stride; const float* a; int a_stride; float* out; float* x0; float* h1; };
 
@@ -275,19 +282,16 @@ static inline int gemm_forward(const GemmFwd* f, int count, hipStream_t stream) 
         if (net.n_out > 1) { g3b[i].W = net.W1b; g3b[i].bias = net.b1b; g3b[i].C = f[i].out + heads; }
     }
     // (a second output head / the action half of a concatenating critic are more problems of the same launch)
-    GemmArgs l1[4], l3[4];
+    GemmArgs l1[kGemmProblems], l3[kGemmProblems];
     int c1 = 0, c3 = 0;
-    for (int i = 0; i < count; ++i) { l1[c1++] = g1[i]; if (n0.cat) { if (c1 >= 4) return RPO_ERR_ARG; l1[c1++] = g1b[i]; } }
-    for (int i = 0; i < count; ++i) { l3[c3++] = g3[i]; if (n0.n_out > 1) { if (c3 >= 4) return RPO_ERR_ARG; l3[c3++] = g3b[i]; } }
+    if (!gemm_fits(n0, count)) return RPO_ERR_ARG;
+    for (int i = 0; i < count; ++i) { l1[c1++] = g1[i]; if (n0.cat) l1[c1++] = g1b[i]; }
+    for (int i = 0; i < count; ++i) { l3[c3++] = g3[i]; if (n0.n_out > 1) l3[c3++] = g3b[i]; }
     if (int e = gemm_launch<true>(l1, c1, stream)) return e;
     if (int e = gemm_launch<true>(g2, count, stream)) return e;
     return gemm_launch<true>(l3, c3, stream);
 }
 
-// whether `count` networks of this shape fit the four problems of one launch (second heads / action halves are problems too)
-static inline bool gemm_fits(const Mlp& net, int count) {
-    return count * (net.cat ? 2 : 1) <= 4 && count * (net.n_out > 1 ? 2 : 1) <= 4;
-}
 
 // rows part of the backward of `count` (1 or 2) same-shaped networks: [TD +] dh | dx0 | [da]
 static inline int gemm_backward_rows(const BwdArgs* b, int count, hipStream_t stream) {
