@@ -61,8 +61,9 @@ __device__ __forceinline__ void mlp_forward_body(const FwdArgs& p) {
     }
 }
 
+// (HIP: the second bound is waves per SIMD -- four = two workgroups per CU; at 146 registers the 64-row form ran ONE -- every phase of a tile exposed, 0.48 of the MFMA peak)
 template <int EIN, int H, int RT, int INS, int INA>
-__global__ __launch_bounds__(kFwdThreads) void mlp_forward_kernel(FwdArgs p) { mlp_forward_body<EIN, H, RT, INS, INA>(p); }
+__global__ __launch_bounds__(kFwdThreads, 4) void mlp_forward_kernel(FwdArgs p) { mlp_forward_body<EIN, H, RT, INS, INA>(p); }
 
 // Up to four same-shaped networks on their own inputs in one launch (gridDim.y = network): Q_targ(s', a') and Q(s, a) of a
 // critic update (and SAC's twins) are independent of each other.
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_forward_multi_kernel(FwdArgs4
     mlp_forward_body<EIN, H, 1, kInS, kInA>(p.net[blockIdx.y]);
 }
 template <int H>
-__global__ __launch_bounds__(kFwdThreads) void mlp_forward_multi64_kernel(FwdArgs4 p) {     // 64 rows per workgroup (large n)
+__global__ __launch_bounds__(kFwdThreads, 4) void mlp_forward_multi64_kernel(FwdArgs4 p) {     // 64 rows per workgroup (large n)
     mlp_forward_body<128, H, 4, 8, 8>(p.net[blockIdx.y]);
 }
 

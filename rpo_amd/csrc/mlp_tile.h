@@ -60,7 +60,7 @@ template <int EIN, int H, int RT>
 struct TileWeights {
     static constexpr int NT = H / (16 * kFwdWaves);              // 16-column tiles per wave
     static constexpr int ITS = EIN / 16;                         // k-groups of 16
-    static constexpr int PRE_MAX = RT > 1 ? 8 : 16;
+    static constexpr int PRE_MAX = RT > 1 ? 4 : 16;           // (64-row form: 120 registers = TWO workgroups per CU; the other k-groups stream from L2)           // (64-row form: 128 registers = two workgroups per CU; the last k-groups stream from L2)
     static constexpr int PRE = ITS < PRE_MAX ? ITS : PRE_MAX;    // k-groups kept in registers
     float bias;
     float ws0[8], wa0[8];                                        // first chunk of the column's first-layer weights
