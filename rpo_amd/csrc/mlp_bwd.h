@@ -734,6 +734,26 @@ __global__ __launch_bounds__(kOnepassThreads) void mlp_bwd_onepass_kernel(BwdArg
 #pragma unroll
             for (int b = 0; b < 8; ++b) accw[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         float xn[kRows * EIN / NT];
+        // first-layer sums: thread (input half, column e) adds dx0[r][e] x its inputs, rows in order -- the PREVIOUS tile's, while
+        // the X waves form dh of the current one (both are vector work: on the X waves alone this phase was exposed, 0.4 ms)
+        float gfl[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) gfl[i] = 0.0f;
+        const int e_own = tid & (EIN - 1);                           // threads [0, 128): state inputs of column e; [128, 256): action inputs
+        const bool act_half = tid >= EIN;
+        auto first_layer = [&](long long tile) {
+            if (act_half && !has_a) return;
+            const float4* in = reinterpret_cast<const float4*>(act_half ? in_ab[tile & 1] : in_sb[tile & 1]);
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) {
+                const float d = dx_s[r * LDX + e_own];
+                const float4 i0 = in[r * 2], i1 = in[r * 2 + 1];         // (the same address in every lane: broadcast reads)
+                gfl[0] = fmaf(d, i0.x, gfl[0]); gfl[1] = fmaf(d, i0.y, gfl[1]); gfl[2] = fmaf(d, i0.z, gfl[2]); gfl[3] = fmaf(d, i0.w, gfl[3]);
+                gfl[4] = fmaf(d, i1.x, gfl[4]); gfl[5] = fmaf(d, i1.y, gfl[5]); gfl[6] = fmaf(d, i1.z, gfl[6]); gfl[7] = fmaf(d, i1.w, gfl[7]);
+                gfl[8] += d;
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        };
         float tq = 0.0f, tqn1 = 0.0f, tqn2 = 0.0f, tlp = 0.0f, trw = 0.0f, tdn = 0.0f, tdo = 0.0f, tin_s = 0.0f, tin_a = 0.0f;   // small operands
         auto request = [&](long long tile) {
             const long long m0 = tile * kRows;
@@ -793,6 +813,7 @@ __global__ __launch_bounds__(kOnepassThreads) void mlp_bwd_onepass_kernel(BwdArg
             }
         if (tile + 1 < t_hi) request(tile + 1);
             __syncthreads();                                         // B1: x0_s, dout_s, the inputs
+            if (tile > t_lo) first_layer(tile - 1);                  // (dx_s of the previous tile: rewritten behind B2)
             __syncthreads();                                         // B2: dh_s
 #pragma unroll
             for (int ks = 0; ks < kRows / 4; ++ks) {                 // dW0 += dh^T relu(x0): hidden rows [64 wave, 64 wave + 64)
@@ -815,6 +836,18 @@ __global__ __launch_bounds__(kOnepassThreads) void mlp_bwd_onepass_kernel(BwdArg
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     RPO_SK(W0)[(size_t)(wave * 64 + mt * 16 + lg * 4 + i) * EIN + nt * 16 + li] = accw[mt][nt][i];
+        first_layer(t_hi - 1);                                       // (the last tile's dx_s is complete: B3)
+        if (!act_half) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < net.S) RPO_SK(Ws)[e_own * net.S + i] = gfl[i];
+            RPO_SK(bs)[e_own] = gfl[8];
+        } else if (has_a) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < net.A) RPO_SK(Wa)[e_own * net.A + i] = gfl[i];
+            RPO_SK(ba)[e_own] = gfl[8];
+        }
         return;
     }
     // ==================================================================== X waves: dh, dx0, hidden vectors, first layer
@@ -824,11 +857,7 @@ __global__ __launch_bounds__(kOnepassThreads) void mlp_bwd_onepass_kernel(BwdArg
 #pragma unroll
         for (int ks = 0; ks < H / 4; ++ks) w0r[t][ks] = net.W0[(size_t)(ks * 4 + lg) * EIN + wave * 32 + t * 16 + li];
     const float w1a = net.W1[tid], w1b = two ? net.W1b[tid] : 0.0f;
-    float gb0 = 0.0f, gw1a = 0.0f, gw1b = 0.0f, gfl[9], gb1a = 0.0f, gb1b = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) gfl[i] = 0.0f;
-    const int e_own = tid & (EIN - 1);                           // threads [0, 128): state inputs of column e; [128, 256): action inputs
-    const bool act_half = tid >= EIN;
+    float gb0 = 0.0f, gw1a = 0.0f, gw1b = 0.0f, gb1a = 0.0f, gb1b = 0.0f;
     float hn[kRows];
     auto request = [&](long long tile) {
         const long long m0 = tile * kRows;
@@ -862,15 +891,18 @@ __global__ __launch_bounds__(kOnepassThreads) void mlp_bwd_onepass_kernel(BwdArg
         if (tile + 1 < t_hi) request(tile + 1);                      // (lands under the MFMA phase and the first-layer sums)
         __syncthreads();                                             // B2
         // ---- dx0 = (dh W0) * 1[x0 > 0]: wave w owns columns [32 w, 32 w + 32)
+        // (two chains per column tile -- even and odd k-steps, added at the end: with one accumulator per tile every MFMA waited
+        //  for the one two before it, 0.85 ms of the launch)
         f32x4 ax[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+        f32x4 ay[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll                                                  // (fully: w0r must be indexed statically to stay in registers;
         for (int kc = 0; kc < H / 32; ++kc) {                    //  fenced in eights so the scheduler does not hoist all 64 LDS reads)
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 const int ks = kc * 8 + kk;
                 const float av = dh_s[li * LDH + ks * 4 + lg];
-                ax[0] = mfma4(av, w0r[0][ks], ax[0]);
-                ax[1] = mfma4(av, w0r[1][ks], ax[1]);
+                if (ks & 1) { ay[0] = mfma4(av, w0r[0][ks], ay[0]); ay[1] = mfma4(av, w0r[1][ks], ay[1]); }
+                else { ax[0] = mfma4(av, w0r[0][ks], ax[0]); ax[1] = mfma4(av, w0r[1][ks], ax[1]); }
             }
         }
 #pragma unroll
@@ -878,40 +910,16 @@ __global__ __launch_bounds__(kOnepassThreads) void mlp_bwd_onepass_kernel(BwdArg
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = lg * 4 + i, n = wave * 32 + t * 16 + li;
-                dx_s[r * LDX + n] = x0_s[r * LDX + n] > 0.0f ? ax[t][i] : 0.0f;
+                dx_s[r * LDX + n] = x0_s[r * LDX + n] > 0.0f ? ax[t][i] + ay[t][i] : 0.0f;
             }
         __syncthreads();                                             // B3
-        // ---- first-layer gradients: thread (half, e) adds dx0[r][e] x its inputs, rows in order
-        if (!act_half || has_a) {
-            const float4* in = reinterpret_cast<const float4*>(act_half ? in_ab[tile & 1] : in_sb[tile & 1]);
-#pragma unroll
-            for (int r = 0; r < kRows; ++r) {
-                const float d = dx_s[r * LDX + e_own];
-                const float4 i0 = in[r * 2], i1 = in[r * 2 + 1];         // (the same address in every lane: broadcast reads)
-                gfl[0] = fmaf(d, i0.x, gfl[0]); gfl[1] = fmaf(d, i0.y, gfl[1]); gfl[2] = fmaf(d, i0.z, gfl[2]); gfl[3] = fmaf(d, i0.w, gfl[3]);
-                gfl[4] = fmaf(d, i1.x, gfl[4]); gfl[5] = fmaf(d, i1.y, gfl[5]); gfl[6] = fmaf(d, i1.z, gfl[6]); gfl[7] = fmaf(d, i1.w, gfl[7]);
-                gfl[8] += d;
-                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // (dx_s is rewritten two barriers from here, the inputs live in the other parity's buffer)
+        // (the first-layer sums of this tile are the W waves' work behind the next B1)
     }
     // ---- the slice's sums into its copy of the gradient span
     RPO_SK(b0)[tid] = gb0;
     RPO_SK(W1)[tid] = gw1a;
     if (two) RPO_SK(W1b)[tid] = gw1b;
     if (tid == 0) { RPO_SK(b1)[0] = gb1a; if (two) RPO_SK(b1b)[0] = gb1b; }
-    if (!act_half) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i < net.S) RPO_SK(Ws)[e_own * net.S + i] = gfl[i];
-        RPO_SK(bs)[e_own] = gfl[8];
-    } else if (has_a) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i < net.A) RPO_SK(Wa)[e_own * net.A + i] = gfl[i];
-        RPO_SK(ba)[e_own] = gfl[8];
-    }
 #undef RPO_SK
 }
 
