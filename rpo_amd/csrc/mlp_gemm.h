@@ -28,14 +28,6 @@ struct GemmArgs {
     const float* mask; int ldmask;             // NULL, or C is zeroed where mask <= 0 (the relu of the saved pre-activation)
     int M, N;
     int relu_a;                                // opA = relu (the consumer applies the producer's activation)
-    // Producer of the A tile (backward): preW != NULL: A is not read but formed here, one column per thread (K == 256):
-    //   A[m][k] = (sum_o preP[m][o] preW[o][k] [+ sum_o preP2[m][o] preW2[o][k]]) * 1[preMask[m][k] > 0]
-    // i.e. dh = (dout W1 [+ dout_b W1b]) * 1[h1 > 0] inside the dx0 launch instead of a launch of its own (~5 us in the EVOPF
-    // windows for 16 x 14 fmas per thread); column block 0 leaves the tile in preOut for the weights pass.  With td.q the one
-    // column of preP is the TD / Huber prologue's dLoss/dQ.
-    const float* preP; int ldp; int preK;
-    const float* preW; const float* preP2; const float* preW2;
-    const float* preMask; float* preOut;
     TdArgs td;                                 // td.q != NULL: A (one column, K = 1) is not read but PRODUCED here -- the TD target +
                                                // Huber loss of the tile's rows (the prologue of mlp_bwd_rows_body): dLoss/dQ into the
                                                // A tile, and (column block 0) into td.dq_out with the tile's loss share
@@ -158,60 +150,7 @@ __global__ __launch_bounds__(kGemmThreads) void mlp_gemm_kernel(GemmArgs4 all, i
     const int kw = (p.K + 16 * CH - 1) / (16 * CH) * (16 * CH), ldk = kw + 4;
     const int kw2 = p.A2 ? (p.K2 + 16 * CH - 1) / (16 * CH) * (16 * CH) : 0, ldk2 = kw2 + 4;
     float* a2_s = a_s + kRows * ldk;
-    if (p.preW) {
-        // ---- the A tile is formed here (see GemmArgs.preW): thread = column k of the tile's 16 rows
-        __shared__ float pd[kRows][32];                            // head gradients of the tile: [row][o | second head's o]
-        const int k = tid, pk = p.preK, pk2 = p.preP2 ? p.preK : 0;
-        float hm[kRows], w1[16], w2[16];
-#pragma unroll
-        for (int r = 0; r < kRows; ++r) {
-            const int m = m0 + r < p.M ? m0 + r : p.M - 1;
-            hm[r] = p.preMask[(size_t)m * p.K + k];
-        }
-#pragma unroll
-        for (int o = 0; o < 16; ++o) {
-            w1[o] = o < pk ? p.preW[(size_t)o * p.K + k] : 0.0f;
-            w2[o] = o < pk2 ? p.preW2[(size_t)o * p.K + k] : 0.0f;
-        }
-        if (p.td.q) {
-            if (tid < 64) {
-                const TdArgs& t = p.td;
-                const int i = m0 + tid;
-                float dq = 0.0f, hub = 0.0f;
-                if (tid < kRows && i < p.M) {
-                    const float qn = rpo_head_dev::td_next_value(t.qn1[i], t.qn2 ? t.qn2[i] : 0.0f, t.qn2 != nullptr,
-                                                                 t.logp ? t.logp[i] : 0.0f, t.logp != nullptr, t.alpha);
-                    const float y = rpo_head_dev::td_target(t.reward[(size_t)i * t.reward_stride], t.done[(size_t)i * t.done_stride],
-                                                            t.gamma, qn);
-                    dq = rpo_head_dev::td_huber_row(t.q[i], y, 1.0f / (float)p.M, &hub);
-                    if (blockIdx.x == 0) t.dq_out[i] = dq;
-                }
-                if (tid < kRows) pd[tid][0] = dq;
-                const float sum = rpo_row16_sum_desc_lane0(hub);     // (the same 16-term sum as the rows kernel's prologue)
-                if (tid == 0 && blockIdx.x == 0) t.loss_partial[blockIdx.y] = sum;
-            }
-        } else {
-            for (int idx = tid; idx < kRows * (pk + pk2); idx += kGemmThreads) {
-                const int r = idx / (pk + pk2), o = idx - r * (pk + pk2);
-                const int m = m0 + r < p.M ? m0 + r : p.M - 1;
-                pd[r][o] = o < pk ? p.preP[(size_t)m * p.ldp + o] : p.preP2[(size_t)m * p.ldp + (o - pk)];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < kRows; ++r) {
-            float v = 0.0f;
-#pragma unroll
-            for (int o = 0; o < 16; ++o)
-                if (o < pk) v = fmaf(pd[r][o], w1[o], v);
-#pragma unroll
-            for (int o = 0; o < 16; ++o)
-                if (o < pk2) v = fmaf(pd[r][pk + o], w2[o], v);
-            if (!(hm[r] > 0.0f) || m0 + r >= p.M) v = 0.0f;
-            a_s[r * ldk + k] = v;
-            if (blockIdx.x == 0 && m0 + r < p.M && p.preOut) p.preOut[(size_t)(m0 + r) * p.K + k] = v;
-        }
-    } else if (p.td.q) {
+    if (p.td.q) {
         for (int idx = tid; idx < kRows * kw; idx += kGemmThreads) a_s[(idx / kw) * ldk + idx % kw] = 0.0f;
         __syncthreads();
         if (tid < 64) {
@@ -354,11 +293,6 @@ static inline int gemm_forward(const GemmFwd* f, int count, hipStream_t stream) 
 }
 
 
-static inline bool gemm_fuse_dh() {
-    const char* e = getenv("RPO_GEMM_FUSE_DH");                 // (0: dh as a launch of its own -- the A/B switch of the tests)
-    return !(e && e[0] == '0');
-}
-
 // rows part of the backward of `count` (1 or 2) same-shaped networks: [TD +] dh | dx0 | [da]
 static inline int gemm_backward_rows(const BwdArgs* b, int count, hipStream_t stream) {
     const Mlp& n0 = b[0].net;
@@ -379,17 +313,7 @@ static inline int gemm_backward_rows(const BwdArgs* b, int count, hipStream_t st
         ga[i].A = b[i].dx0 + (net.cat ? net.E : 0); ga[i].lda = ein; ga[i].K = net.E; ga[i].W = net.Wa; ga[i].ldw = net.A;
         ga[i].C = b[i].da; ga[i].ldc = net.A; ga[i].M = n; ga[i].N = net.A;
     }
-    // dh inside the dx0 launch (GemmArgs.preW) when a thread can own a hidden column and the heads fit its registers
-    const bool fuse = n0.H == kGemmThreads && heads <= 16 && gemm_fuse_dh();
-    if (fuse) {
-        for (int i = 0; i < count; ++i) {
-            gx[i].preP = b[i].dout; gx[i].ldp = outs; gx[i].preK = heads; gx[i].preW = b[i].net.W1;
-            if (b[i].net.n_out > 1) { gx[i].preP2 = b[i].dout + heads; gx[i].preW2 = b[i].net.W1b; }
-            gx[i].preMask = b[i].h1; gx[i].preOut = b[i].dh; gx[i].td = b[i].td;
-        }
-    } else if (int e = gemm_launch<false>(gh, count, stream)) {
-        return e;
-    }
+    if (int e = gemm_launch<false>(gh, count, stream)) return e;
     if (int e = gemm_launch<false>(gx, count, stream)) return e;
     if (b[0].da) return gemm_launch<false>(ga, count, stream);
     return 0;
