@@ -96,6 +96,48 @@ __device__ __forceinline__ void partial_box(const Ws& w, int j, float& lo, float
     else battery_bounds(w.s[2 * NB + j - 9], hi, lo);
 }
 
+// Ybus operands a thread needs again in every Newton / GRG iteration, kept in registers (they are constants; read from LDS they
+// were two reads per Jacobian entry and four per term of the admittance products, behind LDS stores the compiler cannot move
+// them across): column `tid` for flows(), row `i` for the Jacobian row of the equation a thread owns.  Same values, same
+// operations.
+struct YVec {
+    float yr[NB], yi[NB];
+};
+__device__ __forceinline__ YVec y_column(const Ws& w, int k) {
+    YVec y;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) { y.yr[i] = Yr(w, i, k); y.yi[i] = Yi(w, i, k); }
+    return y;
+}
+__device__ __forceinline__ YVec y_row(const Ws& w, int i) {
+    YVec y;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) { y.yr[k] = Yr(w, i, k); y.yi[k] = Yi(w, i, k); }
+    return y;
+}
+
+// flows() with the thread's Ybus column in registers (y_column(w, tid < NB ? tid : 0))
+__device__ __forceinline__ void flows(Ws& w, const YVec& yc) {
+    const int tid = lane_id();
+    if (tid < NB) {
+        float sn, cs;
+        sincosf(w.a[VA0 + tid], &sn, &cs);
+        const float vm = w.a[VM0 + tid];
+        w.cs[tid] = cs; w.sn[tid] = sn; w.vr[tid] = vm * cs; w.vi[tid] = vm * sn;
+    }
+    sync();
+    if (tid < NB) {
+        float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {                       // row vector @ matrix, as written at :527-528
+            t1 += w.vr[i] * yc.yr[i] - w.vi[i] * yc.yi[i];
+            t2 += w.vr[i] * yc.yi[i] + w.vi[i] * yc.yr[i];
+        }
+        w.t1[tid] = t1; w.t2[tid] = t2;
+    }
+    sync();
+}
+
 // cos / sin / rectangular voltages and the two admittance products of eq_resid / eq_jac (evopf.py:523-528,623-630)
 __device__ __forceinline__ void flows(Ws& w) {
     const int tid = lane_id();
@@ -221,6 +263,17 @@ __device__ __forceinline__ RowCoef row_coef(const Ws& w, int eq) {
 
 // eq_jac entry (this thread's equation, variable `var`); `var` is a compile-time constant at every call site, so only
 // the block it names survives.  Battery columns carry the reference's sign (hazard E1).
+__device__ __forceinline__ float jac_row_entry(const Ws& w, const RowCoef& c, int var, const YVec& yrow) {
+    if (var < QG0) return (c.real && kSpv[var] == c.i) ? 1.0f : 0.0f;
+    if (var < VM0) return (!c.real && kSpv[var - QG0] == c.i) ? 1.0f : 0.0f;
+    if (var >= PE0) return (c.real && kSpv[var - PE0] == c.i) ? -1.0f : 0.0f;
+    const bool dvm = var < VA0;
+    const int k = dvm ? var - VM0 : var - VA0;
+    const float yr = yrow.yr[k], yi = yrow.yi[k];              // (k is a compile-time constant at every call site)
+    const float p = dvm ? w.cs[k] : -w.vi[k], q = dvm ? w.sn[k] : w.vr[k];
+    const float A = yr * p - yi * q, B = yi * p + yr * q;
+    return c.ca * A + c.cb * B + (c.i == k ? (dvm ? c.dg_vm : c.dg_va) : 0.0f);
+}
 __device__ __forceinline__ float jac_row_entry(const Ws& w, const RowCoef& c, int var) {
     if (var < QG0) return (c.real && kSpv[var] == c.i) ? 1.0f : 0.0f;
     if (var < VM0) return (!c.real && kSpv[var - QG0] == c.i) ? 1.0f : 0.0f;
@@ -284,14 +337,16 @@ __device__ __forceinline__ int complete_partial(Ws& w, float zj, float tol, int 
     if (tid < NP) w.a[kPartialActions[tid]] = zj;              // (:796-799)
     sync();
     int it = 0;
+    const YVec yc = y_column(w, tid < NB ? tid : 0);           // (w.c is set: load_consts + sync happened before)
+    const YVec yk = y_row(w, (kKeep[tid < NN ? tid : 0]) % NB);
     for (; it < max_iters;) {
-        flows(w);
+        flows(w, yc);
         eq_resid(w);
         float row[NN + 1];                                     // row tid of [J_newton | g]
         {
             const RowCoef rc = row_coef(w, kKeep[tid < NN ? tid : 0]);
 #pragma unroll
-            for (int c = 0; c < NN; ++c) row[c] = tid < NN ? jac_row_entry(w, rc, kNewtonVars[c]) : 0.0f;
+            for (int c = 0; c < NN; ++c) row[c] = tid < NN ? jac_row_entry(w, rc, kNewtonVars[c], yk) : 0.0f;
             row[NN] = tid < NN ? w.eq[kKeep[tid]] : 0.0f;
         }
         int mycol;
@@ -309,7 +364,7 @@ __device__ __forceinline__ int complete_partial(Ws& w, float zj, float tol, int 
         ++it;
         if (sqrtf(rpo_wave_sum(d2)) < tol) break;              // torch.norm(delta) < tol (:834), this lane only
     }
-    flows(w);
+    flows(w, yc);
     eq_resid(w);                                               // with qg = 0 and slack pg = 0
     if (tid < NG) w.a[QG0 + tid] = -w.eq[NB + kSpv[tid]];      // (:844-845)
     if (tid == 0) w.a[PG0] = -w.eq[0];                         // (:847-848)
@@ -319,7 +374,7 @@ __device__ __forceinline__ int complete_partial(Ws& w, float zj, float tol, int 
 }
 
 // ineq_partial_grad (evopf.py:596-612) of (w.s, w.a) into w.dir[43]; flows() must be current.
-__device__ __forceinline__ void ineq_partial_grad(Ws& w) {
+__device__ __forceinline__ void ineq_partial_grad(Ws& w, const YVec& yrow) {   // yrow = y_row(w, bus of equation kRowOrder[tid])
     const int tid = lane_id();
     // thread r owns equation kRowOrder[r] of [J_other | J_partial]
     float row[NY];
@@ -328,7 +383,7 @@ __device__ __forceinline__ void ineq_partial_grad(Ws& w) {
 #pragma unroll
         for (int c = 0; c < NY; ++c) {
             const int var = c < NO ? kOtherVars[c] : kPartialVars[c - NO];
-            row[c] = tid < NEQ ? jac_row_entry(w, rc, var) : 0.0f;
+            row[c] = tid < NEQ ? jac_row_entry(w, rc, var, yrow) : 0.0f;
         }
     }
     ineq_resid(w);                                             // (syncs)
@@ -366,13 +421,19 @@ __device__ __forceinline__ void ineq_partial_grad(Ws& w) {
     sync();
 }
 
+__device__ __forceinline__ void ineq_partial_grad(Ws& w) {
+    ineq_partial_grad(w, y_row(w, kRowOrder[lane_id() < NEQ ? lane_id() : 0] % NB));
+}
+
 // grad_steps (rpo_ddpg.py:266-305, corr_mode 0) on w.a with the lane's own stop test; returns the iteration count
 __device__ __forceinline__ int grad_steps(Ws& w, int max_steps, float lr, float corr_eps, float momentum) {
     const int tid = lane_id();
     if (tid < NY) w.old[tid] = 0.0f;
+    const YVec yc = y_column(w, tid < NB ? tid : 0);
+    const YVec yo = y_row(w, kRowOrder[tid < NEQ ? tid : 0] % NB);
     int k = 0;
     for (; k < max_steps; ++k) {
-        flows(w);
+        flows(w, yc);
         if (k > 0) {
             eq_resid(w);
             ineq_resid(w);
@@ -380,7 +441,7 @@ __device__ __forceinline__ int grad_steps(Ws& w, int max_steps, float lr, float 
             if (tid < NINEQ) m = fmaxf(m, w.ineq[tid]);
             if (!(rpo_wave_max(m) > corr_eps)) break;
         }
-        ineq_partial_grad(w);
+        ineq_partial_grad(w, yo);
         if (tid < NY) {
             const float st = lr * w.dir[tid] + momentum * w.old[tid];
             w.a[tid] -= st;
