@@ -82,6 +82,9 @@ extern "C" {
 #define RPO_EVOPF_C_QUAD 468
 #define RPO_EVOPF_C_LIN 473
 #define RPO_EVOPF_C_CONST 478
+#define RPO_EVOPF_C_FLAGS 479 /* 0: eliminate in the compiled-in static order of the case14 network (sparse; falls back to partial
+                                 pivoting per solve when a pivot is < 2^-6 of the largest one); != 0: always partial pivoting
+                                 (the host sets it when the uploaded Ybus has entries outside case14's branch pattern) */
 #define RPO_EVOPF_C_PS 480
 #define RPO_EVOPF_C_SHARE 504
 #define RPO_EVOPF_C_QSIGN 518

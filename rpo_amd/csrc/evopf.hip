@@ -249,20 +249,35 @@ __global__ __launch_bounds__(RPO_WAVE * kActWaves) void evopf_complete_bwd_kerne
     }
     sync();
     // step 1 (:889-891): d_int = inv(J_newton)^T dl_dy_total[newton vars]
-    float row[NN + 1];                                                  // row tid of [J_newton^T | rhs]
+    const bool force_dyn = w.c[RPO_EVOPF_C_FLAGS] != 0.0f;
+    bool solved = false;
+    float dint = 0.0f;
+    int mycol = tid;
+    if (!force_dyn) {                                                   // static order (evopf_dev.h), accepted by its pivots
+        float row[NN + 1];                                              // row tid of [J_newton^T | rhs]
 #pragma unroll
-    for (int c = 0; c < NN; ++c) row[c] = tid < NN ? jac_entry(w, kKeep[c], kNewtonVars[tid]) : 0.0f;
-    row[NN] = tid < NN ? w.vec[kNewtonVars[tid] - VM0] : 0.0f;
-    int mycol;
-    float mypiv;
-    gauss_jordan_rows<NN, NN + 1, 0>(row, mycol, mypiv);
+        for (int c = 0; c < NN; ++c) row[c] = tid < NN ? jac_entry(w, kKeep[c], kNewtonVars[tid]) : 0.0f;
+        row[NN] = tid < NN ? w.vec[kNewtonVars[tid] - VM0] : 0.0f;
+        const float mypiv = gauss_jordan_static<NN, NN + 1, 0, TabNewtonT>(row);
+        solved = pivots_ok<NN, 0>(mypiv);
+        dint = row[NN] / mypiv;
+    }
+    if (!solved) {                                                      // partial pivoting
+        float row[NN + 1];
+#pragma unroll
+        for (int c = 0; c < NN; ++c) row[c] = tid < NN ? jac_entry(w, kKeep[c], kNewtonVars[tid]) : 0.0f;
+        row[NN] = tid < NN ? w.vec[kNewtonVars[tid] - VM0] : 0.0f;
+        float mypiv;
+        gauss_jordan_rows<NN, NN + 1, 0>(row, mycol, mypiv);
+        dint = row[NN] / mypiv;
+    }
     sync();
-    if (tid < NN) w.old[mycol] = row[NN] / mypiv;                       // d_int
+    if (tid < NN) w.old[mycol] = dint;                                  // d_int, indexed like kKeep
     sync();
     if (tid < NP) {
         float g;
         if (tid < 4) {                                                  // pg at pv gens (:894) + direct term (:907)
-            g = -w.old[tid] + w.dir[PG0 + 1 + tid];
+            g = -w.old[kPvPos[tid]] + w.dir[PG0 + 1 + tid];
         } else if (tid < 9) {                                           // vm at generator buses (:895-896)
             const int var = VM0 + kSpv[tid - 4];
             float acc = 0.0f;
@@ -271,7 +286,7 @@ __global__ __launch_bounds__(RPO_WAVE * kActWaves) void evopf_complete_bwd_kerne
         } else if (tid == 9) {                                          // pe at the slack generator (:898)
             g = w.dir[PG0] + w.dir[PE0];
         } else {                                                        // pe at pv gens (:897)
-            g = w.old[tid - 10] + w.dir[PE0 + tid - 9];
+            g = w.old[kPvPos[tid - 10]] + w.dir[PE0 + tid - 9];
         }
         grad_ap[(size_t)i * NP + tid] = g;
     }

@@ -37,18 +37,80 @@ __device__ constexpr int kLoadSlot[NB] = {-1, 0, 1, 2, 3, 4, -1, -1, 5, 6, 7, 8,
 // variables the actor sets (evopf.py:287-294; z order = pg at pv gens, vm at gens, [slack angle], pe) ...
 __device__ constexpr int kPartialVars[NPV] = {1, 2, 3, 4, 10, 11, 12, 15, 17, 24, 38, 39, 40, 41, 42};
 __device__ constexpr int kPartialActions[NP] = {1, 2, 3, 4, 10, 11, 12, 15, 17, 38, 39, 40, 41, 42};
-// ... and the ones the equations determine (evopf.py:290)
-__device__ constexpr int kOtherVars[NO] = {0, 5, 6, 7, 8, 9, 13, 14, 16, 18, 19, 20, 21, 22, 23,
-                                           25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37};
-// Equation order used for the 28 x 28 elimination: the first six "other" variables (slack pg, qg) appear in exactly
-// one equation each with coefficient 1 (P at the slack bus, Q at the generator buses), so with these rows first the
-// leading 6 x 6 block is the identity and the elimination starts at pivot 6; the rest are the Newton equations.
-__device__ constexpr int kRowOrder[NEQ] = {0, 14, 15, 16, 19, 21, 1, 2, 5, 7, 3, 4, 6, 8, 9, 10, 11, 12, 13,
-                                           17, 18, 20, 22, 23, 24, 25, 26, 27};
-// Newton system (evopf.py:809-816): P at pv, P at pq, Q at pq  x  vm at pq, va at pv, va at pq
-__device__ constexpr int kKeep[NN] = {1, 2, 5, 7, 3, 4, 6, 8, 9, 10, 11, 12, 13, 17, 18, 20, 22, 23, 24, 25, 26, 27};
-__device__ constexpr int kNewtonVars[NN] = {13, 14, 16, 18, 19, 20, 21, 22, 23, 25, 26, 29, 31,
-                                            27, 28, 30, 32, 33, 34, 35, 36, 37};
+// STATIC ELIMINATION ORDER (round 4).  The equations / unknowns of both linear systems are paired along the network: bus i's
+// active-power balance with its angle, and (load buses) its reactive balance with its magnitude -- the diagonal of the
+// power-flow Jacobian -- and the buses are taken in the order kBusOrder below.  With the order fixed at compile time (a) no
+// pivot search, no data-dependent lane index, no hazard nops; (b) the SPARSITY of the 14-bus network is compiled in: when pivot
+// k is taken only the columns in which its row can be non-zero (case14's 20 branches + fill-in, kLive* below, evaluated by
+// the compiler from the adjacency masks) are updated -- 154 instead of 561 (broadcast, fma) pairs for the 28 x 43 system of the
+// GRG direction, 97 instead of 253 for Newton's 22 x 23.  The order minimises that count (simulated annealing over the 13!
+// bus orders, tools/evopf_order.py: generator buses last keeps the J_partial columns sparse longest; minimum degree: 233).
+// Accuracy: on 1500 sampled Jacobians (solved states, GRG-like and gross perturbations, Newton's flat start) the static order's
+// inverse is as close to the float64 one as partial pivoting's (median 1.5e-7, same p99) whenever min|pivot| / max|pivot| >
+// 2^-6; below that (gross perturbations only: near-singular Jacobians) the wave falls back to the partial-pivoting elimination
+// (gauss_jordan_rows) -- a wave-uniform branch, see pivots_ok().  RPO_EVOPF_C_FLAGS != 0 forces the fallback (A/B tests).
+// The first six "other" variables (slack pg, qg) appear in exactly one equation each with coefficient 1 (P at the slack bus,
+// Q at the generator buses): with these rows first the leading 6 x 6 block is the identity and the elimination starts at 6.
+__device__ constexpr int kBusOrder[NB - 1] = {2, 7, 11, 10, 13, 4, 12, 9, 8, 6, 3, 1, 5};
+__device__ constexpr int kRowOrder[NEQ] = {0, 14, 15, 16, 19, 21, 2, 7, 11, 25, 10, 24, 13, 27, 4, 18, 12, 26, 9, 23, 8, 22,
+                                           6, 20, 3, 17, 1, 5};
+// ... and the variables the equations determine (evopf.py:290), in elimination order: column k is solved by row k
+__device__ constexpr int kOtherVars[NO] = {0, 5, 6, 7, 8, 9, 26, 31, 35, 21, 34, 20, 37, 23, 28, 14, 36, 22, 33, 19, 32, 18,
+                                           30, 16, 27, 13, 25, 29};
+// Newton system (evopf.py:809-816: P at pv, P at pq, Q at pq  x  vm at pq, va at pv, va at pq), same pairing and order
+__device__ constexpr int kKeep[NN] = {2, 7, 11, 25, 10, 24, 13, 27, 4, 18, 12, 26, 9, 23, 8, 22, 6, 20, 3, 17, 1, 5};
+__device__ constexpr int kNewtonVars[NN] = {26, 31, 35, 21, 34, 20, 37, 23, 28, 14, 36, 22, 33, 19, 32, 18, 30, 16, 27, 13,
+                                            25, 29};
+__device__ constexpr int kPvPos[NG - 1] = {20, 0, 21, 1};            // position of P at pv bus j (1, 2, 5, 7) in kKeep
+// case14's branches as one adjacency mask per bus (bit k of kAdjMask[i]: Ybus[i][k] != 0, diagonal included); the host
+// checks the Ybus it uploads against these masks (EVOPFKernels) -- the reference hard-wires case14 (evopf.py:211)
+__device__ constexpr unsigned kAdjMask[NB] = {19, 31, 14, 350, 59, 7216, 456, 192, 9032, 1792, 1568, 6176, 14368, 12544};
+
+// d eq / d var can be non-zero (eq_jac, evopf.py:614-661)
+__host__ __device__ constexpr bool jac_struct(int eq, int var) {
+    const bool real = eq < NB;
+    const int i = real ? eq : eq - NB;
+    if (var < QG0) return real && kSpv[var] == i;
+    if (var < VM0) return !real && kSpv[var - QG0] == i;
+    if (var >= PE0) return real && kSpv[var - PE0] == i;
+    return (kAdjMask[i] >> ((var - VM0) % NB)) & 1u;
+}
+
+template <int N, int NC>
+struct LiveTab { bool v[N][NC]; };     // v[k][c]: column c (> k) of pivot row k can be non-zero when pivot k is taken
+
+// Symbolic Gauss-Jordan of an N x NC pattern in the fixed order (pivot k = row k, column k), starting at pivot K0
+template <int N, int NC, int K0, typename F>
+__host__ __device__ constexpr LiveTab<N, NC> symbolic_gj(F pattern) {
+    LiveTab<N, NC> t{};
+    bool p[N][NC] = {};
+    for (int r = 0; r < N; ++r)
+        for (int c = 0; c < NC; ++c) p[r][c] = pattern(r, c);
+    for (int k = K0; k < N; ++k) {
+        for (int c = k + 1; c < NC; ++c) t.v[k][c] = p[k][c];
+        for (int r = 0; r < N; ++r)
+            if (r != k && p[r][k])
+                for (int c = k + 1; c < NC; ++c) p[r][c] = p[r][c] || p[k][c];
+    }
+    return t;
+}
+struct PatGrg {       // [J_other | J_partial], rows kRowOrder
+    __host__ __device__ constexpr bool operator()(int r, int c) const {
+        return jac_struct(kRowOrder[r], c < NO ? kOtherVars[c] : kPartialVars[c - NO]);
+    }
+};
+struct PatNewton {    // [J_newton | g]
+    __host__ __device__ constexpr bool operator()(int r, int c) const { return c == NN || jac_struct(kKeep[r], kNewtonVars[c]); }
+};
+struct PatNewtonT {   // [J_newton^T | rhs] (PFFunction.backward)
+    __host__ __device__ constexpr bool operator()(int r, int c) const { return c == NN || jac_struct(kKeep[c], kNewtonVars[r]); }
+};
+__device__ constexpr LiveTab<NEQ, NY> kLiveGrg = symbolic_gj<NEQ, NY, 6>(PatGrg{});
+__device__ constexpr LiveTab<NN, NN + 1> kLiveNewton = symbolic_gj<NN, NN + 1, 0>(PatNewton{});
+__device__ constexpr LiveTab<NN, NN + 1> kLiveNewtonT = symbolic_gj<NN, NN + 1, 0>(PatNewtonT{});
+struct TabGrg { static __device__ constexpr bool live(int k, int c) { return kLiveGrg.v[k][c]; } };
+struct TabNewton { static __device__ constexpr bool live(int k, int c) { return kLiveNewton.v[k][c]; } };
+struct TabNewtonT { static __device__ constexpr bool live(int k, int c) { return kLiveNewtonT.v[k][c]; } };
 
 struct Ws {                       // per-wave workspace in LDS
     float c[RPO_EVOPF_CONSTS_LEN];
@@ -322,6 +384,37 @@ __device__ __forceinline__ void gauss_jordan_rows(float (&row)[NC], int& mycol, 
     }
 }
 
+// Gauss-Jordan in the STATIC order: pivot k is row k (lane k), column k; only the columns Tab::live(k, c) marks are
+// touched.  Rows are not normalised: on return thread r's row solves unknown r and row[c] / pivot (c >= N) is entry [r][c]
+// of inv(A) @ (the trailing columns); the return value is the thread's pivot.  Same K0 convention as gauss_jordan_rows.
+template <int N, int NC, int K0, typename Tab>
+__device__ __forceinline__ float gauss_jordan_static(float (&row)[NC]) {
+    const int lane = lane_id();
+    float mypiv = 1.0f;
+#pragma unroll
+    for (int k = K0; k < N; ++k) {
+        const float piv = lane_bcast(row[k], k);                     // v_readlane with an immediate lane
+        const float f = lane == k ? 0.0f : -row[k] * (1.0f / piv);
+        mypiv = lane == k ? piv : mypiv;
+#pragma unroll
+        for (int c = k + 1; c < NC; ++c)
+            if (Tab::live(k, c)) row[c] = fmaf(f, lane_bcast(row[c], k), row[c]);
+    }
+    return mypiv;
+}
+
+// The static order's acceptance test (wave-uniform): every pivot within 2^-6 of the largest one.  NaN / zero / infinite
+// pivots fail it.  Lanes [K0, N) hold the pivots.
+template <int N, int K0>
+__device__ __forceinline__ bool pivots_ok(float mypiv) {
+    const int lane = lane_id();
+    const bool mine = lane >= K0 && lane < N;
+    const float a = fabsf(mypiv);
+    const float amax = rpo_wave_max_nonneg(mine ? a : 0.0f);          // (NaN pivots: a > ... below is false)
+    const bool fine = !mine || (a > amax * 0.015625f && a < 3.0e38f);
+    return __builtin_amdgcn_ballot_w64(fine) == ~0ull;
+}
+
 // complete_partial (PFFunction.forward, evopf.py:789-855) for the lane in w.s with basic actions z[14] (registers of
 // threads 0..13 hold z[tid] in `zj`): Newton on (vm_pq, va_pv, va_pq) with the lane's own stop test, then qg and the
 // slack generation from the remaining equations.  Leaves flows()/eq of the completed action current.
@@ -342,17 +435,29 @@ __device__ __forceinline__ int complete_partial(Ws& w, float zj, float tol, int 
     for (; it < max_iters;) {
         flows(w, yc);
         eq_resid(w);
-        float row[NN + 1];                                     // row tid of [J_newton | g]
-        {
+        const bool force_dyn = w.c[RPO_EVOPF_C_FLAGS] != 0.0f;
+        bool solved = false;
+        if (!force_dyn) {                                      // static order (sparse), accepted by its pivots
+            float row[NN + 1];                                 // row tid of [J_newton | g]
             const RowCoef rc = row_coef(w, kKeep[tid < NN ? tid : 0]);
 #pragma unroll
             for (int c = 0; c < NN; ++c) row[c] = tid < NN ? jac_row_entry(w, rc, kNewtonVars[c], yk) : 0.0f;
             row[NN] = tid < NN ? w.eq[kKeep[tid]] : 0.0f;
+            const float mypiv = gauss_jordan_static<NN, NN + 1, 0, TabNewton>(row);
+            solved = pivots_ok<NN, 0>(mypiv);
+            if (solved && tid < NN) w.vec[tid] = row[NN] / mypiv;     // delta = inv(J) g (:832)
         }
-        int mycol;
-        float mypiv;
-        gauss_jordan_rows<NN, NN + 1, 0>(row, mycol, mypiv);
-        if (tid < NN) w.vec[mycol] = row[NN] / mypiv;          // delta = inv(J) g (:832)
+        if (!solved) {                                         // partial pivoting (near-singular Jacobians, or forced)
+            float row[NN + 1];
+            const RowCoef rc = row_coef(w, kKeep[tid < NN ? tid : 0]);
+#pragma unroll
+            for (int c = 0; c < NN; ++c) row[c] = tid < NN ? jac_row_entry(w, rc, kNewtonVars[c], yk) : 0.0f;
+            row[NN] = tid < NN ? w.eq[kKeep[tid]] : 0.0f;
+            int mycol;
+            float mypiv;
+            gauss_jordan_rows<NN, NN + 1, 0>(row, mycol, mypiv);
+            if (tid < NN) w.vec[mycol] = row[NN] / mypiv;
+        }
         sync();
         float d2 = 0.0f;
         if (tid < NN) {
@@ -377,23 +482,41 @@ __device__ __forceinline__ int complete_partial(Ws& w, float zj, float tol, int 
 __device__ __forceinline__ void ineq_partial_grad(Ws& w, const YVec& yrow) {   // yrow = y_row(w, bus of equation kRowOrder[tid])
     const int tid = lane_id();
     // thread r owns equation kRowOrder[r] of [J_other | J_partial]
-    float row[NY];
-    {
+    ineq_resid(w);                                             // (syncs)
+    const bool force_dyn = w.c[RPO_EVOPF_C_FLAGS] != 0.0f;
+    bool solved = false;
+    if (!force_dyn) {                                          // static order (sparse), accepted by its pivots
+        float row[NY];
         const RowCoef rc = row_coef(w, kRowOrder[tid < NEQ ? tid : 0]);
 #pragma unroll
         for (int c = 0; c < NY; ++c) {
             const int var = c < NO ? kOtherVars[c] : kPartialVars[c - NO];
             row[c] = tid < NEQ ? jac_row_entry(w, rc, var, yrow) : 0.0f;
         }
-    }
-    ineq_resid(w);                                             // (syncs)
-    int mycol;
-    float mypiv;
-    gauss_jordan_rows<NEQ, NY, 6>(row, mycol, mypiv);
-    if (tid < NO) {                                            // inv(J_o) J_p = -dynz_dz (:598), row of unknown `mycol`
-        const float inv = 1.0f / mypiv;
+        const float mypiv = gauss_jordan_static<NEQ, NY, 6, TabGrg>(row);
+        solved = pivots_ok<NEQ, 6>(mypiv);
+        if (solved && tid < NO) {                              // inv(J_o) J_p = -dynz_dz (:598), row of unknown `tid`
+            const float inv = 1.0f / mypiv;
 #pragma unroll
-        for (int p = 0; p < NPV; ++p) w.D[mycol][p] = row[NO + p] * inv;
+            for (int p = 0; p < NPV; ++p) w.D[tid][p] = row[NO + p] * inv;
+        }
+    }
+    if (!solved) {                                             // partial pivoting (near-singular Jacobians, or forced)
+        float row[NY];
+        const RowCoef rc = row_coef(w, kRowOrder[tid < NEQ ? tid : 0]);
+#pragma unroll
+        for (int c = 0; c < NY; ++c) {
+            const int var = c < NO ? kOtherVars[c] : kPartialVars[c - NO];
+            row[c] = tid < NEQ ? jac_row_entry(w, rc, var, yrow) : 0.0f;
+        }
+        int mycol;
+        float mypiv;
+        gauss_jordan_rows<NEQ, NY, 6>(row, mycol, mypiv);
+        if (tid < NO) {
+            const float inv = 1.0f / mypiv;
+#pragma unroll
+            for (int p = 0; p < NPV; ++p) w.D[mycol][p] = row[NO + p] * inv;
+        }
     }
     if (tid < NY) {                                            // ineq_grad_new (:590-594): +-1 per violated bound
         float g = 0.0f;

@@ -196,5 +196,78 @@ class EVOPFEnv(HardConstraintEnv):
             g[:, -self.ne:] += grad_ineq[:, -2 * self.ne:-self.ne] - grad_ineq[:, -self.ne:]
         return g
 
+    # -- the reference's remaining constraint functions (evopf.py:564-594,614-707), thin host methods over the kernels:
+    # Jacobian entries come from rpo_evopf_eq_vjp with unit cotangents (autograd_sign = 0: eq_jac's own battery sign, DESIGN E1)
+    def eq_jac(self, action):
+        """d eq_resid / d action as eq_jac builds it (evopf.py:614-661) -> [n, 28, 43]."""
+        a = self._t(action)
+        a = (a if a.dim() == 2 else a.view(1, -1)).contiguous()
+        n, m, y = a.shape[0], self.eq_num, self._ydim
+        rows = a.repeat_interleave(m, dim=0).contiguous()                    # row (b, r) = action b with cotangent e_r
+        cot = torch.eye(m, device=a.device, dtype=a.dtype).repeat(n, 1).contiguous()
+        out = torch.empty(n * m, y, device=a.device, dtype=a.dtype)
+        self.kernels.eq_vjp(rows, cot, out, autograd_sign=False)
+        return out.view(n, m, y)
+
+    def ineq_jac(self, state, action):
+        """Constant +-identity blocks (evopf.py:663-707), expanded over the batch -> [n, 58, 43]."""
+        n = self._t(action).reshape(-1, self._ydim).shape[0]
+        key = ("ineq_jac", self.device)
+        if key not in self._box_cache:
+            ng, nb, ne, y = self.ng, self.nbus, self.ne, self._ydim
+            j = torch.zeros(self.ineq_num, y)
+            r = 0
+            for start, size in ((self.pg_start_yidx, ng), (self.qg_start_yidx, ng), (self.vm_start_yidx, nb),
+                                (self.pe_start_yidx, ne)):
+                j[r:r + size, start:start + size] = torch.eye(size)
+                j[r + size:r + 2 * size, start:start + size] = -torch.eye(size)
+                r += 2 * size
+            self._box_cache[key] = j.to(self.device)
+        return self._box_cache[key].unsqueeze(0).expand(n, -1, -1)
+
+    def eq_grad(self, state, action):
+        """2 J_eq^T eq_resid (evopf.py:574-577) -> [n, 43]."""
+        state, a = self._t(state), self._t(action)
+        a = (a if a.dim() == 2 else a.view(1, -1)).contiguous()
+        resid = self.eq_resid(state if state.dim() == 2 else state.view(1, -1), a).detach().contiguous()
+        out = torch.empty_like(a)
+        self.kernels.eq_vjp(a, resid, out, autograd_sign=False)
+        return 2 * out
+
+    def _ineq_jac_t(self, weights):
+        """ineq_jac^T weights for [n, 58] weights: every inequality bounds one action component from above or below."""
+        ng, nb, ne = self.ng, self.nbus, self.ne
+        g = torch.zeros(weights.shape[0], self._ydim, device=weights.device, dtype=weights.dtype)
+        g[:, :ng] = weights[:, :ng] - weights[:, ng:2 * ng]
+        g[:, ng:2 * ng] = weights[:, 2 * ng:3 * ng] - weights[:, 3 * ng:4 * ng]
+        g[:, 2 * ng:2 * ng + nb] = weights[:, 4 * ng:4 * ng + nb] - weights[:, 4 * ng + nb:4 * ng + 2 * nb]
+        g[:, -ne:] = weights[:, -2 * ne:-ne] - weights[:, -ne:]
+        return g
+
+    def _dist2(self, state, action):
+        state, a = self._t(state), self._t(action)
+        return self.ineq_dist(state if state.dim() == 2 else state.view(1, -1), a if a.dim() == 2 else a.view(1, -1)).detach()
+
+    def ineq_grad(self, state, action, eps=0.0):
+        """2 J_ineq^T (dist + eps 1[dist > 0]) (evopf.py:579-583)."""
+        d = self._dist2(state, action)
+        return 2 * self._ineq_jac_t(d + (d > 0) * eps)
+
+    def ineq_grad_new(self, state, action, eps=0.0):
+        """J_ineq^T 1[dist > 0]: +-1 per violated bound (evopf.py:585-589); `eps` is unused there too."""
+        return self._ineq_jac_t((self._dist2(state, action) > 0).to(torch.float32))
+
+    def ineq_dist_np(self, state, action):
+        """evopf.py:564-567: one (state, action) pair in, [1, 58] array out."""
+        a = torch.as_tensor(np.asarray(action), dtype=torch.float32, device=self.device).view(1, -1)
+        s = torch.as_tensor(np.asarray(state), dtype=torch.float32, device=self.device).view(1, -1)
+        return self.ineq_dist(s, a).detach().cpu().numpy()
+
+    def eq_resid_np(self, state, action):
+        """evopf.py:569-572."""
+        a = torch.as_tensor(np.asarray(action), dtype=torch.float32, device=self.device).view(1, -1)
+        s = torch.as_tensor(np.asarray(state), dtype=torch.float32, device=self.device).view(1, -1)
+        return self.eq_resid(s, a).detach().cpu().numpy()
+
     def opt_solve(self, *a, **k):
         raise NotImplementedError("pypower's interior-point OPF baseline (evopf.py:729-759) is outside the RPO hot path")

@@ -5,6 +5,7 @@ and are captured when that stream is being captured into a hipGraph.  Tensors mu
 contiguous float32 / int32 / int64: there is no CPU path here.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -294,11 +295,20 @@ class EvopfKernels(object):
     newton_tol, newton_max_iters = 1e-5, 50          # PFFunction(env, tol=1e-5, bsz=256, max_iters=50), evopf.py:786
     episode_steps = 24                               # the loaders run out of data after one day (demand.py:71)
     partial = 0
+    CASE14_ADJ = (19, 31, 14, 350, 59, 7216, 456, 192, 9032, 1792, 1568, 6176, 14368, 12544)   # == kAdjMask, evopf_dev.h
 
     def __init__(self, consts):
         self.consts = np.ascontiguousarray(consts, dtype=np.float32)
         if self.consts.shape != (CONST["RPO_EVOPF_CONSTS_LEN"],):
             raise RpoHipError("bad EVOPF constant table")
+        self.consts = self.consts.copy()
+        # The solver eliminates in a static order with case14's branch pattern compiled in (csrc/evopf_dev.h, kAdjMask): a
+        # Ybus with entries outside that pattern -- or RPO_EVOPF_PIVOT=dynamic -- selects partial pivoting instead.
+        yr, yi = (self.consts[CONST[k]:CONST[k] + 196].reshape(14, 14) for k in ("RPO_EVOPF_C_YR", "RPO_EVOPF_C_YI"))
+        inside = np.array([[(m >> k) & 1 for k in range(14)] for m in self.CASE14_ADJ], dtype=bool)
+        dynamic = bool((((yr != 0) | (yi != 0)) & ~inside).any()) or os.environ.get("RPO_EVOPF_PIVOT", "") == "dynamic"
+        self.consts[CONST["RPO_EVOPF_C_FLAGS"]] = 1.0 if dynamic else 0.0
+        self.static_order = not dynamic
         self._dev = {}
 
     def _c(self, like):

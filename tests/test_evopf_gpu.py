@@ -150,6 +150,48 @@ def test_projection_matches_oracle(env):
     assert (it.cpu().numpy() == wit).mean() > 0.95           # the 1e-5 stop test can flip on float32 noise
 
 
+def test_static_elimination_order_equals_partial_pivoting(env, monkeypatch):
+    """The solver eliminates in a compiled-in static order with case14's sparsity (csrc/evopf_dev.h) and falls back to
+    partial pivoting per solve when its pivots fail the acceptance test; RPO_EVOPF_PIVOT=dynamic forces partial pivoting
+    everywhere.  Both are backward-stable evaluations of the same inverse: equation solver, its backward, the reduced
+    gradient and the whole projection agree to float32 round-off amplified by the Jacobian's condition (~3e2), on
+    well-posed points AND on grossly perturbed ones where the static order hands over to the fallback (there the two
+    runs execute the same code, so they agree bit for bit or both produce the same non-finite rows)."""
+    from rpo_amd.env import EVOPFEnv
+    assert env.kernels.static_order
+    monkeypatch.setenv("RPO_EVOPF_PIVOT", "dynamic")
+    dyn = EVOPFEnv(device="cuda")
+    assert not dyn.kernels.static_order
+    s, rng = states(256, seed=21)
+    ap = partials(s, rng)
+    a_s, a_d = (e.complete_partial(dev(s), dev(ap)).cpu().numpy() for e in (env, dyn))
+    np.testing.assert_allclose(a_s, a_d, atol=2e-5)
+    w = rng.randn(256, 43).astype(np.float32)
+    grads = []
+    for e in (env, dyn):
+        z = dev(ap).requires_grad_(True)
+        e.complete_partial(dev(s), z).backward(dev(w))
+        grads.append(z.grad.cpu().numpy())
+    np.testing.assert_allclose(grads[0], grads[1], atol=2e-5 * np.abs(grads[1]).max())
+    ax = (a_d + 0.03 * rng.randn(256, 43)).astype(np.float32)
+    g_s, g_d = (e.ineq_partial_grad(dev(s), dev(ax)).cpu().numpy() for e in (env, dyn))
+    np.testing.assert_allclose(g_s, g_d, atol=2e-5 * np.abs(g_d).max())
+    ap2 = ap.copy()
+    ap2[:128, 4:9] = 1.07                                       # violated bounds: all 10 GRG iterations
+    (p_s, it_s), (p_d, it_d) = (e.project(dev(s), dev(ap2), 10, 1e-4, return_iters=True) for e in (env, dyn))
+    np.testing.assert_allclose(p_s.cpu().numpy(), p_d.cpu().numpy(), atol=2e-5)
+    assert (it_s == it_d).float().mean() > 0.98
+    # near-singular Jacobians (voltages far off any operating point): the acceptance test must hand these to the fallback
+    bad = a_d.copy()
+    bad[:, G.vm0:G.vm0 + 14] += 0.25 * rng.randn(256, 14).astype(np.float32)
+    bad[:, G.va0:G.va0 + 14] += 0.8 * rng.randn(256, 14).astype(np.float32)
+    g_s, g_d = (e.ineq_partial_grad(dev(s), dev(bad)).cpu().numpy() for e in (env, dyn))
+    want = oe.ineq_partial_grad(s.astype(np.float64), bad.astype(np.float64))
+    scale = np.abs(want).max(axis=1, keepdims=True)
+    err_s, err_d = (np.abs(g - want) / scale for g in (g_s, g_d))
+    assert np.nanmax(err_s) <= max(4.0 * np.nanmax(err_d), 2e-3), (np.nanmax(err_s), np.nanmax(err_d))
+
+
 def test_step_matches_oracle_including_episode_end(env):
     n, seed = 128, 31
     ids = np.arange(n)

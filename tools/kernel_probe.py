@@ -86,5 +86,36 @@ def probe_ride(periods=6):
     torch.cuda.synchronize()
 
 
+def probe_window(workload, periods=6):
+    """policy_fre periods of the bench trainer of `workload` with the launches its graph windows issue (the next vector step
+    riding on the update's launches where the schedule does that), eagerly: every kernel is a dispatch of its own that the
+    profiler's counters attribute.  Same recipe as bench.kernel_clinic."""
+    from bench import envs_per_gpu, make_trainer
+    tr = make_trainer(envs_per_gpu(workload), torch.device("cuda"), 10 ** 9, capacity=64, workload=workload)
+    tr._graphs.enabled = False
+    tr.vec.reset()
+    tr.run_steps(2 * tr.policy_fre)
+    tr._flush_tail()
+    for _ in range(periods):
+        t0 = tr._t
+        if getattr(tr, "_ride_ok", lambda d: False)(True):
+            tr._sync_uclock(rollout_pending=True)
+            tr._uclock_ok = True
+            tr._ridden_window(t0, tr.policy_fre)
+            for i in range(tr.policy_fre):
+                tr._advance_host(t0 + i + 1)
+            tr._updates += tr.policy_fre
+        else:
+            for i in range(tr.policy_fre):
+                tr._iteration(False, True, (t0 + i + 1) % tr.policy_fre == 0)
+                tr._advance_host(t0 + i + 1)
+                tr._updates += 1
+    torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
-    {"step": probe_step, "mlp": probe_mlp, "iter": probe_iter, "ride": probe_ride}[sys.argv[1] if len(sys.argv) > 1 else "step"]()
+    what = sys.argv[1] if len(sys.argv) > 1 else "step"
+    if what.startswith("window:"):
+        probe_window(what.split(":", 1)[1])
+    else:
+        {"step": probe_step, "mlp": probe_mlp, "iter": probe_iter, "ride": probe_ride}[what]()

@@ -17,6 +17,9 @@ UNITS = [  # (kernel substring, threads per unit or explicit map)
     ("cartsafe_act_project_kernel", lambda g: g if g <= 4096 else 1 << 20),
     ("replay_sample_gather_kernel", lambda g: 256 if g <= 4096 else 1 << 20),
     ("_ride_kernel", lambda g: 4096),                           # update stage at batch 256 + riders for 4096 lanes
+    ("evopf_act_project_kernel", lambda g: g // 64),            # one wavefront per env lane / batch row
+    ("evopf_step_kernel", lambda g: g // 64),
+    ("evopf_complete_bwd_kernel", lambda g: g // 64),
 ]
 
 
@@ -36,6 +39,9 @@ def parse(path):
 
 
 def main(out_path, files):
+    workload = None
+    if files and files[0] == "--workload":                      # per-workload table (profiles/rNN_pmc_traffic_<workload>.json)
+        workload, files = files[1], files[2:]
     kernels = {}
     for i in range(0, len(files), 2):
         fetch, write = parse(files[i]), parse(files[i + 1])
@@ -57,7 +63,11 @@ def main(out_path, files):
             "coalesced reads and is doubled; WRITE_SIZE is used as reported. Recipe: tools/collect_profiles.sh "
             "(tools/kernel_probe.py step | iter + tools/rocpd_pmc.py). The update kernels' traffic at batch 256 is dominated "
             "by each XCD's L2 fetching its own copy of the weights it touches.")
-    json.dump({"_note": note, "kernels": kernels}, open(out_path, "w"), indent=1)
+    doc = {"_note": note, "kernels": kernels}
+    if workload:
+        doc["workload"] = workload
+        doc["_note"] += " This table: tools/kernel_probe.py window:%s (policy_fre periods of that bench trainer, eagerly)." % workload
+    json.dump(doc, open(out_path, "w"), indent=1)
 
 
 if __name__ == "__main__":
