@@ -127,6 +127,17 @@ __device__ __forceinline__ float rpo_wave_max_nonneg(float v) {
     return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
 }
 
+// Sum over the wave, the same in every lane, without LDS round trips (rpo_wave_sum: six dependent ds_bpermute): DPP inside the
+// 16-lane rows (row_shl fills with zeros), v_readlane across them.  Association: per row ((l + l+8) + (l+4 + l+12)) ... then
+// (r0 + r1) + (r2 + r3) -- NOT rpo_wave_sum's bits.
+__device__ __forceinline__ float rpo_wave_sum_rows(float v) {
+    v = rpo_row16_sum_desc_lane0(v);
+    const int b = __float_as_int(v);
+    const float s0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), s1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+    const float s2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), s3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+    return (s0 + s1) + (s2 + s3);
+}
+
 // take_action's exploration (agent/ddpg_pa.py:108-110): clip(ap + eps_t * noise, lo, hi), unfused like the
 // RPO_NOISE_PHILOX / RPO_NOISE_EXPLICIT branches of the *_explore_project functions
 __device__ __forceinline__ float rpo_explore_clip(float ap, float eps_t, float noise, float lo, float hi) {

@@ -206,8 +206,9 @@ __global__ __launch_bounds__(RPO_WAVE * kActWaves) void evopf_act_project_kernel
             z = fminf(fmaxf(z, lo), hi);
         }
     }
-    complete_partial(w, z, p.newton_tol, p.newton_iters);
-    const int k = grad_steps(w, p.max_steps, p.corr_lr, p.corr_eps, p.corr_momentum);
+    const RowLane L = make_row_lane(w);
+    complete_partial_v2(w, L, z, p.newton_tol, p.newton_iters);
+    const int k = grad_steps_v2(w, L, p.max_steps, p.corr_lr, p.corr_eps, p.corr_momentum);
     if (tid < NY) p.action[(size_t)i * NY + tid] = w.a[tid];
     if (tid == 0) {
         if (p.iters) p.iters[i] = k;
@@ -322,8 +323,11 @@ __global__ __launch_bounds__(RPO_WAVE * kActWaves) void evopf_ipg_kernel(int n, 
     load_row(w.s, state + (size_t)i * state_stride, NS);
     load_row(w.a, action + (size_t)i * NY, NY);
     sync();
-    flows(w);
-    ineq_partial_grad(w);
+    if (tid < NY) w.dir[tid] = 0.0f;                           // (the slack angle's component stays zero: full_grad, evopf.py:608)
+    sync();
+    const RowLane L = make_row_lane(w);
+    sync();
+    grg_iteration_v2(w, L, true, 0.0f, 0.0f, 0.0f, false, w.dir);
     if (tid < NY) step_out[(size_t)i * NY + tid] = w.dir[tid];
 }
 

@@ -108,7 +108,9 @@ struct PatNewtonT {   // [J_newton^T | rhs] (PFFunction.backward)
 __device__ constexpr LiveTab<NEQ, NY> kLiveGrg = symbolic_gj<NEQ, NY, 6>(PatGrg{});
 __device__ constexpr LiveTab<NN, NN + 1> kLiveNewton = symbolic_gj<NN, NN + 1, 0>(PatNewton{});
 __device__ constexpr LiveTab<NN, NN + 1> kLiveNewtonT = symbolic_gj<NN, NN + 1, 0>(PatNewtonT{});
+__device__ constexpr LiveTab<NEQ, NY> kLiveGrg0 = symbolic_gj<NEQ, NY, 0>(PatGrg{});   // incl. the six unit pivots (v2's extra row)
 struct TabGrg { static __device__ constexpr bool live(int k, int c) { return kLiveGrg.v[k][c]; } };
+struct TabGrg0 { static __device__ constexpr bool live(int k, int c) { return kLiveGrg0.v[k][c]; } };
 struct TabNewton { static __device__ constexpr bool live(int k, int c) { return kLiveNewton.v[k][c]; } };
 struct TabNewtonT { static __device__ constexpr bool live(int k, int c) { return kLiveNewtonT.v[k][c]; } };
 
@@ -121,9 +123,9 @@ struct Ws {                       // per-wave workspace in LDS
     float eq[NEQ];
     float ineq[NINEQ + 2];
     float dir[NY + 1];            // direct gradient / step
-    float fp[NPV + 1];            // full_partial_grad
+    alignas(16) float fp[NPV + 1];   // full_partial_grad
     float old[NY + 1];            // momentum term of grad_steps
-    float vec[64];                // scratch
+    alignas(16) float vec[64];    // scratch
 };
 
 // One wavefront per Ws (the kernels index their workspace by wave): the LDS instructions of a wave
@@ -572,6 +574,357 @@ __device__ __forceinline__ int grad_steps(Ws& w, int max_steps, float lr, float 
         }
         sync();
     }
+    return k;
+}
+
+// =====================================================================================================================
+// v2 of the equation solver and the GRG projection (round 4): the whole iteration in registers and wave-uniform values.
+//
+// v1 above hands every intermediate over through LDS (cos / sin / rectangular voltages -> admittance products -> residuals
+// -> Jacobian rows -> D -> two products with D), each a store, a wave barrier and dependent loads: with ONE resident wave
+// nothing hides those round trips.  Here:
+//   * lane r < 28 owns equation kRowOrder[r] (both systems: Newton's 22 x 22 is the block of rows / columns 6..27), lanes
+//     32..45 own bus lane - 32; every lane takes cos / sin of the angle of ITS bus, so the 4 x 14 per-bus values every row
+//     needs are wave-uniform v_readlane results (scalar operands of the FMAs), not LDS traffic;
+//   * a row computes its own admittance products t1_i, t2_i (14 terms from the uniforms and its Ybus column), its own
+//     residual and its own Jacobian row: entry (row i, bus k) = p_k alpha_k + q_k beta_k (+ the diagonal term), alpha / beta
+//     formed once per bus (the same for the |v| and the angle column);
+//   * the reduced gradient needs g_p - D^T g_o and then -D (that): the first is obtained by one more ROW that takes part in
+//     the elimination -- lane 28 holds [g_o^T | g_p^T]; eliminating its first 28 entries with the pivot rows leaves
+//     g_p - g_o^T inv(J_o) J_p in its trailing 15 -- at no cost (one more lane of the same instructions; the six unit pivots
+//     of the slack / qg equations are applied to it first); the second is 15 FMAs per row on its own registers;
+//   * `a` stays in LDS (read by bus, updated by the owner of each component); nothing else does.
+// Same arithmetic as the reference (evopf.py:520-546,596-661,786-855; rpo_ddpg.py:266-305), other association of the
+// Jacobian entries' products than v1 (float32 round-off).
+#ifndef RPO_EVOPF_RCP
+#define RPO_EVOPF_RCP(x) __builtin_amdgcn_rcpf(x)
+#endif
+struct Volt { float cs, sn, vr, vi; };
+
+struct RowLane {
+    bool is_row, real, is_extra;
+    int bus;                 // bus of the equation (row lanes), lane - 32 (bus lanes 32..45), else 0
+    int ia, ib, dem;         // w.a indices of the injections of the row's residual (NY: none -> w.a[NY] == 0), w.s index of its demand
+    float dlt[NB];           // [bus == k] for row lanes, else 0
+    YVec yrow, ycol;         // Ybus row (Jacobian) and column (admittance products) of the bus; zero for non-row lanes
+    float hi, lo;            // bounds of action component `lane` (lanes < 43): ineq_resid (evopf.py:548-563) per component
+    int colpos;              // position of action component `lane` in the [other | partial] column order (NY: none)
+    int own_var;             // row lanes: the unknown of pivot `lane` (kOtherVars[lane]); lanes 32..46: kPartialVars[lane - 32]; else NY
+};
+
+__device__ __forceinline__ RowLane make_row_lane(Ws& w) {
+    RPO_FP_STRICT
+    RowLane L;
+    const int lane = lane_id();
+    L.is_row = lane < NEQ;
+    L.is_extra = lane == NEQ;
+    int eq = 0;
+#pragma unroll
+    for (int r = 0; r < NEQ; ++r) eq = lane == r ? kRowOrder[r] : eq;
+    L.real = eq < NB;
+    const int bl = lane - 32;
+    L.bus = L.is_row ? (L.real ? eq : eq - NB) : ((bl >= 0 && bl < NB) ? bl : 0);
+    int g = -1;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) g = kSpv[j] == L.bus ? j : g;
+    L.ia = (L.is_row && g >= 0) ? (L.real ? PG0 + g : QG0 + g) : NY;
+    L.ib = (L.is_row && L.real && g >= 0) ? PE0 + g : NY;
+    L.dem = L.real ? L.bus : NB + L.bus;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        L.dlt[k] = (L.is_row && L.bus == k) ? 1.0f : 0.0f;
+        L.yrow.yr[k] = L.is_row ? Yr(w, L.bus, k) : 0.0f;
+        L.yrow.yi[k] = L.is_row ? Yi(w, L.bus, k) : 0.0f;
+        L.ycol.yr[k] = L.is_row ? Yr(w, k, L.bus) : 0.0f;
+        L.ycol.yi[k] = L.is_row ? Yi(w, k, L.bus) : 0.0f;
+    }
+    // per-component bounds (the 58 inequalities are an upper and a lower bound on pg, qg, |v|, pe; angles are free)
+    L.hi = 3.0e38f; L.lo = -3.0e38f;
+    if (lane < QG0) { L.hi = w.c[RPO_EVOPF_C_PMAX + lane]; L.lo = w.c[RPO_EVOPF_C_PMIN + lane]; }
+    else if (lane < VM0) { L.hi = w.c[RPO_EVOPF_C_QMAX + lane - QG0]; L.lo = w.c[RPO_EVOPF_C_QMIN + lane - QG0]; }
+    else if (lane < VA0) { L.hi = w.c[RPO_EVOPF_C_VMAX + lane - VM0]; L.lo = w.c[RPO_EVOPF_C_VMIN + lane - VM0]; }
+    else if (lane >= PE0 && lane < NY) battery_bounds(w.s[2 * NB + lane - PE0], L.hi, L.lo);
+    if (lane == 0) w.a[NY] = 0.0f;
+    L.colpos = NY;
+#pragma unroll
+    for (int c = 0; c < NY; ++c) L.colpos = (c < NO ? kOtherVars[c] : kPartialVars[c - NO]) == lane ? c : L.colpos;
+    L.own_var = NY;
+#pragma unroll
+    for (int r = 0; r < NO; ++r) L.own_var = lane == r ? kOtherVars[r] : L.own_var;
+#pragma unroll
+    for (int p = 0; p < NPV; ++p) L.own_var = lane == 32 + p ? kPartialVars[p] : L.own_var;
+    return L;
+}
+
+// cos / sin / rectangular voltage of the lane's bus from w.a, and the 4 x 14 wave-uniform copies (bus lanes 32 + k)
+struct Uniforms { float cs[NB], sn[NB], vr[NB], vi[NB]; };
+__device__ __forceinline__ Volt own_volt(const Ws& w, const RowLane& L) {
+    Volt v;
+    sincosf(w.a[VA0 + L.bus], &v.sn, &v.cs);
+    const float vm = w.a[VM0 + L.bus];
+    v.vr = vm * v.cs; v.vi = vm * v.sn;
+    return v;
+}
+__device__ __forceinline__ Uniforms bus_uniforms(const Volt& v) {
+    Uniforms u;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        u.cs[k] = lane_bcast(v.cs, 32 + k); u.sn[k] = lane_bcast(v.sn, 32 + k);
+        u.vr[k] = lane_bcast(v.vr, 32 + k); u.vi[k] = lane_bcast(v.vi, 32 + k);
+    }
+    return u;
+}
+
+// The row's admittance products (evopf.py:527-528, the sums in v1's order) and its residual (:520-546)
+__device__ __forceinline__ float row_residual(const Ws& w, const RowLane& L, const Volt& v, const Uniforms& u, float& t1, float& t2) {
+    t1 = 0.0f; t2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        t1 += u.vr[k] * L.ycol.yr[k] - u.vi[k] * L.ycol.yi[k];
+        t2 += u.vr[k] * L.ycol.yi[k] + u.vi[k] * L.ycol.yr[k];
+    }
+    const float inj = L.real ? w.a[L.ia] + w.a[L.ib] : w.a[L.ia];
+    const float flow = L.real ? (v.vr * t1 + v.vi * t2) : (-v.vr * t2 + v.vi * t1);
+    return L.is_row ? (inj - w.s[L.dem]) - flow : 0.0f;
+}
+
+// Columns [C0, C0 + NC) (in the [other | partial] order) of the row's Jacobian row (eq_jac, evopf.py:614-661; battery
+// columns with the reference's sign, hazard E1) into out[0 .. NC)
+template <int C0, int NC, int NOUT>
+__device__ __forceinline__ void jacobian_row(const RowLane& L, const Volt& v, const Uniforms& u, float t1, float t2, float (&out)[NOUT]) {
+    const float ca = L.is_row ? (L.real ? -v.vr : -v.vi) : 0.0f, cb = L.is_row ? (L.real ? -v.vi : v.vr) : 0.0f;
+    const float dg_vm = L.real ? -(v.cs * t1 + v.sn * t2) : (v.cs * t2 - v.sn * t1);
+    const float dg_va = L.real ? -(-v.vi * t1 + v.vr * t2) : (-v.vi * t2 - v.vr * t1);
+    float alpha[NB], beta[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        alpha[k] = ca * L.yrow.yr[k] + cb * L.yrow.yi[k];
+        beta[k] = cb * L.yrow.yr[k] - ca * L.yrow.yi[k];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int col = C0 + c, var = col < NO ? kOtherVars[col] : kPartialVars[col - NO];
+        float e;
+        if (var < QG0) e = (L.is_row && L.real && kSpv[var] == L.bus) ? 1.0f : 0.0f;
+        else if (var < VM0) e = (L.is_row && !L.real && kSpv[var - QG0] == L.bus) ? 1.0f : 0.0f;
+        else if (var >= PE0) e = (L.is_row && L.real && kSpv[var - PE0] == L.bus) ? -1.0f : 0.0f;
+        else {
+            const bool dvm = var < VA0;
+            const int k = dvm ? var - VM0 : var - VA0;
+            const float p = dvm ? u.cs[k] : -u.vi[k], q = dvm ? u.sn[k] : u.vr[k];
+            e = fmaf(L.dlt[k], dvm ? dg_vm : dg_va, fmaf(p, alpha[k], q * beta[k]));
+        }
+        out[c] = e;
+    }
+}
+
+// Static-order Gauss-Jordan on columns [OFF, OFF + NC) of the 28-row system held one row per lane (array index = column -
+// OFF): pivots KB .. KE-1, pivot k = lane k; pivots below KUNIT are exactly 1 (the slack / qg equations).  Returns the
+// lane's pivot (1 for lanes that own none).
+template <int KB, int KE, int KUNIT, int OFF, int NC, typename Tab>
+__device__ __forceinline__ float gj_static(float (&row)[NC]) {
+    const int lane = lane_id();
+    float mypiv = 1.0f;
+#pragma unroll
+    for (int k = KB; k < KE; ++k) {
+        const int j = k - OFF;
+        float f;
+        if (k < KUNIT) {
+            f = lane == k ? 0.0f : -row[j];
+        } else {
+            const float piv = lane_bcast(row[j], k);
+            // multiplier with the hardware reciprocal (1 ulp): an error of the multiplier only leaves a residue of that relative
+            // size in the eliminated entry -- the size of the elimination's own rounding errors -- and takes the twelve
+            // dependent instructions of a correctly rounded division off each of the 22 links of the chain
+            f = lane == k ? 0.0f : -row[j] * RPO_EVOPF_RCP(piv);
+            mypiv = lane == k ? piv : mypiv;
+        }
+#pragma unroll
+        for (int c = j + 1; c < NC; ++c)
+            if (Tab::live(j, c)) row[c] = fmaf(f, lane_bcast(row[c], k), row[c]);
+    }
+    return mypiv;
+}
+
+// The same pivots by partial pivoting (the fallback of the static order): rows are not swapped, `mycol` = the pivot a
+// lane ended up owning (its own lane index where it owns none); lanes outside [KB, KE) are never chosen but are updated.
+template <int KB, int KE, int OFF, int NC>
+__device__ __forceinline__ float gj_dynamic(float (&row)[NC], int& mycol) {
+    const int lane = lane_id();
+    bool used = lane < KB || lane >= KE;
+    mycol = lane;
+    float mypiv = 1.0f;
+#pragma unroll
+    for (int k = KB; k < KE; ++k) {
+        const int j = k - OFF;
+        const unsigned key = used ? 0u : ((__float_as_uint(fabsf(row[j])) & ~31u) | (unsigned)lane);
+        const int p = (int)(half_wave_umax(key) & 31u);
+        const float piv = lane_bcast(row[j], p);
+        const bool is_p = lane == p;
+        const float f = is_p ? 0.0f : -row[j] * (1.0f / piv);
+        if (is_p) { used = true; mycol = k; mypiv = piv; }
+#pragma unroll
+        for (int c = j + 1; c < NC; ++c) row[c] = fmaf(f, lane_bcast(row[c], p), row[c]);
+    }
+    return mypiv;
+}
+
+// complete_partial v2 (PFFunction.forward, evopf.py:789-855): Newton on rows / columns 6..27 with the lane's own stop test,
+// then qg and the slack generation from rows 0..5.  zj: basic action z[lane] in lanes 0..13.
+__device__ __forceinline__ int complete_partial_v2(Ws& w, const RowLane& L, float zj, float tol, int max_iters) {
+    const int tid = lane_id();
+    if (tid < NY) {
+        float v = 0.0f;                                        // qg and the slack pg start at zero (:806-807)
+        if (tid >= VM0 && tid < VA0) v = w.c[RPO_EVOPF_C_VM_INIT + tid - VM0];       // load-bus guesses (:802)
+        else if (tid >= VA0 && tid < PE0) v = w.c[RPO_EVOPF_C_VA_INIT + tid - VA0];  // (:798,803-805)
+        w.a[tid] = v;
+    }
+    sync();
+    if (tid < NP) w.a[kPartialActions[tid]] = zj;              // (:796-799)
+    sync();
+    const bool force_dyn = w.c[RPO_EVOPF_C_FLAGS] != 0.0f;
+    int it = 0;
+    for (; it < max_iters;) {
+        const Volt v = own_volt(w, L);
+        const Uniforms u = bus_uniforms(v);
+        float t1, t2;
+        const float resid = row_residual(w, L, v, u, t1, t2);
+        float delta = 0.0f;
+        int unknown = L.own_var;                               // w.a index of the unknown this lane's pivot solves
+        bool solved = false;
+        if (!force_dyn) {
+            float row[NN + 1];                                 // columns 6..27 of the row | g
+            jacobian_row<6, NN>(L, v, u, t1, t2, row);
+            row[NN] = resid;
+            const float mypiv = gj_static<6, NEQ, 6, 6, NN + 1, TabNewton>(row);
+            solved = pivots_ok<NEQ, 6>(mypiv);
+            delta = row[NN] / mypiv;                           // delta = inv(J) g (:832), unknown `tid`
+        }
+        if (!solved) {                                         // partial pivoting (near-singular Jacobians, or forced)
+            float row[NN + 1];
+            jacobian_row<6, NN>(L, v, u, t1, t2, row);
+            row[NN] = resid;
+            int mycol;
+            const float mypiv = gj_dynamic<6, NEQ, 6, NN + 1>(row, mycol);
+            delta = row[NN] / mypiv;
+#pragma unroll
+            for (int r = 0; r < NO; ++r) unknown = mycol == r ? kOtherVars[r] : unknown;
+        }
+        const bool mine = tid >= 6 && tid < NEQ;
+        if (mine) w.a[unknown] -= delta;
+        sync();
+        ++it;
+        if (sqrtf(rpo_wave_sum_rows(mine ? delta * delta : 0.0f)) < tol) break;   // torch.norm(delta) < tol (:834), this lane only
+    }
+    {   // qg at the generators and the slack generation from the remaining equations (:844-848), with qg = pg_slack = 0
+        const Volt v = own_volt(w, L);
+        const Uniforms u = bus_uniforms(v);
+        float t1, t2;
+        const float resid = row_residual(w, L, v, u, t1, t2);
+        if (tid < 6) w.a[L.own_var] = -resid;
+        sync();
+    }
+    return it;
+}
+
+// One evaluation of the reduced gradient at w.a (ineq_partial_grad, evopf.py:590-612) and -- when `lr_step` -- the GRG step
+// a -= lr * grad + momentum * old (rpo_ddpg.py:279-287).  `first`: skip the stop test (rpo_ddpg.py:271, step == 0).
+// Returns false when the stop test ended the loop (nothing was changed).  With `dir_out` the gradient is also written
+// there ([43], by component).
+__device__ __forceinline__ bool grg_iteration_v2(Ws& w, const RowLane& L, bool first, float corr_eps, float lr, float momentum,
+                                                 bool apply, float* dir_out) {
+    const int tid = lane_id();
+    const Volt v = own_volt(w, L);
+    const Uniforms u = bus_uniforms(v);
+    float t1, t2;
+    const float resid = row_residual(w, L, v, u, t1, t2);
+    // per-component inequality residuals (:548-563) and ineq_grad_new (:590-594): +-1 per violated bound
+    const float av = w.a[tid < NY ? tid : NY];
+    const float up = av - L.hi, dn = L.lo - av;
+    if (!first) {
+        float m = fabsf(resid);                                // (0 outside the row lanes)
+        if (tid < NY) m = fmaxf(m, fmaxf(up, dn));
+        if (!(rpo_wave_max_nonneg(fmaxf(m, 0.0f)) > corr_eps)) return false;
+    }
+    const float g = tid < NY ? ((up > 0.0f ? 1.0f : 0.0f) - (dn > 0.0f ? 1.0f : 0.0f)) : 0.0f;
+    w.vec[L.colpos] = g;                                       // (lanes >= NY park a zero in slot NY: never read)
+    sync();
+    const bool force_dyn = w.c[RPO_EVOPF_C_FLAGS] != 0.0f;
+    const float isx = L.is_extra ? 1.0f : 0.0f;
+    float fp[NPV];
+    float dsum = 0.0f;                                         // row lanes: sum_p row[NO + p] fp[p] / pivot = (D fp)[mycol]
+    int mycol = tid;
+    bool solved = false;
+    if (!force_dyn) {
+        float row[NY];
+        jacobian_row<0, NY>(L, v, u, t1, t2, row);
+#pragma unroll
+        for (int c = 0; c < NY; ++c) row[c] = fmaf(isx, w.vec[c], row[c]);       // lane 28: [g_o^T | g_p^T]
+        const float mypiv = gj_static<0, NEQ, 6, 0, NY, TabGrg0>(row);
+        solved = pivots_ok<NEQ, 6>(mypiv);
+        if (solved) {
+            if (L.is_extra) {
+#pragma unroll
+                for (int p = 0; p < NPV; ++p) w.fp[p] = row[NO + p];             // g_p - D^T g_o (:603-606)
+            }
+            sync();
+#pragma unroll
+            for (int p = 0; p < NPV; ++p) fp[p] = w.fp[p];
+            float acc = 0.0f;
+#pragma unroll
+            for (int p = 0; p < NPV; ++p) acc = fmaf(row[NO + p], fp[p], acc);
+            dsum = acc / mypiv;
+        }
+    }
+    if (!solved) {                                             // partial pivoting (near-singular Jacobians, or forced)
+        float row[NY];
+        jacobian_row<0, NY>(L, v, u, t1, t2, row);
+#pragma unroll
+        for (int c = 0; c < NY; ++c) row[c] = fmaf(isx, w.vec[c], row[c]);
+        gj_static<0, 6, 6, 0, NY, TabGrg0>(row);               // the six unit pivots (only the extra row has entries there)
+        const float mypiv = gj_dynamic<6, NEQ, 0, NY>(row, mycol);
+        if (L.is_extra) {
+#pragma unroll
+            for (int p = 0; p < NPV; ++p) w.fp[p] = row[NO + p];
+        }
+        sync();
+#pragma unroll
+        for (int p = 0; p < NPV; ++p) fp[p] = w.fp[p];
+        float acc = 0.0f;
+#pragma unroll
+        for (int p = 0; p < NPV; ++p) acc = fmaf(row[NO + p], fp[p], acc);
+        dsum = acc / mypiv;
+    }
+    // full gradient by component (:608-610): partial components = fp (lanes 32..46), other components = -(D fp) (row lanes:
+    // the unknown of the pivot they own)
+    int var = L.own_var;
+    if (!solved) {
+#pragma unroll
+        for (int r = 0; r < NO; ++r) var = (L.is_row && mycol == r) ? kOtherVars[r] : var;
+    }
+    float gradv = -dsum;
+#pragma unroll
+    for (int p = 0; p < NPV; ++p) gradv = tid == 32 + p ? fp[p] : gradv;
+    if (var < NY) {
+        if (dir_out) dir_out[var] = gradv;
+        if (apply) {
+            const float st = lr * gradv + momentum * w.old[var];
+            w.a[var] -= st;
+            w.old[var] = st;
+        }
+    }
+    sync();
+    return true;
+}
+
+// grad_steps (rpo_ddpg.py:266-305, corr_mode 0) on w.a with the lane's own stop test; returns the iteration count
+__device__ __forceinline__ int grad_steps_v2(Ws& w, const RowLane& L, int max_steps, float lr, float corr_eps, float momentum) {
+    const int tid = lane_id();
+    if (tid < NY) w.old[tid] = 0.0f;
+    sync();
+    int k = 0;
+    for (; k < max_steps; ++k)
+        if (!grg_iteration_v2(w, L, k == 0, corr_eps, lr, momentum, true, nullptr)) break;
     return k;
 }
 
