@@ -701,6 +701,9 @@ def main():
     if tr._t < 1000:
         tr.run_steps(1000 - tr._t)
     tr._harvest(final=True)
+    # did EVERY rank replay captured hipGraphs (data-parallel: with the collectives inside them)?  A rank whose capture
+    # fails takes all ranks to eager launches together (trainer._GraphCache.run), and the line says so.
+    replayed_everywhere = tr.dist.replaying_everywhere(tr._graphs, device)
 
     result = {
         "metric": "env-steps/sec (whole node), %s, rollout + one batch-256 constrained policy update per vector step"
@@ -721,12 +724,15 @@ def main():
                    "parallelism": "dp%d (env shards, one RCCL all-reduce of the flat gradient bucket per update, "
                                   "captured inside the iteration's hipGraph)" % world,
                    "hip_graph": bool(tr._graphs.enabled), "graph_window_iterations": tr._cycle,
+                   "training_batch_projection": tr.projection_mode,
                    # what RCCL saw (0: no process group -- the single-process run has no collective at all), and the
                    # collectives of the data-parallel iteration: one all-reduce of the critic's flat gradient slice per update,
                    # one more (actor slice + multipliers [+ log alpha] in one bucket) on every policy_fre-th
                    "rccl_ranks": rccl_ranks, "data_parallel_path": bool(tr.dist.on),
                    "collectives_per_update": (1.0 + 1.0 / tr.policy_fre) if tr.dist.on else 0.0,
-                   "collectives_in_graph": bool(tr.dist.on and tr.dist.in_graph),
+                   "collectives_in_graph": bool(tr.dist.on and tr.dist.in_graph and replayed_everywhere),
+                   "graphs_replayed_on_all_ranks": bool(replayed_everywhere),
+                   "graph_capture_fell_back_to_eager": bool(tr._graphs.capture_failed),
                    "allreduce_bytes": {"critic_update": 4 * int(tr.agent.flat.gradient(tr.agent.flat.critic_range).numel()),
                                        "policy_step": 4 * int(sum(t.numel() for t in [tr.agent.flat.gradient(tr.agent.flat.policy_bucket)]))}
                    if tr.dist.on else None},
@@ -807,7 +813,14 @@ def main():
                     "sampled_transitions_per_s": 256 * EPG / dt,
                     "over_utd_matched": (EPG / dt) / result["utd_matched_env_steps_per_s"],
                     "note": "one batch-%d update per vector step: 256 sampled transitions per env step like the reference, one "
-                            "optimiser step per vector step (not %d)" % (256 * EPG, EPG)}
+                            "optimiser step per vector step (not %d)" % (256 * EPG, EPG),
+                    # tools/cadence_learning.py, 8 seeds x 3000 updates vs the reference's 384 runs (profiles/r04_cadence_learning.json,
+                    # tests/test_statistical_parity_gpu.py::test_vectorised_cadences_learn_like_the_reference)
+                    "learning_at_matched_updates": "THROUGHPUT FIGURE of another optimiser regime, not the reference's learning "
+                            "curve: at 3000 updates it reaches return 22.7 +- 1.2 (second half 28.6 +- 2.0) where the reference "
+                            "reaches 27.5 +- 0.6 (32.9 +- 0.8), with a LOWER violation rate (0.76e-2 +- 0.12e-2 vs 1.31e-2); the "
+                            "batch-256 cadence of the headline reproduces the reference at matched updates (25.6 +- 2.1 / 34.1 +- "
+                            "3.5, 1.07e-2 +- 0.18e-2)"}
                 if not args.no_clinic:
                     log("kernel clinic of the large-batch update:")
                     cl = kernel_clinic(lb, args.workload)

@@ -102,12 +102,19 @@ class FusedNets(object):
                                                 1, cat)))
         return out
 
-    def enable_splitk(self, flat_floats, slices=256):
+    def enable_splitk(self, batch_size):
         """Large update batches (>= RPO_SPLITK_FROM rows): give every trainable network a scratch buffer for the split-K
-        weights pass of the backward kernels (`slices` copies of at most the whole flat gradient buffer each)."""
+        weights pass of the backward kernels -- Z copies of the network's OWN gradient span (first to last gradient element in
+        the flat buffer, what splitk_plan in csrc/mlp_bwd.h addresses), Z = min(256, batch_size // 4096) as that plan uses.
+        (Round 3 allocated 256 x the whole flat gradient per network: ~64 x what a batch of 16384 touches)"""
+        z = max(2, min(256, int(batch_size) // 4096))
         for name, d in self.descs.items():
-            if "target" not in name and d.splitk is None:
-                d.splitk = torch.zeros(int(slices) * int(flat_floats), device=self.device)
+            if "target" in name or d.splitk is not None:
+                continue
+            grads = [t.grad for t in d.tensors.values() if t is not None and t.grad is not None]
+            lo = min(g.data_ptr() for g in grads)
+            hi = max(g.data_ptr() + 4 * g.numel() for g in grads)
+            d.splitk = torch.zeros(z * ((hi - lo) // 4), device=self.device)
 
     # ------------------------------------------------------------------------------------------ execution
     def buf(self, key, *shape):

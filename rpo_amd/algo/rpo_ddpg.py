@@ -223,7 +223,9 @@ class RPODDPG(RPOTrainerBase):
                                    self._uctrl)
         noise = self._noise_b.view(-1)
         actions = self._complete_only(state, ap_det, noise)
-        q = f.forward("critic", state, actions, f.buf("q", B, 1), save=True)
+        # (its own buffer: the lazily reduced actor loss below keeps a reference to it, and the next critic-only update writes
+        #  Q(s, a_replay) into "q" -- ADVICE r03)
+        q = f.forward("critic", state, actions, f.buf("q_pi", B, 1), save=True)
         lag, g_act = f.buf("loss_lag", 1), f.buf("g_act", B, k.action_dim)
         # (EVOPF kernels write the loss term and add the Lagrangian's d/d action themselves: no torch launch in the step)
         fa = bool(getattr(k, "fused_adds", False))

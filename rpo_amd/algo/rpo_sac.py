@@ -255,8 +255,10 @@ class RPOSAC(RPOTrainerBase):
         eps = self._draw(self._noise_b, self.dist.rank * B * self.kernels.partial_dim, _SALT_ACTOR)
         ap, logp, raw = self._gauss(state, eps, "pi", save=True)
         actions = self._complete_only(state, ap)
-        q1 = f.forward("critic1", state, actions, f.buf("q1", B, 1), save=True)
-        q2 = f.forward("critic2", state, actions, f.buf("q2", B, 1), save=True)
+        # (their own buffers: the lazily reduced actor loss keeps references to them, and the next critic-only update writes
+        #  Q(s, a_replay) into "q1" / "q2" -- ADVICE r03)
+        q1 = f.forward("critic1", state, actions, f.buf("q1_pi", B, 1), save=True)
+        q2 = f.forward("critic2", state, actions, f.buf("q2_pi", B, 1), save=True)
         lag, g_act = f.buf("loss_lag", 1), f.buf("g_act", B, k.action_dim)
         fa = bool(getattr(k, "fused_adds", False))             # (EVOPF kernels: see RPODDPG._actor_update)
         if not fa:

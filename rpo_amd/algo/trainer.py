@@ -111,6 +111,19 @@ class _Dist(object):
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t
 
+    def all_ok(self, ok, device):
+        """True iff `ok` holds on EVERY rank (one MIN all-reduce of a flag; host-synchronising -- for rare decisions only)."""
+        if not self.on:
+            return bool(ok)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
+
+    def replaying_everywhere(self, graphs, device):
+        """For the bench line: did every rank replay captured graphs (with the collectives inside them)?"""
+        mine = bool(graphs.enabled and not graphs.capture_failed and any(e["graph"] is not None for e in graphs.entries.values()))
+        return self.all_ok(mine, device)
+
 
 class _GraphCache(object):
     """Eager for the first ``warm`` calls of a key (on a side stream, as hipGraph capture of autograd wants), then
@@ -118,6 +131,7 @@ class _GraphCache(object):
 
     def __init__(self, enabled, warm=3, owner=None):
         self.enabled, self.warm = enabled, warm
+        self.capture_failed = False     # a capture was attempted and dropped (on this rank or, data-parallel, on any rank)
         self.entries = {}
         self.side = None
         # host state `fn` changes while it is being captured (hand-over flags, launch arguments): an aborted capture has
@@ -150,23 +164,34 @@ class _GraphCache(object):
         import gc
         gc_was_on = gc.isenabled()
         gc.disable()                                            # (a collection inside the capture could destroy an older hipGraph:
-        try:                                                    #  "operation not permitted when stream is capturing", fatal)
+        failure = None                                          #  "operation not permitted when stream is capturing", fatal)
+        try:
             # thread-local capture mode: the collective backend's watchdog thread may touch the HIP runtime meanwhile
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 fn()
         except Exception as exc:                                # noqa: BLE001  (capture is an optimisation, not a need)
+            failure = exc
+        finally:                                                # (KeyboardInterrupt / SystemExit inside fn() too: ADVICE r03)
             if gc_was_on:
                 gc.enable()
+        # Data-parallel ranks decide TOGETHER: a rank that replays a window with captured collectives cannot pair with a rank
+        # that issues them eagerly one iteration at a time in another order of host work -- if any rank's capture failed,
+        # every rank drops its graph and continues eagerly (one flag all-reduce per capture, never per iteration).
+        ok_everywhere = failure is None
+        if owner is not None and owner.dist.on and owner.dist.world > 1:
+            ok_everywhere = owner.dist.all_ok(failure is None, owner.device)
+        if not ok_everywhere:
             import warnings
-            warnings.warn("hipGraph capture failed (%s: %s); continuing with eager launches" % (type(exc).__name__, exc))
+            why = "%s: %s" % (type(failure).__name__, failure) if failure is not None else "another rank's capture failed"
+            warnings.warn("hipGraph capture failed (%s); continuing with eager launches" % why)
             self.enabled = False
+            self.capture_failed = True
+            del g
             torch.cuda.synchronize()
             if owner is not None:
                 owner._set_host_state(state)
             fn()                                                # nothing ran during the aborted capture
             return
-        if gc_was_on:
-            gc.enable()
         e["graph"] = g
         g.replay()
 
@@ -190,6 +215,14 @@ class RPOTrainerBase(object):
             setattr(self, k, v)
         if self.eval_steps is None:
             self.eval_steps = self.max_steps
+        if self.corr_mode != 0:
+            # rpo_ddpg.py:276-278 / rpo_sac.py:290-292: `nju(ineq_grad) + lamb(eq_grad)` applies Dual.forward (F.linear with a
+            # [1, ineq_num] / [1, eq_num] weight, model/dual.py:63-65) to gradients of width action_dim: a shape error in the
+            # reference for every env it ships (cart 2 vs 6 / 1, pendulum 2 vs 1 / 1, EVOPF 43 vs 58 / 28; verified on the
+            # unmodified reference: "mat1 and mat2 shapes cannot be multiplied (1x2 and 6x1)").  There is no behaviour to
+            # reproduce, so the argument is refused here instead of at the first projection.
+            raise ValueError("corr_mode=%r: only corr_mode=0 (reduced-gradient projection) is defined; the reference's "
+                             "corr_mode=1 branch (rpo_ddpg.py:276-278) raises a shape error for every env" % (self.corr_mode,))
         self.backend = backend if backend is not None else hip_ops
         self.base_env = getattr(env, "unwrapped", env)
         self.kernels = self.base_env.kernels
@@ -231,18 +264,28 @@ class RPOTrainerBase(object):
         self._cycle = _env_int("RPO_GRAPH_CYCLE", 16) // max(1, self.policy_fre) * max(1, self.policy_fre)
         # projection of training batches: the reference's literal batched semantics (default) or row-wise
         # (RPO_ROWWISE_PROJECTION=1); rollouts are always per lane == the reference's B = 1 calls
-        self.batch_reference = not bool(_env_int("RPO_ROWWISE_PROJECTION", 0))
-        if self.batch_size > 1024:
+        rowwise = _env_int("RPO_ROWWISE_PROJECTION", None)
+        self.batch_reference = not bool(rowwise)
+        if self.batch_size > 1024 and self.batch_reference and hasattr(self.kernels, "project_batchref"):
             # the reference's batched projection couples every sample of a SpringPendulum batch with every other (n^2 terms
-            # per GRG iteration): defined up to 1024 rows here; larger batches are projected row by row
-            self.batch_reference = False
+            # per GRG iteration, pendulum.py:337-339) and stops on the batch maximum (rpo_ddpg.py:271-272): the
+            # kernel is defined up to 1024 rows.  Larger batches are projected row by row -- OTHER semantics than the
+            # reference's, so it has to be asked for (RPO_ROWWISE_PROJECTION=1), not fallen into.  Envs without
+            # a batch-coupled kernel (CartSafe: both forms coincide, cartpole.py:403; EVOPF: hazard E2) are not affected.
+            raise ValueError(
+                "batch_size=%d > 1024 on %s: the reference's sample-coupled batched projection is defined up to 1024 rows "
+                "here; set RPO_ROWWISE_PROJECTION=1 to project training batches row by row (per-sample stop test, "
+                "no coupling between samples)" % (self.batch_size, self.kernels.name))
+        #: recorded in checkpoints / bench lines: how training batches are projected
+        self.projection_mode = ("batch-reference" if self.batch_reference and hasattr(self.kernels, "project_batchref")
+                                else "row-wise")
         # hand-written f32-MFMA MLP kernels for actor / critics (RPO_FUSED_MLP=0: the torch modules + autograd)
         want_fused = bool(_env_int("RPO_FUSED_MLP", 1)) if fused is None else bool(fused)
         self.fused = FusedNets.build(agent, self.backend, device) if want_fused else None
         if self.fused is not None and self.batch_size >= hip_ops.CONST.get("RPO_SPLITK_FROM", 1 << 30) and device.type == "cuda":
             # one LARGE batch per update (batch 256 * N): the parameter-gradient reductions of the backward
             # kernels split the batch over the chip (rpo_mlp_grad.splitk_scratch)
-            self.fused.enable_splitk(agent.flat.grad.numel())
+            self.fused.enable_splitk(self.batch_size)
         # updates per vector step: 1 = the reference's loop cadence (rpo_ddpg.py:160-161); num_envs = "UTD-matched":
         # as many batch-`batch_size` updates per env step as the reference performs (metric iii)
         self.updates_per_step = max(1, int(updates_per_step) if updates_per_step is not None
@@ -299,8 +342,6 @@ class RPOTrainerBase(object):
         """GRG loop on an action that already satisfies the equalities (rpo_ddpg.py:266-305, corr_mode 0).  The fused
         kernel restarts from the action's basic components, which reproduces the reference whenever the input lies on
         the equality manifold -- the only way the reference ever calls it (rpo_ddpg.py:74-75)."""
-        if self.corr_mode != 0:
-            raise NotImplementedError("corr_mode=1 (Lagrangian direction, rpo_ddpg.py:276-278) is unused by every script")
         idx = torch.as_tensor(np.asarray(self.base_env.partial_actions), device=self.device)
         return self.process_action(state, torch.as_tensor(action, device=self.device)[:, idx], train=train)
 
@@ -1242,7 +1283,7 @@ class RPOTrainerBase(object):
                      ep_count=v.ep_count, ctrl=v.ctrl, rows=b.rows[:filled].clone() if replay else None,
                      pending=self._pending, viol_steps=self.viol_steps, env_steps=self.env_steps,
                      capacity=b.capacity, row_floats=self.kernels.row_floats, algo=type(self).__name__,
-                     env=self.kernels.name)
+                     env=self.kernels.name, projection_mode=self.projection_mode)
         torch.save(state, os.path.join(d, "trainer_state.pth"))
 
     def load(self, weights_only=False):
@@ -1257,7 +1298,8 @@ class RPOTrainerBase(object):
             # validate BEFORE anything is modified
             b = self.buffer
             mine = dict(seed=self.seed, num_envs=self.num_envs, world=self.dist.world, capacity=b.capacity,
-                        row_floats=self.kernels.row_floats, algo=type(self).__name__, env=self.kernels.name)
+                        row_floats=self.kernels.row_floats, algo=type(self).__name__, env=self.kernels.name,
+                        projection_mode=self.projection_mode)
             diff = {k: (st[k], v) for k, v in mine.items() if k in st and st[k] != v}
             if diff:
                 raise ValueError("checkpoint does not match this trainer (checkpoint, trainer): %s" % diff)

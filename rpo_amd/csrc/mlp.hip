@@ -355,10 +355,7 @@ int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int
         if (int e = gemm_backward_rows(&args, 1, (hipStream_t)stream)) return e;
     if (param_grads && ein == 128 && net.H == 256) {              // large batches: rows + weights in ONE pass over the activations
         const SplitK sk = splitk_plan(args, grad_host->splitk_scratch, grad_host->splitk_floats);
-        if (sk.Z > 0) {
-            const int r = launch_onepass<128, 256>(args, sk, (hipStream_t)stream);
-            if (r >= 0) return r;
-        }
+        if (sk.Z > 0 && onepass_applies<128, 256>(args, sk)) return launch_onepass<128, 256>(args, sk, (hipStream_t)stream);
     }
 #define RPO_MLP_BWD(EIN_, H_)                                                                                       \
     if (ein == EIN_ && net.H == H_) {                                                                               \
@@ -407,10 +404,10 @@ int rpo_mlp_backward_pair(const rpo_mlp* net1_host, const rpo_mlp_grad* grad1_ho
     if (param_grads && ein == 128 && n1.H == 256 && grad1_host->splitk_scratch != grad2_host->splitk_scratch) {   // (see rpo_mlp_backward)
         const SplitK k1 = splitk_plan(args.net[0], grad1_host->splitk_scratch, grad1_host->splitk_floats);
         const SplitK k2 = splitk_plan(args.net[1], grad2_host->splitk_scratch, grad2_host->splitk_floats);
-        if (k1.Z > 0 && k2.Z > 0) {
-            const int r = launch_onepass<128, 256>(args.net[0], k1, (hipStream_t)stream);
-            if (r > 0) return r;
-            if (r == 0) return launch_onepass<128, 256>(args.net[1], k2, (hipStream_t)stream);
+        // (both networks or neither: nothing is launched before both are known to qualify)
+        if (k1.Z > 0 && k2.Z > 0 && onepass_applies<128, 256>(args.net[0], k1) && onepass_applies<128, 256>(args.net[1], k2)) {
+            if (int r = launch_onepass<128, 256>(args.net[0], k1, (hipStream_t)stream)) return r;
+            return launch_onepass<128, 256>(args.net[1], k2, (hipStream_t)stream);
         }
     }
 #define RPO_MLP_BWD2(EIN_, H_)                                                                                         \

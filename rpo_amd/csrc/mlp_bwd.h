@@ -949,15 +949,23 @@ static inline SplitK splitk_plan(const BwdArgs& a, float* scratch, long long scr
 }
 
 // The one-pass form applies to the scalar-head 128 -> 256 networks with up to 8 state / action inputs when every parameter
-// gradient is wanted and the action-input gradient is not (critic update, actor update); returns < 0 when it does not apply.
+// gradient is wanted and the action-input gradient is not (critic update, actor update).  Applicability is a question of its
+// own (onepass_applies) so that "does not apply" can never be mistaken for a failed launch (both used to be -1: a failed
+// memset was swallowed, and in the pair form the second network's "not applicable" surfaced as an error after the first
+// had already been launched -- ADVICE r03).
 template <int EIN, int H>
-static inline int launch_onepass(const BwdArgs& args, const SplitK& k, hipStream_t stream) {
+static inline bool onepass_applies(const BwdArgs& args, const SplitK& k) {
     const Mlp& net = args.net;
     if (EIN != 128 || H != 256 || net.cat || net.hd > 1 || net.S > 8 || net.A > 8 || !args.param_grads || args.first_layer_state_only ||
         args.da || k.Z < 2)
-        return -1;
+        return false;
     const char* e = getenv("RPO_BWD_ONEPASS");
-    if (e && e[0] == '0') return -1;
+    return !(e && e[0] == '0');
+}
+
+// Launches the one-pass backward (caller checked onepass_applies): 0 or an RPO_ERR_* / hipError code.
+template <int EIN, int H>
+static inline int launch_onepass(const BwdArgs& args, const SplitK& k, hipStream_t stream) {
     if (hipMemsetAsync(k.scratch, 0, (size_t)k.Z * (size_t)k.span * sizeof(float), stream) != hipSuccess) return RPO_ERR_ARG;
     hipLaunchKernelGGL((mlp_bwd_onepass_kernel<128, 256>), dim3(k.Z), dim3(kOnepassThreads), 0, stream, args, k);
     RPO_LAUNCH_CHECK();

@@ -58,11 +58,53 @@ def _worker(rank, world, port, algo, envname, out_dir):
     assert not torch.equal(gathered[0], gathered[1])            # the shards really sampled different data
     tr.run_steps(7)                                             # includes two policy steps (t = 4, 8)
     tr._harvest(final=True)
+    _check_graph_agreement(tr, rank)
     torch.save(dict(first=first_state, after_one=after_one, flat=fl.data.clone(), nju=tr.agent.nju.weight.data.clone(),
                     target=tr.agent.critic_target_flat.clone(), env_steps=float(tr.env_steps), viol=float(tr.viol_steps)),
                os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _check_graph_agreement(tr, rank):
+    """A hipGraph capture that fails on ONE rank takes every rank to eager launches together (_GraphCache.run): ranks that
+    replay captured collectives cannot pair with a rank that issues them eagerly.  No GPU here: torch.cuda.graph is replaced
+    by a stand-in whose capture raises on rank 1 only; both ranks must end up eager, with their host state restored, `fn`
+    executed exactly once for real, and the bench's "every rank replayed graphs" flag false on both."""
+    from rpo_amd.algo import trainer as T
+    assert tr.dist.all_ok(True, tr.device) and not tr.dist.all_ok(rank == 0, tr.device)
+    calls, restored = [], []
+
+    class FakeGraph(object):
+        def replay(self):
+            calls.append("replay")
+
+    class FakeCapture(object):
+        def __init__(self, g, **kw):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, et, ev, tb):
+            if et is None and rank == 1:
+                raise RuntimeError("capture failed on this rank")
+            return False
+    real = (torch.cuda.CUDAGraph, torch.cuda.graph, torch.cuda.synchronize)
+    torch.cuda.CUDAGraph, torch.cuda.graph, torch.cuda.synchronize = FakeGraph, FakeCapture, lambda *a: None
+    orig_set = tr._set_host_state
+    tr._set_host_state = lambda st: (restored.append(True), orig_set(st))
+    try:
+        cache = T._GraphCache(True, warm=0, owner=tr)
+        cache.run("window", lambda: calls.append("fn"))
+        assert calls == ["fn", "fn"] and restored == [True]      # once inside the (dropped) capture, once eagerly
+        assert not cache.enabled and cache.capture_failed
+        cache.run("window", lambda: calls.append("eager"))
+        assert calls[-1] == "eager"
+        assert not tr.dist.replaying_everywhere(cache, tr.device)
+    finally:
+        torch.cuda.CUDAGraph, torch.cuda.graph, torch.cuda.synchronize = real
+        tr._set_host_state = orig_set
 
 
 @pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "pendulum")])

@@ -150,6 +150,13 @@ def test_projection_matches_oracle(env):
     assert (it.cpu().numpy() == wit).mean() > 0.95           # the 1e-5 stop test can flip on float32 noise
 
 
+def test_env_constraint_api_matches_reference(env):
+    """eq_jac / ineq_jac / eq_grad / ineq_grad / ineq_grad_new / ineq_dist_np / eq_resid_np (evopf.py:564-594,614-707)
+    through rpo_evopf_eq_vjp / rpo_evopf_resid against the reference's own outputs."""
+    from test_evopf_oracle import check_constraint_api
+    check_constraint_api(env, golden("evopf_env"), dev)
+
+
 def test_static_elimination_order_equals_partial_pivoting(env, monkeypatch):
     """The solver eliminates in a compiled-in static order with case14's sparsity (csrc/evopf_dev.h) and falls back to
     partial pivoting per solve when its pivots fail the acceptance test; RPO_EVOPF_PIVOT=dynamic forces partial pivoting

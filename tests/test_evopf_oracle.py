@@ -187,6 +187,36 @@ def test_constraint_functions_match_reference(env_fx):
                                env_fx["ineq_partial_grad_feasible"], atol=2e-3 * max(1.0, np.abs(env_fx["ineq_partial_grad_feasible"]).max()))
 
 
+def check_constraint_api(env, fx, t32):
+    """The rest of the reference's constraint surface (evopf.py:564-594,614-707: eq_jac, ineq_jac, eq_grad, ineq_grad,
+    ineq_grad_new, ineq_dist_np, eq_resid_np) on an EVOPFEnv, against what the unmodified reference returned for the same
+    (S, AX) (tests/golden/make_evopf_golden.py gen_env).  Shared by the CPU leg (oracle backend) and the GPU leg."""
+    S, AX = t32(fx["S"]), t32(fx["AX"])
+    np.testing.assert_allclose(env.eq_jac(AX).cpu().numpy(), fx["eq_jac"], atol=5e-5)
+    assert tuple(env.eq_jac(AX[3]).shape) == (1, 28, 43)
+    np.testing.assert_array_equal(env.ineq_jac(S, AX).cpu().numpy(), fx["ineq_jac"])
+    ref = fx["eq_grad"]
+    np.testing.assert_allclose(env.eq_grad(S, AX).cpu().numpy(), ref, atol=2e-5 * max(1.0, np.abs(ref).max()))
+    np.testing.assert_allclose(env.ineq_grad(S, AX).cpu().numpy(), fx["ineq_grad"], atol=5e-6)
+    np.testing.assert_allclose(env.ineq_grad(S, AX, 0.02).cpu().numpy(), fx["ineq_grad_eps"], atol=5e-6)
+    np.testing.assert_array_equal(env.ineq_grad_new(S, AX).cpu().numpy(), fx["ineq_grad_new"])
+    assert np.abs(fx["ineq_grad_new"]).sum() > 0 and np.abs(fx["ineq_grad"]).max() > 0
+    d = env.ineq_dist_np(fx["S"][3], fx["AX"][3])
+    assert d.shape == (1, 58)
+    np.testing.assert_allclose(d, fx["ineq_dist_np"], atol=2e-6)
+    r = env.eq_resid_np(fx["S"][3], fx["AX"][3])
+    assert r.shape == (1, 28)
+    np.testing.assert_allclose(r, fx["eq_resid_np"], atol=2e-5)
+
+
+def test_env_constraint_api_matches_reference_on_oracle_backend(env_fx):
+    import torch
+    import oracle_backend as ob
+    from rpo_amd.env import EVOPFEnv
+    env = EVOPFEnv(backend=ob, device="cpu")
+    check_constraint_api(env, env_fx, lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32))
+
+
 def test_equation_solver_matches_reference(env_fx):
     S, AP = env_fx["S"].astype(np.float64), env_fx["AP"].astype(np.float64)
     a, jac, jn, _ = oe.complete_partial(S, AP, return_aux=True)

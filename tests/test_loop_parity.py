@@ -67,3 +67,20 @@ def test_shipped_loop_equals_oracle_loop_with_shared_draws(steps):
         worst["nu"] = max(worst["nu"], float((tr.agent.nju.weight.detach() - orc.nju.detach()).abs().max()))
     assert env.episode >= 2 and float(orc.nju.detach().max()) > 0.05     # an episode ended; the multiplier left zero
     assert worst["state"] < 2e-5 and worst["actor"] < 1e-5 and worst["critic"] < 1e-5 and worst["nu"] < 1e-5, worst
+
+
+def test_constructor_refuses_what_it_cannot_reproduce(monkeypatch):
+    """corr_mode=1 (rpo_ddpg.py:276-278) is a shape error in the reference for every env (Dual.forward on action-sized
+    gradients), so it is refused when the trainer is built, not at the first projection.  A SpringPendulum training batch
+    beyond 1024 rows cannot use the reference's sample-coupled projection: refused unless row-wise projection is asked for
+    explicitly, and the mode is recorded on the trainer."""
+    dev = torch.device("cpu")
+    with pytest.raises(ValueError, match="corr_mode"):
+        build_trainer("ddpg", "cart", ob, dev, fused=False, num_envs=1, corr_mode=1)
+    with pytest.raises(ValueError, match="RPO_ROWWISE_PROJECTION"):
+        build_trainer("sac", "pendulum", ob, dev, fused=False, num_envs=4, batch_size=2048, capacity=600)
+    assert build_trainer("sac", "pendulum", ob, dev, fused=False, num_envs=1).projection_mode == "batch-reference"
+    assert build_trainer("ddpg", "cart", ob, dev, fused=False, num_envs=4, batch_size=2048, capacity=600).projection_mode == "row-wise"
+    monkeypatch.setenv("RPO_ROWWISE_PROJECTION", "1")
+    tr = build_trainer("sac", "pendulum", ob, dev, fused=False, num_envs=4, batch_size=2048, capacity=600)
+    assert tr.projection_mode == "row-wise" and not tr.batch_reference

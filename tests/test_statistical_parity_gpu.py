@@ -1,7 +1,7 @@
 """Statistical parity with the reference's CPU runs (north_star: returns and constraint-violation rate).
 
 tests/golden/training_stats_*.npz hold the statistics of 3000-iteration training runs of the unmodified reference
-(scripts/cart_exp.py: 384 seeds; scripts/pen_exp_sac.py: 24 seeds; scripts/cart_exp_sac.py: 96 seeds; scripts/pen_exp.py: 576 seeds;
+(scripts/cart_exp.py: 384 seeds; scripts/pen_exp_sac.py: 192 seeds (round 4; 24 before); scripts/cart_exp_sac.py: 96 seeds; scripts/pen_exp.py: 576 seeds;
 tests/golden/make_golden.py stats).  The same runs are
 repeated here with the shipped trainers at num_envs = 1 -- the reference's cadence, step for step -- on the HIP kernels,
 on TWICE as many seeds (GPU runs are cheap).  Random streams differ (Philox vs numpy/torch global generators) and
@@ -83,14 +83,16 @@ def test_training_statistics_match_reference(golden, algo, envname, se_max):
     assert got[:, 0].min() > 0.9 * steps                         # the logger received (almost) every step
 
 
+@pytest.mark.timeout(1500, method="thread")
 @pytest.mark.parametrize("algo", ["ddpg", "sac"])
 def test_evopf_training_statistics_match_reference(golden, algo):
-    """EVOPF-v0, RPODDPG / RPOSAC with the hyper-parameters of scripts/evopf_exp.py / evopf_exp_sac.py: 3 seeds x 960
-    iterations (40 days) of the reference (on the pypower stand-in, tests/golden/make_evopf_golden.py stats [sac]) vs the
-    shipped trainer at num_envs = 1 on the HIP kernels (MLP kernels, wave-per-lane power flow).  Different random days and
-    exploration streams, so only seed-averaged statistics are compared: violation rate within 3 SE + 0.05, mean
-    max-inequality violation within 3 SE + 30 %, mean return within 3 SE + 15 %; the equalities hold to the level the
-    reference reaches (GRG drift)."""
+    """EVOPF-v0, RPODDPG / RPOSAC with the hyper-parameters of scripts/evopf_exp.py / evopf_exp_sac.py: 24 seeds x 960
+    iterations (40 days) of the reference (on the pypower stand-in, tests/golden/make_evopf_golden.py stats [sac]; 3 seeds
+    until round 3) vs TWICE as many runs of the shipped trainer at num_envs = 1 on the HIP kernels (MLP kernels,
+    wave-per-lane power flow).  Different random days and exploration streams, so only seed-averaged statistics are compared,
+    each within 2 standard errors of the difference + 10 % of the reference's mean (round 3: 3 SE + 0.05 absolute on the rate,
+    30 % / 15 % on the others -- a slack that could not see a 10 % bias): violation rate, mean max-inequality violation, mean
+    return over the run and over its second half; the equalities hold to the level the reference reaches (GRG drift)."""
     from rpo_amd import ops
     from rpo_amd.algo import RPODDPG, RPOSAC
     from rpo_amd.env import EVOPFEnv
@@ -98,37 +100,84 @@ def test_evopf_training_statistics_match_reference(golden, algo):
     import test_train_step_golden as tsg
     g = golden("training_stats_%s_evopf" % algo)
     ref, steps = g["stats"], int(g["steps"])
+    assert len(ref) >= 24
     hp = {k: v for k, v in tsg.EVOPF_HP.items() if k not in ("embed_dim", "hidden_dim", "init_nju", "capacity")}
     if algo == "sac":                                            # scripts/evopf_exp_sac.py:29-32
         del hp["gamma"]
         hp.update(grad_eps=0.1, alpha=0.001, automatic_entropy_tuning=False, fixed=False)
     cls = RPODDPG if algo == "ddpg" else RPOSAC
     rows = []
-    for seed in range(3):
+    os.environ["RPO_VERBOSE"] = "0"
+    for seed in range(2 * len(ref)):
         torch.manual_seed(123 + seed)
         tr = cls(EVOPFEnv(device="cuda"), "/tmp/rpo_test", name="t", logger=None, max_epochs=steps, capacity=20000,
                  device=torch.device("cuda"), num_envs=1, seed=1000 + seed, **hp)
         assert tr.fused is not None
         tr.logger = Logger(("epoch", "reward", "max_ineq", "max_eq"), times=1, epochs=steps)
-        os.environ["RPO_VERBOSE"] = "0"
         tr.run(eval=False)
         n = tr.logger.pointer
         mi, me, rw = [tr.logger.tracker[k][:n] for k in ("max_ineq", "max_eq", "reward")]
         viol = np.maximum(mi, me) > 1e-3
         rows.append([n, viol.mean(), mi.mean(), me.mean(), me.max(), rw.mean(), rw[n // 2:].mean()])
+        del tr
     got = np.array(rows)
-    out = {"ref_mean": ref.mean(0).tolist(), "gpu_mean": got.mean(0).tolist(), "ref_std": ref.std(0).tolist(),
-           "gpu_std": got.std(0).tolist(), "columns": [str(c) for c in g["columns"]]}
+
+    def se(col):
+        return float(np.sqrt(ref[:, col].var(ddof=1) / len(ref) + got[:, col].var(ddof=1) / len(got)))
+    out = {"ref_seeds": len(ref), "gpu_seeds": len(got), "steps": steps, "ref_mean": ref.mean(0).tolist(),
+           "gpu_mean": got.mean(0).tolist(), "ref_std": ref.std(0, ddof=1).tolist(), "gpu_std": got.std(0, ddof=1).tolist(),
+           "se_of_difference": [se(c) for c in range(ref.shape[1])], "columns": [str(c) for c in g["columns"]],
+           "bound": "2 SE + 10 % of the reference mean"}
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/statistical_parity_%s_evopf.json" % algo, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out))
-
-    def se(col):
-        return np.sqrt(ref[:, col].var() / len(ref) + got[:, col].var() / len(got))
     assert got[:, 0].min() == steps                              # 40 complete days, every step logged
-    assert abs(got[:, 1].mean() - ref[:, 1].mean()) <= 3 * se(1) + 0.05
-    assert abs(got[:, 2].mean() - ref[:, 2].mean()) <= 3 * se(2) + 0.3 * ref[:, 2].mean()
+    for col in (1, 2, 5, 6):                                     # violation rate, mean max_ineq, return, return (2nd half)
+        d = abs(got[:, col].mean() - ref[:, col].mean())
+        assert d <= 2 * se(col) + 0.10 * abs(ref[:, col].mean()), (g["columns"][col], d, se(col), ref[:, col].mean())
     assert got[:, 4].max() <= max(2.0 * ref[:, 4].max(), 1e-2)   # equality drift no worse than the reference's
-    for col in (5, 6):
-        assert abs(got[:, col].mean() - ref[:, col].mean()) <= 3 * se(col) + 0.15 * abs(ref[:, col].mean())
+
+
+@pytest.mark.timeout(1500, method="thread")
+def test_vectorised_cadences_learn_like_the_reference(golden):
+    """Learning quality at the BENCHMARKED cadences: cart-RPODDPG at num_envs = 4096 with (a) one batch-256
+    update per vector step (the headline's cadence) and (b) one batch-2^20 update per vector step (`large_batch`), 8 seeds
+    each, to the budget of UPDATES of the reference's runs (3000; tests/golden/training_stats_ddpg_cart.npz, 384 seeds).  The
+    reference's per-run statistics are computed per lane from the replay ring exactly as its Logger records them
+    (tools/cadence_learning.py) and averaged over the lanes of a run; a run is one sample.
+
+    (a) must reproduce the reference at matched updates: return (whole run, second half) within 2 SE + 10 %, violation rate
+    within 2 SE + 1e-3 (measured round 4: 25.6 +- 2.1 / 34.1 +- 3.5 vs 27.5 / 32.9; 1.07e-2 +- 0.18e-2 vs 1.31e-2).
+    (b) is ANOTHER optimiser regime (4096 x the batch, same learning rates and clip): measured 22.7 +- 1.2 / 28.6 +- 2.0 and
+    0.76e-2 +- 0.12e-2 -- fewer violations, ~15 % less return at matched updates -- so it is held to: violation rate not above
+    the reference's (2 SE), return not more than 2 SE + 25 % below; bench.py labels its figure accordingly."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import cadence_learning as cl
+    g = golden("training_stats_ddpg_cart")
+    ref, steps = g["stats"], int(g["steps"])
+    dev = torch.device("cuda")
+    res = {"reference": cl.reference_row(), "modes": []}
+    for mode in ("reference_cadence", "large_batch"):
+        m = cl.run_mode(mode, 8, steps, dev)
+        res["modes"].append(m)
+
+        def se(col, key):
+            return float(np.sqrt(ref[:, col].var(ddof=1) / len(ref) + m["se"][key] ** 2))
+        d_viol = m["mean"]["viol_rate"] - ref[:, 1].mean()
+        d_ret = m["mean"]["mean_return_per_step"] - ref[:, 4].mean()
+        d_ret2 = m["mean"]["mean_return_second_half"] - ref[:, 5].mean()
+        assert abs(m["mean"]["device_viol_rate"] - m["mean"]["viol_rate"]) < 1e-3      # device counter == per-lane replay of the ring
+        assert m["mean"]["logged_steps"] > 0.95 * steps
+        if mode == "reference_cadence":
+            assert abs(d_viol) <= 2 * se(1, "viol_rate") + 1e-3, (d_viol, se(1, "viol_rate"))
+            assert abs(d_ret) <= 2 * se(4, "mean_return_per_step") + 0.10 * ref[:, 4].mean(), d_ret
+            assert abs(d_ret2) <= 2 * se(5, "mean_return_second_half") + 0.10 * ref[:, 5].mean(), d_ret2
+        else:
+            assert d_viol <= 2 * se(1, "viol_rate"), (d_viol, se(1, "viol_rate"))
+            assert d_ret >= -(2 * se(4, "mean_return_per_step") + 0.25 * ref[:, 4].mean()), d_ret
+            assert d_ret2 >= -(2 * se(5, "mean_return_second_half") + 0.25 * ref[:, 5].mean()), d_ret2
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/cadence_learning.json", "w") as f:
+        json.dump(res, f, indent=1)

@@ -747,14 +747,20 @@ def test_fused_front_with_other_batch_sizes(hip, algo, envname, batch, monkeypat
 
 
 @pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "cart"), ("sac", "pendulum")])
-def test_large_batch_update_mode(hip, algo, envname):
+def test_large_batch_update_mode(hip, algo, envname, monkeypatch):
     """batch_size >= RPO_SPLITK_FROM (one batch of 256 * N per vector step): the update runs through the generic
-    MLP kernels with the split-K weights pass; SpringPendulum batches beyond 1024 rows are projected row by row.  hipGraph
+    MLP kernels with the split-K weights pass; SpringPendulum batches beyond 1024 rows are projected row by row -- other
+    semantics than the reference's sample-coupled batch, so the trainer refuses them unless RPO_ROWWISE_PROJECTION=1.  hipGraph
     windows == eager launches bit for bit (every reduction has a fixed order), parameters move and stay finite, and the
     first critic update equals the same update through the plain one-owner weights pass to summation round-off."""
     dev = torch.device("cuda")
     B = hip.CONST["RPO_SPLITK_FROM"]
+    if envname == "pendulum":
+        with pytest.raises(ValueError, match="RPO_ROWWISE_PROJECTION"):
+            build_trainer(algo, envname, hip, dev, num_envs=512, use_graph=False, batch_size=B, capacity=64)
+        monkeypatch.setenv("RPO_ROWWISE_PROJECTION", "1")
     a = _run(algo, envname, hip, dev, 24, 512, use_graph=True, batch_size=B, capacity=64)
+    assert a.projection_mode == "row-wise"
     b = _run(algo, envname, hip, dev, 24, 512, use_graph=False, batch_size=B, capacity=64)
     assert a._large_batch and not a._pipelines and not a._actor_pipeline and a._split_state() is None
     assert all(d.splitk is not None for n, d in a.fused.descs.items() if "target" not in n)
