@@ -346,3 +346,55 @@ def test_lost_producer_fails_loudly_and_leaves_the_device_usable(workload, monke
     h.run_steps(40)
     h._harvest(final=True)
     assert bool(torch.isfinite(h.vec.internal).all()) and bool(torch.isfinite(h.agent.flat.data).all())
+
+
+def test_eight_way_rank_layout_is_invisible_in_the_lanes():
+    """Config 4's rank layout on ONE GPU (rank r owns env ids [4096 r / 8 ...)): eight 512-lane launches of the fused
+    rollout kernel with env_id_base = 512 r leave, over 260 vector steps (the 200-step TimeLimit ends every first episode,
+    terminations restart lanes in between), exactly the lanes, actions, episode bookkeeping and ring rows of ONE 4096-lane
+    launch per step -- CartSafe-v0 with RPOSAC's squashed-Gaussian actor (scripts/cart_exp_sac.py), every random draw keyed by
+    (seed, global env id, step).  Next to the 2-way checks above."""
+    import bench
+    from rpo_amd import ops
+    from rpo_amd.env.vec import VecEnv
+    os.environ["RPO_VERBOSE"] = "0"
+    n, R, steps, cap = 4096, 8, 260, 4
+    tr = bench.make_trainer(n, DEV, 10 ** 9, capacity=4, workload="cart_sac", use_graph=False)
+    k, f = tr.kernels, tr.fused
+    scale, base = tr._box_affine
+
+    def roll(v, rows):
+        k.rollout(f.descs["actor"], True, scale, base, v.internal, None, v.action, v.ep_len, v.ep_ret, v.ep_count, rows, cap,
+                  v.stats, v.ctrl, ops.NOISE_NONE, tr.eps_start, tr.eps, tr.decay_value, tr._box_lo, tr._box_hi, tr.max_steps,
+                  tr.corr_lr, tr.corr_eps, tr.corr_momentum, 200, True, 1e-3, v.seed, v.env_id_base)
+    whole = VecEnv(k, n, DEV, seed=tr.seed, env_id_base=0, max_episode_steps=200)
+    parts = [VecEnv(k, n // R, DEV, seed=tr.seed, env_id_base=r * (n // R), max_episode_steps=200) for r in range(R)]
+    rows_w = torch.zeros(cap * n, k.row_floats, device=DEV)
+    rows_p = [torch.zeros(cap * (n // R), k.row_floats, device=DEV) for _ in range(R)]
+    for v in [whole] + parts:
+        v.reset()
+    assert torch.equal(whole.internal, torch.cat([p.internal for p in parts]))
+    restarts = 0
+    for t in range(steps):
+        roll(whole, rows_w)
+        for p, rp in zip(parts, rows_p):
+            roll(p, rp)
+        if t % 20 == 19 or t == steps - 1:
+            assert torch.equal(whole.internal, torch.cat([p.internal for p in parts])), t
+            assert torch.equal(whole.action, torch.cat([p.action for p in parts])), t
+            assert torch.equal(whole.ep_len, torch.cat([p.ep_len for p in parts]))
+            assert torch.equal(whole.ep_count, torch.cat([p.ep_count for p in parts]))
+            assert torch.equal(whole.ep_ret, torch.cat([p.ep_ret for p in parts]))
+            slot = t % cap                                         # the ring slot of this step: [slot n, (slot + 1) n)
+            mine = rows_w[slot * n:(slot + 1) * n]
+            theirs = torch.cat([rp[slot * (n // R):(slot + 1) * (n // R)] for rp in rows_p])
+            assert torch.equal(mine, theirs), t
+    restarts = int(whole.ep_count.sum())
+    assert restarts >= n and int(whole.ctrl[0]) == steps and all(int(p.ctrl[0]) == steps for p in parts)
+    # per-step statistics: the shards' counters add up to the whole launch's (float sums to rounding)
+    S = ops.STAT
+    sw = ops.reduce_stats(whole.stats[:steps]).cpu().numpy()
+    sp = sum(ops.reduce_stats(p.stats[:steps]).cpu().numpy() for p in parts)
+    for key in ("episodes", "viol_count", "length_sum", "terminated", "proj_iters"):
+        np.testing.assert_array_equal(sw[:, S[key]], sp[:, S[key]])
+    np.testing.assert_allclose(sw[:, S["reward_sum"]], sp[:, S["reward_sum"]], rtol=2e-6)
