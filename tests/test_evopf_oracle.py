@@ -255,3 +255,17 @@ def test_projection_matches_reference(tag):
     if tag == "large":
         start = oe.complete_partial(S, AP)
         assert np.abs(fx["large_eval"] - start).max() > 1e-2
+
+
+def test_recorded_newton_divergence_is_a_property_of_the_input():
+    """One step in 46 080 of the EVOPF-RPOSAC parity runs (round 4, seed 40, step 617) stored an equality violation of 117: the
+    basic action had the generator voltages at the lower edge of their box with almost no generation.  The float64 oracle
+    (numpy LAPACK solves, partial pivoting) does not converge on that input either -- PFFunction's Newton iteration
+    (evopf.py:819-835) simply has no solution to find from the flat start -- so the event is not an artefact of the kernels'
+    float32 static-order elimination (tools/diag_evopf_sac.py: static and pivoted kernels both return garbage there)."""
+    fx = golden("evopf_newton_divergence")
+    s = fx["s"][None].astype(np.float64)
+    ap = fx["a"][None].astype(np.float64)[:, G.partial_actions]
+    a, _, _, its = oe.complete_partial(s, ap, return_aux=True)
+    assert int(np.asarray(its).max()) == 50                       # max_iters: no convergence
+    assert np.abs(oe.eq_resid(s, a)).max() > 0.1
