@@ -40,7 +40,7 @@ extern "C" {
 /* 3: rpo_split_update gained proj_ws / proj_store_mode / debug (the struct grew); rpo_split_critic_pfront*,
  * rpo_pendulum_project_batchref_ws; rpo_evopf_complete_bwd takes grad_action_b / grad_action2, rpo_evopf_lagrangian takes overwrite;
  * rpo_min_q_bwd, rpo_hw_probe */
-#define RPO_ABI_VERSION 3
+#define RPO_ABI_VERSION 4
 
 #define RPO_ERR_ARG (-1)
 #define RPO_ERR_NULL (-2)
@@ -49,12 +49,16 @@ extern "C" {
 #define RPO_CART_ACTION_DIM 2
 #define RPO_CART_INEQ 6
 #define RPO_CART_ROW 24
+#define RPO_CART_RING 32 /* floats between consecutive rows of the REPLAY RING: a 96-byte transition per 128-byte line, so a random
+                            row is one line (96-byte spacing: 1.5 lines on average -- gather traffic 1.58 x, round 3); the last
+                            8 floats of a ring row are never written or read.  Gathered batches stay RPO_CART_ROW wide. */
 #define RPO_CART_CONSTS_LEN 35 /* C[2] C_p C_o_inv b G[12] d[6] G_r[6] d_r[6], cartpole.py:124-136,397-400 */
 
 #define RPO_PEND_INTERNAL_DIM 4
 #define RPO_PEND_OBS_DIM 5
 #define RPO_PEND_ACTION_DIM 2
 #define RPO_PEND_ROW 16
+#define RPO_PEND_RING 16 /* 64-byte rows: two per line, never straddling */
 
 /* EVOPF-v0 (rpo/env/electrical_grid/evopf.py:333-337): observation = pd[14] qd[14] soc[5] price[24]; action = pg[5] qg[5]
  * vm[14] va[14] pe[5]; 14 basic actions = pg at the 4 PV generators, vm at the 5 generator buses, pe[5] (:292-294). */
@@ -277,13 +281,14 @@ int rpo_pendulum_lagrangian(int n, const float* action, const float* nu, float s
 /* ReplayBuffer.sample (buffer.py:31-34): uniform with replacement over the valid rows
  * n_valid = min(t, cap_steps) * n_envs (t = ctrl[RPO_CTRL_T]); index b = mulhi64(Philox(seed; b, t + sample_salt,
  * RPO_STREAM_SAMPLE).xy, n_valid); copies the row into batch[b, :].  idx_out (int64 [B], may be NULL) receives the
- * drawn indices. */
-int rpo_replay_sample_gather(const float* rows, int row_floats, long long cap_steps, int n_envs, int batch,
+ * drawn indices.  ring_floats = floats between consecutive ring rows (RPO_*_RING; >= row_floats), row_floats = floats of a
+ * transition = width of the gathered batch. */
+int rpo_replay_sample_gather(const float* rows, int ring_floats, int row_floats, long long cap_steps, int n_envs, int batch,
                              float* batch_out, long long* idx_out, unsigned long long seed, unsigned sample_salt,
                              const long long* ctrl, void* stream);
 
 /* Same gather with caller-provided indices (int64 [B]) -- parity tests inject the reference's np.random.randint. */
-int rpo_replay_gather(const float* rows, int row_floats, int batch, const long long* idx, float* batch_out,
+int rpo_replay_gather(const float* rows, int ring_floats, int row_floats, int batch, const long long* idx, float* batch_out,
                       void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------

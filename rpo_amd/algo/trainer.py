@@ -1218,7 +1218,7 @@ class RPOTrainerBase(object):
             self._vec_eval = self.base_env.make_vec(lanes, seed=self.seed ^ 0x5EED5EED, env_id_base=0,
                                                     max_episode_steps=self.max_episode_steps, device=self.device,
                                                     stats_cap=2)
-            self._eval_rows = torch.zeros(lanes, self.kernels.row_floats, device=self.device)
+            self._eval_rows = torch.zeros(lanes, self.kernels.ring_floats, device=self.device)
         v, c = self._vec_eval, self.kernels.cols
         v.ep_count += 1                                                 # fresh initial states at every evaluation
         v.reset()

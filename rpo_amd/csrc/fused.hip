@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kFwdThreads) void cart_ddpg_critic_forward_kernel(C
                                             (uint32_t)p.ctrl[RPO_CTRL_UPDATES]);
                 row = (long long)__umul64hi(((unsigned long long)u.x << 32) | u.y, n_valid);
             }
-            v = reinterpret_cast<const float4*>(p.rows)[row * 6 + ch];
+            v = reinterpret_cast<const float4*>(p.rows)[row * (RPO_CART_RING / 4) + ch];
             if (blockIdx.y == 0) {                             // both roles draw the same rows; one publishes them
                 reinterpret_cast<float4*>(p.batch_out)[(size_t)(row0 + r) * 6 + ch] = v;
                 if (p.idx_out && ch == 0) p.idx_out[row0 + r] = row;
@@ -232,8 +232,8 @@ __global__ __launch_bounds__(kFwdThreads) void cart_ddpg_critic_forward_kernel(C
 // (rpo_sac.py:342-353).  CartSafe: all five MLP tiles chained in one workgroup of 16 rows.  SpringPendulum: the
 // reference's batched projection couples the samples of a batch (pendulum.py:337-339), so the chain is cut
 // there: front (sample -> policy) | rpo_pendulum_project_batchref | back (target critics -> critics -> TD).
-struct CartRow { static constexpr int ROW = 24, CH = 6, S = 6, A_OFF = 6, NS_OFF = 8; };
-struct PendRow { static constexpr int ROW = 16, CH = 4, S = 5, A_OFF = 5, NS_OFF = 7; };
+struct CartRow { static constexpr int ROW = 24, CH = 6, RCH = RPO_CART_RING / 4, S = 6, A_OFF = 6, NS_OFF = 8; };
+struct PendRow { static constexpr int ROW = 16, CH = 4, RCH = RPO_PEND_RING / 4, S = 5, A_OFF = 5, NS_OFF = 7; };
 
 struct SacCriticFwdArgs {
     Mlp actor, critic_target1, critic_target2, critic1, critic2;
@@ -274,7 +274,7 @@ __device__ __forceinline__ void sac_sample(const SacCriticFwdArgs& p, float4* ti
                                             (uint32_t)p.ctrl[RPO_CTRL_UPDATES]);
                 row = (long long)__umul64hi(((unsigned long long)u.x << 32) | u.y, n_valid);
             }
-            v = reinterpret_cast<const float4*>(p.rows)[row * L::CH + ch];
+            v = reinterpret_cast<const float4*>(p.rows)[row * L::RCH + ch];
             if (blockIdx.y == 0) {                             // every role draws the same rows; one publishes them
                 reinterpret_cast<float4*>(p.batch_out)[(size_t)(row0 + r) * L::CH + ch] = v;
                 if (p.idx_out && ch == 0) p.idx_out[row0 + r] = row;

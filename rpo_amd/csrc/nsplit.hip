@@ -78,8 +78,8 @@ __global__ __launch_bounds__(RPO_BLOCK) void mlp_split_head_kernel(Mlp net, int 
 // ====================================================================================== column-split critic update
 using rpo_cart_dev::CartConsts;
 
-struct CartRow { typedef CartEnv Env; static constexpr int ROW = RPO_CART_ROW, CH = 6, S = 6, A_OFF = 6, NS_OFF = 8, R_OFF = 14; };
-struct PendRow { typedef PendEnv Env; static constexpr int ROW = RPO_PEND_ROW, CH = 4, S = 5, A_OFF = 5, NS_OFF = 7, R_OFF = 12; };
+struct CartRow { typedef CartEnv Env; static constexpr int ROW = RPO_CART_ROW, CH = 6, RCH = RPO_CART_RING / 4, S = 6, A_OFF = 6, NS_OFF = 8, R_OFF = 14; };
+struct PendRow { typedef PendEnv Env; static constexpr int ROW = RPO_PEND_ROW, CH = 4, RCH = RPO_PEND_RING / 4, S = 5, A_OFF = 5, NS_OFF = 7, R_OFF = 12; };
 
 // Device view of rpo_split_update (host network descriptors resolved to device pointer sets).
 struct SplitArgs {
@@ -210,7 +210,7 @@ __device__ __forceinline__ void ns_sample(const SplitArgs& p, float4* tile, int 
                                             (uint32_t)p.ctrl[RPO_CTRL_UPDATES]);
                 row = (long long)__umul64hi(((unsigned long long)u.x << 32) | u.y, n_valid);
             }
-            v = reinterpret_cast<const float4*>(p.rows)[row * L::CH + ch];
+            v = reinterpret_cast<const float4*>(p.rows)[row * L::RCH + ch];
             if (publish) {
                 reinterpret_cast<float4*>(p.batch_out)[(size_t)(row0 + r) * L::CH + ch] = v;
                 if (p.idx_out && ch == 0) p.idx_out[row0 + r] = row;

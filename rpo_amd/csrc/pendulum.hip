@@ -41,7 +41,7 @@ __global__ __launch_bounds__(RPO_BLOCK) void pendulum_step_kernel(StepArgs p) {
         float4 row[4];
         pend_lane(p, i, s, a, rpo_load_episode(p.ep_len, p.ep_ret, p.ep_count, i), ns, ncs, nsn, row, st);
         if (p.rows) {
-            float4* gr = reinterpret_cast<float4*>(p.rows + (size_t)(ring_base + i) * RPO_PEND_ROW);
+            float4* gr = reinterpret_cast<float4*>(p.rows + (size_t)(ring_base + i) * RPO_PEND_RING);
 #pragma unroll
             for (int q = 0; q < 4; ++q) gr[q] = row[q];
         }

@@ -1,12 +1,13 @@
 // Replay ring sampling (rpo/utils/buffer.py:31-34) on MI355X: uniform-with-replacement index draw (Philox) fused
-// with the row gather.  Rows are 96 B (CartSafe) / 64 B (SpringPendulum) and 16-byte aligned; consecutive lanes copy
+// with the row gather.  Rows are 96 B (CartSafe, one per 128-byte line of the ring: RPO_CART_RING) / 64 B (SpringPendulum) and
+// 16-byte aligned; consecutive lanes copy
 // consecutive float4 chunks of a row, so every row is fetched with full 16 B/lane requests and the batch is written
 // fully coalesced.  HBM-bound: 2 * row bytes per sample (+8 B index).
 #include "common.h"
 
 namespace {
 
-__global__ __launch_bounds__(RPO_BLOCK) void replay_gather_kernel(const float4* __restrict__ rows, int chunks_per_row,
+__global__ __launch_bounds__(RPO_BLOCK) void replay_gather_kernel(const float4* __restrict__ rows, int ring_chunks, int chunks_per_row,
                                                                   long long total_chunks,
                                                                   const long long* __restrict__ idx,
                                                                   float4* __restrict__ out) {
@@ -14,12 +15,12 @@ __global__ __launch_bounds__(RPO_BLOCK) void replay_gather_kernel(const float4* 
          j += (long long)gridDim.x * RPO_BLOCK) {
         const long long b = j / chunks_per_row;
         const int c = (int)(j - b * chunks_per_row);
-        out[j] = rows[idx[b] * chunks_per_row + c];
+        out[j] = rows[idx[b] * ring_chunks + c];
     }
 }
 
 __global__ __launch_bounds__(RPO_BLOCK) void replay_sample_gather_kernel(
-    const float4* __restrict__ rows, int chunks_per_row, long long total_chunks, long long cap_steps, int n_envs,
+    const float4* __restrict__ rows, int ring_chunks, int chunks_per_row, long long total_chunks, long long cap_steps, int n_envs,
     float4* __restrict__ out, long long* __restrict__ idx_out, uint64_t seed, uint32_t salt,
     const long long* __restrict__ ctrl) {
     const long long t = ctrl[RPO_CTRL_T];
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(RPO_BLOCK) void replay_sample_gather_kernel(
         const rpo_u4 r = rpo_philox(seed, (uint32_t)b, (uint32_t)t + salt, RPO_STREAM_SAMPLE, (uint32_t)ctrl[RPO_CTRL_UPDATES]);
         const unsigned long long x = ((unsigned long long)r.x << 32) | r.y;
         const long long row = (long long)__umul64hi(x, n_valid);
-        out[j] = rows[row * chunks_per_row + c];
+        out[j] = rows[row * ring_chunks + c];
         if (idx_out && c == 0) idx_out[b] = row;
     }
 }
@@ -41,27 +42,29 @@ __global__ __launch_bounds__(RPO_BLOCK) void replay_sample_gather_kernel(
 
 extern "C" {
 
-int rpo_replay_gather(const float* rows, int row_floats, int batch, const long long* idx, float* batch_out,
+int rpo_replay_gather(const float* rows, int ring_floats, int row_floats, int batch, const long long* idx, float* batch_out,
                       void* stream) {
-    if (batch <= 0 || row_floats <= 0 || (row_floats & 3)) return RPO_ERR_ARG;
+    if (batch <= 0 || row_floats <= 0 || (row_floats & 3) || ring_floats < row_floats || (ring_floats & 3)) return RPO_ERR_ARG;
     if (!rows || !idx || !batch_out) return RPO_ERR_NULL;
     const int cpr = row_floats / 4;
     const long long total = (long long)batch * cpr;
     hipLaunchKernelGGL(replay_gather_kernel, dim3(rpo_grid_for(total)), dim3(RPO_BLOCK), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(rows), cpr, total, idx, reinterpret_cast<float4*>(batch_out));
+                       reinterpret_cast<const float4*>(rows), ring_floats / 4, cpr, total, idx, reinterpret_cast<float4*>(batch_out));
     RPO_LAUNCH_CHECK();
     return 0;
 }
 
-int rpo_replay_sample_gather(const float* rows, int row_floats, long long cap_steps, int n_envs, int batch,
+int rpo_replay_sample_gather(const float* rows, int ring_floats, int row_floats, long long cap_steps, int n_envs, int batch,
                              float* batch_out, long long* idx_out, unsigned long long seed, unsigned sample_salt,
                              const long long* ctrl, void* stream) {
-    if (batch <= 0 || row_floats <= 0 || (row_floats & 3) || cap_steps <= 0 || n_envs <= 0) return RPO_ERR_ARG;
+    if (batch <= 0 || row_floats <= 0 || (row_floats & 3) || ring_floats < row_floats || (ring_floats & 3) || cap_steps <= 0 ||
+        n_envs <= 0)
+        return RPO_ERR_ARG;
     if (!rows || !batch_out || !ctrl) return RPO_ERR_NULL;
     const int cpr = row_floats / 4;
     const long long total = (long long)batch * cpr;
     hipLaunchKernelGGL(replay_sample_gather_kernel, dim3(rpo_grid_for(total)), dim3(RPO_BLOCK), 0,
-                       (hipStream_t)stream, reinterpret_cast<const float4*>(rows), cpr, total, cap_steps, n_envs,
+                       (hipStream_t)stream, reinterpret_cast<const float4*>(rows), ring_floats / 4, cpr, total, cap_steps, n_envs,
                        reinterpret_cast<float4*>(batch_out), idx_out, (uint64_t)seed, (uint32_t)sample_salt, ctrl);
     RPO_LAUNCH_CHECK();
     return 0;

@@ -41,7 +41,7 @@ struct CartEnv {
         for (int q = 0; q < 6; ++q) s[q] = obs[q];
         rpo_cart_dev::cart_lane(p, c, i, s, a, ep, ns, row, st);
         if (p.rows) {
-            float4* gr = reinterpret_cast<float4*>(p.rows + (size_t)(ring_base + i) * RPO_CART_ROW);
+            float4* gr = reinterpret_cast<float4*>(p.rows + (size_t)(ring_base + i) * RPO_CART_RING);
 #pragma unroll
             for (int q = 0; q < 6; ++q) gr[q] = row[q];
         }
@@ -87,7 +87,7 @@ struct PendEnv {
         float4 row[4];
         rpo_pend_dev::pend_lane(p, i, s, a, ep, ns, ncs, nsn, row, st);
         if (p.rows) {
-            float4* gr = reinterpret_cast<float4*>(p.rows + (size_t)(ring_base + i) * RPO_PEND_ROW);
+            float4* gr = reinterpret_cast<float4*>(p.rows + (size_t)(ring_base + i) * RPO_PEND_RING);
 #pragma unroll
             for (int q = 0; q < 4; ++q) gr[q] = row[q];
         }

@@ -111,7 +111,7 @@ class HardConstraintEnv(gym.Env):
     def _single(self):
         if self._vec is None:
             self._vec = self.make_vec(1, seed=0 if self._np_seed is None else int(self._np_seed), stats_cap=2)
-            self._row = torch.zeros(1, self.kernels.row_floats, device=self.device)
+            self._row = torch.zeros(1, self.kernels.ring_floats, device=self.device)
         return self._vec
 
     def reset(self):

@@ -94,12 +94,14 @@ def philox_normal(out, seed, id_base, salt, stream_tag, ctrl=None):
 
 
 def replay_gather(rows, idx, out):
-    check(_lib.load().rpo_replay_gather(_p(rows), rows.shape[-1], idx.shape[0], _p(idx, torch.int64), _p(out),
+    check(_lib.load().rpo_replay_gather(_p(rows), rows.shape[-1], out.shape[-1], idx.shape[0], _p(idx, torch.int64), _p(out),
                                         _stream()), "rpo_replay_gather")
 
 
 def replay_sample_gather(rows, cap_steps, n_envs, out, idx_out, seed, salt, ctrl):
-    check(_lib.load().rpo_replay_sample_gather(_p(rows), rows.shape[-1], cap_steps, n_envs, out.shape[0], _p(out),
+    # rows: the ring [cap_steps * n_envs, ring_floats]; out: the batch [B, row_floats] (ring_floats >= row_floats: CartSafe rings
+    # keep one 96-byte transition per 128-byte line)
+    check(_lib.load().rpo_replay_sample_gather(_p(rows), rows.shape[-1], out.shape[-1], cap_steps, n_envs, out.shape[0], _p(out),
                                                _p(idx_out, torch.int64, allow_none=True), seed, salt,
                                                _p(ctrl, torch.int64), _stream()), "rpo_replay_sample_gather")
 
@@ -188,6 +190,7 @@ class CartSafeKernels(object):
     name = "CartSafe-v0"
     obs_dim, internal_dim, action_dim, eq_num, ineq_num, partial_dim = 6, 6, 2, 1, 6, 1
     row_floats = CONST["RPO_CART_ROW"]
+    ring_floats = CONST["RPO_CART_RING"]       # floats between consecutive rows of a replay ring (>= row_floats)
     # column ranges of a transition row
     cols = dict(state=(0, 6), action=(6, 8), next_state=(8, 14), reward=(14, 15), done=(15, 16), eq_viol=(16, 17),
                 ineq_viol=(17, 23))
@@ -289,7 +292,7 @@ class EvopfKernels(object):
     obs_dim = internal_dim = CONST["RPO_EVOPF_STATE"]
     action_dim, partial_dim = CONST["RPO_EVOPF_ACTION"], CONST["RPO_EVOPF_PARTIAL"]
     eq_num, ineq_num = CONST["RPO_EVOPF_EQ"], CONST["RPO_EVOPF_INEQ"]
-    row_floats = CONST["RPO_EVOPF_ROW"]
+    row_floats = ring_floats = CONST["RPO_EVOPF_ROW"]
     cols = dict(state=(0, 57), action=(57, 100), next_state=(100, 157), reward=(157, 158), done=(158, 159),
                 eq_viol=(159, 187), ineq_viol=(187, 245))
     newton_tol, newton_max_iters = 1e-5, 50          # PFFunction(env, tol=1e-5, bsz=256, max_iters=50), evopf.py:786
@@ -397,6 +400,7 @@ class PendulumKernels(object):
     name = "SpringPendulum-v0"
     obs_dim, internal_dim, action_dim, eq_num, ineq_num, partial_dim = 5, 4, 2, 1, 1, 1
     row_floats = CONST["RPO_PEND_ROW"]
+    ring_floats = CONST["RPO_PEND_RING"]
     cols = dict(state=(0, 5), action=(5, 7), next_state=(7, 12), reward=(12, 13), done=(13, 14), eq_viol=(14, 15),
                 ineq_viol=(15, 16))
     partial = 0

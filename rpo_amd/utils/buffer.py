@@ -1,8 +1,8 @@
 """Device replay ring with the reference's ``ReplayBuffer`` interface (rpo/utils/buffer.py:3-47).
 
 The reference keeps a dict of numpy arrays on the host and adds one transition per env step.  Here the transitions of
-N vectorised envs live in HBM as one row-major ring ``rows[cap_steps * n_envs, W]`` (W = 24 floats for CartSafe, 16
-for SpringPendulum; layout in include/rpo_hip.h).  The fused *_step kernels scatter a whole vector step into it and
+N vectorised envs live in HBM as one row-major ring ``rows[cap_steps * n_envs, W]`` (W = ring stride: 32 floats for CartSafe
+-- 24 of transition + 8 of padding, one 128-byte line per row --, 16 for SpringPendulum; layout in include/rpo_hip.h).  The fused *_step kernels scatter a whole vector step into it and
 ``sample`` draws + gathers a batch in one kernel.  ``capacity`` keeps the reference's meaning per env:
 each env's own history is a ring of ``capacity`` transitions, total rows = capacity * n_envs.
 """
@@ -22,7 +22,9 @@ class ReplayBuffer(object):
         self.device = device
         self.seed = int(seed)
         self._ops = ops
-        self.rows = torch.zeros(self.capacity * self.n_envs, kernels.row_floats, device=device)
+        # ring rows are kernels.ring_floats apart (CartSafe: 32 floats = one 128-byte line per 96-byte transition); the columns
+        # of a transition (kernels.cols) are its first kernels.row_floats floats
+        self.rows = torch.zeros(self.capacity * self.n_envs, getattr(kernels, "ring_floats", kernels.row_floats), device=device)
         # ctrl[0] = vector steps taken so far; owned by the step kernel, shared with the env state
         self.ctrl = ctrl if ctrl is not None else torch.zeros(hip_ops.CTRL_LEN, dtype=torch.int64, device=device)
         self._steps_host = 0                          # host mirror of ctrl[0] (no device sync needed)

@@ -70,7 +70,7 @@ class _EnvKernels(object):
             row[:, c["eq_viol"][0]:c["eq_viol"][1]] = eq
             row[:, c["ineq_viol"][0]:c["ineq_viol"][1]] = ineq
             base = (t % cap_steps) * n
-            rows[base:base + n] = torch.as_tensor(row)
+            rows[base:base + n, :self.row_floats] = torch.as_tensor(row)
         if stats is not None:
             cap = stats.shape[0]
             r = stats[t % cap, 0]                       # everything into sub-row 0 (the reader sums the sub-rows)
@@ -103,7 +103,7 @@ class _EnvKernels(object):
 class CartSafeKernels(_EnvKernels):
     name = "CartSafe-v0"
     obs_dim, internal_dim, action_dim, eq_num, ineq_num, partial_dim = 6, 6, 2, 1, 6, 1
-    row_floats = CONST["RPO_CART_ROW"]
+    row_floats, ring_floats = CONST["RPO_CART_ROW"], CONST["RPO_CART_RING"]
     cols = dict(state=(0, 6), action=(6, 8), next_state=(8, 14), reward=(14, 15), done=(15, 16), eq_viol=(16, 17),
                 ineq_viol=(17, 23))
 
@@ -168,7 +168,7 @@ class EvopfKernels(_EnvKernels):
     name = "EVOPF-v0"
     obs_dim = internal_dim = 57
     action_dim, partial_dim, eq_num, ineq_num = 43, 14, 28, 58
-    row_floats = CONST["RPO_EVOPF_ROW"]
+    row_floats = ring_floats = CONST["RPO_EVOPF_ROW"]
     cols = dict(state=(0, 57), action=(57, 100), next_state=(100, 157), reward=(157, 158), done=(158, 159),
                 eq_viol=(159, 187), ineq_viol=(187, 245))
     episode_steps = 24
@@ -308,7 +308,7 @@ class EvopfKernels(_EnvKernels):
 class PendulumKernels(_EnvKernels):
     name = "SpringPendulum-v0"
     obs_dim, internal_dim, action_dim, eq_num, ineq_num, partial_dim = 5, 4, 2, 1, 1, 1
-    row_floats = CONST["RPO_PEND_ROW"]
+    row_floats, ring_floats = CONST["RPO_PEND_ROW"], CONST["RPO_PEND_RING"]
     cols = dict(state=(0, 5), action=(5, 7), next_state=(7, 12), reward=(12, 13), done=(13, 14), eq_viol=(14, 15),
                 ineq_viol=(15, 16))
     partial = 0
@@ -391,13 +391,13 @@ def philox_normal(out, seed, id_base, salt, stream_tag, ctrl=None):
 def replay_sample_gather(rows, cap_steps, n_envs, out, idx_out, seed, salt, ctrl):
     t = int(ctrl[0])
     idx = philox.sample_indices(seed, out.shape[0], t, salt, min(t, cap_steps) * n_envs, int(ctrl[2]))
-    out.copy_(rows[torch.as_tensor(idx)])
+    out.copy_(rows[torch.as_tensor(idx)][:, :out.shape[1]])      # (ring rows may be wider than a transition: ring_floats)
     if idx_out is not None:
         _put(idx_out, idx)
 
 
 def replay_gather(rows, idx, out):
-    out.copy_(rows[idx])
+    out.copy_(rows[idx][:, :out.shape[1]])
 
 
 def td_huber(q1, q2, qn1, qn2, logp, alpha, reward, done, gamma, loss_out, grad_q1, grad_q2, target_out=None):

@@ -14,7 +14,7 @@ def test_header_parses():
     for must in ("rpo_cartsafe_step", "rpo_cartsafe_act_project", "rpo_pendulum_step", "rpo_replay_sample_gather",
                  "rpo_td_huber", "rpo_adam_step", "rpo_cartsafe_lagrangian", "rpo_abi_version"):
         assert must in protos
-    assert consts["RPO_CART_ROW"] == 24 and consts["RPO_PEND_ROW"] == 16 and consts["RPO_ERR_ARG"] == -1
+    assert consts["RPO_CART_ROW"] == 24 and consts["RPO_PEND_ROW"] == 16 and consts["RPO_CART_RING"] == 32 and consts["RPO_PEND_RING"] == 16 and consts["RPO_ERR_ARG"] == -1
     # spot-check the type mapping
     assert protos["rpo_polyak"] == [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]
 
@@ -38,7 +38,8 @@ def test_argument_validation_without_gpu():
     lib = _lib.load()
     assert lib.rpo_polyak(0, None, None, 0.5, None) == _lib.CONST["RPO_ERR_ARG"]
     assert lib.rpo_polyak(4, None, None, 0.5, None) == _lib.CONST["RPO_ERR_NULL"]
-    assert lib.rpo_replay_gather(None, 23, 4, None, None, None) == _lib.CONST["RPO_ERR_ARG"]   # row not 16-B multiple
+    assert lib.rpo_replay_gather(None, 32, 23, 4, None, None, None) == _lib.CONST["RPO_ERR_ARG"]   # row not 16-B multiple
+    assert lib.rpo_replay_gather(None, 16, 24, 4, None, None, None) == _lib.CONST["RPO_ERR_ARG"]   # ring stride < row
     with pytest.raises(_lib.RpoHipError):
         _lib.check(-1, "x")
 
@@ -90,4 +91,4 @@ def test_split_update_stages_validate_arguments():
     assert lib.rpo_xcc_probe(0, 16, 4, 256, None, None) == _lib.CONST["RPO_ERR_ARG"]
     for stage in ("critic_fwd_a_ride", "critic_fwd_b_ride", "critic_bwd_b_ride", "critic_front_ride", "critic_mid_ride", "critic_pfront_ride"):            # the riding rollout halves: both structs are required
         assert getattr(lib, "rpo_split_" + stage)(None, None, None) == _lib.CONST["RPO_ERR_NULL"]
-    assert _lib.CONST["RPO_ABI_VERSION"] == 3
+    assert _lib.CONST["RPO_ABI_VERSION"] == 4

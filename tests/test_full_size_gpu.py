@@ -369,8 +369,8 @@ def test_eight_way_rank_layout_is_invisible_in_the_lanes():
                   tr.corr_lr, tr.corr_eps, tr.corr_momentum, 200, True, 1e-3, v.seed, v.env_id_base)
     whole = VecEnv(k, n, DEV, seed=tr.seed, env_id_base=0, max_episode_steps=200)
     parts = [VecEnv(k, n // R, DEV, seed=tr.seed, env_id_base=r * (n // R), max_episode_steps=200) for r in range(R)]
-    rows_w = torch.zeros(cap * n, k.row_floats, device=DEV)
-    rows_p = [torch.zeros(cap * (n // R), k.row_floats, device=DEV) for _ in range(R)]
+    rows_w = torch.zeros(cap * n, k.ring_floats, device=DEV)
+    rows_p = [torch.zeros(cap * (n // R), k.ring_floats, device=DEV) for _ in range(R)]
     for v in [whole] + parts:
         v.reset()
     assert torch.equal(whole.internal, torch.cat([p.internal for p in parts]))

@@ -60,7 +60,7 @@ def test_cart_step_matches_reference(ops, golden, partial):
     state = dev(g["states"])
     action = dev(g["actions"])
     ep_len, ep_ret, ep_count = env_buffers(n)
-    rows = torch.zeros(n, 24, device=DEV)
+    rows = torch.zeros(n, k.ring_floats, device=DEV)          # ring stride 32: one 96-byte transition per 128-byte line
     stats = ops.new_stats(4, DEV)
     ctrl = torch.zeros(ops.CTRL_LEN, dtype=torch.int64, device=DEV)
     k.step(state, state, action, ep_len, ep_ret, ep_count, rows, 1, stats, ctrl, 200, False, 1e-3, 7, 0)
@@ -101,7 +101,7 @@ def test_cart_rollout_bookkeeping(ops):
     k = cart_kernels(ops, 1)
     state = torch.zeros(n, 6, device=DEV)
     ep_len, ep_ret, ep_count = env_buffers(n)
-    rows = torch.zeros(cap * n, 24, device=DEV)
+    rows = torch.zeros(cap * n, k.ring_floats, device=DEV)
     stats = ops.new_stats(16, DEV)
     ctrl = torch.zeros(ops.CTRL_LEN, dtype=torch.int64, device=DEV)
     k.reset(state, state, ep_len, ep_ret, ep_count, seed, base)
@@ -142,7 +142,8 @@ def test_cart_rollout_bookkeeping(ops):
         np.testing.assert_array_equal(ep_count.cpu().numpy(), o_cnt)
     assert int(ctrl[0]) == T
     assert o_cnt.sum() > n            # resets through both the termination test and the TimeLimit happened
-    np.testing.assert_allclose(rows.cpu().numpy(), ring, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(rows.cpu().numpy()[:, :24], ring, rtol=1e-4, atol=1e-4)
+    assert float(rows[:, 24:].abs().max()) == 0.0                # the padding of the 128-byte ring rows stays zero
     np.testing.assert_array_equal(stats[T].cpu().numpy(), 0)      # next row pre-cleared by the last launch
 
 
@@ -423,12 +424,14 @@ def test_pendulum_constraint_kernels(ops, golden):
 
 # ------------------------------------------------------------------------------------------------ replay ring
 
-@pytest.mark.parametrize("row_floats", [24, 16])
-def test_replay_gather_and_sample(ops, row_floats):
+@pytest.mark.parametrize("row_floats,ring_floats", [(24, 32), (24, 24), (16, 16)])
+def test_replay_gather_and_sample(ops, row_floats, ring_floats):
+    """(24, 32) = CartSafe: a 96-byte transition per 128-byte line of the ring, gathered into 24-float batch rows."""
     rng = np.random.RandomState(3)
     n_envs, cap = 257, 5
-    rows_np = rng.randn(cap * n_envs, row_floats).astype(np.float32)
-    rows = dev(rows_np)
+    ring_np = rng.randn(cap * n_envs, ring_floats).astype(np.float32)
+    rows_np = ring_np[:, :row_floats]
+    rows = dev(ring_np)
     idx = rng.randint(0, cap * n_envs, size=1000)
     out = torch.zeros(1000, row_floats, device=DEV)
     ops.replay_gather(rows, dev(idx, torch.int64), out)
@@ -579,7 +582,7 @@ def test_cart_full_size_properties(ops):
     def rollout(splits):
         state = torch.zeros(n, 6, device=DEV)
         ep_len, ep_ret, ep_count = env_buffers(n)
-        rows = torch.zeros(cap * n, 24, device=DEV)
+        rows = torch.zeros(cap * n, k.ring_floats, device=DEV)
         ctrls = [torch.zeros(ops.CTRL_LEN, dtype=torch.int64, device=DEV) for _ in splits]
         for (lo, hi) in splits:
             k.reset(state[lo:hi], state[lo:hi], ep_len[lo:hi], ep_ret[lo:hi], ep_count[lo:hi], 5, lo)

@@ -192,7 +192,7 @@ def run_product_update(golden, algo, envname, backend, device, fused=True):
         np.testing.assert_array_equal(like(g, ag.actor.state_dict()[k]), v)
     for k, v in sd(g, "critic0").items():
         np.testing.assert_array_equal(like(g, ag.critic.state_dict()[k]), v)
-    rows = torch.tensor(buffer_rows(g, tr.kernels.cols, tr.kernels.row_floats)).to(device)
+    rows = torch.tensor(buffer_rows(g, tr.kernels.cols, tr.kernels.ring_floats)).to(device)   # (ring stride >= transition width)
     proxy = ReplayDraws(backend, g, rows, device)
     tr.backend = tr.buffer._ops = proxy
     tr.buffer.rows = rows                                      # fused pipelines sample from the ring directly ...

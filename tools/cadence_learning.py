@@ -33,7 +33,7 @@ def lane_statistics(tr, steps, chunk=100):
     """Per-lane Logger statistics from the replay ring of a finished run -> (dict of seed-level means, curves per `chunk`)."""
     k, n = tr.kernels, tr.n_local
     c = k.cols
-    rows = tr.buffer.rows[: steps * n].view(steps, n, k.row_floats)
+    rows = tr.buffer.rows[: steps * n].view(steps, n, -1)
     r = rows[:, :, c["reward"][0]].double()
     done = rows[:, :, c["done"][0]] > 0.5
     eq = rows[:, :, c["eq_viol"][0]:c["eq_viol"][1]].abs().amax(dim=2)

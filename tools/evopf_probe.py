@@ -23,7 +23,7 @@ def main():
     lo, hi = env.update(v.obs)
     ap = (lo + 0.5 * (hi - lo)).contiguous()
     ap[:, 4:9] = 1.07                                   # violated bounds: the projection runs all its iterations
-    rows = torch.zeros(8 * n, k.row_floats, device="cuda")
+    rows = torch.zeros(8 * n, k.ring_floats, device="cuda")
     it = torch.zeros(n, dtype=torch.int32, device="cuda")
     out = {}
 

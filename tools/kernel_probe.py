@@ -22,7 +22,7 @@ def probe_step(reps=5):
     for n in (4096, 1 << 20):
         v = VecEnv(k, n, torch.device("cuda"), seed=3, stats_cap=64)
         v.reset()
-        rows = torch.zeros(8 * n, k.row_floats, device="cuda")
+        rows = torch.zeros(8 * n, k.ring_floats, device="cuda")
         ap = torch.zeros(n, device="cuda")
         batch = torch.zeros(n if n > 4096 else 256, k.row_floats, device="cuda")
         for _ in range(reps):
