@@ -75,21 +75,28 @@ __device__ __forceinline__ f32x4 gemm_mfma_chunk(const float (&b)[CH][4], const 
     return acc;
 }
 
+// chunks [c0, c1) of the k range (the whole range: 0, ceil(K / (16 CH)))
 template <bool W_NK, bool VEC, int CH>
-__device__ __forceinline__ f32x4 gemm_chain(const float* a_s, int ldk, const float* __restrict__ W, int ldw, int K, int N, int n, int li,
-                                            int lg, f32x4 acc) {
-    const int chunks = (K + 16 * CH - 1) / (16 * CH), nc = n < N ? n : N - 1;
+__device__ __forceinline__ f32x4 gemm_chain_range(const float* a_s, int ldk, const float* __restrict__ W, int ldw, int K, int N, int n,
+                                                  int li, int lg, f32x4 acc, int c0, int c1) {
+    const int nc = n < N ? n : N - 1;
     float b0[CH][4], b1[CH][4];
-    gemm_load_chunk<W_NK, VEC, CH>(b0, W, ldw, K, nc, 0, lg);
-    for (int c = 0; c < chunks; c += 2) {                         // (columns n >= N compute garbage that is never stored)
-        if (c + 1 < chunks) gemm_load_chunk<W_NK, VEC, CH>(b1, W, ldw, K, nc, c + 1, lg);
+    if (c0 < c1) gemm_load_chunk<W_NK, VEC, CH>(b0, W, ldw, K, nc, c0, lg);
+    for (int c = c0; c < c1; c += 2) {                            // (columns n >= N compute garbage that is never stored)
+        if (c + 1 < c1) gemm_load_chunk<W_NK, VEC, CH>(b1, W, ldw, K, nc, c + 1, lg);
         acc = gemm_mfma_chunk<CH>(b0, a_s, ldk, c, li, lg, acc);
-        if (c + 1 < chunks) {
-            if (c + 2 < chunks) gemm_load_chunk<W_NK, VEC, CH>(b0, W, ldw, K, nc, c + 2, lg);
+        if (c + 1 < c1) {
+            if (c + 2 < c1) gemm_load_chunk<W_NK, VEC, CH>(b0, W, ldw, K, nc, c + 2, lg);
             acc = gemm_mfma_chunk<CH>(b1, a_s, ldk, c + 1, li, lg, acc);
         }
     }
     return acc;
+}
+
+template <bool W_NK, bool VEC, int CH>
+__device__ __forceinline__ f32x4 gemm_chain(const float* a_s, int ldk, const float* __restrict__ W, int ldw, int K, int N, int n, int li,
+                                            int lg, f32x4 acc) {
+    return gemm_chain_range<W_NK, VEC, CH>(a_s, ldk, W, ldw, K, N, n, li, lg, acc, 0, (K + 16 * CH - 1) / (16 * CH));
 }
 
 // The 16 rows of an A operand into LDS, zero-padded to `kw` columns (a multiple of 16 CH).  Eight loads per thread are in
@@ -203,6 +210,63 @@ __global__ __launch_bounds__(kGemmThreads) void mlp_gemm_kernel(GemmArgs4 all, i
     }
 }
 
+// The k range split over the four waves of a workgroup (round 4).  A 16 x 16 output tile is an ORDERED chain of K / 4 MFMA steps
+// on one SIMD -- 3.4 us for K = 256, 6.8 us for the concatenating critic's K = 512 -- and that chain, not a launch fee, is what
+// the hidden-layer / head / dx0 launches of the EVOPF windows cost (5-9 us each, seven of them on the critical path of an
+// iteration).  Here a workgroup owns ONE column tile and its waves take a quarter of the k chunks each (chunks of 64); the four
+// partial tiles meet in LDS and wave 0 adds them in the fixed order ((q0 + q1) + q2) + q3 and runs the epilogue: a quarter of
+// the chain, four times the workgroups (the chip is a quarter full otherwise), bitwise reproducible, OTHER summation order than
+// the one-chain kernel (float32 round-off; the comparisons with torch hold at the same tolerances).  Problems without a second
+// operand pair and without the TD prologue, K >= 256.
+template <bool W_NK>
+__global__ __launch_bounds__(kGemmThreads) void mlp_gemm_ksplit_kernel(GemmArgs4 all, int vec_a, int vec_w) {
+    const GemmArgs& p = all.g[blockIdx.z];
+    __builtin_amdgcn_s_setprio(2);
+    extern __shared__ __attribute__((aligned(16))) float a_s[];   // [16][ldk] | partial tiles [4][64] x f32x4
+    constexpr int CH = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int m0 = blockIdx.y * kRows, n = blockIdx.x * 16 + li;
+    if ((int)blockIdx.x * 16 >= p.N) return;
+    const int kw = (p.K + 16 * CH - 1) / (16 * CH) * (16 * CH), ldk = kw + 4;
+    f32x4* red = reinterpret_cast<f32x4*>(a_s + kRows * ldk);
+    gemm_stage(a_s, ldk, kw, p.A, p.lda, p.K, m0, p.M, p.relu_a != 0, vec_a != 0);
+    const int nc = n < p.N ? n : p.N - 1;
+    const float bv = (p.bias ? p.bias[nc] : 0.0f) + (p.bias2 ? p.bias2[nc] : 0.0f);
+    float mk[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    if (p.mask && wave == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + lg * 4 + i, mc = m < p.M ? m : p.M - 1;
+            mk[i] = p.mask[(size_t)mc * p.ldmask + nc];
+        }
+    }
+    __syncthreads();
+    const int chunks = kw / (16 * CH), per = (chunks + 3) / 4, c0 = wave * per, c1 = c0 + per < chunks ? c0 + per : chunks;
+    f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (W_NK && vec_w) acc = gemm_chain_range<W_NK, W_NK, CH>(a_s, ldk, p.W, p.ldw, p.K, p.N, n, li, lg, acc, c0, c1);
+    else acc = gemm_chain_range<W_NK, false, CH>(a_s, ldk, p.W, p.ldw, p.K, p.N, n, li, lg, acc, c0, c1);
+    red[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (wave != 0) return;
+    acc = ((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane];
+    if (n < p.N) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + lg * 4 + i;
+            if (m < p.M) {
+                float v = acc[i] + bv;
+                if (p.mask && !(mk[i] > 0.0f)) v = 0.0f;
+                p.C[(size_t)m * p.ldc + n] = v;
+            }
+        }
+    }
+}
+
+static inline bool gemm_ksplit_enabled() {
+    const char* e = getenv("RPO_GEMM_KSPLIT");
+    return !(e && e[0] == '0');
+}
+
 template <bool W_NK>
 static inline int gemm_launch(const GemmArgs* g, int count, hipStream_t stream) {
     if (count < 1 || count > kGemmProblems) return RPO_ERR_ARG;
@@ -218,6 +282,19 @@ static inline int gemm_launch(const GemmArgs* g, int count, hipStream_t stream) 
         if (g[i].A2 && g[i].K2 > maxK) maxK = g[i].K2;
         vec_a = vec_a && (g[i].lda & 3) == 0 && (g[i].K & 3) == 0 && (reinterpret_cast<uintptr_t>(g[i].A) & 15u) == 0;
         vec_w = vec_w && (g[i].ldw & 3) == 0 && (g[i].K & 15) == 0 && (reinterpret_cast<uintptr_t>(g[i].W) & 15u) == 0;
+    }
+    bool ksplit = gemm_ksplit_enabled();
+    for (int i = 0; i < count; ++i) ksplit = ksplit && g[i].K >= 256 && !g[i].A2 && !g[i].td.q;
+    if (ksplit) {
+        size_t lds = 0;
+        for (int i = 0; i < count; ++i) {
+            const size_t l = (size_t)kRows * ((g[i].K + 63) / 64 * 64 + 4) * sizeof(float) + 4 * 64 * sizeof(f32x4);
+            lds = l > lds ? l : lds;
+        }
+        const dim3 grid((maxN + 15) / 16, (maxM + kRows - 1) / kRows, count);
+        hipLaunchKernelGGL((mlp_gemm_ksplit_kernel<W_NK>), grid, dim3(kGemmThreads), lds, stream, all, (int)vec_a, (int)vec_w);
+        RPO_LAUNCH_CHECK();
+        return 0;
     }
     const int ch = maxK <= 16 ? 1 : maxK <= 64 ? 4 : 8;
     size_t lds = 0;
@@ -236,101 +313,10 @@ static inline int gemm_launch(const GemmArgs* g, int count, hipStream_t stream) 
 
 struct GemmFwd { Mlp net; int n; const float* s; int s_stride; const float* a; int a_stride; float* out; float* x0; float* h1; };
 
-// First layer INSIDE the hidden layer's launch (round 4).  A forward was three launches (first layer | hidden | heads) of 5-9 us
-// each in the EVOPF windows, where a launch costs what it contains plus ~4 us: here every workgroup of the hidden layer's grid
-// (16 rows x 64 columns) first forms the x0 tile of its 16 rows itself -- [s Ws^T + bs | a Wa^T + ba], K <= 64 inputs per half,
-// ein / 16 tiles of 16 x 16 over its four waves, the same ordered MFMA chain as the first-layer launch (same bits) -- straight
-// into the LDS tile the hidden layer reads (relu applied on the way, like gemm_stage does); the column-block-0 workgroup of
-// each row tile also stores the pre-activations for the backward.  Four-fold redundant arithmetic on 16 x 57 inputs, one
-// launch and one trip of x0 through memory less on the chain.
-struct GemmL01Args {
-    GemmArgs main;                             // the hidden layer: A = x0 (not read), K = ein, W = W0, C = h1
-    const float* X[2]; int ldx[2]; int KX[2];  // inputs of the (up to two) halves of x0: state | action of a "cat" network
-    const float* WX[2]; const float* bX[2];    // their [E][KX] matrices and biases
-    int halves, E;
-    float* x0;                                 // [M][ein] pre-activations (saved for the backward), ein = halves * E
-};
-struct GemmL01Args4 { GemmL01Args g[4]; };
-constexpr int kL01In = 64, kL01Ld = kL01In + 4;
-
-__global__ __launch_bounds__(kGemmThreads) void mlp_gemm_l01_kernel(GemmL01Args4 all, int vec_w) {
-    const GemmL01Args& q = all.g[blockIdx.z];
-    const GemmArgs& p = q.main;
-    __builtin_amdgcn_s_setprio(2);
-    extern __shared__ __attribute__((aligned(16))) float a_s[];   // [16][ldk] | [2][16][kL01Ld]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    const int m0 = blockIdx.y * kRows, n = (blockIdx.x * 4 + wave) * 16 + li;
-    if ((int)blockIdx.x * kGemmCols >= p.N) return;
-    constexpr int CH = 8;
-    const int ein = q.halves * q.E, kw = (ein + 16 * CH - 1) / (16 * CH) * (16 * CH), ldk = kw + 4;
-    float* in_s = a_s + kRows * ldk;
-    for (int h = 0; h < q.halves; ++h)
-        gemm_stage(in_s + h * kRows * kL01Ld, kL01Ld, kL01In, q.X[h], q.ldx[h], q.KX[h], m0, p.M, false, false);
-    const int nc = n < p.N ? n : p.N - 1;
-    const float bv = (p.bias ? p.bias[nc] : 0.0f) + (p.bias2 ? p.bias2[nc] : 0.0f);
-    __syncthreads();
-    for (int t = wave; t * 16 < kw; t += 4) {                     // x0 tile t of the row tile: columns [16 t, 16 t + 16)
-        const int col = t * 16 + li, h = col / q.E, ch = col - h * q.E;
-        f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        float b1 = 0.0f;
-        if (t * 16 < ein) {                                       // (wave-uniform: E is a multiple of 16)
-            acc = gemm_chain<true, false, 4>(in_s + h * kRows * kL01Ld, kL01Ld, q.WX[h], q.KX[h], q.KX[h], q.E, ch, li, lg, acc);
-            b1 = (q.bX[h] ? q.bX[h][ch] : 0.0f) + 0.0f;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = lg * 4 + i;
-            const float v = acc[i] + b1;
-            const bool live = m0 + m < p.M && col < ein;
-            if (live && blockIdx.x == 0) q.x0[(size_t)(m0 + m) * ein + col] = v;
-            a_s[m * ldk + col] = live ? fmaxf(v, 0.0f) : 0.0f;
-        }
-    }
-    __syncthreads();
-    f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (vec_w) acc = gemm_chain<true, true, CH>(a_s, ldk, p.W, p.ldw, p.K, p.N, n, li, lg, acc);
-    else acc = gemm_chain<true, false, CH>(a_s, ldk, p.W, p.ldw, p.K, p.N, n, li, lg, acc);
-    if (n < p.N) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + lg * 4 + i;
-            if (m < p.M) p.C[(size_t)m * p.ldc + n] = acc[i] + bv;
-        }
-    }
-}
-
-// MEASURED AND NOT KEPT AS THE DEFAULT (round 4): EVOPF-DDPG 4.99 M env-steps/s with the three launches, 4.74 M with this one
-// (EVOPF-SAC 4.47 -> 4.14 M): the first layer as a launch of its own spreads its tiles over 64-128 workgroups, one tile per
-// wave; here every wave walks 4-8 tiles one after the other (each a chain of dependent L2 round trips for the 57-wide
-// weight rows) in front of the hidden layer's chain -- a launch in these windows costs what it contains, not a fixed fee.
-// RPO_MLP_FUSE01=1 selects it (the bit-equality test does).
-static inline bool gemm_l01_enabled() {
-    const char* e = getenv("RPO_MLP_FUSE01");
-    return e && e[0] == '1';
-}
-
-// first + hidden layer of `count` (<= 4) same-shaped networks in one launch; `g2` = their hidden-layer problems
-static inline int gemm_launch_l01(const GemmFwd* f, const GemmArgs* g2, int count, hipStream_t stream) {
-    GemmL01Args4 all{};
-    const Mlp& n0 = f[0].net;
-    const int halves = n0.cat ? 2 : 1, ein = halves * n0.E;
-    bool vec_w = true;
-    for (int i = 0; i < count; ++i) {
-        const Mlp& net = f[i].net;
-        GemmL01Args& a = all.g[i];
-        a.main = g2[i];
-        a.X[0] = f[i].s; a.ldx[0] = f[i].s_stride; a.KX[0] = net.S; a.WX[0] = net.Ws; a.bX[0] = net.bs;
-        a.X[1] = f[i].a; a.ldx[1] = f[i].a_stride; a.KX[1] = net.A; a.WX[1] = net.Wa; a.bX[1] = net.ba;
-        a.halves = halves; a.E = net.E; a.x0 = f[i].x0;
-        vec_w = vec_w && (g2[i].ldw & 3) == 0 && (g2[i].K & 15) == 0 && (reinterpret_cast<uintptr_t>(g2[i].W) & 15u) == 0;
-    }
-    const int kw = (ein + 127) / 128 * 128;
-    const size_t lds = (size_t)kRows * (kw + 4) * sizeof(float) + (size_t)halves * kRows * kL01Ld * sizeof(float);
-    const dim3 grid((n0.H + kGemmCols - 1) / kGemmCols, (f[0].n + kRows - 1) / kRows, count);
-    hipLaunchKernelGGL(mlp_gemm_l01_kernel, grid, dim3(kGemmThreads), lds, stream, all, (int)vec_w);
-    RPO_LAUNCH_CHECK();
-    return 0;
-}
+// (Round 4 also built the first layer INSIDE the hidden layer's launch -- every workgroup forming the x0 tile of its 16 rows
+// itself, bit-equal -- and measured it slower in the EVOPF windows, 4.99 -> 4.74 M env-steps/s: the separate first-layer launch
+// spreads its tiles over 64-128 workgroups, fused every wave walks 4-8 of them in front of the hidden layer's chain.  Removed;
+// DESIGN.md 4b, commit "mlp_gemm: first layer inside the hidden layer's launch".)
 
 // The layer-by-layer path applies to the wide networks at update-batch sizes when the caller provides x0 / h1 buffers
 // (RPO_MLP_GEMM=0 keeps the row-tile kernels: the A/B switch of the tests).
@@ -347,7 +333,7 @@ static inline bool gemm_fits(const Mlp& net, int count) {
     return count <= 4 && count * (net.cat ? 2 : 1) <= kGemmProblems && count * (net.n_out > 1 ? 2 : 1) <= kGemmProblems;
 }
 
-// forward of `count` same-shaped networks: two launches (first + hidden layer | heads), or three (RPO_MLP_FUSE01=0)
+// forward of `count` same-shaped networks: three launches (first layer | hidden layer | heads)
 
 static inline int gemm_forward(const GemmFwd* f, int count, hipStream_t stream) {
     GemmArgs g1[4], g1b[4], g2[4], g3[4], g3b[4];
@@ -384,14 +370,8 @@ static inline int gemm_forward(const GemmFwd* f, int count, hipStream_t stream) 
     if (!gemm_fits(n0, count)) return RPO_ERR_ARG;
     for (int i = 0; i < count; ++i) { l1[c1++] = g1[i]; if (n0.cat) l1[c1++] = g1b[i]; }
     for (int i = 0; i < count; ++i) { l3[c3++] = g3[i]; if (n0.n_out > 1) l3[c3++] = g3b[i]; }
-    // "add" networks (state and action embeddings summed into one x0) keep the separate first-layer launch
-    const bool l01 = gemm_l01_enabled() && n0.S <= kL01In && n0.A <= kL01In && (n0.cat || n0.A == 0) && n0.E % 16 == 0;
-    if (l01) {
-        if (int e = gemm_launch_l01(f, g2, count, stream)) return e;
-    } else {
-        if (int e = gemm_launch<true>(l1, c1, stream)) return e;
-        if (int e = gemm_launch<true>(g2, count, stream)) return e;
-    }
+    if (int e = gemm_launch<true>(l1, c1, stream)) return e;
+    if (int e = gemm_launch<true>(g2, count, stream)) return e;
     return gemm_launch<true>(l3, c3, stream);
 }
 
