@@ -4,11 +4,11 @@
 #   3. tools/collect_profiles.sh (rocprofv3 kernel stats / timelines of the bench commands, PMC traffic passes).
 # Everything lands in gpurun_out/evidence_rNN/; copy what is to be judged into profiles/.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 OUT=$PWD/gpurun_out/evidence_$R
 mkdir -p $OUT
 export RPO_VERBOSE=0
-timeout 1500 python3 -m pytest tests -q -m gpu > $OUT/pytest_gpu.log 2>&1
+timeout 2700 python3 -m pytest tests -q -m gpu > $OUT/pytest_gpu.log 2>&1
 tail -1 $OUT/pytest_gpu.log
 timeout 900 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 600 python3 bench.py --steps 20 --warmup 5 --no-extras --no-clinic --no-cpu-baseline > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err
