@@ -44,7 +44,7 @@ __device__ constexpr int kPartialActions[NP] = {1, 2, 3, 4, 10, 11, 12, 15, 17, 
 // k is taken only the columns in which its row can be non-zero (case14's 20 branches + fill-in, kLive* below, evaluated by
 // the compiler from the adjacency masks) are updated -- 154 instead of 561 (broadcast, fma) pairs for the 28 x 43 system of the
 // GRG direction, 97 instead of 253 for Newton's 22 x 23.  The order minimises that count (simulated annealing over the 13!
-// bus orders, tools/evopf_order.py: generator buses last keeps the J_partial columns sparse longest; minimum degree: 233).
+// bus orders, tests/evopf_order.py: generator buses last keeps the J_partial columns sparse longest; minimum degree: 233).
 // Accuracy: on 1500 sampled Jacobians (solved states, GRG-like and gross perturbations, Newton's flat start) the static order's
 // inverse is as close to the float64 one as partial pivoting's (median 1.5e-7, same p99) whenever min|pivot| / max|pivot| >
 // 2^-6; below that (gross perturbations only: near-singular Jacobians) the wave falls back to the partial-pivoting elimination

@@ -1,6 +1,6 @@
 import os, sys, json
 import numpy as np, torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 os.environ["RPO_VERBOSE"] = "0"
 from rpo_amd.algo import RPOSAC
 from rpo_amd.env import EVOPFEnv
@@ -24,7 +24,7 @@ for seed in range(48):
         row = tr.buffer.rows[t].cpu().numpy()
         s, a = row[c["state"][0]:c["state"][1]], row[c["action"][0]:c["action"][1]]
         found.append((seed, t, s, a))
-        np.savez("/root/repo/gpurun_out/diag_sac_%d.npz" % seed, s=s, a=a, eq=row[c["eq_viol"][0]:c["eq_viol"][1]])
+        np.savez("gpurun_out/diag_sac_%d.npz" % seed, s=s, a=a, eq=row[c["eq_viol"][0]:c["eq_viol"][1]])
     del tr
 G = oe.GRID
 env = EVOPFEnv(device="cuda")

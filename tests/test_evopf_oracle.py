@@ -262,7 +262,7 @@ def test_recorded_newton_divergence_is_a_property_of_the_input():
     basic action had the generator voltages at the lower edge of their box with almost no generation.  The float64 oracle
     (numpy LAPACK solves, partial pivoting) does not converge on that input either -- PFFunction's Newton iteration
     (evopf.py:819-835) simply has no solution to find from the flat start -- so the event is not an artefact of the kernels'
-    float32 static-order elimination (tools/diag_evopf_sac.py: static and pivoted kernels both return garbage there)."""
+    float32 static-order elimination (tests/diag_evopf_sac.py: static and pivoted kernels both return garbage there)."""
     fx = golden("evopf_newton_divergence")
     s = fx["s"][None].astype(np.float64)
     ap = fx["a"][None].astype(np.float64)[:, G.partial_actions]
