@@ -9,8 +9,12 @@
 // lane) keys, the pivot row is broadcast with v_readlane (lane index in an SGPR), rows are never swapped -- every
 // thread just remembers which unknown its row ended up solving -- and only the small result vectors go through LDS.
 // History: eliminating in LDS cost 60 us per GRG iteration (dependent LDS round trips); one COLUMN per
-// thread 16 us (the serial pivot search and the predicated row swaps ran in every thread); one ROW per thread: see
-// tools/evopf_probe.py.  Workgroup = 1 wave, so the barriers below only order LDS traffic of that wave.
+// thread 16 us (the serial pivot search and the predicated row swaps ran in every thread); one ROW per thread with a DPP
+// pivot search 8.6 us (round 3); round 4: a STATIC elimination order with case14's sparsity compiled in (no search, 154
+// instead of 561 row-update pairs; partial pivoting remains as the fallback of a pivot-ratio test) and the whole iteration in
+// registers / wave-uniform values ("v2" at the end of this file): 3.4 us -- see tools/evopf_probe.py.  The v1 helpers (flows,
+// eq_resid, ineq_resid through LDS; gauss_jordan_rows) still serve the step / residual kernels, PFFunction.backward and the
+// fallback.  Workgroup = 4 waves = 4 env lanes, a workspace each: the barriers below only order LDS traffic of one wave.
 //
 // The network is the IEEE 14-bus case exactly like the reference (case14 hard-wired at evopf.py:211, eq_num = 28 and
 // ineq_num = 58 hard-coded at :336-337): the bus classification is compiled in, every number (admittances, limits, costs,
@@ -105,11 +109,9 @@ struct PatNewton {    // [J_newton | g]
 struct PatNewtonT {   // [J_newton^T | rhs] (PFFunction.backward)
     __host__ __device__ constexpr bool operator()(int r, int c) const { return c == NN || jac_struct(kKeep[c], kNewtonVars[r]); }
 };
-__device__ constexpr LiveTab<NEQ, NY> kLiveGrg = symbolic_gj<NEQ, NY, 6>(PatGrg{});
 __device__ constexpr LiveTab<NN, NN + 1> kLiveNewton = symbolic_gj<NN, NN + 1, 0>(PatNewton{});
 __device__ constexpr LiveTab<NN, NN + 1> kLiveNewtonT = symbolic_gj<NN, NN + 1, 0>(PatNewtonT{});
 __device__ constexpr LiveTab<NEQ, NY> kLiveGrg0 = symbolic_gj<NEQ, NY, 0>(PatGrg{});   // incl. the six unit pivots (v2's extra row)
-struct TabGrg { static __device__ constexpr bool live(int k, int c) { return kLiveGrg.v[k][c]; } };
 struct TabGrg0 { static __device__ constexpr bool live(int k, int c) { return kLiveGrg0.v[k][c]; } };
 struct TabNewton { static __device__ constexpr bool live(int k, int c) { return kLiveNewton.v[k][c]; } };
 struct TabNewtonT { static __device__ constexpr bool live(int k, int c) { return kLiveNewtonT.v[k][c]; } };
@@ -417,170 +419,10 @@ __device__ __forceinline__ bool pivots_ok(float mypiv) {
     return __builtin_amdgcn_ballot_w64(fine) == ~0ull;
 }
 
-// complete_partial (PFFunction.forward, evopf.py:789-855) for the lane in w.s with basic actions z[14] (registers of
-// threads 0..13 hold z[tid] in `zj`): Newton on (vm_pq, va_pv, va_pq) with the lane's own stop test, then qg and the
-// slack generation from the remaining equations.  Leaves flows()/eq of the completed action current.
-__device__ __forceinline__ int complete_partial(Ws& w, float zj, float tol, int max_iters) {
-    const int tid = lane_id();
-    if (tid < NY) {
-        float v = 0.0f;                                        // qg and the slack pg start at zero (:806-807)
-        if (tid >= VM0 && tid < VA0) v = w.c[RPO_EVOPF_C_VM_INIT + tid - VM0];       // load-bus guesses (:802)
-        else if (tid >= VA0 && tid < PE0) v = w.c[RPO_EVOPF_C_VA_INIT + tid - VA0];  // (:798,803-805)
-        w.a[tid] = v;
-    }
-    sync();
-    if (tid < NP) w.a[kPartialActions[tid]] = zj;              // (:796-799)
-    sync();
-    int it = 0;
-    const YVec yc = y_column(w, tid < NB ? tid : 0);           // (w.c is set: load_consts + sync happened before)
-    const YVec yk = y_row(w, (kKeep[tid < NN ? tid : 0]) % NB);
-    for (; it < max_iters;) {
-        flows(w, yc);
-        eq_resid(w);
-        const bool force_dyn = w.c[RPO_EVOPF_C_FLAGS] != 0.0f;
-        bool solved = false;
-        if (!force_dyn) {                                      // static order (sparse), accepted by its pivots
-            float row[NN + 1];                                 // row tid of [J_newton | g]
-            const RowCoef rc = row_coef(w, kKeep[tid < NN ? tid : 0]);
-#pragma unroll
-            for (int c = 0; c < NN; ++c) row[c] = tid < NN ? jac_row_entry(w, rc, kNewtonVars[c], yk) : 0.0f;
-            row[NN] = tid < NN ? w.eq[kKeep[tid]] : 0.0f;
-            const float mypiv = gauss_jordan_static<NN, NN + 1, 0, TabNewton>(row);
-            solved = pivots_ok<NN, 0>(mypiv);
-            if (solved && tid < NN) w.vec[tid] = row[NN] / mypiv;     // delta = inv(J) g (:832)
-        }
-        if (!solved) {                                         // partial pivoting (near-singular Jacobians, or forced)
-            float row[NN + 1];
-            const RowCoef rc = row_coef(w, kKeep[tid < NN ? tid : 0]);
-#pragma unroll
-            for (int c = 0; c < NN; ++c) row[c] = tid < NN ? jac_row_entry(w, rc, kNewtonVars[c], yk) : 0.0f;
-            row[NN] = tid < NN ? w.eq[kKeep[tid]] : 0.0f;
-            int mycol;
-            float mypiv;
-            gauss_jordan_rows<NN, NN + 1, 0>(row, mycol, mypiv);
-            if (tid < NN) w.vec[mycol] = row[NN] / mypiv;
-        }
-        sync();
-        float d2 = 0.0f;
-        if (tid < NN) {
-            const float d = w.vec[tid];
-            w.a[kNewtonVars[tid]] -= d;
-            d2 = d * d;
-        }
-        sync();
-        ++it;
-        if (sqrtf(rpo_wave_sum(d2)) < tol) break;              // torch.norm(delta) < tol (:834), this lane only
-    }
-    flows(w, yc);
-    eq_resid(w);                                               // with qg = 0 and slack pg = 0
-    if (tid < NG) w.a[QG0 + tid] = -w.eq[NB + kSpv[tid]];      // (:844-845)
-    if (tid == 0) w.a[PG0] = -w.eq[0];                         // (:847-848)
-    sync();
-    eq_resid(w);
-    return it;
-}
-
-// ineq_partial_grad (evopf.py:596-612) of (w.s, w.a) into w.dir[43]; flows() must be current.
-__device__ __forceinline__ void ineq_partial_grad(Ws& w, const YVec& yrow) {   // yrow = y_row(w, bus of equation kRowOrder[tid])
-    const int tid = lane_id();
-    // thread r owns equation kRowOrder[r] of [J_other | J_partial]
-    ineq_resid(w);                                             // (syncs)
-    const bool force_dyn = w.c[RPO_EVOPF_C_FLAGS] != 0.0f;
-    bool solved = false;
-    if (!force_dyn) {                                          // static order (sparse), accepted by its pivots
-        float row[NY];
-        const RowCoef rc = row_coef(w, kRowOrder[tid < NEQ ? tid : 0]);
-#pragma unroll
-        for (int c = 0; c < NY; ++c) {
-            const int var = c < NO ? kOtherVars[c] : kPartialVars[c - NO];
-            row[c] = tid < NEQ ? jac_row_entry(w, rc, var, yrow) : 0.0f;
-        }
-        const float mypiv = gauss_jordan_static<NEQ, NY, 6, TabGrg>(row);
-        solved = pivots_ok<NEQ, 6>(mypiv);
-        if (solved && tid < NO) {                              // inv(J_o) J_p = -dynz_dz (:598), row of unknown `tid`
-            const float inv = 1.0f / mypiv;
-#pragma unroll
-            for (int p = 0; p < NPV; ++p) w.D[tid][p] = row[NO + p] * inv;
-        }
-    }
-    if (!solved) {                                             // partial pivoting (near-singular Jacobians, or forced)
-        float row[NY];
-        const RowCoef rc = row_coef(w, kRowOrder[tid < NEQ ? tid : 0]);
-#pragma unroll
-        for (int c = 0; c < NY; ++c) {
-            const int var = c < NO ? kOtherVars[c] : kPartialVars[c - NO];
-            row[c] = tid < NEQ ? jac_row_entry(w, rc, var, yrow) : 0.0f;
-        }
-        int mycol;
-        float mypiv;
-        gauss_jordan_rows<NEQ, NY, 6>(row, mycol, mypiv);
-        if (tid < NO) {
-            const float inv = 1.0f / mypiv;
-#pragma unroll
-            for (int p = 0; p < NPV; ++p) w.D[mycol][p] = row[NO + p] * inv;
-        }
-    }
-    if (tid < NY) {                                            // ineq_grad_new (:590-594): +-1 per violated bound
-        float g = 0.0f;
-        if (tid < QG0) g = (w.ineq[tid] > 0.0f ? 1.0f : 0.0f) - (w.ineq[5 + tid] > 0.0f ? 1.0f : 0.0f);
-        else if (tid < VM0) g = (w.ineq[10 + tid - QG0] > 0.0f ? 1.0f : 0.0f) - (w.ineq[15 + tid - QG0] > 0.0f ? 1.0f : 0.0f);
-        else if (tid < VA0) g = (w.ineq[20 + tid - VM0] > 0.0f ? 1.0f : 0.0f) - (w.ineq[34 + tid - VM0] > 0.0f ? 1.0f : 0.0f);
-        else if (tid >= PE0) g = (w.ineq[48 + tid - PE0] > 0.0f ? 1.0f : 0.0f) - (w.ineq[53 + tid - PE0] > 0.0f ? 1.0f : 0.0f);
-        w.vec[tid] = g;
-    }
-    sync();
-    if (tid < NPV) {                                           // indirect + direct (:603-606)
-        float acc = 0.0f;
-#pragma unroll
-        for (int o = 0; o < NO; ++o) acc = fmaf(-w.D[o][tid], w.vec[kOtherVars[o]], acc);
-        w.fp[tid] = acc + w.vec[kPartialVars[tid]];
-    }
-    sync();
-    if (tid < NPV) w.dir[kPartialVars[tid]] = w.fp[tid];
-    if (tid < NO) {                                            // (:610)
-        float acc = 0.0f;
-#pragma unroll
-        for (int p = 0; p < NPV; ++p) acc = fmaf(-w.D[tid][p], w.fp[p], acc);
-        w.dir[kOtherVars[tid]] = acc;
-    }
-    sync();
-}
-
-__device__ __forceinline__ void ineq_partial_grad(Ws& w) {
-    ineq_partial_grad(w, y_row(w, kRowOrder[lane_id() < NEQ ? lane_id() : 0] % NB));
-}
-
-// grad_steps (rpo_ddpg.py:266-305, corr_mode 0) on w.a with the lane's own stop test; returns the iteration count
-__device__ __forceinline__ int grad_steps(Ws& w, int max_steps, float lr, float corr_eps, float momentum) {
-    const int tid = lane_id();
-    if (tid < NY) w.old[tid] = 0.0f;
-    const YVec yc = y_column(w, tid < NB ? tid : 0);
-    const YVec yo = y_row(w, kRowOrder[tid < NEQ ? tid : 0] % NB);
-    int k = 0;
-    for (; k < max_steps; ++k) {
-        flows(w, yc);
-        if (k > 0) {
-            eq_resid(w);
-            ineq_resid(w);
-            float m = tid < NEQ ? fabsf(w.eq[tid]) : 0.0f;
-            if (tid < NINEQ) m = fmaxf(m, w.ineq[tid]);
-            if (!(rpo_wave_max(m) > corr_eps)) break;
-        }
-        ineq_partial_grad(w, yo);
-        if (tid < NY) {
-            const float st = lr * w.dir[tid] + momentum * w.old[tid];
-            w.a[tid] -= st;
-            w.old[tid] = st;
-        }
-        sync();
-    }
-    return k;
-}
-
 // =====================================================================================================================
 // v2 of the equation solver and the GRG projection (round 4): the whole iteration in registers and wave-uniform values.
 //
-// v1 above hands every intermediate over through LDS (cos / sin / rectangular voltages -> admittance products -> residuals
+// v1 (rounds 1-3; its solver functions were removed in round 4, its helpers above remain) handed every intermediate over through LDS (cos / sin / rectangular voltages -> admittance products -> residuals
 // -> Jacobian rows -> D -> two products with D), each a store, a wave barrier and dependent loads: with ONE resident wave
 // nothing hides those round trips.  Here:
 //   * lane r < 28 owns equation kRowOrder[r] (both systems: Newton's 22 x 22 is the block of rows / columns 6..27), lanes
