@@ -907,7 +907,13 @@ class RPOTrainerBase(object):
             su.run("critic_bwd_a")
         if ride is not None:
             ride.set(defer_clock=int(self._defer_ok))           # ... whose step counter the next update's fwd_a advances
-        su.run("critic_bwd_b", rider=ride)                      # + explore / project / step / scatter of every lane
+        if ride is not None and self.dist.on and self.dist.in_graph and _env_int("RPO_DP_OVERLAP", 0):
+            # experiment: the riders' step on a second captured branch beside the gradient
+            # all-reduce instead of inside bwd_b's launch -- same kernel, same arguments, same bits
+            su.run("critic_bwd_b")
+            self._tail_rider = (su, ride)
+        else:
+            su.run("critic_bwd_b", rider=ride)                  # + explore / project / step / scatter of every lane
         if ride is not None:
             self._clock_pending = bool(self._defer_ok)
             self.vec.steps_host += 1
@@ -1059,8 +1065,18 @@ class RPOTrainerBase(object):
                 self._critic_update(cols)
             finally:
                 self._ride = None
+            tail, self._tail_rider = getattr(self, "_tail_rider", None), None
+            if tail is not None:                                 # fork: riders' step beside the all-reduce + Adam
+                main = torch.cuda.current_stream()
+                if self._ovl_stream is None:
+                    self._ovl_stream = torch.cuda.Stream()
+                self._ovl_stream.wait_stream(main)
+                with torch.cuda.stream(self._ovl_stream):
+                    tail[0].run_ride_tail(tail[1])
             self.dist.mean_([fl.gradient(fl.critic_range)])
             self._critic_step(actor_step)
+            if tail is not None:
+                torch.cuda.current_stream().wait_stream(self._ovl_stream)
             if actor_step:
                 self._last_actor_out = self._actor_update(cols)
                 self.dist.mean_([fl.gradient(fl.policy_bucket)])

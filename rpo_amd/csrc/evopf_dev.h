@@ -572,6 +572,9 @@ __device__ __forceinline__ float gj_static(float (&row)[NC]) {
         const int j = k - OFF;
         float f;
         if (k < KUNIT) {
+            // unit pivots (slack pg / qg equations): only the extra row (lane NEQ: [g_o | g_p]) has an entry in their columns --
+            // nothing to do when the bound of that variable is not violated (wave-uniform skip of the whole step)
+            if (lane_bcast(row[j], NEQ) == 0.0f) continue;
             f = lane == k ? 0.0f : -row[j];
         } else {
             const float piv = lane_bcast(row[j], k);
