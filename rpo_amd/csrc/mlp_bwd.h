@@ -241,11 +241,88 @@ __device__ __forceinline__ float mlp_bwd_first_layer_impl(const BwdArgs& p, int 
     return gmax;
 }
 
+// The same gradients of a WIDE first layer (EVOPF: 256 x (57 + 1 | 43 + 1)) on the matrix cores (round 4).  The scalar role above
+// is a chain of n / 4 rows of dependent loads per thread in 408 workgroups -- 11 of the 12 us of the critic's weights pass at
+// batch 256, the longest of its roles.  Here dWs | dbs (and dWa | dba) are what they are: dx0^T [E x n] times [s | 1] [n x (S + 1)],
+// 16 embedding rows x 64 input columns per workgroup like a dW0 tile (the four waves split the batch, their partial tiles meet
+// in LDS and are added in a fixed order; one owner per output), E / 16 workgroups per input half; the remaining workgroups of
+// the role's grid have nothing to do.  Inputs up to 63 wide; another (fixed) summation order than the scalar role.
+template <int EIN>
+__device__ __forceinline__ float mlp_bwd_first_layer_mfma(const BwdArgs& p, int fl_block) {
+    const Mlp& net = p.net;
+    const int halves = (net.A > 0 && !p.first_layer_state_only) ? 2 : 1, eb = net.E / 16;
+    if (fl_block >= eb * halves) return 0.0f;
+    __shared__ __attribute__((aligned(16))) float fl_tile[4][16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int half = fl_block / eb, et = fl_block - half * eb;
+    const bool is_a = half == 1;
+    const int width = is_a ? net.A : net.S;
+    const float* in = is_a ? p.a : p.s;
+    const int stride = is_a ? p.a_stride : p.s_stride;
+    const int col = ((is_a && net.cat) ? net.E : 0) + et * 16 + li;           // this lane's column of dx0 (A operand, m = li)
+    f32x4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int nk = (p.n + 3) / 4, ks_lo = (nk * wave) / 4, ks_hi = (nk * (wave + 1)) / 4, last = p.n - 1;
+    int ks = ks_lo;
+    for (; ks + 4 <= ks_hi; ks += 4) {                                          // 4 k-steps of loads in flight before their MFMAs
+        float av[4], bv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = (ks + u) * 4 + lg, bc = b < last ? b : last;
+            av[u] = p.dx0[(size_t)bc * EIN + col];
+            if (b > last) av[u] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int i = c * 16 + li;
+                bv[u][c] = i < width ? in[(size_t)bc * stride + i] : (i == width ? 1.0f : 0.0f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = mfma4(av[u], bv[u][c], acc[c]);
+    }
+    for (; ks < ks_hi; ++ks) {
+        const int b = ks * 4 + lg, bc = b < last ? b : last;
+        float av = p.dx0[(size_t)bc * EIN + col];
+        if (b > last) av = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = c * 16 + li;
+            acc[c] = mfma4(av, i < width ? in[(size_t)bc * stride + i] : (i == width ? 1.0f : 0.0f), acc[c]);
+        }
+    }
+    // acc[c][q] = partial d[e = 16 et + 4 lg + q][i = 16 c + li]
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fl_tile[wave][(lg * 4 + q) * 64 + c * 16 + li] = acc[c][q];
+    __syncthreads();
+    float gmax = 0.0f;
+    const int r = tid >> 4, e = et * 16 + r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = (tid & 15) * 4 + q;
+        if (i > width) continue;
+        const int t = r * 64 + i;
+        const float tot = ((fl_tile[0][t] + fl_tile[1][t]) + fl_tile[2][t]) + fl_tile[3][t];
+        float* dst = i < width ? (is_a ? &p.g.Wa[e * net.A + i] : &p.g.Ws[e * net.S + i]) : (is_a ? &p.g.ba[e] : &p.g.bs[e]);
+        const float nv = *dst + tot;
+        *dst = nv;
+        gmax = fmaxf(gmax, fabsf(nv));
+    }
+    return gmax;
+}
+
 template <int EIN>
 __device__ __forceinline__ float mlp_bwd_first_layer(const BwdArgs& p, int fl_block) {
     const Mlp& net = p.net;
     const int outputs = net.E * (net.S + 1 + ((net.A > 0 && !p.first_layer_state_only) ? net.A + 1 : 0));
-    if (outputs > kFlWideFrom) return mlp_bwd_first_layer_impl<EIN, 64>(p, fl_block);
+    if (outputs > kFlWideFrom) {
+        if (net.S < 64 && net.A < 64 && (net.E & 15) == 0) return mlp_bwd_first_layer_mfma<EIN>(p, fl_block);
+        return mlp_bwd_first_layer_impl<EIN, 64>(p, fl_block);
+    }
     return mlp_bwd_first_layer_impl<EIN, 16>(p, fl_block);
 }
 
