@@ -535,8 +535,10 @@ __device__ __forceinline__ float row_residual(const Ws& w, const RowLane& L, con
 template <int C0, int NC, int NOUT>
 __device__ __forceinline__ void jacobian_row(const RowLane& L, const Volt& v, const Uniforms& u, float t1, float t2, float (&out)[NOUT]) {
     const float ca = L.is_row ? (L.real ? -v.vr : -v.vi) : 0.0f, cb = L.is_row ? (L.real ? -v.vi : v.vr) : 0.0f;
-    const float dg_vm = L.real ? -(v.cs * t1 + v.sn * t2) : (v.cs * t2 - v.sn * t1);
-    const float dg_va = L.real ? -(-v.vi * t1 + v.vr * t2) : (-v.vi * t2 - v.vr * t1);
+    // (the diagonal terms enter every column as dlt[k] * dg with dlt = [bus == k]: clamped to finite values so that a non-finite
+    //  term of a diverged Newton iterate stays on the diagonal -- 0 * inf would put a NaN into every entry of the row)
+    const float dg_vm = fminf(fmaxf(L.real ? -(v.cs * t1 + v.sn * t2) : (v.cs * t2 - v.sn * t1), -3.0e38f), 3.0e38f);
+    const float dg_va = fminf(fmaxf(L.real ? -(-v.vi * t1 + v.vr * t2) : (-v.vi * t2 - v.vr * t1), -3.0e38f), 3.0e38f);
     float alpha[NB], beta[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
