@@ -199,6 +199,20 @@ def test_static_elimination_order_equals_partial_pivoting(env, monkeypatch):
     assert np.nanmax(err_s) <= max(4.0 * np.nanmax(err_d), 2e-3), (np.nanmax(err_s), np.nanmax(err_d))
 
 
+def test_diverging_newton_input_stays_finite(env):
+    """The recorded basic action for which Newton has no solution to find (tests/golden/evopf_newton_divergence.npz; the float64
+    oracle does not converge on it either, test_evopf_oracle.py): the kernels return garbage there like the reference would,
+    but FINITE garbage -- a NaN action would poison the replay ring and, one update later, every parameter."""
+    fx = golden("evopf_newton_divergence")
+    s = dev(fx["s"][None])
+    ap = dev(fx["a"][None][:, G.partial_actions])
+    a = env.complete_partial(s, ap)
+    p, it = env.project(s, ap, 10, 1e-4, return_iters=True)
+    g = env.ineq_partial_grad(s, a.detach())
+    assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(p).all()) and bool(torch.isfinite(g).all())
+    assert float(env.eq_resid(s, a.detach()).abs().max()) > 0.1      # (not converged: that is the point of the fixture)
+
+
 def test_step_matches_oracle_including_episode_end(env):
     n, seed = 128, 31
     ids = np.arange(n)
