@@ -183,3 +183,43 @@ def test_bench_refuses_to_print_a_line_for_fewer_gpus_than_asked():
                        capture_output=True, text=True, env=env, timeout=300)
     if torch.cuda.device_count() < 2:
         assert r.returncode == 2 and "refusing" in r.stderr and r.stdout.strip() == ""
+
+
+def test_bench_timing_and_regime_helpers():
+    """bench.py (round 4): value = median of the repeated timed regions with the spread next to it; an HBM-priced launch is
+    labelled by the working set its back-to-back replays touch (LLC-resident below the 256 MiB Infinity Cache -- never an
+    'HBM fraction' -- else streaming, also priced against the 6.29 TB/s a copy achieves)."""
+    import bench
+    st = bench.region_stats([0.0010, 0.0008, 0.0009, 0.0030, 0.00085], 20)
+    assert st["timed_regions"] == 5 and abs(st["median"] - 0.0009) < 1e-12
+    assert abs(st["ms_per_step"] - 0.045) < 1e-9 and abs(st["ms_per_step_min"] - 0.04) < 1e-9 and abs(st["ms_per_step_max"] - 0.15) < 1e-9
+    llc = bench.hbm_regime(42e6, 4400.0)
+    assert llc["regime"].startswith("LLC-resident") and llc["frac_of_achievable"] is None
+    hbm = bench.hbm_regime(1.07e9, 4400.0)
+    assert hbm["regime"].startswith("HBM streaming") and abs(hbm["frac_of_achievable"] - 4400.0 / 6290.0) < 1e-9
+    assert bench.hbm_regime(1.07e9, 9000.0)["frac_of_achievable"] == 1.0
+
+
+def test_evopf_static_order_is_refused_for_another_network():
+    """The EVOPF solver's static elimination order has case14's branch pattern compiled in (csrc/evopf_dev.h: kAdjMask): a
+    constant table whose Ybus has an entry outside that pattern -- or RPO_EVOPF_PIVOT=dynamic -- selects partial pivoting
+    (RPO_EVOPF_C_FLAGS), decided on the host when the kernel set is built (no GPU involved)."""
+    from rpo_amd import ops
+    from rpo_amd.env.electrical_grid import case14
+    C = ops.CONST
+    table = case14.kernel_constants(C, C["RPO_EVOPF_CONSTS_LEN"])
+    k = ops.EvopfKernels(table)
+    assert k.static_order and k.consts[C["RPO_EVOPF_C_FLAGS"]] == 0.0
+    yr = table[C["RPO_EVOPF_C_YR"]:C["RPO_EVOPF_C_YR"] + 196].reshape(14, 14)
+    inside = np.array([[(m >> j) & 1 for j in range(14)] for m in ops.EvopfKernels.CASE14_ADJ], dtype=bool)
+    yi = table[C["RPO_EVOPF_C_YI"]:C["RPO_EVOPF_C_YI"] + 196].reshape(14, 14)
+    np.testing.assert_array_equal((yr != 0) | (yi != 0), inside)   # the compiled-in masks ARE case14's pattern
+    other = table.copy()
+    other[C["RPO_EVOPF_C_YR"] + 0 * 14 + 13] = 0.5              # a branch 1 - 14 that case14 does not have
+    k2 = ops.EvopfKernels(other)
+    assert not k2.static_order and k2.consts[C["RPO_EVOPF_C_FLAGS"]] == 1.0
+    os.environ["RPO_EVOPF_PIVOT"] = "dynamic"
+    try:
+        assert not ops.EvopfKernels(table).static_order
+    finally:
+        os.environ.pop("RPO_EVOPF_PIVOT")
