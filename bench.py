@@ -829,7 +829,8 @@ def main():
                     log("kernel clinic of the large-batch update:")
                     cl = kernel_clinic(lb, args.workload)
                     result["large_batch"]["kernels"] = {
-                        k: {kk: vv for kk, vv in v.items() if kk in ("us", "rate", "unit", "frac", "bound", "n", "launches_per_period")}
+                        k: {kk: vv for kk, vv in v.items() if kk in ("us", "rate", "unit", "frac", "bound", "n", "launches_per_period",
+                                                                     "regime", "frac_of_achievable")}
                         for k, v in cl.items() if "@1M" not in k and v.get("n", 0) == 256 * EPG}
                 del lb
                 torch.cuda.empty_cache()

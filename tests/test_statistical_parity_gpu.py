@@ -1,7 +1,7 @@
 """Statistical parity with the reference's CPU runs (north_star: returns and constraint-violation rate).
 
 tests/golden/training_stats_*.npz hold the statistics of 3000-iteration training runs of the unmodified reference
-(scripts/cart_exp.py: 384 seeds; scripts/pen_exp_sac.py: 192 seeds (round 4; 24 before); scripts/cart_exp_sac.py: 96 seeds; scripts/pen_exp.py: 576 seeds;
+(scripts/cart_exp.py: 384 seeds; scripts/pen_exp_sac.py: 192 seeds (round 4; 24 before); scripts/cart_exp_sac.py: 384 seeds (round 4; 96 before); scripts/pen_exp.py: 576 seeds;
 tests/golden/make_golden.py stats).  The same runs are
 repeated here with the shipped trainers at num_envs = 1 -- the reference's cadence, step for step -- on the HIP kernels,
 on TWICE as many seeds (GPU runs are cheap).  Random streams differ (Philox vs numpy/torch global generators) and
@@ -31,17 +31,18 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.timeout(1500, method="thread")
-# (algo, env, largest standard error of the violation-rate difference the case must reach).  cart-RPOSAC (config 4's
-# algorithm, scripts/cart_exp_sac.py, 96 reference seeds) has a seed-to-seed spread of 7.4e-3 -- more than twice
-# cart-RPODDPG's -- so its comparison resolves 1e-3 at one sigma only; it is a consistency check at that resolution.
-@pytest.mark.parametrize("algo,envname,se_max", [("ddpg", "cart", 5e-4), ("sac", "pendulum", 5e-4), ("sac", "cart", 1e-3),
-                                                 ("ddpg", "pendulum", 5e-4)])
-def test_training_statistics_match_reference(golden, algo, envname, se_max):
+# (algo, env, largest standard error of the violation-rate difference the case must reach, GPU runs per reference run).
+# cart-RPOSAC (config 4's algorithm, scripts/cart_exp_sac.py) has a seed-to-seed spread of 7.4e-3 -- more than twice
+# cart-RPODDPG's: 96 reference seeds resolved 1e-3 at one sigma only (round 3); with 384 reference and 384 GPU runs (round 4)
+# the standard error of the difference is 5.3e-4.
+@pytest.mark.parametrize("algo,envname,se_max,gpu_per_ref", [("ddpg", "cart", 5e-4, 2), ("sac", "pendulum", 5e-4, 2),
+                                                             ("sac", "cart", 6e-4, 1), ("ddpg", "pendulum", 5e-4, 2)])
+def test_training_statistics_match_reference(golden, algo, envname, se_max, gpu_per_ref):
     from rpo_amd import ops
     from rpo_amd.utils.logger import Logger
     g = golden("training_stats_%s_%s" % (algo, envname))
     ref, steps = g["stats"], int(g["steps"])
-    n_gpu = 2 * len(ref)
+    n_gpu = gpu_per_ref * len(ref)
     os.environ["RPO_VERBOSE"] = "0"
     rows = []
     for seed in range(n_gpu):
