@@ -193,6 +193,8 @@ __global__ __launch_bounds__(RPO_BLOCK) void cartsafe_lagrangian_kernel(int n, c
         float r = 0.0f;
         for (int w = 0; w < RPO_BLOCK / RPO_WAVE; ++w) r += red[w * 7 + threadIdx.x];
         r *= scale;
+        // (one workgroup -- a fixed summation order -- up to 256 rows, the update batch of every script; larger batches add
+        //  their per-workgroup partials in arrival order: the large-batch mode is not bitwise reproducible run to run)
         if (threadIdx.x == 0) { if (loss_out) atomicAdd(loss_out, r); }
         else if (grad_nu) atomicAdd(grad_nu + threadIdx.x - 1, r);
     }
