@@ -310,6 +310,7 @@ class RPOTrainerBase(object):
         # split path it is an alias of the rollout's ctrl and nothing changes.
         self._uctrl, self._uclock_ok, self._after_front, self._ovl_stream = self.vec.ctrl, True, None, None
         self._ride, self._rider_cache, self._ride_cut = None, None, 0
+        self._tail_rider = None     # (RPO_DP_OVERLAP=1: the riders' step waiting to be forked beside the all-reduce)
         self._clock_pending, self._iter_actor_step, self._critic_prepared, self._gradmax_stale = False, None, False, False
         self._actor_prepared, self._actor_gradmax_stale = False, False
         self._bump_updates_now, self._updates_out, self._pol_a_done = False, None, False
@@ -1065,7 +1066,7 @@ class RPOTrainerBase(object):
                 self._critic_update(cols)
             finally:
                 self._ride = None
-            tail, self._tail_rider = getattr(self, "_tail_rider", None), None
+            tail, self._tail_rider = self._tail_rider, None
             if tail is not None:                                 # fork: riders' step beside the all-reduce + Adam
                 main = torch.cuda.current_stream()
                 if self._ovl_stream is None:
@@ -1335,7 +1336,10 @@ class RPOTrainerBase(object):
         v.ctrl.copy_(st["ctrl"])
         v.stats.zero_()
         if st["rows"] is not None:
-            b.rows[:st["rows"].shape[0]].copy_(st["rows"])
+            # (the ring stride may differ from the checkpoint's: CartSafe rings went from 24 to 32 floats per row in round 4;
+            #  a transition is the first `row_floats` floats of a ring row either way)
+            w = min(st["rows"].shape[1], b.rows.shape[1])
+            b.rows[:st["rows"].shape[0], :w].copy_(st["rows"][:, :w])
         self._t = self._harvested = int(st["t"])
         self._uclock_ok = False
         self._updates = int(st["updates"])
