@@ -323,7 +323,7 @@ __global__ __launch_bounds__(RPO_WAVE * kActWaves) void evopf_ipg_kernel(int n, 
     load_row(w.s, state + (size_t)i * state_stride, NS);
     load_row(w.a, action + (size_t)i * NY, NY);
     sync();
-    if (tid < NY) w.dir[tid] = 0.0f;                           // (the slack angle's component stays zero: full_grad, evopf.py:608)
+    if (tid < NY) w.dir[tid] = 0.0f;                           // (all 43 components are written below: 28 others + 15 partial vars)
     sync();
     const RowLane L = make_row_lane(w);
     sync();
