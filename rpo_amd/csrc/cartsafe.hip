@@ -79,7 +79,13 @@ __global__ __launch_bounds__(RPO_BLOCK) void cartsafe_step_kernel(StepArgs p, Ca
                 for (int k = 0; k < RC; ++k) {
                     const int ch = k * RPO_BLOCK + tid;         // float4 chunk of the tile's 256 ring rows
                     const int r = ch / RC, part = ch - r * RC;
-                    gr[ch] = part < 6 ? rows_s[r * 7 + part] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    const float4 v4 = part < 6 ? rows_s[r * 7 + part] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (p.n >= 65536) {                         // (streaming regime: the ring is written once and sampled much later)
+                        typedef float v4f __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(v4f{v4.x, v4.y, v4.z, v4.w}, reinterpret_cast<v4f*>(&gr[ch]));
+                    } else {
+                        gr[ch] = v4;
+                    }
                 }
             }
             __syncthreads();                                   // LDS tiles are rewritten by the next iteration

@@ -19,6 +19,11 @@ __global__ __launch_bounds__(RPO_BLOCK) void replay_gather_kernel(const float4* 
     }
 }
 
+// NT: the batch is written with non-temporal stores -- large batches (the 2^20-row updates, the 1M-lane clinic) are written once
+// and read once by the next launch, a quarter of the LLC: streaming them past the L2 took the launch from 40.2 to 38.6 us at
+// 1M rows (0.59 -> 0.62 of 8 TB/s); non-temporal LOADS of the sampled rows made it slower (44.4 us).  Update-sized batches
+// keep plain stores: their consumer is the next launch's first instruction.
+template <bool NT>
 __global__ __launch_bounds__(RPO_BLOCK) void replay_sample_gather_kernel(
     const float4* __restrict__ rows, int ring_chunks, int chunks_per_row, long long total_chunks, long long cap_steps, int n_envs,
     float4* __restrict__ out, long long* __restrict__ idx_out, uint64_t seed, uint32_t salt,
@@ -33,7 +38,13 @@ __global__ __launch_bounds__(RPO_BLOCK) void replay_sample_gather_kernel(
         const rpo_u4 r = rpo_philox(seed, (uint32_t)b, (uint32_t)t + salt, RPO_STREAM_SAMPLE, (uint32_t)ctrl[RPO_CTRL_UPDATES]);
         const unsigned long long x = ((unsigned long long)r.x << 32) | r.y;
         const long long row = (long long)__umul64hi(x, n_valid);
-        out[j] = rows[row * ring_chunks + c];
+        if (NT) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f v = *reinterpret_cast<const v4f*>(&rows[row * ring_chunks + c]);
+            __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(&out[j]));
+        } else {
+            out[j] = rows[row * ring_chunks + c];
+        }
         if (idx_out && c == 0) idx_out[b] = row;
     }
 }
@@ -63,9 +74,14 @@ int rpo_replay_sample_gather(const float* rows, int ring_floats, int row_floats,
     if (!rows || !batch_out || !ctrl) return RPO_ERR_NULL;
     const int cpr = row_floats / 4;
     const long long total = (long long)batch * cpr;
-    hipLaunchKernelGGL(replay_sample_gather_kernel, dim3(rpo_grid_for(total)), dim3(RPO_BLOCK), 0,
-                       (hipStream_t)stream, reinterpret_cast<const float4*>(rows), ring_floats / 4, cpr, total, cap_steps, n_envs,
-                       reinterpret_cast<float4*>(batch_out), idx_out, (uint64_t)seed, (uint32_t)sample_salt, ctrl);
+    if (batch >= 65536)
+        hipLaunchKernelGGL(replay_sample_gather_kernel<true>, dim3(rpo_grid_for(total)), dim3(RPO_BLOCK), 0,
+                           (hipStream_t)stream, reinterpret_cast<const float4*>(rows), ring_floats / 4, cpr, total, cap_steps, n_envs,
+                           reinterpret_cast<float4*>(batch_out), idx_out, (uint64_t)seed, (uint32_t)sample_salt, ctrl);
+    else
+        hipLaunchKernelGGL(replay_sample_gather_kernel<false>, dim3(rpo_grid_for(total)), dim3(RPO_BLOCK), 0,
+                           (hipStream_t)stream, reinterpret_cast<const float4*>(rows), ring_floats / 4, cpr, total, cap_steps, n_envs,
+                           reinterpret_cast<float4*>(batch_out), idx_out, (uint64_t)seed, (uint32_t)sample_salt, ctrl);
     RPO_LAUNCH_CHECK();
     return 0;
 }
