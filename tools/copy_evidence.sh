@@ -1,0 +1,24 @@
+#!/bin/bash
+# Copy what is to be judged from gpurun_out/evidence_rNN/ (tools/collect_evidence.sh) into profiles/ under round-prefixed names.
+set -u
+R=${1:-r04}
+E=gpurun_out/evidence_$R
+P=profiles
+for w in cart_ddpg cart_sac pen_ddpg pen_sac evopf_ddpg evopf_sac; do
+  cp $E/${w}_kernel_stats.txt $P/${R}_bench_${w}_kernel_stats.txt
+  cp $E/bench_$w.json $P/${R}_bench_${w}_profiled.json
+  cp $E/${w}_timeline.txt $P/${R}_timeline_$w.txt
+  cp $E/pmc_traffic_$w.json $P/${R}_pmc_traffic_$w.json
+done
+cp $E/pmc_traffic.json $P/${R}_pmc_traffic.json
+cp $E/pmc_evopf_sq.txt $P/${R}_pmc_evopf_sq.txt
+for c in FETCH_SIZE WRITE_SIZE; do for p in step iter ride; do cp $E/pmc_${c}_$p.txt $P/${R}_pmc_${c}_$p.txt; done; done
+cp $E/bench.json $P/${R}_bench.json
+cp $E/bench_steps20.json $P/${R}_bench_steps20.json
+for w in cart_sac pen_ddpg pen_sac evopf_ddpg evopf_sac; do cp $E/bench_line_$w.json $P/${R}_bench_$w.json; done
+for w in cart_ddpg cart_sac; do cp $E/bench_force_dist_$w.json $P/${R}_bench_force_dist_$w.json; cp $E/probe_large_batch_$w.txt $P/${R}_probe_large_batch_$w.txt; done
+cp $E/pytest_gpu.log $P/${R}_pytest_gpu.log
+cp $E/probe_project.txt $P/${R}_probe_project.txt
+cp gpurun_out/statistical_parity_*.json $P/ 2>/dev/null
+cp gpurun_out/cadence_learning.json $P/${R}_cadence_learning.json 2>/dev/null
+ls $P | grep -c "^$R"
