@@ -821,7 +821,7 @@ def main():
                     # tools/cadence_learning.py, 8 seeds x 3000 updates vs the reference's 384 runs (profiles/r04_cadence_learning.json,
                     # tests/test_statistical_parity_gpu.py::test_vectorised_cadences_learn_like_the_reference)
                     "learning_at_matched_updates": "THROUGHPUT FIGURE of another optimiser regime, not the reference's learning "
-                            "curve: at 3000 updates it reaches return 23.5 +- 1.4 (second half 30.1 +- 2.0) where the reference "
+                            "curve: at 3000 updates it reaches return 24.1 +- 1.8 (second half 31.4 +- 3.0) where the reference "
                             "reaches 27.5 +- 0.6 (32.9 +- 0.8), with a LOWER violation rate (0.76e-2 +- 0.12e-2 vs 1.31e-2); the "
                             "batch-256 cadence of the headline reproduces the reference at matched updates (25.6 +- 2.1 / 34.1 +- "
                             "3.5, 1.07e-2 +- 0.18e-2)"}

@@ -199,8 +199,7 @@ __global__ __launch_bounds__(RPO_BLOCK) void cartsafe_lagrangian_kernel(int n, c
         float r = 0.0f;
         for (int w = 0; w < RPO_BLOCK / RPO_WAVE; ++w) r += red[w * 7 + threadIdx.x];
         r *= scale;
-        // (one workgroup -- a fixed summation order -- up to 256 rows, the update batch of every script; larger batches add
-        //  their per-workgroup partials in arrival order: the large-batch mode is not bitwise reproducible run to run)
+        // (always ONE workgroup that sums -- a fixed order: see rpo_cartsafe_lagrangian for batches beyond 256 rows)
         if (threadIdx.x == 0) { if (loss_out) atomicAdd(loss_out, r); }
         else if (grad_nu) atomicAdd(grad_nu + threadIdx.x - 1, r);
     }
@@ -299,6 +298,20 @@ int rpo_cartsafe_lagrangian(int n, const float* action, const float* nu, float s
     if (!action || !nu) return RPO_ERR_NULL;
     CartConsts c;
     if (int e = load_consts(c, consts_host, partial)) return e;
+    if (n > RPO_BLOCK && (loss_out || grad_nu)) {
+        // More than one workgroup would add its partial sums with float atomics in arrival order (found in round 4: the 2^20-row
+        // updates were not bitwise reproducible from run to run).  The elementwise part keeps the wide grid; the sums are taken
+        // by ONE workgroup in a fixed order (it recomputes the rows: 0.3 ms at 2^20 rows, once per policy period of 22 ms).
+        if (grad_action) {
+            hipLaunchKernelGGL(cartsafe_lagrangian_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n,
+                               action, nu, scale, (float*)nullptr, grad_action, (float*)nullptr, c);
+            RPO_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(cartsafe_lagrangian_kernel, dim3(1), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, action, nu, scale,
+                           loss_out, (float*)nullptr, grad_nu, c);
+        RPO_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(cartsafe_lagrangian_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n,
                        action, nu, scale, loss_out, grad_action, grad_nu, c);
     RPO_LAUNCH_CHECK();

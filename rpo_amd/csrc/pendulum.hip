@@ -274,6 +274,17 @@ int rpo_pendulum_lagrangian(int n, const float* action, const float* nu, float s
                             float* grad_action, float* grad_nu, void* stream) {
     if (n <= 0) return RPO_ERR_ARG;
     if (!action || !nu) return RPO_ERR_NULL;
+    if (n > RPO_BLOCK && (loss_out || grad_nu)) {               // (sums by one workgroup in a fixed order: see rpo_cartsafe_lagrangian)
+        if (grad_action) {
+            hipLaunchKernelGGL(pendulum_lagrangian_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n,
+                               action, nu, scale, (float*)nullptr, grad_action, (float*)nullptr);
+            RPO_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(pendulum_lagrangian_kernel, dim3(1), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, action, nu, scale,
+                           loss_out, (float*)nullptr, grad_nu);
+        RPO_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(pendulum_lagrangian_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n,
                        action, nu, scale, loss_out, grad_action, grad_nu);
     RPO_LAUNCH_CHECK();
