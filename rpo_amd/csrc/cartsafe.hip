@@ -174,7 +174,8 @@ __global__ __launch_bounds__(RPO_BLOCK) void cartsafe_lagrangian_kernel(int n, c
                                                                         const float* __restrict__ nu, float scale,
                                                                         float* __restrict__ loss_out,
                                                                         float* __restrict__ grad_action,
-                                                                        float* __restrict__ grad_nu, CartConsts c) {
+                                                                        float* __restrict__ grad_nu, CartConsts c,
+                                                                        float* __restrict__ partials_out) {
     __shared__ float red[(RPO_BLOCK / RPO_WAVE) * 7];
     float nuv[6];
 #pragma unroll
@@ -199,9 +200,33 @@ __global__ __launch_bounds__(RPO_BLOCK) void cartsafe_lagrangian_kernel(int n, c
         float r = 0.0f;
         for (int w = 0; w < RPO_BLOCK / RPO_WAVE; ++w) r += red[w * 7 + threadIdx.x];
         r *= scale;
-        // (always ONE workgroup that sums -- a fixed order: see rpo_cartsafe_lagrangian for batches beyond 256 rows)
-        if (threadIdx.x == 0) { if (loss_out) atomicAdd(loss_out, r); }
+        // (a launch that adds into loss_out / grad_nu is always ONE workgroup -- a fixed order; wider batches leave their
+        //  per-workgroup sums in partials_out: see rpo_cartsafe_lagrangian)
+        if (partials_out) partials_out[(size_t)blockIdx.x * 8 + threadIdx.x] = r;
+        else if (threadIdx.x == 0) { if (loss_out) atomicAdd(loss_out, r); }
         else if (grad_nu) atomicAdd(grad_nu + threadIdx.x - 1, r);
+    }
+}
+
+// Sum of G per-workgroup partial vectors [G][8] (K <= 8 used) in a FIXED order: thread t takes workgroups t, t + 256, ..., the 256
+// sums meet in an LDS tree; out_k[0] += total_k for the non-NULL outputs.  One workgroup.
+__global__ __launch_bounds__(RPO_BLOCK) void lagrangian_reduce_kernel(int G, int K, const float* __restrict__ partials,
+                                                                      float* __restrict__ loss_out, float* __restrict__ grad_nu) {
+    __shared__ float red[RPO_BLOCK];
+    for (int k = 0; k < K; ++k) {
+        float acc = 0.0f;
+        for (int b = threadIdx.x; b < G; b += RPO_BLOCK) acc += partials[(size_t)b * 8 + k];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int off = RPO_BLOCK / 2; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            float* dst = k == 0 ? loss_out : (grad_nu ? grad_nu + k - 1 : nullptr);
+            if (dst) *dst += red[0];
+        }
+        __syncthreads();
     }
 }
 
@@ -300,20 +325,35 @@ int rpo_cartsafe_lagrangian(int n, const float* action, const float* nu, float s
     if (int e = load_consts(c, consts_host, partial)) return e;
     if (n > RPO_BLOCK && (loss_out || grad_nu)) {
         // More than one workgroup would add its partial sums with float atomics in arrival order (found in round 4: the 2^20-row
-        // updates were not bitwise reproducible from run to run).  The elementwise part keeps the wide grid; the sums are taken
-        // by ONE workgroup in a fixed order (it recomputes the rows: 0.3 ms at 2^20 rows, once per policy period of 22 ms).
+        // updates were not bitwise reproducible from run to run).  Deterministic form: every workgroup leaves its 7 sums in a
+        // scratch area, ONE workgroup adds them in a fixed order, then the elementwise launch writes grad_action -- whose
+        // first 8 G floats ARE the scratch area (G = workgroups <= n / 256, so 8 G <= n / 32 floats of the 2 n).  Without a
+        // grad_action buffer one workgroup recomputes and sums every row.
+        const int G = rpo_grid_for(n);
+        if (grad_action && (long long)8 * G <= (long long)2 * n) {
+            hipLaunchKernelGGL(cartsafe_lagrangian_kernel, dim3(G), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, action, nu, scale,
+                               (float*)nullptr, (float*)nullptr, (float*)nullptr, c, grad_action);
+            RPO_LAUNCH_CHECK();
+            hipLaunchKernelGGL(lagrangian_reduce_kernel, dim3(1), dim3(RPO_BLOCK), 0, (hipStream_t)stream, G, 7,
+                               (const float*)grad_action, loss_out, grad_nu);
+            RPO_LAUNCH_CHECK();
+            hipLaunchKernelGGL(cartsafe_lagrangian_kernel, dim3(G), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, action, nu, scale,
+                               (float*)nullptr, grad_action, (float*)nullptr, c, (float*)nullptr);
+            RPO_LAUNCH_CHECK();
+            return 0;
+        }
         if (grad_action) {
-            hipLaunchKernelGGL(cartsafe_lagrangian_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n,
-                               action, nu, scale, (float*)nullptr, grad_action, (float*)nullptr, c);
+            hipLaunchKernelGGL(cartsafe_lagrangian_kernel, dim3(G), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, action, nu, scale,
+                               (float*)nullptr, grad_action, (float*)nullptr, c, (float*)nullptr);
             RPO_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(cartsafe_lagrangian_kernel, dim3(1), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, action, nu, scale,
-                           loss_out, (float*)nullptr, grad_nu, c);
+                           loss_out, (float*)nullptr, grad_nu, c, (float*)nullptr);
         RPO_LAUNCH_CHECK();
         return 0;
     }
     hipLaunchKernelGGL(cartsafe_lagrangian_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n,
-                       action, nu, scale, loss_out, grad_action, grad_nu, c);
+                       action, nu, scale, loss_out, grad_action, grad_nu, c, (float*)nullptr);
     RPO_LAUNCH_CHECK();
     return 0;
 }

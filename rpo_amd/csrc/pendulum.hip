@@ -151,7 +151,8 @@ __global__ __launch_bounds__(RPO_BLOCK) void pendulum_lagrangian_kernel(int n, c
                                                                         const float* __restrict__ nu, float scale,
                                                                         float* __restrict__ loss_out,
                                                                         float* __restrict__ grad_action,
-                                                                        float* __restrict__ grad_nu) {
+                                                                        float* __restrict__ grad_nu,
+                                                                        float* __restrict__ partials_out) {
     __shared__ float red[RPO_BLOCK / RPO_WAVE];
     const float nu0 = nu[0];
     float acc = 0.0f;
@@ -169,8 +170,34 @@ __global__ __launch_bounds__(RPO_BLOCK) void pendulum_lagrangian_kernel(int n, c
         float s = 0.0f;
         for (int w = 0; w < RPO_BLOCK / RPO_WAVE; ++w) s += red[w];
         s *= scale;
-        if (loss_out) atomicAdd(loss_out, nu0 * s);
-        if (grad_nu) atomicAdd(grad_nu, s);
+        // (a launch that adds into loss_out / grad_nu is always ONE workgroup; wider batches leave per-workgroup sums in
+        //  partials_out: see rpo_cartsafe_lagrangian)
+        if (partials_out) { partials_out[(size_t)blockIdx.x * 8] = nu0 * s; partials_out[(size_t)blockIdx.x * 8 + 1] = s; }
+        else {
+            if (loss_out) atomicAdd(loss_out, nu0 * s);
+            if (grad_nu) atomicAdd(grad_nu, s);
+        }
+    }
+}
+
+// (== lagrangian_reduce_kernel of cartsafe.hip: G partial vectors [G][8] summed in a fixed order by one workgroup)
+__global__ __launch_bounds__(RPO_BLOCK) void pend_lagrangian_reduce_kernel(int G, int K, const float* __restrict__ partials,
+                                                                           float* __restrict__ loss_out, float* __restrict__ grad_nu) {
+    __shared__ float red[RPO_BLOCK];
+    for (int k = 0; k < K; ++k) {
+        float acc = 0.0f;
+        for (int b = threadIdx.x; b < G; b += RPO_BLOCK) acc += partials[(size_t)b * 8 + k];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int off = RPO_BLOCK / 2; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            float* dst = k == 0 ? loss_out : (grad_nu ? grad_nu + k - 1 : nullptr);
+            if (dst) *dst += red[0];
+        }
+        __syncthreads();
     }
 }
 
@@ -274,19 +301,32 @@ int rpo_pendulum_lagrangian(int n, const float* action, const float* nu, float s
                             float* grad_action, float* grad_nu, void* stream) {
     if (n <= 0) return RPO_ERR_ARG;
     if (!action || !nu) return RPO_ERR_NULL;
-    if (n > RPO_BLOCK && (loss_out || grad_nu)) {               // (sums by one workgroup in a fixed order: see rpo_cartsafe_lagrangian)
+    if (n > RPO_BLOCK && (loss_out || grad_nu)) {               // (deterministic sums: see rpo_cartsafe_lagrangian)
+        const int G = rpo_grid_for(n);
+        if (grad_action && (long long)8 * G <= (long long)2 * n) {
+            hipLaunchKernelGGL(pendulum_lagrangian_kernel, dim3(G), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, action, nu, scale,
+                               (float*)nullptr, (float*)nullptr, (float*)nullptr, grad_action);
+            RPO_LAUNCH_CHECK();
+            hipLaunchKernelGGL(pend_lagrangian_reduce_kernel, dim3(1), dim3(RPO_BLOCK), 0, (hipStream_t)stream, G, 2,
+                               (const float*)grad_action, loss_out, grad_nu);
+            RPO_LAUNCH_CHECK();
+            hipLaunchKernelGGL(pendulum_lagrangian_kernel, dim3(G), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, action, nu, scale,
+                               (float*)nullptr, grad_action, (float*)nullptr, (float*)nullptr);
+            RPO_LAUNCH_CHECK();
+            return 0;
+        }
         if (grad_action) {
-            hipLaunchKernelGGL(pendulum_lagrangian_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n,
-                               action, nu, scale, (float*)nullptr, grad_action, (float*)nullptr);
+            hipLaunchKernelGGL(pendulum_lagrangian_kernel, dim3(G), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, action, nu, scale,
+                               (float*)nullptr, grad_action, (float*)nullptr, (float*)nullptr);
             RPO_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(pendulum_lagrangian_kernel, dim3(1), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n, action, nu, scale,
-                           loss_out, (float*)nullptr, grad_nu);
+                           loss_out, (float*)nullptr, grad_nu, (float*)nullptr);
         RPO_LAUNCH_CHECK();
         return 0;
     }
     hipLaunchKernelGGL(pendulum_lagrangian_kernel, dim3(rpo_grid_for(n)), dim3(RPO_BLOCK), 0, (hipStream_t)stream, n,
-                       action, nu, scale, loss_out, grad_action, grad_nu);
+                       action, nu, scale, loss_out, grad_action, grad_nu, (float*)nullptr);
     RPO_LAUNCH_CHECK();
     return 0;
 }

@@ -661,3 +661,35 @@ def test_xcc_probe_and_front_placement(ops):
         lin = torch.arange(128)
         assert all(len(torch.unique(ids[:, lin % 16 == t])) == 1 for t in range(16))
         assert not ops.front_launch_ok(100, False)              # 7 tiles: a tile's column groups land on different XCDs
+
+
+@pytest.mark.parametrize("n", [257, 5000, 300000])
+def test_lagrangian_beyond_one_workgroup_is_deterministic(ops, n):
+    """Batches beyond 256 rows (the large-batch update mode): the per-workgroup sums of rpo_*_lagrangian meet in a scratch area
+    (the head of the grad_action buffer) and ONE workgroup adds them in a fixed order before the elementwise launch overwrites
+    it -- two calls give the same bits (round 3 added the partials with float atomics in arrival order) and match the oracle;
+    without a grad_action buffer one workgroup recomputes and sums the rows (same property)."""
+    rng = np.random.RandomState(n)
+    c = cs.Constants(1)
+    kc = cart_kernels(ops, 1)
+    kp = ops.PendulumKernels()
+    a_np = (rng.randn(n, 2) * 9.0).astype(np.float32)
+    a = dev(a_np)
+    for k, nu_np, oracle in ((kc, np.array([0.3, 0.0, 1.5, 0.2, 0.7, 0.05], np.float32),
+                              lambda: train_ops.lagrangian_cart(a_np, np.array([0.3, 0.0, 1.5, 0.2, 0.7, 0.05], np.float32), c, 1.0 / n)),
+                             (kp, np.array([0.37], np.float32),
+                              lambda: train_ops.lagrangian_pendulum(a_np, np.array([0.37], np.float32), 1.0 / n))):
+        outs = []
+        for with_ga in (True, True, False):
+            loss = torch.zeros(1, device=DEV)
+            g_a = torch.full((n, 2), float("nan"), device=DEV) if with_ga else None
+            g_nu = torch.zeros(len(nu_np), device=DEV)
+            k.lagrangian(a, dev(nu_np), 1.0 / n, loss, g_a, g_nu)
+            outs.append((loss.clone(), g_nu.clone(), g_a))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+        w_loss, w_ga, w_gnu = oracle()
+        for loss, g_nu, g_a in outs:
+            np.testing.assert_allclose(float(loss), w_loss, rtol=2e-5)
+            np.testing.assert_allclose(g_nu.cpu().numpy(), w_gnu, rtol=2e-5, atol=1e-7)
+            if g_a is not None:
+                np.testing.assert_allclose(g_a.cpu().numpy(), w_ga, rtol=1e-5, atol=1e-8)
