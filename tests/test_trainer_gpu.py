@@ -375,12 +375,15 @@ def _spawn_rccl(world, out_dir, algo, n_total, iters, budget=240):
     return [torch.load(os.path.join(out_dir, "rank%d.pt" % r), weights_only=False) for r in range(world)]
 
 
-@pytest.mark.parametrize("algo", ["ddpg", "sac"])
-def test_rccl_collectives_inside_the_graph_single_rank(hip, tmp_path, algo, monkeypatch):
+@pytest.mark.parametrize("algo,overlap", [("ddpg", 0), ("sac", 0), ("sac", 1)])
+def test_rccl_collectives_inside_the_graph_single_rank(hip, tmp_path, algo, overlap, monkeypatch):
     """The data-parallel iteration over RCCL on the one GPU of this box (world size 1, RPO_DIST_FORCE): every gradient
     all-reduce is issued inside the hipGraph of the iteration / of the 8-iteration window.  With one rank the mean over
     ranks is the identity, so the run must equal the plain single-process run bit for bit -- which also pins that the
     data-parallel path (no in-backward inf-norm, explicit rpo_absmax) computes the same update."""
+    # overlap = 1 (RPO_DP_OVERLAP, an experiment of round 4, not the default): the riders' env step forked onto a second captured
+    # branch beside the all-reduce (rpo_split_ride_tail) instead of inside bwd_b's launch -- same kernel, same bits
+    monkeypatch.setenv("RPO_DP_OVERLAP", str(overlap))
     (r0,) = _spawn_rccl(1, str(tmp_path), algo, 256, 70)
     monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
     torch.manual_seed(5)
