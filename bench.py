@@ -362,12 +362,16 @@ def streaming_clinic(tr):
                          frac=r / HBM_PEAK_GBS, **hbm_regime(working_set, r))
     hbm("cartsafe_step_kernel@1M", time_kernel(lambda: k.step(
         big.internal, big.obs, big.action, big.ep_len, big.ep_ret, big.ep_count, rows, 8, big.stats, big.ctrl, 200, True,
-        1e-3, big.seed, big.env_id_base), reps=20)[0], 145, ring_bytes)
+        1e-3, big.seed, big.env_id_base), reps=20)[0], 145, ring_bytes)   # SURVEY 8d's algorithmic 145 B; the launch WRITES
+    # a whole 128-byte ring line per lane (96 B of transition + 32 B of padding, round 4): 177 B actually leave / enter the CU
+    out["cartsafe_step_kernel@1M"]["moved_bytes_per_lane"] = 4 * 6 + 4 * 2 + 4 * 6 + 4 * k.ring_floats
     hbm("cartsafe_act_project_kernel@1M", time_kernel(lambda: k.act_project(
         big.obs, big_ap, None, big.action, None, ops.NOISE_PHILOX, 1.0, 1.0, 0.0, -10.0, 10.0, 10, 2e-2, 1e-5, 0.0,
         big.seed, big.env_id_base, big.ctrl, big.stats), reps=20)[0], 40, 40 * big_n)      # the same 42 MB every launch: LLC
     hbm("replay_sample_gather_kernel@1M", time_kernel(lambda: ops.replay_sample_gather(
-        rows, 8, big_n, big_batch, None, 1, 0, big.ctrl), reps=20)[0], 178 + 4, ring_bytes)
+        rows, 8, big_n, big_batch, None, 1, 0, big.ctrl), reps=20)[0], 178 + 4, ring_bytes)   # 2 x 89 B + index
+    # what the launch moves since the 128-byte ring rows: one 128-byte line read + a 96-byte batch row written (+ 4 B index)
+    out["replay_sample_gather_kernel@1M"]["moved_bytes_per_sample"] = 4 * k.ring_floats + 4 * k.row_floats + 4
     us = time_kernel(lambda: k.rollout(
         f.descs["actor"], False, scale, base, big.internal, None, big.action, big.ep_len, big.ep_ret, big.ep_count, rows,
         8, big.stats, big.ctrl, ops.NOISE_PHILOX, 1.0, 1.0, 0.0, -10.0, 10.0, 10, 2e-2, 1e-5, 0.0, 200, True, 1e-3,
@@ -548,11 +552,13 @@ def cpu_baseline(workload, seconds=12.0):
 
 # ------------------------------------------------------------------------------------------------ launch of N ranks
 
-def self_launch(n, argv):
+def self_launch(n, argv, backend="nccl"):
     """`python bench.py --gpus N` without a launcher: start N ranks as children of a process that has NOT touched the GPU
-    (torch.cuda.device_count() does not initialise HIP on this image) and pass their output / exit code through."""
+    (torch.cuda.device_count() does not initialise HIP on this image) and pass their output / exit code through.
+    ``backend="gloo"`` (RPO_BENCH_BACKEND / --backend): the ranks may SHARE the visible GPUs (rank r on cuda:r mod #GPUs) --
+    the control-flow check of the N > 1 path on a one-GPU box, never a scaling figure."""
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and not (backend == "gloo" and have >= 1):
         log("bench.py: --gpus %d requested but only %d GPU(s) are visible; refusing to print a %d-GPU line" % (n, have, have))
         sys.exit(2)
     s = socket.socket()
@@ -657,13 +663,23 @@ def main():
                          "rpo_absmax_slots launch inside the graph windows): the measured intercept of the 1 -> N expectation")
     ap.add_argument("--n1-seeds", type=int, default=384,
                     help="headline extras: seeds of the num_envs = 1 violation-rate figure (0: skip)")
+    ap.add_argument("--backend", default=os.environ.get("RPO_BENCH_BACKEND", "nccl"), choices=("nccl", "gloo"),
+                    help="collective backend of an N > 1 run.  nccl (= RCCL, one rank per GPU) is what is measured; gloo lets "
+                         "the ranks share a GPU with host-driven collectives between hipGraph segments -- a control-flow check "
+                         "of the N > 1 path on a one-GPU box, labelled as such in the line")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        self_launch(args.gpus, sys.argv[1:])                     # never returns
+        os.environ["RPO_BENCH_BACKEND"] = args.backend           # (the ranks read it like the flag)
+        self_launch(args.gpus, sys.argv[1:], args.backend)       # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    shared_gpu = False
+    if args.backend == "gloo" and world > 1:
+        have = torch.cuda.device_count()                         # (does not initialise HIP)
+        shared_gpu = have < world
+        local_rank = local_rank % max(1, have)
     if world != args.gpus:
         log("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
     headline = args.workload == "cart_ddpg"
@@ -687,11 +703,14 @@ def main():
             s0.close()
             os.environ["RPO_DIST_FORCE"] = "1"
             dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
+        elif args.backend == "gloo":
+            dist.init_process_group(backend="gloo")              # host-driven collectives on GPU tensors; no device binding
         else:
             dist.init_process_group(backend="nccl", device_id=device)
-        log("rank %d/%d on cuda:%d: process group up, backend %s (RCCL), %d ranks" % (
-            rank, world, local_rank, dist.get_backend(), dist.get_world_size()))
-    rccl_ranks = dist.get_world_size() if dist.is_initialized() else 0
+        log("rank %d/%d on cuda:%d: process group up, backend %s%s, %d ranks" % (
+            rank, world, local_rank, dist.get_backend(), " (RCCL)" if dist.get_backend() == "nccl" else
+            " (host-driven%s)" % (", ranks share a GPU" if shared_gpu else ""), dist.get_world_size()))
+    rccl_ranks = dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0
 
     EPG = envs_per_gpu(args.workload)
     n_total = EPG * world
@@ -725,8 +744,11 @@ def main():
                                 "capacity 20000 per env" % EPG) if headline else
                                "%s, %d vectorised envs per MI355X (extra measurement, not the headline)" % (DESCRIBE[args.workload], EPG),
                    "envs_per_gpu": EPG, "global_envs": n_total, "update_batch": 256,
-                   "parallelism": "dp%d (env shards, one RCCL all-reduce of the flat gradient bucket per update, "
-                                  "captured inside the iteration's hipGraph)" % world,
+                   "parallelism": ("dp%d (env shards, one RCCL all-reduce of the flat gradient bucket per update, "
+                                   "captured inside the iteration's hipGraph)" % world) if args.backend == "nccl" or world == 1 else
+                                  ("dp%d (env shards, one gloo all-reduce of the flat gradient bucket per update, issued by the "
+                                   "host between hipGraph segments)" % world),
+                   "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                    "hip_graph": bool(tr._graphs.enabled), "graph_window_iterations": tr._cycle,
                    "training_batch_projection": tr.projection_mode,
                    # what RCCL saw (0: no process group -- the single-process run has no collective at all), and the
@@ -744,6 +766,10 @@ def main():
         # first `constraint_violation_window` of THIS run, in which the policy receives one update per VECTOR step (1 / 4096 of
         # the reference's learning per env step) -- it mostly measures how early in training the window sits.  The figure that
         # is comparable with the reference's 3000-step single-env runs is constraint_violation_rate_n1 below.
+        **({"control_flow_check": "gloo%s: control-flow check of the N > 1 path, NOT a scaling figure (the measured "
+                                  "configuration is one rank per GPU over RCCL)" % (", %d ranks time-slicing %d GPU(s)" % (
+                                      world, torch.cuda.device_count()) if shared_gpu else "")}
+           if (world > 1 and args.backend == "gloo") else {}),
         "constraint_violation_rate_vector_cadence": tr.viol_rate,
         "constraint_violation_window": "%d vector steps x %d envs" % (tr._t, n_total),
         "mean_projection_iters": tr.proj_iters_mean,
@@ -909,7 +935,8 @@ def roofline(clinic, workload):
          "note": "dominant launch of the iteration at the bench size (latency-bound: %d units per launch); "
                  "all_kernels lists every launch of one policy_fre period with its own roofline" % d["n"],
          "all_kernels": {k: {kk: vv for kk, vv in v.items() if kk in ("us", "rate", "unit", "frac", "bound", "n",
-                                                                     "launches_per_period", "regime", "frac_of_achievable")}
+                                                                     "launches_per_period", "regime", "frac_of_achievable",
+                                                                     "moved_bytes_per_lane", "moved_bytes_per_sample")}
                          for k, v in clinic.items()}}
     st = clinic.get("cartsafe_step_kernel@1M")
     if st is not None:

@@ -40,7 +40,7 @@ extern "C" {
 /* 3: rpo_split_update gained proj_ws / proj_store_mode / debug (the struct grew); rpo_split_critic_pfront*,
  * rpo_pendulum_project_batchref_ws; rpo_evopf_complete_bwd takes grad_action_b / grad_action2, rpo_evopf_lagrangian takes overwrite;
  * rpo_min_q_bwd, rpo_hw_probe */
-#define RPO_ABI_VERSION 4
+#define RPO_ABI_VERSION 5
 
 #define RPO_ERR_ARG (-1)
 #define RPO_ERR_NULL (-2)
@@ -51,7 +51,10 @@ extern "C" {
 #define RPO_CART_ROW 24
 #define RPO_CART_RING 32 /* floats between consecutive rows of the REPLAY RING: a 96-byte transition per 128-byte line, so a random
                             row is one line (96-byte spacing: 1.5 lines on average -- gather traffic 1.58 x, round 3); the last
-                            8 floats of a ring row are never written or read.  Gathered batches stay RPO_CART_ROW wide. */
+                            8 floats of a ring row are PADDING: the step kernel's full-tile path writes zeros there (whole
+                            128-byte lines leave the CU), its partial-tile path leaves them alone, and no kernel reads them.
+                            Gathered batches stay RPO_CART_ROW wide.  The stride is compiled into the step / rollout / rider /
+                            fused-sampling kernels: a ring must be [rows, RPO_CART_RING] floats (rpo_amd/ops.py refuses others). */
 #define RPO_CART_CONSTS_LEN 35 /* C[2] C_p C_o_inv b G[12] d[6] G_r[6] d_r[6], cartpole.py:124-136,397-400 */
 
 #define RPO_PEND_INTERNAL_DIM 4
@@ -86,9 +89,13 @@ extern "C" {
 #define RPO_EVOPF_C_QUAD 468
 #define RPO_EVOPF_C_LIN 473
 #define RPO_EVOPF_C_CONST 478
-#define RPO_EVOPF_C_FLAGS 479 /* 0: eliminate in the compiled-in static order of the case14 network (sparse; falls back to partial
-                                 pivoting per solve when a pivot is < 2^-6 of the largest one); != 0: always partial pivoting
-                                 (the host sets it when the uploaded Ybus has entries outside case14's branch pattern) */
+#define RPO_EVOPF_C_FLAGS 479 /* 1.0f (RPO_EVOPF_STATIC_OK): eliminate in the compiled-in static order of the case14 network (sparse;
+                                 falls back to partial pivoting per solve when a pivot is < 2^-6 of the largest one) -- set ONLY by a
+                                 host that has checked that every non-zero Ybus entry lies inside case14's branch pattern
+                                 (rpo_amd/ops.py EvopfKernels; a skipped non-zero column gives a wrong answer, not a small pivot).
+                                 Anything else -- in particular the 0 a table built by other code carries there -- = always
+                                 partial pivoting: the safe choice is the default (ABI 5; the meaning was inverted in ABI 4). */
+#define RPO_EVOPF_STATIC_OK 1.0f
 #define RPO_EVOPF_C_PS 480
 #define RPO_EVOPF_C_SHARE 504
 #define RPO_EVOPF_C_QSIGN 518
@@ -139,6 +146,21 @@ extern "C" {
 #define RPO_STREAM_EVOPF_PRICE 6  /* episode price profile: magnitude + hourly noise   (data/price.py:41-43)  */
 
 int rpo_abi_version(void);
+
+/* Kernel-variant switches: process-wide integers the launch code reads on every call (the library reads NO environment
+ * variable).  They select between kernels that compute the same values (bit-equal, or to summation round-off where a test
+ * says so) and exist for A/B tests and measurements; the defaults are what is shipped and measured.
+ * rpo_tuning(key, value): sets `key` to `value` and returns the previous value; value < 0 only queries; RPO_ERR_ARG for an
+ * unknown key.  Not thread-safe against concurrent launches (one host thread per device, as everywhere in this ABI). */
+#define RPO_TUNE_FWD_STREAM 0       /* 1: large-n forward (n >= 12288, 128 -> 256 scalar heads) through the weights-in-LDS
+                                       streaming kernel (mlp_stream.h); 0: the 64-row tile kernel of rounds 3-4 */
+#define RPO_TUNE_FWD_STREAM_WAVES 1 /* waves per workgroup of that kernel: 12 (default, <= 168 registers) or 16 (<= 128) */
+#define RPO_TUNE_BWD_ONEPASS 2      /* 1: large-batch backward in one pass over the activations; 0: rows pass + split-K weights pass */
+#define RPO_TUNE_GEMM_KSPLIT 3      /* 1: K >= 256 layer launches split k over the four waves of a workgroup; 0: one chain */
+#define RPO_TUNE_MLP_GEMM 4         /* 1: 256-wide networks layer by layer (mlp_gemm.h); 0: row-tile kernels */
+#define RPO_TUNE_ROLLOUT_WIDE 5     /* fused rollout: 0 16-lane tiles, 1 64-lane tiles, 2 (default) by lane count */
+#define RPO_TUNE_COUNT 6
+int rpo_tuning(int key, int value);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Philox4x32-10 (Salmon et al., SC'11), the build's counter-based RNG: key = seed, counter = (id, index, stream, sub);

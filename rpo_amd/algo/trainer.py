@@ -1034,7 +1034,7 @@ class RPOTrainerBase(object):
         if self._rider_cache is None:
             scale, base = self._box_affine
             self._rider_cache = self.backend.RolloutRider(
-                n_envs=v.internal.shape[0], gauss=int(self._gauss_policy), scale=scale, base=base, state=v.internal,
+                ring_floats=self.kernels.ring_floats, n_envs=v.internal.shape[0], gauss=int(self._gauss_policy), scale=scale, base=base, state=v.internal,
                 obs=None if v.obs is v.internal else v.obs, action=v.action, ep_len=v.ep_len, ep_ret=v.ep_ret,
                 ep_count=v.ep_count, stats=v.stats, stats_cap=v.stats.shape[0], ctrl=v.ctrl,
                 noise_mode=hip_ops.NOISE_NONE if self._gauss_policy else hip_ops.NOISE_PHILOX, eps_start=self.eps_start,

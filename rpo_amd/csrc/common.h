@@ -17,6 +17,11 @@
         if (e__ != hipSuccess) return (int)e__;   \
     } while (0)
 
+// Kernel-variant switches (include/rpo_hip.h: rpo_tuning, RPO_TUNE_*): one process-wide table, defined in train_ops.hip,
+// read by the launch code on every call (no getenv in the library).
+extern int g_rpo_tune[RPO_TUNE_COUNT];
+static inline int rpo_tune(int key) { return g_rpo_tune[key]; }
+
 static inline int rpo_grid_for(long long n, int per_block = RPO_BLOCK) {
     long long g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(RPO_WAVE * kActWaves) void evopf_complete_bwd_kerne
     }
     sync();
     // step 1 (:889-891): d_int = inv(J_newton)^T dl_dy_total[newton vars]
-    const bool force_dyn = w.c[RPO_EVOPF_C_FLAGS] != 0.0f;
+    const bool force_dyn = w.c[RPO_EVOPF_C_FLAGS] != RPO_EVOPF_STATIC_OK;
     bool solved = false;
     float dint = 0.0f;
     int mycol = tid;

@@ -52,7 +52,8 @@ __device__ constexpr int kPartialActions[NP] = {1, 2, 3, 4, 10, 11, 12, 15, 17, 
 // Accuracy: on 1500 sampled Jacobians (solved states, GRG-like and gross perturbations, Newton's flat start) the static order's
 // inverse is as close to the float64 one as partial pivoting's (median 1.5e-7, same p99) whenever min|pivot| / max|pivot| >
 // 2^-6; below that (gross perturbations only: near-singular Jacobians) the wave falls back to the partial-pivoting elimination
-// (gauss_jordan_rows) -- a wave-uniform branch, see pivots_ok().  RPO_EVOPF_C_FLAGS != 0 forces the fallback (A/B tests).
+// (gauss_jordan_rows) -- a wave-uniform branch, see pivots_ok().  RPO_EVOPF_C_FLAGS != RPO_EVOPF_STATIC_OK forces the fallback
+// (the default of a table nobody validated; A/B tests).
 // The first six "other" variables (slack pg, qg) appear in exactly one equation each with coefficient 1 (P at the slack bus,
 // Q at the generator buses): with these rows first the leading 6 x 6 block is the identity and the elimination starts at 6.
 __device__ constexpr int kBusOrder[NB - 1] = {2, 7, 11, 10, 13, 4, 12, 9, 8, 6, 3, 1, 5};
@@ -629,7 +630,7 @@ __device__ __forceinline__ int complete_partial_v2(Ws& w, const RowLane& L, floa
     sync();
     if (tid < NP) w.a[kPartialActions[tid]] = zj;              // (:796-799)
     sync();
-    const bool force_dyn = w.c[RPO_EVOPF_C_FLAGS] != 0.0f;
+    const bool force_dyn = w.c[RPO_EVOPF_C_FLAGS] != RPO_EVOPF_STATIC_OK;
     int it = 0;
     for (; it < max_iters;) {
         const Volt v = own_volt(w, L);
@@ -696,7 +697,7 @@ __device__ __forceinline__ bool grg_iteration_v2(Ws& w, const RowLane& L, bool f
     const float g = tid < NY ? ((up > 0.0f ? 1.0f : 0.0f) - (dn > 0.0f ? 1.0f : 0.0f)) : 0.0f;
     w.vec[L.colpos] = g;                                       // (lanes >= NY park a zero in slot NY: never read)
     sync();
-    const bool force_dyn = w.c[RPO_EVOPF_C_FLAGS] != 0.0f;
+    const bool force_dyn = w.c[RPO_EVOPF_C_FLAGS] != RPO_EVOPF_STATIC_OK;
     const float isx = L.is_extra ? 1.0f : 0.0f;
     float fp[NPV];
     float dsum = 0.0f;                                         // row lanes: sum_p row[NO + p] fp[p] / pivot = (D fp)[mycol]

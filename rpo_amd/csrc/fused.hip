@@ -111,10 +111,10 @@ __global__ __launch_bounds__(kFwdThreads) void rollout_kernel(RolloutArgs<ENV> p
 template <class ENV>
 int launch_rollout(const RolloutArgs<ENV>& args, const typename ENV::Consts& c, int n_envs, void* stream) {
     // 64 lanes per workgroup once that still fills the chip: the 128 KB hidden-layer matrix is streamed once per
-    // workgroup, so wider tiles cut the L2 traffic 4x (RPO_ROLLOUT_WIDE=0/1 overrides the size rule)
-    const char* wide_env = getenv("RPO_ROLLOUT_WIDE");
+    // workgroup, so wider tiles cut the L2 traffic 4x (rpo_tuning(RPO_TUNE_ROLLOUT_WIDE, 0 / 1) overrides the size rule)
+    const int wide_sel = rpo_tune(RPO_TUNE_ROLLOUT_WIDE);        // 0 / 1: forced (tests), 2: by size
     const int E = args.actor.E;
-    const bool wide = E == 128 && (wide_env ? atoi(wide_env) != 0 : n_envs >= 64 * 192);
+    const bool wide = E == 128 && (wide_sel != 2 ? wide_sel != 0 : n_envs >= 64 * 192);
     if (E == 128 && wide) {
         hipLaunchKernelGGL((rollout_kernel<ENV, 128, 256, 4>), dim3((n_envs + 63) / 64), dim3(kFwdThreads), 0,
                            (hipStream_t)stream, args, c);

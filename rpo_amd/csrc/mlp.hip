@@ -20,6 +20,7 @@
 #include "mlp_bwd.h"
 #include "mlp_gemm.h"
 #include "mlp_tile.h"
+#include "mlp_stream.h"
 
 namespace {
 
@@ -77,6 +78,45 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_forward_multi_kernel(FwdArgs4
 template <int H>
 __global__ __launch_bounds__(kFwdThreads, 4) void mlp_forward_multi64_kernel(FwdArgs4 p) {     // 64 rows per workgroup (large n)
     mlp_forward_body<128, H, 4, 8, 8>(p.net[blockIdx.y]);
+}
+
+// Large n: weights stationary in LDS, rows stream through independent waves (mlp_stream.h); gridDim.y = network.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void mlp_forward_stream_kernel(FwdArgs4 p) {
+    mlp_forward_stream_body<256, NW>(p);
+}
+
+static int stream_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            cus = v;
+        else
+            cus = 256;
+    }
+    return cus;
+}
+
+// the streaming forward applies: large n, every network of the launch 128 -> 256 with scalar heads and <= 11 inputs
+static bool stream_applies(const FwdArgs4& a, int count, int n) {
+    if (!rpo_tune(RPO_TUNE_FWD_STREAM) || n < 64 * 192) return false;
+    for (int k = 0; k < count; ++k)
+        if (!stream_shape_ok(a.net[k].net)) return false;
+    return true;
+}
+
+static int launch_stream(const FwdArgs4& a, int count, int n, hipStream_t stream) {
+    const int nw = rpo_tune(RPO_TUNE_FWD_STREAM_WAVES) == 16 ? 16 : 12;
+    const int tiles = (n + kRows - 1) / kRows;
+    int gx = stream_cus() / count;                              // one persistent workgroup per CU (LDS: 150 KB each)
+    if (gx < 1) gx = 1;
+    if (gx > (tiles + nw - 1) / nw) gx = (tiles + nw - 1) / nw;
+    if (nw == 16) hipLaunchKernelGGL((mlp_forward_stream_kernel<16>), dim3(gx, count), dim3(16 * 64), 0, stream, a);
+    else hipLaunchKernelGGL((mlp_forward_stream_kernel<12>), dim3(gx, count), dim3(12 * 64), 0, stream, a);
+    RPO_LAUNCH_CHECK();
+    return 0;
 }
 
 // Multi-output networks (hd > 1, e.g. the 14 basic actions of EVOPF-v0): same tile, MFMA head, raw outputs
@@ -225,6 +265,11 @@ int rpo_mlp_forward(const rpo_mlp* net_host, int n, const float* s, int s_stride
         RPO_MLP_FWD_WIDE(256, 256)
         return RPO_ERR_ARG;
     }
+    {
+        FwdArgs4 one{};
+        one.net[0] = args;
+        if (stream_applies(one, 1, n)) return launch_stream(one, 1, n, (hipStream_t)stream);
+    }
     // 64 rows per workgroup once that still fills the chip (and the inputs fit the narrow LDS tiles); else 16
     const bool wide = n >= 64 * 192 && net.S <= 8 && net.A <= 8 && ein == 128;   // (LDS: 64 x 132 floats of x1)
 #define RPO_MLP_FWD(EIN_, H_)                                                                                          \
@@ -319,6 +364,7 @@ int rpo_mlp_forward_multi(int count, const rpo_mlp* const* nets, int n, const fl
             return gemm_forward(f, count, (hipStream_t)stream);
         }
     }
+    if (stream_applies(args, count, n)) return launch_stream(args, count, n, (hipStream_t)stream);
     if (n >= 64 * 192 && net.S <= 8 && net.A <= 8 && ein == 128 && net.H == 256) {   // as rpo_mlp_forward: 64-row tiles
         hipLaunchKernelGGL((mlp_forward_multi64_kernel<256>), dim3((n + 63) / 64, count), dim3(kFwdThreads), 0,
                            (hipStream_t)stream, args);

@@ -1036,8 +1036,7 @@ static inline bool onepass_applies(const BwdArgs& args, const SplitK& k) {
     if (EIN != 128 || H != 256 || net.cat || net.hd > 1 || net.S > 8 || net.A > 8 || !args.param_grads || args.first_layer_state_only ||
         args.da || k.Z < 2)
         return false;
-    const char* e = getenv("RPO_BWD_ONEPASS");
-    return !(e && e[0] == '0');
+    return rpo_tune(RPO_TUNE_BWD_ONEPASS) != 0;
 }
 
 // Launches the one-pass backward (caller checked onepass_applies): 0 or an RPO_ERR_* / hipError code.

@@ -263,8 +263,7 @@ __global__ __launch_bounds__(kGemmThreads) void mlp_gemm_ksplit_kernel(GemmArgs4
 }
 
 static inline bool gemm_ksplit_enabled() {
-    const char* e = getenv("RPO_GEMM_KSPLIT");
-    return !(e && e[0] == '0');
+    return rpo_tune(RPO_TUNE_GEMM_KSPLIT) != 0;
 }
 
 template <bool W_NK>
@@ -319,10 +318,9 @@ struct GemmFwd { Mlp net; int n; const float* s; int s_stride; const float* a; i
 // DESIGN.md 4b, commit "mlp_gemm: first layer inside the hidden layer's launch".)
 
 // The layer-by-layer path applies to the wide networks at update-batch sizes when the caller provides x0 / h1 buffers
-// (RPO_MLP_GEMM=0 keeps the row-tile kernels: the A/B switch of the tests).
+// (rpo_tuning(RPO_TUNE_MLP_GEMM, 0) keeps the row-tile kernels: the A/B switch of the tests).
 static inline bool gemm_path_enabled() {
-    const char* e = getenv("RPO_MLP_GEMM");                     // (read per call: the tests switch it inside one process)
-    return !(e && e[0] == '0');
+    return rpo_tune(RPO_TUNE_MLP_GEMM) != 0;                    // (read per call: the tests switch it inside one process)
 }
 static inline bool gemm_path_ok(const Mlp& net, int n, const void* x0, const void* h1, int out_mode) {
     return gemm_path_enabled() && net.E == 256 && net.H == 256 && x0 && h1 && out_mode == 0 && n <= 16384;

@@ -228,6 +228,10 @@ __global__ __launch_bounds__(RPO_BLOCK) void philox_normal_kernel(int n, float* 
 
 }  // namespace
 
+// defaults of the kernel-variant switches (RPO_TUNE_* order)
+int g_rpo_tune[RPO_TUNE_COUNT] = {/* FWD_STREAM */ 1, /* FWD_STREAM_WAVES */ 12, /* BWD_ONEPASS */ 1, /* GEMM_KSPLIT */ 1,
+                                  /* MLP_GEMM */ 1, /* ROLLOUT_WIDE: 2 = by size */ 2};
+
 extern "C" {
 
 int rpo_philox_normal(int n, float* out, unsigned long long seed, unsigned id_base, unsigned salt,
@@ -241,6 +245,13 @@ int rpo_philox_normal(int n, float* out, unsigned long long seed, unsigned id_ba
 }
 
 int rpo_abi_version(void) { return RPO_ABI_VERSION; }
+
+int rpo_tuning(int key, int value) {
+    if (key < 0 || key >= RPO_TUNE_COUNT) return RPO_ERR_ARG;
+    const int old = g_rpo_tune[key];
+    if (value >= 0) g_rpo_tune[key] = value;
+    return old;
+}
 
 int rpo_philox_fill(int n, unsigned* out, unsigned long long seed, unsigned id_base, unsigned index,
                     unsigned stream_tag, void* stream) {

@@ -29,6 +29,42 @@ STAT = {k[len("RPO_STAT_"):].lower(): v for k, v in CONST.items()
         if k.startswith("RPO_STAT_") and k not in ("RPO_STATS_LEN", "RPO_STATS_SUB")}
 
 
+TUNE = {k[len("RPO_TUNE_"):].lower(): v for k, v in CONST.items() if k.startswith("RPO_TUNE_") and k != "RPO_TUNE_COUNT"}
+
+
+class tuning(object):
+    """Kernel-variant switches of the library (include/rpo_hip.h: rpo_tuning, RPO_TUNE_*; the library reads no environment
+    variable).  ``tuning(fwd_stream=0)`` sets them at once; used as a context manager the previous values come back on exit:
+
+        with ops.tuning(bwd_onepass=0):
+            ...                                  # the two-launch backward
+    ``tuning.get(name)`` queries one.  A/B tests and measurements only: the defaults are what ships."""
+
+    def __init__(self, **values):
+        lib = _lib.load()
+        self._old = {}
+        for name, value in values.items():
+            if name not in TUNE:
+                raise RpoHipError("unknown tuning key %r (have: %s)" % (name, ", ".join(sorted(TUNE))))
+            old = lib.rpo_tuning(TUNE[name], int(value))
+            if old < 0:
+                raise RpoHipError("rpo_tuning(%s) failed" % name)
+            self._old[name] = old
+
+    @staticmethod
+    def get(name):
+        return _lib.load().rpo_tuning(TUNE[name], -1)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        lib = _lib.load()
+        for name, old in self._old.items():
+            lib.rpo_tuning(TUNE[name], old)
+        return False
+
+
 def new_stats(stats_cap, device):
     """Statistics buffer [stats_cap, RPO_STATS_SUB, RPO_STATS_LEN] (see include/rpo_hip.h)."""
     return torch.zeros(int(stats_cap), STATS_SUB, STATS_LEN, device=device)
@@ -75,6 +111,18 @@ def _col_view(t):
             raise RpoHipError("expected [n,1], got %s" % (tuple(t.shape),))
         return _p(t, contiguous=False), int(t.stride(0))
     return _p(t, contiguous=False), int(t.stride(0))
+
+
+def _ring(rows, ring_floats, allow_none=True):
+    """Pointer of a replay ring [cap_steps * n_envs, ring_floats].  The ring stride is a COMPILE-TIME constant of the step,
+    rollout, rider and fused-sampling kernels (RPO_CART_RING / RPO_PEND_RING / RPO_EVOPF_ROW): a ring of another width --
+    e.g. [., row_floats] rows of ABI <= 3 callers -- would be written and read out of bounds, so it is refused here."""
+    if rows is None:
+        return _p(rows, allow_none=allow_none)
+    if rows.dim() != 2 or rows.shape[-1] != ring_floats:
+        raise RpoHipError("replay ring must be [rows, %d] float32 (the kernels' compiled ring stride), got %s"
+                          % (ring_floats, tuple(rows.shape)))
+    return _p(rows)
 
 
 def _host_ptr(arr):
@@ -215,7 +263,7 @@ class CartSafeKernels(object):
              auto_reset, viol_thresh, seed, env_id_base):
         check(_lib.load().rpo_cartsafe_step(
             internal.shape[0], _p(internal), _p(action), _p(ep_len, torch.int32), _p(ep_ret),
-            _p(ep_count, torch.int32), _p(rows, allow_none=True), cap_steps, _p(stats, allow_none=True),
+            _p(ep_count, torch.int32), _ring(rows, self.ring_floats), cap_steps, _p(stats, allow_none=True),
             0 if stats is None else stats.shape[0], _p(ctrl, torch.int64, allow_none=True), self._cptr, self.partial,
             max_episode_steps, int(auto_reset), viol_thresh, seed, env_id_base, _stream()), "rpo_cartsafe_step")
 
@@ -235,7 +283,7 @@ class CartSafeKernels(object):
         net = actor_desc.net_struct()
         check(_lib.load().rpo_cartsafe_rollout(
             ctypes.byref(net), int(gauss), scale, base, internal.shape[0], _p(internal), _p(action),
-            _p(ep_len, torch.int32), _p(ep_ret), _p(ep_count, torch.int32), _p(rows, allow_none=True), cap_steps,
+            _p(ep_len, torch.int32), _p(ep_ret), _p(ep_count, torch.int32), _ring(rows, self.ring_floats), cap_steps,
             _p(stats, allow_none=True), 0 if stats is None else stats.shape[0], _p(ctrl, torch.int64), noise_mode,
             eps_start, eps_end, eps_decay, box_lo, box_hi, max_steps, corr_lr, corr_eps, corr_momentum, self._cptr,
             self.partial, max_episode_steps, int(auto_reset), viol_thresh, seed, env_id_base, int(defer_clock), _stream()),
@@ -246,7 +294,7 @@ class CartSafeKernels(object):
                             q_out, qn_out, x0_save, h1_save):
         at, ct, cr = actor_target.net_struct(), critic_target.net_struct(), critic.net_struct()
         check(_lib.load().rpo_cartsafe_ddpg_critic_forward(
-            ctypes.byref(at), ctypes.byref(ct), ctypes.byref(cr), scale, base, _p(rows), cap_steps, n_envs,
+            ctypes.byref(at), ctypes.byref(ct), ctypes.byref(cr), scale, base, _ring(rows, self.ring_floats, False), cap_steps, n_envs,
             batch_out.shape[0], _p(batch_out), _p(idx_out, torch.int64, allow_none=True),
             _p(idx_in, torch.int64, allow_none=True), seed, salt, _p(ctrl, torch.int64), max_steps, corr_lr, corr_eps,
             corr_momentum, box_lo, box_hi, self._cptr, self.partial, _p(q_out), _p(qn_out), _p(x0_save), _p(h1_save),
@@ -258,7 +306,7 @@ class CartSafeKernels(object):
                            q1_out, q2_out, qn1_out, qn2_out, logp_out, x0_save1, h1_save1, x0_save2, h1_save2):
         nets = [d.net_struct() for d in (actor, critic_target1, critic_target2, critic1, critic2)]
         check(_lib.load().rpo_cartsafe_sac_critic_forward(
-            *[ctypes.byref(n) for n in nets], scale, base, _p(rows), cap_steps, n_envs, batch_out.shape[0], _p(batch_out),
+            *[ctypes.byref(n) for n in nets], scale, base, _ring(rows, self.ring_floats, False), cap_steps, n_envs, batch_out.shape[0], _p(batch_out),
             _p(idx_out, torch.int64, allow_none=True), _p(idx_in, torch.int64, allow_none=True),
             _p(eps_in, allow_none=True), sample_seed, sample_salt, noise_seed, noise_id_base, noise_salt,
             _p(ctrl, torch.int64), max_steps, corr_lr, corr_eps, corr_momentum, box_lo, box_hi, self._cptr, self.partial,
@@ -310,7 +358,8 @@ class EvopfKernels(object):
         yr, yi = (self.consts[CONST[k]:CONST[k] + 196].reshape(14, 14) for k in ("RPO_EVOPF_C_YR", "RPO_EVOPF_C_YI"))
         inside = np.array([[(m >> k) & 1 for k in range(14)] for m in self.CASE14_ADJ], dtype=bool)
         dynamic = bool((((yr != 0) | (yi != 0)) & ~inside).any()) or os.environ.get("RPO_EVOPF_PIVOT", "") == "dynamic"
-        self.consts[CONST["RPO_EVOPF_C_FLAGS"]] = 1.0 if dynamic else 0.0
+        # 1.0 = "validated: static order allowed"; everything else (the 0 of a table built elsewhere) = partial pivoting
+        self.consts[CONST["RPO_EVOPF_C_FLAGS"]] = 0.0 if dynamic else 1.0
         self.static_order = not dynamic
         self._dev = {}
 
@@ -329,7 +378,7 @@ class EvopfKernels(object):
              auto_reset, viol_thresh, seed, env_id_base):
         check(_lib.load().rpo_evopf_step(
             internal.shape[0], _p(internal), _p(action), _p(ep_len, torch.int32), _p(ep_ret), _p(ep_count, torch.int32),
-            _p(rows, allow_none=True), cap_steps, _p(stats, allow_none=True), 0 if stats is None else stats.shape[0],
+            _ring(rows, self.ring_floats), cap_steps, _p(stats, allow_none=True), 0 if stats is None else stats.shape[0],
             _p(ctrl, torch.int64, allow_none=True), max_episode_steps, int(auto_reset), viol_thresh, self._c(internal),
             seed, env_id_base, _stream()), "rpo_evopf_step")
 
@@ -414,7 +463,7 @@ class PendulumKernels(object):
              auto_reset, viol_thresh, seed, env_id_base):
         check(_lib.load().rpo_pendulum_step(
             internal.shape[0], _p(internal), _p(obs, allow_none=True), _p(action), _p(ep_len, torch.int32), _p(ep_ret),
-            _p(ep_count, torch.int32), _p(rows, allow_none=True), cap_steps, _p(stats, allow_none=True),
+            _p(ep_count, torch.int32), _ring(rows, self.ring_floats), cap_steps, _p(stats, allow_none=True),
             0 if stats is None else stats.shape[0], _p(ctrl, torch.int64, allow_none=True), max_episode_steps,
             int(auto_reset), viol_thresh, seed, env_id_base, _stream()), "rpo_pendulum_step")
 
@@ -434,7 +483,7 @@ class PendulumKernels(object):
         net = actor_desc.net_struct()
         check(_lib.load().rpo_pendulum_rollout(
             ctypes.byref(net), int(gauss), scale, base, internal.shape[0], _p(internal), _p(obs, allow_none=True),
-            _p(action), _p(ep_len, torch.int32), _p(ep_ret), _p(ep_count, torch.int32), _p(rows, allow_none=True),
+            _p(action), _p(ep_len, torch.int32), _p(ep_ret), _p(ep_count, torch.int32), _ring(rows, self.ring_floats),
             cap_steps, _p(stats, allow_none=True), 0 if stats is None else stats.shape[0], _p(ctrl, torch.int64),
             noise_mode, eps_start, eps_end, eps_decay, box_lo, box_hi, max_steps, corr_lr, corr_eps, corr_momentum,
             max_episode_steps, int(auto_reset), viol_thresh, seed, env_id_base, int(defer_clock), _stream()),
@@ -444,7 +493,7 @@ class PendulumKernels(object):
                           sample_salt, ctrl, ap_out):
         net = actor_target.net_struct()
         check(_lib.load().rpo_pendulum_ddpg_critic_front(
-            ctypes.byref(net), scale, base, _p(rows), cap_steps, n_envs, batch_out.shape[0], _p(batch_out),
+            ctypes.byref(net), scale, base, _ring(rows, self.ring_floats, False), cap_steps, n_envs, batch_out.shape[0], _p(batch_out),
             _p(idx_out, torch.int64, allow_none=True), _p(idx_in, torch.int64, allow_none=True), sample_seed, sample_salt,
             _p(ctrl, torch.int64), _p(ap_out), _stream()), "rpo_pendulum_ddpg_critic_front")
 
@@ -458,7 +507,7 @@ class PendulumKernels(object):
                          eps_in, sample_seed, sample_salt, noise_seed, noise_id_base, noise_salt, ctrl, ap_out, logp_out):
         net = actor.net_struct()
         check(_lib.load().rpo_pendulum_sac_critic_front(
-            ctypes.byref(net), scale, base, box_lo, box_hi, _p(rows), cap_steps, n_envs, batch_out.shape[0], _p(batch_out),
+            ctypes.byref(net), scale, base, box_lo, box_hi, _ring(rows, self.ring_floats, False), cap_steps, n_envs, batch_out.shape[0], _p(batch_out),
             _p(idx_out, torch.int64, allow_none=True), _p(idx_in, torch.int64, allow_none=True),
             _p(eps_in, allow_none=True), sample_seed, sample_salt, noise_seed, noise_id_base, noise_salt,
             _p(ctrl, torch.int64), _p(ap_out), _p(logp_out), _stream()), "rpo_pendulum_sac_critic_front")
@@ -819,13 +868,16 @@ class RolloutRider(object):
 
     _DTYPES = dict(ep_len=torch.int32, ep_count=torch.int32, ctrl=torch.int64)
 
-    def __init__(self, **fields):
-        self.st, self._held = _RolloutRiderStruct(), {}
+    def __init__(self, ring_floats=None, **fields):
+        """``ring_floats``: the env kernel set's ring stride; `rows=` tensors of another width are refused (`_ring`)."""
+        self.st, self._held, self.ring_floats = _RolloutRiderStruct(), {}, ring_floats
         self.set(**fields)
 
     def set(self, **fields):
         for k, v in fields.items():
             if isinstance(v, torch.Tensor):
+                if k == "rows" and self.ring_floats is not None:
+                    _ring(v, self.ring_floats)
                 self._held[k] = v
                 setattr(self.st, k, _p(v, self._DTYPES.get(k, torch.float32)).value)
             else:
@@ -843,7 +895,7 @@ class SplitUpdate(object):
     def __init__(self, env_kernels, descs, twin, batch, fields):
         """descs: name -> MlpDesc for actor, actor_target (RPODDPG), critic1, critic2, critic_target1, critic_target2;
         fields: remaining struct fields (tensors become device pointers, Python scalars are copied)."""
-        self._keep, self._held = [], {}
+        self._keep, self._held, self.ring_floats = [], {}, env_kernels.ring_floats
         st = self.st = _SplitUpdateStruct()
         for name in ("actor", "actor_target", "critic1", "critic2", "critic_target1", "critic_target2"):
             d = descs.get(name)
@@ -871,6 +923,8 @@ class SplitUpdate(object):
                     (torch.int32 if k in ("proj_iters", "prep_step", "tile_sync") else torch.float32)
                 if k == "proj_ws":
                     dt = torch.int64
+                if k == "rows":                                     # the fused sampling reads rows at the compiled ring stride
+                    _ring(v, self.ring_floats)
                 self._held[k] = v                                   # keeps the buffer alive while the struct points at it
                 setattr(self.st, k, _p(v, dt).value)
             else:

@@ -61,9 +61,10 @@ class ReplayBuffer(object):
             self.sample_ctrl[0] = self._steps_host
 
     def sample_rows(self, num, out=None, idx_out=None, salt=0):
-        """Uniform-with-replacement draw + gather of ``num`` rows (buffer.py:31-34) -> [num, W] device tensor."""
+        """Uniform-with-replacement draw + gather of ``num`` rows (buffer.py:31-34) -> [num, row_floats] device tensor (a
+        transition is the first `row_floats` floats of a ring row; the ring's padding is not part of a sample)."""
         if out is None:
-            out = torch.empty(num, self.rows.shape[1], device=self.device)
+            out = torch.empty(num, self.kernels.row_floats, device=self.device)
         self._ops.replay_sample_gather(self.rows, self.capacity, self.n_envs, out, idx_out, self.seed, salt, self.sample_ctrl)
         return out
 

@@ -209,7 +209,8 @@ def test_evopf_static_order_is_refused_for_another_network():
     C = ops.CONST
     table = case14.kernel_constants(C, C["RPO_EVOPF_CONSTS_LEN"])
     k = ops.EvopfKernels(table)
-    assert k.static_order and k.consts[C["RPO_EVOPF_C_FLAGS"]] == 0.0
+    assert table[C["RPO_EVOPF_C_FLAGS"]] == 0.0                  # an unvalidated table asks for partial pivoting (the safe default)
+    assert k.static_order and k.consts[C["RPO_EVOPF_C_FLAGS"]] == 1.0
     yr = table[C["RPO_EVOPF_C_YR"]:C["RPO_EVOPF_C_YR"] + 196].reshape(14, 14)
     inside = np.array([[(m >> j) & 1 for j in range(14)] for m in ops.EvopfKernels.CASE14_ADJ], dtype=bool)
     yi = table[C["RPO_EVOPF_C_YI"]:C["RPO_EVOPF_C_YI"] + 196].reshape(14, 14)
@@ -217,7 +218,7 @@ def test_evopf_static_order_is_refused_for_another_network():
     other = table.copy()
     other[C["RPO_EVOPF_C_YR"] + 0 * 14 + 13] = 0.5              # a branch 1 - 14 that case14 does not have
     k2 = ops.EvopfKernels(other)
-    assert not k2.static_order and k2.consts[C["RPO_EVOPF_C_FLAGS"]] == 1.0
+    assert not k2.static_order and k2.consts[C["RPO_EVOPF_C_FLAGS"]] == 0.0
     os.environ["RPO_EVOPF_PIVOT"] = "dynamic"
     try:
         assert not ops.EvopfKernels(table).static_order

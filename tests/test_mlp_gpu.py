@@ -109,13 +109,9 @@ def test_mlp_forward_backward_match_torch(kind, S, A, E, H, n):
         assert torch.equal(out, out2)
         # hidden layer / heads with the k range split over the four waves of a workgroup (default, csrc/mlp_gemm.h) vs the
         # one-chain kernel: the same sums in another (fixed) order
-        import os
         x0b, h1b = torch.full_like(x0, float("nan")), torch.full_like(h1, float("nan"))
-        os.environ["RPO_GEMM_KSPLIT"] = "0"
-        try:
+        with ops.tuning(gemm_ksplit=0):
             ops.mlp_forward(d, s, a, out2, x0b, h1b)
-        finally:
-            os.environ.pop("RPO_GEMM_KSPLIT")
         assert torch.equal(x0, x0b)                           # (first layers: K <= 64, never split)
         np.testing.assert_allclose(h1.cpu().numpy(), h1b.cpu().numpy(), rtol=1e-5, atol=2e-6)
         np.testing.assert_allclose(out.cpu().numpy(), out2.cpu().numpy(), rtol=1e-5, atol=2e-6)

@@ -411,23 +411,26 @@ def test_wide_rollout_tiles_are_bitwise_identical(hip, monkeypatch):
     """The 64-lane-per-workgroup rollout pipeline (used from 12 288 lanes up) and the 16-lane one compute the same
     bits: same per-row arithmetic, only the work distribution differs.  Same for the wide MLP forward."""
     dev = torch.device("cuda")
-    monkeypatch.setenv("RPO_ROLLOUT_WIDE", "0")
-    a = _run("ddpg", "cart", hip, dev, 12, 1000, use_graph=False)
-    monkeypatch.setenv("RPO_ROLLOUT_WIDE", "1")
-    b = _run("ddpg", "cart", hip, dev, 12, 1000, use_graph=False)
+    with hip.tuning(rollout_wide=0):
+        a = _run("ddpg", "cart", hip, dev, 12, 1000, use_graph=False)
+    with hip.tuning(rollout_wide=1):
+        b = _run("ddpg", "cart", hip, dev, 12, 1000, use_graph=False)
     assert torch.equal(a.vec.internal, b.vec.internal) and torch.equal(a.buffer.rows, b.buffer.rows)
     assert torch.equal(a.agent.flat.data, b.agent.flat.data)
     # statistics are float sums over differently shaped workgroups: equal up to summation order
     np.testing.assert_allclose(hip.reduce_stats(a.vec.stats[:12]).cpu().numpy(),
                                hip.reduce_stats(b.vec.stats[:12]).cpu().numpy(), rtol=1e-5, atol=1e-9)
-    # generic forward: n >= 12288 takes the wide path, a 4096-row slice of the same input the narrow one
+    # generic forward: n >= 12288 takes the streaming kernel (weights in LDS, round 5; 12 or 16 waves per workgroup) or, with
+    # the switch off, the 64-row tiles of rounds 3-4; a 4096-row slice of the same input the 16-row tiles: the same bits
     f = a.fused
     s = torch.randn(16384, 6, device=dev)
-    out_w = torch.empty(16384, 1, device=dev)
     out_n = torch.empty(4096, 1, device=dev)
-    f.forward("actor", s, None, out_w)
     f.forward("actor", s[:4096], None, out_n)
-    assert torch.equal(out_w[:4096], out_n)
+    for kw in (dict(fwd_stream=1, fwd_stream_waves=12), dict(fwd_stream=1, fwd_stream_waves=16), dict(fwd_stream=0)):
+        out_w = torch.empty(16384, 1, device=dev)
+        with hip.tuning(**kw):
+            f.forward("actor", s, None, out_w)
+        assert torch.equal(out_w[:4096], out_n), kw
 
 
 @pytest.mark.parametrize("n_envs", [100, 12500], ids=["16_lane_tiles", "64_lane_tiles"])

@@ -11,7 +11,11 @@ PER LANE from the transitions the step kernel wrote into the replay ring (capaci
 reference's Logger would have recorded that lane, then averaged over the 4096 lanes of a run.  Lanes of one run share one
 policy, so a RUN is one sample; the spread is over seeds.
 
-    python tools/cadence_learning.py [seeds=8] [steps=3000]      # writes gpurun_out/cadence_learning.json
+    python tools/cadence_learning.py [seeds=128] [steps=3000] [large_batch_seeds=32]   # writes gpurun_out/cadence_learning.json
+
+Round 5: 128 seeds at the reference cadence (0.12 s of GPU each) and 32 at the large batch (17 s each)
+-- 8 + 8 before, whose standard error of 1.8e-3 on the violation rate could not see the north_star's 1e-3.  The per-seed rows
+are kept in the JSON; tests/test_host_utils.py asserts the committed file's resolution and bounds on the CPU.
 """
 import json
 import os
@@ -81,7 +85,9 @@ def run_mode(mode, seeds, steps, device):
         out.append(s)
         curves.append(cv)
         print(mode, "seed", seed, json.dumps(s), file=sys.stderr, flush=True)
-        del tr
+        del tr, s, cv
+        import gc
+        gc.collect()                                              # (the 1.5 GB ring of the finished run goes before the next one comes)
         torch.cuda.empty_cache()
     keys = [k for k in out[0] if k != "seconds"]
     arr = {k: np.array([o[k] for o in out]) for k in keys}
@@ -101,10 +107,12 @@ def reference_row():
 
 
 def main():
-    seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+    seeds_lb = int(sys.argv[3]) if len(sys.argv) > 3 else max(1, seeds // 4)
     device = torch.device("cuda")
-    res = dict(reference=reference_row(), modes=[run_mode(m, seeds, steps, device) for m in ("reference_cadence", "large_batch")])
+    res = dict(reference=reference_row(), modes=[run_mode(m, n, steps, device)
+                                                 for m, n in (("reference_cadence", seeds), ("large_batch", seeds_lb)) if n > 0])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "cadence_learning.json"), "w") as f:
         json.dump(res, f, indent=1)
