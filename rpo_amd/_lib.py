@@ -9,7 +9,8 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "rpo_hip.h")
-LIBRARY = os.path.join(_HERE, "csrc", "librpo_hip.so")
+# (RPO_HIP_LIBRARY: another build of the SAME ABI, e.g. the sanitizer build csrc/librpo_hip_asan.so of tests/test_sanitizers.py)
+LIBRARY = os.environ.get("RPO_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "librpo_hip.so")
 
 _CTYPES = (
     ("unsigned long long", ctypes.c_ulonglong),

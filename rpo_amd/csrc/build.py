@@ -1,6 +1,12 @@
 """Build librpo_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-    python rpo_amd/csrc/build.py [--force]
+    python rpo_amd/csrc/build.py [--force] [--asan]
+
+``--asan`` (SURVEY 5 "race detection / sanitizers"): the HOST side of every translation unit -- the C-ABI entry points, their
+argument validation, the launch plumbing -- instrumented with AddressSanitizer + UndefinedBehaviorSanitizer into a separate
+``librpo_hip_asan.so`` (objects under asan/); the device code is compiled as usual (-fno-gpu-sanitize: GPU ASan / XNACK are not
+available on the target pool).  tests/test_sanitizers.py runs the ABI tests against it with the ASan runtime preloaded, on the
+CPU box only.
 """
 import os
 import subprocess
@@ -21,25 +27,42 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+SANITIZE = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-gpu-sanitize", "-g"]
+TARGET_ASAN = os.path.join(HERE, "librpo_hip_asan.so")
+
+
+def asan_runtime():
+    """The AddressSanitizer runtime of hipcc's clang (to LD_PRELOAD into a Python process that loads librpo_hip_asan.so)."""
+    clang = os.path.join(os.path.dirname(os.path.realpath(HIPCC)), "..", "lib", "llvm", "bin", "clang")
+    if not os.path.exists(clang):
+        clang = "/opt/rocm/lib/llvm/bin/clang"
+    return subprocess.check_output([clang, "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+
+
+def build(force=False, verbose=True, asan=False):
     hdrs = [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
     objs = []
+    obj_dir = os.path.join(HERE, "asan") if asan else HERE
+    os.makedirs(obj_dir, exist_ok=True)
+    target = TARGET_ASAN if asan else TARGET
+    flags = FLAGS + (SANITIZE if asan else [])
     for src in SOURCES:
         s = os.path.join(HERE, src)
-        o = os.path.join(HERE, src.replace(".hip", ".o"))
+        o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            cmd = [HIPCC] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-    if force or _stale(TARGET, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", TARGET] + objs
+    if force or _stale(target, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs + \
+            (["-fsanitize=address,undefined", "-shared-libsan"] if asan else [])
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return TARGET
+    return target
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, asan="--asan" in sys.argv)

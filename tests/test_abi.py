@@ -92,3 +92,36 @@ def test_split_update_stages_validate_arguments():
     for stage in ("critic_fwd_a_ride", "critic_fwd_b_ride", "critic_bwd_b_ride", "critic_front_ride", "critic_mid_ride", "critic_pfront_ride"):            # the riding rollout halves: both structs are required
         assert getattr(lib, "rpo_split_" + stage)(None, None, None) == _lib.CONST["RPO_ERR_NULL"]
     assert _lib.CONST["RPO_ABI_VERSION"] == 5
+
+
+def test_every_entry_point_survives_null_arguments():
+    """Every `int rpo_*(...)` of the header called (a) with all-zero arguments and (b) with sizes = 4, scalars = 1 and NULL
+    pointers: the validation in front of every launch must answer RPO_ERR_ARG / RPO_ERR_NULL (or, at worst, a HIP error code
+    from a launch attempt on a box without a GPU) -- never dereference a NULL host pointer.  Run under ASan + UBSan by
+    tests/test_sanitizers.py."""
+    lib = _lib.load()
+    skip = {"rpo_abi_version", "rpo_tuning", "rpo_mlp_supported", "rpo_mlp_split_supported"}    # (predicates: 0 = "no")
+    assert lib.rpo_mlp_supported(0, 0, 0) == 0 and lib.rpo_mlp_split_supported(None) == 0
+    bad = {}
+    for name, argtypes in _lib.PROTOTYPES.items():
+        if name in skip:
+            continue
+        fn = getattr(lib, name)
+        for fill in (0, 4):
+            args = []
+            for t in argtypes:
+                if t is ctypes.c_void_p:
+                    args.append(None)
+                elif t is ctypes.c_float:
+                    args.append(float(fill and 1.0))
+                else:
+                    args.append(fill)
+            rc = fn(*args)
+            if rc == 0:
+                bad[(name, fill)] = rc
+    assert not bad, "entry points that report success on NULL / empty arguments: %s" % bad
+    # the switch table: unknown keys are refused, a query does not change the value
+    assert lib.rpo_tuning(-1, 1) == _lib.CONST["RPO_ERR_ARG"] and lib.rpo_tuning(_lib.CONST["RPO_TUNE_COUNT"], 1) == _lib.CONST["RPO_ERR_ARG"]
+    was = lib.rpo_tuning(_lib.CONST["RPO_TUNE_BWD_ONEPASS"], -1)
+    assert lib.rpo_tuning(_lib.CONST["RPO_TUNE_BWD_ONEPASS"], 0) == was and lib.rpo_tuning(_lib.CONST["RPO_TUNE_BWD_ONEPASS"], was) == 0
+    assert lib.rpo_tuning(_lib.CONST["RPO_TUNE_BWD_ONEPASS"], -1) == was
