@@ -648,7 +648,6 @@ def prepared_trainer(n_total, device, workload):
 
 def main():
     os.environ.setdefault("RPO_VERBOSE", "0")
-    os.environ.setdefault("RPO_TAIL_WINDOWS", "1")              # the tail of a short timed region as one window (see timed_run)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -672,6 +671,12 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         os.environ["RPO_BENCH_BACKEND"] = args.backend           # (the ranks read it like the flag)
         self_launch(args.gpus, sys.argv[1:], args.backend)       # never returns
+    # stdout carries ONE JSON line (rank 0's) and nothing else: whatever a library prints there (gloo announces its
+    # connections on stdout from C++, from every rank) goes to stderr -- file descriptor 1 is pointed at 2 for the whole run
+    # and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -701,7 +706,7 @@ def main():
             s0.bind(("127.0.0.1", 0))
             os.environ.setdefault("MASTER_PORT", str(s0.getsockname()[1]))
             s0.close()
-            os.environ["RPO_DIST_FORCE"] = "1"
+            os.environ["RPO_SCHEDULE"] = ",".join(filter(None, [os.environ.get("RPO_SCHEDULE", ""), "force_dist=1"]))
             dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
         elif args.backend == "gloo":
             dist.init_process_group(backend="gloo")              # host-driven collectives on GPU tensors; no device binding
@@ -877,7 +882,8 @@ def main():
                 result["utd_matched_over_cpu"] = result["utd_matched_env_steps_per_s"] / cpu["value"]
                 result["utd_matched_over_cpu_single_core"] = result["utd_matched_env_steps_per_s"] / cpu["single_core_value"]
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -647,9 +647,6 @@ typedef struct {
 int rpo_split_critic_fwd_a_ride(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream);
 int rpo_split_critic_fwd_b_ride(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream);
 int rpo_split_critic_bwd_b_ride(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream);
-/* The riders of rpo_split_critic_bwd_b_ride (explore / project / step / scatter of every lane) as a launch of their own:
- * data-parallel runs may put it on a second stream beside the gradient all-reduce (experiment of round 4). */
-int rpo_split_ride_tail(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream);
 /* CartSafe-v0: rpo_split_critic_front with the actor forward of lanes [lane_begin, lane_end) riding in the planes behind its
  * own (replaces fwd_a_ride + fwd_b_ride + bwd_a; bwd_b_ride follows with the lanes' step). */
 int rpo_split_critic_front_ride(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream);

@@ -57,7 +57,7 @@ class RPODDPG(RPOTrainerBase):
                  policy_fre=2, eval_fre=500, max_epochs=100000, grad_eps=1e-3, eval_steps=None, init_lamb=0.0,
                  init_nju=0.0, fixed=False, clip_thres="inf", partial=False, partial_idx=None,
                  device=torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu"),
-                 num_envs=None, seed=None, backend=None, use_graph=None, updates_per_step=None):
+                 num_envs=None, seed=None, backend=None, use_graph=None, updates_per_step=None, schedule=None):
         base = getattr(env, "unwrapped", env)
         agent = PDDDPG_PA(
             base.state_dim, base.action_dim, base.eq_num, base.ineq_num, embed_dim=embed_dim, hidden_dim=hidden_dim,
@@ -72,7 +72,8 @@ class RPODDPG(RPOTrainerBase):
                   corr_mode=corr_mode, grad_eps=grad_eps, clip_thres=clip_thres, eval_steps=eval_steps,
                   batch_size=batch_size, policy_fre=policy_fre, eval_fre=eval_fre, warmup=warmup, max_epochs=max_epochs,
                   fixed=fixed, partial=partial, eps=eps, eps_start=eps_start, eps_epoch=eps_epoch)
-        self._setup(env, work_dir, name, logger, agent, hp, device, num_envs, seed, backend, use_graph, updates_per_step)
+        self._setup(env, work_dir, name, logger, agent, hp, device, num_envs, seed, backend, use_graph, updates_per_step,
+                    schedule=schedule)
 
     # ---- rollout policy (rpo_ddpg.py:98-106, agent/ddpg_pa.py:101-112) ----------------------------------------
     def _actor_out(self, name, obs, save=False):
@@ -101,7 +102,7 @@ class RPODDPG(RPOTrainerBase):
         k = self.kernels
         return (self.fused is not None and (hasattr(k, "ddpg_critic_forward") or hasattr(k, "ddpg_critic_front"))
                 and "actor_target" in self.fused.descs and "critic" in self.fused.descs
-                and _env_int("RPO_FUSED_CRITIC", 1) and not self._large_batch)
+                and self.schedule["fused_critic"] and not self._large_batch)
 
     def _sample(self):
         if self._pipelines:
@@ -169,7 +170,7 @@ class RPODDPG(RPOTrainerBase):
         return (hasattr(self.backend, "ddpg_actor_forward") and "actor" in d and "critic" in d and d["actor"].E == 128
                 and d["critic"].E == 128 and not d["critic"].cat and self._box_affine is not None
                 and self.kernels.partial_dim == 1 and self.kernels.action_dim == 2
-                and _env_int("RPO_FUSED_ACTOR", 1) and not self._large_batch)
+                and self.schedule["fused_actor"] and not self._large_batch)
 
     def _actor_update_pipeline(self, cols):
         """The policy step in two launches + the actor's weights pass (fused.hip)."""

@@ -49,7 +49,7 @@ class RPOSAC(RPOTrainerBase):
                  max_epochs=100000, grad_eps=1e-3, eval_steps=None, init_lamb=0.0, init_nju=0.0, fixed=False,
                  clip_thres="inf", partial=False, partial_idx=None,
                  device=torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu"),
-                 num_envs=None, seed=None, backend=None, use_graph=None, updates_per_step=None):
+                 num_envs=None, seed=None, backend=None, use_graph=None, updates_per_step=None, schedule=None):
         base = getattr(env, "unwrapped", env)
         agent = PDSAC_PA(
             automatic_entropy_tuning, base.state_dim, base.action_dim, base.eq_num, base.ineq_num,
@@ -66,7 +66,8 @@ class RPOSAC(RPOTrainerBase):
                   corr_mode=corr_mode, grad_eps=grad_eps, clip_thres=clip_thres, eval_steps=eval_steps,
                   batch_size=batch_size, policy_fre=policy_fre, eval_fre=eval_fre, warmup=warmup, max_epochs=max_epochs,
                   fixed=fixed, partial=partial, eps=eps, eps_start=eps_start, eps_epoch=eps_epoch)
-        self._setup(env, work_dir, name, logger, agent, hp, device, num_envs, seed, backend, use_graph, updates_per_step)
+        self._setup(env, work_dir, name, logger, agent, hp, device, num_envs, seed, backend, use_graph, updates_per_step,
+                    schedule=schedule)
         self._act_kw = {}        # the Gaussian head kernels emit finished (boxed, clipped) basic actions, never raw ones
 
     _gauss_policy = True
@@ -113,7 +114,7 @@ class RPOSAC(RPOTrainerBase):
     def _pipelines(self):
         k = self.kernels
         return (self.fused is not None and (hasattr(k, "sac_critic_forward") or hasattr(k, "sac_critic_front"))
-                and "critic1" in self.fused.descs and "actor" in self.fused.descs and _env_int("RPO_FUSED_CRITIC", 1) and not self._large_batch)
+                and "critic1" in self.fused.descs and "actor" in self.fused.descs and self.schedule["fused_critic"] and not self._large_batch)
 
     def _sample(self):
         if self._pipelines:
@@ -188,7 +189,7 @@ class RPOSAC(RPOTrainerBase):
         d = self.fused.descs if self.fused is not None else {}
         return (hasattr(self.backend, "sac_actor_forward") and "actor" in d and "critic1" in d and d["actor"].E == 128
                 and d["critic1"].E == 128 and not d["critic1"].cat and self._box_affine is not None
-                and self.kernels.partial_dim == 1 and self.kernels.action_dim == 2 and _env_int("RPO_FUSED_ACTOR", 1)
+                and self.kernels.partial_dim == 1 and self.kernels.action_dim == 2 and self.schedule["fused_actor"]
                 and not self._large_batch)
 
     def _actor_update_pipeline(self, cols):

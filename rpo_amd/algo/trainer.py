@@ -70,17 +70,17 @@ class _LagrangianFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------ helpers
 class _Dist(object):
-    def __init__(self):
+    def __init__(self, force=False):
         init = dist.is_available() and dist.is_initialized()
-        # RPO_DIST_FORCE=1: take the data-parallel code path with a single rank too (tests: the RCCL collective inside
-        # the iteration's hipGraph can be exercised on a one-GPU box)
-        self.on = init and (dist.get_world_size() > 1 or bool(_env_int("RPO_DIST_FORCE", 0)))
+        # force (trainer kwarg `force_dist`; RPO_SCHEDULE=force_dist=1): take the data-parallel code path with a single rank
+        # too (tests, bench.py --force-dist: the RCCL collective inside the iteration's hipGraph on a one-GPU box)
+        self.on = init and (dist.get_world_size() > 1 or bool(force))
         self.rank = dist.get_rank() if self.on else 0
         self.world = dist.get_world_size() if self.on else 1
         # RCCL collectives are stream-ordered device work: they are captured INSIDE the iteration's hipGraph (and inside
         # the multi-iteration windows) like any kernel.  Host-driven backends (gloo: CPU tests, two ranks sharing one
         # GPU) cannot be captured: there the iteration is cut into graph segments with eager collectives in between.
-        self.in_graph = self.on and dist.get_backend() == "nccl" and bool(_env_int("RPO_DP_GRAPH", 1))
+        self.in_graph = self.on and dist.get_backend() == "nccl"
 
     def mean_(self, tensors):
         """In-place all-reduce(mean) of flat gradient buckets: ONE collective per bucket, one bucket per update (critic
@@ -201,6 +201,37 @@ def _env_int(name, default):
     return default if v in (None, "") else int(v)
 
 
+#: The launch schedule's optional parts, all ON by default.  Every part off gives the same results (bit for bit
+#: unless a test states a tolerance): they exist for the A/B tests that pin the fused / riding launches against the plain
+#: ones, and as the operational fallback the hand-over error messages name (`front=0`).  One variable sets them from outside
+#: -- RPO_SCHEDULE="front=0,ride=0" -- or the trainers' `schedule=dict(front=0)` argument; read ONCE, at construction.
+#:   fused_mlp      hand-written f32-MFMA MLP kernels (0: the torch modules + autograd)
+#:   fused_rollout  actor -> head -> Complete -> GRG -> env step -> ring scatter as one launch (0: three launches)
+#:   fused_critic   critic-update pipelines (0: generic MLP launches + rpo_*_act_project / rpo_td)
+#:   fused_actor    policy-step pipelines (0: generic launches)
+#:   split          column-split update stages rpo_split_* (0: the row-tile pipelines of fused.hip)
+#:   ride           the next vector step rides on the critic update's launches where nothing is shared (0: serial windows)
+#:   front          in-launch hand-overs: fused critic / policy fronts, the SpringPendulum front around the projection and the
+#:                  projection on one workgroup per row tile (0: one launch per stage, one-workgroup projection)
+#:   force_dist     (default 0) data-parallel code path over a one-rank process group
+SCHEDULE_DEFAULTS = dict(fused_mlp=1, fused_rollout=1, fused_critic=1, fused_actor=1, split=1, ride=1, front=1, force_dist=0)
+
+
+def parse_schedule(overrides=None):
+    out = dict(SCHEDULE_DEFAULTS)
+    text = os.environ.get("RPO_SCHEDULE", "")
+    for item in filter(None, (x.strip() for x in text.split(","))):
+        k, _, v = item.partition("=")
+        if k.strip() not in out:
+            raise ValueError("RPO_SCHEDULE: unknown part %r (have: %s)" % (k, ", ".join(sorted(out))))
+        out[k.strip()] = int(v) if v.strip() else 1
+    for k, v in (overrides or {}).items():
+        if k not in out:
+            raise ValueError("schedule: unknown part %r (have: %s)" % (k, ", ".join(sorted(out))))
+        out[k] = int(v)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ trainer core
 class RPOTrainerBase(object):
     """Everything except agent construction and the two losses."""
@@ -208,8 +239,11 @@ class RPOTrainerBase(object):
     sac = False
 
     def _setup(self, env, work_dir, name, logger, agent, hp, device, num_envs=None, seed=None, backend=None,
-               use_graph=None, updates_per_step=None, fused=None):
+               use_graph=None, updates_per_step=None, fused=None, schedule=None):
         self.env, self.agent, self.device = env, agent, device
+        self.schedule = parse_schedule(schedule)
+        if fused is not None:
+            self.schedule["fused_mlp"] = int(bool(fused))
         self.work_dir, self.name, self.logger = work_dir, name, logger
         for k, v in hp.items():
             setattr(self, k, v)
@@ -229,7 +263,7 @@ class RPOTrainerBase(object):
         self.env_eval = copy.deepcopy(self.env)                          # rpo_ddpg.py:61
         self.box_constraint = BoxConstraint(*self.base_env.box_constraint, device=device)
         self.decay_value = (hp["eps_start"] - hp["eps"]) / hp["eps_epoch"]   # rpo_ddpg.py:70
-        self.dist = _Dist()
+        self.dist = _Dist(force=self.schedule["force_dist"])
         n_total = int(num_envs) if num_envs is not None else _env_int("RPO_NUM_ENVS", 1)
         if n_total % self.dist.world:
             raise ValueError("num_envs (%d) must be divisible by the world size (%d)" % (n_total, self.dist.world))
@@ -256,12 +290,15 @@ class RPOTrainerBase(object):
         self._noise_b = torch.zeros(self.batch_size, P, device=device)
         self._noise_n = torch.zeros(self.n_local, P, device=device)
         self._box_lo, self._box_hi = self.base_env.partial_box
+        # RPO_GRAPH_CYCLE: iterations per hipGraph window (default 16, rounded to a multiple of policy_fre); 1: one graph per
+        # iteration; 0: no hipGraphs at all (eager launches)
+        cycle = _env_int("RPO_GRAPH_CYCLE", 16)
         if use_graph is None:
-            use_graph = bool(_env_int("RPO_GRAPH", 1)) and device.type == "cuda"
+            use_graph = cycle > 0 and device.type == "cuda"
         self._graphs = _GraphCache(use_graph, owner=self)
         self._tail = None           # data-parallel runs: deferred last segment of the previous iteration
         self._last_cols = self._last_actor_out = None
-        self._cycle = _env_int("RPO_GRAPH_CYCLE", 16) // max(1, self.policy_fre) * max(1, self.policy_fre)
+        self._cycle = max(cycle, 1) // max(1, self.policy_fre) * max(1, self.policy_fre)
         # projection of training batches: the reference's literal batched semantics (default) or row-wise
         # (RPO_ROWWISE_PROJECTION=1); rollouts are always per lane == the reference's B = 1 calls
         rowwise = _env_int("RPO_ROWWISE_PROJECTION", None)
@@ -279,9 +316,8 @@ class RPOTrainerBase(object):
         #: recorded in checkpoints / bench lines: how training batches are projected
         self.projection_mode = ("batch-reference" if self.batch_reference and hasattr(self.kernels, "project_batchref")
                                 else "row-wise")
-        # hand-written f32-MFMA MLP kernels for actor / critics (RPO_FUSED_MLP=0: the torch modules + autograd)
-        want_fused = bool(_env_int("RPO_FUSED_MLP", 1)) if fused is None else bool(fused)
-        self.fused = FusedNets.build(agent, self.backend, device) if want_fused else None
+        # hand-written f32-MFMA MLP kernels for actor / critics (schedule fused_mlp=0: the torch modules + autograd)
+        self.fused = FusedNets.build(agent, self.backend, device) if self.schedule["fused_mlp"] else None
         if self.fused is not None and self.batch_size >= hip_ops.CONST.get("RPO_SPLITK_FROM", 1 << 30) and device.type == "cuda":
             # one LARGE batch per update (batch 256 * N): the parameter-gradient reductions of the backward
             # kernels split the batch over the chip (rpo_mlp_grad.splitk_scratch)
@@ -308,9 +344,8 @@ class RPOTrainerBase(object):
         # ctrl[RPO_CTRL_T], and the iteration's last optimiser launch advances it -- so the NEXT rollout (which advances
         # ctrl[RPO_CTRL_T]) may run on another stream of the same hipGraph while the update is still going.  Without the
         # split path it is an alias of the rollout's ctrl and nothing changes.
-        self._uctrl, self._uclock_ok, self._after_front, self._ovl_stream = self.vec.ctrl, True, None, None
+        self._uctrl, self._uclock_ok, self._ovl_stream = self.vec.ctrl, True, None
         self._ride, self._rider_cache, self._ride_cut = None, None, 0
-        self._tail_rider = None     # (RPO_DP_OVERLAP=1: the riders' step waiting to be forked beside the all-reduce)
         self._clock_pending, self._iter_actor_step, self._critic_prepared, self._gradmax_stale = False, None, False, False
         self._actor_prepared, self._actor_gradmax_stale = False, False
         self._bump_updates_now, self._updates_out, self._pol_a_done = False, None, False
@@ -365,7 +400,7 @@ class RPOTrainerBase(object):
     @property
     def _rollout_pipeline(self):
         return (self.fused is not None and hasattr(self.kernels, "rollout") and "actor" in self.fused.descs
-                and _env_int("RPO_FUSED_ROLLOUT", 1))
+                and self.schedule["fused_rollout"])
 
     @property
     def _defer_ok(self):
@@ -615,12 +650,12 @@ class RPOTrainerBase(object):
     def _split_state(self):
         """The column-split update stages (rpo_split_*, rpo_amd/csrc/nsplit.hip) when this configuration supports them:
         CartSafe / SpringPendulum kernels, every network 128 -> 256 with scalar heads, the reference's batched projection
-        semantics on SpringPendulum, batch <= 1024.  ``RPO_SPLIT=0`` keeps the row-tile pipelines."""
+        semantics on SpringPendulum, batch <= 1024.  Schedule ``split=0`` keeps the row-tile pipelines."""
         if getattr(self, "_split_cache", False) is not False:
             return self._split_cache
         self._split_cache = None
         f, k, be = self.fused, self.kernels, self.backend
-        if f is None or not hasattr(be, "SplitUpdate") or not _env_int("RPO_SPLIT", 1) or self._box_affine is None \
+        if f is None or not hasattr(be, "SplitUpdate") or not self.schedule["split"] or self._box_affine is None \
                 or self.device.type != "cuda":
             return None
         if not isinstance(k, (be.CartSafeKernels, be.PendulumKernels)) or self.batch_size > 1024:
@@ -671,17 +706,15 @@ class RPOTrainerBase(object):
             fields.update(raw=b("pi.raw", B, 2))
         else:
             fields.update(ap_det=b("act.ap_det", B))
-        if isinstance(k, be.PendulumKernels) and _env_int("RPO_PROJ_MULTI", 1) and B <= 256 and self.max_steps <= 30:
+        if isinstance(k, be.PendulumKernels) and self.schedule["front"] and B <= 256 and self.max_steps <= 30:
             # the batch-coupled projection on one workgroup per row tile (rpo_split_pend_head_project); workspace of
-            # RPO_PROJ_WS_WORDS 64-bit words.  RPO_PROJ_STORE: 0 agent-scope granule stores, 1 (default) plain stores when the
-            # workgroups share an XCD (checked inside every launch)
-            fields.update(proj_ws=torch.zeros(hip_ops.PROJ_WS_WORDS + _env_int("RPO_PROJ_WS_EXTRA", 0), dtype=torch.int64, device=self.device),
-                          proj_store_mode=_env_int("RPO_PROJ_STORE", 1))
+            # RPO_PROJ_WS_WORDS 64-bit words; store mode 1: plain stores when the workgroups share an XCD (checked inside every
+            # launch), agent-scope granule stores otherwise
+            fields.update(proj_ws=torch.zeros(hip_ops.PROJ_WS_WORDS, dtype=torch.int64, device=self.device), proj_store_mode=1)
         self._split_cache = be.SplitUpdate(k, descs, self.sac, B, fields)
-        self._front_cache = bool(_env_int("RPO_FRONT", 1)) and hasattr(be, "front_launch_ok") and be.front_launch_ok(B, self.sac)
-        # SpringPendulum: fwd_a + projection + fwd_b + bwd_a as one launch (rpo_split_critic_pfront; RPO_PFRONT=0: fwd_a | project | mid)
-        self._pfront = bool(self._front_cache and "proj_ws" in fields and _env_int("RPO_PFRONT", 1) and
-                            be.front_launch_ok(B, self.sac, 1))
+        self._front_cache = bool(self.schedule["front"]) and hasattr(be, "front_launch_ok") and be.front_launch_ok(B, self.sac)
+        # SpringPendulum: fwd_a + projection + fwd_b + bwd_a as one launch (rpo_split_critic_pfront)
+        self._pfront = bool(self._front_cache and "proj_ws" in fields and be.front_launch_ok(B, self.sac, 1))
         self._split_loss = fields["loss_partial"]
         self._split_logp = (fields["logp"], b("pi.logp", B))          # log pi(a'|s') of the critic update | log pi(a|s)
         return self._split_cache
@@ -782,14 +815,14 @@ class RPOTrainerBase(object):
         # CartSafe: fwd_a, fwd_b and bwd_a are one launch (the later stages' workgroups wait inside it for the
         # workgroups of their own row tile, rpo_split_critic_front) -- same values, two launch boundaries less
         early = bool(actor_step) and ride is None and self.agent.flat.sizes[1] == 0 and getattr(self, "_actor_pipeline", False)
-        if su.st.env == 0 and self._after_front is None and self._front_ok():
+        if su.st.env == 0 and self._front_ok():
             self._pol_a_done = early
             if ride is not None:
                 ride.set(lane_begin=0, lane_end=n)              # the whole actor forward of the next step rides along
             su.run("critic_front_pol" if early else "critic_front", rider=ride)   # (pol_a as one more plane, see below)
             self._critic_update_split_back(su, ride, bwd_a=False)
             return
-        if su.st.env == 1 and self._after_front is None and self._pfront:
+        if su.st.env == 1 and self._pfront:
             self._pol_a_done = early                             # SpringPendulum: the same, around the projection's workgroups
             if ride is not None:
                 ride.set(lane_begin=0, lane_end=n)
@@ -797,8 +830,6 @@ class RPOTrainerBase(object):
             self._critic_update_split_back(su, ride, bwd_a=False)
             return
         su.run("critic_fwd_a", rider=ride)                      # + actor forward of lanes [0, cut)
-        if self._after_front is not None:                       # overlapped windows: the next rollout forks off here
-            self._after_front()
         if su.st.env == 1:
             su.run("pend_head_project")
         if ride is not None:
@@ -855,11 +886,11 @@ class RPOTrainerBase(object):
     def _raise_handover(self, front, proj):
         if front:
             raise RuntimeError("rpo_split_*_front: a workgroup gave up waiting for its row tile (tile_sync flag set); the "
-                               "values of that launch are undefined -- rerun with RPO_FRONT=0")
+                               "values of that launch are undefined -- rerun with RPO_SCHEDULE=front=0")
         if proj:
             raise RuntimeError("rpo_split_pend_head_project / rpo_split_critic_pfront: a workgroup gave up waiting for another "
                                "one's granules (workspace flag set); the values of that launch are undefined -- rerun with "
-                               "RPO_PROJ_MULTI=0")
+                               "RPO_SCHEDULE=front=0")
 
     def _check_tile_sync(self):
         """The fused front launches raise a flag word when a workgroup gave up waiting for its producers (nsplit.hip,
@@ -896,7 +927,7 @@ class RPOTrainerBase(object):
         st["event"].record()
 
     def _front_ok(self):
-        """rpo_split_critic_front usable here (``RPO_FRONT=0``: never): see ops.front_launch_ok."""
+        """rpo_split_critic_front usable here (schedule ``front=0``: never): see ops.front_launch_ok."""
         return self._front_cache                                 # (probed in _split_state, outside any graph capture)
 
     def _critic_update_split_back(self, su, ride, bwd_a=True):
@@ -908,13 +939,7 @@ class RPOTrainerBase(object):
             su.run("critic_bwd_a")
         if ride is not None:
             ride.set(defer_clock=int(self._defer_ok))           # ... whose step counter the next update's fwd_a advances
-        if ride is not None and self.dist.on and self.dist.in_graph and _env_int("RPO_DP_OVERLAP", 0):
-            # experiment: the riders' step on a second captured branch beside the gradient
-            # all-reduce instead of inside bwd_b's launch -- same kernel, same arguments, same bits
-            su.run("critic_bwd_b")
-            self._tail_rider = (su, ride)
-        else:
-            su.run("critic_bwd_b", rider=ride)                  # + explore / project / step / scatter of every lane
+        su.run("critic_bwd_b", rider=ride)                      # + explore / project / step / scatter of every lane
         if ride is not None:
             self._clock_pending = bool(self._defer_ok)
             self.vec.steps_host += 1
@@ -1021,12 +1046,12 @@ class RPOTrainerBase(object):
     def _ride_ok(self, do_train):
         """The next vector step may ride on the critic update's launches (rpo_split_critic_fwd_a_ride / _fwd_b_ride /
         _bwd_b_ride, rpo_amd/csrc/nsplit.hip): column-split update, one-launch rollout available, no shared state embedding, the update
-        on its own clock.  Results are identical to the serial order.  ``RPO_RIDE=0`` keeps the serial windows."""
+        on its own clock.  Results are identical to the serial order.  Schedule ``ride=0`` keeps the serial windows."""
         if not (do_train and self._uctrl is not self.vec.ctrl and self.agent.flat.sizes[1] == 0 and self._bump):
             return False
         if not (getattr(self, "_pipelines", False) and self._split_state() is not None and self._rollout_pipeline):
             return False
-        return bool(_env_int("RPO_RIDE", 1)) and not _env_int("RPO_OVERLAP", 0)
+        return bool(self.schedule["ride"])
 
     def _rider(self):
         """Arguments of the riding rollout halves: what `_rollout` hands to the one-launch rollout."""
@@ -1066,18 +1091,8 @@ class RPOTrainerBase(object):
                 self._critic_update(cols)
             finally:
                 self._ride = None
-            tail, self._tail_rider = self._tail_rider, None
-            if tail is not None:                                 # fork: riders' step beside the all-reduce + Adam
-                main = torch.cuda.current_stream()
-                if self._ovl_stream is None:
-                    self._ovl_stream = torch.cuda.Stream()
-                self._ovl_stream.wait_stream(main)
-                with torch.cuda.stream(self._ovl_stream):
-                    tail[0].run_ride_tail(tail[1])
             self.dist.mean_([fl.gradient(fl.critic_range)])
             self._critic_step(actor_step)
-            if tail is not None:
-                torch.cuda.current_stream().wait_stream(self._ovl_stream)
             if actor_step:
                 self._last_actor_out = self._actor_update(cols)
                 self.dist.mean_([fl.gradient(fl.policy_bucket)])
@@ -1088,17 +1103,16 @@ class RPOTrainerBase(object):
     def _overlap_ok(self, do_train):
         """Rollout t+1 may run beside the update of t (on a second stream of the window's hipGraph) when the update does
         not touch what the rollout reads -- no shared state embedding, and not on policy steps -- and the update reads
-        its own clock (`_uctrl`).  Results are identical either way.  ``RPO_OVERLAP`` = 0 / 1 overrides the default: OFF for
-        the classic-control envs -- on one MI355X the fork / join of the second graph branch costs more than the 16 us
-        rollout it hides (cart-SAC 75.7 vs 71.0 us per iteration, measured) -- and ON for EVOPF-v0, whose rollout is a
-        ~160 us chain of latency-bound launches (one wavefront per lane) that runs well beside the update's."""
+        its own clock (`_uctrl`).  Results are identical either way.  OFF for the classic-control envs -- on one MI355X the
+        fork / join of the second graph branch costs more than the 16 us rollout it hides (cart-SAC 75.7 vs 71.0 us per
+        iteration, measured in round 2; the switch went with round 5) -- and ON for EVOPF-v0, whose rollout is a chain of
+        latency-bound launches (one wavefront per lane) that runs well beside the update's.  (`_overlap_enabled = False`
+        on a trainer keeps the serial order: the A/B test.)"""
         if not (do_train and self._uctrl is not self.vec.ctrl and self.agent.flat.sizes[1] == 0 and self._bump):
             return False
-        # the fork point needs the sampling launch on its own or first in the split path (not inside a row-tile pipeline)
-        if getattr(self, "_pipelines", False) and self._split_state() is None:
+        if getattr(self, "_pipelines", False):                            # short launches: the branch costs more than it hides
             return False
-        default = 0 if getattr(self, "_pipelines", False) else 1          # long kernels (EVOPF): the branch pays
-        return bool(_env_int("RPO_OVERLAP", default))
+        return bool(getattr(self, "_overlap_enabled", True))
 
     def _overlapped_window(self, t, L):
         """L iterations (t is a policy_fre boundary) with rollout i+1 forked off right after the sampling launch of update i
@@ -1119,16 +1133,11 @@ class RPOTrainerBase(object):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     self._rollout(False)
-            split = self._split_state() is not None and getattr(self, "_pipelines", False)
-            self._after_front = fork if (overlap and split) else None       # split path: fork behind its sampling launch
             self._iter_actor_step = actor_step
-            try:
-                cols = self._last_cols = self._sample()
-                if overlap and not split:
-                    fork()                                                  # generic path: _sample() launched the gather
-                self._critic_update(cols)
-            finally:
-                self._after_front = None
+            cols = self._last_cols = self._sample()
+            if overlap:
+                fork()                                                      # (_sample() launched the gather)
+            self._critic_update(cols)
             self.dist.mean_([fl.gradient(fl.critic_range)])
             self._critic_step(actor_step)
             if actor_step:
@@ -1148,10 +1157,8 @@ class RPOTrainerBase(object):
         if L <= 1 or warm or (self.dist.on and not self.dist.in_graph) or not self._graphs.enabled:
             return 1
         if left < L:
-            # the tail of a run: single iterations, or (RPO_TAIL_WINDOWS=1) one shorter window of whole policy_fre periods -- a
-            # hipGraph of its own per length, worth it for callers that repeat the same short run (bench.py --steps 20)
-            if not _env_int("RPO_TAIL_WINDOWS", 0):
-                return 1
+            # the tail of a run: one shorter window of whole policy_fre periods (a hipGraph of its own per length once a caller
+            # has repeated the same short run three times -- bench.py --steps 20 --, eager launches on the side stream before)
             L = left // self.policy_fre * self.policy_fre if do_train else left
             if L < 2:
                 return 1

@@ -2276,21 +2276,6 @@ int rpo_split_critic_bwd_b_ride(const rpo_split_update* u, const rpo_rollout_rid
     return 0;
 }
 
-int rpo_split_ride_tail(const rpo_split_update* u, const rpo_rollout_rider* r, void* stream) {
-    if (int e = ride_check(u, r)) return e;
-    SplitArgs a; CartConsts c;
-    if (int e = to_args(u, 2u | 8u | 32u, a, c)) return e;
-    const dim3 grid((r->n_envs + kThreads - 1) / kThreads, 1);   // rider blocks only (own_blocks = 0)
-    if (u->env == 0)
-        hipLaunchKernelGGL(split_critic_bwd_b_ride_kernel<CartRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c,
-                           ride_args<CartEnv>(a, r), 0);
-    else
-        hipLaunchKernelGGL(split_critic_bwd_b_ride_kernel<PendRow>, grid, dim3(kThreads), 0, (hipStream_t)stream, a, c,
-                           ride_args<PendEnv>(a, r), 0);
-    RPO_LAUNCH_CHECK();
-    return 0;
-}
-
 }  // extern "C"
 
 extern "C" {

@@ -942,10 +942,6 @@ class SplitUpdate(object):
             else:
                 self.st.prep2_step[j] = None
 
-    def run_ride_tail(self, rider):
-        """The riders of critic_bwd_b as a launch of their own (rpo_split_ride_tail)."""
-        check(_lib.load().rpo_split_ride_tail(ctypes.byref(self.st), ctypes.byref(rider.st), _stream()), "rpo_split_ride_tail")
-
     def run(self, stage, rider=None):
         """``rider``: a RolloutRider whose share of the next vector step rides on this launch (critic_fwd_a / critic_fwd_b:
         the actor forward of lanes [lane_begin, lane_end), critic_bwd_b: explore / project / step / scatter)."""

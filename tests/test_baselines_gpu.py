@@ -91,10 +91,9 @@ def test_baseline_graph_windows_equal_eager(algo, envname, monkeypatch):
     from rpo_amd import gym_shim
     from rpo_amd.algo import DDPG_LA, SAC_LA
     from rpo_amd.env import CartSafeEnv, SpringPendulumEnv
-    monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
     out = []
     for graph in ("1", "0"):
-        monkeypatch.setenv("RPO_GRAPH", graph)
+        monkeypatch.setenv("RPO_GRAPH_CYCLE", "8" if graph == "1" else "0")     # (0: no hipGraphs, eager launches)
         torch.manual_seed(1)
         env = gym_shim.TimeLimit((CartSafeEnv if envname == "cart" else SpringPendulumEnv)(device="cuda"), 200)
         kw = dict(automatic_entropy_tuning=False, alpha=0.05) if algo == "sac" else {}

@@ -212,7 +212,7 @@ def test_cart_ddpg_4096_lanes_properties(monkeypatch):
     """Config 2, the headline (CartSafe-v0 RPODDPG, 4096 lanes, scripts/cart_exp.py with its shared state embedding): the one
     configuration where the rollout does NOT ride and the policy front takes pol_a itself.  80 iterations through the
     shipped trainer with the bench's hyper-parameters: ring chain, statistics == ring, hipGraph windows == eager launches,
-    fused front launches (RPO_FRONT=1) == separate launches (RPO_FRONT=0), bit for bit."""
+    fused front launches == separate launches (RPO_SCHEDULE=front=0), bit for bit."""
     from rpo_amd import ops
     n = 4096
     g, first = run("cart_ddpg", n, use_graph=True)
@@ -235,7 +235,7 @@ def test_cart_ddpg_4096_lanes_properties(monkeypatch):
     np.testing.assert_allclose(st[:, S["reward_sum"]], cols["reward"][:, :, 0].sum(dim=1).cpu().numpy(), rtol=1e-6)
     assert abs(g.viol_rate - float(viol.double().mean())) < 1e-9 and g.env_steps == T * n
     e, _ = run("cart_ddpg", n, use_graph=False)
-    monkeypatch.setenv("RPO_FRONT", "0")
+    monkeypatch.setenv("RPO_SCHEDULE", "front=0")
     s, _ = run("cart_ddpg", n, use_graph=True)
     assert not s._front_ok()
     for other in (e, s):
@@ -248,7 +248,7 @@ def test_cart_ddpg_4096_lanes_properties(monkeypatch):
 def _forced_rccl_worker(rank, port, out_dir, n, iters):
     """Config 4's per-rank workload (CartSafe-v0 RPOSAC, 4096 lanes per GPU) on the data-parallel code path over RCCL with a
     forced one-rank group: the gradient all-reduces are captured inside the ridden 16-iteration windows."""
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RPO_VERBOSE="0", RPO_DIST_FORCE="1")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RPO_VERBOSE="0", RPO_SCHEDULE="force_dist=1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -272,7 +272,7 @@ def _forced_rccl_worker(rank, port, out_dir, n, iters):
 
 def test_cart_sac_4096_lanes_forced_rccl_in_ridden_windows(tmp_path):
     """SCALE config (CartSafe-v0 RPOSAC, 4096 lanes per rank, RCCL gradient all-reduce): what ONE GPU can check -- the
-    data-parallel iteration with its collectives captured inside the ridden hipGraph windows (RPO_DIST_FORCE: a one-rank
+    data-parallel iteration with its collectives captured inside the ridden hipGraph windows (schedule force_dist=1: a one-rank
     RCCL group, the mean over ranks is the identity) leaves the same parameters, lanes and ring as the plain single-process
     run, bit for bit; the inf-norm then comes from rpo_absmax_slots behind the all-reduce instead of the backward kernels."""
     import socket

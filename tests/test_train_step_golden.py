@@ -100,12 +100,9 @@ def test_oracle_loop_matches_reference_update(golden, algo, envname):
 
 
 def build_trainer(algo, envname, backend, device, fused=True, **extra):
-    import os
-    os.environ["RPO_FUSED_MLP"] = "1" if fused else "0"
-    try:
-        tr = _build_trainer(algo, envname, backend, device, **extra)
-    finally:
-        os.environ.pop("RPO_FUSED_MLP", None)
+    extra = dict(extra)
+    extra["schedule"] = dict(extra.get("schedule") or {}, fused_mlp=int(bool(fused)))
+    tr = _build_trainer(algo, envname, backend, device, **extra)
     assert (tr.fused is not None) == fused
     return tr
 
@@ -129,7 +126,7 @@ def _build_trainer(algo, envname, backend, device, **extra):
         args = dict(LA_HP, shared_param=(algo == "ddpgla"))
         if algo == "sacla":
             args.update(automatic_entropy_tuning=False, alpha=0.05)
-        args.update({k: v for k, v in extra.items() if k != "use_graph"})
+        args.update({k: v for k, v in extra.items() if k not in ("use_graph", "schedule")})   # (torch modules + autograd, always)
         return (DDPG_LA if algo == "ddpgla" else SAC_LA)(env, "/tmp/rpo_test", name="t", logger=None, max_epochs=10,
                                                          device=device, backend=backend, seed=seed, **args)
     cls = RPODDPG if algo == "ddpg" else RPOSAC

@@ -105,7 +105,7 @@ def test_multi_iteration_graph_equals_single_iteration_graphs(hip, algo, envname
     against eager launches; 70 iterations = 3 eager passes of the window, its capture, 4 replays and a ragged tail."""
     dev = torch.device("cuda")
     monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
-    monkeypatch.setenv("RPO_RIDE", "0")                        # (the riding rollout has its own test below)
+    monkeypatch.setenv("RPO_SCHEDULE", "ride=0")               # (the riding rollout has its own test below)
     a = _run(algo, envname, hip, dev, 70, 256, use_graph=True)
     assert a._cycle == 8 and a._graphs.entries[("cycle", 8, True)]["graph"] is not None
     monkeypatch.setenv("RPO_GRAPH_CYCLE", "1")
@@ -322,13 +322,13 @@ def test_data_parallel_graph_segments_on_gpu(hip, tmp_path):
 
 def _rccl_worker(rank, world, port, out_dir, algo, n_total, iters):
     """One rank per GPU over RCCL (backend "nccl"); world == 1 exercises the same code path on a one-GPU box through
-    RPO_DIST_FORCE (the collective is then a self-reduce, but it is issued, captured and replayed like any other)."""
+    the schedule's force_dist (the collective is then a self-reduce, but it is issued, captured and replayed like any other)."""
     import os
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
     sys.path.insert(0, os.path.dirname(here))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RPO_VERBOSE="0", RPO_DIST_FORCE="1",
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RPO_VERBOSE="0", RPO_SCHEDULE="force_dist=1",
                       RPO_GRAPH_CYCLE="8")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
@@ -375,15 +375,14 @@ def _spawn_rccl(world, out_dir, algo, n_total, iters, budget=240):
     return [torch.load(os.path.join(out_dir, "rank%d.pt" % r), weights_only=False) for r in range(world)]
 
 
-@pytest.mark.parametrize("algo,overlap", [("ddpg", 0), ("sac", 0), ("sac", 1)])
-def test_rccl_collectives_inside_the_graph_single_rank(hip, tmp_path, algo, overlap, monkeypatch):
-    """The data-parallel iteration over RCCL on the one GPU of this box (world size 1, RPO_DIST_FORCE): every gradient
+@pytest.mark.parametrize("algo", ["ddpg", "sac"])
+def test_rccl_collectives_inside_the_graph_single_rank(hip, tmp_path, algo, monkeypatch):
+    """The data-parallel iteration over RCCL on the one GPU of this box (world size 1, schedule force_dist=1): every gradient
     all-reduce is issued inside the hipGraph of the iteration / of the 8-iteration window.  With one rank the mean over
     ranks is the identity, so the run must equal the plain single-process run bit for bit -- which also pins that the
     data-parallel path (no in-backward inf-norm, explicit rpo_absmax) computes the same update."""
-    # overlap = 1 (RPO_DP_OVERLAP, an experiment of round 4, not the default): the riders' env step forked onto a second captured
-    # branch beside the all-reduce (rpo_split_ride_tail) instead of inside bwd_b's launch -- same kernel, same bits
-    monkeypatch.setenv("RPO_DP_OVERLAP", str(overlap))
+    # (round 4's RPO_DP_OVERLAP variant -- the riders' env step on a second captured branch beside the all-reduce -- was
+    # measured slower, 46.7 -> 66 us per iteration, and went with round 5: DESIGN.md 7)
     (r0,) = _spawn_rccl(1, str(tmp_path), algo, 256, 70)
     monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
     torch.manual_seed(5)
@@ -441,10 +440,10 @@ def test_rollout_pipeline_equals_single_stage_launches(hip, algo, envname, n_env
     bit, for both envs and both policy heads; n_envs is ragged against both tile heights."""
     dev = torch.device("cuda")
     iters = 10
-    monkeypatch.setenv("RPO_FUSED_ROLLOUT", "0")
+    monkeypatch.setenv("RPO_SCHEDULE", "fused_rollout=0")
     a = _run(algo, envname, hip, dev, iters, n_envs, use_graph=False)
     assert not a._rollout_pipeline
-    monkeypatch.setenv("RPO_FUSED_ROLLOUT", "1")
+    monkeypatch.setenv("RPO_SCHEDULE", "fused_rollout=1")
     b = _run(algo, envname, hip, dev, iters, n_envs, use_graph=False)
     assert b._rollout_pipeline
     assert torch.equal(a.vec.internal, b.vec.internal) and torch.equal(a.vec.obs, b.vec.obs)
@@ -462,10 +461,10 @@ def test_critic_forward_pipeline_equals_single_stage_launches(hip, algo, envname
     one launch; SpringPendulum: front | batch-coupled projection | back) leaves the same bits behind as the launches it replaces: parameters, targets and replay after 16
     iterations with Philox-drawn batches and noise."""
     dev = torch.device("cuda")
-    monkeypatch.setenv("RPO_FUSED_CRITIC", "0")
+    monkeypatch.setenv("RPO_SCHEDULE", "fused_critic=0")
     a = _run(algo, envname, hip, dev, 16, 256, use_graph=False)
     assert not a._pipelines
-    monkeypatch.setenv("RPO_FUSED_CRITIC", "1")
+    monkeypatch.setenv("RPO_SCHEDULE", "fused_critic=1")
     b = _run(algo, envname, hip, dev, 16, 256, use_graph=False)
     assert b._pipelines
     assert torch.equal(a.agent.flat.data, b.agent.flat.data)
@@ -480,10 +479,10 @@ def test_actor_update_pipeline_matches_single_stage_launches(hip, shared, monkey
     launches they replace.  Row-local arithmetic is shared code (bit-identical); the Lagrangian sums and, with a shared
     embedding, the first-layer reduction are associated differently -> parameters agree to 1e-7 after 24 iterations."""
     dev = torch.device("cuda")
-    monkeypatch.setenv("RPO_FUSED_ACTOR", "0")
+    monkeypatch.setenv("RPO_SCHEDULE", "fused_actor=0")
     a = _run("ddpg", "cart_viol", hip, dev, 24, 256, use_graph=False, shared_param=shared)
     assert not a._actor_pipeline
-    monkeypatch.setenv("RPO_FUSED_ACTOR", "1")
+    monkeypatch.setenv("RPO_SCHEDULE", "fused_actor=1")
     b = _run("ddpg", "cart_viol", hip, dev, 24, 256, use_graph=False, shared_param=shared)
     assert b._actor_pipeline
     # 1e-7 absolute, or one ulp for the few parameters above 1 (1.2e-7)
@@ -499,10 +498,10 @@ def test_sac_actor_update_pipeline_matches_single_stage_launches(hip, envname, m
     """rpo_sac_actor_forward / _backward against the ~20 launches (kernels and torch elementwise ops) they replace:
     parameters agree to 1e-7 after 24 iterations (the Lagrangian sums are associated differently)."""
     dev = torch.device("cuda")
-    monkeypatch.setenv("RPO_FUSED_ACTOR", "0")
+    monkeypatch.setenv("RPO_SCHEDULE", "fused_actor=0")
     a = _run("sac", envname, hip, dev, 24, 256, use_graph=False)
     assert not a._actor_pipeline
-    monkeypatch.setenv("RPO_FUSED_ACTOR", "1")
+    monkeypatch.setenv("RPO_SCHEDULE", "fused_actor=1")
     b = _run("sac", envname, hip, dev, 24, 256, use_graph=False)
     assert b._actor_pipeline
     np.testing.assert_allclose(a.agent.flat.data.cpu().numpy(), b.agent.flat.data.cpu().numpy(), rtol=0, atol=1e-7)
@@ -514,10 +513,10 @@ def test_sac_actor_update_pipeline_matches_single_stage_launches(hip, envname, m
 def test_ddpg_actor_update_pipeline_on_pendulum(hip, monkeypatch):
     """The env-generic RPODDPG actor pipelines on SpringPendulum-v0 against the single-stage launches (1e-7)."""
     dev = torch.device("cuda")
-    monkeypatch.setenv("RPO_FUSED_ACTOR", "0")
+    monkeypatch.setenv("RPO_SCHEDULE", "fused_actor=0")
     a = _run("ddpg", "pendulum_viol", hip, dev, 24, 256, use_graph=False)
     assert not a._actor_pipeline
-    monkeypatch.setenv("RPO_FUSED_ACTOR", "1")
+    monkeypatch.setenv("RPO_SCHEDULE", "fused_actor=1")
     b = _run("ddpg", "pendulum_viol", hip, dev, 24, 256, use_graph=False)
     assert b._actor_pipeline
     # (the two forms associate the Lagrangian sums differently: 1e-7 per step; after 24 iterations through the batch-coupled
@@ -532,12 +531,10 @@ def test_pipelines_with_a_ragged_batch(hip, algo, envname, monkeypatch):
     """batch_size = 100 (not a multiple of the 16-row tile): critic-forward and actor-update pipelines against the
     single-stage launches."""
     dev = torch.device("cuda")
-    monkeypatch.setenv("RPO_FUSED_CRITIC", "0")
-    monkeypatch.setenv("RPO_FUSED_ACTOR", "0")
+    monkeypatch.setenv("RPO_SCHEDULE", "fused_critic=0,fused_actor=0")
     a = _run(algo, envname, hip, dev, 16, 64, use_graph=False, batch_size=100)
     assert not a._pipelines and not a._actor_pipeline
-    monkeypatch.setenv("RPO_FUSED_CRITIC", "1")
-    monkeypatch.setenv("RPO_FUSED_ACTOR", "1")
+    monkeypatch.setenv("RPO_SCHEDULE", "fused_critic=1,fused_actor=1")
     b = _run(algo, envname, hip, dev, 16, 64, use_graph=False, batch_size=100)
     assert b._pipelines and b._actor_pipeline
     np.testing.assert_allclose(a.agent.flat.data.cpu().numpy(), b.agent.flat.data.cpu().numpy(), rtol=0, atol=1e-7)
@@ -552,18 +549,18 @@ def test_split_update_equals_row_tile_pipelines(hip, algo, envname, monkeypatch)
     """The column-split update (rpo_split_*: 128 workgroups per network evaluation, head partials summed by the
     consumer, TD prologue + on-the-fly dh in the backward) against the row-tile pipelines it replaces."""
     dev = torch.device("cuda")
-    monkeypatch.setenv("RPO_SPLIT", "0")
+    monkeypatch.setenv("RPO_SCHEDULE", "split=0")
     a = _run(algo, envname, hip, dev, 26, 300, use_graph=False)
     assert a._split_state() is None
-    monkeypatch.setenv("RPO_SPLIT", "1")
+    monkeypatch.setenv("RPO_SCHEDULE", "split=1")
     b = _run(algo, envname, hip, dev, 26, 300, use_graph=False)
     assert b._split_state() is not None
     c = _run(algo, envname, hip, dev, 26, 300, use_graph=True)
     assert torch.equal(b.agent.flat.data, c.agent.flat.data) and torch.equal(b.buffer.rows, c.buffer.rows)   # graph == eager
     # critic update: bit for bit (3 iterations: before the first policy step)
-    monkeypatch.setenv("RPO_SPLIT", "0")
+    monkeypatch.setenv("RPO_SCHEDULE", "split=0")
     a3 = _run(algo, envname, hip, dev, 3, 300, use_graph=False)
-    monkeypatch.setenv("RPO_SPLIT", "1")
+    monkeypatch.setenv("RPO_SCHEDULE", "split=1")
     b3 = _run(algo, envname, hip, dev, 3, 300, use_graph=False)
     assert torch.equal(a3.agent.flat.data, b3.agent.flat.data)
     assert torch.equal(a3.agent.critic_target_flat, b3.agent.critic_target_flat)
@@ -583,13 +580,16 @@ def test_overlapped_rollout_equals_serial(hip, algo, envname, monkeypatch):
     """Inside a multi-iteration hipGraph the rollout of step t+1 runs on a second stream beside the update of step t (no
     shared embedding; forked after the sampling launch, joined before the next one; serial after policy steps).  The
     update reads its own clock, so nothing it sees moves: 70 iterations equal the serial order bit for bit."""
+    # (round 5: the branch is the default where the update runs through the generic launches -- EVOPF-v0 --, never beside
+    # the pipelines of the classic-control envs, where it was measured slower; here the classic-control envs on the generic
+    # launches exercise it, `_overlap_enabled = False` is the serial order)
+    from rpo_amd.algo.trainer import RPOTrainerBase
     dev = torch.device("cuda")
     monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
-    monkeypatch.setenv("RPO_RIDE", "0")
-    monkeypatch.setenv("RPO_OVERLAP", "1")
+    monkeypatch.setenv("RPO_SCHEDULE", "fused_critic=0,fused_actor=0")
     a = _run(algo, envname, hip, dev, 70, 300, use_graph=True)
     assert a._overlap_ok(True) and a._graphs.entries[("cycle", 8, True, "overlap")]["graph"] is not None
-    monkeypatch.setenv("RPO_OVERLAP", "0")
+    monkeypatch.setattr(RPOTrainerBase, "_overlap_enabled", False, raising=False)
     b = _run(algo, envname, hip, dev, 70, 300, use_graph=True)
     assert ("cycle", 8, True, "overlap") not in b._graphs.entries
     c = _run(algo, envname, hip, dev, 70, 300, use_graph=False)
@@ -603,8 +603,9 @@ def test_overlapped_rollout_equals_serial(hip, algo, envname, monkeypatch):
     assert int(a._uctrl[0]) == 71 and int(a.vec.ctrl[0]) == 70       # the update clock runs one ahead between iterations
     # a full ring: the fork sits behind the gather, so the rollout never overwrites a slot the sampler still reads
     d = _run(algo, envname, hip, dev, 70, 64, use_graph=True, capacity=5)
-    monkeypatch.setenv("RPO_OVERLAP", "1")
+    monkeypatch.setattr(RPOTrainerBase, "_overlap_enabled", True, raising=False)
     e = _run(algo, envname, hip, dev, 70, 64, use_graph=True, capacity=5)
+    assert ("cycle", 8, True, "overlap") in e._graphs.entries and ("cycle", 8, True, "overlap") not in d._graphs.entries
     assert torch.equal(d.agent.flat.data, e.agent.flat.data) and torch.equal(d.buffer.rows, e.buffer.rows)
 
 
@@ -619,7 +620,7 @@ def test_ridden_rollout_equals_serial(hip, algo, envname, monkeypatch):
     monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
     a = _run(algo, envname, hip, dev, 70, 300, use_graph=True)
     assert a._ride_ok(True) and a._graphs.entries[("cycle", 8, True, "ride")]["graph"] is not None
-    monkeypatch.setenv("RPO_RIDE", "0")
+    monkeypatch.setenv("RPO_SCHEDULE", "ride=0")
     b = _run(algo, envname, hip, dev, 70, 300, use_graph=True)
     assert not b._ride_ok(True) and ("cycle", 8, True, "ride") not in b._graphs.entries
     c = _run(algo, envname, hip, dev, 70, 300, use_graph=False)
@@ -635,7 +636,7 @@ def test_ridden_rollout_equals_serial(hip, algo, envname, monkeypatch):
     assert int(a._uctrl[0]) == 71 and int(a.vec.ctrl[0]) == 70 and a.vec.steps_host == 70
     # a full ring: both halves sit behind the gather, so the step never overwrites a slot the sampler still reads
     d = _run(algo, envname, hip, dev, 70, 64, use_graph=True, capacity=5)
-    monkeypatch.setenv("RPO_RIDE", "1")
+    monkeypatch.setenv("RPO_SCHEDULE", "ride=1")
     e = _run(algo, envname, hip, dev, 70, 64, use_graph=True, capacity=5)
     assert ("cycle", 8, True, "ride") in e._graphs.entries
     assert torch.equal(d.agent.flat.data, e.agent.flat.data) and torch.equal(d.buffer.rows, e.buffer.rows)
@@ -657,11 +658,10 @@ def test_fused_front_launch_equals_separate_launches(hip, algo, envname, shared,
     and bwd_a (rpo_split_critic_mid*; the batch-coupled projection in between keeps fwd_a a launch of its own)."""
     dev = torch.device("cuda")
     monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
-    monkeypatch.setenv("RPO_RIDE", ride)                       # (rides in the graph windows only)
     extra = dict(shared_param=shared) if algo == "ddpg" else {}
     runs = {}
     for front in ("0", "1"):
-        monkeypatch.setenv("RPO_FRONT", front)
+        monkeypatch.setenv("RPO_SCHEDULE", "ride=%s,front=%s" % (ride, front))   # (rides in the graph windows only)
         for graph in (False, True):
             runs[front, graph] = _run(algo, envname, hip, dev, 45, 300, use_graph=graph, **extra)
     a = runs["0", False]
@@ -712,11 +712,11 @@ def test_aborted_graph_capture_falls_back_to_eager_from_a_clean_state(hip, algo,
 
 @pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "cart")])
 def test_tail_windows_equal_eager(hip, algo, envname, monkeypatch):
-    """RPO_TAIL_WINDOWS=1: the last < RPO_GRAPH_CYCLE iterations of a run_steps call are one shorter graph window (whole
-    policy_fre periods) instead of single-iteration graphs -- same launches in the same order: six calls of 20 iterations
-    (a 16-iteration window + a 4-iteration one each, both captured by then) equal 120 eager iterations bit for bit."""
+    """The last < RPO_GRAPH_CYCLE iterations of a run_steps call are one shorter graph window (whole policy_fre periods; the
+    library default since round 5, bench.py's own switch before) instead of single-iteration graphs -- same launches in the
+    same order: six calls of 20 iterations (a 16-iteration window + a 4-iteration one each, both captured by then) equal 120
+    eager iterations bit for bit."""
     dev = torch.device("cuda")
-    monkeypatch.setenv("RPO_TAIL_WINDOWS", "1")
     runs = []
     for graph in (False, True):
         torch.manual_seed(5)
@@ -742,7 +742,7 @@ def test_fused_front_with_other_batch_sizes(hip, algo, envname, batch, monkeypat
     monkeypatch.setenv("RPO_GRAPH_CYCLE", "8")
     runs = {}
     for front in ("0", "1"):
-        monkeypatch.setenv("RPO_FRONT", front)
+        monkeypatch.setenv("RPO_SCHEDULE", "front=" + front)
         runs[front] = _run(algo, envname, hip, dev, 45, 300, use_graph=True, batch_size=batch)
     a, b = runs["0"], runs["1"]
     assert b._front_ok() and not a._front_ok()

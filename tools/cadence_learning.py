@@ -68,8 +68,11 @@ def lane_statistics(tr, steps, chunk=100):
     return seed_level, dict(viol_rate=vm.cpu().tolist(), reward_row=rm.cpu().tolist())
 
 
-def run_mode(mode, seeds, steps, device):
+def run_mode(mode, seeds, steps, device, lanes=LANES):
+    """``lanes``: env lanes per run (4096 = the bench; smaller counts interpolate towards the reference's single env: the
+    `lanes` sweep of round 5 shows how the statistics move with the number of independent histories an update samples from)."""
     out, curves = [], []
+    LANES = lanes                                                 # noqa: N806  (shadows the module default below)
     for seed in range(seeds):
         extra = dict(batch_size=256 * LANES) if mode == "large_batch" else {}
         t0 = time.perf_counter()
@@ -106,7 +109,29 @@ def reference_row():
                 se=dict(zip(cols, (ref.std(0, ddof=1) / np.sqrt(len(ref))).tolist())))
 
 
+def sweep(lane_counts, seeds, steps, device):
+    """Reference cadence at several lane counts -> gpurun_out/cadence_lanes.json (means, standard errors, z against the
+    reference's runs)."""
+    ref = reference_row()
+    rows = []
+    for n in lane_counts:
+        m = run_mode("reference_cadence", seeds, steps, device, lanes=n)
+        m.pop("per_seed")
+        m.pop("curves_mean")
+        m["z_vs_reference"] = {k: (m["mean"][k] - ref["mean"][k]) / float(np.sqrt(m["se"][k] ** 2 + ref["se"][k] ** 2))
+                               for k in ("viol_rate", "mean_max_ineq", "mean_return_per_step", "mean_return_second_half") if k in ref["mean"]}
+        rows.append(m)
+        print(n, json.dumps(m["mean"]), json.dumps(m["z_vs_reference"]), flush=True)
+    with open(os.path.join(ROOT, "gpurun_out", "cadence_lanes.json"), "w") as f:
+        json.dump(dict(reference=ref, sweep=rows), f, indent=1)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "lanes":             # python tools/cadence_learning.py lanes 1,16,256 128 [steps]
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        sweep([int(x) for x in sys.argv[2].split(",")], int(sys.argv[3]) if len(sys.argv) > 3 else 128,
+              int(sys.argv[4]) if len(sys.argv) > 4 else 3000, torch.device("cuda"))
+        return
     seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
     seeds_lb = int(sys.argv[3]) if len(sys.argv) > 3 else max(1, seeds // 4)

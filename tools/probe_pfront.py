@@ -9,7 +9,6 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("RPO_VERBOSE", "0")
-os.environ["RPO_PROJ_WS_EXTRA"] = "64"
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -20,6 +19,8 @@ NAMES = {0: "proj start", 1: "proj rows gathered", 2: "proj pi granules in", 3: 
 
 def main(workload="pen_sac"):
     from bench import make_trainer
+    from rpo_amd import ops
+    ops.PROJ_WS_WORDS += 64                                      # (room for the stamps behind the projection workspace)
     tr = make_trainer(4096, torch.device("cuda"), 10 ** 9, capacity=64, workload=workload, use_graph=False)
     tr.vec.reset()
     tr.run_steps(400)
