@@ -219,22 +219,13 @@ class RPODDPG(RPOTrainerBase):
             return self._actor_update_pipeline(cols)
         f, ag, B, k = self.fused, self.agent, self.batch_size, self.kernels
         state = cols[0]
-        ap_det = self._actor_out("actor", state, save=True)
-        self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * B * k.partial_dim, _SALT_ACTOR, hip_ops.STREAM_POLICY,
-                                   self._uctrl)
-        noise = self._noise_b.view(-1)
-        actions = self._complete_only(state, ap_det, noise)
+        pre, self._actor_pre = getattr(self, "_actor_pre", None), None
+        if pre is None:
+            pre = self._actor_prefix(cols)
+        ap_det, noise, actions, lag, g_act, fa = pre
         # (its own buffer: the lazily reduced actor loss below keeps a reference to it, and the next critic-only update writes
         #  Q(s, a_replay) into "q" -- ADVICE r03)
         q = f.forward("critic", state, actions, f.buf("q_pi", B, 1), save=True)
-        lag, g_act = f.buf("loss_lag", 1), f.buf("g_act", B, k.action_dim)
-        # (EVOPF kernels write the loss term and add the Lagrangian's d/d action themselves: no torch launch in the step)
-        fa = bool(getattr(k, "fused_adds", False))
-        if not fa:
-            lag.zero_()
-        self._zero_grads()                 # parameters AND multipliers (they live in the same flat buffer)
-        k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1), obs=state,
-                     **(dict(overwrite=True) if fa else {}))
         dq = self._const_dq(B)                                 # d mean(-Q) / dQ: a constant, filled once
         da = f.buf("da", B, k.action_dim)
         shared = ag.flat.sizes[1] > 0      # shared embedding: the critic path contributes to its gradient
@@ -261,6 +252,29 @@ class RPODDPG(RPOTrainerBase):
         loss = _LazyMeanDiff(lag, q)                          # lag[0] - mean(Q), reduced only when somebody looks
         self.last_losses["actor"] = loss
         return loss
+
+    def _actor_prefix(self, cols):
+        """What the policy step computes from the ACTOR alone (generic launches): pi(s) with saved activations, the exploration
+        draw, Complete, and the Lagrangian term of the completed actions (its d/d action and d/d nu).  None of it reads what
+        the critic update writes, so the graph windows of EVOPF-v0 run it on the second captured branch BESIDE the critic
+        update of a policy iteration (trainer._overlapped_window; round 5: ~50 us off a 364 us chain) -- same launches, same
+        arguments, same bits as inside `_actor_update`."""
+        f, ag, B, k = self.fused, self.agent, self.batch_size, self.kernels
+        state = cols[0]
+        ap_det = self._actor_out("actor", state, save=True)
+        self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * B * k.partial_dim, _SALT_ACTOR, hip_ops.STREAM_POLICY,
+                                   self._uctrl)
+        noise = self._noise_b.view(-1)
+        actions = self._complete_only(state, ap_det, noise)
+        lag, g_act = f.buf("loss_lag", 1), f.buf("g_act", B, k.action_dim)
+        # (EVOPF kernels write the loss term and add the Lagrangian's d/d action themselves: no torch launch in the step)
+        fa = bool(getattr(k, "fused_adds", False))
+        if not fa:
+            lag.zero_()
+        self._zero_grads()                 # parameters AND multipliers (they live in the same flat buffer)
+        k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1), obs=state,
+                     **(dict(overwrite=True) if fa else {}))
+        return ap_det, noise, actions, lag, g_act, fa
 
     def _const_dq(self, B):
         key = ("dq_pi_const", B)

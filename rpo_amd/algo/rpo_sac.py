@@ -253,20 +253,14 @@ class RPOSAC(RPOTrainerBase):
             return self._actor_update_pipeline(cols)
         f, ag, B, k = self.fused, self.agent, self.batch_size, self.kernels
         state = cols[0]
-        eps = self._draw(self._noise_b, self.dist.rank * B * self.kernels.partial_dim, _SALT_ACTOR)
-        ap, logp, raw = self._gauss(state, eps, "pi", save=True)
-        actions = self._complete_only(state, ap)
+        pre, self._actor_pre = getattr(self, "_actor_pre", None), None
+        if pre is None:
+            pre = self._actor_prefix(cols)
+        eps, ap, logp, raw, actions, lag, g_act, fa = pre
         # (their own buffers: the lazily reduced actor loss keeps references to them, and the next critic-only update writes
         #  Q(s, a_replay) into "q1" / "q2" -- ADVICE r03)
         q1 = f.forward("critic1", state, actions, f.buf("q1_pi", B, 1), save=True)
         q2 = f.forward("critic2", state, actions, f.buf("q2_pi", B, 1), save=True)
-        lag, g_act = f.buf("loss_lag", 1), f.buf("g_act", B, k.action_dim)
-        fa = bool(getattr(k, "fused_adds", False))             # (EVOPF kernels: see RPODDPG._actor_update)
-        if not fa:
-            lag.zero_()
-        self._zero_grads()                 # parameters AND multipliers (they live in the same flat buffer)
-        k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1), obs=state,
-                     **(dict(overwrite=True) if fa else {}))
         # d(-min(q1, q2))/dq: the smaller one takes the gradient, ties are split (torch.min's backward)
         dq1, dq2 = f.buf("dq1", B, 1), f.buf("dq2", B, 1)
         if hasattr(self.backend, "min_q_bwd"):
@@ -301,6 +295,26 @@ class RPOSAC(RPOTrainerBase):
         loss = _LazySacLoss(lag, float(ag.alpha), logp, q1, q2)   # reduced only when somebody looks (five launches otherwise)
         self.last_losses["actor"] = loss
         return loss, logp.view(-1, 1)
+
+    def _actor_prefix(self, cols):
+        """The part of the policy step that depends on the ACTOR alone (see RPODDPG._actor_prefix): the rsample draw -- into a
+        buffer of its own, the critic update draws into `_noise_b` --, the Gaussian head with saved activations, Complete, the
+        Lagrangian term."""
+        f, ag, B, k = self.fused, self.agent, self.batch_size, self.kernels
+        state = cols[0]
+        if getattr(self, "_noise_pi", None) is None:
+            self._noise_pi = torch.zeros_like(self._noise_b)
+        eps = self._draw(self._noise_pi, self.dist.rank * B * self.kernels.partial_dim, _SALT_ACTOR)
+        ap, logp, raw = self._gauss(state, eps, "pi", save=True)
+        actions = self._complete_only(state, ap)
+        lag, g_act = f.buf("loss_lag", 1), f.buf("g_act", B, k.action_dim)
+        fa = bool(getattr(k, "fused_adds", False))             # (EVOPF kernels: see RPODDPG._actor_update)
+        if not fa:
+            lag.zero_()
+        self._zero_grads()                 # parameters AND multipliers (they live in the same flat buffer)
+        k.lagrangian(actions, ag.nju.weight.view(-1), 1.0 / B, lag, g_act, ag.nju.weight.grad.view(-1), obs=state,
+                     **(dict(overwrite=True) if fa else {}))
+        return eps, ap, logp, raw, actions, lag, g_act, fa
 
     # ---- losses ---------------------------------------------------------------------------------------------
     def critic_loss(self, state, action, next_state, done, reward, ineq_viol=None, eq_viol=None):

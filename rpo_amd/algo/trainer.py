@@ -213,8 +213,11 @@ def _env_int(name, default):
 #:   ride           the next vector step rides on the critic update's launches where nothing is shared (0: serial windows)
 #:   front          in-launch hand-overs: fused critic / policy fronts, the SpringPendulum front around the projection and the
 #:                  projection on one workgroup per row tile (0: one launch per stage, one-workgroup projection)
+#:   branch         second captured branch of the generic-launch windows (EVOPF-v0): rollout t+1 beside update t, and the
+#:                  actor-only prefix of the policy step beside the critic update (0: serial windows)
 #:   force_dist     (default 0) data-parallel code path over a one-rank process group
-SCHEDULE_DEFAULTS = dict(fused_mlp=1, fused_rollout=1, fused_critic=1, fused_actor=1, split=1, ride=1, front=1, force_dist=0)
+SCHEDULE_DEFAULTS = dict(fused_mlp=1, fused_rollout=1, fused_critic=1, fused_actor=1, split=1, ride=1, front=1, branch=1,
+                         force_dist=0)
 
 
 def parse_schedule(overrides=None):
@@ -844,7 +847,7 @@ class RPOTrainerBase(object):
         su.run("critic_fwd_b_pol" if early else "critic_fwd_b", rider=ride)   # (+ actor forward of lanes [cut, n))
         self._critic_update_split_back(su, ride)
 
-    _HOST_STATE = ("_clock_pending", "_iter_actor_step", "_critic_prepared", "_gradmax_stale", "_actor_prepared",
+    _HOST_STATE = ("_actor_pre", "_clock_pending", "_iter_actor_step", "_critic_prepared", "_gradmax_stale", "_actor_prepared",
                    "_actor_gradmax_stale", "_pol_a_done", "_gradmax_ready", "_actor_gradmax_ready", "_bump_updates_now",
                    "_updates_out", "_last_cols", "_last_actor_out")
 
@@ -1112,7 +1115,14 @@ class RPOTrainerBase(object):
             return False
         if getattr(self, "_pipelines", False):                            # short launches: the branch costs more than it hides
             return False
-        return bool(getattr(self, "_overlap_enabled", True))
+        return bool(self.schedule["branch"] and getattr(self, "_overlap_enabled", True))
+
+    def _policy_prefix_ok(self):
+        """The actor-only prefix of the policy step may run beside the critic update: generic fused launches (not the policy
+        pipelines, whose front is one launch), multipliers stepped (`fixed` runs zero nu's gradient inside the prefix -- harmless,
+        but nothing to gain).  `_policy_prefix_enabled = False` on a trainer keeps the serial order (A/B)."""
+        return bool(self.fused is not None and hasattr(self, "_actor_prefix") and not getattr(self, "_actor_pipeline", False)
+                    and self.agent.flat.sizes[1] == 0 and getattr(self, "_policy_prefix_enabled", True))
 
     def _overlapped_window(self, t, L):
         """L iterations (t is a policy_fre boundary) with rollout i+1 forked off right after the sampling launch of update i
@@ -1137,10 +1147,19 @@ class RPOTrainerBase(object):
             cols = self._last_cols = self._sample()
             if overlap:
                 fork()                                                      # (_sample() launched the gather)
+            # policy iteration: what the policy step computes from the actor alone (pi(s), noise, Complete, Lagrangian) runs on
+            # the second branch beside the critic update (`_actor_prefix`; no shared embedding here: `_overlap_ok`)
+            prefix = actor_step and self._policy_prefix_ok()
+            if prefix:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._actor_pre = self._actor_prefix(cols)
             self._critic_update(cols)
             self.dist.mean_([fl.gradient(fl.critic_range)])
             self._critic_step(actor_step)
             if actor_step:
+                if prefix:
+                    main.wait_stream(side)
                 self._last_actor_out = self._actor_update(cols)
                 self.dist.mean_([fl.gradient(fl.policy_bucket)])
                 self._actor_step(self._last_actor_out)

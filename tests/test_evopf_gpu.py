@@ -375,12 +375,26 @@ def _run(n_envs, iters, use_graph, seed_all=5, algo="ddpg", fused=False, **extra
 
 
 @pytest.mark.parametrize("fused", [True, False], ids=["fused_mlp", "torch_mlp"])
-def test_training_iterations_graph_equals_eager_and_episodes_roll_over(fused):
+def test_training_iterations_graph_equals_eager_and_episodes_roll_over(fused, monkeypatch):
+    """30 iterations through hipGraph windows of one policy_fre period (RPO_GRAPH_CYCLE=4: eager passes on the side stream, the
+    capture at the fourth window, replays, a ragged tail) == 30 eager iterations, bit for bit.  The windows of this workload
+    have TWO captured branches: rollout t+1 beside update t, and (round 5, fused networks) the actor-only prefix of the policy
+    step -- pi(s), noise, Complete, Lagrangian -- beside the critic update of a policy iteration; the serial order
+    (`_policy_prefix_enabled = False`) gives the same bits again."""
+    from rpo_amd.algo.trainer import RPOTrainerBase
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "4")
     a = _run(64, 30, use_graph=False, fused=fused)
     b = _run(64, 30, use_graph=True, fused=fused)
-    assert any(e["graph"] is not None for e in b._graphs.entries.values())
-    assert torch.equal(a.vec.internal, b.vec.internal) and torch.equal(a.buffer.rows, b.buffer.rows)
-    assert torch.equal(a.agent.flat.data, b.agent.flat.data)
+    assert b._graphs.entries[("cycle", 4, True, "overlap")]["graph"] is not None and not b._graphs.capture_failed
+    assert b._policy_prefix_ok() == fused
+    monkeypatch.setattr(RPOTrainerBase, "_policy_prefix_enabled", False, raising=False)
+    c = _run(64, 30, use_graph=True, fused=fused)
+    assert not c._policy_prefix_ok() and c._graphs.entries[("cycle", 4, True, "overlap")]["graph"] is not None
+    monkeypatch.undo()
+    for other in (b, c):
+        assert torch.equal(a.vec.internal, other.vec.internal) and torch.equal(a.buffer.rows, other.buffer.rows)
+        assert torch.equal(a.agent.flat.data, other.agent.flat.data) and torch.equal(a.agent.nju.weight, other.agent.nju.weight)
+        assert torch.equal(a.agent.critic_target_flat, other.agent.critic_target_flat)
     assert int(a.vec.ctrl[0]) == 30 and (a.vec.ep_count == 1).all() and (a.vec.ep_len == 6).all()
     a._harvest()
     assert a.env_steps == 64 * 30 and 0.0 <= a.viol_rate <= 1.0
@@ -388,13 +402,16 @@ def test_training_iterations_graph_equals_eager_and_episodes_roll_over(fused):
     assert len(res) == 10 and np.isfinite(res).all()
 
 
-def test_sac_on_evopf_runs_and_replays():
+def test_sac_on_evopf_runs_and_replays(monkeypatch):
     """scripts/evopf_exp_sac.py's configuration: RPOSAC with a 14-dimensional squashed-Gaussian policy and the
-    state-dependent box; hipGraph replay equals the eager run, stored transitions stay near the equality manifold."""
+    state-dependent box; hipGraph replay (one graph per iteration) equals the eager run, stored transitions stay near the
+    equality manifold."""
     kw = dict(lr_actor=1e-4, lr_critic=3e-4, grad_eps=0.1, init_lamb=0.0, init_nju=0.0, alpha=0.001,
               automatic_entropy_tuning=False, fixed=False)            # scripts/evopf_exp_sac.py:30-33
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "1")
     a = _run(32, 12, use_graph=False, algo="sac", **kw)
     b = _run(32, 12, use_graph=True, algo="sac", **kw)
+    assert any(e["graph"] is not None for e in b._graphs.entries.values())
     assert torch.equal(a.vec.internal, b.vec.internal) and torch.equal(a.agent.flat.data, b.agent.flat.data)
     c = a.kernels.cols
     rows = a.buffer.rows[:12 * 32]
@@ -414,7 +431,7 @@ def test_fused_and_torch_mlp_paths_agree_on_evopf():
     np.testing.assert_allclose(a.agent.flat.data.cpu().numpy(), b.agent.flat.data.cpu().numpy(), rtol=0, atol=2e-5)
 
 
-def test_sac_fused_and_torch_paths_agree_on_evopf():
+def test_sac_fused_and_torch_paths_agree_on_evopf(monkeypatch):
     """RPOSAC on EVOPF through the MLP kernels (2 x 14 MFMA heads) + rpo_evopf_gauss_head(_bwd) vs the torch modules:
     same Philox draws, same transitions, parameters equal to float32 summation order after 12 iterations; hipGraph
     replay of the fused path equals its eager run."""
@@ -426,5 +443,10 @@ def test_sac_fused_and_torch_paths_agree_on_evopf():
     np.testing.assert_allclose(a.buffer.rows.cpu().numpy(), b.buffer.rows.cpu().numpy(), rtol=0, atol=2e-4)
     np.testing.assert_allclose(a.agent.flat.data.cpu().numpy(), b.agent.flat.data.cpu().numpy(), rtol=0, atol=2e-5)
     np.testing.assert_allclose(a.agent.nju.weight.detach().cpu().numpy(), b.agent.nju.weight.detach().cpu().numpy(), rtol=1e-3, atol=1e-6)
-    c = _run(48, 12, use_graph=True, algo="sac", fused=True, **kw)
-    assert torch.equal(a.agent.flat.data, c.agent.flat.data) and torch.equal(a.buffer.rows, c.buffer.rows)
+    # windows of one policy_fre period: rollout t+1 and the actor-only prefix of the policy step on the second captured branch
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "4")
+    c = _run(48, 24, use_graph=True, algo="sac", fused=True, **kw)
+    d = _run(48, 24, use_graph=False, algo="sac", fused=True, **kw)
+    assert c._graphs.entries[("cycle", 4, True, "overlap")]["graph"] is not None and c._policy_prefix_ok()
+    assert torch.equal(d.agent.flat.data, c.agent.flat.data) and torch.equal(d.buffer.rows, c.buffer.rows)
+    assert torch.equal(d.agent.nju.weight, c.agent.nju.weight)

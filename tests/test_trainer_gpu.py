@@ -61,8 +61,9 @@ def _stats_equal(a, b, n):
 
 @pytest.mark.parametrize("fused", [True, False], ids=["fused_mlp", "torch_mlp"])
 @pytest.mark.parametrize("algo,envname", [("ddpg", "cart"), ("sac", "pendulum")])
-def test_graph_replay_equals_eager(hip, algo, envname, fused):
+def test_graph_replay_equals_eager(hip, algo, envname, fused, monkeypatch):
     dev = torch.device("cuda")
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "4")                  # (24 iterations: three eager windows, the capture, two replays)
     a = _run(algo, envname, hip, dev, 24, 512, use_graph=False, fused=fused)
     b = _run(algo, envname, hip, dev, 24, 512, use_graph=True, fused=fused)
     assert any(e["graph"] is not None for e in b._graphs.entries.values())
