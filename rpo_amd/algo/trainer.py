@@ -163,37 +163,44 @@ class _GraphCache(object):
         state = owner._host_state() if owner is not None else None
         import gc
         gc_was_on = gc.isenabled()
-        gc.disable()                                            # (a collection inside the capture could destroy an older hipGraph:
-        failure = None                                          #  "operation not permitted when stream is capturing", fatal)
+        # A collection inside the capture could destroy an older trainer's hipGraph ("operation not permitted when stream is
+        # capturing", fatal) -- and one right BEHIND it, between the instantiation and the first launch of the new graph, was a
+        # segmentation fault inside hipGraphLaunch in the full test session (round 5: trainers of earlier tests were still
+        # waiting for the cyclic collector).  So: collect what is collectable NOW, outside the capture, and keep the collector
+        # off until the new graph has been launched once.
+        gc.collect()
+        gc.disable()
+        failure = None
         try:
-            # thread-local capture mode: the collective backend's watchdog thread may touch the HIP runtime meanwhile
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                fn()
-        except Exception as exc:                                # noqa: BLE001  (capture is an optimisation, not a need)
-            failure = exc
+            try:
+                # thread-local capture mode: the collective backend's watchdog thread may touch the HIP runtime meanwhile
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    fn()
+            except Exception as exc:                            # noqa: BLE001  (capture is an optimisation, not a need)
+                failure = exc
+            # Data-parallel ranks decide TOGETHER: a rank that replays a window with captured collectives cannot pair with a
+            # rank that issues them eagerly one iteration at a time in another order of host work -- if any rank's capture
+            # failed, every rank drops its graph and continues eagerly (one flag all-reduce per capture, never per iteration).
+            ok_everywhere = failure is None
+            if owner is not None and owner.dist.on and owner.dist.world > 1:
+                ok_everywhere = owner.dist.all_ok(failure is None, owner.device)
+            if not ok_everywhere:
+                import warnings
+                why = "%s: %s" % (type(failure).__name__, failure) if failure is not None else "another rank's capture failed"
+                warnings.warn("hipGraph capture failed (%s); continuing with eager launches" % why)
+                self.enabled = False
+                self.capture_failed = True
+                del g
+                torch.cuda.synchronize()
+                if owner is not None:
+                    owner._set_host_state(state)
+                fn()                                            # nothing ran during the aborted capture
+                return
+            e["graph"] = g
+            g.replay()
         finally:                                                # (KeyboardInterrupt / SystemExit inside fn() too: ADVICE r03)
             if gc_was_on:
                 gc.enable()
-        # Data-parallel ranks decide TOGETHER: a rank that replays a window with captured collectives cannot pair with a rank
-        # that issues them eagerly one iteration at a time in another order of host work -- if any rank's capture failed,
-        # every rank drops its graph and continues eagerly (one flag all-reduce per capture, never per iteration).
-        ok_everywhere = failure is None
-        if owner is not None and owner.dist.on and owner.dist.world > 1:
-            ok_everywhere = owner.dist.all_ok(failure is None, owner.device)
-        if not ok_everywhere:
-            import warnings
-            why = "%s: %s" % (type(failure).__name__, failure) if failure is not None else "another rank's capture failed"
-            warnings.warn("hipGraph capture failed (%s); continuing with eager launches" % why)
-            self.enabled = False
-            self.capture_failed = True
-            del g
-            torch.cuda.synchronize()
-            if owner is not None:
-                owner._set_host_state(state)
-            fn()                                                # nothing ran during the aborted capture
-            return
-        e["graph"] = g
-        g.replay()
 
 
 def _env_int(name, default):

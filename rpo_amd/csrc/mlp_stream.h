@@ -1,92 +1,115 @@
-// Large-batch forward of the 128 -> 256 scalar-head networks: WEIGHTS STATIONARY IN LDS, ROWS STREAM THROUGH, WAVES INDEPENDENT
-// (round 5; reference work: rpo/algo/rpo_ddpg.py:163-205 at SURVEY 8d-iii's batch of 256 * N rows).
+// Large-batch forward of the 128 -> 256 scalar-head networks: WEIGHTS STATIONARY IN LDS, ROWS STREAM THROUGH, WAVES INDEPENDENT,
+// EVERYTHING TRANSPOSED (round 5; reference work: rpo/algo/rpo_ddpg.py:163-205 at SURVEY 8d-iii's batch of 256 * N rows).
 //
 // The 64-row tile kernel (mlp_tile.h, RT = 4) gives every tile a workgroup that pulls W0 (128 KB) from L2 again, splits the
-// hidden COLUMNS over its eight waves and meets at four barriers per tile: 0.63 of the f32 MFMA peak at 2^20 rows, the MFMA
-// phase itself at ~0.7 (rounds 3-4).  Here one persistent workgroup per CU stages W0 ONCE into LDS (256 x 136 floats =
-// 136 KB of the CU's 160 KB; row stride 136: the ds_read_b128 of the B operand -- lane (li, lg) reads W0[16 c + li][16 it +
-// 4 lg ..+3] -- is conflict-free for 136 / 4 = 2 mod 16, the padding 132 of the row-tile kernels has a two-way conflict), and
-// every WAVE owns whole 16-row tiles end to end:
-//   * first layer on the vector ALU straight into the A-operand layout: lane (li, lg) forms x0[row li][16 it + 4 lg + m] for
-//     the k-group it is about to feed (weights of the <= 11 inputs from a packed LDS table, the row's inputs in registers);
-//   * hidden layer: all 16 column tiles of the row tile in 64 accumulator registers, B from LDS (one ds_read_b128 per four
-//     MFMAs), consecutive MFMAs on four different accumulators;
-//   * head, pre-activation stores and output from the accumulators.
-// No barrier after the staging, no LDS traffic between waves: a SIMD's MFMA pipe is fed by three or four independent
-// instruction streams.  Arithmetic = the row-tile kernels' to the bit: the same k-ordered MFMA chains from a zero
-// accumulator, bias afterwards; the first layer's fmaf order (bias, state inputs, action inputs); the head as eight
-// 32-column partial sums (the old waves' shares: fma over the two tiles, quad / row butterfly, added to the bias in wave
-// order).  (Inputs beyond S + A are zero-weighted zeros: fmaf(0, 0, x) == x except for x == -0.0 -> +0.0, a sign of zero.)
+// hidden COLUMNS over its eight waves and meets at four barriers per tile: 0.63 of the f32 MFMA peak at 2^20 rows.  Here one
+// persistent workgroup per CU stages W0 ONCE into LDS (256 x 136 floats = 136 KB of the CU's 160 KB; row stride 136: the
+// ds_read_b128 of lane (li, lg) at W0[16 jt + li][16 it + 4 lg ..+3] is conflict-free for 136 / 4 = 2 mod 16; the padding 132 of
+// the row-tile kernels has a two-way conflict) and every WAVE owns whole 16-row tiles end to end: no barrier after the staging,
+// no LDS traffic between waves.
+//
+// What the first version of this kernel taught (timing-only builds with phases left out, RPO_STREAM_SKIP): v_mfma_f32_16x16x4_f32
+// runs at the f32 VECTOR rate because it runs on the vector FMA lanes -- vector instructions of the other waves of a SIMD do
+// not hide under it, their issue time ADDS to the MFMA time (MFMA loop alone 0.94 of the peak; + 1300 vector instructions per
+// tile for the first layer, head and stores: 0.73).  So this version has almost no vector instructions, by computing both
+// layers TRANSPOSED:
+//   * first layer  x0^T[e][row] = Wfl[e][u] in^T[u][row] + bias[e]: three MFMAs per 16 e (K = 12: the <= 11 inputs, zero
+//     padded), the bias as the accumulator's initial value.  Its C layout -- lane (li, lg) holds x0[row li][16 it + 4 lg + i] --
+//     IS the B-operand layout the hidden layer needs for k-group it (B[k = lg][n = li]), so relu(x0) feeds the next MFMAs from
+//     the registers it lands in, and the pre-activation store is one 16-byte store per lane;
+//   * hidden layer h1^T[j][row] = W0[j][e] x1^T[e][row]: A from LDS (the same ds_read_b128 as before), 16 accumulators of
+//     the row tile; lane (li, lg) ends with h1[row li][16 jt + 4 lg + i]: 16-byte pre-activation stores, and the head is a
+//     lane-local fma chain + two cross-lane adds per partial.
+// Arithmetic = the row-tile kernels' to the bit (tests/test_trainer_gpu.py, tools/probe_mlp_large.py check): an MFMA is the
+// k-ordered fmaf chain the vector first layer was (bias, state inputs, action inputs; products commute); the hidden layer's
+// chains are unchanged (operands swapped); the head adds the old eight 32-column partials in the old association -- in the
+// old kernel lane l' of a wave held fma(hr[32 w + 16 + l'], w1, hr[32 w + l'] w1) and a quad / row butterfly added the 16
+// lanes as ((q0 + q1) + (q2 + q3)) + ... ; here lane (li, lg) holds the four q of lanes 4 lg .. 4 lg + 3 of its row.
+// (Inputs beyond S + A are zero-weighted zeros: fmaf(0, 0, x) == x except for x == -0.0 -> +0.0, a sign of zero.)
 #pragma once
 #include "mlp_tile.h"
 
 namespace rpo_mlp_dev {
 
+#ifndef RPO_STREAM_SKIP
+#define RPO_STREAM_SKIP 0          // debug builds only (tools/probe/build_stream_variants.sh): 1 no input loads, 2 no first layer,
+#endif                             // 4 no epilogue -- wrong results, timing only
+#ifndef RPO_STREAM_NT
+#define RPO_STREAM_NT 1            // pre-activation stores: 1 non-temporal (default), 0 plain (A/B builds)
+#endif
+#if RPO_STREAM_NT
+#define RPO_STREAM_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define RPO_STREAM_STORE(v, p) (*(p) = (v))
+#endif
 constexpr int kStreamLdW = 136;        // floats between rows of W0 in LDS
-constexpr int kStreamIn = 11;          // S + A <= 11 inputs; slot 11 of a first-layer table row holds the bias
+constexpr int kStreamIn = 11;          // S + A <= 11 inputs (K = 12 of the first-layer MFMAs, the last slot is zero)
 
 template <int H>
 struct StreamLds {
     __attribute__((aligned(16))) float w0[H * kStreamLdW];
-    __attribute__((aligned(16))) float fl[128 * 12];            // [e][w_0 .. w_10 | bias]
-    __attribute__((aligned(16))) float hb[H * 4];               // [col][b0, W1, W1b, 0]: one ds_read_b128 per column tile of the epilogue
+    __attribute__((aligned(16))) float fl[128 * 16];            // [e][lg][ks]: W_first[e][4 ks + lg] (ks = 0..2; slot 3 unused)
+    __attribute__((aligned(16))) float bias[128];               // bs (+ ba): the accumulator's initial value
+    __attribute__((aligned(16))) float b0[H], w1a[H], w1b[H];
 };
 
 static inline bool stream_shape_ok(const Mlp& net) {
     return !net.cat && net.E == 128 && net.H == 256 && net.hd <= 1 && net.S + net.A <= kStreamIn && net.S > 0;
 }
 
+__device__ __forceinline__ float stream_xlane(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+
 // One 16-row tile, start to finish, by one wave.  FULL: every row of the tile exists (no guards: a guarded store is a branch
-// of its own, 80 per tile); otherwise the inputs come from a clamped row and the stores are guarded.
-template <int H, bool FULL, int CH, class ARGS>
-__device__ __forceinline__ void stream_tile(const ARGS& p, const StreamLds<H>& lds, int row0, int li, int lg, float b1a, float b1b) {
+// of its own); otherwise the inputs come from a clamped row and the stores are guarded.  CH: column tiles per chunk of the
+// hidden layer (an accumulator is revisited every CH MFMAs = 64+ cycles >= the 40 of a dependent pair).  SAVE / TWO: whether
+// the pre-activations are stored / the network has a second head, as compile-time facts (1 / 0) on the hot path -- as run-time
+// conditions (-1: the rare partial tile) every share of the epilogue is a branch region of its own.
+template <int H, bool FULL, int CH, int SAVE, int TWO, class ARGS>
+__device__ __forceinline__ void stream_tile(const ARGS& p, const StreamLds<H>& lds, int row0, int lane, float b1a, float b1b) {
     constexpr int EIN = 128;
     const Mlp& net = p.net;
+    const int li = lane & 15, lg = lane >> 4;
     const int nin = net.S + net.A;
-    const bool two = net.n_out > 1;
+    const bool two = TWO < 0 ? net.n_out > 1 : TWO != 0;
+    const bool save_x0 = SAVE < 0 ? p.x0_save != nullptr : SAVE != 0, save_h1 = SAVE < 0 ? p.h1_save != nullptr : SAVE != 0;
     const int row = row0 + li;
     const bool live = FULL || row < p.n;
     const int rc = FULL ? row : (row < p.n ? row : p.n - 1);
-    // ---- the row's inputs (wave-uniform selects of the source; no divergent control flow)
+    // ---- the B operand of the first layer: in^T[u = 4 ks + lg][row li], three values per lane
     const float* sp = p.s + (size_t)rc * p.s_stride;
     const float* ap = net.A > 0 ? p.a + (size_t)rc * p.a_stride : sp;
-    float in[kStreamIn];
+    float in3[3];
 #pragma unroll
-    for (int u = 0; u < kStreamIn; ++u) {
+    for (int ks = 0; ks < 3; ++ks) {
+        const int u = 4 * ks + lg;
         const bool is_s = u < net.S, is_a = !is_s && u < nin;
         const float* q = is_s ? sp + u : (is_a ? ap + (u - net.S) : sp);
-        const float v = *q;
-        in[u] = (is_s || is_a) ? v : 0.0f;
+        const float v = (RPO_STREAM_SKIP & 1) ? 0.25f * (float)(u + li) : *q;
+        in3[ks] = (is_s || is_a) ? v : 0.0f;
     }
     f32x4 acc[H / 16];
 #pragma unroll
     for (int c = 0; c < H / 16; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float* x0p = (save_x0 && live) ? p.x0_save + (size_t)row * EIN + lg * 4 : nullptr;
 #pragma unroll 1
     for (int it = 0; it < EIN / 16; ++it) {                      // (rolled: fully unrolled, the scheduler hoisted every LDS read of
-        // ---- first layer for the four k's this lane feeds: e = 16 it + 4 lg + m            the tile and spilled 700 registers)
-        float x0v[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const float* wrow = &lds.fl[(it * 16 + lg * 4 + m) * 12];
-            const float4 wA = *reinterpret_cast<const float4*>(wrow);
-            const float4 wB = *reinterpret_cast<const float4*>(wrow + 4);
-            const float4 wC = *reinterpret_cast<const float4*>(wrow + 8);
-            float a1 = wC.w;
-            a1 = fmaf(in[0], wA.x, a1); a1 = fmaf(in[1], wA.y, a1); a1 = fmaf(in[2], wA.z, a1); a1 = fmaf(in[3], wA.w, a1);
-            a1 = fmaf(in[4], wB.x, a1); a1 = fmaf(in[5], wB.y, a1); a1 = fmaf(in[6], wB.z, a1); a1 = fmaf(in[7], wB.w, a1);
-            a1 = fmaf(in[8], wC.x, a1); a1 = fmaf(in[9], wC.y, a1); a1 = fmaf(in[10], wC.z, a1);
-            x0v[m] = a1;
+        // ---- first layer, transposed: x0[row li][16 it + 4 lg + i] in the C layout               the tile and spilled 700 registers)
+        f32x4 x0 = *reinterpret_cast<const f32x4*>(&lds.bias[it * 16 + lg * 4]);
+        if (!(RPO_STREAM_SKIP & 2)) {
+            const float4 w3 = *reinterpret_cast<const float4*>(&lds.fl[((it * 16 + li) * 4 + lg) * 4]);
+            x0 = mfma4(w3.x, in3[0], x0);
+            x0 = mfma4(w3.y, in3[1], x0);
+            x0 = mfma4(w3.z, in3[2], x0);
         }
-        if (p.x0_save && live)
-            __builtin_nontemporal_store(f32x4{x0v[0], x0v[1], x0v[2], x0v[3]},
-                                        reinterpret_cast<f32x4*>(&p.x0_save[(size_t)row * EIN + it * 16 + lg * 4]));
+        if ((FULL && SAVE > 0) || x0p) RPO_STREAM_STORE(x0, reinterpret_cast<f32x4*>(x0p + it * 16));
         float a4[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) a4[m] = fmaxf(x0v[m], 0.0f);
-        // ---- hidden layer: CH column tiles at a time (4; 2 in the 16-wave form, whose budget is 128 registers: an accumulator is
-        // revisited every CH MFMAs = 64+ cycles >= the 40 of a dependent pair), consecutive MFMAs on different accumulators; the B operands of
-        // chunk cc + 1 are requested BEFORE the MFMAs of chunk cc (register ping-pong; the scheduling barriers pin that order:
-        // left alone the compiler issues the reads behind the chunk's last MFMAs, or -- unrolled -- all of them up front)
+        for (int m = 0; m < 4; ++m) a4[m] = fmaxf(x0[m], 0.0f);
+        // ---- hidden layer, transposed: CH column tiles at a time, consecutive MFMAs on different accumulators; the A operands
+        // (W0 from LDS) of chunk cc + 1 are requested BEFORE the MFMAs of chunk cc (register ping-pong; the scheduling barriers pin
+        // that order: left alone the compiler issues the reads behind the chunk's last MFMAs, or -- unrolled -- all of them up front)
         const float* wb = &lds.w0[li * kStreamLdW + it * 16 + lg * 4];
         float4 bcur[CH], bnxt[CH];
 #pragma unroll
@@ -99,62 +122,79 @@ __device__ __forceinline__ void stream_tile(const ARGS& p, const StreamLds<H>& l
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < CH; ++q) acc[cc + q] = mfma4(a4[0], bcur[q].x, acc[cc + q]);
+            for (int q = 0; q < CH; ++q) acc[cc + q] = mfma4(bcur[q].x, a4[0], acc[cc + q]);
 #pragma unroll
-            for (int q = 0; q < CH; ++q) acc[cc + q] = mfma4(a4[1], bcur[q].y, acc[cc + q]);
+            for (int q = 0; q < CH; ++q) acc[cc + q] = mfma4(bcur[q].y, a4[1], acc[cc + q]);
 #pragma unroll
-            for (int q = 0; q < CH; ++q) acc[cc + q] = mfma4(a4[2], bcur[q].z, acc[cc + q]);
+            for (int q = 0; q < CH; ++q) acc[cc + q] = mfma4(bcur[q].z, a4[2], acc[cc + q]);
 #pragma unroll
-            for (int q = 0; q < CH; ++q) acc[cc + q] = mfma4(a4[3], bcur[q].w, acc[cc + q]);
+            for (int q = 0; q < CH; ++q) acc[cc + q] = mfma4(bcur[q].w, a4[3], acc[cc + q]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < CH; ++q) bcur[q] = bnxt[q];
         }
     }
-    // ---- epilogue: acc[c][i] = h1[row0 + 4 lg + i][16 c + li] before the bias
-    float v0[4] = {b1a, b1a, b1a, b1a}, v1[4] = {b1b, b1b, b1b, b1b};
-    float* h1p = p.h1_save ? p.h1_save + (size_t)(row0 + lg * 4) * H + li : nullptr;
+    if (RPO_STREAM_SKIP & 4) {
+        float t = 0.0f;
+#pragma unroll
+        for (int c = 0; c < H / 16; ++c) t += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+        if (t == 12345.678f) p.out[row0] = t;
+        return;
+    }
+    // ---- epilogue: acc[jt][i] = h1[row li][16 jt + 4 lg + i] before the bias
+    float v0 = b1a, v1 = b1b;
+    // ONE base register for the 32 - 48 table reads of the epilogue (b0 | w1a | w1b are contiguous: immediate offsets).  Opaque to
+    // the optimiser on purpose: it otherwise forms one `base | constant` address per read outside the tile loop -- 48 registers
+    // that it then spills around the MFMA loop and reloads here.
+    typedef const f32x4 __attribute__((address_space(3))) * lds_f4;
+    typedef const float __attribute__((address_space(3))) * lds_f;
+    unsigned ep = (unsigned)(__UINTPTR_TYPE__)((lds_f)(&lds.b0[0])) + lg * 16;
+    asm volatile("" : "+v"(ep));
+    float* h1p = (save_h1 && live) ? p.h1_save + (size_t)row * H + lg * 4 : nullptr;
 #pragma unroll
     for (int w8 = 0; w8 < H / 32; ++w8) {                        // the 32-column shares of the row-tile kernels' eight waves
-        float p0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, p1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float q0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int c = 2 * w8; c < 2 * w8 + 2; ++c) {
-            const float4 hb = *reinterpret_cast<const float4*>(&lds.hb[(16 * c + li) * 4]);
-            const float b0 = hb.x, wa = hb.y, wb = hb.z;
-            float h[4];
+        for (int jt = 2 * w8; jt < 2 * w8 + 2; ++jt) {
+            const f32x4 b0 = *(lds_f4)(__UINTPTR_TYPE__)(ep + 64 * jt);
+            const f32x4 wa = *(lds_f4)(__UINTPTR_TYPE__)(ep + 64 * jt + 4 * H);
+            const f32x4 h = acc[jt] + b0;
+            if ((FULL && SAVE > 0) || h1p) RPO_STREAM_STORE(h, reinterpret_cast<f32x4*>(h1p + 16 * jt));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) h[i] = acc[c][i] + b0;
-            if (h1p) {
+            for (int i = 0; i < 4; ++i) q0[i] = fmaf(fmaxf(h[i], 0.0f), wa[i], q0[i]);
+            if (two) {
+                const f32x4 wb2 = *(lds_f4)(__UINTPTR_TYPE__)(ep + 64 * jt + 8 * H);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (FULL || row0 + lg * 4 + i < p.n) __builtin_nontemporal_store(h[i], h1p + (size_t)i * H + 16 * c);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float hr = fmaxf(h[i], 0.0f);
-                p0[i] = fmaf(hr, wa, p0[i]);
-                p1[i] = fmaf(hr, wb, p1[i]);
+                for (int i = 0; i < 4; ++i) q1[i] = fmaf(fmaxf(h[i], 0.0f), wb2[i], q1[i]);
             }
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v0[i] += rpo_row16_sum_lane0(p0[i]);
+        // the old butterfly over the 16 lanes of a row, regrouped: quad sums are lane-local, the two row_shl steps are the two
+        // exchanges below (lane lg = 0 adds in exactly the old order; the others get the same bits by commutativity)
+        float s = (q0[0] + q0[1]) + (q0[2] + q0[3]);
+        s = s + stream_xlane(s, lane ^ 16);
+        s = s + stream_xlane(s, lane ^ 32);
+        v0 += s;
         if (two) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v1[i] += rpo_row16_sum_lane0(p1[i]);
+            float t = (q1[0] + q1[1]) + (q1[2] + q1[3]);
+            t = t + stream_xlane(t, lane ^ 16);
+            t = t + stream_xlane(t, lane ^ 32);
+            v1 += t;
         }
+        __builtin_amdgcn_sched_barrier(0);                       // (else every share's LDS reads are hoisted to the front: spills)
     }
-    if (li == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = row0 + lg * 4 + i;
-            if (FULL || r < p.n) {
-                float o0 = v0[i];
-                if (p.out_mode == 1) o0 = p.scale * tanhf(o0) + p.base;
-                p.out[(size_t)r * net.n_out] = o0;
-                if (two) p.out[(size_t)r * net.n_out + 1] = v1[i];
-            }
-        }
+    if (lg == 0 && live) {
+        float o0 = v0;
+        if (p.out_mode == 1) o0 = p.scale * tanhf(o0) + p.base;
+        p.out[(size_t)row * net.n_out] = o0;
+        if (two) p.out[(size_t)row * net.n_out + 1] = v1;
     }
+}
+
+// The rare tile -- the ragged last one, or a caller that saves only one of the pre-activations -- with every condition at run
+// time (out of line it cost 900 bytes of scratch per lane for the argument copy: inlined)
+template <int H, int CH, class ARGS>
+__device__ __forceinline__ void stream_tile_any(const ARGS& p, const StreamLds<H>& lds, int row0, int lane, float b1a, float b1b) {
+    stream_tile<H, false, CH, -1, -1>(p, lds, row0, lane, b1a, b1b);
 }
 
 // FwdArgs is declared by the includer (mlp.hip); the kernel takes the FwdArgs4 of the multi-network launches
@@ -165,7 +205,6 @@ __device__ __forceinline__ void mlp_forward_stream_body(const ARGS4& p4) {
     const auto& p = p4.net[blockIdx.y];
     const Mlp& net = p.net;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lg = lane >> 4;
     const int nin = net.S + net.A;
     // ---- staging, once per workgroup
     for (int idx = tid; idx < H * (EIN / 4); idx += NW * 64) {
@@ -173,25 +212,37 @@ __device__ __forceinline__ void mlp_forward_stream_body(const ARGS4& p4) {
         *reinterpret_cast<float4*>(&lds.w0[j * kStreamLdW + q * 4]) =
             *reinterpret_cast<const float4*>(&net.W0[(size_t)j * EIN + q * 4]);
     }
-    for (int idx = tid; idx < EIN * 12; idx += NW * 64) {
-        const int e = idx / 12, u = idx - e * 12;
+    for (int idx = tid; idx < EIN * 16; idx += NW * 64) {       // fl[e][lg][ks] = W_first[e][u = 4 ks + lg]
+        const int e = idx >> 4, g = (idx >> 2) & 3, ks = idx & 3, u = 4 * ks + g;
         float v = 0.0f;
-        if (u < net.S) v = net.Ws[e * net.S + u];
-        else if (u < nin) v = net.Wa[e * net.A + (u - net.S)];
-        else if (u == 11) v = net.A > 0 ? net.bs[e] + net.ba[e] : net.bs[e];
+        if (ks < 3) {
+            if (u < net.S) v = net.Ws[e * net.S + u];
+            else if (u < nin) v = net.Wa[e * net.A + (u - net.S)];
+        }
         lds.fl[idx] = v;
     }
-    for (int idx = tid; idx < H; idx += NW * 64)
-        *reinterpret_cast<float4*>(&lds.hb[idx * 4]) =
-            make_float4(net.b0[idx], net.W1[idx], net.n_out > 1 ? net.W1b[idx] : 0.0f, 0.0f);
+    for (int idx = tid; idx < EIN; idx += NW * 64) lds.bias[idx] = net.A > 0 ? net.bs[idx] + net.ba[idx] : net.bs[idx];
+    for (int idx = tid; idx < H; idx += NW * 64) {
+        lds.b0[idx] = net.b0[idx];
+        lds.w1a[idx] = net.W1[idx];
+        lds.w1b[idx] = net.n_out > 1 ? net.W1b[idx] : 0.0f;
+    }
     __syncthreads();
     const float b1a = net.b1[0], b1b = net.n_out > 1 ? net.b1b[0] : 0.0f;
     const int tiles = (p.n + kRows - 1) / kRows;
     for (int t = blockIdx.x * NW + wave; t < tiles; t += gridDim.x * NW) {
         const int row0 = t * kRows;
         constexpr int CH = NW > 12 ? 2 : 4;
-        if (row0 + kRows <= p.n) stream_tile<H, true, CH>(p, lds, row0, li, lg, b1a, b1b);
-        else stream_tile<H, false, CH>(p, lds, row0, li, lg, b1a, b1b);
+        if (row0 + kRows <= p.n) {
+            const bool save = p.x0_save && p.h1_save, none = !p.x0_save && !p.h1_save, two = net.n_out > 1;
+            if (save && !two) stream_tile<H, true, CH, 1, 0>(p, lds, row0, lane, b1a, b1b);          // critics
+            else if (none && !two) stream_tile<H, true, CH, 0, 0>(p, lds, row0, lane, b1a, b1b);     // target networks, DDPG actor
+            else if (save && two) stream_tile<H, true, CH, 1, 1>(p, lds, row0, lane, b1a, b1b);      // Gaussian actor (policy step)
+            else if (none && two) stream_tile<H, true, CH, 0, 1>(p, lds, row0, lane, b1a, b1b);      // Gaussian actor (inference)
+            else stream_tile_any<H, CH>(p, lds, row0, lane, b1a, b1b);                               // (one of x0 / h1 saved)
+        } else {
+            stream_tile_any<H, CH>(p, lds, row0, lane, b1a, b1b);
+        }
     }
 }
 

@@ -385,11 +385,12 @@ def test_training_iterations_graph_equals_eager_and_episodes_roll_over(fused, mo
     monkeypatch.setenv("RPO_GRAPH_CYCLE", "4")
     a = _run(64, 30, use_graph=False, fused=fused)
     b = _run(64, 30, use_graph=True, fused=fused)
-    assert b._graphs.entries[("cycle", 4, True, "overlap")]["graph"] is not None and not b._graphs.capture_failed
+    key = ("cycle", 4, True, "overlap") if fused else ("cycle", 4, True)      # (torch modules: no update clock, serial windows)
+    assert b._graphs.entries[key]["graph"] is not None and not b._graphs.capture_failed
     assert b._policy_prefix_ok() == fused
     monkeypatch.setattr(RPOTrainerBase, "_policy_prefix_enabled", False, raising=False)
     c = _run(64, 30, use_graph=True, fused=fused)
-    assert not c._policy_prefix_ok() and c._graphs.entries[("cycle", 4, True, "overlap")]["graph"] is not None
+    assert not c._policy_prefix_ok() and c._graphs.entries[key]["graph"] is not None
     monkeypatch.undo()
     for other in (b, c):
         assert torch.equal(a.vec.internal, other.vec.internal) and torch.equal(a.buffer.rows, other.buffer.rows)

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Timing-only variants of the streaming forward (RPO_STREAM_SKIP bits, csrc/mlp_stream.h): rpo_amd/csrc/librpo_hip_skipN.so
+set -e
+cd $(dirname $0)/../../rpo_amd/csrc
+for N in "$@"; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DRPO_STREAM_SKIP=$N -c mlp.hip -o /tmp/mlp_skip$N.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o librpo_hip_skip$N.so cartsafe.o pendulum.o evopf.o replay.o train_ops.o /tmp/mlp_skip$N.o fused.o nsplit.o
+done
+ls -la librpo_hip_skip*.so

@@ -60,6 +60,8 @@ def main():
         return
 
     def report(name, fn, flops, reps=10):
+        if mode == "once" and False:
+            pass
         if mode == "once":
             fn()
             torch.cuda.synchronize()
@@ -73,6 +75,8 @@ def main():
             report("forward critic (x0, h1 saved), stream/%d" % waves, lambda: ops.mlp_forward(dcs[0], s, a, out[0], x0[0], h1[0]), f_c)
             report("forward_multi Q_targ || Q, stream/%d" % waves, lambda: ops.mlp_forward_multi(
                 [(dcs[0], s2, a2, out[0], x0[0], h1[0]), (dcs[1], s, a, out[1], x0[1], h1[1])]), 2 * f_c)
+    if mode == "fwd":
+        return
     with ops.tuning(fwd_stream=0):
         report("forward actor (nothing saved), 64-row tiles", lambda: ops.mlp_forward(da, s, None, out[0]), f_a)
         report("forward critic (x0, h1 saved), 64-row tiles", lambda: ops.mlp_forward(dcs[0], s, a, out[0], x0[0], h1[0]), f_c)
