@@ -21,6 +21,7 @@
 #include "mlp_gemm.h"
 #include "mlp_tile.h"
 #include "mlp_stream.h"
+#include "mlp_bwd_stream.h"
 
 namespace {
 
@@ -399,7 +400,12 @@ int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int
     const bool gemm_rows = gemm_path_ok(net, n, x0, h1, 0);       // wide networks: dh | dx0 | da as GEMM launches (mlp_gemm.h)
     if (gemm_rows)
         if (int e = gemm_backward_rows(&args, 1, (hipStream_t)stream)) return e;
-    if (param_grads && ein == 128 && net.H == 256) {              // large batches: rows + weights in ONE pass over the activations
+    if (ein == 128 && net.H == 256 && !gemm_rows) {               // large batches: the two streaming launches (mlp_bwd_stream.h)
+        SplitK sk{nullptr, nullptr, 0, 0};
+        if (param_grads) sk = splitk_plan(args, grad_host->splitk_scratch, grad_host->splitk_floats);
+        if (bwd_stream_applies(args, sk)) return launch_bwd_stream(args, sk, (hipStream_t)stream);
+    }
+    if (param_grads && ein == 128 && net.H == 256) {              // ... or rows + weights in ONE pass over the activations (round 3)
         const SplitK sk = splitk_plan(args, grad_host->splitk_scratch, grad_host->splitk_floats);
         if (sk.Z > 0 && onepass_applies<128, 256>(args, sk)) return launch_onepass<128, 256>(args, sk, (hipStream_t)stream);
     }
@@ -447,6 +453,18 @@ int rpo_mlp_backward_pair(const rpo_mlp* net1_host, const rpo_mlp_grad* grad1_ho
     const bool gemm_rows = gemm_path_ok(n1, n, x0_1, h1_1, 0) && x0_2 && h1_2 && gemm_fits(n1, 2);
     if (gemm_rows)
         if (int e = gemm_backward_rows(args.net, 2, (hipStream_t)stream)) return e;
+    if (ein == 128 && n1.H == 256 && !gemm_rows) {                // (see rpo_mlp_backward: both networks or neither)
+        SplitK k1{nullptr, nullptr, 0, 0}, k2{nullptr, nullptr, 0, 0};
+        const bool own = !param_grads || grad1_host->splitk_scratch != grad2_host->splitk_scratch;
+        if (param_grads) {
+            k1 = splitk_plan(args.net[0], grad1_host->splitk_scratch, grad1_host->splitk_floats);
+            k2 = splitk_plan(args.net[1], grad2_host->splitk_scratch, grad2_host->splitk_floats);
+        }
+        if (own && bwd_stream_applies(args.net[0], k1) && bwd_stream_applies(args.net[1], k2)) {
+            if (int r = launch_bwd_stream(args.net[0], k1, (hipStream_t)stream)) return r;
+            return launch_bwd_stream(args.net[1], k2, (hipStream_t)stream);
+        }
+    }
     if (param_grads && ein == 128 && n1.H == 256 && grad1_host->splitk_scratch != grad2_host->splitk_scratch) {   // (see rpo_mlp_backward)
         const SplitK k1 = splitk_plan(args.net[0], grad1_host->splitk_scratch, grad1_host->splitk_floats);
         const SplitK k2 = splitk_plan(args.net[1], grad2_host->splitk_scratch, grad2_host->splitk_floats);

@@ -353,3 +353,100 @@ def test_split_forward_is_bitwise_the_tile_forward(kind, S, A, n):
     ops.mlp_split_head(d, part, out_s, *mode)
     assert torch.equal(out, out_s) and torch.equal(x0, x0_s) and torch.equal(h1, h1_s)
     assert torch.equal(part, part2)
+
+
+def _flat_grads(net):
+    """ONE flat gradient buffer behind the network's parameters (like agent/flat.py) -> (flat, {name: (offset, shape)})."""
+    total = sum((p.numel() + 3) // 4 * 4 for p in net.parameters())
+    flat = torch.zeros(total + 8, device=DEV)
+    off = (-flat.data_ptr() // 4) % 4
+    for p in net.parameters():
+        p.grad = flat[off:off + p.numel()].view(p.shape)
+        off += (p.numel() + 3) // 4 * 4
+    return flat, total
+
+
+@pytest.mark.parametrize("kind,S,A,n", [("add", 6, 2, 40007), ("add", 5, 2, 16384), ("actor", 6, 0, 20011), ("gauss", 5, 0, 33000)])
+def test_streaming_backward_matches_the_two_pass_kernels(kind, S, A, n):
+    """Large batches, 128 -> 256 networks (round 5, csrc/mlp_bwd_stream.h): the backward as two streaming launches -- rows
+    kernel with W0 in LDS (dx0, first-layer gradients on MFMA, optionally da), weights kernel (dW0, db0, dW1, db1) -- against
+    the rows pass + split-K weights pass of round 3 (rpo_tuning bwd_stream = 0, bwd_onepass = 0): every parameter gradient to
+    1e-5 of its tensor's largest entry (other summation orders; the single-head rows kernel multiplies by dout after the
+    k-sum), the inf-norm of what was written, bitwise reproducible from call to call, += onto existing gradients; the TD /
+    Huber prologue as a launch of its own (same dq and loss shares, bit for bit); the policy step's forms: da alone, and da
+    with the state part of a shared embedding's first-layer gradients."""
+    from rpo_amd import ops
+    torch.manual_seed(n)
+    E, H = 128, 256
+    se = StateEmbedding(S, E, H)
+    if kind == "actor":
+        net = SharedPolicy(S, 1, se, E, H, 1, None)
+    elif kind == "gauss":
+        net = GaussianSharedPolicy(S, 1, se, E, H, 1, None)
+    else:
+        net = SharedValueAdd(S, A, se, ActionEmbedding(A, E, H), E, H)
+    aligned_params(net)
+    flat, total = _flat_grads(net)
+    d = desc_for(ops, net, kind, S, A, E, H)
+    d.splitk = torch.full((max(2, min(256, n // 4096)) * total,), 3.0, device=DEV)      # (dirty: the launch zeroes what it uses)
+    s = torch.randn(n, S, device=DEV)
+    a = torch.randn(n, A, device=DEV) if A else None
+    n_out = 2 if kind == "gauss" else 1
+    out, x0, h1 = torch.empty(n, n_out, device=DEV), torch.empty(n, E, device=DEV), torch.empty(n, H, device=DEV)
+    ops.mlp_forward(d, s, a, out, x0, h1)
+    dout = torch.randn(n, n_out, device=DEV) / n
+    dh, dx0 = torch.empty(n, H, device=DEV), torch.empty(n, E, device=DEV)
+    gm = torch.zeros(ops.CONST["RPO_GRADMAX_LEN"], device=DEV)
+
+    def run(stream, **kw):
+        flat.zero_()
+        gm.zero_()
+        with ops.tuning(bwd_stream=stream, bwd_onepass=0):
+            ops.mlp_backward(d, s, a, x0, h1, dout, dh, dx0, None, gradmax=gm, **kw)
+        return flat.clone(), float(gm.max())
+    ref, ref_max = run(0)
+    got, got_max = run(1)
+    again, _ = run(1)
+    assert torch.equal(got, again)                                           # fixed orders: bitwise reproducible
+    view = {k: (t.grad.data_ptr() - flat.data_ptr()) // 4 for k, t in d.tensors.items() if t is not None}
+    for k, t in d.tensors.items():
+        if t is None:
+            continue
+        r = ref[view[k]:view[k] + t.numel()].cpu().numpy()
+        g = got[view[k]:view[k] + t.numel()].cpu().numpy()
+        assert np.abs(r).max() > 0, k
+        np.testing.assert_allclose(g, r, rtol=1e-5, atol=1e-5 * np.abs(r).max() + 1e-12, err_msg=k)
+    assert got_max == float(got.abs().max()) and abs(got_max - ref_max) <= 1e-5 * ref_max
+    with ops.tuning(bwd_stream=1):                                           # += onto the existing gradients
+        ops.mlp_backward(d, s, a, x0, h1, dout, dh, dx0, None)
+    np.testing.assert_allclose(flat.cpu().numpy(), 2 * got.cpu().numpy(), rtol=1e-5, atol=2e-5 * float(got.abs().max()))
+    if kind != "add":
+        return
+    # ---- TD / Huber prologue (critic update)
+    q, qn1 = out.view(-1).clone(), torch.randn(n, device=DEV)
+    wide = torch.randn(n, 2, device=DEV)
+    reward, done = wide[:, 0:1], (wide[:, 1:2] > 0.5).float()
+    res = {}
+    for stream in (0, 1):
+        flat.zero_()
+        dq, parts = torch.empty(n, device=DEV), torch.zeros((n + 15) // 16, device=DEV)
+        td = ops.Td(q, qn1, None, None, reward, done, 0.0, 0.95, dq, parts)
+        with ops.tuning(bwd_stream=stream, bwd_onepass=0):
+            ops.mlp_backward(d, s, a, x0, h1, None, dh, dx0, None, td=td)
+        res[stream] = (dq.clone(), parts.clone(), flat.clone())
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    np.testing.assert_allclose(res[1][2].cpu().numpy(), res[0][2].cpu().numpy(), rtol=1e-5, atol=1e-5 * float(res[0][2].abs().max()))
+    # ---- the policy step's pass through the critic: dQ/da alone, and with the state part of the first layer (shared embedding)
+    for kw in (dict(param_grads=False), dict(param_grads=True, first_layer_state_only=True)):
+        das = {}
+        for stream in (0, 1):
+            flat.zero_()
+            da = torch.full((n, A), float("nan"), device=DEV)
+            with ops.tuning(bwd_stream=stream, bwd_onepass=0):
+                ops.mlp_backward(d, s, a, x0, h1, dout, dh, dx0, da, **kw)
+            das[stream] = (da.clone(), flat.clone())
+        np.testing.assert_allclose(das[1][0].cpu().numpy(), das[0][0].cpu().numpy(), rtol=1e-5, atol=1e-5 * float(das[0][0].abs().max()))
+        np.testing.assert_allclose(das[1][1].cpu().numpy(), das[0][1].cpu().numpy(), rtol=1e-5, atol=1e-5 * float(das[0][1].abs().max()) + 1e-30)
+        if kw["param_grads"]:
+            ws = d.tensors["Ws"]
+            assert float(ws.grad.abs().max()) > 0 and float(d.tensors["W0"].grad.abs().max()) == 0      # the state part only
