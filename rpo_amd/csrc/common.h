@@ -22,6 +22,14 @@
 extern int g_rpo_tune[RPO_TUNE_COUNT];
 static inline int rpo_tune(int key) { return g_rpo_tune[key]; }
 
+// relu as ONE instruction: the integer maximum of the bit pattern with 0 (positive floats order like their bits, negative
+// floats and -0.0 are negative integers).  fmaxf(x, 0.0f) compiles to two v_max_f32 -- the first quiets a signalling NaN the
+// value could be -- which matters next to f32 MFMAs: vector instructions share their lanes.  Same bits for every non-NaN x.
+__device__ __forceinline__ float rpo_relu_bits(float x) {
+    const int b = __float_as_int(x);
+    return __int_as_float(b > 0 ? b : 0);
+}
+
 static inline int rpo_grid_for(long long n, int per_block = RPO_BLOCK) {
     long long g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;

@@ -29,6 +29,9 @@
 
 namespace rpo_mlp_dev {
 
+#ifndef RPO_BWDS_SKIP
+#define RPO_BWDS_SKIP 0            // timing-only builds (tools/probe/build_stream_variants.sh): weights kernel 1 no loads, 2 no MFMAs;
+#endif                             // rows kernel 4 no h1 loads, 8 no epilogue (x0 loads, first-layer gradients) -- wrong results
 constexpr int kBwdStreamWaves = 16;
 
 struct BwdStreamLds {
@@ -64,7 +67,8 @@ __global__ __launch_bounds__(kBwdStreamWaves * 64, kBwdStreamWaves / 4) void bwd
     constexpr int EIN = 128, H = 256, NW = kBwdStreamWaves;
     __shared__ BwdStreamLds lds;
     const Mlp& net = p.net;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the tile arithmetic stays on the scalar unit)
     const int nin = net.S + net.A;
     for (int idx = tid; idx < H * EIN / 4; idx += NW * 64)
         reinterpret_cast<float4*>(lds.w0)[idx] = reinterpret_cast<const float4*>(net.W0)[idx];
@@ -102,8 +106,8 @@ __global__ __launch_bounds__(kBwdStreamWaves * 64, kBwdStreamWaves / 4) void bwd
         f32x4 hcur = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(h1p));
 #pragma unroll 1
         for (int jt = 0; jt < H / 16; ++jt) {
-            f32x4 hnext = hcur;
-            if (jt + 1 < H / 16) hnext = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(h1p + 16 * (jt + 1)));
+            const int jn = jt + 1 < H / 16 ? jt + 1 : jt;        // (no branch around the prefetch: the last chunk is read twice)
+            const f32x4 hnext = (RPO_BWDS_SKIP & 4) ? f32x4{1.0f, -1.0f, 2.0f, (float)jn} : __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(h1p + 16 * jn));
             const f32x4 wv = *(lds_f4)(__UINTPTR_TYPE__)(w1p + 64 * jt);
             float a4[4];
             if (TWO) {
@@ -129,6 +133,15 @@ __global__ __launch_bounds__(kBwdStreamWaves * 64, kBwdStreamWaves / 4) void bwd
                 acc[1][3] = mfma4(a4[m], b1.w, acc[1][3]);
             }
             hcur = hnext;
+        }
+        if (RPO_BWDS_SKIP & 8) {
+            float tsum = 0.0f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) tsum += acc[h][c][0] + acc[h][c][1] + acc[h][c][2] + acc[h][c][3];
+            if (tsum == 12345.678f) g[0][0][0] += tsum;
+            continue;
         }
         // ---- dx0[row 4 lg + i][e = 64 h + 4 li + c] = dout * acc * 1[x0 > 0]; rows beyond n contribute zeros
         float dsc[4];
@@ -217,110 +230,151 @@ __global__ __launch_bounds__(kBwdStreamWaves * 64, kBwdStreamWaves / 4) void bwd
 }
 
 // --------------------------------------------------------------------------------------------------------- weights kernel
+
+// Eight waves per workgroup (two per SIMD, <= 256 registers): wave (set, jq) owns dW0[64 jq .. 64 jq + 63][all 128 e] of its
+// set's tiles as 4 x 8 interleaved tiles (128 accumulator registers): per k-step ONE 16-byte load of h1 and two of x0 feed 32
+// MFMAs.  (The first cut -- sixteen waves with 4 x 4 tiles, two loads per 16 MFMAs, every x0 chunk read by four waves and
+// every h1 chunk by two -- ran at 0.63 of the peak: 1.9 vector instructions and 0.19 load instructions per MFMA; this
+// form has 1.1 and 0.09.)
+constexpr int kBwdWeightsWaves = 8;
+
 template <bool TWO>
-__global__ __launch_bounds__(kBwdStreamWaves * 64, kBwdStreamWaves / 4) void bwd_stream_weights_kernel(BwdArgs p, SplitK k) {
-    constexpr int EIN = 128, H = 256, NW = kBwdStreamWaves;
-    __shared__ __attribute__((aligned(16))) float red[H * EIN];  // the second set's dW0 at the end; small vectors behind it
+__global__ __launch_bounds__(kBwdWeightsWaves * 64, kBwdWeightsWaves / 4) void bwd_stream_weights_kernel(BwdArgs p, SplitK k) {
+    constexpr int EIN = 128, H = 256;
+    __shared__ __attribute__((aligned(16))) float red[H * EIN];  // the second set's dW0 at the end
     __shared__ float vec[2][3][H];                               // [set][db0 | dW1a | dW1b][j]
     __shared__ float sc[2][2];                                   // [set][db1a | db1b]
     const Mlp& net = p.net;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    const int set = wave >> 3, q = wave & 7, eh = q & 1, jq = q >> 1;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the tile arithmetic below stays on the scalar unit)
+    const int set = wave >> 2, jq = wave & 3;
     const int z = blockIdx.x, Z = gridDim.x;
     const long long tiles = ((long long)p.n + kRows - 1) / kRows;
     const long long t_lo = tiles * z / Z, t_hi = tiles * (z + 1) / Z;
-    const int outs = TWO ? 2 : 1;
-    const int j0 = 64 * jq + 4 * li, e0 = 64 * eh + 4 * li;
+    constexpr int outs = TWO ? 2 : 1;
+    const int j0 = 64 * jq + 4 * li, e0 = 4 * li;
     const f32x4 w1a = *reinterpret_cast<const f32x4*>(net.W1 + j0);
     f32x4 w1b = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     if (TWO) w1b = *reinterpret_cast<const f32x4*>(net.W1b + j0);
-    f32x4 acc[4][4];                                             // [cj][ce]: dW0[j0 + 16 (4 lg' + i) ... see the store below]
+    f32x4 acc[4][8];                                             // [cj][4 eh + ce]: see the store below
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    // per-lane partial sums over its rows (slot lg): db0 on the waves of e-half 0, dW1 (dW1b) on those of e-half 1 -- the
-    // same registers: the branch is wave-uniform
-    f32x4 gv = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, gv2 = gv;
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 gb0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, gw1 = gb0, gw2 = gb0;      // per-lane partial sums over its rows (slot lg)
     float gb1a = 0.0f, gb1b = 0.0f;
-    // operands of k-step (tile, ks): rows row0 + 4 ks + lg
-    auto load = [&](long long t, int ks, f32x4& hv, f32x4& xv, float& da_, float& db_) {
-        const long long r = t * kRows + 4 * ks + lg;
-        const long long rc = r < p.n ? r : (long long)p.n - 1;
-        hv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.h1 + (size_t)rc * H + j0));
-        xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.x0 + (size_t)rc * EIN + e0));
-        da_ = r < p.n ? p.dout[(size_t)rc * outs] : 0.0f;
-        db_ = (TWO && r < p.n) ? p.dout[(size_t)rc * outs + 1] : 0.0f;
+    // one k-step = 4 rows (slot lg): 32 MFMAs on the operands of three 16-byte loads
+    auto step = [&](const f32x4& hv, const f32x4& xa, const f32x4& xb, float da_, float db_) {
+        f32x4 dh;
+        float x1[8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float d = TWO ? fmaf(db_, w1b[c], da_ * w1a[c]) : da_ * w1a[c];
+            dh[c] = hv[c] > 0.0f ? d : 0.0f;
+            x1[c] = rpo_relu_bits(xa[c]);
+            x1[4 + c] = rpo_relu_bits(xb[c]);
+        }
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+            for (int ce = 0; ce < 8; ++ce) {
+                if (RPO_BWDS_SKIP & 2) acc[cj][ce][0] += dh[cj] + x1[ce];
+                else acc[cj][ce] = mfma4(dh[cj], x1[ce], acc[cj][ce]);
+            }
+        gb0 += dh;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float hr = rpo_relu_bits(hv[c]);
+            gw1[c] = fmaf(da_, hr, gw1[c]);
+            if (TWO) gw2[c] = fmaf(db_, hr, gw2[c]);
+        }
+        if (jq == 0 && li == 0) { gb1a += da_; gb1b += db_; }
     };
-    f32x4 hq[3], xq[3];
-    float daq[3], dbq[3];
-    // flat index over (tile, ks) of this set's tiles: tiles t_lo + set, + 2, ...
-    const long long n_t = t_hi > t_lo + set ? (t_hi - t_lo - set + 1) / 2 : 0, n_steps = n_t * 4;
-    auto tile_of = [&](long long s) { return t_lo + set + 2 * (s >> 2); };
-    if (n_steps > 0) load(tile_of(0), 0, hq[0], xq[0], daq[0], dbq[0]);
-    if (n_steps > 1) load(tile_of(1), 1, hq[1], xq[1], daq[1], dbq[1]);
-    for (long long s = 0; s < n_steps; s += 3) {
+    // this set's tiles: t_lo + set, + 2, ...; the FULL ones (every row exists) run through a ring of four k-steps whose loads
+    // are issued without a branch from a scalar base + a per-lane constant offset; a ragged last tile takes the guarded path
+    const long long n_t = t_hi > t_lo + set ? (t_hi - t_lo - set + 1) / 2 : 0;
+    const bool ragged = n_t > 0 && (t_lo + set + 2 * (n_t - 1) + 1) * kRows > p.n;
+    const long long n_steps = (n_t - (ragged ? 1 : 0)) * 4;
+    const float* hbase = p.h1 + (size_t)lg * H + j0;
+    const float* xbase = p.x0 + (size_t)lg * EIN + e0;
+    const float* dbase = p.dout + (size_t)lg * outs;
+    auto load = [&](long long s, f32x4& hv, f32x4& xa, f32x4& xb, float& da_, float& db_) {
+        const long long sc2 = s < n_steps ? s : n_steps - 1;     // (scalar clamp: the last loads are repeated, not skipped)
+        const long long rb = (t_lo + set + 2 * (sc2 >> 2)) * kRows + 4 * (sc2 & 3);   // scalar row base
+        if (RPO_BWDS_SKIP & 1) {
+            const float f = (float)(rb & 7) + (float)li;
+            hv = f32x4{f, -f, f, f}; xa = f32x4{f, f, -f, f}; xb = xa; da_ = f; db_ = f;
+            return;
+        }
+        hv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(hbase + (size_t)rb * H));
+        xa = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xbase + (size_t)rb * EIN));
+        xb = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xbase + (size_t)rb * EIN + 64));
+        da_ = dbase[(size_t)rb * outs];
+        db_ = TWO ? dbase[(size_t)rb * outs + 1] : 0.0f;
+    };
+    if (n_steps > 0) {
+        constexpr int RING = 4;
+        f32x4 hq[RING], xaq[RING], xbq[RING];
+        float daq[RING], dbq[RING];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {                            // ring of three k-steps: two loads in flight behind the MFMAs
-            if (s + b >= n_steps) break;
-            const int nb = (b + 2) % 3;
-            if (s + b + 2 < n_steps) load(tile_of(s + b + 2), (int)((s + b + 2) & 3), hq[nb], xq[nb], daq[nb], dbq[nb]);
-            f32x4 dh, x1;
+        for (int b = 0; b < RING - 1; ++b) load(b, hq[b], xaq[b], xbq[b], daq[b], dbq[b]);
+        for (long long s = 0; s < n_steps; s += RING) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float d = TWO ? fmaf(dbq[b], w1b[c], daq[b] * w1a[c]) : daq[b] * w1a[c];
-                dh[c] = hq[b][c] > 0.0f ? d : 0.0f;
-                x1[c] = fmaxf(xq[b][c], 0.0f);
+            for (int b = 0; b < RING; ++b) {                     // three steps of loads in flight behind the MFMAs of the current one
+                if (s + b >= n_steps) break;
+                constexpr int dummy = 0; (void)dummy;
+                load(s + b + RING - 1, hq[(b + RING - 1) % RING], xaq[(b + RING - 1) % RING], xbq[(b + RING - 1) % RING],
+                     daq[(b + RING - 1) % RING], dbq[(b + RING - 1) % RING]);
+                step(hq[b], xaq[b], xbq[b], daq[b], dbq[b]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int cj = 0; cj < 4; ++cj)
-#pragma unroll
-                for (int ce = 0; ce < 4; ++ce) acc[cj][ce] = mfma4(dh[cj], x1[ce], acc[cj][ce]);
-            if (eh == 0) {
-                gv += dh;
-            } else {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float hr = fmaxf(hq[b][c], 0.0f);
-                    gv[c] = fmaf(daq[b], hr, gv[c]);
-                    if (TWO) gv2[c] = fmaf(dbq[b], hr, gv2[c]);
-                }
-                if (jq == 0 && li == 0) { gb1a += daq[b]; gb1b += dbq[b]; }
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // ---- results.  acc[cj][ce][i] = dW0[j = 64 jq + 4 (4 lg + i) + cj][e = 64 eh + 4 li + ce]: the second set through LDS, the
-    // first adds and writes 16-byte chunks along e into the slice's copy of the gradient span
+    if (ragged) {
+        const long long t = t_lo + set + 2 * (n_t - 1);
+        for (int ks = 0; ks < 4; ++ks) {
+            const long long r = t * kRows + 4 * ks + lg, rc = r < p.n ? r : (long long)p.n - 1;
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(p.h1 + (size_t)rc * H + j0);
+            const f32x4 xa = *reinterpret_cast<const f32x4*>(p.x0 + (size_t)rc * EIN + e0);
+            const f32x4 xb = *reinterpret_cast<const f32x4*>(p.x0 + (size_t)rc * EIN + e0 + 64);
+            const float da_ = r < p.n ? p.dout[(size_t)rc * outs] : 0.0f;
+            const float db_ = (TWO && r < p.n) ? p.dout[(size_t)rc * outs + 1] : 0.0f;
+            step(hv, xa, xb, da_, db_);
+        }
+    }
+    // ---- results.  acc[cj][4 eh + ce][i] = dW0[j = 64 jq + 4 (4 lg + i) + cj][e = 64 eh + 4 li + ce]: the second set through
+    // LDS, the first adds and writes 16-byte chunks along e into the slice's copy of the gradient span
     float* base = k.scratch + (long long)z * k.span;
     if (set == 1) {
 #pragma unroll
         for (int cj = 0; cj < 4; ++cj)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                *reinterpret_cast<f32x4*>(&red[(64 * jq + 4 * (4 * lg + i) + cj) * EIN + e0]) =
-                    f32x4{acc[cj][0][i], acc[cj][1][i], acc[cj][2][i], acc[cj][3][i]};
+#pragma unroll
+                for (int eh = 0; eh < 2; ++eh)
+                    *reinterpret_cast<f32x4*>(&red[(64 * jq + 4 * (4 * lg + i) + cj) * EIN + 64 * eh + e0]) =
+                        f32x4{acc[cj][4 * eh][i], acc[cj][4 * eh + 1][i], acc[cj][4 * eh + 2][i], acc[cj][4 * eh + 3][i]};
     }
     // small vectors: the four slot lanes (lg) of a column, then the sets
-    {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float s1 = gv[c] + bwd_xlane(gv[c], lane ^ 16);
-            s1 = s1 + bwd_xlane(s1, lane ^ 32);
-            if (lg == 0) vec[set][eh == 0 ? 0 : 1][j0 + c] = s1;
-            if (TWO && eh == 1) {
-                float s2 = gv2[c] + bwd_xlane(gv2[c], lane ^ 16);
-                s2 = s2 + bwd_xlane(s2, lane ^ 32);
-                if (lg == 0) vec[set][2][j0 + c] = s2;
-            }
-        }
-        if (eh == 1 && jq == 0 && li == 0) {
-            float s1 = gb1a + bwd_xlane(gb1a, lane ^ 16);
-            s1 = s1 + bwd_xlane(s1, lane ^ 32);
-            float s2 = gb1b + bwd_xlane(gb1b, lane ^ 16);
+    for (int c = 0; c < 4; ++c) {
+        float s0 = gb0[c] + bwd_xlane(gb0[c], lane ^ 16);
+        s0 = s0 + bwd_xlane(s0, lane ^ 32);
+        float s1 = gw1[c] + bwd_xlane(gw1[c], lane ^ 16);
+        s1 = s1 + bwd_xlane(s1, lane ^ 32);
+        if (lg == 0) { vec[set][0][j0 + c] = s0; vec[set][1][j0 + c] = s1; }
+        if (TWO) {
+            float s2 = gw2[c] + bwd_xlane(gw2[c], lane ^ 16);
             s2 = s2 + bwd_xlane(s2, lane ^ 32);
-            if (lg == 0) { sc[set][0] = s1; sc[set][1] = s2; }
+            if (lg == 0) vec[set][2][j0 + c] = s2;
         }
+    }
+    if (jq == 0 && li == 0) {
+        float s1 = gb1a + bwd_xlane(gb1a, lane ^ 16);
+        s1 = s1 + bwd_xlane(s1, lane ^ 32);
+        float s2 = gb1b + bwd_xlane(gb1b, lane ^ 16);
+        s2 = s2 + bwd_xlane(s2, lane ^ 32);
+        if (lg == 0) { sc[set][0] = s1; sc[set][1] = s2; }
     }
     __syncthreads();
     if (set == 0) {
@@ -328,12 +382,15 @@ __global__ __launch_bounds__(kBwdStreamWaves * 64, kBwdStreamWaves / 4) void bwd
 #pragma unroll
         for (int cj = 0; cj < 4; ++cj)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int j = 64 * jq + 4 * (4 * lg + i) + cj;
-                const f32x4 o = *reinterpret_cast<const f32x4*>(&red[j * EIN + e0]);
-                *reinterpret_cast<f32x4*>(dst + (size_t)j * EIN + e0) =
-                    f32x4{acc[cj][0][i] + o[0], acc[cj][1][i] + o[1], acc[cj][2][i] + o[2], acc[cj][3][i] + o[3]};
-            }
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int eh = 0; eh < 2; ++eh) {
+                    const int j = 64 * jq + 4 * (4 * lg + i) + cj;
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(&red[j * EIN + 64 * eh + e0]);
+                    *reinterpret_cast<f32x4*>(dst + (size_t)j * EIN + 64 * eh + e0) =
+                        f32x4{acc[cj][4 * eh][i] + o[0], acc[cj][4 * eh + 1][i] + o[1], acc[cj][4 * eh + 2][i] + o[2],
+                              acc[cj][4 * eh + 3][i] + o[3]};
+                }
     }
     if (tid < H) {
         base[(p.g.b0 - k.lo) + tid] = vec[0][0][tid] + vec[1][0][tid];
@@ -387,12 +444,13 @@ static inline int launch_bwd_stream(const BwdArgs& args_in, const SplitK& k, hip
 #undef RPO_ROWS
     RPO_LAUNCH_CHECK();
     if (gmode == 1) {
-        if (two) hipLaunchKernelGGL((bwd_stream_weights_kernel<true>), grid, block, 0, stream, a, k);
-        else hipLaunchKernelGGL((bwd_stream_weights_kernel<false>), grid, block, 0, stream, a, k);
+        const dim3 wblock(kBwdWeightsWaves * 64);
+        if (two) hipLaunchKernelGGL((bwd_stream_weights_kernel<true>), grid, wblock, 0, stream, a, k);
+        else hipLaunchKernelGGL((bwd_stream_weights_kernel<false>), grid, wblock, 0, stream, a, k);
         RPO_LAUNCH_CHECK();
     }
     if (grads) {
-        long long blocks = (k.span + RPO_BLOCK - 1) / RPO_BLOCK;
+        long long blocks = (k.span + RPO_BLOCK / 4 - 1) / (RPO_BLOCK / 4);
         if (blocks > 1024) blocks = 1024;
         hipLaunchKernelGGL((splitk_reduce_kernel<0>), dim3((int)blocks), dim3(RPO_BLOCK), 0, stream, k, a.gradmax);
         RPO_LAUNCH_CHECK();

@@ -106,7 +106,7 @@ __device__ __forceinline__ void stream_tile(const ARGS& p, const StreamLds<H>& l
         if ((FULL && SAVE > 0) || x0p) RPO_STREAM_STORE(x0, reinterpret_cast<f32x4*>(x0p + it * 16));
         float a4[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) a4[m] = fmaxf(x0[m], 0.0f);
+        for (int m = 0; m < 4; ++m) a4[m] = rpo_relu_bits(x0[m]);
         // ---- hidden layer, transposed: CH column tiles at a time, consecutive MFMAs on different accumulators; the A operands
         // (W0 from LDS) of chunk cc + 1 are requested BEFORE the MFMAs of chunk cc (register ping-pong; the scheduling barriers pin
         // that order: left alone the compiler issues the reads behind the chunk's last MFMAs, or -- unrolled -- all of them up front)
@@ -161,11 +161,11 @@ __device__ __forceinline__ void stream_tile(const ARGS& p, const StreamLds<H>& l
             const f32x4 h = acc[jt] + b0;
             if ((FULL && SAVE > 0) || h1p) RPO_STREAM_STORE(h, reinterpret_cast<f32x4*>(h1p + 16 * jt));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) q0[i] = fmaf(fmaxf(h[i], 0.0f), wa[i], q0[i]);
+            for (int i = 0; i < 4; ++i) q0[i] = fmaf(rpo_relu_bits(h[i]), wa[i], q0[i]);
             if (two) {
                 const f32x4 wb2 = *(lds_f4)(__UINTPTR_TYPE__)(ep + 64 * jt + 8 * H);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) q1[i] = fmaf(fmaxf(h[i], 0.0f), wb2[i], q1[i]);
+                for (int i = 0; i < 4; ++i) q1[i] = fmaf(rpo_relu_bits(h[i]), wb2[i], q1[i]);
             }
         }
         // the old butterfly over the 16 lanes of a row, regrouped: quad sums are lane-local, the two row_shl steps are the two

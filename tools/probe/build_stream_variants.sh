@@ -3,7 +3,8 @@
 set -e
 cd $(dirname $0)/../../rpo_amd/csrc
 for N in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DRPO_STREAM_SKIP=$N -c mlp.hip -o /tmp/mlp_skip$N.o
+  if [ "${KIND:-fwd}" = bwd ]; then BWDS_SKIP=$N; STREAM_SKIP=0; else STREAM_SKIP=$N; BWDS_SKIP=0; fi
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DRPO_STREAM_SKIP=${STREAM_SKIP:-0} -DRPO_BWDS_SKIP=${BWDS_SKIP:-0} -c mlp.hip -o /tmp/mlp_skip$N.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o librpo_hip_skip$N.so cartsafe.o pendulum.o evopf.o replay.o train_ops.o /tmp/mlp_skip$N.o fused.o nsplit.o
 done
 ls -la librpo_hip_skip*.so
