@@ -413,9 +413,9 @@ def pmc_traffic(kernel, lanes, workload="cart_ddpg"):
     gfx950 FETCH_SIZE correction are described there): the workload's own table first (tools/kernel_probe.py
     window:<workload>), then the CartSafe tables of earlier rounds.  None when that (kernel, size) was not collected."""
     base = kernel.split("<")[0].split(" ")[0]
-    names = ["r04_pmc_traffic_%s.json" % workload]
+    names = ["r05_pmc_traffic_%s.json" % workload, "r04_pmc_traffic_%s.json" % workload]
     if workload.startswith("cart"):
-        names += ["r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"]
+        names += ["r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"]
     for name in names:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:

@@ -92,6 +92,14 @@ __global__ __launch_bounds__(kBwdStreamWaves * 64, kBwdStreamWaves / 4) void bwd
     typedef const float __attribute__((address_space(3))) * lds_f;
     unsigned w1p = (unsigned)(__UINTPTR_TYPE__)((lds_f)(&lds.w1a[0])) + lg * 16;
     asm volatile("" : "+v"(w1p));                                // (one base register, immediate offsets: see mlp_stream.h)
+    // (the first h1 chunk of a tile is requested during the PREVIOUS tile's epilogue: at the tile's start the load would expose
+    //  a full memory latency per tile)
+    auto h1_row = [&](long long t) {
+        const long long r = t * kRows + li;
+        return p.h1 + (size_t)(r < p.n ? r : (long long)p.n - 1) * H + lg * 4;
+    };
+    f32x4 hfirst = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (t_lo + wave < t_hi) hfirst = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(h1_row(t_lo + wave)));
     for (long long t = t_lo + wave; t < t_hi; t += NW) {
         const long long row0 = t * kRows;
         const long long rowA = row0 + li < p.n ? row0 + li : (long long)p.n - 1;       // this lane's row of the h1 chunks
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(kBwdStreamWaves * 64, kBwdStreamWaves / 4) void bwd
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[h][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        f32x4 hcur = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(h1p));
+        f32x4 hcur = hfirst;
 #pragma unroll 1
         for (int jt = 0; jt < H / 16; ++jt) {
             const int jn = jt + 1 < H / 16 ? jt + 1 : jt;        // (no branch around the prefetch: the last chunk is read twice)
@@ -134,6 +142,7 @@ __global__ __launch_bounds__(kBwdStreamWaves * 64, kBwdStreamWaves / 4) void bwd
             }
             hcur = hnext;
         }
+        hfirst = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(h1_row(t + NW < t_hi ? t + NW : t)));
         if (RPO_BWDS_SKIP & 8) {
             float tsum = 0.0f;
 #pragma unroll

@@ -66,21 +66,16 @@ __device__ __forceinline__ float stream_xlane(float v, int src_lane) {
 // hidden layer (an accumulator is revisited every CH MFMAs = 64+ cycles >= the 40 of a dependent pair).  SAVE / TWO: whether
 // the pre-activations are stored / the network has a second head, as compile-time facts (1 / 0) on the hot path -- as run-time
 // conditions (-1: the rare partial tile) every share of the epilogue is a branch region of its own.
-template <int H, bool FULL, int CH, int SAVE, int TWO, class ARGS>
-__device__ __forceinline__ void stream_tile(const ARGS& p, const StreamLds<H>& lds, int row0, int lane, float b1a, float b1b) {
-    constexpr int EIN = 128;
+// The B operand of the first layer for the tile at row0: in^T[u = 4 ks + lg][row li], three values per lane (rows beyond n:
+// a clamped row -- their results are never stored).  Requested one tile AHEAD by the caller: at the tile's start the loads
+// would expose a full memory latency per tile.
+template <class ARGS>
+__device__ __forceinline__ void stream_inputs(const ARGS& p, long long row0, int lane, float (&in3)[3]) {
     const Mlp& net = p.net;
-    const int li = lane & 15, lg = lane >> 4;
-    const int nin = net.S + net.A;
-    const bool two = TWO < 0 ? net.n_out > 1 : TWO != 0;
-    const bool save_x0 = SAVE < 0 ? p.x0_save != nullptr : SAVE != 0, save_h1 = SAVE < 0 ? p.h1_save != nullptr : SAVE != 0;
-    const int row = row0 + li;
-    const bool live = FULL || row < p.n;
-    const int rc = FULL ? row : (row < p.n ? row : p.n - 1);
-    // ---- the B operand of the first layer: in^T[u = 4 ks + lg][row li], three values per lane
+    const int li = lane & 15, lg = lane >> 4, nin = net.S + net.A;
+    const long long row = row0 + li, rc = row < p.n ? row : (long long)p.n - 1;
     const float* sp = p.s + (size_t)rc * p.s_stride;
     const float* ap = net.A > 0 ? p.a + (size_t)rc * p.a_stride : sp;
-    float in3[3];
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
         const int u = 4 * ks + lg;
@@ -89,6 +84,18 @@ __device__ __forceinline__ void stream_tile(const ARGS& p, const StreamLds<H>& l
         const float v = (RPO_STREAM_SKIP & 1) ? 0.25f * (float)(u + li) : *q;
         in3[ks] = (is_s || is_a) ? v : 0.0f;
     }
+}
+
+template <int H, bool FULL, int CH, int SAVE, int TWO, class ARGS>
+__device__ __forceinline__ void stream_tile(const ARGS& p, const StreamLds<H>& lds, int row0, int lane, float b1a, float b1b,
+                                            const float (&in3)[3]) {
+    constexpr int EIN = 128;
+    const Mlp& net = p.net;
+    const int li = lane & 15, lg = lane >> 4;
+    const bool two = TWO < 0 ? net.n_out > 1 : TWO != 0;
+    const bool save_x0 = SAVE < 0 ? p.x0_save != nullptr : SAVE != 0, save_h1 = SAVE < 0 ? p.h1_save != nullptr : SAVE != 0;
+    const int row = row0 + li;
+    const bool live = FULL || row < p.n;
     f32x4 acc[H / 16];
 #pragma unroll
     for (int c = 0; c < H / 16; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -193,8 +200,9 @@ __device__ __forceinline__ void stream_tile(const ARGS& p, const StreamLds<H>& l
 // The rare tile -- the ragged last one, or a caller that saves only one of the pre-activations -- with every condition at run
 // time (out of line it cost 900 bytes of scratch per lane for the argument copy: inlined)
 template <int H, int CH, class ARGS>
-__device__ __forceinline__ void stream_tile_any(const ARGS& p, const StreamLds<H>& lds, int row0, int lane, float b1a, float b1b) {
-    stream_tile<H, false, CH, -1, -1>(p, lds, row0, lane, b1a, b1b);
+__device__ __forceinline__ void stream_tile_any(const ARGS& p, const StreamLds<H>& lds, int row0, int lane, float b1a, float b1b,
+                                                const float (&in3)[3]) {
+    stream_tile<H, false, CH, -1, -1>(p, lds, row0, lane, b1a, b1b, in3);
 }
 
 // FwdArgs is declared by the includer (mlp.hip); the kernel takes the FwdArgs4 of the multi-network launches
@@ -204,7 +212,8 @@ __device__ __forceinline__ void mlp_forward_stream_body(const ARGS4& p4) {
     __shared__ StreamLds<H> lds;
     const auto& p = p4.net[blockIdx.y];
     const Mlp& net = p.net;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar tile arithmetic)
     const int nin = net.S + net.A;
     // ---- staging, once per workgroup
     for (int idx = tid; idx < H * (EIN / 4); idx += NW * 64) {
@@ -230,19 +239,26 @@ __device__ __forceinline__ void mlp_forward_stream_body(const ARGS4& p4) {
     __syncthreads();
     const float b1a = net.b1[0], b1b = net.n_out > 1 ? net.b1b[0] : 0.0f;
     const int tiles = (p.n + kRows - 1) / kRows;
-    for (int t = blockIdx.x * NW + wave; t < tiles; t += gridDim.x * NW) {
+    const int t0 = blockIdx.x * NW + wave, dt = gridDim.x * NW;
+    float in3[3] = {0.0f, 0.0f, 0.0f};
+    if (t0 < tiles) stream_inputs(p, (long long)t0 * kRows, lane, in3);
+    for (int t = t0; t < tiles; t += dt) {
         const int row0 = t * kRows;
+        float nxt[3];
+        stream_inputs(p, (long long)(t + dt < tiles ? t + dt : t) * kRows, lane, nxt);   // the next tile's inputs land under this tile's MFMAs
         constexpr int CH = NW > 12 ? 2 : 4;
         if (row0 + kRows <= p.n) {
             const bool save = p.x0_save && p.h1_save, none = !p.x0_save && !p.h1_save, two = net.n_out > 1;
-            if (save && !two) stream_tile<H, true, CH, 1, 0>(p, lds, row0, lane, b1a, b1b);          // critics
-            else if (none && !two) stream_tile<H, true, CH, 0, 0>(p, lds, row0, lane, b1a, b1b);     // target networks, DDPG actor
-            else if (save && two) stream_tile<H, true, CH, 1, 1>(p, lds, row0, lane, b1a, b1b);      // Gaussian actor (policy step)
-            else if (none && two) stream_tile<H, true, CH, 0, 1>(p, lds, row0, lane, b1a, b1b);      // Gaussian actor (inference)
-            else stream_tile_any<H, CH>(p, lds, row0, lane, b1a, b1b);                               // (one of x0 / h1 saved)
+            if (save && !two) stream_tile<H, true, CH, 1, 0>(p, lds, row0, lane, b1a, b1b, in3);          // critics
+            else if (none && !two) stream_tile<H, true, CH, 0, 0>(p, lds, row0, lane, b1a, b1b, in3);     // target networks, DDPG actor
+            else if (save && two) stream_tile<H, true, CH, 1, 1>(p, lds, row0, lane, b1a, b1b, in3);      // Gaussian actor (policy step)
+            else if (none && two) stream_tile<H, true, CH, 0, 1>(p, lds, row0, lane, b1a, b1b, in3);      // Gaussian actor (inference)
+            else stream_tile_any<H, CH>(p, lds, row0, lane, b1a, b1b, in3);                               // (one of x0 / h1 saved)
         } else {
-            stream_tile_any<H, CH>(p, lds, row0, lane, b1a, b1b);
+            stream_tile_any<H, CH>(p, lds, row0, lane, b1a, b1b, in3);
         }
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) in3[ks] = nxt[ks];
     }
 }
 

@@ -4,7 +4,7 @@
 #   3. tools/collect_profiles.sh (rocprofv3 kernel stats / timelines of the bench commands, PMC traffic passes).
 # Everything lands in gpurun_out/evidence_rNN/; copy what is to be judged into profiles/.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 OUT=$PWD/gpurun_out/evidence_$R
 mkdir -p $OUT
 export RPO_VERBOSE=0
@@ -23,6 +23,16 @@ done
 for W in cart_sac pen_ddpg pen_sac evopf_ddpg evopf_sac; do
   timeout 900 python3 bench.py --workload $W > $OUT/bench_line_$W.json 2> $OUT/bench_line_$W.err
 done
+# bench.py's N > 1 control flow on this one GPU (gloo, two ranks sharing cuda:0): a control-flow check, not a scaling figure
+RPO_BENCH_BACKEND=gloo timeout 600 python3 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_gloo_2ranks.json 2> $OUT/bench_gloo_2ranks.err
+# the large-batch update's GEMM-shaped launches: event-timed rooflines, rocprofv3 kernel stats, SQ / GRBM counters
+timeout 600 python3 tools/probe_mlp_large.py > $OUT/probe_mlp_large.txt 2>&1
+( export TMPDIR=/tmp; ROOT=$PWD; cd /tmp; rm -rf /tmp/p_lb
+  rocprofv3 --kernel-trace --stats -d /tmp/p_lb -o t -- python3 $ROOT/tools/probe_large_batch.py cart_ddpg 1048576 4096 > $OUT/large_batch_cart_ddpg_profiled.txt 2>&1
+  DB=$(ls /tmp/p_lb/*results.db 2>/dev/null | head -1)
+  [ -n "$DB" ] && python3 $ROOT/tools/rocpd_summary.py $DB 30 > $OUT/large_batch_cart_ddpg_kernel_stats.txt )
+bash tools/pmc_mlp_large.sh > $OUT/pmc_mlp_large.log 2>&1
+cp gpurun_out/pmc_mlp_large.txt gpurun_out/mlp_large_kernel_stats.txt $OUT/ 2>/dev/null
 bash tools/collect_profiles.sh $R > $OUT/collect_profiles.log 2>&1
 cp -r gpurun_out/prof_$R/* $OUT/ 2>/dev/null
 ls $OUT | head -80

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy what is to be judged from gpurun_out/evidence_rNN/ (tools/collect_evidence.sh) into profiles/ under round-prefixed names.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 E=gpurun_out/evidence_$R
 P=profiles
 for w in cart_ddpg cart_sac pen_ddpg pen_sac evopf_ddpg evopf_sac; do
@@ -19,6 +19,12 @@ for w in cart_sac pen_ddpg pen_sac evopf_ddpg evopf_sac; do cp $E/bench_line_$w.
 for w in cart_ddpg cart_sac; do cp $E/bench_force_dist_$w.json $P/${R}_bench_force_dist_$w.json; cp $E/probe_large_batch_$w.txt $P/${R}_probe_large_batch_$w.txt; done
 cp $E/pytest_gpu.log $P/${R}_pytest_gpu.log
 cp $E/probe_project.txt $P/${R}_probe_project.txt
-cp gpurun_out/statistical_parity_*.json $P/ 2>/dev/null
-cp gpurun_out/cadence_learning.json $P/${R}_cadence_learning.json 2>/dev/null
+# (the in-suite statistical samples are sanity samples since round 5: the resolved evidence is profiles/r05_stat_rows_* and
+#  profiles/r05_cadence_*, collected by tools/statistical_parity.py / tools/cadence_learning.py)
+for f in gpurun_out/statistical_parity_*.json; do cp $f $P/${R}_suite_$(basename $f) 2>/dev/null; done
+cp $E/bench_gloo_2ranks.json $P/${R}_bench_gloo_2ranks.json
+cp $E/probe_mlp_large.txt $P/${R}_probe_mlp_large.txt
+cp $E/large_batch_cart_ddpg_kernel_stats.txt $P/${R}_large_batch_cart_ddpg_kernel_stats.txt
+cp $E/pmc_mlp_large.txt $P/${R}_pmc_mlp_large.txt
+cp $E/mlp_large_kernel_stats.txt $P/${R}_mlp_large_kernel_stats.txt
 ls $P | grep -c "^$R"

@@ -97,7 +97,8 @@ def main():
     dcs[0] = desc_for(ops, net, "add", S, A, E, H)
     dcs[0].splitk = torch.zeros(max(2, min(256, n // 4096)) * total, device=dev)
     report("backward critic (param grads)", lambda: ops.mlp_backward(dcs[0], s, a, x0[0], h1[0], dout, dh, dx0, None), 2 * f_c, reps=5)
-    report("backward critic rows only (dQ/da)", lambda: ops.mlp_backward(dcs[0], s, a, x0[0], h1[0], dout, dh, dx0, dA, param_grads=False), 2 * f_c, reps=5)
+    # (the dQ/da pass of the policy step: dh -> dx0 -> da, no parameter gradients: one forward's worth of flops)
+    report("backward critic rows only (dQ/da)", lambda: ops.mlp_backward(dcs[0], s, a, x0[0], h1[0], dout, dh, dx0, dA, param_grads=False), f_c, reps=5)
 
 
 if __name__ == "__main__":
