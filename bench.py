@@ -770,7 +770,9 @@ def main():
         # NOT the reference's quantity: the fraction of (env, vector step) pairs with max(max_ineq, max_eq) > 1e-3 over the
         # first `constraint_violation_window` of THIS run, in which the policy receives one update per VECTOR step (1 / 4096 of
         # the reference's learning per env step) -- it mostly measures how early in training the window sits.  The figure that
-        # is comparable with the reference's 3000-step single-env runs is constraint_violation_rate_n1 below.
+        # is comparable with the reference's 3000-step single-env runs is constraint_violation_rate_n1 below (1536 + 1536 seeds
+        # in profiles/r05_stat_rows_ddpg_cart.*: +0.12e-3 +- 0.27e-3); at matched UPDATES the vectorised cadence violates 2.2e-3
+        # LESS than the reference (profiles/r05_cadence_learning.json).
         **({"control_flow_check": "gloo%s: control-flow check of the N > 1 path, NOT a scaling figure (the measured "
                                   "configuration is one rank per GPU over RCCL)" % (", %d ranks time-slicing %d GPU(s)" % (
                                       world, torch.cuda.device_count()) if shared_gpu else "")}
@@ -849,13 +851,14 @@ def main():
                     "over_utd_matched": (EPG / dt) / result["utd_matched_env_steps_per_s"],
                     "note": "one batch-%d update per vector step: 256 sampled transitions per env step like the reference, one "
                             "optimiser step per vector step (not %d)" % (256 * EPG, EPG),
-                    # tools/cadence_learning.py, 8 seeds x 3000 updates vs the reference's 384 runs (profiles/r04_cadence_learning.json,
-                    # tests/test_statistical_parity_gpu.py::test_vectorised_cadences_learn_like_the_reference)
+                    # tools/cadence_learning.py, 32 (large batch) / 128 (batch 256) seeds x 3000 updates vs the reference's 1536 runs
+                    # (profiles/r05_cadence_learning.json, tests/test_statistical_evidence.py)
                     "learning_at_matched_updates": "THROUGHPUT FIGURE of another optimiser regime, not the reference's learning "
-                            "curve: at 3000 updates it reaches return 24.1 +- 1.8 (second half 31.4 +- 3.0) where the reference "
-                            "reaches 27.5 +- 0.6 (32.9 +- 0.8), with a LOWER violation rate (0.76e-2 +- 0.12e-2 vs 1.31e-2); the "
-                            "batch-256 cadence of the headline reproduces the reference at matched updates (25.6 +- 2.1 / 34.1 +- "
-                            "3.5, 1.07e-2 +- 0.18e-2)"}
+                            "curve: at 3000 updates it reaches return 24.9 +- 1.2 (second half 29.6 +- 1.6) where the reference "
+                            "reaches 28.9 +- 0.35 (35.5 +- 0.5), with a LOWER violation rate (0.67e-2 +- 0.08e-2 vs 1.33e-2); the "
+                            "batch-256 cadence of the headline is BETTER than the reference on both at matched updates (33.4 +- 1.6 "
+                            "/ 42.6 +- 2.3, 1.10e-2 +- 0.06e-2: sampling from 4096 independent histories; one lane reproduces the "
+                            "reference, DESIGN.md 5 round 5)"}
                 if not args.no_clinic:
                     log("kernel clinic of the large-batch update:")
                     cl = kernel_clinic(lb, args.workload)
