@@ -154,7 +154,8 @@ int rpo_abi_version(void);
  * unknown key.  Not thread-safe against concurrent launches (one host thread per device, as everywhere in this ABI). */
 #define RPO_TUNE_FWD_STREAM 0       /* 1: large-n forward (n >= 12288, 128 -> 256 scalar heads) through the weights-in-LDS
                                        streaming kernel (mlp_stream.h); 0: the 64-row tile kernel of rounds 3-4 */
-#define RPO_TUNE_FWD_STREAM_WAVES 1 /* waves per workgroup of that kernel: 12 (default, <= 168 registers) or 16 (<= 128) */
+#define RPO_TUNE_FWD_STREAM_WAVES 1 /* waves per workgroup of that kernel: 16 (default, <= 128 registers: 528 us at 2^20 rows) or 12
+                                       (<= 168 registers: 576 us) */
 #define RPO_TUNE_BWD_ONEPASS 2      /* 1: large-batch backward in one pass over the activations; 0: rows pass + split-K weights pass */
 #define RPO_TUNE_GEMM_KSPLIT 3      /* 1: K >= 256 layer launches split k over the four waves of a workgroup; 0: one chain */
 #define RPO_TUNE_MLP_GEMM 4         /* 1: 256-wide networks layer by layer (mlp_gemm.h); 0: row-tile kernels */

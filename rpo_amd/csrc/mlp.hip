@@ -109,7 +109,7 @@ static bool stream_applies(const FwdArgs4& a, int count, int n) {
 }
 
 static int launch_stream(const FwdArgs4& a, int count, int n, hipStream_t stream) {
-    const int nw = rpo_tune(RPO_TUNE_FWD_STREAM_WAVES) == 16 ? 16 : 12;
+    const int nw = rpo_tune(RPO_TUNE_FWD_STREAM_WAVES) == 12 ? 12 : 16;
     const int tiles = (n + kRows - 1) / kRows;
     int gx = stream_cus() / count;                              // one persistent workgroup per CU (LDS: 150 KB each)
     if (gx < 1) gx = 1;

@@ -224,3 +224,42 @@ def test_evopf_static_order_is_refused_for_another_network():
         assert not ops.EvopfKernels(table).static_order
     finally:
         os.environ.pop("RPO_EVOPF_PIVOT")
+
+
+def test_schedule_parsing_and_ring_validation(monkeypatch):
+    """Round 5: ONE structured switch for the optional parts of the launch schedule (RPO_SCHEDULE / schedule=), read at
+    construction; unknown parts are refused.  And the replay ring's width is validated where tensors become pointers (ADVICE
+    r04: the ring stride is compiled into the step / rollout / rider / fused-sampling kernels)."""
+    import torch
+    from rpo_amd import ops
+    from rpo_amd.algo.trainer import SCHEDULE_DEFAULTS, parse_schedule
+    monkeypatch.delenv("RPO_SCHEDULE", raising=False)
+    assert parse_schedule() == SCHEDULE_DEFAULTS and SCHEDULE_DEFAULTS["front"] == 1 and SCHEDULE_DEFAULTS["force_dist"] == 0
+    monkeypatch.setenv("RPO_SCHEDULE", "front=0, ride=0,force_dist")
+    s = parse_schedule(dict(split=0))
+    assert (s["front"], s["ride"], s["force_dist"], s["split"], s["fused_mlp"]) == (0, 0, 1, 0, 1)
+    monkeypatch.setenv("RPO_SCHEDULE", "frnot=0")
+    with pytest.raises(ValueError):
+        parse_schedule()
+    monkeypatch.delenv("RPO_SCHEDULE")
+    with pytest.raises(ValueError):
+        parse_schedule(dict(nope=1))
+    # a [rows, 24] ring (ABI <= 3) where the kernels stride 32 floats: refused before anything is launched
+    k = ops.CartSafeKernels(np.zeros(ops.CONST["RPO_CART_CONSTS_LEN"], dtype=np.float32), 1)
+    with pytest.raises(ops.RpoHipError, match="ring"):
+        ops._ring(torch.zeros(8, k.row_floats), k.ring_floats)
+    with pytest.raises(ops.RpoHipError, match="ring"):
+        ops.RolloutRider(ring_floats=k.ring_floats, rows=torch.zeros(8, k.row_floats))
+    assert ops._ring(None, k.ring_floats) is None
+
+
+def test_tuning_switches_round_trip():
+    """rpo_tuning (the library reads no environment variable): set / restore through the context manager, unknown keys refused,
+    defaults = what ships (streaming forward on 16 waves, streaming backward)."""
+    from rpo_amd import ops
+    assert ops.tuning.get("fwd_stream") == 1 and ops.tuning.get("fwd_stream_waves") == 16 and ops.tuning.get("bwd_stream") == 1
+    with ops.tuning(fwd_stream=0, bwd_onepass=0):
+        assert ops.tuning.get("fwd_stream") == 0 and ops.tuning.get("bwd_onepass") == 0
+    assert ops.tuning.get("fwd_stream") == 1 and ops.tuning.get("bwd_onepass") == 1
+    with pytest.raises(ops.RpoHipError):
+        ops.tuning(no_such_key=1)
