@@ -116,6 +116,8 @@ __global__ __launch_bounds__(kBwdStreamWaves * 64, kBwdStreamWaves / 4) void bwd
         for (int jt = 0; jt < H / 16; ++jt) {
             const int jn = jt + 1 < H / 16 ? jt + 1 : jt;        // (no branch around the prefetch: the last chunk is read twice)
             const f32x4 hnext = (RPO_BWDS_SKIP & 4) ? f32x4{1.0f, -1.0f, 2.0f, (float)jn} : __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(h1p + 16 * jn));
+            __builtin_amdgcn_sched_barrier(0);                   // (the request stays HERE: the scheduler otherwise sinks it behind the
+                                                                 //  chunk's MFMAs to reuse hcur's registers -- a full latency per chunk)
             const f32x4 wv = *(lds_f4)(__UINTPTR_TYPE__)(w1p + 64 * jt);
             float a4[4];
             if (TWO) {
