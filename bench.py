@@ -666,6 +666,9 @@ def main():
                     help="collective backend of an N > 1 run.  nccl (= RCCL, one rank per GPU) is what is measured; gloo lets "
                          "the ranks share a GPU with host-driven collectives between hipGraph segments -- a control-flow check "
                          "of the N > 1 path on a one-GPU box, labelled as such in the line")
+    ap.add_argument("--tuning", default="", metavar="KEY=VALUE[,...]",
+                    help="A/B aid: library kernel-variant switches (rpo_tuning / ops.TUNE) set before the trainer is built; the "
+                         "line reports them under config.tuning")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -717,6 +720,10 @@ def main():
             " (host-driven%s)" % (", ranks share a GPU" if shared_gpu else ""), dist.get_world_size()))
     rccl_ranks = dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0
 
+    tuning = {k.strip(): int(v) for k, _, v in (item.partition("=") for item in args.tuning.split(",") if item.strip())}
+    if tuning:
+        from rpo_amd import ops as _ops
+        _ops.tuning(**tuning).__enter__()                        # (for the life of the process)
     EPG = envs_per_gpu(args.workload)
     n_total = EPG * world
     spin_up(device)
@@ -756,6 +763,7 @@ def main():
                    "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                    "hip_graph": bool(tr._graphs.enabled), "graph_window_iterations": tr._cycle,
                    "training_batch_projection": tr.projection_mode,
+                   **({"tuning": tuning} if tuning else {}),
                    # what RCCL saw (0: no process group -- the single-process run has no collective at all), and the
                    # collectives of the data-parallel iteration: one all-reduce of the critic's flat gradient slice per update,
                    # one more (actor slice + multipliers [+ log alpha] in one bucket) on every policy_fre-th

@@ -1134,7 +1134,13 @@ class RPOTrainerBase(object):
     def _overlapped_window(self, t, L):
         """L iterations (t is a policy_fre boundary) with rollout i+1 forked off right after the sampling launch of update i
         -- the gather must see the ring before the next rollout overwrites its oldest slot -- and joined before update
-        i+1 samples.  After a policy step the next rollout waits for the new actor (serial)."""
+        i+1 samples.  After a policy step the next rollout waits for the new actor (serial).
+
+        Capture order matters (round 5, tools/probe/branch_probe.py): of the two successors of the fork point, hipGraph keeps
+        the one captured FIRST in the queue of the fork point (its next launch starts 2.8 us later) and hands the other to a
+        second queue (9.5 us).  So the fork is an EVENT recorded behind the sampling launch, the update's launches -- the
+        critical chain -- are captured first, and the second branch is captured behind them waiting for that event (it has the
+        slack); the join then costs 5 us instead of 8.5.  Same dependencies, same bits."""
         F, fl = self.policy_fre, self.agent.flat
         main = torch.cuda.current_stream()
         if self._ovl_stream is None:
@@ -1146,24 +1152,24 @@ class RPOTrainerBase(object):
             more = i + 1 < L
             overlap = more and not actor_step
 
-            def fork():
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    self._rollout(False)
             self._iter_actor_step = actor_step
             cols = self._last_cols = self._sample()
-            if overlap:
-                fork()                                                      # (_sample() launched the gather)
             # policy iteration: what the policy step computes from the actor alone (pi(s), noise, Complete, Lagrangian) runs on
             # the second branch beside the critic update (`_actor_prefix`; no shared embedding here: `_overlap_ok`)
             prefix = actor_step and self._policy_prefix_ok()
-            if prefix:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    self._actor_pre = self._actor_prefix(cols)
+            if overlap or prefix:
+                forked = torch.cuda.Event()
+                forked.record(main)                                         # (_sample() launched the gather)
             self._critic_update(cols)
             self.dist.mean_([fl.gradient(fl.critic_range)])
             self._critic_step(actor_step)
+            if overlap or prefix:                                           # the second branch, captured behind the critical chain
+                side.wait_event(forked)
+                with torch.cuda.stream(side):
+                    if prefix:
+                        self._actor_pre = self._actor_prefix(cols)
+                    else:
+                        self._rollout(False)
             if actor_step:
                 if prefix:
                     main.wait_stream(side)
