@@ -37,6 +37,10 @@ struct GemmArgs4 { GemmArgs g[kGemmProblems]; };
 
 constexpr int kGemmThreads = 256, kGemmCols = 64, kGemmMaxK = 512;
 
+#ifndef RPO_GEMM_SKIP
+#define RPO_GEMM_SKIP 0            // debug builds only (tools/probe/build_stream_variants.sh KIND=gemm): timing with a phase left
+#endif                             // out -- 1 no A loads, 2 no weight loads, 4 no MFMA chain, 8 no stores, 16 no epilogue operands
+
 // One operand pair of a 16 x 16 output tile.  The k range runs in chunks of CH blocks of 16: the weight operands of chunk c + 1
 // are requested before the MFMAs of chunk c are issued (register ping-pong), in a ROLLED loop.  Two things this replaces, both
 // measured at 24 us for the hidden layer (K = 512): loads inside the k loop (32 dependent L2 round trips), and the fully
@@ -48,7 +52,9 @@ __device__ __forceinline__ void gemm_load_chunk(float (&b)[CH][4], const float* 
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
         const int kb = (c * CH + u) * 16 + lg * 4;
-        if (VEC) {
+        if (RPO_GEMM_SKIP & 2) {
+            b[u][0] = b[u][1] = b[u][2] = b[u][3] = 0.001f * (float)(kb + nc);
+        } else if (VEC) {
             const int kc = kb + 3 < K ? kb : 0;
             const float4 v = *reinterpret_cast<const float4*>(&W[(size_t)nc * ldw + kc]);
             b[u][0] = v.x; b[u][1] = v.y; b[u][2] = v.z; b[u][3] = v.w;
@@ -67,6 +73,7 @@ __device__ __forceinline__ f32x4 gemm_mfma_chunk(const float (&b)[CH][4], const 
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
         const float4 a4 = *reinterpret_cast<const float4*>(&a_s[li * ldk + (c * CH + u) * 16 + lg * 4]);
+        if (RPO_GEMM_SKIP & 4) { acc[0] += a4.x * b[u][0]; acc[1] += a4.y * b[u][1]; acc[2] += a4.z * b[u][2]; acc[3] += a4.w * b[u][3]; continue; }
         acc = mfma4(a4.x, b[u][0], acc);
         acc = mfma4(a4.y, b[u][1], acc);
         acc = mfma4(a4.z, b[u][2], acc);
@@ -104,6 +111,10 @@ __device__ __forceinline__ f32x4 gemm_chain(const float* a_s, int ldk, const flo
 __device__ __forceinline__ void gemm_stage(float* a_s, int ldk, int kw, const float* __restrict__ A, int lda, int K, int m0, int M,
                                            bool relu, bool vec) {
     const int tid = threadIdx.x;
+    if (RPO_GEMM_SKIP & 1) {
+        for (int idx = tid; idx < kRows * kw; idx += kGemmThreads) a_s[(idx / kw) * ldk + idx % kw] = 0.5f;
+        return;
+    }
     if (vec) {                                                   // (uniform: rows are 16-byte aligned and K % 4 == 0)
         const int q = kw / 4, total = kRows * q;
         for (int base = tid; base < total; base += kGemmThreads * 8) {
@@ -182,9 +193,9 @@ __global__ __launch_bounds__(kGemmThreads) void mlp_gemm_kernel(GemmArgs4 all, i
     if (p.A2) gemm_stage(a2_s, ldk2, kw2, p.A2, p.lda2, p.K2, m0, p.M, false, false);
     // (the epilogue's operands too: they do not depend on the chain)
     const int nc = n < p.N ? n : p.N - 1;
-    const float bv = (p.bias ? p.bias[nc] : 0.0f) + (p.bias2 ? p.bias2[nc] : 0.0f);
+    const float bv = (RPO_GEMM_SKIP & 16) ? 0.0f : (p.bias ? p.bias[nc] : 0.0f) + (p.bias2 ? p.bias2[nc] : 0.0f);
     float mk[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-    if (p.mask) {
+    if (p.mask && !(RPO_GEMM_SKIP & 16)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + lg * 4 + i, mc = m < p.M ? m : p.M - 1;
@@ -204,6 +215,7 @@ __global__ __launch_bounds__(kGemmThreads) void mlp_gemm_kernel(GemmArgs4 all, i
             if (m < p.M) {
                 float v = acc[i] + bv;
                 if (p.mask && !(mk[i] > 0.0f)) v = 0.0f;
+                if ((RPO_GEMM_SKIP & 8) && v != 12345.678f) continue;
                 p.C[(size_t)m * p.ldc + n] = v;
             }
         }
@@ -231,9 +243,9 @@ __global__ __launch_bounds__(kGemmThreads) void mlp_gemm_ksplit_kernel(GemmArgs4
     f32x4* red = reinterpret_cast<f32x4*>(a_s + kRows * ldk);
     gemm_stage(a_s, ldk, kw, p.A, p.lda, p.K, m0, p.M, p.relu_a != 0, vec_a != 0);
     const int nc = n < p.N ? n : p.N - 1;
-    const float bv = (p.bias ? p.bias[nc] : 0.0f) + (p.bias2 ? p.bias2[nc] : 0.0f);
+    const float bv = (RPO_GEMM_SKIP & 16) ? 0.0f : (p.bias ? p.bias[nc] : 0.0f) + (p.bias2 ? p.bias2[nc] : 0.0f);
     float mk[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-    if (p.mask && wave == 0) {
+    if (p.mask && wave == 0 && !(RPO_GEMM_SKIP & 16)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + lg * 4 + i, mc = m < p.M ? m : p.M - 1;
@@ -256,6 +268,7 @@ __global__ __launch_bounds__(kGemmThreads) void mlp_gemm_ksplit_kernel(GemmArgs4
             if (m < p.M) {
                 float v = acc[i] + bv;
                 if (p.mask && !(mk[i] > 0.0f)) v = 0.0f;
+                if ((RPO_GEMM_SKIP & 8) && v != 12345.678f) continue;
                 p.C[(size_t)m * p.ldc + n] = v;
             }
         }
