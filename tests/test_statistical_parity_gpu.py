@@ -105,7 +105,8 @@ def test_evopf_training_statistics_match_reference(golden, algo):
         del hp["gamma"]
         hp.update(grad_eps=0.1, alpha=0.001, automatic_entropy_tuning=False, fixed=False)
     cls = RPODDPG if algo == "ddpg" else RPOSAC
-    rows = []
+    rows, outliers, drift_converged = [], [], []
+    from oracle import evopf as oe                               # (test infrastructure: the checker of the outlier steps)
     os.environ["RPO_VERBOSE"] = "0"
     for seed in range(2 * len(ref)):
         torch.manual_seed(123 + seed)
@@ -118,6 +119,20 @@ def test_evopf_training_statistics_match_reference(golden, algo):
         mi, me, rw = [tr.logger.tracker[k][:n] for k in ("max_ineq", "max_eq", "reward")]
         viol = np.maximum(mi, me) > 1e-3
         rows.append([n, viol.mean(), mi.mean(), me.mean(), me.max(), rw.mean(), rw[n // 2:].mean()])
+        # every step that stored an equality violation > 0.1 is replayed through the float64 oracle: the stored
+        # basic action completed from the flat start, numpy LAPACK solves with partial pivoting
+        c = tr.kernels.cols
+        ring = tr.buffer.rows[:n].cpu().numpy().astype(np.float64)       # (num_envs = 1: ring row = step)
+        eqv = np.abs(ring[:, c["eq_viol"][0]:c["eq_viol"][1]]).max(1)
+        ok_steps = np.ones(n, dtype=bool)
+        for tb in np.nonzero(eqv > 0.1)[0]:
+            st = ring[tb:tb + 1, c["state"][0]:c["state"][1]]
+            ap = ring[tb:tb + 1, c["action"][0]:c["action"][1]][:, oe.GRID.partial_actions]
+            a64, _, _, its = oe.complete_partial(st, ap, return_aux=True)
+            diverges = int(np.asarray(its).max()) >= 50 or float(np.abs(oe.eq_resid(st, a64)).max()) > 0.1
+            outliers.append((seed, int(tb), float(eqv[tb]), bool(diverges)))
+            ok_steps[tb] = not diverges
+        drift_converged.append(float(eqv[ok_steps].max()))
         del tr
     got = np.array(rows)
 
@@ -126,7 +141,8 @@ def test_evopf_training_statistics_match_reference(golden, algo):
     out = {"ref_seeds": len(ref), "gpu_seeds": len(got), "steps": steps, "ref_mean": ref.mean(0).tolist(),
            "gpu_mean": got.mean(0).tolist(), "ref_std": ref.std(0, ddof=1).tolist(), "gpu_std": got.std(0, ddof=1).tolist(),
            "se_of_difference": [se(c) for c in range(ref.shape[1])], "columns": [str(c) for c in g["columns"]],
-           "bound": "2 SE + 10 % of the reference mean"}
+           "bound": "2 SE + 10 % of the reference mean",
+           "steps_with_eq_violation_above_0.1": [dict(seed=a, step=b, max_eq=c, oracle_diverges_too=d) for a, b, c, d in outliers]}
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/statistical_parity_%s_evopf.json" % algo, "w") as f:
         json.dump(out, f, indent=1)
@@ -140,9 +156,12 @@ def test_evopf_training_statistics_match_reference(golden, algo):
     # solution near the flat start (round 4: 1 step in 46 080, max_eq 117; the float64 oracle with LAPACK pivoting does not
     # converge on that input either: tests/golden/evopf_newton_divergence.npz, test_evopf_oracle.py).  The reference's 24 runs
     # contain no such step (23 040 steps), which does not separate the two rates.
-    drift = np.sort(got[:, 4])
-    assert drift[int(0.95 * len(drift)) - 1] <= max(2.0 * ref[:, 4].max(), 1e-2), drift[-5:]
-    assert (got[:, 4] > 0.1).sum() <= 2, drift[-5:]
+    # Since round 5 no blanket allowance: EVERY step with a stored violation > 0.1 is replayed through the float64
+    # oracle above and must fail to converge there too (a property of the input, not of the float32 static-order solver); over
+    # all other steps the strict bound of round 3 holds again: max drift <= 2 x the reference's max.
+    assert all(d for _, _, _, d in outliers), outliers
+    assert len(outliers) <= 4, outliers                          # (r04: 1 step in 46 080)
+    assert max(drift_converged) <= max(2.0 * ref[:, 4].max(), 1e-2), sorted(drift_converged)[-5:]
 
 
 @pytest.mark.timeout(900, method="thread")
