@@ -374,22 +374,29 @@ def _run(n_envs, iters, use_graph, seed_all=5, algo="ddpg", fused=False, **extra
     return tr
 
 
-@pytest.mark.parametrize("fused", [True, False], ids=["fused_mlp", "torch_mlp"])
-def test_training_iterations_graph_equals_eager_and_episodes_roll_over(fused, monkeypatch):
+_SAC_KW = dict(lr_actor=1e-4, lr_critic=3e-4, grad_eps=0.1, init_lamb=0.0, init_nju=0.0, alpha=0.001,
+               automatic_entropy_tuning=False, fixed=False)            # scripts/evopf_exp_sac.py:30-33
+
+
+@pytest.mark.parametrize("fused,algo", [(True, "ddpg"), (False, "ddpg"), (True, "sac")], ids=["fused_mlp", "torch_mlp", "fused_mlp_sac"])
+def test_training_iterations_graph_equals_eager_and_episodes_roll_over(fused, algo, monkeypatch):
     """30 iterations through hipGraph windows of one policy_fre period (RPO_GRAPH_CYCLE=4: eager passes on the side stream, the
     capture at the fourth window, replays, a ragged tail) == 30 eager iterations, bit for bit.  The windows of this workload
     have TWO captured branches: rollout t+1 beside update t, and (round 5, fused networks) the actor-only prefix of the policy
     step -- pi(s), noise, Complete, Lagrangian -- beside the critic update of a policy iteration; the serial order
-    (`_policy_prefix_enabled = False`) gives the same bits again."""
+    (`_policy_prefix_enabled = False`) gives the same bits again.  Since the re-capture of round 5 (the update chain first, the
+    second branch behind an event: DESIGN 4b) this is also the test that the event form carries the same dependencies; RPOSAC
+    (its prefix draws into a buffer of its own) goes through the same windows."""
     from rpo_amd.algo.trainer import RPOTrainerBase
     monkeypatch.setenv("RPO_GRAPH_CYCLE", "4")
-    a = _run(64, 30, use_graph=False, fused=fused)
-    b = _run(64, 30, use_graph=True, fused=fused)
+    kw = dict(algo=algo, **(_SAC_KW if algo == "sac" else {}))
+    a = _run(64, 30, use_graph=False, fused=fused, **kw)
+    b = _run(64, 30, use_graph=True, fused=fused, **kw)
     key = ("cycle", 4, True, "overlap") if fused else ("cycle", 4, True)      # (torch modules: no update clock, serial windows)
     assert b._graphs.entries[key]["graph"] is not None and not b._graphs.capture_failed
     assert b._policy_prefix_ok() == fused
     monkeypatch.setattr(RPOTrainerBase, "_policy_prefix_enabled", False, raising=False)
-    c = _run(64, 30, use_graph=True, fused=fused)
+    c = _run(64, 30, use_graph=True, fused=fused, **kw)
     assert not c._policy_prefix_ok() and c._graphs.entries[key]["graph"] is not None
     monkeypatch.undo()
     for other in (b, c):
@@ -407,8 +414,7 @@ def test_sac_on_evopf_runs_and_replays(monkeypatch):
     """scripts/evopf_exp_sac.py's configuration: RPOSAC with a 14-dimensional squashed-Gaussian policy and the
     state-dependent box; hipGraph replay (one graph per iteration) equals the eager run, stored transitions stay near the
     equality manifold."""
-    kw = dict(lr_actor=1e-4, lr_critic=3e-4, grad_eps=0.1, init_lamb=0.0, init_nju=0.0, alpha=0.001,
-              automatic_entropy_tuning=False, fixed=False)            # scripts/evopf_exp_sac.py:30-33
+    kw = _SAC_KW
     monkeypatch.setenv("RPO_GRAPH_CYCLE", "1")
     a = _run(32, 12, use_graph=False, algo="sac", **kw)
     b = _run(32, 12, use_graph=True, algo="sac", **kw)

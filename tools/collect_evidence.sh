@@ -33,6 +33,8 @@ timeout 600 python3 tools/probe_mlp_large.py > $OUT/probe_mlp_large.txt 2>&1
   [ -n "$DB" ] && python3 $ROOT/tools/rocpd_summary.py $DB 30 > $OUT/large_batch_cart_ddpg_kernel_stats.txt )
 bash tools/pmc_mlp_large.sh > $OUT/pmc_mlp_large.log 2>&1
 cp gpurun_out/pmc_mlp_large.txt gpurun_out/mlp_large_kernel_stats.txt $OUT/ 2>/dev/null
+# what a captured branch / a dependent layer launch costs, and the two kinds of EVOPF iteration
+bash tools/collect_probes.sh $OUT
 bash tools/collect_profiles.sh $R > $OUT/collect_profiles.log 2>&1
 cp -r gpurun_out/prof_$R/* $OUT/ 2>/dev/null
 ls $OUT | head -80

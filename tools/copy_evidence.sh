@@ -27,4 +27,5 @@ cp $E/probe_mlp_large.txt $P/${R}_probe_mlp_large.txt
 cp $E/large_batch_cart_ddpg_kernel_stats.txt $P/${R}_large_batch_cart_ddpg_kernel_stats.txt
 cp $E/pmc_mlp_large.txt $P/${R}_pmc_mlp_large.txt
 cp $E/mlp_large_kernel_stats.txt $P/${R}_mlp_large_kernel_stats.txt
+for f in probe_branch probe_branch3 probe_gemm_launch probe_evopf_period; do cp $E/$f.txt $P/${R}_$f.txt; done
 ls $P | grep -c "^$R"
