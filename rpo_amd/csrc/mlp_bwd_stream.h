@@ -305,23 +305,29 @@ __global__ __launch_bounds__(kBwdWeightsWaves * 64, kBwdWeightsWaves / 4) void b
     // are issued without a branch from a scalar base + a per-lane constant offset; a ragged last tile takes the guarded path
     const long long n_t = t_hi > t_lo + set ? (t_hi - t_lo - set + 1) / 2 : 0;
     const bool ragged = n_t > 0 && (t_lo + set + 2 * (n_t - 1) + 1) * kRows > p.n;
-    const long long n_steps = (n_t - (ragged ? 1 : 0)) * 4;
-    const float* hbase = p.h1 + (size_t)lg * H + j0;
-    const float* xbase = p.x0 + (size_t)lg * EIN + e0;
-    const float* dbase = p.dout + (size_t)lg * outs;
-    auto load = [&](long long s, f32x4& hv, f32x4& xa, f32x4& xb, float& da_, float& db_) {
-        const long long sc2 = s < n_steps ? s : n_steps - 1;     // (scalar clamp: the last loads are repeated, not skipped)
-        const long long rb = (t_lo + set + 2 * (sc2 >> 2)) * kRows + 4 * (sc2 & 3);   // scalar row base
+    const int n_steps = (int)((n_t - (ragged ? 1 : 0)) * 4);      // (32-bit: the scalar unit has no ordered 64-bit compare)
+    const int tile0 = (int)(t_lo + set);
+    // (addresses = a SCALAR row base + a 32-bit per-lane byte offset: the loads take the base from scalar registers, no vector
+    //  address arithmetic between the MFMAs)
+    unsigned ho = 4u * (unsigned)(lg * H + j0), xo = 4u * (unsigned)(lg * EIN + e0), dof = 4u * (unsigned)(lg * outs);
+    auto load = [&](int s, f32x4& hv, f32x4& xa, f32x4& xb, float& da_, float& db_) {
+        const int sc2 = s < n_steps ? s : n_steps - 1;           // (scalar clamp: the last loads are repeated, not skipped)
+        const long long rb = (long long)(tile0 + 2 * (sc2 >> 2)) * kRows + 4 * (sc2 & 3);   // scalar row base
         if (RPO_BWDS_SKIP & 1) {
             const float f = (float)(rb & 7) + (float)li;
             hv = f32x4{f, -f, f, f}; xa = f32x4{f, f, -f, f}; xb = xa; da_ = f; db_ = f;
             return;
         }
-        hv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(hbase + (size_t)rb * H));
-        xa = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xbase + (size_t)rb * EIN));
-        xb = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xbase + (size_t)rb * EIN + 64));
-        da_ = dbase[(size_t)rb * outs];
-        db_ = TWO ? dbase[(size_t)rb * outs + 1] : 0.0f;
+        const char* hrow = reinterpret_cast<const char*>(p.h1 + (size_t)rb * H);
+        const char* xrow = reinterpret_cast<const char*>(p.x0 + (size_t)rb * EIN);
+        const char* drow = reinterpret_cast<const char*>(p.dout + (size_t)rb * outs);
+        asm volatile("" : "+v"(ho), "+v"(xo), "+v"(dof));        // opaque (no instruction): keeps `scalar base + 32-bit lane
+                                                                 // offset` at the load -- hoisted, it is a 64-bit vector add per load
+        hv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(hrow + ho));
+        xa = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xrow + xo));
+        xb = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xrow + xo + 256u));
+        da_ = *reinterpret_cast<const float*>(drow + dof);
+        db_ = TWO ? *reinterpret_cast<const float*>(drow + dof + 4u) : 0.0f;
     };
     if (n_steps > 0) {
         constexpr int RING = 4;
@@ -329,11 +335,10 @@ __global__ __launch_bounds__(kBwdWeightsWaves * 64, kBwdWeightsWaves / 4) void b
         float daq[RING], dbq[RING];
 #pragma unroll
         for (int b = 0; b < RING - 1; ++b) load(b, hq[b], xaq[b], xbq[b], daq[b], dbq[b]);
-        for (long long s = 0; s < n_steps; s += RING) {
+        for (int s = 0; s < n_steps; s += RING) {
 #pragma unroll
             for (int b = 0; b < RING; ++b) {                     // three steps of loads in flight behind the MFMAs of the current one
-                if (s + b >= n_steps) break;
-                constexpr int dummy = 0; (void)dummy;
+                                                                 // (n_steps is a multiple of RING: four k-steps per tile)
                 load(s + b + RING - 1, hq[(b + RING - 1) % RING], xaq[(b + RING - 1) % RING], xbq[(b + RING - 1) % RING],
                      daq[(b + RING - 1) % RING], dbq[(b + RING - 1) % RING]);
                 step(hq[b], xaq[b], xbq[b], daq[b], dbq[b]);
