@@ -103,8 +103,11 @@ static int stream_cus() {
 // the streaming forward applies: large n, every network of the launch 128 -> 256 with scalar heads and <= 11 inputs
 static bool stream_applies(const FwdArgs4& a, int count, int n) {
     if (!rpo_tune(RPO_TUNE_FWD_STREAM) || n < 64 * 192) return false;
-    for (int k = 0; k < count; ++k)
+    for (int k = 0; k < count; ++k) {
         if (!stream_shape_ok(a.net[k].net)) return false;
+        // (the pre-activations leave as 16-byte stores: buffers that are not 16-byte aligned keep the row-tile kernels)
+        if ((reinterpret_cast<uintptr_t>(a.net[k].x0_save) | reinterpret_cast<uintptr_t>(a.net[k].h1_save)) & 15u) return false;
+    }
     return true;
 }
 

@@ -600,6 +600,7 @@ struct SplitK {
     float* lo;             // lowest address of the network's gradient tensors (the span starts here)
     long long span;        // floats from `lo` to the end of the highest tensor
     int Z;
+    long long stride;      // floats between two slices' copies: span rounded up to 4 (every slice starts 16-byte aligned)
 };
 
 // dW0 tile of 64 hidden rows x 64 input columns over the slice's rows: wave w owns hidden rows [16 w, 16 w + 16) for the WHOLE
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(kThreads) void mlp_bwd_weights_splitk_kernel(BwdArg
     q.x0 += r0 * EIN; q.h1 += r0 * H; q.dh += r0 * H; q.dx0 += r0 * EIN;
     q.dout += r0 * (p.net.hd > 1 ? p.net.n_out * p.net.hd : p.net.n_out);
     q.gradmax = nullptr;
-    float* base = k.scratch + (long long)z * k.span;
+    float* base = k.scratch + (long long)z * k.stride;
 #define RPO_SK(F) q.g.F = p.g.F ? base + (p.g.F - k.lo) : nullptr
     RPO_SK(Ws); RPO_SK(bs); RPO_SK(Wa); RPO_SK(ba); RPO_SK(W0); RPO_SK(b0); RPO_SK(W1); RPO_SK(b1); RPO_SK(W1b); RPO_SK(b1b);
 #undef RPO_SK
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(RPO_BLOCK) void splitk_reduce_kernel(SplitK k, floa
         const long long i = i0 + e_in;
         float s = 0.0f;
         if (i < k.span)
-            for (int z = z_lo; z < z_hi; ++z) s += k.scratch[(long long)z * k.span + i];    // slices in order
+            for (int z = z_lo; z < z_hi; ++z) s += k.scratch[(long long)z * k.stride + i];    // slices in order
         part[quarter][e_in] = s;
         __syncthreads();
         if (quarter == 0 && i < k.span) {
@@ -816,7 +817,7 @@ __global__ __launch_bounds__(kOnepassThreads) void mlp_bwd_onepass_kernel(BwdArg
     const long long t_lo = tiles * z / Z, t_hi = tiles * (z + 1) / Z;
     if (t_hi <= t_lo) return;
     const bool two = net.n_out > 1, has_a = net.A > 0;
-    float* base = k.scratch + (long long)z * k.span;
+    float* base = k.scratch + (long long)z * k.stride;
 #define RPO_SK(F) (base + (p.g.F - k.lo))
     if (!xgrp) {
         // ================================================================ W waves: x0 staging + dW0
@@ -1017,7 +1018,7 @@ __global__ __launch_bounds__(kOnepassThreads) void mlp_bwd_onepass_kernel(BwdArg
 
 // Host side: the split-K plan for `args` (Z = 0: not applicable -- small batch, no scratch, or scratch too small)
 static inline SplitK splitk_plan(const BwdArgs& a, float* scratch, long long scratch_floats) {
-    SplitK k{nullptr, nullptr, 0, 0};
+    SplitK k{nullptr, nullptr, 0, 0, 0};
     if (!scratch || a.n < RPO_SPLITK_FROM || !a.param_grads) return k;
     const Mlp& net = a.net;
     const long long ein = net.cat ? 2 * net.E : net.E, heads = net.hd > 1 ? net.hd : 1;
@@ -1031,12 +1032,12 @@ static inline SplitK splitk_plan(const BwdArgs& a, float* scratch, long long scr
         if (!hi || ptr[i] + len[i] > hi) hi = ptr[i] + len[i];
     }
     if (!lo) return k;
-    const long long span = hi - lo;
+    const long long span = hi - lo, stride = (span + 3) & ~3ll;
     long long Z = a.n / 4096;                                    // (per thread of the hidden-vector blocks: 1024 rows)
     if (Z > 256) Z = 256;
-    if (Z * span > scratch_floats) Z = scratch_floats / span;
+    if (Z * stride > scratch_floats) Z = scratch_floats / stride;
     if (Z < 2) return k;
-    k.scratch = scratch; k.lo = const_cast<float*>(lo); k.span = span; k.Z = (int)Z;
+    k.scratch = scratch; k.lo = const_cast<float*>(lo); k.span = span; k.Z = (int)Z; k.stride = stride;
     return k;
 }
 
@@ -1057,7 +1058,7 @@ static inline bool onepass_applies(const BwdArgs& args, const SplitK& k) {
 // Launches the one-pass backward (caller checked onepass_applies): 0 or an RPO_ERR_* / hipError code.
 template <int EIN, int H>
 static inline int launch_onepass(const BwdArgs& args, const SplitK& k, hipStream_t stream) {
-    if (hipMemsetAsync(k.scratch, 0, (size_t)k.Z * (size_t)k.span * sizeof(float), stream) != hipSuccess) return RPO_ERR_ARG;
+    if (hipMemsetAsync(k.scratch, 0, (size_t)k.Z * (size_t)k.stride * sizeof(float), stream) != hipSuccess) return RPO_ERR_ARG;
     hipLaunchKernelGGL((mlp_bwd_onepass_kernel<128, 256>), dim3(k.Z), dim3(kOnepassThreads), 0, stream, args, k);
     RPO_LAUNCH_CHECK();
     long long blocks = (k.span + RPO_BLOCK / 4 - 1) / (RPO_BLOCK / 4);
@@ -1069,7 +1070,7 @@ static inline int launch_onepass(const BwdArgs& args, const SplitK& k, hipStream
 
 template <int EIN, int H>
 static inline int launch_weights_splitk(const BwdArgs& args, const SplitK& k, int grid_w, hipStream_t stream) {
-    if (hipMemsetAsync(k.scratch, 0, (size_t)k.Z * (size_t)k.span * sizeof(float), stream) != hipSuccess) return RPO_ERR_ARG;
+    if (hipMemsetAsync(k.scratch, 0, (size_t)k.Z * (size_t)k.stride * sizeof(float), stream) != hipSuccess) return RPO_ERR_ARG;
     // (grid_w counts the plain pass's blocks: its (H / 16) (EIN / 64) dW0 tiles become (H / 64) (EIN / 64); a narrow first
     // layer becomes E / 16 column blocks per input half)
     const Mlp& net = args.net;

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kBwdStreamWaves * 64, kBwdStreamWaves / 4) void bwd
 #pragma unroll
             for (int i = 0; i < 4; ++i) red[(wave * EIN + 64 * h + 4 * (4 * lg + i) + c) * 16 + li] = g[h][c][i];
     __syncthreads();
-    float* base = k.scratch + (long long)z * k.span;
+    float* base = k.scratch + (long long)z * k.stride;
     for (int idx = tid; idx < EIN * 16; idx += NW * 64) {
         const int e = idx >> 4, u = idx & 15;
         float tot = red[idx];
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(kBwdWeightsWaves * 64, kBwdWeightsWaves / 4) void b
     }
     // ---- results.  acc[cj][4 eh + ce][i] = dW0[j = 64 jq + 4 (4 lg + i) + cj][e = 64 eh + 4 li + ce]: the second set through
     // LDS, the first adds and writes 16-byte chunks along e into the slice's copy of the gradient span
-    float* base = k.scratch + (long long)z * k.span;
+    float* base = k.scratch + (long long)z * k.stride;
     if (set == 1) {
 #pragma unroll
         for (int cj = 0; cj < 4; ++cj)
@@ -429,6 +429,11 @@ static inline bool bwd_stream_applies(const BwdArgs& a, const SplitK& k) {
     if (a.param_grads && k.Z < 2) return false;                  // (needs the slices' scratch)
     if (a.da && (net.n_out > 1 || net.A > 2)) return false;
     if (a.param_grads && !a.first_layer_state_only && a.da) return false;   // (no caller; keep the two-pass form)
+    // 16-byte loads of the saved activations and of W1, 16-byte stores into the slices' copies of the gradient span
+    uintptr_t bits = reinterpret_cast<uintptr_t>(a.x0) | reinterpret_cast<uintptr_t>(a.h1) | reinterpret_cast<uintptr_t>(net.W1) |
+                     reinterpret_cast<uintptr_t>(net.W1b) | reinterpret_cast<uintptr_t>(net.W0);
+    if (a.param_grads) bits |= reinterpret_cast<uintptr_t>(k.scratch) | (uintptr_t)(4 * (a.g.W0 - k.lo));
+    if (bits & 15u) return false;
     return true;
 }
 
@@ -444,7 +449,7 @@ static inline int launch_bwd_stream(const BwdArgs& args_in, const SplitK& k, hip
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         cus = 256;
     const bool grads = a.param_grads != 0;
-    if (grads && hipMemsetAsync(k.scratch, 0, (size_t)k.Z * (size_t)k.span * sizeof(float), stream) != hipSuccess) return RPO_ERR_ARG;
+    if (grads && hipMemsetAsync(k.scratch, 0, (size_t)k.Z * (size_t)k.stride * sizeof(float), stream) != hipSuccess) return RPO_ERR_ARG;
     const int Z = grads ? k.Z : cus;                             // rows only: nothing is reduced, every CU takes a share
     const dim3 grid(Z), block(kBwdStreamWaves * 64);
     const bool want_da = a.da != nullptr;
