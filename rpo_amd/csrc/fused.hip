@@ -41,6 +41,10 @@ struct RolloutArgs {
     typename ENV::StepArgs step;  // env state, bookkeeping, ring, statistics, ctrl
 };
 
+#ifndef RPO_ROLLOUT_SKIP
+#define RPO_ROLLOUT_SKIP 0         // timing-only builds (tools/probe/build_stream_variants.sh KIND=rollout): 1 no actor MLP, 2 no
+#endif                             // projection, 4 no env step / ring row, 8 no Philox draw, 16 no statistics / clock epilogue
+
 template <class ENV, int EIN, int H, int RT>
 __global__ __launch_bounds__(kFwdThreads) void rollout_kernel(RolloutArgs<ENV> p, typename ENV::Consts c) {
     typedef TileLds<EIN, RT, 8, 8> Lds;                          // 16 * RT lanes per workgroup; OBS <= 8
@@ -59,13 +63,18 @@ __global__ __launch_bounds__(kFwdThreads) void rollout_kernel(RolloutArgs<ENV> p
     // instructions that would otherwise head the per-lane chain behind the MLP run in the shadow of its weight loads.
     float draw = 0.0f;
     const bool philox_noise = !p.gauss && p.act.noise_mode == RPO_NOISE_PHILOX;
-    if (tid < kLanes && row0 + tid < n && (p.gauss || philox_noise)) {
+    if (!(RPO_ROLLOUT_SKIP & 8) && tid < kLanes && row0 + tid < n && (p.gauss || philox_noise)) {
         const rpo_u4 u = p.gauss ? rpo_philox(p.act.seed, p.act.env_id_base + (uint32_t)(row0 + tid), (uint32_t)t, RPO_STREAM_POLICY,
                                               (uint32_t)p.step.ctrl[RPO_CTRL_UPDATES])
                                  : rpo_philox(p.act.seed, p.act.env_id_base + (uint32_t)(row0 + tid), (uint32_t)t, RPO_STREAM_ACT);
         draw = rpo_normal(u.x, u.y);
     }
-    mlp_tile_forward<EIN, H, RT, Lds>(p.actor, lds, row0, n, nullptr, nullptr, p.gauss ? 0 : 1, p.scale, p.base);
+    if (RPO_ROLLOUT_SKIP & 1) {
+        if (tid < 2 * kLanes) lds.out[tid] = 0.25f;
+        __syncthreads();
+    } else {
+        mlp_tile_forward<EIN, H, RT, Lds>(p.actor, lds, row0, n, nullptr, nullptr, p.gauss ? 0 : 1, p.scale, p.base);
+    }
 
     float st[kStats];
 #pragma unroll
@@ -86,12 +95,15 @@ __global__ __launch_bounds__(kFwdThreads) void rollout_kernel(RolloutArgs<ENV> p
             ap = rpo_explore_clip(ap, eps_t, draw, p.act.box_lo, p.act.box_hi);
             act.noise_mode = RPO_NOISE_NONE;
         }
-        const float2 a = ENV::project(act, c, lds.in_s + tid * kInS, i, ap, eps_t, t, k);
+        float2 a;
+        if (RPO_ROLLOUT_SKIP & 2) { a = make_float2(ap, 0.5f * ap); k = 0; }
+        else a = ENV::project(act, c, lds.in_s + tid * kInS, i, ap, eps_t, t, k);
         iters_f = (float)k;
         reinterpret_cast<float2*>(p.act.action)[i] = a;
         const long long ring_base = p.step.rows ? (t % p.step.cap_steps) * (long long)n : 0;
-        ENV::lane(p.step, c, i, lds.in_s + tid * kInS, a, ep, ring_base, st);
+        if (!(RPO_ROLLOUT_SKIP & 4)) ENV::lane(p.step, c, i, lds.in_s + tid * kInS, a, ep, ring_base, st);
     }
+    if (RPO_ROLLOUT_SKIP & 16) return;
     if (p.step.stats && tid < 64) {                            // only wave 0 holds data: wave reduction, lane 0 adds
         float* srow = rpo_stats_row(p.step.stats, p.step.stats_cap, t);
         const int slot[kStats + 1] = {RPO_STAT_REWARD_SUM, RPO_STAT_EPISODES, RPO_STAT_RETURN_SUM, RPO_STAT_LENGTH_SUM,
