@@ -69,12 +69,29 @@ struct TileWeights {
     float b1v;
 };
 
+#ifndef RPO_TILE_SKIP
+#define RPO_TILE_SKIP 0            // timing-only builds (tools/probe/build_stream_variants.sh KIND=rollout TILE=N): 1 no weight loads,
+#endif                             // 2 no first layer, 4 no MFMA loop, 8 no head reduction
+
 template <int EIN, int H, int RT>
 __device__ __forceinline__ void tile_load_weights(const Mlp& net, TileWeights<EIN, H, RT>& w) {
     constexpr int ROWS = kRows * RT;
     constexpr int NT = TileWeights<EIN, H, RT>::NT, PRE = TileWeights<EIN, H, RT>::PRE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
+    if (RPO_TILE_SKIP & 1) {
+        w.bias = 0.01f * (float)li;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { w.ws0[u] = 0.1f; w.wa0[u] = 0.1f; }
+#pragma unroll
+        for (int it = 0; it < PRE; ++it)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) w.wpre[it][c] = make_float4(0.01f, -0.01f, 0.02f, 0.01f * (float)lg);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) { w.b0v[c] = 0.1f; w.w1av[c] = 0.05f; w.w1bv[c] = 0.0f; }
+        w.b1v = 0.0f;
+        return;
+    }
     // ---- layer-1 operands of this thread first: they are what layer 1 waits for (returns are in order)
     const int e_col = tid % EIN;
     const bool act_part = net.cat && e_col >= net.E;            // concatenating critic: columns [E, 2E) embed the action
@@ -134,7 +151,7 @@ __device__ __forceinline__ void tile_compute(const Mlp& net, const TileWeights<E
     __syncthreads();
 
     // ---- layer 1 (VALU): x0[r][e]
-    if (use_s) {
+    if (use_s && !(RPO_TILE_SKIP & 2)) {
         for (int i0 = 0; i0 < net.S; i0 += 8) {
             float wv[8];
 #pragma unroll
@@ -148,7 +165,7 @@ __device__ __forceinline__ void tile_compute(const Mlp& net, const TileWeights<E
             }
         }
     }
-    if (use_a) {
+    if (use_a && !(RPO_TILE_SKIP & 2)) {
         for (int i0 = 0; i0 < net.A; i0 += 8) {
             float wv[8];
 #pragma unroll
@@ -176,7 +193,7 @@ __device__ __forceinline__ void tile_compute(const Mlp& net, const TileWeights<E
 #pragma unroll
         for (int c = 0; c < NT; ++c) acc[rt][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int it = 0; it < ITS; ++it) {
+    for (int it = 0; it < ((RPO_TILE_SKIP & 4) ? 1 : ITS); ++it) {
         float4 a4[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -267,7 +284,7 @@ __device__ __forceinline__ void tile_compute(const Mlp& net, const TileWeights<E
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float v = po[o][i];
-                v = rpo_row16_sum_lane0(v);                      // (same association as the xor butterfly, at li == 0)
+                if (!(RPO_TILE_SKIP & 8)) v = rpo_row16_sum_lane0(v);   // (same association as the xor butterfly, at li == 0)
                 if (li == 0) part[(wave * ROWS + rt * kRows + lg * 4 + i) * 2 + o] = v;
             }
     }

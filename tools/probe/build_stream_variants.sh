@@ -7,7 +7,7 @@ cd $(dirname $0)/../../rpo_amd/csrc
 for N in "$@"; do
   GEMM_SKIP=0
   if [ "${KIND:-fwd}" = rollout ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DRPO_ROLLOUT_SKIP=$N -c fused.hip -o /tmp/fused_skip$N.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DRPO_ROLLOUT_SKIP=${ROLL:-$N} -DRPO_TILE_SKIP=${TILE:-0} -c fused.hip -o /tmp/fused_skip$N.o
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o librpo_hip_skip$N.so cartsafe.o pendulum.o evopf.o replay.o train_ops.o mlp.o /tmp/fused_skip$N.o nsplit.o
     continue
   fi
