@@ -457,7 +457,7 @@ int rpo_mlp_forward_multi(int count, const rpo_mlp* const* nets, int n, const fl
                           float* const* h1_save, void* stream);
 
 /* Column-split forward (rpo_amd/csrc/nsplit_dev.h): the hidden layer of 1..4 same-shaped scalar-head networks (E = 128,
- * H = 256, "add" critics / actors, S, A <= 8) on 16 row tiles x 8 column groups of workgroups each.  Leaves the head
+ * H = 256, "add" critics / actors, S <= 6, A <= 4: the first layer is three matrix-core steps) on 16 row tiles x 8 column groups of workgroups each.  Leaves the head
  * partials of the column groups in part_k [8, n, 2]; rpo_mlp_split_head (or the prologue of any consumer kernel) adds
  * them in the order of rpo_mlp_forward's wave loop, so the outputs are bitwise those of rpo_mlp_forward.  This is how
  * the batch-256 update kernels use the width of the chip: one network evaluation is 128 workgroups with a 16 KB weight

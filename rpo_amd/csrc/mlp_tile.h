@@ -62,12 +62,28 @@ struct TileWeights {
     static constexpr int ITS = EIN / 16;                         // k-groups of 16
     static constexpr int PRE_MAX = RT > 1 ? 4 : 16;           // (64-row form: 120 registers = TWO workgroups per CU; the other k-groups stream from L2)           // (64-row form: 128 registers = two workgroups per CU; the last k-groups stream from L2)
     static constexpr int PRE = ITS < PRE_MAX ? ITS : PRE_MAX;    // k-groups kept in registers
+    static constexpr int TPW = EIN / (16 * kFwdWaves);           // first-layer column tiles per wave (matrix-core form)
     float bias;
     float ws0[8], wa0[8];                                        // first chunk of the column's first-layer weights
+    float wk[TPW][3];                                            // matrix-core form: A operands of the three k-steps, per tile
     float4 wpre[PRE][NT];
     float b0v[NT], w1av[NT], w1bv[NT];
     float b1v;
 };
+
+// The first layer on the matrix cores (round 5; the streaming kernels of mlp_stream.h had it first): x0^T[e][row] =
+// Wcat[e][u] in^T[u][row] with the k slots u = (bs x 1 | ba x 1 | state inputs | zero pad || action inputs | zero pad) as three
+// 16 x 16 x 4 steps per 16 columns.  The biases enter as the FIRST terms -- (0 + bs) + ba is the vector form's bias = bs + ba,
+// exactly -- so the MFMA is the k-ordered fmaf chain the vector form was (bias, state inputs in order, action inputs in order;
+// zero pads are exact no-ops) and the bits do not change; the vector form's scalar LDS reads and run-time bounds on 16 + 16
+// unrolled steps become a dozen instructions.  Every operand is ONE predicated load and nothing is computed from loaded values
+// where the weights are requested (nsplit_dev.h NsWeights has the measurements behind that rule).  For 128-wide networks
+// without concatenation, S <= 6, A <= 4: every classic-control network
+// (the wider row-tile kernels are a cold path -- EVOPF's networks run layer by layer, mlp_gemm.h -- and keep the vector form).
+template <int EIN>
+__device__ __forceinline__ bool tile_l1_mfma(const Mlp& net) {
+    return EIN == 128 && !net.cat && net.S <= 6 && net.A <= 4 && net.S > 0;
+}
 
 #ifndef RPO_TILE_SKIP
 #define RPO_TILE_SKIP 0            // timing-only builds (tools/probe/build_stream_variants.sh KIND=rollout TILE=N): 1 no weight loads,
@@ -93,15 +109,30 @@ __device__ __forceinline__ void tile_load_weights(const Mlp& net, TileWeights<EI
         return;
     }
     // ---- layer-1 operands of this thread first: they are what layer 1 waits for (returns are in order)
-    const int e_col = tid % EIN;
-    const bool act_part = net.cat && e_col >= net.E;            // concatenating critic: columns [E, 2E) embed the action
-    const int er = act_part ? e_col - net.E : e_col;
-    const bool use_s = !act_part, use_a = net.A > 0 && (act_part || !net.cat);
-    w.bias = act_part ? net.ba[er] : (net.bs[er] + ((net.A > 0 && !net.cat) ? net.ba[er] : 0.0f));
+    if (tile_l1_mfma<EIN>(net)) {
+        constexpr int TPW = TileWeights<EIN, H, RT>::TPW;
+        const bool add_a = net.A > 0;
+        w.bias = 0.0f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        w.ws0[u] = (use_s && u < net.S) ? net.Ws[er * net.S + u] : 0.0f;
-        w.wa0[u] = (use_a && u < net.A) ? net.Wa[er * net.A + u] : 0.0f;
+        for (int t = 0; t < TPW; ++t) {
+            const int e = (wave + t * kFwdWaves) * 16 + li;      // this lane's row of the A operand; k slots 0 / 1: the biases
+            const float* p0 = lg == 0 ? net.bs + e : (lg == 1 ? net.ba + e : net.Ws + e * net.S + (lg - 2));
+            const bool live0 = lg == 0 || (lg == 1 ? add_a : lg - 2 < net.S);
+            w.wk[t][0] = live0 ? *p0 : 0.0f;
+            w.wk[t][1] = 2 + lg < net.S ? net.Ws[e * net.S + 2 + lg] : 0.0f;
+            w.wk[t][2] = (add_a && lg < net.A) ? net.Wa[e * net.A + lg] : 0.0f;
+        }
+    } else {
+        const int e_col = tid % EIN;
+        const bool act_part = net.cat && e_col >= net.E;        // concatenating critic: columns [E, 2E) embed the action
+        const int er = act_part ? e_col - net.E : e_col;
+        const bool use_s = !act_part, use_a = net.A > 0 && (act_part || !net.cat);
+        w.bias = act_part ? net.ba[er] : (net.bs[er] + ((net.A > 0 && !net.cat) ? net.ba[er] : 0.0f));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            w.ws0[u] = (use_s && u < net.S) ? net.Ws[er * net.S + u] : 0.0f;
+            w.wa0[u] = (use_a && u < net.A) ? net.Wa[er * net.A + u] : 0.0f;
+        }
     }
     // ---- then the wave's slice of W0: it streams in underneath layer 1 and feeds the MFMA loop k-group by k-group
     const int j0 = wave * (H / kFwdWaves);
@@ -149,9 +180,40 @@ __device__ __forceinline__ void tile_compute(const Mlp& net, const TileWeights<E
 #pragma unroll
     for (int r = 0; r < RPT; ++r) acc1[r] = w.bias;
     __syncthreads();
+    const bool l1_mfma = tile_l1_mfma<EIN>(net);
+    if (l1_mfma) {
+        // ---- layer 1 (MFMA, see tile_l1_mfma): wave w owns column tiles w, w + 8, ... for every row tile
+        constexpr int TPW = TileWeights<EIN, H, RT>::TPW;
+        const bool x0_vec = (reinterpret_cast<uintptr_t>(x0_save) & 15u) == 0;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int row = rt * kRows + li;
+            const float b0 = lg < 2 ? 1.0f : (lg - 2 < net.S ? in_s[row * kInS + lg - 2] : 0.0f);
+            const float b1 = 2 + lg < net.S ? in_s[row * kInS + 2 + lg] : 0.0f;
+            const float b2 = (net.A > 0 && lg < net.A) ? in_a[row * kInA + lg] : 0.0f;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                f32x4 c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (!(RPO_TILE_SKIP & 2)) {
+                    c = mfma4(w.wk[t][0], b0, c);
+                    c = mfma4(w.wk[t][1], b1, c);
+                    c = mfma4(w.wk[t][2], b2, c);
+                }
+                // c[i] = x0[row][e0 + i], e0 = 16 (w + 8 t) + 4 lg
+                const int e0 = (wave + t * kFwdWaves) * 16 + 4 * lg;
+                if (x0_save && row0 + row < n) {
+                    float* dst = x0_save + (size_t)(row0 + row) * EIN + e0;
+                    if (x0_vec) *reinterpret_cast<f32x4*>(dst) = c;
+                    else { dst[0] = c[0]; dst[1] = c[1]; dst[2] = c[2]; dst[3] = c[3]; }
+                }
+                *reinterpret_cast<f32x4*>(&x1[row * LDX + e0]) =
+                    f32x4{fmaxf(c[0], 0.0f), fmaxf(c[1], 0.0f), fmaxf(c[2], 0.0f), fmaxf(c[3], 0.0f)};
+            }
+        }
+    }
 
     // ---- layer 1 (VALU): x0[r][e]
-    if (use_s && !(RPO_TILE_SKIP & 2)) {
+    if (!l1_mfma && use_s && !(RPO_TILE_SKIP & 2)) {
         for (int i0 = 0; i0 < net.S; i0 += 8) {
             float wv[8];
 #pragma unroll
@@ -165,7 +227,7 @@ __device__ __forceinline__ void tile_compute(const Mlp& net, const TileWeights<E
             }
         }
     }
-    if (use_a && !(RPO_TILE_SKIP & 2)) {
+    if (!l1_mfma && use_a && !(RPO_TILE_SKIP & 2)) {
         for (int i0 = 0; i0 < net.A; i0 += 8) {
             float wv[8];
 #pragma unroll
@@ -179,10 +241,12 @@ __device__ __forceinline__ void tile_compute(const Mlp& net, const TileWeights<E
             }
         }
     }
+    if (!l1_mfma) {
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-        if (x0_save && row0 + r_lo + r < n) x0_save[(size_t)(row0 + r_lo + r) * EIN + e_col] = acc1[r];
-        x1[(r_lo + r) * LDX + e_col] = fmaxf(acc1[r], 0.0f);
+        for (int r = 0; r < RPT; ++r) {
+            if (x0_save && row0 + r_lo + r < n) x0_save[(size_t)(row0 + r_lo + r) * EIN + e_col] = acc1[r];
+            x1[(r_lo + r) * LDX + e_col] = fmaxf(acc1[r], 0.0f);
+        }
     }
     __syncthreads();
 

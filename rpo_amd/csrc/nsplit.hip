@@ -20,7 +20,7 @@ Mlp to_dev(const rpo_mlp* h) {
 }
 
 bool split_ok(const Mlp& m) {
-    return m.E == 128 && m.H == 256 && !m.cat && m.hd <= 1 && m.S <= 8 && m.A <= 8 && m.n_out >= 1 && m.n_out <= 2 && m.Ws && m.W0 &&
+    return m.E == 128 && m.H == 256 && !m.cat && m.hd <= 1 && m.S <= 6 && m.A <= 4 && m.n_out >= 1 && m.n_out <= 2 && m.Ws && m.W0 &&
            m.W1 && (m.A == 0 || m.Wa) && (m.n_out == 1 || m.W1b);
 }
 

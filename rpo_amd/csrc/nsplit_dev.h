@@ -24,25 +24,46 @@ struct NsLds {
     float xch[2 * 4 * 64];                                        // wave 0 -> wave 1: head partials after column tile 0
 };
 
-// What a thread keeps in registers: its first-layer column and its wave's 16 x EIN slice of W0.
+// What a thread keeps in registers: its first-layer operands and its wave's 16 x EIN slice of W0.
+// First layer on the matrix cores (round 5, as mlp_tile.h tile_l1_mfma): wave w owns first-layer columns [64 w, 64 w + 64) as
+// four 16-column tiles, x0^T[e][row] = Wcat[e][u] in^T[u][row] with the k slots u = (bs x 1 | ba x 1 | state inputs | zero pad)
+// in two steps, then (action inputs | zero pad) in one: wk[t][s] is this lane's A operand of step s.  The biases enter as the
+// FIRST terms of the chain -- (0 + bs) + ba is the vector form's bias = bs + ba, exactly -- so this is its k-ordered fmaf chain
+// (bias, state inputs in order, action inputs in order): no bit changes, on 12 registers instead of 17.  What was measured on
+// the way (bench A/B on one box each): a separate accumulator initialiser (16 more registers) -- RPODDPG +3.4 %, RPOSAC -6 %
+// (its riding launches went over 128 registers); the sum bs + ba formed where the weights are loaded, under a per-lane branch --
+// the wait for those two loads lands in front of every other weight request: -2.5 .. -5 % on the riding workloads; a fourth
+// step for wider inputs with its operands fetched where they are used -- the same wait, between the steps.  Hence: every
+// operand ONE predicated load, no arithmetic on loaded values before the first layer, six state and four action inputs
+// (split_ok; wider inputs keep the row-tile pipelines).
 template <int EIN>
 struct NsWeights {
-    float bias, ws0[8], wa0[8];
+    float wk[4][3];
     float4 w0[EIN / 16];
     float b0v, w1av, w1bv;
 };
+
+// A operand of first-layer column e at k slot u of the state steps (slots 0 / 1: the two biases) / at action input u
+__device__ __forceinline__ float ns_l1_state_w(const Mlp& net, int e, int u) {
+    const float* ptr = u == 0 ? net.bs + e : (u == 1 ? net.ba + e : net.Ws + e * net.S + (u - 2));
+    const bool live = u == 0 || (u == 1 ? net.A > 0 : u - 2 < net.S);
+    return live ? *ptr : 0.0f;
+}
+__device__ __forceinline__ float ns_l1_action_w(const Mlp& net, int e, int u) {
+    return (net.A > 0 && u < net.A) ? net.Wa[e * net.A + u] : 0.0f;
+}
 
 // Issue every weight load of the slab (they return underneath the input staging / gather of the caller).
 template <int EIN, int H>
 __device__ __forceinline__ void ns_load_weights(const Mlp& net, int g, NsWeights<EIN>& w) {
     static_assert(EIN == kNsThreads, "one first-layer column per thread");
     const int tid = threadIdx.x & (kNsThreads - 1), lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;   // (two slab units may share a 256-thread workgroup)
-    const int e = tid;
-    w.bias = net.bs[e] + (net.A > 0 ? net.ba[e] : 0.0f);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        w.ws0[u] = u < net.S ? net.Ws[e * net.S + u] : 0.0f;
-        w.wa0[u] = (net.A > 0 && u < net.A) ? net.Wa[e * net.A + u] : 0.0f;
+    for (int t = 0; t < 4; ++t) {
+        const int e = 64 * wave + 16 * t + li;                   // this lane's row of the A operand
+        w.wk[t][0] = ns_l1_state_w(net, e, lg);
+        w.wk[t][1] = ns_l1_state_w(net, e, 4 + lg);
+        w.wk[t][2] = ns_l1_action_w(net, e, lg);
     }
     const int j = g * 32 + wave * 16 + li;                       // hidden column of this lane's B operand / outputs
 #pragma unroll
@@ -59,16 +80,25 @@ __device__ __forceinline__ void ns_load_weights(const Mlp& net, int g, NsWeights
 // The state half of layer 1 (bias, then the state inputs in order) of the rows staged in lds.in_s: what ns_hidden starts
 // with.  A caller whose ACTION inputs arrive late (a consumer inside a fused launch) runs this before it waits and hands
 // the accumulators to ns_hidden (`pre`): same operations in the same order.  The caller synchronises before (staging).
+#ifndef RPO_NS_SKIP
+#define RPO_NS_SKIP 0              // timing-only builds: 1 = no first-layer fmaf loops in the column-split stages
+#endif
+// (acc1: the four C tiles of the lane, acc1[4 t + i] = x0[row li][64 w + 16 t + 4 lg + i] so far)
 template <int EIN>
 __device__ __forceinline__ void ns_layer1_state(const Mlp& net, const NsWeights<EIN>& w, const NsLds<EIN>& lds, float (&acc1)[kRows]) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    // B operands: slot u of row li -- 1.0 for the two bias slots, state input u - 2, zero beyond S
+    const float b0 = lg < 2 ? 1.0f : (lg - 2 < net.S ? lds.in_s[li * 8 + lg - 2] : 0.0f);
+    const float b1 = 2 + lg < net.S ? lds.in_s[li * 8 + 2 + lg] : 0.0f;
 #pragma unroll
-    for (int r = 0; r < kRows; ++r) acc1[r] = w.bias;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        if (u < net.S) {
-#pragma unroll
-            for (int r = 0; r < kRows; ++r) acc1[r] = fmaf(lds.in_s[r * 8 + u], w.ws0[u], acc1[r]);
+    for (int t = 0; t < 4; ++t) {
+        f32x4 c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (!(RPO_NS_SKIP & 1)) {
+            c = mfma4(w.wk[t][0], b0, c);
+            c = mfma4(w.wk[t][1], b1, c);
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc1[4 * t + i] = c[i];
     }
 }
 
@@ -79,7 +109,7 @@ __device__ __forceinline__ void ns_hidden(const Mlp& net, const NsWeights<EIN>& 
     constexpr int LDX = EIN + 4;
     const int tid = threadIdx.x & (kNsThreads - 1), lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;   // (two slab units may share a 256-thread workgroup)
     __syncthreads();
-    // ---- layer 1 (VALU): thread = column e, all 16 rows; same fmaf order as tile_compute (state inputs, then action)
+    // ---- layer 1 (MFMA, see NsWeights): the state steps (or `pre`), then the action steps; same fmaf order as tile_compute
     float acc1[kRows];
     if (pre) {
 #pragma unroll
@@ -87,19 +117,23 @@ __device__ __forceinline__ void ns_hidden(const Mlp& net, const NsWeights<EIN>& 
     } else {
         ns_layer1_state<EIN>(net, w, lds, acc1);
     }
-    if (net.A > 0) {
+    const bool act = net.A > 0 && !(RPO_NS_SKIP & 1);
+    const float b2 = (act && lg < net.A) ? lds.in_a[li * 8 + lg] : 0.0f;
+    const bool x0_vec = (reinterpret_cast<uintptr_t>(x0_save) & 15u) == 0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (u < net.A) {
-#pragma unroll
-                for (int r = 0; r < kRows; ++r) acc1[r] = fmaf(lds.in_a[r * 8 + u], w.wa0[u], acc1[r]);
-            }
+    for (int t = 0; t < 4; ++t) {
+        f32x4 c = f32x4{acc1[4 * t], acc1[4 * t + 1], acc1[4 * t + 2], acc1[4 * t + 3]};
+        if (act) {
+            c = mfma4(w.wk[t][2], b2, c);
         }
-    }
-#pragma unroll
-    for (int r = 0; r < kRows; ++r) {
-        if (x0_save && g == 0 && row0 + r < n) x0_save[(size_t)(row0 + r) * EIN + tid] = acc1[r];
-        lds.x1[r * LDX + tid] = fmaxf(acc1[r], 0.0f);
+        const int e0 = 64 * wave + 16 * t + 4 * lg;              // c[i] = x0[row li][e0 + i]
+        if (x0_save && g == 0 && row0 + li < n) {
+            float* dst = x0_save + (size_t)(row0 + li) * EIN + e0;
+            if (x0_vec) *reinterpret_cast<f32x4*>(dst) = c;
+            else { dst[0] = c[0]; dst[1] = c[1]; dst[2] = c[2]; dst[3] = c[3]; }
+        }
+        *reinterpret_cast<f32x4*>(&lds.x1[li * LDX + e0]) =
+            f32x4{fmaxf(c[0], 0.0f), fmaxf(c[1], 0.0f), fmaxf(c[2], 0.0f), fmaxf(c[3], 0.0f)};
     }
     __syncthreads();
     // ---- layer 2 (MFMA): one 16 x 16 output tile per wave, k-ordered chain of EIN / 4 instructions
