@@ -201,7 +201,8 @@ __device__ __forceinline__ float mlp_bwd_first_layer_impl(const BwdArgs& p, int 
     const int wS = net.S + 1, wA = (net.A > 0 && !p.first_layer_state_only) ? net.A + 1 : 0;   // +1: the bias
     const int idx = fl_block * OUT + o;
     const bool valid = idx < net.E * (wS + wA);
-    float acc = 0.0f;
+    float acc = 0.0f, cur = 0.0f;
+    float* dst = nullptr;
     int e = 0, i = 0, width = 0;
     bool is_a = false;
     if (valid) {
@@ -210,6 +211,9 @@ __device__ __forceinline__ float mlp_bwd_first_layer_impl(const BwdArgs& p, int 
         is_a = q >= wS;
         i = is_a ? q - wS : q;
         width = is_a ? net.A : net.S;
+        // (what the gradient holds so far is requested now, not where it is added at the end of the chain)
+        dst = (i < width) ? (is_a ? &p.g.Wa[e * net.A + i] : &p.g.Ws[e * net.S + i]) : (is_a ? &p.g.ba[e] : &p.g.bs[e]);
+        if (part == 0) cur = *dst;
         const int col = (is_a && net.cat) ? net.E + e : e;
         const float* in = is_a ? p.a : p.s;
         const int stride = is_a ? p.a_stride : p.s_stride;
@@ -233,8 +237,7 @@ __device__ __forceinline__ float mlp_bwd_first_layer_impl(const BwdArgs& p, int 
         float tot = fl_partial[0][o];
 #pragma unroll
         for (int sl = 1; sl < SL; ++sl) tot += fl_partial[sl][o];
-        float* dst = (i < width) ? (is_a ? &p.g.Wa[e * net.A + i] : &p.g.Ws[e * net.S + i]) : (is_a ? &p.g.ba[e] : &p.g.bs[e]);
-        const float nv = *dst + tot;
+        const float nv = cur + tot;
         *dst = nv;
         gmax = fabsf(nv);
     }

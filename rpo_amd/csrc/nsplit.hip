@@ -790,6 +790,18 @@ __device__ __forceinline__ float ns_hv_block(const Mlp& net, const MlpGrad& gr, 
     const int tid = threadIdx.x;
     float gmax = 0.0f;
     float (*partial)[3][16] = reinterpret_cast<float (*)[3][16]>(smem);       // [4][3][16]
+    // what the gradients hold so far (+=) is requested NOW: read where it is added, at the end of the role's chain, it was one
+    // more exposed round trip on the longest role of the launch (round 5)
+    float cur_b0 = 0.0f, cur_w1 = 0.0f, cur_w1b = 0.0f, cur_b1 = 0.0f, cur_b1b = 0.0f;
+    if (tid < 16) {
+        cur_b0 = gr.b0[rb * 16 + tid];
+        cur_w1 = gr.W1[rb * 16 + tid];
+        if (two) cur_w1b = gr.W1b[rb * 16 + tid];
+    }
+    if (rb == 0 && tid == 0) {
+        cur_b1 = gr.b1[0];
+        if (two) cur_b1b = gr.b1b[0];
+    }
     if (tid < 64) {
         const int o = tid & 15, part = tid >> 4;
         const int b_lo = (int)(((long long)B * part) / 4), b_hi = (int)(((long long)B * (part + 1)) / 4);
@@ -841,13 +853,13 @@ __device__ __forceinline__ float ns_hv_block(const Mlp& net, const MlpGrad& gr, 
     __syncthreads();
     if (tid < 16) {
         const int o = tid, j = rb * 16 + o;
-        const float nb0 = gr.b0[j] + (((partial[0][0][o] + partial[1][0][o]) + partial[2][0][o]) + partial[3][0][o]);
-        const float nw1 = gr.W1[j] + (((partial[0][1][o] + partial[1][1][o]) + partial[2][1][o]) + partial[3][1][o]);
+        const float nb0 = cur_b0 + (((partial[0][0][o] + partial[1][0][o]) + partial[2][0][o]) + partial[3][0][o]);
+        const float nw1 = cur_w1 + (((partial[0][1][o] + partial[1][1][o]) + partial[2][1][o]) + partial[3][1][o]);
         gr.b0[j] = nb0;
         gr.W1[j] = nw1;
         gmax = fmaxf(fabsf(nb0), fabsf(nw1));
         if (two) {
-            const float nw1b = gr.W1b[j] + (((partial[0][2][o] + partial[1][2][o]) + partial[2][2][o]) + partial[3][2][o]);
+            const float nw1b = cur_w1b + (((partial[0][2][o] + partial[1][2][o]) + partial[2][2][o]) + partial[3][2][o]);
             gr.W1b[j] = nw1b;
             gmax = fmaxf(gmax, fabsf(nw1b));
         }
@@ -865,11 +877,11 @@ __device__ __forceinline__ float ns_hv_block(const Mlp& net, const MlpGrad& gr, 
         if ((tid & 63) == 0) { red[(tid >> 6) * 2] = s0; red[(tid >> 6) * 2 + 1] = s1; }
         __syncthreads();
         if (tid == 0) {
-            const float nb1 = gr.b1[0] + (((red[0] + red[2]) + red[4]) + red[6]);
+            const float nb1 = cur_b1 + (((red[0] + red[2]) + red[4]) + red[6]);
             gr.b1[0] = nb1;
             gmax = fmaxf(gmax, fabsf(nb1));
             if (two) {
-                const float nb1b = gr.b1b[0] + (((red[1] + red[3]) + red[5]) + red[7]);
+                const float nb1b = cur_b1b + (((red[1] + red[3]) + red[5]) + red[7]);
                 gr.b1b[0] = nb1b;
                 gmax = fmaxf(gmax, fabsf(nb1b));
             }
