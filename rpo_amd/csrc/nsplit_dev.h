@@ -76,7 +76,7 @@ __device__ __forceinline__ void ns_load_weights(const Mlp& net, int g, NsWeights
 
 // Hidden slab of column group g for the 16 rows staged in lds.in_s / lds.in_a (the caller wrote them; this function
 // synchronises before reading).  Writes part[(g * n + row) * 2 + o] for rows < n (o < n_out), h1_save columns of the
-// group, x0_save (group 0 only).  S, A <= 8, "add" critics / actors with EIN = E = 128.
+// group, x0_save (group 0 only).  S <= 6, A <= 4 (split_ok), "add" critics / actors with EIN = E = 128.
 // The state half of layer 1 (bias, then the state inputs in order) of the rows staged in lds.in_s: what ns_hidden starts
 // with.  A caller whose ACTION inputs arrive late (a consumer inside a fused launch) runs this before it waits and hands
 // the accumulators to ns_hidden (`pre`): same operations in the same order.  The caller synchronises before (staging).
