@@ -62,7 +62,11 @@ CASES = [("actor", 6, 0, 128, 256, 4096), ("actor", 5, 0, 128, 256, 250), ("add"
          ("add", 6, 2, 256, 256, 512),
          # multi-output heads (MFMA head): EVOPF-v0 actor (57 -> 256 -> 256 -> 14) and its SAC form (2 x 14)
          ("actor14", 57, 0, 256, 256, 1000), ("actor14", 57, 0, 256, 256, 256), ("gauss14", 57, 0, 256, 256, 77),
-         ("actor14", 6, 0, 128, 256, 300)]
+         ("actor14", 6, 0, 128, 256, 300),
+         # the matrix-core first layer (S <= 6, A <= 4: bias slots | state | action as three k steps) at its edges, and the
+         # vector form just beyond them
+         ("add", 3, 1, 128, 256, 100), ("actor", 1, 0, 128, 256, 33), ("add", 6, 4, 128, 256, 64), ("add", 7, 2, 128, 256, 48),
+         ("add", 6, 5, 128, 256, 48), ("gauss", 2, 0, 128, 256, 17)]
 
 
 @pytest.mark.parametrize("kind,S,A,E,H,n", CASES)
