@@ -162,7 +162,9 @@ int rpo_abi_version(void);
 #define RPO_TUNE_ROLLOUT_WIDE 5     /* fused rollout: 0 16-lane tiles, 1 64-lane tiles, 2 (default) by lane count */
 #define RPO_TUNE_BWD_STREAM 6       /* 1: large-batch backward as the two streaming launches of mlp_bwd_stream.h (rows kernel with W0
                                        in LDS + weights kernel); 0: the one-pass / two-pass kernels of round 3 */
-#define RPO_TUNE_COUNT 7
+#define RPO_TUNE_L1_MFMA 7         /* 1: first layer of the 128-wide row-tile forward as three matrix-core steps (S <= 6, A <= 4);
+                                       0: the vector form -- the same fmaf chain, the same bits (rpo_mlp_forward / _multi only) */
+#define RPO_TUNE_COUNT 8
 int rpo_tuning(int key, int value);
 
 /* ---------------------------------------------------------------------------------------------------------------

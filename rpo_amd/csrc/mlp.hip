@@ -246,7 +246,7 @@ int rpo_mlp_forward(const rpo_mlp* net_host, int n, const float* s, int s_stride
     if (!net_host) return RPO_ERR_NULL;
     Mlp net{net_host->Ws, net_host->bs, net_host->Wa, net_host->ba, net_host->W0, net_host->b0, net_host->W1,
             net_host->b1, net_host->W1b, net_host->b1b, net_host->S, net_host->A, net_host->E, net_host->H,
-            net_host->n_out, net_host->cat, net_host->head_dim};
+            net_host->n_out, net_host->cat, net_host->head_dim, rpo_tune(RPO_TUNE_L1_MFMA) ? 0 : 1};
     if (int e = check_net(net)) return e;
     if (n <= 0 || s_stride < net.S || (net.A > 0 && a_stride < net.A)) return RPO_ERR_ARG;
     if (!s || !out || (net.A > 0 && !a)) return RPO_ERR_NULL;
@@ -345,7 +345,7 @@ int rpo_mlp_forward_multi(int count, const rpo_mlp* const* nets, int n, const fl
         const rpo_mlp* h = nets[k];
         if (!h) return RPO_ERR_NULL;
         Mlp net{h->Ws, h->bs, h->Wa, h->ba, h->W0, h->b0, h->W1, h->b1, h->W1b, h->b1b, h->S, h->A, h->E, h->H,
-                h->n_out, h->cat, h->head_dim};
+                h->n_out, h->cat, h->head_dim, rpo_tune(RPO_TUNE_L1_MFMA) ? 0 : 1};
         if (int e = check_net(net)) return e;
         if (net.hd > 1 || s_stride[k] < net.S || (net.A > 0 && a_stride[k] < net.A)) return RPO_ERR_ARG;
         if (!s[k] || !out[k] || (net.A > 0 && !a[k])) return RPO_ERR_NULL;

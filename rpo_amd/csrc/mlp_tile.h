@@ -23,6 +23,7 @@ struct Mlp {
     const float *Ws, *bs, *Wa, *ba, *W0, *b0, *W1, *b1, *W1b, *b1b;   // W1b / b1b: second head (SAC log-std), n_out = 2
     int S, A, E, H, n_out, cat;
     int hd;   // outputs per head (0 / 1: scalar heads, reduced with wave shuffles; > 1: the head is a 16 x 16 MFMA tile)
+    int l1_vec;   // 1: keep the first layer on the vector ALU (rpo_tuning(RPO_TUNE_L1_MFMA, 0): the A/B form of the tests)
 };
 struct MlpGrad {
     float *Ws, *bs, *Wa, *ba, *W0, *b0, *W1, *b1, *W1b, *b1b;
@@ -82,7 +83,7 @@ struct TileWeights {
 // (the wider row-tile kernels are a cold path -- EVOPF's networks run layer by layer, mlp_gemm.h -- and keep the vector form).
 template <int EIN>
 __device__ __forceinline__ bool tile_l1_mfma(const Mlp& net) {
-    return EIN == 128 && !net.cat && net.S <= 6 && net.A <= 4 && net.S > 0;
+    return EIN == 128 && !net.cat && net.S <= 6 && net.A <= 4 && net.S > 0 && !net.l1_vec;
 }
 
 #ifndef RPO_TILE_SKIP

@@ -124,6 +124,13 @@ def test_mlp_forward_backward_match_torch(kind, S, A, E, H, n):
     else:
         ops.mlp_forward(d, s, a, out2)                   # inference form (nothing saved) gives the same bits
         assert torch.equal(out, out2)
+        # the first layer as three matrix-core steps (S <= 6, A <= 4; round 5) vs the vector form: the same fmaf chain, so the
+        # pre-activations, the hidden layer and the outputs are the same BITS (csrc/mlp_tile.h tile_l1_mfma)
+        x0v, h1v = torch.full_like(x0, float("nan")), torch.full_like(h1, float("nan"))
+        with ops.tuning(l1_mfma=0):
+            ops.mlp_forward(d, s, a, out2, x0v, h1v)
+        assert torch.equal(x0, x0v) and torch.equal(h1, h1v) and torch.equal(out, out2)
+        assert float(x0.abs().max()) > 0
 
     dout = torch.randn(n, n_out, device=DEV) / n
     ref.backward(dout)
