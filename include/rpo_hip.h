@@ -39,8 +39,9 @@ extern "C" {
 
 /* 3: rpo_split_update gained proj_ws / proj_store_mode / debug (the struct grew); rpo_split_critic_pfront*,
  * rpo_pendulum_project_batchref_ws; rpo_evopf_complete_bwd takes grad_action_b / grad_action2, rpo_evopf_lagrangian takes overwrite;
- * rpo_min_q_bwd, rpo_hw_probe */
-#define RPO_ABI_VERSION 5
+ * rpo_min_q_bwd, rpo_hw_probe
+ * 6: ctrl[RPO_CTRL_NONFINITE] (the step / rollout kernels' sticky failure word) */
+#define RPO_ABI_VERSION 6
 
 #define RPO_ERR_ARG (-1)
 #define RPO_ERR_NULL (-2)
@@ -107,6 +108,11 @@ extern "C" {
 #define RPO_CTRL_ARRIVE 1   /* top-level arrival counter of the running *_step launch (always 0 between launches) */
 #define RPO_CTRL_UPDATES 2  /* updates done within the current vector step (host-maintained, 0 unless several updates
                                per step are requested): 4th Philox counter word of the sampling / update-noise draws */
+#define RPO_CTRL_NONFINITE 3 /* failure detection (the reference asserts on a NaN action: cartpole.py:170-174,
+                               pendulum.py:85-89): 0, or 1 + the vector step at which a lane FIRST stepped with a NaN action or
+                               reached a non-finite next state / reward.  Sticky: set once by the *_step / *_rollout / riding
+                               kernels (one compare-and-swap per offending lane, nothing on the clean path), cleared only by the
+                               host; the transitions of that step ARE in the ring -- the host must stop, not train on. */
 #define RPO_CTRL_SUB0 16    /* 16 sub-counters, one per 128-byte line: ctrl[RPO_CTRL_SUB0 + RPO_CTRL_SUB_STRIDE * j] */
 #define RPO_CTRL_SUB_STRIDE 16
 
@@ -159,7 +165,10 @@ int rpo_abi_version(void);
 #define RPO_TUNE_BWD_ONEPASS 2      /* 1: large-batch backward in one pass over the activations; 0: rows pass + split-K weights pass */
 #define RPO_TUNE_GEMM_KSPLIT 3      /* 1: K >= 256 layer launches split k over the four waves of a workgroup; 0: one chain */
 #define RPO_TUNE_MLP_GEMM 4         /* 1: 256-wide networks layer by layer (mlp_gemm.h); 0: row-tile kernels */
-#define RPO_TUNE_ROLLOUT_WIDE 5     /* fused rollout: 0 16-lane tiles, 1 64-lane tiles, 2 (default) by lane count */
+#define RPO_TUNE_ROLLOUT_WIDE 5     /* fused rollout: 0 16-lane tiles, 1 64-lane tiles, 3 the streaming form (weights stationary in LDS,
+                                      fused.hip rollout_stream_kernel), 2 (default) by lane count: 16-lane tiles below 12 288 lanes,
+                                      64-lane tiles below RPO_ROLLOUT_STREAM_FROM, streaming from there */
+#define RPO_ROLLOUT_STREAM_FROM 65536
 #define RPO_TUNE_BWD_STREAM 6       /* 1: large-batch backward as the two streaming launches of mlp_bwd_stream.h (rows kernel with W0
                                        in LDS + weights kernel); 0: the one-pass / two-pass kernels of round 3 */
 #define RPO_TUNE_L1_MFMA 7         /* 1: first layer of the 128-wide row-tile forward as three matrix-core steps (S <= 6, A <= 4);

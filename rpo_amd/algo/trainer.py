@@ -22,6 +22,13 @@ from .. import ops as hip_ops
 from .agent.fused import FusedNets
 from .model import BoxConstraint
 
+
+
+class NonFiniteError(FloatingPointError):
+    """An env lane was stepped with a NaN action or reached a non-finite state (ctrl[RPO_CTRL_NONFINITE] of the step
+    kernels; the reference's `assert self.action_space.contains(action_fixed)`, cartpole.py:170-174, pendulum.py:85-89)."""
+
+
 _SALT_CRITIC = 1 << 20      # Philox index offsets that separate the update step's draws from the rollout's
 _SALT_ACTOR = 2 << 20
 
@@ -893,45 +900,68 @@ class RPOTrainerBase(object):
         return (sync[-32:-31] if sync is not None and getattr(self, "_front_cache", False) else None,
                 ws[hip_ops.PROJ_WS_GAVE_UP:hip_ops.PROJ_WS_GAVE_UP + 1] if ws is not None else None)
 
-    def _raise_handover(self, front, proj):
-        if front:
+    def _device_flags(self):
+        """[(kind, one-word device tensor)]: the hand-over words above and the step kernels' sticky failure word
+        ctrl[RPO_CTRL_NONFINITE] (include/rpo_hip.h; SURVEY 5 "failure detection": the reference's NaN -> assert,
+        cartpole.py:170-174 / pendulum.py:85-89, kept as a device-side flag)."""
+        f, g = self._handover_flags()
+        nf = hip_ops.CONST["RPO_CTRL_NONFINITE"]
+        return [(k, x) for k, x in (("front", f), ("proj", g), ("nonfinite", self.vec.ctrl[nf:nf + 1])) if x is not None]
+
+    def _raise_flags(self, vals):
+        if vals.get("front"):
             raise RuntimeError("rpo_split_*_front: a workgroup gave up waiting for its row tile (tile_sync flag set); the "
                                "values of that launch are undefined -- rerun with RPO_SCHEDULE=front=0")
-        if proj:
+        if vals.get("proj"):
             raise RuntimeError("rpo_split_pend_head_project / rpo_split_critic_pfront: a workgroup gave up waiting for another "
                                "one's granules (workspace flag set); the values of that launch are undefined -- rerun with "
                                "RPO_SCHEDULE=front=0")
+        if vals.get("nonfinite"):
+            raise NonFiniteError("vector step %d (0-based): an env lane was stepped with a NaN action or reached a non-finite "
+                                 "next state / reward (ctrl[RPO_CTRL_NONFINITE]).  The reference stops at this point too "
+                                 "(`assert self.action_space.contains(action_fixed)`, cartpole.py:170-174); the transitions "
+                                 "of that step are in the replay ring, so this trainer must not be trained on or "
+                                 "checkpointed -- restart from the last checkpoint" % (int(vals["nonfinite"]) - 1))
 
-    def _check_tile_sync(self):
+    def _check_flags(self):
         """The fused front launches raise a flag word when a workgroup gave up waiting for its producers (nsplit.hip,
-        kNsSpinMax / kPmSpinMax): the values of that launch are then undefined -- fail loudly instead of training on.
+        kNsSpinMax / kPmSpinMax): the values of that launch are then undefined; the step kernels raise
+        ctrl[RPO_CTRL_NONFINITE] when a lane goes non-finite -- fail loudly instead of training on.
         (Synchronising read: harvest, save(), the end of run().)"""
-        f, g = self._handover_flags()
-        self._raise_handover(f is not None and int(f[0]) != 0, g is not None and int(g[0]) != 0)
+        flags = self._device_flags()
+        if self.dist.on:                                          # every rank raises together (harvest / save are collective
+            word = torch.stack([x.reshape(()).to(torch.int64) for _, x in flags])   # points of the loop: no rank is left
+            dist.all_reduce(word, op=dist.ReduceOp.MAX)           # waiting in the next all-reduce)
+            vals = {k: int(v) for (k, _), v in zip(flags, word.tolist())}
+        else:
+            vals = {k: int(x[0]) for k, x in flags}
+        self._raise_flags(vals)
 
-    def _poll_handover(self):
-        """The same without waiting for the device: after every FOURTH graph window the flag words are copied to pinned host
-        memory asynchronously (plain device-to-host copies, no kernel; every window cost 1.4 us per iteration in the kernel
-        trace); a copy that has landed is inspected before a later window is launched, so a lost producer stops the run
-        within a few windows instead of at the next statistics harvest."""
-        st = getattr(self, "_handover_poll", None)
+    def _poll_flags(self, every=4):
+        """The same without waiting for the device: after every `every`-th call (graph windows: every FOURTH; eager
+        iterations: every 16th) the flag words are copied to pinned host memory asynchronously (plain device-to-host
+        copies, no kernel; every window cost 1.4 us per iteration in the kernel trace); a copy that has landed is
+        inspected before a later window is launched, so a lost producer or a NaN actor stops the run within a few windows
+        instead of at the next statistics harvest."""
+        if self.device.type != "cuda":
+            return self._raise_flags({k: int(x[0]) for k, x in self._device_flags()})
+        st = getattr(self, "_flag_poll", None)
         if st is None:
-            f, g = self._handover_flags()
-            st = self._handover_poll = dict(flags=[x for x in (f, g) if x is not None], event=None, calls=0)
-            st["host"] = [torch.zeros(1, dtype=x.dtype).pin_memory() for x in st["flags"]]
-            st["which"] = [x is f for x in st["flags"]]
-        if not st["flags"]:
-            return
+            st = self._flag_poll = dict(event=None, calls=0, host={}, pending=[])
         if st["event"] is not None:
             if not st["event"].query():
                 return                                            # the previous copy is still in flight: look again later
             st["event"] = None
-            vals = {bool(w): int(h[0]) for w, h in zip(st["which"], st["host"])}
-            self._raise_handover(vals.get(True, 0) != 0, vals.get(False, 0) != 0)
+            self._raise_flags({k: int(st["host"][k][0]) for k in st["pending"]})
         st["calls"] += 1
-        if st["calls"] % 4 != 1:
+        if every > 1 and st["calls"] % every != 1:
             return
-        for h, x in zip(st["host"], st["flags"]):
+        flags = self._device_flags()                              # (the hand-over workspaces appear with the first update)
+        st["pending"] = [k for k, _ in flags]
+        for k, x in flags:
+            h = st["host"].get(k)
+            if h is None or h.dtype != x.dtype:
+                h = st["host"][k] = torch.zeros(1, dtype=x.dtype).pin_memory()
             h.copy_(x, non_blocking=True)
         st["event"] = torch.cuda.Event()
         st["event"].record()
@@ -1024,10 +1054,10 @@ class RPOTrainerBase(object):
                     self._graphs.run(("cycle", L, do_train), lambda: [self._run_segments(self._segments(
                         False, do_train, do_train and (t + i + 1) % self.policy_fre == 0)) for i in range(L)])
                 self._updates += L if do_train else 0
-                if do_train:
-                    self._poll_handover()
+                self._poll_flags()
             else:
                 self._iteration(warm, do_train, actor_step)
+                self._poll_flags(every=16)
                 if do_train:
                     self._updates += 1
                     if self.updates_per_step > 1:
@@ -1221,7 +1251,7 @@ class RPOTrainerBase(object):
             for k in ("max_ineq_max", "max_eq_max"):
                 rows[:, hip_ops.STAT[k]] = mx[:, hip_ops.STAT[k]]
         rows = rows.cpu().numpy().astype(np.float64)
-        self._check_tile_sync()                                   # (the copy above already waited for the device)
+        self._check_flags()                                       # (the copy above already waited for the device)
         S = hip_ops.STAT
         n = float(self.num_envs)
         # whole-array bookkeeping (a Python loop over the rows kept the GPU idle for ~12 us per iteration at 4096 lanes)
@@ -1329,7 +1359,7 @@ class RPOTrainerBase(object):
         os.makedirs(d, exist_ok=True)
         if self.device.type == "cuda":
             torch.cuda.synchronize()
-            self._check_tile_sync()                                 # never checkpoint parameters of undefined origin
+        self._check_flags()                                         # never checkpoint parameters of undefined origin
         self.agent.save_model(d)
         self._harvest()
         v, b = self.vec, self.buffer

@@ -46,15 +46,22 @@ def build(force=False, verbose=True, asan=False):
     os.makedirs(obj_dir, exist_ok=True)
     target = TARGET_ASAN if asan else TARGET
     flags = FLAGS + (SANITIZE if asan else [])
+    cmds = []
     for src in SOURCES:
         s = os.path.join(HERE, src)
         o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + flags + ["-c", s, "-o", o]
+            cmds.append([HIPCC] + flags + ["-c", s, "-o", o])
+    if cmds:                                                    # translation units are independent: RPO_BUILD_JOBS at a time (4)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max(1, int(os.environ.get("RPO_BUILD_JOBS", "4")))) as pool:
+            list(pool.map(run, cmds))
     if force or _stale(target, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs + \
             (["-fsanitize=address,undefined", "-shared-libsan"] if asan else [])

@@ -143,6 +143,8 @@ __device__ __forceinline__ void cart_lane(const StepArgs& p, const CartConsts& c
     ns[5] = thetaacc;
     const bool terminated = ns[0] < -kXThreshold || ns[0] > kXThreshold || ns[3] < -kThetaThreshold ||
                             ns[3] > kThetaThreshold;                                  // cartpole.py:208-213
+    // (a NaN action is what the reference's assert stops on, cartpole.py:170-174; a non-finite next state is a diverged lane)
+    rpo_flag_nonfinite(p.ctrl, a.x != a.x || a.y != a.y || !__builtin_isfinite(((ns[0] + ns[1]) + (ns[2] + ns[3])) + (ns[4] + ns[5])));
     const int len = ep.len + 1;
     const bool done = terminated || len >= p.max_episode_steps;                        // gym TimeLimit
     const float reward = 1.0f;                                                         // cartpole.py:215-221
@@ -213,16 +215,16 @@ __device__ __forceinline__ float2 cart_explore_project(const ActArgs& p, const C
     RPO_FP_STRICT
     float ap = (p.noise_mode == RPO_NOISE_UNIFORM) ? 0.0f : ap_in;
     if (p.noise_mode == RPO_NOISE_EXPLICIT) {
-        ap = fminf(fmaxf(ap + eps_t * p.noise[i], p.box_lo), p.box_hi);                  // ddpg_pa.py:108-110
+        ap = rpo_clamp(ap + eps_t * p.noise[i], p.box_lo, p.box_hi);                  // ddpg_pa.py:108-110
     } else if (p.noise_mode == RPO_NOISE_PHILOX) {
         const rpo_u4 r = rpo_philox(p.seed, p.env_id_base + (uint32_t)i, (uint32_t)t, RPO_STREAM_ACT);
-        ap = fminf(fmaxf(ap + eps_t * rpo_normal(r.x, r.y), p.box_lo), p.box_hi);
+        ap = rpo_clamp(ap + eps_t * rpo_normal(r.x, r.y), p.box_lo, p.box_hi);
     } else if (p.noise_mode == RPO_NOISE_UNIFORM) {                                      // model/utils.py:53-62
         const rpo_u4 r = rpo_philox(p.seed, p.env_id_base + (uint32_t)i, (uint32_t)t, RPO_STREAM_ACT);
         const float scale = (p.box_hi - p.box_lo) * 0.5f;
         ap = scale * (2.0f * rpo_u01(r.x) - 1.0f) + (p.box_lo + scale);
     } else if (p.noise_mode == RPO_NOISE_CLIP_ONLY) {
-        ap = fminf(fmaxf(ap, p.box_lo), p.box_hi);
+        ap = rpo_clamp(ap, p.box_lo, p.box_hi);
     }
     // complete_partial, cartpole.py:369-373
     float ao = (c.b - ap * c.C_p) * c.C_o_inv;

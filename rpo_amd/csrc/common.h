@@ -151,11 +151,19 @@ __device__ __forceinline__ float rpo_wave_sum_rows(float v) {
     return (s0 + s1) + (s2 + s3);
 }
 
+// torch.clamp / np.clip propagate a NaN; fminf(fmaxf(x, lo), hi) would return `lo` for it -- and a diverged actor's NaN
+// output would become a legal action at the edge of its box instead of reaching the step kernels' failure word
+// (rpo_flag_nonfinite below; the reference's assert, cartpole.py:170-174).  Same bits for every non-NaN x.
+__device__ __forceinline__ float rpo_clamp(float x, float lo, float hi) {
+    const float c = fminf(fmaxf(x, lo), hi);
+    return x != x ? x : c;
+}
+
 // take_action's exploration (agent/ddpg_pa.py:108-110): clip(ap + eps_t * noise, lo, hi), unfused like the
 // RPO_NOISE_PHILOX / RPO_NOISE_EXPLICIT branches of the *_explore_project functions
 __device__ __forceinline__ float rpo_explore_clip(float ap, float eps_t, float noise, float lo, float hi) {
     RPO_FP_STRICT
-    return fminf(fmaxf(ap + eps_t * noise, lo), hi);
+    return rpo_clamp(ap + eps_t * noise, lo, hi);
 }
 
 __device__ __forceinline__ float rpo_wave_sum(float v) {
@@ -195,6 +203,15 @@ __device__ __forceinline__ void rpo_atomic_max_nonneg(float* addr, float v) {
 struct RpoEpisode { int len; float ret; unsigned count; };
 __device__ __forceinline__ RpoEpisode rpo_load_episode(const int* ep_len, const float* ep_ret, const unsigned* ep_count, int i) {
     return RpoEpisode{ep_len[i], ep_ret[i], ep_count[i]};
+}
+
+// Failure detection (include/rpo_hip.h: RPO_CTRL_NONFINITE).  The reference stops on a NaN action (`assert
+// self.action_space.contains(action_fixed)`: cartpole.py:170-174, pendulum.py:85-89; an infinite action is clipped and passes)
+// and everything after it is garbage; here a diverged actor would fill the ring with NaN transitions silently.  `bad` is the
+// lane's own test; the word keeps the FIRST offending vector step + 1.  Clean path: one compare + a not-taken branch.
+__device__ __forceinline__ void rpo_flag_nonfinite(long long* ctrl, bool bad) {
+    if (bad && ctrl != nullptr)
+        atomicCAS(reinterpret_cast<unsigned long long*>(ctrl + RPO_CTRL_NONFINITE), 0ull, (unsigned long long)(ctrl[RPO_CTRL_T] + 1));
 }
 
 // Statistics rows are split into RPO_STATS_SUB sub-rows (one cache line each); a workgroup adds into sub-row

@@ -103,6 +103,12 @@ __device__ __forceinline__ void evopf_step_lane(const StepArgs& p, Ws& w, float*
     if (tid < NINEQ) row[2 * NS + NY + 2 + NEQ + tid] = fmaxf(w.ineq[tid], 0.0f);
     if (tid < RPO_EVOPF_ROW - (2 * NS + NY + 2 + NEQ + NINEQ)) row[2 * NS + NY + 2 + NEQ + NINEQ + tid] = 0.0f;
     sync();
+    {   // failure detection (RPO_CTRL_NONFINITE): the reference has no assertion in EVOPFEnv.step (evopf.py:348-366) and would go
+        // on with NaNs; here a non-finite entry anywhere in the transition row (action, next state, reward, violations) stops the run
+        bool bad = false;
+        for (int k = tid; k < 2 * NS + NY + 2 + NEQ + NINEQ; k += RPO_WAVE) bad |= !__builtin_isfinite(row[k]);
+        if (__ballot(bad) != 0ull) rpo_flag_nonfinite(p.ctrl, tid == 0);
+    }
     if (p.rows) {
         const long long ring = (t % p.cap_steps) * (long long)p.n + i;
         float4* dst = reinterpret_cast<float4*>(p.rows + (size_t)ring * RPO_EVOPF_ROW);
@@ -192,18 +198,18 @@ __global__ __launch_bounds__(RPO_WAVE * kActWaves) void evopf_act_project_kernel
             z = scale * tanhf(z) + (lo + scale);
         }
         if (p.noise_mode == RPO_NOISE_EXPLICIT) {
-            z = fminf(fmaxf(z + eps_t * p.noise[(size_t)i * NP + tid], lo), hi);
+            z = rpo_clamp(z + eps_t * p.noise[(size_t)i * NP + tid], lo, hi);
         } else if (p.noise_mode == RPO_NOISE_PHILOX) {
             const rpo_u4 r = rpo_philox(p.seed, env_id, (uint32_t)t, RPO_STREAM_ACT, (uint32_t)(tid >> 1));
             const float nz = (tid & 1) ? rpo_normal(r.z, r.w) : rpo_normal(r.x, r.y);
-            z = fminf(fmaxf(z + eps_t * nz, lo), hi);
+            z = rpo_clamp(z + eps_t * nz, lo, hi);
         } else if (p.noise_mode == RPO_NOISE_UNIFORM) {
             const rpo_u4 r = rpo_philox(p.seed, env_id, (uint32_t)t, RPO_STREAM_ACT, (uint32_t)(tid >> 2));
             const uint32_t word = (tid & 3) == 0 ? r.x : ((tid & 3) == 1 ? r.y : ((tid & 3) == 2 ? r.z : r.w));
             const float scale = (hi - lo) * 0.5f;
             z = scale * (2.0f * rpo_u01(word) - 1.0f) + (lo + scale);
         } else if (p.noise_mode == RPO_NOISE_CLIP_ONLY) {
-            z = fminf(fmaxf(z, lo), hi);
+            z = rpo_clamp(z, lo, hi);
         }
     }
     const RowLane L = make_row_lane(w);

@@ -11,12 +11,12 @@ constexpr float kLogSigMin = -23.0f, kLogSigMax = -2.0f, kHalfLog2Pi = 0.9189385
 __device__ __forceinline__ float gauss_head_row(float raw_mean, float raw_ls, float e, float scale, float base, float lo,
                                                 float hi, int deterministic, float* logp) {
     RPO_FP_STRICT
-    const float ls = fminf(fmaxf(raw_ls - 3.0f, kLogSigMin), kLogSigMax);
+    const float ls = rpo_clamp(raw_ls - 3.0f, kLogSigMin, kLogSigMax);
     const float x = raw_mean + e * expf(ls);
     const float y = tanhf(x);
     if (logp) *logp = -0.5f * e * e - ls - kHalfLog2Pi - logf(scale * (1.0f - y * y) + 1e-6f);
     const float a = deterministic ? scale * tanhf(raw_mean) + base : scale * y + base;
-    return fminf(fmaxf(a, lo), hi);
+    return rpo_clamp(a, lo, hi);                                  // (NaN-propagating like torch.clamp, agent/sac_pa.py:111)
 }
 
 // Backward of gauss_head_row w.r.t. (mean head, log-std head) given d loss / d ap and the coefficient of log pi in the

@@ -27,6 +27,8 @@
 // lanes as ((q0 + q1) + (q2 + q3)) + ... ; here lane (li, lg) holds the four q of lanes 4 lg .. 4 lg + 3 of its row.
 // (Inputs beyond S + A are zero-weighted zeros: fmaf(0, 0, x) == x except for x == -0.0 -> +0.0, a sign of zero.)
 #pragma once
+#include <type_traits>
+
 #include "mlp_tile.h"
 
 namespace rpo_mlp_dev {
@@ -86,9 +88,11 @@ __device__ __forceinline__ void stream_inputs(const ARGS& p, long long row0, int
     }
 }
 
-template <int H, bool FULL, int CH, int SAVE, int TWO, class ARGS>
+// EMIT: what happens to a row's outputs -- emit(row, o0, o1, two) is called by the lane that holds row li's values (lg == 0) for
+// every existing row: the forward kernels store them, the streaming rollout (fused.hip) keeps them for its per-lane phase.
+template <int H, bool FULL, int CH, int SAVE, int TWO, class ARGS, class EMIT>
 __device__ __forceinline__ void stream_tile(const ARGS& p, const StreamLds<H>& lds, int row0, int lane, float b1a, float b1b,
-                                            const float (&in3)[3]) {
+                                            const float (&in3)[3], const EMIT& emit) {
     constexpr int EIN = 128;
     const Mlp& net = p.net;
     const int li = lane & 15, lg = lane >> 4;
@@ -192,30 +196,33 @@ __device__ __forceinline__ void stream_tile(const ARGS& p, const StreamLds<H>& l
     if (lg == 0 && live) {
         float o0 = v0;
         if (p.out_mode == 1) o0 = p.scale * tanhf(o0) + p.base;
-        p.out[(size_t)row * net.n_out] = o0;
-        if (two) p.out[(size_t)row * net.n_out + 1] = v1;
+        emit(row, o0, v1, two);
     }
 }
 
+// the forward kernels' EMIT: outputs to p.out [n, n_out]
+template <class ARGS>
+struct StreamStoreOut {
+    const ARGS& p;
+    __device__ __forceinline__ void operator()(int row, float o0, float o1, bool two) const {
+        p.out[(size_t)row * p.net.n_out] = o0;
+        if (two) p.out[(size_t)row * p.net.n_out + 1] = o1;
+    }
+};
+
 // The rare tile -- the ragged last one, or a caller that saves only one of the pre-activations -- with every condition at run
 // time (out of line it cost 900 bytes of scratch per lane for the argument copy: inlined)
-template <int H, int CH, class ARGS>
+template <int H, int CH, class ARGS, class EMIT>
 __device__ __forceinline__ void stream_tile_any(const ARGS& p, const StreamLds<H>& lds, int row0, int lane, float b1a, float b1b,
-                                                const float (&in3)[3]) {
-    stream_tile<H, false, CH, -1, -1>(p, lds, row0, lane, b1a, b1b, in3);
+                                                const float (&in3)[3], const EMIT& emit) {
+    stream_tile<H, false, CH, -1, -1>(p, lds, row0, lane, b1a, b1b, in3, emit);
 }
 
-// FwdArgs is declared by the includer (mlp.hip); the kernel takes the FwdArgs4 of the multi-network launches
-template <int H, int NW, class ARGS4>
-__device__ __forceinline__ void mlp_forward_stream_body(const ARGS4& p4) {
+// Staging of a network into the workgroup's StreamLds (once per workgroup; the caller synchronises)
+template <int H, int NW>
+__device__ __forceinline__ void stream_stage(const Mlp& net, StreamLds<H>& lds, int tid) {
     constexpr int EIN = 128;
-    __shared__ StreamLds<H> lds;
-    const auto& p = p4.net[blockIdx.y];
-    const Mlp& net = p.net;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar tile arithmetic)
     const int nin = net.S + net.A;
-    // ---- staging, once per workgroup
     for (int idx = tid; idx < H * (EIN / 4); idx += NW * 64) {
         const int j = idx / (EIN / 4), q = idx - j * (EIN / 4);
         *reinterpret_cast<float4*>(&lds.w0[j * kStreamLdW + q * 4]) =
@@ -236,6 +243,18 @@ __device__ __forceinline__ void mlp_forward_stream_body(const ARGS4& p4) {
         lds.w1a[idx] = net.W1[idx];
         lds.w1b[idx] = net.n_out > 1 ? net.W1b[idx] : 0.0f;
     }
+}
+
+// FwdArgs is declared by the includer (mlp.hip); the kernel takes the FwdArgs4 of the multi-network launches
+template <int H, int NW, class ARGS4>
+__device__ __forceinline__ void mlp_forward_stream_body(const ARGS4& p4) {
+    constexpr int EIN = 128;
+    __shared__ StreamLds<H> lds;
+    const auto& p = p4.net[blockIdx.y];
+    const Mlp& net = p.net;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar tile arithmetic)
+    stream_stage<H, NW>(net, lds, tid);                         // ---- staging, once per workgroup
     __syncthreads();
     const float b1a = net.b1[0], b1b = net.n_out > 1 ? net.b1b[0] : 0.0f;
     const int tiles = (p.n + kRows - 1) / kRows;
@@ -247,15 +266,16 @@ __device__ __forceinline__ void mlp_forward_stream_body(const ARGS4& p4) {
         float nxt[3];
         stream_inputs(p, (long long)(t + dt < tiles ? t + dt : t) * kRows, lane, nxt);   // the next tile's inputs land under this tile's MFMAs
         constexpr int CH = NW > 12 ? 2 : 4;
+        const StreamStoreOut<typename std::remove_reference<decltype(p)>::type> emit{p};
         if (row0 + kRows <= p.n) {
             const bool save = p.x0_save && p.h1_save, none = !p.x0_save && !p.h1_save, two = net.n_out > 1;
-            if (save && !two) stream_tile<H, true, CH, 1, 0>(p, lds, row0, lane, b1a, b1b, in3);          // critics
-            else if (none && !two) stream_tile<H, true, CH, 0, 0>(p, lds, row0, lane, b1a, b1b, in3);     // target networks, DDPG actor
-            else if (save && two) stream_tile<H, true, CH, 1, 1>(p, lds, row0, lane, b1a, b1b, in3);      // Gaussian actor (policy step)
-            else if (none && two) stream_tile<H, true, CH, 0, 1>(p, lds, row0, lane, b1a, b1b, in3);      // Gaussian actor (inference)
-            else stream_tile_any<H, CH>(p, lds, row0, lane, b1a, b1b, in3);                               // (one of x0 / h1 saved)
+            if (save && !two) stream_tile<H, true, CH, 1, 0>(p, lds, row0, lane, b1a, b1b, in3, emit);          // critics
+            else if (none && !two) stream_tile<H, true, CH, 0, 0>(p, lds, row0, lane, b1a, b1b, in3, emit);     // target networks, DDPG actor
+            else if (save && two) stream_tile<H, true, CH, 1, 1>(p, lds, row0, lane, b1a, b1b, in3, emit);      // Gaussian actor (policy step)
+            else if (none && two) stream_tile<H, true, CH, 0, 1>(p, lds, row0, lane, b1a, b1b, in3, emit);      // Gaussian actor (inference)
+            else stream_tile_any<H, CH>(p, lds, row0, lane, b1a, b1b, in3, emit);                               // (one of x0 / h1 saved)
         } else {
-            stream_tile_any<H, CH>(p, lds, row0, lane, b1a, b1b, in3);
+            stream_tile_any<H, CH>(p, lds, row0, lane, b1a, b1b, in3, emit);
         }
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) in3[ks] = nxt[ks];

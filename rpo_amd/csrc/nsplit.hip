@@ -1123,7 +1123,7 @@ struct PendPol {
 // take_action's exploration (agent/ddpg_pa.py:108-110): the arithmetic of cart/pend_explore_project's RPO_NOISE_EXPLICIT
 __device__ __forceinline__ float explore_clip(float ap_det, float eps_t, float e, float lo, float hi) {
     RPO_FP_STRICT
-    return fminf(fmaxf(ap_det + eps_t * e, lo), hi);
+    return rpo_clamp(ap_det + eps_t * e, lo, hi);
 }
 
 // ---- pol_a: pi hidden slabs on the batch states, pre-activations saved.  grid (row tiles, 8)

@@ -90,6 +90,8 @@ __device__ __forceinline__ void pend_lane(const StepArgs& p, int i, float4 s, fl
     const float nldot = ldot + lacc * kDt;
     const float nth = th + nthdot * kDt;                                     // semi-implicit in theta :119
     const float nl = l + ldot * kDt;                                         // explicit in l :120
+    // (pendulum.py:85-89 asserts on a NaN action; the speed clip below would launder a NaN: tested before it)
+    rpo_flag_nonfinite(p.ctrl, a.x != a.x || a.y != a.y || !__builtin_isfinite((nth + nthdot) + (nl + nldot)));
     nthdot = fminf(fmaxf(nthdot, -kMaxSpeed), kMaxSpeed);
     const bool terminated = nl <= 0.5f || nl >= 1.5f || nth >= kThetaLim || nth <= -kThetaLim;   // :124
     const float reward = 1.0f / (100.0f * costs + 1.0f);
@@ -167,16 +169,16 @@ __device__ __forceinline__ float2 pend_explore_project(const ActArgs& p, const f
     const Eq e = set_eq(o[0], o[1], o[2], o[3], o[4]);
     float ax = (p.noise_mode == RPO_NOISE_UNIFORM) ? 0.0f : ap_in;
     if (p.noise_mode == RPO_NOISE_EXPLICIT) {
-        ax = fminf(fmaxf(ax + eps_t * p.noise[i], p.box_lo), p.box_hi);
+        ax = rpo_clamp(ax + eps_t * p.noise[i], p.box_lo, p.box_hi);
     } else if (p.noise_mode == RPO_NOISE_PHILOX) {
         const rpo_u4 r = rpo_philox(p.seed, p.env_id_base + (uint32_t)i, (uint32_t)t, RPO_STREAM_ACT);
-        ax = fminf(fmaxf(ax + eps_t * rpo_normal(r.x, r.y), p.box_lo), p.box_hi);
+        ax = rpo_clamp(ax + eps_t * rpo_normal(r.x, r.y), p.box_lo, p.box_hi);
     } else if (p.noise_mode == RPO_NOISE_UNIFORM) {
         const rpo_u4 r = rpo_philox(p.seed, p.env_id_base + (uint32_t)i, (uint32_t)t, RPO_STREAM_ACT);
         const float scale = (p.box_hi - p.box_lo) * 0.5f;
         ax = scale * (2.0f * rpo_u01(r.x) - 1.0f) + (p.box_lo + scale);
     } else if (p.noise_mode == RPO_NOISE_CLIP_ONLY) {
-        ax = fminf(fmaxf(ax, p.box_lo), p.box_hi);
+        ax = rpo_clamp(ax, p.box_lo, p.box_hi);
     }
     float ay = (e.b - ax * e.C_p) * e.C_o_inv;                               // complete_partial :256-262
     float old_x = 0.0f, old_y = 0.0f;

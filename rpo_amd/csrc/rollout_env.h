@@ -32,9 +32,11 @@ struct CartEnv {
     __device__ static __forceinline__ RpoEpisode episode(const StepArgs& p, int i) {
         return rpo_load_episode(p.ep_len, p.ep_ret, p.ep_count, i);
     }
+    // `full_line`: the 32 bytes of padding behind the transition are written too (zeros, like the step kernel's tile path), so
+    // that a whole 128-byte line leaves the CU -- the streaming rollout at >= 65 536 lanes, where the ring is HBM traffic
     __device__ static __forceinline__ void lane(const StepArgs& p, const Consts& c, int i, const float* obs, float2 a,
                                                 const RpoEpisode& ep, long long ring_base,
-                                                float (&st)[rpo_cart_dev::kStepStats]) {
+                                                float (&st)[rpo_cart_dev::kStepStats], bool full_line = false) {
         float s[6], ns[6];
         float4 row[6];
 #pragma unroll
@@ -44,9 +46,15 @@ struct CartEnv {
             float4* gr = reinterpret_cast<float4*>(p.rows + (size_t)(ring_base + i) * RPO_CART_RING);
 #pragma unroll
             for (int q = 0; q < 6; ++q) gr[q] = row[q];
+            if (full_line) {
+#pragma unroll
+                for (int q = 6; q < RPO_CART_RING / 4; ++q) gr[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
         }
         rpo_cart_dev::store_state(p.state + (size_t)i * 6, ns);
     }
+    // where the actor's inputs of the lanes live, as rows of OBS floats (the streaming rollout reads them in the MFMA layout)
+    __device__ __host__ static __forceinline__ const float* obs_rows(const StepArgs& p) { return p.state; }
 };
 
 struct PendEnv {
@@ -81,7 +89,7 @@ struct PendEnv {
     }
     __device__ static __forceinline__ void lane(const StepArgs& p, const Consts&, int i, const float* obs, float2 a,
                                                 const RpoEpisode& ep, long long ring_base,
-                                                float (&st)[rpo_pend_dev::kStepStats]) {
+                                                float (&st)[rpo_pend_dev::kStepStats], bool full_line = false) {
         const float4 s = reinterpret_cast<const float4*>(p.internal)[i];
         float ns[4], ncs, nsn;
         float4 row[4];
@@ -94,6 +102,7 @@ struct PendEnv {
         reinterpret_cast<float4*>(p.internal)[i] = make_float4(ns[0], ns[1], ns[2], ns[3]);
         if (p.obs) rpo_pend_dev::store_obs(p.obs + (size_t)i * 5, ncs, nsn, ns[1], ns[2], ns[3]);
     }
+    __device__ __host__ static __forceinline__ const float* obs_rows(const StepArgs& p) { return p.obs; }   // (NULL: no streaming form)
 };
 
 }  // namespace

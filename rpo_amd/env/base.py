@@ -126,7 +126,10 @@ class HardConstraintEnv(gym.Env):
         """One env step through the same fused HIP kernel the vectorised rollout uses (n = 1, no auto-reset).
         Returns (obs, reward, done, {'ineq_viol', 'eq_viol'}) like cartpole.py:229 / pendulum.py:128."""
         vec = self._single()
-        a = self._t(np.asarray(action, dtype=np.float32).reshape(1, -1))
+        a_np = np.asarray(action, dtype=np.float32).reshape(1, -1)
+        # cartpole.py:170-174 / pendulum.py:85-89: the CLIPPED action must lie in the action space -- it does unless it is NaN
+        assert not np.isnan(a_np).any(), "%r (%s) invalid" % (action, type(action))
+        a = self._t(a_np)
         vec.ctrl.zero_()
         vec.ep_len.zero_()            # the TimeLimit lives in the gym wrapper, not here
         self.kernels.step(vec.internal, vec.obs, a, vec.ep_len, vec.ep_ret, vec.ep_count, self._row, 1, None, vec.ctrl,

@@ -92,6 +92,10 @@ class _EnvKernels(object):
         _put(ep_len, np.where(reset_mask, 0, length))
         _put(ep_ret, np.where(reset_mask, 0, ret))
         if ctrl is not None:
+            # failure detection (include/rpo_hip.h RPO_CTRL_NONFINITE; the reference's assert on a NaN action, cartpole.py:170-174)
+            if int(ctrl[CONST["RPO_CTRL_NONFINITE"]]) == 0 and (np.isnan(action).any() or not np.isfinite(nxt_obs).all() or
+                                                                not np.isfinite(reward).all()):
+                ctrl[CONST["RPO_CTRL_NONFINITE"]] = t + 1
             ctrl[0] = t + 1
         return reset_mask
 

@@ -91,7 +91,7 @@ def test_split_update_stages_validate_arguments():
     assert lib.rpo_xcc_probe(0, 16, 4, 256, None, None) == _lib.CONST["RPO_ERR_ARG"]
     for stage in ("critic_fwd_a_ride", "critic_fwd_b_ride", "critic_bwd_b_ride", "critic_front_ride", "critic_mid_ride", "critic_pfront_ride"):            # the riding rollout halves: both structs are required
         assert getattr(lib, "rpo_split_" + stage)(None, None, None) == _lib.CONST["RPO_ERR_NULL"]
-    assert _lib.CONST["RPO_ABI_VERSION"] == 5
+    assert _lib.CONST["RPO_ABI_VERSION"] == 6
 
 
 def test_every_entry_point_survives_null_arguments():
