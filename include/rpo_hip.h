@@ -674,6 +674,8 @@ int rpo_split_critic_pfront_ride(const rpo_split_update* u, const rpo_rollout_ri
  * agent/ddpg_pa.py:34-36).  dh [n, H] and dx0 [n, Ein] are caller-provided scratch; da [n, A] (may be NULL) receives
  * the gradient w.r.t. the action input (actor loss: -Q(s, a) back to the policy, rpo_ddpg.py:317).
  * param_grads = 0: only dx0 / da; first_layer_state_only = 1: of the parameters only Ws / bs are accumulated.
+ * dh / dx0 are SCRATCH of the two-pass kernels: from RPO_SPLITK_FROM rows the streaming kernels (mlp_bwd_stream.h) keep both in
+ * registers and leave the buffers untouched -- a caller must not read them back.
  * gradmax (may be NULL; [RPO_GRADMAX_LEN]): its slots receive max(slot, max |gradient element written by this call|) -- when the buffers were
  * zero before the call this is clip_grad_norm_'s inf-norm of the network (rpo_ddpg.py:180), without the rpo_absmax pass. */
 int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int n, const float* s, int s_stride,

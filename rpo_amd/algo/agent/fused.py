@@ -105,9 +105,9 @@ class FusedNets(object):
     def enable_splitk(self, batch_size):
         """Large update batches (>= RPO_SPLITK_FROM rows): give every trainable network a scratch buffer for the split-K
         weights pass of the backward kernels -- Z copies of the network's OWN gradient span (first to last gradient element in
-        the flat buffer, what splitk_plan in csrc/mlp_bwd.h addresses), Z = min(256, batch_size // 4096) as that plan uses.
+        the flat buffer, what splitk_plan in csrc/mlp_bwd.h addresses), Z = min(256, batch_size // 512) as that plan uses.
         (Round 3 allocated 256 x the whole flat gradient per network: ~64 x what a batch of 16384 touches)"""
-        z = max(2, min(256, int(batch_size) // 4096))
+        z = max(2, min(256, int(batch_size) // 512))
         for name, d in self.descs.items():
             if "target" in name or d.splitk is not None:
                 continue

@@ -76,12 +76,14 @@ class RPODDPG(RPOTrainerBase):
                     schedule=schedule)
 
     # ---- rollout policy (rpo_ddpg.py:98-106, agent/ddpg_pa.py:101-112) ----------------------------------------
-    def _actor_out(self, name, obs, save=False):
-        """Deterministic basic action [n] of `actor` / `actor_target` through the fused MLP kernel."""
+    def _actor_out(self, name, obs, save=False, tag=None):
+        """Deterministic basic action [n] of `actor` / `actor_target` through the fused MLP kernel.  `tag`: the output buffer's
+        name when it must not be the rollout's (the policy step's prefix runs on a second stream BESIDE other launches: with
+        num_envs == batch_size the shape-keyed "actor.out" would be one buffer for both)."""
         f = self.fused
         P = self.kernels.partial_dim
         # P > 1 (EVOPF): raw outputs; the env kernels apply the state-dependent tanh box (ap_is_raw)
-        return f.forward(name, obs, None, f.buf(name + ".out", obs.shape[0], P), save=save,
+        return f.forward(name, obs, None, f.buf((tag or name) + ".out", obs.shape[0], P), save=save,
                          tanh_box=self._box_affine).view(-1)
 
     def _policy_partial(self, obs, warm):
@@ -261,7 +263,7 @@ class RPODDPG(RPOTrainerBase):
         arguments, same bits as inside `_actor_update`."""
         f, ag, B, k = self.fused, self.agent, self.batch_size, self.kernels
         state = cols[0]
-        ap_det = self._actor_out("actor", state, save=True)
+        ap_det = self._actor_out("actor", state, save=True, tag="pi")
         self.backend.philox_normal(self._noise_b, self.seed, self.dist.rank * B * k.partial_dim, _SALT_ACTOR, hip_ops.STREAM_POLICY,
                                    self._uctrl)
         noise = self._noise_b.view(-1)

@@ -928,13 +928,14 @@ class RPOTrainerBase(object):
         kNsSpinMax / kPmSpinMax): the values of that launch are then undefined; the step kernels raise
         ctrl[RPO_CTRL_NONFINITE] when a lane goes non-finite -- fail loudly instead of training on.
         (Synchronising read: harvest, save(), the end of run().)"""
-        flags = self._device_flags()
+        vals = {k: int(x[0]) for k, x in self._device_flags()}
         if self.dist.on:                                          # every rank raises together (harvest / save are collective
-            word = torch.stack([x.reshape(()).to(torch.int64) for _, x in flags])   # points of the loop: no rank is left
-            dist.all_reduce(word, op=dist.ReduceOp.MAX)           # waiting in the next all-reduce)
-            vals = {k: int(v) for (k, _), v in zip(flags, word.tolist())}
-        else:
-            vals = {k: int(x[0]) for k, x in flags}
+            # points of the loop: no rank is left waiting in the next all-reduce).  A FIXED-size word: which hand-over
+            # workspaces exist is a per-rank fact (the placement probe of 4.3 may answer differently on ranks that share a GPU)
+            kinds = ("front", "proj", "nonfinite")
+            word = torch.tensor([vals.get(k, 0) for k in kinds], dtype=torch.int64, device=self.device)
+            dist.all_reduce(word, op=dist.ReduceOp.MAX)
+            vals = dict(zip(kinds, word.tolist()))
         self._raise_flags(vals)
 
     def _poll_flags(self, every=4):
@@ -1156,10 +1157,11 @@ class RPOTrainerBase(object):
 
     def _policy_prefix_ok(self):
         """The actor-only prefix of the policy step may run beside the critic update: generic fused launches (not the policy
-        pipelines, whose front is one launch), multipliers stepped (`fixed` runs zero nu's gradient inside the prefix -- harmless,
-        but nothing to gain).  `_policy_prefix_enabled = False` on a trainer keeps the serial order (A/B)."""
+        pipelines, whose front is one launch), multipliers stepped (`fixed` runs would zero nu's gradient inside the prefix,
+        concurrently with the critic update, for nothing: serial there).  `_policy_prefix_enabled = False` on a
+        trainer keeps the serial order (A/B: tests/test_evopf_gpu.py)."""
         return bool(self.fused is not None and hasattr(self, "_actor_prefix") and not getattr(self, "_actor_pipeline", False)
-                    and self.agent.flat.sizes[1] == 0 and getattr(self, "_policy_prefix_enabled", True))
+                    and self.agent.flat.sizes[1] == 0 and not self.fixed and getattr(self, "_policy_prefix_enabled", True))
 
     def _overlapped_window(self, t, L):
         """L iterations (t is a policy_fre boundary) with rollout i+1 forked off right after the sampling launch of update i

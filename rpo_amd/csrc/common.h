@@ -30,6 +30,19 @@ __device__ __forceinline__ float rpo_relu_bits(float x) {
     return __int_as_float(b > 0 ? b : 0);
 }
 
+// Compute units of the CURRENT device, cached per device id (the persistent kernels launch one workgroup per CU; ADVICE r05:
+// one cache for the streaming forward, backward and rollout instead of a query per launch / a first-device-only static).
+static inline int rpo_cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int v = 0;
+        cached[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return cached[dev];
+}
+
 static inline int rpo_grid_for(long long n, int per_block = RPO_BLOCK) {
     long long g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;

@@ -87,18 +87,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mlp_forward_stream_kernel(Fwd
     mlp_forward_stream_body<256, NW>(p);
 }
 
-static int stream_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            cus = v;
-        else
-            cus = 256;
-    }
-    return cus;
-}
+static int stream_cus() { return rpo_cu_count(); }
 
 // the streaming forward applies: large n, every network of the launch 128 -> 256 with scalar heads and <= 11 inputs
 static bool stream_applies(const FwdArgs4& a, int count, int n) {

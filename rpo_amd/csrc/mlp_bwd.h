@@ -1036,8 +1036,9 @@ static inline SplitK splitk_plan(const BwdArgs& a, float* scratch, long long scr
     }
     if (!lo) return k;
     const long long span = hi - lo, stride = (span + 3) & ~3ll;
-    long long Z = a.n / 4096;                                    // (per thread of the hidden-vector blocks: 1024 rows)
-    if (Z > 256) Z = 256;
+    long long Z = a.n / 512;                                     // (>= 32 row tiles per slice: two per wave of a streaming workgroup.
+    if (Z > 256) Z = 256;                                        //  Until round 6 n / 4096: 4 workgroups at 16 384 rows, 16 at 65 536 --
+                                                                 //  the persistent kernels reached one per CU only at 2^20)
     if (Z * stride > scratch_floats) Z = scratch_floats / stride;
     if (Z < 2) return k;
     k.scratch = scratch; k.lo = const_cast<float*>(lo); k.span = span; k.Z = (int)Z; k.stride = stride;

@@ -426,6 +426,8 @@ static inline bool bwd_stream_applies(const BwdArgs& a, const SplitK& k) {
     const Mlp& net = a.net;
     if (!rpo_tune(RPO_TUNE_BWD_STREAM) || net.cat || net.E != 128 || net.H != 256 || net.hd > 1 || net.S + net.A > 11 || net.A > 8) return false;
     if (a.n < RPO_SPLITK_FROM) return false;
+    if (!a.param_grads && !a.da) return false;                   // (nothing the streaming kernels produce is asked for: dh / dx0
+                                                                 //  only -- the two-pass kernels write those)
     if (a.param_grads && k.Z < 2) return false;                  // (needs the slices' scratch)
     if (a.da && (net.n_out > 1 || net.A > 2)) return false;
     if (a.param_grads && !a.first_layer_state_only && a.da) return false;   // (no caller; keep the two-pass form)
@@ -445,9 +447,7 @@ static inline int launch_bwd_stream(const BwdArgs& args_in, const SplitK& k, hip
         RPO_LAUNCH_CHECK();
         a.dout = a.td.dq_out;
     }
-    int cus = 0, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-        cus = 256;
+    const int cus = rpo_cu_count();
     const bool grads = a.param_grads != 0;
     if (grads && hipMemsetAsync(k.scratch, 0, (size_t)k.Z * (size_t)k.stride * sizeof(float), stream) != hipSuccess) return RPO_ERR_ARG;
     const int Z = grads ? k.Z : cus;                             // rows only: nothing is reduced, every CU takes a share
@@ -461,7 +461,7 @@ static inline int launch_bwd_stream(const BwdArgs& args_in, const SplitK& k, hip
     else if (gmode == 2 && !two && want_da) RPO_ROWS(2, false, true);
     else if (gmode == 2 && !two && !want_da) RPO_ROWS(2, false, false);
     else if (gmode == 2 && two && !want_da) RPO_ROWS(2, true, false);
-    else return RPO_ERR_ARG;
+    else return RPO_ERR_ARG;                                     // (unreachable: bwd_stream_applies admits exactly the six forms above)
 #undef RPO_ROWS
     RPO_LAUNCH_CHECK();
     if (gmode == 1) {

@@ -248,7 +248,6 @@ __device__ __forceinline__ void stream_stage(const Mlp& net, StreamLds<H>& lds, 
 // FwdArgs is declared by the includer (mlp.hip); the kernel takes the FwdArgs4 of the multi-network launches
 template <int H, int NW, class ARGS4>
 __device__ __forceinline__ void mlp_forward_stream_body(const ARGS4& p4) {
-    constexpr int EIN = 128;
     __shared__ StreamLds<H> lds;
     const auto& p = p4.net[blockIdx.y];
     const Mlp& net = p.net;

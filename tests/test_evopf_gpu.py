@@ -410,6 +410,22 @@ def test_training_iterations_graph_equals_eager_and_episodes_roll_over(fused, al
     assert len(res) == 10 and np.isfinite(res).all()
 
 
+@pytest.mark.parametrize("lanes,extra,prefix", [(256, {}, True), (64, dict(fixed=True), False)], ids=["lanes_equal_batch", "fixed_multipliers"])
+def test_policy_prefix_branch_edge_cases(lanes, extra, prefix, monkeypatch):
+    """ADVICE r05 on the actor-only prefix branch: (i) with num_envs == batch_size the rollout's actor output and the
+    prefix's pi(s) would be ONE shape-keyed scratch buffer written from two streams -- the prefix now has a buffer of its own
+    ("pi.out"); (ii) with `fixed=True` (multipliers not stepped) the prefix only zeroed nu's gradient beside the critic update:
+    the serial order is kept there.  hipGraph windows == eager launches, bit for bit, in both."""
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "4")
+    a = _run(lanes, 22, use_graph=False, fused=True, **extra)
+    b = _run(lanes, 22, use_graph=True, fused=True, **extra)
+    assert b._policy_prefix_ok() == prefix and not b._graphs.capture_failed
+    assert torch.equal(a.vec.internal, b.vec.internal) and torch.equal(a.buffer.rows, b.buffer.rows)
+    assert torch.equal(a.agent.flat.data, b.agent.flat.data) and torch.equal(a.agent.nju.weight, b.agent.nju.weight)
+    if prefix:
+        assert ("pi.out", 256, 14) in b.fused._scratch and b.fused._scratch[("pi.out", 256, 14)] is not b.fused._scratch[("actor.out", 256, 14)]
+
+
 def test_sac_on_evopf_runs_and_replays(monkeypatch):
     """scripts/evopf_exp_sac.py's configuration: RPOSAC with a 14-dimensional squashed-Gaussian policy and the
     state-dependent box; hipGraph replay (one graph per iteration) equals the eager run, stored transitions stay near the

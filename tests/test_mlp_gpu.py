@@ -399,7 +399,7 @@ def test_streaming_backward_matches_the_two_pass_kernels(kind, S, A, n):
     aligned_params(net)
     flat, total = _flat_grads(net)
     d = desc_for(ops, net, kind, S, A, E, H)
-    d.splitk = torch.full((max(2, min(256, n // 4096)) * total,), 3.0, device=DEV)      # (dirty: the launch zeroes what it uses)
+    d.splitk = torch.full((max(2, min(256, n // 512)) * total,), 3.0, device=DEV)      # (dirty: the launch zeroes what it uses)
     s = torch.randn(n, S, device=DEV)
     a = torch.randn(n, A, device=DEV) if A else None
     n_out = 2 if kind == "gauss" else 1

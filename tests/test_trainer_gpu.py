@@ -433,6 +433,28 @@ def test_wide_rollout_tiles_are_bitwise_identical(hip, monkeypatch):
         assert torch.equal(out_w[:4096], out_n), kw
 
 
+@pytest.mark.parametrize("sel,n_envs", [(3, 1000), (3, 16 * 16 * 256 * 2 + 37)], ids=["one_workgroup_per_cu_not_full", "several_tiles_per_wave"])
+@pytest.mark.parametrize("algo,envname", CASES)
+def test_streaming_rollout_equals_the_row_tile_rollout(hip, algo, envname, sel, n_envs):
+    """The streaming form of the one-launch rollout (fused.hip rollout_stream_kernel: the actor's hidden matrix stationary in
+    LDS, one wave per 16-lane tile, both layers transposed on the matrix cores, the env step as the epilogue; default from
+    65 536 lanes) against the 16-lane row tiles: the same per-lane functions behind a forward that is the row-tile forward to
+    the bit -- states, actions, ring rows (incl. the zeroed padding of CartSafe's 128-byte ring lines, which the row tiles
+    leave untouched = zero) and therefore the parameters after the updates are EQUAL; statistics are sums over other groupings."""
+    dev = torch.device("cuda")
+    iters = 9
+    with hip.tuning(rollout_wide=0):
+        a = _run(algo, envname, hip, dev, iters, n_envs, use_graph=False, capacity=16)
+    with hip.tuning(rollout_wide=sel):
+        b = _run(algo, envname, hip, dev, iters, n_envs, use_graph=False, capacity=16)
+    assert torch.equal(a.vec.internal, b.vec.internal) and torch.equal(a.vec.action, b.vec.action)
+    assert torch.equal(a.vec.ep_len, b.vec.ep_len) and torch.equal(a.vec.ep_ret, b.vec.ep_ret)
+    assert torch.equal(a.buffer.rows, b.buffer.rows)
+    assert torch.equal(a.agent.flat.data, b.agent.flat.data)
+    assert int(b.vec.ctrl[0]) == iters
+    _stats_equal(a, b, iters)
+
+
 @pytest.mark.parametrize("n_envs", [100, 12500], ids=["16_lane_tiles", "64_lane_tiles"])
 @pytest.mark.parametrize("algo,envname", CASES)
 def test_rollout_pipeline_equals_single_stage_launches(hip, algo, envname, n_envs, monkeypatch):
