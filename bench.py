@@ -339,49 +339,56 @@ def kernel_clinic(tr, workload):
     return out
 
 
-def streaming_clinic(tr):
-    """The HBM-bound CartSafe kernels at 1M lanes, where the streaming regime is actually reached."""
+def streaming_clinic(tr, sizes=((1 << 20, "1M"), (65536, "64K"))):
+    """The HBM-bound CartSafe kernels and the one-launch rollout at SURVEY 8d's large micro-benchmark sizes, 2^20 lanes (where
+    the streaming regime is actually reached) and 65 536 (round 6: the mid point)."""
     from rpo_amd import ops
     from rpo_amd.env.vec import VecEnv
     out = {}
     k, f = tr.kernels, tr.fused
     scale, base = tr._box_affine
     dev = tr.vec.device
-    big_n = 1 << 20
-    big = VecEnv(k, big_n, dev, seed=3, stats_cap=64)
-    big.reset()
-    rows = torch.zeros(8 * big_n, k.ring_floats, device=dev)
-    big_ap = torch.zeros(big_n, device=dev)
-    big_batch = torch.zeros(big_n, k.row_floats, device=dev)
+    for big_n, tag in sizes:
+        big = VecEnv(k, big_n, dev, seed=3, stats_cap=64)
+        big.reset()
+        rows = torch.zeros(8 * big_n, k.ring_floats, device=dev)
+        big_ap = torch.zeros(big_n, device=dev)
+        big_batch = torch.zeros(big_n, k.row_floats, device=dev)
+        ring_bytes = rows.numel() * 4                            # 8 slots x n rows x 128 B (1.07 GB at 2^20: cycled through, never cached)
+        reps = 20 if big_n > 200000 else 50
 
-    ring_bytes = rows.numel() * 4                                # 8 slots x 1M rows x 128 B = 1.07 GB: cycled through, never cached
-
-    def hbm(name, us, per, working_set):
-        r = per * big_n / us * 1e-3
-        out[name] = dict(n=big_n, us=us, bound="hbm", work=per * big_n, rate=r, unit="GB/s", peak=HBM_PEAK_GBS,
-                         frac=r / HBM_PEAK_GBS, **hbm_regime(working_set, r))
-    hbm("cartsafe_step_kernel@1M", time_kernel(lambda: k.step(
-        big.internal, big.obs, big.action, big.ep_len, big.ep_ret, big.ep_count, rows, 8, big.stats, big.ctrl, 200, True,
-        1e-3, big.seed, big.env_id_base), reps=20)[0], 145, ring_bytes)   # SURVEY 8d's algorithmic 145 B; the launch WRITES
-    # a whole 128-byte ring line per lane (96 B of transition + 32 B of padding, round 4): 177 B actually leave / enter the CU
-    out["cartsafe_step_kernel@1M"]["moved_bytes_per_lane"] = 4 * 6 + 4 * 2 + 4 * 6 + 4 * k.ring_floats
-    hbm("cartsafe_act_project_kernel@1M", time_kernel(lambda: k.act_project(
-        big.obs, big_ap, None, big.action, None, ops.NOISE_PHILOX, 1.0, 1.0, 0.0, -10.0, 10.0, 10, 2e-2, 1e-5, 0.0,
-        big.seed, big.env_id_base, big.ctrl, big.stats), reps=20)[0], 40, 40 * big_n)      # the same 42 MB every launch: LLC
-    hbm("replay_sample_gather_kernel@1M", time_kernel(lambda: ops.replay_sample_gather(
-        rows, 8, big_n, big_batch, None, 1, 0, big.ctrl), reps=20)[0], 178 + 4, ring_bytes)   # SURVEY 8d: 2 x 89 B + index
-    # what the launch moves since the 128-byte ring rows: one 128-byte line read + a 96-byte batch row written (+ 4 B index)
-    out["replay_sample_gather_kernel@1M"]["moved_bytes_per_sample"] = 4 * k.ring_floats + 4 * k.row_floats + 4
-    us = time_kernel(lambda: k.rollout(
-        f.descs["actor"], False, scale, base, big.internal, None, big.action, big.ep_len, big.ep_ret, big.ep_count, rows,
-        8, big.stats, big.ctrl, ops.NOISE_PHILOX, 1.0, 1.0, 0.0, -10.0, 10.0, 10, 2e-2, 1e-5, 0.0, 200, True, 1e-3,
-        big.seed, big.env_id_base), reps=5)[0]
-    fl = mlp_flops(f.descs["actor"])
-    out["rollout_kernel<CartEnv>@1M"] = dict(n=big_n, us=us, bound="mfma", work=fl * big_n, rate=fl * big_n / us * 1e-6,
-                                             unit="TFLOP/s", peak=MFMA_F32_PEAK_TFLOPS,
-                                             frac=fl * big_n / us * 1e-6 / MFMA_F32_PEAK_TFLOPS)
-    del big, rows, big_batch
-    torch.cuda.empty_cache()
+        def hbm(name, us, per, working_set):
+            r = per * big_n / us * 1e-3
+            out[name] = dict(n=big_n, us=us, bound="hbm", work=per * big_n, rate=r, unit="GB/s", peak=HBM_PEAK_GBS,
+                             frac=r / HBM_PEAK_GBS, **hbm_regime(working_set, r))
+        hbm("cartsafe_step_kernel@" + tag, time_kernel(lambda: k.step(
+            big.internal, big.obs, big.action, big.ep_len, big.ep_ret, big.ep_count, rows, 8, big.stats, big.ctrl, 200, True,
+            1e-3, big.seed, big.env_id_base), reps=reps)[0], 145, ring_bytes)   # SURVEY 8d's algorithmic 145 B; the launch MOVES
+        # 208 B per lane: s 24 + a 8 + bookkeeping 12 read; s' 24 + bookkeeping 12 + a whole 128-byte ring line written
+        out["cartsafe_step_kernel@" + tag]["moved_bytes_per_lane"] = 4 * 6 + 4 * 2 + 12 + 4 * 6 + 12 + 4 * k.ring_floats
+        hbm("cartsafe_act_project_kernel@" + tag, time_kernel(lambda: k.act_project(
+            big.obs, big_ap, None, big.action, None, ops.NOISE_PHILOX, 1.0, 1.0, 0.0, -10.0, 10.0, 10, 2e-2, 1e-5, 0.0,
+            big.seed, big.env_id_base, big.ctrl, big.stats), reps=reps)[0], 40, 40 * big_n)      # the same buffers every launch: LLC
+        hbm("replay_sample_gather_kernel@" + tag, time_kernel(lambda: ops.replay_sample_gather(
+            rows, 8, big_n, big_batch, None, 1, 0, big.ctrl), reps=reps)[0], 178 + 4, ring_bytes)   # SURVEY 8d: 2 x 89 B + index
+        # what the launch moves since the 128-byte ring rows: one 128-byte line read + a 96-byte batch row written (+ 4 B index)
+        out["replay_sample_gather_kernel@" + tag]["moved_bytes_per_sample"] = 4 * k.ring_floats + 4 * k.row_floats + 4
+        for e in (out["cartsafe_step_kernel@" + tag], out["replay_sample_gather_kernel@" + tag]):
+            moved = e.get("moved_bytes_per_lane", e.get("moved_bytes_per_sample")) * big_n / e["us"] * 1e-3
+            e["moved_rate_gbs"] = moved                          # (the launch's own HBM rate: both run AT the achievable 6.29 TB/s)
+            e["moved_frac_of_achievable"] = moved / HBM_ACHIEVABLE_GBS
+        us = time_kernel(lambda: k.rollout(
+            f.descs["actor"], False, scale, base, big.internal, None, big.action, big.ep_len, big.ep_ret, big.ep_count, rows,
+            8, big.stats, big.ctrl, ops.NOISE_PHILOX, 1.0, 1.0, 0.0, -10.0, 10.0, 10, 2e-2, 1e-5, 0.0, 200, True, 1e-3,
+            big.seed, big.env_id_base), reps=5 if big_n > 200000 else 20)[0]
+        fl = mlp_flops(f.descs["actor"])
+        out["rollout_kernel<CartEnv>@" + tag] = dict(
+            n=big_n, us=us, bound="mfma", work=fl * big_n, rate=fl * big_n / us * 1e-6, unit="TFLOP/s", peak=MFMA_F32_PEAK_TFLOPS,
+            frac=fl * big_n / us * 1e-6 / MFMA_F32_PEAK_TFLOPS, env_steps_per_s=big_n / us * 1e6,
+            kernel="rollout_stream_kernel<CartEnv, 1> (fused.hip: weights stationary in LDS, the env step as the epilogue)"
+            if big_n >= 65536 else "rollout_kernel<CartEnv, 128, 256, 4>")
+        del big, rows, big_batch, big_ap
+        torch.cuda.empty_cache()
     return out
 
 
@@ -413,9 +420,9 @@ def pmc_traffic(kernel, lanes, workload="cart_ddpg"):
     gfx950 FETCH_SIZE correction are described there): the workload's own table first (tools/kernel_probe.py
     window:<workload>), then the CartSafe tables of earlier rounds.  None when that (kernel, size) was not collected."""
     base = kernel.split("<")[0].split(" ")[0]
-    names = ["r05_pmc_traffic_%s.json" % workload, "r04_pmc_traffic_%s.json" % workload]
+    names = ["r06_pmc_traffic_%s.json" % workload, "r05_pmc_traffic_%s.json" % workload, "r04_pmc_traffic_%s.json" % workload]
     if workload.startswith("cart"):
-        names += ["r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"]
+        names += ["r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"]
     for name in names:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -952,7 +959,7 @@ def main():
                     result["large_batch"]["kernels"] = {
                         k: {kk: vv for kk, vv in v.items() if kk in ("us", "rate", "unit", "frac", "bound", "n", "launches_per_period",
                                                                      "regime", "frac_of_achievable")}
-                        for k, v in cl.items() if "@1M" not in k and v.get("n", 0) == 256 * EPG}
+                        for k, v in cl.items() if "@" not in k and v.get("n", 0) == 256 * EPG}
                 del lb
                 torch.cuda.empty_cache()
         if not args.no_clinic:
@@ -1033,7 +1040,7 @@ def roofline(clinic, workload):
     """The dominant kernel of the iteration: the single launch with the largest share of one policy_fre period
     (duration x launches per period) among the priced launches at the bench size; the backward entries are PAIRS of
     launches (rows pass + weights pass) and are listed in all_kernels only."""
-    in_iter = {k: v for k, v in clinic.items() if "rate" in v and "@1M" not in k and not k.startswith("mlp_backward")}
+    in_iter = {k: v for k, v in clinic.items() if "rate" in v and "@" not in k and not k.startswith("mlp_backward")}
     dom = max(in_iter, key=lambda n: in_iter[n]["us"] * in_iter[n].get("launches_per_period", 1))
     d = in_iter[dom]
     kernel = KERNEL_OF.get(dom.split("[")[0], dom)
@@ -1047,7 +1054,8 @@ def roofline(clinic, workload):
                  "all_kernels lists every launch of one policy_fre period with its own roofline" % d["n"],
          "all_kernels": {k: {kk: vv for kk, vv in v.items() if kk in ("us", "rate", "unit", "frac", "bound", "n",
                                                                      "launches_per_period", "regime", "frac_of_achievable",
-                                                                     "moved_bytes_per_lane", "moved_bytes_per_sample")}
+                                                                     "moved_bytes_per_lane", "moved_bytes_per_sample", "moved_rate_gbs",
+                                                                     "moved_frac_of_achievable", "env_steps_per_s", "kernel")}
                          for k, v in clinic.items()}}
     st = clinic.get("cartsafe_step_kernel@1M")
     if st is not None:
@@ -1056,7 +1064,11 @@ def roofline(clinic, workload):
                               "frac": st["frac"], "frac_of_achievable": st.get("frac_of_achievable"),
                               "achievable_peak": HBM_ACHIEVABLE_GBS, "regime": st.get("regime"),
                               "traffic": pmc_traffic("cartsafe_step_kernel", st["n"]),
-                              "algorithmic_bytes_per_launch": st["work"]}
+                              "algorithmic_bytes_per_launch": st["work"],
+                              # the launch MOVES 208 B per lane (ring padding + episode bookkeeping are outside SURVEY's 145 B): its
+                              # own HBM rate is the achievable one -- the fraction above is the ratio of algorithmic to moved bytes
+                              "moved_bytes_per_launch": st.get("moved_bytes_per_lane", 0) * st["n"],
+                              "moved_rate": st.get("moved_rate_gbs"), "moved_frac_of_achievable": st.get("moved_frac_of_achievable")}
     return r
 
 

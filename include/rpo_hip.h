@@ -173,7 +173,11 @@ int rpo_abi_version(void);
                                        in LDS + weights kernel); 0: the one-pass / two-pass kernels of round 3 */
 #define RPO_TUNE_L1_MFMA 7         /* 1: first layer of the 128-wide row-tile forward as three matrix-core steps (S <= 6, A <= 4);
                                        0: the vector form -- the same fmaf chain, the same bits (rpo_mlp_forward / _multi only) */
-#define RPO_TUNE_COUNT 8
+#define RPO_TUNE_EVOPF_PLACE 8    /* EXPERIMENT (round 6; default 0 = off): 1: rpo_evopf_act_project places a batch
+                                      projection (<= 512 rows) on XCDs 0-1 and a rollout projection on XCDs 2-7 (block b runs on XCD b % 8:
+                                      the grid is padded and the other XCDs' workgroups leave at once), so that the two launches that
+                                      overlap in the training windows never share a SIMD.  Measured: DESIGN.md 4b */
+#define RPO_TUNE_COUNT 9
 int rpo_tuning(int key, int value);
 
 /* ---------------------------------------------------------------------------------------------------------------

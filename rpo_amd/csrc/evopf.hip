@@ -168,6 +168,7 @@ struct ActArgs {
     const long long* ctrl;
     float* stats;
     int stats_cap;
+    int place;     // rpo_tuning(RPO_TUNE_EVOPF_PLACE): 0 none; 1 only the workgroups on XCDs 0-1 work; 2 only those on XCDs 2-7
 };
 
 // take_action's exploration + clip to the state-dependent box (agent/ddpg_pa.py:101-112, model/utils.py:53-62,90-101,
@@ -179,8 +180,14 @@ __global__ __launch_bounds__(RPO_WAVE * kActWaves) void evopf_act_project_kernel
     // shares the chip with the 1024-lane projection of the next rollout (one wave per SIMD, the other branch of the window,
     // which has slack): its waves then sit on SIMDs that already hold a wave, and both are bound by instruction issue.  Raised
     // priority gives the batch's waves the issue slots: 171 -> 1xx us measured for it, the rollout's waves on those SIMDs lag.
-    if (gridDim.x * kActWaves <= 512) __builtin_amdgcn_s_setprio(3);
-    const int i = blockIdx.x * kActWaves + threadIdx.x / RPO_WAVE, tid = lane_id();
+    int blk = blockIdx.x;
+    if (p.place) {                                               // (experiment: block b runs on XCD b % 8 -- observed, not promised)
+        const int x = blk & 7, q = blk >> 3;
+        if (p.place == 1) { if (x >= 2) return; blk = q * 2 + x; }
+        else { if (x < 2) return; blk = q * 6 + (x - 2); }
+    }
+    if ((p.place ? p.n : (int)gridDim.x * kActWaves) <= 512) __builtin_amdgcn_s_setprio(3);
+    const int i = blk * kActWaves + threadIdx.x / RPO_WAVE, tid = lane_id();
     if (i >= p.n) return;                                        // (waves never meet at a workgroup barrier)
     const long long t = p.ctrl ? p.ctrl[RPO_CTRL_T] : 0;
     load_consts(w, p.consts);
@@ -552,8 +559,14 @@ int rpo_evopf_act_project(int n, const float* state, int state_stride, const flo
     if (state_stride < RPO_EVOPF_STATE) return RPO_ERR_ARG;
     ActArgs p{n, state, state_stride, ap_raw, noise, action, iters, noise_mode, ap_is_raw, eps_start, eps_end, eps_decay, max_steps, corr_lr,
               corr_eps, corr_momentum, newton_tol, newton_max_iters, consts_dev, (uint64_t)seed, (uint32_t)env_id_base, ctrl,
-              stats, stats_cap};
-    hipLaunchKernelGGL(evopf_act_project_kernel, dim3((n + kActWaves - 1) / kActWaves), dim3(RPO_WAVE * kActWaves), 0, (hipStream_t)stream, p);
+              stats, stats_cap, 0};
+    int blocks = (n + kActWaves - 1) / kActWaves;
+    if (rpo_tune(RPO_TUNE_EVOPF_PLACE)) {
+        p.place = n <= 512 ? 1 : 2;
+        const int per = p.place == 1 ? 2 : 6;
+        blocks = (blocks + per - 1) / per * 8;
+    }
+    hipLaunchKernelGGL(evopf_act_project_kernel, dim3(blocks), dim3(RPO_WAVE * kActWaves), 0, (hipStream_t)stream, p);
     RPO_LAUNCH_CHECK();
     return 0;
 }

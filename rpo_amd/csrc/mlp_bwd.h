@@ -749,6 +749,29 @@ __global__ __launch_bounds__(kThreads) void mlp_bwd_weights_splitk_kernel(BwdArg
 // (round 5: four threads per element, each adding a quarter of the slices in order, the four partial sums combined as
 //  ((q0 + q1) + q2) + q3 -- one thread per element walked 256 dependent loads, 62 us of a 1.4 ms backward.  Still one owner per
 //  element and fixed orders.)
+// The slices' scratch is zeroed by a KERNEL of this library (RPO_SPLITK_ZERO: 1 default; 0: hipMemsetAsync, the form of rounds
+// 3-5).  Round 6 found the large-batch update non-reproducible from run to run under hipGraph replay -- garbage of the size of a
+// gradient in the padding floats behind the critic's head bias, NaN once in a few thousand updates -- never with eager launches
+// and never when anything was inspected between replays (tools/probe/dbg_padding.py): see DESIGN.md 4.5.
+#ifndef RPO_SPLITK_ZERO
+#define RPO_SPLITK_ZERO 1
+#endif
+template <int DUMMY>                                           // (a template: one definition across the translation units that include this)
+__global__ __launch_bounds__(RPO_BLOCK) void splitk_zero_kernel(float4* __restrict__ p, long long n4) {
+    for (long long i = (long long)blockIdx.x * RPO_BLOCK + threadIdx.x; i < n4; i += (long long)gridDim.x * RPO_BLOCK)
+        p[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+static inline int splitk_zero(const SplitK& k, hipStream_t stream) {
+    const size_t floats = (size_t)k.Z * (size_t)k.stride;        // (stride is a multiple of 4 floats; the scratch is 16-byte aligned)
+    if (RPO_SPLITK_ZERO && (reinterpret_cast<uintptr_t>(k.scratch) & 15u) == 0) {
+        long long n4 = (long long)(floats / 4), blocks = (n4 + RPO_BLOCK - 1) / RPO_BLOCK;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_zero_kernel<0>, dim3((unsigned)blocks), dim3(RPO_BLOCK), 0, stream, reinterpret_cast<float4*>(k.scratch), n4);
+        return hipGetLastError() == hipSuccess ? 0 : RPO_ERR_ARG;
+    }
+    return hipMemsetAsync(k.scratch, 0, floats * sizeof(float), stream) == hipSuccess ? 0 : RPO_ERR_ARG;
+}
+
 template <int DUMMY>
 __global__ __launch_bounds__(RPO_BLOCK) void splitk_reduce_kernel(SplitK k, float* gradmax) {
     __shared__ float red[RPO_BLOCK / RPO_WAVE];
@@ -1062,7 +1085,7 @@ static inline bool onepass_applies(const BwdArgs& args, const SplitK& k) {
 // Launches the one-pass backward (caller checked onepass_applies): 0 or an RPO_ERR_* / hipError code.
 template <int EIN, int H>
 static inline int launch_onepass(const BwdArgs& args, const SplitK& k, hipStream_t stream) {
-    if (hipMemsetAsync(k.scratch, 0, (size_t)k.Z * (size_t)k.stride * sizeof(float), stream) != hipSuccess) return RPO_ERR_ARG;
+    if (splitk_zero(k, stream) != 0) return RPO_ERR_ARG;
     hipLaunchKernelGGL((mlp_bwd_onepass_kernel<128, 256>), dim3(k.Z), dim3(kOnepassThreads), 0, stream, args, k);
     RPO_LAUNCH_CHECK();
     long long blocks = (k.span + RPO_BLOCK / 4 - 1) / (RPO_BLOCK / 4);
@@ -1074,7 +1097,7 @@ static inline int launch_onepass(const BwdArgs& args, const SplitK& k, hipStream
 
 template <int EIN, int H>
 static inline int launch_weights_splitk(const BwdArgs& args, const SplitK& k, int grid_w, hipStream_t stream) {
-    if (hipMemsetAsync(k.scratch, 0, (size_t)k.Z * (size_t)k.stride * sizeof(float), stream) != hipSuccess) return RPO_ERR_ARG;
+    if (splitk_zero(k, stream) != 0) return RPO_ERR_ARG;
     // (grid_w counts the plain pass's blocks: its (H / 16) (EIN / 64) dW0 tiles become (H / 64) (EIN / 64); a narrow first
     // layer becomes E / 16 column blocks per input half)
     const Mlp& net = args.net;

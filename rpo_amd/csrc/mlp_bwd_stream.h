@@ -449,7 +449,7 @@ static inline int launch_bwd_stream(const BwdArgs& args_in, const SplitK& k, hip
     }
     const int cus = rpo_cu_count();
     const bool grads = a.param_grads != 0;
-    if (grads && hipMemsetAsync(k.scratch, 0, (size_t)k.Z * (size_t)k.stride * sizeof(float), stream) != hipSuccess) return RPO_ERR_ARG;
+    if (grads && splitk_zero(k, stream) != 0) return RPO_ERR_ARG;
     const int Z = grads ? k.Z : cus;                             // rows only: nothing is reduced, every CU takes a share
     const dim3 grid(Z), block(kBwdStreamWaves * 64);
     const bool want_da = a.da != nullptr;

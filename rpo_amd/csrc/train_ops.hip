@@ -231,7 +231,7 @@ __global__ __launch_bounds__(RPO_BLOCK) void philox_normal_kernel(int n, float* 
 // defaults of the kernel-variant switches (RPO_TUNE_* order)
 int g_rpo_tune[RPO_TUNE_COUNT] = {/* FWD_STREAM */ 1, /* FWD_STREAM_WAVES */ 16, /* BWD_ONEPASS */ 1, /* GEMM_KSPLIT */ 1,
                                   /* MLP_GEMM */ 1, /* ROLLOUT_WIDE: 2 = by size */ 2, /* BWD_STREAM */ 1,
-                                  /* L1_MFMA */ 1};
+                                  /* L1_MFMA */ 1, /* EVOPF_PLACE */ 0};
 
 extern "C" {
 

@@ -76,3 +76,42 @@ def test_bench_two_ranks_over_gloo_on_one_gpu():
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_gloo_2ranks.json"), "w") as f:
         json.dump(dict(line=r, seconds=time.time() - t0, attempts=attempt + 1), f, indent=1)
+
+
+@pytest.mark.timeout(900, method="thread")
+def test_scale_preflight_over_gloo_on_one_gpu():
+    """tools/scale_preflight.py -- what to run FIRST on a multi-GPU box -- in its control-flow form: two ranks
+    sharing this GPU over gloo, config 4's algorithm at 512 lanes per rank, 64 iterations: one JSON verdict, replicas bit-equal
+    after 64 iterations with graph segments AND with eager launches, the lanes sharded, microseconds per iteration for the
+    plain process and the two-rank run."""
+    import signal
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "scale_preflight.py"), "--gpus", "2", "--backend", "gloo", "--lanes", "512",
+           "--quick"]
+    out = err = ""
+    rc = None
+    for attempt in range(3):                                     # (two processes time-slicing one GPU through gloo: see above)
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, err = p.communicate(timeout=280)
+            rc = p.returncode
+            break
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)
+            out, err = p.communicate()
+    assert rc is not None, "scale_preflight over gloo did not finish within 280 s, three times in a row\n" + err[-3000:]
+    lines = [l for l in out.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out + err[-3000:]
+    v = json.loads(lines[0])
+    assert rc == 0 and v["verdict"] == "ok", json.dumps(v, indent=1)[:4000]
+    assert v["ranks"] == 2 and v["backend"] == "gloo" and v["iterations"] == 64
+    assert v["replicas_bit_equal_after_64_iterations"] is True
+    nr = v["legs"]["n_ranks"]["result"]
+    assert nr["world"] == 2 and nr["lanes_per_rank"] == 512 and nr["data_parallel_path"] and nr["lanes_differ_between_ranks"]
+    assert nr["rccl_ranks"] == 0 and nr["collectives_in_graph"] is False          # gloo: host-driven collectives between segments
+    assert v["legs"]["n_ranks_eager"]["result"]["replicas_bit_equal"] is True
+    assert v["us_per_iteration"]["plain_process"] > 0 and v["us_per_iteration"]["n_ranks"] > 0
+    assert "control-flow form" in v["note"]
+    with open(os.path.join(ROOT, "gpurun_out", "scale_preflight_gloo.json"), "w") as f:
+        json.dump(v, f, indent=1)

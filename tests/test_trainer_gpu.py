@@ -823,3 +823,37 @@ def test_large_batch_mode_is_reproducible_run_to_run(hip):
         torch.cuda.empty_cache()
     assert all(torch.equal(a, b) for a, b in zip(*runs))
     assert float(runs[0][1].abs().max()) > 0.0                  # the multipliers moved: the reduction in question was exercised
+
+
+def test_large_batch_graph_windows_keep_the_padding_floats_zero(hip, monkeypatch):
+    """Round 6, found by the failure flag (tests/test_failure_flag.py): under hipGraph REPLAY the large-batch update was not
+    what the eager launches compute.  The split-K scratch (35 MB at 2^20 rows) was zeroed by `hipMemsetAsync`, which stream
+    capture turns into a memset NODE; replayed, stale partial sums of the previous backward survived in it and were added
+    again -- visible as a gradient-sized value in the three padding floats behind the critic's head bias (which no kernel
+    writes), different from run to run, NaN once in a few thousand updates (the NaN reached an action at update 2060 of a
+    3000-update run: NonFiniteError).  Never with eager launches.  The scratch is now zeroed by a kernel of the library
+    (mlp_bwd.h splitk_zero_kernel; -DRPO_SPLITK_ZERO=0 is the old form, tools/probe/dbg_padding.py the reproducer).
+    Asserted: after 48 iterations through graph windows every padding float of the flat parameter buffer, of its gradient and
+    of both optimisers' moments is exactly zero, and the parameters equal the eager run's bit for bit."""
+    dev = torch.device("cuda")
+    monkeypatch.setenv("RPO_GRAPH_CYCLE", "4")
+    out = {}
+    for use_graph in (False, True):
+        tr = _run("ddpg", "cart", hip, dev, 48, 4096, use_graph=use_graph, batch_size=256 * 4096, capacity=64)
+        fl = tr.agent.flat
+        pad = torch.ones(fl.total, dtype=torch.bool, device=dev)
+        for mod in (tr.agent.actor, tr.agent.critic, tr.agent.nju):
+            for p in mod.parameters():
+                o = fl.offset.get(id(p))
+                if o is not None:
+                    pad[o:o + p.numel()] = False
+        assert int(pad.sum()) >= 3                              # (the critic's one-float head bias is followed by three)
+        assert not bool(fl.data[pad].any()) and not bool(fl.grad[pad].any()), (use_graph, fl.data[pad].tolist())
+        for opt, (lo, hi) in ((tr.agent.critic_optim, fl.critic_range), (tr.agent.actor_optim, fl.actor_range)):
+            assert not bool(opt.exp_avg[pad[lo:hi]].any()) and not bool(opt.exp_avg_sq[pad[lo:hi]].any()), use_graph
+        if use_graph:
+            assert any(e["graph"] is not None for e in tr._graphs.entries.values()) and not tr._graphs.capture_failed
+        out[use_graph] = (fl.data.clone(), tr.agent.nju.weight.detach().clone())
+        del tr
+        torch.cuda.empty_cache()
+    assert torch.equal(out[False][0], out[True][0]) and torch.equal(out[False][1], out[True][1])

@@ -22,7 +22,7 @@ for W in cart_ddpg cart_sac pen_sac pen_ddpg evopf_ddpg evopf_sac; do
   fi
 done
 for C in FETCH_SIZE WRITE_SIZE; do
-  for P in step iter ride; do
+  for P in step step65k iter ride; do
     rm -rf /tmp/q_${C}_$P
     rocprofv3 --pmc $C --kernel-trace -d /tmp/q_${C}_$P -o t -- python3 $ROOT/tools/kernel_probe.py $P > /dev/null 2> $OUT/pmc_${C}_$P.err
     DB=$(ls /tmp/q_${C}_$P/*results.db 2>/dev/null | head -1)
@@ -50,5 +50,6 @@ for G in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_WAIT_ANY 
 done
 cd $ROOT
 python3 tools/pmc_to_json.py $OUT/pmc_traffic.json $OUT/pmc_FETCH_SIZE_step.txt $OUT/pmc_WRITE_SIZE_step.txt \
+    $OUT/pmc_FETCH_SIZE_step65k.txt@65536 $OUT/pmc_WRITE_SIZE_step65k.txt@65536 \
     $OUT/pmc_FETCH_SIZE_iter.txt $OUT/pmc_WRITE_SIZE_iter.txt $OUT/pmc_FETCH_SIZE_ride.txt $OUT/pmc_WRITE_SIZE_ride.txt
 ls -la $OUT

@@ -12,7 +12,7 @@ for w in cart_ddpg cart_sac pen_ddpg pen_sac evopf_ddpg evopf_sac; do
 done
 cp $E/pmc_traffic.json $P/${R}_pmc_traffic.json
 cp $E/pmc_evopf_sq.txt $P/${R}_pmc_evopf_sq.txt
-for c in FETCH_SIZE WRITE_SIZE; do for p in step iter ride; do cp $E/pmc_${c}_$p.txt $P/${R}_pmc_${c}_$p.txt; done; done
+for c in FETCH_SIZE WRITE_SIZE; do for p in step step65k iter ride; do cp $E/pmc_${c}_$p.txt $P/${R}_pmc_${c}_$p.txt; done; done
 cp $E/bench.json $P/${R}_bench.json
 cp $E/bench_steps20.json $P/${R}_bench_steps20.json
 for w in cart_sac pen_ddpg pen_sac evopf_ddpg evopf_sac; do cp $E/bench_line_$w.json $P/${R}_bench_$w.json; done

@@ -13,13 +13,15 @@ os.environ.setdefault("RPO_VERBOSE", "0")
 import torch  # noqa: E402
 
 
-def probe_step(reps=5):
+def probe_step(reps=5, sizes=(4096, 1 << 20)):
     from bench import make_trainer
     from rpo_amd import ops
     from rpo_amd.env.vec import VecEnv
     tr = make_trainer(4096, torch.device("cuda"), 10, capacity=8)
     k = tr.kernels
-    for n in (4096, 1 << 20):
+    scale, base = tr._box_affine
+    for n in sizes:                                             # SURVEY 8d's micro-benchmark sizes; `step65k`: 65 536 alone (round 6: the
+                                                                # streaming rollout launches the same grid at 65 536 and 2^20 lanes)
         v = VecEnv(k, n, torch.device("cuda"), seed=3, stats_cap=64)
         v.reset()
         rows = torch.zeros(8 * n, k.ring_floats, device="cuda")
@@ -31,6 +33,10 @@ def probe_step(reps=5):
             k.step(v.internal, v.obs, v.action, v.ep_len, v.ep_ret, v.ep_count, rows, 8, v.stats, v.ctrl, 200, True, 1e-3,
                    v.seed, 0)
             ops.replay_sample_gather(rows, 8, n, batch, None, 1, 0, v.ctrl)
+            if n >= 65536:                                      # the one-launch rollout in its streaming form (fused.hip, round 6)
+                k.rollout(tr.fused.descs["actor"], False, scale, base, v.internal, None, v.action, v.ep_len, v.ep_ret, v.ep_count,
+                          rows, 8, v.stats, v.ctrl, ops.NOISE_PHILOX, 1.0, 1.0, 0.0, -10.0, 10.0, 10, 2e-2, 1e-5, 0.0, 200, True,
+                          1e-3, v.seed, 0)
         torch.cuda.synchronize()
 
 
@@ -118,4 +124,5 @@ if __name__ == "__main__":
     if what.startswith("window:"):
         probe_window(what.split(":", 1)[1])
     else:
-        {"step": probe_step, "mlp": probe_mlp, "iter": probe_iter, "ride": probe_ride}[what]()
+        {"step": probe_step, "step65k": lambda: probe_step(sizes=(65536,)), "mlp": probe_mlp, "iter": probe_iter,
+         "ride": probe_ride}[what]()

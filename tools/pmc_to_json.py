@@ -3,6 +3,8 @@
 collected in SEPARATE rocprofv3 --pmc passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes).
 
     python tools/pmc_to_json.py out.json fetch1.txt write1.txt [fetch2.txt write2.txt ...]
+A pair written as `fetch.txt@65536 write.txt@65536` forces the units of its LANE kernels (step / act_project / gather / rollout) to
+65536: the streaming rollout launches the same grid at every size, so its size is a fact of the probe, not of the grid.
 
 traffic_bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB: FETCH_SIZE on gfx950 reports half of the bytes of wide coalesced reads
 (guide, HBM section); WRITE_SIZE is used as reported.  Keys: kernel short name -> units per launch (lanes for the env
@@ -13,6 +15,7 @@ import sys
 
 UNITS = [  # (kernel substring, threads per unit or explicit map)
     ("rollout_kernel", lambda g: g // 32),                      # 512 threads per 16 lanes
+    ("rollout_stream_kernel", lambda g: 1 << 20),               # persistent: one workgroup per CU at every size (see @N above)
     ("cartsafe_step_kernel", lambda g: g if g <= 4096 else 1 << 20),
     ("cartsafe_act_project_kernel", lambda g: g if g <= 4096 else 1 << 20),
     ("replay_sample_gather_kernel", lambda g: 256 if g <= 4096 else 1 << 20),
@@ -44,7 +47,10 @@ def main(out_path, files):
         workload, files = files[1], files[2:]
     kernels = {}
     for i in range(0, len(files), 2):
-        fetch, write = parse(files[i]), parse(files[i + 1])
+        forced = None
+        if "@" in files[i]:
+            forced = int(files[i].rsplit("@", 1)[1])
+        fetch, write = parse(files[i].rsplit("@", 1)[0] if forced else files[i]), parse(files[i + 1].rsplit("@", 1)[0] if forced else files[i + 1])
         for (name, grid), (_, fkb, n) in fetch.items():
             if "at::native" in name or "rocclr" in name or (name, grid) not in write:
                 continue
@@ -52,6 +58,8 @@ def main(out_path, files):
             for sub, fn in UNITS:
                 if sub in name:
                     units = fn(grid)
+                    if forced and not sub.startswith("evopf") and sub != "_ride_kernel":
+                        units = forced
             wkb = write[(name, grid)][1]
             if str(units) in kernels.get(short(name), {}):      # earlier files win (cart-DDPG iterations before the cart-SAC ride probe)
                 continue

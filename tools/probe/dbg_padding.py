@@ -1,0 +1,72 @@
+"""Debugging aid (round 6): which launch leaves a non-zero gradient in the PADDING floats of the flat parameter buffer?"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ.setdefault("RPO_VERBOSE", "0")
+import torch  # noqa: E402
+import bench  # noqa: E402
+from rpo_amd import ops  # noqa: E402
+
+dev = torch.device("cuda")
+n = 4096
+for use_graph in (False, True):
+    tr = bench.make_trainer(n, dev, 3000, capacity=64, workload="cart_ddpg", torch_seed=123, seed=7000, batch_size=256 * n,
+                            use_graph=use_graph)
+    tr.vec.reset()
+    fl = tr.agent.flat
+    pad = torch.ones(fl.total, dtype=torch.bool, device=dev)
+    for mod in (tr.agent.actor, tr.agent.critic, tr.agent.nju):
+        for p_ in mod.parameters():
+            o = fl.offset.get(id(p_))
+            if o is not None:
+                pad[o:o + p_.numel()] = False
+    pad_idx = torch.nonzero(pad).view(-1)
+    # wrap the backward entry point: padding of the gradient right after every call
+    orig = ops.mlp_backward
+
+    def wrapped(*a, **kw):
+        r = orig(*a, **kw)
+        if not torch.cuda.is_current_stream_capturing():
+            g = fl.grad[pad_idx]
+            if bool((g != 0).any()):
+                print("   after mlp_backward(n=%d, param_grads=%s, da=%s, state_only=%s): grad padding" % (
+                    a[1].shape[0], kw.get("param_grads", True), kw.get("da") is not None, kw.get("first_layer_state_only", False)),
+                    [(int(i), float(x)) for i, x in zip(pad_idx.tolist(), g.tolist()) if x != 0], flush=True)
+            for name, d in tr.fused.descs.items():
+                if getattr(d, "splitk", None) is not None:
+                    pass
+        return r
+    ops.mlp_backward = wrapped
+    first = None
+    for it in range(48):
+        tr.run_steps(1)
+        torch.cuda.synchronize()
+        if first is None and os.environ.get("DBG_INSPECT", "0") == "1":
+            for name, d in tr.fused.descs.items():
+                sk = getattr(d, "splitk", None)
+                if sk is None:
+                    continue
+                grads = [t.grad for t in d.tensors.values() if t is not None and t.grad is not None]
+                lo = min(g.data_ptr() for g in grads)
+                hi = max(g.data_ptr() + 4 * g.numel() for g in grads)
+                span = (hi - lo) // 4
+                stride = (span + 3) // 4 * 4
+                Z = sk.numel() // stride
+                view = sk[:Z * stride].view(Z, stride)
+                base_idx = (lo - fl.grad.data_ptr()) // 4
+                cols = [int(i) - base_idx for i in pad_idx.tolist() if base_idx <= int(i) < base_idx + span]
+                if cols:
+                    sub = view[:, cols]
+                    nz = torch.nonzero(sub)
+                    if nz.numel():
+                        print("   it %d: scratch of %s (Z=%d, span=%d, base %d): non-zero PADDING entries at (slice, flat index):" % (it, name, Z, span, base_idx),
+                              [(int(a), cols[int(b)] + base_idx, float(sub[a, b])) for a, b in nz[:8].tolist()], flush=True)
+        v = fl.data[pad_idx]
+        if bool((v != 0).any()) and first is None:
+            first = it
+            print("use_graph=%s: padding of the PARAMETERS non-zero after iteration %d:" % (use_graph, it),
+                  [(int(i), float(x)) for i, x in zip(pad_idx.tolist(), v.tolist()) if x != 0], flush=True)
+    print("use_graph=%s: first non-zero padding at iteration %s" % (use_graph, first), flush=True)
+    ops.mlp_backward = orig
+    del tr
+    torch.cuda.empty_cache()
