@@ -385,7 +385,7 @@ def streaming_clinic(tr, sizes=((1 << 20, "1M"), (65536, "64K"))):
         out["rollout_kernel<CartEnv>@" + tag] = dict(
             n=big_n, us=us, bound="mfma", work=fl * big_n, rate=fl * big_n / us * 1e-6, unit="TFLOP/s", peak=MFMA_F32_PEAK_TFLOPS,
             frac=fl * big_n / us * 1e-6 / MFMA_F32_PEAK_TFLOPS, env_steps_per_s=big_n / us * 1e6,
-            kernel="rollout_stream_kernel<CartEnv, 1> (fused.hip: weights stationary in LDS, the env step as the epilogue)"
+            kernel="rollout_stream_kernel<CartEnv, 1> (rollout_stream.hip: weights stationary in LDS, the env step as the epilogue)"
             if big_n >= 65536 else "rollout_kernel<CartEnv, 128, 256, 4>")
         del big, rows, big_batch, big_ap
         torch.cuda.empty_cache()

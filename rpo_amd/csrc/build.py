@@ -13,7 +13,10 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["cartsafe.hip", "pendulum.hip", "evopf.hip", "replay.hip", "train_ops.hip", "mlp.hip", "fused.hip", "nsplit.hip"]
+SOURCES = ["cartsafe.hip", "pendulum.hip", "evopf.hip", "replay.hip", "train_ops.hip", "mlp.hip", "fused.hip", "nsplit.hip",
+           "rollout_stream.hip"]
+# per-file flags: the streaming rollout is compiled without SLP vectorisation (see the header of rollout_stream.hip)
+FILE_FLAGS = {"rollout_stream.hip": ["-fno-slp-vectorize"]}
 HEADERS = sorted(f for f in os.listdir(HERE) if f.endswith(".h")) + [os.path.join("..", "..", "include", "rpo_hip.h")]   # (every header: a stale object is worse than a rebuild)
 TARGET = os.path.join(HERE, "librpo_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -52,7 +55,7 @@ def build(force=False, verbose=True, asan=False):
         o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmds.append([HIPCC] + flags + ["-c", s, "-o", o])
+            cmds.append([HIPCC] + flags + FILE_FLAGS.get(src, []) + ["-c", s, "-o", o])
     if cmds:                                                    # translation units are independent: RPO_BUILD_JOBS at a time (4)
         from concurrent.futures import ThreadPoolExecutor
 

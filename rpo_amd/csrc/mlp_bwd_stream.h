@@ -46,7 +46,7 @@ __device__ __forceinline__ float bwd_xlane(float v, int src_lane) {
 
 // TD target + Huber loss of every row (the prologue of the rows passes, as a launch of its own in front of the two kernels):
 // dq_out[i] and the 16-row tiles' loss shares, the same functions and the same order as td prologue of mlp_bwd_rows_body.
-__global__ __launch_bounds__(256) void bwd_stream_td_kernel(TdArgs t, int n) {
+static __global__ __launch_bounds__(256) void bwd_stream_td_kernel(TdArgs t, int n) {   // (static: not a symbol of the shared library)
     const int i = blockIdx.x * 256 + threadIdx.x;
     float dq = 0.0f, hub = 0.0f;
     if (i < n) {

@@ -31,6 +31,8 @@ def test_library_exports_every_declared_symbol():
     syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIBRARY], capture_output=True, text=True).stdout
     exported = {line.split()[-1] for line in syms.splitlines() if " T " in line}
     assert set(_lib.PROTOTYPES) <= exported
+    # ... and nothing else: the dynamic symbol table IS the header (internal cross-unit functions are visibility("hidden"))
+    assert exported == set(_lib.PROTOTYPES), sorted(exported - set(_lib.PROTOTYPES))
 
 
 def test_argument_validation_without_gpu():

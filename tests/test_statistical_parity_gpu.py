@@ -108,7 +108,9 @@ def test_evopf_training_statistics_match_reference(golden, algo):
     rows, outliers, drift_converged = [], [], []
     from oracle import evopf as oe                               # (test infrastructure: the checker of the outlier steps)
     os.environ["RPO_VERBOSE"] = "0"
-    for seed in range(2 * len(ref)):
+    # GPU seeds: twice the reference's while that pin was thin (24 reference seeds until round 5), as many as the reference's
+    # since it has 96 (round 6, VERDICT r05 next 7: SE of the difference 0.25 -> 0.14 of the seed-to-seed spread)
+    for seed in range(2 * len(ref) if len(ref) < 96 else len(ref)):
         torch.manual_seed(123 + seed)
         tr = cls(EVOPFEnv(device="cuda"), "/tmp/rpo_test", name="t", logger=None, max_epochs=steps, capacity=20000,
                  device=torch.device("cuda"), num_envs=1, seed=1000 + seed, **hp)

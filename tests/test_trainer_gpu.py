@@ -436,7 +436,7 @@ def test_wide_rollout_tiles_are_bitwise_identical(hip, monkeypatch):
 @pytest.mark.parametrize("sel,n_envs", [(3, 1000), (3, 16 * 16 * 256 * 2 + 37)], ids=["one_workgroup_per_cu_not_full", "several_tiles_per_wave"])
 @pytest.mark.parametrize("algo,envname", CASES)
 def test_streaming_rollout_equals_the_row_tile_rollout(hip, algo, envname, sel, n_envs):
-    """The streaming form of the one-launch rollout (fused.hip rollout_stream_kernel: the actor's hidden matrix stationary in
+    """The streaming form of the one-launch rollout (rollout_stream.hip: the actor's hidden matrix stationary in
     LDS, one wave per 16-lane tile, both layers transposed on the matrix cores, the env step as the epilogue; default from
     65 536 lanes) against the 16-lane row tiles: the same per-lane functions behind a forward that is the row-tile forward to
     the bit -- states, actions, ring rows (incl. the zeroed padding of CartSafe's 128-byte ring lines, which the row tiles

@@ -33,7 +33,7 @@ def probe_step(reps=5, sizes=(4096, 1 << 20)):
             k.step(v.internal, v.obs, v.action, v.ep_len, v.ep_ret, v.ep_count, rows, 8, v.stats, v.ctrl, 200, True, 1e-3,
                    v.seed, 0)
             ops.replay_sample_gather(rows, 8, n, batch, None, 1, 0, v.ctrl)
-            if n >= 65536:                                      # the one-launch rollout in its streaming form (fused.hip, round 6)
+            if n >= 65536:                                      # the one-launch rollout in its streaming form (rollout_stream.hip, round 6)
                 k.rollout(tr.fused.descs["actor"], False, scale, base, v.internal, None, v.action, v.ep_len, v.ep_ret, v.ep_count,
                           rows, 8, v.stats, v.ctrl, ops.NOISE_PHILOX, 1.0, 1.0, 0.0, -10.0, 10.0, 10, 2e-2, 1e-5, 0.0, 200, True,
                           1e-3, v.seed, 0)
