@@ -4,7 +4,7 @@
 #   windows, and HBM traffic counters (FETCH_SIZE / WRITE_SIZE in separate passes) of eager iterations.
 # Everything lands in gpurun_out/prof_rNN/ as text; copy what is to be judged into profiles/.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 OUT=$PWD/gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp RPO_VERBOSE=0

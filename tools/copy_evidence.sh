@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy what is to be judged from gpurun_out/evidence_rNN/ (tools/collect_evidence.sh) into profiles/ under round-prefixed names.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 E=gpurun_out/evidence_$R
 P=profiles
 for w in cart_ddpg cart_sac pen_ddpg pen_sac evopf_ddpg evopf_sac; do
@@ -28,4 +28,10 @@ cp $E/large_batch_cart_ddpg_kernel_stats.txt $P/${R}_large_batch_cart_ddpg_kerne
 cp $E/pmc_mlp_large.txt $P/${R}_pmc_mlp_large.txt
 cp $E/mlp_large_kernel_stats.txt $P/${R}_mlp_large_kernel_stats.txt
 for f in probe_branch probe_branch3 probe_gemm_launch probe_evopf_period; do cp $E/$f.txt $P/${R}_$f.txt; done
+ls $P | grep -c "^$R"
+# round 6
+cp $E/probe_lanes.txt $P/${R}_probe_lanes.txt
+cp $E/scale_preflight_gloo.json $P/${R}_scale_preflight_gloo.json
+cp $E/pmc_rollout_stream.txt $P/${R}_pmc_rollout_stream.txt
+cp $E/rollout_stream_kernel_stats.txt $P/${R}_rollout_stream_kernel_stats.txt
 ls $P | grep -c "^$R"
