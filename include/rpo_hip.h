@@ -166,7 +166,7 @@ int rpo_abi_version(void);
 #define RPO_TUNE_GEMM_KSPLIT 3      /* 1: K >= 256 layer launches split k over the four waves of a workgroup; 0: one chain */
 #define RPO_TUNE_MLP_GEMM 4         /* 1: 256-wide networks layer by layer (mlp_gemm.h); 0: row-tile kernels */
 #define RPO_TUNE_ROLLOUT_WIDE 5     /* fused rollout: 0 16-lane tiles, 1 64-lane tiles, 3 the streaming form (weights stationary in LDS,
-                                      rollout_stream.hip), 2 (default) by lane count: 16-lane tiles below 12 288 lanes,
+                                      rollout_stream.hip; 4: the same with 64-lane groups forced, its form from 2^18 lanes), 2 (default) by lane count: 16-lane tiles below 12 288 lanes,
                                       64-lane tiles below RPO_ROLLOUT_STREAM_FROM, streaming from there */
 #define RPO_ROLLOUT_STREAM_FROM 65536
 #define RPO_TUNE_BWD_STREAM 6       /* 1: large-batch backward as the two streaming launches of mlp_bwd_stream.h (rows kernel with W0

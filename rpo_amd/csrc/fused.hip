@@ -124,7 +124,7 @@ int launch_rollout(const RolloutArgs<ENV>& args, const typename ENV::Consts& c, 
     // 16-lane tiles below 64 x 192 lanes, 64-lane tiles up to RPO_ROLLOUT_STREAM_FROM, the streaming form from there
     {
         const int sel = rpo_tune(RPO_TUNE_ROLLOUT_WIDE);
-        if (sel == 3 || (sel == 2 && n_envs >= RPO_ROLLOUT_STREAM_FROM)) {
+        if (sel == 3 || sel == 4 || (sel == 2 && n_envs >= RPO_ROLLOUT_STREAM_FROM)) {   // (4: 64-lane groups forced, tests)
             const int e = rpo_rollout_stream_launch(std::is_same<ENV, CartEnv>::value ? 0 : 1, &args, &c, n_envs, stream);
             if (e >= 0) return e;                                // (-1: the streaming form does not apply to this network / env)
         }

@@ -195,13 +195,19 @@ int launch_stream(const void* args_v, const void* consts_v, int n_envs, void* st
     const RolloutArgs<ENV>& args = *static_cast<const RolloutArgs<ENV>*>(args_v);
     const typename ENV::Consts& c = *static_cast<const typename ENV::Consts*>(consts_v);
     if (!rollout_stream_ok<ENV>(args)) return -1;
-    // (G = 4 -- 64-lane groups, every lane of the wave busy in the per-lane phase -- measured the SAME 563 us at 2^20 lanes
-    //  and 147 us instead of 52 at 65 536, where it leaves three waves in four without a tile: the per-lane phase is
-    //  not what bounds the launch.  One form.)
-    const int groups = (n_envs + kRows - 1) / kRows;
+    // G = 4 (64-lane groups: every lane of the wave busy in the per-lane phase) once every wave of the chip gets a group; G = 1
+    // below.  Timing-only builds at 2^20 lanes (RPO_RSTREAM_SKIP, one box): MLP alone 507 us, per-lane phase alone 114 us (G = 1) /
+    // 60 us (G = 4), together 627 / 557 us -- the per-lane phase's vector instructions ADD to the MFMA time (f32 MFMA shares the
+    // vector lanes), so issuing them for 64 instead of 16 lanes is worth 11 %.  At 65 536 lanes G = 4 leaves three waves in four
+    // without a tile (147 us instead of 52).  rpo_tuning(RPO_TUNE_ROLLOUT_WIDE): 3 forces the streaming form with this size
+    // rule, 4 with G = 4 (tests).
+    const int sel = rpo_tune(RPO_TUNE_ROLLOUT_WIDE);
+    const bool g4 = sel == 4 || n_envs >= 4 * kRows * kRolloutStreamWaves * rollout_stream_cus();
+    const int groups = (n_envs + (g4 ? 4 : 1) * kRows - 1) / ((g4 ? 4 : 1) * kRows);
     int gx = (groups + kRolloutStreamWaves - 1) / kRolloutStreamWaves;
     if (gx > rollout_stream_cus()) gx = rollout_stream_cus();
-    hipLaunchKernelGGL((rollout_stream_kernel<ENV, 1>), dim3(gx), dim3(kRolloutStreamWaves * 64), 0, (hipStream_t)stream, args, c);
+    if (g4) hipLaunchKernelGGL((rollout_stream_kernel<ENV, 4>), dim3(gx), dim3(kRolloutStreamWaves * 64), 0, (hipStream_t)stream, args, c);
+    else hipLaunchKernelGGL((rollout_stream_kernel<ENV, 1>), dim3(gx), dim3(kRolloutStreamWaves * 64), 0, (hipStream_t)stream, args, c);
     RPO_LAUNCH_CHECK();
     return 0;
 }

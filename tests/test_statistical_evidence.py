@@ -20,9 +20,49 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROFILES = os.path.join(ROOT, "profiles")
 
 
+def _provenance(stamp, what):
+    """committed rows say which kernels produced them (tools/provenance.py).  Rows of another ABI version are STALE:
+    fail (regenerate: tools/collect_statistics.sh).  Rows of this ABI whose kernel-source hash differs from the tree's were
+    measured before a later kernel edit: the numbers below are still asserted, with a warning that names the regeneration job."""
+    import sys
+    import warnings
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import provenance
+    if stamp.get("abi") is None:
+        return                                                  # (round-5 files carry no stamp; they were produced at ABI 5)
+    assert int(stamp["abi"]) == provenance.abi_version(), "%s was produced at ABI %s, the tree is ABI %d: regenerate with " \
+        "tools/collect_statistics.sh" % (what, stamp["abi"], provenance.abi_version())
+    if str(stamp.get("csrc_sha16")) != provenance.csrc_sha16():
+        warnings.warn("%s was produced by kernel sources %s, the tree is %s: regenerate with tools/collect_statistics.sh before "
+                      "quoting it for this tree" % (what, stamp.get("csrc_sha16"), provenance.csrc_sha16()))
+
+
+def _rows(algo, envname):
+    """The newest committed per-seed rows of (algo, env): round 6's (stamped with ABI + source hash) where they exist."""
+    for r in ("r06", "r05"):
+        path = os.path.join(PROFILES, "%s_stat_rows_%s_%s.npz" % (r, algo, envname))
+        if os.path.exists(path):
+            z = np.load(path)
+            _provenance({"abi": int(z["abi"]) if "abi" in z.files else None,
+                         "csrc_sha16": str(z["csrc_sha16"]) if "csrc_sha16" in z.files else None}, os.path.basename(path))
+            return z["stats"]
+    raise AssertionError("no committed rows for %s %s" % (algo, envname))
+
+
+def _cadence(name):
+    for r in ("r06", "r05"):
+        path = os.path.join(PROFILES, "%s_%s.json" % (r, name))
+        if os.path.exists(path):
+            with open(path) as f:
+                res = json.load(f)
+            _provenance(res, os.path.basename(path))
+            return res
+    raise AssertionError("no committed " + name)
+
+
 def _compare(algo, envname):
     ref = np.load(os.path.join(ROOT, "tests", "golden", "training_stats_%s_%s.npz" % (algo, envname)))["stats"]
-    got = np.load(os.path.join(PROFILES, "r05_stat_rows_%s_%s.npz" % (algo, envname)))["stats"]
+    got = _rows(algo, envname)
     se = np.sqrt(ref.var(0, ddof=1) / len(ref) + got.var(0, ddof=1) / len(got))
     d = got.mean(0) - ref.mean(0)
     return ref, got, d, se
@@ -68,8 +108,7 @@ def test_vectorised_cadences_at_128_and_32_seeds():
     both: violation rate 1.10e-2 +- 0.06e-2 vs 1.33e-2 +- 0.02e-2 (-2.2e-3, z = -3.5), return 33.4 +- 1.6 vs 28.9 +- 0.35.  The lane
     sweep below shows where that comes from.  Asserted: the resolution, and that the vectorised cadences are not WORSE than the
     reference (violations, 2 SE) and not below it in return (2 SE + 10 % / 25 %)."""
-    with open(os.path.join(PROFILES, "r05_cadence_learning.json")) as f:
-        res = json.load(f)
+    res = _cadence("cadence_learning")
     ref = np.load(os.path.join(ROOT, "tests", "golden", "training_stats_ddpg_cart.npz"))["stats"]
     modes = {m["mode"]: m for m in res["modes"]}
     a, b = modes["reference_cadence"], modes["large_batch"]
@@ -92,8 +131,7 @@ def test_lane_sweep_locates_the_shift_of_the_vectorised_cadence():
     lanes and does not grow to 4096 -- it comes with the FIRST independent histories a batch can draw from (the reference fills
     its replay buffer with one correlated trajectory: for the first 256 steps a batch of 256 resamples fewer than 256 distinct
     transitions; 97 % of a run's violations fall into its first 250 steps), not with the kernels and not with the lane count."""
-    with open(os.path.join(PROFILES, "r05_cadence_lanes.json")) as f:
-        res = json.load(f)
+    res = _cadence("cadence_lanes")
     rows = {m["lanes"]: m for m in res["sweep"]}
     assert set(rows) >= {1, 16, 256}
     one = rows[1]["z_vs_reference"]

@@ -433,7 +433,8 @@ def test_wide_rollout_tiles_are_bitwise_identical(hip, monkeypatch):
         assert torch.equal(out_w[:4096], out_n), kw
 
 
-@pytest.mark.parametrize("sel,n_envs", [(3, 1000), (3, 16 * 16 * 256 * 2 + 37)], ids=["one_workgroup_per_cu_not_full", "several_tiles_per_wave"])
+@pytest.mark.parametrize("sel,n_envs", [(3, 1000), (3, 16 * 16 * 256 * 2 + 37), (4, 1000), (4, 64 * 16 * 256 + 16 * 3 + 5)],
+                         ids=["16_lane_groups", "several_tiles_per_wave", "64_lane_groups", "64_lane_groups_ragged_second_pass"])
 @pytest.mark.parametrize("algo,envname", CASES)
 def test_streaming_rollout_equals_the_row_tile_rollout(hip, algo, envname, sel, n_envs):
     """The streaming form of the one-launch rollout (rollout_stream.hip: the actor's hidden matrix stationary in

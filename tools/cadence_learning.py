@@ -27,6 +27,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 os.environ.setdefault("RPO_VERBOSE", "0")
 import bench  # noqa: E402
 
@@ -122,8 +123,9 @@ def sweep(lane_counts, seeds, steps, device):
                                for k in ("viol_rate", "mean_max_ineq", "mean_return_per_step", "mean_return_second_half") if k in ref["mean"]}
         rows.append(m)
         print(n, json.dumps(m["mean"]), json.dumps(m["z_vs_reference"]), flush=True)
+    import provenance
     with open(os.path.join(ROOT, "gpurun_out", "cadence_lanes.json"), "w") as f:
-        json.dump(dict(reference=ref, sweep=rows), f, indent=1)
+        json.dump(dict(reference=ref, sweep=rows, **provenance.stamp()), f, indent=1)
 
 
 def main():
@@ -136,8 +138,10 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
     seeds_lb = int(sys.argv[3]) if len(sys.argv) > 3 else max(1, seeds // 4)
     device = torch.device("cuda")
+    import provenance
     res = dict(reference=reference_row(), modes=[run_mode(m, n, steps, device)
-                                                 for m, n in (("reference_cadence", seeds), ("large_batch", seeds_lb)) if n > 0])
+                                                 for m, n in (("reference_cadence", seeds), ("large_batch", seeds_lb)) if n > 0],
+               **provenance.stamp())
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "cadence_learning.json"), "w") as f:
         json.dump(res, f, indent=1)

@@ -37,7 +37,7 @@ for n in sizes:
                   big.ep_len, big.ep_ret, big.ep_count, rows, cap, big.stats, big.ctrl, noise, tr.eps_start, tr.eps, tr.decay_value,
                   tr._box_lo, tr._box_hi, tr.max_steps, tr.corr_lr, tr.corr_eps, tr.corr_momentum, 200, True, 1e-3, big.seed,
                   big.env_id_base)
-    for sel, label in ((1, "64-lane row tiles"), (3, "streaming form"), (2, "size rule")):
+    for sel, label in ((1, "64-lane row tiles"), (3, "streaming form"), (4, "streaming, 64-lane groups forced"), (2, "size rule")):
         with ops.tuning(rollout_wide=sel):
             us = bench.time_kernel(launch, reps=10 if n > 200000 else 40)[0]
         tf = fl * n / us * 1e-6

@@ -70,11 +70,15 @@ def main():
     got = gpu_rows(algo, envname, seeds, steps)
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import provenance
+    st = provenance.stamp()
     np.savez_compressed(os.path.join(out_dir, "stat_rows_%s_%s.npz" % (algo, envname)), stats=got, steps=steps,
-                        columns=np.array(COLUMNS), torch_seed_base=123, philox_seed_base=5000)
+                        columns=np.array(COLUMNS), torch_seed_base=123, philox_seed_base=5000, abi=st["abi"],
+                        csrc_sha16=np.array(st["csrc_sha16"]))
     ref = np.load(os.path.join(ROOT, "tests", "golden", "training_stats_%s_%s.npz" % (algo, envname)))["stats"]
     res = compare(ref, got)
-    res.update(steps=steps, seconds=time.time() - t0)
+    res.update(steps=steps, seconds=time.time() - t0, **st)
     with open(os.path.join(out_dir, "stat_rows_%s_%s.json" % (algo, envname)), "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps({k: res[k] for k in ("ref_seeds", "gpu_seeds", "gpu_minus_ref", "se_of_difference", "z", "seconds")}))
