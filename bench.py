@@ -850,8 +850,8 @@ def main():
         # first `constraint_violation_window` of THIS run, in which the policy receives one update per VECTOR step (1 / 4096 of
         # the reference's learning per env step) -- it mostly measures how early in training the window sits.  The figure that
         # is comparable with the reference's 3000-step single-env runs is constraint_violation_rate_n1 below (1536 + 1536 seeds
-        # in profiles/r05_stat_rows_ddpg_cart.*: +0.12e-3 +- 0.27e-3); at matched UPDATES the vectorised cadence violates 2.2e-3
-        # LESS than the reference (profiles/r05_cadence_learning.json).
+        # in profiles/r06_stat_rows_ddpg_cart.*: +0.12e-3 +- 0.27e-3); at matched UPDATES the vectorised cadence violates 2.2e-3
+        # LESS than the reference (profiles/r06_cadence_learning.json).
         **({"control_flow_check": "gloo%s: control-flow check of the N > 1 path, NOT a scaling figure (the measured "
                                   "configuration is one rank per GPU over RCCL)" % (", %d ranks time-slicing %d GPU(s)" % (
                                       world, torch.cuda.device_count()) if shared_gpu else "")}
@@ -946,13 +946,14 @@ def main():
                     "note": "one batch-%d update per vector step: 256 sampled transitions per env step like the reference, one "
                             "optimiser step per vector step (not %d)" % (256 * EPG, EPG),
                     # tools/cadence_learning.py, 32 (large batch) / 128 (batch 256) seeds x 3000 updates vs the reference's 1536 runs
-                    # (profiles/r05_cadence_learning.json, tests/test_statistical_evidence.py)
-                    "learning_at_matched_updates": "THROUGHPUT FIGURE of another optimiser regime, not the reference's learning "
-                            "curve: at 3000 updates it reaches return 24.9 +- 1.2 (second half 29.6 +- 1.6) where the reference "
-                            "reaches 28.9 +- 0.35 (35.5 +- 0.5), with a LOWER violation rate (0.67e-2 +- 0.08e-2 vs 1.33e-2); the "
-                            "batch-256 cadence of the headline is BETTER than the reference on both at matched updates (33.4 +- 1.6 "
-                            "/ 42.6 +- 2.3, 1.10e-2 +- 0.06e-2: sampling from 4096 independent histories; one lane reproduces the "
-                            "reference, DESIGN.md 5 round 5)"}
+                    # (profiles/r06_cadence_learning.json, tests/test_statistical_evidence.py; round 5's figures for this mode were
+                    # collected with the hipGraph memset-node bug of DESIGN.md 4.5 and read 24.9 / 29.6)
+                    "learning_at_matched_updates": "another optimiser regime (one step per vector step): at 3000 updates it reaches "
+                            "return 27.4 +- 2.0 (second half 34.6 +- 3.1) where the reference reaches 28.9 +- 0.35 (35.5 +- 0.5) -- not "
+                            "distinguishable at 32 seeds -- with HALF the violation rate (0.66e-2 +- 0.08e-2 vs 1.33e-2); the batch-256 "
+                            "cadence of the headline is better than the reference on both at matched updates (33.4 +- 1.6 / 42.6 +- 2.3, "
+                            "1.10e-2 +- 0.06e-2: sampling from 4096 independent histories; one lane reproduces the reference, "
+                            "DESIGN.md 5)"}
                 if not args.no_clinic:
                     log("kernel clinic of the large-batch update:")
                     cl = kernel_clinic(lb, args.workload)

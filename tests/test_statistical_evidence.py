@@ -102,12 +102,12 @@ def test_other_workloads_match_the_reference(algo, envname, se_max):
 def test_vectorised_cadences_at_128_and_32_seeds():
     """cart-RPODDPG at 4096 lanes to the reference's budget of UPDATES (3000): (a) one batch-256 update per vector step (the
     headline's cadence), 128 seeds; (b) one batch-2^20 update per vector step (`large_batch`), 32 seeds
-    (profiles/r05_cadence_learning.json, tools/cadence_learning.py).  Round 4's 8 + 8 seeds (SE 1.8e-3) could not see 1e-3.
+    (profiles/r06_cadence_learning.json -- r05_* before the kernels of ABI 6 --, tools/cadence_learning.py).  Round 4's 8 + 8 seeds (SE 1.8e-3) could not see 1e-3.
 
     What 128 seeds show: the vectorised cadence does NOT reproduce the reference's numbers at matched updates -- it is BETTER on
     both: violation rate 1.10e-2 +- 0.06e-2 vs 1.33e-2 +- 0.02e-2 (-2.2e-3, z = -3.5), return 33.4 +- 1.6 vs 28.9 +- 0.35.  The lane
     sweep below shows where that comes from.  Asserted: the resolution, and that the vectorised cadences are not WORSE than the
-    reference (violations, 2 SE) and not below it in return (2 SE + 10 % / 25 %)."""
+    reference (violations, 2 SE) and not below it in return (2 SE + 10 %)."""
     res = _cadence("cadence_learning")
     ref = np.load(os.path.join(ROOT, "tests", "golden", "training_stats_ddpg_cart.npz"))["stats"]
     modes = {m["mode"]: m for m in res["modes"]}
@@ -117,7 +117,7 @@ def test_vectorised_cadences_at_128_and_32_seeds():
     def se(m, key, col):
         return float(np.sqrt(ref[:, col].var(ddof=1) / len(ref) + m["se"][key] ** 2))
     assert a["se"]["viol_rate"] <= 8e-4 and b["se"]["viol_rate"] <= 1.2e-3          # (round 4: 1.8e-3 / 1.2e-3 on 8 seeds)
-    for m, slack in ((a, 0.10), (b, 0.25)):
+    for m, slack in ((a, 0.10), (b, 0.10)):       # (the large batch needed 25 % until the memset-node bug of DESIGN 4.5 was fixed)
         assert m["mean"]["viol_rate"] - ref[:, 1].mean() <= 2 * se(m, "viol_rate", 1)
         assert abs(m["mean"]["device_viol_rate"] - m["mean"]["viol_rate"]) < 1e-3
         for key, col in (("mean_return_per_step", 4), ("mean_return_second_half", 5)):
@@ -126,7 +126,7 @@ def test_vectorised_cadences_at_128_and_32_seeds():
 
 
 def test_lane_sweep_locates_the_shift_of_the_vectorised_cadence():
-    """Reference cadence at 1, 16 and 256 lanes, 128 seeds each (profiles/r05_cadence_lanes.json): one lane reproduces the
+    """Reference cadence at 1, 16 and 256 lanes, 128 seeds each (profiles/r06_cadence_lanes.json): one lane reproduces the
     reference (every |z| < 2.5: it IS the reference's algorithm step for step); the shift of the statistics is complete at 16
     lanes and does not grow to 4096 -- it comes with the FIRST independent histories a batch can draw from (the reference fills
     its replay buffer with one correlated trajectory: for the first 256 steps a batch of 256 resamples fewer than 256 distinct
