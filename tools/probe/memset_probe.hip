@@ -10,13 +10,19 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 
+__device__ void spin(long long cycles) {                        // (long-running kernels, like the 500 us backward launches)
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(8);
+}
 __global__ void write_some(float* scratch, long long stride, int Z, long long span, int salt) {
+    spin(20000);                                                 // 100 MHz clock: 200 us
     // slice z writes every position except those with (i % 97) == 3 (the "padding" no kernel writes)
     const int z = blockIdx.y;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < span; i += (long long)gridDim.x * blockDim.x)
         if (i % 97 != 3) scratch[z * stride + i] = 1.0f + (float)((i + salt) & 7);
 }
 __global__ void reduce(const float* scratch, long long stride, int Z, long long span, float* out) {
+    spin(20000);
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < span; i += (long long)gridDim.x * blockDim.x) {
         float s = 0.0f;
         for (int z = 0; z < Z; ++z) s += scratch[z * stride + i];
@@ -48,7 +54,7 @@ int run(bool graph, bool memset_node, int replays) {
     };
     if (graph) {
         hipGraph_t g; hipGraphExec_t ge;
-        CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+        CK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));   // (torch captures in relaxed / thread-local mode)
         body();
         CK(hipStreamEndCapture(s, &g));
         CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
