@@ -113,5 +113,6 @@ def test_scale_preflight_over_gloo_on_one_gpu():
     assert v["legs"]["n_ranks_eager"]["result"]["replicas_bit_equal"] is True
     assert v["us_per_iteration"]["plain_process"] > 0 and v["us_per_iteration"]["n_ranks"] > 0
     assert "control-flow form" in v["note"]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "scale_preflight_gloo.json"), "w") as f:
         json.dump(v, f, indent=1)

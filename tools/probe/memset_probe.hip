@@ -2,7 +2,8 @@
 // what the eager call zeroes?  Pattern of the large-batch backward: [memset scratch] -> [kernel A: every slice writes SOME
 // positions of its copy] -> [kernel R: sums the copies into out where the sum is non-zero], twice per graph (two backwards share
 // the scratch), replayed back to back.  A position that no kernel writes must stay zero in `out`.
-//   hipcc --offload-arch=gfx950 -O2 -o tools/probe/memset_probe tools/probe/memset_probe.hip && tools/probe/memset_probe
+//   hipcc --offload-arch=gfx950 -O2 -o tools/probe/memset_probe tools/probe/memset_probe.hip && tools/probe/memset_probe      (ROCm's runtime)
+//   python tools/probe/memset_probe.py   (the same code inside a Python process bound to the HIP runtime PyTorch bundles)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -44,8 +45,15 @@ int run(bool graph, bool memset_node, int replays) {
     CK(hipMemset(out, 0, sizeof(float) * span));
     hipStream_t s;
     CK(hipStreamCreate(&s));
+    // a SECOND kind of memset in the same graph (another destination, another size, another value): if the nodes' arguments
+    // were mixed up at replay, `scratch` would show this pattern, or `other` zeros
+    unsigned char* other;
+    const size_t other_bytes = 3 * 1000 * 1000 + 13;
+    CK(hipMalloc(&other, other_bytes));
+    CK(hipMemset(other, 0, other_bytes));
     auto body = [&]() {
         for (int pass = 0; pass < 2; ++pass) {
+            if (memset_node) CK(hipMemsetAsync(other, 0x7f - pass, other_bytes, s));
             if (memset_node) CK(hipMemsetAsync(scratch, 0, sizeof(float) * Z * stride, s));
             else hipLaunchKernelGGL(zero_kernel, dim3(2048), dim3(256), 0, s, (float4*)scratch, (long long)Z * stride / 4);
             hipLaunchKernelGGL(write_some, dim3(64, Z), dim3(256), 0, s, scratch, stride, Z, span, pass);
@@ -73,13 +81,21 @@ int run(bool graph, bool memset_node, int replays) {
             if (h[i] != (float)want) expect_err += 1;
         }
     }
+    if (memset_node) {
+        std::vector<unsigned char> ho(other_bytes);
+        CK(hipMemcpy(ho.data(), other, other_bytes, hipMemcpyDeviceToHost));
+        long long wrong = 0;
+        for (size_t i = 0; i < other_bytes; ++i) wrong += ho[i] != 0x7e;
+        if (wrong) { printf("   second memset's buffer: %lld of %zu bytes are not its last pattern\n", wrong, other_bytes); ++bad; }
+    }
+    CK(hipFree(other));
     printf("%-6s %-12s %3d replays: %d never-written positions non-zero, %g written positions off\n", graph ? "graph" : "eager",
            memset_node ? "memset" : "zero kernel", replays, bad, expect_err);
     CK(hipFree(scratch)); CK(hipFree(out));
     return bad;
 }
 
-int main() {
+extern "C" int memset_probe_main() {
     int bad = 0;
     for (int rep = 0; rep < 2; ++rep) {
         bad += run(false, true, 20);
@@ -88,3 +104,4 @@ int main() {
     }
     return bad ? 1 : 0;
 }
+int main() { return memset_probe_main(); }
