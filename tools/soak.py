@@ -29,6 +29,8 @@ def main():
     if tr._uctrl is not tr.vec.ctrl:
         assert int(tr._uctrl[0]) == steps + 1, int(tr._uctrl[0])
     assert int(tr.vec.ctrl[1]) == 0 and int(tr.vec.ctrl[16:].abs().max()) == 0          # arrival counters at rest
+    from rpo_amd import _lib
+    assert int(tr.vec.ctrl[_lib.CONST["RPO_CTRL_NONFINITE"]]) == 0                       # the failure word stayed clear (round 6)
     assert int(ag.critic_optim.step_dev[0]) == steps - tr.warmup + (1 if tr.warmup else 0) or int(ag.critic_optim.step_dev[0]) == steps
     assert int(ag.actor_optim.step_dev[0]) == steps // tr.policy_fre
     for opt in (ag.critic_optim, ag.actor_optim):
