@@ -14,9 +14,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["cartsafe.hip", "pendulum.hip", "evopf.hip", "replay.hip", "train_ops.hip", "mlp.hip", "fused.hip", "nsplit.hip",
-           "rollout_stream.hip"]
-# per-file flags: the streaming rollout is compiled without SLP vectorisation (see the header of rollout_stream.hip)
-FILE_FLAGS = {"rollout_stream.hip": ["-fno-slp-vectorize"]}
+           "rollout_stream.hip", "mlp_bwd_stream.hip"]
+# per-file flags: the streaming rollout and the streaming backward are compiled without SLP vectorisation (see their headers)
+FILE_FLAGS = {"rollout_stream.hip": ["-fno-slp-vectorize"], "mlp_bwd_stream.hip": ["-fno-slp-vectorize"]}
 HEADERS = sorted(f for f in os.listdir(HERE) if f.endswith(".h")) + [os.path.join("..", "..", "include", "rpo_hip.h")]   # (every header: a stale object is worse than a rebuild)
 TARGET = os.path.join(HERE, "librpo_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -21,7 +21,6 @@
 #include "mlp_gemm.h"
 #include "mlp_tile.h"
 #include "mlp_stream.h"
-#include "mlp_bwd_stream.h"
 
 namespace {
 
@@ -395,7 +394,7 @@ int rpo_mlp_backward(const rpo_mlp* net_host, const rpo_mlp_grad* grad_host, int
     if (ein == 128 && net.H == 256 && !gemm_rows) {               // large batches: the two streaming launches (mlp_bwd_stream.h)
         SplitK sk{nullptr, nullptr, 0, 0};
         if (param_grads) sk = splitk_plan(args, grad_host->splitk_scratch, grad_host->splitk_floats);
-        if (bwd_stream_applies(args, sk)) return launch_bwd_stream(args, sk, (hipStream_t)stream);
+        if (bwd_stream_applies_x(args, sk)) return launch_bwd_stream_x(args, sk, (hipStream_t)stream);
     }
     if (param_grads && ein == 128 && net.H == 256) {              // ... or rows + weights in ONE pass over the activations (round 3)
         const SplitK sk = splitk_plan(args, grad_host->splitk_scratch, grad_host->splitk_floats);
@@ -452,9 +451,9 @@ int rpo_mlp_backward_pair(const rpo_mlp* net1_host, const rpo_mlp_grad* grad1_ho
             k1 = splitk_plan(args.net[0], grad1_host->splitk_scratch, grad1_host->splitk_floats);
             k2 = splitk_plan(args.net[1], grad2_host->splitk_scratch, grad2_host->splitk_floats);
         }
-        if (own && bwd_stream_applies(args.net[0], k1) && bwd_stream_applies(args.net[1], k2)) {
-            if (int r = launch_bwd_stream(args.net[0], k1, (hipStream_t)stream)) return r;
-            return launch_bwd_stream(args.net[1], k2, (hipStream_t)stream);
+        if (own && bwd_stream_applies_x(args.net[0], k1) && bwd_stream_applies_x(args.net[1], k2)) {
+            if (int r = launch_bwd_stream_x(args.net[0], k1, (hipStream_t)stream)) return r;
+            return launch_bwd_stream_x(args.net[1], k2, (hipStream_t)stream);
         }
     }
     if (param_grads && ein == 128 && n1.H == 256 && grad1_host->splitk_scratch != grad2_host->splitk_scratch) {   // (see rpo_mlp_backward)

@@ -1113,4 +1113,10 @@ static inline int launch_weights_splitk(const BwdArgs& args, const SplitK& k, in
     return 0;
 }
 
+// The streaming backward (mlp_bwd_stream.h) lives in a translation unit of its own, mlp_bwd_stream.hip, compiled with
+// -fno-slp-vectorize (packed f32 vector instructions beside f32 MFMAs: 1 179 -> 1 144 us at 2^20 rows, round 6); mlp.hip
+// reaches it through these two (hidden: not symbols of the shared library's ABI).
+__attribute__((visibility("hidden"))) bool bwd_stream_applies_x(const BwdArgs& a, const SplitK& k);
+__attribute__((visibility("hidden"))) int launch_bwd_stream_x(const BwdArgs& a, const SplitK& k, hipStream_t stream);
+
 }  // namespace rpo_mlp_dev

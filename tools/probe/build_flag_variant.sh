@@ -10,7 +10,7 @@ while [ $# -gt 0 ] && [ "$1" != "--" ]; do FLAGS+=("$1"); shift; done
 FILES=("$@")
 cd $(dirname $0)/../../rpo_amd/csrc
 OBJ=/tmp/rpo_variant_$NAME; mkdir -p $OBJ
-ALL="cartsafe pendulum evopf replay train_ops mlp fused nsplit rollout_stream"
+ALL="cartsafe pendulum evopf replay train_ops mlp fused nsplit rollout_stream mlp_bwd_stream"
 for f in $ALL; do
   EXTRA=("${FLAGS[@]}")
   if [ ${#FILES[@]} -gt 0 ]; then case " ${FILES[*]} " in *" $f.hip "*) ;; *) EXTRA=();; esac; fi
