@@ -664,40 +664,17 @@ def lanes_sweep(device, sizes, workload="cart_ddpg"):
     """Whole-iteration figures of the headline workload at `sizes` lanes on ONE GPU: (i) rollout only, (ii) rollout + the
     reference-cadence update (one batch-256 update per vector step), each as env-steps/s and as fractions of the f32 MFMA
     peak (67 584 flop per lane + the update's flops) and of the HBM roofline (185 algorithmic bytes per lane + the update's
-    bytes), in hipGraph windows like the headline.  From 65 536 lanes the rollout launch is the streaming form (fused.hip
-    rollout_stream_kernel).  Replay capacity 8 vector steps per lane (1 GiB at 2^20 lanes), everything else as the headline."""
+    bytes), in hipGraph windows like the headline.  From 65 536 lanes the rollout launch is the streaming form
+    (rollout_stream.hip).  Replay capacity 8 vector steps per lane (1 GiB at 2^20 lanes), everything else as the headline."""
     out = []
     for n in sizes:
         row = {"lanes": int(n)}
-        for mode in ("rollout_only", "with_update"):
+        try:
+            _lanes_row(row, int(n), device, workload)
+        except Exception as e:                                  # noqa: BLE001  (an extra must never cost the line its headline)
+            row["error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
+            log("lanes %d: %s" % (n, row["error"]))
             torch.cuda.empty_cache()
-            tr = make_trainer(int(n), device, 10 ** 9, capacity=8, workload=workload)
-            tr.vec.reset()
-            train = mode == "with_update"
-            tr.run_steps(5 * max(tr._cycle, 4), train=train)      # eager passes + graph capture
-            steps = int(max(2 * tr._cycle, min(2000, 2 ** 28 // n)))
-            steps -= steps % max(tr._cycle, 1)
-            regions = []
-            for _ in range(5):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                tr.run_steps(steps, train=train)
-                torch.cuda.synchronize()
-                regions.append((time.perf_counter() - t0) / steps)
-            dt = float(np.median(regions))
-            flop = n * ROLLOUT_FLOP_PER_LANE + (256 * UPDATE_FLOP_PER_SAMPLE if train else 0.0)
-            byts = n * ROLLOUT_BYTES_PER_LANE + (UPDATE_BYTES if train else 0.0)
-            row[mode] = {"ms_per_step": dt * 1e3, "env_steps_per_s": n / dt, "steps_timed": steps,
-                         "frac_of_f32_mfma_peak": flop / dt * 1e-12 / MFMA_F32_PEAK_TFLOPS,
-                         "frac_of_hbm_roofline": byts / dt * 1e-9 / HBM_PEAK_GBS,
-                         "hip_graph_window": tr._cycle}
-            tr._harvest(final=True)
-            del tr
-        log("lanes %8d: rollout only %9.1f M env-steps/s (%.3f of the f32 MFMA peak, %.4f of the HBM roofline); with the "
-            "batch-256 update %9.1f M (%.3f / %.4f)" % (n, row["rollout_only"]["env_steps_per_s"] * 1e-6,
-                                                       row["rollout_only"]["frac_of_f32_mfma_peak"], row["rollout_only"]["frac_of_hbm_roofline"],
-                                                       row["with_update"]["env_steps_per_s"] * 1e-6,
-                                                       row["with_update"]["frac_of_f32_mfma_peak"], row["with_update"]["frac_of_hbm_roofline"]))
         out.append(row)
     torch.cuda.empty_cache()
     return {"workload": DESCRIBE[workload], "rows": out,
@@ -705,6 +682,36 @@ def lanes_sweep(device, sizes, workload="cart_ddpg"):
                     "/ %.1f TFLOP/s and (lanes x %d B [+ %.2f MB of update]) / time / %.0f GB/s (SURVEY 8d's algorithmic figures)"
                     % (ROLLOUT_FLOP_PER_LANE, 256 * UPDATE_FLOP_PER_SAMPLE * 1e-6, MFMA_F32_PEAK_TFLOPS, ROLLOUT_BYTES_PER_LANE,
                        UPDATE_BYTES * 1e-6, HBM_PEAK_GBS)}
+
+
+def _lanes_row(row, n, device, workload):
+    for mode in ("rollout_only", "with_update"):
+        torch.cuda.empty_cache()
+        tr = make_trainer(int(n), device, 10 ** 9, capacity=8, workload=workload)
+        tr.vec.reset()
+        train = mode == "with_update"
+        tr.run_steps(5 * max(tr._cycle, 4), train=train)          # eager passes + graph capture
+        steps = int(max(2 * tr._cycle, min(2000, 2 ** 28 // n)))
+        steps -= steps % max(tr._cycle, 1)
+        regions = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tr.run_steps(steps, train=train)
+            torch.cuda.synchronize()
+            regions.append((time.perf_counter() - t0) / steps)
+        dt = float(np.median(regions))
+        flop = n * ROLLOUT_FLOP_PER_LANE + (256 * UPDATE_FLOP_PER_SAMPLE if train else 0.0)
+        byts = n * ROLLOUT_BYTES_PER_LANE + (UPDATE_BYTES if train else 0.0)
+        row[mode] = {"ms_per_step": dt * 1e3, "env_steps_per_s": n / dt, "steps_timed": steps,
+                     "frac_of_f32_mfma_peak": flop / dt * 1e-12 / MFMA_F32_PEAK_TFLOPS,
+                     "frac_of_hbm_roofline": byts / dt * 1e-9 / HBM_PEAK_GBS, "hip_graph_window": tr._cycle}
+        tr._harvest(final=True)
+        del tr
+    ro, wu = row["rollout_only"], row["with_update"]
+    log("lanes %8d: rollout only %9.1f M env-steps/s (%.3f of the f32 MFMA peak, %.4f of the HBM roofline); with the batch-256 "
+        "update %9.1f M (%.3f / %.4f)" % (n, ro["env_steps_per_s"] * 1e-6, ro["frac_of_f32_mfma_peak"], ro["frac_of_hbm_roofline"],
+                                         wu["env_steps_per_s"] * 1e-6, wu["frac_of_f32_mfma_peak"], wu["frac_of_hbm_roofline"]))
 
 
 def main():
