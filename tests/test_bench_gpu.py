@@ -116,3 +116,24 @@ def test_scale_preflight_over_gloo_on_one_gpu():
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "scale_preflight_gloo.json"), "w") as f:
         json.dump(v, f, indent=1)
+
+
+def test_lanes_sweep_rows_carry_both_rooflines():
+    """bench.py's `lanes_sweep`: whole iterations -- rollout only, rollout + the batch-256 update -- with
+    env-steps/s and the fractions of the f32 MFMA peak and of the HBM roofline.  Here at two small sizes (the bench runs 4096 /
+    65 536 / 2^20); a size that cannot run is reported in its row, not raised."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    os.environ.setdefault("RPO_VERBOSE", "0")
+    res = bench.lanes_sweep(torch.device("cuda"), [512, 8192])
+    assert [r["lanes"] for r in res["rows"]] == [512, 8192] and "flop" in res["note"]
+    for r in res["rows"]:
+        assert "error" not in r, r
+        for mode in ("rollout_only", "with_update"):
+            m = r[mode]
+            assert m["env_steps_per_s"] > 0 and 0 < m["frac_of_f32_mfma_peak"] < 1 and 0 < m["frac_of_hbm_roofline"] < 1
+            assert abs(m["env_steps_per_s"] - r["lanes"] / (m["ms_per_step"] * 1e-3)) < 1e-6 * m["env_steps_per_s"]
+        assert r["with_update"]["ms_per_step"] > r["rollout_only"]["ms_per_step"]
+    bad = bench.lanes_sweep(torch.device("cuda"), [-5])          # (make_trainer refuses: the row says so)
+    assert "error" in bad["rows"][0]
