@@ -9,10 +9,10 @@ OUT=$PWD/gpurun_out/statistics_$R
 mkdir -p $OUT
 export RPO_VERBOSE=0
 # num_envs = 1, 3000 iterations per seed, as many GPU seeds as the reference has (cart-RPODDPG 1536, pendulum-RPODDPG 576 x 2,
-# cart-RPOSAC 384, pendulum-RPOSAC 192 x 2): tests/test_statistical_evidence.py
+# cart-RPOSAC 1152, pendulum-RPOSAC 192 x 2): tests/test_statistical_evidence.py
 python3 tools/run_group.py 900 python3 tools/statistical_parity.py ddpg cart 1536 > $OUT/log_ddpg_cart.txt 2>&1
 python3 tools/run_group.py 900 python3 tools/statistical_parity.py ddpg pendulum 1152 > $OUT/log_ddpg_pendulum.txt 2>&1
-python3 tools/run_group.py 900 python3 tools/statistical_parity.py sac cart 384 > $OUT/log_sac_cart.txt 2>&1
+python3 tools/run_group.py 1500 python3 tools/statistical_parity.py sac cart 1152 > $OUT/log_sac_cart.txt 2>&1
 python3 tools/run_group.py 900 python3 tools/statistical_parity.py sac pendulum 384 > $OUT/log_sac_pendulum.txt 2>&1
 cp gpurun_out/stat_rows_*.npz gpurun_out/stat_rows_*.json $OUT/
 # the vectorised cadences at matched updates: 128 seeds (batch 256 per vector step) + 32 (one 2^20-row batch); the lane sweep
