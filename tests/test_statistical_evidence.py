@@ -84,9 +84,10 @@ def test_cart_ddpg_violation_rate_at_1536_plus_1536_seeds():
     assert got[:, 0].min() > 0.9 * 3000
 
 
-@pytest.mark.parametrize("algo,envname,se_max", [("sac", "pendulum", 1.0e-4), ("sac", "cart", 6.5e-4), ("ddpg", "pendulum", 6.0e-5)])
+@pytest.mark.parametrize("algo,envname,se_max", [("sac", "pendulum", 1.0e-4), ("sac", "cart", 4.0e-4), ("ddpg", "pendulum", 6.0e-5)])
 def test_other_workloads_match_the_reference(algo, envname, se_max):
-    """pendulum-RPOSAC (config 3: 192 reference seeds), cart-RPOSAC (config 4's algorithm: 384), pendulum-RPODDPG (576), one or
+    """pendulum-RPOSAC (config 3: 192 reference seeds), cart-RPOSAC (config 4's algorithm: 1152 since round 6, 384 before: SE of
+    the difference 5.9e-4 -> 3.5e-4), pendulum-RPODDPG (576), one or
     two GPU runs per reference run: |delta violation rate| <= 1e-3 + 2 SE at a resolution that can see 1e-3, per-step violation
     within 15 % + 2 SE, returns within 5 % + 2 SE."""
     ref, got, d, se = _compare(algo, envname)
