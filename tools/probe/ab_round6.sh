@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round-6 A/B in one GPU-box call: (1) -fno-slp-vectorize (whole library / fused.hip only) against the default build on the
+# Round-6 A/B in one GPU-box call (build the variants first: bash tools/probe/build_flag_variant.sh noslp -fno-slp-vectorize;
+# bash tools/probe/build_flag_variant.sh noslpf -fno-slp-vectorize -- fused.hip): (1) -fno-slp-vectorize (whole library / fused.hip only) against the default build on the
 # streaming kernels and the headline, (2) the EVOPF projection placement switch.  Output: gpurun_out/ab_r06/*.txt
 set -u
 OUT=$PWD/gpurun_out/ab_r06; mkdir -p $OUT

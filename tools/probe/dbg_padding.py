@@ -1,4 +1,11 @@
-"""Debugging aid (round 6): which launch leaves a non-zero gradient in the PADDING floats of the flat parameter buffer?"""
+"""Debugging aid and reproducer (round 6): which launch leaves a non-zero gradient in the PADDING floats of the
+flat parameter buffer?  With the shipped library (split-K scratch zeroed by a kernel) nothing does; with the old form,
+
+    bash tools/probe/build_flag_variant.sh memset -DRPO_SPLITK_ZERO=0
+    RPO_HIP_LIBRARY=$PWD/rpo_amd/csrc/librpo_hip_memset.so python tools/probe/dbg_padding.py
+
+the hipGraph run shows garbage behind the critic's head bias after its first replayed window (iteration 5), the eager run never.
+DBG_INSPECT=1 additionally looks into the slices' scratch between iterations (which makes the symptom disappear)."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
