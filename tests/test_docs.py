@@ -47,3 +47,23 @@ def test_design_is_short_and_names_only_what_exists():
     # tests it cites by name exist
     for t in set(re.findall(r"`(test_[a-z_0-9]+)`", text)):
         assert re.search(r"def %s\b" % t, tree), t
+
+
+def test_the_library_issues_nothing_a_capture_turns_into_a_memset_or_memcpy_node():
+    """a hipMemsetAsync captured into the trainer's windows filled the split-K scratch with a stale pattern at
+    replay.  Every launch of the library is a kernel; the one remaining hipMemsetAsync is the reproducer's form behind
+    RPO_SPLITK_ZERO=0."""
+    d = os.path.join(ROOT, "rpo_amd", "csrc")
+    calls = []
+    for fn in sorted(os.listdir(d)):
+        if not fn.endswith((".hip", ".h")):
+            continue
+        with open(os.path.join(d, fn)) as f:
+            for no, line in enumerate(f, 1):
+                code = line.split("//")[0]
+                for m in re.findall(r"\bhipMem(?:set|cpy)\w*\s*\(", code):
+                    calls.append((fn, no, m))
+    assert [c[0] for c in calls] == ["mlp_bwd.h"] and calls[0][2].startswith("hipMemsetAsync"), calls
+    with open(os.path.join(d, "mlp_bwd.h")) as f:
+        text = f.read()
+    assert "#define RPO_SPLITK_ZERO 1" in text

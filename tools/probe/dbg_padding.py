@@ -5,7 +5,14 @@ flat parameter buffer?  With the shipped library (split-K scratch zeroed by a ke
     RPO_HIP_LIBRARY=$PWD/rpo_amd/csrc/librpo_hip_memset.so python tools/probe/dbg_padding.py
 
 the hipGraph run shows garbage behind the critic's head bias after its first replayed window (iteration 5), the eager run never.
-DBG_INSPECT=1 additionally looks into the slices' scratch between iterations (which makes the symptom disappear)."""
+DBG_INSPECT=1 additionally looks into the slices' scratch between iterations (which makes the symptom disappear).  The post
+mortem after the first bad iteration prints what the scratch holds; with slices padded by floats that NO kernel writes,
+
+    git apply tools/probe/splitk_pad.patch && bash tools/probe/build_flag_variant.sh memsetpad -DRPO_SPLITK_ZERO=0 -DRPO_SPLITK_PAD=64
+    git checkout rpo_amd/csrc/mlp_bwd.h
+    DBG_SPLITK_PAD=64 RPO_HIP_LIBRARY=$PWD/rpo_amd/csrc/librpo_hip_memsetpad.so python tools/probe/dbg_padding.py
+
+it shows what the replayed memset node left there: the 16-byte group {12, 0, 1, 12} (int32) instead of zeros."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -57,7 +64,7 @@ for use_graph in (False, True):
                 lo = min(g.data_ptr() for g in grads)
                 hi = max(g.data_ptr() + 4 * g.numel() for g in grads)
                 span = (hi - lo) // 4
-                stride = (span + 3) // 4 * 4
+                stride = (span + 3) // 4 * 4 + int(os.environ.get('DBG_SPLITK_PAD', '0'))
                 Z = sk.numel() // stride
                 view = sk[:Z * stride].view(Z, stride)
                 base_idx = (lo - fl.grad.data_ptr()) // 4
@@ -73,6 +80,39 @@ for use_graph in (False, True):
             first = it
             print("use_graph=%s: padding of the PARAMETERS non-zero after iteration %d:" % (use_graph, it),
                   [(int(i), float(x)) for i, x in zip(pad_idx.tolist(), v.tolist()) if x != 0], flush=True)
+            # post mortem (nothing was allocated or inspected before this point): what do the slices' scratch copies, the
+            # gradient and the moments hold at the padding positions NOW?
+            for name, d in tr.fused.descs.items():
+                sk = getattr(d, "splitk", None)
+                if sk is None:
+                    continue
+                grads = [t.grad for t in d.tensors.values() if t is not None and t.grad is not None]
+                lo = min(g.data_ptr() for g in grads)
+                hi = max(g.data_ptr() + 4 * g.numel() for g in grads)
+                span = (hi - lo) // 4
+                stride = (span + 3) // 4 * 4 + int(os.environ.get('DBG_SPLITK_PAD', '0'))
+                Z = sk.numel() // stride
+                view = sk[:Z * stride].view(Z, stride)
+                base_idx = (lo - fl.grad.data_ptr()) // 4
+                cols = [int(i) - base_idx for i in pad_idx.tolist() if base_idx <= int(i) < base_idx + span]
+                sub = view[:, cols] if cols else view[:, :0]
+                nz = torch.nonzero(sub)
+                print("   post mortem: scratch of %s (Z=%d, span=%d, base %d, ptr %% 4096 = %d): %d non-zero padding entries %s; "
+                      "non-finite anywhere: %d" % (name, Z, span, base_idx, sk.data_ptr() % 4096, nz.shape[0],
+                                                   [(int(a), cols[int(b)] + base_idx, float(sub[a, b])) for a, b in nz[:6].tolist()],
+                                                   int((~torch.isfinite(view)).sum())), flush=True)
+                den = (view != 0) & (view.abs() < 1e-37)
+                dcols = torch.nonzero(den.any(0)).view(-1)
+                print("   post mortem: %s scratch: %d denormal entries in %d columns %s; slice 0 around the head bias: %s; as int32: %s" % (
+                    name, int(den.sum()), dcols.numel(), (dcols[:12] + base_idx).tolist(),
+                    view[0, max(0, 33660 - base_idx):max(0, 33672 - base_idx)].tolist(),
+                    view[0, max(0, 33660 - base_idx):max(0, 33672 - base_idx)].view(torch.int32).tolist()), flush=True)
+                if stride > (span + 3) // 4 * 4:
+                    tail = view[:, (span + 3) // 4 * 4:].contiguous().view(torch.int32)
+                    print("   post mortem: %s scratch, the %d floats behind each slice that NO kernel writes, as int32: slice 0 %s ... slice %d %s;"
+                          " distinct 16-byte groups: %s" % (name, tail.shape[1], tail[0, :16].tolist(), Z - 1, tail[-1, :8].tolist(),
+                                                           torch.unique(tail.view(-1, 4), dim=0)[:6].tolist()), flush=True)
+            print("   post mortem: grad padding", fl.grad[pad_idx].tolist(), flush=True)
     print("use_graph=%s: first non-zero padding at iteration %s" % (use_graph, first), flush=True)
     ops.mlp_backward = orig
     del tr

@@ -16,14 +16,14 @@ __device__ void spin(long long cycles) {                        // (long-running
     while (wall_clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(8);
 }
 __global__ void write_some(float* scratch, long long stride, int Z, long long span, int salt) {
-    spin(20000);                                                 // 100 MHz clock: 200 us
+    spin(5000);                                                  // 100 MHz clock: 50 us
     // slice z writes every position except those with (i % 97) == 3 (the "padding" no kernel writes)
     const int z = blockIdx.y;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < span; i += (long long)gridDim.x * blockDim.x)
         if (i % 97 != 3) scratch[z * stride + i] = 1.0f + (float)((i + salt) & 7);
 }
 __global__ void reduce(const float* scratch, long long stride, int Z, long long span, float* out) {
-    spin(20000);
+    spin(5000);
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < span; i += (long long)gridDim.x * blockDim.x) {
         float s = 0.0f;
         for (int z = 0; z < Z; ++z) s += scratch[z * stride + i];
@@ -35,11 +35,21 @@ __global__ void zero_kernel(float4* p, long long n4) {
         p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-int run(bool graph, bool memset_node, int replays) {
+// `between`: what the host does between two launches of the graph (the trainer polls a few words of device memory, torch fills and
+// copies small tensors): 0 nothing | 1 an eager 4-byte-pattern memset of another buffer | 2 a 12-byte copy to pageable host memory |
+// 3 the same to pinned memory, asynchronously, on another stream | 4 all of them
+__global__ void small_kernel(float* p, int a, int b, int c, long long d) { if (threadIdx.x == 0 && blockIdx.x == 0) p[a] = (float)(b + c) + (float)d; }
+// `passes` backwards per graph with `extra` small kernel nodes after each (the trainer's 16-iteration window holds ~50 memset
+// nodes among ~500 kernel nodes)
+// `copies`: small device-to-device hipMemcpyAsync calls (memcpy NODES: torch's copy_ under capture) after each pass
+int run(bool graph, bool memset_node, int replays, long long offset_floats = 0, int between = 0, int passes = 2, int extra = 0, int copies = 0) {
     const int Z = 256;
     const long long span = 34564, stride = 34564;
-    float *scratch, *out;
-    CK(hipMalloc(&scratch, sizeof(float) * Z * stride));
+    float *scratch_base, *scratch, *out;
+    // (PyTorch's caching allocator hands out 512-byte-aligned pieces of larger segments: `offset_floats` moves the destination off
+    //  the allocation's own alignment)
+    CK(hipMalloc(&scratch_base, sizeof(float) * (Z * stride + 4096)));
+    scratch = scratch_base + offset_floats;
     CK(hipMalloc(&out, sizeof(float) * span));
     CK(hipMemset(scratch, 0, sizeof(float) * Z * stride));
     CK(hipMemset(out, 0, sizeof(float) * span));
@@ -52,12 +62,15 @@ int run(bool graph, bool memset_node, int replays) {
     CK(hipMalloc(&other, other_bytes));
     CK(hipMemset(other, 0, other_bytes));
     auto body = [&]() {
-        for (int pass = 0; pass < 2; ++pass) {
+        for (int pass = 0; pass < passes; ++pass) {
             if (memset_node) CK(hipMemsetAsync(other, 0x7f - pass, other_bytes, s));
             if (memset_node) CK(hipMemsetAsync(scratch, 0, sizeof(float) * Z * stride, s));
-            else hipLaunchKernelGGL(zero_kernel, dim3(2048), dim3(256), 0, s, (float4*)scratch, (long long)Z * stride / 4);
+            else hipLaunchKernelGGL(zero_kernel, dim3(2048), dim3(256), 0, s, (float4*)scratch, (long long)Z * stride / 4);   // (16-byte aligned offsets only)
             hipLaunchKernelGGL(write_some, dim3(64, Z), dim3(256), 0, s, scratch, stride, Z, span, pass);
             hipLaunchKernelGGL(reduce, dim3(136), dim3(256), 0, s, scratch, stride, Z, span, out);
+            for (int c = 0; c < copies; ++c)
+                CK(hipMemcpyAsync(other + 4096 + 64 * c, other + 8192 + 64 * c, 12 + 4 * (c & 3), hipMemcpyDeviceToDevice, s));
+            for (int e = 0; e < extra; ++e) hipLaunchKernelGGL(small_kernel, dim3(4), dim3(64), 0, s, (float*)other, 0, 1, 12, (long long)e);
         }
     };
     if (graph) {
@@ -66,7 +79,19 @@ int run(bool graph, bool memset_node, int replays) {
         body();
         CK(hipStreamEndCapture(s, &g));
         CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        for (int r = 0; r < replays; ++r) CK(hipGraphLaunch(ge, s));
+        unsigned int *small_dev, *pinned, pageable[4];
+        hipStream_t s2;
+        CK(hipStreamCreate(&s2));
+        CK(hipMalloc(&small_dev, 4096));
+        CK(hipHostMalloc(&pinned, 4096));
+        for (int r = 0; r < replays; ++r) {
+            CK(hipGraphLaunch(ge, s));
+            if (between == 1 || between == 4) CK(hipMemsetD32Async((hipDeviceptr_t)small_dev, 0x0C0C0C0Cu + r, 1024, s));
+            if (between == 2 || between == 4) CK(hipMemcpy(pageable, small_dev, 12, hipMemcpyDeviceToHost));
+            if (between == 3 || between == 4) { CK(hipMemcpyAsync(pinned, small_dev, 12, hipMemcpyDeviceToHost, s2)); CK(hipStreamSynchronize(s2)); }
+        }
+        CK(hipStreamSynchronize(s));
+        CK(hipFree(small_dev)); CK(hipHostFree(pinned)); CK(hipStreamDestroy(s2));
     } else {
         for (int r = 0; r < replays; ++r) body();
     }
@@ -77,7 +102,8 @@ int run(bool graph, bool memset_node, int replays) {
     for (long long i = 0; i < span; ++i) {
         if (i % 97 == 3) { if (h[i] != 0.0f) { if (bad < 3) printf("   position %lld (never written) = %g\n", i, h[i]); ++bad; } }
         else {
-            const double want = (double)replays * Z * ((1.0 + ((i + 0) & 7)) + (1.0 + ((i + 1) & 7)));
+            double want = 0;
+            for (int pass = 0; pass < passes; ++pass) want += (double)replays * Z * (1.0 + ((i + pass) & 7));
             if (h[i] != (float)want) expect_err += 1;
         }
     }
@@ -85,13 +111,14 @@ int run(bool graph, bool memset_node, int replays) {
         std::vector<unsigned char> ho(other_bytes);
         CK(hipMemcpy(ho.data(), other, other_bytes, hipMemcpyDeviceToHost));
         long long wrong = 0;
-        for (size_t i = 0; i < other_bytes; ++i) wrong += ho[i] != 0x7e;
+        for (size_t i = 0; i < other_bytes; ++i) wrong += ho[i] != (unsigned char)(0x7f - (passes - 1)) && i >= 16384;
         if (wrong) { printf("   second memset's buffer: %lld of %zu bytes are not its last pattern\n", wrong, other_bytes); ++bad; }
     }
     CK(hipFree(other));
+    if (between) printf("(between the launches: %d) ", between);
     printf("%-6s %-12s %3d replays: %d never-written positions non-zero, %g written positions off\n", graph ? "graph" : "eager",
            memset_node ? "memset" : "zero kernel", replays, bad, expect_err);
-    CK(hipFree(scratch)); CK(hipFree(out));
+    CK(hipFree(scratch_base)); CK(hipFree(out));
     return bad;
 }
 
@@ -101,6 +128,17 @@ extern "C" int memset_probe_main() {
         bad += run(false, true, 20);
         bad += run(true, false, 20);
         bad += run(true, true, 20);
+        for (long long off : {128ll, 132ll, 1024ll, 3ll * 128}) {   // 512-byte / 528-byte / 4-KB-off / 1.5-KB destinations
+            printf("destination offset %lld floats: ", off);
+            bad += run(true, true, 20, off);
+        }
+        for (int between = 1; between <= 4; ++between) bad += run(true, true, 20, 0, between);
+        printf("48 passes per graph, 8 small kernels after each: ");
+        bad += run(true, true, 6, 0, 4, 48, 8);
+        printf("2 passes, 3 small device-to-device copies after each: ");
+        bad += run(true, true, 20, 0, 0, 2, 0, 3);
+        printf("48 passes, 8 small kernels and 3 small device-to-device copies after each: ");
+        bad += run(true, true, 6, 0, 4, 48, 8, 3);
     }
     return bad ? 1 : 0;
 }
