@@ -132,6 +132,37 @@ class _Dist(object):
         return self.all_ok(mine, device)
 
 
+_NODE_KINDS = ("kernel", "memcpy", "memset", "host", "graph", "empty", "wait_event", "event_record", "sem_signal", "sem_wait",
+               "mem_alloc", "mem_free", "memcpy_from_symbol", "memcpy_to_symbol", "batch_mem_op")
+
+
+def _graph_node_kinds(g):
+    """{kind: count} of the nodes of a captured ``torch.cuda.CUDAGraph(keep_graph=True)`` (hipGraphGetNodes /
+    hipGraphNodeGetType of the HIP runtime the process is bound to).  The windows are meant to hold KERNEL nodes only (plus the
+    collective backend's own in data-parallel runs): a hipMemsetAsync captured into them was replayed with a stale fill
+    pattern, so anything that is not a kernel is worth a look -- ``RPO_GRAPH_AUDIT=1``."""
+    import ctypes
+    from .. import _lib
+    _lib._bind_to_torch_hip_runtime()
+    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    hip = ctypes.CDLL(bundled if os.path.exists(bundled) else "libamdhip64.so", mode=ctypes.RTLD_GLOBAL)
+    graph = ctypes.c_void_p(int(g.raw_cuda_graph()))
+    n = ctypes.c_size_t(0)
+    if hip.hipGraphGetNodes(graph, None, ctypes.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    nodes = (ctypes.c_void_p * max(1, n.value))()
+    if n.value and hip.hipGraphGetNodes(graph, nodes, ctypes.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    kinds = {}
+    for i in range(n.value):
+        t = ctypes.c_int(-1)
+        if hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t)) != 0:
+            raise RuntimeError("hipGraphNodeGetType failed")
+        name = _NODE_KINDS[t.value] if 0 <= t.value < len(_NODE_KINDS) else "type_%d" % t.value
+        kinds[name] = kinds.get(name, 0) + 1
+    return kinds
+
+
 class _GraphCache(object):
     """Eager for the first ``warm`` calls of a key (on a side stream, as hipGraph capture of autograd wants), then
     captured once and replayed.  Every call performs the work exactly once."""
@@ -141,6 +172,7 @@ class _GraphCache(object):
         self.capture_failed = False     # a capture was attempted and dropped (on this rank or, data-parallel, on any rank)
         self.entries = {}
         self.side = None
+        self.audit = os.environ.get("RPO_GRAPH_AUDIT", "0") == "1"   # keep the captured hipGraph_t and count its node kinds
         # host state `fn` changes while it is being captured (hand-over flags, launch arguments): an aborted capture has
         # run the Python but no launch -- the eager re-run must start from the state the capture started from
         # (owner._host_state / _set_host_state).  A WEAK reference: a trainer <-> cache cycle would leave the trainer's
@@ -165,7 +197,7 @@ class _GraphCache(object):
                 fn()
             cur.wait_stream(self.side)
             return
-        g = torch.cuda.CUDAGraph()
+        g = torch.cuda.CUDAGraph(keep_graph=True) if self.audit else torch.cuda.CUDAGraph()
         owner = self._owner() if self._owner is not None else None
         state = owner._host_state() if owner is not None else None
         import gc
@@ -204,6 +236,8 @@ class _GraphCache(object):
                 fn()                                            # nothing ran during the aborted capture
                 return
             e["graph"] = g
+            if self.audit:
+                e["node_kinds"] = _graph_node_kinds(g)
             g.replay()
         finally:                                                # (KeyboardInterrupt / SystemExit inside fn() too: ADVICE r03)
             if gc_was_on:

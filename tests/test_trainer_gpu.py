@@ -829,9 +829,9 @@ def test_large_batch_mode_is_reproducible_run_to_run(hip):
 def test_large_batch_graph_windows_keep_the_padding_floats_zero(hip, monkeypatch):
     """Round 6, found by the failure flag (tests/test_failure_flag.py): under hipGraph REPLAY the large-batch update was not
     what the eager launches compute.  The split-K scratch (35 MB at 2^20 rows) was zeroed by `hipMemsetAsync`, which stream
-    capture turns into a memset NODE; replayed, stale partial sums of the previous backward survived in it and were added
-    again -- visible as a gradient-sized value in the three padding floats behind the critic's head bias (which no kernel
-    writes), different from run to run, NaN once in a few thousand updates (the NaN reached an action at update 2060 of a
+    capture turns into a memset NODE; replayed inside the trainer's windows, that node filled the buffer with a stale 16-byte
+    pattern instead of zeros -- visible in the three padding floats behind the critic's head bias (which no
+    kernel writes), different from run to run, NaN once in a few thousand updates (the NaN reached an action at update 2060 of a
     3000-update run: NonFiniteError).  Never with eager launches.  The scratch is now zeroed by a kernel of the library
     (mlp_bwd.h splitk_zero_kernel; -DRPO_SPLITK_ZERO=0 is the old form, tools/probe/dbg_padding.py the reproducer).
     Asserted: after 48 iterations through graph windows every padding float of the flat parameter buffer, of its gradient and
@@ -858,3 +858,18 @@ def test_large_batch_graph_windows_keep_the_padding_floats_zero(hip, monkeypatch
         del tr
         torch.cuda.empty_cache()
     assert torch.equal(out[False][0], out[True][0]) and torch.equal(out[False][1], out[True][1])
+
+
+@pytest.mark.parametrize("algo,envname,n,extra", [("ddpg", "cart", 4096, {}), ("ddpg", "cart", 4096, dict(batch_size=256 * 4096, capacity=64)),
+                                                  ("sac", "pendulum", 4096, {}), ("ddpg", "evopf256", 1024, {})])
+def test_the_windows_hold_kernel_nodes_only(hip, monkeypatch, algo, envname, n, extra):
+    """a hipMemsetAsync captured into the windows (a memset NODE) was replayed with a stale fill pattern.  The
+    library launches kernels only (tests/test_docs.py) and the trainer issues no torch operation inside a window that the
+    capture turns into a memset / memcpy node: with RPO_GRAPH_AUDIT=1 the captured hipGraph_t is kept and its nodes are counted
+    by kind (hipGraphGetNodes / hipGraphNodeGetType)."""
+    monkeypatch.setenv("RPO_GRAPH_AUDIT", "1")
+    tr = _run(algo, envname, hip, torch.device("cuda"), 96, n, use_graph=True, **extra)
+    kinds = [e.get("node_kinds") for e in tr._graphs.entries.values() if e["graph"] is not None]
+    assert kinds and not tr._graphs.capture_failed
+    for k in kinds:
+        assert set(k) == {"kernel"} and k["kernel"] >= 16, k
