@@ -113,6 +113,34 @@ for use_graph in (False, True):
                           " distinct 16-byte groups: %s" % (name, tail.shape[1], tail[0, :16].tolist(), Z - 1, tail[-1, :8].tolist(),
                                                            torch.unique(tail.view(-1, 4), dim=0)[:6].tolist()), flush=True)
             print("   post mortem: grad padding", fl.grad[pad_idx].tolist(), flush=True)
+            if os.environ.get("RPO_GRAPH_AUDIT", "0") == "1":      # what did the capture RECORD for the memset nodes?
+                import ctypes
+
+                class MemsetParams(ctypes.Structure):
+                    _fields_ = [("dst", ctypes.c_void_p), ("elementSize", ctypes.c_uint), ("height", ctypes.c_size_t),
+                                ("pitch", ctypes.c_size_t), ("value", ctypes.c_uint), ("width", ctypes.c_size_t)]
+                hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"), mode=ctypes.RTLD_GLOBAL)
+                scr = {int(d.splitk.data_ptr()): name for name, d in tr.fused.descs.items() if getattr(d, "splitk", None) is not None}
+                for key, e in tr._graphs.entries.items():
+                    if e.get("graph") is None:
+                        continue
+                    graph = ctypes.c_void_p(int(e["graph"].raw_cuda_graph()))
+                    cnt = ctypes.c_size_t(0)
+                    hip.hipGraphGetNodes(graph, None, ctypes.byref(cnt))
+                    nodes = (ctypes.c_void_p * max(1, cnt.value))()
+                    hip.hipGraphGetNodes(graph, nodes, ctypes.byref(cnt))
+                    seen = {}
+                    for i in range(cnt.value):
+                        t = ctypes.c_int(-1)
+                        hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t))
+                        if t.value != 2:
+                            continue
+                        mp = MemsetParams()
+                        rc = hip.hipGraphMemsetNodeGetParams(ctypes.c_void_p(nodes[i]), ctypes.byref(mp))
+                        k = (rc, scr.get(int(mp.dst or 0), hex(int(mp.dst or 0))), mp.elementSize, mp.width, mp.height, mp.pitch, mp.value)
+                        seen[k] = seen.get(k, 0) + 1
+                    print("   window %r: node kinds %s; memset nodes (rc, dst, elementSize, width, height, pitch, value) x count: %s" % (
+                        key, e.get("node_kinds"), seen), flush=True)
     print("use_graph=%s: first non-zero padding at iteration %s" % (use_graph, first), flush=True)
     ops.mlp_backward = orig
     del tr
