@@ -15,14 +15,19 @@ __device__ void spin(long long cycles) {                        // (long-running
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(8);
 }
-__global__ void write_some(float* scratch, long long stride, int Z, long long span, int salt) {
+// (the library's launches carry ~450 bytes of arguments by value -- BwdArgs + SplitK: `Big` makes the probe's as large, with
+//  recognisable words, in case the replayed fill takes its pattern from memory a neighbouring node's arguments occupy)
+struct Big { int v[112]; };
+__global__ void write_some(float* scratch, long long stride, int Z, long long span, int salt, Big big) {
+    if (big.v[5] == 12345678) scratch[0] = 1.0f;                 // (keeps the argument alive)
     spin(5000);                                                  // 100 MHz clock: 50 us
     // slice z writes every position except those with (i % 97) == 3 (the "padding" no kernel writes)
     const int z = blockIdx.y;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < span; i += (long long)gridDim.x * blockDim.x)
         if (i % 97 != 3) scratch[z * stride + i] = 1.0f + (float)((i + salt) & 7);
 }
-__global__ void reduce(const float* scratch, long long stride, int Z, long long span, float* out) {
+__global__ void reduce(const float* scratch, long long stride, int Z, long long span, float* out, Big big) {
+    if (big.v[7] == 12345678) out[0] = 1.0f;
     spin(5000);
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < span; i += (long long)gridDim.x * blockDim.x) {
         float s = 0.0f;
@@ -61,13 +66,15 @@ int run(bool graph, bool memset_node, int replays, long long offset_floats = 0, 
     const size_t other_bytes = 3 * 1000 * 1000 + 13;
     CK(hipMalloc(&other, other_bytes));
     CK(hipMemset(other, 0, other_bytes));
+    Big big;
+    for (int i = 0; i < 112; ++i) big.v[i] = 0x1000 + i;
     auto body = [&]() {
         for (int pass = 0; pass < passes; ++pass) {
             if (memset_node) CK(hipMemsetAsync(other, 0x7f - pass, other_bytes, s));
             if (memset_node) CK(hipMemsetAsync(scratch, 0, sizeof(float) * Z * stride, s));
             else hipLaunchKernelGGL(zero_kernel, dim3(2048), dim3(256), 0, s, (float4*)scratch, (long long)Z * stride / 4);   // (16-byte aligned offsets only)
-            hipLaunchKernelGGL(write_some, dim3(64, Z), dim3(256), 0, s, scratch, stride, Z, span, pass);
-            hipLaunchKernelGGL(reduce, dim3(136), dim3(256), 0, s, scratch, stride, Z, span, out);
+            hipLaunchKernelGGL(write_some, dim3(64, Z), dim3(256), 0, s, scratch, stride, Z, span, pass, big);
+            hipLaunchKernelGGL(reduce, dim3(136), dim3(256), 0, s, scratch, stride, Z, span, out, big);
             for (int c = 0; c < copies; ++c)
                 CK(hipMemcpyAsync(other + 4096 + 64 * c, other + 8192 + 64 * c, 12 + 4 * (c & 3), hipMemcpyDeviceToDevice, s));
             for (int e = 0; e < extra; ++e) hipLaunchKernelGGL(small_kernel, dim3(4), dim3(64), 0, s, (float*)other, 0, 1, 12, (long long)e);
@@ -143,3 +150,20 @@ extern "C" int memset_probe_main() {
     return bad ? 1 : 0;
 }
 int main() { return memset_probe_main(); }
+
+// The same launches on a stream and buffers the CALLER owns (tools/probe/memset_probe.py: torch tensors, captured by
+// torch.cuda.graph into torch's private pool, replayed by torch).
+extern "C" int memset_probe_body(void* stream, float* scratch, float* out, unsigned char* other, long long other_bytes, int Z,
+                                 long long stride, long long span, int passes, int memset_node) {
+    hipStream_t s = (hipStream_t)stream;
+    Big big;
+    for (int i = 0; i < 112; ++i) big.v[i] = 0x1000 + i;
+    for (int pass = 0; pass < passes; ++pass) {
+        if (memset_node && other) CK(hipMemsetAsync(other, 0x7f - pass, other_bytes, s));
+        if (memset_node) CK(hipMemsetAsync(scratch, 0, sizeof(float) * Z * stride, s));
+        else hipLaunchKernelGGL(zero_kernel, dim3(2048), dim3(256), 0, s, (float4*)scratch, (long long)Z * stride / 4);
+        hipLaunchKernelGGL(write_some, dim3(64, Z), dim3(256), 0, s, scratch, stride, Z, span, pass, big);
+        hipLaunchKernelGGL(reduce, dim3(136), dim3(256), 0, s, scratch, stride, Z, span, out, big);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}

@@ -23,3 +23,43 @@ x = torch.zeros(1, device="cuda")                               # torch owns the
 lib = ctypes.CDLL(so)
 rc = lib.memset_probe_main()
 print("rc", rc)
+
+# ---- the same launches captured by torch.cuda.graph (torch's capture stream, private memory pool, instantiation and launch)
+lib.memset_probe_body.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,
+                                  ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
+Z, span = 256, 34564
+for pad, passes, node in ((0, 2, 1), (64, 2, 1), (64, 24, 1), (64, 2, 0)):
+    stride = span + pad
+    scratch = torch.zeros(Z * stride, device="cuda")
+    out = torch.zeros(span, device="cuda")
+    other = torch.zeros(3 * 1000 * 1000 + 13, dtype=torch.uint8, device="cuda")
+
+    def body():
+        rc = lib.memset_probe_body(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), scratch.data_ptr(), out.data_ptr(),
+                                   other.data_ptr(), other.numel(), Z, stride, span, passes, node)
+        assert rc == 0
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            body()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    out.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        body()
+    replays = 20
+    for r in range(replays):
+        g.replay()
+        if r % 4 == 0:
+            torch.cuda.synchronize()
+            _ = float(out[5])                                    # (host activity between the launches, like the trainer's polling)
+    torch.cuda.synchronize()
+    idx = torch.arange(span, device="cuda")
+    never = (idx % 97) == 3
+    bad = int((out[never] != 0).sum())
+    tail = scratch.view(Z, stride)[:, span:].contiguous().view(torch.int32) if pad else None
+    print("torch.cuda.graph, %s, %d passes, %d unwritten floats per slice: %d never-written positions non-zero%s" % (
+        "memset node" if node else "zero kernel", passes, pad, bad,
+        "" if tail is None else "; unwritten tail groups: %s" % torch.unique(tail.view(-1, 4), dim=0)[:4].tolist()), flush=True)
