@@ -6,7 +6,7 @@ from .. import ops as hip_ops
 from .agent import PDDDPG_PA
 from .model import BoxConstraint
 from .agent.flat import FusedAdam
-from .trainer import _SALT_ACTOR, RPOTrainerBase, _LagrangianFn, _TDHuberFn, _env_int
+from .trainer import _SALT_ACTOR, RPOTrainerBase, _LagrangianFn, _TDHuberFn
 
 
 class _LazySum(object):

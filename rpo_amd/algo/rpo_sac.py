@@ -7,7 +7,7 @@ from .agent import PDSAC_PA
 from .model import BoxConstraint
 from .agent.flat import FusedAdam
 from .rpo_ddpg import _LazySum
-from .trainer import _SALT_ACTOR, _SALT_CRITIC, RPOTrainerBase, _LagrangianFn, _TDHuberFn, _env_int
+from .trainer import _SALT_ACTOR, _SALT_CRITIC, RPOTrainerBase, _LagrangianFn, _TDHuberFn
 
 
 class _LazySumPair(object):

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 from rpo_amd import ops
-from rpo_amd.algo.model import ActionEmbedding, SharedPolicy, SharedValueAdd, StateEmbedding
+from rpo_amd.algo.model import ActionEmbedding, SharedValueAdd, StateEmbedding
 from test_mlp_gpu import aligned_params, desc_for
 from bench import time_kernel
 
