@@ -139,6 +139,42 @@ for use_graph in (False, True):
                         rc = hip.hipGraphMemsetNodeGetParams(ctypes.c_void_p(nodes[i]), ctypes.byref(mp))
                         k = (rc, scr.get(int(mp.dst or 0), hex(int(mp.dst or 0))), mp.elementSize, mp.width, mp.height, mp.pitch, mp.value)
                         seen[k] = seen.get(k, 0) + 1
+                    # the window's nodes in dependency order, kernels by name
+                    class Dim3(ctypes.Structure):
+                        _fields_ = [("x", ctypes.c_uint), ("y", ctypes.c_uint), ("z", ctypes.c_uint)]
+
+                    class KernelParams(ctypes.Structure):
+                        _fields_ = [("blockDim", Dim3), ("extra", ctypes.c_void_p), ("func", ctypes.c_void_p), ("gridDim", Dim3),
+                                    ("kernelParams", ctypes.c_void_p), ("sharedMemBytes", ctypes.c_uint)]
+                    hip.hipKernelNameRefByPtr.restype = ctypes.c_char_p
+                    ne = ctypes.c_size_t(0)
+                    hip.hipGraphGetEdges(graph, None, None, ctypes.byref(ne))
+                    fr, to = (ctypes.c_void_p * max(1, ne.value))(), (ctypes.c_void_p * max(1, ne.value))()
+                    hip.hipGraphGetEdges(graph, fr, to, ctypes.byref(ne))
+                    succ = {}
+                    indeg = {int(nodes[i]): 0 for i in range(cnt.value)}
+                    for i in range(ne.value):
+                        succ.setdefault(int(fr[i]), []).append(int(to[i]))
+                        indeg[int(to[i])] += 1
+                    order, ready = [], [h for h, d_ in indeg.items() if d_ == 0]
+                    while ready:
+                        h = ready.pop(0)
+                        order.append(h)
+                        for t2 in succ.get(h, []):
+                            indeg[t2] -= 1
+                            if indeg[t2] == 0:
+                                ready.append(t2)
+                    for pos, h in enumerate(order):
+                        t = ctypes.c_int(-1)
+                        hip.hipGraphNodeGetType(ctypes.c_void_p(h), ctypes.byref(t))
+                        if t.value == 0:
+                            kp = KernelParams()
+                            hip.hipGraphKernelNodeGetParams(ctypes.c_void_p(h), ctypes.byref(kp))
+                            nm = hip.hipKernelNameRefByPtr(ctypes.c_void_p(kp.func), None)
+                            desc = "%s grid %d block %d lds %d" % ((nm or b"?").decode()[:90], kp.gridDim.x * kp.gridDim.y, kp.blockDim.x, kp.sharedMemBytes)
+                        else:
+                            desc = "node type %d" % t.value
+                        print("      %2d (%d successors) %s" % (pos, len(succ.get(h, [])), desc), flush=True)
                     print("   window %r: node kinds %s; memset nodes (rc, dst, elementSize, width, height, pitch, value) x count: %s" % (
                         key, e.get("node_kinds"), seen), flush=True)
     print("use_graph=%s: first non-zero padding at iteration %s" % (use_graph, first), flush=True)

@@ -36,7 +36,15 @@ dq, parts = torch.empty(n, device=DEV), torch.zeros((n + 15) // 16, device=DEV)
 td = ops.Td(q, qn1, None, None, reward, done, 0.0, 0.95, dq, parts)
 
 
+out2 = torch.empty(n, 1, device=DEV)
+PRE = int(os.environ.get("PROBE_PRE_FORWARDS", "0"))             # forward launches in front of the backward inside the graph
+
+
 def body():
+    for _ in range(PRE):
+        ops.mlp_forward(d, s, a, out2, None, None)
+    if PRE:
+        ops.mlp_forward(d, s, a, out, x0, h1)
     ops.mlp_backward(d, s, a, x0, h1, None, dh, dx0, None, gradmax=gm, td=td)
 
 
@@ -62,6 +70,15 @@ for r in range(6):
     diff = torch.nonzero(flat != eager).view(-1)
     print("replay %d: gradient %s the eager launch's%s" % (r, "==" if same else "!=", "" if same else
           " at %d positions, e.g. %s" % (diff.numel(), [(int(i), float(flat[i]), float(eager[i])) for i in diff[:4]])), flush=True)
+PAD = int(os.environ.get("DBG_SPLITK_PAD", "0"))                 # (a library built with -DRPO_SPLITK_PAD=<this>: floats per slice no kernel writes)
+if PAD:
+    lo = min(t.grad.data_ptr() for t in d.tensors.values() if t is not None)
+    hi = max(t.grad.data_ptr() + 4 * t.numel() for t in d.tensors.values() if t is not None)
+    span = (hi - lo) // 4
+    stride = (span + 3) // 4 * 4 + PAD
+    tail = d.splitk[:Z * stride].view(Z, stride)[:, stride - PAD:].contiguous().view(torch.int32)
+    print("the %d floats behind each slice that no kernel writes, distinct 16-byte groups (int32): %s" % (
+        PAD, torch.unique(tail.view(-1, 4), dim=0)[:6].tolist()))
 ints = d.splitk.view(torch.int32)
 small = (ints != 0) & (ints.abs() < 4096)
 print("scratch words that look like small integers: %d; distinct 16-byte groups among them: %s" % (

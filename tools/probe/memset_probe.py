@@ -23,6 +23,8 @@ x = torch.zeros(1, device="cuda")                               # torch owns the
 lib = ctypes.CDLL(so)
 rc = lib.memset_probe_main()
 print("rc", rc)
+lib.memset_probe_layouts.argtypes = [ctypes.c_void_p, ctypes.c_int]
+print("rc", lib.memset_probe_layouts(None, 6))
 
 # ---- the same launches captured by torch.cuda.graph (torch's capture stream, private memory pool, instantiation and launch)
 lib.memset_probe_body.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,
