@@ -1,9 +1,17 @@
 #!/usr/bin/env python
 """DESIGN.md 4.5 at unit level: ONE rpo_mlp_backward call of the large-batch critic (TD prologue -> [zero the split-K scratch] ->
 rows kernel -> weights kernel -> ordered reduce) captured by torch.cuda.graph and replayed, against the same call launched
-eagerly.  With the shipped library (scratch zeroed by a kernel) the results are equal bit for bit; with the old form
-(bash tools/probe/build_flag_variant.sh memset -DRPO_SPLITK_ZERO=0; RPO_HIP_LIBRARY=.../librpo_hip_memset.so) this shows whether the
-memset NODE alone, next to the library's kernels, is enough for the stale fill pattern."""
+eagerly.  With the shipped library (scratch zeroed by a kernel) everything is clean.  With the old form and slices that carry
+floats no kernel writes,
+
+    git apply tools/probe/splitk_pad.patch
+    bash tools/probe/build_flag_variant.sh memsetpad -DRPO_SPLITK_ZERO=0 -DRPO_SPLITK_PAD=64 ; git checkout rpo_amd/csrc/mlp_bwd.h
+    DBG_SPLITK_PAD=64 RPO_HIP_LIBRARY=$PWD/rpo_amd/csrc/librpo_hip_memsetpad.so python tools/probe/memset_backward_probe.py
+
+the replayed memset NODE leaves the 16-byte group {34572, 0, <low word>, <high word of a device pointer>} in every unwritten
+position: `stride` and `gradmax`, bytes 32..47 of the arguments of the reduce launch three nodes behind it (the gradient still
+equals the eager one here because this network's span has no padding inside it; in the trainer the critic's has three floats).
+PROBE_PRE_FORWARDS=k puts k forward launches in front of the backward inside the graph (same result)."""
 import os
 import sys
 
